@@ -1,0 +1,128 @@
+/* libomlm_hip.so -- C ABI of the MI355X (gfx950) kernels behind the open-musiclm
+ * TokenConditionedTransformer hot path.
+ *
+ * The reference (zhvng/open-musiclm) is pure Python/PyTorch and has NO FFI / plugin / custom-op
+ * interface for this path; its only fused-operator seam is the optional
+ * xformers.ops.memory_efficient_attention call at open_musiclm/transformer.py:298.  Each entry point
+ * below therefore names the reference *Python* code whose arithmetic it replaces.  INTEGRATION.md shows
+ * the ctypes binding a maintainer of the reference would add at each of those sites.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error (omlm_last_error() gives the thread-local message);
+ *   - all pointers are DEVICE pointers unless stated otherwise; the caller owns every buffer, including
+ *     workspaces; the library never allocates device memory, never synchronises, never changes the device;
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it and the call returns at once;
+ *   - dtype codes: 0 = fp32, 1 = bf16.  For GEMM / attention OPERANDS, fp32 selects the "bf16x3" split
+ *     (hi*hi + hi*lo + lo*hi on the bf16 matrix cores, fp32 accumulation), bf16 the single-pass mode;
+ *   - row-major everywhere; "ld" = row pitch in elements.
+ */
+#ifndef OMLM_H
+#define OMLM_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int         omlm_version(void);
+const char* omlm_last_error(void);
+void        omlm_set_error(const char* msg);
+
+/* C[m,n] = alpha * sum_k A(m,k) B(n,k) (+ Cin[m,n]).  Replaces every nn.Linear / einsum contraction on the path:
+ * to_q / to_kv / to_out (transformer.py:203-212,254,333), ConvFeedForward Linear layers (:144,:149), the
+ * per-quantizer logit heads einsum 'q c d, b n q d -> b n q c' (open_musiclm.py:173,180), RelativePositionBias
+ * Linear layers (transformer.py:48-53) and the autograd backward of each.
+ * a_kmajor/b_kmajor: operand stored [K, M] / [K, N] instead of [M, K] / [N, K].
+ * a_map / b_map / c_map (optional, int32): physical row of each logical row (k row for k-major operands);
+ * c_map < 0 skips the row.  a_rows / b_rows: physical row counts (bounds for out-of-range zero fill). */
+int omlm_gemm(const void* A, const void* B, void* C, const float* Cin,
+              const int* a_map, const int* b_map, const int* c_map, long long a_rows, long long b_rows,
+              int M, int N, int K, int lda, int ldb, int ldc, int ldcin,
+              int a_kmajor, int b_kmajor, int in_dtype, int out_dtype, float alpha, void* stream);
+
+/* LayerNorm (transformer.py:24-31: F.layer_norm, learnable gamma, beta == 0, eps 1e-5).
+ * fwd: y = LN(x)*gamma in out_dtype (pitch ldy); xcast (optional) = cast(x) for the K/V projection, which the
+ *      reference feeds with the UN-normalised input (kv_input bound at :228 before the pre-norm at :250).
+ * bwd: dx = dx_scale * (dres + LN^T(dy)); dxcast (optional) = cast(dx); dgamma += sum_rows dy * xhat. */
+int omlm_layernorm_fwd(const float* x, const float* gamma, void* y, void* xcast, float* mean, float* rstd,
+                       int M, int D, int ldy, float eps, int out_dtype, void* stream);
+int omlm_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                       const float* dres, float* dx, void* dxcast, float* dgamma, int M, int D,
+                       float dx_scale, int cast_dtype, void* stream);
+
+/* q/k l2-normalise * learned per-dim scale, v pass-through (transformer.py:265-271; utils.py:68-69), dim_head 64. */
+int omlm_qk_norm_fwd(const float* q_raw, const float* kv_raw, const float* q_scale, const float* k_scale,
+                     void* q, void* k, void* v, int M, int H, int out_dtype, void* stream);
+int omlm_qk_norm_bwd(const float* dq, const float* dk, const float* dv, const float* q_raw, const float* kv_raw,
+                     const float* q_scale, const float* k_scale, void* dq_raw, void* dkv_raw,
+                     float* dq_scale, float* dk_scale, int M, int H, int out_dtype, void* stream);
+
+/* Causal multi-query attention with rel-pos bias table and key mask (transformer.py:303-331; the same logical
+ * inputs as the xformers seam at :275-301, without materialising attn_bias).  bias: [N, bias_ld] fp32, row = i-j,
+ * column = head (the un-gathered MLP output of RelativePositionBias, :60-64).  keymask: [B, N] uint8, 1 = attend.
+ * lse: [B, H, N] (log2 domain).  bwd: dq [B*N, H*64], dk, dv [B*N, 64] fp32 overwritten; dbias += ; delta scratch [B,H,N]. */
+int omlm_mqa_attn_fwd(const void* q, const void* k, const void* v, const float* bias, const unsigned char* keymask,
+                      void* out, float* lse, int B, int N, int H, float scale, int bias_ld, int dtype, void* stream);
+int omlm_mqa_attn_bwd(const void* q, const void* k, const void* v, const float* bias, const unsigned char* keymask,
+                      const void* out, const void* dout, const float* lse, float* delta,
+                      float* dq, float* dk, float* dv, float* dbias,
+                      int B, int N, int H, float scale, int bias_ld, int dtype, void* stream);
+
+/* Middle of ConvFeedForward: CausalDSConv -> GEGLU -> LayerNorm(F) -> Dropout (transformer.py:122-148).
+ * h1: [M, 2*Fp] (value half cols [0,F), gate half cols [Fp, Fp+F)); h2: [M, Fp]; convw: [2F, 3] (reference
+ * ds_conv.weight [2F,1,3]); rows are b*nseq + t.  Dropout mask = Philox(seed, element index), regenerated in bwd. */
+int omlm_ffmid_fwd(const void* h1, const float* convw, const float* gamma, void* h2, float* mean, float* rstd,
+                   int M, int nseq, int F, int Fp, float eps, float p, unsigned long long seed, int dtype, void* stream);
+long long omlm_ffmid_bwd_workspace_bytes(int F, int Fp);
+int omlm_ffmid_bwd(const void* dh2, const void* h1, const float* convw, const float* gamma, const float* mean,
+                   const float* rstd, void* du_tmp, void* dh1, float* dgamma, float* dconv, float* workspace,
+                   int M, int nseq, int F, int Fp, float p, unsigned long long seed, int dtype, void* stream);
+int omlm_colsum_accumulate(const float* part, float* out, int P, int C, int ldp, void* stream);
+
+/* Embedding gather + start-token interleave + concat (open_musiclm.py:123-145; utils.get_embeds :126-143) and its
+ * transpose with the grad_shrink factor (utils.py:60-61).  tables/starts/pos: HOST arrays of device pointers. */
+int omlm_embed_gather_fwd(const int* ids, const int* seg, const int* posidx,
+                          const float* const* tables, const float* const* starts, const float* const* pos,
+                          int nseq, float* out, int B, int N, int D, void* stream);
+int omlm_embed_gather_bwd(const int* ids, const int* seg, const int* posidx,
+                          float* const* dtables, float* const* dstarts, float* const* dpos,
+                          int nseq, const float* dx, int B, int N, int D, float alpha, void* stream);
+
+/* F.cross_entropy(logits, labels) pieces (open_musiclm.py:401-405): per-row lse + NLL sum; (softmax-onehot)*coef*g. */
+int omlm_cross_entropy_fwd(const float* logits, const int* labels, float* row_lse, float* nll_sum,
+                           int R, int V, int ld, void* stream);
+int omlm_cross_entropy_bwd(const float* logits, const int* labels, const float* row_lse, const float* gscale,
+                           float coef, void* dlogits, int R, int V, int ld, int ldd, int out_dtype, void* stream);
+
+/* clip_grad_norm_ + Adam/AdamW on flat buffers (optimizer.py:10-34; trainer.py:444-447). */
+int omlm_sumsq_accumulate(const float* g, long long n, float* out, void* stream);
+int omlm_adamw_clip_step(float* p, float* g, float* m, float* v, void* p16, long long n,
+                         float lr, float beta1, float beta2, float eps, float wd, int step,
+                         float gscale, const float* gnorm_sq, float max_norm, int decoupled, int zero_grad, void* stream);
+
+/* operand casts / weight repack */
+int omlm_cast_pad(const float* src, void* dst, long long R, int C, int ld_src, int ld_dst, int out_dtype, void* stream);
+
+/* RelativePositionBias MLP helpers (transformer.py:55-64): SiLU layers around omlm_gemm. */
+int omlm_relpos_first_fwd(const float* w0, const float* b0, float* pre, float* z, int n, int Hd, void* stream);
+int omlm_relpos_first_bwd(const float* ds, float* dw0, int n, int Hd, void* stream);
+int omlm_bias_silu_fwd(const float* a, const float* b, float* pre, float* z, long long R, int C, void* stream);
+int omlm_silu_bwd(const float* dz, const float* pre, float* ds, long long total, void* stream);
+int omlm_bias_add(const float* a, const float* b, float* out, int R, int C, int ld, void* stream);
+
+/* Nearest-codeword kernels: ClapQuantized.quantize -> ResidualVQ eval path (clap_quantized.py:75-87) and
+ * HfHubertWithKmeans assign (hf_hubert_kmeans.py:87).  codebooks_T: [nstage][D][C] (transposed); indices int32 [n, nstage]. */
+int omlm_rvq_encode(const float* x, const float* codebooks_T, int* indices, float* residual_out,
+                    int n, int D, int C, int nstage, void* stream);
+int omlm_nearest_centroid(const float* x, const float* centroids_T, int* indices, int n, int D, int C, void* stream);
+
+/* AR sampler: eos suppression + top_k(thres) + gumbel_sample (open_musiclm.py:309-316; utils.py:65-84). */
+int omlm_sample_topk_gumbel(const float* logits, const float* uniform, long long* out, int B, int V, int ld,
+                            int k, float temperature, int forbid_last, void* stream);
+
+/* hardware probe (tests only): raw ds_read_b64_tr_b16 result for a linear LDS image, 64 lanes x 4 int16 */
+int omlm_probe_tr16(short* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,527 @@
+// Causal multi-query attention of the reference trunk (transformer.py:254-331, non-xformers branch),
+// flash-style: the [B, H, N, N] score / bias / mask tensors of the reference are never materialised.
+//
+//   sim[b,h,i,j] = 8 * <q[b,i,h,:], k[b,j,:]> + bias[h, i-j]        (one shared K/V head: MQA, :203-204)
+//   masked (key mask, j > i)  -> excluded (reference fills -finfo.max; with >= 1 live key per row, which
+//                                the wrapper guarantees since position 0 is never masked, that is identical)
+//   out[b,i,h,:] = softmax_j(sim) @ v[b,j,:]
+//
+// MI355X mapping
+//   * everything is computed transposed -- S^T = K Q^T, O^T = V^T P^T -- so that after the MFMA a lane
+//     owns ONE query (column = lane & 31) and 16 keys: running max / sum / rescale are lane-local, and the
+//     fp32 S^T accumulator registers are, after exp2 and bf16 packing, directly the B operand of the
+//     second MFMA (no cross-lane shuffle, no LDS round trip for P).
+//   * K/V tiles (64 keys x 64 dims) are staged once per workgroup in LDS and shared by the workgroup's
+//     4 waves = 4 heads (the MQA reuse); V^T and K^T operands come from the same row-major tiles through
+//     the hardware transpose read ds_read_b64_tr_b16.
+//   * rel-pos bias is a 1-D table [H, N] (i - j >= 0) staged in LDS (pre-multiplied by log2 e), instead of
+//     the reference's [H, N, N] gather; its gradient is reduced in LDS and flushed with one atomic per bin.
+//   * T = float inputs select the bf16x3 split (hi*hi + hi*lo + lo*hi) for the forward; the backward
+//     kernels always run single-pass bf16 MFMA with fp32 accumulation.
+#include "common.h"
+
+#define AT_THREADS 256
+#define TQ 32
+#define TKV 64
+#define NEG_BIG (-1.0e30f)
+#define LOG2E 1.4426950408889634f
+
+// [rows][64 dims] bf16 tile, 128 B per row; 16-B chunk index XOR ((row >> 1) & 7)
+__device__ __forceinline__ int tile_off(int row, int colbyte) {
+    return row * 128 + ((((colbyte >> 4) ^ ((row >> 1) & 7)) << 4) | (colbyte & 15));
+}
+
+// key row held in accumulator register r of a 32x32 MFMA result for half-wave hi
+__device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// ---- global -> register fragment: 8 consecutive elements of one row as bf16 (hi, optional lo) -------------
+template <typename T, bool PRECISE>
+__device__ __forceinline__ void load_row8(const T* p, bool ok, bf16x8& hi, bf16x8& lo);
+
+template <>
+__device__ __forceinline__ void load_row8<bf16_t, false>(const bf16_t* p, bool ok, bf16x8& hi, bf16x8& lo) {
+    u32x4 z = {0u, 0u, 0u, 0u};
+    u32x4 v = ok ? *(const u32x4*)p : z;
+    hi = __builtin_bit_cast(bf16x8, v);
+}
+template <>
+__device__ __forceinline__ void load_row8<float, false>(const float* p, bool ok, bf16x8& hi, bf16x8& lo) {
+    float4 a = make_float4(0, 0, 0, 0), b = a;
+    if (ok) { a = ((const float4*)p)[0]; b = ((const float4*)p)[1]; }
+    u32x4 v;
+    v[0] = pack_bf16_rne(a.x, a.y); v[1] = pack_bf16_rne(a.z, a.w);
+    v[2] = pack_bf16_rne(b.x, b.y); v[3] = pack_bf16_rne(b.z, b.w);
+    hi = __builtin_bit_cast(bf16x8, v);
+}
+template <>
+__device__ __forceinline__ void load_row8<float, true>(const float* p, bool ok, bf16x8& hi, bf16x8& lo) {
+    float4 a = make_float4(0, 0, 0, 0), b = a;
+    if (ok) { a = ((const float4*)p)[0]; b = ((const float4*)p)[1]; }
+    u32x4 h, l;
+    unsigned h0, l0;
+    split_pair(a.x, a.y, h0, l0); h[0] = h0; l[0] = l0;
+    split_pair(a.z, a.w, h0, l0); h[1] = h0; l[1] = l0;
+    split_pair(b.x, b.y, h0, l0); h[2] = h0; l[2] = l0;
+    split_pair(b.z, b.w, h0, l0); h[3] = h0; l[3] = l0;
+    hi = __builtin_bit_cast(bf16x8, h);
+    lo = __builtin_bit_cast(bf16x8, l);
+}
+
+// stage a [TKV keys][64] tile of k or v (rows j0.., zero beyond N) into LDS (hi and, if PRECISE, lo plane)
+template <typename T, bool PRECISE>
+__device__ __forceinline__ void stage_kv(const T* base /* row 0 of this sample, ld 64 */, int j0, int N, char* lds_hi, char* lds_lo) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = threadIdx.x + AT_THREADS * i;       // 512 chunks of 8 dims
+        const int row = c >> 3, ch = c & 7;
+        bf16x8 hi, lo;
+        load_row8<T, PRECISE>(base + (size_t)(j0 + row) * 64 + ch * 8, (j0 + row) < N, hi, lo);
+        *(bf16x8*)(lds_hi + tile_off(row, ch * 16)) = hi;
+        if (PRECISE) *(bf16x8*)(lds_lo + tile_off(row, ch * 16)) = lo;
+    }
+}
+
+// normal operand fragment: row = row0 + (lane & 31), dims 16 s + 8 (lane >> 5) .. +7
+__device__ __forceinline__ bf16x8 frag_rows(const char* lds, int row0, int s, int lane) {
+    return *(const bf16x8*)(lds + tile_off(row0 + (lane & 31), (2 * s + (lane >> 5)) * 16));
+}
+// transposed operand fragment from a [rows][64] tile: lane gets column (col0 + (lane & 31)) and the 8 tile rows
+// that MFMA k-index 8*(lane>>5)+e maps to under the accumulator row order:  row0 + 16 s + 8 (e>>2) + 4 (lane>>5) + (e&3)
+__device__ __forceinline__ bf16x8 frag_cols_tr(const char* lds, int row0, int s, int col0, int lane) {
+    const int hi = lane >> 5, g = (lane >> 4) & 1, i = lane & 15;
+    const int r1 = row0 + 16 * s + 4 * hi + (i >> 2);
+    const int colbyte = (col0 + 16 * g + 4 * (i & 3)) * 2;
+    s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, lds + tile_off(r1, colbyte)));
+    s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, lds + tile_off(r1 + 8, colbyte)));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+// pack accumulator registers 8s..8s+7 into a bf16 B-operand (RNE), optional residual (lo) operand
+template <bool PRECISE>
+__device__ __forceinline__ void pack_acc(const f32x16& p, int s, bf16x8& hi, bf16x8& lo) {
+    u32x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float a = p[8 * s + 2 * e], b = p[8 * s + 2 * e + 1];
+        if (PRECISE) { unsigned hh, ll; split_pair(a, b, hh, ll); h[e] = hh; l[e] = ll; }
+        else h[e] = pack_bf16_rne(a, b);
+    }
+    hi = __builtin_bit_cast(bf16x8, h);
+    if (PRECISE) lo = __builtin_bit_cast(bf16x8, l);
+}
+
+// =============================================================================================================
+// forward
+// =============================================================================================================
+template <typename T>
+__global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                              const T* __restrict__ v, const float* __restrict__ bias,
+                                                              const unsigned char* __restrict__ keymask, T* __restrict__ out,
+                                                              float* __restrict__ lse, int B, int N, int H, float scale, int bias_ld) {
+    constexpr bool PRECISE = elt_traits<T>::precise;
+    constexpr int PLANE = TKV * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Kh = smem;
+    char* Vh = smem + PLANE;
+    char* Kl = smem + 2 * PLANE;
+    char* Vl = smem + 3 * PLANE;
+    float* bias_l = (float*)(smem + (PRECISE ? 4 : 2) * PLANE);   // [4 waves][nb]
+
+    const int nqt = (N + TQ - 1) / TQ;
+    const int qt = nqt - 1 - (int)blockIdx.x;          // heavy (late) query tiles first
+    const int b = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
+    const int h = blockIdx.y * 4 + wave;
+    const bool active = h < H;
+    const int i0 = qt * TQ;
+    const int qi = i0 + (lane & 31);
+    const int nb = i0 + TQ;                             // bias bins needed: rel in [0, i0 + 31]
+    const size_t rowbase = (size_t)b * N;
+
+    if (active) {
+        float* bl = bias_l + (size_t)wave * nb;
+        for (int r = lane; r < nb; r += 64) bl[r] = bias ? bias[(size_t)min(r, N - 1) * bias_ld + h] * LOG2E : 0.f;
+    }
+    bf16x8 qh[4], ql[4];
+    if (active) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            load_row8<T, PRECISE>(q + (rowbase + min(qi, N - 1)) * (size_t)(H * 64) + h * 64 + 16 * s + 8 * hi, qi < N, qh[s], ql[s]);
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
+    float m = NEG_BIG, lsum = 0.f;
+    const float c = scale * LOG2E;
+    const float* bl = bias_l + (size_t)wave * nb;
+
+    const int nkt = (i0 + TQ + TKV - 1) / TKV;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int j0 = kt * TKV;
+        __syncthreads();
+        stage_kv<T, PRECISE>(k + rowbase * 64, j0, N, Kh, Kl);
+        stage_kv<T, PRECISE>(v + rowbase * 64, j0, N, Vh, Vl);
+        const int jk = j0 + lane;
+        const bool live = jk < N && (keymask ? keymask[rowbase + jk] != 0 : true);
+        const unsigned long long bits = __ballot(live);
+        __syncthreads();
+        if (!active) continue;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int jb = j0 + 32 * sub;
+            if (jb > i0 + TQ - 1) break;
+            f32x16 st;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) st[e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 ka = frag_rows(Kh, 32 * sub, s, lane);
+                if (PRECISE) {
+                    const bf16x8 kla = frag_rows(Kl, 32 * sub, s, lane);
+                    st = MFMA(kla, qh[s], st);
+                    st = MFMA(ka, ql[s], st);
+                }
+                st = MFMA(ka, qh[s], st);
+            }
+            float mloc = NEG_BIG;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kr = 32 * sub + crow(r, hi);
+                const int key = j0 + kr;
+                const int rel = qi - key;
+                const bool ok = (rel >= 0) && ((bits >> kr) & 1ull);
+                const float val = st[r] * c + bl[max(min(rel, nb - 1), 0)];
+                st[r] = ok ? val : NEG_BIG;
+                mloc = fmaxf(mloc, st[r]);
+            }
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            const float mnew = fmaxf(m, mloc);
+            const float alpha = exp2f(m - mnew);
+            m = mnew;
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st[r] = exp2f(st[r] - mnew); psum += st[r]; }
+            lsum = lsum * alpha + psum;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc[0][e] *= alpha; acc[1][e] *= alpha; }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 ph, pl;
+                pack_acc<PRECISE>(st, s, ph, pl);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const bf16x8 va = frag_cols_tr(Vh, 32 * sub, s, 32 * dt, lane);
+                    if (PRECISE) {
+                        const bf16x8 vla = frag_cols_tr(Vl, 32 * sub, s, 32 * dt, lane);
+                        acc[dt] = MFMA(vla, ph, acc[dt]);
+                        acc[dt] = MFMA(va, pl, acc[dt]);
+                    }
+                    acc[dt] = MFMA(va, ph, acc[dt]);
+                }
+            }
+        }
+    }
+    if (!active || qi >= N) return;
+    lsum += __shfl_xor(lsum, 32, 64);
+    const float inv = 1.0f / lsum;
+    T* orow = out + (rowbase + qi) * (size_t)(H * 64) + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int d = 32 * dt + 8 * g4 + 4 * hi;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) store_from_float(orow + d + e, acc[dt][4 * g4 + e] * inv);
+        }
+    if (hi == 0 && lse) lse[((size_t)b * H + h) * N + qi] = m + log2f(lsum);   // log2 domain
+}
+
+// =============================================================================================================
+// backward, kernel B: dQ, d(bias table), delta_i = sum_d dO[i,d] O[i,d]     (same geometry as the forward)
+// =============================================================================================================
+template <typename T>
+__global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                                 const T* __restrict__ v, const float* __restrict__ bias,
+                                                                 const unsigned char* __restrict__ keymask,
+                                                                 const T* __restrict__ out, const T* __restrict__ dout,
+                                                                 const float* __restrict__ lse, float* __restrict__ delta,
+                                                                 float* __restrict__ dq, float* __restrict__ dbias,
+                                                                 int B, int N, int H, float scale, int bias_ld) {
+    constexpr int PLANE = TKV * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vs = smem + PLANE;
+    const int nqt = (N + TQ - 1) / TQ;
+    const int qt = nqt - 1 - (int)blockIdx.x;
+    const int b = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
+    const int h = blockIdx.y * 4 + wave;
+    const bool active = h < H;
+    const int i0 = qt * TQ;
+    const int qi = i0 + (lane & 31);
+    const int nb = i0 + TQ;
+    float* bias_l = (float*)(smem + 2 * PLANE) + (size_t)wave * nb;              // [4][nb]
+    float* dbias_l = (float*)(smem + 2 * PLANE) + (size_t)(4 + wave) * nb;       // [4][nb]
+    const size_t rowbase = (size_t)b * N;
+    const size_t qrow = (rowbase + min(qi, N - 1)) * (size_t)(H * 64) + (active ? h : 0) * 64;
+
+    bf16x8 qf[4], dof[4], dummy;
+    float dl = 0.f, L = 0.f;
+    if (active) {
+        for (int r = lane; r < nb; r += 64) {
+            bias_l[r] = bias ? bias[(size_t)min(r, N - 1) * bias_ld + h] * LOG2E : 0.f;
+            dbias_l[r] = 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 of;
+            load_row8<T, false>(q + qrow + 16 * s + 8 * hi, qi < N, qf[s], dummy);
+            load_row8<T, false>(dout + qrow + 16 * s + 8 * hi, qi < N, dof[s], dummy);
+            // delta uses the unrounded tensors
+            if (qi < N) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    dl += load_as_float(dout + qrow + 16 * s + 8 * hi + e) * load_as_float(out + qrow + 16 * s + 8 * hi + e);
+            }
+        }
+        dl += __shfl_xor(dl, 32, 64);
+        L = lse[((size_t)b * H + h) * N + min(qi, N - 1)];
+        if (hi == 0 && qi < N) delta[((size_t)b * H + h) * N + qi] = dl;
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
+    const float c = scale * LOG2E;
+
+    const int nkt = (i0 + TQ + TKV - 1) / TKV;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int j0 = kt * TKV;
+        __syncthreads();
+        stage_kv<T, false>(k + rowbase * 64, j0, N, Ks, Ks);
+        stage_kv<T, false>(v + rowbase * 64, j0, N, Vs, Vs);
+        const int jk = j0 + lane;
+        const bool live = jk < N && (keymask ? keymask[rowbase + jk] != 0 : true);
+        const unsigned long long bits = __ballot(live);
+        __syncthreads();
+        if (!active) continue;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int jb = j0 + 32 * sub;
+            if (jb > i0 + TQ - 1) break;
+            f32x16 st, dp;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { st[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                st = MFMA(frag_rows(Ks, 32 * sub, s, lane), qf[s], st);      // S^T  = K Q^T
+                dp = MFMA(frag_rows(Vs, 32 * sub, s, lane), dof[s], dp);     // dP^T = V dO^T
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kr = 32 * sub + crow(r, hi);
+                const int rel = qi - (j0 + kr);
+                const bool ok = (rel >= 0) && ((bits >> kr) & 1ull) && (qi < N);
+                const int bin = max(min(rel, nb - 1), 0);
+                const float p = ok ? exp2f(st[r] * c + bias_l[bin] - L) : 0.f;
+                const float ds = p * (dp[r] - dl);
+                if (ok) atomicAdd(dbias_l + bin, ds);
+                st[r] = ds * scale;
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 dsb;
+                pack_acc<false>(st, s, dsb, dummy);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    acc[dt] = MFMA(frag_cols_tr(Ks, 32 * sub, s, 32 * dt, lane), dsb, acc[dt]);   // dQ^T += K^T dS^T
+            }
+        }
+    }
+    if (!active) return;
+    if (qi < N) {
+        float* drow = dq + (rowbase + qi) * (size_t)(H * 64) + h * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d = 32 * dt + 8 * g4 + 4 * hi;
+                *(float4*)(drow + d) = make_float4(acc[dt][4 * g4], acc[dt][4 * g4 + 1], acc[dt][4 * g4 + 2], acc[dt][4 * g4 + 3]);
+            }
+    }
+    if (dbias) {
+        // LDS atomics of this wave are complete in program order for this wave's own later reads
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        for (int r = lane; r < min(nb, N); r += 64) {
+            const float vv = dbias_l[r];
+            if (vv != 0.f) unsafeAtomicAdd(dbias + (size_t)r * bias_ld + h, vv);
+        }
+    }
+}
+
+// =============================================================================================================
+// backward, kernel A: dK, dV.  One workgroup per (sample, 32-key tile); its 4 waves split the (query tile, head)
+// work items and reduce their partial dK^T / dV^T through LDS at the end -- no atomics on dK / dV.
+// =============================================================================================================
+template <typename T>
+__global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                                  const T* __restrict__ v, const float* __restrict__ bias,
+                                                                  const unsigned char* __restrict__ keymask,
+                                                                  const T* __restrict__ dout, const float* __restrict__ lse,
+                                                                  const float* __restrict__ delta, float* __restrict__ dk,
+                                                                  float* __restrict__ dv, int B, int N, int H, float scale, int bias_ld) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
+    char* Qs = smem + wave * 8192;            // per-wave private [32][64] bf16 tiles (Q, dO) for the transpose reads
+    char* dOs = Qs + 4096;
+    float* red = (float*)(smem);              // reused at the end: [4 waves][64 d][32 j] fp32 = 32 KiB
+
+    const int nqt = (N + TQ - 1) / TQ;
+    const int jt = blockIdx.x;                // 32-key tile; low tiles carry the most (causal) work and launch first
+    const int b = blockIdx.z;
+    const int j0 = jt * 32;
+    const int kj = j0 + (lane & 31);          // this lane's key (column of S)
+    const size_t rowbase = (size_t)b * N;
+    const float c = scale * LOG2E;
+    bf16x8 dummy;
+
+    // K^T, V^T B-operands: lane n = key kj, dims 16 s + 8 hi .. +7 -- resident for the whole kernel
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        load_row8<T, false>(k + (rowbase + min(kj, N - 1)) * 64 + 16 * s + 8 * hi, kj < N, kf[s], dummy);
+        load_row8<T, false>(v + (rowbase + min(kj, N - 1)) * 64 + 16 * s + 8 * hi, kj < N, vf[s], dummy);
+    }
+    const bool keylive = kj < N && (keymask ? keymask[rowbase + kj] != 0 : true);
+
+    f32x16 dkacc[2], dvacc[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { dkacc[0][e] = 0.f; dkacc[1][e] = 0.f; dvacc[0][e] = 0.f; dvacc[1][e] = 0.f; }
+
+    const int nitems = (nqt - jt) * H;        // (query tile it >= jt) x head
+    for (int item = wave; item < nitems; item += 4) {
+        const int it = jt + item / H, h = item % H;
+        const int i0 = it * TQ;
+        // A-operand fragments (rows = queries i0 + (lane&31), dims 16 s + 8 hi): Q and dO, also parked in LDS
+        const int qi = i0 + (lane & 31);
+        const size_t qrow = (rowbase + min(qi, N - 1)) * (size_t)(H * 64) + h * 64;
+        bf16x8 qa[4], doa[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            load_row8<T, false>(q + qrow + 16 * s + 8 * hi, qi < N, qa[s], dummy);
+            load_row8<T, false>(dout + qrow + 16 * s + 8 * hi, qi < N, doa[s], dummy);
+            *(bf16x8*)(Qs + tile_off(lane & 31, (2 * s + hi) * 16)) = qa[s];
+            *(bf16x8*)(dOs + tile_off(lane & 31, (2 * s + hi) * 16)) = doa[s];
+        }
+        f32x16 st, dp;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { st[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            st = MFMA(qa[s], kf[s], st);       // S  = Q K^T   (rows i, column = this lane's key)
+            dp = MFMA(doa[s], vf[s], dp);      // dP = dO V^T
+        }
+        const float* Lr = lse + ((size_t)b * H + h) * N;
+        const float* Dr = delta + ((size_t)b * H + h) * N;
+        const float* br = bias ? bias + h : nullptr;
+        f32x16 pp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = i0 + crow(r, hi);
+            const int rel = i - kj;
+            const bool ok = (rel >= 0) && keylive && (i < N);
+            const int ic = min(i, N - 1);
+            const float bv = br ? br[(size_t)max(min(rel, N - 1), 0) * bias_ld] * LOG2E : 0.f;
+            const float p = ok ? exp2f(st[r] * c + bv - Lr[ic]) : 0.f;
+            pp[r] = p;
+            st[r] = p * (dp[r] - Dr[ic]) * scale;     // dS * d(sim)/d(dot)
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 pb, dsb;
+            pack_acc<false>(pp, s, pb, dummy);
+            pack_acc<false>(st, s, dsb, dummy);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                dvacc[dt] = MFMA(frag_cols_tr(dOs, 0, s, 32 * dt, lane), pb, dvacc[dt]);    // dV^T += dO^T P
+                dkacc[dt] = MFMA(frag_cols_tr(Qs, 0, s, 32 * dt, lane), dsb, dkacc[dt]);    // dK^T += Q^T dS
+            }
+        }
+    }
+    // cross-wave reduction through LDS, one accumulator pair at a time
+    for (int which = 0; which < 2; ++which) {
+        __syncthreads();
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = 32 * dt + crow(r, hi);
+                red[((size_t)wave * 64 + d) * 32 + (lane & 31)] = which == 0 ? dkacc[dt][r] : dvacc[dt][r];
+            }
+        __syncthreads();
+        float* dst = which == 0 ? dk : dv;
+        for (int e = threadIdx.x; e < 64 * 32; e += AT_THREADS) {
+            const int j = e >> 6, d = e & 63;          // consecutive threads -> consecutive d (coalesced rows)
+            const float s4 = red[(0 * 64 + d) * 32 + j] + red[(1 * 64 + d) * 32 + j] + red[(2 * 64 + d) * 32 + j] + red[(3 * 64 + d) * 32 + j];
+            if (j0 + j < N) dst[(rowbase + j0 + j) * 64 + d] = s4;
+        }
+    }
+}
+
+// =============================================================================================================
+static size_t fwd_lds(int N, bool precise) { return (size_t)(precise ? 4 : 2) * TKV * 128 + (size_t)4 * ((N + TQ - 1) / TQ * TQ) * sizeof(float); }
+static size_t dq_lds(int N) { return (size_t)2 * TKV * 128 + (size_t)8 * ((N + TQ - 1) / TQ * TQ) * sizeof(float); }
+
+template <typename K>
+static int set_lds(K kernel, size_t bytes) {
+    if (bytes > 160 * 1024) { omlm_set_error("attention: sequence too long for the LDS-resident bias table"); return OMLM_ERR_UNSUPPORTED; }
+    if (bytes > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return OMLM_OK;
+}
+
+// q [B*N, H*64], k, v [B*N, 64] (dtype), bias [N, bias_ld] fp32 (row = i - j, column = head) or null, keymask [B, N] uint8 or null (1 = attend)
+// out [B*N, H*64] (dtype), lse [B, H, N] fp32 (log2 domain)
+extern "C" int omlm_mqa_attn_fwd(const void* q, const void* k, const void* v, const float* bias, const unsigned char* keymask,
+                                 void* out, float* lse, int B, int N, int H, float scale, int bias_ld, int dtype, void* stream) {
+    if (B <= 0 || N <= 0) return OMLM_OK;
+    OMLM_CHECK_ARG(q && k && v && out && lse, "null pointer");
+    OMLM_CHECK_ARG(H >= 1 && (!bias || bias_ld >= H), "heads / bias pitch");
+    dim3 grid((N + TQ - 1) / TQ, (H + 3) / 4, B), block(AT_THREADS);
+    int rc;
+    if (dtype == 0) {
+        const size_t lds = fwd_lds(N, true);
+        if ((rc = set_lds(attn_fwd_kernel<float>, lds))) return rc;
+        hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, block, lds, as_stream(stream), (const float*)q, (const float*)k, (const float*)v, bias, keymask, (float*)out, lse, B, N, H, scale, bias_ld);
+    } else {
+        const size_t lds = fwd_lds(N, false);
+        if ((rc = set_lds(attn_fwd_kernel<bf16_t>, lds))) return rc;
+        hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, grid, block, lds, as_stream(stream), (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, bias, keymask, (bf16_t*)out, lse, B, N, H, scale, bias_ld);
+    }
+    return omlm_post_launch("omlm_mqa_attn_fwd");
+}
+
+// dq [B*N, H*64] fp32, dk, dv [B*N, 64] fp32 (overwritten), dbias [N, bias_ld] fp32 (accumulated, +=), delta [B, H, N] scratch
+extern "C" int omlm_mqa_attn_bwd(const void* q, const void* k, const void* v, const float* bias, const unsigned char* keymask,
+                                 const void* out, const void* dout, const float* lse, float* delta,
+                                 float* dq, float* dk, float* dv, float* dbias,
+                                 int B, int N, int H, float scale, int bias_ld, int dtype, void* stream) {
+    if (B <= 0 || N <= 0) return OMLM_OK;
+    OMLM_CHECK_ARG(q && k && v && out && dout && lse && delta && dq && dk && dv, "null pointer");
+    dim3 gridq((N + TQ - 1) / TQ, (H + 3) / 4, B), gridk((N + 31) / 32, 1, B), block(AT_THREADS);
+    const size_t ldsq = dq_lds(N), ldsk = 32 * 1024;
+    int rc;
+    hipStream_t st = as_stream(stream);
+    if (dtype == 0) {
+        if ((rc = set_lds(attn_bwd_dq_kernel<float>, ldsq))) return rc;
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<float>, gridq, block, ldsq, st, (const float*)q, (const float*)k, (const float*)v, bias, keymask, (const float*)out, (const float*)dout, lse, delta, dq, dbias, B, N, H, scale, bias_ld);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<float>, gridk, block, ldsk, st, (const float*)q, (const float*)k, (const float*)v, bias, keymask, (const float*)dout, lse, delta, dk, dv, B, N, H, scale, bias_ld);
+    } else {
+        if ((rc = set_lds(attn_bwd_dq_kernel<bf16_t>, ldsq))) return rc;
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<bf16_t>, gridq, block, ldsq, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, bias, keymask, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, dq, dbias, B, N, H, scale, bias_ld);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<bf16_t>, gridk, block, ldsk, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, bias, keymask, (const bf16_t*)dout, lse, delta, dk, dv, B, N, H, scale, bias_ld);
+    }
+    return omlm_post_launch("omlm_mqa_attn_bwd");
+}

@@ -1,0 +1,137 @@
+// Shared device/host helpers for libomlm_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define OMLM_OK 0
+#define OMLM_ERR_ARG (-1)
+#define OMLM_ERR_LAUNCH (-2)
+#define OMLM_ERR_UNSUPPORTED (-3)
+
+extern "C" void omlm_set_error(const char* msg);
+
+#define OMLM_CHECK_ARG(cond, msg)                                                     \
+    do {                                                                              \
+        if (!(cond)) {                                                                \
+            omlm_set_error("bad argument: " msg " [" #cond "]");                      \
+            return OMLM_ERR_ARG;                                                      \
+        }                                                                             \
+    } while (0)
+
+static inline int omlm_post_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        char buf[256];
+        snprintf(buf, sizeof(buf), "%s: launch failed: %s", what, hipGetErrorString(e));
+        omlm_set_error(buf);
+        return OMLM_ERR_LAUNCH;
+    }
+    return OMLM_OK;
+}
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+__device__ __forceinline__ unsigned f2u(float f) { return __float_as_uint(f); }
+__device__ __forceinline__ float u2f(unsigned u) { return __uint_as_float(u); }
+
+// round-to-nearest-even fp32 -> bf16 bits (finite inputs)
+__device__ __forceinline__ unsigned bf16_bits_rne(float f) {
+    unsigned u = f2u(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ unsigned pack_bf16_rne(float lo, float hi) {
+    bf16x2 v;
+    v[0] = (__bf16)lo;
+    v[1] = (__bf16)hi;
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float bf16_lo_to_f(unsigned packed) { return u2f(packed << 16); }
+__device__ __forceinline__ float bf16_hi_to_f(unsigned packed) { return u2f(packed & 0xFFFF0000u); }
+
+// split fp32 pair into packed (truncated) hi bf16 pair and RNE lo bf16 pair: x ~= hi + lo
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
+    unsigned ua = f2u(a) & 0xFFFF0000u, ub = f2u(b) & 0xFFFF0000u;
+    hi = ub | (ua >> 16);
+    lo = pack_bf16_rne(a - u2f(ua), b - u2f(ub));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// block-wide sum for blockDim.x == NT (multiple of 64); `red` is >= NT/64 floats of LDS.
+template <int NT>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) t += red[i];
+    return t;
+}
+
+// Philox-4x32-10 counter RNG: the dropout mask of element e is a pure function of (seed, e),
+// so the backward kernel regenerates it instead of storing it.
+__device__ __forceinline__ void philox4x32(unsigned c0, unsigned c1, unsigned c2, unsigned c3,
+                                           unsigned k0, unsigned k1, unsigned out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+        unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+        unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
+        unsigned n1 = (unsigned)p1;
+        unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+        unsigned n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// uniform in [0,1) for element index e (one Philox call serves 4 consecutive elements)
+__device__ __forceinline__ float dropout_uniform(unsigned long long seed, unsigned long long e) {
+    unsigned o[4];
+    unsigned long long blk = e >> 2;
+    philox4x32((unsigned)blk, (unsigned)(blk >> 32), 0u, 0u, (unsigned)seed, (unsigned)(seed >> 32), o);
+    return (float)(o[e & 3] >> 8) * (1.0f / 16777216.0f);
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned long long bytes) {
+    unsigned n = bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)bytes;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)n, 0x00020000);
+}
+#define OOB_OFF 0xFFFFFFF0u
+
+template <typename T> struct elt_traits;
+template <> struct elt_traits<float> { static constexpr bool precise = true; };
+template <> struct elt_traits<bf16_t> { static constexpr bool precise = false; };
+
+__device__ __forceinline__ float load_as_float(const float* p) { return *p; }
+__device__ __forceinline__ float load_as_float(const bf16_t* p) { return (float)(*p); }
+__device__ __forceinline__ void store_from_float(float* p, float v) { *p = v; }
+__device__ __forceinline__ void store_from_float(bf16_t* p, float v) { *p = (bf16_t)v; }
+
+static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }

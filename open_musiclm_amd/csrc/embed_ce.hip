@@ -1,0 +1,173 @@
+// Token-side kernels of TokenConditionedTransformer (reference open_musiclm.py:116-145, :389-410):
+//   * fused embedding gather: per-quantizer offset ids -> rows of the per-sequence tables, pad -> 0,
+//     learned start tokens interleaved, optional absolute position rows added, written straight into the
+//     concatenated [B, N, D] trunk input (the reference builds 2*n_seq tensors and torch.cat's them).
+//   * its transpose (scatter-add with the grad_shrink factor, utils.py:60-61).
+//   * cross-entropy forward (per-row log-sum-exp + NLL sum) and backward (softmax - onehot) over the padded
+//     logits rows produced by the head GEMMs.
+#include "common.h"
+
+#define MAX_SEQ 4
+struct EmbedTables {
+    const float* table[MAX_SEQ];
+    const float* start[MAX_SEQ];
+    const float* pos[MAX_SEQ];      // absolute position tables or null
+    float* dtable[MAX_SEQ];
+    float* dstart[MAX_SEQ];
+    float* dpos[MAX_SEQ];
+};
+
+// ids [B, N] int32: >= 0 table row (offsets already applied), -1 pad (zero row), -2 start token.
+// seg [N] int32: sequence index of the position; posidx [N]: index inside its sequence (for abs-pos tables).
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int* __restrict__ ids, const int* __restrict__ seg,
+                                                        const int* __restrict__ posidx, EmbedTables t,
+                                                        float* __restrict__ out, int B, int N, int D) {
+    const int nv = D / 4;
+    for (long long row = blockIdx.x; row < (long long)B * N; row += gridDim.x) {
+        const int n = (int)(row % N);
+        const int id = ids[row], s = seg[n];
+        const float4* src = nullptr;
+        if (id >= 0) src = (const float4*)(t.table[s] + (size_t)id * D);
+        else if (id == -2) src = (const float4*)t.start[s];
+        const float4* ps = (id >= 0 || id == -1) && t.pos[s] ? (const float4*)(t.pos[s] + (size_t)posidx[n] * D) : nullptr;
+        float4* dst = (float4*)(out + (size_t)row * D);
+        for (int c = threadIdx.x; c < nv; c += 256) {
+            float4 v = src ? src[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ps) { const float4 p = ps[c]; v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
+            dst[c] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int* __restrict__ ids, const int* __restrict__ seg,
+                                                        const int* __restrict__ posidx, EmbedTables t,
+                                                        const float* __restrict__ dx, int B, int N, int D, float alpha) {
+    for (long long row = blockIdx.x; row < (long long)B * N; row += gridDim.x) {
+        const int n = (int)(row % N);
+        const int id = ids[row], s = seg[n];
+        float* dst = nullptr;
+        if (id >= 0) dst = t.dtable[s] ? t.dtable[s] + (size_t)id * D : nullptr;
+        else if (id == -2) dst = t.dstart[s];
+        float* pd = (id >= 0 || id == -1) && t.dpos[s] ? t.dpos[s] + (size_t)posidx[n] * D : nullptr;
+        const float* src = dx + (size_t)row * D;
+        for (int c = threadIdx.x; c < D; c += 256) {
+            const float g = src[c] * alpha;
+            if (dst) unsafeAtomicAdd(dst + c, g);
+            if (pd) unsafeAtomicAdd(pd + c, g);
+        }
+    }
+}
+
+static int fill_tables(EmbedTables& t, const float* const* tables, const float* const* starts, const float* const* pos,
+                       float* const* dtables, float* const* dstarts, float* const* dpos, int nseq) {
+    memset(&t, 0, sizeof(t));
+    for (int i = 0; i < nseq; ++i) {
+        if (tables) t.table[i] = tables[i];
+        if (starts) t.start[i] = starts[i];
+        if (pos) t.pos[i] = pos[i];
+        if (dtables) t.dtable[i] = dtables[i];
+        if (dstarts) t.dstart[i] = dstarts[i];
+        if (dpos) t.dpos[i] = dpos[i];
+    }
+    return 0;
+}
+
+// tables/starts/pos: host arrays (length nseq) of DEVICE pointers.
+extern "C" int omlm_embed_gather_fwd(const int* ids, const int* seg, const int* posidx,
+                                     const float* const* tables, const float* const* starts, const float* const* pos,
+                                     int nseq, float* out, int B, int N, int D, void* stream) {
+    if (B <= 0 || N <= 0) return OMLM_OK;
+    OMLM_CHECK_ARG(ids && seg && tables && starts && out, "null pointer");
+    OMLM_CHECK_ARG(nseq >= 1 && nseq <= MAX_SEQ, "1..4 token sequences supported");
+    OMLM_CHECK_ARG(D % 4 == 0, "D % 4");
+    OMLM_CHECK_ARG(!pos || posidx, "posidx required with position tables");
+    EmbedTables t;
+    fill_tables(t, tables, starts, pos, nullptr, nullptr, nullptr, nseq);
+    long long rows = (long long)B * N;
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3((unsigned)(rows < 16384 ? rows : 16384)), dim3(256), 0, as_stream(stream), ids, seg, posidx, t, out, B, N, D);
+    return omlm_post_launch("omlm_embed_gather_fwd");
+}
+
+// accumulates (+=) alpha * dx rows into the table / start-token / position gradients.
+extern "C" int omlm_embed_gather_bwd(const int* ids, const int* seg, const int* posidx,
+                                     float* const* dtables, float* const* dstarts, float* const* dpos,
+                                     int nseq, const float* dx, int B, int N, int D, float alpha, void* stream) {
+    if (B <= 0 || N <= 0) return OMLM_OK;
+    OMLM_CHECK_ARG(ids && seg && dtables && dstarts && dx, "null pointer");
+    OMLM_CHECK_ARG(nseq >= 1 && nseq <= MAX_SEQ, "1..4 token sequences supported");
+    EmbedTables t;
+    fill_tables(t, nullptr, nullptr, nullptr, dtables, dstarts, dpos, nseq);
+    long long rows = (long long)B * N;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)(rows < 16384 ? rows : 16384)), dim3(256), 0, as_stream(stream), ids, seg, posidx, t, dx, B, N, D, alpha);
+    return omlm_post_launch("omlm_embed_gather_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// cross entropy over rows of padded logits [R, ld] (first V columns valid).  Rows are addressed through an
+// optional row map so the labels can stay in [B, n] order while logits live in the head-GEMM layout.
+// label < 0 -> row ignored (ignore_index semantics).
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, const int* __restrict__ labels,
+                                                     float* __restrict__ row_lse, float* __restrict__ nll_sum,
+                                                     int R, int V, int ld) {
+    __shared__ float red[4];
+    float local = 0.f;
+    for (int row = blockIdx.x; row < R; row += gridDim.x) {
+        const float* lr = logits + (size_t)row * ld;
+        float mx = -INFINITY;
+        for (int c = threadIdx.x; c < V; c += 256) mx = fmaxf(mx, lr[c]);
+        mx = wave_max(mx);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        float s = 0.f;
+        for (int c = threadIdx.x; c < V; c += 256) s += __expf(lr[c] - mx);
+        s = block_sum<256>(s, red);
+        const float lse = mx + __logf(s);
+        if (threadIdx.x == 0) {
+            row_lse[row] = lse;
+            const int lb = labels[row];
+            if (lb >= 0) local += lse - lr[lb];
+        }
+    }
+    if (threadIdx.x == 0 && local != 0.f) unsafeAtomicAdd(nll_sum, local);
+}
+
+// dlogits[row, c] = coef * g * (softmax - onehot) for c < V, 0 for V <= c < ldd
+template <typename T>
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, const int* __restrict__ labels,
+                                                     const float* __restrict__ row_lse, const float* __restrict__ gscale,
+                                                     float coef, T* __restrict__ dlogits, int R, int V, int ld, int ldd) {
+    const float g = coef * (gscale ? gscale[0] : 1.0f);
+    for (int row = blockIdx.x; row < R; row += gridDim.x) {
+        const float* lr = logits + (size_t)row * ld;
+        T* dr = dlogits + (size_t)row * ldd;
+        const int lb = labels[row];
+        const float lse = row_lse[row];
+        for (int c = threadIdx.x; c < ldd; c += 256) {
+            float v = 0.f;
+            if (c < V && lb >= 0) v = g * (__expf(lr[c] - lse) - (c == lb ? 1.0f : 0.0f));
+            store_from_float(dr + c, v);
+        }
+    }
+}
+
+extern "C" int omlm_cross_entropy_fwd(const float* logits, const int* labels, float* row_lse, float* nll_sum,
+                                      int R, int V, int ld, void* stream) {
+    if (R <= 0) return OMLM_OK;
+    OMLM_CHECK_ARG(logits && labels && row_lse && nll_sum && ld >= V, "cross entropy arguments");
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(R < 4096 ? R : 4096), dim3(256), 0, as_stream(stream), logits, labels, row_lse, nll_sum, R, V, ld);
+    return omlm_post_launch("omlm_cross_entropy_fwd");
+}
+
+extern "C" int omlm_cross_entropy_bwd(const float* logits, const int* labels, const float* row_lse, const float* gscale,
+                                      float coef, void* dlogits, int R, int V, int ld, int ldd, int out_dtype, void* stream) {
+    if (R <= 0) return OMLM_OK;
+    OMLM_CHECK_ARG(logits && labels && row_lse && dlogits && ld >= V && ldd >= V, "cross entropy arguments");
+    dim3 grid(R < 8192 ? R : 8192), block(256);
+    if (out_dtype == 0)
+        hipLaunchKernelGGL(ce_bwd_kernel<float>, grid, block, 0, as_stream(stream), logits, labels, row_lse, gscale, coef, (float*)dlogits, R, V, ld, ldd);
+    else
+        hipLaunchKernelGGL(ce_bwd_kernel<bf16_t>, grid, block, 0, as_stream(stream), logits, labels, row_lse, gscale, coef, (bf16_t*)dlogits, R, V, ld, ldd);
+    return omlm_post_launch("omlm_cross_entropy_bwd");
+}

@@ -1,0 +1,332 @@
+// Fused middle of ConvFeedForward (reference transformer.py:122-150):
+//   h1 [M, 2*Fp]  --causal depthwise conv k=3-->  u  --GEGLU (erf GELU on the gate half)-->  g
+//      --LayerNorm over the F real channels-->  --Dropout(p)-->  h2 [M, Fp]
+// h1 is the output of the FF-in GEMM in a padded layout: value half in columns [0, F), gate half in
+// columns [Fp, Fp + F), Fp = F rounded up to 8 so both halves are 16-byte aligned; pad columns are 0.
+// Rows are tokens (b * n_seq + t); the conv is causal *within a sample* (left pad 2, :129).
+// With use_conv_ff=False (plain FeedForward :152-161) the host passes conv weights (0, 0, 1).
+//
+// HBM-bound: forward reads h1 once (the two halo rows come from L2) and writes h2; nothing but the
+// per-row LN statistics is saved -- the backward recomputes u and g from h1.
+#include "common.h"
+
+#define FF_THREADS 256
+#define FF_MAXC 3          // 8-channel chunks per thread -> Fp <= 6144
+
+template <typename T> struct vec8;
+template <> struct vec8<float> {
+    float v[8];
+    __device__ __forceinline__ void load(const float* p) {
+        const float4 a = ((const float4*)p)[0], b = ((const float4*)p)[1];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    __device__ __forceinline__ void store(float* p) const {
+        ((float4*)p)[0] = make_float4(v[0], v[1], v[2], v[3]);
+        ((float4*)p)[1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+};
+template <> struct vec8<bf16_t> {
+    float v[8];
+    __device__ __forceinline__ void load(const bf16_t* p) {
+        const u32x4 a = *(const u32x4*)p;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = bf16_lo_to_f(a[i]); v[2 * i + 1] = bf16_hi_to_f(a[i]); }
+    }
+    __device__ __forceinline__ void store(bf16_t* p) const {
+        u32x4 a;
+        a[0] = pack_bf16_rne(v[0], v[1]); a[1] = pack_bf16_rne(v[2], v[3]);
+        a[2] = pack_bf16_rne(v[4], v[5]); a[3] = pack_bf16_rne(v[6], v[7]);
+        *(u32x4*)p = a;
+    }
+};
+__device__ __forceinline__ void zero8(float* v) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = 0.f;
+}
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+// conv weights w[ch][3]: y[t] = w0 x[t-2] + w1 x[t-1] + w2 x[t]
+template <typename T>
+__device__ __forceinline__ void conv_row(const T* __restrict__ h1, const float* __restrict__ w, size_t row, int t, int ld,
+                                         int col, int wch, int nvalid, float* u) {
+    vec8<T> c0, c1, c2;
+    c2.load(h1 + row * ld + col);
+    if (t >= 1) c1.load(h1 + (row - 1) * ld + col); else zero8(c1.v);
+    if (t >= 2) c0.load(h1 + (row - 2) * ld + col); else zero8(c0.v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (i < nvalid) {
+            const float* wi = w + (size_t)(wch + i) * 3;
+            u[i] = wi[0] * c0.v[i] + wi[1] * c1.v[i] + wi[2] * c2.v[i];
+        } else {
+            u[i] = 0.f;     // zero-padded channel
+        }
+    }
+}
+
+// keep-mask * 1/(1-p) for 8 consecutive elements starting at element index e0 (multiple of 8)
+__device__ __forceinline__ void dropout8(unsigned long long seed, unsigned long long e0, float p, float* m) {
+    const float inv = 1.0f / (1.0f - p);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        unsigned o[4];
+        const unsigned long long blk = (e0 >> 2) + h;
+        philox4x32((unsigned)blk, (unsigned)(blk >> 32), 0u, 0u, (unsigned)seed, (unsigned)(seed >> 32), o);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) m[4 * h + i] = ((float)(o[i] >> 8) * (1.0f / 16777216.0f)) >= p ? inv : 0.f;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(FF_THREADS) void ffmid_fwd_kernel(const T* __restrict__ h1, const float* __restrict__ convw,
+                                                               const float* __restrict__ gamma, T* __restrict__ h2,
+                                                               float* __restrict__ mean, float* __restrict__ rstd,
+                                                               int M, int nseq, int F, int Fp, float eps, float p,
+                                                               unsigned long long seed) {
+    __shared__ float red[FF_THREADS / 64];
+    const int nchunk = Fp / 8, ld = 2 * Fp;
+    for (int row = blockIdx.x; row < M; row += gridDim.x) {
+        const int t = row % nseq;
+        float g[FF_MAXC][8];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < FF_MAXC; ++k) {
+            const int ch = (threadIdx.x + k * FF_THREADS) * 8;
+            if (ch < Fp) {
+                float ux[8], ug[8];
+                conv_row<T>(h1, convw, row, t, ld, ch, ch, F - ch, ux);
+                conv_row<T>(h1, convw, row, t, ld, Fp + ch, F + ch, F - ch, ug);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    g[k][i] = (ch + i < F) ? gelu_f(ug[i]) * ux[i] : 0.f;
+                    s += g[k][i];
+                }
+            }
+        }
+        const float mu = block_sum<FF_THREADS>(s, red) / (float)F;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < FF_MAXC; ++k) {
+            const int ch = (threadIdx.x + k * FF_THREADS) * 8;
+            if (ch < Fp) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) if (ch + i < F) { const float d = g[k][i] - mu; q += d * d; }
+            }
+        }
+        const float rs = rsqrtf(block_sum<FF_THREADS>(q, red) / (float)F + eps);
+        if (threadIdx.x == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+        for (int k = 0; k < FF_MAXC; ++k) {
+            const int ch = (threadIdx.x + k * FF_THREADS) * 8;
+            if (ch < Fp) {
+                float m[8];
+                if (p > 0.f) dropout8(seed, (unsigned long long)row * Fp + ch, p, m);
+                vec8<T> o;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float gm = (ch + i < F) ? gamma[ch + i] : 0.f;
+                    float y = (g[k][i] - mu) * rs * gm;
+                    if (p > 0.f) y *= m[i];
+                    o.v[i] = (ch + i < F) ? y : 0.f;
+                }
+                o.store(h2 + (size_t)row * Fp + ch);
+            }
+        }
+    }
+}
+
+// Backward, stage 1 (row-local): dh2 -> dropout^T -> LayerNorm^T -> GEGLU^T  => du [M, 2*Fp]
+// plus per-block partial sums of dgamma (thread owns its channels over the block's rows).
+template <typename T>
+__global__ __launch_bounds__(FF_THREADS) void ffmid_bwd1_kernel(const T* __restrict__ dh2, const T* __restrict__ h1,
+                                                                const float* __restrict__ convw, const float* __restrict__ gamma,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                T* __restrict__ du, float* __restrict__ part_dgamma,
+                                                                int M, int nseq, int F, int Fp, float p, unsigned long long seed) {
+    __shared__ float red[FF_THREADS / 64];
+    const int ld = 2 * Fp;
+    float dgam[FF_MAXC][8];
+#pragma unroll
+    for (int k = 0; k < FF_MAXC; ++k) zero8(dgam[k]);
+    for (int row = blockIdx.x; row < M; row += gridDim.x) {
+        const int t = row % nseq;
+        const float mu = mean[row], rs = rstd[row];
+        float ux[FF_MAXC][8], ug[FF_MAXC][8], gy[FF_MAXC][8], gh[FF_MAXC][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < FF_MAXC; ++k) {
+            const int ch = (threadIdx.x + k * FF_THREADS) * 8;
+            if (ch < Fp) {
+                conv_row<T>(h1, convw, row, t, ld, ch, ch, F - ch, ux[k]);
+                conv_row<T>(h1, convw, row, t, ld, Fp + ch, F + ch, F - ch, ug[k]);
+                vec8<T> d;
+                d.load(dh2 + (size_t)row * Fp + ch);
+                float m[8];
+                if (p > 0.f) dropout8(seed, (unsigned long long)row * Fp + ch, p, m);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const bool ok = ch + i < F;
+                    const float gv = ok ? gelu_f(ug[k][i]) * ux[k][i] : 0.f;
+                    float dyv = ok ? d.v[i] : 0.f;
+                    if (p > 0.f) dyv *= m[i];
+                    gh[k][i] = ok ? (gv - mu) * rs : 0.f;
+                    dgam[k][i] += dyv * gh[k][i];
+                    gy[k][i] = ok ? dyv * gamma[ch + i] : 0.f;
+                    s1 += gy[k][i];
+                    s2 += gy[k][i] * gh[k][i];
+                }
+            }
+        }
+        const float m1 = block_sum<FF_THREADS>(s1, red) / (float)F;
+        const float m2 = block_sum<FF_THREADS>(s2, red) / (float)F;
+#pragma unroll
+        for (int k = 0; k < FF_MAXC; ++k) {
+            const int ch = (threadIdx.x + k * FF_THREADS) * 8;
+            if (ch < Fp) {
+                vec8<T> ox, og;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const bool ok = ch + i < F;
+                    const float dg = ok ? rs * (gy[k][i] - m1 - gh[k][i] * m2) : 0.f;
+                    ox.v[i] = dg * gelu_f(ug[k][i]);
+                    og.v[i] = dg * ux[k][i] * gelu_grad_f(ug[k][i]);
+                }
+                ox.store(du + (size_t)row * ld + ch);
+                og.store(du + (size_t)row * ld + Fp + ch);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < FF_MAXC; ++k) {
+        const int ch = (threadIdx.x + k * FF_THREADS) * 8;
+        if (ch < Fp) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) part_dgamma[(size_t)blockIdx.x * Fp + ch + i] = dgam[k][i];
+        }
+    }
+}
+
+// Backward, stage 2 (conv^T): dh1[t] = w2 du[t] + w1 du[t+1] + w0 du[t+2] (within the sample), and
+// per-block partials of dconv_w[ch][k] = sum_t du[t, ch] * h1[t-2+k, ch].
+// One thread owns 8 channels of the padded 2*Fp layout for a strip of rows.
+template <typename T>
+__global__ __launch_bounds__(FF_THREADS) void ffmid_bwd2_kernel(const T* __restrict__ du, const T* __restrict__ h1,
+                                                                const float* __restrict__ convw, T* __restrict__ dh1,
+                                                                float* __restrict__ part_dconv, int M, int nseq, int F, int Fp) {
+    const int ld = 2 * Fp, nchunk = ld / 8;
+    const int strips = gridDim.y;
+    const int chunk = blockIdx.x * FF_THREADS + threadIdx.x;
+    if (chunk >= nchunk) return;
+    const int col = chunk * 8;
+    const bool gate = col >= Fp;
+    const int chreal = gate ? col - Fp : col;          // channel index inside its half
+    const int wch = gate ? F + chreal : chreal;        // row of the reference conv weight [2F, 1, 3]
+    float w[8][3], dw[8][3];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const bool ok = chreal + i < F;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { w[i][k] = ok ? convw[(size_t)(wch + i) * 3 + k] : 0.f; dw[i][k] = 0.f; }
+    }
+    const int rows_per = (M + strips - 1) / strips;
+    const int r_begin = blockIdx.y * rows_per, r_end = min(M, r_begin + rows_per);
+    for (int row = r_begin; row < r_end; ++row) {
+        const int t = row % nseq;
+        vec8<T> d0, d1, d2, x0, x1, x2;
+        d0.load(du + (size_t)row * ld + col);
+        if (t + 1 < nseq) d1.load(du + (size_t)(row + 1) * ld + col); else zero8(d1.v);
+        if (t + 2 < nseq) d2.load(du + (size_t)(row + 2) * ld + col); else zero8(d2.v);
+        x2.load(h1 + (size_t)row * ld + col);
+        if (t >= 1) x1.load(h1 + (size_t)(row - 1) * ld + col); else zero8(x1.v);
+        if (t >= 2) x0.load(h1 + (size_t)(row - 2) * ld + col); else zero8(x0.v);
+        vec8<T> o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            o.v[i] = w[i][2] * d0.v[i] + w[i][1] * d1.v[i] + w[i][0] * d2.v[i];
+            dw[i][0] += d0.v[i] * x0.v[i];
+            dw[i][1] += d0.v[i] * x1.v[i];
+            dw[i][2] += d0.v[i] * x2.v[i];
+        }
+        o.store(dh1 + (size_t)row * ld + col);
+    }
+    // partials layout: [strip][2F real channels][3]
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (chreal + i < F) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                part_dconv[((size_t)blockIdx.y * 2 * F + wch + i) * 3 + k] = dw[i][k];
+        }
+    }
+}
+
+// out[c] += sum_p part[p * ldp + c],  c < C
+__global__ void colsum_kernel(const float* __restrict__ part, float* __restrict__ out, int P, int C, int ldp) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += part[(size_t)p * ldp + c];
+    out[c] += s;
+}
+
+extern "C" int omlm_colsum_accumulate(const float* part, float* out, int P, int C, int ldp, void* stream) {
+    if (P <= 0 || C <= 0) return OMLM_OK;
+    OMLM_CHECK_ARG(part && out && ldp >= C, "colsum arguments");
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), part, out, P, C, ldp);
+    return omlm_post_launch("omlm_colsum_accumulate");
+}
+
+#define FF_BWD1_BLOCKS 512
+#define FF_BWD2_STRIPS 64
+
+extern "C" long long omlm_ffmid_bwd_workspace_bytes(int F, int Fp) {
+    return (long long)sizeof(float) * ((long long)FF_BWD1_BLOCKS * Fp + (long long)FF_BWD2_STRIPS * 2 * F * 3);
+}
+
+extern "C" int omlm_ffmid_fwd(const void* h1, const float* convw, const float* gamma, void* h2, float* mean, float* rstd,
+                              int M, int nseq, int F, int Fp, float eps, float p, unsigned long long seed, int dtype, void* stream) {
+    if (M <= 0) return OMLM_OK;
+    OMLM_CHECK_ARG(h1 && convw && gamma && h2 && mean && rstd, "null pointer");
+    OMLM_CHECK_ARG(Fp % 8 == 0 && Fp >= F && Fp <= 8 * FF_THREADS * FF_MAXC, "Fp must be F rounded up to 8 and <= 6144");
+    OMLM_CHECK_ARG(nseq > 0 && M % nseq == 0, "M must be batch * nseq");
+    OMLM_CHECK_ARG(p >= 0.f && p < 1.f, "dropout p");
+    dim3 grid(M < 8192 ? M : 8192), block(FF_THREADS);
+    if (dtype == 0)
+        hipLaunchKernelGGL(ffmid_fwd_kernel<float>, grid, block, 0, as_stream(stream), (const float*)h1, convw, gamma, (float*)h2, mean, rstd, M, nseq, F, Fp, eps, p, seed);
+    else
+        hipLaunchKernelGGL(ffmid_fwd_kernel<bf16_t>, grid, block, 0, as_stream(stream), (const bf16_t*)h1, convw, gamma, (bf16_t*)h2, mean, rstd, M, nseq, F, Fp, eps, p, seed);
+    return omlm_post_launch("omlm_ffmid_fwd");
+}
+
+// du_tmp: [M, 2*Fp] scratch of the operand dtype; dh1: [M, 2*Fp] output; workspace: omlm_ffmid_bwd_workspace_bytes.
+// dgamma [F], dconv [2F*3] are accumulated into (+=).
+extern "C" int omlm_ffmid_bwd(const void* dh2, const void* h1, const float* convw, const float* gamma, const float* mean,
+                              const float* rstd, void* du_tmp, void* dh1, float* dgamma, float* dconv, float* workspace,
+                              int M, int nseq, int F, int Fp, float p, unsigned long long seed, int dtype, void* stream) {
+    if (M <= 0) return OMLM_OK;
+    OMLM_CHECK_ARG(dh2 && h1 && convw && gamma && mean && rstd && du_tmp && dh1 && workspace, "null pointer");
+    OMLM_CHECK_ARG(Fp % 8 == 0 && Fp >= F && Fp <= 8 * FF_THREADS * FF_MAXC, "Fp must be F rounded up to 8 and <= 6144");
+    OMLM_CHECK_ARG(nseq > 0 && M % nseq == 0, "M must be batch * nseq");
+    hipStream_t st = as_stream(stream);
+    float* part_g = workspace;
+    float* part_c = workspace + (size_t)FF_BWD1_BLOCKS * Fp;
+    const int b1 = M < FF_BWD1_BLOCKS ? M : FF_BWD1_BLOCKS;
+    const int strips = M < FF_BWD2_STRIPS ? M : FF_BWD2_STRIPS;
+    dim3 g2((2 * Fp / 8 + FF_THREADS - 1) / FF_THREADS, strips);
+    if (dtype == 0) {
+        hipLaunchKernelGGL(ffmid_bwd1_kernel<float>, dim3(b1), dim3(FF_THREADS), 0, st, (const float*)dh2, (const float*)h1, convw, gamma, mean, rstd, (float*)du_tmp, part_g, M, nseq, F, Fp, p, seed);
+        hipLaunchKernelGGL(ffmid_bwd2_kernel<float>, g2, dim3(FF_THREADS), 0, st, (const float*)du_tmp, (const float*)h1, convw, (float*)dh1, part_c, M, nseq, F, Fp);
+    } else {
+        hipLaunchKernelGGL(ffmid_bwd1_kernel<bf16_t>, dim3(b1), dim3(FF_THREADS), 0, st, (const bf16_t*)dh2, (const bf16_t*)h1, convw, gamma, mean, rstd, (bf16_t*)du_tmp, part_g, M, nseq, F, Fp, p, seed);
+        hipLaunchKernelGGL(ffmid_bwd2_kernel<bf16_t>, g2, dim3(FF_THREADS), 0, st, (const bf16_t*)du_tmp, (const bf16_t*)h1, convw, (bf16_t*)dh1, part_c, M, nseq, F, Fp);
+    }
+    int rc = omlm_post_launch("omlm_ffmid_bwd");
+    if (rc) return rc;
+    if (dgamma) { rc = omlm_colsum_accumulate(part_g, dgamma, b1, F, Fp, stream); if (rc) return rc; }
+    if (dconv)  { rc = omlm_colsum_accumulate(part_c, dconv, strips, 2 * F * 3, 2 * F * 3, stream); if (rc) return rc; }
+    return OMLM_OK;
+}

@@ -1,0 +1,292 @@
+// MFMA GEMM for every dense contraction of the TokenConditionedTransformer path
+// (to_q / to_kv / to_out, FF in/out, per-quantizer logit heads, and all their backward GEMMs).
+//
+//   C[m, n] = alpha * sum_k A(m, k) * B(n, k)  (+ Cin[m, n])
+//
+// A is either row-major [M, K] ("normal", k contiguous) or k-major [K, M] (A_KMAJ);
+// B is either [N, K] (nn.Linear weight layout, k contiguous) or k-major [K, N] (B_KMAJ).
+// With those two switches the forward (x W^T), the input-gradient (dY W) and the
+// weight-gradient (dY^T X) contractions all read their operands exactly as the
+// autograd graph leaves them in HBM -- no transposed copies are ever materialised.
+// k-major tiles are staged row-for-row into LDS and fed to the matrix cores through the
+// gfx950 hardware transpose read (ds_read_b64_tr_b16).
+//
+// Element type T selects the arithmetic:
+//   T = bf16  : operands are bf16 in HBM, one v_mfma_f32_32x32x16_bf16 per k16 step  ("bf16")
+//   T = float : operands are fp32 in HBM and are split on the fly into bf16 hi + bf16 lo
+//               while being staged into LDS; hi*hi + hi*lo + lo*hi on the matrix cores
+//               ("bf16x3": fp32-grade products at 1/3 of the bf16 MFMA rate, still ~5x the
+//               fp32-MFMA rate).  Accumulation is fp32 in both modes.
+//
+// Tile: 128 x 128 x 64 per workgroup of 4 waves (2x2), each wave 64x64 = 2x2 MFMA 32x32 tiles.
+// Staging: global -> registers (issued before the MFMA phase of the previous tile) -> LDS
+// after the barrier (async-STAGE split, guide T14).  LDS images are XOR-swizzled so that both
+// ds_read_b128 (normal) and ds_read_b64_tr_b16 (k-major) fragment reads are conflict-free.
+// Out-of-range rows/columns are read through a buffer descriptor with an out-of-bounds offset
+// (hardware returns 0), so M, N and K may be ragged at 8-element granularity.
+// Optional row maps (int32) gather A rows / k rows and scatter C rows: this is how the
+// per-quantizer logit heads read the positions p = q (mod Q) of the hidden states in place.
+#include "common.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define NTHREADS 256
+
+struct GemmArgs {
+    const void* A;  const void* B;  void* C;  const float* Cin;
+    const int* a_map;   // normal A: physical row of logical row m;  k-major A: physical row of k
+    const int* b_map;   // normal B: physical row of logical row n;  k-major B: physical row of k
+    const int* c_map;   // physical row of logical row m in C / Cin
+    long long a_rows, b_rows;   // physical row counts (for the buffer descriptors)
+    int M, N, K;
+    int lda, ldb, ldc, ldcin;
+    float alpha;
+};
+
+// ---- LDS images ---------------------------------------------------------------------------
+// normal tile: [128 rows][64 k] bf16, 128 B per row, 16-B chunk index XOR ((row >> 1) & 7)
+__device__ __forceinline__ int lds_off_normal(int row, int kchunk) {
+    return row * 128 + ((kchunk ^ ((row >> 1) & 7)) << 4);
+}
+// k-major tile: [64 k][128 cols] bf16, 256 B per row, 64-B segment index XOR (k & 3)
+__device__ __forceinline__ int lds_off_kmaj(int k, int colbyte) {
+    return k * 256 + ((((colbyte >> 6) ^ (k & 3)) << 6) | (colbyte & 63));
+}
+
+template <typename T, bool KMAJ>
+struct Stager {
+    static constexpr bool PRECISE = elt_traits<T>::precise;
+    // per thread: 4 pieces of 8 elements
+    u32x4 r[PRECISE ? 8 : 4];
+
+    // tile origin: (r0 along the tile's 128-wide dim, k0 along the contraction)
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, const int* map, int ld, int nvalid128,
+                                         int r0, int k0, int K) {
+        const int t = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = t + NTHREADS * i;
+            unsigned off;
+            if (!KMAJ) {
+                const int row = c >> 3, kc = c & 7;               // 8 chunks (of 8 k) per row
+                const int gr = r0 + row, gk = k0 + kc * 8;
+                const bool ok = (gr < nvalid128) && (gk < K);
+                long long pr = gr;
+                if (ok && map) pr = map[gr];
+                off = ok ? (unsigned)((pr * ld + gk) * (long long)sizeof(T)) : OOB_OFF;
+            } else {
+                const int kr = c >> 4, cc = c & 15;               // 16 chunks (of 8 cols) per k row
+                const int gk = k0 + kr, gc = r0 + cc * 8;
+                const bool ok = (gk < K) && (gc < nvalid128);
+                long long pr = gk;
+                if (ok && map) pr = map[gk];
+                off = ok ? (unsigned)((pr * ld + gc) * (long long)sizeof(T)) : OOB_OFF;
+            }
+            if (PRECISE) {
+                r[2 * i] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+                r[2 * i + 1] = __builtin_amdgcn_raw_buffer_load_b128(rs, off == OOB_OFF ? OOB_OFF : off + 16, 0, 0);
+            } else {
+                r[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+            }
+        }
+    }
+
+    __device__ __forceinline__ void store(char* lds_hi, char* lds_lo) {
+        const int t = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = t + NTHREADS * i;
+            int o;
+            if (!KMAJ) o = lds_off_normal(c >> 3, c & 7);
+            else       o = lds_off_kmaj(c >> 4, (c & 15) * 16);
+            if (PRECISE) {
+                u32x4 hi, lo;
+                const u32x4 x0 = r[2 * i], x1 = r[2 * i + 1];
+                unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+                split_pair(u2f(x0[0]), u2f(x0[1]), h0, l0);
+                split_pair(u2f(x0[2]), u2f(x0[3]), h1, l1);
+                split_pair(u2f(x1[0]), u2f(x1[1]), h2, l2);
+                split_pair(u2f(x1[2]), u2f(x1[3]), h3, l3);
+                hi[0] = h0; hi[1] = h1; hi[2] = h2; hi[3] = h3;
+                lo[0] = l0; lo[1] = l1; lo[2] = l2; lo[3] = l3;
+                *(u32x4*)(lds_hi + o) = hi;
+                *(u32x4*)(lds_lo + o) = lo;
+            } else {
+                *(u32x4*)(lds_hi + o) = r[i];
+            }
+        }
+    }
+};
+
+// fragment of a 32-wide sub-tile (rows/cols sub0..sub0+31 of the 128-wide tile), k16 step s
+template <bool KMAJ>
+__device__ __forceinline__ bf16x8 read_frag(const char* lds, int sub0, int s, int lane) {
+    if (!KMAJ) {
+        const int row = sub0 + (lane & 31);
+        const int kc = 2 * s + (lane >> 5);
+        return *(const bf16x8*)(lds + lds_off_normal(row, kc));
+    } else {
+        // two transpose reads, 4 k each: lane gets column (sub0 + (lane&31)), k = 16s + 8*(lane>>5) + 0..7
+        const int g = (lane >> 4) & 1, i = lane & 15;
+        const int kb = 16 * s + 8 * (lane >> 5) + (i >> 2);
+        const int colbyte = (sub0 + 16 * g + 4 * (i & 3)) * 2;
+        s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, lds + lds_off_kmaj(kb, colbyte)));
+        s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, lds + lds_off_kmaj(kb + 4, colbyte)));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        s16x8 v = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, v);
+    }
+}
+
+template <typename T, bool A_KMAJ, bool B_KMAJ, typename TOUT>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs g) {
+    constexpr bool PRECISE = elt_traits<T>::precise;
+    constexpr int PLANE = BM * BK * 2;                       // 16 KiB per bf16 plane
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As_hi = smem;
+    char* Bs_hi = smem + PLANE;
+    char* As_lo = smem + 2 * PLANE;
+    char* Bs_lo = smem + 3 * PLANE;
+
+    // XCD-aware tile order: consecutive tiles of one XCD walk along N for a fixed M tile, so the
+    // A panel of a tile row stays in that XCD's L2.
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(g.A, (unsigned long long)g.a_rows * g.lda * sizeof(T));
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(g.B, (unsigned long long)g.b_rows * g.ldb * sizeof(T));
+
+    Stager<T, A_KMAJ> sa;
+    Stager<T, B_KMAJ> sb;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = (g.K + BK - 1) / BK;
+    sa.load(rsA, g.a_map, g.lda, g.M, m0, 0, g.K);
+    sb.load(rsB, g.b_map, g.ldb, g.N, n0, 0, g.K);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        sa.store(As_hi, As_lo);
+        sb.store(Bs_hi, Bs_lo);
+        __syncthreads();
+        if (kt + 1 < nk) {
+            sa.load(rsA, g.a_map, g.lda, g.M, m0, (kt + 1) * BK, g.K);
+            sb.load(rsB, g.b_map, g.ldb, g.N, n0, (kt + 1) * BK, g.K);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 ah[2], bh[2], al[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = read_frag<A_KMAJ>(As_hi, wm + 32 * i, s, lane);
+                bh[i] = read_frag<B_KMAJ>(Bs_hi, wn + 32 * i, s, lane);
+                if (PRECISE) {
+                    al[i] = read_frag<A_KMAJ>(As_lo, wm + 32 * i, s, lane);
+                    bl[i] = read_frag<B_KMAJ>(Bs_lo, wn + 32 * i, s, lane);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (PRECISE) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C-layout of v_mfma_f32_32x32x16: col = lane & 31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    TOUT* C = (TOUT*)g.C;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = m0 + wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            if (row >= g.M) continue;
+            const long long prow = g.c_map ? (long long)g.c_map[row] : (long long)row;
+            if (prow < 0) continue;          // row dropped by the scatter map (padding rows of a repacked weight)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + wn + 32 * j + (lane & 31);
+                if (col >= g.N) continue;
+                float v = g.alpha * acc[i][j][e];
+                if (g.Cin) v += g.Cin[prow * g.ldcin + col];
+                store_from_float(C + prow * g.ldc + col, v);
+            }
+        }
+    }
+}
+
+template <typename T, typename TOUT>
+static int launch_layout(const GemmArgs& g, int a_kmaj, int b_kmaj, hipStream_t st) {
+    const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    const size_t lds = (elt_traits<T>::precise ? 4 : 2) * (size_t)(BM * BK * 2);
+    dim3 grid(tiles), block(NTHREADS);
+    if (!a_kmaj && !b_kmaj)      hipLaunchKernelGGL((gemm_kernel<T, false, false, TOUT>), grid, block, lds, st, g);
+    else if (!a_kmaj && b_kmaj)  hipLaunchKernelGGL((gemm_kernel<T, false, true, TOUT>), grid, block, lds, st, g);
+    else if (a_kmaj && b_kmaj)   hipLaunchKernelGGL((gemm_kernel<T, true, true, TOUT>), grid, block, lds, st, g);
+    else                         hipLaunchKernelGGL((gemm_kernel<T, true, false, TOUT>), grid, block, lds, st, g);
+    return omlm_post_launch("omlm_gemm");
+}
+
+// dtype codes shared with the Python host: 0 = fp32, 1 = bf16
+extern "C" int omlm_gemm(const void* A, const void* B, void* C, const float* Cin,
+                         const int* a_map, const int* b_map, const int* c_map,
+                         long long a_rows, long long b_rows,
+                         int M, int N, int K, int lda, int ldb, int ldc, int ldcin,
+                         int a_kmajor, int b_kmajor, int in_dtype, int out_dtype, float alpha, void* stream) {
+    if (M <= 0 || N <= 0) return OMLM_OK;
+    OMLM_CHECK_ARG(A && B && C, "null operand");
+    OMLM_CHECK_ARG(K > 0, "K must be positive");
+    OMLM_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0, "operand leading dimensions must be multiples of 8 elements");
+    OMLM_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "operands must be 16-byte aligned");
+    OMLM_CHECK_ARG(in_dtype == 0 || in_dtype == 1, "in_dtype: 0=fp32 (bf16x3) or 1=bf16");
+    OMLM_CHECK_ARG(out_dtype == 0 || out_dtype == 1, "out_dtype: 0=fp32 or 1=bf16");
+    const size_t esz = in_dtype == 0 ? 4 : 2;
+    OMLM_CHECK_ARG((unsigned long long)a_rows * lda * esz < 0xFFFFFFF0ull, "A exceeds the 4 GiB buffer-descriptor window");
+    OMLM_CHECK_ARG((unsigned long long)b_rows * ldb * esz < 0xFFFFFFF0ull, "B exceeds the 4 GiB buffer-descriptor window");
+    // contiguous dims are consumed in chunks of 8: a ragged contiguous extent must be zero-padded to 8 by the caller
+    if (a_kmajor) OMLM_CHECK_ARG(lda >= ((M + 7) / 8) * 8, "k-major A: row pitch shorter than M padded to 8");
+    if (b_kmajor) OMLM_CHECK_ARG(ldb >= ((N + 7) / 8) * 8, "k-major B: row pitch shorter than N padded to 8");
+    if (!a_kmajor || !b_kmajor) OMLM_CHECK_ARG(K % 8 == 0, "k-contiguous operands need K % 8 == 0 (zero-pad the contraction)");
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.Cin = Cin; g.a_map = a_map; g.b_map = b_map; g.c_map = c_map;
+    g.a_rows = a_rows; g.b_rows = b_rows; g.M = M; g.N = N; g.K = K;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldcin = ldcin; g.alpha = alpha;
+    hipStream_t st = as_stream(stream);
+    if (in_dtype == 0) {
+        static bool attr_done = false;   // 64 KiB dynamic LDS needs the opt-in attribute once per kernel
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)gemm_kernel<float, false, false, float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+            (void)hipFuncSetAttribute((const void*)gemm_kernel<float, false, true, float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+            (void)hipFuncSetAttribute((const void*)gemm_kernel<float, true, true, float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+            (void)hipFuncSetAttribute((const void*)gemm_kernel<float, true, false, float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+            attr_done = true;
+        }
+        OMLM_CHECK_ARG(out_dtype == 0, "fp32 operands produce fp32 output");
+        return launch_layout<float, float>(g, a_kmajor, b_kmajor, st);
+    }
+    if (out_dtype == 0) return launch_layout<bf16_t, float>(g, a_kmajor, b_kmajor, st);
+    return launch_layout<bf16_t, bf16_t>(g, a_kmajor, b_kmajor, st);
+}

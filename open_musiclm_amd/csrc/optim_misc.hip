@@ -1,0 +1,320 @@
+// Optimizer step, casts/repacks, small element-wise helpers, quantizer argmin and a hardware probe.
+#include "common.h"
+#include <math.h>
+
+// ---------------------------------------------------------------------------------------------------------
+// global grad-norm (sum of squares, one atomic per block) and fused clip + Adam/AdamW step on flat buffers
+// (reference optimizer.py:10-34 -> torch.optim.Adam/AdamW defaults; trainer.py:444-447 clip then step).
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const long long n4 = n / 4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 v = ((const float4*)g)[i];
+        s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[n4 * 4 + threadIdx.x]; s += v * v; }
+    s = block_sum<256>(s, red);
+    if (threadIdx.x == 0) unsafeAtomicAdd(out, s);
+}
+
+extern "C" int omlm_sumsq_accumulate(const float* g, long long n, float* out, void* stream) {
+    if (n <= 0) return OMLM_OK;
+    OMLM_CHECK_ARG(g && out && ((uintptr_t)g % 16) == 0, "sumsq arguments");
+    long long blocks = (n / 4 + 255) / 256; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), g, n, out);
+    return omlm_post_launch("omlm_sumsq_accumulate");
+}
+
+// p, g, m, v: flat fp32.  g is first scaled by gscale (1/world_size for the DP mean) and by the clip coefficient
+// min(1, max_norm / (gscale * sqrt(*gnorm_sq) + 1e-6)) (torch.nn.utils.clip_grad_norm_), all on device: no host sync.
+// decoupled != 0 -> AdamW (p *= 1 - lr*wd); else Adam with L2 folded into the gradient (wd is 0 on the reference's Adam path).
+// p16 (optional) receives the bf16 copy of the updated parameters; zero_grad != 0 clears g in the same pass.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, bf16_t* __restrict__ p16, long long n,
+                                                    float lr, float beta1, float beta2, float eps, float wd,
+                                                    float bc1, float bc2_sqrt, float gscale, const float* __restrict__ gnorm_sq,
+                                                    float max_norm, int decoupled, int zero_grad) {
+    float clip = 1.0f;
+    if (gnorm_sq && max_norm > 0.f) {
+        const float nrm = sqrtf(gnorm_sq[0]) * gscale;
+        clip = fminf(1.0f, max_norm / (nrm + 1e-6f));
+    }
+    const float gs = gscale * clip;
+    const float step = lr / bc1;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float pi = p[i], gi = g[i] * gs;
+        if (decoupled) pi *= (1.0f - lr * wd); else gi += wd * pi;
+        const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+        pi -= step * mi / (sqrtf(vi) / bc2_sqrt + eps);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+        if (p16) p16[i] = (bf16_t)pi;
+        if (zero_grad) g[i] = 0.f;
+    }
+}
+
+extern "C" int omlm_adamw_clip_step(float* p, float* g, float* m, float* v, void* p16, long long n,
+                                    float lr, float beta1, float beta2, float eps, float wd, int step,
+                                    float gscale, const float* gnorm_sq, float max_norm, int decoupled, int zero_grad,
+                                    void* stream) {
+    if (n <= 0) return OMLM_OK;
+    OMLM_CHECK_ARG(p && g && m && v && step >= 1, "adamw arguments");
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)step)), bc2 = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    long long blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), p, g, m, v, (bf16_t*)p16, n,
+                       lr, beta1, beta2, eps, wd, bc1, bc2, gscale, gnorm_sq, max_norm, decoupled, zero_grad);
+    return omlm_post_launch("omlm_adamw_clip_step");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// dst[r, c] = (T) src[r, c] for c < C ; 0 for C <= c < ldd.   (weight repack / operand casts)
+template <typename T>
+__global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__ src, T* __restrict__ dst, long long R, int C, int lds_, int ldd) {
+    for (long long r = blockIdx.x; r < R; r += gridDim.x)
+        for (int c = threadIdx.x; c < ldd; c += 256)
+            store_from_float(dst + r * ldd + c, c < C ? src[r * lds_ + c] : 0.f);
+}
+extern "C" int omlm_cast_pad(const float* src, void* dst, long long R, int C, int ld_src, int ld_dst, int out_dtype, void* stream) {
+    if (R <= 0 || C <= 0) return OMLM_OK;
+    OMLM_CHECK_ARG(src && dst && ld_src >= C && ld_dst >= C, "cast_pad arguments");
+    dim3 grid((unsigned)(R < 8192 ? R : 8192)), block(256);
+    if (out_dtype == 0) hipLaunchKernelGGL(cast_pad_kernel<float>, grid, block, 0, as_stream(stream), src, (float*)dst, R, C, ld_src, ld_dst);
+    else hipLaunchKernelGGL(cast_pad_kernel<bf16_t>, grid, block, 0, as_stream(stream), src, (bf16_t*)dst, R, C, ld_src, ld_dst);
+    return omlm_post_launch("omlm_cast_pad");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// rel-pos MLP helpers (reference transformer.py:36-67): SiLU layers.  pre = a + bias is saved for the backward.
+//   first layer (Linear(1, Hd)): a[r, c] = r * w0[c]
+__global__ void relpos_first_kernel(const float* __restrict__ w0, const float* __restrict__ b0, float* __restrict__ pre,
+                                    float* __restrict__ z, int n, int Hd) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)n * Hd) return;
+    const int r = (int)(i / Hd), c = (int)(i % Hd);
+    const float s = (float)r * w0[c] + b0[c];
+    pre[i] = s;
+    z[i] = s / (1.0f + __expf(-s));
+}
+__global__ void bias_silu_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ pre,
+                                     float* __restrict__ z, long long total, int C) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float s = a[i] + b[i % C];
+    pre[i] = s;
+    z[i] = s / (1.0f + __expf(-s));
+}
+// ds = dz * silu'(pre)
+__global__ void silu_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ pre, float* __restrict__ ds, long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float s = pre[i], sg = 1.0f / (1.0f + __expf(-s));
+    ds[i] = dz[i] * (sg * (1.0f + s * (1.0f - sg)));
+}
+// out[r, c] = a[r, c] + b[c] (no activation: last rel-pos layer), row pitch ld (pad columns -> 0)
+__global__ void bias_add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int R, int C, int ld) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)R * ld) return;
+    const int c = (int)(i % ld);
+    out[i] = c < C ? a[i] + b[c] : 0.f;
+}
+// dw0[c] += sum_r r * ds[r, c]   (first-layer weight gradient), one thread per column
+__global__ void relpos_first_bwd_kernel(const float* __restrict__ ds, float* __restrict__ dw0, int n, int Hd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Hd) return;
+    float s = 0.f;
+    for (int r = 0; r < n; ++r) s += (float)r * ds[(size_t)r * Hd + c];
+    dw0[c] += s;
+}
+
+extern "C" int omlm_relpos_first_fwd(const float* w0, const float* b0, float* pre, float* z, int n, int Hd, void* stream) {
+    OMLM_CHECK_ARG(w0 && b0 && pre && z && n > 0 && Hd > 0, "relpos_first arguments");
+    const long long tot = (long long)n * Hd;
+    hipLaunchKernelGGL(relpos_first_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, as_stream(stream), w0, b0, pre, z, n, Hd);
+    return omlm_post_launch("omlm_relpos_first_fwd");
+}
+extern "C" int omlm_bias_silu_fwd(const float* a, const float* b, float* pre, float* z, long long R, int C, void* stream) {
+    OMLM_CHECK_ARG(a && b && pre && z && R > 0 && C > 0, "bias_silu arguments");
+    const long long tot = R * C;
+    hipLaunchKernelGGL(bias_silu_fwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, as_stream(stream), a, b, pre, z, tot, C);
+    return omlm_post_launch("omlm_bias_silu_fwd");
+}
+extern "C" int omlm_silu_bwd(const float* dz, const float* pre, float* ds, long long total, void* stream) {
+    OMLM_CHECK_ARG(dz && pre && ds && total > 0, "silu_bwd arguments");
+    hipLaunchKernelGGL(silu_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), dz, pre, ds, total);
+    return omlm_post_launch("omlm_silu_bwd");
+}
+extern "C" int omlm_bias_add(const float* a, const float* b, float* out, int R, int C, int ld, void* stream) {
+    OMLM_CHECK_ARG(a && b && out && R > 0 && ld >= C, "bias_add arguments");
+    const long long tot = (long long)R * ld;
+    hipLaunchKernelGGL(bias_add_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, as_stream(stream), a, b, out, R, C, ld);
+    return omlm_post_launch("omlm_bias_add");
+}
+extern "C" int omlm_relpos_first_bwd(const float* ds, float* dw0, int n, int Hd, void* stream) {
+    OMLM_CHECK_ARG(ds && dw0 && n > 0 && Hd > 0, "relpos_first_bwd arguments");
+    hipLaunchKernelGGL(relpos_first_bwd_kernel, dim3((Hd + 255) / 256), dim3(256), 0, as_stream(stream), ds, dw0, n, Hd);
+    return omlm_post_launch("omlm_relpos_first_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Residual-VQ / k-means nearest-codeword (clap_quantized.py:75-87 -> ResidualVQ eval path; hf_hubert_kmeans.py:87).
+// Bit-exact contract (oracle.nearest_code): dist(c) = sum_d (x_d - e_{c,d})^2 in fp32, d in index order, the
+// multiply and the add rounded separately (no FMA contraction), argmin with ties -> lowest index; then
+// r <- r - e_idx (one fp32 subtraction per element).  cbT is the codebook TRANSPOSED: [n_stage][D][C], so that
+// consecutive threads (codes) read consecutive addresses.
+__global__ __launch_bounds__(256) void rvq_kernel(const float* __restrict__ x, const float* __restrict__ cbT,
+                                                  int* __restrict__ idx_out, float* __restrict__ resid_out,
+                                                  int n, int D, int C, int nstage) {
+    extern __shared__ float r[];                  // [D] running residual
+    __shared__ float bd[4];
+    __shared__ int bi[4];
+    __shared__ int chosen;
+    const int row = blockIdx.x;
+    for (int d = threadIdx.x; d < D; d += 256) r[d] = x[(size_t)row * D + d];
+    __syncthreads();
+    for (int s = 0; s < nstage; ++s) {
+        const float* cb = cbT + (size_t)s * D * C;
+        float best = INFINITY;
+        int besti = 0x7fffffff;
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float dist = 0.f;
+            for (int d = 0; d < D; ++d) {
+                const float diff = __fsub_rn(r[d], cb[(size_t)d * C + c]);
+                dist = __fadd_rn(dist, __fmul_rn(diff, diff));
+            }
+            if (dist < best) { best = dist; besti = c; }      // ascending c per thread: strict < keeps the lowest index
+        }
+        // lexicographic (dist, index) min over the block
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float od = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(besti, o, 64);
+            if (od < best || (od == best && oi < besti)) { best = od; besti = oi; }
+        }
+        if ((threadIdx.x & 63) == 0) { bd[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = besti; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float b = bd[0]; int i0 = bi[0];
+            for (int w = 1; w < 4; ++w) if (bd[w] < b || (bd[w] == b && bi[w] < i0)) { b = bd[w]; i0 = bi[w]; }
+            chosen = i0;
+            idx_out[(size_t)row * nstage + s] = i0;
+        }
+        __syncthreads();
+        const int ci = chosen;
+        for (int d = threadIdx.x; d < D; d += 256) r[d] = __fsub_rn(r[d], cb[(size_t)d * C + ci]);
+        __syncthreads();
+    }
+    if (resid_out) for (int d = threadIdx.x; d < D; d += 256) resid_out[(size_t)row * D + d] = r[d];
+}
+
+extern "C" int omlm_rvq_encode(const float* x, const float* codebooks_T, int* indices, float* residual_out,
+                               int n, int D, int C, int nstage, void* stream) {
+    if (n <= 0) return OMLM_OK;
+    OMLM_CHECK_ARG(x && codebooks_T && indices && D > 0 && C > 0 && nstage > 0, "rvq arguments");
+    OMLM_CHECK_ARG((size_t)D * sizeof(float) <= 48 * 1024, "D too large");
+    hipLaunchKernelGGL(rvq_kernel, dim3(n), dim3(256), D * sizeof(float), as_stream(stream), x, codebooks_T, indices, residual_out, n, D, C, nstage);
+    return omlm_post_launch("omlm_rvq_encode");
+}
+extern "C" int omlm_nearest_centroid(const float* x, const float* centroids_T, int* indices, int n, int D, int C, void* stream) {
+    return omlm_rvq_encode(x, centroids_T, indices, nullptr, n, D, C, 1, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// fused sampler of the AR loop (open_musiclm.py:309-316; utils.py:65-84): last-position logits [B, V] ->
+//   eos logit -> -inf (unless allowed), keep the k = max(int((1-thres) V), 1) largest logits, argmax(l / T + Gumbel(u)).
+// One workgroup per row; V <= 2048.  The k-th largest value is found by a bitwise radix descent on the
+// order-preserving integer image of the floats (exact, no sort); ties at the threshold are kept in index order
+// like torch.topk + scatter (which keeps exactly k entries: the lowest indices among equals).
+__device__ __forceinline__ unsigned f_ord(float f) { unsigned u = f2u(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+
+__global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ logits, const float* __restrict__ uniform,
+                                                     long long* __restrict__ out, int V, int ld, int k, float temperature,
+                                                     int forbid_last) {
+    __shared__ unsigned keys[2048];
+    __shared__ int cnt[4];
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    const int row = blockIdx.x;
+    const float* lr = logits + (size_t)row * ld;
+    for (int c = threadIdx.x; c < V; c += 256) {
+        float v = lr[c];
+        if (forbid_last && c == V - 1) v = -INFINITY;
+        keys[c] = f_ord(v);
+    }
+    __syncthreads();
+    // largest threshold t such that count(keys >= t) >= k
+    unsigned t = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned cand = t | (1u << bit);
+        int c0 = 0;
+        for (int c = threadIdx.x; c < V; c += 256) c0 += keys[c] >= cand;
+        c0 = (int)wave_sum((float)c0);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = c0;
+        __syncthreads();
+        if (cnt[0] + cnt[1] + cnt[2] + cnt[3] >= k) t = cand;
+    }
+    // strictly-greater entries are all kept; of the entries equal to t keep the first (k - n_greater) by index
+    int ng = 0;
+    for (int c = threadIdx.x; c < V; c += 256) ng += keys[c] > t;
+    ng = (int)wave_sum((float)ng);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = ng;
+    __syncthreads();
+    const int n_equal_keep = k - (cnt[0] + cnt[1] + cnt[2] + cnt[3]);
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    // sequential scan by one wave keeps the index order of equal entries cheaply (V <= 2048)
+    if (threadIdx.x < 64) {
+        int seen_eq = 0;
+        for (int base = 0; base < V; base += 64) {
+            const int c = base + threadIdx.x;
+            const bool in = c < V;
+            const unsigned kk = in ? keys[c] : 0u;
+            const bool eq = in && kk == t;
+            const unsigned long long eqmask = __ballot(eq);
+            const int rank = seen_eq + __popcll(eqmask & ((1ull << threadIdx.x) - 1ull));
+            const bool keep = in && (kk > t || (eq && rank < n_equal_keep));
+            seen_eq += __popcll(eqmask);
+            if (keep) {
+                float v = lr[c];
+                const float u = uniform[(size_t)row * V + c];
+                const float gum = -logf(-logf(u + 1e-20f) + 1e-20f);
+                v = v / temperature + gum;
+                if (v > best) { best = v; besti = c; }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(besti, o, 64);
+            if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+        }
+        if (threadIdx.x == 0) out[row] = besti;
+    }
+}
+
+extern "C" int omlm_sample_topk_gumbel(const float* logits, const float* uniform, long long* out, int B, int V, int ld,
+                                       int k, float temperature, int forbid_last, void* stream) {
+    if (B <= 0) return OMLM_OK;
+    OMLM_CHECK_ARG(logits && uniform && out && V > 0 && V <= 2048 && k >= 1 && k <= V && temperature > 0.f, "sampler arguments");
+    hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(256), 0, as_stream(stream), logits, uniform, out, V, ld, k, temperature, forbid_last);
+    return omlm_post_launch("omlm_sample_topk_gumbel");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Hardware probe used by tests/test_gpu_probe.py: dumps what ds_read_b64_tr_b16 returns for a linear LDS image
+// (lds[i] = i as 16-bit) when lane l supplies byte address 8*l, so the transpose-read assumption that the GEMM
+// and attention fragment loaders are built on is checked on the real chip.
+__global__ void probe_tr16_kernel(short* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) short lds[1024];
+    for (int i = threadIdx.x; i < 1024; i += 64) lds[i] = (short)i;
+    __syncthreads();
+    s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, (char*)lds + threadIdx.x * 8));
+    for (int j = 0; j < 4; ++j) out[threadIdx.x * 4 + j] = v[j];
+}
+extern "C" int omlm_probe_tr16(short* out, void* stream) {
+    OMLM_CHECK_ARG(out, "null");
+    hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, as_stream(stream), out);
+    return omlm_post_launch("omlm_probe_tr16");
+}

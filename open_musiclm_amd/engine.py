@@ -1,0 +1,599 @@
+"""Forward / backward engine of the TokenConditionedTransformer path on MI355X.
+
+This is the host side of the hot path: it owns the activation buffers, sequences the HIP kernels of
+``ops.py`` for the forward and the hand-written backward, and exposes them to autograd through two
+``torch.autograd.Function``s (logits path, fused-loss path).  Gradients of parameters are accumulated by the
+kernels directly into ``param.grad`` (GEMM epilogue ``C += ...`` / atomics), so there is no autograd
+AccumulateGrad pass and, under data parallelism, the flat gradient buffer is ready for ONE all-reduce.
+
+Reference arithmetic being reproduced (file:line into /root/reference/open_musiclm):
+  transformer.py:385-424 (trunk), :214-333 (attention), :140-161 (feed-forward), :36-117 (rel-pos bias),
+  open_musiclm.py:100-190 (embed / heads), :389-410 (loss).
+"""
+from __future__ import annotations
+
+import math
+import os
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+from .hip import require_gpu
+
+ATTN_SCALE = 8.0
+DIM_HEAD = 64
+
+_PRECISIONS = {"bf16": torch.bfloat16, "bf16x3": torch.float32}
+
+
+def default_precision() -> str:
+    p = os.environ.get("OMLM_PRECISION", "bf16")
+    if p not in _PRECISIONS:
+        raise ValueError(f"OMLM_PRECISION must be one of {list(_PRECISIONS)}, got {p}")
+    return p
+
+
+def ceil_to(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def grad_of(p: torch.Tensor) -> torch.Tensor:
+    """fp32 gradient buffer of a parameter (allocated zeroed on first use); kernels accumulate into it."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+    return p.grad
+
+
+# ------------------------------------------------------------------------------------------------------
+# static description of one forward call (positions, row maps) -- cached per (batch, lengths)
+# ------------------------------------------------------------------------------------------------------
+@dataclass
+class SeqLayout:
+    B: int
+    N: int
+    lens: Tuple[int, ...]                  # tokens per sequence (after eos append / last-token drop)
+    starts: Tuple[int, ...]                # position of each sequence's start token
+    n_out: Tuple[int, ...]                 # logit rows per sample per sequence
+    seg: torch.Tensor                      # [N] int32
+    posidx: torch.Tensor                   # [N] int32
+    start_col: torch.Tensor                # [N] bool: position is a start token
+    final_only: bool = False               # AR decode: only the last row of the last sequence is scored -> [B, ldV]
+    head_maps: Dict[Tuple[int, int], Tuple[torch.Tensor, torch.Tensor, int]] = field(default_factory=dict)
+
+
+def build_layout(B: int, lens: Sequence[int], quantizers: Sequence[int], device, final_rows_only: bool = False) -> SeqLayout:
+    starts, pos = [], 0
+    for l in lens:
+        starts.append(pos)
+        pos += l + 1
+    N = pos
+    seg = torch.empty(N, dtype=torch.int32)
+    posidx = torch.zeros(N, dtype=torch.int32)
+    start_col = torch.zeros(N, dtype=torch.bool)
+    for s, (st, l) in enumerate(zip(starts, lens)):
+        seg[st: st + l + 1] = s
+        start_col[st] = True
+        posidx[st + 1: st + l + 1] = torch.arange(l, dtype=torch.int32)
+    n_out = [l for l in lens[:-1]] + [lens[-1] + 1]
+    lay = SeqLayout(B, N, tuple(lens), tuple(starts), tuple(n_out), seg.to(device), posidx.to(device),
+                    start_col.to(device), final_rows_only)
+    if final_rows_only:
+        s, st, n_s, Q = len(lens) - 1, starts[-1], n_out[-1], quantizers[-1]
+        b = torch.arange(B)
+        a_map = (b * N + st + n_s - 1).to(torch.int32)
+        lay.head_maps[(s, (n_s - 1) % Q)] = (a_map.to(device), b.to(torch.int32).to(device), B)
+        return lay
+    for s, (st, n_s, Q) in enumerate(zip(starts, n_out, quantizers)):
+        for qq in range(Q):
+            js = torch.arange(qq, n_s, Q)
+            if js.numel() == 0:
+                continue
+            b = torch.arange(B)[:, None]
+            a_map = (b * N + st + js[None, :]).reshape(-1).to(torch.int32)
+            c_map = (b * n_s + js[None, :]).reshape(-1).to(torch.int32)
+            lay.head_maps[(s, qq)] = (a_map.to(device), c_map.to(device), int(a_map.numel()))
+    return lay
+
+
+# ------------------------------------------------------------------------------------------------------
+# operand copies of the weights in the GEMM operand dtype / padded layouts
+# ------------------------------------------------------------------------------------------------------
+class PreparedWeights:
+    def __init__(self, model, precision: str):
+        tr = model.transformer
+        self.precision = precision
+        self.T = _PRECISIONS[precision]
+        T = self.T
+        dev = model.start_tokens[0].device
+        D = tr.dim
+        self.layers = []
+        for attn, _, ff in tr.layers:
+            F = ff.inner_dim
+            Fp = ceil_to(F, 8)
+            w1 = ff.w_in.weight            # [2F, D]
+            w2 = ff.w_out.weight           # [D, F]
+            ent = {}
+            if T == torch.float32:
+                ent["Wq"], ent["Wkv"], ent["Wo"] = attn.to_q.weight, attn.to_kv.weight, attn.to_out[0].weight
+            else:
+                for name, w in (("Wq", attn.to_q.weight), ("Wkv", attn.to_kv.weight), ("Wo", attn.to_out[0].weight)):
+                    c = torch.empty(w.shape, dtype=T, device=dev)
+                    ops.cast_pad(w, c, w.shape[0], w.shape[1], w.shape[1], w.shape[1])
+                    ent[name] = c
+            W1p = torch.zeros(2 * Fp, D, dtype=T, device=dev)
+            ops.cast_pad(w1, W1p, F, D, D, D)
+            ops.cast_pad(w1[F:], W1p[Fp:], F, D, D, D)
+            W2p = torch.empty(D, Fp, dtype=T, device=dev)
+            ops.cast_pad(w2, W2p, D, F, F, Fp)
+            ent["W1p"], ent["W2p"], ent["F"], ent["Fp"] = W1p, W2p, F, Fp
+            ent["convw"] = ff.conv_weight()             # fp32 [2F, 3] (identity taps for plain FeedForward)
+            cm = torch.full((2 * Fp,), -1, dtype=torch.int32)
+            cm[:F] = torch.arange(F, dtype=torch.int32)
+            cm[Fp:Fp + F] = torch.arange(F, 2 * F, dtype=torch.int32)
+            ent["dW1_cmap"] = cm.to(dev)
+            self.layers.append(ent)
+        self.heads = []
+        for w in model.logit_weights:
+            if T == torch.float32:
+                self.heads.append(w)
+            else:
+                c = torch.empty(w.shape, dtype=T, device=dev)
+                ops.cast_pad(w, c, w.shape[0] * w.shape[1], w.shape[2], w.shape[2], w.shape[2])
+                self.heads.append(c)
+
+
+def prepared_weights(model, precision: str) -> PreparedWeights:
+    """Rebuilt on every grad-enabled forward (weights change every step; ~0.4 GB of traffic for musiclm_small);
+    cached under no_grad (AR decoding) keyed on the parameters' autograd version counters."""
+    key = (precision, sum(p._version for p in model.parameters()), tuple(p.data_ptr() for p in model.parameters()))
+    cache = getattr(model, "_omlm_prepared", None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    pw = PreparedWeights(model, precision)
+    object.__setattr__(model, "_omlm_prepared", (key, pw))
+    return pw
+
+
+# ------------------------------------------------------------------------------------------------------
+# relative position bias  ->  table [N, ldb] (row = i - j >= 0, column = head)
+# ------------------------------------------------------------------------------------------------------
+def relpos_forward(tr, n: int, save: bool):
+    rp = tr.rel_pos_bias
+    if rp is None:
+        return None, None
+    H = tr.heads
+    ldb = ceil_to(H, 8)
+    dev = tr.norm.gamma.device
+    if tr.relative_position_bias_type == "t5":
+        # 32-bucket embedding lookup (transformer.py:85-117); tiny, index plumbing done with torch
+        from .transformer import t5_bucket_of_distance
+        bucket = t5_bucket_of_distance(torch.arange(n, device=dev), rp.num_buckets, rp.max_distance)
+        table = torch.zeros(n, ldb, device=dev, dtype=torch.float32)
+        table[:, :H] = rp.relative_attention_bias.weight.detach()[bucket]
+        return table, ("t5", bucket)
+    lin = [rp.net[0][0], rp.net[1][0], rp.net[2][0], rp.net[3]]
+    Hd = lin[0].weight.shape[0]
+    pres, zs = [], []
+    pre = torch.empty(n, Hd, device=dev)
+    z = torch.empty(n, Hd, device=dev)
+    ops.relpos_first_fwd(lin[0].weight.detach().reshape(-1), lin[0].bias.detach(), pre, z, n, Hd)
+    pres.append(pre); zs.append(z)
+    for k in (1, 2):
+        a = torch.empty(n, Hd, device=dev)
+        ops.gemm(zs[-1], lin[k].weight.detach(), a, M=n, N=Hd, K=Hd)
+        pre = torch.empty(n, Hd, device=dev)
+        z = torch.empty(n, Hd, device=dev)
+        ops.bias_silu_fwd(a, lin[k].bias.detach(), pre, z, n, Hd)
+        pres.append(pre); zs.append(z)
+    a = torch.zeros(n, ldb, device=dev)
+    ops.gemm(zs[-1], lin[3].weight.detach(), a, M=n, N=H, K=Hd, ldc=ldb)
+    table = torch.empty(n, ldb, device=dev)
+    ops.bias_add(a, lin[3].bias.detach(), table, n, H, ldb)
+    return table, (("mlp", pres, zs) if save else None)
+
+
+def relpos_backward(tr, n: int, saved, dtable: torch.Tensor):
+    """dtable: [n, ldb] fp32 gradient of the bias table."""
+    rp = tr.rel_pos_bias
+    H = tr.heads
+    ldb = dtable.shape[-1]
+    dev = dtable.device
+    if saved[0] == "t5":
+        g = grad_of(rp.relative_attention_bias.weight)
+        g.index_add_(0, saved[1], dtable[:, :H])
+        return
+    _, pres, zs = saved
+    lin = [rp.net[0][0], rp.net[1][0], rp.net[2][0], rp.net[3]]
+    Hd = lin[0].weight.shape[0]
+    # last layer: table = z2 @ W3^T + b3
+    ops.colsum_accumulate(dtable, grad_of(lin[3].bias), n, H, ldb)
+    gw = grad_of(lin[3].weight)                                           # [H, Hd]
+    ops.gemm(dtable, zs[2], gw, M=H, N=Hd, K=n, a_kmajor=True, b_kmajor=True, Cin=gw, lda=ldb)
+    dz = torch.empty(n, Hd, device=dev)
+    ops.gemm(dtable, lin[3].weight.detach(), dz, M=n, N=Hd, K=ldb, b_kmajor=True, lda=ldb, b_rows=H)
+    for k in (2, 1):
+        ds = torch.empty(n, Hd, device=dev)
+        ops.silu_bwd(dz, pres[k], ds, n * Hd)
+        ops.colsum_accumulate(ds, grad_of(lin[k].bias), n, Hd, Hd)
+        gw = grad_of(lin[k].weight)
+        ops.gemm(ds, zs[k - 1], gw, M=Hd, N=Hd, K=n, a_kmajor=True, b_kmajor=True, Cin=gw)
+        dz = torch.empty(n, Hd, device=dev)
+        ops.gemm(ds, lin[k].weight.detach(), dz, M=n, N=Hd, K=Hd, b_kmajor=True)
+    ds = torch.empty(n, Hd, device=dev)
+    ops.silu_bwd(dz, pres[0], ds, n * Hd)
+    ops.colsum_accumulate(ds, grad_of(lin[0].bias), n, Hd, Hd)
+    ops.relpos_first_bwd(ds, grad_of(lin[0].weight).view(-1), n, Hd)
+
+
+# ------------------------------------------------------------------------------------------------------
+# trunk
+# ------------------------------------------------------------------------------------------------------
+class LayerSaved:
+    __slots__ = ("x", "m1", "r1", "xn", "xc", "q_raw", "kv_raw", "q", "k", "v", "o", "lse",
+                 "x1", "m2", "r2", "xn2", "h1", "h2", "m3", "r3", "seed", "p")
+
+
+def trunk_forward(tr, pw: PreparedWeights, x: torch.Tensor, keymask: Optional[torch.Tensor], B: int, N: int,
+                  save: bool, training: bool):
+    """x: [B*N, D] fp32 (consumed as the layer-0 residual).  Returns (final LN output in operand dtype, saved)."""
+    T = pw.T
+    dev = x.device
+    M, D = x.shape
+    H = tr.heads
+    table, rp_saved = relpos_forward(tr, N, save)
+    saved_layers: List[LayerSaved] = []
+    for li, ((attn, _, ff), w) in enumerate(zip(tr.layers, pw.layers)):
+        sv = LayerSaved()
+        F, Fp = w["F"], w["Fp"]
+        m1 = torch.empty(M, device=dev); r1 = torch.empty(M, device=dev)
+        xn = torch.empty(M, D, dtype=T, device=dev)
+        xc = x if T == torch.float32 else torch.empty(M, D, dtype=T, device=dev)
+        ops.layernorm_fwd(x, attn.norm.gamma.detach(), xn, None if T == torch.float32 else xc, m1, r1)
+        q_raw = torch.empty(M, H * DIM_HEAD, device=dev)
+        kv_raw = torch.empty(M, 2 * DIM_HEAD, device=dev)
+        ops.gemm(xn, w["Wq"], q_raw, M=M, N=H * DIM_HEAD, K=D)
+        ops.gemm(xc, w["Wkv"], kv_raw, M=M, N=2 * DIM_HEAD, K=D)      # K/V from the un-normalised residual (:228)
+        q = torch.empty(M, H * DIM_HEAD, dtype=T, device=dev)
+        k = torch.empty(M, DIM_HEAD, dtype=T, device=dev)
+        v = torch.empty(M, DIM_HEAD, dtype=T, device=dev)
+        ops.qk_norm_fwd(q_raw, kv_raw, attn.q_scale.detach(), attn.k_scale.detach(), q, k, v, H)
+        o = torch.empty(M, H * DIM_HEAD, dtype=T, device=dev)
+        lse = torch.empty(B, H, N, device=dev)
+        ops.attn_fwd(q, k, v, table, keymask, o, lse, B, N, H, ATTN_SCALE)
+        x1 = torch.empty(M, D, device=dev)
+        ops.gemm(o, w["Wo"], x1, M=M, N=D, K=H * DIM_HEAD, Cin=x)
+        # feed-forward
+        m2 = torch.empty(M, device=dev); r2 = torch.empty(M, device=dev)
+        xn2 = torch.empty(M, D, dtype=T, device=dev)
+        ops.layernorm_fwd(x1, ff.norm_in.gamma.detach(), xn2, None, m2, r2)
+        h1 = torch.empty(M, 2 * Fp, dtype=T, device=dev)
+        ops.gemm(xn2, w["W1p"], h1, M=M, N=2 * Fp, K=D)
+        h2 = torch.empty(M, Fp, dtype=T, device=dev)
+        m3 = torch.empty(M, device=dev); r3 = torch.empty(M, device=dev)
+        p = float(ff.dropout_p) if training else 0.0
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0
+        ops.ffmid_fwd(h1, w["convw"], ff.norm_mid.gamma.detach(), h2, m3, r3, N, F, Fp, p, seed)
+        x2 = torch.empty(M, D, device=dev)
+        ops.gemm(h2, w["W2p"], x2, M=M, N=D, K=Fp, Cin=x1)
+        if save:
+            sv.x, sv.m1, sv.r1, sv.xn, sv.xc = x, m1, r1, xn, xc
+            sv.q_raw, sv.kv_raw, sv.q, sv.k, sv.v, sv.o, sv.lse = q_raw, kv_raw, q, k, v, o, lse
+            sv.x1, sv.m2, sv.r2, sv.xn2, sv.h1, sv.h2, sv.m3, sv.r3, sv.seed, sv.p = x1, m2, r2, xn2, h1, h2, m3, r3, seed, p
+            saved_layers.append(sv)
+        x = x2
+    mf = torch.empty(M, device=dev); rf = torch.empty(M, device=dev)
+    y = torch.empty(M, D, dtype=T, device=dev)
+    ops.layernorm_fwd(x, tr.norm.gamma.detach(), y, None, mf, rf)
+    saved = dict(layers=saved_layers, xL=x, mf=mf, rf=rf, table=table, rp=rp_saved, keymask=keymask) if save else None
+    return y, saved
+
+
+def trunk_backward(tr, pw: PreparedWeights, saved, dy: torch.Tensor, B: int, N: int, out_scale: float):
+    """dy: [M, D] fp32 gradient of the final LayerNorm output.  Accumulates parameter grads; returns
+    d(trunk input) * out_scale (fp32).  out_scale carries the grad_shrink factor (utils.py:60-61)."""
+    T = pw.T
+    dev = dy.device
+    M, D = dy.shape
+    H = tr.heads
+    table, keymask = saved["table"], saved["keymask"]
+    dtable = torch.zeros_like(table) if table is not None else None
+    nl = len(saved["layers"])
+    dres = torch.empty(M, D, device=dev)
+    dres_c = dres if T == torch.float32 else torch.empty(M, D, dtype=T, device=dev)
+    ops.layernorm_bwd(dy, saved["xL"], tr.norm.gamma.detach(), saved["mf"], saved["rf"], None, dres,
+                      None if T == torch.float32 else dres_c, grad_of(tr.norm.gamma),
+                      dx_scale=out_scale if nl == 0 else 1.0)
+    ws = None
+    for li in range(nl - 1, -1, -1):
+        attn, _, ff = tr.layers[li]
+        w, sv = pw.layers[li], saved["layers"][li]
+        F, Fp = w["F"], w["Fp"]
+        # ---- feed-forward block: x2 = x1 + h2 W2^T ----
+        dh2 = torch.empty(M, Fp, dtype=T, device=dev)
+        ops.gemm(dres_c, w["W2p"], dh2, M=M, N=Fp, K=D, b_kmajor=True)
+        gW2 = grad_of(ff.w_out.weight)                                              # [D, F]
+        ops.gemm(dres_c, sv.h2, gW2, M=D, N=F, K=M, a_kmajor=True, b_kmajor=True, Cin=gW2)
+        if ws is None or ws.numel() < ops.ffmid_bwd_workspace_floats(F, Fp):
+            ws = torch.empty(ops.ffmid_bwd_workspace_floats(F, Fp), device=dev)
+        du = torch.empty(M, 2 * Fp, dtype=T, device=dev)
+        dh1 = torch.empty(M, 2 * Fp, dtype=T, device=dev)
+        gconv = grad_of(ff.conv_param()).view(-1) if ff.conv_param() is not None else None
+        ops.ffmid_bwd(dh2, sv.h1, w["convw"], ff.norm_mid.gamma.detach(), sv.m3, sv.r3, du, dh1,
+                      grad_of(ff.norm_mid.gamma), gconv, ws, N, F, Fp, sv.p, sv.seed)
+        del du, dh2
+        dxn2 = torch.empty(M, D, device=dev)
+        ops.gemm(dh1, w["W1p"], dxn2, M=M, N=D, K=2 * Fp, b_kmajor=True)
+        gW1 = grad_of(ff.w_in.weight)                                               # [2F, D]
+        ops.gemm(dh1, sv.xn2, gW1, M=2 * Fp, N=D, K=M, a_kmajor=True, b_kmajor=True, Cin=gW1, c_map=w["dW1_cmap"])
+        del dh1
+        dx1 = torch.empty(M, D, device=dev)
+        dx1_c = dx1 if T == torch.float32 else torch.empty(M, D, dtype=T, device=dev)
+        ops.layernorm_bwd(dxn2, sv.x1, ff.norm_in.gamma.detach(), sv.m2, sv.r2, dres, dx1,
+                          None if T == torch.float32 else dx1_c, grad_of(ff.norm_in.gamma))
+        # ---- attention block: x1 = x + o Wo^T ----
+        do = torch.empty(M, H * DIM_HEAD, dtype=T, device=dev)
+        ops.gemm(dx1_c, w["Wo"], do, M=M, N=H * DIM_HEAD, K=D, b_kmajor=True)
+        gWo = grad_of(attn.to_out[0].weight)
+        ops.gemm(dx1_c, sv.o, gWo, M=D, N=H * DIM_HEAD, K=M, a_kmajor=True, b_kmajor=True, Cin=gWo)
+        dq = torch.empty(M, H * DIM_HEAD, device=dev)
+        dk = torch.empty(M, DIM_HEAD, device=dev)
+        dv = torch.empty(M, DIM_HEAD, device=dev)
+        delta = torch.empty(B, H, N, device=dev)
+        ops.attn_bwd(sv.q, sv.k, sv.v, table, keymask, sv.o, do, sv.lse, delta, dq, dk, dv, dtable, B, N, H, ATTN_SCALE)
+        dq_raw = torch.empty(M, H * DIM_HEAD, dtype=T, device=dev)
+        dkv_raw = torch.empty(M, 2 * DIM_HEAD, dtype=T, device=dev)
+        ops.qk_norm_bwd(dq, dk, dv, sv.q_raw, sv.kv_raw, attn.q_scale.detach(), attn.k_scale.detach(),
+                        dq_raw, dkv_raw, grad_of(attn.q_scale), grad_of(attn.k_scale), H)
+        dxn = torch.empty(M, D, device=dev)
+        ops.gemm(dq_raw, w["Wq"], dxn, M=M, N=D, K=H * DIM_HEAD, b_kmajor=True)
+        tmp = torch.empty(M, D, device=dev)
+        ops.gemm(dkv_raw, w["Wkv"], tmp, M=M, N=D, K=2 * DIM_HEAD, b_kmajor=True, Cin=dx1)
+        gWq = grad_of(attn.to_q.weight)
+        ops.gemm(dq_raw, sv.xn, gWq, M=H * DIM_HEAD, N=D, K=M, a_kmajor=True, b_kmajor=True, Cin=gWq)
+        gWkv = grad_of(attn.to_kv.weight)
+        ops.gemm(dkv_raw, sv.xc, gWkv, M=2 * DIM_HEAD, N=D, K=M, a_kmajor=True, b_kmajor=True, Cin=gWkv)
+        dres = torch.empty(M, D, device=dev)
+        dres_c = dres if T == torch.float32 else torch.empty(M, D, dtype=T, device=dev)
+        last = li == 0
+        ops.layernorm_bwd(dxn, sv.x, attn.norm.gamma.detach(), sv.m1, sv.r1, tmp, dres,
+                          None if (T == torch.float32 or last) else dres_c, grad_of(attn.norm.gamma),
+                          dx_scale=out_scale if last else 1.0)
+    if dtable is not None and saved["rp"] is not None:
+        relpos_backward(tr, N, saved["rp"], dtable)
+    return dres
+
+
+# ------------------------------------------------------------------------------------------------------
+# embedding gather, logit heads, loss
+# ------------------------------------------------------------------------------------------------------
+def build_ids(model, all_token_ids: Sequence[torch.Tensor]) -> Tuple[torch.Tensor, List[int]]:
+    """open_musiclm.py:116-130 + get_embeds (utils.py:133-134): flatten, add per-quantizer offsets, mark pads
+    (id == -1 AFTER the offset add, exactly like the reference) and put the start-token marker (-2) in front."""
+    parts, lens = [], []
+    for seq, ids in zip(model.token_sequences, all_token_ids):
+        ids = ids.reshape(ids.shape[0], -1)
+        if seq.num_quantizers > 1:
+            off = seq.codebook_size * (torch.arange(ids.shape[-1], device=ids.device) % seq.num_quantizers)
+            ids = ids + off
+        lens.append(ids.shape[-1])
+        parts += [torch.full((ids.shape[0], 1), -2, device=ids.device, dtype=torch.int32), ids.to(torch.int32)]
+    return torch.cat(parts, dim=1).contiguous(), lens
+
+
+def get_layout(model, B: int, lens: Sequence[int], device, final_rows_only: bool) -> SeqLayout:
+    cache = model.__dict__.setdefault("_omlm_layouts", {})
+    key = (B, tuple(lens), str(device), final_rows_only)
+    if key not in cache:
+        if len(cache) > 64:
+            cache.clear()
+        cache[key] = build_layout(B, lens, [s.num_quantizers for s in model.token_sequences], device, final_rows_only)
+    return cache[key]
+
+
+def embed_forward(model, ids32: torch.Tensor, lay: SeqLayout) -> torch.Tensor:
+    B, N = ids32.shape
+    D = model.dim
+    x = torch.empty(B * N, D, device=ids32.device)
+    pos = [e.weight.detach() for e in model.absolute_position_embeddings] if model.use_absolute_position_embeddings else None
+    ops.embed_fwd(ids32, lay.seg, lay.posidx, [e.weight.detach() for e in model.embeddings],
+                  [s.detach() for s in model.start_tokens], pos, x.view(B, N, D))
+    return x
+
+
+def embed_backward(model, ids32: torch.Tensor, lay: SeqLayout, dx: torch.Tensor, alpha: float):
+    B, N = ids32.shape
+    dpos = [grad_of(e.weight) for e in model.absolute_position_embeddings] if model.use_absolute_position_embeddings else None
+    ops.embed_bwd(ids32, lay.seg, lay.posidx, [grad_of(e.weight) for e in model.embeddings],
+                  [grad_of(s) for s in model.start_tokens], dpos, dx.view(B, N, -1), alpha)
+
+
+def heads_forward(model, pw: PreparedWeights, y: torch.Tensor, lay: SeqLayout, want: Sequence[bool]):
+    """y: [B*N, D] operand dtype.  Returns per sequence a padded fp32 logits buffer [B*n_s, ldV] or None.
+    (einsum 'q c d, b n q d -> b n q c' incl. the remainder positions, open_musiclm.py:163-186: the hidden
+    position j of a sequence is scored by quantizer head j mod Q.)"""
+    D = model.dim
+    out = []
+    for s, seq in enumerate(model.token_sequences):
+        if not want[s]:
+            out.append(None)
+            continue
+        V1 = seq.codebook_size + 1
+        ldV = ceil_to(V1, 8)
+        n_s = lay.n_out[s]
+        buf = torch.zeros(lay.B if lay.final_only else lay.B * n_s, ldV, device=y.device)
+        for qq in range(seq.num_quantizers):
+            ent = lay.head_maps.get((s, qq))
+            if ent is None:
+                continue
+            a_map, c_map, rows = ent
+            ops.gemm(y, pw.heads[s][qq], buf, M=rows, N=V1, K=D, a_map=a_map, c_map=c_map, ldc=ldV,
+                     a_rows=y.shape[0], b_rows=V1)
+        out.append(buf)
+    return out
+
+
+def heads_backward(model, pw: PreparedWeights, y: torch.Tensor, lay: SeqLayout, dlogits: Sequence[Optional[torch.Tensor]]):
+    """dlogits[s]: [B*n_s, ldV] in the operand dtype with zeroed pad columns, or None.  Returns dy fp32 [B*N, D]."""
+    D = model.dim
+    dy = torch.zeros(y.shape[0], D, device=y.device)
+    for s, seq in enumerate(model.token_sequences):
+        dl = dlogits[s]
+        if dl is None:
+            continue
+        V1 = seq.codebook_size + 1
+        ldV = dl.shape[-1]
+        gW = grad_of(model.logit_weights[s])                                   # [Q, V1, D]
+        for qq in range(seq.num_quantizers):
+            ent = lay.head_maps.get((s, qq))
+            if ent is None:
+                continue
+            a_map, c_map, rows = ent
+            # dy[rows] = dlogits[rows] @ W_q          (each hidden row belongs to exactly one head)
+            ops.gemm(dl, pw.heads[s][qq], dy, M=rows, N=D, K=ldV, b_kmajor=True, a_map=c_map, c_map=a_map,
+                     a_rows=dl.shape[0], b_rows=V1)
+            # dW_q += dlogits[rows]^T @ y[rows]
+            ops.gemm(dl, y, gW[qq], M=V1, N=D, K=rows, a_kmajor=True, b_kmajor=True, a_map=c_map, b_map=a_map,
+                     Cin=gW[qq], lda=ldV, a_rows=dl.shape[0], b_rows=y.shape[0])
+    return dy
+
+
+class ForwardState:
+    """Everything one forward leaves behind for its backward."""
+    __slots__ = ("model", "pw", "ids32", "lay", "trunk", "y", "B", "N", "logits", "labels", "lse_rows", "coefs")
+
+
+def run_forward(model, all_token_ids, self_attn_mask, only_final: bool, save: bool, precision: str,
+                want: Optional[Sequence[bool]] = None, final_rows_only: bool = False):
+    tr = model.transformer
+    if tr.non_causal_prefix_size != 0:
+        raise NotImplementedError("non_causal_prefix_size > 0 is not supported by the MI355X attention kernel "
+                                  "(every shipped config uses 0)")
+    require_gpu(model.start_tokens[0], "model parameters")
+    ids32, lens = build_ids(model, all_token_ids)
+    require_gpu(ids32, "token ids")
+    B, N = ids32.shape
+    lay = get_layout(model, B, lens, ids32.device, final_rows_only)
+    pw = prepared_weights(model, precision) if not save else PreparedWeights(model, precision)
+    keymask = None
+    if self_attn_mask is not None:
+        assert self_attn_mask.shape == (B, N), f"self_attn_mask must be [{B}, {N}]"
+        keymask = self_attn_mask.to(torch.uint8).contiguous()
+    x = embed_forward(model, ids32, lay)
+    y, tsaved = trunk_forward(tr, pw, x, keymask, B, N, save, model.training)
+    nseq = len(model.token_sequences)
+    if want is None:
+        want = [(not only_final) or s == nseq - 1 for s in range(nseq)]
+    logits = heads_forward(model, pw, y, lay, want)
+    st = None
+    if save:
+        st = ForwardState()
+        st.model, st.pw, st.ids32, st.lay, st.trunk, st.y, st.B, st.N, st.logits = model, pw, ids32, lay, tsaved, y, B, N, logits
+    return logits, lay, st
+
+
+def run_backward(st: ForwardState, dlogits: Sequence[Optional[torch.Tensor]]):
+    model = st.model
+    dy = heads_backward(model, st.pw, st.y, st.lay, dlogits)
+    alpha = float(model.transformer.grad_shrink_alpha)
+    dx = trunk_backward(model.transformer, st.pw, st.trunk, dy, st.B, st.N, out_scale=alpha)
+    embed_backward(model, st.ids32, st.lay, dx, 1.0)
+
+
+def logits_views(model, lay: SeqLayout, bufs):
+    out = []
+    for s, (seq, buf) in enumerate(zip(model.token_sequences, bufs)):
+        if buf is None:
+            out.append(None)
+        else:
+            out.append(buf.view(lay.B, -1, buf.shape[-1])[:, :, : seq.codebook_size + 1])
+    return out
+
+
+class LogitsFunction(torch.autograd.Function):
+    """TokenConditionedTransformer.forward as one autograd node (open_musiclm.py:100-190)."""
+
+    @staticmethod
+    def forward(ctx, model, all_token_ids, self_attn_mask, only_final, precision, *params):
+        bufs, lay, st = run_forward(model, all_token_ids, self_attn_mask, only_final, True, precision)
+        ctx.st = st
+        ctx.nparams = len(params)
+        views = logits_views(model, lay, bufs)
+        ctx.present = [v is not None for v in views]
+        return tuple(v for v in views if v is not None)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        st = ctx.st
+        T = st.pw.T
+        gi = iter(grads)
+        dl = []
+        for s, (seq, present) in enumerate(zip(st.model.token_sequences, ctx.present)):
+            g = next(gi) if present else None
+            if g is None:
+                dl.append(None)
+                continue
+            V1 = seq.codebook_size + 1
+            ldV = ceil_to(V1, 8)
+            g2 = g.reshape(-1, V1).to(torch.float32).contiguous()
+            d = torch.empty(g2.shape[0], ldV, dtype=T, device=g2.device)
+            ops.cast_pad(g2, d, g2.shape[0], V1, V1, ldV)
+            dl.append(d)
+        run_backward(st, dl)
+        ctx.st = None
+        return (None,) * (5 + ctx.nparams)
+
+
+class LossFunction(torch.autograd.Function):
+    """Wrapper.forward(return_loss=True) (open_musiclm.py:378-410) fused: logits + cross entropy.
+
+    Returns (loss, *logits) with the logits marked non-differentiable; the backward regenerates
+    softmax - onehot from the saved logits / row lse directly in the GEMM operand dtype."""
+
+    @staticmethod
+    def forward(ctx, model, all_token_ids, labels, self_attn_mask, loss_weights, precision, *params):
+        nseq = len(model.token_sequences)
+        bufs, lay, st = run_forward(model, all_token_ids, self_attn_mask, False, True, precision,
+                                    want=[True] * nseq)
+        dev = bufs[-1].device
+        total = 0
+        nll = torch.zeros(nseq, device=dev)
+        st.labels, st.lse_rows, st.coefs = [], [], []
+        for s, (seq, buf, lb, w) in enumerate(zip(model.token_sequences, bufs, labels, loss_weights)):
+            if w > 0:
+                lb32 = lb.reshape(-1).to(torch.int32).contiguous()
+                assert lb32.numel() == buf.shape[0], (lb32.numel(), buf.shape)
+                lse_rows = torch.empty(buf.shape[0], device=dev)
+                ops.ce_fwd(buf, lb32, lse_rows, nll[s:s + 1], seq.codebook_size + 1)
+                total += lb32.numel()
+                st.labels.append(lb32); st.lse_rows.append(lse_rows)
+            else:
+                st.labels.append(None); st.lse_rows.append(None)
+        # loss = sum_s w_s * nll_sum_s / total   (== sum_s mean_s * n_s * w_s / sum n_s, :407-410)
+        wt = torch.tensor([float(w) if w > 0 else 0.0 for w in loss_weights], device=dev)
+        loss = (nll * wt).sum() / float(total)
+        st.coefs = [float(w) / float(total) if w > 0 else 0.0 for w in loss_weights]
+        ctx.st = st
+        ctx.nparams = len(params)
+        views = logits_views(model, lay, bufs)
+        ctx.mark_non_differentiable(*views)
+        return (loss, *views)
+
+    @staticmethod
+    def backward(ctx, gloss, *unused):
+        st = ctx.st
+        T = st.pw.T
+        g = gloss.reshape(1).to(torch.float32).contiguous()
+        dl = []
+        for s, seq in enumerate(st.model.token_sequences):
+            if st.labels[s] is None:
+                dl.append(None)
+                continue
+            buf = st.logits[s]
+            d = torch.empty(buf.shape[0], buf.shape[1], dtype=T, device=buf.device)
+            ops.ce_bwd(buf, st.labels[s], st.lse_rows[s], g, st.coefs[s], d, seq.codebook_size + 1)
+            dl.append(d)
+        run_backward(st, dl)
+        ctx.st = None
+        return (None,) * (6 + ctx.nparams)

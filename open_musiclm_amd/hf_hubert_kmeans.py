@@ -1,0 +1,72 @@
+"""HfHubertWithKmeans (reference open_musiclm/hf_hubert_kmeans.py).  The MERT/HuBERT feature extractor is a
+pretrained third-party network outside the hot path; the k-means ASSIGN step (:87, sklearn predict) runs as a
+HIP nearest-centroid kernel, bit-exact against oracle.kmeans_assign."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import ops
+from .utils import exists
+
+
+class KmeansAssigner(nn.Module):
+    def __init__(self, centroids: torch.Tensor):
+        super().__init__()
+        self.register_buffer("centroids", centroids.float().contiguous())          # [C, D]
+        self._cT = None
+
+    @property
+    def codebook_size(self):
+        return self.centroids.shape[0]
+
+    @torch.no_grad()
+    def predict(self, feats: torch.Tensor) -> torch.Tensor:
+        """feats [n, D] fp32 (cuda) -> cluster ids [n] int64."""
+        if self._cT is None or self._cT.device != self.centroids.device:
+            self._cT = self.centroids.t().contiguous()                              # [D, C]
+        feats = feats.contiguous().float()
+        idx = torch.empty(feats.shape[0], 1, dtype=torch.int32, device=feats.device)
+        ops.rvq_encode(feats, self._cT, idx, None, feats.shape[0], feats.shape[1], self.centroids.shape[0], 1)
+        return idx[:, 0].long()
+
+
+class HfHubertWithKmeans(nn.Module):
+    def __init__(self, *, hubert=None, kmeans=None, embed_layer=7, target_sample_hz=16000, seq_len_multiple_of=None,
+                 normalize_embeds=True, codebook_size: int = 1024, output_hz: int = 50):
+        super().__init__()
+        self.target_sample_hz, self.output_hz = target_sample_hz, output_hz
+        self.embed_layer, self.normalize_embeds = embed_layer, normalize_embeds
+        self.seq_len_multiple_of = seq_len_multiple_of
+        self.codebook_size = codebook_size
+        self.hubert = hubert
+        self.kmeans = None
+        if exists(kmeans):
+            centers = torch.as_tensor(getattr(kmeans, "cluster_centers_", kmeans))
+            self.kmeans = KmeansAssigner(centers)
+            self.codebook_size = self.kmeans.codebook_size
+
+    @torch.no_grad()
+    def assign(self, embed: torch.Tensor) -> torch.Tensor:
+        """embed [B, T, D] -> ids [B, T] (hf_hubert_kmeans.py:78-94 minus the feature extractor)."""
+        from .utils import zero_mean_unit_var_norm
+        if self.normalize_embeds:
+            embed = zero_mean_unit_var_norm(embed)
+        b, t, d = embed.shape
+        return self.kmeans.predict(embed.reshape(b * t, d)).reshape(b, t)
+
+    def forward(self, wav_input, flatten=True, return_embed=False, input_sample_hz=None):
+        if not exists(self.hubert):
+            raise RuntimeError("HfHubertWithKmeans was built without the MERT/HuBERT feature extractor (pretrained weights are "
+                               "outside the MI355X hot path); use .assign(features) or supply semantic_token_ids")
+        raise NotImplementedError("audio feature extraction is outside the MI355X hot path")
+
+
+def get_hubert_kmeans(model_name: str = "m-a-p/MERT-v0", kmeans_path: Optional[str] = None, **kwargs):
+    kmeans = None
+    if exists(kmeans_path):
+        import joblib
+        kmeans = joblib.load(kmeans_path)
+    return HfHubertWithKmeans(hubert=None, kmeans=kmeans, **kwargs)

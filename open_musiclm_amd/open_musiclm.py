@@ -1,0 +1,553 @@
+"""TokenConditionedTransformer, its training / sampling wrapper, the three stages and MusicLM, with the
+reference's public API (reference open_musiclm/open_musiclm.py) on top of the MI355X engine.
+
+Host responsibilities kept here (all on tiny integer tensors): eos append, label construction, key-mask
+construction incl. the forgetful mask, loss weighting bookkeeping, the AR sampling loop and the
+sliding-window hierarchical decode.  Everything floating point goes through ``engine`` -> libomlm_hip.so.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+from tqdm import tqdm
+
+from . import engine, ops
+from .transformer import Transformer
+from .utils import (append_eos_id, batch_unique_consecutive, beartype_jit, default, eval_decorator, exists,
+                    float32_to_int16, generate_mask_with_prob, int16_to_float32, mask_out_after_eos_id)
+
+
+@dataclass
+class TokenSequenceInfo():
+    """open_musiclm.py:23-30"""
+    codebook_size: int
+    num_quantizers: int
+    unique_consecutive: bool
+
+
+def _flat(t: torch.Tensor) -> torch.Tensor:
+    return t.reshape(t.shape[0], -1)
+
+
+class TokenConditionedTransformer(nn.Module):
+    """open_musiclm.py:33-215.  Parameters and state_dict keys are identical to the reference:
+    start_tokens.{i}, logit_weights.{i}, embeddings.{i}.weight, [absolute_position_embeddings.{i}.weight],
+    transformer.*"""
+
+    def __init__(self, *, token_sequences: List[TokenSequenceInfo], dim, depth, heads=8, attn_dropout=0.,
+                 ff_dropout=0.1, has_condition=False, cond_as_self_attn_prefix=False, cond_drop_prob=0.5,
+                 grad_shrink_alpha=0.1, use_absolute_position_embeddings=False,
+                 max_absolute_position_embeddings=262, precision: Optional[str] = None, **kwargs):
+        super().__init__()
+        if len(token_sequences) > 4:
+            raise ValueError("at most 4 token sequences are supported by the fused gather kernel")
+        self.token_sequences = token_sequences
+        self.dim = dim
+        self.has_condition = has_condition
+        self.cond_drop_prob = cond_drop_prob
+        self.use_absolute_position_embeddings = use_absolute_position_embeddings
+        self.precision = precision            # None -> engine.default_precision() ($OMLM_PRECISION, default bf16)
+
+        self.start_tokens = torch.nn.ParameterList()
+        self.logit_weights = torch.nn.ParameterList()
+        self.embeddings = torch.nn.ModuleList()
+        self.absolute_position_embeddings = torch.nn.ModuleList() if use_absolute_position_embeddings else None
+        self.eos_ids = []
+        for sequence in token_sequences:
+            self.start_tokens.append(nn.Parameter(torch.randn(dim)))
+            self.eos_ids.append(sequence.codebook_size)
+            rows = sequence.codebook_size + 1
+            self.embeddings.append(nn.Embedding(rows * sequence.num_quantizers, dim))
+            self.logit_weights.append(nn.Parameter(torch.randn(sequence.num_quantizers, rows, dim)))
+            if use_absolute_position_embeddings:
+                self.absolute_position_embeddings.append(nn.Embedding(max_absolute_position_embeddings, dim))
+
+        self.transformer = Transformer(dim=dim, depth=depth, heads=heads, attn_dropout=attn_dropout,
+                                       ff_dropout=ff_dropout,
+                                       cross_attend=has_condition and not cond_as_self_attn_prefix,
+                                       cond_as_self_attn_prefix=cond_as_self_attn_prefix,
+                                       grad_shrink_alpha=grad_shrink_alpha, **kwargs)
+        self.transformer.__dict__["_omlm_owner"] = self
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def _precision(self) -> str:
+        return self.precision or engine.default_precision()
+
+    def forward(self, *, all_token_ids: List[torch.Tensor], self_attn_mask=None, cond_drop_prob=None,
+                return_only_final_seq_logits=False):
+        """Returns one [B, n_i, codebook_size+1] fp32 logits tensor per sequence (None for skipped ones).
+        cond_drop_prob is accepted and ignored exactly like the reference (no text conditioning)."""
+        assert len(all_token_ids) == len(self.token_sequences) == len(self.embeddings)
+        ids = [_flat(t).to(self.device) for t in all_token_ids]
+        prec = self._precision()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            outs = engine.LogitsFunction.apply(self, ids, self_attn_mask, bool(return_only_final_seq_logits), prec,
+                                               *self.parameters())
+            it = iter(outs)
+            n = len(self.token_sequences)
+            return [next(it) if (not return_only_final_seq_logits or s == n - 1) else None for s in range(n)]
+        bufs, lay, _ = engine.run_forward(self, ids, self_attn_mask, bool(return_only_final_seq_logits), False, prec)
+        return engine.logits_views(self, lay, bufs)
+
+    def forward_with_cond_scale(self, *args, cond_scale=3, **kwargs):
+        """open_musiclm.py:192-215: a no-op around forward() without text conditioning."""
+        logits = self.forward(*args, cond_drop_prob=0., **kwargs)
+        if cond_scale == 1 or not self.has_condition:
+            return logits
+        null_logits = self.forward(*args, cond_drop_prob=1., **kwargs)
+        return [None if a is None else b + (a - b) * cond_scale for a, b in zip(logits, null_logits)]
+
+    # ---- fast paths used by the wrapper ---------------------------------------------------------------
+    def last_logits(self, ids: List[torch.Tensor]) -> torch.Tensor:
+        """[B, ldV] logits of the final position of the final sequence only (AR decode step, no autograd)."""
+        bufs, _, _ = engine.run_forward(self, ids, None, True, False, self._precision(), final_rows_only=True)
+        return bufs[-1]
+
+    def loss_and_logits(self, ids, labels, self_attn_mask, loss_weights):
+        return engine.LossFunction.apply(self, ids, labels, self_attn_mask, tuple(loss_weights), self._precision(),
+                                         *self.parameters())
+
+
+@beartype_jit
+class TokenConditionedTransformerWrapper(nn.Module):
+    """open_musiclm.py:219-410."""
+
+    def __init__(self, *, transformer: TokenConditionedTransformer, pad_id=-1, unique_consecutive=True,
+                 cross_entropy_loss_weights: Optional[List[float]] = None, mask_prob=0.15):
+        super().__init__()
+        self.transformer = transformer
+        self.token_sequences = transformer.token_sequences
+        self.unique_consecutive = unique_consecutive
+        self.pad_id = pad_id
+        self.cross_entropy_loss_weights = default(cross_entropy_loss_weights, [1 for _ in self.token_sequences])
+        self.eos_ids = transformer.eos_ids
+        self.mask_prob = mask_prob
+        assert len(self.token_sequences) == len(self.eos_ids) == len(self.cross_entropy_loss_weights)
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    @eval_decorator
+    @torch.no_grad()
+    def generate(self, *, conditioning_token_ids: List[torch.Tensor], pred_token_ids: Optional[torch.Tensor] = None,
+                 max_time_steps=512, filter_thres=0.9, temperature=1., include_eos_in_output=False,
+                 append_eos_to_conditioning_tokens=True, allow_eos_in_output=False, uniforms=None, **kwargs):
+        """AR sampling (open_musiclm.py:253-326).  Every step re-runs the full causal forward over the grown
+        sequence like the reference (results are identical to a KV-cached decode because the stack is strictly
+        causal); only the last position's logits are formed, and eos suppression + top-k + Gumbel-argmax run in
+        one sampler kernel.  ``uniforms`` ([steps, B, V+1]) injects the uniform draws (tests)."""
+        assert len(conditioning_token_ids) == len(self.token_sequences) - 1
+        batch, device = conditioning_token_ids[0].shape[0], self.device
+        cond = [t.to(device) for t in conditioning_token_ids]
+        if exists(pred_token_ids):
+            assert pred_token_ids.shape[0] == batch
+            first_step = pred_token_ids.shape[1]
+            sampled = _flat(pred_token_ids).to(device).long()
+        else:
+            first_step = 0
+            sampled = torch.empty((batch, 0), device=device, dtype=torch.long)
+        pred_info, pred_eos_id = self.token_sequences[-1], self.eos_ids[-1]
+
+        for i, info in enumerate(self.token_sequences[:-1]):
+            if info.unique_consecutive:
+                cond[i] = batch_unique_consecutive(cond[i], pad_value=self.pad_id)
+        if pred_info.unique_consecutive:
+            sampled = batch_unique_consecutive(sampled, pad_value=self.pad_id)
+        if append_eos_to_conditioning_tokens:
+            cond = [append_eos_id(_flat(t).long(), e) for t, e in zip(cond, self.eos_ids)]
+
+        V1 = pred_info.codebook_size + 1
+        k = max(int((1 - filter_thres) * V1), 1)
+        Q = pred_info.num_quantizers
+        step = 0
+        nxt = torch.empty(batch, device=device, dtype=torch.long)
+        for _t in tqdm(range(first_step, max_time_steps), desc='generating predicted tokens'):
+            for ind in range(Q):
+                last = self.transformer.last_logits(cond + [sampled])
+                forbid = (not allow_eos_in_output) or (ind != Q - 1)
+                u = uniforms[step].to(device).float().contiguous() if exists(uniforms) \
+                    else torch.empty(batch, V1, device=device).uniform_(0, 1)
+                ops.sample_topk_gumbel(last, u, nxt, V1, k, temperature, forbid)
+                sampled = torch.cat((sampled, nxt[:, None]), dim=-1)
+                step += 1
+        sampled = mask_out_after_eos_id(sampled, pred_eos_id, keep_eos=include_eos_in_output)
+        return sampled.reshape(batch, -1, Q)
+
+    def _prepare(self, all_token_ids, return_loss, input_has_eos):
+        """eos append, labels, last-token drop, key mask (open_musiclm.py:340-376)."""
+        batch, device = all_token_ids[0].shape[0], self.device
+        ids = [_flat(t).to(device).long() for t in all_token_ids]
+        if self.training:
+            assert not input_has_eos, "train sequences (from clap, wav2vec, etc.) shouldn't come with an eos token"
+        if not input_has_eos:
+            ids = [append_eos_id(t, e) for t, e in zip(ids, self.eos_ids)]
+        if self.unique_consecutive:
+            for i, info in enumerate(self.token_sequences):
+                if info.unique_consecutive:
+                    ids[i] = batch_unique_consecutive(ids[i], pad_value=self.pad_id)
+        labels = None
+        if return_loss:
+            labels = [t.clone() for t in ids]
+            ids[-1] = ids[-1][:, :-1]
+        pieces = []
+        for i in range(len(ids) - 1):
+            live = (ids[i] != self.pad_id) & (ids[i] != self.eos_ids[i])
+            ids[i] = ids[i].masked_fill(~live, 0)
+            pieces.append(F.pad(live, (1, 0), value=True))            # the sequence's start token is always attended
+        mask = torch.cat(pieces, dim=-1) if pieces else torch.empty((batch, 0), device=device, dtype=torch.bool)
+        mask = F.pad(mask, (0, ids[-1].shape[-1] + 1), value=True)   # predicted tokens + their start token
+        if self.mask_prob > 0 and self.training:
+            mask = mask & generate_mask_with_prob(mask.shape, self.mask_prob, device=mask.device)
+        return ids, labels, mask
+
+    def forward(self, *, all_token_ids: List[torch.Tensor], return_loss: bool = False, input_has_eos: bool = False,
+                **kwargs):
+        assert len(all_token_ids) == len(self.token_sequences)
+        ids, labels, mask = self._prepare(all_token_ids, return_loss, input_has_eos)
+        if not return_loss:
+            return self.transformer(all_token_ids=ids, self_attn_mask=mask, **kwargs)
+        weights = []
+        for info, w in zip(self.token_sequences, self.cross_entropy_loss_weights):
+            if info.unique_consecutive and self.unique_consecutive and w > 0:
+                raise NotImplementedError("unique_consecutive sequences (padded labels) are not supported in the fused loss")
+            weights.append(float(w))
+        if torch.is_grad_enabled():
+            loss, *logits = self.transformer.loss_and_logits(ids, labels, mask, weights)
+        else:
+            with torch.enable_grad():
+                loss, *logits = self.transformer.loss_and_logits(ids, labels, mask, weights)
+            loss = loss.detach()
+        all_logits = [l.transpose(1, 2) for l in logits]               # 'b n c -> b c n' (:389)
+        return loss, all_logits, labels
+
+
+def create_semantic_transformer(dim=1024, depth=6, clap_codebook_size=1024, semantic_codebook_size=1024,
+                                num_clap_quantizers=12, **kwargs):
+    """open_musiclm.py:414-428"""
+    seqs = [TokenSequenceInfo(clap_codebook_size, num_clap_quantizers, False),
+            TokenSequenceInfo(semantic_codebook_size, 1, False)]
+    return TokenConditionedTransformer(token_sequences=seqs, dim=dim, depth=depth, **kwargs)
+
+
+def create_coarse_transformer(dim=512, depth=6, clap_codebook_size=1024, semantic_codebook_size=1024,
+                              acoustic_codebook_size=1024, num_clap_quantizers=12, num_coarse_quantizers=4, **kwargs):
+    """open_musiclm.py:432-450"""
+    seqs = [TokenSequenceInfo(clap_codebook_size, num_clap_quantizers, False),
+            TokenSequenceInfo(semantic_codebook_size, 1, False),
+            TokenSequenceInfo(acoustic_codebook_size, num_coarse_quantizers, False)]
+    return TokenConditionedTransformer(token_sequences=seqs, dim=dim, depth=depth, **kwargs)
+
+
+def create_fine_transformer(dim=512, depth=6, clap_codebook_size=1024, acoustic_codebook_size=1024,
+                            num_clap_quantizers=12, num_coarse_quantizers=4, num_fine_quantizers=8, **kwargs):
+    """open_musiclm.py:454-472"""
+    seqs = [TokenSequenceInfo(clap_codebook_size, num_clap_quantizers, False),
+            TokenSequenceInfo(acoustic_codebook_size, num_coarse_quantizers, False),
+            TokenSequenceInfo(acoustic_codebook_size, num_fine_quantizers, False)]
+    return TokenConditionedTransformer(token_sequences=seqs, dim=dim, depth=depth, **kwargs)
+
+
+def get_or_compute_clap_token_ids(clap_token_ids, clap, conditioning_audio, conditioning_text):
+    """open_musiclm.py:476-485"""
+    if not exists(clap_token_ids):
+        assert exists(conditioning_audio) ^ exists(conditioning_text), "either condition on text or audio"
+        assert exists(clap)
+        clap_token_ids = clap(text_input=conditioning_text) if exists(conditioning_text) else clap(audio_input=conditioning_audio)
+    return clap_token_ids
+
+
+def get_or_compute_semantic_token_ids(semantic_token_ids, raw_audio, wav2vec):
+    """open_musiclm.py:489-495"""
+    if not exists(semantic_token_ids):
+        assert exists(raw_audio)
+        assert exists(wav2vec)
+        semantic_token_ids = wav2vec(raw_audio, flatten=False)
+    return semantic_token_ids
+
+
+def get_or_compute_acoustic_token_ids(coarse_token_ids, fine_token_ids, raw_audio, neural_codec, num_coarse_quantizers: int):
+    """open_musiclm.py:499-510"""
+    if exists(raw_audio):
+        assert not exists(coarse_token_ids) and not exists(fine_token_ids), "either provide coarse + fine ids or raw audio"
+        assert exists(neural_codec), 'A neural audio codec must be provided if given raw wave for training'
+        with torch.no_grad():
+            neural_codec.eval()
+            _, indices, _ = neural_codec(raw_audio, return_encoded=True)
+            coarse_token_ids, fine_token_ids = indices[..., :num_coarse_quantizers], indices[..., num_coarse_quantizers:]
+    return coarse_token_ids, fine_token_ids
+
+
+class _Stage(nn.Module):
+    """Shared plumbing of SemanticStage / CoarseStage / FineStage (open_musiclm.py:514-814)."""
+
+    def _make_wrapper(self, transformer, pad_id, unique_consecutive, cross_entropy_loss_weights, mask_prob):
+        self.transformer_wrapper = TokenConditionedTransformerWrapper(
+            transformer=transformer, pad_id=pad_id, unique_consecutive=unique_consecutive,
+            cross_entropy_loss_weights=cross_entropy_loss_weights, mask_prob=mask_prob)
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def _sample(self, conditioning, pred, max_time_steps, filter_thres, temperature, include_eos_in_output,
+                append_eos_to_conditioning_tokens, **kwargs):
+        return self.transformer_wrapper.generate(
+            conditioning_token_ids=conditioning, pred_token_ids=pred, max_time_steps=max_time_steps,
+            filter_thres=filter_thres, temperature=temperature, include_eos_in_output=include_eos_in_output,
+            append_eos_to_conditioning_tokens=append_eos_to_conditioning_tokens, **kwargs)
+
+
+class SemanticStage(_Stage):
+    def __init__(self, *, semantic_transformer: TokenConditionedTransformer, wav2vec=None, clap=None, pad_id=-1,
+                 unique_consecutive=False, cross_entropy_loss_weights: List[float] = None, mask_prob=0.15):
+        super().__init__()
+        self.wav2vec, self.clap = wav2vec, clap
+        num_semantic_tokens = semantic_transformer.token_sequences[1].codebook_size
+        if exists(wav2vec):
+            assert wav2vec.codebook_size == num_semantic_tokens, \
+                f'num_semantic_tokens on SemanticTransformer must be set to {wav2vec.codebook_size}'
+        self._make_wrapper(semantic_transformer, pad_id, unique_consecutive, cross_entropy_loss_weights, mask_prob)
+
+    @eval_decorator
+    @torch.no_grad()
+    def generate(self, *, conditioning_text=None, conditioning_audio=None, input_audio=None, clap_token_ids=None,
+                 semantic_token_ids=None, filter_thres=0.9, temperature=1., max_time_steps=30 * 25,
+                 include_eos_in_output=False, append_eos_to_conditioning_tokens=True, **kwargs):
+        clap_token_ids = get_or_compute_clap_token_ids(clap_token_ids, self.clap, conditioning_audio, conditioning_text)
+        if exists(semantic_token_ids) or exists(input_audio):
+            semantic_token_ids = get_or_compute_semantic_token_ids(semantic_token_ids, input_audio, self.wav2vec)
+        else:
+            semantic_token_ids = None
+        return self._sample([clap_token_ids], semantic_token_ids, max_time_steps, filter_thres, temperature,
+                            include_eos_in_output, append_eos_to_conditioning_tokens, **kwargs)
+
+    def forward(self, *, raw_wave_for_clap=None, raw_wave_for_semantic=None, clap_token_ids=None,
+                semantic_token_ids=None, return_loss=False, **kwargs):
+        clap_token_ids = get_or_compute_clap_token_ids(clap_token_ids, self.clap, raw_wave_for_clap, conditioning_text=None)
+        semantic_token_ids = get_or_compute_semantic_token_ids(semantic_token_ids, raw_wave_for_semantic, self.wav2vec)
+        return self.transformer_wrapper.forward(all_token_ids=[clap_token_ids, semantic_token_ids],
+                                                return_loss=return_loss, **kwargs)
+
+
+class CoarseStage(_Stage):
+    def __init__(self, *, coarse_transformer: TokenConditionedTransformer, wav2vec=None, clap=None, neural_codec=None,
+                 pad_id=-1, unique_consecutive=False, cross_entropy_loss_weights: List[float] = None, mask_prob=0.15):
+        super().__init__()
+        self.wav2vec, self.clap, self.neural_codec = wav2vec, clap, neural_codec
+        num_semantic_tokens = coarse_transformer.token_sequences[1].codebook_size
+        if exists(wav2vec):
+            assert wav2vec.codebook_size == num_semantic_tokens, \
+                f'num_semantic_tokens on CoarseTransformer must be set to {wav2vec.codebook_size}'
+        self.num_coarse_quantizers = coarse_transformer.token_sequences[-1].num_quantizers
+        self._make_wrapper(coarse_transformer, pad_id, unique_consecutive, cross_entropy_loss_weights, mask_prob)
+
+    @eval_decorator
+    @torch.no_grad()
+    def generate(self, *, semantic_token_ids, coarse_token_ids=None, conditioning_text=None, conditioning_audio=None,
+                 clap_token_ids=None, filter_thres=0.9, temperature=1., max_time_steps=10 * 600,
+                 include_eos_in_output=False, append_eos_to_conditioning_tokens=True, reconstruct_wave=False, **kwargs):
+        clap_token_ids = get_or_compute_clap_token_ids(clap_token_ids, self.clap, conditioning_audio, conditioning_text)
+        sampled = self._sample([clap_token_ids, semantic_token_ids], coarse_token_ids, max_time_steps, filter_thres,
+                               temperature, include_eos_in_output, append_eos_to_conditioning_tokens, **kwargs)
+        if reconstruct_wave:
+            assert exists(self.neural_codec)
+            wave = self.neural_codec.decode_from_codebook_indices(sampled)
+            return wave.squeeze(1)
+        return sampled
+
+    def forward(self, *, raw_wave_for_clap=None, raw_wave_for_semantic=None, raw_wave_for_acoustic=None,
+                clap_token_ids=None, semantic_token_ids=None, coarse_token_ids=None, return_loss=False, **kwargs):
+        clap_token_ids = get_or_compute_clap_token_ids(clap_token_ids, self.clap, raw_wave_for_clap, conditioning_text=None)
+        semantic_token_ids = get_or_compute_semantic_token_ids(semantic_token_ids, raw_wave_for_semantic, self.wav2vec)
+        coarse_token_ids, _ = get_or_compute_acoustic_token_ids(coarse_token_ids, None, raw_wave_for_acoustic,
+                                                                self.neural_codec, self.num_coarse_quantizers)
+        return self.transformer_wrapper.forward(all_token_ids=[clap_token_ids, semantic_token_ids, coarse_token_ids],
+                                                return_loss=return_loss, **kwargs)
+
+
+class FineStage(_Stage):
+    def __init__(self, *, fine_transformer: TokenConditionedTransformer, clap=None, neural_codec=None, pad_id=-1,
+                 unique_consecutive=False, cross_entropy_loss_weights: List[float] = None, mask_prob=0.15):
+        super().__init__()
+        self.clap, self.neural_codec = clap, neural_codec
+        self.num_coarse_quantizers = fine_transformer.token_sequences[1].num_quantizers
+        self._make_wrapper(fine_transformer, pad_id, unique_consecutive, cross_entropy_loss_weights, mask_prob)
+
+    @eval_decorator
+    @torch.no_grad()
+    def generate(self, *, coarse_token_ids, fine_token_ids=None, conditioning_text=None, conditioning_audio=None,
+                 clap_token_ids=None, filter_thres=0.9, temperature=1., max_time_steps=3 * 600,
+                 include_eos_in_output=False, append_eos_to_conditioning_tokens=True, reconstruct_wave=False, **kwargs):
+        clap_token_ids = get_or_compute_clap_token_ids(clap_token_ids, self.clap, conditioning_audio, conditioning_text)
+        sampled = self._sample([clap_token_ids, coarse_token_ids], fine_token_ids, max_time_steps, filter_thres,
+                               temperature, include_eos_in_output, append_eos_to_conditioning_tokens, **kwargs)
+        if reconstruct_wave:
+            assert exists(self.neural_codec)
+            wave = self.neural_codec.decode_from_codebook_indices(torch.cat((coarse_token_ids, sampled), dim=-1))
+            return wave.squeeze(1)
+        return sampled
+
+    def forward(self, *, raw_wave_for_clap=None, raw_wave_for_acoustic=None, clap_token_ids=None,
+                coarse_token_ids=None, fine_token_ids=None, return_loss=False, **kwargs):
+        clap_token_ids = get_or_compute_clap_token_ids(clap_token_ids, self.clap, raw_wave_for_clap, conditioning_text=None)
+        coarse_token_ids, fine_token_ids = get_or_compute_acoustic_token_ids(
+            coarse_token_ids, fine_token_ids, raw_wave_for_acoustic, self.neural_codec, self.num_coarse_quantizers)
+        assert exists(coarse_token_ids) and exists(fine_token_ids)
+        return self.transformer_wrapper.forward(all_token_ids=[clap_token_ids, coarse_token_ids, fine_token_ids],
+                                                return_loss=return_loss, **kwargs)
+
+
+def _windows(t: torch.Tensor, size: int, step: int):
+    """[B, T, ...] -> list of [B, size, ...] windows at stride `step` (tensor.unfold semantics, :958-959)."""
+    n = (t.shape[1] - size) // step + 1
+    return [t[:, i * step: i * step + size] for i in range(max(n, 0))]
+
+
+class MusicLM(nn.Module):
+    """open_musiclm.py:818-1071: hierarchical semantic -> coarse -> fine sliding-window decode.
+
+    Extensions over the reference signature (all optional, defaults reproduce the reference):
+      clap_token_ids  -- bypass the CLAP text tower with pre-quantised conditioning ids (synthetic benchmarks);
+      return_tokens   -- return (semantic, coarse, fine) id tensors instead of decoding a waveform.
+    ``generate`` is an alias of ``forward``."""
+
+    def __init__(self, *, wav2vec=None, clap=None, neural_codec=None, semantic_transformer: TokenConditionedTransformer,
+                 coarse_transformer: TokenConditionedTransformer, fine_transformer: TokenConditionedTransformer):
+        super().__init__()
+        assert semantic_transformer.token_sequences[1].codebook_size == coarse_transformer.token_sequences[1].codebook_size
+        assert coarse_transformer.token_sequences[2].codebook_size == fine_transformer.token_sequences[2].codebook_size
+        assert coarse_transformer.token_sequences[2].num_quantizers == fine_transformer.token_sequences[1].num_quantizers
+        self.semantic = SemanticStage(semantic_transformer=semantic_transformer, wav2vec=wav2vec, clap=clap)
+        self.coarse = CoarseStage(coarse_transformer=coarse_transformer, wav2vec=wav2vec, clap=clap, neural_codec=neural_codec)
+        self.fine = FineStage(fine_transformer=fine_transformer, clap=clap, neural_codec=neural_codec)
+        self.wav2vec, self.clap, self.neural_codec = wav2vec, clap, neural_codec
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    @eval_decorator
+    @torch.no_grad()
+    def forward(self, *, text: Optional[List[str]] = None, prime_wave=None, prime_wave_sample_hz=None, output_seconds=8,
+                semantic_window_seconds=10, coarse_window_seconds=4, fine_window_seconds=2,
+                semantic_steps_per_second=50, acoustic_steps_per_second=75, return_coarse_generated_wave=False,
+                mask_out_generated_fine_tokens=False, semantic_sliding_window_step_percent=0.5,
+                coarse_sliding_window_step_percent=0.5, fine_sliding_window_step_percent=1,
+                clap_token_ids=None, return_tokens=False):
+        if not exists(clap_token_ids):
+            assert exists(text), 'text needs to be passed in if one of the transformer requires conditioning'
+            clap_token_ids = get_or_compute_clap_token_ids(None, self.clap, conditioning_audio=None, conditioning_text=text)
+
+        sem_hz, ac_hz = semantic_steps_per_second, acoustic_steps_per_second
+        # audio continuation (open_musiclm.py:896-926)
+        prime_coarse_all = prime_fine_all = None
+        prime_sem = prime_coarse = prime_fine = None
+        sem_adjust = coarse_adjust = fine_adjust = 0
+        if exists(prime_wave):
+            from .utils import prepare_audio
+            assert exists(prime_wave_sample_hz)
+            wave_w2v = prepare_audio(prime_wave, prime_wave_sample_hz, self.wav2vec.target_sample_hz, normalize=True,
+                                     target_length_seconds=semantic_window_seconds)
+            wave_codec = prepare_audio(prime_wave, prime_wave_sample_hz, self.neural_codec.sample_rate, normalize=False,
+                                       target_length_seconds=semantic_window_seconds)
+            c_sem = get_or_compute_semantic_token_ids(None, wave_w2v, self.wav2vec)
+            c_coarse, c_fine = get_or_compute_acoustic_token_ids(
+                None, None, wave_codec, self.neural_codec, self.coarse.transformer_wrapper.token_sequences[2].num_quantizers)
+            n_sem = int(sem_hz * semantic_window_seconds * (1 - semantic_sliding_window_step_percent))
+            n_coarse = int(ac_hz * coarse_window_seconds * (1 - coarse_sliding_window_step_percent))
+            n_fine = int(ac_hz * fine_window_seconds * (1 - fine_sliding_window_step_percent))
+            prime_coarse_all, prime_fine_all = c_coarse, c_fine
+            prime_sem = c_sem[:, -n_sem:] if c_sem.shape[1] >= n_sem else c_sem
+            prime_coarse = c_coarse[:, -n_coarse:]
+            prime_fine = c_fine[:, -n_fine:] if n_fine > 0 else None
+            sem_adjust = n_sem - int(sem_hz * coarse_window_seconds * (1 - coarse_sliding_window_step_percent))
+            coarse_adjust = n_coarse - int(ac_hz * fine_window_seconds * (1 - fine_sliding_window_step_percent))
+            fine_adjust = n_fine
+
+        # ---- semantic stage (:930-952): one window, then 50%-overlap continuation windows ----
+        sem = self.semantic.generate(clap_token_ids=clap_token_ids, semantic_token_ids=prime_sem,
+                                     max_time_steps=int(min(output_seconds, semantic_window_seconds) * sem_hz),
+                                     include_eos_in_output=False, append_eos_to_conditioning_tokens=True)
+        while sem.shape[1] < int(output_seconds * sem_hz):
+            keep = int(semantic_window_seconds * sem_hz * (1 - semantic_sliding_window_step_percent))
+            nxt = self.semantic.generate(clap_token_ids=clap_token_ids, semantic_token_ids=sem[:, -keep:],
+                                         max_time_steps=int(semantic_window_seconds * sem_hz),
+                                         include_eos_in_output=False, append_eos_to_conditioning_tokens=True)
+            sem = torch.cat([sem, nxt[:, keep:]], dim=1)
+        sem_all = sem
+        sem = sem[:, sem_adjust:]
+
+        # ---- coarse stage (:956-984): semantic windows of coarse_window*50-1 ids at 50% stride ----
+        win = int(coarse_window_seconds * sem_hz - 1)
+        coarse = None
+        for sem_win in _windows(sem, win, int(win * coarse_sliding_window_step_percent)):
+            if exists(coarse):
+                keep = int(coarse_window_seconds * ac_hz * (1 - coarse_sliding_window_step_percent))
+                cond_coarse = coarse[:, -keep:]
+            else:
+                keep, cond_coarse = 0, prime_coarse
+            pred = self.coarse.generate(clap_token_ids=clap_token_ids, semantic_token_ids=sem_win,
+                                        coarse_token_ids=cond_coarse,
+                                        max_time_steps=int(coarse_window_seconds * ac_hz), reconstruct_wave=False,
+                                        include_eos_in_output=False, append_eos_to_conditioning_tokens=True,
+                                        temperature=0.95)
+            coarse = pred if not exists(coarse) else torch.cat([coarse, pred[:, keep:]], dim=1)
+        if return_coarse_generated_wave:
+            return self.neural_codec.decode_from_codebook_indices(coarse).squeeze(1)
+        coarse = coarse[:, coarse_adjust:]
+
+        # ---- fine stage (:996-1026): non-overlapping (100% stride) coarse windows ----
+        fwin = int(fine_window_seconds * ac_hz)
+        fstep = int(fwin * fine_sliding_window_step_percent)
+        fine = None
+        for coarse_win in _windows(coarse, fwin, fstep):
+            if exists(fine):
+                keep = int(fwin * (1 - fine_sliding_window_step_percent))
+                cond_fine = fine[:, -keep:] if keep > 0 else None
+            else:
+                keep, cond_fine = 0, prime_fine
+            pred = self.fine.generate(clap_token_ids=clap_token_ids, coarse_token_ids=coarse_win, fine_token_ids=cond_fine,
+                                      max_time_steps=fwin, reconstruct_wave=False, include_eos_in_output=False,
+                                      append_eos_to_conditioning_tokens=True, temperature=0.4)
+            fine = pred if not exists(fine) else torch.cat([fine, pred[:, keep:]], dim=1)
+        fine = fine[:, fine_adjust:]
+        if exists(prime_coarse_all) and exists(prime_fine_all):
+            fine = torch.cat([prime_fine_all, fine], dim=1)
+            coarse = torch.cat([prime_coarse_all, coarse], dim=1)
+        if return_tokens:
+            return sem_all, coarse, fine
+        acoustic = torch.cat([coarse[:, : fine.shape[1]], fine], dim=-1) if coarse.shape[1] != fine.shape[1] \
+            else torch.cat([coarse, fine], dim=-1)
+        assert exists(self.neural_codec), "a neural codec is required to decode tokens to a waveform (or pass return_tokens=True)"
+        return self.neural_codec.decode_from_codebook_indices(acoustic).squeeze(1)
+
+    generate = forward
+
+    @eval_decorator
+    @torch.no_grad()
+    def generate_top_match(self, *, text: List[str], num_samples=4, num_top_matches: int = 1, **kwargs):
+        """open_musiclm.py:1039-1071: sample num_samples waves per prompt, rank by CLAP text/audio cosine similarity."""
+        try:
+            from torchaudio.functional import resample
+        except ImportError as e:  # pragma: no cover
+            raise ImportError("generate_top_match needs torchaudio to resample for CLAP") from e
+        all_samples, all_similarities = [], []
+        for prompt in text:
+            batch_text = [prompt] * num_samples
+            samples = self.forward(text=batch_text, **kwargs)
+            text_latents = self.clap(text_input=[prompt], return_embedding=True).repeat(num_samples, 1)
+            clap_input = int16_to_float32(float32_to_int16(resample(samples, self.neural_codec.sample_rate, self.clap.sample_rate)))
+            audio_latents = self.clap(audio_input=clap_input, return_embedding=True)
+            sim = F.cosine_similarity(text_latents, audio_latents, dim=-1)
+            top = sim.topk(num_top_matches, dim=0, sorted=True).indices
+            all_similarities.append(sim[top].detach().cpu())
+            all_samples.append(samples[top])
+        return all_samples, all_similarities

@@ -1,0 +1,190 @@
+"""Tensor-level wrappers over the C ABI (include/omlm.h).  No autograd, no fallbacks.
+
+dtype code convention: 0 = fp32 ("bf16x3" split for GEMM/attention operands), 1 = bf16.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import hip
+from .hip import call, ptr, stream_ptr
+
+F32, BF16 = 0, 1
+
+
+def dcode(dtype: torch.dtype) -> int:
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported operand dtype {dtype}")
+
+
+def tdtype(code: int) -> torch.dtype:
+    return torch.float32 if code == F32 else torch.bfloat16
+
+
+def _chk(t: torch.Tensor, name: str):
+    hip.require_gpu(t, name)
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+
+
+def gemm(A: torch.Tensor, B: torch.Tensor, C_: torch.Tensor, *, M: int, N: int, K: int,
+         lda: Optional[int] = None, ldb: Optional[int] = None, ldc: Optional[int] = None,
+         a_kmajor: bool = False, b_kmajor: bool = False, Cin: Optional[torch.Tensor] = None,
+         ldcin: Optional[int] = None, a_map=None, b_map=None, c_map=None, alpha: float = 1.0,
+         a_rows: Optional[int] = None, b_rows: Optional[int] = None):
+    """C[m,n] = alpha * sum_k A(m,k) B(n,k) (+ Cin).  A, B share dtype (bf16 or fp32); C is fp32 or bf16."""
+    hip.require_gpu(A, "A")
+    assert A.dtype == B.dtype, (A.dtype, B.dtype)
+    lda = lda if lda is not None else A.shape[-1]
+    ldb = ldb if ldb is not None else B.shape[-1]
+    ldc = ldc if ldc is not None else C_.shape[-1]
+    if Cin is not None:
+        assert Cin.dtype == torch.float32
+        ldcin = ldcin if ldcin is not None else Cin.shape[-1]
+    a_rows = a_rows if a_rows is not None else A.numel() // lda
+    b_rows = b_rows if b_rows is not None else B.numel() // ldb
+    call("omlm_gemm", ptr(A), ptr(B), ptr(C_), ptr(Cin), ptr(a_map), ptr(b_map), ptr(c_map),
+         a_rows, b_rows, M, N, K, lda, ldb, ldc, ldcin or 0, int(a_kmajor), int(b_kmajor),
+         dcode(A.dtype), dcode(C_.dtype), float(alpha), stream_ptr())
+
+
+def layernorm_fwd(x, gamma, y, xcast, mean, rstd, eps=1e-5):
+    M, D = x.shape
+    call("omlm_layernorm_fwd", ptr(x), ptr(gamma), ptr(y), ptr(xcast), ptr(mean), ptr(rstd),
+         M, D, y.shape[-1], float(eps), dcode(y.dtype), stream_ptr())
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dx, dxcast, dgamma, dx_scale=1.0):
+    M, D = x.shape
+    code = dcode(dxcast.dtype) if dxcast is not None else F32
+    call("omlm_layernorm_bwd", ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx),
+         ptr(dxcast), ptr(dgamma), M, D, float(dx_scale), code, stream_ptr())
+
+
+def qk_norm_fwd(q_raw, kv_raw, q_scale, k_scale, q, k, v, H):
+    call("omlm_qk_norm_fwd", ptr(q_raw), ptr(kv_raw), ptr(q_scale), ptr(k_scale), ptr(q), ptr(k), ptr(v),
+         q_raw.shape[0], H, dcode(q.dtype), stream_ptr())
+
+
+def qk_norm_bwd(dq, dk, dv, q_raw, kv_raw, q_scale, k_scale, dq_raw, dkv_raw, dq_scale, dk_scale, H):
+    call("omlm_qk_norm_bwd", ptr(dq), ptr(dk), ptr(dv), ptr(q_raw), ptr(kv_raw), ptr(q_scale), ptr(k_scale),
+         ptr(dq_raw), ptr(dkv_raw), ptr(dq_scale), ptr(dk_scale), q_raw.shape[0], H, dcode(dq_raw.dtype), stream_ptr())
+
+
+def attn_fwd(q, k, v, bias, keymask, out, lse, B, N, H, scale):
+    call("omlm_mqa_attn_fwd", ptr(q), ptr(k), ptr(v), ptr(bias), ptr(keymask), ptr(out), ptr(lse),
+         B, N, H, float(scale), bias.shape[-1] if bias is not None else 0, dcode(q.dtype), stream_ptr())
+
+
+def attn_bwd(q, k, v, bias, keymask, out, dout, lse, delta, dq, dk, dv, dbias, B, N, H, scale):
+    call("omlm_mqa_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(bias), ptr(keymask), ptr(out), ptr(dout), ptr(lse),
+         ptr(delta), ptr(dq), ptr(dk), ptr(dv), ptr(dbias), B, N, H, float(scale),
+         bias.shape[-1] if bias is not None else 0, dcode(q.dtype), stream_ptr())
+
+
+def ffmid_fwd(h1, convw, gamma, h2, mean, rstd, nseq, F, Fp, p, seed, eps=1e-5):
+    call("omlm_ffmid_fwd", ptr(h1), ptr(convw), ptr(gamma), ptr(h2), ptr(mean), ptr(rstd),
+         h1.shape[0], nseq, F, Fp, float(eps), float(p), int(seed), dcode(h1.dtype), stream_ptr())
+
+
+def ffmid_bwd_workspace_floats(F, Fp) -> int:
+    return int(hip.lib().omlm_ffmid_bwd_workspace_bytes(F, Fp)) // 4
+
+
+def ffmid_bwd(dh2, h1, convw, gamma, mean, rstd, du_tmp, dh1, dgamma, dconv, workspace, nseq, F, Fp, p, seed):
+    call("omlm_ffmid_bwd", ptr(dh2), ptr(h1), ptr(convw), ptr(gamma), ptr(mean), ptr(rstd), ptr(du_tmp), ptr(dh1),
+         ptr(dgamma), ptr(dconv), ptr(workspace), h1.shape[0], nseq, F, Fp, float(p), int(seed),
+         dcode(h1.dtype), stream_ptr())
+
+
+def _ptr_array(tensors: Sequence[Optional[torch.Tensor]]):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = ptr(t) if t is not None else None
+    return arr
+
+
+def embed_fwd(ids, seg, posidx, tables, starts, pos_tables, out):
+    B, N = ids.shape
+    D = out.shape[-1]
+    pos_arr = _ptr_array(pos_tables) if pos_tables is not None else None
+    call("omlm_embed_gather_fwd", ptr(ids), ptr(seg), ptr(posidx), _ptr_array(tables), _ptr_array(starts),
+         pos_arr, len(tables), ptr(out), B, N, D, stream_ptr())
+
+
+def embed_bwd(ids, seg, posidx, dtables, dstarts, dpos_tables, dx, alpha):
+    B, N = ids.shape
+    D = dx.shape[-1]
+    pos_arr = _ptr_array(dpos_tables) if dpos_tables is not None else None
+    call("omlm_embed_gather_bwd", ptr(ids), ptr(seg), ptr(posidx), _ptr_array(dtables), _ptr_array(dstarts),
+         pos_arr, len(dtables), ptr(dx), B, N, D, float(alpha), stream_ptr())
+
+
+def ce_fwd(logits, labels, row_lse, nll_sum, V):
+    R, ld = logits.shape
+    call("omlm_cross_entropy_fwd", ptr(logits), ptr(labels), ptr(row_lse), ptr(nll_sum), R, V, ld, stream_ptr())
+
+
+def ce_bwd(logits, labels, row_lse, gscale, coef, dlogits, V):
+    R, ld = logits.shape
+    call("omlm_cross_entropy_bwd", ptr(logits), ptr(labels), ptr(row_lse), ptr(gscale), float(coef), ptr(dlogits),
+         R, V, ld, dlogits.shape[-1], dcode(dlogits.dtype), stream_ptr())
+
+
+def sumsq_accumulate(g, out):
+    call("omlm_sumsq_accumulate", ptr(g), g.numel(), ptr(out), stream_ptr())
+
+
+def adamw_clip_step(p, g, m, v, p16, *, lr, beta1, beta2, eps, wd, step, gscale, gnorm_sq, max_norm,
+                    decoupled, zero_grad):
+    call("omlm_adamw_clip_step", ptr(p), ptr(g), ptr(m), ptr(v), ptr(p16), p.numel(), float(lr), float(beta1),
+         float(beta2), float(eps), float(wd), int(step), float(gscale), ptr(gnorm_sq), float(max_norm or 0.0),
+         int(decoupled), int(zero_grad), stream_ptr())
+
+
+def cast_pad(src, dst, R, C_, ld_src, ld_dst):
+    call("omlm_cast_pad", ptr(src), ptr(dst), R, C_, ld_src, ld_dst, dcode(dst.dtype), stream_ptr())
+
+
+def colsum_accumulate(part, out, P, C_, ldp):
+    call("omlm_colsum_accumulate", ptr(part), ptr(out), P, C_, ldp, stream_ptr())
+
+
+def relpos_first_fwd(w0, b0, pre, z, n, Hd):
+    call("omlm_relpos_first_fwd", ptr(w0), ptr(b0), ptr(pre), ptr(z), n, Hd, stream_ptr())
+
+
+def relpos_first_bwd(ds, dw0, n, Hd):
+    call("omlm_relpos_first_bwd", ptr(ds), ptr(dw0), n, Hd, stream_ptr())
+
+
+def bias_silu_fwd(a, b, pre, z, R, C_):
+    call("omlm_bias_silu_fwd", ptr(a), ptr(b), ptr(pre), ptr(z), R, C_, stream_ptr())
+
+
+def silu_bwd(dz, pre, ds, total):
+    call("omlm_silu_bwd", ptr(dz), ptr(pre), ptr(ds), total, stream_ptr())
+
+
+def bias_add(a, b, out, R, C_, ld):
+    call("omlm_bias_add", ptr(a), ptr(b), ptr(out), R, C_, ld, stream_ptr())
+
+
+def rvq_encode(x, codebooks_T, indices, residual_out, n, D, C_, nstage):
+    call("omlm_rvq_encode", ptr(x), ptr(codebooks_T), ptr(indices), ptr(residual_out), n, D, C_, nstage, stream_ptr())
+
+
+def sample_topk_gumbel(logits, uniform, out, V, k, temperature, forbid_last):
+    B, ld = logits.shape
+    call("omlm_sample_topk_gumbel", ptr(logits), ptr(uniform), ptr(out), B, V, ld, int(k), float(temperature),
+         int(forbid_last), stream_ptr())
+
+
+def probe_tr16(out):
+    call("omlm_probe_tr16", ptr(out), stream_ptr())

@@ -1,0 +1,191 @@
+"""Optimizer factory with the reference's signature (reference open_musiclm/optimizer.py:10-40) returning a
+fused MI355X implementation: parameters, gradients and both Adam moments live in FLAT fp32 buffers, so that
+
+  * backward kernels accumulate straight into the flat gradient buffer (param.grad are views of it),
+  * data parallelism needs exactly ONE all-reduce of that buffer per optimizer step,
+  * global-norm clipping + Adam/AdamW + zero_grad are two kernel launches per weight-decay group
+    (sum of squares, then the fused update) with no host synchronisation.
+
+Numerics follow torch.optim.Adam / AdamW (non-amsgrad, eps outside the bias-corrected sqrt).
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional
+
+import torch
+from torch.optim import lr_scheduler
+
+from . import ops
+
+
+def separate_weight_decayable_params(params):
+    """optimizer.py:3-8: ndim >= 2 tensors are decayed, vectors / scalars are not."""
+    wd_params = [p for p in params if p.ndim >= 2]
+    no_wd_params = [p for p in params if p.ndim < 2]
+    return wd_params, no_wd_params
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, param_groups, lr=1e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.0, decoupled=True):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, decoupled=decoupled,
+                        amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False, fused=None)
+        super().__init__(param_groups, defaults)
+        self._flat = None
+        self._t = 0
+        self._grads_clean = False
+        self._gnorm_sq = None
+        self.last_grad_norm_sq = None
+
+    # ---- flat storage --------------------------------------------------------------------------------
+    def _all_params(self) -> List[torch.Tensor]:
+        return [p for g in self.param_groups for p in g['params']]
+
+    def _flatten(self):
+        params = self._all_params()
+        dev = params[0].device
+        if dev.type != 'cuda':
+            raise RuntimeError("FusedAdam needs the parameters on the MI355X (cuda) device; there is no CPU path")
+        sizes = [p.numel() for p in params]
+        offs, tot = [], 0
+        for n in sizes:
+            offs.append(tot)
+            tot += (n + 3) // 4 * 4                     # keep every tensor 16-byte aligned inside the flat buffers
+        old = self._flat
+        P = torch.zeros(tot, device=dev)
+        G = torch.zeros(tot, device=dev)
+        M = torch.zeros(tot, device=dev)
+        V = torch.zeros(tot, device=dev)
+        for i, (p, o, n) in enumerate(zip(params, offs, sizes)):
+            P[o:o + n].copy_(p.data.reshape(-1))
+            if p.grad is not None:
+                G[o:o + n].copy_(p.grad.reshape(-1))
+            if old is not None:
+                M[o:o + n].copy_(old['M'][old['offs'][i]: old['offs'][i] + n])
+                V[o:o + n].copy_(old['V'][old['offs'][i]: old['offs'][i] + n])
+            p.data = P[o:o + n].view(p.shape)
+            p.grad = G[o:o + n].view(p.shape)
+        self._flat = dict(P=P, G=G, M=M, V=V, offs=offs, sizes=sizes, total=tot)
+        self._gnorm_sq = torch.zeros(1, device=dev)
+        # group ranges (groups are contiguous in the flat order by construction)
+        r, k = [], 0
+        for g in self.param_groups:
+            n = len(g['params'])
+            if n == 0:
+                r.append((0, 0))
+            else:
+                r.append((offs[k], offs[k + n - 1] + (sizes[k + n - 1] + 3) // 4 * 4))
+            k += n
+        self._flat['ranges'] = r
+
+    def _ensure_flat(self):
+        if self._flat is None:
+            self._flatten()
+            return
+        params = self._all_params()
+        base_p, base_g = self._flat['P'].data_ptr(), self._flat['G'].data_ptr()
+        for p, o in zip(params, self._flat['offs']):
+            if p.data_ptr() != base_p + 4 * o or p.grad is None or p.grad.data_ptr() != base_g + 4 * o:
+                self._flatten()                         # a .to() / load re-bound the storage: re-adopt it
+                return
+
+    @property
+    def flat_grad(self) -> torch.Tensor:
+        self._ensure_flat()
+        return self._flat['G']
+
+    @property
+    def flat_param(self) -> torch.Tensor:
+        self._ensure_flat()
+        return self._flat['P']
+
+    # ---- torch.optim API -------------------------------------------------------------------------------
+    def zero_grad(self, set_to_none: bool = False):
+        self._ensure_flat()
+        if not self._grads_clean:
+            self._flat['G'].zero_()
+            self._grads_clean = True
+
+    @torch.no_grad()
+    def step(self, closure=None, max_grad_norm: Optional[float] = None, grad_scale: float = 1.0):
+        """One optimizer step.  grad_scale multiplies every gradient first (1/world_size after a SUM all-reduce);
+        max_grad_norm clips by the global norm of the scaled gradients (torch clip_grad_norm_ semantics)."""
+        self._ensure_flat()
+        f = self._flat
+        self._t += 1
+        gn = None
+        if max_grad_norm is not None and max_grad_norm > 0:
+            self._gnorm_sq.zero_()
+            ops.sumsq_accumulate(f['G'], self._gnorm_sq)
+            gn = self._gnorm_sq
+        self.last_grad_norm_sq = gn
+        for g, (a, b) in zip(self.param_groups, f['ranges']):
+            if b <= a:
+                continue
+            beta1, beta2 = g['betas']
+            ops.adamw_clip_step(f['P'][a:b], f['G'][a:b], f['M'][a:b], f['V'][a:b], None, lr=g['lr'], beta1=beta1,
+                                beta2=beta2, eps=g['eps'], wd=g['weight_decay'], step=self._t, gscale=grad_scale,
+                                gnorm_sq=gn, max_norm=max_grad_norm or 0.0, decoupled=g['decoupled'], zero_grad=True)
+        self._grads_clean = True
+        for p in self._all_params():                    # the kernels wrote through raw pointers: tell autograd
+            torch._C._increment_version(p) if hasattr(torch._C, "_increment_version") else p.add_(0)
+        return None
+
+    def mark_grads_dirty(self):
+        self._grads_clean = False
+
+    def state_dict(self):
+        """torch.optim.Adam(W)-shaped state_dict so checkpoints interoperate with the reference's trainer."""
+        self._ensure_flat()
+        f = self._flat
+        state, k = {}, 0
+        groups = []
+        for g in self.param_groups:
+            idx = []
+            for _ in g['params']:
+                o, n = f['offs'][k], f['sizes'][k]
+                shape = self._all_params()[k].shape
+                state[k] = dict(step=torch.tensor(float(self._t)), exp_avg=f['M'][o:o + n].view(shape).clone(),
+                                exp_avg_sq=f['V'][o:o + n].view(shape).clone())
+                idx.append(k)
+                k += 1
+            groups.append({**{kk: vv for kk, vv in g.items() if kk != 'params'}, 'params': idx})
+        return dict(state=state if self._t > 0 else {}, param_groups=groups)
+
+    def load_state_dict(self, sd):
+        self._ensure_flat()
+        f = self._flat
+        for g, sg in zip(self.param_groups, sd['param_groups']):
+            for kk in ('lr', 'betas', 'eps', 'weight_decay'):
+                if kk in sg:
+                    g[kk] = sg[kk]
+            if 'initial_lr' in sg:
+                g['initial_lr'] = sg['initial_lr']
+        t = 0
+        for k, st in sd.get('state', {}).items():
+            k = int(k)
+            o, n = f['offs'][k], f['sizes'][k]
+            f['M'][o:o + n].copy_(st['exp_avg'].reshape(-1).to(f['M'].device))
+            f['V'][o:o + n].copy_(st['exp_avg_sq'].reshape(-1).to(f['V'].device))
+            t = max(t, int(float(st['step'])))
+        self._t = t
+
+
+def get_optimizer(params: Iterable[torch.Tensor], lr=1e-4, wd=1e-2, betas=(0.9, 0.99), eps=1e-8,
+                  filter_by_requires_grad=False, group_wd_params=True, **kwargs):
+    """optimizer.py:10-34: Adam when wd == 0, else AdamW with ndim<2 parameters exempt from decay."""
+    params = list(params)
+    if filter_by_requires_grad:
+        params = [p for p in params if p.requires_grad]
+    if wd == 0:
+        return FusedAdam([{'params': params}], lr=lr, betas=betas, eps=eps, weight_decay=0.0, decoupled=False)
+    if group_wd_params:
+        wd_params, no_wd_params = separate_weight_decayable_params(params)
+        groups = [{'params': wd_params}, {'params': no_wd_params, 'weight_decay': 0}]
+    else:
+        groups = [{'params': params}]
+    return FusedAdam(groups, lr=lr, betas=betas, eps=eps, weight_decay=wd, decoupled=True)
+
+
+def get_linear_scheduler(optimizer, total_iters=10000, start_factor=1e-7):
+    """optimizer.py:36-41"""
+    return lr_scheduler.LinearLR(optimizer=optimizer, start_factor=start_factor, end_factor=1., total_iters=total_iters)

@@ -1,0 +1,86 @@
+"""Data-parallel runtime: one process per GPU, torch.distributed over RCCL (backend "nccl" on ROCm) / xGMI.
+
+The reference uses HF accelerate -> torch DDP, which all-reduces bucketed gradients on EVERY micro-batch
+backward (trainer.py:154-155,439; no no_sync) -- 8 collectives of 366 MB per optimizer step for coarse-small.
+Here the backward kernels accumulate into one flat fp32 gradient buffer (optimizer.FusedAdam) and the whole
+step does ONE SUM all-reduce of that buffer; the 1/world_size mean is folded into the fused optimizer kernel.
+Validation-only collectives (scalar mean, all-gather of predictions) mirror trainer.py:470-473.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+class DataParallel:
+    def __init__(self, device: Optional[torch.device] = None, backend: Optional[str] = None):
+        self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.owns_group = False
+        if self.world_size > 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            use_cuda = torch.cuda.is_available() and (device is None or torch.device(device).type == "cuda")
+            if use_cuda:
+                torch.cuda.set_device(self.local_rank)
+            dist.init_process_group(backend=backend or ("nccl" if use_cuda else "gloo"),
+                                    rank=self.rank, world_size=self.world_size)
+            self.owns_group = True
+        if dist.is_initialized():
+            self.world_size, self.rank = dist.get_world_size(), dist.get_rank()
+
+    @property
+    def is_distributed(self):
+        return self.world_size > 1
+
+    @property
+    def is_main(self):
+        return self.rank == 0
+
+    @property
+    def is_local_main(self):
+        return self.local_rank == 0
+
+    def allreduce_sum_(self, flat: torch.Tensor) -> torch.Tensor:
+        """THE gradient exchange: one SUM all-reduce of the flat buffer (mean is applied by the optimizer kernel)."""
+        if self.is_distributed:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        return flat
+
+    def grad_scale(self) -> float:
+        return 1.0 / self.world_size
+
+    def reduce_mean(self, t: torch.Tensor) -> torch.Tensor:
+        if self.is_distributed:
+            t = t.clone()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            t /= self.world_size
+        return t
+
+    def all_gather_cat(self, t: torch.Tensor) -> torch.Tensor:
+        if not self.is_distributed:
+            return t
+        out = [torch.empty_like(t) for _ in range(self.world_size)]
+        dist.all_gather(out, t.contiguous())
+        return torch.cat(out, dim=0)
+
+    def broadcast_(self, t: torch.Tensor, src: int = 0):
+        if self.is_distributed:
+            dist.broadcast(t, src=src)
+        return t
+
+    def barrier(self):
+        if self.is_distributed:
+            dist.barrier()
+
+    def print(self, *a, **k):
+        if self.is_main:
+            print(*a, **k)
+
+    def shutdown(self):
+        if self.owns_group and dist.is_initialized():
+            dist.destroy_process_group()

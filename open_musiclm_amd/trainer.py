@@ -1,0 +1,338 @@
+"""SingleStageTrainer with the reference's constructor / method surface (reference open_musiclm/trainer.py:111-560),
+re-hosted on the MI355X engine:
+
+  * no HF accelerate / DDP: one process per GPU (parallel.DataParallel over RCCL); gradients of all
+    grad_accum_every micro-batches accumulate in the optimizer's flat buffer and are exchanged with ONE
+    SUM all-reduce per optimizer step (the reference all-reduces on every micro-batch backward, :439);
+  * clip_grad_norm_ + Adam(W) + zero_grad + LinearLR warm-up are the fused optimizer step (:444-449);
+  * the per-micro-batch `loss.item()` host sync of the reference (:441) is replaced by one device-side
+    accumulation that is read back once per optimizer step.
+
+Checkpoint files keep the reference's names and formats ({stage}.transformer|optimizer|scheduler.{step}.pt, :536-549)
+so scripts/train_utils.py resumes from them unchanged.
+"""
+from __future__ import annotations
+
+import itertools
+import json
+import os
+import sys
+import time
+from dataclasses import asdict, is_dataclass
+from pathlib import Path
+from shutil import rmtree
+from typing import List, Optional
+
+import numpy as np
+import torch
+from torch import nn
+from torch.utils.data import DataLoader, Dataset, random_split
+
+from .data import PreprocessedDataset, SoundDataset, get_dataloader, get_preprocessed_dataloader
+from .open_musiclm import (CoarseStage, FineStage, SemanticStage, TokenConditionedTransformer)
+from .optimizer import get_linear_scheduler, get_optimizer
+from .parallel import DataParallel
+from .utils import copy_file_to_folder, default, exists
+
+
+def cycle(dl):
+    while True:
+        for data in dl:
+            yield data
+
+
+def yes_or_no(question):
+    if not sys.stdin or not sys.stdin.isatty():       # non-interactive launch (torchrun, CI): keep existing results
+        return False
+    answer = input(f'{question} (y/n) ')
+    return answer.lower() in ('yes', 'y')
+
+
+def accum_log(log, new_logs):
+    for key, new_value in new_logs.items():
+        log[key] = log.get(key, 0.) + new_value
+    return log
+
+
+def noop(*args, **kwargs):
+    pass
+
+
+class _JsonlTracker:
+    """Stand-in for accelerate's trackers (tensorboard / wandb are not hot-path): metrics go to a JSONL file."""
+
+    def __init__(self, logging_dir, run_name, config, enabled):
+        self.f = None
+        if enabled and logging_dir:
+            os.makedirs(logging_dir, exist_ok=True)
+            self.f = open(os.path.join(logging_dir, f"{run_name}.jsonl"), "a")
+            self.f.write(json.dumps({"config": config}, default=str) + "\n")
+
+    def log(self, values, step):
+        if self.f:
+            self.f.write(json.dumps({"step": step, **values}) + "\n")
+            self.f.flush()
+
+
+class SingleStageTrainer(nn.Module):
+    """trainer.py:111-560.  semantic: needs audio_conditioner + wav2vec (or preprocessed / token datasets);
+    coarse: + neural_codec; fine: audio_conditioner + neural_codec."""
+
+    def __init__(self, transformer: TokenConditionedTransformer, stage, *, num_train_steps, batch_size,
+                 model_config=None, training_config=None, dataset: Optional[Dataset] = None, wav2vec=None,
+                 neural_codec=None, audio_conditioner=None, data_max_length_seconds=1,
+                 ignore_files: Optional[List[str]] = None, cross_entropy_loss_weights: Optional[List[float]] = None,
+                 ignore_load_errors=True, folder=None, use_preprocessed_data=False, lr=3e-4, lr_warmup=0,
+                 grad_accum_every=1, wd=0., max_grad_norm=0.5, valid_frac=0.05, random_split_seed=42,
+                 save_results_every=100, save_predicted_tokens=True, save_reconstructed_wave=True,
+                 save_model_every=1000, results_folder='./results', accelerate_kwargs: dict = {},
+                 config_paths: Optional[List[str]] = None, dataset_yields_tokens: Optional[bool] = None):
+        super().__init__()
+        # accelerate_kwargs is accepted for script compatibility: log_with / logging_dir select the JSONL tracker
+        self.dp = DataParallel(device=transformer.device)
+        self.log_with = accelerate_kwargs.get('log_with')
+        self.logging_dir = accelerate_kwargs.get('logging_dir') or accelerate_kwargs.get('project_dir')
+
+        self.use_preprocessed_data = use_preprocessed_data
+        tokens_in = use_preprocessed_data or bool(default(dataset_yields_tokens, exists(dataset) and not exists(audio_conditioner)))
+        self.model_config, self.training_config = model_config, training_config
+        self.transformer = transformer
+        self.wav2vec, self.audio_conditioner, self.neural_codec = wav2vec, audio_conditioner, neural_codec
+        self.stage = stage
+
+        if stage == 'semantic':
+            assert tokens_in or (exists(audio_conditioner) and exists(wav2vec))
+            self.train_wrapper = SemanticStage(semantic_transformer=transformer, wav2vec=wav2vec, clap=audio_conditioner,
+                                               cross_entropy_loss_weights=default(cross_entropy_loss_weights, [0., 1.]))
+            token_fields, wave_fields = ('clap_token_ids', 'semantic_token_ids'), ('raw_wave_for_clap', 'raw_wave_for_semantic')
+        elif stage == 'coarse':
+            assert tokens_in or (exists(wav2vec) and exists(audio_conditioner) and exists(neural_codec))
+            self.train_wrapper = CoarseStage(coarse_transformer=transformer, neural_codec=neural_codec, wav2vec=wav2vec,
+                                             clap=audio_conditioner,
+                                             cross_entropy_loss_weights=default(cross_entropy_loss_weights, [0., 0., 1.]))
+            token_fields = ('clap_token_ids', 'semantic_token_ids', 'coarse_token_ids')
+            wave_fields = ('raw_wave_for_clap', 'raw_wave_for_semantic', 'raw_wave_for_acoustic')
+        elif stage == 'fine':
+            assert tokens_in or (exists(audio_conditioner) and exists(neural_codec))
+            self.train_wrapper = FineStage(fine_transformer=transformer, clap=audio_conditioner, neural_codec=neural_codec,
+                                           cross_entropy_loss_weights=default(cross_entropy_loss_weights, [0., 0., 1.]))
+            token_fields = ('clap_token_ids', 'coarse_token_ids', 'fine_token_ids')
+            wave_fields = ('raw_wave_for_clap', 'raw_wave_for_acoustic')
+        else:
+            raise ValueError(f'invalid stage: {stage}')
+        self.ds_fields = token_fields if tokens_in else wave_fields
+
+        self.register_buffer('steps', torch.Tensor([0]))
+        self.num_train_steps, self.batch_size, self.grad_accum_every = num_train_steps, batch_size, grad_accum_every
+
+        self.optim = get_optimizer(transformer.parameters(), lr=lr, wd=wd)
+        self.scheduler = get_linear_scheduler(self.optim, total_iters=lr_warmup) if lr_warmup > 0 else None
+        self.max_grad_norm = max_grad_norm
+
+        # ---- data ----
+        if self.use_preprocessed_data:
+            g = self.model_config.global_cfg
+            self.ds = PreprocessedDataset(folder, stage=self.stage,
+                                          semantic_window_seconds=int(g.semantic_audio_length_seconds),
+                                          coarse_window_seconds=int(g.coarse_audio_length_seconds),
+                                          fine_window_seconds=int(g.fine_audio_length_seconds),
+                                          semantic_steps_per_second=self.model_config.hubert_kmeans_cfg.output_hz,
+                                          acoustic_steps_per_second=self.model_config.encodec_cfg.output_hz)
+        else:
+            self.ds = dataset
+            if not exists(self.ds):
+                assert exists(folder), 'folder must be passed in, if not passing in a custom dataset for text conditioned audio synthesis training'
+                self.ds = SoundDataset(folder, max_length_seconds=data_max_length_seconds, ignore_files=default(ignore_files, []),
+                                       ignore_load_errors=ignore_load_errors)
+        if valid_frac > 0:
+            train_size = int((1 - valid_frac) * len(self.ds))
+            valid_size = len(self.ds) - train_size
+            self.ds, self.valid_ds = random_split(self.ds, [train_size, valid_size],
+                                                  generator=torch.Generator().manual_seed(random_split_seed))
+            self.print(f'training with dataset of {len(self.ds)} samples and validating with randomly splitted {len(self.valid_ds)} samples')
+        else:
+            self.valid_ds = self.ds
+            self.print(f'training with shared training and valid dataset of {len(self.ds)} samples')
+
+        make_dl = get_preprocessed_dataloader if (self.use_preprocessed_data or tokens_in) else get_dataloader
+        sampler = vsampler = None
+        if self.dp.is_distributed:        # per-rank shard of the data (accelerate.prepare(dl) equivalent; batch_size is per process)
+            from torch.utils.data.distributed import DistributedSampler
+            sampler = DistributedSampler(self.ds, num_replicas=self.dp.world_size, rank=self.dp.rank, shuffle=True)
+            vsampler = DistributedSampler(self.valid_ds, num_replicas=self.dp.world_size, rank=self.dp.rank, shuffle=True)
+        self.dl = make_dl(self.ds, batch_size=batch_size, shuffle=sampler is None, sampler=sampler)
+        self.valid_dl = make_dl(self.valid_ds, batch_size=batch_size, shuffle=vsampler is None, sampler=vsampler)
+        self.dl_iter, self.valid_dl_iter = cycle(self.dl), cycle(self.valid_dl)
+
+        self.save_model_every, self.save_results_every = save_model_every, save_results_every
+        self.save_predicted_tokens, self.save_reconstructed_wave = save_predicted_tokens, save_reconstructed_wave
+        self.results_folder = Path(results_folder)
+        if self.is_main and len([*self.results_folder.glob('**/*')]) > 0 and yes_or_no('do you want to clear previous experiment checkpoints and results?'):
+            rmtree(str(self.results_folder))
+        self.results_folder.mkdir(parents=True, exist_ok=True)
+        self.dp.barrier()
+        if exists(save_reconstructed_wave):
+            self.waves_folder = self.results_folder / 'reconstructed_waves'
+            self.waves_folder.mkdir(parents=True, exist_ok=True)
+        if exists(save_predicted_tokens):
+            self.tokens_folder = self.results_folder / 'tokens'
+            self.tokens_folder.mkdir(parents=True, exist_ok=True)
+
+        hps = {}
+        if exists(model_config) and is_dataclass(model_config):
+            hps.update(asdict(model_config.global_cfg))
+            hps.update(asdict(getattr(model_config, f'{stage}_cfg')))
+        if exists(training_config) and is_dataclass(training_config):
+            hps.update(asdict(getattr(training_config, f'{stage}_trainer_cfg')))
+        self.tracker = _JsonlTracker(self.logging_dir, f"{stage}_stage_{int(time.time() * 1000)}", hps,
+                                     enabled=self.is_main and exists(self.log_with))
+        if self.is_main and exists(config_paths):
+            configs_folder = self.results_folder / "configs"
+            configs_folder.mkdir(parents=True, exist_ok=True)
+            for config_path in config_paths:
+                copy_file_to_folder(config_path, configs_folder)
+        self._loss_acc = None
+
+    # ---- checkpointing (trainer.py:359-391) ----------------------------------------------------------
+    def save(self, model_path, optim_path, scheduler_path=None):
+        torch.save({k: v.detach().cpu() for k, v in self.transformer.state_dict().items()}, model_path)
+        torch.save(self.optim.state_dict(), optim_path)
+        if exists(self.scheduler):
+            assert exists(scheduler_path)
+            torch.save(self.scheduler.state_dict(), scheduler_path)
+
+    def load(self, model_path, optim_path, scheduler_path=None, steps=0):
+        model_path, optim_path = Path(model_path), Path(optim_path)
+        assert model_path.exists() and optim_path.exists()
+        self.transformer.load_state_dict(torch.load(model_path, map_location=self.device))
+        self.optim.load_state_dict(torch.load(optim_path, map_location=self.device, weights_only=False))
+        if exists(self.scheduler):
+            assert exists(scheduler_path), 'the config specifies lr warmup is used, but no scheduler checkpoint is given. try setting lr_warmup to 0.'
+            scheduler_path = Path(scheduler_path)
+            assert scheduler_path.exists()
+            self.scheduler.load_state_dict(torch.load(scheduler_path, map_location=self.device, weights_only=False))
+        if steps > 0:
+            assert int(self.steps.item()) == 0, 'steps should be 0 when loading a checkpoint for the first time'
+            self.steps += steps
+
+    def print(self, msg):
+        self.dp.print(msg)
+
+    def generate(self, *args, **kwargs):
+        return self.train_wrapper.generate(*args, **kwargs)
+
+    @property
+    def device(self):
+        return self.transformer.device
+
+    @property
+    def is_distributed(self):
+        return self.dp.is_distributed
+
+    @property
+    def is_main(self):
+        return self.dp.is_main
+
+    @property
+    def is_local_main(self):
+        return self.dp.is_local_main
+
+    def _next_batch(self, it):
+        batch = next(it)
+        if isinstance(batch, torch.Tensor):
+            batch = (batch,)
+        return {k: v.to(self.device, non_blocking=True) for k, v in zip(self.ds_fields, batch)}
+
+    # ---- one optimizer step (trainer.py:415-552) -------------------------------------------------------
+    def micro_step(self, data_kwargs):
+        """forward + backward of ONE micro-batch; gradients accumulate in the optimizer's flat buffer."""
+        loss, _, _ = self.train_wrapper(**data_kwargs, return_loss=True)
+        (loss / self.grad_accum_every).backward()
+        self.optim.mark_grads_dirty()
+        return loss.detach()
+
+    def optimizer_step(self):
+        """ONE gradient exchange + fused clip/Adam(W)/zero_grad + scheduler tick."""
+        self.dp.allreduce_sum_(self.optim.flat_grad)
+        self.optim.step(max_grad_norm=self.max_grad_norm, grad_scale=self.dp.grad_scale())
+        if exists(self.scheduler):
+            self.scheduler.step()
+
+    def train_step(self):
+        steps = int(self.steps.item())
+        self.transformer.train()
+        self.train_wrapper.train()
+        self.optim.zero_grad()
+        loss_acc = torch.zeros((), device=self.device)
+        for _ in range(self.grad_accum_every):
+            loss_acc += self.micro_step(self._next_batch(self.dl_iter))
+        self.optimizer_step()
+        logs = {'loss': float(loss_acc.item()) / self.grad_accum_every}       # single host sync per optimizer step
+        self.print(f"{steps}: loss: {logs['loss']}")
+
+        valid_loss = valid_accuracy = None
+        if not (steps % self.save_results_every):
+            valid_loss, valid_accuracy = self.validate(steps)
+        self.tracker.log({"train_loss": logs['loss'], "valid_loss": valid_loss, "valid_accuracy": valid_accuracy}, step=steps)
+
+        if self.is_main and not (steps % self.save_model_every):
+            self.print(f'{steps}: saving model to {str(self.results_folder)}')
+            self.save(str(self.results_folder / f'{self.stage}.transformer.{steps}.pt'),
+                      str(self.results_folder / f'{self.stage}.optimizer.{steps}.pt'),
+                      str(self.results_folder / f'{self.stage}.scheduler.{steps}.pt'))
+            if exists(self.audio_conditioner) and getattr(self.audio_conditioner, 'learn_rvq', False):
+                torch.save(self.audio_conditioner.rq.state_dict(), str(self.results_folder / f'{self.stage}.conditioner_rvq.{steps}.pt'))
+        self.steps += 1
+        return logs
+
+    @torch.no_grad()
+    def validate(self, steps):
+        """trainer.py:457-526: teacher-forced validation loss / token accuracy, token dumps, optional wave reconstruction."""
+        self.train_wrapper.eval()
+        data_kwargs = self._next_batch(self.valid_dl_iter)
+        valid_loss, all_logits, all_labels = self.train_wrapper(**data_kwargs, return_loss=True)
+        valid_loss = float(self.dp.reduce_mean(valid_loss.detach().reshape(1)).item())
+        pred = self.dp.all_gather_cat(all_logits[-1].argmax(1).contiguous()).cpu().long()
+        gt = self.dp.all_gather_cat(all_labels[-1].contiguous()).cpu().long()
+        valid_accuracy = (pred == gt).float().mean().item()
+        self.print(f'{steps}: valid loss {valid_loss}, valid acc {valid_accuracy}')
+        if self.is_main and self.save_predicted_tokens:
+            inter = torch.empty((pred.shape[0] + gt.shape[0], pred.shape[1]), dtype=pred.dtype)
+            inter[0::2], inter[1::2] = pred, gt
+            np.savetxt(str(self.tokens_folder / f'{self.stage}.tokens.{steps}.txt'), inter, fmt='%-6s',
+                       header='predicted and ground truth tokens from the validation set. row 0%2 is predicted, 1%2 is ground truth\n ')
+        if self.is_main and self.save_reconstructed_wave and self.stage in ('coarse', 'fine') and exists(self.neural_codec):
+            toks = all_logits[-1].argmax(1)[:, :-1]
+            toks[toks == self.transformer.eos_ids[-1]] = 0
+            q = self.transformer.token_sequences[-1].num_quantizers
+            toks = toks.reshape(toks.shape[0], -1, q)
+            if self.stage == 'fine':
+                cq = self.transformer.token_sequences[-2].num_quantizers
+                coarse = all_labels[-2][:, :-1].reshape(toks.shape[0], -1, cq)
+                toks = torch.cat((coarse, toks), dim=-1)
+            waves = self.neural_codec.decode_from_codebook_indices(toks).cpu()
+            try:
+                import torchaudio
+                for i, wave in enumerate(waves[:4]):
+                    torchaudio.save(str(self.waves_folder / f'{self.stage}.reconstructed_wave_{i}.{steps}.wav'), wave, self.neural_codec.sample_rate)
+            except ImportError:
+                pass
+        return valid_loss, valid_accuracy
+
+    def train(self, log_fn=noop):
+        while self.steps < self.num_train_steps:
+            logs = self.train_step()
+            log_fn(logs)
+        self.print('training complete')
+
+
+class ClapRVQTrainer(nn.Module):
+    """Out of scope for the hot path: one-off quantizer fitting needing pretrained CLAP + audio."""
+
+    def __init__(self, *a, **k):
+        raise NotImplementedError("ClapRVQTrainer is outside the MI355X TokenConditionedTransformer hot path")
+
+
+class HfHubertKmeansTrainer(nn.Module):
+    def __init__(self, *a, **k):
+        raise NotImplementedError("HfHubertKmeansTrainer is outside the MI355X TokenConditionedTransformer hot path")

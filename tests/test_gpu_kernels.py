@@ -1,0 +1,444 @@
+"""GPU: every HIP kernel of libomlm_hip.so, called through the C ABI, against a plain PyTorch reference of the
+same op (fp32 / fp64, torch ops on the same device).  Tolerances are written next to each check:
+ * fp32 operands ("bf16x3" split) must reproduce fp32 math to ~1e-5 relative;
+ * bf16 operands are compared against the reference evaluated on bf16-rounded inputs (so only accumulation
+   order differs) to ~1e-5, or to the stated bf16 tolerance where outputs are rounded to bf16;
+ * integer outputs (quantizer ids, sampled ids) must be bit-exact.
+Every metric is also appended to gpurun_out/kernel_report.json for post-mortem reading."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPORT = os.path.join(ROOT, "gpurun_out", "kernel_report.json")
+
+
+def report(name, **metrics):
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    data = {}
+    if os.path.exists(REPORT):
+        try:
+            data = json.load(open(REPORT))
+        except Exception:
+            data = {}
+    data[name] = {k: (float(v) if isinstance(v, (int, float, np.floating)) else v) for k, v in metrics.items()}
+    json.dump(data, open(REPORT, "w"), indent=1)
+
+
+def relerr(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from open_musiclm_amd import ops as o
+    from open_musiclm_amd import hip
+    hip.lib()       # fail loudly if the extension is missing
+    return o
+
+
+def test_probe_transpose_read(ops, dev):
+    out = torch.zeros(64 * 4, dtype=torch.int16, device=dev)
+    ops.probe_tr16(out)
+    got = out.cpu().numpy().reshape(64, 4)
+    exp = np.zeros((64, 4), dtype=np.int64)
+    for l in range(64):
+        g0, c = 16 * (l // 16), l % 16
+        for j in range(4):
+            exp[l, j] = 4 * (g0 + 4 * j + c // 4) + c % 4
+    report("probe_tr16", match=bool((got == exp).all()), got=got.tolist())
+    assert (got == exp).all(), f"ds_read_b64_tr_b16 semantic differs from the assumed one:\n{got}"
+
+
+GEMM_CASES = [
+    # M, N, K, a_kmaj, b_kmaj
+    (200, 136, 192, False, False),
+    (257, 1032, 64, False, False),
+    (130, 72, 200, False, True),
+    (96, 264, 1000, True, True),
+    (1025, 128, 333, True, True),
+    (384, 512, 512, False, False),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,akm,bkm", GEMM_CASES)
+def test_gemm_layouts(ops, dev, dtype, M, N, K, akm, bkm):
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K)
+    c8 = lambda x: (x + 7) // 8 * 8
+    Am = torch.randn(M, K, generator=g).to(dtype)          # logical operands (asymmetric random data)
+    Bm = torch.randn(N, K, generator=g).to(dtype)
+    Kp = c8(K)
+
+    def store(mat, kmaj, n):
+        if kmaj:                                            # [K, ld8(n)]: pad columns hold garbage that must not leak
+            st = torch.randn(K, c8(n), generator=g).to(dtype)
+            st[:, :n] = mat.t()
+            return st
+        st = torch.zeros(n, Kp, dtype=dtype)                # [n, Kp]: contraction zero-padded to 8
+        st[:, :K] = mat
+        return st
+
+    A, B = store(Am, akm, M).to(dev), store(Bm, bkm, N).to(dev)
+    Kcall = K if (akm and bkm) else Kp                      # k-major operands are bounded by their row count
+    Cin = torch.randn(M, N, generator=g).to(dev)
+    C = torch.full((M, N), float("nan"), device=dev)
+    ops.gemm(A, B, C, M=M, N=N, K=Kcall, a_kmajor=akm, b_kmajor=bkm, Cin=Cin, alpha=0.5,
+             a_rows=K if akm else M, b_rows=K if bkm else N)
+    ref = 0.5 * (Am.double() @ Bm.double().t()).to(dev) + Cin.double()
+    e = relerr(C, ref)
+    report(f"gemm[{dtype},{M},{N},{K},{akm},{bkm}]", relerr=e)
+    assert not torch.isnan(C).any()
+    assert e < 2e-5, e          # fp32-grade: bf16x3 split, or exact products of bf16 inputs, fp32 accumulation
+
+
+def test_gemm_row_maps_and_bf16_out(ops, dev):
+    g = torch.Generator().manual_seed(5)
+    rows, D, V = 300, 128, 41
+    y = torch.randn(rows, D, generator=g).to(dev).bfloat16()
+    W = torch.randn(V, D, generator=g).to(dev).bfloat16()
+    a_map = torch.randperm(rows, generator=g)[:77].to(torch.int32).to(dev)
+    c_map = torch.randperm(150, generator=g)[:77].to(torch.int32).to(dev)
+    c_map[5] = -1                                       # dropped row
+    out = torch.zeros(150, 48, device=dev, dtype=torch.bfloat16)
+    ops.gemm(y, W, out, M=77, N=V, K=D, a_map=a_map, c_map=c_map, ldc=48, a_rows=rows, b_rows=V)
+    ref = torch.zeros(150, 48, dtype=torch.float64, device=dev)
+    prod = y.double()[a_map.long()] @ W.double().t()
+    for r in range(77):
+        if int(c_map[r]) >= 0:
+            ref[int(c_map[r]), :V] = prod[r]
+    e = relerr(out, ref)
+    report("gemm_row_maps_bf16_out", relerr=e)
+    assert e < 5e-3             # output rounded to bf16: 2^-9 relative
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layernorm_fwd_bwd(ops, dev, dtype):
+    M, D = 333, 1024
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(M, D, generator=g) * 3 + 1).to(dev)
+    gamma = (1 + 0.1 * torch.randn(D, generator=g)).to(dev)
+    y = torch.empty(M, D, device=dev, dtype=dtype)
+    xc = torch.empty(M, D, device=dev, dtype=dtype)
+    mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    ops.layernorm_fwd(x, gamma, y, xc, mean, rstd)
+    xr = x.double().requires_grad_(True)
+    gr = gamma.double().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (D,), gr, None, 1e-5)
+    tol = 1e-5 if dtype == torch.float32 else 5e-3
+    e_y, e_c = relerr(y, yr.detach()), relerr(xc, x)
+    dy = torch.randn(M, D, generator=g).to(dev)
+    dres = torch.randn(M, D, generator=g).to(dev)
+    yr.backward(dy.double())
+    dx = torch.empty(M, D, device=dev)
+    dxc = torch.empty(M, D, device=dev, dtype=dtype)
+    dgamma = torch.zeros(D, device=dev)
+    ops.layernorm_bwd(dy, x, gamma, mean, rstd, dres, dx, dxc, dgamma, dx_scale=0.1)
+    e_dx = relerr(dx, 0.1 * (xr.grad + dres.double()))
+    e_dg = relerr(dgamma, gr.grad)
+    report(f"layernorm[{dtype}]", y=e_y, xcast=e_c, dx=e_dx, dgamma=e_dg, dxcast=relerr(dxc, dx))
+    assert e_y < tol and e_c < tol and e_dx < 1e-5 and e_dg < 1e-4 and relerr(dxc, dx) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_qk_norm_fwd_bwd(ops, dev, dtype):
+    M, H = 150, 3
+    g = torch.Generator().manual_seed(2)
+    q_raw = torch.randn(M, H * 64, generator=g).to(dev)
+    kv_raw = torch.randn(M, 128, generator=g).to(dev)
+    qs = (1 + 0.2 * torch.randn(64, generator=g)).to(dev)
+    ks = (1 + 0.2 * torch.randn(64, generator=g)).to(dev)
+    q = torch.empty(M, H * 64, device=dev, dtype=dtype)
+    k = torch.empty(M, 64, device=dev, dtype=dtype)
+    v = torch.empty(M, 64, device=dev, dtype=dtype)
+    ops.qk_norm_fwd(q_raw, kv_raw, qs, ks, q, k, v, H)
+    qr, kvr = q_raw.double().requires_grad_(True), kv_raw.double().requires_grad_(True)
+    qsr, ksr = qs.double().requires_grad_(True), ks.double().requires_grad_(True)
+    qn = torch.nn.functional.normalize(qr.view(M, H, 64), dim=-1) * qsr
+    kn = torch.nn.functional.normalize(kvr[:, :64], dim=-1) * ksr
+    vn = kvr[:, 64:]
+    tol = 1e-5 if dtype == torch.float32 else 5e-3
+    e = max(relerr(q, qn.reshape(M, -1).detach()), relerr(k, kn.detach()), relerr(v, vn.detach()))
+    dq, dk, dv = (torch.randn(M, H * 64, generator=g).to(dev), torch.randn(M, 64, generator=g).to(dev),
+                  torch.randn(M, 64, generator=g).to(dev))
+    (qn.reshape(M, -1) * dq.double()).sum().add((kn * dk.double()).sum()).add((vn * dv.double()).sum()).backward()
+    dq_raw = torch.empty(M, H * 64, device=dev, dtype=dtype)
+    dkv_raw = torch.empty(M, 128, device=dev, dtype=dtype)
+    dqs, dks = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+    ops.qk_norm_bwd(dq, dk, dv, q_raw, kv_raw, qs, ks, dq_raw, dkv_raw, dqs, dks, H)
+    eb = max(relerr(dq_raw, qr.grad), relerr(dkv_raw, kvr.grad))
+    es = max(relerr(dqs, qsr.grad), relerr(dks, ksr.grad))
+    report(f"qk_norm[{dtype}]", fwd=e, bwd=eb, dscale=es)
+    assert e < tol and eb < tol and es < 1e-4
+
+
+def naive_attention(q, k, v, bias, keymask, H, scale=8.0):
+    """q [B,N,H*64], k,v [B,N,64] double; bias [N, >=H]; keymask [B,N] bool."""
+    B, N, _ = q.shape
+    qh = q.view(B, N, H, 64).permute(0, 2, 1, 3)
+    sim = torch.einsum("bhid,bjd->bhij", qh, k) * scale
+    idx = (torch.arange(N, device=q.device)[:, None] - torch.arange(N, device=q.device)[None, :]).clamp(min=0)
+    if bias is not None:
+        sim = sim + bias[:, :H].t()[:, idx]
+    neg = -torch.finfo(torch.float32).max
+    if keymask is not None:
+        sim = sim.masked_fill(~keymask[:, None, None, :], neg)
+    sim = sim.masked_fill(torch.ones(N, N, dtype=torch.bool, device=q.device).triu(1), neg)
+    out = torch.einsum("bhij,bjd->bhid", sim.softmax(-1), v)
+    return out.permute(0, 2, 1, 3).reshape(B, N, H * 64)
+
+
+@pytest.mark.parametrize("dtype,B,N,H", [(torch.float32, 2, 77, 2), (torch.bfloat16, 2, 77, 2),
+                                         (torch.bfloat16, 1, 200, 5), (torch.float32, 1, 130, 8)])
+def test_attention_fwd_bwd(ops, dev, dtype, B, N, H):
+    g = torch.Generator().manual_seed(N + H)
+    M = B * N
+    unit = lambda t: torch.nn.functional.normalize(t, dim=-1)
+    q = unit(torch.randn(B, N, H, 64, generator=g)).reshape(M, H * 64).to(dev)
+    k = unit(torch.randn(M, 64, generator=g)).to(dev)
+    v = torch.randn(M, 64, generator=g).to(dev)
+    ldb = (H + 7) // 8 * 8
+    bias = torch.zeros(N, ldb)
+    bias[:, :H] = torch.randn(N, H, generator=g) * 2
+    bias = bias.to(dev)
+    keymask = (torch.rand(B, N, generator=g) > 0.2)
+    keymask[:, 0] = True
+    keymask = keymask.to(dev)
+    qd, kd, vd = q.to(dtype), k.to(dtype), v.to(dtype)
+    out = torch.empty(M, H * 64, device=dev, dtype=dtype)
+    lse = torch.empty(B, H, N, device=dev)
+    ops.attn_fwd(qd, kd, vd, bias, keymask.to(torch.uint8), out, lse, B, N, H, 8.0)
+    qr = qd.double().view(B, N, H * 64).requires_grad_(True)
+    kr = kd.double().view(B, N, 64).requires_grad_(True)
+    vr = vd.double().view(B, N, 64).requires_grad_(True)
+    br = bias.double().requires_grad_(True)
+    ref = naive_attention(qr, kr, vr, br, keymask, H)
+    e_f = relerr(out.view(B, N, -1), ref.detach())
+    # fp32 operands: bf16x3 forward -> fp32-grade; bf16 operands: P and the output are rounded to bf16
+    tol_f = 2e-5 if dtype == torch.float32 else 1e-2
+    do = torch.randn(B, N, H * 64, generator=g).to(dev)
+    ref.backward(do.double())
+    dq = torch.empty(M, H * 64, device=dev)
+    dk = torch.empty(M, 64, device=dev)
+    dv = torch.empty(M, 64, device=dev)
+    dbias = torch.zeros(N, ldb, device=dev)
+    delta = torch.empty(B, H, N, device=dev)
+    ops.attn_bwd(qd, kd, vd, bias, keymask.to(torch.uint8), out, do.reshape(M, -1).to(dtype).contiguous(), lse, delta,
+                 dq, dk, dv, dbias, B, N, H, 8.0)
+    e_q, e_k, e_v = relerr(dq.view(B, N, -1), qr.grad), relerr(dk.view(B, N, -1), kr.grad), relerr(dv.view(B, N, -1), vr.grad)
+    e_b = relerr(dbias[:, :H], br.grad[:, :H])
+    report(f"attention[{dtype},{B},{N},{H}]", fwd=e_f, dq=e_q, dk=e_k, dv=e_v, dbias=e_b)
+    assert e_f < tol_f, e_f
+    # backward always runs single-pass bf16 MFMA (P, dS, dO rounded to bf16): 2^-8-level relative error
+    assert max(e_q, e_k, e_v, e_b) < 2e-2, (e_q, e_k, e_v, e_b)
+
+
+def ffmid_reference(h1, convw, gamma, F, Fp, nseq, drop=None):
+    """h1 [M, 2Fp] double in the padded layout; returns h2 [M, F]."""
+    M = h1.shape[0]
+    x = torch.cat([h1[:, :F], h1[:, Fp:Fp + F]], dim=-1).view(M // nseq, nseq, 2 * F)
+    xp = torch.nn.functional.pad(x, (0, 0, 2, 0))
+    u = xp[:, :-2] * convw[:, 0] + xp[:, 1:-1] * convw[:, 1] + xp[:, 2:] * convw[:, 2]
+    a, gate = u[..., :F], u[..., F:]
+    gl = torch.nn.functional.gelu(gate) * a
+    y = torch.nn.functional.layer_norm(gl, (F,), gamma, None, 1e-5)
+    return y.reshape(M, F)
+
+
+@pytest.mark.parametrize("dtype,F", [(torch.float32, 341), (torch.bfloat16, 341), (torch.float32, 2730)])
+def test_ffmid_fwd_bwd(ops, dev, dtype, F):
+    nseq, Bn = 19, 3
+    M = nseq * Bn
+    Fp = (F + 7) // 8 * 8
+    g = torch.Generator().manual_seed(F)
+    h1 = torch.zeros(M, 2 * Fp)
+    h1[:, :F] = torch.randn(M, F, generator=g)
+    h1[:, Fp:Fp + F] = torch.randn(M, F, generator=g)
+    convw = (torch.randn(2 * F, 3, generator=g) * 0.5).to(dev)
+    gamma = (1 + 0.1 * torch.randn(F, generator=g)).to(dev)
+    h1d = h1.to(dev).to(dtype)
+    h2 = torch.empty(M, Fp, device=dev, dtype=dtype)
+    mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    ops.ffmid_fwd(h1d, convw, gamma, h2, mean, rstd, nseq, F, Fp, 0.0, 0)
+    h1r = h1d.double().requires_grad_(True)
+    cr, gr = convw.double().requires_grad_(True), gamma.double().requires_grad_(True)
+    ref = ffmid_reference(h1r, cr, gr, F, Fp, nseq)
+    tol = 2e-5 if dtype == torch.float32 else 8e-3
+    e_f = relerr(h2[:, :F], ref.detach())
+    pad_zero = bool((h2[:, F:] == 0).all())
+    dh2 = torch.zeros(M, Fp)
+    dh2[:, :F] = torch.randn(M, F, generator=g)
+    dh2d = dh2.to(dev).to(dtype)
+    ref.backward(dh2d.double()[:, :F])
+    du = torch.empty(M, 2 * Fp, device=dev, dtype=dtype)
+    dh1 = torch.empty(M, 2 * Fp, device=dev, dtype=dtype)
+    dgamma, dconv = torch.zeros(F, device=dev), torch.zeros(2 * F * 3, device=dev)
+    ws = torch.empty(ops.ffmid_bwd_workspace_floats(F, Fp), device=dev)
+    ops.ffmid_bwd(dh2d, h1d, convw, gamma, mean, rstd, du, dh1, dgamma, dconv, ws, nseq, F, Fp, 0.0, 0)
+    gref = h1r.grad
+    e_x = max(relerr(dh1[:, :F], gref[:, :F]), relerr(dh1[:, Fp:Fp + F], gref[:, Fp:Fp + F]))
+    e_g, e_c = relerr(dgamma, gr.grad), relerr(dconv.view(2 * F, 3), cr.grad)
+    report(f"ffmid[{dtype},{F}]", fwd=e_f, dh1=e_x, dgamma=e_g, dconv=e_c, pad_zero=pad_zero)
+    assert pad_zero and e_f < tol and e_x < (2e-5 if dtype == torch.float32 else 2e-2)
+    assert e_g < (1e-4 if dtype == torch.float32 else 2e-2) and e_c < (1e-4 if dtype == torch.float32 else 2e-2)
+
+
+def test_ffmid_dropout_statistics_and_replay(ops, dev):
+    F, nseq = 341, 16
+    Fp, M = 344, 64
+    g = torch.Generator().manual_seed(9)
+    h1 = torch.randn(M, 2 * Fp, generator=g).to(dev)
+    convw = torch.randn(2 * F, 3, generator=g).to(dev)
+    gamma = torch.ones(F, device=dev)
+    mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    base = torch.empty(M, Fp, device=dev)
+    ops.ffmid_fwd(h1, convw, gamma, base, mean, rstd, nseq, F, Fp, 0.0, 0)
+    a, b, c = (torch.empty(M, Fp, device=dev) for _ in range(3))
+    ops.ffmid_fwd(h1, convw, gamma, a, mean, rstd, nseq, F, Fp, 0.1, 1234)
+    ops.ffmid_fwd(h1, convw, gamma, b, mean, rstd, nseq, F, Fp, 0.1, 1234)
+    ops.ffmid_fwd(h1, convw, gamma, c, mean, rstd, nseq, F, Fp, 0.1, 99)
+    kept = (a[:, :F] != 0)
+    frac = 1 - kept.float().mean().item()
+    scale_ok = relerr(a[:, :F][kept], (base[:, :F] / 0.9)[kept])
+    report("ffmid_dropout", dropped_frac=frac, scale=scale_ok)
+    assert torch.equal(a, b) and not torch.equal(a, c)          # mask is a pure function of (seed, element)
+    assert abs(frac - 0.1) < 0.02 and scale_ok < 1e-5
+
+
+def test_embed_gather_fwd_bwd(ops, dev):
+    B, D = 3, 64
+    g = torch.Generator().manual_seed(3)
+    tables = [torch.randn(30, D, generator=g).to(dev), torch.randn(11, D, generator=g).to(dev)]
+    starts = [torch.randn(D, generator=g).to(dev), torch.randn(D, generator=g).to(dev)]
+    lens = [5, 4]
+    N = sum(lens) + 2
+    ids = torch.full((B, N), -2, dtype=torch.int32)
+    ids[:, 1:6] = torch.randint(0, 30, (B, 5), generator=g, dtype=torch.int32)
+    ids[:, 7:] = torch.randint(0, 11, (B, 4), generator=g, dtype=torch.int32)
+    ids[0, 2] = -1
+    seg = torch.tensor([0] * 6 + [1] * 5, dtype=torch.int32)
+    posidx = torch.zeros(N, dtype=torch.int32)
+    ids, seg, posidx = ids.to(dev), seg.to(dev), posidx.to(dev)
+    out = torch.empty(B, N, D, device=dev)
+    ops.embed_fwd(ids, seg, posidx, tables, starts, None, out)
+    ref = torch.zeros(B, N, D, device=dev)
+    for b in range(B):
+        for n in range(N):
+            s, i = int(seg[n]), int(ids[b, n])
+            ref[b, n] = starts[s] if i == -2 else (tables[s][i] if i >= 0 else 0)
+    assert torch.equal(out, ref)                                 # a gather is a copy: bit-exact
+    dx = torch.randn(B, N, D, generator=g).to(dev)
+    dt = [torch.zeros_like(t) for t in tables]
+    ds = [torch.zeros_like(s) for s in starts]
+    ops.embed_bwd(ids, seg, posidx, dt, ds, None, dx, 0.1)
+    rt = [torch.zeros_like(t, dtype=torch.float64) for t in tables]
+    rs = [torch.zeros_like(s, dtype=torch.float64) for s in starts]
+    for b in range(B):
+        for n in range(N):
+            s, i = int(seg[n]), int(ids[b, n])
+            if i == -2:
+                rs[s] += 0.1 * dx[b, n].double()
+            elif i >= 0:
+                rt[s][i] += 0.1 * dx[b, n].double()
+    e = max(max(relerr(a, b_) for a, b_ in zip(dt, rt)), max(relerr(a, b_) for a, b_ in zip(ds, rs)))
+    report("embed", bwd=e)
+    assert e < 1e-5
+
+
+def test_cross_entropy_fwd_bwd(ops, dev):
+    R, V, ld = 97, 41, 48
+    g = torch.Generator().manual_seed(4)
+    logits = torch.zeros(R, ld)
+    logits[:, :V] = torch.randn(R, V, generator=g) * 5
+    labels = torch.randint(0, V, (R,), generator=g, dtype=torch.int32)
+    lg, lb = logits.to(dev), labels.to(dev)
+    lse, nll = torch.empty(R, device=dev), torch.zeros(1, device=dev)
+    ops.ce_fwd(lg, lb, lse, nll, V)
+    lr = lg[:, :V].double().requires_grad_(True)
+    loss = torch.nn.functional.cross_entropy(lr, lb.long(), reduction="sum")
+    e_f = abs(float(nll) - float(loss)) / float(loss)
+    gs = torch.tensor([0.25], device=dev)
+    (loss * 0.25 * 3.0).backward()
+    dl = torch.full((R, ld), float("nan"), device=dev)
+    ops.ce_bwd(lg, lb, lse, gs, 3.0, dl, V)
+    e_b = relerr(dl[:, :V], lr.grad)
+    report("cross_entropy", fwd=e_f, bwd=e_b)
+    assert e_f < 1e-5 and e_b < 1e-4 and bool((dl[:, V:] == 0).all())
+
+
+def test_adamw_clip_matches_torch(ops, dev):
+    n = 10007
+    g = torch.Generator().manual_seed(6)
+    p0 = torch.randn(n, generator=g)
+    ref_p = torch.nn.Parameter(p0.clone().double())
+    opt = torch.optim.AdamW([ref_p], lr=3e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01)
+    P, M, V = p0.clone().to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    nsq = torch.zeros(1, device=dev)
+    for step in range(1, 4):
+        grad = torch.randn(n, generator=g) * (3.0 if step == 2 else 0.001)
+        ref_p.grad = grad.double().clone() / 2.0                  # grad_scale 0.5 (2-rank mean)
+        torch.nn.utils.clip_grad_norm_([ref_p], 0.5)
+        opt.step()
+        G = grad.clone().to(dev)
+        nsq.zero_()
+        ops.sumsq_accumulate(G, nsq)
+        ops.adamw_clip_step(P, G, M, V, None, lr=3e-4, beta1=0.9, beta2=0.99, eps=1e-8, wd=0.01, step=step, gscale=0.5,
+                            gnorm_sq=nsq, max_norm=0.5, decoupled=True, zero_grad=True)
+        assert float(G.abs().max()) == 0.0
+    e = relerr(P, ref_p.detach())
+    report("adamw", relerr=e)
+    assert e < 1e-6
+
+
+def test_rvq_and_kmeans_bit_exact(ops, dev, golden_dir):
+    from oracle import musiclm_oracle as O
+    rng = np.random.RandomState(0)
+    cb = rng.randn(12, 256, 512).astype(np.float32)
+    x = rng.randn(33, 512).astype(np.float32)
+    exp = O.rvq_encode(x, cb)
+    cbT = torch.from_numpy(cb).to(dev).transpose(1, 2).contiguous()
+    idx = torch.empty(33, 12, dtype=torch.int32, device=dev)
+    res = torch.empty(33, 512, device=dev)
+    ops.rvq_encode(torch.from_numpy(x).to(dev), cbT, idx, res, 33, 512, 256, 12)
+    assert np.array_equal(idx.cpu().numpy().astype(np.int64), exp)           # bit-exact ids (stated definition)
+    z = np.load(os.path.join(golden_dir, "kmeans_assign.npz"))
+    cT = torch.from_numpy(z["centroids"]).to(dev).t().contiguous()
+    out = torch.empty(len(z["x"]), 1, dtype=torch.int32, device=dev)
+    ops.rvq_encode(torch.from_numpy(z["x"]).to(dev), cT, out, None, len(z["x"]), z["x"].shape[1], cT.shape[1], 1)
+    assert np.array_equal(out[:, 0].cpu().numpy().astype(np.int64), z["assign"])   # == sklearn predict fixture
+    # ties -> lowest index; duplicated codeword
+    cb2 = np.repeat(rng.randn(1, 4, 8).astype(np.float32), 1, axis=0)
+    cb2[0, 3] = cb2[0, 1]
+    x2 = cb2[0, 1][None].copy()
+    i2 = torch.empty(1, 1, dtype=torch.int32, device=dev)
+    ops.rvq_encode(torch.from_numpy(x2).to(dev), torch.from_numpy(cb2).to(dev).transpose(1, 2).contiguous(), i2, None, 1, 8, 4, 1)
+    assert int(i2) == 1
+    report("rvq_kmeans", exact=True)
+
+
+def test_sampler_matches_oracle(ops, dev):
+    from oracle import musiclm_oracle as O
+    B, V = 5, 1025
+    g = torch.Generator().manual_seed(8)
+    logits = torch.randn(B, 1032, generator=g) * 4
+    u = torch.rand(B, V, generator=g)
+    last = logits[:, :V].clone()
+    last[:, -1] = float("-inf")
+    exp = O.gumbel_argmax(O.top_k_filter(last, 0.9), u, 0.95)
+    out = torch.empty(B, dtype=torch.long, device=dev)
+    ops.sample_topk_gumbel(logits.to(dev), u.to(dev), out, V, max(int(0.1 * V), 1), 0.95, True)
+    report("sampler", equal=bool(torch.equal(out.cpu(), exp)))
+    assert torch.equal(out.cpu(), exp)

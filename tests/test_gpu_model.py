@@ -1,0 +1,248 @@
+"""GPU: end-to-end parity of the MI355X path (through the C ABI) against
+  (a) the golden vectors produced by the REAL reference (tests/golden/*.npz), and
+  (b) the CPU oracle (oracle/musiclm_oracle.py) at BASELINE.json's full sizes.
+
+Tolerances (written here, per north_star "logits within 1e-3 rel of CPU reference"):
+  precision "bf16x3" (fp32 operands split hi/lo on the bf16 matrix cores):
+      logits  max|d| / max|ref| <= 1e-3   (the north-star bar; measured values are ~1e-5)
+      loss    <= 1e-4 relative;  parameter grads  max|d| / max|ref| <= 3e-2 per tensor
+      (the attention BACKWARD runs single-pass bf16 MFMA in both modes -- stated in DESIGN.md)
+      sampled token ids: bit-exact against the reference's golden ids (same injected uniforms)
+  precision "bf16" (single-pass bf16 operands, fp32 accumulation / residual / statistics):
+      logits  <= 3e-2  -- bf16 operand rounding (2^-9 per element) cannot meet 1e-3; SURVEY.md measured 1.25e-2
+      for the reference itself under bf16 autocast.  Throughput numbers quoted in bf16 carry THIS parity figure.
+"""
+import ast
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPORT = os.path.join(ROOT, "gpurun_out", "model_report.json")
+
+TOL = {"bf16x3": dict(logits=1e-3, loss=1e-4, grad=3e-2), "bf16": dict(logits=3e-2, loss=5e-3, grad=1.5e-1)}
+
+
+def report(name, **metrics):
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    data = {}
+    if os.path.exists(REPORT):
+        try:
+            data = json.load(open(REPORT))
+        except Exception:
+            data = {}
+    data[name] = metrics
+    json.dump(data, open(REPORT, "w"), indent=1, default=float)
+
+
+def relerr(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+
+
+def rel_l2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp(min=1e-30))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    from open_musiclm_amd import hip
+    hip.lib()
+    return torch.device("cuda:0")
+
+
+def build_from_golden(golden_dir, name, dev, precision):
+    from open_musiclm_amd import open_musiclm as M
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    stage, kwargs = str(z["meta.stage"]), ast.literal_eval(str(z["meta.kwargs"]))
+    model = getattr(M, f"create_{stage}_transformer")(**kwargs, precision=precision)
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd.")}
+    model.load_state_dict(sd, strict=True)                       # reference checkpoints load strictly
+    return z, model.to(dev)
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("name", ["tiny_coarse", "tiny_fine_allweights", "tiny_semantic_t5_plainff"])
+def test_training_step_matches_reference_golden(golden_dir, dev, monkeypatch, name, precision):
+    from open_musiclm_amd import open_musiclm as M
+    from oracle import musiclm_oracle as O
+    z, model = build_from_golden(golden_dir, name, dev, precision)
+    noise = torch.from_numpy(z["forget_noise"])
+    monkeypatch.setattr(M, "generate_mask_with_prob",
+                        lambda shape, p, device: O.forgetful_mask_from_noise(noise, p).to(device))
+    wrapper = M.TokenConditionedTransformerWrapper(transformer=model, unique_consecutive=False,
+                                                   cross_entropy_loss_weights=list(z["loss_weights"]), mask_prob=0.15)
+    wrapper.train()
+    ids = [torch.from_numpy(z[f"ids.{i}"]).to(dev) for i in range(len(model.token_sequences))]
+    loss, logits, labels = wrapper(all_token_ids=ids, return_loss=True)
+    loss.backward()
+    tol = TOL[precision]
+    e_loss = abs(float(loss) - float(z["loss"])) / float(z["loss"])
+    e_logits = [relerr(l, torch.from_numpy(z[f"logits.{i}"])) for i, l in enumerate(logits)]
+    for i, lb in enumerate(labels):
+        assert torch.equal(lb.cpu(), torch.from_numpy(z[f"labels.{i}"]))
+    grads = {}
+    for k, p in model.named_parameters():
+        gk = "grad." + k
+        if gk not in z.files:
+            continue
+        ref = torch.from_numpy(z[gk])
+        got = p.grad if p.grad is not None else torch.zeros_like(p)
+        if float(ref.abs().max()) < 1e-5 and float(got.abs().max()) < 1e-4:
+            continue
+        grads[k] = relerr(got, ref)
+    worst = max(grads.items(), key=lambda kv: kv[1])
+    report(f"train[{name},{precision}]", loss=e_loss, logits=e_logits, worst_grad=worst, grads=grads)
+    assert e_loss < tol["loss"], e_loss
+    assert max(e_logits) < tol["logits"], e_logits
+    assert worst[1] < tol["grad"], worst
+    # eval-mode forward (no forgetful mask), return_loss=False path
+    wrapper.eval()
+    with torch.no_grad():
+        ev = wrapper(all_token_ids=ids, return_loss=False)
+    e_ev = [relerr(l, torch.from_numpy(z[f"eval_logits.{i}"])) for i, l in enumerate(ev)]
+    assert max(e_ev) < tol["logits"], e_ev
+
+
+def test_logits_path_autograd_matches_fused_loss(golden_dir, dev, monkeypatch):
+    """TokenConditionedTransformer.forward (logits with grad) + torch CE == the fused loss path."""
+    from open_musiclm_amd import open_musiclm as M
+    z, model = build_from_golden(golden_dir, "tiny_coarse", dev, "bf16x3")
+    model.eval()
+    ids = [torch.from_numpy(z[f"ids.{i}"]).to(dev) for i in range(3)]
+    full = [M.append_eos_id(i.reshape(i.shape[0], -1).long(), e) for i, e in zip(ids, model.eos_ids)]
+    logits = model(all_token_ids=[full[0], full[1], full[2][:, :-1]])
+    loss = torch.nn.functional.cross_entropy(logits[-1].transpose(1, 2), full[2])
+    loss.backward()
+    g1 = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    model.zero_grad(set_to_none=True)
+    wrapper = M.TokenConditionedTransformerWrapper(transformer=model, unique_consecutive=False,
+                                                   cross_entropy_loss_weights=[0., 0., 1.], mask_prob=0.0)
+    wrapper.eval()
+    # eval-mode wrapper masks the conditioning eos tokens; replicate by calling the transformer directly above
+    # without a mask, so compare against the fused path under the same (no-mask) conditions:
+    l2, *_ = model.loss_and_logits([full[0], full[1], full[2][:, :-1]], full, None, [0., 0., 1.])
+    l2.backward()
+    assert abs(float(l2) - float(loss)) < 1e-4 * abs(float(loss))
+    worst = max(relerr(p.grad, g1[k]) for k, p in model.named_parameters() if k in g1 and float(g1[k].abs().max()) > 1e-6)
+    report("logits_vs_fused", worst=worst)
+    assert worst < 1e-3
+
+
+@pytest.mark.parametrize("precision", ["bf16x3"])
+def test_generate_matches_reference_golden_ids(golden_dir, dev, precision):
+    from open_musiclm_amd import open_musiclm as M
+    z = np.load(os.path.join(golden_dir, "tiny_coarse_generate.npz"))
+    zt, model = build_from_golden(golden_dir, "tiny_coarse", dev, precision)
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd.")}
+    model.load_state_dict(sd, strict=True)
+    wrapper = M.TokenConditionedTransformerWrapper(transformer=model, unique_consecutive=False)
+    cond = [torch.from_numpy(z["cond.0"]).to(dev), torch.from_numpy(z["cond.1"]).to(dev)]
+    out = wrapper.generate(conditioning_token_ids=cond, max_time_steps=int(z["max_time_steps"]),
+                           temperature=float(z["temperature"]), uniforms=torch.from_numpy(z["uniforms"]))
+    out2 = wrapper.generate(conditioning_token_ids=cond, pred_token_ids=torch.from_numpy(z["prime"]).to(dev),
+                            max_time_steps=int(z["max_time_steps"]), temperature=float(z["temperature"]),
+                            uniforms=torch.from_numpy(z["uniforms_primed"]))
+    report("generate_golden", equal=bool(np.array_equal(out.cpu().numpy(), z["generated"])),
+           got=out.cpu().numpy().tolist(), want=z["generated"].tolist())
+    assert np.array_equal(out.cpu().numpy(), z["generated"])               # bit-exact token ids
+    assert np.array_equal(out2.cpu().numpy(), z["generated_primed"])
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_full_size_coarse_small_vs_oracle(dev, precision):
+    """BASELINE config 2 shapes: musiclm_small coarse stage, N = 1116, B = 2; logits, loss and grads vs the CPU oracle."""
+    from open_musiclm_amd import open_musiclm as M
+    from oracle import musiclm_oracle as O
+    torch.manual_seed(0)
+    model = M.create_coarse_transformer(dim=1024, depth=6, heads=8, num_coarse_quantizers=3, ff_dropout=0.0,
+                                        precision=precision).to(dev)
+    spec = O.coarse_spec(dim=1024, depth=6, heads=8)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ids = O.synthetic_ids(spec, 2, [1, 199, 300], seed=1234)
+    noise = torch.randn(2, 1116, generator=torch.Generator().manual_seed(7))
+    sdo = {k: v.clone().requires_grad_(k in ("transformer.layers.0.2.1.weight", "transformer.layers.5.0.to_q.weight",
+                                             "embeddings.2.weight", "logit_weights.2",
+                                             "transformer.rel_pos_bias.net.1.0.weight",
+                                             "transformer.layers.3.0.to_kv.weight",
+                                             "transformer.layers.2.2.2.ds_conv.weight")) for k, v in sd.items()}
+    o_loss, o_logits, _ = O.wrapper_forward_loss(sdo, spec, ids, [0., 0., 1.], forget_noise=noise)
+    names = [k for k, v in sdo.items() if v.requires_grad]
+    o_grads = dict(zip(names, torch.autograd.grad(o_loss, [sdo[k] for k in names])))
+
+    import open_musiclm_amd.open_musiclm as MM
+    orig = MM.generate_mask_with_prob
+    MM.generate_mask_with_prob = lambda shape, p, device: O.forgetful_mask_from_noise(noise, p).to(device)
+    try:
+        wrapper = M.TokenConditionedTransformerWrapper(transformer=model, unique_consecutive=False,
+                                                       cross_entropy_loss_weights=[0., 0., 1.], mask_prob=0.15)
+        wrapper.train()
+        loss, logits, _ = wrapper(all_token_ids=[t.to(dev) for t in ids], return_loss=True)
+        loss.backward()
+    finally:
+        MM.generate_mask_with_prob = orig
+    e_inf = relerr(logits[-1], o_logits[-1])
+    e_l2 = rel_l2(logits[-1], o_logits[-1])
+    e_loss = abs(float(loss) - float(o_loss)) / float(o_loss)
+    top1 = float((logits[-1].argmax(1).cpu() == o_logits[-1].argmax(1)).float().mean())
+    g = {k: relerr(dict(model.named_parameters())[k].grad, o_grads[k]) for k in names}
+    report(f"full_coarse_small[{precision}]", logits_inf=e_inf, logits_l2=e_l2, loss=e_loss, top1_agree=top1, grads=g,
+           loss_value=float(loss))
+    tol = TOL[precision]
+    assert e_inf < tol["logits"], (e_inf, e_l2)
+    assert e_loss < tol["loss"]
+    assert max(g.values()) < tol["grad"], g
+
+
+def test_trainer_steps_and_checkpoint_roundtrip(dev, tmp_path):
+    from open_musiclm_amd import open_musiclm as M
+    from open_musiclm_amd.data import SyntheticTokenDataset
+    from open_musiclm_amd.trainer import SingleStageTrainer
+    torch.manual_seed(0)
+    model = M.create_coarse_transformer(dim=128, depth=2, heads=2, num_coarse_quantizers=3, ff_dropout=0.1,
+                                        precision="bf16").to(dev)
+    ds = SyntheticTokenDataset("coarse", length=8, coarse_window_seconds=1, semantic_window_seconds=2)
+    tr = SingleStageTrainer(model, "coarse", num_train_steps=30, batch_size=2, dataset=ds, lr=3e-3, lr_warmup=5,
+                            grad_accum_every=2, wd=0.01, max_grad_norm=0.5, valid_frac=0.0, save_results_every=1000,
+                            save_model_every=1000, results_folder=str(tmp_path / "res"), save_predicted_tokens=False,
+                            save_reconstructed_wave=False)
+    losses = [tr.train_step()["loss"] for _ in range(30)]
+    report("trainer", first=losses[0], last=losses[-1])
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0] * 0.9          # memorises 8 samples
+    mp, op, sp = (str(tmp_path / f"coarse.{n}.5.pt") for n in ("transformer", "optimizer", "scheduler"))
+    tr.save(mp, op, sp)
+    sd = torch.load(mp)
+    assert list(sd.keys()) == list(model.state_dict().keys())
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    tr.train_step()
+    tr.steps.zero_()
+    tr.load(mp, op, sp, steps=6)
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    assert int(tr.steps.item()) == 6
+
+
+def test_musiclm_hierarchical_decode_tokens(dev):
+    """MusicLM.forward window stitching on tiny stages: shapes of the 3-level token hierarchy."""
+    from open_musiclm_amd import open_musiclm as M
+    torch.manual_seed(0)
+    kw = dict(dim=64, depth=1, heads=1, precision="bf16")
+    sem = M.create_semantic_transformer(**kw).to(dev)
+    coarse = M.create_coarse_transformer(num_coarse_quantizers=3, **kw).to(dev)
+    fine = M.create_fine_transformer(num_coarse_quantizers=3, num_fine_quantizers=5, **kw).to(dev)
+    mlm = M.MusicLM(wav2vec=None, clap=None, neural_codec=None, semantic_transformer=sem, coarse_transformer=coarse,
+                    fine_transformer=fine)
+    clap_ids = torch.randint(0, 1024, (1, 12, 1), device=dev)
+    s, c, f = mlm.generate(clap_token_ids=clap_ids, output_seconds=2, semantic_window_seconds=1, coarse_window_seconds=1,
+                           fine_window_seconds=1, semantic_steps_per_second=10, acoustic_steps_per_second=6,
+                           return_tokens=True)
+    report("musiclm_tokens", sem=list(s.shape), coarse=list(c.shape), fine=list(f.shape))
+    assert s.shape == (1, 20, 1) and c.shape[0] == 1 and c.shape[2] == 3 and f.shape[2] == 5
+    assert c.shape[1] == f.shape[1]
+    assert int(c.max()) < 1024 and int(c.min()) >= 0

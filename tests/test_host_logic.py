@@ -1,0 +1,273 @@
+"""CPU: host-side logic of the drop-in boundary (no GPU compute): C-ABI export surface, state_dict schema,
+id / label / mask construction, row maps of the logit heads, sampling filters, optimizer grouping, token
+datasets, config loaders, loud failure without a GPU, and the world_size-2 data-parallel exchange over gloo."""
+import io
+import json
+import os
+import re
+import sqlite3
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import musiclm_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_library_exports_every_header_symbol():
+    import __graft_entry__ as G
+    from open_musiclm_amd import hip
+    if not os.path.exists(hip.LIB_PATH):
+        G.build()
+    lib = hip.lib()                                           # also binds every SIGNATURES entry via getattr
+    hdr = open(os.path.join(ROOT, "include", "omlm.h")).read()
+    declared = set(re.findall(r"\b(omlm_\w+)\s*\(", hdr))
+    assert declared == set(hip.SIGNATURES), declared ^ set(hip.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.omlm_version() >= 100
+
+
+def tiny(stage="coarse", **kw):
+    from open_musiclm_amd import open_musiclm as M
+    torch.manual_seed(0)
+    base = dict(dim=128, depth=2, heads=2, attn_dropout=0.0, ff_dropout=0.0)
+    base.update(kw)
+    return getattr(M, f"create_{stage}_transformer")(**base)
+
+
+def test_state_dict_schema_matches_reference_golden(golden_dir):
+    z = np.load(os.path.join(golden_dir, "tiny_coarse.npz"))
+    ref_keys = [k[3:] for k in z.files if k.startswith("sd.")]
+    m = tiny("coarse", num_coarse_quantizers=3, clap_codebook_size=32, semantic_codebook_size=48, acoustic_codebook_size=40)
+    assert list(m.state_dict().keys()) == ref_keys
+    m.load_state_dict({k: torch.from_numpy(z["sd." + k]) for k in ref_keys}, strict=True)
+    z2 = np.load(os.path.join(golden_dir, "tiny_semantic_t5_plainff.npz"))
+    m2 = tiny("semantic", use_conv_ff=False, relative_position_bias_type="t5", clap_codebook_size=32, semantic_codebook_size=48)
+    assert list(m2.state_dict().keys()) == [k[3:] for k in z2.files if k.startswith("sd.")]
+
+
+def test_forward_fails_loudly_without_gpu():
+    m = tiny("coarse", num_coarse_quantizers=3)
+    ids = [torch.zeros(1, 12, dtype=torch.long), torch.zeros(1, 4, dtype=torch.long), torch.zeros(1, 6, dtype=torch.long)]
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(all_token_ids=ids)
+    from open_musiclm_amd.optimizer import get_optimizer
+    opt = get_optimizer(m.parameters(), lr=1e-3, wd=0.01)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        opt.step()
+
+
+def test_wrapper_prepare_matches_oracle_ids_labels_mask():
+    from open_musiclm_amd import open_musiclm as M
+    m = tiny("coarse", num_coarse_quantizers=3)
+    w = M.TokenConditionedTransformerWrapper(transformer=m, unique_consecutive=False, cross_entropy_loss_weights=[0, 0, 1])
+    spec = O.coarse_spec(dim=128, depth=2, heads=2)
+    ids = O.synthetic_ids(spec, 3, [1, 7, 5], seed=2)
+    w.eval()
+    got_ids, got_labels, got_mask = w._prepare([t.clone() for t in ids], True, False)
+    exp_ids, exp_labels, exp_mask = O.build_training_inputs(ids, spec)
+    for a, b in zip(got_ids, exp_ids):
+        assert torch.equal(a, b)
+    for a, b in zip(got_labels, exp_labels):
+        assert torch.equal(a, b)
+    assert torch.equal(got_mask, exp_mask)
+    # training mode adds the forgetful mask: int(0.15 N) keys dropped per row, never position 0
+    w.train()
+    torch.manual_seed(3)
+    _, _, tm = w._prepare([t.clone() for t in ids], True, False)
+    n = tm.shape[1]
+    assert tm[:, 0].all()
+    assert ((exp_mask & ~tm).sum(1) <= int(0.15 * n)).all() and ((~tm).sum(1) >= int(0.15 * n)).all()
+    with pytest.raises(AssertionError):
+        w._prepare(ids, True, True)                        # eos in training input is rejected like the reference
+
+
+def test_build_ids_offsets_pads_and_layout_maps():
+    from open_musiclm_amd import engine
+    m = tiny("fine", num_coarse_quantizers=3, num_fine_quantizers=5)
+    B = 2
+    clap = torch.randint(0, 1024, (B, 12))
+    coarse = torch.randint(0, 1024, (B, 7))                # ragged: 7 is not a multiple of 3
+    fine = torch.randint(0, 1024, (B, 11))
+    clap[0, 0] = -1                                        # pad at quantizer 0 stays a pad ...
+    clap[0, 1] = -1                                        # ... but -1 at quantizer 1 becomes 1023 (reference quirk, :126-134)
+    ids32, lens = engine.build_ids(m, [clap, coarse, fine])
+    assert lens == [12, 7, 11] and ids32.shape == (B, 12 + 7 + 11 + 3)
+    assert int(ids32[0, 0]) == -2 and int(ids32[0, 1]) == -1 and int(ids32[0, 2]) == 1023
+    assert int(ids32[1, 3]) == int(clap[1, 2]) + 2 * 1024
+    assert int(ids32[0, 13]) == -2 and int(ids32[0, 14 + 4]) == int(coarse[0, 4]) + 1024
+    lay = engine.build_layout(B, lens, [12, 3, 5], "cpu")
+    assert lay.N == 33 and lay.starts == (0, 13, 21) and lay.n_out == (12, 7, 12)
+    # every logit row of every sequence is produced by exactly one (sequence, quantizer) GEMM, from hidden
+    # position start + j with head j mod Q (open_musiclm.py:149-186 incl. the remainder handling)
+    for s, (Q, n_s, st) in enumerate(zip([12, 3, 5], lay.n_out, lay.starts)):
+        seen = torch.zeros(B * n_s, dtype=torch.int32)
+        for qq in range(Q):
+            if (s, qq) not in lay.head_maps:
+                continue
+            a_map, c_map, rows = lay.head_maps[(s, qq)]
+            assert rows == a_map.numel() == c_map.numel()
+            j = c_map % n_s
+            b = c_map // n_s
+            assert ((j % Q) == qq).all()
+            assert torch.equal(a_map, (b * lay.N + st + j).to(torch.int32))
+            seen[c_map.long()] += 1
+        assert (seen == 1).all()
+    fin = engine.build_layout(B, lens, [12, 3, 5], "cpu", final_rows_only=True)
+    (key, (a_map, c_map, rows)), = fin.head_maps.items()
+    assert key == (2, 11 % 5) and rows == B and torch.equal(c_map, torch.arange(B, dtype=torch.int32))
+    assert torch.equal(a_map, (torch.arange(B) * 33 + 21 + 11).to(torch.int32))
+
+
+def test_sampling_helpers_match_oracle():
+    from open_musiclm_amd import utils as U
+    torch.manual_seed(0)
+    x = torch.randn(4, 1025)
+    assert torch.equal(U.top_k(x, 0.9), O.top_k_filter(x, 0.9))
+    assert int((U.top_k(x, 0.9) > -float("inf")).sum(1)[0]) == 102
+    t = torch.tensor([[1, 5, 9, 5, 2], [9, 1, 2, 3, 4], [1, 2, 3, 4, 5]])
+    for keep in (True, False):
+        assert torch.equal(U.mask_out_after_eos_id(t, 9, keep_eos=keep), O.mask_out_after_eos(t, 9, keep))
+    torch.manual_seed(5)
+    a = U.generate_mask_with_prob((3, 40), 0.15, "cpu")
+    torch.manual_seed(5)
+    assert torch.equal(a, O.forgetful_mask_from_noise(torch.randn(3, 40), 0.15))
+    u = torch.rand(4, 1025)
+    torch.manual_seed(7)
+    ref = (x / 0.95 + (-torch.log(-torch.log(u + 1e-20) + 1e-20))).argmax(-1)
+    assert torch.equal(O.gumbel_argmax(x, u, 0.95), ref)
+
+
+def test_optimizer_grouping_and_state_dict_shape():
+    from open_musiclm_amd.optimizer import FusedAdam, get_optimizer, get_linear_scheduler
+    m = tiny("semantic")
+    opt = get_optimizer(m.parameters(), lr=3e-4, wd=0.01)
+    assert isinstance(opt, FusedAdam) and len(opt.param_groups) == 2
+    assert all(p.ndim >= 2 for p in opt.param_groups[0]["params"]) and opt.param_groups[0]["weight_decay"] == 0.01
+    assert all(p.ndim < 2 for p in opt.param_groups[1]["params"]) and opt.param_groups[1]["weight_decay"] == 0
+    assert opt.param_groups[0]["betas"] == (0.9, 0.99) and opt.param_groups[0]["decoupled"]
+    plain = get_optimizer(m.parameters(), lr=3e-4, wd=0)
+    assert len(plain.param_groups) == 1 and not plain.param_groups[0]["decoupled"]
+    sched = get_linear_scheduler(opt, total_iters=10)
+    assert abs(opt.param_groups[0]["lr"] - 3e-4 * 1e-7) < 1e-12       # LinearLR warm-up from 1e-7 (optimizer.py:36-41)
+    # same two-group ordering as torch AdamW built the reference's way -> interchangeable param indices
+    n_wd = len(opt.param_groups[0]["params"])
+    assert n_wd + len(opt.param_groups[1]["params"]) == len(list(m.parameters()))
+
+
+def _write_db(path, rows):
+    def blob(a):
+        b = io.BytesIO()
+        np.save(b, a)
+        return sqlite3.Binary(b.getvalue())
+    conn = sqlite3.connect(path)
+    conn.execute("create table tokens (idx integer primary key, path text, clap array, semantic array, coarse array, fine array)")
+    for i, r in enumerate(rows):
+        conn.execute("insert into tokens values (?,?,?,?,?,?)", (i, f"f{i}.mp3", *[blob(a) for a in r]))
+    conn.commit()
+    conn.close()
+
+
+def test_preprocessed_dataset_reads_reference_sqlite_format(tmp_path):
+    from open_musiclm_amd.data import PreprocessedDataset, get_preprocessed_dataloader
+    secs = 14
+    rng = np.random.RandomState(0)
+    rows = []
+    for _ in range(3):
+        rows.append((rng.randint(0, 1024, (secs - 10 + 1, 12, 1)).astype(np.uint16),        # one clap row per sliding 10 s window
+                     rng.randint(0, 1024, (1, secs * 50 - 1)).astype(np.uint16),
+                     rng.randint(0, 1024, (1, secs * 75, 3)).astype(np.uint16),
+                     rng.randint(0, 1024, (1, secs * 75, 5)).astype(np.uint16)))
+    _write_db(str(tmp_path / "preprocessed.db"), rows)
+    for stage, shapes in (("semantic", [(2, 12, 1), (2, 499)]), ("coarse", [(2, 12, 1), (2, 199), (2, 300, 3)]),
+                          ("fine", [(2, 12, 1), (2, 150, 3), (2, 150, 5)])):
+        ds = PreprocessedDataset(str(tmp_path), stage=stage)
+        assert len(ds) == 3
+        batch = next(iter(get_preprocessed_dataloader(ds, batch_size=2)))
+        assert [tuple(t.shape) for t in batch] == shapes and all(t.dtype == torch.int32 for t in batch)
+    # crops are consistent slices of the stored arrays (coarse stage: semantic and coarse share the inner window)
+    import random
+    random.seed(1)
+    ds = PreprocessedDataset(str(tmp_path), stage="coarse")
+    clap, sem, coarse = ds[1]
+    full_sem, full_coarse = torch.from_numpy(rows[1][1].astype(np.int32)), torch.from_numpy(rows[1][2].astype(np.int32))
+    starts = [s for s in range(0, secs - 3) if torch.equal(full_sem[:, s * 50: s * 50 + 199], sem)]
+    assert len(starts) >= 1 and any(torch.equal(full_coarse[:, s * 75: s * 75 + 300], coarse) for s in starts)
+
+
+def test_synthetic_dataset_shapes_match_survey_lengths():
+    from open_musiclm_amd.data import SyntheticTokenDataset
+    from open_musiclm_amd import engine
+    for stage, N, q in (("semantic", 514, [12, 1]), ("coarse", 1116, [12, 1, 3]), ("fine", 1217, [12, 3, 5])):
+        item = SyntheticTokenDataset(stage)[0]
+        lens = [int(np.prod(t.shape[1:])) + 1 for t in item]          # + eos
+        lens[-1] -= 1                                                  # last token dropped for the loss
+        assert engine.build_layout(1, lens, q, "cpu").N == N           # SURVEY.md §8 table [probed with the reference]
+
+
+def test_config_loaders_roundtrip(tmp_path):
+    from open_musiclm_amd import config as Cfg
+    model_json = dict(
+        global_cfg=dict(semantic_audio_length_seconds=10.0, coarse_audio_length_seconds=4.0, fine_audio_length_seconds=2.0,
+                        clap_audio_length_seconds=10.0, num_coarse_quantizers=3, num_fine_quantizers=5),
+        clap_rvq_cfg=dict(enable_fusion=False, rq_num_quantizers=12, codebook_size=1024, rq_ema_decay=0.95, threshold_ema_dead_code=0.5),
+        hubert_kmeans_cfg=dict(model_name="m-a-p/MERT-v0", normalize_embeds=True, embed_layer=7, target_sample_hz=16000,
+                               seq_len_multiple_of=320, codebook_size=1024, output_hz=50),
+        encodec_cfg=dict(bandwidth=6.0, codebook_size=1024, output_hz=75),
+        semantic_cfg=dict(dim=128, depth=1, heads=2), coarse_cfg=dict(dim=128, depth=1, heads=2, ff_dropout=0.0),
+        fine_cfg=dict(dim=128, depth=1, heads=2))
+    stage = dict(folder="./x", valid_frac=0.05, lr=3e-4, lr_warmup=3000, batch_size=4, grad_accum_every=8, wd=0.01,
+                 max_grad_norm=0.5, cross_entropy_loss_weights=[0.0, 1.0], num_train_steps=10, save_results_every=5,
+                 save_model_every=5, save_predicted_tokens=True, save_reconstructed_wave=True, use_preprocessed_data=False)
+    train_json = dict(
+        clap_rvq_trainer_cfg=dict(folder="./x", num_train_steps=1, batch_size=2, accumulate_batches=1, save_model_every=1, save_results_every=1),
+        hubert_kmeans_trainer_cfg=dict(folder="./x", feature_extraction_num_steps=1, feature_extraction_batch_size=1),
+        semantic_trainer_cfg=dict(stage="semantic", **stage),
+        coarse_trainer_cfg=dict(stage="coarse", **{**stage, "cross_entropy_loss_weights": [0.0, 0.0, 1.0]}),
+        fine_trainer_cfg=dict(stage="fine", **{**stage, "cross_entropy_loss_weights": [0.0, 0.0, 1.0]}),
+        data_preprocessor_cfg={})
+    (tmp_path / "m.json").write_text(json.dumps(model_json))
+    (tmp_path / "t.json").write_text(json.dumps(train_json))
+    mc = Cfg.load_model_config(str(tmp_path / "m.json"))
+    tc = Cfg.load_training_config(str(tmp_path / "t.json"))
+    assert mc.coarse_cfg.relative_position_bias_type == "continuous" and tc.coarse_trainer_cfg.grad_accum_every == 8
+    t = Cfg.create_coarse_transformer_from_config(mc, None, "cpu")
+    assert [s.num_quantizers for s in t.token_sequences] == [12, 1, 3] and t.eos_ids == [1024, 1024, 1024]
+    # the reference's scripts import through the `open_musiclm` package name
+    from open_musiclm.config import load_model_config as aliased
+    assert aliased is Cfg.load_model_config
+
+
+DP_SCRIPT = r"""
+import os, sys, torch
+sys.path.insert(0, %r)
+from open_musiclm_amd.parallel import DataParallel
+dp = DataParallel(device=torch.device('cpu'))
+assert dp.world_size == 2 and dp.is_distributed
+g = torch.full((1000,), float(dp.rank + 1))
+dp.allreduce_sum_(g)                                  # THE single gradient exchange
+assert torch.allclose(g * dp.grad_scale(), torch.full((1000,), 1.5))
+m = dp.reduce_mean(torch.tensor([float(dp.rank)]))
+assert abs(float(m) - 0.5) < 1e-6
+cat = dp.all_gather_cat(torch.full((2, 3), dp.rank))
+assert cat.shape == (4, 3) and int(cat[0, 0]) == 0 and int(cat[3, 0]) == 1
+p = torch.full((5,), float(dp.rank)); dp.broadcast_(p, 0); assert float(p.sum()) == 0.0
+dp.barrier(); dp.shutdown()
+print('rank', dp.rank, 'ok')
+"""
+
+
+def test_data_parallel_exchange_world_size_2_gloo(tmp_path):
+    script = tmp_path / "dp.py"
+    script.write_text(DP_SCRIPT % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("ok" in o for o in outs)
