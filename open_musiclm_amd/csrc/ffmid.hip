@@ -11,7 +11,7 @@
 #include "common.h"
 
 #define FF_THREADS 256
-#define FF_MAXC 3          // 8-channel chunks per thread -> Fp <= 6144
+#define FF_MAXC_LIMIT 16   // 8-channel chunks per lane (wave-per-row kernels) -> Fp <= 8192
 
 template <typename T> struct vec8;
 template <> struct vec8<float> {
@@ -81,57 +81,78 @@ __device__ __forceinline__ void dropout8(unsigned long long seed, unsigned long 
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(FF_THREADS) void ffmid_fwd_kernel(const T* __restrict__ h1, const float* __restrict__ convw,
-                                                               const float* __restrict__ gamma, T* __restrict__ h2,
-                                                               float* __restrict__ mean, float* __restrict__ rstd,
-                                                               int M, int nseq, int F, int Fp, float eps, float p,
-                                                               unsigned long long seed) {
-    __shared__ float red[FF_THREADS / 64];
-    const int nchunk = Fp / 8, ld = 2 * Fp;
-    for (int row = blockIdx.x; row < M; row += gridDim.x) {
+// One WAVE per row: the row's F channels are spread over the 64 lanes in 8-channel chunks, the two LayerNorm
+// reductions are wave shuffles (no LDS, no barrier), and a 256-thread workgroup keeps 4 independent rows in
+// flight -- at ~4 waves/SIMD that is ~16 rows per CU hiding HBM latency, instead of one row per workgroup
+// serialised behind two block-wide reductions.
+// (n, mean, M2) merge of two partial statistics (Chan et al.); n == 0 partials are neutral
+__device__ __forceinline__ void welford_merge(float& n, float& mean, float& m2, float nb, float meanb, float m2b) {
+    const float nt = n + nb;
+    if (nt > 0.f) {
+        const float d = meanb - mean, r = nb / nt;
+        mean += d * r;
+        m2 += m2b + d * d * n * r;
+    }
+    n = nt;
+}
+
+template <typename T, int MAXC>
+__global__ __launch_bounds__(FF_THREADS, 4) void ffmid_fwd_kernel(const T* __restrict__ h1, const float* __restrict__ convw,
+                                                                  const float* __restrict__ gamma, T* __restrict__ h2,
+                                                                  float* __restrict__ mean, float* __restrict__ rstd,
+                                                                  int M, int nseq, int F, int Fp, float eps, float p,
+                                                                  unsigned long long seed) {
+    const int lane = threadIdx.x & 63;
+    const int ld = 2 * Fp;
+    const int nwaves = gridDim.x * (FF_THREADS / 64);
+    for (int row = blockIdx.x * (FF_THREADS / 64) + (threadIdx.x >> 6); row < M; row += nwaves) {
         const int t = row % nseq;
-        float g[FF_MAXC][8];
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < FF_MAXC; ++k) {
-            const int ch = (threadIdx.x + k * FF_THREADS) * 8;
-            if (ch < Fp) {
-                float ux[8], ug[8];
+        // sweep 1: LayerNorm statistics of g = gelu(gate) * value over the F real channels (single pass, Welford)
+        float wn = 0.f, wmean = 0.f, wm2 = 0.f;
+#pragma unroll 1
+        for (int k = 0; k < MAXC; ++k) {
+            const int ch = (lane + 64 * k) * 8;
+            if (ch < F) {
+                float ux[8], ug[8], gv[8];
                 conv_row<T>(h1, convw, row, t, ld, ch, ch, F - ch, ux);
                 conv_row<T>(h1, convw, row, t, ld, Fp + ch, F + ch, F - ch, ug);
+                const int nv = min(8, F - ch);
+                float cs = 0.f;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    g[k][i] = (ch + i < F) ? gelu_f(ug[i]) * ux[i] : 0.f;
-                    s += g[k][i];
-                }
+                for (int i = 0; i < 8; ++i) { gv[i] = gelu_f(ug[i]) * ux[i]; if (i < nv) cs += gv[i]; }
+                const float cm = cs / (float)nv;
+                float c2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) if (i < nv) { const float d = gv[i] - cm; c2 += d * d; }
+                welford_merge(wn, wmean, wm2, (float)nv, cm, c2);
             }
         }
-        const float mu = block_sum<FF_THREADS>(s, red) / (float)F;
-        float q = 0.f;
 #pragma unroll
-        for (int k = 0; k < FF_MAXC; ++k) {
-            const int ch = (threadIdx.x + k * FF_THREADS) * 8;
-            if (ch < Fp) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) if (ch + i < F) { const float d = g[k][i] - mu; q += d * d; }
-            }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float nb = __shfl_xor(wn, o, 64), mb = __shfl_xor(wmean, o, 64), qb = __shfl_xor(wm2, o, 64);
+            welford_merge(wn, wmean, wm2, nb, mb, qb);
         }
-        const float rs = rsqrtf(block_sum<FF_THREADS>(q, red) / (float)F + eps);
-        if (threadIdx.x == 0) { mean[row] = mu; rstd[row] = rs; }
-#pragma unroll
-        for (int k = 0; k < FF_MAXC; ++k) {
-            const int ch = (threadIdx.x + k * FF_THREADS) * 8;
+        const float mu = wmean;
+        const float rs = rsqrtf(wm2 / (float)F + eps);
+        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+        // sweep 2: recompute (the three h1 rows are L1/L2 hits now), normalise, dropout, store
+#pragma unroll 1
+        for (int k = 0; k < MAXC; ++k) {
+            const int ch = (lane + 64 * k) * 8;
             if (ch < Fp) {
-                float m[8];
+                float ux[8], ug[8], m[8];
+                conv_row<T>(h1, convw, row, t, ld, ch, ch, F - ch, ux);
+                conv_row<T>(h1, convw, row, t, ld, Fp + ch, F + ch, F - ch, ug);
                 if (p > 0.f) dropout8(seed, (unsigned long long)row * Fp + ch, p, m);
                 vec8<T> o;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const float gm = (ch + i < F) ? gamma[ch + i] : 0.f;
-                    float y = (g[k][i] - mu) * rs * gm;
-                    if (p > 0.f) y *= m[i];
-                    o.v[i] = (ch + i < F) ? y : 0.f;
+                    float y = 0.f;
+                    if (ch + i < F) {
+                        y = (gelu_f(ug[i]) * ux[i] - mu) * rs * gamma[ch + i];
+                        if (p > 0.f) y *= m[i];
+                    }
+                    o.v[i] = y;
                 }
                 o.store(h2 + (size_t)row * Fp + ch);
             }
@@ -139,75 +160,84 @@ __global__ __launch_bounds__(FF_THREADS) void ffmid_fwd_kernel(const T* __restri
     }
 }
 
-// Backward, stage 1 (row-local): dh2 -> dropout^T -> LayerNorm^T -> GEGLU^T  => du [M, 2*Fp]
-// plus per-block partial sums of dgamma (thread owns its channels over the block's rows).
-template <typename T>
-__global__ __launch_bounds__(FF_THREADS) void ffmid_bwd1_kernel(const T* __restrict__ dh2, const T* __restrict__ h1,
+// Backward, stage 1 (row-local): dh2 -> dropout^T -> LayerNorm^T -> GEGLU^T  => du [M, 2*Fp].
+// Wave per row, two sweeps over the row's chunks (sums first, outputs second; the second sweep re-reads the three
+// h1 rows and dh2 from L1/L2) so that nothing but the two reduction scalars lives across the sweep boundary.
+// dgamma is accumulated in an LDS array per workgroup (ds_add_f32) and written once as a partial row.
+template <typename T, int MAXC>
+__global__ __launch_bounds__(FF_THREADS, 4) void ffmid_bwd1_kernel(const T* __restrict__ dh2, const T* __restrict__ h1,
                                                                 const float* __restrict__ convw, const float* __restrict__ gamma,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 T* __restrict__ du, float* __restrict__ part_dgamma,
                                                                 int M, int nseq, int F, int Fp, float p, unsigned long long seed) {
-    __shared__ float red[FF_THREADS / 64];
+    extern __shared__ float dg_lds[];                    // [Fp]
+    for (int c = threadIdx.x; c < Fp; c += FF_THREADS) dg_lds[c] = 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
     const int ld = 2 * Fp;
-    float dgam[FF_MAXC][8];
-#pragma unroll
-    for (int k = 0; k < FF_MAXC; ++k) zero8(dgam[k]);
-    for (int row = blockIdx.x; row < M; row += gridDim.x) {
+    const int nwaves = gridDim.x * (FF_THREADS / 64);
+    for (int row = blockIdx.x * (FF_THREADS / 64) + (threadIdx.x >> 6); row < M; row += nwaves) {
         const int t = row % nseq;
         const float mu = mean[row], rs = rstd[row];
-        float ux[FF_MAXC][8], ug[FF_MAXC][8], gy[FF_MAXC][8], gh[FF_MAXC][8];
         float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int k = 0; k < FF_MAXC; ++k) {
-            const int ch = (threadIdx.x + k * FF_THREADS) * 8;
+#pragma unroll 1
+        for (int k = 0; k < MAXC; ++k) {
+            const int ch = (lane + 64 * k) * 8;
             if (ch < Fp) {
-                conv_row<T>(h1, convw, row, t, ld, ch, ch, F - ch, ux[k]);
-                conv_row<T>(h1, convw, row, t, ld, Fp + ch, F + ch, F - ch, ug[k]);
+                float ux[8], ug[8], m[8];
+                conv_row<T>(h1, convw, row, t, ld, ch, ch, F - ch, ux);
+                conv_row<T>(h1, convw, row, t, ld, Fp + ch, F + ch, F - ch, ug);
                 vec8<T> d;
                 d.load(dh2 + (size_t)row * Fp + ch);
-                float m[8];
                 if (p > 0.f) dropout8(seed, (unsigned long long)row * Fp + ch, p, m);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const bool ok = ch + i < F;
-                    const float gv = ok ? gelu_f(ug[k][i]) * ux[k][i] : 0.f;
-                    float dyv = ok ? d.v[i] : 0.f;
-                    if (p > 0.f) dyv *= m[i];
-                    gh[k][i] = ok ? (gv - mu) * rs : 0.f;
-                    dgam[k][i] += dyv * gh[k][i];
-                    gy[k][i] = ok ? dyv * gamma[ch + i] : 0.f;
-                    s1 += gy[k][i];
-                    s2 += gy[k][i] * gh[k][i];
+                    if (ch + i < F) {
+                        const float gh = (gelu_f(ug[i]) * ux[i] - mu) * rs;
+                        float dyv = d.v[i];
+                        if (p > 0.f) dyv *= m[i];
+                        atomicAdd(dg_lds + ch + i, dyv * gh);
+                        const float gy = dyv * gamma[ch + i];
+                        s1 += gy;
+                        s2 += gy * gh;
+                    }
                 }
             }
         }
-        const float m1 = block_sum<FF_THREADS>(s1, red) / (float)F;
-        const float m2 = block_sum<FF_THREADS>(s2, red) / (float)F;
-#pragma unroll
-        for (int k = 0; k < FF_MAXC; ++k) {
-            const int ch = (threadIdx.x + k * FF_THREADS) * 8;
+        const float m1 = wave_sum(s1) / (float)F;
+        const float m2 = wave_sum(s2) / (float)F;
+#pragma unroll 1
+        for (int k = 0; k < MAXC; ++k) {
+            const int ch = (lane + 64 * k) * 8;
             if (ch < Fp) {
-                vec8<T> ox, og;
+                float ux[8], ug[8], m[8];
+                conv_row<T>(h1, convw, row, t, ld, ch, ch, F - ch, ux);
+                conv_row<T>(h1, convw, row, t, ld, Fp + ch, F + ch, F - ch, ug);
+                vec8<T> d, ox, og;
+                d.load(dh2 + (size_t)row * Fp + ch);
+                if (p > 0.f) dropout8(seed, (unsigned long long)row * Fp + ch, p, m);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const bool ok = ch + i < F;
-                    const float dg = ok ? rs * (gy[k][i] - m1 - gh[k][i] * m2) : 0.f;
-                    ox.v[i] = dg * gelu_f(ug[k][i]);
-                    og.v[i] = dg * ux[k][i] * gelu_grad_f(ug[k][i]);
+                    float dx = 0.f, dgt = 0.f;
+                    if (ch + i < F) {
+                        const float ge = gelu_f(ug[i]);
+                        const float gh = (ge * ux[i] - mu) * rs;
+                        float dyv = d.v[i];
+                        if (p > 0.f) dyv *= m[i];
+                        const float dg = rs * (dyv * gamma[ch + i] - m1 - gh * m2);
+                        dx = dg * ge;
+                        dgt = dg * ux[i] * gelu_grad_f(ug[i]);
+                    }
+                    ox.v[i] = dx;
+                    og.v[i] = dgt;
                 }
                 ox.store(du + (size_t)row * ld + ch);
                 og.store(du + (size_t)row * ld + Fp + ch);
             }
         }
     }
-#pragma unroll
-    for (int k = 0; k < FF_MAXC; ++k) {
-        const int ch = (threadIdx.x + k * FF_THREADS) * 8;
-        if (ch < Fp) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) part_dgamma[(size_t)blockIdx.x * Fp + ch + i] = dgam[k][i];
-        }
-    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < Fp; c += FF_THREADS) part_dgamma[(size_t)blockIdx.x * Fp + c] = dg_lds[c];
 }
 
 // Backward, stage 2 (conv^T): dh1[t] = w2 du[t] + w1 du[t+1] + w0 du[t+2] (within the sample), and
@@ -268,20 +298,23 @@ __global__ __launch_bounds__(FF_THREADS) void ffmid_bwd2_kernel(const T* __restr
 __global__ void colsum_kernel(const float* __restrict__ part, float* __restrict__ out, int P, int C, int ldp) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    const int per = (P + gridDim.y - 1) / gridDim.y;
+    const int p0 = blockIdx.y * per, p1 = min(P, p0 + per);
     float s = 0.f;
-    for (int p = 0; p < P; ++p) s += part[(size_t)p * ldp + c];
-    out[c] += s;
+    for (int p = p0; p < p1; ++p) s += part[(size_t)p * ldp + c];
+    if (p1 > p0) unsafeAtomicAdd(out + c, s);
 }
 
 extern "C" int omlm_colsum_accumulate(const float* part, float* out, int P, int C, int ldp, void* stream) {
     if (P <= 0 || C <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(part && out && ldp >= C, "colsum arguments");
-    hipLaunchKernelGGL(colsum_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), part, out, P, C, ldp);
+    const int ysplit = P >= 64 ? 16 : 1;
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + 255) / 256, ysplit), dim3(256), 0, as_stream(stream), part, out, P, C, ldp);
     return omlm_post_launch("omlm_colsum_accumulate");
 }
 
-#define FF_BWD1_BLOCKS 512
-#define FF_BWD2_STRIPS 64
+#define FF_BWD1_BLOCKS 1024
+#define FF_BWD2_STRIPS 512
 
 extern "C" long long omlm_ffmid_bwd_workspace_bytes(int F, int Fp) {
     return (long long)sizeof(float) * ((long long)FF_BWD1_BLOCKS * Fp + (long long)FF_BWD2_STRIPS * 2 * F * 3);
@@ -291,14 +324,16 @@ extern "C" int omlm_ffmid_fwd(const void* h1, const float* convw, const float* g
                               int M, int nseq, int F, int Fp, float eps, float p, unsigned long long seed, int dtype, void* stream) {
     if (M <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(h1 && convw && gamma && h2 && mean && rstd, "null pointer");
-    OMLM_CHECK_ARG(Fp % 8 == 0 && Fp >= F && Fp <= 8 * FF_THREADS * FF_MAXC, "Fp must be F rounded up to 8 and <= 6144");
+    OMLM_CHECK_ARG(Fp % 8 == 0 && Fp >= F && Fp <= 512 * FF_MAXC_LIMIT, "Fp must be F rounded up to 8 and <= 8192");
     OMLM_CHECK_ARG(nseq > 0 && M % nseq == 0, "M must be batch * nseq");
     OMLM_CHECK_ARG(p >= 0.f && p < 1.f, "dropout p");
-    dim3 grid(M < 8192 ? M : 8192), block(FF_THREADS);
-    if (dtype == 0)
-        hipLaunchKernelGGL(ffmid_fwd_kernel<float>, grid, block, 0, as_stream(stream), (const float*)h1, convw, gamma, (float*)h2, mean, rstd, M, nseq, F, Fp, eps, p, seed);
-    else
-        hipLaunchKernelGGL(ffmid_fwd_kernel<bf16_t>, grid, block, 0, as_stream(stream), (const bf16_t*)h1, convw, gamma, (bf16_t*)h2, mean, rstd, M, nseq, F, Fp, eps, p, seed);
+    const int rows4 = (M + 3) / 4;
+    dim3 grid(rows4 < 4096 ? rows4 : 4096), block(FF_THREADS);
+    hipStream_t st = as_stream(stream);
+#define FF_FWD(T_, MC_) hipLaunchKernelGGL((ffmid_fwd_kernel<T_, MC_>), grid, block, 0, st, (const T_*)h1, convw, gamma, (T_*)h2, mean, rstd, M, nseq, F, Fp, eps, p, seed)
+#define FF_FWD_DISPATCH(T_) do { const int mc = (Fp / 8 + 63) / 64; \
+        if (mc <= 2) FF_FWD(T_, 2); else if (mc <= 6) FF_FWD(T_, 6); else if (mc <= 8) FF_FWD(T_, 8); else FF_FWD(T_, 16); } while (0)
+    if (dtype == 0) FF_FWD_DISPATCH(float); else FF_FWD_DISPATCH(bf16_t);
     return omlm_post_launch("omlm_ffmid_fwd");
 }
 
@@ -309,19 +344,24 @@ extern "C" int omlm_ffmid_bwd(const void* dh2, const void* h1, const float* conv
                               int M, int nseq, int F, int Fp, float p, unsigned long long seed, int dtype, void* stream) {
     if (M <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(dh2 && h1 && convw && gamma && mean && rstd && du_tmp && dh1 && workspace, "null pointer");
-    OMLM_CHECK_ARG(Fp % 8 == 0 && Fp >= F && Fp <= 8 * FF_THREADS * FF_MAXC, "Fp must be F rounded up to 8 and <= 6144");
+    OMLM_CHECK_ARG(Fp % 8 == 0 && Fp >= F && Fp <= 512 * FF_MAXC_LIMIT, "Fp must be F rounded up to 8 and <= 8192");
     OMLM_CHECK_ARG(nseq > 0 && M % nseq == 0, "M must be batch * nseq");
     hipStream_t st = as_stream(stream);
     float* part_g = workspace;
     float* part_c = workspace + (size_t)FF_BWD1_BLOCKS * Fp;
-    const int b1 = M < FF_BWD1_BLOCKS ? M : FF_BWD1_BLOCKS;
+    const int rows4 = (M + 3) / 4;
+    const int b1 = rows4 < FF_BWD1_BLOCKS ? rows4 : FF_BWD1_BLOCKS;
     const int strips = M < FF_BWD2_STRIPS ? M : FF_BWD2_STRIPS;
     dim3 g2((2 * Fp / 8 + FF_THREADS - 1) / FF_THREADS, strips);
+    const size_t lds1 = (size_t)Fp * sizeof(float);
+#define FF_B1(T_, MC_) hipLaunchKernelGGL((ffmid_bwd1_kernel<T_, MC_>), dim3(b1), dim3(FF_THREADS), lds1, st, (const T_*)dh2, (const T_*)h1, convw, gamma, mean, rstd, (T_*)du_tmp, part_g, M, nseq, F, Fp, p, seed)
+#define FF_B1_DISPATCH(T_) do { const int mc = (Fp / 8 + 63) / 64; \
+        if (mc <= 2) FF_B1(T_, 2); else if (mc <= 6) FF_B1(T_, 6); else if (mc <= 8) FF_B1(T_, 8); else FF_B1(T_, 16); } while (0)
     if (dtype == 0) {
-        hipLaunchKernelGGL(ffmid_bwd1_kernel<float>, dim3(b1), dim3(FF_THREADS), 0, st, (const float*)dh2, (const float*)h1, convw, gamma, mean, rstd, (float*)du_tmp, part_g, M, nseq, F, Fp, p, seed);
+        FF_B1_DISPATCH(float);
         hipLaunchKernelGGL(ffmid_bwd2_kernel<float>, g2, dim3(FF_THREADS), 0, st, (const float*)du_tmp, (const float*)h1, convw, (float*)dh1, part_c, M, nseq, F, Fp);
     } else {
-        hipLaunchKernelGGL(ffmid_bwd1_kernel<bf16_t>, dim3(b1), dim3(FF_THREADS), 0, st, (const bf16_t*)dh2, (const bf16_t*)h1, convw, gamma, mean, rstd, (bf16_t*)du_tmp, part_g, M, nseq, F, Fp, p, seed);
+        FF_B1_DISPATCH(bf16_t);
         hipLaunchKernelGGL(ffmid_bwd2_kernel<bf16_t>, g2, dim3(FF_THREADS), 0, st, (const bf16_t*)du_tmp, (const bf16_t*)h1, convw, (bf16_t*)dh1, part_c, M, nseq, F, Fp);
     }
     int rc = omlm_post_launch("omlm_ffmid_bwd");

@@ -26,6 +26,16 @@
 // (hardware returns 0), so M, N and K may be ragged at 8-element granularity.
 // Optional row maps (int32) gather A rows / k rows and scatter C rows: this is how the
 // per-quantizer logit heads read the positions p = q (mod Q) of the hidden states in place.
+//
+// bf16 operands take the LDS-DMA path (gemm_bf16_kernel): tiles go HBM -> LDS directly with
+// buffer_load_dwordx4 ... lds (no VGPR staging, no ds_write pass), the swizzle is applied on the
+// per-lane SOURCE address (the DMA destination is lane-linear), LDS is double-buffered and there
+// is ONE barrier per k-tile: the DMA of tile t+1 is in flight while tile t is on the matrix cores.
+// fp32 operands (bf16x3) keep the register-staged path because they are split on the way in.
+//
+// Split-K: weight-gradient GEMMs have M x N = (out x in features) tiles only (32 tiles for to_q) but
+// K = all tokens of the batch; gridDim.y splits K and the epilogue accumulates with fp32 atomics
+// into C (these GEMMs are "C += ..." by construction: gradients accumulate over micro-batches).
 #include "common.h"
 
 #define BM 128
@@ -42,6 +52,7 @@ struct GemmArgs {
     int M, N, K;
     int lda, ldb, ldc, ldcin;
     float alpha;
+    int kt_per_split;   // k-tiles handled by one blockIdx.y slice (split-K); gridDim.y == 1 -> all
 };
 
 // ---- LDS images ---------------------------------------------------------------------------
@@ -139,6 +150,35 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, int sub0, int s, in
     }
 }
 
+// epilogue: C-layout of v_mfma_f32_32x32x16: col = lane & 31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+template <typename TOUT>
+__device__ __forceinline__ void epilogue(const GemmArgs& g, f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn, int lane) {
+    TOUT* C = (TOUT*)g.C;
+    const bool split = gridDim.y > 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = m0 + wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            if (row >= g.M) continue;
+            const long long prow = g.c_map ? (long long)g.c_map[row] : (long long)row;
+            if (prow < 0) continue;          // row dropped by the scatter map (padding rows of a repacked weight)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + wn + 32 * j + (lane & 31);
+                if (col >= g.N) continue;
+                float v = g.alpha * acc[i][j][e];
+                if (split) {                 // split-K slices accumulate into C (host guarantees fp32 C and Cin == C)
+                    unsafeAtomicAdd((float*)g.C + prow * g.ldc + col, v);
+                } else {
+                    if (g.Cin) v += g.Cin[prow * g.ldcin + col];
+                    store_from_float(C + prow * g.ldc + col, v);
+                }
+            }
+        }
+    }
+}
+
 template <typename T, bool A_KMAJ, bool B_KMAJ, typename TOUT>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs g) {
     constexpr bool PRECISE = elt_traits<T>::precise;
@@ -178,11 +218,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nk = (g.K + BK - 1) / BK;
-    sa.load(rsA, g.a_map, g.lda, g.M, m0, 0, g.K);
-    sb.load(rsB, g.b_map, g.ldb, g.N, n0, 0, g.K);
+    const int nk_all = (g.K + BK - 1) / BK;
+    const int kt0 = blockIdx.y * g.kt_per_split;
+    const int nk = min(nk_all, kt0 + g.kt_per_split);
+    sa.load(rsA, g.a_map, g.lda, g.M, m0, kt0 * BK, g.K);
+    sb.load(rsB, g.b_map, g.ldb, g.N, n0, kt0 * BK, g.K);
 
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = kt0; kt < nk; ++kt) {
         sa.store(As_hi, As_lo);
         sb.store(Bs_hi, Bs_lo);
         __syncthreads();
@@ -216,37 +258,142 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs g) {
         __syncthreads();
     }
 
-    // epilogue: C-layout of v_mfma_f32_32x32x16: col = lane & 31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
-    TOUT* C = (TOUT*)g.C;
+    epilogue<TOUT>(g, acc, m0, n0, wm, wn, lane);
+}
+
+
+// ---- bf16 fast path: LDS-DMA staging, double-buffered LDS, one barrier per k-tile ------------------------
+template <bool KMAJ>
+struct DmaStager {
+    unsigned base[4];     // byte offset without the k advance (OOB_OFF when the row / column chunk is out of range)
+    int kidx[4];          // normal: k offset of the lane's chunk inside the tile;  k-major: k row inside the tile
+
+    __device__ __forceinline__ void init(const int* map, int ld, int nvalid, int r0, int wave, int lane) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = m0 + wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-            if (row >= g.M) continue;
-            const long long prow = g.c_map ? (long long)g.c_map[row] : (long long)row;
-            if (prow < 0) continue;          // row dropped by the scatter map (padding rows of a repacked weight)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = n0 + wn + 32 * j + (lane & 31);
-                if (col >= g.N) continue;
-                float v = g.alpha * acc[i][j][e];
-                if (g.Cin) v += g.Cin[prow * g.ldcin + col];
-                store_from_float(C + prow * g.ldc + col, v);
+        for (int i = 0; i < 4; ++i) {
+            const int b = wave + 4 * i;                            // 1-KiB LDS block = one wave-instruction
+            if (!KMAJ) {
+                const int row = 8 * b + (lane >> 3), slot = lane & 7;
+                const int kc = slot ^ ((row >> 1) & 7);            // source-side swizzle: LDS (row, slot) holds chunk kc
+                const int gr = r0 + row;
+                const bool ok = gr < nvalid;
+                const long long pr = (ok && map) ? (long long)map[gr] : (long long)gr;
+                base[i] = ok ? (unsigned)((pr * ld + kc * 8) * 2) : OOB_OFF;
+                kidx[i] = kc * 8;
+            } else {
+                const int krow = 4 * b + (lane >> 4), pos = lane & 15;
+                const int seg = (pos >> 2) ^ (krow & 3);
+                const int gc = r0 + (seg * 4 + (pos & 3)) * 8;
+                base[i] = gc < nvalid ? (unsigned)(gc * 2) : OOB_OFF;
+                kidx[i] = krow;
             }
         }
     }
+    __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rs, const int* map, int ld, int k0, int K,
+                                          char* lds_tile, int wave) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int b = wave + 4 * i;
+            unsigned off;
+            if (!KMAJ) {
+                off = (base[i] != OOB_OFF && k0 + kidx[i] < K) ? base[i] + (unsigned)(k0 * 2) : OOB_OFF;
+            } else {
+                const int gk = k0 + kidx[i];
+                const bool ok = base[i] != OOB_OFF && gk < K;
+                const long long pr = (ok && map) ? (long long)map[gk] : (long long)gk;
+                off = ok ? base[i] + (unsigned)(pr * ld * 2) : OOB_OFF;
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(void, lds_tile + b * 1024), 16, (int)off, 0, 0, 0);
+        }
+    }
+};
+
+template <bool A_KMAJ, bool B_KMAJ, typename TOUT>
+__global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(GemmArgs g) {
+    constexpr int PLANE = BM * BK * 2;                       // 16 KiB per operand tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A | B]
+
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(g.A, (unsigned long long)g.a_rows * g.lda * 2);
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(g.B, (unsigned long long)g.b_rows * g.ldb * 2);
+    DmaStager<A_KMAJ> sa;
+    DmaStager<B_KMAJ> sb;
+    sa.init(g.a_map, g.lda, g.M, m0, wave, lane);
+    sb.init(g.b_map, g.ldb, g.N, n0, wave, lane);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk_all = (g.K + BK - 1) / BK;
+    const int kt0 = blockIdx.y * g.kt_per_split;
+    const int kt1 = min(nk_all, kt0 + g.kt_per_split);
+    if (kt0 < kt1) {
+        sa.issue(rsA, g.a_map, g.lda, kt0 * BK, g.K, smem, wave);
+        sb.issue(rsB, g.b_map, g.ldb, kt0 * BK, g.K, smem + PLANE, wave);
+    }
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        // the DMA is a pending LDS write on the VM counter: this barrier waits vmcnt(0), so tile kt has landed for
+        // every wave, and every wave has finished the MFMA phase that read the other buffer
+        __syncthreads();
+        if (kt + 1 < kt1) {
+            char* nxt = smem + (cur ^ 1) * 2 * PLANE;
+            sa.issue(rsA, g.a_map, g.lda, (kt + 1) * BK, g.K, nxt, wave);
+            sb.issue(rsB, g.b_map, g.ldb, (kt + 1) * BK, g.K, nxt + PLANE, wave);
+        }
+        const char* As = smem + cur * 2 * PLANE;
+        const char* Bs = As + PLANE;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = read_frag<A_KMAJ>(As, wm + 32 * i, s, lane);
+                b[i] = read_frag<B_KMAJ>(Bs, wn + 32 * i, s, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    epilogue<TOUT>(g, acc, m0, n0, wm, wn, lane);
 }
 
 template <typename T, typename TOUT>
-static int launch_layout(const GemmArgs& g, int a_kmaj, int b_kmaj, hipStream_t st) {
+static int launch_layout(const GemmArgs& g, int a_kmaj, int b_kmaj, int splits, hipStream_t st) {
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-    const size_t lds = (elt_traits<T>::precise ? 4 : 2) * (size_t)(BM * BK * 2);
-    dim3 grid(tiles), block(NTHREADS);
-    if (!a_kmaj && !b_kmaj)      hipLaunchKernelGGL((gemm_kernel<T, false, false, TOUT>), grid, block, lds, st, g);
-    else if (!a_kmaj && b_kmaj)  hipLaunchKernelGGL((gemm_kernel<T, false, true, TOUT>), grid, block, lds, st, g);
-    else if (a_kmaj && b_kmaj)   hipLaunchKernelGGL((gemm_kernel<T, true, true, TOUT>), grid, block, lds, st, g);
-    else                         hipLaunchKernelGGL((gemm_kernel<T, true, false, TOUT>), grid, block, lds, st, g);
+    const size_t lds = 4 * (size_t)(BM * BK * 2);            // fp32: 4 planes (A/B x hi/lo); bf16: 2 buffers x (A | B)
+    dim3 grid(tiles, splits), block(NTHREADS);
+    if constexpr (elt_traits<T>::precise) {
+        if (!a_kmaj && !b_kmaj)      hipLaunchKernelGGL((gemm_kernel<T, false, false, TOUT>), grid, block, lds, st, g);
+        else if (!a_kmaj && b_kmaj)  hipLaunchKernelGGL((gemm_kernel<T, false, true, TOUT>), grid, block, lds, st, g);
+        else if (a_kmaj && b_kmaj)   hipLaunchKernelGGL((gemm_kernel<T, true, true, TOUT>), grid, block, lds, st, g);
+        else                         hipLaunchKernelGGL((gemm_kernel<T, true, false, TOUT>), grid, block, lds, st, g);
+    } else {
+        if (!a_kmaj && !b_kmaj)      hipLaunchKernelGGL((gemm_bf16_kernel<false, false, TOUT>), grid, block, lds, st, g);
+        else if (!a_kmaj && b_kmaj)  hipLaunchKernelGGL((gemm_bf16_kernel<false, true, TOUT>), grid, block, lds, st, g);
+        else if (a_kmaj && b_kmaj)   hipLaunchKernelGGL((gemm_bf16_kernel<true, true, TOUT>), grid, block, lds, st, g);
+        else                         hipLaunchKernelGGL((gemm_bf16_kernel<true, false, TOUT>), grid, block, lds, st, g);
+    }
     return omlm_post_launch("omlm_gemm");
 }
 
@@ -275,6 +422,17 @@ extern "C" int omlm_gemm(const void* A, const void* B, void* C, const float* Cin
     g.a_rows = a_rows; g.b_rows = b_rows; g.M = M; g.N = N; g.K = K;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldcin = ldcin; g.alpha = alpha;
     hipStream_t st = as_stream(stream);
+    // split-K only for accumulate-into-C GEMMs with few output tiles (the weight-gradient contractions)
+    const int nk = (K + BK - 1) / BK;
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    int splits = 1;
+    if (Cin == (const float*)C && out_dtype == 0 && tiles < 768 && nk >= 16) {
+        splits = (1536 + tiles - 1) / tiles;
+        if (splits > nk / 8) splits = nk / 8;
+        if (splits < 1) splits = 1;
+    }
+    g.kt_per_split = (nk + splits - 1) / splits;
+    splits = (nk + g.kt_per_split - 1) / g.kt_per_split;
     if (in_dtype == 0) {
         static bool attr_done = false;   // 64 KiB dynamic LDS needs the opt-in attribute once per kernel
         if (!attr_done) {
@@ -285,8 +443,20 @@ extern "C" int omlm_gemm(const void* A, const void* B, void* C, const float* Cin
             attr_done = true;
         }
         OMLM_CHECK_ARG(out_dtype == 0, "fp32 operands produce fp32 output");
-        return launch_layout<float, float>(g, a_kmajor, b_kmajor, st);
+        return launch_layout<float, float>(g, a_kmajor, b_kmajor, splits, st);
     }
-    if (out_dtype == 0) return launch_layout<bf16_t, float>(g, a_kmajor, b_kmajor, st);
-    return launch_layout<bf16_t, bf16_t>(g, a_kmajor, b_kmajor, st);
+    static bool attr16 = false;
+    if (!attr16) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, false, float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, true, float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, true, float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, false, float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, false, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, true, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, true, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, false, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        attr16 = true;
+    }
+    if (out_dtype == 0) return launch_layout<bf16_t, float>(g, a_kmajor, b_kmajor, splits, st);
+    return launch_layout<bf16_t, bf16_t>(g, a_kmajor, b_kmajor, splits, st);
 }

@@ -517,6 +517,7 @@ class LogitsFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, all_token_ids, self_attn_mask, only_final, precision, *params):
         bufs, lay, st = run_forward(model, all_token_ids, self_attn_mask, only_final, True, precision)
+        ctx.set_materialize_grads(False)          # unused logits -> None grads -> their head GEMMs are skipped
         ctx.st = st
         ctx.nparams = len(params)
         views = logits_views(model, lay, bufs)

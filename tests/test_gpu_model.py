@@ -98,8 +98,16 @@ def test_training_step_matches_reference_golden(golden_dir, dev, monkeypatch, na
         ref = torch.from_numpy(z[gk])
         got = (p.grad if p.grad is not None else torch.zeros_like(p)).detach().cpu()
         grads[k] = float((got.double() - ref.double()).abs().max() / max(float(ref.abs().max()), 1e-3 * gscale))
+    # The softmax is invariant to a per-head constant added to the rel-pos bias, so the gradient along that direction
+    # (net.3.bias; for the causal T5 variant every distance maps to bucket 0, so its whole table) is analytically ZERO:
+    # the reference holds ~1e-8 of rounding noise there, a flash-style backward holds its own (row sums of dS cancel
+    # only to the precision of delta = sum(dO * O) vs sum(P * dP)).  Those entries are bounded in absolute terms only.
+    invariant = {k: v for k, v in grads.items() if k.endswith("rel_pos_bias.net.3.bias") or k.endswith("relative_attention_bias.weight")}
+    for k in invariant:
+        grads.pop(k)
+    assert all(v < 5.0 for v in invariant.values()), invariant          # < 5e-3 of the largest gradient entry in the model
     worst = max(grads.items(), key=lambda kv: kv[1])
-    report(f"train[{name},{precision}]", loss=e_loss, logits=e_logits, worst_grad=worst, grads=grads)
+    report(f"train[{name},{precision}]", loss=e_loss, logits=e_logits, worst_grad=worst, grads=grads, invariant=invariant)
     assert e_loss < tol["loss"], e_loss
     assert max(e_logits) < tol["logits"], e_logits
     assert worst[1] < tol["grad"], worst
@@ -132,8 +140,9 @@ def test_logits_path_autograd_matches_fused_loss(golden_dir, dev, monkeypatch):
     l2.backward()
     assert abs(float(l2) - float(loss)) < 1e-4 * abs(float(loss))
     gscale = max(float(v.abs().max()) for v in g1.values())
+    assert {k for k, p in model.named_parameters() if p.grad is not None} == set(g1)
     errs = {k: float((p.grad.double() - g1[k].double()).abs().max() / max(float(g1[k].abs().max()), 1e-3 * gscale))
-            for k, p in model.named_parameters() if k in g1}
+            for k, p in model.named_parameters() if k in g1 and not k.endswith("rel_pos_bias.net.3.bias")}
     worst = max(errs.items(), key=lambda kv: kv[1])
     report("logits_vs_fused", worst=worst)
     assert worst[1] < 2e-2, worst      # both paths share the kernels; they differ only in how dlogits is rounded
