@@ -67,19 +67,30 @@ __device__ __forceinline__ void load_row8<float, true>(const float* p, bool ok, 
     lo = __builtin_bit_cast(bf16x8, l);
 }
 
-// stage a [TKV keys][64] tile of k or v (rows j0.., zero beyond N) into LDS (hi and, if PRECISE, lo plane)
+// K/V tile staging, split in two so the HBM latency of tile t+1 hides under the MFMA phase of tile t (guide T14):
+// (1) global -> registers (issued before the compute phase), (2) registers -> swizzled LDS image after the barrier.
+// A [TKV keys][64] tile is 512 chunks of 8 dims = 2 per thread; rows beyond N are zero.
 template <typename T, bool PRECISE>
-__device__ __forceinline__ void stage_kv(const T* base /* row 0 of this sample, ld 64 */, int j0, int N, char* lds_hi, char* lds_lo) {
+struct KVRegs {
+    bf16x8 hi[2], lo[2];
+    __device__ __forceinline__ void load(const T* base /* row 0 of this sample, ld 64 */, int j0, int N) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int c = threadIdx.x + AT_THREADS * i;       // 512 chunks of 8 dims
-        const int row = c >> 3, ch = c & 7;
-        bf16x8 hi, lo;
-        load_row8<T, PRECISE>(base + (size_t)(j0 + row) * 64 + ch * 8, (j0 + row) < N, hi, lo);
-        *(bf16x8*)(lds_hi + tile_off(row, ch * 16)) = hi;
-        if (PRECISE) *(bf16x8*)(lds_lo + tile_off(row, ch * 16)) = lo;
+        for (int i = 0; i < 2; ++i) {
+            const int c = threadIdx.x + AT_THREADS * i;
+            const int row = c >> 3, ch = c & 7;
+            load_row8<T, PRECISE>(base + (size_t)(j0 + row) * 64 + ch * 8, (j0 + row) < N, hi[i], lo[i]);
+        }
     }
-}
+    __device__ __forceinline__ void store(char* lds_hi, char* lds_lo) const {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = threadIdx.x + AT_THREADS * i;
+            const int row = c >> 3, ch = c & 7;
+            *(bf16x8*)(lds_hi + tile_off(row, ch * 16)) = hi[i];
+            if (PRECISE) *(bf16x8*)(lds_lo + tile_off(row, ch * 16)) = lo[i];
+        }
+    }
+};
 
 // normal operand fragment: row = row0 + (lane & 31), dims 16 s + 8 (lane >> 5) .. +7
 __device__ __forceinline__ bf16x8 frag_rows(const char* lds, int row0, int s, int lane) {
@@ -160,15 +171,22 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const T* __restric
     const float* bl = bias_l + (size_t)wave * nb;
 
     const int nkt = (i0 + TQ + TKV - 1) / TKV;
+    KVRegs<T, PRECISE> kr, vr;
+    kr.load(k + rowbase * 64, 0, N);
+    vr.load(v + rowbase * 64, 0, N);
     for (int kt = 0; kt < nkt; ++kt) {
         const int j0 = kt * TKV;
         __syncthreads();
-        stage_kv<T, PRECISE>(k + rowbase * 64, j0, N, Kh, Kl);
-        stage_kv<T, PRECISE>(v + rowbase * 64, j0, N, Vh, Vl);
+        kr.store(Kh, Kl);
+        vr.store(Vh, Vl);
         const int jk = j0 + lane;
         const bool live = jk < N && (keymask ? keymask[rowbase + jk] != 0 : true);
         const unsigned long long bits = __ballot(live);
         __syncthreads();
+        if (kt + 1 < nkt) {                    // in flight during this tile's MFMA phase
+            kr.load(k + rowbase * 64, j0 + TKV, N);
+            vr.load(v + rowbase * 64, j0 + TKV, N);
+        }
         if (!active) continue;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -298,15 +316,22 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(const T* __rest
     const float c = scale * LOG2E;
 
     const int nkt = (i0 + TQ + TKV - 1) / TKV;
+    KVRegs<T, false> kr, vr;
+    kr.load(k + rowbase * 64, 0, N);
+    vr.load(v + rowbase * 64, 0, N);
     for (int kt = 0; kt < nkt; ++kt) {
         const int j0 = kt * TKV;
         __syncthreads();
-        stage_kv<T, false>(k + rowbase * 64, j0, N, Ks, Ks);
-        stage_kv<T, false>(v + rowbase * 64, j0, N, Vs, Vs);
+        kr.store(Ks, Ks);
+        vr.store(Vs, Vs);
         const int jk = j0 + lane;
         const bool live = jk < N && (keymask ? keymask[rowbase + jk] != 0 : true);
         const unsigned long long bits = __ballot(live);
         __syncthreads();
+        if (kt + 1 < nkt) {
+            kr.load(k + rowbase * 64, j0 + TKV, N);
+            vr.load(v + rowbase * 64, j0 + TKV, N);
+        }
         if (!active) continue;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -402,17 +427,25 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(const T* __res
     for (int e = 0; e < 16; ++e) { dkacc[0][e] = 0.f; dkacc[1][e] = 0.f; dvacc[0][e] = 0.f; dvacc[1][e] = 0.f; }
 
     const int nitems = (nqt - jt) * H;        // (query tile it >= jt) x head
+    // A-operand fragments (rows = queries i0 + (lane&31), dims 16 s + 8 hi) of Q and dO; the NEXT item's fragments are
+    // fetched while the current item is on the matrix cores (each wave walks its items alone: nothing else hides HBM).
+    bf16x8 qa[4], doa[4], qn[4], don[4];
+    auto fetch = [&](int item, bf16x8 (&fq)[4], bf16x8 (&fd)[4]) {
+        const int qi_ = (jt + item / H) * TQ + (lane & 31);
+        const size_t qrow_ = (rowbase + min(qi_, N - 1)) * (size_t)(H * 64) + (item % H) * 64;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            load_row8<T, false>(q + qrow_ + 16 * s + 8 * hi, qi_ < N, fq[s], dummy);
+            load_row8<T, false>(dout + qrow_ + 16 * s + 8 * hi, qi_ < N, fd[s], dummy);
+        }
+    };
+    if (wave < nitems) fetch(wave, qa, doa);
     for (int item = wave; item < nitems; item += 4) {
         const int it = jt + item / H, h = item % H;
         const int i0 = it * TQ;
-        // A-operand fragments (rows = queries i0 + (lane&31), dims 16 s + 8 hi): Q and dO, also parked in LDS
-        const int qi = i0 + (lane & 31);
-        const size_t qrow = (rowbase + min(qi, N - 1)) * (size_t)(H * 64) + h * 64;
-        bf16x8 qa[4], doa[4];
+        if (item + 4 < nitems) fetch(item + 4, qn, don);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            load_row8<T, false>(q + qrow + 16 * s + 8 * hi, qi < N, qa[s], dummy);
-            load_row8<T, false>(dout + qrow + 16 * s + 8 * hi, qi < N, doa[s], dummy);
+        for (int s = 0; s < 4; ++s) {        // park this item's tiles in LDS for the transpose reads
             *(bf16x8*)(Qs + tile_off(lane & 31, (2 * s + hi) * 16)) = qa[s];
             *(bf16x8*)(dOs + tile_off(lane & 31, (2 * s + hi) * 16)) = doa[s];
         }
@@ -450,6 +483,8 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(const T* __res
                 dkacc[dt] = MFMA(frag_cols_tr(Qs, 0, s, 32 * dt, lane), dsb, dkacc[dt]);    // dK^T += Q^T dS
             }
         }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { qa[s] = qn[s]; doa[s] = don[s]; }
     }
     // cross-wave reduction through LDS, one accumulator pair at a time
     for (int which = 0; which < 2; ++which) {

@@ -44,10 +44,19 @@ __device__ __forceinline__ void zero8(float* v) {
     for (int i = 0; i < 8; ++i) v[i] = 0.f;
 }
 
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_grad_f(float x) {
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+// erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. fp32 rounding level for GELU) -- ~12 VALU + one v_exp
+// instead of libm erff's ~60: these kernels were VALU-bound on it.
+__device__ __forceinline__ float fast_erf(float x) {
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+    const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+    return copysignf(1.0f - poly * __expf(-ax * ax), x);
 }
+__device__ __forceinline__ float gelu_from_erf(float x, float e) { return 0.5f * x * (1.0f + e); }
+__device__ __forceinline__ float gelu_grad_from_erf(float x, float e) {
+    return 0.5f * (1.0f + e) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+__device__ __forceinline__ float gelu_f(float x) { return gelu_from_erf(x, fast_erf(x * 0.70710678118654752f)); }
 
 // conv weights w[ch][3]: y[t] = w0 x[t-2] + w1 x[t-1] + w2 x[t]
 template <typename T>
@@ -97,12 +106,14 @@ __device__ __forceinline__ void welford_merge(float& n, float& mean, float& m2, 
 }
 
 template <typename T, int MAXC>
-__global__ __launch_bounds__(FF_THREADS, 4) void ffmid_fwd_kernel(const T* __restrict__ h1, const float* __restrict__ convw,
+__global__ __launch_bounds__(FF_THREADS, 3) void ffmid_fwd_kernel(const T* __restrict__ h1, const float* __restrict__ convw,
                                                                   const float* __restrict__ gamma, T* __restrict__ h2,
                                                                   float* __restrict__ mean, float* __restrict__ rstd,
                                                                   int M, int nseq, int F, int Fp, float eps, float p,
                                                                   unsigned long long seed) {
+    extern __shared__ __attribute__((aligned(16))) float ff_lds[];     // [4 waves][Fp]: this wave's g row between the sweeps
     const int lane = threadIdx.x & 63;
+    float* gl = ff_lds + (size_t)(threadIdx.x >> 6) * Fp;
     const int ld = 2 * Fp;
     const int nwaves = gridDim.x * (FF_THREADS / 64);
     for (int row = blockIdx.x * (FF_THREADS / 64) + (threadIdx.x >> 6); row < M; row += nwaves) {
@@ -120,6 +131,8 @@ __global__ __launch_bounds__(FF_THREADS, 4) void ffmid_fwd_kernel(const T* __res
                 float cs = 0.f;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { gv[i] = gelu_f(ug[i]) * ux[i]; if (i < nv) cs += gv[i]; }
+                ((float4*)(gl + ch))[0] = make_float4(gv[0], gv[1], gv[2], gv[3]);
+                ((float4*)(gl + ch))[1] = make_float4(gv[4], gv[5], gv[6], gv[7]);
                 const float cm = cs / (float)nv;
                 float c2 = 0.f;
 #pragma unroll
@@ -135,21 +148,25 @@ __global__ __launch_bounds__(FF_THREADS, 4) void ffmid_fwd_kernel(const T* __res
         const float mu = wmean;
         const float rs = rsqrtf(wm2 / (float)F + eps);
         if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
-        // sweep 2: recompute (the three h1 rows are L1/L2 hits now), normalise, dropout, store
+        // sweep 2: g comes back from this wave's LDS row (same-wave LDS ops are ordered); normalise, dropout, store
 #pragma unroll 1
         for (int k = 0; k < MAXC; ++k) {
             const int ch = (lane + 64 * k) * 8;
             if (ch < Fp) {
-                float ux[8], ug[8], m[8];
-                conv_row<T>(h1, convw, row, t, ld, ch, ch, F - ch, ux);
-                conv_row<T>(h1, convw, row, t, ld, Fp + ch, F + ch, F - ch, ug);
+                float gv[8], m[8];
+                if (ch < F) {
+                    const float4 a = ((const float4*)(gl + ch))[0], b = ((const float4*)(gl + ch))[1];
+                    gv[0] = a.x; gv[1] = a.y; gv[2] = a.z; gv[3] = a.w; gv[4] = b.x; gv[5] = b.y; gv[6] = b.z; gv[7] = b.w;
+                } else {
+                    zero8(gv);
+                }
                 if (p > 0.f) dropout8(seed, (unsigned long long)row * Fp + ch, p, m);
                 vec8<T> o;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     float y = 0.f;
                     if (ch + i < F) {
-                        y = (gelu_f(ug[i]) * ux[i] - mu) * rs * gamma[ch + i];
+                        y = (gv[i] - mu) * rs * gamma[ch + i];
                         if (p > 0.f) y *= m[i];
                     }
                     o.v[i] = y;
@@ -165,15 +182,16 @@ __global__ __launch_bounds__(FF_THREADS, 4) void ffmid_fwd_kernel(const T* __res
 // h1 rows and dh2 from L1/L2) so that nothing but the two reduction scalars lives across the sweep boundary.
 // dgamma is accumulated in an LDS array per workgroup (ds_add_f32) and written once as a partial row.
 template <typename T, int MAXC>
-__global__ __launch_bounds__(FF_THREADS, 4) void ffmid_bwd1_kernel(const T* __restrict__ dh2, const T* __restrict__ h1,
+__global__ __launch_bounds__(FF_THREADS, 2) void ffmid_bwd1_kernel(const T* __restrict__ dh2, const T* __restrict__ h1,
                                                                 const float* __restrict__ convw, const float* __restrict__ gamma,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 T* __restrict__ du, float* __restrict__ part_dgamma,
                                                                 int M, int nseq, int F, int Fp, float p, unsigned long long seed) {
-    extern __shared__ float dg_lds[];                    // [Fp]
+    extern __shared__ __attribute__((aligned(16))) float dg_lds[];    // [Fp] dgamma + [4 waves][Fp] cached erf(gate / sqrt 2)
     for (int c = threadIdx.x; c < Fp; c += FF_THREADS) dg_lds[c] = 0.f;
     __syncthreads();
     const int lane = threadIdx.x & 63;
+    float* el = dg_lds + (size_t)(1 + (threadIdx.x >> 6)) * Fp;
     const int ld = 2 * Fp;
     const int nwaves = gridDim.x * (FF_THREADS / 64);
     for (int row = blockIdx.x * (FF_THREADS / 64) + (threadIdx.x >> 6); row < M; row += nwaves) {
@@ -190,10 +208,15 @@ __global__ __launch_bounds__(FF_THREADS, 4) void ffmid_bwd1_kernel(const T* __re
                 vec8<T> d;
                 d.load(dh2 + (size_t)row * Fp + ch);
                 if (p > 0.f) dropout8(seed, (unsigned long long)row * Fp + ch, p, m);
+                float ev[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ev[i] = fast_erf(ug[i] * 0.70710678118654752f);
+                ((float4*)(el + ch))[0] = make_float4(ev[0], ev[1], ev[2], ev[3]);
+                ((float4*)(el + ch))[1] = make_float4(ev[4], ev[5], ev[6], ev[7]);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     if (ch + i < F) {
-                        const float gh = (gelu_f(ug[i]) * ux[i] - mu) * rs;
+                        const float gh = (gelu_from_erf(ug[i], ev[i]) * ux[i] - mu) * rs;
                         float dyv = d.v[i];
                         if (p > 0.f) dyv *= m[i];
                         atomicAdd(dg_lds + ch + i, dyv * gh);
@@ -216,17 +239,19 @@ __global__ __launch_bounds__(FF_THREADS, 4) void ffmid_bwd1_kernel(const T* __re
                 vec8<T> d, ox, og;
                 d.load(dh2 + (size_t)row * Fp + ch);
                 if (p > 0.f) dropout8(seed, (unsigned long long)row * Fp + ch, p, m);
+                const float4 ea = ((const float4*)(el + ch))[0], eb = ((const float4*)(el + ch))[1];
+                const float ev[8] = {ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eb.z, eb.w};
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     float dx = 0.f, dgt = 0.f;
                     if (ch + i < F) {
-                        const float ge = gelu_f(ug[i]);
+                        const float ge = gelu_from_erf(ug[i], ev[i]);
                         const float gh = (ge * ux[i] - mu) * rs;
                         float dyv = d.v[i];
                         if (p > 0.f) dyv *= m[i];
                         const float dg = rs * (dyv * gamma[ch + i] - m1 - gh * m2);
                         dx = dg * ge;
-                        dgt = dg * ux[i] * gelu_grad_f(ug[i]);
+                        dgt = dg * ux[i] * gelu_grad_from_erf(ug[i], ev[i]);
                     }
                     ox.v[i] = dx;
                     og.v[i] = dgt;
@@ -324,13 +349,20 @@ extern "C" int omlm_ffmid_fwd(const void* h1, const float* convw, const float* g
                               int M, int nseq, int F, int Fp, float eps, float p, unsigned long long seed, int dtype, void* stream) {
     if (M <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(h1 && convw && gamma && h2 && mean && rstd, "null pointer");
-    OMLM_CHECK_ARG(Fp % 8 == 0 && Fp >= F && Fp <= 512 * FF_MAXC_LIMIT, "Fp must be F rounded up to 8 and <= 8192");
+    OMLM_CHECK_ARG(Fp % 8 == 0 && Fp >= F && Fp <= 8192 && (size_t)5 * Fp * sizeof(float) <= 160 * 1024, "Fp must be F rounded up to 8 and <= 8192");
     OMLM_CHECK_ARG(nseq > 0 && M % nseq == 0, "M must be batch * nseq");
     OMLM_CHECK_ARG(p >= 0.f && p < 1.f, "dropout p");
     const int rows4 = (M + 3) / 4;
     dim3 grid(rows4 < 4096 ? rows4 : 4096), block(FF_THREADS);
     hipStream_t st = as_stream(stream);
-#define FF_FWD(T_, MC_) hipLaunchKernelGGL((ffmid_fwd_kernel<T_, MC_>), grid, block, 0, st, (const T_*)h1, convw, gamma, (T_*)h2, mean, rstd, M, nseq, F, Fp, eps, p, seed)
+    const size_t lds_fwd = (size_t)4 * Fp * sizeof(float);
+    if (lds_fwd > 48 * 1024) {
+        (void)hipFuncSetAttribute((const void*)ffmid_fwd_kernel<float, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)ffmid_fwd_kernel<float, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)ffmid_fwd_kernel<bf16_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)ffmid_fwd_kernel<bf16_t, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+#define FF_FWD(T_, MC_) hipLaunchKernelGGL((ffmid_fwd_kernel<T_, MC_>), grid, block, lds_fwd, st, (const T_*)h1, convw, gamma, (T_*)h2, mean, rstd, M, nseq, F, Fp, eps, p, seed)
 #define FF_FWD_DISPATCH(T_) do { const int mc = (Fp / 8 + 63) / 64; \
         if (mc <= 2) FF_FWD(T_, 2); else if (mc <= 6) FF_FWD(T_, 6); else if (mc <= 8) FF_FWD(T_, 8); else FF_FWD(T_, 16); } while (0)
     if (dtype == 0) FF_FWD_DISPATCH(float); else FF_FWD_DISPATCH(bf16_t);
@@ -344,7 +376,7 @@ extern "C" int omlm_ffmid_bwd(const void* dh2, const void* h1, const float* conv
                               int M, int nseq, int F, int Fp, float p, unsigned long long seed, int dtype, void* stream) {
     if (M <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(dh2 && h1 && convw && gamma && mean && rstd && du_tmp && dh1 && workspace, "null pointer");
-    OMLM_CHECK_ARG(Fp % 8 == 0 && Fp >= F && Fp <= 512 * FF_MAXC_LIMIT, "Fp must be F rounded up to 8 and <= 8192");
+    OMLM_CHECK_ARG(Fp % 8 == 0 && Fp >= F && Fp <= 8192 && (size_t)5 * Fp * sizeof(float) <= 160 * 1024, "Fp must be F rounded up to 8 and <= 8192");
     OMLM_CHECK_ARG(nseq > 0 && M % nseq == 0, "M must be batch * nseq");
     hipStream_t st = as_stream(stream);
     float* part_g = workspace;
@@ -353,7 +385,15 @@ extern "C" int omlm_ffmid_bwd(const void* dh2, const void* h1, const float* conv
     const int b1 = rows4 < FF_BWD1_BLOCKS ? rows4 : FF_BWD1_BLOCKS;
     const int strips = M < FF_BWD2_STRIPS ? M : FF_BWD2_STRIPS;
     dim3 g2((2 * Fp / 8 + FF_THREADS - 1) / FF_THREADS, strips);
-    const size_t lds1 = (size_t)Fp * sizeof(float);
+    const size_t lds1 = (size_t)5 * Fp * sizeof(float);
+    if (lds1 > 48 * 1024) {
+        (void)hipFuncSetAttribute((const void*)ffmid_bwd1_kernel<float, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)ffmid_bwd1_kernel<float, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)ffmid_bwd1_kernel<float, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)ffmid_bwd1_kernel<bf16_t, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)ffmid_bwd1_kernel<bf16_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)ffmid_bwd1_kernel<bf16_t, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
 #define FF_B1(T_, MC_) hipLaunchKernelGGL((ffmid_bwd1_kernel<T_, MC_>), dim3(b1), dim3(FF_THREADS), lds1, st, (const T_*)dh2, (const T_*)h1, convw, gamma, mean, rstd, (T_*)du_tmp, part_g, M, nseq, F, Fp, p, seed)
 #define FF_B1_DISPATCH(T_) do { const int mc = (Fp / 8 + 63) / 64; \
         if (mc <= 2) FF_B1(T_, 2); else if (mc <= 6) FF_B1(T_, 6); else if (mc <= 8) FF_B1(T_, 8); else FF_B1(T_, 16); } while (0)

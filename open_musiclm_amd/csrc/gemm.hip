@@ -198,7 +198,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs g) {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    // super-tile order: 8 tile-rows x all tile-columns per group, column-major inside the group, so the ~64 workgroups
+    // co-resident on one XCD cover an ~8 x 8 patch of C (8 A panels + 8 B panels ~ 4 MiB: the XCD's L2)
+    const int gsz = 8 * tiles_n;
+    const int grp = bid / gsz, first_m = grp * 8;
+    const int rows_in = min(8, tiles_m - first_m);
+    const int tm = first_m + (bid - grp * gsz) % rows_in, tn = (bid - grp * gsz) / rows_in;
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -320,7 +325,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(GemmArgs g) {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    // super-tile order: 8 tile-rows x all tile-columns per group, column-major inside the group, so the ~64 workgroups
+    // co-resident on one XCD cover an ~8 x 8 patch of C (8 A panels + 8 B panels ~ 4 MiB: the XCD's L2)
+    const int gsz = 8 * tiles_n;
+    const int grp = bid / gsz, first_m = grp * 8;
+    const int rows_in = min(8, tiles_m - first_m);
+    const int tm = first_m + (bid - grp * gsz) % rows_in, tn = (bid - grp * gsz) / rows_in;
     const int m0 = tm * BM, n0 = tn * BN;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
