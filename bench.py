@@ -144,6 +144,16 @@ def main():
         "final_loss": round(final_loss, 4),
     }
 
+    if os.environ.get("BENCH_STEP_TIMES") == "1":
+        for k in range(3):
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            one_step(args.warmup + args.steps + 10 + k)
+            tb = time.perf_counter()
+            torch.cuda.synchronize()
+            tc = time.perf_counter()
+            progress(f"diagnostic step {k}: host enqueue {1e3 * (tb - ta):.1f} ms, until GPU idle {1e3 * (tc - ta):.1f} ms")
+
     if rank == 0:
         # ---- live roofline of the dominant kernel (the MFMA GEMM): HIP events around every GEMM launch of 2 extra steps
         ops_gemm = ops.gemm

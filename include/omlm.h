@@ -68,8 +68,9 @@ int omlm_mqa_attn_bwd(const void* q, const void* k, const void* v, const float* 
                       int B, int N, int H, float scale, int bias_ld, int dtype, void* stream);
 
 /* Middle of ConvFeedForward: CausalDSConv -> GEGLU -> LayerNorm(F) -> Dropout (transformer.py:122-148).
- * h1: [M, 2*Fp] (value half cols [0,F), gate half cols [Fp, Fp+F)); h2: [M, Fp]; convw: [2F, 3] (reference
- * ds_conv.weight [2F,1,3]); rows are b*nseq + t.  Dropout mask = Philox(seed, element index), regenerated in bwd. */
+ * h1: [M, 2*Fp] (value half cols [0,F), gate half cols [Fp, Fp+F)); h2: [M, Fp]; convw: taps re-packed tap-major and
+ * padded, [3, 2*Fp] in h1's column layout (from the reference ds_conv.weight [2F,1,3]); gamma padded to [Fp] with zeros;
+ * dconv is accumulated in the reference layout [2F, 3].  rows are b*nseq + t.  Dropout mask = Philox(seed, element index). */
 int omlm_ffmid_fwd(const void* h1, const float* convw, const float* gamma, void* h2, float* mean, float* rstd,
                    int M, int nseq, int F, int Fp, float eps, float p, unsigned long long seed, int dtype, void* stream);
 long long omlm_ffmid_bwd_workspace_bytes(int F, int Fp);

@@ -5,6 +5,9 @@
 // columns [Fp, Fp + F), Fp = F rounded up to 8 so both halves are 16-byte aligned; pad columns are 0.
 // Rows are tokens (b * n_seq + t); the conv is causal *within a sample* (left pad 2, :129).
 // With use_conv_ff=False (plain FeedForward :152-161) the host passes conv weights (0, 0, 1).
+// Conv taps and gamma arrive re-packed by the host (ops.pack_conv_taps / padded gamma): taps TAP-MAJOR and padded,
+// convT[3][2*Fp] with the same column layout as h1 (pad columns 0), gamma_p[Fp] (pad 0), so that a lane's 8 channels
+// are two aligned float4 loads per tap instead of 24 scattered dwords.
 //
 // HBM-bound: forward reads h1 once (the two halo rows come from L2) and writes h2; nothing but the
 // per-row LN statistics is saved -- the backward recomputes u and g from h1.
@@ -58,23 +61,18 @@ __device__ __forceinline__ float gelu_grad_from_erf(float x, float e) {
 }
 __device__ __forceinline__ float gelu_f(float x) { return gelu_from_erf(x, fast_erf(x * 0.70710678118654752f)); }
 
-// conv weights w[ch][3]: y[t] = w0 x[t-2] + w1 x[t-1] + w2 x[t]
+// y[t] = w0 x[t-2] + w1 x[t-1] + w2 x[t]; taps from convT[3][ld] at the same column as the data
 template <typename T>
-__device__ __forceinline__ void conv_row(const T* __restrict__ h1, const float* __restrict__ w, size_t row, int t, int ld,
-                                         int col, int wch, int nvalid, float* u) {
+__device__ __forceinline__ void conv_row(const T* __restrict__ h1, const float* __restrict__ convT, size_t row, int t, int ld,
+                                         int col, float* u) {
     vec8<T> c0, c1, c2;
+    vec8<float> w0, w1, w2;
     c2.load(h1 + row * ld + col);
     if (t >= 1) c1.load(h1 + (row - 1) * ld + col); else zero8(c1.v);
     if (t >= 2) c0.load(h1 + (row - 2) * ld + col); else zero8(c0.v);
+    w0.load(convT + col); w1.load(convT + ld + col); w2.load(convT + 2 * (size_t)ld + col);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        if (i < nvalid) {
-            const float* wi = w + (size_t)(wch + i) * 3;
-            u[i] = wi[0] * c0.v[i] + wi[1] * c1.v[i] + wi[2] * c2.v[i];
-        } else {
-            u[i] = 0.f;     // zero-padded channel
-        }
-    }
+    for (int i = 0; i < 8; ++i) u[i] = w0.v[i] * c0.v[i] + w1.v[i] * c1.v[i] + w2.v[i] * c2.v[i];
 }
 
 // keep-mask * 1/(1-p) for 8 consecutive elements starting at element index e0 (multiple of 8)
@@ -125,8 +123,8 @@ __global__ __launch_bounds__(FF_THREADS, 3) void ffmid_fwd_kernel(const T* __res
             const int ch = (lane + 64 * k) * 8;
             if (ch < F) {
                 float ux[8], ug[8], gv[8];
-                conv_row<T>(h1, convw, row, t, ld, ch, ch, F - ch, ux);
-                conv_row<T>(h1, convw, row, t, ld, Fp + ch, F + ch, F - ch, ug);
+                conv_row<T>(h1, convw, row, t, ld, ch, ux);
+                conv_row<T>(h1, convw, row, t, ld, Fp + ch, ug);
                 const int nv = min(8, F - ch);
                 float cs = 0.f;
 #pragma unroll
@@ -162,13 +160,12 @@ __global__ __launch_bounds__(FF_THREADS, 3) void ffmid_fwd_kernel(const T* __res
                 }
                 if (p > 0.f) dropout8(seed, (unsigned long long)row * Fp + ch, p, m);
                 vec8<T> o;
+                vec8<float> gm;
+                gm.load(gamma + ch);                               // padded gamma: 0 beyond F
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    float y = 0.f;
-                    if (ch + i < F) {
-                        y = (gv[i] - mu) * rs * gamma[ch + i];
-                        if (p > 0.f) y *= m[i];
-                    }
+                    float y = (gv[i] - mu) * rs * gm.v[i];
+                    if (p > 0.f) y *= m[i];
                     o.v[i] = y;
                 }
                 o.store(h2 + (size_t)row * Fp + ch);
@@ -203,12 +200,15 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffmid_bwd1_kernel(const T* __re
             const int ch = (lane + 64 * k) * 8;
             if (ch < Fp) {
                 float ux[8], ug[8], m[8];
-                conv_row<T>(h1, convw, row, t, ld, ch, ch, F - ch, ux);
-                conv_row<T>(h1, convw, row, t, ld, Fp + ch, F + ch, F - ch, ug);
+                conv_row<T>(h1, convw, row, t, ld, ch, ux);
+                conv_row<T>(h1, convw, row, t, ld, Fp + ch, ug);
                 vec8<T> d;
                 d.load(dh2 + (size_t)row * Fp + ch);
                 if (p > 0.f) dropout8(seed, (unsigned long long)row * Fp + ch, p, m);
                 float ev[8];
+                vec8<float> gm;
+                gm.load(gamma + ch);
+                const int nch = Fp >> 3;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) ev[i] = fast_erf(ug[i] * 0.70710678118654752f);
                 ((float4*)(el + ch))[0] = make_float4(ev[0], ev[1], ev[2], ev[3]);
@@ -219,8 +219,8 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffmid_bwd1_kernel(const T* __re
                         const float gh = (gelu_from_erf(ug[i], ev[i]) * ux[i] - mu) * rs;
                         float dyv = d.v[i];
                         if (p > 0.f) dyv *= m[i];
-                        atomicAdd(dg_lds + ch + i, dyv * gh);
-                        const float gy = dyv * gamma[ch + i];
+                        atomicAdd(dg_lds + i * nch + (ch >> 3), dyv * gh);      // [8][Fp/8]: consecutive lanes -> consecutive banks
+                        const float gy = dyv * gm.v[i];
                         s1 += gy;
                         s2 += gy * gh;
                     }
@@ -234,11 +234,13 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffmid_bwd1_kernel(const T* __re
             const int ch = (lane + 64 * k) * 8;
             if (ch < Fp) {
                 float ux[8], ug[8], m[8];
-                conv_row<T>(h1, convw, row, t, ld, ch, ch, F - ch, ux);
-                conv_row<T>(h1, convw, row, t, ld, Fp + ch, F + ch, F - ch, ug);
+                conv_row<T>(h1, convw, row, t, ld, ch, ux);
+                conv_row<T>(h1, convw, row, t, ld, Fp + ch, ug);
                 vec8<T> d, ox, og;
                 d.load(dh2 + (size_t)row * Fp + ch);
                 if (p > 0.f) dropout8(seed, (unsigned long long)row * Fp + ch, p, m);
+                vec8<float> gm;
+                gm.load(gamma + ch);
                 const float4 ea = ((const float4*)(el + ch))[0], eb = ((const float4*)(el + ch))[1];
                 const float ev[8] = {ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eb.z, eb.w};
 #pragma unroll
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffmid_bwd1_kernel(const T* __re
                         const float gh = (ge * ux[i] - mu) * rs;
                         float dyv = d.v[i];
                         if (p > 0.f) dyv *= m[i];
-                        const float dg = rs * (dyv * gamma[ch + i] - m1 - gh * m2);
+                        const float dg = rs * (dyv * gm.v[i] - m1 - gh * m2);
                         dx = dg * ge;
                         dgt = dg * ux[i] * gelu_grad_from_erf(ug[i], ev[i]);
                     }
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffmid_bwd1_kernel(const T* __re
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < Fp; c += FF_THREADS) part_dgamma[(size_t)blockIdx.x * Fp + c] = dg_lds[c];
+    for (int c = threadIdx.x; c < Fp; c += FF_THREADS) part_dgamma[(size_t)blockIdx.x * Fp + c] = dg_lds[(c & 7) * (Fp >> 3) + (c >> 3)];
 }
 
 // Backward, stage 2 (conv^T): dh1[t] = w2 du[t] + w1 du[t+1] + w0 du[t+2] (within the sample), and
@@ -282,10 +284,11 @@ __global__ __launch_bounds__(FF_THREADS) void ffmid_bwd2_kernel(const T* __restr
     const int wch = gate ? F + chreal : chreal;        // row of the reference conv weight [2F, 1, 3]
     float w[8][3], dw[8][3];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const bool ok = chreal + i < F;
+    for (int k = 0; k < 3; ++k) {
+        vec8<float> wv;
+        wv.load(convw + (size_t)k * ld + col);         // tap-major padded taps (0 in pad columns)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { w[i][k] = ok ? convw[(size_t)(wch + i) * 3 + k] : 0.f; dw[i][k] = 0.f; }
+        for (int i = 0; i < 8; ++i) { w[i][k] = wv.v[i]; dw[i][k] = 0.f; }
     }
     const int rows_per = (M + strips - 1) / strips;
     const int r_begin = blockIdx.y * rows_per, r_end = min(M, r_begin + rows_per);

@@ -128,7 +128,8 @@ class PreparedWeights:
             W2p = torch.empty(D, Fp, dtype=T, device=dev)
             ops.cast_pad(w2, W2p, D, F, F, Fp)
             ent["W1p"], ent["W2p"], ent["F"], ent["Fp"] = W1p, W2p, F, Fp
-            ent["convw"] = ff.conv_weight()             # fp32 [2F, 3] (identity taps for plain FeedForward)
+            ent["convw"] = ops.pack_conv_taps(ff.conv_weight().detach(), F, Fp)    # taps [3, 2Fp] (identity taps for plain FeedForward)
+            ent["gamma_mid"] = ops.pad_vector(ff.norm_mid.gamma.detach(), Fp)
             cm = torch.full((2 * Fp,), -1, dtype=torch.int32)
             cm[:F] = torch.arange(F, dtype=torch.int32)
             cm[Fp:Fp + F] = torch.arange(F, 2 * F, dtype=torch.int32)
@@ -274,7 +275,7 @@ def trunk_forward(tr, pw: PreparedWeights, x: torch.Tensor, keymask: Optional[to
         m3 = torch.empty(M, device=dev); r3 = torch.empty(M, device=dev)
         p = float(ff.dropout_p) if training else 0.0
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0
-        ops.ffmid_fwd(h1, w["convw"], ff.norm_mid.gamma.detach(), h2, m3, r3, N, F, Fp, p, seed)
+        ops.ffmid_fwd(h1, w["convw"], w["gamma_mid"], h2, m3, r3, N, F, Fp, p, seed)
         x2 = torch.empty(M, D, device=dev)
         ops.gemm(h2, w["W2p"], x2, M=M, N=D, K=Fp, Cin=x1)
         if save:
@@ -320,7 +321,7 @@ def trunk_backward(tr, pw: PreparedWeights, saved, dy: torch.Tensor, B: int, N: 
         du = torch.empty(M, 2 * Fp, dtype=T, device=dev)
         dh1 = torch.empty(M, 2 * Fp, dtype=T, device=dev)
         gconv = grad_of(ff.conv_param()).view(-1) if ff.conv_param() is not None else None
-        ops.ffmid_bwd(dh2, sv.h1, w["convw"], ff.norm_mid.gamma.detach(), sv.m3, sv.r3, du, dh1,
+        ops.ffmid_bwd(dh2, sv.h1, w["convw"], w["gamma_mid"], sv.m3, sv.r3, du, dh1,
                       grad_of(ff.norm_mid.gamma), gconv, ws, N, F, Fp, sv.p, sv.seed)
         del du, dh2
         dxn2 = torch.empty(M, D, device=dev)

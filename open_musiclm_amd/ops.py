@@ -88,7 +88,23 @@ def attn_bwd(q, k, v, bias, keymask, out, dout, lse, delta, dq, dk, dv, dbias, B
          bias.shape[-1] if bias is not None else 0, dcode(q.dtype), stream_ptr())
 
 
+def pack_conv_taps(convw: torch.Tensor, F: int, Fp: int) -> torch.Tensor:
+    """Reference ds_conv.weight viewed [2F, 3] -> tap-major, padded [3, 2*Fp] in h1's column layout (tiny re-pack)."""
+    out = torch.zeros(3, 2 * Fp, device=convw.device, dtype=torch.float32)
+    out[:, :F] = convw[:F].t()
+    out[:, Fp:Fp + F] = convw[F:].t()
+    return out
+
+
+def pad_vector(v: torch.Tensor, n: int) -> torch.Tensor:
+    out = torch.zeros(n, device=v.device, dtype=torch.float32)
+    out[: v.numel()] = v
+    return out
+
+
 def ffmid_fwd(h1, convw, gamma, h2, mean, rstd, nseq, F, Fp, p, seed, eps=1e-5):
+    """convw: packed taps [3, 2*Fp] (pack_conv_taps); gamma: padded [Fp] (pad_vector)."""
+    assert convw.shape == (3, 2 * Fp) and gamma.numel() == Fp
     call("omlm_ffmid_fwd", ptr(h1), ptr(convw), ptr(gamma), ptr(h2), ptr(mean), ptr(rstd),
          h1.shape[0], nseq, F, Fp, float(eps), float(p), int(seed), dcode(h1.dtype), stream_ptr())
 
@@ -98,6 +114,7 @@ def ffmid_bwd_workspace_floats(F, Fp) -> int:
 
 
 def ffmid_bwd(dh2, h1, convw, gamma, mean, rstd, du_tmp, dh1, dgamma, dconv, workspace, nseq, F, Fp, p, seed):
+    assert convw.shape == (3, 2 * Fp) and gamma.numel() == Fp
     call("omlm_ffmid_bwd", ptr(dh2), ptr(h1), ptr(convw), ptr(gamma), ptr(mean), ptr(rstd), ptr(du_tmp), ptr(dh1),
          ptr(dgamma), ptr(dconv), ptr(workspace), h1.shape[0], nseq, F, Fp, float(p), int(seed),
          dcode(h1.dtype), stream_ptr())
