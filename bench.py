@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--precision", default=os.environ.get("OMLM_PRECISION", "bf16"), choices=["bf16", "bf16x3"])
     ap.add_argument("--batch", type=int, default=32, help="samples per GPU per optimizer step")
     ap.add_argument("--accum", type=int, default=1, help="micro-batches per optimizer step")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured HIP graph")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--decode-ids", type=int, default=48)
@@ -89,12 +90,23 @@ def main():
         return [torch.cat([it[f] for it in items], 0).to(dev) for f in range(3)]
     batches = [make_batch(i) for i in range(min(n_micro, 8))]       # resident in HBM before timing
 
+    from open_musiclm_amd.graph import GraphedForwardBackward
+    fb = GraphedForwardBackward(lambda **kw: stage(**kw, return_loss=True)[0], loss_scale=1.0 / args.accum,
+                                enabled=not args.no_graph)
+    optim.zero_grad()                                      # adopt the flat parameter / gradient buffers before capture
+
+    def discard():
+        optim.mark_grads_dirty()
+        optim.zero_grad()
+    fb.prepare(dict(clap_token_ids=batches[0][0], semantic_token_ids=batches[0][1], coarse_token_ids=batches[0][2]),
+               after_warmup=discard)
+    progress(f"micro-step captured into a HIP graph: {fb.graph is not None}" + (f" ({fb.capture_error})" if fb.capture_error else ""))
+
     def one_step(k):
         optim.zero_grad()
         for a in range(args.accum):
             clap, sem, coarse = batches[(k * args.accum + a) % len(batches)]
-            loss, _, _ = stage(clap_token_ids=clap, semantic_token_ids=sem, coarse_token_ids=coarse, return_loss=True)
-            (loss / args.accum).backward()
+            loss = fb(clap_token_ids=clap, semantic_token_ids=sem, coarse_token_ids=coarse)
             optim.mark_grads_dirty()
         dp.allreduce_sum_(optim.flat_grad)
         optim.step(max_grad_norm=0.5, grad_scale=dp.grad_scale())
@@ -137,6 +149,7 @@ def main():
                                "(3 start + 13 clap + 200 semantic + 900 coarse), forgetful mask 0.15, ff_dropout 0.1",
                    "global_batch": args.batch * world, "per_gpu_batch": args.batch, "grad_accum": args.accum,
                    "seq_len": N_SEQ, "parallelism": f"dp{world}", "precision": args.precision,
+                   "hip_graph": fb.graph is not None,
                    "parity": "bf16x3: logits <=1e-3 vs CPU reference; bf16: <=3e-2 (tests/test_gpu_model.py)"},
         "steps_per_sec": round(steps_per_s, 4),
         "model_tflops_per_gpu": round(model_tflops_per_gpu, 2),
@@ -167,9 +180,16 @@ def main():
             rec.append((e0, e1, 2.0 * M * N * K))
         import open_musiclm_amd.engine as E
         E.ops.gemm = timed_gemm
+        def eager_step(k):                                # the graph replays recorded launches: instrument eager ones
+            optim.zero_grad()
+            for a in range(args.accum):
+                clap, sem, coarse = batches[(k * args.accum + a) % len(batches)]
+                fb._eager(dict(clap_token_ids=clap, semantic_token_ids=sem, coarse_token_ids=coarse))
+                optim.mark_grads_dirty()
+            optim.step(max_grad_norm=0.5, grad_scale=dp.grad_scale())
         try:
             for k in range(2):
-                one_step(args.warmup + args.steps + k)
+                eager_step(args.warmup + args.steps + k)
             torch.cuda.synchronize()
         finally:
             E.ops.gemm = ops_gemm

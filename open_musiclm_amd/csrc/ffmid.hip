@@ -108,7 +108,8 @@ __global__ __launch_bounds__(FF_THREADS, 3) void ffmid_fwd_kernel(const T* __res
                                                                   const float* __restrict__ gamma, T* __restrict__ h2,
                                                                   float* __restrict__ mean, float* __restrict__ rstd,
                                                                   int M, int nseq, int F, int Fp, float eps, float p,
-                                                                  unsigned long long seed) {
+                                                                  unsigned long long seed, const unsigned long long* __restrict__ seed_dev) {
+    if (seed_dev) seed += seed_dev[0] * 0x9E3779B97F4A7C15ull;      // per-step salt from device memory (graph replays differ)
     extern __shared__ __attribute__((aligned(16))) float ff_lds[];     // [4 waves][Fp]: this wave's g row between the sweeps
     const int lane = threadIdx.x & 63;
     float* gl = ff_lds + (size_t)(threadIdx.x >> 6) * Fp;
@@ -183,7 +184,9 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffmid_bwd1_kernel(const T* __re
                                                                 const float* __restrict__ convw, const float* __restrict__ gamma,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 T* __restrict__ du, float* __restrict__ part_dgamma,
-                                                                int M, int nseq, int F, int Fp, float p, unsigned long long seed) {
+                                                                int M, int nseq, int F, int Fp, float p, unsigned long long seed,
+                                                                const unsigned long long* __restrict__ seed_dev) {
+    if (seed_dev) seed += seed_dev[0] * 0x9E3779B97F4A7C15ull;
     extern __shared__ __attribute__((aligned(16))) float dg_lds[];    // [Fp] dgamma + [4 waves][Fp] cached erf(gate / sqrt 2)
     for (int c = threadIdx.x; c < Fp; c += FF_THREADS) dg_lds[c] = 0.f;
     __syncthreads();
@@ -349,7 +352,8 @@ extern "C" long long omlm_ffmid_bwd_workspace_bytes(int F, int Fp) {
 }
 
 extern "C" int omlm_ffmid_fwd(const void* h1, const float* convw, const float* gamma, void* h2, float* mean, float* rstd,
-                              int M, int nseq, int F, int Fp, float eps, float p, unsigned long long seed, int dtype, void* stream) {
+                              int M, int nseq, int F, int Fp, float eps, float p, unsigned long long seed,
+                              const unsigned long long* seed_dev, int dtype, void* stream) {
     if (M <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(h1 && convw && gamma && h2 && mean && rstd, "null pointer");
     OMLM_CHECK_ARG(Fp % 8 == 0 && Fp >= F && Fp <= 8192 && (size_t)5 * Fp * sizeof(float) <= 160 * 1024, "Fp must be F rounded up to 8 and <= 8192");
@@ -365,7 +369,7 @@ extern "C" int omlm_ffmid_fwd(const void* h1, const float* convw, const float* g
         (void)hipFuncSetAttribute((const void*)ffmid_fwd_kernel<bf16_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)ffmid_fwd_kernel<bf16_t, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-#define FF_FWD(T_, MC_) hipLaunchKernelGGL((ffmid_fwd_kernel<T_, MC_>), grid, block, lds_fwd, st, (const T_*)h1, convw, gamma, (T_*)h2, mean, rstd, M, nseq, F, Fp, eps, p, seed)
+#define FF_FWD(T_, MC_) hipLaunchKernelGGL((ffmid_fwd_kernel<T_, MC_>), grid, block, lds_fwd, st, (const T_*)h1, convw, gamma, (T_*)h2, mean, rstd, M, nseq, F, Fp, eps, p, seed, seed_dev)
 #define FF_FWD_DISPATCH(T_) do { const int mc = (Fp / 8 + 63) / 64; \
         if (mc <= 2) FF_FWD(T_, 2); else if (mc <= 6) FF_FWD(T_, 6); else if (mc <= 8) FF_FWD(T_, 8); else FF_FWD(T_, 16); } while (0)
     if (dtype == 0) FF_FWD_DISPATCH(float); else FF_FWD_DISPATCH(bf16_t);
@@ -376,7 +380,8 @@ extern "C" int omlm_ffmid_fwd(const void* h1, const float* convw, const float* g
 // dgamma [F], dconv [2F*3] are accumulated into (+=).
 extern "C" int omlm_ffmid_bwd(const void* dh2, const void* h1, const float* convw, const float* gamma, const float* mean,
                               const float* rstd, void* du_tmp, void* dh1, float* dgamma, float* dconv, float* workspace,
-                              int M, int nseq, int F, int Fp, float p, unsigned long long seed, int dtype, void* stream) {
+                              int M, int nseq, int F, int Fp, float p, unsigned long long seed,
+                              const unsigned long long* seed_dev, int dtype, void* stream) {
     if (M <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(dh2 && h1 && convw && gamma && mean && rstd && du_tmp && dh1 && workspace, "null pointer");
     OMLM_CHECK_ARG(Fp % 8 == 0 && Fp >= F && Fp <= 8192 && (size_t)5 * Fp * sizeof(float) <= 160 * 1024, "Fp must be F rounded up to 8 and <= 8192");
@@ -397,7 +402,7 @@ extern "C" int omlm_ffmid_bwd(const void* dh2, const void* h1, const float* conv
         (void)hipFuncSetAttribute((const void*)ffmid_bwd1_kernel<bf16_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)ffmid_bwd1_kernel<bf16_t, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-#define FF_B1(T_, MC_) hipLaunchKernelGGL((ffmid_bwd1_kernel<T_, MC_>), dim3(b1), dim3(FF_THREADS), lds1, st, (const T_*)dh2, (const T_*)h1, convw, gamma, mean, rstd, (T_*)du_tmp, part_g, M, nseq, F, Fp, p, seed)
+#define FF_B1(T_, MC_) hipLaunchKernelGGL((ffmid_bwd1_kernel<T_, MC_>), dim3(b1), dim3(FF_THREADS), lds1, st, (const T_*)dh2, (const T_*)h1, convw, gamma, mean, rstd, (T_*)du_tmp, part_g, M, nseq, F, Fp, p, seed, seed_dev)
 #define FF_B1_DISPATCH(T_) do { const int mc = (Fp / 8 + 63) / 64; \
         if (mc <= 2) FF_B1(T_, 2); else if (mc <= 6) FF_B1(T_, 6); else if (mc <= 8) FF_B1(T_, 8); else FF_B1(T_, 16); } while (0)
     if (dtype == 0) {

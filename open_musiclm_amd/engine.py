@@ -130,10 +130,13 @@ class PreparedWeights:
             ent["W1p"], ent["W2p"], ent["F"], ent["Fp"] = W1p, W2p, F, Fp
             ent["convw"] = ops.pack_conv_taps(ff.conv_weight().detach(), F, Fp)    # taps [3, 2Fp] (identity taps for plain FeedForward)
             ent["gamma_mid"] = ops.pad_vector(ff.norm_mid.gamma.detach(), Fp)
-            cm = torch.full((2 * Fp,), -1, dtype=torch.int32)
-            cm[:F] = torch.arange(F, dtype=torch.int32)
-            cm[Fp:Fp + F] = torch.arange(F, 2 * F, dtype=torch.int32)
-            ent["dW1_cmap"] = cm.to(dev)
+            cache = ff.__dict__.setdefault("_omlm_cmap", {})
+            if (F, Fp, str(dev)) not in cache:            # static scatter map: uploaded once (no H2D inside graph capture)
+                cm = torch.full((2 * Fp,), -1, dtype=torch.int32)
+                cm[:F] = torch.arange(F, dtype=torch.int32)
+                cm[Fp:Fp + F] = torch.arange(F, 2 * F, dtype=torch.int32)
+                cache[(F, Fp, str(dev))] = cm.to(dev)
+            ent["dW1_cmap"] = cache[(F, Fp, str(dev))]
             self.layers.append(ent)
         self.heads = []
         for w in model.logit_weights:
@@ -236,6 +239,20 @@ class LayerSaved:
                  "x1", "m2", "r2", "xn2", "h1", "h2", "m3", "r3", "seed", "p")
 
 
+def dropout_salt(tr, dev) -> torch.Tensor:
+    """Per-forward dropout salt living in DEVICE memory: a counter bumped by a (graph-capturable) torch op on every
+    training forward, snapshotted so that the backward of THIS forward regenerates the same masks.  Per-layer base
+    seeds are fixed host constants; kernels combine both (omlm_ffmid_*: seed + *seed_dev * phi)."""
+    st = tr.__dict__.get("_omlm_dropout")
+    if st is None or st["counter"].device != dev:
+        g = torch.Generator().manual_seed(int(torch.initial_seed()) & 0x7FFFFFFF)
+        st = dict(counter=torch.zeros(1, dtype=torch.int64, device=dev),
+                  seeds=[int(v) for v in torch.randint(1, 2 ** 62, (len(tr.layers),), generator=g)])
+        tr.__dict__["_omlm_dropout"] = st
+    st["counter"].add_(1)
+    return st["counter"].clone(), st["seeds"]
+
+
 def trunk_forward(tr, pw: PreparedWeights, x: torch.Tensor, keymask: Optional[torch.Tensor], B: int, N: int,
                   save: bool, training: bool):
     """x: [B*N, D] fp32 (consumed as the layer-0 residual).  Returns (final LN output in operand dtype, saved)."""
@@ -245,6 +262,9 @@ def trunk_forward(tr, pw: PreparedWeights, x: torch.Tensor, keymask: Optional[to
     H = tr.heads
     table, rp_saved = relpos_forward(tr, N, save)
     saved_layers: List[LayerSaved] = []
+    salt, seeds = (None, None)
+    if training and any(float(ff.dropout_p) > 0 for _, _, ff in tr.layers):
+        salt, seeds = dropout_salt(tr, dev)
     for li, ((attn, _, ff), w) in enumerate(zip(tr.layers, pw.layers)):
         sv = LayerSaved()
         F, Fp = w["F"], w["Fp"]
@@ -274,8 +294,8 @@ def trunk_forward(tr, pw: PreparedWeights, x: torch.Tensor, keymask: Optional[to
         h2 = torch.empty(M, Fp, dtype=T, device=dev)
         m3 = torch.empty(M, device=dev); r3 = torch.empty(M, device=dev)
         p = float(ff.dropout_p) if training else 0.0
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0
-        ops.ffmid_fwd(h1, w["convw"], w["gamma_mid"], h2, m3, r3, N, F, Fp, p, seed)
+        seed = seeds[li] if (p > 0 and seeds is not None) else 0
+        ops.ffmid_fwd(h1, w["convw"], w["gamma_mid"], h2, m3, r3, N, F, Fp, p, seed, seed_dev=salt if p > 0 else None)
         x2 = torch.empty(M, D, device=dev)
         ops.gemm(h2, w["W2p"], x2, M=M, N=D, K=Fp, Cin=x1)
         if save:
@@ -287,7 +307,7 @@ def trunk_forward(tr, pw: PreparedWeights, x: torch.Tensor, keymask: Optional[to
     mf = torch.empty(M, device=dev); rf = torch.empty(M, device=dev)
     y = torch.empty(M, D, dtype=T, device=dev)
     ops.layernorm_fwd(x, tr.norm.gamma.detach(), y, None, mf, rf)
-    saved = dict(layers=saved_layers, xL=x, mf=mf, rf=rf, table=table, rp=rp_saved, keymask=keymask) if save else None
+    saved = dict(layers=saved_layers, xL=x, mf=mf, rf=rf, table=table, rp=rp_saved, keymask=keymask, salt=salt) if save else None
     return y, saved
 
 
@@ -322,7 +342,8 @@ def trunk_backward(tr, pw: PreparedWeights, saved, dy: torch.Tensor, B: int, N: 
         dh1 = torch.empty(M, 2 * Fp, dtype=T, device=dev)
         gconv = grad_of(ff.conv_param()).view(-1) if ff.conv_param() is not None else None
         ops.ffmid_bwd(dh2, sv.h1, w["convw"], w["gamma_mid"], sv.m3, sv.r3, du, dh1,
-                      grad_of(ff.norm_mid.gamma), gconv, ws, N, F, Fp, sv.p, sv.seed)
+                      grad_of(ff.norm_mid.gamma), gconv, ws, N, F, Fp, sv.p, sv.seed,
+                      seed_dev=saved["salt"] if sv.p > 0 else None)
         del du, dh2
         dxn2 = torch.empty(M, D, device=dev)
         ops.gemm(dh1, w["W1p"], dxn2, M=M, N=D, K=2 * Fp, b_kmajor=True)
@@ -572,9 +593,13 @@ class LossFunction(torch.autograd.Function):
                 st.labels.append(lb32); st.lse_rows.append(lse_rows)
             else:
                 st.labels.append(None); st.lse_rows.append(None)
-        # loss = sum_s w_s * nll_sum_s / total   (== sum_s mean_s * n_s * w_s / sum n_s, :407-410)
-        wt = torch.tensor([float(w) if w > 0 else 0.0 for w in loss_weights], device=dev)
-        loss = (nll * wt).sum() / float(total)
+        # loss = sum_s w_s * nll_sum_s / total   (== sum_s mean_s * n_s * w_s / sum n_s, :407-410); python-scalar
+        # multiplies only: nothing is uploaded from the host here (graph-capture safe)
+        loss = None
+        for s, w in enumerate(loss_weights):
+            if w > 0:
+                term = nll[s] * (float(w) / float(total))
+                loss = term if loss is None else loss + term
         st.coefs = [float(w) / float(total) if w > 0 else 0.0 for w in loss_weights]
         ctx.st = st
         ctx.nparams = len(params)

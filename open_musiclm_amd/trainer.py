@@ -86,7 +86,8 @@ class SingleStageTrainer(nn.Module):
                  grad_accum_every=1, wd=0., max_grad_norm=0.5, valid_frac=0.05, random_split_seed=42,
                  save_results_every=100, save_predicted_tokens=True, save_reconstructed_wave=True,
                  save_model_every=1000, results_folder='./results', accelerate_kwargs: dict = {},
-                 config_paths: Optional[List[str]] = None, dataset_yields_tokens: Optional[bool] = None):
+                 config_paths: Optional[List[str]] = None, dataset_yields_tokens: Optional[bool] = None,
+                 use_hip_graph: Optional[bool] = None):
         super().__init__()
         # accelerate_kwargs is accepted for script compatibility: log_with / logging_dir select the JSONL tracker
         self.dp = DataParallel(device=transformer.device)
@@ -191,7 +192,9 @@ class SingleStageTrainer(nn.Module):
             configs_folder.mkdir(parents=True, exist_ok=True)
             for config_path in config_paths:
                 copy_file_to_folder(config_path, configs_folder)
-        self._loss_acc = None
+        # static-shape token training -> capture the micro-step into a HIP graph (graph.py); raw-audio front-ends stay eager
+        self.use_hip_graph = tokens_in if use_hip_graph is None else use_hip_graph
+        self._graphed = None
 
     # ---- checkpointing (trainer.py:359-391) ----------------------------------------------------------
     def save(self, model_path, optim_path, scheduler_path=None):
@@ -246,6 +249,21 @@ class SingleStageTrainer(nn.Module):
     # ---- one optimizer step (trainer.py:415-552) -------------------------------------------------------
     def micro_step(self, data_kwargs):
         """forward + backward of ONE micro-batch; gradients accumulate in the optimizer's flat buffer."""
+        if self.use_hip_graph and self.device.type == 'cuda':
+            if self._graphed is None:
+                from .graph import GraphedForwardBackward
+                self._graphed = GraphedForwardBackward(lambda **kw: self.train_wrapper(**kw, return_loss=True)[0],
+                                                       loss_scale=1.0 / self.grad_accum_every)
+
+                def discard():                          # warm-up steps really ran: throw their gradients away
+                    self.optim.mark_grads_dirty()
+                    self.optim.zero_grad()
+                self._graphed.prepare(data_kwargs, after_warmup=discard)
+                if self._graphed.capture_error:
+                    self.print(f'HIP graph capture unavailable ({self._graphed.capture_error}); launching eagerly')
+            loss = self._graphed(**data_kwargs)
+            self.optim.mark_grads_dirty()
+            return loss.clone()
         loss, _, _ = self.train_wrapper(**data_kwargs, return_loss=True)
         (loss / self.grad_accum_every).backward()
         self.optim.mark_grads_dirty()

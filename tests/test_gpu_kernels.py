@@ -316,6 +316,12 @@ def test_ffmid_dropout_statistics_and_replay(ops, dev):
     scale_ok = relerr(a[:, :F][kept], (base[:, :F] / 0.9)[kept])
     report("ffmid_dropout", dropped_frac=frac, scale=scale_ok)
     assert torch.equal(a, b) and not torch.equal(a, c)          # mask is a pure function of (seed, element)
+    salt = torch.tensor([5], dtype=torch.int64, device=dev)
+    d, e = torch.empty(M, Fp, device=dev), torch.empty(M, Fp, device=dev)
+    ops.ffmid_fwd(h1, convw, gamma, d, mean, rstd, nseq, F, Fp, 0.1, 1234, seed_dev=salt)
+    salt += 1                                                   # what a graph replay does between steps
+    ops.ffmid_fwd(h1, convw, gamma, e, mean, rstd, nseq, F, Fp, 0.1, 1234, seed_dev=salt)
+    assert not torch.equal(d, a) and not torch.equal(d, e)
     assert abs(frac - 0.1) < 0.02 and scale_ok < 1e-5
 
 
