@@ -31,6 +31,17 @@ __device__ __forceinline__ int tile_off(int row, int colbyte) {
     return row * 128 + ((((colbyte >> 4) ^ ((row >> 1) & 7)) << 4) | (colbyte & 15));
 }
 
+// Blocked image of a [rows][64 dims] tile for the TRANSPOSE read: ds_read_b64_tr_b16 serves a [4 row][16 col] block
+// (128 B) per 16-lane group; blocks are ordered so that a wave's four groups read 512 contiguous bytes
+// (address = unit base + 8 * lane): unit = (row / 16, col / 32) -> 1 KiB; block p = r*4 + hi*2 + cc with
+// (row / 4) & 3 = 2 r + hi (accumulator-row order: read r covers rows +8r, half-wave hi rows +4hi), cc = (col/16) & 1.
+__device__ __forceinline__ int tile_off_blk(int row, int colbyte) {
+    const int col = colbyte >> 1;
+    const int rq = (row >> 2) & 3;
+    const int p = ((rq >> 1) << 2) | ((rq & 1) << 1) | ((col >> 4) & 1);
+    return (((row >> 4) << 1) + (col >> 5)) * 1024 + p * 128 + (row & 3) * 32 + (col & 15) * 2;
+}
+
 // key row held in accumulator register r of a 32x32 MFMA result for half-wave hi
 __device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
@@ -90,6 +101,15 @@ struct KVRegs {
             if (PRECISE) *(bf16x8*)(lds_lo + tile_off(row, ch * 16)) = lo[i];
         }
     }
+    __device__ __forceinline__ void store_blk(char* lds_hi, char* lds_lo) const {      // image for frag_cols_tr
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = threadIdx.x + AT_THREADS * i;
+            const int row = c >> 3, ch = c & 7;
+            *(bf16x8*)(lds_hi + tile_off_blk(row, ch * 16)) = hi[i];
+            if (PRECISE) *(bf16x8*)(lds_lo + tile_off_blk(row, ch * 16)) = lo[i];
+        }
+    }
 };
 
 // normal operand fragment: row = row0 + (lane & 31), dims 16 s + 8 (lane >> 5) .. +7
@@ -99,11 +119,10 @@ __device__ __forceinline__ bf16x8 frag_rows(const char* lds, int row0, int s, in
 // transposed operand fragment from a [rows][64] tile: lane gets column (col0 + (lane & 31)) and the 8 tile rows
 // that MFMA k-index 8*(lane>>5)+e maps to under the accumulator row order:  row0 + 16 s + 8 (e>>2) + 4 (lane>>5) + (e&3)
 __device__ __forceinline__ bf16x8 frag_cols_tr(const char* lds, int row0, int s, int col0, int lane) {
-    const int hi = lane >> 5, g = (lane >> 4) & 1, i = lane & 15;
-    const int r1 = row0 + 16 * s + 4 * hi + (i >> 2);
-    const int colbyte = (col0 + 16 * g + 4 * (i & 3)) * 2;
-    s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, lds + tile_off(r1, colbyte)));
-    s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, lds + tile_off(r1 + 8, colbyte)));
+    // blocked image (tile_off_blk): both reads are linear in the lane id
+    const char* base = lds + ((((row0 >> 4) + s) << 1) + (col0 >> 5)) * 1024 + lane * 8;
+    s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base));
+    s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base + 512));
     typedef __attribute__((ext_vector_type(8))) short s16x8;
     s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8, v);
@@ -178,7 +197,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const T* __restric
         const int j0 = kt * TKV;
         __syncthreads();
         kr.store(Kh, Kl);
-        vr.store(Vh, Vl);
+        vr.store_blk(Vh, Vl);
         const int jk = j0 + lane;
         const bool live = jk < N && (keymask ? keymask[rowbase + jk] != 0 : true);
         const unsigned long long bits = __ballot(live);
@@ -271,8 +290,9 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(const T* __rest
                                                                  int B, int N, int H, float scale, int bias_ld) {
     constexpr int PLANE = TKV * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Ks = smem;
-    char* Vs = smem + PLANE;
+    char* Ks = smem;                       // K rows  (S^T = K Q^T)
+    char* Vs = smem + PLANE;               // V rows  (dP^T = V dO^T)
+    char* Kt = smem + 2 * PLANE;           // K again, blocked for the transpose read (dQ^T += K^T dS^T)
     const int nqt = (N + TQ - 1) / TQ;
     const int qt = nqt - 1 - (int)blockIdx.x;
     const int b = blockIdx.z;
@@ -282,8 +302,8 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(const T* __rest
     const int i0 = qt * TQ;
     const int qi = i0 + (lane & 31);
     const int nb = i0 + TQ;
-    float* bias_l = (float*)(smem + 2 * PLANE) + (size_t)wave * nb;              // [4][nb]
-    float* dbias_l = (float*)(smem + 2 * PLANE) + (size_t)(4 + wave) * nb;       // [4][nb]
+    float* bias_l = (float*)(smem + 3 * PLANE) + (size_t)wave * nb;              // [4][nb]
+    float* dbias_l = (float*)(smem + 3 * PLANE) + (size_t)(4 + wave) * nb;       // [4][nb]
     const size_t rowbase = (size_t)b * N;
     const size_t qrow = (rowbase + min(qi, N - 1)) * (size_t)(H * 64) + (active ? h : 0) * 64;
 
@@ -323,6 +343,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(const T* __rest
         const int j0 = kt * TKV;
         __syncthreads();
         kr.store(Ks, Ks);
+        kr.store_blk(Kt, Kt);
         vr.store(Vs, Vs);
         const int jk = j0 + lane;
         const bool live = jk < N && (keymask ? keymask[rowbase + jk] != 0 : true);
@@ -362,7 +383,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(const T* __rest
                 pack_acc<false>(st, s, dsb, dummy);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
-                    acc[dt] = MFMA(frag_cols_tr(Ks, 32 * sub, s, 32 * dt, lane), dsb, acc[dt]);   // dQ^T += K^T dS^T
+                    acc[dt] = MFMA(frag_cols_tr(Kt, 32 * sub, s, 32 * dt, lane), dsb, acc[dt]);   // dQ^T += K^T dS^T
             }
         }
     }
@@ -446,8 +467,8 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(const T* __res
         if (item + 4 < nitems) fetch(item + 4, qn, don);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {        // park this item's tiles in LDS for the transpose reads
-            *(bf16x8*)(Qs + tile_off(lane & 31, (2 * s + hi) * 16)) = qa[s];
-            *(bf16x8*)(dOs + tile_off(lane & 31, (2 * s + hi) * 16)) = doa[s];
+            *(bf16x8*)(Qs + tile_off_blk(lane & 31, (2 * s + hi) * 16)) = qa[s];
+            *(bf16x8*)(dOs + tile_off_blk(lane & 31, (2 * s + hi) * 16)) = doa[s];
         }
         f32x16 st, dp;
 #pragma unroll
@@ -508,7 +529,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(const T* __res
 
 // =============================================================================================================
 static size_t fwd_lds(int N, bool precise) { return (size_t)(precise ? 4 : 2) * TKV * 128 + (size_t)4 * ((N + TQ - 1) / TQ * TQ) * sizeof(float); }
-static size_t dq_lds(int N) { return (size_t)2 * TKV * 128 + (size_t)8 * ((N + TQ - 1) / TQ * TQ) * sizeof(float); }
+static size_t dq_lds(int N) { return (size_t)3 * TKV * 128 + (size_t)8 * ((N + TQ - 1) / TQ * TQ) * sizeof(float); }
 
 template <typename K>
 static int set_lds(K kernel, size_t bytes) {

@@ -60,9 +60,17 @@ struct GemmArgs {
 __device__ __forceinline__ int lds_off_normal(int row, int kchunk) {
     return row * 128 + ((kchunk ^ ((row >> 1) & 7)) << 4);
 }
-// k-major tile: [64 k][128 cols] bf16, 256 B per row, 64-B segment index XOR (k & 3)
+// k-major tile [64 k][128 cols] bf16, blocked for the transpose read: the unit of ds_read_b64_tr_b16 is a [4 k][16 col]
+// block (128 B, one per 16-lane group).  Blocks are ordered so that the four groups of a wave read four ADJACENT
+// blocks -- one 512-B contiguous run per instruction (address = base + 8 * lane), conflict-free by construction:
+//   1-KiB unit  (j = col / 32, s = k / 16)          -> (j * 4 + s) * 1024
+//   block in unit p = r * 4 + hi * 2 + cc,  kk = (k / 4) & 3 = r + 2 hi,  cc = (col / 16) & 1   -> p * 128
+//   inside block  row k & 3 (32 B), column col & 15
 __device__ __forceinline__ int lds_off_kmaj(int k, int colbyte) {
-    return k * 256 + ((((colbyte >> 6) ^ (k & 3)) << 6) | (colbyte & 63));
+    const int col = colbyte >> 1;
+    const int kk = (k >> 2) & 3;
+    const int p = ((kk & 1) << 2) | ((kk >> 1) << 1) | ((col >> 4) & 1);
+    return (((col >> 5) << 2) + (k >> 4)) * 1024 + p * 128 + (k & 3) * 32 + (col & 15) * 2;
 }
 
 template <typename T, bool KMAJ>
@@ -138,12 +146,11 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, int sub0, int s, in
         const int kc = 2 * s + (lane >> 5);
         return *(const bf16x8*)(lds + lds_off_normal(row, kc));
     } else {
-        // two transpose reads, 4 k each: lane gets column (sub0 + (lane&31)), k = 16s + 8*(lane>>5) + 0..7
-        const int g = (lane >> 4) & 1, i = lane & 15;
-        const int kb = 16 * s + 8 * (lane >> 5) + (i >> 2);
-        const int colbyte = (sub0 + 16 * g + 4 * (i & 3)) * 2;
-        s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, lds + lds_off_kmaj(kb, colbyte)));
-        s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, lds + lds_off_kmaj(kb + 4, colbyte)));
+        // two transpose reads, 4 k each: lane gets column (sub0 + (lane&31)), k = 16s + 8*(lane>>5) + 0..7.
+        // In the blocked image both are linear: unit base + 8 * lane, and + 512 for k + 4.
+        const char* base = lds + (((sub0 >> 5) << 2) + s) * 1024 + lane * 8;
+        s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base));
+        s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base + 512));
         typedef __attribute__((ext_vector_type(8))) short s16x8;
         s16x8 v = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
         return __builtin_bit_cast(bf16x8, v);
@@ -286,9 +293,11 @@ struct DmaStager {
                 base[i] = ok ? (unsigned)((pr * ld + kc * 8) * 2) : OOB_OFF;
                 kidx[i] = kc * 8;
             } else {
-                const int krow = 4 * b + (lane >> 4), pos = lane & 15;
-                const int seg = (pos >> 2) ^ (krow & 3);
-                const int gc = r0 + (seg * 4 + (pos & 3)) * 8;
+                // unit b = (j = b >> 2, s = b & 3); lane -> block p = lane >> 3, row (lane & 7) >> 1, column half lane & 1
+                const int p = lane >> 3;
+                const int kk = (p >> 2) + 2 * ((p >> 1) & 1);
+                const int krow = 16 * (b & 3) + 4 * kk + ((lane & 7) >> 1);
+                const int gc = r0 + 32 * (b >> 2) + 16 * (p & 1) + 8 * (lane & 1);
                 base[i] = gc < nvalid ? (unsigned)(gc * 2) : OOB_OFF;
                 kidx[i] = krow;
             }
