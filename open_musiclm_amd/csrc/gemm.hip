@@ -37,6 +37,7 @@
 // K = all tokens of the batch; gridDim.y splits K and the epilogue accumulates with fp32 atomics
 // into C (these GEMMs are "C += ..." by construction: gradients accumulate over micro-batches).
 #include "common.h"
+#include <stdlib.h>
 
 #define BM 128
 #define BN 128
@@ -397,6 +398,158 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(GemmArgs g) {
     epilogue<TOUT>(g, acc, m0, n0, wm, wn, lane);
 }
 
+
+// ---- bf16 fast path v3: 4-stage LDS ring (BK = 32), counted vmcnt, raw barrier -----------------------------------
+// Stage = A tile [128][32] (8 KiB) | B tile (8 KiB).  Three tiles are requested ahead of the one being multiplied; the
+// top of iteration t waits only until tile t has landed (s_waitcnt vmcnt(8): the 2 x 4 DMA instructions of tiles t+1
+// and t+2 stay in flight ACROSS the barrier -- __syncthreads() would drain them), then one raw s_barrier publishes
+// tile t to all waves and proves everyone left tile t-1, whose stage is immediately re-filled with tile t+3.
+#define BK3 32
+#define NSTAGE 4
+// normal tile: [128 rows][32 k] bf16, 64 B per row, 16-B chunk index XOR ((row >> 2) & 3)  (conflict-free b128 reads)
+__device__ __forceinline__ int lds3_off_normal(int row, int kc) { return row * 64 + ((kc ^ ((row >> 2) & 3)) << 4); }
+
+template <bool KMAJ>
+struct DmaStager3 {
+    unsigned base[2];
+    int kidx[2];
+    __device__ __forceinline__ void init(const int* map, int ld, int nvalid, int r0, int wave, int lane) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int u = wave + 4 * i;                            // 8 one-KiB units per operand tile
+            if (!KMAJ) {
+                const int row = 16 * u + (lane >> 2), slot = lane & 3;
+                const int kc = slot ^ ((row >> 2) & 3);
+                const int gr = r0 + row;
+                const bool ok = gr < nvalid;
+                const long long pr = (ok && map) ? (long long)map[gr] : (long long)gr;
+                base[i] = ok ? (unsigned)((pr * ld + kc * 8) * 2) : OOB_OFF;
+                kidx[i] = kc * 8;
+            } else {
+                // unit u = (j = u >> 1, s = u & 1); blocked image as in lds_off_kmaj
+                const int p = lane >> 3;
+                const int kk = (p >> 2) + 2 * ((p >> 1) & 1);
+                const int krow = 16 * (u & 1) + 4 * kk + ((lane & 7) >> 1);
+                const int gc = r0 + 32 * (u >> 1) + 16 * (p & 1) + 8 * (lane & 1);
+                base[i] = gc < nvalid ? (unsigned)(gc * 2) : OOB_OFF;
+                kidx[i] = krow;
+            }
+        }
+    }
+    __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rs, const int* map, int ld, int k0, int K,
+                                          char* lds_tile, int wave) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int u = wave + 4 * i;
+            unsigned off;
+            if (!KMAJ) {
+                off = (base[i] != OOB_OFF && k0 + kidx[i] < K) ? base[i] + (unsigned)(k0 * 2) : OOB_OFF;
+            } else {
+                const int gk = k0 + kidx[i];
+                const bool ok = base[i] != OOB_OFF && gk < K;
+                const long long pr = (ok && map) ? (long long)map[gk] : (long long)gk;
+                off = ok ? base[i] + (unsigned)(pr * ld * 2) : OOB_OFF;
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(void, lds_tile + u * 1024), 16, (int)off, 0, 0, 0);
+        }
+    }
+};
+
+template <bool KMAJ>
+__device__ __forceinline__ bf16x8 read_frag3(const char* lds, int sub0, int s, int lane) {
+    if (!KMAJ) {
+        const int row = sub0 + (lane & 31);
+        return *(const bf16x8*)(lds + lds3_off_normal(row, 2 * s + (lane >> 5)));
+    } else {
+        const char* base = lds + (((sub0 >> 5) << 1) + s) * 1024 + lane * 8;
+        s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base));
+        s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base + 512));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        s16x8 v = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, v);
+    }
+}
+
+template <bool A_KMAJ, bool B_KMAJ, typename TOUT>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_p4_kernel(GemmArgs g) {
+    constexpr int OPB = BM * BK3 * 2;                        // 8 KiB per operand tile
+    constexpr int STG = 2 * OPB;                             // 16 KiB per stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // ONE LDS object: [NSTAGE][A | B]
+
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int gsz = 8 * tiles_n;
+    const int grp = bid / gsz, first_m = grp * 8;
+    const int rows_in = min(8, tiles_m - first_m);
+    const int tm = first_m + (bid - grp * gsz) % rows_in, tn = (bid - grp * gsz) / rows_in;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(g.A, (unsigned long long)g.a_rows * g.lda * 2);
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(g.B, (unsigned long long)g.b_rows * g.ldb * 2);
+    DmaStager3<A_KMAJ> sa;
+    DmaStager3<B_KMAJ> sb;
+    sa.init(g.a_map, g.lda, g.M, m0, wave, lane);
+    sb.init(g.b_map, g.ldb, g.N, n0, wave, lane);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // split-K bookkeeping is in units of 64 (BK) to stay compatible with the host's kt_per_split
+    const int nk_all = (g.K + BK3 - 1) / BK3;
+    const int t0 = blockIdx.y * g.kt_per_split * 2;
+    const int t1 = min(nk_all, t0 + g.kt_per_split * 2);
+    const int nt = t1 - t0;
+#pragma unroll
+    for (int pre = 0; pre < NSTAGE - 1; ++pre) {
+        if (pre < nt) {
+            sa.issue(rsA, g.a_map, g.lda, (t0 + pre) * BK3, g.K, smem + pre * STG, wave);
+            sb.issue(rsB, g.b_map, g.ldb, (t0 + pre) * BK3, g.K, smem + pre * STG + OPB, wave);
+        }
+    }
+    for (int t = 0; t < nt; ++t) {
+        const int ahead = nt - 1 - t;                        // tiles requested after tile t (each = 4 DMA instructions/wave)
+        if (ahead >= 2)      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + NSTAGE - 1 < nt) {
+            char* dst = smem + ((t + NSTAGE - 1) & (NSTAGE - 1)) * STG;
+            sa.issue(rsA, g.a_map, g.lda, (t0 + t + NSTAGE - 1) * BK3, g.K, dst, wave);
+            sb.issue(rsB, g.b_map, g.ldb, (t0 + t + NSTAGE - 1) * BK3, g.K, dst + OPB, wave);
+        }
+        const char* As = smem + (t & (NSTAGE - 1)) * STG;
+        const char* Bs = As + OPB;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = read_frag3<A_KMAJ>(As, wm + 32 * i, s, lane);
+                b[i] = read_frag3<B_KMAJ>(Bs, wn + 32 * i, s, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    epilogue<TOUT>(g, acc, m0, n0, wm, wn, lane);
+}
+
 template <typename T, typename TOUT>
 static int launch_layout(const GemmArgs& g, int a_kmaj, int b_kmaj, int splits, hipStream_t st) {
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
@@ -407,6 +560,11 @@ static int launch_layout(const GemmArgs& g, int a_kmaj, int b_kmaj, int splits, 
         else if (!a_kmaj && b_kmaj)  hipLaunchKernelGGL((gemm_kernel<T, false, true, TOUT>), grid, block, lds, st, g);
         else if (a_kmaj && b_kmaj)   hipLaunchKernelGGL((gemm_kernel<T, true, true, TOUT>), grid, block, lds, st, g);
         else                         hipLaunchKernelGGL((gemm_kernel<T, true, false, TOUT>), grid, block, lds, st, g);
+    } else if (getenv("OMLM_GEMM_V2") == nullptr) {
+        if (!a_kmaj && !b_kmaj)      hipLaunchKernelGGL((gemm_bf16_p4_kernel<false, false, TOUT>), grid, block, lds, st, g);
+        else if (!a_kmaj && b_kmaj)  hipLaunchKernelGGL((gemm_bf16_p4_kernel<false, true, TOUT>), grid, block, lds, st, g);
+        else if (a_kmaj && b_kmaj)   hipLaunchKernelGGL((gemm_bf16_p4_kernel<true, true, TOUT>), grid, block, lds, st, g);
+        else                         hipLaunchKernelGGL((gemm_bf16_p4_kernel<true, false, TOUT>), grid, block, lds, st, g);
     } else {
         if (!a_kmaj && !b_kmaj)      hipLaunchKernelGGL((gemm_bf16_kernel<false, false, TOUT>), grid, block, lds, st, g);
         else if (!a_kmaj && b_kmaj)  hipLaunchKernelGGL((gemm_bf16_kernel<false, true, TOUT>), grid, block, lds, st, g);
@@ -466,6 +624,14 @@ extern "C" int omlm_gemm(const void* A, const void* B, void* C, const float* Cin
     }
     static bool attr16 = false;
     if (!attr16) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_p4_kernel<false, false, float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_p4_kernel<false, true, float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_p4_kernel<true, true, float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_p4_kernel<true, false, float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_p4_kernel<false, false, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_p4_kernel<false, true, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_p4_kernel<true, true, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_p4_kernel<true, false, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, false, float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, true, float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, true, float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
