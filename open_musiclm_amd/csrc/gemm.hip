@@ -550,6 +550,176 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_p4_kernel(GemmArgs g) {
     epilogue<TOUT>(g, acc, m0, n0, wm, wn, lane);
 }
 
+
+// ---- bf16 fast path, generalised tile: BM_ x BN_ x 64 per workgroup, waves of WM_ x WN_ -------------------------------
+// Measured on MI355X: the 128x128 kernel saturates the L2 -> LDS DMA path (~10-12 TB/s chip-wide) at ~600 TFLOP/s because
+// a 128x128x64 tile moves 32 KiB per 2.1 MFLOP (64 FLOP/B).  256x256 (8 waves of 128x64) doubles that to 128 FLOP/B,
+// 256x128 (8 waves of 64x64) gives 85 FLOP/B for the narrow-N GEMMs where 256-wide tiles would leave CUs idle.
+// Same LDS images, DMA staging, double buffering and one barrier per k-tile as gemm_bf16_kernel above.
+template <bool KMAJ, int ROWS, int NWAVES>
+struct DmaStagerT {
+    static constexpr int UPW = (ROWS / 8) / NWAVES;       // 1-KiB units per wave per tile
+    unsigned base[UPW];
+    int kidx[UPW];
+    __device__ __forceinline__ void init(const int* map, int ld, int nvalid, int r0, int wave, int lane) {
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) {
+            const int b = wave + NWAVES * i;
+            if (!KMAJ) {
+                const int row = 8 * b + (lane >> 3), slot = lane & 7;
+                const int kc = slot ^ ((row >> 1) & 7);
+                const int gr = r0 + row;
+                const bool ok = gr < nvalid;
+                const long long pr = (ok && map) ? (long long)map[gr] : (long long)gr;
+                base[i] = ok ? (unsigned)((pr * ld + kc * 8) * 2) : OOB_OFF;
+                kidx[i] = kc * 8;
+            } else {
+                const int p = lane >> 3;
+                const int kk = (p >> 2) + 2 * ((p >> 1) & 1);
+                const int krow = 16 * (b & 3) + 4 * kk + ((lane & 7) >> 1);
+                const int gc = r0 + 32 * (b >> 2) + 16 * (p & 1) + 8 * (lane & 1);
+                base[i] = gc < nvalid ? (unsigned)(gc * 2) : OOB_OFF;
+                kidx[i] = krow;
+            }
+        }
+    }
+    __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rs, const int* map, int ld, int k0, int K,
+                                          char* lds_tile, int wave) {
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) {
+            const int b = wave + NWAVES * i;
+            unsigned off;
+            if (!KMAJ) {
+                off = (base[i] != OOB_OFF && k0 + kidx[i] < K) ? base[i] + (unsigned)(k0 * 2) : OOB_OFF;
+            } else {
+                const int gk = k0 + kidx[i];
+                const bool ok = base[i] != OOB_OFF && gk < K;
+                const long long pr = (ok && map) ? (long long)map[gk] : (long long)gk;
+                off = ok ? base[i] + (unsigned)(pr * ld * 2) : OOB_OFF;
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(void, lds_tile + b * 1024), 16, (int)off, 0, 0, 0);
+        }
+    }
+};
+
+template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ, bool B_KMAJ, typename TOUT>
+__global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile_kernel(GemmArgs g) {
+    constexpr int NWN = BN_ / WN_, NWAVES = (BM_ / WM_) * NWN;
+    constexpr int MI = WM_ / 32, NJ = WN_ / 32;
+    constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BN_ * BK * 2, STAGE = A_BYTES + B_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A | B]
+
+    const int tiles_m = (g.M + BM_ - 1) / BM_, tiles_n = (g.N + BN_ - 1) / BN_;
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    constexpr int GROUP = 1024 / BM_;                       // tile rows per super-tile (same footprint as the 128 kernel's 8)
+    const int gsz = GROUP * tiles_n;
+    const int grp = bid / gsz, first_m = grp * GROUP;
+    const int rows_in = min(GROUP, tiles_m - first_m);
+    const int tm = first_m + (bid - grp * gsz) % rows_in, tn = (bid - grp * gsz) / rows_in;
+    const int m0 = tm * BM_, n0 = tn * BN_;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = (wave / NWN) * WM_, wn = (wave % NWN) * WN_;
+
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(g.A, (unsigned long long)g.a_rows * g.lda * 2);
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(g.B, (unsigned long long)g.b_rows * g.ldb * 2);
+    DmaStagerT<A_KMAJ, BM_, NWAVES> sa;
+    DmaStagerT<B_KMAJ, BN_, NWAVES> sb;
+    sa.init(g.a_map, g.lda, g.M, m0, wave, lane);
+    sb.init(g.b_map, g.ldb, g.N, n0, wave, lane);
+
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk_all = (g.K + BK - 1) / BK;
+    const int kt0 = blockIdx.y * g.kt_per_split;
+    const int kt1 = min(nk_all, kt0 + g.kt_per_split);
+    if (kt0 < kt1) {
+        sa.issue(rsA, g.a_map, g.lda, kt0 * BK, g.K, smem, wave);
+        sb.issue(rsB, g.b_map, g.ldb, kt0 * BK, g.K, smem + A_BYTES, wave);
+    }
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        __syncthreads();          // waits vmcnt(0): tile kt landed everywhere, and the other stage is free
+        if (kt + 1 < kt1) {
+            char* nxt = smem + (cur ^ 1) * STAGE;
+            sa.issue(rsA, g.a_map, g.lda, (kt + 1) * BK, g.K, nxt, wave);
+            sb.issue(rsB, g.b_map, g.ldb, (kt + 1) * BK, g.K, nxt + A_BYTES, wave);
+        }
+        const char* As = smem + cur * STAGE;
+        const char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 a[MI], b[NJ];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a[i] = read_frag<A_KMAJ>(As, wm + 32 * i, s, lane);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) b[j] = read_frag<B_KMAJ>(Bs, wn + 32 * j, s, lane);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // epilogue (C-layout of v_mfma_f32_32x32x16: col = lane & 31, row = (e&3) + 8*(e>>2) + 4*(lane>>5))
+    TOUT* C = (TOUT*)g.C;
+    const bool split = gridDim.y > 1;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = m0 + wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            if (row >= g.M) continue;
+            const long long prow = g.c_map ? (long long)g.c_map[row] : (long long)row;
+            if (prow < 0) continue;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int col = n0 + wn + 32 * j + (lane & 31);
+                if (col >= g.N) continue;
+                float v = g.alpha * acc[i][j][e];
+                if (split) {
+                    unsafeAtomicAdd((float*)g.C + prow * g.ldc + col, v);
+                } else {
+                    if (g.Cin) v += g.Cin[prow * g.ldcin + col];
+                    store_from_float(C + prow * g.ldc + col, v);
+                }
+            }
+        }
+    }
+}
+
+template <int BM_, int BN_, int WM_, int WN_, typename TOUT>
+static int launch_tile(const GemmArgs& g, int a_kmaj, int b_kmaj, int splits, hipStream_t st) {
+    constexpr int NTH = (BM_ / WM_) * (BN_ / WN_) * 64;
+    constexpr size_t LDS = 2 * (size_t)(BM_ + BN_) * BK * 2;
+    const int tiles = ((g.M + BM_ - 1) / BM_) * ((g.N + BN_ - 1) / BN_);
+    dim3 grid(tiles, splits), block(NTH);
+#define OMLM_TILE_LAUNCH(AK, BKM)                                                                                          \
+    do {                                                                                                                    \
+        auto kfn = gemm_bf16_tile_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT>;                                               \
+        static bool attr = false;                                                                                           \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); attr = true; } \
+        hipLaunchKernelGGL(kfn, grid, block, LDS, st, g);                                                                  \
+    } while (0)
+    if (!a_kmaj && !b_kmaj)      OMLM_TILE_LAUNCH(false, false);
+    else if (!a_kmaj && b_kmaj)  OMLM_TILE_LAUNCH(false, true);
+    else if (a_kmaj && b_kmaj)   OMLM_TILE_LAUNCH(true, true);
+    else                         OMLM_TILE_LAUNCH(true, false);
+#undef OMLM_TILE_LAUNCH
+    return omlm_post_launch("omlm_gemm");
+}
+
 template <typename T, typename TOUT>
 static int launch_layout(const GemmArgs& g, int a_kmaj, int b_kmaj, int splits, hipStream_t st) {
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
@@ -560,7 +730,7 @@ static int launch_layout(const GemmArgs& g, int a_kmaj, int b_kmaj, int splits, 
         else if (!a_kmaj && b_kmaj)  hipLaunchKernelGGL((gemm_kernel<T, false, true, TOUT>), grid, block, lds, st, g);
         else if (a_kmaj && b_kmaj)   hipLaunchKernelGGL((gemm_kernel<T, true, true, TOUT>), grid, block, lds, st, g);
         else                         hipLaunchKernelGGL((gemm_kernel<T, true, false, TOUT>), grid, block, lds, st, g);
-    } else if (getenv("OMLM_GEMM_V2") == nullptr) {
+    } else if (getenv("OMLM_GEMM_RING") != nullptr) {
         if (!a_kmaj && !b_kmaj)      hipLaunchKernelGGL((gemm_bf16_p4_kernel<false, false, TOUT>), grid, block, lds, st, g);
         else if (!a_kmaj && b_kmaj)  hipLaunchKernelGGL((gemm_bf16_p4_kernel<false, true, TOUT>), grid, block, lds, st, g);
         else if (a_kmaj && b_kmaj)   hipLaunchKernelGGL((gemm_bf16_p4_kernel<true, true, TOUT>), grid, block, lds, st, g);
@@ -599,12 +769,21 @@ extern "C" int omlm_gemm(const void* A, const void* B, void* C, const float* Cin
     g.a_rows = a_rows; g.b_rows = b_rows; g.M = M; g.N = N; g.K = K;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldcin = ldcin; g.alpha = alpha;
     hipStream_t st = as_stream(stream);
+    // tile shape (bf16 path): 256x256 when both output dims are wide, 256x128 for tall-narrow outputs, else 128x128
+    int bm = BM, bn = BN;
+    const char* force = getenv("OMLM_GEMM_TILE");
+    if (in_dtype == 1) {
+        if (force) { if (!strcmp(force, "256x256")) { bm = 256; bn = 256; } else if (!strcmp(force, "256x128")) { bm = 256; bn = 128; } }
+        else if (M >= 1024 && N >= 1536) { bm = 256; bn = 256; }
+        else if (M >= 2048 && N >= 256) { bm = 256; bn = 128; }
+        else if (N >= 2048 && M >= 256) { bm = 256; bn = 256; }
+    }
     // split-K only for accumulate-into-C GEMMs with few output tiles (the weight-gradient contractions)
     const int nk = (K + BK - 1) / BK;
-    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const int tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
     int splits = 1;
-    if (Cin == (const float*)C && out_dtype == 0 && tiles < 768 && nk >= 16) {
-        splits = (1536 + tiles - 1) / tiles;
+    if (Cin == (const float*)C && out_dtype == 0 && tiles < 512 && nk >= 16) {
+        splits = (1024 + tiles - 1) / tiles;
         if (splits > nk / 8) splits = nk / 8;
         if (splits < 1) splits = 1;
     }
@@ -642,6 +821,12 @@ extern "C" int omlm_gemm(const void* A, const void* B, void* C, const float* Cin
         (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, false, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         attr16 = true;
     }
+    if (bm == 256 && bn == 256)
+        return out_dtype == 0 ? launch_tile<256, 256, 128, 64, float>(g, a_kmajor, b_kmajor, splits, st)
+                              : launch_tile<256, 256, 128, 64, bf16_t>(g, a_kmajor, b_kmajor, splits, st);
+    if (bm == 256 && bn == 128)
+        return out_dtype == 0 ? launch_tile<256, 128, 64, 64, float>(g, a_kmajor, b_kmajor, splits, st)
+                              : launch_tile<256, 128, 64, 64, bf16_t>(g, a_kmajor, b_kmajor, splits, st);
     if (out_dtype == 0) return launch_layout<bf16_t, float>(g, a_kmajor, b_kmajor, splits, st);
     return launch_layout<bf16_t, bf16_t>(g, a_kmajor, b_kmajor, splits, st);
 }
