@@ -658,18 +658,28 @@ __global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile
         }
         const char* As = smem + cur * STAGE;
         const char* Bs = As + A_BYTES;
+        // software-pipelined fragments: the LDS reads of k16-step s+1 are issued BEFORE the MFMAs of step s, so their
+        // latency hides under the matrix pipe (hipcc's own schedule read-then-multiplied each step: MFMA busy 30 %)
+        bf16x8 a[2][MI], b[2][NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[0][i] = read_frag<A_KMAJ>(As, wm + 32 * i, 0, lane);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) b[0][j] = read_frag<B_KMAJ>(Bs, wn + 32 * j, 0, lane);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            bf16x8 a[MI], b[NJ];
+            if (s < 3) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i) a[i] = read_frag<A_KMAJ>(As, wm + 32 * i, s, lane);
+                for (int i = 0; i < MI; ++i) a[(s + 1) & 1][i] = read_frag<A_KMAJ>(As, wm + 32 * i, s + 1, lane);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) b[j] = read_frag<B_KMAJ>(Bs, wn + 32 * j, s, lane);
+                for (int j = 0; j < NJ; ++j) b[(s + 1) & 1][j] = read_frag<B_KMAJ>(Bs, wn + 32 * j, s + 1, lane);
+                __builtin_amdgcn_sched_barrier(0);                            // DS reads of step s+1 stay above ...
+            }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s & 1][i], b[s & 1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);                                // ... the MFMAs of step s
         }
     }
     // epilogue (C-layout of v_mfma_f32_32x32x16: col = lane & 31, row = (e&3) + 8*(e>>2) + 4*(lane>>5))
@@ -773,7 +783,7 @@ extern "C" int omlm_gemm(const void* A, const void* B, void* C, const float* Cin
     int bm = BM, bn = BN;
     const char* force = getenv("OMLM_GEMM_TILE");
     if (in_dtype == 1) {
-        if (force) { if (!strcmp(force, "256x256")) { bm = 256; bn = 256; } else if (!strcmp(force, "256x128")) { bm = 256; bn = 128; } }
+        if (force && force[0]) { if (!strcmp(force, "256x256")) { bm = 256; bn = 256; } else if (!strcmp(force, "256x128")) { bm = 256; bn = 128; } }
         else if (M >= 1024 && N >= 1536) { bm = 256; bn = 256; }
         else if (M >= 2048 && N >= 256) { bm = 256; bn = 128; }
         else if (N >= 2048 && M >= 256) { bm = 256; bn = 256; }
@@ -827,6 +837,9 @@ extern "C" int omlm_gemm(const void* A, const void* B, void* C, const float* Cin
     if (bm == 256 && bn == 128)
         return out_dtype == 0 ? launch_tile<256, 128, 64, 64, float>(g, a_kmajor, b_kmajor, splits, st)
                               : launch_tile<256, 128, 64, 64, bf16_t>(g, a_kmajor, b_kmajor, splits, st);
+    if (getenv("OMLM_GEMM_LEGACY") == nullptr)
+        return out_dtype == 0 ? launch_tile<128, 128, 64, 64, float>(g, a_kmajor, b_kmajor, splits, st)
+                              : launch_tile<128, 128, 64, 64, bf16_t>(g, a_kmajor, b_kmajor, splits, st);
     if (out_dtype == 0) return launch_layout<bf16_t, float>(g, a_kmajor, b_kmajor, splits, st);
     return launch_layout<bf16_t, bf16_t>(g, a_kmajor, b_kmajor, splits, st);
 }
