@@ -54,6 +54,7 @@ struct GemmArgs {
     int lda, ldb, ldc, ldcin;
     float alpha;
     int kt_per_split;   // k-tiles handled by one blockIdx.y slice (split-K); gridDim.y == 1 -> all
+    int debug;          // profiling ablations only (OMLM_GEMM_DEBUG): bit 0 = skip the per-tile DMA, bit 1 = skip the MFMAs
 };
 
 // ---- LDS images ---------------------------------------------------------------------------
@@ -651,7 +652,7 @@ __global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile
     for (int kt = kt0; kt < kt1; ++kt) {
         const int cur = (kt - kt0) & 1;
         __syncthreads();          // waits vmcnt(0): tile kt landed everywhere, and the other stage is free
-        if (kt + 1 < kt1) {
+        if (kt + 1 < kt1 && !(g.debug & 1)) {
             char* nxt = smem + (cur ^ 1) * STAGE;
             sa.issue(rsA, g.a_map, g.lda, (kt + 1) * BK, g.K, nxt, wave);
             sb.issue(rsB, g.b_map, g.ldb, (kt + 1) * BK, g.K, nxt + A_BYTES, wave);
@@ -677,33 +678,76 @@ __global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j)
+                for (int j = 0; j < NJ; ++j) {
+                    if (g.debug & 2) { asm volatile("" :: "v"(a[s & 1][i]), "v"(b[s & 1][j])); continue; }
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s & 1][i], b[s & 1][j], acc[i][j], 0, 0, 0);
+                }
             __builtin_amdgcn_sched_barrier(0);                                // ... the MFMAs of step s
         }
     }
-    // epilogue (C-layout of v_mfma_f32_32x32x16: col = lane & 31, row = (e&3) + 8*(e>>2) + 4*(lane>>5))
+    // Epilogue.  In the MFMA C-layout a lane owns ONE column and 16 rows, so direct stores are 2- or 4-byte scatters
+    // (measured: ~480 of 650 us of the FF-in GEMM).  Each 32-row strip of the wave's tile is therefore transposed
+    // through a per-wave LDS patch (the k-loop stages are dead after the barrier) and written as 16-byte row-contiguous
+    // stores: 8 bf16 / 4 fp32 per lane, full 128-byte lines per row.
+    __syncthreads();
+    constexpr int SROW = WN_ + 4;                                  // padded row (floats), keeps 16-B alignment
+    float* stg = (float*)smem + (size_t)wave * 32 * SROW;
+    constexpr int VEC = sizeof(TOUT) == 2 ? 8 : 4;                 // elements per 16-byte store
+    constexpr int LPR = WN_ / VEC;                                 // lanes per row
+    constexpr int RPP = 64 / LPR;                                  // rows per pass
     TOUT* C = (TOUT*)g.C;
     const bool split = gridDim.y > 1;
+    const bool vec_ok = (g.ldc % VEC == 0) && (((uintptr_t)g.C & 15) == 0) &&
+                        (!g.Cin || ((g.ldcin % 4 == 0) && (((uintptr_t)g.Cin & 15) == 0)));
+    const int hi = lane >> 5;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = m0 + wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-            if (row >= g.M) continue;
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                stg[((e & 3) + 8 * (e >> 2) + 4 * hi) * SROW + 32 * j + (lane & 31)] = g.alpha * acc[i][j][e];
+#pragma unroll
+        for (int pass = 0; pass < 32 / RPP; ++pass) {
+            const int r = pass * RPP + lane / LPR, c = (lane % LPR) * VEC;
+            const int row = m0 + wm + 32 * i + r, col = n0 + wn + c;
+            float v[VEC];
+#pragma unroll
+            for (int x = 0; x < VEC; x += 4) {
+                const float4 t = *(const float4*)(stg + r * SROW + c + x);
+                v[x] = t.x; v[x + 1] = t.y; v[x + 2] = t.z; v[x + 3] = t.w;
+            }
+            if (row >= g.M || col >= g.N) continue;
             const long long prow = g.c_map ? (long long)g.c_map[row] : (long long)row;
             if (prow < 0) continue;
+            if (split) {                                           // split-K slices accumulate into fp32 C (Cin == C)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int col = n0 + wn + 32 * j + (lane & 31);
-                if (col >= g.N) continue;
-                float v = g.alpha * acc[i][j][e];
-                if (split) {
-                    unsafeAtomicAdd((float*)g.C + prow * g.ldc + col, v);
-                } else {
-                    if (g.Cin) v += g.Cin[prow * g.ldcin + col];
-                    store_from_float(C + prow * g.ldc + col, v);
+                for (int x = 0; x < VEC; ++x)
+                    if (col + x < g.N) unsafeAtomicAdd((float*)g.C + prow * g.ldc + col + x, v[x]);
+            } else if (vec_ok && col + VEC <= g.N) {
+                if (g.Cin) {
+#pragma unroll
+                    for (int x = 0; x < VEC; x += 4) {
+                        const float4 t = *(const float4*)(g.Cin + prow * g.ldcin + col + x);
+                        v[x] += t.x; v[x + 1] += t.y; v[x + 2] += t.z; v[x + 3] += t.w;
+                    }
                 }
+                if (sizeof(TOUT) == 2) {
+                    u32x4 o;
+                    o[0] = pack_bf16_rne(v[0], v[1]); o[1] = pack_bf16_rne(v[2], v[3]);
+                    o[2] = pack_bf16_rne(v[4 % VEC], v[5 % VEC]); o[3] = pack_bf16_rne(v[6 % VEC], v[7 % VEC]);
+                    *(u32x4*)(C + prow * g.ldc + col) = o;
+                } else {
+                    *(float4*)((float*)g.C + prow * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            } else {
+#pragma unroll
+                for (int x = 0; x < VEC; ++x)
+                    if (col + x < g.N) {
+                        float o = v[x];
+                        if (g.Cin) o += g.Cin[prow * g.ldcin + col + x];
+                        store_from_float(C + prow * g.ldc + col + x, o);
+                    }
             }
         }
     }
@@ -778,6 +822,7 @@ extern "C" int omlm_gemm(const void* A, const void* B, void* C, const float* Cin
     g.A = A; g.B = B; g.C = C; g.Cin = Cin; g.a_map = a_map; g.b_map = b_map; g.c_map = c_map;
     g.a_rows = a_rows; g.b_rows = b_rows; g.M = M; g.N = N; g.K = K;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldcin = ldcin; g.alpha = alpha;
+    { const char* dbg = getenv("OMLM_GEMM_DEBUG"); g.debug = dbg ? atoi(dbg) : 0; }
     hipStream_t st = as_stream(stream);
     // tile shape (bf16 path): 256x256 when both output dims are wide, 256x128 for tall-narrow outputs, else 128x128
     int bm = BM, bn = BN;

@@ -31,3 +31,34 @@ for tile in os.environ.get("TILES", "128x128,256x256,256x128").split(","):
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / reps
         print(f"{tile:8s} {name:18s} {us:8.1f} us  {2.0 * M * F2 * D / us / 1e6:7.1f} TFLOP/s", flush=True)
+
+# ---- A/B: same FF-in GEMM with padded row pitch (tests the power-of-two-stride L2 channel-conflict hypothesis)
+if os.environ.get("PITCH_AB", "1") == "1":
+    for pad in (0, 8, 32, 64, 128):
+        Xp = torch.zeros(M, D + pad, device=dev, dtype=torch.bfloat16); Xp[:, :D] = X
+        Wp = torch.zeros(F2, D + pad, device=dev, dtype=torch.bfloat16); Wp[:, :D] = W
+        for tile in ("128x128", "256x256"):
+            os.environ["OMLM_GEMM_TILE"] = tile
+            fn = lambda: ops.gemm(Xp, Wp, H, M=M, N=F2, K=D, lda=D + pad, ldb=D + pad)
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps): fn()
+            e1.record(); torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / reps
+            print(f"pitch {D + pad:5d} {tile:8s} ffin_NT {us:8.1f} us  {2.0 * M * F2 * D / us / 1e6:7.1f} TFLOP/s", flush=True)
+
+if os.environ.get("ABLATE", "1") == "1":
+    for tile in ("128x128", "256x256"):
+        os.environ["OMLM_GEMM_TILE"] = tile
+        for dbg, label in ((0, "full"), (1, "no-DMA"), (2, "no-MFMA"), (3, "no-DMA no-MFMA")):
+            os.environ["OMLM_GEMM_DEBUG"] = str(dbg)
+            fn = shapes["ffin_NT_bf16out"]
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps): fn()
+            e1.record(); torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / reps
+            print(f"ablate {tile:8s} {label:16s} {us:8.1f} us", flush=True)
+    os.environ["OMLM_GEMM_DEBUG"] = "0"
