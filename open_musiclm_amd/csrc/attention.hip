@@ -271,8 +271,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const T* __restric
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             const int d = 32 * dt + 8 * g4 + 4 * hi;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) store_from_float(orow + d + e, acc[dt][4 * g4 + e] * inv);
+            store4_from_float(orow + d, acc[dt][4 * g4] * inv, acc[dt][4 * g4 + 1] * inv, acc[dt][4 * g4 + 2] * inv, acc[dt][4 * g4 + 3] * inv);
         }
     if (hi == 0 && lse) lse[((size_t)b * H + h) * N + qi] = m + log2f(lsum);   // log2 domain
 }

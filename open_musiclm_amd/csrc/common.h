@@ -134,4 +134,13 @@ __device__ __forceinline__ float load_as_float(const bf16_t* p) { return (float)
 __device__ __forceinline__ void store_from_float(float* p, float v) { *p = v; }
 __device__ __forceinline__ void store_from_float(bf16_t* p, float v) { *p = (bf16_t)v; }
 
+// 4 consecutive outputs as ONE store (16 B fp32 / 8 B bf16) -- scalar bf16 stores are 2-byte scatters
+__device__ __forceinline__ void store4_from_float(float* p, float a, float b, float c, float d) { *(float4*)p = make_float4(a, b, c, d); }
+__device__ __forceinline__ void store4_from_float(bf16_t* p, float a, float b, float c, float d) {
+    u32x2 o;
+    o[0] = pack_bf16_rne(a, b);
+    o[1] = pack_bf16_rne(c, d);
+    *(u32x2*)p = o;
+}
+
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }

@@ -662,6 +662,7 @@ __global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile
         // software-pipelined fragments: the LDS reads of k16-step s+1 are issued BEFORE the MFMAs of step s, so their
         // latency hides under the matrix pipe (hipcc's own schedule read-then-multiplied each step: MFMA busy 30 %)
         bf16x8 a[2][MI], b[2][NJ];
+        if (g.debug & 8) continue;
 #pragma unroll
         for (int i = 0; i < MI; ++i) a[0][i] = read_frag<A_KMAJ>(As, wm + 32 * i, 0, lane);
 #pragma unroll
@@ -700,6 +701,24 @@ __global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile
     const bool vec_ok = (g.ldc % VEC == 0) && (((uintptr_t)g.C & 15) == 0) &&
                         (!g.Cin || ((g.ldcin % 4 == 0) && (((uintptr_t)g.Cin & 15) == 0)));
     const int hi = lane >> 5;
+    if (g.debug & 4) return;
+    if (split) {      // split-K slices accumulate into fp32 C (Cin == C): the C-layout already gives 128-B coalesced atomics
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                if (row >= g.M) continue;
+                const long long prow = g.c_map ? (long long)g.c_map[row] : (long long)row;
+                if (prow < 0) continue;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int col = n0 + wn + 32 * j + (lane & 31);
+                    if (col < g.N) unsafeAtomicAdd((float*)g.C + prow * g.ldc + col, g.alpha * acc[i][j][e]);
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -720,11 +739,7 @@ __global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile
             if (row >= g.M || col >= g.N) continue;
             const long long prow = g.c_map ? (long long)g.c_map[row] : (long long)row;
             if (prow < 0) continue;
-            if (split) {                                           // split-K slices accumulate into fp32 C (Cin == C)
-#pragma unroll
-                for (int x = 0; x < VEC; ++x)
-                    if (col + x < g.N) unsafeAtomicAdd((float*)g.C + prow * g.ldc + col + x, v[x]);
-            } else if (vec_ok && col + VEC <= g.N) {
+            if (vec_ok && col + VEC <= g.N) {
                 if (g.Cin) {
 #pragma unroll
                     for (int x = 0; x < VEC; x += 4) {

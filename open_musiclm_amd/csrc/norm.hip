@@ -45,14 +45,10 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restr
             if (c < nv) {
                 const float4 g = ((const float4*)gamma)[c];
                 T* yo = y + (size_t)row * ldy + 4 * c;
-                store_from_float(yo + 0, (v[i].x - mu) * rs * g.x);
-                store_from_float(yo + 1, (v[i].y - mu) * rs * g.y);
-                store_from_float(yo + 2, (v[i].z - mu) * rs * g.z);
-                store_from_float(yo + 3, (v[i].w - mu) * rs * g.w);
+                store4_from_float(yo, (v[i].x - mu) * rs * g.x, (v[i].y - mu) * rs * g.y, (v[i].z - mu) * rs * g.z, (v[i].w - mu) * rs * g.w);
                 if (xcast) {
                     T* xo = xcast + (size_t)row * D + 4 * c;
-                    store_from_float(xo + 0, v[i].x); store_from_float(xo + 1, v[i].y);
-                    store_from_float(xo + 2, v[i].z); store_from_float(xo + 3, v[i].w);
+                    store4_from_float(xo, v[i].x, v[i].y, v[i].z, v[i].w);
                 }
             }
         }
@@ -107,8 +103,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const float* __restr
                 ((float4*)(dx + (size_t)row * D))[c] = r;
                 if (dxcast) {
                     T* o = dxcast + (size_t)row * D + 4 * c;
-                    store_from_float(o + 0, r.x); store_from_float(o + 1, r.y);
-                    store_from_float(o + 2, r.z); store_from_float(o + 3, r.w);
+                    store4_from_float(o, r.x, r.y, r.z, r.w);
                 }
             }
         }

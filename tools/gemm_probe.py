@@ -51,7 +51,7 @@ if os.environ.get("PITCH_AB", "1") == "1":
 if os.environ.get("ABLATE", "1") == "1":
     for tile in ("128x128", "256x256"):
         os.environ["OMLM_GEMM_TILE"] = tile
-        for dbg, label in ((0, "full"), (1, "no-DMA"), (2, "no-MFMA"), (3, "no-DMA no-MFMA")):
+        for dbg, label in ((0, "full"), (3, "no-DMA no-MFMA"), (4, "no-epilogue"), (7, "no-DMA/MFMA/epi"), (15, "barriers only"), (12, "DMA+barrier only")):
             os.environ["OMLM_GEMM_DEBUG"] = str(dbg)
             fn = shapes["ffin_NT_bf16out"]
             fn(); torch.cuda.synchronize()
