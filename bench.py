@@ -47,8 +47,8 @@ def progress(msg):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--precision", default=os.environ.get("OMLM_PRECISION", "bf16"), choices=["bf16", "bf16x3"])
     ap.add_argument("--batch", type=int, default=32, help="samples per GPU per optimizer step")
     ap.add_argument("--accum", type=int, default=1, help="micro-batches per optimizer step")
