@@ -100,6 +100,16 @@ def build_layout(B: int, lens: Sequence[int], quantizers: Sequence[int], device,
 # ------------------------------------------------------------------------------------------------------
 # operand copies of the weights in the GEMM operand dtype / padded layouts
 # ------------------------------------------------------------------------------------------------------
+def bf16_operand(w: torch.Tensor) -> torch.Tensor:
+    """bf16 copy of a weight as GEMM operand: the optimizer's shadow if it is current, else a fresh cast."""
+    sh = getattr(w, "_omlm_bf16", None)
+    if sh is not None and getattr(w, "_omlm_bf16_version", -1) == w._version and sh.device == w.device:
+        return sh
+    c = torch.empty(w.shape, dtype=torch.bfloat16, device=w.device)
+    ops.cast_pad(w.detach(), c, w.numel() // w.shape[-1], w.shape[-1], w.shape[-1], w.shape[-1])
+    return c
+
+
 class PreparedWeights:
     def __init__(self, model, precision: str):
         tr = model.transformer
@@ -119,9 +129,7 @@ class PreparedWeights:
                 ent["Wq"], ent["Wkv"], ent["Wo"] = attn.to_q.weight, attn.to_kv.weight, attn.to_out[0].weight
             else:
                 for name, w in (("Wq", attn.to_q.weight), ("Wkv", attn.to_kv.weight), ("Wo", attn.to_out[0].weight)):
-                    c = torch.empty(w.shape, dtype=T, device=dev)
-                    ops.cast_pad(w, c, w.shape[0], w.shape[1], w.shape[1], w.shape[1])
-                    ent[name] = c
+                    ent[name] = bf16_operand(w)
             W1p = torch.zeros(2 * Fp, D, dtype=T, device=dev)
             ops.cast_pad(w1, W1p, F, D, D, D)
             ops.cast_pad(w1[F:], W1p[Fp:], F, D, D, D)
@@ -143,9 +151,7 @@ class PreparedWeights:
             if T == torch.float32:
                 self.heads.append(w)
             else:
-                c = torch.empty(w.shape, dtype=T, device=dev)
-                ops.cast_pad(w, c, w.shape[0] * w.shape[1], w.shape[2], w.shape[2], w.shape[2])
-                self.heads.append(c)
+                self.heads.append(bf16_operand(w))
 
 
 def prepared_weights(model, precision: str) -> PreparedWeights:

@@ -64,7 +64,14 @@ class FusedAdam(torch.optim.Optimizer):
                 V[o:o + n].copy_(old['V'][old['offs'][i]: old['offs'][i] + n])
             p.data = P[o:o + n].view(p.shape)
             p.grad = G[o:o + n].view(p.shape)
-        self._flat = dict(P=P, G=G, M=M, V=V, offs=offs, sizes=sizes, total=tot)
+        # bf16 shadow of every parameter, refreshed by the SAME kernel that updates the fp32 master (adamw p16 output):
+        # the engine's bf16 GEMM operands are views of it, so the per-step weight-cast launches disappear.
+        P16 = torch.empty(tot, device=dev, dtype=torch.bfloat16)
+        ops.cast_pad(P, P16, 1, tot, tot, tot)
+        for p, o, n in zip(params, offs, sizes):
+            p._omlm_bf16 = P16[o:o + n].view(p.shape)
+            p._omlm_bf16_version = p._version
+        self._flat = dict(P=P, G=G, M=M, V=V, P16=P16, offs=offs, sizes=sizes, total=tot)
         self._gnorm_sq = torch.zeros(1, device=dev)
         # group ranges (groups are contiguous in the flat order by construction)
         r, k = [], 0
@@ -122,12 +129,13 @@ class FusedAdam(torch.optim.Optimizer):
             if b <= a:
                 continue
             beta1, beta2 = g['betas']
-            ops.adamw_clip_step(f['P'][a:b], f['G'][a:b], f['M'][a:b], f['V'][a:b], None, lr=g['lr'], beta1=beta1,
+            ops.adamw_clip_step(f['P'][a:b], f['G'][a:b], f['M'][a:b], f['V'][a:b], f['P16'][a:b], lr=g['lr'], beta1=beta1,
                                 beta2=beta2, eps=g['eps'], wd=g['weight_decay'], step=self._t, gscale=grad_scale,
                                 gnorm_sq=gn, max_norm=max_grad_norm or 0.0, decoupled=g['decoupled'], zero_grad=True)
         self._grads_clean = True
         for p in self._all_params():                    # the kernels wrote through raw pointers: tell autograd
             torch._C._increment_version(p) if hasattr(torch._C, "_increment_version") else p.add_(0)
+            p._omlm_bf16_version = p._version           # the shadow written by this very kernel is current
         return None
 
     def mark_grads_dirty(self):

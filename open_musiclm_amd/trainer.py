@@ -214,6 +214,7 @@ class SingleStageTrainer(nn.Module):
             scheduler_path = Path(scheduler_path)
             assert scheduler_path.exists()
             self.scheduler.load_state_dict(torch.load(scheduler_path, map_location=self.device, weights_only=False))
+        self._graphed = None        # weights changed under the captured graph: re-capture on the next micro-step
         if steps > 0:
             assert int(self.steps.item()) == 0, 'steps should be 0 when loading a checkpoint for the first time'
             self.steps += steps
