@@ -49,7 +49,7 @@ class FusedAdam(torch.optim.Optimizer):
         offs, tot = [], 0
         for n in sizes:
             offs.append(tot)
-            tot += (n + 3) // 4 * 4                     # keep every tensor 16-byte aligned inside the flat buffers
+            tot += (n + 7) // 8 * 8                     # 8-element granules: 16-byte aligned in the fp32 AND the bf16 buffer
         old = self._flat
         P = torch.zeros(tot, device=dev)
         G = torch.zeros(tot, device=dev)
@@ -80,7 +80,7 @@ class FusedAdam(torch.optim.Optimizer):
             if n == 0:
                 r.append((0, 0))
             else:
-                r.append((offs[k], offs[k + n - 1] + (sizes[k + n - 1] + 3) // 4 * 4))
+                r.append((offs[k], offs[k + n - 1] + (sizes[k + n - 1] + 7) // 8 * 8))
             k += n
         self._flat['ranges'] = r
 
