@@ -157,6 +157,16 @@ def main():
         "final_loss": round(final_loss, 4),
     }
 
+    if os.environ.get("BENCH_HOST_PROFILE") == "1":
+        import cProfile, pstats, io
+        batch = dict(clap_token_ids=batches[0][0], semantic_token_ids=batches[0][1], coarse_token_ids=batches[0][2])
+        fb._eager(batch); torch.cuda.synchronize()
+        pr = cProfile.Profile(); pr.enable()
+        fb._eager(batch)
+        pr.disable(); torch.cuda.synchronize()
+        sio = io.StringIO(); pstats.Stats(pr, stream=sio).sort_stats("tottime").print_stats(22)
+        print(sio.getvalue(), file=sys.stderr)
+
     if os.environ.get("BENCH_STEP_TIMES") == "1":
         for k in range(3):
             torch.cuda.synchronize()
