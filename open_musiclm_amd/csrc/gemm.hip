@@ -18,16 +18,16 @@
 //               ("bf16x3": fp32-grade products at 1/3 of the bf16 MFMA rate, still ~5x the
 //               fp32-MFMA rate).  Accumulation is fp32 in both modes.
 //
-// Tile: 128 x 128 x 64 per workgroup of 4 waves (2x2), each wave 64x64 = 2x2 MFMA 32x32 tiles.
-// Staging: global -> registers (issued before the MFMA phase of the previous tile) -> LDS
-// after the barrier (async-STAGE split, guide T14).  LDS images are XOR-swizzled so that both
-// ds_read_b128 (normal) and ds_read_b64_tr_b16 (k-major) fragment reads are conflict-free.
+// fp32 path (gemm_kernel): 128 x 128 x 64 per workgroup of 4 waves (2x2), each wave 64x64 = 2x2 MFMA 32x32 tiles;
+// staging global -> registers (issued before the MFMA phase of the previous tile) -> split -> LDS after the barrier.
+// LDS images are XOR-swizzled so that both ds_read_b128 (normal) and ds_read_b64_tr_b16 (k-major) fragment reads
+// are conflict-free.
 // Out-of-range rows/columns are read through a buffer descriptor with an out-of-bounds offset
 // (hardware returns 0), so M, N and K may be ragged at 8-element granularity.
 // Optional row maps (int32) gather A rows / k rows and scatter C rows: this is how the
 // per-quantizer logit heads read the positions p = q (mod Q) of the hidden states in place.
 //
-// bf16 operands take the LDS-DMA path (gemm_bf16_kernel): tiles go HBM -> LDS directly with
+// bf16 operands take the LDS-DMA path (gemm_bf16_tile_kernel: 256x256 / 256x128 / 128x128 tiles): tiles go HBM -> LDS directly with
 // buffer_load_dwordx4 ... lds (no VGPR staging, no ds_write pass), the swizzle is applied on the
 // per-lane SOURCE address (the DMA destination is lane-linear), LDS is double-buffered and there
 // is ONE barrier per k-tile: the DMA of tile t+1 is in flight while tile t is on the matrix cores.
@@ -62,17 +62,17 @@ struct GemmArgs {
 __device__ __forceinline__ int lds_off_normal(int row, int kchunk) {
     return row * 128 + ((kchunk ^ ((row >> 1) & 7)) << 4);
 }
-// k-major tile [64 k][128 cols] bf16, blocked for the transpose read: the unit of ds_read_b64_tr_b16 is a [4 k][16 col]
-// block (128 B, one per 16-lane group).  Blocks are ordered so that the four groups of a wave read four ADJACENT
-// blocks -- one 512-B contiguous run per instruction (address = base + 8 * lane), conflict-free by construction:
-//   1-KiB unit  (j = col / 32, s = k / 16)          -> (j * 4 + s) * 1024
-//   block in unit p = r * 4 + hi * 2 + cc,  kk = (k / 4) & 3 = r + 2 hi,  cc = (col / 16) & 1   -> p * 128
-//   inside block  row k & 3 (32 B), column col & 15
+// k-major tile [64 k][W cols] bf16 (W = 128 or 256), stored as W/128 panels of [64 k][128 cols], 256 B per k-row, with
+// the 64-byte piece index of a row XORed with (k & 3).  Why this image:
+//   * global side: one LDS-DMA wave-instruction (1 KiB, lane-linear destination) is 4 k-rows x 256 contiguous bytes, i.e.
+//     full 128-B lines read by adjacent lanes.  (The first version used a [4 k][16 col]-blocked image whose instruction
+//     touched 32 separate 32-byte runs: the DMA phase of the weight-gradient GEMM measured 690 us vs 199 us row-major.)
+//   * LDS side: ds_read_b64_tr_b16 is served in two 32-lane groups; a group reads 4 consecutive k-rows x 32 cols (64 B
+//     each).  With 256-B rows those would all sit on the same quarter of the 64-bank row; the XOR puts row k on quarter
+//     piece ^ (k & 3): four distinct quarters, conflict-free.
 __device__ __forceinline__ int lds_off_kmaj(int k, int colbyte) {
     const int col = colbyte >> 1;
-    const int kk = (k >> 2) & 3;
-    const int p = ((kk & 1) << 2) | ((kk >> 1) << 1) | ((col >> 4) & 1);
-    return (((col >> 5) << 2) + (k >> 4)) * 1024 + p * 128 + (k & 3) * 32 + (col & 15) * 2;
+    return (col >> 7) * 16384 + k * 256 + ((((col >> 5) & 3) ^ (k & 3)) << 6) + (col & 31) * 2;
 }
 
 template <typename T, bool KMAJ>
@@ -148,11 +148,14 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, int sub0, int s, in
         const int kc = 2 * s + (lane >> 5);
         return *(const bf16x8*)(lds + lds_off_normal(row, kc));
     } else {
-        // two transpose reads, 4 k each: lane gets column (sub0 + (lane&31)), k = 16s + 8*(lane>>5) + 0..7.
-        // In the blocked image both are linear: unit base + 8 * lane, and + 512 for k + 4.
-        const char* base = lds + (((sub0 >> 5) << 2) + s) * 1024 + lane * 8;
+        // two transpose reads of 4 k each: the lane ends up with column sub0 + (lane & 31), k = 16s + 8*(lane>>5) + 0..7.
+        // Lane i of a 16-lane group supplies the address of the 8-byte piece (k-row i>>2, cols 4*(i&3)..+3) of the group's
+        // [4 k][16 col] block; groups 0/1 are the two 16-col halves of the sub-tile, groups 2/3 the same for k + 8.
+        const int i16 = lane & 15, grp = lane >> 4, r = i16 >> 2;
+        const int k = 16 * s + 8 * (grp >> 1) + r;
+        const char* base = lds + (sub0 >> 7) * 16384 + k * 256 + ((((sub0 >> 5) & 3) ^ r) << 6) + (16 * (grp & 1) + 4 * (i16 & 3)) * 2;
         s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base));
-        s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base + 512));
+        s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base + 1024));
         typedef __attribute__((ext_vector_type(8))) short s16x8;
         s16x8 v = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
         return __builtin_bit_cast(bf16x8, v);
@@ -276,287 +279,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs g) {
 }
 
 
-// ---- bf16 fast path: LDS-DMA staging, double-buffered LDS, one barrier per k-tile ------------------------
-template <bool KMAJ>
-struct DmaStager {
-    unsigned base[4];     // byte offset without the k advance (OOB_OFF when the row / column chunk is out of range)
-    int kidx[4];          // normal: k offset of the lane's chunk inside the tile;  k-major: k row inside the tile
-
-    __device__ __forceinline__ void init(const int* map, int ld, int nvalid, int r0, int wave, int lane) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int b = wave + 4 * i;                            // 1-KiB LDS block = one wave-instruction
-            if (!KMAJ) {
-                const int row = 8 * b + (lane >> 3), slot = lane & 7;
-                const int kc = slot ^ ((row >> 1) & 7);            // source-side swizzle: LDS (row, slot) holds chunk kc
-                const int gr = r0 + row;
-                const bool ok = gr < nvalid;
-                const long long pr = (ok && map) ? (long long)map[gr] : (long long)gr;
-                base[i] = ok ? (unsigned)((pr * ld + kc * 8) * 2) : OOB_OFF;
-                kidx[i] = kc * 8;
-            } else {
-                // unit b = (j = b >> 2, s = b & 3); lane -> block p = lane >> 3, row (lane & 7) >> 1, column half lane & 1
-                const int p = lane >> 3;
-                const int kk = (p >> 2) + 2 * ((p >> 1) & 1);
-                const int krow = 16 * (b & 3) + 4 * kk + ((lane & 7) >> 1);
-                const int gc = r0 + 32 * (b >> 2) + 16 * (p & 1) + 8 * (lane & 1);
-                base[i] = gc < nvalid ? (unsigned)(gc * 2) : OOB_OFF;
-                kidx[i] = krow;
-            }
-        }
-    }
-    __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rs, const int* map, int ld, int k0, int K,
-                                          char* lds_tile, int wave) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int b = wave + 4 * i;
-            unsigned off;
-            if (!KMAJ) {
-                off = (base[i] != OOB_OFF && k0 + kidx[i] < K) ? base[i] + (unsigned)(k0 * 2) : OOB_OFF;
-            } else {
-                const int gk = k0 + kidx[i];
-                const bool ok = base[i] != OOB_OFF && gk < K;
-                const long long pr = (ok && map) ? (long long)map[gk] : (long long)gk;
-                off = ok ? base[i] + (unsigned)(pr * ld * 2) : OOB_OFF;
-            }
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(void, lds_tile + b * 1024), 16, (int)off, 0, 0, 0);
-        }
-    }
-};
-
-template <bool A_KMAJ, bool B_KMAJ, typename TOUT>
-__global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(GemmArgs g) {
-    constexpr int PLANE = BM * BK * 2;                       // 16 KiB per operand tile
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A | B]
-
-    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
-    const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    // super-tile order: 8 tile-rows x all tile-columns per group, column-major inside the group, so the ~64 workgroups
-    // co-resident on one XCD cover an ~8 x 8 patch of C (8 A panels + 8 B panels ~ 4 MiB: the XCD's L2)
-    const int gsz = 8 * tiles_n;
-    const int grp = bid / gsz, first_m = grp * 8;
-    const int rows_in = min(8, tiles_m - first_m);
-    const int tm = first_m + (bid - grp * gsz) % rows_in, tn = (bid - grp * gsz) / rows_in;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-
-    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(g.A, (unsigned long long)g.a_rows * g.lda * 2);
-    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(g.B, (unsigned long long)g.b_rows * g.ldb * 2);
-    DmaStager<A_KMAJ> sa;
-    DmaStager<B_KMAJ> sb;
-    sa.init(g.a_map, g.lda, g.M, m0, wave, lane);
-    sb.init(g.b_map, g.ldb, g.N, n0, wave, lane);
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const int nk_all = (g.K + BK - 1) / BK;
-    const int kt0 = blockIdx.y * g.kt_per_split;
-    const int kt1 = min(nk_all, kt0 + g.kt_per_split);
-    if (kt0 < kt1) {
-        sa.issue(rsA, g.a_map, g.lda, kt0 * BK, g.K, smem, wave);
-        sb.issue(rsB, g.b_map, g.ldb, kt0 * BK, g.K, smem + PLANE, wave);
-    }
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int cur = (kt - kt0) & 1;
-        // the DMA is a pending LDS write on the VM counter: this barrier waits vmcnt(0), so tile kt has landed for
-        // every wave, and every wave has finished the MFMA phase that read the other buffer
-        __syncthreads();
-        if (kt + 1 < kt1) {
-            char* nxt = smem + (cur ^ 1) * 2 * PLANE;
-            sa.issue(rsA, g.a_map, g.lda, (kt + 1) * BK, g.K, nxt, wave);
-            sb.issue(rsB, g.b_map, g.ldb, (kt + 1) * BK, g.K, nxt + PLANE, wave);
-        }
-        const char* As = smem + cur * 2 * PLANE;
-        const char* Bs = As + PLANE;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            bf16x8 a[2], b[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[i] = read_frag<A_KMAJ>(As, wm + 32 * i, s, lane);
-                b[i] = read_frag<B_KMAJ>(Bs, wn + 32 * i, s, lane);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-    }
-    epilogue<TOUT>(g, acc, m0, n0, wm, wn, lane);
-}
-
-
-// ---- bf16 fast path v3: 4-stage LDS ring (BK = 32), counted vmcnt, raw barrier -----------------------------------
-// Stage = A tile [128][32] (8 KiB) | B tile (8 KiB).  Three tiles are requested ahead of the one being multiplied; the
-// top of iteration t waits only until tile t has landed (s_waitcnt vmcnt(8): the 2 x 4 DMA instructions of tiles t+1
-// and t+2 stay in flight ACROSS the barrier -- __syncthreads() would drain them), then one raw s_barrier publishes
-// tile t to all waves and proves everyone left tile t-1, whose stage is immediately re-filled with tile t+3.
-#define BK3 32
-#define NSTAGE 4
-// normal tile: [128 rows][32 k] bf16, 64 B per row, 16-B chunk index XOR ((row >> 2) & 3)  (conflict-free b128 reads)
-__device__ __forceinline__ int lds3_off_normal(int row, int kc) { return row * 64 + ((kc ^ ((row >> 2) & 3)) << 4); }
-
-template <bool KMAJ>
-struct DmaStager3 {
-    unsigned base[2];
-    int kidx[2];
-    __device__ __forceinline__ void init(const int* map, int ld, int nvalid, int r0, int wave, int lane) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int u = wave + 4 * i;                            // 8 one-KiB units per operand tile
-            if (!KMAJ) {
-                const int row = 16 * u + (lane >> 2), slot = lane & 3;
-                const int kc = slot ^ ((row >> 2) & 3);
-                const int gr = r0 + row;
-                const bool ok = gr < nvalid;
-                const long long pr = (ok && map) ? (long long)map[gr] : (long long)gr;
-                base[i] = ok ? (unsigned)((pr * ld + kc * 8) * 2) : OOB_OFF;
-                kidx[i] = kc * 8;
-            } else {
-                // unit u = (j = u >> 1, s = u & 1); blocked image as in lds_off_kmaj
-                const int p = lane >> 3;
-                const int kk = (p >> 2) + 2 * ((p >> 1) & 1);
-                const int krow = 16 * (u & 1) + 4 * kk + ((lane & 7) >> 1);
-                const int gc = r0 + 32 * (u >> 1) + 16 * (p & 1) + 8 * (lane & 1);
-                base[i] = gc < nvalid ? (unsigned)(gc * 2) : OOB_OFF;
-                kidx[i] = krow;
-            }
-        }
-    }
-    __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rs, const int* map, int ld, int k0, int K,
-                                          char* lds_tile, int wave) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int u = wave + 4 * i;
-            unsigned off;
-            if (!KMAJ) {
-                off = (base[i] != OOB_OFF && k0 + kidx[i] < K) ? base[i] + (unsigned)(k0 * 2) : OOB_OFF;
-            } else {
-                const int gk = k0 + kidx[i];
-                const bool ok = base[i] != OOB_OFF && gk < K;
-                const long long pr = (ok && map) ? (long long)map[gk] : (long long)gk;
-                off = ok ? base[i] + (unsigned)(pr * ld * 2) : OOB_OFF;
-            }
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(void, lds_tile + u * 1024), 16, (int)off, 0, 0, 0);
-        }
-    }
-};
-
-template <bool KMAJ>
-__device__ __forceinline__ bf16x8 read_frag3(const char* lds, int sub0, int s, int lane) {
-    if (!KMAJ) {
-        const int row = sub0 + (lane & 31);
-        return *(const bf16x8*)(lds + lds3_off_normal(row, 2 * s + (lane >> 5)));
-    } else {
-        const char* base = lds + (((sub0 >> 5) << 1) + s) * 1024 + lane * 8;
-        s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base));
-        s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base + 512));
-        typedef __attribute__((ext_vector_type(8))) short s16x8;
-        s16x8 v = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
-        return __builtin_bit_cast(bf16x8, v);
-    }
-}
-
-template <bool A_KMAJ, bool B_KMAJ, typename TOUT>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_p4_kernel(GemmArgs g) {
-    constexpr int OPB = BM * BK3 * 2;                        // 8 KiB per operand tile
-    constexpr int STG = 2 * OPB;                             // 16 KiB per stage
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // ONE LDS object: [NSTAGE][A | B]
-
-    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
-    const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int gsz = 8 * tiles_n;
-    const int grp = bid / gsz, first_m = grp * 8;
-    const int rows_in = min(8, tiles_m - first_m);
-    const int tm = first_m + (bid - grp * gsz) % rows_in, tn = (bid - grp * gsz) / rows_in;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-
-    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(g.A, (unsigned long long)g.a_rows * g.lda * 2);
-    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(g.B, (unsigned long long)g.b_rows * g.ldb * 2);
-    DmaStager3<A_KMAJ> sa;
-    DmaStager3<B_KMAJ> sb;
-    sa.init(g.a_map, g.lda, g.M, m0, wave, lane);
-    sb.init(g.b_map, g.ldb, g.N, n0, wave, lane);
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    // split-K bookkeeping is in units of 64 (BK) to stay compatible with the host's kt_per_split
-    const int nk_all = (g.K + BK3 - 1) / BK3;
-    const int t0 = blockIdx.y * g.kt_per_split * 2;
-    const int t1 = min(nk_all, t0 + g.kt_per_split * 2);
-    const int nt = t1 - t0;
-#pragma unroll
-    for (int pre = 0; pre < NSTAGE - 1; ++pre) {
-        if (pre < nt) {
-            sa.issue(rsA, g.a_map, g.lda, (t0 + pre) * BK3, g.K, smem + pre * STG, wave);
-            sb.issue(rsB, g.b_map, g.ldb, (t0 + pre) * BK3, g.K, smem + pre * STG + OPB, wave);
-        }
-    }
-    for (int t = 0; t < nt; ++t) {
-        const int ahead = nt - 1 - t;                        // tiles requested after tile t (each = 4 DMA instructions/wave)
-        if (ahead >= 2)      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (t + NSTAGE - 1 < nt) {
-            char* dst = smem + ((t + NSTAGE - 1) & (NSTAGE - 1)) * STG;
-            sa.issue(rsA, g.a_map, g.lda, (t0 + t + NSTAGE - 1) * BK3, g.K, dst, wave);
-            sb.issue(rsB, g.b_map, g.ldb, (t0 + t + NSTAGE - 1) * BK3, g.K, dst + OPB, wave);
-        }
-        const char* As = smem + (t & (NSTAGE - 1)) * STG;
-        const char* Bs = As + OPB;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 a[2], b[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[i] = read_frag3<A_KMAJ>(As, wm + 32 * i, s, lane);
-                b[i] = read_frag3<B_KMAJ>(Bs, wn + 32 * i, s, lane);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-    }
-    epilogue<TOUT>(g, acc, m0, n0, wm, wn, lane);
-}
-
-
 // ---- bf16 fast path, generalised tile: BM_ x BN_ x 64 per workgroup, waves of WM_ x WN_ -------------------------------
 // Measured on MI355X: the 128x128 kernel saturates the L2 -> LDS DMA path (~10-12 TB/s chip-wide) at ~600 TFLOP/s because
 // a 128x128x64 tile moves 32 KiB per 2.1 MFLOP (64 FLOP/B).  256x256 (8 waves of 128x64) doubles that to 128 FLOP/B,
 // 256x128 (8 waves of 64x64) gives 85 FLOP/B for the narrow-N GEMMs where 256-wide tiles would leave CUs idle.
-// Same LDS images, DMA staging, double buffering and one barrier per k-tile as gemm_bf16_kernel above.
 template <bool KMAJ, int ROWS, int NWAVES>
 struct DmaStagerT {
     static constexpr int UPW = (ROWS / 8) / NWAVES;       // 1-KiB units per wave per tile
@@ -575,10 +301,10 @@ struct DmaStagerT {
                 base[i] = ok ? (unsigned)((pr * ld + kc * 8) * 2) : OOB_OFF;
                 kidx[i] = kc * 8;
             } else {
-                const int p = lane >> 3;
-                const int kk = (p >> 2) + 2 * ((p >> 1) & 1);
-                const int krow = 16 * (b & 3) + 4 * kk + ((lane & 7) >> 1);
-                const int gc = r0 + 32 * (b >> 2) + 16 * (p & 1) + 8 * (lane & 1);
+                // unit b = (panel b >> 4, k-group b & 15): 4 k-rows x 256 B; lane = (row lane >> 4, 16-B chunk lane & 15)
+                const int krow = 4 * (b & 15) + (lane >> 4);
+                const int piece = ((lane & 15) >> 2) ^ (lane >> 4);                 // image piece -> logical piece (k & 3 == lane >> 4)
+                const int gc = r0 + 128 * (b >> 4) + 32 * piece + 8 * (lane & 3);
                 base[i] = gc < nvalid ? (unsigned)(gc * 2) : OOB_OFF;
                 kidx[i] = krow;
             }
@@ -799,16 +525,6 @@ static int launch_layout(const GemmArgs& g, int a_kmaj, int b_kmaj, int splits, 
         else if (!a_kmaj && b_kmaj)  hipLaunchKernelGGL((gemm_kernel<T, false, true, TOUT>), grid, block, lds, st, g);
         else if (a_kmaj && b_kmaj)   hipLaunchKernelGGL((gemm_kernel<T, true, true, TOUT>), grid, block, lds, st, g);
         else                         hipLaunchKernelGGL((gemm_kernel<T, true, false, TOUT>), grid, block, lds, st, g);
-    } else if (getenv("OMLM_GEMM_RING") != nullptr) {
-        if (!a_kmaj && !b_kmaj)      hipLaunchKernelGGL((gemm_bf16_p4_kernel<false, false, TOUT>), grid, block, lds, st, g);
-        else if (!a_kmaj && b_kmaj)  hipLaunchKernelGGL((gemm_bf16_p4_kernel<false, true, TOUT>), grid, block, lds, st, g);
-        else if (a_kmaj && b_kmaj)   hipLaunchKernelGGL((gemm_bf16_p4_kernel<true, true, TOUT>), grid, block, lds, st, g);
-        else                         hipLaunchKernelGGL((gemm_bf16_p4_kernel<true, false, TOUT>), grid, block, lds, st, g);
-    } else {
-        if (!a_kmaj && !b_kmaj)      hipLaunchKernelGGL((gemm_bf16_kernel<false, false, TOUT>), grid, block, lds, st, g);
-        else if (!a_kmaj && b_kmaj)  hipLaunchKernelGGL((gemm_bf16_kernel<false, true, TOUT>), grid, block, lds, st, g);
-        else if (a_kmaj && b_kmaj)   hipLaunchKernelGGL((gemm_bf16_kernel<true, true, TOUT>), grid, block, lds, st, g);
-        else                         hipLaunchKernelGGL((gemm_bf16_kernel<true, false, TOUT>), grid, block, lds, st, g);
     }
     return omlm_post_launch("omlm_gemm");
 }
@@ -872,35 +588,12 @@ extern "C" int omlm_gemm(const void* A, const void* B, void* C, const float* Cin
         OMLM_CHECK_ARG(out_dtype == 0, "fp32 operands produce fp32 output");
         return launch_layout<float, float>(g, a_kmajor, b_kmajor, splits, st);
     }
-    static bool attr16 = false;
-    if (!attr16) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_p4_kernel<false, false, float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_p4_kernel<false, true, float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_p4_kernel<true, true, float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_p4_kernel<true, false, float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_p4_kernel<false, false, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_p4_kernel<false, true, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_p4_kernel<true, true, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_p4_kernel<true, false, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, false, float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, true, float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, true, float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, false, float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, false, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, true, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, true, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, false, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        attr16 = true;
-    }
     if (bm == 256 && bn == 256)
         return out_dtype == 0 ? launch_tile<256, 256, 128, 64, float>(g, a_kmajor, b_kmajor, splits, st)
                               : launch_tile<256, 256, 128, 64, bf16_t>(g, a_kmajor, b_kmajor, splits, st);
     if (bm == 256 && bn == 128)
         return out_dtype == 0 ? launch_tile<256, 128, 64, 64, float>(g, a_kmajor, b_kmajor, splits, st)
                               : launch_tile<256, 128, 64, 64, bf16_t>(g, a_kmajor, b_kmajor, splits, st);
-    if (getenv("OMLM_GEMM_LEGACY") == nullptr)
-        return out_dtype == 0 ? launch_tile<128, 128, 64, 64, float>(g, a_kmajor, b_kmajor, splits, st)
-                              : launch_tile<128, 128, 64, 64, bf16_t>(g, a_kmajor, b_kmajor, splits, st);
-    if (out_dtype == 0) return launch_layout<bf16_t, float>(g, a_kmajor, b_kmajor, splits, st);
-    return launch_layout<bf16_t, bf16_t>(g, a_kmajor, b_kmajor, splits, st);
+    return out_dtype == 0 ? launch_tile<128, 128, 64, 64, float>(g, a_kmajor, b_kmajor, splits, st)
+                          : launch_tile<128, 128, 64, 64, bf16_t>(g, a_kmajor, b_kmajor, splits, st);
 }

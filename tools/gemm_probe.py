@@ -49,16 +49,18 @@ if os.environ.get("PITCH_AB", "1") == "1":
             print(f"pitch {D + pad:5d} {tile:8s} ffin_NT {us:8.1f} us  {2.0 * M * F2 * D / us / 1e6:7.1f} TFLOP/s", flush=True)
 
 if os.environ.get("ABLATE", "1") == "1":
-    for tile in ("128x128", "256x256"):
-        os.environ["OMLM_GEMM_TILE"] = tile
-        for dbg, label in ((0, "full"), (3, "no-DMA no-MFMA"), (4, "no-epilogue"), (7, "no-DMA/MFMA/epi"), (15, "barriers only"), (12, "DMA+barrier only")):
-            os.environ["OMLM_GEMM_DEBUG"] = str(dbg)
-            fn = shapes["ffin_NT_bf16out"]
-            fn(); torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps): fn()
-            e1.record(); torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) * 1e3 / reps
-            print(f"ablate {tile:8s} {label:16s} {us:8.1f} us", flush=True)
+    for name in os.environ.get("ABLATE_SHAPES", "ffin_NT_bf16out").split(","):
+        for tile in os.environ.get("ABLATE_TILES", "128x128,256x256").split(","):
+            os.environ["OMLM_GEMM_TILE"] = tile
+            for dbg, label in ((0, "full"), (3, "no-DMA no-MFMA"), (4, "no-epilogue"), (7, "no-DMA/MFMA/epi"), (15, "barriers only"),
+                               (12, "DMA+barrier only"), (2, "no-MFMA"), (1, "no-DMA")):
+                os.environ["OMLM_GEMM_DEBUG"] = str(dbg)
+                fn = shapes[name]
+                fn(); torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps): fn()
+                e1.record(); torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / reps
+                print(f"ablate {name:16s} {tile:8s} {label:16s} {us:8.1f} us", flush=True)
     os.environ["OMLM_GEMM_DEBUG"] = "0"
