@@ -167,6 +167,36 @@ def main():
         sio = io.StringIO(); pstats.Stats(pr, stream=sio).sort_stats("tottime").print_stats(22)
         print(sio.getvalue(), file=sys.stderr)
 
+    if os.environ.get("BENCH_HOST_TIMELINE") == "1":
+        # host-side phase stamps over consecutive un-synchronised steps (steady state, queues full)
+        import gc
+        stamps = []
+        torch.cuda.synchronize()
+        gc_was = gc.isenabled()
+        if os.environ.get("BENCH_GC_OFF") == "1":
+            gc.disable()
+        for k in range(6):
+            kk = args.warmup + args.steps + 20 + k
+            t = [time.perf_counter()]
+            optim.zero_grad(); t.append(time.perf_counter())
+            clap, sem, coarse = batches[kk % len(batches)]
+            loss = fb(clap_token_ids=clap, semantic_token_ids=sem, coarse_token_ids=coarse); t.append(time.perf_counter())
+            optim.mark_grads_dirty()
+            dp.allreduce_sum_(optim.flat_grad); t.append(time.perf_counter())
+            optim.step(max_grad_norm=0.5, grad_scale=dp.grad_scale()); t.append(time.perf_counter())
+            sched.step(); t.append(time.perf_counter())
+            del loss; t.append(time.perf_counter())
+            stamps.append(t)
+        torch.cuda.synchronize()
+        tend = time.perf_counter()
+        if gc_was:
+            gc.enable()
+        names = ["zero_grad", "fwd+bwd", "allreduce", "optim.step", "sched.step", "del loss"]
+        for k, t in enumerate(stamps):
+            progress(f"host timeline step {k}: start {1e3 * (t[0] - stamps[0][0]):7.1f} ms | " +
+                     " ".join(f"{n} {1e3 * (t[i + 1] - t[i]):.1f}" for i, n in enumerate(names)))
+        progress(f"host timeline: all 6 steps issued at {1e3 * (stamps[-1][-1] - stamps[0][0]):.1f} ms, GPU idle at {1e3 * (tend - stamps[0][0]):.1f} ms")
+
     if os.environ.get("BENCH_STEP_TIMES") == "1":
         for k in range(3):
             torch.cuda.synchronize()

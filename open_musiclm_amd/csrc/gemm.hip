@@ -338,10 +338,17 @@ __global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile
 
     const int tiles_m = (g.M + BM_ - 1) / BM_, tiles_n = (g.N + BN_ - 1) / BN_;
     const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
+    // XCD-aware order over the WHOLE grid (tiles x K-splits): workgroups are dealt round-robin to the 8 XCDs in linear
+    // dispatch order, so XCD c is given one contiguous chunk of the logical (split-major) sequence.  For split-K GEMMs
+    // this puts all co-resident workgroups of an XCD on the SAME K range (they share A and B panels through its L2);
+    // with the tile-only remap an XCD held 3 unrelated K ranges at a time (measured L2 hit 48 % on the dW1 GEMM).
+    int bid, ksplit;
     {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        const int total = nwg * gridDim.y, lin = blockIdx.y * nwg + blockIdx.x;
+        const int q = total >> 3, r = total & 7, xcd = lin & 7, idx = lin >> 3;
+        const int lg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        ksplit = lg / nwg;
+        bid = lg - ksplit * nwg;
     }
     constexpr int GROUP = 1024 / BM_;                       // tile rows per super-tile (same footprint as the 128 kernel's 8)
     const int gsz = GROUP * tiles_n;
@@ -369,7 +376,7 @@ __global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nk_all = (g.K + BK - 1) / BK;
-    const int kt0 = blockIdx.y * g.kt_per_split;
+    const int kt0 = ksplit * g.kt_per_split;
     const int kt1 = min(nk_all, kt0 + g.kt_per_split);
     if (kt0 < kt1) {
         sa.issue(rsA, g.a_map, g.lda, kt0 * BK, g.K, smem, wave);

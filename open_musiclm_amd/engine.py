@@ -121,7 +121,7 @@ class PreparedWeights:
         self.layers = []
         for attn, _, ff in tr.layers:
             F = ff.inner_dim
-            Fp = ceil_to(F, 8)
+            Fp = ceil_to(F, 64)      # 128-byte aligned bf16 rows for h1 / dh1 (2*Fp pitch) and whole k-tiles for FF-out
             w1 = ff.w_in.weight            # [2F, D]
             w2 = ff.w_out.weight           # [D, F]
             ent = {}

@@ -70,6 +70,11 @@ class GraphedForwardBackward:
             torch.cuda.synchronize()
         if after_warmup is not None:
             after_warmup()
+        # Everything alive now (model, optimizer state, captured graphs) is long-lived: move it out of the collector's
+        # young generations so a full collection (measured: a ~65 ms pause every other step) does not rescan it.
+        import gc
+        gc.collect()
+        gc.freeze()
 
     def __call__(self, **inputs) -> torch.Tensor:
         key = tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(inputs.items()))

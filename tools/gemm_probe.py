@@ -5,7 +5,7 @@ import torch
 from open_musiclm_amd import ops
 
 dev = torch.device("cuda:0")
-M, D, F2 = 35712, 1024, 5472
+M, D, F2 = int(os.environ.get("MROWS", "35712")), 1024, 5472
 g = torch.Generator().manual_seed(0)
 X = torch.randn(M, D, generator=g).to(dev).bfloat16()
 W = (torch.randn(F2, D, generator=g) * 0.03).to(dev).bfloat16()

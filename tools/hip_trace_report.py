@@ -50,3 +50,26 @@ for name, s, e in kern:
     if prev_end is not None and s - prev_end > 5e5:
         print(f"   gap {(s - prev_end) / 1e6:7.2f} ms before {name[:60]}")
     prev_end = max(prev_end or e, e)
+
+# ---- host timeline around one step boundary (argv[3] = index of the optimizer step, default: middle of the trace)
+bi = int(sys.argv[3]) if len(sys.argv) > 3 else len(marks) // 2
+tb = marks[bi]
+nxt = min((s for _, s, e in kern if s > tb), default=tb)
+print(f"=== host timeline around the end of step {bi}: adamw kernel ends at t=0, next kernel starts at +{(nxt - tb) / 1e6:.2f} ms")
+win = list(db.execute("select name, tid, start, end from regions where end > ? and start < ? order by start", (tb - 70e6, nxt + 5e6)))
+last_end = {}
+lines = 0
+for name, tid, s, e in win:
+    gap = (s - last_end.get(tid, s)) / 1e6
+    dur = (e - s) / 1e6
+    if gap > 0.3 or dur > 0.3:
+        print(f"   t={(s - tb) / 1e6:8.2f} ms tid {tid} {name:28s} dur {dur:6.2f} ms  (host gap before: {gap:6.2f} ms)")
+        lines += 1
+        if lines > 60:
+            break
+    last_end[tid] = e
+# first/last launch per thread inside the window -> who launches when
+for tid in sorted({w[1] for w in win}):
+    ls = [w for w in win if w[1] == tid and "Launch" in w[0]]
+    if ls:
+        print(f"   tid {tid}: {len(ls)} launches, first at t={(ls[0][2] - tb) / 1e6:.2f}, last at t={(ls[-1][2] - tb) / 1e6:.2f} ms")
