@@ -106,6 +106,9 @@ int omlm_adamw_clip_step(float* p, float* g, float* m, float* v, void* p16, long
 
 /* operand casts / weight repack */
 int omlm_cast_pad(const float* src, void* dst, long long R, int C, int ld_src, int ld_dst, int out_dtype, void* stream);
+/* dst[c, r] = cast(src[r, c]): k-contiguous W^T copies for the input-gradient GEMMs (the autograd transpose of
+ * nn.Linear, transformer.py:203-212,144,149), refreshed once per optimizer step. */
+int omlm_transpose_cast(const float* src, void* dst, int R, int C, int ld_src, int ld_dst, int out_dtype, void* stream);
 
 /* RelativePositionBias MLP helpers (transformer.py:55-64): SiLU layers around omlm_gemm. */
 int omlm_relpos_first_fwd(const float* w0, const float* b0, float* pre, float* z, int n, int Hd, void* stream);

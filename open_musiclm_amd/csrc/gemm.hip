@@ -310,30 +310,38 @@ struct DmaStagerT {
             }
         }
     }
+    // one 1-KiB unit (one wave-instruction).  `live` false -> out-of-bounds offset: the DMA writes zeros, no memory traffic
+    __device__ __forceinline__ void issue_one(int i, __amdgpu_buffer_rsrc_t rs, const int* map, int ld, int k0, int K,
+                                              char* lds_tile, int wave, bool live, int aux = 0) {
+        const int b = wave + NWAVES * i;
+        unsigned off;
+        if (!KMAJ) {
+            off = (live && base[i] != OOB_OFF && k0 + kidx[i] < K) ? base[i] + (unsigned)(k0 * 2) : OOB_OFF;
+        } else {
+            const int gk = k0 + kidx[i];
+            const bool ok = live && base[i] != OOB_OFF && gk < K;
+            const long long pr = (ok && map) ? (long long)map[gk] : (long long)gk;
+            off = ok ? base[i] + (unsigned)(pr * ld * 2) : OOB_OFF;
+        }
+        if (aux == 0)      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(void, lds_tile + b * 1024), 16, (int)off, 0, 0, 0);
+        else if (aux == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(void, lds_tile + b * 1024), 16, (int)off, 0, 0, 1);
+        else if (aux == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(void, lds_tile + b * 1024), 16, (int)off, 0, 0, 2);
+        else               __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(void, lds_tile + b * 1024), 16, (int)off, 0, 0, 3);
+    }
     __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rs, const int* map, int ld, int k0, int K,
                                           char* lds_tile, int wave) {
 #pragma unroll
-        for (int i = 0; i < UPW; ++i) {
-            const int b = wave + NWAVES * i;
-            unsigned off;
-            if (!KMAJ) {
-                off = (base[i] != OOB_OFF && k0 + kidx[i] < K) ? base[i] + (unsigned)(k0 * 2) : OOB_OFF;
-            } else {
-                const int gk = k0 + kidx[i];
-                const bool ok = base[i] != OOB_OFF && gk < K;
-                const long long pr = (ok && map) ? (long long)map[gk] : (long long)gk;
-                off = ok ? base[i] + (unsigned)(pr * ld * 2) : OOB_OFF;
-            }
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(void, lds_tile + b * 1024), 16, (int)off, 0, 0, 0);
-        }
+        for (int i = 0; i < UPW; ++i) issue_one(i, rs, map, ld, k0, K, lds_tile, wave, true);
     }
 };
 
-template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ, bool B_KMAJ, typename TOUT>
+template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ, bool B_KMAJ, typename TOUT, bool DBG>
 __global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile_kernel(GemmArgs g) {
+    const int dbg = DBG ? g.debug : 0;      // ablation switches exist only in the DBG instantiation (OMLM_GEMM_DEBUG set)
     constexpr int NWN = BN_ / WN_, NWAVES = (BM_ / WM_) * NWN;
     constexpr int MI = WM_ / 32, NJ = WN_ / 32;
     constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BN_ * BK * 2, STAGE = A_BYTES + B_BYTES;
+    constexpr int UA = (BM_ / 8) / NWAVES, UB = (BN_ / 8) / NWAVES;   // DMA wave-instructions per k-tile per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A | B]
 
     const int tiles_m = (g.M + BM_ - 1) / BM_, tiles_n = (g.N + BN_ - 1) / BN_;
@@ -385,17 +393,23 @@ __global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile
     for (int kt = kt0; kt < kt1; ++kt) {
         const int cur = (kt - kt0) & 1;
         __syncthreads();          // waits vmcnt(0): tile kt landed everywhere, and the other stage is free
-        if (kt + 1 < kt1 && !(g.debug & 1)) {
-            char* nxt = smem + (cur ^ 1) * STAGE;
-            sa.issue(rsA, g.a_map, g.lda, (kt + 1) * BK, g.K, nxt, wave);
-            sb.issue(rsB, g.b_map, g.ldb, (kt + 1) * BK, g.K, nxt + A_BYTES, wave);
-        }
+        // The DMA of tile kt+1 is NOT issued in one burst here: a wave's instruction stream is in order, and a
+        // buffer_load..lds stalls at issue while the CU's vector-memory path is full, so a burst of 8 loads kept every
+        // wave out of its MFMAs for the whole transfer (measured: full time ~ DMA-only time + compute-only time).
+        // The loads are spread over the MFMAs of the first three k16 steps instead; the last step covers their latency.
+        const bool live = kt + 1 < kt1 && !(dbg & 1);
+        char* nxt = smem + (cur ^ 1) * STAGE;
+        const int knext = (kt + 1) * BK;
         const char* As = smem + cur * STAGE;
         const char* Bs = As + A_BYTES;
         // software-pipelined fragments: the LDS reads of k16-step s+1 are issued BEFORE the MFMAs of step s, so their
         // latency hides under the matrix pipe (hipcc's own schedule read-then-multiplied each step: MFMA busy 30 %)
         bf16x8 a[2][MI], b[2][NJ];
-        if (g.debug & 8) continue;
+        if (dbg & 8) {
+            if (!(dbg & 16)) sa.issue(rsA, g.a_map, g.lda, live ? knext : g.K, g.K, nxt, wave);
+            if (!(dbg & 32)) sb.issue(rsB, g.b_map, g.ldb, live ? knext : g.K, g.K, nxt + A_BYTES, wave);
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i) a[0][i] = read_frag<A_KMAJ>(As, wm + 32 * i, 0, lane);
 #pragma unroll
@@ -413,8 +427,20 @@ __global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    if (g.debug & 2) { asm volatile("" :: "v"(a[s & 1][i]), "v"(b[s & 1][j])); continue; }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s & 1][i], b[s & 1][j], acc[i][j], 0, 0, 0);
+                    if (!(dbg & 2))
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s & 1][i], b[s & 1][j], acc[i][j], 0, 0, 0);
+                    else
+                        asm volatile("" :: "v"(a[s & 1][i]), "v"(b[s & 1][j]));
+                    constexpr int MPS = MI * NJ, NLOAD = UA + UB;
+                    constexpr int STRIDE = (3 * MPS) / NLOAD > 0 ? (3 * MPS) / NLOAD : 1;
+                    const int midx = s * MPS + i * NJ + j;                    // compile-time after unrolling
+                    if (midx % STRIDE == 0 && midx / STRIDE < NLOAD) {
+                        const int l = midx / STRIDE;
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (l < UA) { if (!(dbg & 16)) sa.issue_one(l, rsA, g.a_map, g.lda, knext, g.K, nxt, wave, live, (dbg >> 6) & 3); }
+                        else        { if (!(dbg & 32)) sb.issue_one(l - UA, rsB, g.b_map, g.ldb, knext, g.K, nxt + A_BYTES, wave, live, (dbg >> 6) & 3); }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             __builtin_amdgcn_sched_barrier(0);                                // ... the MFMAs of step s
         }
@@ -434,7 +460,7 @@ __global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile
     const bool vec_ok = (g.ldc % VEC == 0) && (((uintptr_t)g.C & 15) == 0) &&
                         (!g.Cin || ((g.ldcin % 4 == 0) && (((uintptr_t)g.Cin & 15) == 0)));
     const int hi = lane >> 5;
-    if (g.debug & 4) return;
+    if (dbg & 4) return;
     if (split) {      // split-K slices accumulate into fp32 C (Cin == C): the C-layout already gives 128-B coalesced atomics
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -509,10 +535,16 @@ static int launch_tile(const GemmArgs& g, int a_kmaj, int b_kmaj, int splits, hi
     dim3 grid(tiles, splits), block(NTH);
 #define OMLM_TILE_LAUNCH(AK, BKM)                                                                                          \
     do {                                                                                                                    \
-        auto kfn = gemm_bf16_tile_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT>;                                               \
+        auto kfn = gemm_bf16_tile_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT, false>;                                        \
+        auto kdbg = gemm_bf16_tile_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT, true>;                                        \
         static bool attr = false;                                                                                           \
-        if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); attr = true; } \
-        hipLaunchKernelGGL(kfn, grid, block, LDS, st, g);                                                                  \
+        if (!attr) {                                                                                                        \
+            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);             \
+            (void)hipFuncSetAttribute((const void*)kdbg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);            \
+            attr = true;                                                                                                    \
+        }                                                                                                                   \
+        if (g.debug) hipLaunchKernelGGL(kdbg, grid, block, LDS, st, g);                                                    \
+        else         hipLaunchKernelGGL(kfn, grid, block, LDS, st, g);                                                     \
     } while (0)
     if (!a_kmaj && !b_kmaj)      OMLM_TILE_LAUNCH(false, false);
     else if (!a_kmaj && b_kmaj)  OMLM_TILE_LAUNCH(false, true);

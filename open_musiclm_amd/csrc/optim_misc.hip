@@ -68,6 +68,38 @@ extern "C" int omlm_adamw_clip_step(float* p, float* g, float* m, float* v, void
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// dst[c, r] = (T) src[r, c]  (r < R, c < C): transposed operand copies of the weights, so that the input-gradient GEMMs
+// (dX = dY W) read W^T k-contiguous instead of W k-major.  Measured on MI355X: the same contraction runs at 795 TFLOP/s
+// with a k-contiguous B versus 517 with a k-major B; the weights are tiny next to the activations, so the copy is ~free.
+// 64x64 tile through LDS (pitch 65 floats): 256-byte coalesced reads, 128-byte coalesced bf16 writes.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __restrict__ src, T* __restrict__ dst, int R, int C,
+                                                             int ld_src, int ld_dst) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + ty + 4 * i, c = c0 + tx;
+        tile[ty + 4 * i][tx] = (r < R && c < C) ? src[(long long)r * ld_src + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = c0 + ty + 4 * i, r = r0 + tx;
+        if (c < C && r < R) store_from_float(dst + (long long)c * ld_dst + r, tile[tx][ty + 4 * i]);
+    }
+}
+extern "C" int omlm_transpose_cast(const float* src, void* dst, int R, int C, int ld_src, int ld_dst, int out_dtype, void* stream) {
+    if (R <= 0 || C <= 0) return OMLM_OK;
+    OMLM_CHECK_ARG(src && dst && ld_src >= C && ld_dst >= R, "transpose_cast arguments");
+    dim3 grid((C + 63) / 64, (R + 63) / 64), block(256);
+    if (out_dtype == 0) hipLaunchKernelGGL(transpose_cast_kernel<float>, grid, block, 0, as_stream(stream), src, (float*)dst, R, C, ld_src, ld_dst);
+    else hipLaunchKernelGGL(transpose_cast_kernel<bf16_t>, grid, block, 0, as_stream(stream), src, (bf16_t*)dst, R, C, ld_src, ld_dst);
+    return omlm_post_launch("omlm_transpose_cast");
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // dst[r, c] = (T) src[r, c] for c < C ; 0 for C <= c < ldd.   (weight repack / operand casts)
 template <typename T>
 __global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__ src, T* __restrict__ dst, long long R, int C, int lds_, int ldd) {

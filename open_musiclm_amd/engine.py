@@ -111,7 +111,7 @@ def bf16_operand(w: torch.Tensor) -> torch.Tensor:
 
 
 class PreparedWeights:
-    def __init__(self, model, precision: str):
+    def __init__(self, model, precision: str, with_transposes: bool = False):
         tr = model.transformer
         self.precision = precision
         self.T = _PRECISIONS[precision]
@@ -136,6 +136,21 @@ class PreparedWeights:
             W2p = torch.empty(D, Fp, dtype=T, device=dev)
             ops.cast_pad(w2, W2p, D, F, F, Fp)
             ent["W1p"], ent["W2p"], ent["F"], ent["Fp"] = W1p, W2p, F, Fp
+            if T == torch.bfloat16 and with_transposes:
+                # k-contiguous W^T copies: every input-gradient GEMM (dX = dY W) then runs in the fast NT form
+                def wt(w, R, C, rows_pad=None, cols_pad=None):
+                    t = torch.zeros(rows_pad or C, cols_pad or R, dtype=T, device=dev)
+                    ops.transpose_cast(w.detach(), t, R, C, w.shape[-1], t.shape[-1])
+                    return t
+                HD = attn.to_q.weight.shape[0]
+                ent["WqT"] = wt(attn.to_q.weight, HD, D)                      # [D, H*dh]
+                ent["WkvT"] = wt(attn.to_kv.weight, attn.to_kv.weight.shape[0], D)
+                ent["WoT"] = wt(attn.to_out[0].weight, D, HD)                 # [H*dh, D]
+                W1pT = torch.zeros(D, 2 * Fp, dtype=T, device=dev)            # [D, 2Fp]: value half cols [0,F), gate half [Fp, Fp+F)
+                ops.transpose_cast(w1.detach(), W1pT, F, D, D, 2 * Fp)
+                ops.transpose_cast(w1.detach()[F:], W1pT[:, Fp:], F, D, D, 2 * Fp)
+                ent["W1pT"] = W1pT
+                ent["W2pT"] = wt(w2, D, F, rows_pad=Fp, cols_pad=D)           # [Fp, D], rows >= F zero
             ent["convw"] = ops.pack_conv_taps(ff.conv_weight().detach(), F, Fp)    # taps [3, 2Fp] (identity taps for plain FeedForward)
             ent["gamma_mid"] = ops.pad_vector(ff.norm_mid.gamma.detach(), Fp)
             cache = ff.__dict__.setdefault("_omlm_cmap", {})
@@ -147,11 +162,19 @@ class PreparedWeights:
             ent["dW1_cmap"] = cache[(F, Fp, str(dev))]
             self.layers.append(ent)
         self.heads = []
+        self.headsT = []
         for w in model.logit_weights:
             if T == torch.float32:
                 self.heads.append(w)
             else:
                 self.heads.append(bf16_operand(w))
+                if with_transposes:                                          # [Q, D, ldV], pad columns zero
+                    Q, V1 = w.shape[0], w.shape[1]
+                    ldV = ceil_to(V1, 8)
+                    t = torch.zeros(Q, D, ldV, dtype=T, device=dev)
+                    for qq in range(Q):
+                        ops.transpose_cast(w.detach()[qq], t[qq], V1, D, D, ldV)
+                    self.headsT.append(t)
 
 
 def prepared_weights(model, precision: str) -> PreparedWeights:
@@ -339,7 +362,8 @@ def trunk_backward(tr, pw: PreparedWeights, saved, dy: torch.Tensor, B: int, N: 
         F, Fp = w["F"], w["Fp"]
         # ---- feed-forward block: x2 = x1 + h2 W2^T ----
         dh2 = torch.empty(M, Fp, dtype=T, device=dev)
-        ops.gemm(dres_c, w["W2p"], dh2, M=M, N=Fp, K=D, b_kmajor=True)
+        if "W2pT" in w: ops.gemm(dres_c, w["W2pT"], dh2, M=M, N=Fp, K=D)
+        else: ops.gemm(dres_c, w["W2p"], dh2, M=M, N=Fp, K=D, b_kmajor=True)
         gW2 = grad_of(ff.w_out.weight)                                              # [D, F]
         ops.gemm(dres_c, sv.h2, gW2, M=D, N=F, K=M, a_kmajor=True, b_kmajor=True, Cin=gW2)
         if ws is None or ws.numel() < ops.ffmid_bwd_workspace_floats(F, Fp):
@@ -352,7 +376,8 @@ def trunk_backward(tr, pw: PreparedWeights, saved, dy: torch.Tensor, B: int, N: 
                       seed_dev=saved["salt"] if sv.p > 0 else None)
         del du, dh2
         dxn2 = torch.empty(M, D, device=dev)
-        ops.gemm(dh1, w["W1p"], dxn2, M=M, N=D, K=2 * Fp, b_kmajor=True)
+        if "W1pT" in w: ops.gemm(dh1, w["W1pT"], dxn2, M=M, N=D, K=2 * Fp)
+        else: ops.gemm(dh1, w["W1p"], dxn2, M=M, N=D, K=2 * Fp, b_kmajor=True)
         gW1 = grad_of(ff.w_in.weight)                                               # [2F, D]
         ops.gemm(dh1, sv.xn2, gW1, M=2 * Fp, N=D, K=M, a_kmajor=True, b_kmajor=True, Cin=gW1, c_map=w["dW1_cmap"])
         del dh1
@@ -362,7 +387,8 @@ def trunk_backward(tr, pw: PreparedWeights, saved, dy: torch.Tensor, B: int, N: 
                           None if T == torch.float32 else dx1_c, grad_of(ff.norm_in.gamma))
         # ---- attention block: x1 = x + o Wo^T ----
         do = torch.empty(M, H * DIM_HEAD, dtype=T, device=dev)
-        ops.gemm(dx1_c, w["Wo"], do, M=M, N=H * DIM_HEAD, K=D, b_kmajor=True)
+        if "WoT" in w: ops.gemm(dx1_c, w["WoT"], do, M=M, N=H * DIM_HEAD, K=D)
+        else: ops.gemm(dx1_c, w["Wo"], do, M=M, N=H * DIM_HEAD, K=D, b_kmajor=True)
         gWo = grad_of(attn.to_out[0].weight)
         ops.gemm(dx1_c, sv.o, gWo, M=D, N=H * DIM_HEAD, K=M, a_kmajor=True, b_kmajor=True, Cin=gWo)
         dq = torch.empty(M, H * DIM_HEAD, device=dev)
@@ -375,9 +401,13 @@ def trunk_backward(tr, pw: PreparedWeights, saved, dy: torch.Tensor, B: int, N: 
         ops.qk_norm_bwd(dq, dk, dv, sv.q_raw, sv.kv_raw, attn.q_scale.detach(), attn.k_scale.detach(),
                         dq_raw, dkv_raw, grad_of(attn.q_scale), grad_of(attn.k_scale), H)
         dxn = torch.empty(M, D, device=dev)
-        ops.gemm(dq_raw, w["Wq"], dxn, M=M, N=D, K=H * DIM_HEAD, b_kmajor=True)
         tmp = torch.empty(M, D, device=dev)
-        ops.gemm(dkv_raw, w["Wkv"], tmp, M=M, N=D, K=2 * DIM_HEAD, b_kmajor=True, Cin=dx1)
+        if "WqT" in w:
+            ops.gemm(dq_raw, w["WqT"], dxn, M=M, N=D, K=H * DIM_HEAD)
+            ops.gemm(dkv_raw, w["WkvT"], tmp, M=M, N=D, K=2 * DIM_HEAD, Cin=dx1)
+        else:
+            ops.gemm(dq_raw, w["Wq"], dxn, M=M, N=D, K=H * DIM_HEAD, b_kmajor=True)
+            ops.gemm(dkv_raw, w["Wkv"], tmp, M=M, N=D, K=2 * DIM_HEAD, b_kmajor=True, Cin=dx1)
         gWq = grad_of(attn.to_q.weight)
         ops.gemm(dq_raw, sv.xn, gWq, M=H * DIM_HEAD, N=D, K=M, a_kmajor=True, b_kmajor=True, Cin=gWq)
         gWkv = grad_of(attn.to_kv.weight)
@@ -479,8 +509,11 @@ def heads_backward(model, pw: PreparedWeights, y: torch.Tensor, lay: SeqLayout, 
                 continue
             a_map, c_map, rows = ent
             # dy[rows] = dlogits[rows] @ W_q          (each hidden row belongs to exactly one head)
-            ops.gemm(dl, pw.heads[s][qq], dy, M=rows, N=D, K=ldV, b_kmajor=True, a_map=c_map, c_map=a_map,
-                     a_rows=dl.shape[0], b_rows=V1)
+            if pw.headsT:
+                ops.gemm(dl, pw.headsT[s][qq], dy, M=rows, N=D, K=ldV, a_map=c_map, c_map=a_map, a_rows=dl.shape[0])
+            else:
+                ops.gemm(dl, pw.heads[s][qq], dy, M=rows, N=D, K=ldV, b_kmajor=True, a_map=c_map, c_map=a_map,
+                         a_rows=dl.shape[0], b_rows=V1)
             # dW_q += dlogits[rows]^T @ y[rows]
             ops.gemm(dl, y, gW[qq], M=V1, N=D, K=rows, a_kmajor=True, b_kmajor=True, a_map=c_map, b_map=a_map,
                      Cin=gW[qq], lda=ldV, a_rows=dl.shape[0], b_rows=y.shape[0])
@@ -503,7 +536,7 @@ def run_forward(model, all_token_ids, self_attn_mask, only_final: bool, save: bo
     require_gpu(ids32, "token ids")
     B, N = ids32.shape
     lay = get_layout(model, B, lens, ids32.device, final_rows_only)
-    pw = prepared_weights(model, precision) if not save else PreparedWeights(model, precision)
+    pw = prepared_weights(model, precision) if not save else PreparedWeights(model, precision, with_transposes=True)
     keymask = None
     if self_attn_mask is not None:
         assert self_attn_mask.shape == (B, N), f"self_attn_mask must be [{B}, {N}]"

@@ -169,6 +169,11 @@ def cast_pad(src, dst, R, C_, ld_src, ld_dst):
     call("omlm_cast_pad", ptr(src), ptr(dst), R, C_, ld_src, ld_dst, dcode(dst.dtype), stream_ptr())
 
 
+def transpose_cast(src, dst, R, C_, ld_src, ld_dst):
+    """dst[c, r] = cast(src[r, c]) for r < R, c < C_ (fp32 source, dst fp32 or bf16)."""
+    call("omlm_transpose_cast", ptr(src), ptr(dst), R, C_, ld_src, ld_dst, dcode(dst.dtype), stream_ptr())
+
+
 def colsum_accumulate(part, out, P, C_, ldp):
     call("omlm_colsum_accumulate", ptr(part), ptr(out), P, C_, ldp, stream_ptr())
 

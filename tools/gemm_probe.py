@@ -19,6 +19,19 @@ shapes = {
     "dX_NN_f32out": lambda: ops.gemm(dH, W, dX, M=M, N=D, K=F2, b_kmajor=True),
     "dW_TN_splitk": lambda: ops.gemm(dH, X, dW, M=F2, N=D, K=M, a_kmajor=True, b_kmajor=True, Cin=dW),
 }
+if os.environ.get("EXTRA", "0") == "1":      # layout experiments: same contractions with operands stored the other way round
+    W1T = W.t().contiguous()                 # [D, F2]
+    XT = X.t().contiguous()                  # [D, M]
+    dHT = dH.t().contiguous()                # [F2, M]
+    shapes["dX_NT_longK"] = lambda: ops.gemm(dH, W1T, dX, M=M, N=D, K=F2)
+    shapes["dW_TN_Bnormal"] = lambda: ops.gemm(dH, XT, dW, M=F2, N=D, K=M, a_kmajor=True, Cin=dW)
+    shapes["dW_NT_splitk"] = lambda: ops.gemm(dHT, XT, dW, M=F2, N=D, K=M, Cin=dW)
+if os.environ.get("PITCHK", "0") != "0":     # k-major operands with a padded row pitch
+    pad = int(os.environ["PITCHK"])
+    Wp2 = torch.zeros(F2, D + pad, device=dev, dtype=torch.bfloat16); Wp2[:, :D] = W
+    Xp2 = torch.zeros(M, D + pad, device=dev, dtype=torch.bfloat16); Xp2[:, :D] = X
+    shapes["dX_NN_padB"] = lambda: ops.gemm(dH, Wp2, dX, M=M, N=D, K=F2, b_kmajor=True, ldb=D + pad)
+    shapes["dW_TN_padB"] = lambda: ops.gemm(dH, Xp2, dW, M=F2, N=D, K=M, a_kmajor=True, b_kmajor=True, Cin=dW, ldb=D + pad)
 sel = os.environ.get("SHAPES", ",".join(shapes)).split(",")
 for tile in os.environ.get("TILES", "128x128,256x256,256x128").split(","):
     os.environ["OMLM_GEMM_TILE"] = tile
@@ -53,7 +66,7 @@ if os.environ.get("ABLATE", "1") == "1":
         for tile in os.environ.get("ABLATE_TILES", "128x128,256x256").split(","):
             os.environ["OMLM_GEMM_TILE"] = tile
             for dbg, label in ((0, "full"), (3, "no-DMA no-MFMA"), (4, "no-epilogue"), (7, "no-DMA/MFMA/epi"), (15, "barriers only"),
-                               (12, "DMA+barrier only"), (2, "no-MFMA"), (1, "no-DMA")):
+                               (12, "DMA+barrier only"), (2, "no-MFMA"), (1, "no-DMA"), (12 + 32, "A-DMA only"), (12 + 16, "B-DMA only"), (64, "aux1"), (128, "aux2"), (192, "aux3")):
                 os.environ["OMLM_GEMM_DEBUG"] = str(dbg)
                 fn = shapes[name]
                 fn(); torch.cuda.synchronize()
