@@ -311,6 +311,10 @@ struct DmaStagerT {
         }
     }
     // one 1-KiB unit (one wave-instruction).  `live` false -> out-of-bounds offset: the DMA writes zeros, no memory traffic
+    // KMAP: a k-row map is honoured (an ORDINARY global load inside the k-loop).  It is a template switch because its mere
+    // presence -- even behind a null-pointer test -- makes hipcc wait vmcnt(0) before every LDS-DMA issue and every
+    // fragment read, which serialised the whole pipeline of the k-major GEMMs (2x slower; found in the ISA).
+    template <bool KMAP>
     __device__ __forceinline__ void issue_one(int i, __amdgpu_buffer_rsrc_t rs, const int* map, int ld, int k0, int K,
                                               char* lds_tile, int wave, bool live, int aux = 0) {
         const int b = wave + NWAVES * i;
@@ -320,7 +324,8 @@ struct DmaStagerT {
         } else {
             const int gk = k0 + kidx[i];
             const bool ok = live && base[i] != OOB_OFF && gk < K;
-            const long long pr = (ok && map) ? (long long)map[gk] : (long long)gk;
+            long long pr = gk;
+            if (KMAP) { if (ok && map) pr = map[gk]; }
             off = ok ? base[i] + (unsigned)(pr * ld * 2) : OOB_OFF;
         }
         if (aux == 0)      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(void, lds_tile + b * 1024), 16, (int)off, 0, 0, 0);
@@ -328,14 +333,15 @@ struct DmaStagerT {
         else if (aux == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(void, lds_tile + b * 1024), 16, (int)off, 0, 0, 2);
         else               __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(void, lds_tile + b * 1024), 16, (int)off, 0, 0, 3);
     }
+    template <bool KMAP>
     __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rs, const int* map, int ld, int k0, int K,
                                           char* lds_tile, int wave) {
 #pragma unroll
-        for (int i = 0; i < UPW; ++i) issue_one(i, rs, map, ld, k0, K, lds_tile, wave, true);
+        for (int i = 0; i < UPW; ++i) issue_one<KMAP>(i, rs, map, ld, k0, K, lds_tile, wave, true);
     }
 };
 
-template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ, bool B_KMAJ, typename TOUT, bool DBG>
+template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ, bool B_KMAJ, typename TOUT, bool DBG, bool KMAP>
 __global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile_kernel(GemmArgs g) {
     const int dbg = DBG ? g.debug : 0;      // ablation switches exist only in the DBG instantiation (OMLM_GEMM_DEBUG set)
     constexpr int NWN = BN_ / WN_, NWAVES = (BM_ / WM_) * NWN;
@@ -387,8 +393,8 @@ __global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile
     const int kt0 = ksplit * g.kt_per_split;
     const int kt1 = min(nk_all, kt0 + g.kt_per_split);
     if (kt0 < kt1) {
-        sa.issue(rsA, g.a_map, g.lda, kt0 * BK, g.K, smem, wave);
-        sb.issue(rsB, g.b_map, g.ldb, kt0 * BK, g.K, smem + A_BYTES, wave);
+        sa.template issue<KMAP>(rsA, g.a_map, g.lda, kt0 * BK, g.K, smem, wave);
+        sb.template issue<KMAP>(rsB, g.b_map, g.ldb, kt0 * BK, g.K, smem + A_BYTES, wave);
     }
     for (int kt = kt0; kt < kt1; ++kt) {
         const int cur = (kt - kt0) & 1;
@@ -406,8 +412,8 @@ __global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile
         // latency hides under the matrix pipe (hipcc's own schedule read-then-multiplied each step: MFMA busy 30 %)
         bf16x8 a[2][MI], b[2][NJ];
         if (dbg & 8) {
-            if (!(dbg & 16)) sa.issue(rsA, g.a_map, g.lda, live ? knext : g.K, g.K, nxt, wave);
-            if (!(dbg & 32)) sb.issue(rsB, g.b_map, g.ldb, live ? knext : g.K, g.K, nxt + A_BYTES, wave);
+            if (!(dbg & 16)) sa.template issue<KMAP>(rsA, g.a_map, g.lda, live ? knext : g.K, g.K, nxt, wave);
+            if (!(dbg & 32)) sb.template issue<KMAP>(rsB, g.b_map, g.ldb, live ? knext : g.K, g.K, nxt + A_BYTES, wave);
             continue;
         }
 #pragma unroll
@@ -437,8 +443,8 @@ __global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile
                     if (midx % STRIDE == 0 && midx / STRIDE < NLOAD) {
                         const int l = midx / STRIDE;
                         __builtin_amdgcn_sched_barrier(0);
-                        if (l < UA) { if (!(dbg & 16)) sa.issue_one(l, rsA, g.a_map, g.lda, knext, g.K, nxt, wave, live, (dbg >> 6) & 3); }
-                        else        { if (!(dbg & 32)) sb.issue_one(l - UA, rsB, g.b_map, g.ldb, knext, g.K, nxt + A_BYTES, wave, live, (dbg >> 6) & 3); }
+                        if (l < UA) { if (!(dbg & 16)) sa.template issue_one<KMAP>(l, rsA, g.a_map, g.lda, knext, g.K, nxt, wave, live, (dbg >> 6) & 3); }
+                        else        { if (!(dbg & 32)) sb.template issue_one<KMAP>(l - UA, rsB, g.b_map, g.ldb, knext, g.K, nxt + A_BYTES, wave, live, (dbg >> 6) & 3); }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -533,18 +539,23 @@ static int launch_tile(const GemmArgs& g, int a_kmaj, int b_kmaj, int splits, hi
     constexpr size_t LDS = 2 * (size_t)(BM_ + BN_) * BK * 2;
     const int tiles = ((g.M + BM_ - 1) / BM_) * ((g.N + BN_ - 1) / BN_);
     dim3 grid(tiles, splits), block(NTH);
+    const bool need_kmap = (a_kmaj && g.a_map) || (b_kmaj && g.b_map);       // host routes these to the 128x128 tile
+    if (need_kmap && BM_ != 128) { omlm_set_error("omlm_gemm: k-row maps are only built for the 128x128 tile"); return OMLM_ERR_UNSUPPORTED; }
 #define OMLM_TILE_LAUNCH(AK, BKM)                                                                                          \
     do {                                                                                                                    \
-        auto kfn = gemm_bf16_tile_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT, false>;                                        \
-        auto kdbg = gemm_bf16_tile_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT, true>;                                        \
+        auto kfn = gemm_bf16_tile_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT, false, false>;                                 \
+        auto kdbg = gemm_bf16_tile_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT, true, false>;                                 \
+        auto kmap = gemm_bf16_tile_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT, false, (AK || BKM) && BM_ == 128>;            \
         static bool attr = false;                                                                                           \
         if (!attr) {                                                                                                        \
             (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);             \
             (void)hipFuncSetAttribute((const void*)kdbg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);            \
+            (void)hipFuncSetAttribute((const void*)kmap, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);            \
             attr = true;                                                                                                    \
         }                                                                                                                   \
-        if (g.debug) hipLaunchKernelGGL(kdbg, grid, block, LDS, st, g);                                                    \
-        else         hipLaunchKernelGGL(kfn, grid, block, LDS, st, g);                                                     \
+        if (need_kmap)    hipLaunchKernelGGL(kmap, grid, block, LDS, st, g);                                               \
+        else if (g.debug) hipLaunchKernelGGL(kdbg, grid, block, LDS, st, g);                                               \
+        else              hipLaunchKernelGGL(kfn, grid, block, LDS, st, g);                                                \
     } while (0)
     if (!a_kmaj && !b_kmaj)      OMLM_TILE_LAUNCH(false, false);
     else if (!a_kmaj && b_kmaj)  OMLM_TILE_LAUNCH(false, true);
@@ -597,7 +608,8 @@ extern "C" int omlm_gemm(const void* A, const void* B, void* C, const float* Cin
     // tile shape (bf16 path): 256x256 when both output dims are wide, 256x128 for tall-narrow outputs, else 128x128
     int bm = BM, bn = BN;
     const char* force = getenv("OMLM_GEMM_TILE");
-    if (in_dtype == 1) {
+    const bool need_kmap = (a_kmajor && a_map) || (b_kmajor && b_map);
+    if (in_dtype == 1 && !need_kmap) {
         if (force && force[0]) { if (!strcmp(force, "256x256")) { bm = 256; bn = 256; } else if (!strcmp(force, "256x128")) { bm = 256; bn = 128; } }
         else if (M >= 1024 && N >= 1536) { bm = 256; bn = 256; }
         else if (a_kmajor && b_kmajor && M >= 1024 && N >= 1024) { bm = 256; bn = 256; }   // weight gradients: measured 1.1 vs 1.4 ms
