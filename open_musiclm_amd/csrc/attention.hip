@@ -280,7 +280,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const T* __restric
 // backward, kernel B: dQ, d(bias table), delta_i = sum_d dO[i,d] O[i,d]     (same geometry as the forward)
 // =============================================================================================================
 template <typename T>
-__global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k,
+__global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                                  const T* __restrict__ v, const float* __restrict__ bias,
                                                                  const unsigned char* __restrict__ keymask,
                                                                  const T* __restrict__ out, const T* __restrict__ dout,
@@ -303,6 +303,8 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(const T* __rest
     const int nb = i0 + TQ;
     float* bias_l = (float*)(smem + 3 * PLANE) + (size_t)wave * nb;              // [4][nb]
     float* dbias_l = (float*)(smem + 3 * PLANE) + (size_t)(4 + wave) * nb;       // [4][nb]
+    // key-mask ballots of every 64-key tile, built once (a global load + ballot per k-tile stalled each iteration)
+    unsigned long long* mbits = (unsigned long long*)(smem + 3 * PLANE + (size_t)8 * (nqt * TQ) * sizeof(float));
     const size_t rowbase = (size_t)b * N;
     const size_t qrow = (rowbase + min(qi, N - 1)) * (size_t)(H * 64) + (active ? h : 0) * 64;
 
@@ -338,16 +340,20 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(const T* __rest
     KVRegs<T, false> kr, vr;
     kr.load(k + rowbase * 64, 0, N);
     vr.load(v + rowbase * 64, 0, N);
+    for (int ch = wave; ch < nkt; ch += 4) {
+        const int jk = ch * TKV + lane;
+        const bool live = jk < N && (keymask ? keymask[rowbase + jk] != 0 : true);
+        const unsigned long long bb = __ballot(live);
+        if (lane == 0) mbits[ch] = bb;
+    }
     for (int kt = 0; kt < nkt; ++kt) {
         const int j0 = kt * TKV;
         __syncthreads();
         kr.store(Ks, Ks);
         kr.store_blk(Kt, Kt);
         vr.store(Vs, Vs);
-        const int jk = j0 + lane;
-        const bool live = jk < N && (keymask ? keymask[rowbase + jk] != 0 : true);
-        const unsigned long long bits = __ballot(live);
         __syncthreads();
+        const unsigned long long bits = mbits[kt];
         if (kt + 1 < nkt) {
             kr.load(k + rowbase * 64, j0 + TKV, N);
             vr.load(v + rowbase * 64, j0 + TKV, N);
@@ -365,16 +371,36 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(const T* __rest
                 st = MFMA(frag_rows(Ks, 32 * sub, s, lane), qf[s], st);      // S^T  = K Q^T
                 dp = MFMA(frag_rows(Vs, 32 * sub, s, lane), dof[s], dp);     // dP^T = V dO^T
             }
+            // three straight passes (gather bias, arithmetic, scatter d(bias)): a fused per-element loop compiled to 16
+            // serialised LDS round trips (read -> wait -> exp -> atomic), ~3k cycles per 32x32 block
+            float bv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bv[r] = bias_l[max(min(qi - (j0 + 32 * sub + crow(r, hi)), nb - 1), 0)];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int kr = 32 * sub + crow(r, hi);
                 const int rel = qi - (j0 + kr);
                 const bool ok = (rel >= 0) && ((bits >> kr) & 1ull) && (qi < N);
-                const int bin = max(min(rel, nb - 1), 0);
-                const float p = ok ? exp2f(st[r] * c + bias_l[bin] - L) : 0.f;
-                const float ds = p * (dp[r] - dl);
-                if (ok) atomicAdd(dbias_l + bin, ds);
-                st[r] = ds * scale;
+                const float p = __builtin_amdgcn_exp2f(ok ? st[r] * c + bv[r] - L : NEG_BIG);   // branch-free: 2^-inf = 0
+                bv[r] = p * (dp[r] - dl);                                     // dS (0 where masked)
+                st[r] = bv[r] * scale;
+            }
+            if (dbias) {
+                // d(bias)[rel] = sum of dS over the diagonal rel = i - j.  LDS float atomics (one per element) cost 930 us
+                // per layer (measured: 1496 -> 565 us without them), so the 63 diagonals of the 32x32 block are summed in
+                // registers instead: output lane L stands for t = q - kr = L - 31 and pulls row kr's element from query
+                // column q = t + kr through the cross-lane permute (no LDS memory access); then ONE plain read-add-write
+                // of the wave-private table, predicated so that every lane owns a distinct bin.
+                float dsum = 0.f;
+#pragma unroll
+                for (int kr = 0; kr < 32; ++kr) {
+                    const int r = 4 * (kr >> 3) + (kr & 3), hh = (kr >> 2) & 1;
+                    const int src = lane - 31 + kr;
+                    const float got = __shfl(bv[r], (32 * hh + src) & 63, 64);
+                    dsum += (src >= 0 && src < 32) ? got : 0.f;
+                }
+                const int rel = (i0 - j0 - 32 * sub) + (lane - 31);
+                if (rel >= 0 && rel < nb) dbias_l[rel] += dsum;
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -412,7 +438,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_kernel(const T* __rest
 // work items and reduce their partial dK^T / dV^T through LDS at the end -- no atomics on dK / dV.
 // =============================================================================================================
 template <typename T>
-__global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k,
+__global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                                   const T* __restrict__ v, const float* __restrict__ bias,
                                                                   const unsigned char* __restrict__ keymask,
                                                                   const T* __restrict__ dout, const float* __restrict__ lse,
@@ -423,6 +449,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(const T* __res
     char* Qs = smem + wave * 8192;            // per-wave private [32][64] bf16 tiles (Q, dO) for the transpose reads
     char* dOs = Qs + 4096;
     float* red = (float*)(smem);              // reused at the end: [4 waves][64 d][32 j] fp32 = 32 KiB
+    float* bias_s = (float*)(smem + 32768);   // [H][nbk] rel-pos table (x log2 e) for rel in [0, N - j0)
 
     const int nqt = (N + TQ - 1) / TQ;
     const int jt = blockIdx.x;                // 32-key tile; low tiles carry the most (causal) work and launch first
@@ -431,7 +458,15 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(const T* __res
     const int kj = j0 + (lane & 31);          // this lane's key (column of S)
     const size_t rowbase = (size_t)b * N;
     const float c = scale * LOG2E;
+    const int nbk = nqt * TQ - j0;            // rel = i - kj <= nqt*TQ - 1 - j0
     bf16x8 dummy;
+
+    // The rel-pos column of every head goes to LDS once.  (Per-element global gathers of bias / lse / delta -- 48
+    // dependent L2 round trips per work item -- were >95 % of this kernel: 26k cycles per item for 16 MFMAs.)
+    for (int idx = threadIdx.x; idx < H * nbk; idx += AT_THREADS) {
+        const int r = idx / H, hh = idx - r * H;
+        bias_s[hh * nbk + r] = bias ? bias[(size_t)min(r, N - 1) * bias_ld + hh] * LOG2E : 0.f;
+    }
 
     // K^T, V^T B-operands: lane n = key kj, dims 16 s + 8 hi .. +7 -- resident for the whole kernel
     bf16x8 kf[4], vf[4];
@@ -447,28 +482,37 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(const T* __res
     for (int e = 0; e < 16; ++e) { dkacc[0][e] = 0.f; dkacc[1][e] = 0.f; dvacc[0][e] = 0.f; dvacc[1][e] = 0.f; }
 
     const int nitems = (nqt - jt) * H;        // (query tile it >= jt) x head
-    // A-operand fragments (rows = queries i0 + (lane&31), dims 16 s + 8 hi) of Q and dO; the NEXT item's fragments are
-    // fetched while the current item is on the matrix cores (each wave walks its items alone: nothing else hides HBM).
+    // A-operand fragments (rows = queries i0 + (lane&31), dims 16 s + 8 hi) of Q and dO plus the tile's lse / delta
+    // (one value per lane = per query); the NEXT item's are fetched while the current item is on the matrix cores.
     bf16x8 qa[4], doa[4], qn[4], don[4];
-    auto fetch = [&](int item, bf16x8 (&fq)[4], bf16x8 (&fd)[4]) {
+    float La = 0.f, Da = 0.f, Ln = 0.f, Dn = 0.f;
+    auto fetch = [&](int item, bf16x8 (&fq)[4], bf16x8 (&fd)[4], float& fl, float& fdl) {
         const int qi_ = (jt + item / H) * TQ + (lane & 31);
-        const size_t qrow_ = (rowbase + min(qi_, N - 1)) * (size_t)(H * 64) + (item % H) * 64;
+        const int hh = item % H;
+        const size_t qrow_ = (rowbase + min(qi_, N - 1)) * (size_t)(H * 64) + hh * 64;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             load_row8<T, false>(q + qrow_ + 16 * s + 8 * hi, qi_ < N, fq[s], dummy);
             load_row8<T, false>(dout + qrow_ + 16 * s + 8 * hi, qi_ < N, fd[s], dummy);
         }
+        fl = lse[((size_t)b * H + hh) * N + min(qi_, N - 1)];
+        fdl = delta[((size_t)b * H + hh) * N + min(qi_, N - 1)];
     };
-    if (wave < nitems) fetch(wave, qa, doa);
+    if (wave < nitems) fetch(wave, qa, doa, La, Da);
+    __syncthreads();                           // bias_s staged
     for (int item = wave; item < nitems; item += 4) {
         const int it = jt + item / H, h = item % H;
         const int i0 = it * TQ;
-        if (item + 4 < nitems) fetch(item + 4, qn, don);
+        if (item + 4 < nitems) fetch(item + 4, qn, don, Ln, Dn);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {        // park this item's tiles in LDS for the transpose reads
             *(bf16x8*)(Qs + tile_off_blk(lane & 31, (2 * s + hi) * 16)) = qa[s];
             *(bf16x8*)(dOs + tile_off_blk(lane & 31, (2 * s + hi) * 16)) = doa[s];
         }
+        const float* bh = bias_s + h * nbk;
+        float bv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bv[r] = bh[max(min(i0 + crow(r, hi) - kj, nbk - 1), 0)];
         f32x16 st, dp;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { st[e] = 0.f; dp[e] = 0.f; }
@@ -477,20 +521,20 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(const T* __res
             st = MFMA(qa[s], kf[s], st);       // S  = Q K^T   (rows i, column = this lane's key)
             dp = MFMA(doa[s], vf[s], dp);      // dP = dO V^T
         }
-        const float* Lr = lse + ((size_t)b * H + h) * N;
-        const float* Dr = delta + ((size_t)b * H + h) * N;
-        const float* br = bias ? bias + h : nullptr;
         f32x16 pp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+            // row i = i0 + crow(r, hi): its lse / delta sit in lane crow(r, hi) of La / Da (a wave-uniform lane per half)
+            const float l0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, La), crow(r, 0)));
+            const float l1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, La), crow(r, 1)));
+            const float d0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, Da), crow(r, 0)));
+            const float d1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, Da), crow(r, 1)));
+            const float Li = hi ? l1 : l0, Di = hi ? d1 : d0;
             const int i = i0 + crow(r, hi);
-            const int rel = i - kj;
-            const bool ok = (rel >= 0) && keylive && (i < N);
-            const int ic = min(i, N - 1);
-            const float bv = br ? br[(size_t)max(min(rel, N - 1), 0) * bias_ld] * LOG2E : 0.f;
-            const float p = ok ? exp2f(st[r] * c + bv - Lr[ic]) : 0.f;
+            const bool ok = (i >= kj) && keylive && (i < N);
+            const float p = __builtin_amdgcn_exp2f(ok ? st[r] * c + bv[r] - Li : NEG_BIG);      // branch-free: 2^-inf = 0
             pp[r] = p;
-            st[r] = p * (dp[r] - Dr[ic]) * scale;     // dS * d(sim)/d(dot)
+            st[r] = p * (dp[r] - Di) * scale;     // dS * d(sim)/d(dot)
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -505,6 +549,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(const T* __res
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) { qa[s] = qn[s]; doa[s] = don[s]; }
+        La = Ln; Da = Dn;
     }
     // cross-wave reduction through LDS, one accumulator pair at a time
     for (int which = 0; which < 2; ++which) {
@@ -528,7 +573,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_kernel(const T* __res
 
 // =============================================================================================================
 static size_t fwd_lds(int N, bool precise) { return (size_t)(precise ? 4 : 2) * TKV * 128 + (size_t)4 * ((N + TQ - 1) / TQ * TQ) * sizeof(float); }
-static size_t dq_lds(int N) { return (size_t)3 * TKV * 128 + (size_t)8 * ((N + TQ - 1) / TQ * TQ) * sizeof(float); }
+static size_t dq_lds(int N) { return (size_t)3 * TKV * 128 + (size_t)8 * ((N + TQ - 1) / TQ * TQ) * sizeof(float) + (size_t)8 * ((N + TKV - 1) / TKV + 1); }
 
 template <typename K>
 static int set_lds(K kernel, size_t bytes) {
@@ -566,15 +611,17 @@ extern "C" int omlm_mqa_attn_bwd(const void* q, const void* k, const void* v, co
     if (B <= 0 || N <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(q && k && v && out && dout && lse && delta && dq && dk && dv, "null pointer");
     dim3 gridq((N + TQ - 1) / TQ, (H + 3) / 4, B), gridk((N + 31) / 32, 1, B), block(AT_THREADS);
-    const size_t ldsq = dq_lds(N), ldsk = 32 * 1024;
+    const size_t ldsq = dq_lds(N), ldsk = 32 * 1024 + (size_t)H * ((N + TQ - 1) / TQ * TQ) * sizeof(float);
     int rc;
     hipStream_t st = as_stream(stream);
     if (dtype == 0) {
         if ((rc = set_lds(attn_bwd_dq_kernel<float>, ldsq))) return rc;
+        if ((rc = set_lds(attn_bwd_dkv_kernel<float>, ldsk))) return rc;
         hipLaunchKernelGGL(attn_bwd_dq_kernel<float>, gridq, block, ldsq, st, (const float*)q, (const float*)k, (const float*)v, bias, keymask, (const float*)out, (const float*)dout, lse, delta, dq, dbias, B, N, H, scale, bias_ld);
         hipLaunchKernelGGL(attn_bwd_dkv_kernel<float>, gridk, block, ldsk, st, (const float*)q, (const float*)k, (const float*)v, bias, keymask, (const float*)dout, lse, delta, dk, dv, B, N, H, scale, bias_ld);
     } else {
         if ((rc = set_lds(attn_bwd_dq_kernel<bf16_t>, ldsq))) return rc;
+        if ((rc = set_lds(attn_bwd_dkv_kernel<bf16_t>, ldsk))) return rc;
         hipLaunchKernelGGL(attn_bwd_dq_kernel<bf16_t>, gridq, block, ldsq, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, bias, keymask, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, dq, dbias, B, N, H, scale, bias_ld);
         hipLaunchKernelGGL(attn_bwd_dkv_kernel<bf16_t>, gridk, block, ldsk, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, bias, keymask, (const bf16_t*)dout, lse, delta, dk, dv, B, N, H, scale, bias_ld);
     }

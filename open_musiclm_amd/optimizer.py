@@ -67,7 +67,7 @@ class FusedAdam(torch.optim.Optimizer):
         # bf16 shadow of every parameter, refreshed by the SAME kernel that updates the fp32 master (adamw p16 output):
         # the engine's bf16 GEMM operands are views of it, so the per-step weight-cast launches disappear.
         P16 = torch.empty(tot, device=dev, dtype=torch.bfloat16)
-        ops.cast_pad(P, P16, 1, tot, tot, tot)
+        P16.copy_(P)                                    # one-off cast (cast_pad walks rows: a single 91M-element row is one workgroup)
         for p, o, n in zip(params, offs, sizes):
             p._omlm_bf16 = P16[o:o + n].view(p.shape)
             p._omlm_bf16_version = p._version
