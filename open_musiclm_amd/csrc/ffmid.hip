@@ -88,6 +88,13 @@ __device__ __forceinline__ void dropout8(unsigned long long seed, unsigned long 
     }
 }
 
+// keep-mask of 8 consecutive elements from the byte the forward kernel stored (bit i = element i kept)
+__device__ __forceinline__ void dropout8_from_bits(unsigned bits, float p, float* m) {
+    const float inv = 1.0f / (1.0f - p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m[i] = ((bits >> i) & 1u) ? inv : 0.f;
+}
+
 // One WAVE per row: the row's F channels are spread over the 64 lanes in 8-channel chunks, the two LayerNorm
 // reductions are wave shuffles (no LDS, no barrier), and a 256-thread workgroup keeps 4 independent rows in
 // flight -- at ~4 waves/SIMD that is ~16 rows per CU hiding HBM latency, instead of one row per workgroup
@@ -108,7 +115,8 @@ __global__ __launch_bounds__(FF_THREADS, 3) void ffmid_fwd_kernel(const T* __res
                                                                   const float* __restrict__ gamma, T* __restrict__ h2,
                                                                   float* __restrict__ mean, float* __restrict__ rstd,
                                                                   int M, int nseq, int F, int Fp, float eps, float p,
-                                                                  unsigned long long seed, const unsigned long long* __restrict__ seed_dev) {
+                                                                  unsigned long long seed, const unsigned long long* __restrict__ seed_dev,
+                                                                  unsigned char* __restrict__ drop_bits) {
     if (seed_dev) seed += seed_dev[0] * 0x9E3779B97F4A7C15ull;      // per-step salt from device memory (graph replays differ)
     extern __shared__ __attribute__((aligned(16))) float ff_lds[];     // [4 waves][Fp]: this wave's g row between the sweeps
     const int lane = threadIdx.x & 63;
@@ -159,7 +167,15 @@ __global__ __launch_bounds__(FF_THREADS, 3) void ffmid_fwd_kernel(const T* __res
                 } else {
                     zero8(gv);
                 }
-                if (p > 0.f) dropout8(seed, (unsigned long long)row * Fp + ch, p, m);
+                if (p > 0.f) {
+                    dropout8(seed, (unsigned long long)row * Fp + ch, p, m);
+                    if (drop_bits) {                               // 1 bit per element for the backward (Philox there was ~40 % of its VALU work)
+                        unsigned bits = 0;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) bits |= (m[i] != 0.f ? 1u : 0u) << i;
+                        drop_bits[(size_t)row * (Fp >> 3) + (ch >> 3)] = (unsigned char)bits;
+                    }
+                }
                 vec8<T> o;
                 vec8<float> gm;
                 gm.load(gamma + ch);                               // padded gamma: 0 beyond F
@@ -185,13 +201,19 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffmid_bwd1_kernel(const T* __re
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 T* __restrict__ du, float* __restrict__ part_dgamma,
                                                                 int M, int nseq, int F, int Fp, float p, unsigned long long seed,
-                                                                const unsigned long long* __restrict__ seed_dev) {
+                                                                const unsigned long long* __restrict__ seed_dev,
+                                                                const unsigned char* __restrict__ drop_bits) {
     if (seed_dev) seed += seed_dev[0] * 0x9E3779B97F4A7C15ull;
-    extern __shared__ __attribute__((aligned(16))) float dg_lds[];    // [Fp] dgamma + [4 waves][Fp] cached erf(gate / sqrt 2)
-    for (int c = threadIdx.x; c < Fp; c += FF_THREADS) dg_lds[c] = 0.f;
+    // [4 waves][Fp]: each wave's PRIVATE d(gamma) partial, updated with plain vector read-add-write (a lane always owns
+    // the same channels, so there is nothing to arbitrate).  The first version used one shared array with ds_add_f32 per
+    // element: LDS float atomics turned out to run at ~1 lane per clock (they cost 930 us per layer in the attention
+    // backward), i.e. ~0.5 ms of this kernel.  erf(gate) is recomputed in the second sweep instead of being cached, which
+    // keeps the LDS footprint at 4*Fp floats (3 workgroups per CU).
+    extern __shared__ __attribute__((aligned(16))) float dg_lds[];
+    for (int c = threadIdx.x; c < 4 * Fp; c += FF_THREADS) dg_lds[c] = 0.f;
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    float* el = dg_lds + (size_t)(1 + (threadIdx.x >> 6)) * Fp;
+    float* dgw = dg_lds + (size_t)(threadIdx.x >> 6) * Fp;
     const int ld = 2 * Fp;
     const int nwaves = gridDim.x * (FF_THREADS / 64);
     for (int row = blockIdx.x * (FF_THREADS / 64) + (threadIdx.x >> 6); row < M; row += nwaves) {
@@ -207,27 +229,31 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffmid_bwd1_kernel(const T* __re
                 conv_row<T>(h1, convw, row, t, ld, Fp + ch, ug);
                 vec8<T> d;
                 d.load(dh2 + (size_t)row * Fp + ch);
-                if (p > 0.f) dropout8(seed, (unsigned long long)row * Fp + ch, p, m);
-                float ev[8];
+                if (p > 0.f) {
+                    if (drop_bits) dropout8_from_bits(drop_bits[(size_t)row * (Fp >> 3) + (ch >> 3)], p, m);
+                    else dropout8(seed, (unsigned long long)row * Fp + ch, p, m);
+                }
                 vec8<float> gm;
                 gm.load(gamma + ch);
-                const int nch = Fp >> 3;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) ev[i] = fast_erf(ug[i] * 0.70710678118654752f);
-                ((float4*)(el + ch))[0] = make_float4(ev[0], ev[1], ev[2], ev[3]);
-                ((float4*)(el + ch))[1] = make_float4(ev[4], ev[5], ev[6], ev[7]);
+                float dgv[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
+                    dgv[i] = 0.f;
                     if (ch + i < F) {
-                        const float gh = (gelu_from_erf(ug[i], ev[i]) * ux[i] - mu) * rs;
+                        const float gh = (gelu_f(ug[i]) * ux[i] - mu) * rs;
                         float dyv = d.v[i];
                         if (p > 0.f) dyv *= m[i];
-                        atomicAdd(dg_lds + i * nch + (ch >> 3), dyv * gh);      // [8][Fp/8]: consecutive lanes -> consecutive banks
+                        dgv[i] = dyv * gh;
                         const float gy = dyv * gm.v[i];
                         s1 += gy;
                         s2 += gy * gh;
                     }
                 }
+                float4 a = ((float4*)(dgw + ch))[0], b = ((float4*)(dgw + ch))[1];
+                a.x += dgv[0]; a.y += dgv[1]; a.z += dgv[2]; a.w += dgv[3];
+                b.x += dgv[4]; b.y += dgv[5]; b.z += dgv[6]; b.w += dgv[7];
+                ((float4*)(dgw + ch))[0] = a;
+                ((float4*)(dgw + ch))[1] = b;
             }
         }
         const float m1 = wave_sum(s1) / (float)F;
@@ -241,11 +267,15 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffmid_bwd1_kernel(const T* __re
                 conv_row<T>(h1, convw, row, t, ld, Fp + ch, ug);
                 vec8<T> d, ox, og;
                 d.load(dh2 + (size_t)row * Fp + ch);
-                if (p > 0.f) dropout8(seed, (unsigned long long)row * Fp + ch, p, m);
+                if (p > 0.f) {
+                    if (drop_bits) dropout8_from_bits(drop_bits[(size_t)row * (Fp >> 3) + (ch >> 3)], p, m);
+                    else dropout8(seed, (unsigned long long)row * Fp + ch, p, m);
+                }
                 vec8<float> gm;
                 gm.load(gamma + ch);
-                const float4 ea = ((const float4*)(el + ch))[0], eb = ((const float4*)(el + ch))[1];
-                const float ev[8] = {ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eb.z, eb.w};
+                float ev[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ev[i] = fast_erf(ug[i] * 0.70710678118654752f);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     float dx = 0.f, dgt = 0.f;
@@ -267,7 +297,8 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffmid_bwd1_kernel(const T* __re
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < Fp; c += FF_THREADS) part_dgamma[(size_t)blockIdx.x * Fp + c] = dg_lds[(c & 7) * (Fp >> 3) + (c >> 3)];
+    for (int c = threadIdx.x; c < Fp; c += FF_THREADS)
+        part_dgamma[(size_t)blockIdx.x * Fp + c] = dg_lds[c] + dg_lds[Fp + c] + dg_lds[2 * Fp + c] + dg_lds[3 * Fp + c];
 }
 
 // Backward, stage 2 (conv^T): dh1[t] = w2 du[t] + w1 du[t+1] + w0 du[t+2] (within the sample), and
@@ -353,7 +384,7 @@ extern "C" long long omlm_ffmid_bwd_workspace_bytes(int F, int Fp) {
 
 extern "C" int omlm_ffmid_fwd(const void* h1, const float* convw, const float* gamma, void* h2, float* mean, float* rstd,
                               int M, int nseq, int F, int Fp, float eps, float p, unsigned long long seed,
-                              const unsigned long long* seed_dev, int dtype, void* stream) {
+                              const unsigned long long* seed_dev, unsigned char* drop_bits, int dtype, void* stream) {
     if (M <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(h1 && convw && gamma && h2 && mean && rstd, "null pointer");
     OMLM_CHECK_ARG(Fp % 8 == 0 && Fp >= F && Fp <= 8192 && (size_t)5 * Fp * sizeof(float) <= 160 * 1024, "Fp must be F rounded up to 8 and <= 8192");
@@ -369,7 +400,7 @@ extern "C" int omlm_ffmid_fwd(const void* h1, const float* convw, const float* g
         (void)hipFuncSetAttribute((const void*)ffmid_fwd_kernel<bf16_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)ffmid_fwd_kernel<bf16_t, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-#define FF_FWD(T_, MC_) hipLaunchKernelGGL((ffmid_fwd_kernel<T_, MC_>), grid, block, lds_fwd, st, (const T_*)h1, convw, gamma, (T_*)h2, mean, rstd, M, nseq, F, Fp, eps, p, seed, seed_dev)
+#define FF_FWD(T_, MC_) hipLaunchKernelGGL((ffmid_fwd_kernel<T_, MC_>), grid, block, lds_fwd, st, (const T_*)h1, convw, gamma, (T_*)h2, mean, rstd, M, nseq, F, Fp, eps, p, seed, seed_dev, drop_bits)
 #define FF_FWD_DISPATCH(T_) do { const int mc = (Fp / 8 + 63) / 64; \
         if (mc <= 2) FF_FWD(T_, 2); else if (mc <= 6) FF_FWD(T_, 6); else if (mc <= 8) FF_FWD(T_, 8); else FF_FWD(T_, 16); } while (0)
     if (dtype == 0) FF_FWD_DISPATCH(float); else FF_FWD_DISPATCH(bf16_t);
@@ -381,7 +412,7 @@ extern "C" int omlm_ffmid_fwd(const void* h1, const float* convw, const float* g
 extern "C" int omlm_ffmid_bwd(const void* dh2, const void* h1, const float* convw, const float* gamma, const float* mean,
                               const float* rstd, void* du_tmp, void* dh1, float* dgamma, float* dconv, float* workspace,
                               int M, int nseq, int F, int Fp, float p, unsigned long long seed,
-                              const unsigned long long* seed_dev, int dtype, void* stream) {
+                              const unsigned long long* seed_dev, const unsigned char* drop_bits, int dtype, void* stream) {
     if (M <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(dh2 && h1 && convw && gamma && mean && rstd && du_tmp && dh1 && workspace, "null pointer");
     OMLM_CHECK_ARG(Fp % 8 == 0 && Fp >= F && Fp <= 8192 && (size_t)5 * Fp * sizeof(float) <= 160 * 1024, "Fp must be F rounded up to 8 and <= 8192");
@@ -393,7 +424,7 @@ extern "C" int omlm_ffmid_bwd(const void* dh2, const void* h1, const float* conv
     const int b1 = rows4 < FF_BWD1_BLOCKS ? rows4 : FF_BWD1_BLOCKS;
     const int strips = M < FF_BWD2_STRIPS ? M : FF_BWD2_STRIPS;
     dim3 g2((2 * Fp / 8 + FF_THREADS - 1) / FF_THREADS, strips);
-    const size_t lds1 = (size_t)5 * Fp * sizeof(float);
+    const size_t lds1 = (size_t)4 * Fp * sizeof(float);
     if (lds1 > 48 * 1024) {
         (void)hipFuncSetAttribute((const void*)ffmid_bwd1_kernel<float, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)ffmid_bwd1_kernel<float, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -402,7 +433,7 @@ extern "C" int omlm_ffmid_bwd(const void* dh2, const void* h1, const float* conv
         (void)hipFuncSetAttribute((const void*)ffmid_bwd1_kernel<bf16_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)ffmid_bwd1_kernel<bf16_t, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-#define FF_B1(T_, MC_) hipLaunchKernelGGL((ffmid_bwd1_kernel<T_, MC_>), dim3(b1), dim3(FF_THREADS), lds1, st, (const T_*)dh2, (const T_*)h1, convw, gamma, mean, rstd, (T_*)du_tmp, part_g, M, nseq, F, Fp, p, seed, seed_dev)
+#define FF_B1(T_, MC_) hipLaunchKernelGGL((ffmid_bwd1_kernel<T_, MC_>), dim3(b1), dim3(FF_THREADS), lds1, st, (const T_*)dh2, (const T_*)h1, convw, gamma, mean, rstd, (T_*)du_tmp, part_g, M, nseq, F, Fp, p, seed, seed_dev, drop_bits)
 #define FF_B1_DISPATCH(T_) do { const int mc = (Fp / 8 + 63) / 64; \
         if (mc <= 2) FF_B1(T_, 2); else if (mc <= 6) FF_B1(T_, 6); else if (mc <= 8) FF_B1(T_, 8); else FF_B1(T_, 16); } while (0)
     if (dtype == 0) {

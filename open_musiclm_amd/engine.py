@@ -265,7 +265,7 @@ def relpos_backward(tr, n: int, saved, dtable: torch.Tensor):
 # ------------------------------------------------------------------------------------------------------
 class LayerSaved:
     __slots__ = ("x", "m1", "r1", "xn", "xc", "q_raw", "kv_raw", "q", "k", "v", "o", "lse",
-                 "x1", "m2", "r2", "xn2", "h1", "h2", "m3", "r3", "seed", "p")
+                 "x1", "m2", "r2", "xn2", "h1", "h2", "m3", "r3", "seed", "p", "drop_bits")
 
 
 def dropout_salt(tr, dev) -> torch.Tensor:
@@ -324,13 +324,16 @@ def trunk_forward(tr, pw: PreparedWeights, x: torch.Tensor, keymask: Optional[to
         m3 = torch.empty(M, device=dev); r3 = torch.empty(M, device=dev)
         p = float(ff.dropout_p) if training else 0.0
         seed = seeds[li] if (p > 0 and seeds is not None) else 0
-        ops.ffmid_fwd(h1, w["convw"], w["gamma_mid"], h2, m3, r3, N, F, Fp, p, seed, seed_dev=salt if p > 0 else None)
+        drop_bits = torch.empty(M, Fp // 8, dtype=torch.uint8, device=dev) if (p > 0 and save) else None
+        ops.ffmid_fwd(h1, w["convw"], w["gamma_mid"], h2, m3, r3, N, F, Fp, p, seed, seed_dev=salt if p > 0 else None,
+                      drop_bits=drop_bits)
         x2 = torch.empty(M, D, device=dev)
         ops.gemm(h2, w["W2p"], x2, M=M, N=D, K=Fp, Cin=x1)
         if save:
             sv.x, sv.m1, sv.r1, sv.xn, sv.xc = x, m1, r1, xn, xc
             sv.q_raw, sv.kv_raw, sv.q, sv.k, sv.v, sv.o, sv.lse = q_raw, kv_raw, q, k, v, o, lse
             sv.x1, sv.m2, sv.r2, sv.xn2, sv.h1, sv.h2, sv.m3, sv.r3, sv.seed, sv.p = x1, m2, r2, xn2, h1, h2, m3, r3, seed, p
+            sv.drop_bits = drop_bits
             saved_layers.append(sv)
         x = x2
     mf = torch.empty(M, device=dev); rf = torch.empty(M, device=dev)
@@ -373,7 +376,7 @@ def trunk_backward(tr, pw: PreparedWeights, saved, dy: torch.Tensor, B: int, N: 
         gconv = grad_of(ff.conv_param()).view(-1) if ff.conv_param() is not None else None
         ops.ffmid_bwd(dh2, sv.h1, w["convw"], w["gamma_mid"], sv.m3, sv.r3, du, dh1,
                       grad_of(ff.norm_mid.gamma), gconv, ws, N, F, Fp, sv.p, sv.seed,
-                      seed_dev=saved["salt"] if sv.p > 0 else None)
+                      seed_dev=saved["salt"] if sv.p > 0 else None, drop_bits=sv.drop_bits)
         del du, dh2
         dxn2 = torch.empty(M, D, device=dev)
         if "W1pT" in w: ops.gemm(dh1, w["W1pT"], dxn2, M=M, N=D, K=2 * Fp)

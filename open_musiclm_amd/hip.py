@@ -31,9 +31,9 @@ SIGNATURES = {
     "omlm_qk_norm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "omlm_mqa_attn_fwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, vp],
     "omlm_mqa_attn_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, vp],
-    "omlm_ffmid_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, u64, vp, i32, vp],
+    "omlm_ffmid_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, u64, vp, vp, i32, vp],
     "omlm_ffmid_bwd_workspace_bytes": [i32, i32],
-    "omlm_ffmid_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp, i32, vp],
+    "omlm_ffmid_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp, vp, i32, vp],
     "omlm_colsum_accumulate": [vp, vp, i32, i32, i32, vp],
     "omlm_embed_gather_fwd": [vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, vp],
     "omlm_embed_gather_bwd": [vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, f32, vp],

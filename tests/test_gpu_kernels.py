@@ -323,6 +323,23 @@ def test_ffmid_dropout_statistics_and_replay(ops, dev):
     ops.ffmid_fwd(h1, convw, gamma, e, mean, rstd, nseq, F, Fp, 0.1, 1234, seed_dev=salt)
     assert not torch.equal(d, a) and not torch.equal(d, e)
     assert abs(frac - 0.1) < 0.02 and scale_ok < 1e-5
+    # the stored keep-mask (1 bit per element) reproduces the regenerated one in the backward, bit for bit
+    bits = torch.empty(M, Fp // 8, dtype=torch.uint8, device=dev)
+    a2 = torch.empty(M, Fp, device=dev)
+    ops.ffmid_fwd(h1, convw, gamma, a2, mean, rstd, nseq, F, Fp, 0.1, 1234, drop_bits=bits)
+    assert torch.equal(a2, a)
+    unpacked = ((bits[:, :, None] >> torch.arange(8, device=dev, dtype=torch.uint8)) & 1).reshape(M, Fp).bool()
+    assert torch.equal(unpacked[:, :F], kept | (base[:, :F] == 0))
+    dh2 = torch.randn(M, Fp, generator=g).to(dev)
+    outs = []
+    for db in (None, bits):
+        du, dh1 = torch.empty(M, 2 * Fp, device=dev), torch.empty(M, 2 * Fp, device=dev)
+        dgamma, dconv = torch.zeros(F, device=dev), torch.zeros(2 * F * 3, device=dev)
+        ws = torch.empty(ops.ffmid_bwd_workspace_floats(F, Fp), device=dev)
+        ops.ffmid_bwd(dh2, h1, convw, gamma, mean, rstd, du, dh1, dgamma, dconv, ws, nseq, F, Fp, 0.1, 1234, drop_bits=db)
+        outs.append((dh1, dgamma, dconv))
+    assert torch.equal(outs[0][0], outs[1][0])                  # dh1: deterministic, must match bit for bit
+    assert relerr(outs[0][1], outs[1][1]) < 1e-5 and relerr(outs[0][2], outs[1][2]) < 1e-5   # atomically reduced partials
 
 
 def test_embed_gather_fwd_bwd(ops, dev):
