@@ -244,23 +244,25 @@ def main():
                            "launches": len(rec) // 2, "gemm_ms_per_step": round(tot_ms / 2, 3),
                            "large_gemm_achieved": round(sum(f for _, f in big) / (sum(t for t, _ in big) * 1e-3) / 1e12, 2) if big else None}
 
-        # ---- AR decode (reference-style full re-forward per id, open_musiclm.py:299-319), B = 1
+        # ---- AR decode, B = 1: KV-cached single-row steps (decode.py) and, for comparison, the reference's own scheme
+        #      (full re-forward per id, open_musiclm.py:299-319).  Rates include the prompt prefill.
         if not args.no_decode:
             stage.eval()
             g = torch.Generator().manual_seed(99)
             clap = torch.randint(0, 1024, (1, 12, 1), generator=g).to(dev)
             sem = torch.randint(0, 1024, (1, 199), generator=g).to(dev)
-            steps_new = max(args.decode_ids // 3, 1)
             res = {}
-            for label, primed in (("empty_context", 0), ("full_context", 300 - steps_new)):
-                prime = torch.randint(0, 1024, (1, primed, 3), generator=g).to(dev) if primed else None
-                tgt = primed + steps_new
-                stage.generate(clap_token_ids=clap, semantic_token_ids=sem, coarse_token_ids=prime, max_time_steps=primed + 1)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                stage.generate(clap_token_ids=clap, semantic_token_ids=sem, coarse_token_ids=prime, max_time_steps=tgt)
-                torch.cuda.synchronize()
-                res[label] = round(steps_new * 3 / (time.perf_counter() - t1), 2)
+            for mode, use_cache, steps_new in (("kv_cache", True, 100), ("reforward", False, max(args.decode_ids // 3, 1))):
+                for label, primed in (("empty_context", 0), ("full_context", 300 - steps_new)):
+                    prime = torch.randint(0, 1024, (1, primed, 3), generator=g).to(dev) if primed else None
+                    tgt = primed + steps_new
+                    kw = dict(clap_token_ids=clap, semantic_token_ids=sem, coarse_token_ids=prime, use_cache=use_cache)
+                    stage.generate(max_time_steps=primed + 2, **kw)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    stage.generate(max_time_steps=tgt, **kw)
+                    torch.cuda.synchronize()
+                    res[f"{mode}_{label}"] = round(steps_new * 3 / (time.perf_counter() - t1), 2)
             out["ar_tokens_per_sec"] = res
             progress(f"decode {res}")
             stage.train()

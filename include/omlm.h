@@ -128,6 +128,34 @@ int omlm_nearest_centroid(const float* x, const float* centroids_T, int* indices
 int omlm_sample_topk_gumbel(const float* logits, const float* uniform, long long* out, int B, int V, int ld,
                             int k, float temperature, int forbid_last, void* stream);
 
+/* KV-cached AR decode step: ONE new row (index *pos_dev) per sample through all L layers and the logit head of the quantizer
+ * that row predicts -- replaces the reference's full re-forward per sampled id (wrapper.generate, open_musiclm.py:301-321;
+ * the trunk is strictly causal, so the logits are the same).  State owned by the caller, all fp32:
+ *   Kc/Vc[l]  [B, Nmax, 64]   l2-normalised keys / values of rows < pos (row `pos` is appended by this call)
+ *   hist[l]   [B, 2, 2*Fp]    FF-in outputs of rows pos-2, pos-1 (conv state; advanced by this call)
+ * Pointer-array members are HOST arrays of L device pointers.  w_dtype 0: fp32 weights, 1: bf16 operand copies (then
+ * round_bf16 = 1 rounds the activations the batched path keeps in bf16).  W1p [2*Fp, D] / W2p [D, Fp] / convw [3, 2*Fp] /
+ * mid_gamma [Fp] are the padded layouts of omlm_ffmid_fwd.  emb_table (optional): x = emb_table[ids[b] + emb_row_offset]
+ * first (open_musiclm.py:123-134); otherwise x must already hold the new row.  head_W (optional) [V1, D]: logits
+ * [B, ldV] = LN(x_L) head_W^T.  B <= 8. */
+typedef struct omlm_decode_args {
+    int B, D, H, L, F, Fp, Nmax, w_dtype, round_bf16, nsplit;     /* nsplit >= ceil(Nmax / 64): attention key ranges */
+    float eps, scale;
+    const int* pos_dev;                                            /* DEVICE int: index of the row computed by this step */
+    const void* const* Wq; const void* const* Wkv; const void* const* Wo; const void* const* W1p; const void* const* W2p;
+    const float* const* attn_gamma; const float* const* q_scale; const float* const* k_scale;
+    const float* const* ffin_gamma; const float* const* convw; const float* const* mid_gamma;
+    float* const* Kc; float* const* Vc; float* const* hist;
+    const float* bias_table; int bias_ld;
+    const float* final_gamma; const void* head_W; int V1; int ldV;
+    const float* emb_table; long long emb_row_offset; long long emb_rows;
+    float* x; float* x1; float* q; float* parts; float* u; float* logits;   /* scratch: parts [B, nsplit, H, 66] */
+} omlm_decode_args;
+int omlm_decode_step(const omlm_decode_args* args, const long long* ids, void* stream);
+/* *pos_dev += 1, *step_dev += 1 (either may be null): keeps the row / sampler-step counters on the device so that a
+ * captured step can be replayed. */
+int omlm_decode_advance(int* pos_dev, int* step_dev, void* stream);
+
 /* hardware probe (tests only): raw ds_read_b64_tr_b16 result for a linear LDS image, 64 lanes x 4 int16 */
 int omlm_probe_tr16(short* out, void* stream);
 

@@ -1,0 +1,376 @@
+// KV-cached autoregressive decode step of the TokenConditionedTransformer trunk.
+//
+// The reference samples by re-running the full causal forward over the grown sequence for every new id
+// (open_musiclm.py:301-321: no KV cache).  Every op of the trunk is causal -- attention (transformer.py:303-331), the
+// depthwise conv of ConvFeedForward (left pad 2, :122-137), LayerNorm per token -- so row p depends on rows <= p only,
+// and the same logits are obtained by computing ONE new row per step against
+//   * the l2-normalised keys / values of rows < p          (K/V cache, fp32, [B, Nmax, 64] per layer), and
+//   * the FF-in outputs of rows p-2, p-1                    (conv state,  fp32, [B, 2, 2*Fp] per layer).
+// One step is weight-bandwidth and latency bound (all 91.6 M parameters are read once for up to 8 samples), so:
+//   * the projections are skinny GEMVs on the vector ALUs, 16 weight rows per workgroup (hundreds of workgroups keep
+//     enough loads in flight); the B activation rows sit in LDS and LayerNorm is recomputed per workgroup;
+//   * attention is split over 64-key ranges (the single K/V head is read once for all heads: MQA) into partial
+//     (max, sum, o) triples that the out-projection kernel combines while staging its activation;
+//   * the row index lives in DEVICE memory (*pos_dev), grids and LDS sizes do not depend on it, so a whole step
+//     (31 launches + sampler + advance) can be captured once into a HIP graph and replayed per sampled id.
+//
+// TW = bf16_t: weights are the bf16 operand copies ("bf16" mode; activations that the batched path rounds to bf16 before
+// its GEMMs are rounded here too, so both paths see the same operands); TW = float: fp32 weights, fp32 FMA chains.
+#include "common.h"
+
+#define DEC_T 256
+#define DEC_BMAX 8
+#define DEC_ROWS 16            // weight rows per workgroup (4 per wave)
+#define DEC_KS 64              // keys per attention split
+#define DEC_PART 66            // floats per (split, head) partial: max, sum, o[64]
+
+struct omlm_decode_args {
+    int B, D, H, L, F, Fp, Nmax, w_dtype, round_bf16, nsplit;
+    float eps, scale;
+    const int* pos_dev;
+    const void* const* Wq; const void* const* Wkv; const void* const* Wo; const void* const* W1p; const void* const* W2p;
+    const float* const* attn_gamma; const float* const* q_scale; const float* const* k_scale;
+    const float* const* ffin_gamma; const float* const* convw; const float* const* mid_gamma;
+    float* const* Kc; float* const* Vc; float* const* hist;
+    const float* bias_table; int bias_ld;
+    const float* final_gamma; const void* head_W; int V1; int ldV;
+    const float* emb_table; long long emb_row_offset; long long emb_rows;
+    float* x; float* x1; float* q; float* parts; float* u; float* logits;
+};
+
+__device__ __forceinline__ float round_if(float v, int on) { return on ? (float)(bf16_t)v : v; }
+
+__device__ __forceinline__ void load_w8(const float* p, float* w) {
+    const float4 a = ((const float4*)p)[0], b = ((const float4*)p)[1];
+    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+}
+__device__ __forceinline__ void load_w8(const bf16_t* p, float* w) {
+    const u32x4 a = *(const u32x4*)p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { w[2 * i] = bf16_lo_to_f(a[i]); w[2 * i + 1] = bf16_hi_to_f(a[i]); }
+}
+
+// vals[r * DEC_BMAX + b] = sum_k W[r, k] * xs[b * Kp + k]  for r < nrows <= 16 (weight rows of pitch ldw), b < B.
+// Each wave owns 4 rows (4 independent load streams per lane); a lane owns the 8-element chunks lane, lane+64, ...
+template <typename TW>
+__device__ void wg_gemv(const TW* __restrict__ W, long long ldw, int K, int nrows, const float* xs, int Kp, int B, float* vals) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nch = K >> 3;
+    const int r0 = wave * 4;
+    if (r0 >= nrows) return;
+    float acc[4][DEC_BMAX];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int b = 0; b < DEC_BMAX; ++b) acc[i][b] = 0.f;
+    const TW* wr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wr[i] = W + (long long)min(r0 + i, nrows - 1) * ldw;     // clamped rows are dropped below
+#pragma unroll 2
+    for (int c = lane; c < nch; c += 64) {
+        float w[4][8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_w8(wr[i] + c * 8, w[i]);
+#pragma unroll
+        for (int b = 0; b < DEC_BMAX; ++b) {
+            if (b < B) {
+                const float4 x0 = *(const float4*)(xs + (size_t)b * Kp + c * 8), x1 = *(const float4*)(xs + (size_t)b * Kp + c * 8 + 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[i][b] += w[i][0] * x0.x + w[i][1] * x0.y + w[i][2] * x0.z + w[i][3] * x0.w +
+                                 w[i][4] * x1.x + w[i][5] * x1.y + w[i][6] * x1.z + w[i][7] * x1.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int b = 0; b < DEC_BMAX; ++b) {
+            if (b < B) {
+                const float s = wave_sum(acc[i][b]);
+                if (lane == 0 && r0 + i < nrows) vals[(r0 + i) * DEC_BMAX + b] = s;
+            }
+        }
+}
+
+// xs[b][0..K) <- in[b][0..K); optional LayerNorm over the first Kstat entries (gamma has K entries, 0 in any padding)
+__device__ void stage_activation(const float* __restrict__ in, int ldin, int K, int Kstat, const float* __restrict__ gamma, float eps,
+                                 int B, int round_bf16, float* xs, float* red) {
+    for (int b = 0; b < B; ++b) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < K; i += DEC_T) {
+            const float v = in[(size_t)b * ldin + i];
+            xs[(size_t)b * K + i] = v;
+            if (i < Kstat) s += v;
+        }
+        if (gamma) {
+            const float mean = block_sum<DEC_T>(s, red) / (float)Kstat;
+            float q = 0.f;
+            for (int i = threadIdx.x; i < Kstat; i += DEC_T) { const float d = xs[(size_t)b * K + i] - mean; q += d * d; }
+            const float rstd = rsqrtf(block_sum<DEC_T>(q, red) / (float)Kstat + eps);
+            for (int i = threadIdx.x; i < K; i += DEC_T)
+                xs[(size_t)b * K + i] = round_if((xs[(size_t)b * K + i] - mean) * rstd * gamma[i], round_bf16);
+        } else if (round_bf16) {
+            for (int i = threadIdx.x; i < K; i += DEC_T) xs[(size_t)b * K + i] = round_if(xs[(size_t)b * K + i], 1);
+        }
+    }
+    __syncthreads();
+}
+
+// xs[b][h*64 + d] <- softmax-combine of the attention partials of the splits covering keys 0..pos
+__device__ void stage_attention(const float* __restrict__ parts, int nsplit, int H, int pos, int B, int round_bf16, float* xs) {
+    const int ns = pos / DEC_KS + 1;
+    for (int idx = threadIdx.x; idx < B * H * 64; idx += DEC_T) {
+        const int b = idx / (H * 64), hd = idx - b * H * 64, h = hd >> 6, d = hd & 63;
+        const float* pb = parts + ((size_t)b * nsplit * H + h) * DEC_PART;
+        float m = -3.0e38f;
+        for (int s = 0; s < ns; ++s) m = fmaxf(m, pb[(size_t)s * H * DEC_PART]);
+        float l = 0.f, o = 0.f;
+        for (int s = 0; s < ns; ++s) {
+            const float* p = pb + (size_t)s * H * DEC_PART;
+            const float w = __expf(p[0] - m);
+            l += w * p[1];
+            o += w * p[2 + d];
+        }
+        xs[idx] = round_if(o / l, round_bf16);
+    }
+    __syncthreads();
+}
+
+// ---- embedding gather of the ids sampled in the previous step (open_musiclm.py:123-134: id + quantizer offset) ----
+__global__ __launch_bounds__(DEC_T) void dec_embed_kernel(const long long* __restrict__ ids, const float* __restrict__ table,
+                                                         long long row_off, long long rows, float* __restrict__ x, int D) {
+    const int b = blockIdx.x;
+    long long r = ids[b] + row_off;
+    r = r < 0 ? 0 : (r >= rows ? rows - 1 : r);
+    for (int i = threadIdx.x; i < D; i += DEC_T) x[(size_t)b * D + i] = table[r * D + i];
+}
+
+// ---- A: raw projections of the new row: q_raw = LN(x) Wq^T -> q;  [k_raw | v] = x Wkv^T -> cache row pos ----
+// (transformer.py:228,250-254: keys / values are projected from the UN-normalised residual.)  The l2 normalisations
+// (:265-271) happen where the 64 dims of a head meet again: in the attention kernel.
+template <typename TW>
+__global__ __launch_bounds__(DEC_T) void dec_qkv_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                       const TW* __restrict__ Wq, const TW* __restrict__ Wkv,
+                                                       float* __restrict__ q, float* __restrict__ Kc, float* __restrict__ Vc,
+                                                       int B, int D, int H, int Nmax, const int* __restrict__ pos_dev, float eps,
+                                                       int round_bf16) {
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    float* xs = dsm;                                   // [B][D]
+    float* vals = xs + (size_t)B * D;                  // [16][DEC_BMAX]
+    float* red = vals + DEC_ROWS * DEC_BMAX;           // [8]
+    const int pos = *pos_dev;
+    const int n0 = blockIdx.x * DEC_ROWS, HD = H * 64;
+    const bool isq = n0 < HD;
+    stage_activation(x, D, D, D, isq ? gamma : nullptr, eps, B, round_bf16, xs, red);
+    const TW* W = isq ? Wq + (size_t)n0 * D : Wkv + (size_t)(n0 - HD) * D;
+    wg_gemv<TW>(W, D, D, DEC_ROWS, xs, D, B, vals);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < B * DEC_ROWS; idx += DEC_T) {
+        const int b = idx / DEC_ROWS, r = idx - b * DEC_ROWS, n = n0 + r;
+        const float v = vals[r * DEC_BMAX + b];
+        if (isq) q[(size_t)b * HD + n] = v;
+        else if (n < HD + 64) Kc[((size_t)b * Nmax + pos) * 64 + (n - HD)] = v;                       // raw: normalised by dec_attn
+        else Vc[((size_t)b * Nmax + pos) * 64 + (n - HD - 64)] = round_if(v, round_bf16);
+    }
+}
+
+// ---- B1: attention partials of one 64-key range for ALL heads (the single K/V head is read once) ----
+//   part[b][s][h] = { m = max_j s_j,  l = sum_j e^(s_j - m),  o[d] = sum_j e^(s_j - m) v_j[d] },  s_j = scale <q_h, k_j> + bias[pos - j, h]
+// The split that holds row `pos` finds it un-normalised (written by dec_qkv this step): it l2-normalises it, uses it and
+// stores it back, so the cache holds final keys from then on.  q is l2-normalised here as well.
+__global__ __launch_bounds__(DEC_T) void dec_attn_kernel(const float* __restrict__ q, float* __restrict__ Kc,
+                                                        const float* __restrict__ Vc, const float* __restrict__ q_scale,
+                                                        const float* __restrict__ k_scale, const float* __restrict__ bias, int bias_ld,
+                                                        float* __restrict__ parts, int H, int Nmax, int nsplit,
+                                                        const int* __restrict__ pos_dev, float scale, int round_bf16) {
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    const int pos = *pos_dev;
+    const int s = blockIdx.x, b = blockIdx.y;
+    const int j0 = s * DEC_KS;
+    if (j0 > pos) return;
+    const int nk = min(DEC_KS, pos + 1 - j0);
+    float* Ks = dsm;                        // [64][65]
+    float* Vs = Ks + 64 * 65;               // [64][64]
+    float* qn = Vs + 64 * 64;               // [H][64]
+    float* sc = qn + H * 64;                // [H][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int h = wave; h < H; h += 4) {                                   // q: l2norm * q_scale per head (utils.py:68-69)
+        const float v = q[(size_t)b * H * 64 + h * 64 + lane];
+        const float nrm = fmaxf(sqrtf(wave_sum(v * v)), 1e-12f);
+        qn[h * 64 + lane] = round_if(v / nrm * q_scale[lane], round_bf16);
+    }
+    float* Kb = Kc + ((size_t)b * Nmax + j0) * 64;
+    const float* Vb = Vc + ((size_t)b * Nmax + j0) * 64;
+    for (int idx = threadIdx.x; idx < nk * 16; idx += DEC_T) {            // coalesced float4 rows
+        const int j = idx >> 4, c = idx & 15;
+        const float4 kk = ((const float4*)(Kb + (size_t)j * 64))[c];
+        const float4 vv = ((const float4*)(Vb + (size_t)j * 64))[c];
+        Ks[j * 65 + 4 * c] = kk.x; Ks[j * 65 + 4 * c + 1] = kk.y; Ks[j * 65 + 4 * c + 2] = kk.z; Ks[j * 65 + 4 * c + 3] = kk.w;
+        *(float4*)(Vs + j * 64 + 4 * c) = vv;
+    }
+    __syncthreads();
+    if (pos - j0 < DEC_KS && wave == 0) {                                 // the new key: normalise once, keep it in the cache
+        const int j = pos - j0;
+        const float v = Ks[j * 65 + lane];
+        const float nrm = fmaxf(sqrtf(wave_sum(v * v)), 1e-12f);
+        const float kn = round_if(v / nrm * k_scale[lane], round_bf16);
+        Ks[j * 65 + lane] = kn;
+        Kb[(size_t)j * 64 + lane] = kn;
+    }
+    __syncthreads();
+    for (int h = wave; h < H; h += 4) {                                   // one wave per head: lane = key
+        float dot = 0.f;
+        if (lane < nk) {
+#pragma unroll 16
+            for (int d = 0; d < 64; ++d) dot += qn[h * 64 + d] * Ks[lane * 65 + d];
+        }
+        const float sv = lane < nk ? dot * scale + (bias ? bias[(size_t)(pos - j0 - lane) * bias_ld + h] : 0.f) : -3.0e38f;
+        const float m = wave_max(sv);
+        const float p = lane < nk ? __expf(sv - m) : 0.f;
+        const float l = wave_sum(p);
+        sc[h * 64 + lane] = p;
+        if (lane == 0) {
+            float* pp = parts + (((size_t)b * nsplit + s) * H + h) * DEC_PART;
+            pp[0] = m; pp[1] = l;
+        }
+    }
+    __syncthreads();
+    for (int h = wave; h < H; h += 4) {                                   // lane = dim
+        float acc = 0.f;
+        for (int j = 0; j < nk; ++j) acc += sc[h * 64 + j] * Vs[j * 64 + lane];
+        parts[(((size_t)b * nsplit + s) * H + h) * DEC_PART + 2 + lane] = acc;
+    }
+}
+
+// ---- B2: out[b, n] = sum_k act[b, k] W[n, k] (+ res[b, n]); 16 output features per workgroup.
+//      act = LN?(in[b, :]) or (parts != null) the combined attention output ----
+template <typename TW>
+__global__ __launch_bounds__(DEC_T) void dec_gemv_kernel(const float* __restrict__ in, int ldin, const float* __restrict__ gamma,
+                                                        int Kstat, float eps, const float* __restrict__ parts, int nsplit, int H,
+                                                        const int* __restrict__ pos_dev, const TW* __restrict__ W, long long ldw,
+                                                        int K, int Nout, const float* __restrict__ res, int ldres,
+                                                        float* __restrict__ out, int ldout, int B, int round_bf16) {
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    float* xs = dsm;
+    float* vals = xs + (size_t)B * K;
+    float* red = vals + DEC_ROWS * DEC_BMAX;
+    if (parts) stage_attention(parts, nsplit, H, *pos_dev, B, round_bf16, xs);
+    else stage_activation(in, ldin, K, Kstat, gamma, eps, B, round_bf16, xs, red);
+    const int n0 = blockIdx.x * DEC_ROWS;
+    const int rows = min(DEC_ROWS, Nout - n0);
+    wg_gemv<TW>(W + (size_t)n0 * ldw, ldw, K, rows, xs, K, B, vals);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < B * rows; idx += DEC_T) {
+        const int b = idx / rows, r = idx - b * rows;
+        float v = vals[r * DEC_BMAX + b];
+        if (res) v += res[(size_t)b * ldres + n0 + r];
+        out[(size_t)b * ldout + n0 + r] = v;
+    }
+}
+
+// erf by Abramowitz-Stegun 7.1.26, identical to ffmid.hip (the batched path's GELU)
+__device__ __forceinline__ float dec_gelu(float x) {
+    const float z = x * 0.70710678118654752f, ax = fabsf(z);
+    const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+    const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+    return 0.5f * x * (1.0f + copysignf(1.0f - poly * __expf(-ax * ax), z));
+}
+
+// ---- C1: h1 = LN(x1) W1^T (value + gate rows of 8 channels), causal depthwise conv over (p-2, p-1, p) with the conv
+//          state, GEGLU; u[b, c] = value_conv * gelu(gate_conv); conv state advanced ----
+template <typename TW>
+__global__ __launch_bounds__(DEC_T) void dec_ffin_kernel(const float* __restrict__ x1, const float* __restrict__ gamma,
+                                                        const TW* __restrict__ W1p, const float* __restrict__ convw,
+                                                        float* __restrict__ hist, float* __restrict__ u,
+                                                        int B, int D, int Fp, float eps, int round_bf16) {
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    float* xs = dsm;
+    float* vals = xs + (size_t)B * D;
+    float* red = vals + DEC_ROWS * DEC_BMAX;
+    stage_activation(x1, D, D, D, gamma, eps, B, round_bf16, xs, red);
+    const int c0 = blockIdx.x * 8;
+    // waves 0,1 -> the 8 value rows, waves 2,3 -> the 8 gate rows
+    const int wave = threadIdx.x >> 6;
+    {
+        const TW* W = W1p + (size_t)((wave < 2 ? c0 : Fp + c0 - 8)) * D;   // row r of this call = W[r]: gate rows start at r = 8
+        wg_gemv<TW>(W, D, D, DEC_ROWS, xs, D, B, vals);
+    }
+    __syncthreads();
+    const int ld = 2 * Fp;
+    for (int idx = threadIdx.x; idx < B * 8; idx += DEC_T) {
+        const int b = idx >> 3, c = idx & 7, col = c0 + c;
+        const float hv = round_if(vals[c * DEC_BMAX + b], round_bf16);
+        const float hg = round_if(vals[(8 + c) * DEC_BMAX + b], round_bf16);
+        float* h0 = hist + (size_t)(b * 2) * ld;        // row p-2
+        float* h1 = h0 + ld;                             // row p-1
+        const float uv = convw[col] * h0[col] + convw[ld + col] * h1[col] + convw[2 * (size_t)ld + col] * hv;
+        const float ug = convw[Fp + col] * h0[Fp + col] + convw[ld + Fp + col] * h1[Fp + col] + convw[2 * (size_t)ld + Fp + col] * hg;
+        u[(size_t)b * Fp + col] = dec_gelu(ug) * uv;
+        h0[col] = h1[col];       h0[Fp + col] = h1[Fp + col];
+        h1[col] = hv;            h1[Fp + col] = hg;
+    }
+}
+
+// ---- end of step: the row index (and the sampler's step counter) move on, on the device ----
+__global__ void dec_advance_kernel(int* pos_dev, int* step_dev) {
+    if (threadIdx.x == 0) { if (pos_dev) pos_dev[0] += 1; if (step_dev) step_dev[0] += 1; }
+}
+extern "C" int omlm_decode_advance(int* pos_dev, int* step_dev, void* stream) {
+    hipLaunchKernelGGL(dec_advance_kernel, dim3(1), dim3(64), 0, as_stream(stream), pos_dev, step_dev);
+    return omlm_post_launch("omlm_decode_advance");
+}
+
+template <typename TW>
+static int decode_step_t(const omlm_decode_args& a, const long long* ids, hipStream_t st) {
+    const int B = a.B, D = a.D, H = a.H, Fp = a.Fp;
+    const size_t tail = (DEC_ROWS * DEC_BMAX + 16) * sizeof(float);
+    const size_t lds_d = (size_t)B * D * sizeof(float) + tail;
+    const size_t lds_hd = (size_t)B * H * 64 * sizeof(float) + tail;
+    const size_t lds_fp = (size_t)B * Fp * sizeof(float) + tail;
+    const size_t lds_at = (size_t)(64 * 65 + 64 * 64 + 2 * H * 64) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)dec_gemv_kernel<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)dec_qkv_kernel<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)dec_ffin_kernel<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)dec_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    const int HD = H * 64;
+    if (a.emb_table)
+        hipLaunchKernelGGL(dec_embed_kernel, dim3(B), dim3(DEC_T), 0, st, ids, a.emb_table, a.emb_row_offset, a.emb_rows, a.x, D);
+    for (int l = 0; l < a.L; ++l) {
+        hipLaunchKernelGGL((dec_qkv_kernel<TW>), dim3((HD + 128) / DEC_ROWS), dim3(DEC_T), lds_d, st, a.x, a.attn_gamma[l],
+                           (const TW*)a.Wq[l], (const TW*)a.Wkv[l], a.q, a.Kc[l], a.Vc[l], B, D, H, a.Nmax, a.pos_dev, a.eps, a.round_bf16);
+        hipLaunchKernelGGL(dec_attn_kernel, dim3(a.nsplit, B), dim3(DEC_T), lds_at, st, a.q, a.Kc[l], a.Vc[l], a.q_scale[l], a.k_scale[l],
+                           a.bias_table, a.bias_ld, a.parts, H, a.Nmax, a.nsplit, a.pos_dev, a.scale, a.round_bf16);
+        hipLaunchKernelGGL((dec_gemv_kernel<TW>), dim3((D + DEC_ROWS - 1) / DEC_ROWS), dim3(DEC_T), lds_hd, st, (const float*)nullptr, 0,
+                           (const float*)nullptr, 0, a.eps, a.parts, a.nsplit, H, a.pos_dev, (const TW*)a.Wo[l], (long long)HD, HD, D,
+                           a.x, D, a.x1, D, B, a.round_bf16);
+        hipLaunchKernelGGL((dec_ffin_kernel<TW>), dim3(Fp / 8), dim3(DEC_T), lds_d, st, a.x1, a.ffin_gamma[l], (const TW*)a.W1p[l],
+                           a.convw[l], a.hist[l], a.u, B, D, Fp, a.eps, a.round_bf16);
+        hipLaunchKernelGGL((dec_gemv_kernel<TW>), dim3((D + DEC_ROWS - 1) / DEC_ROWS), dim3(DEC_T), lds_fp, st, a.u, Fp, a.mid_gamma[l],
+                           a.F, a.eps, (const float*)nullptr, 0, 0, (const int*)nullptr, (const TW*)a.W2p[l], (long long)Fp, Fp, D,
+                           a.x1, D, a.x, D, B, a.round_bf16);
+    }
+    if (a.head_W)
+        hipLaunchKernelGGL((dec_gemv_kernel<TW>), dim3((a.V1 + DEC_ROWS - 1) / DEC_ROWS), dim3(DEC_T), lds_d, st, a.x, D, a.final_gamma,
+                           D, a.eps, (const float*)nullptr, 0, 0, (const int*)nullptr, (const TW*)a.head_W, (long long)D, D, a.V1,
+                           (const float*)nullptr, 0, a.logits, a.ldV, B, a.round_bf16);
+    return omlm_post_launch("omlm_decode_step");
+}
+
+// One decode step for the row at index *pos_dev (see include/omlm.h).  ids: [B] int64 sampled in the previous step (used
+// when a->emb_table is set; otherwise a->x already holds the new row's embedding).  Does NOT advance *pos_dev.
+extern "C" int omlm_decode_step(const omlm_decode_args* a, const long long* ids, void* stream) {
+    OMLM_CHECK_ARG(a != nullptr, "null argument block");
+    OMLM_CHECK_ARG(a->B >= 1 && a->B <= DEC_BMAX, "decode batch must be 1..8 (use the batched forward beyond that)");
+    OMLM_CHECK_ARG(a->D % 8 == 0 && a->Fp % 8 == 0 && a->pos_dev && a->parts, "decode geometry");
+    OMLM_CHECK_ARG(a->H >= 1 && a->H <= 16 && (a->H * 64 + 128) % DEC_ROWS == 0, "heads");
+    OMLM_CHECK_ARG(a->nsplit * DEC_KS >= a->Nmax, "nsplit must cover Nmax keys");
+    OMLM_CHECK_ARG((size_t)a->B * a->Fp * sizeof(float) + 1024 <= 150 * 1024, "B * Fp exceeds the LDS budget");
+    OMLM_CHECK_ARG(!a->emb_table || ids, "ids required with an embedding table");
+    if (a->w_dtype == 0) return decode_step_t<float>(*a, ids, as_stream(stream));
+    return decode_step_t<bf16_t>(*a, ids, as_stream(stream));
+}

@@ -611,8 +611,7 @@ extern "C" int omlm_gemm(const void* A, const void* B, void* C, const float* Cin
     const bool need_kmap = (a_kmajor && a_map) || (b_kmajor && b_map);
     if (in_dtype == 1 && !need_kmap) {
         if (force && force[0]) { if (!strcmp(force, "256x256")) { bm = 256; bn = 256; } else if (!strcmp(force, "256x128")) { bm = 256; bn = 128; } }
-        else if (M >= 1024 && N >= 1536) { bm = 256; bn = 256; }
-        else if (a_kmajor && b_kmajor && M >= 1024 && N >= 1024) { bm = 256; bn = 256; }   // weight gradients: measured 1.1 vs 1.4 ms
+        else if (M >= 1024 && N >= 1024) { bm = 256; bn = 256; }   // measured (probe, N = 1024): 256x256 514 us, 128x128 543, 256x128 657
         else if (M >= 2048 && N >= 256) { bm = 256; bn = 128; }
         else if (N >= 2048 && M >= 256) { bm = 256; bn = 256; }
     }

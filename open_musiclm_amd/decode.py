@@ -1,0 +1,152 @@
+"""KV-cached autoregressive decoding for TokenConditionedTransformer (host side of csrc/decode.hip).
+
+The reference's ``generate`` (open_musiclm.py:253-326) re-runs the whole causal forward for every sampled id.  Because
+every op of the trunk is causal, the same logits come out of computing one new row per step against a key/value cache
+and the two-row state of the causal depthwise convolution -- that is what :class:`CachedDecoder` does:
+
+    dec = CachedDecoder(model, batch, max_rows)
+    logits = dec.prefill(cond_ids + [sampled_so_far])      # batched forward over the prompt rows, fills the caches
+    logits = dec.step(new_ids, k)                           # one row: ids sampled from `logits`, k = index of that id
+
+``step`` is one call into libomlm_hip.so (32 kernel launches: embedding gather, 5 per layer, logit head) plus the
+counter advance; the row index lives on the device so that a step can be captured into a HIP graph.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Sequence
+
+import torch
+
+from . import engine, hip, ops
+from .hip import call, ptr, stream_ptr
+
+MAX_DECODE_BATCH = 8
+
+_PTRS = ["Wq", "Wkv", "Wo", "W1p", "W2p", "attn_gamma", "q_scale", "k_scale", "ffin_gamma", "convw", "mid_gamma",
+         "Kc", "Vc", "hist"]
+
+
+class DecodeArgs(C.Structure):
+    """Mirror of ``omlm_decode_args`` (include/omlm.h)."""
+    _fields_ = ([(n, C.c_int) for n in ("B", "D", "H", "L", "F", "Fp", "Nmax", "w_dtype", "round_bf16", "nsplit")] +
+                [("eps", C.c_float), ("scale", C.c_float), ("pos_dev", C.c_void_p)] +
+                [(n, C.POINTER(C.c_void_p)) for n in _PTRS] +
+                [("bias_table", C.c_void_p), ("bias_ld", C.c_int),
+                 ("final_gamma", C.c_void_p), ("head_W", C.c_void_p), ("V1", C.c_int), ("ldV", C.c_int),
+                 ("emb_table", C.c_void_p), ("emb_row_offset", C.c_longlong), ("emb_rows", C.c_longlong)] +
+                [(n, C.c_void_p) for n in ("x", "x1", "q", "parts", "u", "logits")])
+
+
+def supports(model, batch: int) -> bool:
+    tr = model.transformer
+    return batch <= MAX_DECODE_BATCH and not model.use_absolute_position_embeddings and tr.non_causal_prefix_size == 0
+
+
+class CachedDecoder:
+    def __init__(self, model, batch: int, max_rows: int, precision: str):
+        if batch > MAX_DECODE_BATCH:
+            raise ValueError(f"cached decode handles up to {MAX_DECODE_BATCH} samples per call; got {batch}")
+        self.model, self.B, self.Nmax, self.precision = model, batch, int(max_rows), precision
+        tr = model.transformer
+        dev = model.start_tokens[0].device
+        hip.require_gpu(model.start_tokens[0], "model parameters")
+        self.pw = engine.prepared_weights(model, precision)
+        self.T = self.pw.T
+        L, D, H = len(tr.layers), tr.dim, tr.heads
+        F, Fp = self.pw.layers[0]["F"], self.pw.layers[0]["Fp"]
+        self.L, self.D, self.H, self.F, self.Fp = L, D, H, F, Fp
+        B, Nmax = self.B, self.Nmax
+        f32 = dict(device=dev, dtype=torch.float32)
+        self.Kc = [torch.zeros(B, Nmax, engine.DIM_HEAD, **f32) for _ in range(L)]
+        self.Vc = [torch.zeros(B, Nmax, engine.DIM_HEAD, **f32) for _ in range(L)]
+        self.hist = [torch.zeros(B, 2, 2 * Fp, **f32) for _ in range(L)]
+        self.x, self.x1 = torch.empty(B, D, **f32), torch.empty(B, D, **f32)
+        self.q = torch.empty(B, H * engine.DIM_HEAD, **f32)
+        self.nsplit = (Nmax + 63) // 64
+        self.parts = torch.zeros(B, self.nsplit, H, 66, **f32)                 # attention partials (max, sum, o[64])
+        self.pos_dev = torch.zeros(1, device=dev, dtype=torch.int32)           # row index, kept on the device
+        self.u = torch.empty(B, Fp, **f32)
+        seq = model.token_sequences[-1]
+        self.Q, self.V1 = seq.num_quantizers, seq.codebook_size + 1
+        self.ldV = engine.ceil_to(self.V1, 8)
+        self.logits = torch.zeros(B, self.ldV, **f32)
+        self.codebook = seq.codebook_size
+        self.emb = model.embeddings[-1].weight.detach()
+        # rel-pos table for every distance the cache can hold: [Nmax, ld] fp32 (row = i - j, column = head)
+        self.table, _ = engine.relpos_forward(tr, Nmax, False)
+        self.rows = 0                       # rows already in the caches == index of the next row
+        self._keep = []                     # python references that keep the pointer arrays' targets alive
+        a = DecodeArgs()
+        a.B, a.D, a.H, a.L, a.F, a.Fp, a.Nmax, a.nsplit = B, D, H, L, F, Fp, Nmax, self.nsplit
+        a.pos_dev = self.pos_dev.data_ptr()
+        a.w_dtype = 0 if self.T == torch.float32 else 1
+        a.round_bf16 = 0 if self.T == torch.float32 else 1
+        a.eps, a.scale = 1e-5, float(engine.ATTN_SCALE)
+
+        def arr(tensors: Sequence[torch.Tensor]):
+            ts = [t.detach() for t in tensors]
+            for t in ts:
+                hip.require_gpu(t, "decode operand")
+                assert t.is_contiguous()
+            self._keep.append(ts)
+            out = (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+            self._keep.append(out)
+            return C.cast(out, C.POINTER(C.c_void_p))
+        lay = self.pw.layers
+        a.Wq, a.Wkv, a.Wo = arr([w["Wq"] for w in lay]), arr([w["Wkv"] for w in lay]), arr([w["Wo"] for w in lay])
+        a.W1p, a.W2p = arr([w["W1p"] for w in lay]), arr([w["W2p"] for w in lay])
+        a.convw, a.mid_gamma = arr([w["convw"] for w in lay]), arr([w["gamma_mid"] for w in lay])
+        a.attn_gamma = arr([attn.norm.gamma for attn, _, _ in tr.layers])
+        a.q_scale = arr([attn.q_scale for attn, _, _ in tr.layers])
+        a.k_scale = arr([attn.k_scale for attn, _, _ in tr.layers])
+        a.ffin_gamma = arr([ff.norm_in.gamma for _, _, ff in tr.layers])
+        a.Kc, a.Vc, a.hist = arr(self.Kc), arr(self.Vc), arr(self.hist)
+        a.bias_table = self.table.data_ptr() if self.table is not None else None
+        a.bias_ld = self.table.shape[-1] if self.table is not None else 0
+        a.final_gamma = tr.norm.gamma.detach().data_ptr()
+        a.V1, a.ldV = self.V1, self.ldV
+        a.emb_table, a.emb_rows = self.emb.data_ptr(), self.emb.shape[0]
+        for n in ("x", "x1", "q", "parts", "u", "logits"):
+            setattr(a, n, getattr(self, n).data_ptr())
+        self.args = a
+
+    # ---- prompt: the batched forward over all known rows, keeping what the single-row steps need ---------------------
+    def prefill(self, all_token_ids: List[torch.Tensor]) -> torch.Tensor:
+        """all_token_ids: the conditioning sequences followed by the ids sampled so far (may be empty).  Returns the
+        [B, ldV] logits of the last row (they predict the next id) and leaves the caches filled for rows < N."""
+        model, tr = self.model, self.model.transformer
+        ids32, lens = engine.build_ids(model, all_token_ids)
+        B, N = ids32.shape
+        assert B == self.B and N <= self.Nmax, (B, N, self.B, self.Nmax)
+        lay = engine.get_layout(model, B, lens, ids32.device, True)
+        x = engine.embed_forward(model, ids32, lay)
+        y, saved = engine.trunk_forward(tr, self.pw, x, None, B, N, True, False)
+        nseq = len(model.token_sequences)
+        logits = engine.heads_forward(model, self.pw, y, lay, [s == nseq - 1 for s in range(nseq)])[-1]
+        for l, sv in enumerate(saved["layers"]):
+            self.Kc[l][:, :N].copy_(sv.k.view(B, N, -1))
+            self.Vc[l][:, :N].copy_(sv.v.view(B, N, -1))
+            h1 = sv.h1.view(B, N, -1)
+            self.hist[l].zero_()
+            take = min(2, N)
+            self.hist[l][:, 2 - take:].copy_(h1[:, N - take:])
+        self.rows = N
+        self.pos_dev.fill_(N)
+        return logits
+
+    def step(self, new_ids: torch.Tensor, k: int) -> torch.Tensor:
+        """Append the row of ``new_ids`` ([B] int64: the k-th sampled id of every sample, k counted from 0) and return the
+        [B, ldV] logits that predict id k + 1 (quantizer head (k + 1) mod Q)."""
+        if self.rows >= self.Nmax:
+            raise RuntimeError(f"decode cache full ({self.Nmax} rows)")
+        a = self.args
+        a.emb_row_offset = self.codebook * (k % self.Q) if self.Q > 1 else 0
+        head = self.pw.heads[-1][(k + 1) % self.Q]
+        a.head_W = head.data_ptr()
+        ids = new_ids.contiguous()
+        assert ids.dtype == torch.int64 and ids.numel() == self.B
+        call("omlm_decode_step", C.addressof(a), ptr(ids), stream_ptr())
+        call("omlm_decode_advance", self.pos_dev.data_ptr(), None, stream_ptr())
+        self.rows += 1
+        return self.logits

@@ -15,7 +15,7 @@ import torch.nn.functional as F
 from torch import nn
 from tqdm import tqdm
 
-from . import engine, ops
+from . import decode, engine, ops
 from .transformer import Transformer
 from .utils import (append_eos_id, batch_unique_consecutive, beartype_jit, default, eval_decorator, exists,
                     float32_to_int16, generate_mask_with_prob, int16_to_float32, mask_out_after_eos_id)
@@ -169,15 +169,26 @@ class TokenConditionedTransformerWrapper(nn.Module):
         Q = pred_info.num_quantizers
         step = 0
         nxt = torch.empty(batch, device=device, dtype=torch.long)
+        n_new = max(max_time_steps - first_step, 0) * Q
+        use_cache = kwargs.pop('use_cache', True) and decode.supports(self.transformer, batch) and n_new > 0
+        dec = None
+        if use_cache:
+            # KV-cached decode (decode.py): one new row per sampled id instead of the reference's full re-forward
+            rows = sum(t.shape[-1] + 1 for t in cond) + 1 + sampled.shape[-1] + n_new
+            dec = decode.CachedDecoder(self.transformer, batch, rows, self.transformer._precision())
+            last = dec.prefill(cond + [sampled])
         for _t in tqdm(range(first_step, max_time_steps), desc='generating predicted tokens'):
             for ind in range(Q):
-                last = self.transformer.last_logits(cond + [sampled])
+                if dec is None:
+                    last = self.transformer.last_logits(cond + [sampled])
                 forbid = (not allow_eos_in_output) or (ind != Q - 1)
                 u = uniforms[step].to(device).float().contiguous() if exists(uniforms) \
                     else torch.empty(batch, V1, device=device).uniform_(0, 1)
                 ops.sample_topk_gumbel(last, u, nxt, V1, k, temperature, forbid)
                 sampled = torch.cat((sampled, nxt[:, None]), dim=-1)
                 step += 1
+                if dec is not None and step < n_new:
+                    last = dec.step(nxt, sampled.shape[-1] - 1)
         sampled = mask_out_after_eos_id(sampled, pred_eos_id, keep_eos=include_eos_in_output)
         return sampled.reshape(batch, -1, Q)
 

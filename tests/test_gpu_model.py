@@ -169,6 +169,42 @@ def test_generate_matches_reference_golden_ids(golden_dir, dev, precision):
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_cached_decode_matches_full_reforward(golden_dir, dev, precision):
+    """KV-cached single-row decode (csrc/decode.hip) vs the reference-style full re-forward of the same model: the logits
+    of every step agree to the precision mode's tolerance, and the sampled ids are identical for the same uniforms."""
+    from open_musiclm_amd import decode
+    from open_musiclm_amd import open_musiclm as M
+    z = np.load(os.path.join(golden_dir, "tiny_coarse_generate.npz"))
+    zt, model = build_from_golden(golden_dir, "tiny_coarse", dev, precision)
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd.")}
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    wrapper = M.TokenConditionedTransformerWrapper(transformer=model, unique_consecutive=False)
+    cond = [torch.from_numpy(z["cond.0"]).to(dev), torch.from_numpy(z["cond.1"]).to(dev)]
+    kw = dict(conditioning_token_ids=cond, max_time_steps=int(z["max_time_steps"]), temperature=float(z["temperature"]),
+              uniforms=torch.from_numpy(z["uniforms"]))
+    a = wrapper.generate(use_cache=True, **kw)
+    b = wrapper.generate(use_cache=False, **kw)
+    assert torch.equal(a, b)
+    # step-by-step logits: teacher-forced on the ids of the run above
+    with torch.no_grad():
+        from open_musiclm_amd.utils import append_eos_id
+        condx = [append_eos_id(t.reshape(t.shape[0], -1).long(), e) for t, e in zip(cond, wrapper.eos_ids)]
+        flat = a.reshape(a.shape[0], -1)
+        B, n = flat.shape
+        rows = sum(t.shape[-1] + 1 for t in condx) + 1 + n
+        dec = decode.CachedDecoder(model, B, rows, precision)
+        got = [dec.prefill(condx + [flat[:, :0]]).clone()]
+        for k in range(n - 1):
+            got.append(dec.step(flat[:, k].contiguous(), k).clone())
+        want = [model.last_logits(condx + [flat[:, :k]]).clone() for k in range(n)]
+    V1 = dec.V1
+    err = max(relerr(g[:, :V1], w[:, :V1]) for g, w in zip(got, want))
+    report("cached_decode_" + precision, max_rel_err=err, steps=n)
+    assert err < TOL[precision]["logits"], err
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
 def test_full_size_coarse_small_vs_oracle(dev, precision):
     """BASELINE config 2 shapes: musiclm_small coarse stage, N = 1116, B = 2; logits, loss and grads vs the CPU oracle."""
     from open_musiclm_amd import open_musiclm as M
