@@ -171,24 +171,34 @@ class TokenConditionedTransformerWrapper(nn.Module):
         nxt = torch.empty(batch, device=device, dtype=torch.long)
         n_new = max(max_time_steps - first_step, 0) * Q
         use_cache = kwargs.pop('use_cache', True) and decode.supports(self.transformer, batch) and n_new > 0
-        dec = None
         if use_cache:
-            # KV-cached decode (decode.py): one new row per sampled id instead of the reference's full re-forward
+            # KV-cached decode (decode.py): one new row per sampled id instead of the reference's full re-forward.
+            # Ids are sampled straight into a [steps, B] buffer that the next decode step reads: no per-step cat / copies.
             rows = sum(t.shape[-1] + 1 for t in cond) + 1 + sampled.shape[-1] + n_new
             dec = decode.CachedDecoder(self.transformer, batch, rows, self.transformer._precision())
             last = dec.prefill(cond + [sampled])
-        for _t in tqdm(range(first_step, max_time_steps), desc='generating predicted tokens'):
-            for ind in range(Q):
-                if dec is None:
+            n0 = sampled.shape[-1]
+            buf = torch.empty(n0 + n_new, batch, device=device, dtype=torch.long)
+            buf[:n0] = sampled.t()
+            U = uniforms.to(device).float().contiguous() if exists(uniforms) else torch.rand(n_new, batch, V1, device=device)
+            for _t in tqdm(range(first_step, max_time_steps), desc='generating predicted tokens'):
+                for ind in range(Q):
+                    forbid = (not allow_eos_in_output) or (ind != Q - 1)
+                    ops.sample_topk_gumbel(last, U[step], buf[n0 + step], V1, k, temperature, forbid)
+                    step += 1
+                    if step < n_new:
+                        last = dec.step(buf[n0 + step - 1], n0 + step - 1)
+            sampled = buf.t().contiguous()
+        else:
+            for _t in tqdm(range(first_step, max_time_steps), desc='generating predicted tokens'):
+                for ind in range(Q):
                     last = self.transformer.last_logits(cond + [sampled])
-                forbid = (not allow_eos_in_output) or (ind != Q - 1)
-                u = uniforms[step].to(device).float().contiguous() if exists(uniforms) \
-                    else torch.empty(batch, V1, device=device).uniform_(0, 1)
-                ops.sample_topk_gumbel(last, u, nxt, V1, k, temperature, forbid)
-                sampled = torch.cat((sampled, nxt[:, None]), dim=-1)
-                step += 1
-                if dec is not None and step < n_new:
-                    last = dec.step(nxt, sampled.shape[-1] - 1)
+                    forbid = (not allow_eos_in_output) or (ind != Q - 1)
+                    u = uniforms[step].to(device).float().contiguous() if exists(uniforms) \
+                        else torch.empty(batch, V1, device=device).uniform_(0, 1)
+                    ops.sample_topk_gumbel(last, u, nxt, V1, k, temperature, forbid)
+                    sampled = torch.cat((sampled, nxt[:, None]), dim=-1)
+                    step += 1
         sampled = mask_out_after_eos_id(sampled, pred_eos_id, keep_eos=include_eos_in_output)
         return sampled.reshape(batch, -1, Q)
 
