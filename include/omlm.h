@@ -69,16 +69,17 @@ int omlm_mqa_attn_bwd(const void* q, const void* k, const void* v, const float* 
 
 /* Middle of ConvFeedForward: CausalDSConv -> GEGLU -> LayerNorm(F) -> Dropout (transformer.py:122-148).
  * h1: [M, 2*Fp] (value half cols [0,F), gate half cols [Fp, Fp+F)); h2: [M, Fp]; convw: taps re-packed tap-major and
- * padded, [3, 2*Fp] in h1's column layout (from the reference ds_conv.weight [2F,1,3]); gamma padded to [Fp] with zeros;
+ * padded, [3, 2*Fp] in h1's column layout (from the reference ds_conv.weight [2F,1,3]); gamma padded to [Fp] with zeros; both in
+ * the operand dtype of h1 (they are re-read by every row, so in bf16 mode they travel as bf16 like every other operand);
  * dconv is accumulated in the reference layout [2F, 3].  rows are b*nseq + t.  Dropout mask = Philox(seed', element index)
  * with seed' = seed + *seed_dev * golden-ratio (seed_dev optional device word: lets a captured HIP graph draw a new mask
  * on every replay).  drop_bits (optional, [M, Fp/8] bytes): the forward stores the keep-mask, 1 bit per element, and the
  * backward reads it instead of regenerating it (null: the backward regenerates the mask from the same (seed, salt) pair). */
-int omlm_ffmid_fwd(const void* h1, const float* convw, const float* gamma, void* h2, float* mean, float* rstd,
+int omlm_ffmid_fwd(const void* h1, const void* convw, const void* gamma, void* h2, float* mean, float* rstd,
                    int M, int nseq, int F, int Fp, float eps, float p, unsigned long long seed,
                    const unsigned long long* seed_dev, unsigned char* drop_bits, int dtype, void* stream);
 long long omlm_ffmid_bwd_workspace_bytes(int F, int Fp);
-int omlm_ffmid_bwd(const void* dh2, const void* h1, const float* convw, const float* gamma, const float* mean,
+int omlm_ffmid_bwd(const void* dh2, const void* h1, const void* convw, const void* gamma, const float* mean,
                    const float* rstd, void* du_tmp, void* dh1, float* dgamma, float* dconv, float* workspace,
                    int M, int nseq, int F, int Fp, float p, unsigned long long seed,
                    const unsigned long long* seed_dev, const unsigned char* drop_bits, int dtype, void* stream);

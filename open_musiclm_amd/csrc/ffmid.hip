@@ -63,10 +63,11 @@ __device__ __forceinline__ float gelu_f(float x) { return gelu_from_erf(x, fast_
 
 // y[t] = w0 x[t-2] + w1 x[t-1] + w2 x[t]; taps from convT[3][ld] at the same column as the data
 template <typename T>
-__device__ __forceinline__ void conv_row(const T* __restrict__ h1, const float* __restrict__ convT, size_t row, int t, int ld,
+__device__ __forceinline__ void conv_row(const T* __restrict__ h1, const T* __restrict__ convT, size_t row, int t, int ld,
                                          int col, float* u) {
     vec8<T> c0, c1, c2;
-    vec8<float> w0, w1, w2;
+    vec8<T> w0, w1, w2;      // taps / gamma travel in the operand dtype: they are row-invariant, and as fp32 they were 70 % of
+                             // the L2->L1 bytes of these kernels (which run at the L2 bandwidth, not at HBM's)
     c2.load(h1 + row * ld + col);
     if (t >= 1) c1.load(h1 + (row - 1) * ld + col); else zero8(c1.v);
     if (t >= 2) c0.load(h1 + (row - 2) * ld + col); else zero8(c0.v);
@@ -111,8 +112,8 @@ __device__ __forceinline__ void welford_merge(float& n, float& mean, float& m2, 
 }
 
 template <typename T, int MAXC>
-__global__ __launch_bounds__(FF_THREADS, 3) void ffmid_fwd_kernel(const T* __restrict__ h1, const float* __restrict__ convw,
-                                                                  const float* __restrict__ gamma, T* __restrict__ h2,
+__global__ __launch_bounds__(FF_THREADS, 3) void ffmid_fwd_kernel(const T* __restrict__ h1, const T* __restrict__ convw,
+                                                                  const T* __restrict__ gamma, T* __restrict__ h2,
                                                                   float* __restrict__ mean, float* __restrict__ rstd,
                                                                   int M, int nseq, int F, int Fp, float eps, float p,
                                                                   unsigned long long seed, const unsigned long long* __restrict__ seed_dev,
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(FF_THREADS, 3) void ffmid_fwd_kernel(const T* __res
                     }
                 }
                 vec8<T> o;
-                vec8<float> gm;
+                vec8<T> gm;
                 gm.load(gamma + ch);                               // padded gamma: 0 beyond F
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(FF_THREADS, 3) void ffmid_fwd_kernel(const T* __res
 // dgamma is accumulated in an LDS array per workgroup (ds_add_f32) and written once as a partial row.
 template <typename T, int MAXC>
 __global__ __launch_bounds__(FF_THREADS, 2) void ffmid_bwd1_kernel(const T* __restrict__ dh2, const T* __restrict__ h1,
-                                                                const float* __restrict__ convw, const float* __restrict__ gamma,
+                                                                const T* __restrict__ convw, const T* __restrict__ gamma,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 T* __restrict__ du, float* __restrict__ part_dgamma,
                                                                 int M, int nseq, int F, int Fp, float p, unsigned long long seed,
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffmid_bwd1_kernel(const T* __re
                     if (drop_bits) dropout8_from_bits(drop_bits[(size_t)row * (Fp >> 3) + (ch >> 3)], p, m);
                     else dropout8(seed, (unsigned long long)row * Fp + ch, p, m);
                 }
-                vec8<float> gm;
+                vec8<T> gm;
                 gm.load(gamma + ch);
                 float dgv[8];
 #pragma unroll
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffmid_bwd1_kernel(const T* __re
                     if (drop_bits) dropout8_from_bits(drop_bits[(size_t)row * (Fp >> 3) + (ch >> 3)], p, m);
                     else dropout8(seed, (unsigned long long)row * Fp + ch, p, m);
                 }
-                vec8<float> gm;
+                vec8<T> gm;
                 gm.load(gamma + ch);
                 float ev[8];
 #pragma unroll
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffmid_bwd1_kernel(const T* __re
 // One thread owns 8 channels of the padded 2*Fp layout for a strip of rows.
 template <typename T>
 __global__ __launch_bounds__(FF_THREADS) void ffmid_bwd2_kernel(const T* __restrict__ du, const T* __restrict__ h1,
-                                                                const float* __restrict__ convw, T* __restrict__ dh1,
+                                                                const T* __restrict__ convw, T* __restrict__ dh1,
                                                                 float* __restrict__ part_dconv, int M, int nseq, int F, int Fp) {
     const int ld = 2 * Fp, nchunk = ld / 8;
     const int strips = gridDim.y;
@@ -319,29 +320,38 @@ __global__ __launch_bounds__(FF_THREADS) void ffmid_bwd2_kernel(const T* __restr
     float w[8][3], dw[8][3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        vec8<float> wv;
+        vec8<T> wv;
         wv.load(convw + (size_t)k * ld + col);         // tap-major padded taps (0 in pad columns)
 #pragma unroll
         for (int i = 0; i < 8; ++i) { w[i][k] = wv.v[i]; dw[i][k] = 0.f; }
     }
     const int rows_per = (M + strips - 1) / strips;
     const int r_begin = blockIdx.y * rows_per, r_end = min(M, r_begin + rows_per);
+    // rolling window over the strip: du rows (row, row+1, row+2) and h1 rows (row-2, row-1, row) are carried in registers, so
+    // each step loads ONE new du row and ONE new h1 row instead of three of each (sequence boundaries are applied as masks)
+    vec8<T> da, db, dc, xa, xb, xc;
+    zero8(da.v); zero8(db.v); zero8(dc.v); zero8(xa.v); zero8(xb.v); zero8(xc.v);
+    if (r_begin < r_end) {
+        db.load(du + (size_t)r_begin * ld + col);
+        if (r_begin + 1 < M) dc.load(du + (size_t)(r_begin + 1) * ld + col);
+        if (r_begin >= 1) xc.load(h1 + (size_t)(r_begin - 1) * ld + col);
+        if (r_begin >= 2) xb.load(h1 + (size_t)(r_begin - 2) * ld + col);
+    }
     for (int row = r_begin; row < r_end; ++row) {
         const int t = row % nseq;
-        vec8<T> d0, d1, d2, x0, x1, x2;
-        d0.load(du + (size_t)row * ld + col);
-        if (t + 1 < nseq) d1.load(du + (size_t)(row + 1) * ld + col); else zero8(d1.v);
-        if (t + 2 < nseq) d2.load(du + (size_t)(row + 2) * ld + col); else zero8(d2.v);
-        x2.load(h1 + (size_t)row * ld + col);
-        if (t >= 1) x1.load(h1 + (size_t)(row - 1) * ld + col); else zero8(x1.v);
-        if (t >= 2) x0.load(h1 + (size_t)(row - 2) * ld + col); else zero8(x0.v);
+        da = db; db = dc;                                            // du[row], du[row + 1]
+        if (row + 2 < M) dc.load(du + (size_t)(row + 2) * ld + col); else zero8(dc.v);
+        xa = xb; xb = xc;                                            // h1[row - 2], h1[row - 1]
+        xc.load(h1 + (size_t)row * ld + col);
+        const float m1 = t + 1 < nseq ? 1.f : 0.f, m2 = t + 2 < nseq ? 1.f : 0.f;
+        const float p1 = t >= 1 ? 1.f : 0.f, p2 = t >= 2 ? 1.f : 0.f;
         vec8<T> o;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            o.v[i] = w[i][2] * d0.v[i] + w[i][1] * d1.v[i] + w[i][0] * d2.v[i];
-            dw[i][0] += d0.v[i] * x0.v[i];
-            dw[i][1] += d0.v[i] * x1.v[i];
-            dw[i][2] += d0.v[i] * x2.v[i];
+            o.v[i] = w[i][2] * da.v[i] + w[i][1] * (m1 * db.v[i]) + w[i][0] * (m2 * dc.v[i]);
+            dw[i][0] += da.v[i] * (p2 * xa.v[i]);
+            dw[i][1] += da.v[i] * (p1 * xb.v[i]);
+            dw[i][2] += da.v[i] * xc.v[i];
         }
         o.store(dh1 + (size_t)row * ld + col);
     }
@@ -382,7 +392,7 @@ extern "C" long long omlm_ffmid_bwd_workspace_bytes(int F, int Fp) {
     return (long long)sizeof(float) * ((long long)FF_BWD1_BLOCKS * Fp + (long long)FF_BWD2_STRIPS * 2 * F * 3);
 }
 
-extern "C" int omlm_ffmid_fwd(const void* h1, const float* convw, const float* gamma, void* h2, float* mean, float* rstd,
+extern "C" int omlm_ffmid_fwd(const void* h1, const void* convw, const void* gamma, void* h2, float* mean, float* rstd,
                               int M, int nseq, int F, int Fp, float eps, float p, unsigned long long seed,
                               const unsigned long long* seed_dev, unsigned char* drop_bits, int dtype, void* stream) {
     if (M <= 0) return OMLM_OK;
@@ -400,7 +410,7 @@ extern "C" int omlm_ffmid_fwd(const void* h1, const float* convw, const float* g
         (void)hipFuncSetAttribute((const void*)ffmid_fwd_kernel<bf16_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)ffmid_fwd_kernel<bf16_t, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-#define FF_FWD(T_, MC_) hipLaunchKernelGGL((ffmid_fwd_kernel<T_, MC_>), grid, block, lds_fwd, st, (const T_*)h1, convw, gamma, (T_*)h2, mean, rstd, M, nseq, F, Fp, eps, p, seed, seed_dev, drop_bits)
+#define FF_FWD(T_, MC_) hipLaunchKernelGGL((ffmid_fwd_kernel<T_, MC_>), grid, block, lds_fwd, st, (const T_*)h1, (const T_*)convw, (const T_*)gamma, (T_*)h2, mean, rstd, M, nseq, F, Fp, eps, p, seed, seed_dev, drop_bits)
 #define FF_FWD_DISPATCH(T_) do { const int mc = (Fp / 8 + 63) / 64; \
         if (mc <= 2) FF_FWD(T_, 2); else if (mc <= 6) FF_FWD(T_, 6); else if (mc <= 8) FF_FWD(T_, 8); else FF_FWD(T_, 16); } while (0)
     if (dtype == 0) FF_FWD_DISPATCH(float); else FF_FWD_DISPATCH(bf16_t);
@@ -409,7 +419,7 @@ extern "C" int omlm_ffmid_fwd(const void* h1, const float* convw, const float* g
 
 // du_tmp: [M, 2*Fp] scratch of the operand dtype; dh1: [M, 2*Fp] output; workspace: omlm_ffmid_bwd_workspace_bytes.
 // dgamma [F], dconv [2F*3] are accumulated into (+=).
-extern "C" int omlm_ffmid_bwd(const void* dh2, const void* h1, const float* convw, const float* gamma, const float* mean,
+extern "C" int omlm_ffmid_bwd(const void* dh2, const void* h1, const void* convw, const void* gamma, const float* mean,
                               const float* rstd, void* du_tmp, void* dh1, float* dgamma, float* dconv, float* workspace,
                               int M, int nseq, int F, int Fp, float p, unsigned long long seed,
                               const unsigned long long* seed_dev, const unsigned char* drop_bits, int dtype, void* stream) {
@@ -433,15 +443,15 @@ extern "C" int omlm_ffmid_bwd(const void* dh2, const void* h1, const float* conv
         (void)hipFuncSetAttribute((const void*)ffmid_bwd1_kernel<bf16_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)ffmid_bwd1_kernel<bf16_t, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-#define FF_B1(T_, MC_) hipLaunchKernelGGL((ffmid_bwd1_kernel<T_, MC_>), dim3(b1), dim3(FF_THREADS), lds1, st, (const T_*)dh2, (const T_*)h1, convw, gamma, mean, rstd, (T_*)du_tmp, part_g, M, nseq, F, Fp, p, seed, seed_dev, drop_bits)
+#define FF_B1(T_, MC_) hipLaunchKernelGGL((ffmid_bwd1_kernel<T_, MC_>), dim3(b1), dim3(FF_THREADS), lds1, st, (const T_*)dh2, (const T_*)h1, (const T_*)convw, (const T_*)gamma, mean, rstd, (T_*)du_tmp, part_g, M, nseq, F, Fp, p, seed, seed_dev, drop_bits)
 #define FF_B1_DISPATCH(T_) do { const int mc = (Fp / 8 + 63) / 64; \
         if (mc <= 2) FF_B1(T_, 2); else if (mc <= 6) FF_B1(T_, 6); else if (mc <= 8) FF_B1(T_, 8); else FF_B1(T_, 16); } while (0)
     if (dtype == 0) {
         FF_B1_DISPATCH(float);
-        hipLaunchKernelGGL(ffmid_bwd2_kernel<float>, g2, dim3(FF_THREADS), 0, st, (const float*)du_tmp, (const float*)h1, convw, (float*)dh1, part_c, M, nseq, F, Fp);
+        hipLaunchKernelGGL(ffmid_bwd2_kernel<float>, g2, dim3(FF_THREADS), 0, st, (const float*)du_tmp, (const float*)h1, (const float*)convw, (float*)dh1, part_c, M, nseq, F, Fp);
     } else {
         FF_B1_DISPATCH(bf16_t);
-        hipLaunchKernelGGL(ffmid_bwd2_kernel<bf16_t>, g2, dim3(FF_THREADS), 0, st, (const bf16_t*)du_tmp, (const bf16_t*)h1, convw, (bf16_t*)dh1, part_c, M, nseq, F, Fp);
+        hipLaunchKernelGGL(ffmid_bwd2_kernel<bf16_t>, g2, dim3(FF_THREADS), 0, st, (const bf16_t*)du_tmp, (const bf16_t*)h1, (const bf16_t*)convw, (bf16_t*)dh1, part_c, M, nseq, F, Fp);
     }
     int rc = omlm_post_launch("omlm_ffmid_bwd");
     if (rc) return rc;

@@ -615,14 +615,28 @@ extern "C" int omlm_gemm(const void* A, const void* B, void* C, const float* Cin
         else if (M >= 2048 && N >= 256) { bm = 256; bn = 128; }
         else if (N >= 2048 && M >= 256) { bm = 256; bn = 256; }
     }
-    // split-K only for accumulate-into-C GEMMs with few output tiles (the weight-gradient contractions)
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ncu = n;
+        else ncu = 256;
+    }
+    // split-K only for accumulate-into-C GEMMs with few output tiles (the weight-gradient contractions).  The 256-wide
+    // tiles run one workgroup per CU, so the split count is chosen for whole rounds of the machine: e.g. dW1 has 88 tiles;
+    // 12 splits = 1056 workgroups = 4.1 rounds (82 % of the last 5 used), 11 splits = 968 = 3.8 rounds (95 %).
     const int nk = (K + BK - 1) / BK;
     const int tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
     int splits = 1;
     if (Cin == (const float*)C && out_dtype == 0 && tiles < 512 && nk >= 16) {
-        splits = (1024 + tiles - 1) / tiles;
-        if (splits > nk / 8) splits = nk / 8;
-        if (splits < 1) splits = 1;
+        const int slots = (bm == 256 ? 1 : 2) * ncu;              // co-resident workgroups (LDS: 128 KiB tiles 1 / CU, 64 KiB 2 / CU)
+        int smax = nk / 8; if (smax > 32) smax = 32; if (smax < 1) smax = 1;
+        int smin = (2 * slots + tiles - 1) / tiles; if (smin > smax) smin = smax; if (smin < 1) smin = 1;
+        float best = -1.f;
+        for (int sp = smin; sp <= smax; ++sp) {
+            const int total = tiles * sp, rounds = (total + slots - 1) / slots;
+            const float util = (float)total / (float)(rounds * slots) - 0.004f * (float)sp;      // mild preference for fewer atomics
+            if (util > best) { best = util; splits = sp; }
+        }
     }
     g.kt_per_split = (nk + splits - 1) / splits;
     splits = (nk + g.kt_per_split - 1) / g.kt_per_split;
@@ -638,12 +652,37 @@ extern "C" int omlm_gemm(const void* A, const void* B, void* C, const float* Cin
         OMLM_CHECK_ARG(out_dtype == 0, "fp32 operands produce fp32 output");
         return launch_layout<float, float>(g, a_kmajor, b_kmajor, splits, st);
     }
-    if (bm == 256 && bn == 256)
-        return out_dtype == 0 ? launch_tile<256, 256, 128, 64, float>(g, a_kmajor, b_kmajor, splits, st)
-                              : launch_tile<256, 256, 128, 64, bf16_t>(g, a_kmajor, b_kmajor, splits, st);
-    if (bm == 256 && bn == 128)
-        return out_dtype == 0 ? launch_tile<256, 128, 64, 64, float>(g, a_kmajor, b_kmajor, splits, st)
-                              : launch_tile<256, 128, 64, 64, bf16_t>(g, a_kmajor, b_kmajor, splits, st);
-    return out_dtype == 0 ? launch_tile<128, 128, 64, 64, float>(g, a_kmajor, b_kmajor, splits, st)
-                          : launch_tile<128, 128, 64, 64, bf16_t>(g, a_kmajor, b_kmajor, splits, st);
+    auto launch = [&](const GemmArgs& ga, int tm_, int tn_, int sp) -> int {
+        if (tm_ == 256 && tn_ == 256)
+            return out_dtype == 0 ? launch_tile<256, 256, 128, 64, float>(ga, a_kmajor, b_kmajor, sp, st)
+                                  : launch_tile<256, 256, 128, 64, bf16_t>(ga, a_kmajor, b_kmajor, sp, st);
+        if (tm_ == 256 && tn_ == 128)
+            return out_dtype == 0 ? launch_tile<256, 128, 64, 64, float>(ga, a_kmajor, b_kmajor, sp, st)
+                                  : launch_tile<256, 128, 64, 64, bf16_t>(ga, a_kmajor, b_kmajor, sp, st);
+        return out_dtype == 0 ? launch_tile<128, 128, 64, 64, float>(ga, a_kmajor, b_kmajor, sp, st)
+                              : launch_tile<128, 128, 64, 64, bf16_t>(ga, a_kmajor, b_kmajor, sp, st);
+    };
+    // Tail peeling for the one-workgroup-per-CU 256x256 tiles: dX-type GEMMs have 560 tiles = 2.19 rounds of 256 CUs, i.e. a
+    // third round that is 19 % full.  The m-tile rows that fill whole rounds keep the 256x256 kernel; the remaining rows go to
+    // the 128x128 kernel (2 workgroups per CU, ~1/3 of the time per tile).
+    if (bm == 256 && bn == 256 && splits == 1 && !a_kmajor && !a_map && !c_map && !(force && force[0]) && tiles > ncu) {
+        const int tiles_n = (N + 255) / 256, tiles_m = (M + 255) / 256;
+        const int rem = tiles % ncu;
+        const int m_full = ((tiles / ncu) * ncu) / tiles_n;
+        if (rem > 0 && rem < ncu / 2 && m_full >= 1 && m_full < tiles_m) {
+            const size_t osz = out_dtype == 0 ? 4 : 2;
+            const long long M1 = (long long)m_full * 256;
+            GemmArgs g1 = g, g2 = g;
+            g1.M = (int)M1;
+            g2.M = M - (int)M1;
+            g2.A = (const char*)A + (size_t)M1 * lda * 2;
+            g2.a_rows = a_rows - M1;
+            g2.C = (char*)C + (size_t)M1 * ldc * osz;
+            if (Cin) g2.Cin = Cin + (size_t)M1 * ldcin;
+            const int rc = launch(g1, 256, 256, 1);
+            if (rc != OMLM_OK) return rc;
+            return launch(g2, 128, 128, 1);
+        }
+    }
+    return launch(g, bm, bn, splits);
 }

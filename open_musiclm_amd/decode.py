@@ -96,7 +96,8 @@ class CachedDecoder:
         lay = self.pw.layers
         a.Wq, a.Wkv, a.Wo = arr([w["Wq"] for w in lay]), arr([w["Wkv"] for w in lay]), arr([w["Wo"] for w in lay])
         a.W1p, a.W2p = arr([w["W1p"] for w in lay]), arr([w["W2p"] for w in lay])
-        a.convw, a.mid_gamma = arr([w["convw"] for w in lay]), arr([w["gamma_mid"] for w in lay])
+        # fp32 views of the (operand-dtype) taps / gamma: same values as the batched path uses
+        a.convw, a.mid_gamma = arr([w["convw"].float() for w in lay]), arr([w["gamma_mid"].float() for w in lay])
         a.attn_gamma = arr([attn.norm.gamma for attn, _, _ in tr.layers])
         a.q_scale = arr([attn.q_scale for attn, _, _ in tr.layers])
         a.k_scale = arr([attn.k_scale for attn, _, _ in tr.layers])

@@ -151,8 +151,10 @@ class PreparedWeights:
                 ops.transpose_cast(w1.detach()[F:], W1pT[:, Fp:], F, D, D, 2 * Fp)
                 ent["W1pT"] = W1pT
                 ent["W2pT"] = wt(w2, D, F, rows_pad=Fp, cols_pad=D)           # [Fp, D], rows >= F zero
-            ent["convw"] = ops.pack_conv_taps(ff.conv_weight().detach(), F, Fp)    # taps [3, 2Fp] (identity taps for plain FeedForward)
-            ent["gamma_mid"] = ops.pad_vector(ff.norm_mid.gamma.detach(), Fp)
+            # taps [3, 2Fp] (identity taps for plain FeedForward) and the padded LN gamma travel in the operand dtype: they are
+            # re-read for every row, and as fp32 they were 70 % of the L2->L1 bytes of the conv-GEGLU-LN kernels
+            ent["convw"] = ops.pack_conv_taps(ff.conv_weight().detach(), F, Fp).to(T)
+            ent["gamma_mid"] = ops.pad_vector(ff.norm_mid.gamma.detach(), Fp).to(T)
             cache = ff.__dict__.setdefault("_omlm_cmap", {})
             if (F, Fp, str(dev)) not in cache:            # static scatter map: uploaded once (no H2D inside graph capture)
                 cm = torch.full((2 * Fp,), -1, dtype=torch.int32)

@@ -267,12 +267,13 @@ def test_ffmid_fwd_bwd(ops, dev, dtype, F):
     h1 = torch.zeros(M, 2 * Fp)
     h1[:, :F] = torch.randn(M, F, generator=g)
     h1[:, Fp:Fp + F] = torch.randn(M, F, generator=g)
-    convw = (torch.randn(2 * F, 3, generator=g) * 0.5).to(dev)
-    gamma = (1 + 0.1 * torch.randn(F, generator=g)).to(dev)
+    # taps / gamma are operands of the kernel dtype: the reference uses the same (rounded) values
+    convw = (torch.randn(2 * F, 3, generator=g) * 0.5).to(dev).to(dtype).float()
+    gamma = (1 + 0.1 * torch.randn(F, generator=g)).to(dev).to(dtype).float()
     h1d = h1.to(dev).to(dtype)
     h2 = torch.empty(M, Fp, device=dev, dtype=dtype)
     mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
-    taps, gpad = ops.pack_conv_taps(convw, F, Fp), ops.pad_vector(gamma, Fp)
+    taps, gpad = ops.pack_conv_taps(convw, F, Fp).to(dtype), ops.pad_vector(gamma, Fp).to(dtype)
     ops.ffmid_fwd(h1d, taps, gpad, h2, mean, rstd, nseq, F, Fp, 0.0, 0)
     h1r = h1d.double().requires_grad_(True)
     cr, gr = convw.double().requires_grad_(True), gamma.double().requires_grad_(True)
