@@ -205,6 +205,42 @@ def test_cached_decode_matches_full_reforward(golden_dir, dev, precision):
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("name", ["tiny_fine_allweights", "tiny_semantic_t5_plainff"])
+def test_cached_decode_other_stages(golden_dir, dev, name, precision):
+    """The cached decode on the other trunk variants: fine stage (two conditioning sequences, Q > 1 heads / offsets) and the
+    semantic stage with the T5 bucket bias and the plain FeedForward (identity conv taps, Q = 1)."""
+    from open_musiclm_amd import decode
+    from open_musiclm_amd import open_musiclm as M
+    from open_musiclm_amd.utils import append_eos_id
+    z, model = build_from_golden(golden_dir, name, dev, precision)
+    model.eval()
+    wrapper = M.TokenConditionedTransformerWrapper(transformer=model, unique_consecutive=False)
+    nseq = len(model.token_sequences)
+    cond = [torch.from_numpy(z[f"ids.{i}"]).to(dev) for i in range(nseq - 1)]
+    B = cond[0].shape[0]
+    seq = model.token_sequences[-1]
+    V1, Q, steps = seq.codebook_size + 1, seq.num_quantizers, 4
+    g = torch.Generator().manual_seed(5)
+    U = torch.rand(steps * Q, B, V1, generator=g)
+    kw = dict(conditioning_token_ids=cond, max_time_steps=steps, uniforms=U)
+    a = wrapper.generate(use_cache=True, **kw)
+    b = wrapper.generate(use_cache=False, **kw)
+    assert torch.equal(a, b), (a.tolist(), b.tolist())
+    with torch.no_grad():
+        condx = [append_eos_id(t.reshape(t.shape[0], -1).long(), e) for t, e in zip(cond, wrapper.eos_ids)]
+        flat = a.reshape(B, -1)
+        n = flat.shape[1]
+        dec = decode.CachedDecoder(model, B, sum(t.shape[-1] + 1 for t in condx) + 1 + n, precision)
+        got = [dec.prefill(condx + [flat[:, :0]]).clone()]
+        for k in range(n - 1):
+            got.append(dec.step(flat[:, k].contiguous(), k).clone())
+        want = [model.last_logits(condx + [flat[:, :k]]).clone() for k in range(n)]
+    err = max(relerr(x[:, :V1], y[:, :V1]) for x, y in zip(got, want))
+    report(f"cached_decode_{name}_{precision}", max_rel_err=err, steps=n)
+    assert err < TOL[precision]["logits"], err
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
 def test_full_size_coarse_small_vs_oracle(dev, precision):
     """BASELINE config 2 shapes: musiclm_small coarse stage, N = 1116, B = 2; logits, loss and grads vs the CPU oracle."""
     from open_musiclm_amd import open_musiclm as M
