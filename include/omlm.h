@@ -129,6 +129,11 @@ int omlm_nearest_centroid(const float* x, const float* centroids_T, int* indices
 int omlm_sample_topk_gumbel(const float* logits, const float* uniform, long long* out, int B, int V, int ld,
                             int k, float temperature, int forbid_last, void* stream);
 
+/* The same sampler in graph-replayable form: uniform_base [steps, B, V] and hist [steps, B] (optional) are indexed by the
+ * DEVICE counter *step_dev; out [B] is the fixed buffer the next decode step embeds from. */
+int omlm_sample_topk_gumbel_at(const float* logits, const float* uniform_base, const int* step_dev, long long* out,
+                               long long* hist, int B, int V, int ld, int k, float temperature, int forbid_last, void* stream);
+
 /* KV-cached AR decode step: ONE new row (index *pos_dev) per sample through all L layers and the logit head of the quantizer
  * that row predicts -- replaces the reference's full re-forward per sampled id (wrapper.generate, open_musiclm.py:301-321;
  * the trunk is strictly causal, so the logits are the same).  State owned by the caller, all fp32:

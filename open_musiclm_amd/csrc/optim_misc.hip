@@ -261,7 +261,12 @@ __device__ __forceinline__ unsigned f_ord(float f) { unsigned u = f2u(f); return
 
 __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ logits, const float* __restrict__ uniform,
                                                      long long* __restrict__ out, int V, int ld, int k, float temperature,
-                                                     int forbid_last) {
+                                                     int forbid_last, const int* __restrict__ step_dev, long long* __restrict__ hist) {
+    if (step_dev) {          // graph-replayable form: this step's uniforms / history slot are selected by a DEVICE counter
+        const long long sidx = step_dev[0];
+        uniform += sidx * (long long)gridDim.x * V;
+        if (hist) hist += sidx * gridDim.x;
+    }
     __shared__ unsigned keys[2048];
     __shared__ int cnt[4];
     __shared__ float bv[4];
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
             const int oi = __shfl_xor(besti, o, 64);
             if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
         }
-        if (threadIdx.x == 0) out[row] = besti;
+        if (threadIdx.x == 0) { out[row] = besti; if (hist) hist[row] = besti; }
     }
 }
 
@@ -330,8 +335,20 @@ extern "C" int omlm_sample_topk_gumbel(const float* logits, const float* uniform
                                        int k, float temperature, int forbid_last, void* stream) {
     if (B <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(logits && uniform && out && V > 0 && V <= 2048 && k >= 1 && k <= V && temperature > 0.f, "sampler arguments");
-    hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(256), 0, as_stream(stream), logits, uniform, out, V, ld, k, temperature, forbid_last);
+    hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(256), 0, as_stream(stream), logits, uniform, out, V, ld, k, temperature, forbid_last,
+                       (const int*)nullptr, (long long*)nullptr);
     return omlm_post_launch("omlm_sample_topk_gumbel");
+}
+
+// Same sampler for a captured decode step: uniforms [steps, B, V] and the id history [steps, B] are indexed by *step_dev.
+extern "C" int omlm_sample_topk_gumbel_at(const float* logits, const float* uniform_base, const int* step_dev, long long* out,
+                                          long long* hist, int B, int V, int ld, int k, float temperature, int forbid_last,
+                                          void* stream) {
+    if (B <= 0) return OMLM_OK;
+    OMLM_CHECK_ARG(logits && uniform_base && step_dev && out && V > 0 && V <= 2048 && k >= 1 && k <= V && temperature > 0.f, "sampler arguments");
+    hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(256), 0, as_stream(stream), logits, uniform_base, out, V, ld, k, temperature,
+                       forbid_last, step_dev, hist);
+    return omlm_post_launch("omlm_sample_topk_gumbel_at");
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -43,6 +43,7 @@ SIGNATURES = {
     "omlm_adamw_clip_step": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp, f32, i32, i32, vp],
     "omlm_cast_pad": [vp, vp, i64, i32, i32, i32, i32, vp],
     "omlm_transpose_cast": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "omlm_sample_topk_gumbel_at": [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
     "omlm_decode_step": [vp, vp, vp],
     "omlm_decode_advance": [vp, vp, vp],
     "omlm_relpos_first_fwd": [vp, vp, vp, vp, i32, i32, vp],

@@ -178,17 +178,11 @@ class TokenConditionedTransformerWrapper(nn.Module):
             dec = decode.CachedDecoder(self.transformer, batch, rows, self.transformer._precision())
             last = dec.prefill(cond + [sampled])
             n0 = sampled.shape[-1]
-            buf = torch.empty(n0 + n_new, batch, device=device, dtype=torch.long)
-            buf[:n0] = sampled.t()
-            U = uniforms.to(device).float().contiguous() if exists(uniforms) else torch.rand(n_new, batch, V1, device=device)
-            for _t in tqdm(range(first_step, max_time_steps), desc='generating predicted tokens'):
-                for ind in range(Q):
-                    forbid = (not allow_eos_in_output) or (ind != Q - 1)
-                    ops.sample_topk_gumbel(last, U[step], buf[n0 + step], V1, k, temperature, forbid)
-                    step += 1
-                    if step < n_new:
-                        last = dec.step(buf[n0 + step - 1], n0 + step - 1)
-            sampled = buf.t().contiguous()
+            U = uniforms[:n_new].to(device).float().contiguous() if exists(uniforms) else torch.rand(n_new, batch, V1, device=device)
+            forbid = [(not allow_eos_in_output) or (ind != Q - 1) for ind in range(Q)]
+            loop = decode.SamplingLoop(dec, last, U, n0, n_new, k, temperature, forbid, use_graph=kwargs.pop('use_graph', False))
+            new_ids = loop.run()                                   # [n_new, B]
+            sampled = torch.cat((sampled, new_ids.t()), dim=-1)
         else:
             for _t in tqdm(range(first_step, max_time_steps), desc='generating predicted tokens'):
                 for ind in range(Q):

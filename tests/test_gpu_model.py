@@ -185,7 +185,8 @@ def test_cached_decode_matches_full_reforward(golden_dir, dev, precision):
               uniforms=torch.from_numpy(z["uniforms"]))
     a = wrapper.generate(use_cache=True, **kw)
     b = wrapper.generate(use_cache=False, **kw)
-    assert torch.equal(a, b)
+    c = wrapper.generate(use_cache=True, use_graph=True, **kw)      # cycles captured into HIP graphs and replayed
+    assert torch.equal(a, b) and torch.equal(a, c)
     # step-by-step logits: teacher-forced on the ids of the run above
     with torch.no_grad():
         from open_musiclm_amd.utils import append_eos_id
