@@ -76,6 +76,60 @@ __device__ __forceinline__ void conv_row(const T* __restrict__ h1, const T* __re
     for (int i = 0; i < 8; ++i) u[i] = w0.v[i] * c0.v[i] + w1.v[i] * c1.v[i] + w2.v[i] * c2.v[i];
 }
 
+// Packed 8-element loads kept un-converted, so that the NEXT chunk's operands can sit in registers (16 B each in bf16)
+// while the current chunk is computed: each wave walks its row chunk by chunk, and with only 2-3 waves per SIMD a chunk's
+// load latency (~1.7 us under load) was serialised with its ~1.7 us of arithmetic.
+template <typename T> struct raw8;
+template <> struct raw8<bf16_t> {
+    u32x4 r;
+    __device__ __forceinline__ void load(const bf16_t* p) { r = *(const u32x4*)p; }
+    __device__ __forceinline__ void zero() { r[0] = 0u; r[1] = 0u; r[2] = 0u; r[3] = 0u; }
+    __device__ __forceinline__ void unpack(float* v) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = bf16_lo_to_f(r[i]); v[2 * i + 1] = bf16_hi_to_f(r[i]); }
+    }
+};
+template <> struct raw8<float> {
+    float4 a, b;
+    __device__ __forceinline__ void load(const float* p) { a = ((const float4*)p)[0]; b = ((const float4*)p)[1]; }
+    __device__ __forceinline__ void zero() { a = make_float4(0.f, 0.f, 0.f, 0.f); b = a; }
+    __device__ __forceinline__ void unpack(float* v) const {
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+};
+// operands of y[t] = w0 x[t-2] + w1 x[t-1] + w2 x[t] for 8 channels
+template <typename T> struct ConvIn {
+    raw8<T> c0, c1, c2, w0, w1, w2;
+    __device__ __forceinline__ void load(const T* __restrict__ h1, const T* __restrict__ convT, size_t row, int t, int ld, int col) {
+        c2.load(h1 + row * ld + col);
+        if (t >= 1) c1.load(h1 + (row - 1) * ld + col); else c1.zero();
+        if (t >= 2) c0.load(h1 + (row - 2) * ld + col); else c0.zero();
+        w0.load(convT + col); w1.load(convT + ld + col); w2.load(convT + 2 * (size_t)ld + col);
+    }
+    __device__ __forceinline__ void eval(float* u) const {
+        float a0[8], a1[8], a2[8], b0[8], b1[8], b2[8];
+        c0.unpack(a0); c1.unpack(a1); c2.unpack(a2); w0.unpack(b0); w1.unpack(b1); w2.unpack(b2);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) u[i] = b0[i] * a0[i] + b1[i] * a1[i] + b2[i] * a2[i];
+    }
+};
+
+// everything one chunk of the backward row sweep reads: conv operands of both halves, dh2, gamma, the keep-mask byte
+template <typename T> struct Bwd1In {
+    ConvIn<T> x, g;
+    raw8<T> d, gm;
+    unsigned bits;
+    __device__ __forceinline__ void load(const T* __restrict__ h1, const T* __restrict__ convw, const T* __restrict__ dh2,
+                                         const T* __restrict__ gamma, const unsigned char* __restrict__ drop_bits,
+                                         size_t row, int t, int ld, int Fp, int ch) {
+        x.load(h1, convw, row, t, ld, ch);
+        g.load(h1, convw, row, t, ld, Fp + ch);
+        d.load(dh2 + row * Fp + ch);
+        gm.load(gamma + ch);
+        bits = drop_bits ? drop_bits[row * (Fp >> 3) + (ch >> 3)] : 0xFFu;
+    }
+};
+
 // keep-mask * 1/(1-p) for 8 consecutive elements starting at element index e0 (multiple of 8)
 __device__ __forceinline__ void dropout8(unsigned long long seed, unsigned long long e0, float p, float* m) {
     const float inv = 1.0f / (1.0f - p);
@@ -112,7 +166,7 @@ __device__ __forceinline__ void welford_merge(float& n, float& mean, float& m2, 
 }
 
 template <typename T, int MAXC>
-__global__ __launch_bounds__(FF_THREADS, 3) void ffmid_fwd_kernel(const T* __restrict__ h1, const T* __restrict__ convw,
+__global__ __launch_bounds__(FF_THREADS, 2) void ffmid_fwd_kernel(const T* __restrict__ h1, const T* __restrict__ convw,
                                                                   const T* __restrict__ gamma, T* __restrict__ h2,
                                                                   float* __restrict__ mean, float* __restrict__ rstd,
                                                                   int M, int nseq, int F, int Fp, float eps, float p,
@@ -128,13 +182,22 @@ __global__ __launch_bounds__(FF_THREADS, 3) void ffmid_fwd_kernel(const T* __res
         const int t = row % nseq;
         // sweep 1: LayerNorm statistics of g = gelu(gate) * value over the F real channels (single pass, Welford)
         float wn = 0.f, wmean = 0.f, wm2 = 0.f;
+        constexpr bool PF = sizeof(T) == 2;                 // operand prefetch one chunk ahead (register budget: bf16 only)
+        ConvIn<T> xin, gin, xnx, gnx;
+        if (PF && lane * 8 < F) { xin.load(h1, convw, row, t, ld, lane * 8); gin.load(h1, convw, row, t, ld, Fp + lane * 8); }
 #pragma unroll 1
         for (int k = 0; k < MAXC; ++k) {
             const int ch = (lane + 64 * k) * 8;
+            if (PF) {
+                const int chn = ch + 512;
+                if (k + 1 < MAXC && chn < F) { xnx.load(h1, convw, row, t, ld, chn); gnx.load(h1, convw, row, t, ld, Fp + chn); }
+            } else if (ch < F) {
+                xin.load(h1, convw, row, t, ld, ch); gin.load(h1, convw, row, t, ld, Fp + ch);
+            }
             if (ch < F) {
                 float ux[8], ug[8], gv[8];
-                conv_row<T>(h1, convw, row, t, ld, ch, ux);
-                conv_row<T>(h1, convw, row, t, ld, Fp + ch, ug);
+                xin.eval(ux);
+                gin.eval(ug);
                 const int nv = min(8, F - ch);
                 float cs = 0.f;
 #pragma unroll
@@ -147,6 +210,7 @@ __global__ __launch_bounds__(FF_THREADS, 3) void ffmid_fwd_kernel(const T* __res
                 for (int i = 0; i < 8; ++i) if (i < nv) { const float d = gv[i] - cm; c2 += d * d; }
                 welford_merge(wn, wmean, wm2, (float)nv, cm, c2);
             }
+            if (PF) { xin = xnx; gin = gnx; }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -221,21 +285,25 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffmid_bwd1_kernel(const T* __re
         const int t = row % nseq;
         const float mu = mean[row], rs = rstd[row];
         float s1 = 0.f, s2 = 0.f;
+        constexpr bool PF = sizeof(T) == 2;                 // operand prefetch one chunk ahead (register budget: bf16 only)
+        Bwd1In<T> cur, nxt;
+        if (PF && lane * 8 < Fp) cur.load(h1, convw, dh2, gamma, drop_bits, (size_t)row, t, ld, Fp, lane * 8);
 #pragma unroll 1
         for (int k = 0; k < MAXC; ++k) {
             const int ch = (lane + 64 * k) * 8;
+            if (PF) { if (k + 1 < MAXC && ch + 512 < Fp) nxt.load(h1, convw, dh2, gamma, drop_bits, (size_t)row, t, ld, Fp, ch + 512); }
+            else if (ch < Fp) cur.load(h1, convw, dh2, gamma, drop_bits, (size_t)row, t, ld, Fp, ch);
             if (ch < Fp) {
                 float ux[8], ug[8], m[8];
-                conv_row<T>(h1, convw, row, t, ld, ch, ux);
-                conv_row<T>(h1, convw, row, t, ld, Fp + ch, ug);
-                vec8<T> d;
-                d.load(dh2 + (size_t)row * Fp + ch);
+                cur.x.eval(ux);
+                cur.g.eval(ug);
+                vec8<T> d, gm;
+                cur.d.unpack(d.v);
+                cur.gm.unpack(gm.v);
                 if (p > 0.f) {
-                    if (drop_bits) dropout8_from_bits(drop_bits[(size_t)row * (Fp >> 3) + (ch >> 3)], p, m);
+                    if (drop_bits) dropout8_from_bits(cur.bits, p, m);
                     else dropout8(seed, (unsigned long long)row * Fp + ch, p, m);
                 }
-                vec8<T> gm;
-                gm.load(gamma + ch);
                 float dgv[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -256,24 +324,27 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffmid_bwd1_kernel(const T* __re
                 ((float4*)(dgw + ch))[0] = a;
                 ((float4*)(dgw + ch))[1] = b;
             }
+            if (PF) cur = nxt;
         }
         const float m1 = wave_sum(s1) / (float)F;
         const float m2 = wave_sum(s2) / (float)F;
+        if (PF && lane * 8 < Fp) cur.load(h1, convw, dh2, gamma, drop_bits, (size_t)row, t, ld, Fp, lane * 8);
 #pragma unroll 1
         for (int k = 0; k < MAXC; ++k) {
             const int ch = (lane + 64 * k) * 8;
+            if (PF) { if (k + 1 < MAXC && ch + 512 < Fp) nxt.load(h1, convw, dh2, gamma, drop_bits, (size_t)row, t, ld, Fp, ch + 512); }
+            else if (ch < Fp) cur.load(h1, convw, dh2, gamma, drop_bits, (size_t)row, t, ld, Fp, ch);
             if (ch < Fp) {
                 float ux[8], ug[8], m[8];
-                conv_row<T>(h1, convw, row, t, ld, ch, ux);
-                conv_row<T>(h1, convw, row, t, ld, Fp + ch, ug);
-                vec8<T> d, ox, og;
-                d.load(dh2 + (size_t)row * Fp + ch);
+                cur.x.eval(ux);
+                cur.g.eval(ug);
+                vec8<T> d, ox, og, gm;
+                cur.d.unpack(d.v);
+                cur.gm.unpack(gm.v);
                 if (p > 0.f) {
-                    if (drop_bits) dropout8_from_bits(drop_bits[(size_t)row * (Fp >> 3) + (ch >> 3)], p, m);
+                    if (drop_bits) dropout8_from_bits(cur.bits, p, m);
                     else dropout8(seed, (unsigned long long)row * Fp + ch, p, m);
                 }
-                vec8<T> gm;
-                gm.load(gamma + ch);
                 float ev[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) ev[i] = fast_erf(ug[i] * 0.70710678118654752f);
@@ -295,6 +366,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffmid_bwd1_kernel(const T* __re
                 ox.store(du + (size_t)row * ld + ch);
                 og.store(du + (size_t)row * ld + Fp + ch);
             }
+            if (PF) cur = nxt;
         }
     }
     __syncthreads();
