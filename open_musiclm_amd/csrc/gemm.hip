@@ -630,14 +630,16 @@ extern "C" int omlm_gemm(const void* A, const void* B, void* C, const float* Cin
     if (Cin == (const float*)C && out_dtype == 0 && tiles < 512 && nk >= 16) {
         const int slots = (bm == 256 ? 1 : 2) * ncu;              // co-resident workgroups (LDS: 128 KiB tiles 1 / CU, 64 KiB 2 / CU)
         int smax = nk / 8; if (smax > 32) smax = 32; if (smax < 1) smax = 1;
-        int smin = (2 * slots + tiles - 1) / tiles; if (smin > smax) smin = smax; if (smin < 1) smin = 1;
+        int smin = (slots + tiles - 1) / tiles; if (smin > smax) smin = smax; if (smin < 1) smin = 1;      // at least one full round
         float best = -1.f;
         for (int sp = smin; sp <= smax; ++sp) {
             const int total = tiles * sp, rounds = (total + slots - 1) / slots;
-            const float util = (float)total / (float)(rounds * slots) - 0.004f * (float)sp;      // mild preference for fewer atomics
+            // every split adds one atomic pass over C: ~1.2 % of the kernel each (probe: 88 tiles -> 5 / 8 / 11 splits = 651 / 631 / 676 us)
+            const float util = (float)total / (float)(rounds * slots) - 0.012f * (float)sp;
             if (util > best) { best = util; splits = sp; }
         }
     }
+    { const char* e = getenv("OMLM_GEMM_SPLITS"); if (e && atoi(e) > 0 && splits > 1) splits = atoi(e); }     // tuning override
     g.kt_per_split = (nk + splits - 1) / splits;
     splits = (nk + g.kt_per_split - 1) / g.kt_per_split;
     if (in_dtype == 0) {
