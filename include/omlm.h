@@ -42,11 +42,13 @@ int omlm_gemm(const void* A, const void* B, void* C, const float* Cin,
 /* LayerNorm (transformer.py:24-31: F.layer_norm, learnable gamma, beta == 0, eps 1e-5).
  * fwd: y = LN(x)*gamma in out_dtype (pitch ldy); xcast (optional) = cast(x) for the K/V projection, which the
  *      reference feeds with the UN-normalised input (kv_input bound at :228 before the pre-norm at :250).
- * bwd: dx = dx_scale * (dres + LN^T(dy)); dxcast (optional) = cast(dx); dgamma += sum_rows dy * xhat. */
+ * bwd: dx = dx_scale * (dres + LN^T(dy)); dxcast (optional) = cast(dx); dgamma += sum_rows dy * xhat.  workspace (optional,
+ *      omlm_layernorm_bwd_workspace_bytes): per-workgroup dgamma partials instead of contended atomics. */
 int omlm_layernorm_fwd(const float* x, const float* gamma, void* y, void* xcast, float* mean, float* rstd,
                        int M, int D, int ldy, float eps, int out_dtype, void* stream);
+long long omlm_layernorm_bwd_workspace_bytes(int D);
 int omlm_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
-                       const float* dres, float* dx, void* dxcast, float* dgamma, int M, int D,
+                       const float* dres, float* dx, void* dxcast, float* dgamma, float* workspace, int M, int D,
                        float dx_scale, int cast_dtype, void* stream);
 
 /* q/k l2-normalise * learned per-dim scale, v pass-through (transformer.py:265-271; utils.py:68-69), dim_head 64. */

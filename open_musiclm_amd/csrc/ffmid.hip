@@ -452,7 +452,7 @@ __global__ void colsum_kernel(const float* __restrict__ part, float* __restrict_
 extern "C" int omlm_colsum_accumulate(const float* part, float* out, int P, int C, int ldp, void* stream) {
     if (P <= 0 || C <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(part && out && ldp >= C, "colsum arguments");
-    const int ysplit = P >= 64 ? 16 : 1;
+    const int ysplit = P >= 1024 ? 128 : (P >= 64 ? 16 : 1);      // enough workgroups to stream a [2048, D] partial buffer
     hipLaunchKernelGGL(colsum_kernel, dim3((C + 255) / 256, ysplit), dim3(256), 0, as_stream(stream), part, out, P, C, ldp);
     return omlm_post_launch("omlm_colsum_accumulate");
 }

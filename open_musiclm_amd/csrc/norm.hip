@@ -63,7 +63,8 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const float* __restr
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ dres,
                                                             float* __restrict__ dx, T* __restrict__ dxcast,
-                                                            float* __restrict__ dgamma, int M, int D, float dx_scale) {
+                                                            float* __restrict__ dgamma, float* __restrict__ part, int M, int D,
+                                                            float dx_scale) {
     __shared__ float red[LN_THREADS / 64];
     const int nv = D / 4;
     float4 dg[LN_MAXV];
@@ -108,7 +109,13 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const float* __restr
             }
         }
     }
-    if (dgamma) {
+    if (part) {                         // one partial row per workgroup, reduced by colsum afterwards (no contended atomics)
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = threadIdx.x + i * LN_THREADS;
+            if (c < nv) ((float4*)(part + (size_t)blockIdx.x * D))[c] = dg[i];
+        }
+    } else if (dgamma) {
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
             const int c = threadIdx.x + i * LN_THREADS;
@@ -136,18 +143,30 @@ extern "C" int omlm_layernorm_fwd(const float* x, const float* gamma, void* y, v
     return omlm_post_launch("omlm_layernorm_fwd");
 }
 
+extern "C" int omlm_colsum_accumulate(const float* part, float* out, int P, int C, int ldp, void* stream);
+extern "C" long long omlm_layernorm_bwd_workspace_bytes(int D) { return (long long)2048 * D * sizeof(float); }
+
 extern "C" int omlm_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
-                                  const float* dres, float* dx, void* dxcast, float* dgamma, int M, int D,
+                                  const float* dres, float* dx, void* dxcast, float* dgamma, float* workspace, int M, int D,
                                   float dx_scale, int cast_dtype, void* stream) {
     if (M <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(dy && x && gamma && mean && rstd && dx, "null pointer");
     OMLM_CHECK_ARG(D % 4 == 0 && D <= 4 * LN_THREADS * LN_MAXV, "D must be a multiple of 4 and <= 4096");
-    dim3 grid(M < 512 ? M : 512), block(LN_THREADS);
+    // Each row is a dependent chain (load -> two block reductions -> load dres -> store), so the rate is set by the rows
+    // in flight.  With a workspace (omlm_layernorm_bwd_workspace_bytes) 2048 workgroups each leave one partial dgamma row
+    // for colsum; without it dgamma is accumulated with atomics, which only scale to 512 workgroups (2048: 194 -> 273 us).
+    const bool two_level = workspace != nullptr && dgamma != nullptr;
+    const int blocks = two_level ? (M < 2048 ? M : 2048) : (M < 512 ? M : 512);
+    dim3 grid(blocks), block(LN_THREADS);
+    float* part = two_level ? workspace : nullptr;
     if (cast_dtype == 0)
-        hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, block, 0, as_stream(stream), dy, x, gamma, mean, rstd, dres, dx, (float*)dxcast, dgamma, M, D, dx_scale);
+        hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, block, 0, as_stream(stream), dy, x, gamma, mean, rstd, dres, dx, (float*)dxcast, dgamma, part, M, D, dx_scale);
     else
-        hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, grid, block, 0, as_stream(stream), dy, x, gamma, mean, rstd, dres, dx, (bf16_t*)dxcast, dgamma, M, D, dx_scale);
-    return omlm_post_launch("omlm_layernorm_bwd");
+        hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, grid, block, 0, as_stream(stream), dy, x, gamma, mean, rstd, dres, dx, (bf16_t*)dxcast, dgamma, part, M, D, dx_scale);
+    int rc = omlm_post_launch("omlm_layernorm_bwd");
+    if (rc) return rc;
+    if (two_level) return omlm_colsum_accumulate(part, dgamma, blocks, D, D, stream);
+    return OMLM_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

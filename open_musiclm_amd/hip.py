@@ -26,7 +26,8 @@ SIGNATURES = {
     "omlm_set_error": [C.c_char_p],
     "omlm_gemm": [vp, vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp],
     "omlm_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp],
-    "omlm_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp],
+    "omlm_layernorm_bwd_workspace_bytes": [i32],
+    "omlm_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp],
     "omlm_qk_norm_fwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "omlm_qk_norm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "omlm_mqa_attn_fwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, vp],
@@ -56,7 +57,8 @@ SIGNATURES = {
     "omlm_sample_topk_gumbel": [vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
     "omlm_probe_tr16": [vp, vp],
 }
-_RESTYPES = {"omlm_last_error": C.c_char_p, "omlm_ffmid_bwd_workspace_bytes": C.c_longlong, "omlm_set_error": None}
+_RESTYPES = {"omlm_last_error": C.c_char_p, "omlm_ffmid_bwd_workspace_bytes": C.c_longlong,
+             "omlm_layernorm_bwd_workspace_bytes": C.c_longlong, "omlm_set_error": None}
 
 
 class HipLibraryMissing(RuntimeError):

@@ -60,11 +60,22 @@ def layernorm_fwd(x, gamma, y, xcast, mean, rstd, eps=1e-5):
          M, D, y.shape[-1], float(eps), dcode(y.dtype), stream_ptr())
 
 
+_LN_WS = {}
+
+
+def _ln_workspace(D: int, device) -> torch.Tensor:
+    key = (D, str(device))
+    if key not in _LN_WS:
+        _LN_WS[key] = torch.empty(int(hip.lib().omlm_layernorm_bwd_workspace_bytes(D)) // 4, device=device)
+    return _LN_WS[key]
+
+
 def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dx, dxcast, dgamma, dx_scale=1.0):
     M, D = x.shape
     code = dcode(dxcast.dtype) if dxcast is not None else F32
+    ws = _ln_workspace(D, x.device) if dgamma is not None else None       # stream-ordered reuse: one backward at a time
     call("omlm_layernorm_bwd", ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx),
-         ptr(dxcast), ptr(dgamma), M, D, float(dx_scale), code, stream_ptr())
+         ptr(dxcast), ptr(dgamma), ptr(ws), M, D, float(dx_scale), code, stream_ptr())
 
 
 def qk_norm_fwd(q_raw, kv_raw, q_scale, k_scale, q, k, v, H):
