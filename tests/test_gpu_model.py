@@ -287,6 +287,44 @@ def test_full_size_coarse_small_vs_oracle(dev, precision):
     assert max(g.values()) < tol["grad"], g
 
 
+@pytest.mark.parametrize("stage,lengths,N,kw", [("semantic", [1, 499], 514, {}),
+                                                 ("fine", [1, 150, 150], 1217, dict(num_coarse_quantizers=3, num_fine_quantizers=5))])
+def test_full_size_other_stages_forward_loss_vs_oracle(dev, stage, lengths, N, kw):
+    """BASELINE sequence shapes of the other two musiclm_small stages (semantic N = 514, fine N = 1217, 5 fine quantizers):
+    training-mode loss and final-sequence logits vs the CPU oracle, B = 1, default bf16 mode."""
+    from open_musiclm_amd import open_musiclm as M
+    from oracle import musiclm_oracle as O
+    torch.manual_seed(1)
+    # musiclm_small quantizer counts (configs/model/musiclm_small.json): 3 coarse, 5 fine; the factory defaults are 4 / 8
+    model = getattr(M, f"create_{stage}_transformer")(dim=1024, depth=6, heads=8, ff_dropout=0.0, precision="bf16", **kw).to(dev)
+    spec = getattr(O, f"{stage}_spec")(dim=1024, depth=6, heads=8)
+    assert [(s.codebook_size, s.num_quantizers) for s in spec.token_sequences] == \
+           [(s.codebook_size, s.num_quantizers) for s in model.token_sequences]
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ids = O.synthetic_ids(spec, 1, lengths, seed=4321)
+    nseq = len(ids)
+    w = [0.] * (nseq - 1) + [1.]
+    noise = torch.randn(1, N, generator=torch.Generator().manual_seed(11))
+    with torch.no_grad():
+        o_loss, o_logits, _ = O.wrapper_forward_loss(sd, spec, ids, w, forget_noise=noise)
+    import open_musiclm_amd.open_musiclm as MM
+    orig = MM.generate_mask_with_prob
+    MM.generate_mask_with_prob = lambda shape, p, device: O.forgetful_mask_from_noise(noise, p).to(device)
+    try:
+        wrapper = M.TokenConditionedTransformerWrapper(transformer=model, unique_consecutive=False,
+                                                       cross_entropy_loss_weights=w, mask_prob=0.15)
+        wrapper.train()
+        loss, logits, _ = wrapper(all_token_ids=[t.to(dev) for t in ids], return_loss=True)
+        loss.backward()
+    finally:
+        MM.generate_mask_with_prob = orig
+    assert logits[-1].shape == o_logits[-1].shape
+    e_inf, e_loss = relerr(logits[-1], o_logits[-1]), abs(float(loss) - float(o_loss)) / float(o_loss)
+    gfinite = all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    report(f"full_{stage}_small[bf16]", logits_inf=e_inf, loss=e_loss, N=N, grads_finite=gfinite)
+    assert e_inf < TOL["bf16"]["logits"] and e_loss < TOL["bf16"]["loss"] and gfinite
+
+
 def test_trainer_steps_and_checkpoint_roundtrip(dev, tmp_path):
     from open_musiclm_amd import open_musiclm as M
     from open_musiclm_amd.data import SyntheticTokenDataset
