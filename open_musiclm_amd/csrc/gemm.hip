@@ -438,7 +438,10 @@ __global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile
                     else
                         asm volatile("" :: "v"(a[s & 1][i]), "v"(b[s & 1][j]));
                     constexpr int MPS = MI * NJ, NLOAD = UA + UB;
-                    constexpr int STRIDE = (3 * MPS) / NLOAD > 0 ? (3 * MPS) / NLOAD : 1;
+#ifndef OMLM_DMA_SPREAD
+#define OMLM_DMA_SPREAD 3          /* k16 steps (of 4) over which the next tile's DMA issue is spread; tuned on the probe shapes */
+#endif
+                    constexpr int STRIDE = (OMLM_DMA_SPREAD * MPS) / NLOAD > 0 ? (OMLM_DMA_SPREAD * MPS) / NLOAD : 1;
                     const int midx = s * MPS + i * NJ + j;                    // compile-time after unrolling
                     if (midx % STRIDE == 0 && midx / STRIDE < NLOAD) {
                         const int l = midx / STRIDE;

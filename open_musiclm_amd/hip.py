@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libomlm_hip.so")
+LIB_PATH = os.environ.get("OMLM_LIB_PATH") or os.path.join(_HERE, "libomlm_hip.so")      # override: A/B builds while tuning
 
 _lib: Optional[C.CDLL] = None
 
