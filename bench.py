@@ -263,6 +263,16 @@ def main():
                     stage.generate(max_time_steps=tgt, **kw)
                     torch.cuda.synchronize()
                     res[f"{mode}_{label}"] = round(steps_new * 3 / (time.perf_counter() - t1), 2)
+            # batched decode (8 independent samples per step share every weight read): aggregate ids/s
+            clap8 = torch.randint(0, 1024, (8, 12, 1), generator=g).to(dev)
+            sem8 = torch.randint(0, 1024, (8, 199), generator=g).to(dev)
+            kw8 = dict(clap_token_ids=clap8, semantic_token_ids=sem8, use_cache=True)
+            stage.generate(max_time_steps=2, **kw8)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            stage.generate(max_time_steps=50, **kw8)
+            torch.cuda.synchronize()
+            res["kv_cache_batch8_empty_context"] = round(8 * 50 * 3 / (time.perf_counter() - t1), 2)
             out["ar_tokens_per_sec"] = res
             progress(f"decode {res}")
             stage.train()
