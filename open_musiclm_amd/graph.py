@@ -1,8 +1,8 @@
 """HIP-graph capture of one training micro-step (forward + backward).
 
-A coarse-small micro-step is ~500 kernel launches and ~600 buffer allocations issued from Python; on the GPU box
-the host needs 70-140 ms to enqueue what the GPU executes in ~70 ms, i.e. the step is launch-bound.  Shapes in
-training are static (fixed crops, data.py), so the whole micro-step -- id preparation, forgetful mask, weight
+A coarse-small micro-step is ~700 kernel launches and ~600 buffer allocations issued from Python (about 8 ms of host time
+for 37 ms of GPU work on the MI355X box; the early "launch-bound" diagnosis turned out to be a 49 ms stall inside the optimizer
+step).  Shapes in training are static (fixed crops, data.py), so the whole micro-step -- id preparation, forgetful mask, weight
 re-pack, embedding gather, trunk, heads, loss and the hand-written backward, all accumulating into the optimizer's
 flat gradient buffer -- is captured ONCE into a HIP graph through torch's stream capture and replayed with a single
 hipGraphLaunch.  Everything that varies per step lives in device memory: token ids (static input buffers),
@@ -21,9 +21,8 @@ class GraphedForwardBackward:
         """fn(**inputs) -> scalar loss (with autograd graph).  loss_scale multiplies the loss before backward
         (1 / grad_accum_every)."""
         self.fn, self.loss_scale, self.warmup_iters, self.enabled = fn, loss_scale, warmup_iters, enabled
-        # Two captured instances are replayed alternately: launching a graph exec while its previous launch is still
-        # running blocks the host until that one finishes (measured: 51 / 121 ms alternating hipGraphLaunch times),
-        # which serialises host enqueue and GPU execution.  With two instances launch k+1 overlaps execution k.
+        # Two captured instances are replayed alternately, so the launch of step k+1 never has to wait for the exec of
+        # step k (a graph exec cannot be launched again while its previous launch is still running).
         self.instances = max(1, instances)
         self.graphs = []
         self.graph: Optional[torch.cuda.CUDAGraph] = None
