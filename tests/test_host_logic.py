@@ -271,3 +271,22 @@ def test_data_parallel_exchange_world_size_2_gloo(tmp_path):
     outs = [p.communicate(timeout=180)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all("ok" in o for o in outs)
+
+
+def test_decode_args_struct_layout_matches_header(tmp_path):
+    """The ctypes mirror of omlm_decode_args (decode.py) has the size and field offsets a C compiler gives the header struct."""
+    import ctypes
+    import subprocess
+    from open_musiclm_amd import decode
+    fields = [f[0] for f in decode.DecodeArgs._fields_]
+    src = tmp_path / "layout.c"
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(ROOT, "include", "omlm.h")}"', 'int main(void) {',
+             '  printf("%zu\\n", sizeof(omlm_decode_args));']
+    lines += [f'  printf("%zu\\n", offsetof(omlm_decode_args, {f}));' for f in fields]
+    lines += ['  return 0; }']
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-o", str(exe), str(src)], check=True)
+    out = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert out[0] == ctypes.sizeof(decode.DecodeArgs)
+    assert out[1:] == [getattr(decode.DecodeArgs, f).offset for f in fields]
