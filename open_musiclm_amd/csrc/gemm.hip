@@ -364,7 +364,10 @@ __global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile
         ksplit = lg / nwg;
         bid = lg - ksplit * nwg;
     }
-    constexpr int GROUP = 1024 / BM_;                       // tile rows per super-tile (same footprint as the 128 kernel's 8)
+#ifndef OMLM_SUPER_ROWS
+#define OMLM_SUPER_ROWS 1024       /* C rows per super-tile (tile rows walked column-major inside it) */
+#endif
+    constexpr int GROUP = OMLM_SUPER_ROWS / BM_;                       // tile rows per super-tile (same footprint as the 128 kernel's 8)
     const int gsz = GROUP * tiles_n;
     const int grp = bid / gsz, first_m = grp * GROUP;
     const int rows_in = min(GROUP, tiles_m - first_m);
