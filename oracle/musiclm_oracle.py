@@ -252,6 +252,71 @@ def trunk(sd: Dict[str, Tensor], x: Tensor, key_mask: Optional[Tensor], spec: Mo
 
 
 # ----------------------------------------------------------------------------
+# KV-cached formulation of the trunk (checker for csrc/decode.hip)
+# ----------------------------------------------------------------------------
+# The reference has no cached decode (open_musiclm.py:301-321 re-runs the whole forward per id).  Because attention is
+# causal (:315-322), the depthwise conv only looks back 2 rows (:122-131) and LayerNorm is per row, row p of every layer
+# depends on rows <= p only.  trunk_cached_rows() computes new rows against
+#   K/V  : the l2-normalised, scaled keys and the values of the earlier rows of each layer,
+#   hist : the FF-in outputs of the two previous rows (state of the causal conv),
+# which is what the HIP decode kernels keep.  tests/test_oracle_golden.py checks it row by row against trunk().
+
+def new_trunk_cache(spec: ModelSpec, batch: int) -> Dict[str, list]:
+    return dict(k=[None] * spec.depth, v=[None] * spec.depth, hist=[None] * spec.depth, rows=0)
+
+
+def trunk_cached_rows(sd: Dict[str, Tensor], x_new: Tensor, cache: Dict[str, list], spec: ModelSpec,
+                      n_total: int, prefix: str = "transformer.") -> Tensor:
+    """x_new: [B, m, d] embeddings of rows cache['rows'] .. cache['rows'] + m - 1 (m = 1 in decode, m = prompt length in the
+    prefill).  n_total only sizes the rel-pos table (its entries do not depend on it).  Returns the final-LN hidden rows."""
+    b, m, _ = x_new.shape
+    h, dh = spec.heads, spec.dim_head
+    p0 = cache["rows"]
+    table = None
+    if spec.relative_position_bias_type == "continuous":
+        table = rel_pos_table_continuous(sd, prefix + "rel_pos_bias.", n_total)
+    elif spec.relative_position_bias_type == "t5":
+        table = rel_pos_table_t5(sd, prefix + "rel_pos_bias.", n_total)
+    x = x_new
+    for l in range(spec.depth):
+        ap, fp = f"{prefix}layers.{l}.0.", f"{prefix}layers.{l}.2."
+        xn = layer_norm(x, sd[ap + "norm.gamma"])
+        q = F.linear(xn, sd[ap + "to_q.weight"]).view(b, m, h, dh)
+        kv = F.linear(x, sd[ap + "to_kv.weight"])                    # un-normalised input, as in attention()
+        k_new, v_new = kv[..., :dh], kv[..., dh:]
+        q = q / q.norm(dim=-1, keepdim=True).clamp(min=1e-12) * sd[ap + "q_scale"]
+        k_new = k_new / k_new.norm(dim=-1, keepdim=True).clamp(min=1e-12) * sd[ap + "k_scale"]
+        k = k_new if cache["k"][l] is None else torch.cat([cache["k"][l], k_new], 1)
+        v = v_new if cache["v"][l] is None else torch.cat([cache["v"][l], v_new], 1)
+        cache["k"][l], cache["v"][l] = k, v
+        sim = torch.einsum("bihd,bjd->bhij", q, k) * spec.attn_scale  # [b, h, m, p0 + m]
+        i_idx = torch.arange(p0, p0 + m)[:, None]
+        j_idx = torch.arange(p0 + m)[None, :]
+        if table is not None:
+            sim = sim + table[:, (i_idx - j_idx).clamp(min=-(n_total - 1)) + n_total - 1]
+        sim = sim.masked_fill(j_idx > i_idx, -torch.finfo(sim.dtype).max)
+        out = torch.einsum("bhij,bjd->bihd", sim.softmax(-1), v).reshape(b, m, h * dh)
+        x = F.linear(out, sd[ap + "to_out.0.weight"]) + x
+        xn = layer_norm(x, sd[fp + "0.gamma"])
+        hdn = F.linear(xn, sd[fp + "1.weight"])
+        if spec.use_conv_ff:
+            prev = cache["hist"][l] if cache["hist"][l] is not None else torch.zeros(b, 2, hdn.shape[-1], dtype=hdn.dtype)
+            ext = torch.cat([prev, hdn], 1)                          # rows p0-2 .. p0+m-1
+            cache["hist"][l] = ext[:, -2:]
+            w = sd[fp + "2.ds_conv.weight"].reshape(-1, 3)
+            hdn = ext[:, :-2] * w[:, 0] + ext[:, 1:-1] * w[:, 1] + ext[:, 2:] * w[:, 2]
+            a, gate = hdn.chunk(2, dim=-1)
+            g = layer_norm(gelu_erf(gate) * a, sd[fp + "4.gamma"])
+            x = F.linear(g, sd[fp + "6.weight"]) + x
+        else:
+            a, gate = hdn.chunk(2, dim=-1)
+            g = layer_norm(gelu_erf(gate) * a, sd[fp + "3.gamma"])
+            x = F.linear(g, sd[fp + "5.weight"]) + x
+    cache["rows"] = p0 + m
+    return layer_norm(x, sd[prefix + "norm.gamma"])
+
+
+# ----------------------------------------------------------------------------
 # open_musiclm.py restatement
 # ----------------------------------------------------------------------------
 

@@ -109,3 +109,23 @@ def test_causality_prefix_property():
         short = full[:2] + [full[2][:, :5]]
         b = O.token_conditioned_forward(sd, spec, short, None, only_final=True)[-1]
     assert rel_err(b, a[:, : b.shape[1]]) < 1e-5
+
+
+@pytest.mark.parametrize("bias,conv", [("continuous", True), ("t5", False)])
+def test_cached_trunk_formulation_equals_full_forward(bias, conv):
+    """The KV-cache + conv-state formulation that csrc/decode.hip implements, restated in the oracle, reproduces the
+    reference-style full forward row by row (prefill of a prompt, then one row at a time)."""
+    from oracle import musiclm_oracle as O
+    spec = O.coarse_spec(dim=64, depth=3, heads=2, relative_position_bias_type=bias, use_conv_ff=conv)
+    sd = O.init_state_dict(spec, seed=3, dtype=torch.float64)
+    B, N, P = 2, 23, 9
+    x = torch.randn(B, N, spec.dim, dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        full = O.trunk(sd, x, None, spec)
+        cache = O.new_trunk_cache(spec, B)
+        rows = [O.trunk_cached_rows(sd, x[:, :P], cache, spec, N)]
+        for p in range(P, N):
+            rows.append(O.trunk_cached_rows(sd, x[:, p:p + 1], cache, spec, N))
+    got = torch.cat(rows, 1)
+    assert cache["rows"] == N and cache["k"][0].shape[1] == N
+    assert float((got - full).abs().max() / full.abs().max()) < 1e-10
