@@ -136,7 +136,10 @@ class FusedAdam(torch.optim.Optimizer):
         params = self._all_params()                     # the kernels wrote through raw pointers: tell autograd.
         # NB: _increment_version takes an ITERABLE of tensors; handing it one tensor iterates its rows (unbind), which
         # cost 49 ms of host time per step here before this was a single call on the list.
-        torch._C._increment_version(params)
+        if hasattr(torch._C, "_increment_version"):
+            torch._C._increment_version(params)
+        else:                                           # older torch: an in-place no-op bumps the counters
+            torch._foreach_add_(params, 0.0)
         for p in params:
             p._omlm_bf16_version = p._version           # the shadow written by this very kernel is current
         return None
