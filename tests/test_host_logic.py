@@ -290,3 +290,19 @@ def test_decode_args_struct_layout_matches_header(tmp_path):
     out = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     assert out[0] == ctypes.sizeof(decode.DecodeArgs)
     assert out[1:] == [getattr(decode.DecodeArgs, f).offset for f in fields]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/scripts"), reason="reference checkout not present (GPU box)")
+@pytest.mark.parametrize("script", ["train_semantic_stage", "train_coarse_stage", "train_fine_stage"])
+def test_reference_training_scripts_import_against_this_package(script):
+    """Drop-in boundary: the reference's own entry scripts resolve `open_musiclm.*` to this repository (alias package) and
+    get every name they import from it; `--help` stops before any GPU work."""
+    import subprocess
+    import sys
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    probe = ("import runpy, sys, open_musiclm; assert open_musiclm.__file__.startswith(%r), open_musiclm.__file__; "
+             "sys.argv = [%r, '--help']; runpy.run_path(%r, run_name='__main__')") % (
+                 ROOT, script, f"/root/reference/scripts/{script}.py")
+    r = subprocess.run([sys.executable, "-c", probe], cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "--model_config" in r.stdout
