@@ -12,8 +12,6 @@
 // HBM-bound: forward reads h1 once (the two halo rows come from L2) and writes h2; nothing but the
 // per-row LN statistics is saved -- the backward recomputes u and g from h1.
 #include "common.h"
-#include <stdlib.h>
-#include <string.h>
 
 #define FF_THREADS 256
 #define FF_MAXC_LIMIT 16   // 8-channel chunks per lane (wave-per-row kernels) -> Fp <= 8192
@@ -155,6 +153,11 @@ __device__ __forceinline__ void dropout8_from_bits(unsigned bits, float p, float
     for (int i = 0; i < 8; ++i) m[i] = ((bits >> i) & 1u) ? inv : 0.f;
 }
 
+// (A strip formulation -- a thread owns 8 channels for a strip of rows, taps and the conv halo in registers, h1 read once,
+// R rows requested together, LayerNorm statistics exchanged through LDS -- was built and measured at 400 us against this
+// kernel's 328 us, with or without a prefetched next batch: these kernels are VALU-bound (wave64 = 4 cycles per
+// instruction, quarter-rate exp / rcp / 64-bit mads), not latency-bound, and the strip form pays 4x the shuffles per row.
+// profiles/r01_ffmid_strip_ab.md; the code is in history at 36014b0.)
 // One WAVE per row: the row's F channels are spread over the 64 lanes in 8-channel chunks, the two LayerNorm
 // reductions are wave shuffles (no LDS, no barrier), and a 256-thread workgroup keeps 4 independent rows in
 // flight -- at ~4 waves/SIMD that is ~16 rows per CU hiding HBM latency, instead of one row per workgroup
@@ -257,148 +260,6 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffmid_fwd_kernel(const T* __res
                 }
                 o.store(h2 + (size_t)row * Fp + ch);
             }
-        }
-    }
-}
-
-// ---- forward, strip formulation -------------------------------------------------------------------------------------------
-// The wave-per-row kernel above is latency-bound: a wave has ONE row chunk of loads in flight (12 x 16 B per lane, half of
-// them row-invariant taps and a third L2-resident halo rows), its registers go to staging those, and at 2 waves per SIMD a
-// ~1.7 us load latency meets ~0.35 us of arithmetic per chunk (measured: 350 us for 0.6 GB of traffic and ~120 us of VALU work).
-// Here a THREAD owns 8 channels (of both halves) for a whole strip of consecutive rows, like the conv^T kernel below:
-//   * taps and gamma live in registers for the strip; the two halo rows are a rolling register window (h1 is read ONCE,
-//     nothing comes back from L1/L2 a second and third time);
-//   * the only loads are the new row's 2 x 16 B per thread, so R rows are requested at once (R x 2 KiB per wave in flight);
-//   * the workgroup spans the row (ceil(Fp / 512) waves); LayerNorm statistics of R rows are reduced together:
-//     wave shuffle + one LDS exchange per pass (mean, then centred second moment), two barriers per R rows.
-#ifndef FF_STRIP_R
-#define FF_STRIP_R 3               /* rows requested and reduced together */
-#endif
-#ifndef FF_STRIP_MINB
-#define FF_STRIP_MINB 3            /* workgroups per CU the register budget is sized for (NT <= 512) */
-#endif
-template <typename T, int R, int NT, bool PF>
-__global__ __launch_bounds__(NT, (NT <= 512 ? FF_STRIP_MINB : 1)) void ffmid_fwd_strip_kernel(const T* __restrict__ h1, const T* __restrict__ convw,
-                                                              const T* __restrict__ gamma, T* __restrict__ h2,
-                                                              float* __restrict__ mean, float* __restrict__ rstd,
-                                                              int M, int nseq, int F, int Fp, float eps, float p,
-                                                              unsigned long long seed, const unsigned long long* __restrict__ seed_dev,
-                                                              unsigned char* __restrict__ drop_bits, int rows_per) {
-    if (seed_dev) seed += seed_dev[0] * 0x9E3779B97F4A7C15ull;
-    __shared__ float red[2][R][16];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int ch = threadIdx.x * 8;
-    const bool active = ch < Fp;
-    const int nv = active ? max(0, min(8, F - ch)) : 0;                 // real channels of this thread (pad columns carry zeros)
-    const int ld = 2 * Fp;
-    const int r0 = blockIdx.x * rows_per, r1 = min(M, r0 + rows_per);
-    if (r0 >= r1) return;
-    float wx[3][8], wg[3][8], gm[8];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        vec8<T> a, b;
-        if (active) { a.load(convw + (size_t)k * ld + ch); b.load(convw + (size_t)k * ld + Fp + ch); } else { zero8(a.v); zero8(b.v); }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { wx[k][i] = a.v[i]; wg[k][i] = b.v[i]; }
-    }
-    {
-        vec8<T> a;
-        if (active) a.load(gamma + ch); else zero8(a.v);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) gm[i] = a.v[i];
-    }
-    // rolling window: (xa, ga) = row - 2, (xb, gb) = row - 1 of the current sample (zeros before its first row)
-    float xa[8], xb[8], ga[8], gb[8];
-    zero8(xa); zero8(xb); zero8(ga); zero8(gb);
-    {
-        const int t0 = r0 % nseq;
-        if (active && t0 >= 1) { vec8<T> a, b; a.load(h1 + (size_t)(r0 - 1) * ld + ch); b.load(h1 + (size_t)(r0 - 1) * ld + Fp + ch);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { xb[i] = a.v[i]; gb[i] = b.v[i]; } }
-        if (active && t0 >= 2) { vec8<T> a, b; a.load(h1 + (size_t)(r0 - 2) * ld + ch); b.load(h1 + (size_t)(r0 - 2) * ld + Fp + ch);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { xa[i] = a.v[i]; ga[i] = b.v[i]; } }
-    }
-    const float invF = 1.0f / (float)F;
-    raw8<T> lx[R], lg[R], nx[R], ng[R];
-    auto request = [&](raw8<T> (&bx)[R], raw8<T> (&bg)[R], int rbase) {
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-            const int row = rbase + j;
-            if (active && row < r1) { bx[j].load(h1 + (size_t)row * ld + ch); bg[j].load(h1 + (size_t)row * ld + Fp + ch); }
-            else { bx[j].zero(); bg[j].zero(); }
-        }
-    };
-    if (PF) request(lx, lg, r0);
-    for (int rb = r0; rb < r1; rb += R) {
-        // PF: the NEXT batch is requested before this one is computed (a workgroup walks its strip serially, and with two
-        // workgroups per CU nothing else covers the ~1.7 us load latency)
-        if (PF) request(nx, ng, rb + R); else request(lx, lg, rb);
-        float gv[R][8], mu[R], rs[R];
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-            const int t = (rb + j) % nseq;
-            if (t == 0) { zero8(xa); zero8(xb); zero8(ga); zero8(gb); }            // a new sample starts: no history
-            float xc[8], gc[8];
-            lx[j].unpack(xc); lg[j].unpack(gc);
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float ux = wx[0][i] * xa[i] + wx[1][i] * xb[i] + wx[2][i] * xc[i];
-                const float ug = wg[0][i] * ga[i] + wg[1][i] * gb[i] + wg[2][i] * gc[i];
-                gv[j][i] = gelu_f(ug) * ux;
-                if (i < nv) s += gv[j][i];
-                xa[i] = xb[i]; xb[i] = xc[i]; ga[i] = gb[i]; gb[i] = gc[i];
-            }
-            s = wave_sum(s);
-            if (lane == 0) red[0][j][wave] = s;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-            float s = 0.f;
-            for (int w = 0; w < nw; ++w) s += red[0][j][w];
-            mu[j] = s * invF;
-            float q = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) if (i < nv) { const float d = gv[j][i] - mu[j]; q += d * d; }
-            q = wave_sum(q);
-            if (lane == 0) red[1][j][wave] = q;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-            const int row = rb + j;
-            float q = 0.f;
-            for (int w = 0; w < nw; ++w) q += red[1][j][w];
-            rs[j] = rsqrtf(q * invF + eps);
-            if (row < r1) {
-                if (threadIdx.x == 0) { mean[row] = mu[j]; rstd[row] = rs[j]; }
-                if (active) {
-                    float m[8];
-                    if (p > 0.f) {
-                        dropout8(seed, (unsigned long long)row * Fp + ch, p, m);
-                        if (drop_bits) {
-                            unsigned bits = 0;
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) bits |= (m[i] != 0.f ? 1u : 0u) << i;
-                            drop_bits[(size_t)row * (Fp >> 3) + (ch >> 3)] = (unsigned char)bits;
-                        }
-                    }
-                    vec8<T> o;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        float y = (gv[j][i] - mu[j]) * rs[j] * gm[i];
-                        if (p > 0.f) y *= m[i];
-                        o.v[i] = y;
-                    }
-                    o.store(h2 + (size_t)row * Fp + ch);
-                }
-            }
-        }
-        if (PF) {
-#pragma unroll
-            for (int j = 0; j < R; ++j) { lx[j] = nx[j]; lg[j] = ng[j]; }
         }
     }
 }
@@ -628,26 +489,6 @@ extern "C" int omlm_ffmid_fwd(const void* h1, const void* convw, const void* gam
         (void)hipFuncSetAttribute((const void*)ffmid_fwd_kernel<float, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)ffmid_fwd_kernel<bf16_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)ffmid_fwd_kernel<bf16_t, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
-    {
-        // strip formulation (see ffmid_fwd_strip_kernel); OMLM_FFMID_FWD=row selects the wave-per-row kernel
-        const char* impl = getenv("OMLM_FFMID_FWD");
-        if (!(impl && !strcmp(impl, "row"))) {
-            const int nchunk = Fp / 8, nthreads = ((nchunk + 63) / 64) * 64;
-            const char* e = getenv("OMLM_FFMID_STRIPS");
-            int strips = e && atoi(e) > 0 ? atoi(e) : 1024;
-            int rows_per = (M + strips - 1) / strips; if (rows_per < 4) rows_per = 4;
-            strips = (M + rows_per - 1) / rows_per;
-#define FF_STRIP(T_, NT_, R_, PF_) hipLaunchKernelGGL((ffmid_fwd_strip_kernel<T_, R_, NT_, PF_>), dim3(strips), dim3(NT_), 0, st, (const T_*)h1, (const T_*)convw, (const T_*)gamma, (T_*)h2, mean, rstd, M, nseq, F, Fp, eps, p, seed, seed_dev, drop_bits, rows_per)
-#define FF_STRIP_NT(T_, R_, PF_) do { \
-        if (nthreads <= 128) FF_STRIP(T_, 128, R_, PF_); else if (nthreads <= 256) FF_STRIP(T_, 256, R_, PF_); else if (nthreads <= 384) FF_STRIP(T_, 384, R_, PF_); \
-        else if (nthreads <= 512) FF_STRIP(T_, 512, R_, PF_); else if (nthreads <= 768) FF_STRIP(T_, 768, R_, PF_); else FF_STRIP(T_, 1024, R_, PF_); } while (0)
-            const char* ev = getenv("OMLM_FFMID_STRIP_VARIANT");       // "r3" (no prefetch), "r2pf", "r3pf"
-            const int variant = !ev ? 0 : (!strcmp(ev, "r2pf") ? 1 : (!strcmp(ev, "r3pf") ? 2 : 0));
-#define FF_STRIP_DISPATCH(T_) do { if (variant == 1) FF_STRIP_NT(T_, 2, true); else if (variant == 2) FF_STRIP_NT(T_, 3, true); else FF_STRIP_NT(T_, 3, false); } while (0)
-            if (dtype == 0) FF_STRIP_DISPATCH(float); else FF_STRIP_DISPATCH(bf16_t);
-            return omlm_post_launch("omlm_ffmid_fwd");
-        }
     }
 #define FF_FWD(T_, MC_) hipLaunchKernelGGL((ffmid_fwd_kernel<T_, MC_>), grid, block, lds_fwd, st, (const T_*)h1, (const T_*)convw, (const T_*)gamma, (T_*)h2, mean, rstd, M, nseq, F, Fp, eps, p, seed, seed_dev, drop_bits)
 #define FF_FWD_DISPATCH(T_) do { const int mc = (Fp / 8 + 63) / 64; \

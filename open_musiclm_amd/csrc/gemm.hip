@@ -545,198 +545,6 @@ __global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile
     tile_epilogue<MI, NJ, WN_, TOUT>(g, acc, smem, m0, n0, wm, wn, wave, lane, dbg);
 }
 
-// ---- 256x256 NT tile, quadrant-phased schedule ("q8"; EXPERIMENTAL, OMLM_GEMM_Q8=1) -------------------------------------
-// Same tile, LDS images, fragments and epilogue as gemm_bf16_tile_kernel<256,256,128,64> for two k-contiguous operands, but
-// a different k-loop.  The tile kernel above has one barrier per k-tile that drains vmcnt(0), and every wave alternates
-// between "read fragments" and "multiply" on its own; here the 8 waves form two groups (wave rows 0 / 1 = the two waves
-// that share a SIMD) that run ONE program one slot apart, so that while one group reads LDS the other one owns the matrix
-// pipe.  A k-tile is 4 phases x (read slot, multiply slot); phase (qa, qb) multiplies the wave's C quadrant
-// rows 64 qa.., cols 32 qb.. over the whole k-tile (8 MFMAs), in the order (0,0) (0,1) (1,1) (1,0) so that each phase
-// loads only the operand quarter that changed (24 ds_read_b128 per wave per k-tile, as before).
-//
-// LDS holds two k-tiles; a quarter of an operand is dead as soon as its one read slot is over:
-//     A(wave row 0, qa 0) after slot 0   A(1, 0), B(., qb 0) after slot 1   B(., 1) after slot 3   A(0, 1) after 4   A(1, 1) after 5
-// (global slot numbers inside the k-tile; group 1 runs local slot s at global s + 1).  Each wave issues ONE 1-KiB DMA unit
-// per slot, for k-tile t+2, into the quarter that died longest ago:
-//     slot 0: A(1,1) of t+1   1: A(0,0)   2: A(1,0)   3,4: B(.,0)   5,6: B(.,1)   7: A(0,1)
-// so every unit is at least 12 slots old when it is first read, `s_waitcnt vmcnt(8)` in every read slot (one unit per slot
-// per wave -> "everything issued 8 or more slots ago has landed") followed by that slot's barrier is the only
-// synchronisation the data path needs, and the DMA queue never holds more than ~9 KiB per wave.
-#define OMLM_Q8_BAR()                                                                                                      \
-    do {                                                                                                                    \
-        asm volatile("" ::: "memory");                                                                                     \
-        __builtin_amdgcn_sched_barrier(0);                                                                                  \
-        __builtin_amdgcn_s_barrier();                                                                                       \
-        __builtin_amdgcn_sched_barrier(0);                                                                                  \
-        asm volatile("" ::: "memory");                                                                                     \
-    } while (0)
-#ifndef OMLM_Q8_VMCNT
-#define OMLM_Q8_VMCNT 8            /* 0 = drain every DMA unit in every read slot (checks the counted-wait reasoning) */
-#endif
-#define OMLM_Q8_STR2(x) #x
-#define OMLM_Q8_STR(x) OMLM_Q8_STR2(x)
-#define OMLM_Q8_WAIT_READ() asm volatile("s_waitcnt vmcnt(" OMLM_Q8_STR(OMLM_Q8_VMCNT) ") lgkmcnt(0)" ::: "memory")
-
-template <typename TOUT>
-__global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmArgs g) {
-    constexpr int A_BYTES = 256 * BK * 2, STAGE = 2 * A_BYTES;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 k-tiles][A 256 x 64 | B 256 x 64], normal images
-
-    const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + 255) / 256;
-    const int nwg = tiles_m * tiles_n;
-    int bid;
-    {
-        const int lin = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = lin & 7, idx = lin >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    constexpr int GROUP = OMLM_SUPER_ROWS / 256;
-    const int gsz = GROUP * tiles_n;
-    const int grp = bid / gsz, first_m = grp * GROUP;
-    const int rows_in = min(GROUP, tiles_m - first_m);
-    const int tm = first_m + (bid - grp * gsz) % rows_in, tn = (bid - grp * gsz) / rows_in;
-    const int m0 = tm * 256, n0 = tn * 256;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-    const int wm = wr * 128, wn = wc * 64;
-
-    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(g.A, (unsigned long long)g.a_rows * g.lda * 2);
-    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(g.B, (unsigned long long)g.b_rows * g.ldb * 2);
-
-    // DMA units (8 rows x 64 k = 1 KiB, one wave-instruction).  A unit i of this wave: rows 8 wave + 64 i = quarter
-    // (wave row i >> 1, qa i & 1).  B unit i: wave column wave >> 1, qb i & 1, 8-row piece 2 (wave & 1) + (i >> 1) of the quarter.
-    unsigned baseA[4], baseB[4];
-    int kA[4], kB[4], ldsA[4], ldsB[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int bA = wave + 8 * i;
-        const int bB = (wave >> 1) * 8 + (i & 1) * 4 + 2 * (wave & 1) + (i >> 1);
-        {
-            const int row = 8 * bA + (lane >> 3), kc = (lane & 7) ^ ((row >> 1) & 7), gr = m0 + row;
-            const bool ok = gr < g.M;
-            const long long pr = (ok && g.a_map) ? (long long)g.a_map[gr] : (long long)gr;
-            baseA[i] = ok ? (unsigned)((pr * g.lda + kc * 8) * 2) : OOB_OFF;
-            kA[i] = kc * 8;
-            ldsA[i] = bA * 1024;
-        }
-        {
-            const int row = 8 * bB + (lane >> 3), kc = (lane & 7) ^ ((row >> 1) & 7), gr = n0 + row;
-            const bool ok = gr < g.N;
-            const long long pr = (ok && g.b_map) ? (long long)g.b_map[gr] : (long long)gr;
-            baseB[i] = ok ? (unsigned)((pr * g.ldb + kc * 8) * 2) : OOB_OFF;
-            kB[i] = kc * 8;
-            ldsB[i] = A_BYTES + bB * 1024;
-        }
-    }
-    auto dma = [&](const __amdgpu_buffer_rsrc_t rs, unsigned base, int kidx, int k0, bool live, char* dst) {
-        const unsigned off = (live && base != OOB_OFF && k0 + kidx < g.K) ? base + (unsigned)(k0 * 2) : OOB_OFF;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(void, dst), 16, (int)off, 0, 0, 0);
-    };
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const int kt0 = 0, kt1 = (g.K + BK - 1) / BK;
-    // prologue: k-tile 0 whole, k-tile 1 except A(1,1) (slot 0 of the first iteration issues that one)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        dma(rsA, baseA[i], kA[i], 0, true, smem + ldsA[i]);
-        dma(rsB, baseB[i], kB[i], 0, true, smem + ldsB[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (i < 3) dma(rsA, baseA[i], kA[i], BK, kt1 > 1, smem + STAGE + ldsA[i]);
-        dma(rsB, baseB[i], kB[i], BK, kt1 > 1, smem + STAGE + ldsB[i]);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (wr == 1) OMLM_Q8_BAR();                   // group 1 runs one slot behind group 0
-
-    bf16x8 fa[2][4], fb0[4], fb1[4];
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int cur = (kt - kt0) & 1;
-        char* S0 = smem + cur * STAGE;            // k-tile kt (being consumed; dead quarters receive k-tile kt + 2)
-        char* S1 = smem + (cur ^ 1) * STAGE;      // k-tile kt + 1
-        const bool live1 = kt + 1 < kt1, live2 = kt + 2 < kt1;
-        const int k1 = (kt + 1) * BK, k2 = (kt + 2) * BK;
-        const char* As = S0;
-        const char* Bs = S0 + A_BYTES;
-#define OMLM_Q8_READ_A(QA)                                                                                                 \
-        _Pragma("unroll") for (int ib = 0; ib < 2; ++ib)                                                                    \
-            _Pragma("unroll") for (int s = 0; s < 4; ++s) fa[ib][s] = read_frag<false>(As, wm + 64 * (QA) + 32 * ib, s, lane)
-#define OMLM_Q8_READ_B(FB, QB)                                                                                             \
-        _Pragma("unroll") for (int s = 0; s < 4; ++s) FB[s] = read_frag<false>(Bs, wn + 32 * (QB), s, lane)
-#define OMLM_Q8_MM(QA, FB, QB)                                                                                             \
-        _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                                       \
-            _Pragma("unroll") for (int ib = 0; ib < 2; ++ib)                                                                \
-                acc[2 * (QA) + ib][QB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ib][s], FB[s], acc[2 * (QA) + ib][QB], 0, 0, 0)
-        // slot 0: read A(qa 0), B(qb 0)
-        OMLM_Q8_READ_A(0);
-        OMLM_Q8_READ_B(fb0, 0);
-        dma(rsA, baseA[3], kA[3], k1, live1, S1 + ldsA[3]);
-        OMLM_Q8_WAIT_READ();
-        OMLM_Q8_BAR();
-        // slot 1: multiply (0, 0)
-        OMLM_Q8_MM(0, fb0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        dma(rsA, baseA[0], kA[0], k2, live2, S0 + ldsA[0]);
-        OMLM_Q8_BAR();
-        // slot 2: read B(qb 1)
-        OMLM_Q8_READ_B(fb1, 1);
-        dma(rsA, baseA[2], kA[2], k2, live2, S0 + ldsA[2]);
-        OMLM_Q8_WAIT_READ();
-        OMLM_Q8_BAR();
-        // slot 3: multiply (0, 1)
-        OMLM_Q8_MM(0, fb1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        dma(rsB, baseB[0], kB[0], k2, live2, S0 + ldsB[0]);
-        OMLM_Q8_BAR();
-        // slot 4: read A(qa 1)
-        OMLM_Q8_READ_A(1);
-        dma(rsB, baseB[2], kB[2], k2, live2, S0 + ldsB[2]);
-        OMLM_Q8_WAIT_READ();
-        OMLM_Q8_BAR();
-        // slot 5: multiply (1, 1)
-        OMLM_Q8_MM(1, fb1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        dma(rsB, baseB[1], kB[1], k2, live2, S0 + ldsB[1]);
-        OMLM_Q8_BAR();
-        // slot 6: nothing to read (B(qb 0) is still in registers)
-        dma(rsB, baseB[3], kB[3], k2, live2, S0 + ldsB[3]);
-        OMLM_Q8_WAIT_READ();
-        OMLM_Q8_BAR();
-        // slot 7: multiply (1, 0)
-        OMLM_Q8_MM(1, fb0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        dma(rsA, baseA[1], kA[1], k2, live2, S0 + ldsA[1]);
-        OMLM_Q8_BAR();
-#undef OMLM_Q8_READ_A
-#undef OMLM_Q8_READ_B
-#undef OMLM_Q8_MM
-    }
-    if (wr == 0) OMLM_Q8_BAR();
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __syncthreads();
-    tile_epilogue<4, 2, 64, TOUT>(g, acc, smem, m0, n0, wm, wn, wave, lane, 0);
-}
-
-template <typename TOUT>
-static int launch_q8(const GemmArgs& g, hipStream_t st) {
-    constexpr size_t LDS = 2 * (size_t)(256 + 256) * BK * 2;
-    const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
-    auto kfn = gemm_bf16_q8_kernel<TOUT>;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); attr = true; }
-    hipLaunchKernelGGL(kfn, dim3(tiles, 1), dim3(512), LDS, st, g);
-    return omlm_post_launch("omlm_gemm");
-}
-
 template <int BM_, int BN_, int WM_, int WN_, typename TOUT>
 static int launch_tile(const GemmArgs& g, int a_kmaj, int b_kmaj, int splits, hipStream_t st) {
     constexpr int NTH = (BM_ / WM_) * (BN_ / WN_) * 64;
@@ -858,14 +666,7 @@ extern "C" int omlm_gemm(const void* A, const void* B, void* C, const float* Cin
         OMLM_CHECK_ARG(out_dtype == 0, "fp32 operands produce fp32 output");
         return launch_layout<float, float>(g, a_kmajor, b_kmajor, splits, st);
     }
-    const bool use_w4 = [] { const char* e = getenv("OMLM_GEMM_W4"); return e && atoi(e) > 0; }();   // experimental: 4 waves of 128x128 (accumulators in AGPRs)
-    const bool use_q8 = [] { const char* e = getenv("OMLM_GEMM_Q8"); return e && atoi(e) > 0; }();   // experimental schedule, see gemm_bf16_q8_kernel
     auto launch = [&](const GemmArgs& ga, int tm_, int tn_, int sp) -> int {
-        if (tm_ == 256 && tn_ == 256 && use_q8 && sp == 1 && !a_kmajor && !b_kmajor)
-            return out_dtype == 0 ? launch_q8<float>(ga, st) : launch_q8<bf16_t>(ga, st);
-        if (tm_ == 256 && tn_ == 256 && use_w4)
-            return out_dtype == 0 ? launch_tile<256, 256, 128, 128, float>(ga, a_kmajor, b_kmajor, sp, st)
-                                  : launch_tile<256, 256, 128, 128, bf16_t>(ga, a_kmajor, b_kmajor, sp, st);
         if (tm_ == 256 && tn_ == 256)
             return out_dtype == 0 ? launch_tile<256, 256, 128, 64, float>(ga, a_kmajor, b_kmajor, sp, st)
                                   : launch_tile<256, 256, 128, 64, bf16_t>(ga, a_kmajor, b_kmajor, sp, st);
