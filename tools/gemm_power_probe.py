@@ -26,13 +26,9 @@ data = {
     "randn": (torch.randn(M, K, generator=g).to(dev).bfloat16(), torch.randn(N, K, generator=g).to(dev).bfloat16()),
 }
 tf = 2.0 * M * N * K / 1e6
-for variant in ("tile", "w4", "q8"):
-    os.environ["OMLM_GEMM_Q8"] = "1" if variant == "q8" else "0"
-    os.environ["OMLM_GEMM_W4"] = "1" if variant == "w4" else "0"
-    for name, (A, B) in data.items():
-        t = timeit(A, B)
-        print(f"{variant:5s} data={name:6s} {t:8.1f} us {tf / t:7.1f} TF", flush=True)
-os.environ["OMLM_GEMM_Q8"] = "0"; os.environ["OMLM_GEMM_W4"] = "0"
+for name, (A, B) in data.items():
+    t = timeit(A, B)
+    print(f"data={name:6s} {t:8.1f} us {tf / t:7.1f} TF", flush=True)
 A, B = data["randn"]
 for dbg, label in ((0, "full"), (1, "no DMA (reads+MFMA+epi)"), (3, "no DMA, no MFMA (reads+epi)"), (2, "no MFMA (DMA+reads+epi)"),
                    (8, "DMA + barriers only + epi"), (9, "barriers + epi"), (4, "no epilogue")):
