@@ -132,7 +132,7 @@ template <typename T> struct Bwd1In {
 
 // keep-mask * 1/(1-p) for 8 consecutive elements starting at element index e0 (multiple of 8).  ONE Philox-4x32-10 call per
 // 8 elements: each element gets a 16-bit draw (keep iff draw >= p * 65536).  The first version spent a 24-bit draw per
-// element = two calls per chunk, ~200 of the ~560 VALU instructions a row-chunk of the forward costs.
+// element = two calls per chunk, ~140 of the ~560 VALU instructions a row-chunk of the forward costs (350 -> 328 us).
 __device__ __forceinline__ void dropout8(unsigned long long seed, unsigned long long e0, float p, float* m) {
     const float inv = 1.0f / (1.0f - p);
     const unsigned thr = (unsigned)(p * 65536.0f + 0.5f);
@@ -155,8 +155,8 @@ __device__ __forceinline__ void dropout8_from_bits(unsigned bits, float p, float
 
 // (A strip formulation -- a thread owns 8 channels for a strip of rows, taps and the conv halo in registers, h1 read once,
 // R rows requested together, LayerNorm statistics exchanged through LDS -- was built and measured at 400 us against this
-// kernel's 328 us, with or without a prefetched next batch: these kernels are VALU-bound (wave64 = 4 cycles per
-// instruction, quarter-rate exp / rcp / 64-bit mads), not latency-bound, and the strip form pays 4x the shuffles per row.
+// kernel's 328 us, with or without a prefetched next batch: with the memory side out of the way the kernel is no faster,
+// i.e. what is left is instruction issue (~560 VALU per 8-channel chunk), and the strip form pays 4x the shuffles per row.
 // profiles/r01_ffmid_strip_ab.md; the code is in history at 36014b0.)
 // One WAVE per row: the row's F channels are spread over the 64 lanes in 8-channel chunks, the two LayerNorm
 // reductions are wave shuffles (no LDS, no barrier), and a 256-thread workgroup keeps 4 independent rows in
