@@ -73,8 +73,8 @@ int omlm_mqa_attn_bwd(const void* q, const void* k, const void* v, const float* 
  * h1: [M, 2*Fp] (value half cols [0,F), gate half cols [Fp, Fp+F)); h2: [M, Fp]; convw: taps re-packed tap-major and
  * padded, [3, 2*Fp] in h1's column layout (from the reference ds_conv.weight [2F,1,3]); gamma padded to [Fp] with zeros; both in
  * the operand dtype of h1 (they are re-read by every row, so in bf16 mode they travel as bf16 like every other operand);
- * dconv is accumulated in the reference layout [2F, 3].  rows are b*nseq + t.  Dropout mask = Philox(seed', element index)
- * with seed' = seed + *seed_dev * golden-ratio (seed_dev optional device word: lets a captured HIP graph draw a new mask
+ * dconv is accumulated in the reference layout [2F, 3].  rows are b*nseq + t.  Dropout mask = Philox-4x32-10(seed', element
+ * index / 8): one 16-bit draw per element, kept iff draw >= p * 65536; seed' = seed + *seed_dev * golden-ratio (seed_dev optional device word: lets a captured HIP graph draw a new mask
  * on every replay).  drop_bits (optional, [M, Fp/8] bytes): the forward stores the keep-mask, 1 bit per element, and the
  * backward reads it instead of regenerating it (null: the backward regenerates the mask from the same (seed, salt) pair). */
 int omlm_ffmid_fwd(const void* h1, const void* convw, const void* gamma, void* h2, float* mean, float* rstd,

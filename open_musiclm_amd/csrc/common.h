@@ -111,14 +111,6 @@ __device__ __forceinline__ void philox4x32(unsigned c0, unsigned c1, unsigned c2
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
-// uniform in [0,1) for element index e (one Philox call serves 4 consecutive elements)
-__device__ __forceinline__ float dropout_uniform(unsigned long long seed, unsigned long long e) {
-    unsigned o[4];
-    unsigned long long blk = e >> 2;
-    philox4x32((unsigned)blk, (unsigned)(blk >> 32), 0u, 0u, (unsigned)seed, (unsigned)(seed >> 32), o);
-    return (float)(o[e & 3] >> 8) * (1.0f / 16777216.0f);
-}
-
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned long long bytes) {
     unsigned n = bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)bytes;
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)n, 0x00020000);
