@@ -49,9 +49,30 @@ __device__ __forceinline__ void zero8(float* v) {
 
 // erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. fp32 rounding level for GELU) -- ~12 VALU + one v_exp
 // instead of libm erff's ~60: these kernels were VALU-bound on it.
+// FF_FAST_RCP=1: v_rcp_f32 (1 ulp) instead of __frcp_rn, which hipcc expands to the full IEEE division sequence
+// (v_div_scale x2, v_rcp, 4 fma, v_div_fmas, v_div_fixup: 80 of the 433 VALU instructions of a forward row-chunk, seen in the
+// ISA after the last GPU session of round 1).  The argument is >= 1, the change in erf is below its 1.5e-7 approximation
+// error; off until the parity tests have run with it on the GPU.
+#ifndef FF_FAST_RCP
+#define FF_FAST_RCP 0
+#endif
+__device__ __forceinline__ float ff_rcp(float x) {
+#if FF_FAST_RCP
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return __frcp_rn(x);
+#endif
+}
+__device__ __forceinline__ float ff_div(float a, float b) {       // same switch for the Welford quotients (benign: see welford_merge)
+#if FF_FAST_RCP
+    return a * __builtin_amdgcn_rcpf(b);
+#else
+    return a / b;
+#endif
+}
 __device__ __forceinline__ float fast_erf(float x) {
     const float ax = fabsf(x);
-    const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+    const float t = ff_rcp(1.0f + 0.3275911f * ax);
     const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
     return copysignf(1.0f - poly * __expf(-ax * ax), x);
 }
@@ -166,7 +187,7 @@ __device__ __forceinline__ void dropout8_from_bits(unsigned bits, float p, float
 __device__ __forceinline__ void welford_merge(float& n, float& mean, float& m2, float nb, float meanb, float m2b) {
     const float nt = n + nb;
     if (nt > 0.f) {
-        const float d = meanb - mean, r = nb / nt;
+        const float d = meanb - mean, r = ff_div(nb, nt);   // a 1-ulp error in r or in a chunk mean only moves the pivot of an exact identity
         mean += d * r;
         m2 += m2b + d * d * n * r;
     }
@@ -212,7 +233,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffmid_fwd_kernel(const T* __res
                 for (int i = 0; i < 8; ++i) { gv[i] = gelu_f(ug[i]) * ux[i]; if (i < nv) cs += gv[i]; }
                 ((float4*)(gl + ch))[0] = make_float4(gv[0], gv[1], gv[2], gv[3]);
                 ((float4*)(gl + ch))[1] = make_float4(gv[4], gv[5], gv[6], gv[7]);
-                const float cm = cs / (float)nv;
+                const float cm = ff_div(cs, (float)nv);
                 float c2 = 0.f;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) if (i < nv) { const float d = gv[i] - cm; c2 += d * d; }
