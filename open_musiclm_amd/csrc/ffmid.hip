@@ -63,7 +63,7 @@ __device__ __forceinline__ float ff_rcp(float x) {
     return __frcp_rn(x);
 #endif
 }
-__device__ __forceinline__ float ff_div(float a, float b) {       // same switch for the Welford quotients (benign: see welford_merge)
+__device__ __forceinline__ float ff_div(float a, float b) {       // same switch for the Welford quotients
 #if FF_FAST_RCP
     return a * __builtin_amdgcn_rcpf(b);
 #else
@@ -187,7 +187,7 @@ __device__ __forceinline__ void dropout8_from_bits(unsigned bits, float p, float
 __device__ __forceinline__ void welford_merge(float& n, float& mean, float& m2, float nb, float meanb, float m2b) {
     const float nt = n + nb;
     if (nt > 0.f) {
-        const float d = meanb - mean, r = ff_div(nb, nt);   // a 1-ulp error in r or in a chunk mean only moves the pivot of an exact identity
+        const float d = meanb - mean, r = ff_div(nb, nt);   // (FF_FAST_RCP: a 1-ulp error in r enters mean / M2 at the 1e-7 relative level)
         mean += d * r;
         m2 += m2b + d * d * n * r;
     }
