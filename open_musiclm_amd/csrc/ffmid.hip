@@ -49,12 +49,12 @@ __device__ __forceinline__ void zero8(float* v) {
 
 // erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. fp32 rounding level for GELU) -- ~12 VALU + one v_exp
 // instead of libm erff's ~60: these kernels were VALU-bound on it.
-// FF_FAST_RCP=1: v_rcp_f32 (1 ulp) instead of __frcp_rn, which hipcc expands to the full IEEE division sequence
-// (v_div_scale x2, v_rcp, 4 fma, v_div_fmas, v_div_fixup: 80 of the 433 VALU instructions of a forward row-chunk, seen in the
-// ISA after the last GPU session of round 1).  The argument is >= 1, the change in erf is below its 1.5e-7 approximation
-// error; off until the parity tests have run with it on the GPU.
+// v_rcp_f32 (1 ulp) instead of __frcp_rn / '/', which hipcc expands to the full IEEE division sequence (v_div_scale x2, v_rcp,
+// 4 fma, v_div_fmas, v_div_fixup: 164 of the 958 static VALU instructions of the forward, found in the ISA).  The erf argument
+// is >= 1 and the change is below the 1.5e-7 approximation error: the kernel parity tests report the same errors to all
+// printed digits with either build; forward 328 -> 304 us at the bench shape.  FF_FAST_RCP=0 restores the exact quotients.
 #ifndef FF_FAST_RCP
-#define FF_FAST_RCP 0
+#define FF_FAST_RCP 1
 #endif
 __device__ __forceinline__ float ff_rcp(float x) {
 #if FF_FAST_RCP

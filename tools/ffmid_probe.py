@@ -34,3 +34,10 @@ def fwd():
 h2, mean, rstd, bits, t = fwd()
 print(f"ffmid_fwd {t:8.1f} us | sum h2 {float(h2.float().sum()):.6e} sum|h2| {float(h2.float().abs().sum()):.6e} "
       f"sum mean {float(mean.sum()):.6e} sum rstd {float(rstd.sum()):.6e} bits checksum {int(bits.long().sum())}", flush=True)
+
+if os.environ.get("RUN_TESTS") == "1":      # the kernel-level parity tests against the same library build, same process
+    import pytest
+    del h1, h2, bits
+    torch.cuda.empty_cache()
+    rc = pytest.main(["-q", "-x", "-m", "gpu", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "test_gpu_kernels.py"), "-k", "ffmid"])
+    print(f"pytest -k ffmid exit code {int(rc)}", flush=True)
