@@ -147,8 +147,28 @@ __device__ __forceinline__ void pack_acc(const f32x16& p, int s, bf16x8& hi, bf1
 // =============================================================================================================
 // forward
 // =============================================================================================================
+// AT_LEAN=1 (forward, and the mask / bias part of the dQ kernel; off until it has run through the parity tests on the GPU): the ISA of the forward shows ~400 VALU
+// instructions per 8 MFMAs (one 32-key subtile), i.e. the kernel is VALU-bound 3:1.  The lean variant removes, without changing
+// a single result bit except where noted:
+//   * 80 v_accvgpr_read/write per subtile: without an occupancy hint hipcc keeps the accumulators in AGPRs and copies them out
+//     and back for the alpha rescale and the softmax -> amdgpu_waves_per_eu(2) (VGPR-form MFMA, as in the backward kernels);
+//   * the rescale itself when no lane's running max moved (alpha == 1 for the whole wave: multiplying by 1.0 is exact);
+//   * exp2f's denormal-range fix-up (v_ldexp + compare + select per score) -> raw v_exp_f32: differs only for results < 2^-126,
+//     which only masked scores reach (they are 0 either way);
+//   * on subtiles entirely below the diagonal (all but one per query tile): the causal compare, the clamp of the bias index and
+//     the per-score address arithmetic (constant LDS offsets from one base), and the 64-bit mask-bit test (one 32-bit word).
+#ifndef AT_LEAN
+#define AT_LEAN 0
+#endif
+#if AT_LEAN
+#define AT_FWD_OCC __attribute__((amdgpu_waves_per_eu(2)))
+#define AT_EXP2(x) __builtin_amdgcn_exp2f(x)
+#else
+#define AT_FWD_OCC
+#define AT_EXP2(x) exp2f(x)
+#endif
 template <typename T>
-__global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
+__global__ __launch_bounds__(AT_THREADS) AT_FWD_OCC void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                               const T* __restrict__ v, const float* __restrict__ bias,
                                                               const unsigned char* __restrict__ keymask, T* __restrict__ out,
                                                               float* __restrict__ lse, int B, int N, int H, float scale, int bias_ld) {
@@ -225,26 +245,41 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const T* __restric
                 st = MFMA(ka, qh[s], st);
             }
             float mloc = NEG_BIG;
+            if (AT_LEAN && jb + 31 <= i0) {
+                // every key of the subtile precedes every query of the wave: 0 <= rel = qi - key < nb without a test
+                const unsigned w32 = (unsigned)(bits >> (32 * sub)) >> (4 * hi);
+                const float* bp = bl + (qi - jb - 4 * hi);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kr = 32 * sub + crow(r, hi);
-                const int key = j0 + kr;
-                const int rel = qi - key;
-                const bool ok = (rel >= 0) && ((bits >> kr) & 1ull);
-                const float val = st[r] * c + bl[max(min(rel, nb - 1), 0)];
-                st[r] = ok ? val : NEG_BIG;
-                mloc = fmaxf(mloc, st[r]);
+                for (int r = 0; r < 16; ++r) {
+                    const int cr = (r & 3) + 8 * (r >> 2);                 // crow(r, hi) - 4 hi, a compile-time constant
+                    const float val = st[r] * c + bp[-cr];
+                    st[r] = ((w32 >> cr) & 1u) ? val : NEG_BIG;
+                    mloc = fmaxf(mloc, st[r]);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kr = 32 * sub + crow(r, hi);
+                    const int key = j0 + kr;
+                    const int rel = qi - key;
+                    const bool ok = (rel >= 0) && ((bits >> kr) & 1ull);
+                    const float val = st[r] * c + bl[max(min(rel, nb - 1), 0)];
+                    st[r] = ok ? val : NEG_BIG;
+                    mloc = fmaxf(mloc, st[r]);
+                }
             }
             mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
             const float mnew = fmaxf(m, mloc);
-            const float alpha = exp2f(m - mnew);
+            const float alpha = AT_EXP2(m - mnew);
             m = mnew;
             float psum = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { st[r] = exp2f(st[r] - mnew); psum += st[r]; }
+            for (int r = 0; r < 16; ++r) { st[r] = AT_EXP2(st[r] - mnew); psum += st[r]; }
             lsum = lsum * alpha + psum;
+            if (!AT_LEAN || !__all(alpha == 1.0f)) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { acc[0][e] *= alpha; acc[1][e] *= alpha; }
+                for (int e = 0; e < 16; ++e) { acc[0][e] *= alpha; acc[1][e] *= alpha; }
+            }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 bf16x8 ph, pl;
@@ -373,6 +408,32 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
             }
             // three straight passes (gather bias, arithmetic, scatter d(bias)): a fused per-element loop compiled to 16
             // serialised LDS round trips (read -> wait -> exp -> atomic), ~3k cycles per 32x32 block
+#if AT_LEAN
+            float bv[16];
+            auto element = [&](int r, bool ok) {
+                const float p = __builtin_amdgcn_exp2f(ok ? st[r] * c + bv[r] - L : NEG_BIG);
+                bv[r] = p * (dp[r] - dl);
+                st[r] = bv[r] * scale;
+            };
+            if (jb + 31 <= i0) {
+                // subtile entirely below the diagonal (see the forward): constant LDS offsets from one base, one 32-bit mask word
+                const unsigned w32 = qi < N ? (unsigned)(bits >> (32 * sub)) >> (4 * hi) : 0u;
+                const float* bp = bias_l + (qi - jb - 4 * hi);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bv[r] = bp[-((r & 3) + 8 * (r >> 2))];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) element(r, (w32 >> ((r & 3) + 8 * (r >> 2))) & 1u);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bv[r] = bias_l[max(min(qi - (j0 + 32 * sub + crow(r, hi)), nb - 1), 0)];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kr = 32 * sub + crow(r, hi);
+                    const int rel = qi - (j0 + kr);
+                    element(r, (rel >= 0) && ((bits >> kr) & 1ull) && (qi < N));
+                }
+            }
+#else
             float bv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) bv[r] = bias_l[max(min(qi - (j0 + 32 * sub + crow(r, hi)), nb - 1), 0)];
@@ -385,6 +446,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
                 bv[r] = p * (dp[r] - dl);                                     // dS (0 where masked)
                 st[r] = bv[r] * scale;
             }
+#endif
             if (dbias) {
                 // d(bias)[rel] = sum of dS over the diagonal rel = i - j.  LDS float atomics (one per element) cost 930 us
                 // per layer (measured: 1496 -> 565 us without them), so the 63 diagonals of the 32x32 block are summed in
