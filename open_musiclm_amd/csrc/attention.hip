@@ -147,7 +147,8 @@ __device__ __forceinline__ void pack_acc(const f32x16& p, int s, bf16x8& hi, bf1
 // =============================================================================================================
 // forward
 // =============================================================================================================
-// AT_LEAN=1 (forward, and the mask / bias part of the dQ kernel; off until it has run through the parity tests on the GPU): the ISA of the forward shows ~400 VALU
+// AT_LEAN=1 (forward, the mask / bias part of the dQ kernel, the score loop of the dK/dV kernel; off until it has run through the
+// parity tests on the GPU): the ISA of the forward shows ~400 VALU
 // instructions per 8 MFMAs (one 32-key subtile), i.e. the kernel is VALU-bound 3:1.  The lean variant removes, without changing
 // a single result bit except where noted:
 //   * 80 v_accvgpr_read/write per subtile: without an occupancy hint hipcc keeps the accumulators in AGPRs and copies them out
@@ -571,6 +572,45 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
             *(bf16x8*)(Qs + tile_off_blk(lane & 31, (2 * s + hi) * 16)) = qa[s];
             *(bf16x8*)(dOs + tile_off_blk(lane & 31, (2 * s + hi) * 16)) = doa[s];
         }
+#if AT_LEAN
+        // lean variant (see the forward): the tile's lse / delta go through a 64-float per-wave LDS patch instead of 4 v_readlane +
+        // 2 selects per score row, and items whose queries all follow this workgroup's keys (all but the first query tile) skip the
+        // causal compare, the i < N compare and the clamp of the bias index (constant LDS offsets from one base)
+        const float* bh = bias_s + h * nbk;
+        float* ld_l = (float*)(smem + 32768 + (size_t)H * (nqt * TQ) * sizeof(float)) + wave * 64;
+        if (lane < 32) { ld_l[lane] = La; ld_l[32 + lane] = Da; }
+        f32x16 st, dp;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { st[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            st = MFMA(qa[s], kf[s], st);       // S  = Q K^T   (rows i, column = this lane's key)
+            dp = MFMA(doa[s], vf[s], dp);      // dP = dO V^T
+        }
+        f32x16 pp;
+        const float* lp = ld_l + 4 * hi;
+        if (i0 >= j0 + 31 && i0 + 31 < N) {
+            const float* bp = bh + (i0 - kj + 4 * hi);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cr = (r & 3) + 8 * (r >> 2);                     // crow(r, hi) - 4 hi
+                const float p = __builtin_amdgcn_exp2f(keylive ? st[r] * c + bp[cr] - lp[cr] : NEG_BIG);
+                pp[r] = p;
+                st[r] = p * (dp[r] - lp[32 + cr]) * scale;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cr = (r & 3) + 8 * (r >> 2);
+                const int i = i0 + crow(r, hi);
+                const bool ok = (i >= kj) && keylive && (i < N);
+                const float bvr = bh[max(min(i - kj, nbk - 1), 0)];
+                const float p = __builtin_amdgcn_exp2f(ok ? st[r] * c + bvr - lp[cr] : NEG_BIG);
+                pp[r] = p;
+                st[r] = p * (dp[r] - lp[32 + cr]) * scale;
+            }
+        }
+#else
         const float* bh = bias_s + h * nbk;
         float bv[16];
 #pragma unroll
@@ -598,6 +638,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
             pp[r] = p;
             st[r] = p * (dp[r] - Di) * scale;     // dS * d(sim)/d(dot)
         }
+#endif
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8 pb, dsb;
@@ -673,7 +714,7 @@ extern "C" int omlm_mqa_attn_bwd(const void* q, const void* k, const void* v, co
     if (B <= 0 || N <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(q && k && v && out && dout && lse && delta && dq && dk && dv, "null pointer");
     dim3 gridq((N + TQ - 1) / TQ, (H + 3) / 4, B), gridk((N + 31) / 32, 1, B), block(AT_THREADS);
-    const size_t ldsq = dq_lds(N), ldsk = 32 * 1024 + (size_t)H * ((N + TQ - 1) / TQ * TQ) * sizeof(float);
+    const size_t ldsq = dq_lds(N), ldsk = 32 * 1024 + (size_t)H * ((N + TQ - 1) / TQ * TQ) * sizeof(float) + (AT_LEAN ? 1024 : 0);
     int rc;
     hipStream_t st = as_stream(stream);
     if (dtype == 0) {
