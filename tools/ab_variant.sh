@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of one build option against the in-tree library, in one GPU call.
 #   here (no GPU):   tools/ab_variant.sh build attention -DAT_LEAN=1     -> .variants/libomlm_variant.so (travels with gpurun)
-#   on the GPU box:  tools/ab_variant.sh run "attn or attention" tools/attn_probe.py
+#   on the GPU box:  tools/ab_variant.sh run attention tools/attn_probe.py
 # `run` executes the matching kernel parity tests and the probe against BOTH libraries (OMLM_LIB_PATH selects the build).
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
