@@ -11,13 +11,19 @@ forward + backward (forgetful mask on, FF dropout 0.1 on) + ONE gradient all-red
 are synthetic (seeded U{0..1023}) and already resident in HBM when the timed region starts; weights are the
 reference's random init (no checkpoints offline).  For N > 1 launch with torch.distributed.run (one rank per GPU).
 
-`value` = whole-job training samples/s (global batch * steps / s, max over ranks); steps/s and AR tokens/s are
-reported next to it, as are the live GEMM roofline (HIP events around every MFMA GEMM launch of extra, untimed-for-
-`value` instrumented steps) and the CPU oracle timed on this box's host cores.
+`value` = whole-job training samples/s (global batch * steps / s, max over ranks) of BASELINE config 2 in the
+precision it names ("bf16").  At N = 1 the same JSON line carries, under "legs", the other configurations of
+BASELINE.json measured in the same run:
+  legs.bf16x3       the same train step in the precision mode that meets the north-star 1e-3 logits tolerance
+  legs.large_fine   BASELINE config 4: musiclm_large fine stage (depth 24, heads 16, N = 1817, 5 fine quantizers)
+  legs.e2e_generate BASELINE config 5: MusicLM.generate, 10 s (RVQ + 500 semantic + 2250 coarse + 3750 fine ids)
+plus `roofline` (HIP events around every MFMA GEMM launch of extra, instrumented steps), `ar_tokens_per_sec`
+(coarse-stage decode) and `cpu_baseline` (the CPU oracle on this box's host cores, timed BEFORE the GPU regions).
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -27,13 +33,15 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 N_SEQ = 1116
-PEAK_TFLOPS = {"bf16": 2500.0, "bf16x3": 2500.0}      # dense bf16 MFMA peak (MI355X_MICROARCH.md); bf16x3 issues 3 MFMAs per algorithmic product
-P_LIN = 9_566_208                                       # linear MACs / token / layer, musiclm_small
+PEAK_TFLOPS = 2500.0                                    # dense bf16 MFMA peak (MI355X_MICROARCH.md); bf16x3 issues 3 MFMAs per product
+HBM_ACHIEVABLE_TBS = 6.3                                # measured streaming rate (MI355X_MICROARCH.md)
+P_LIN = {8: 9_566_208, 16: 10_614_784}                  # linear MACs / token / layer by head count
 
 
 def algorithmic_flops_per_sample(N=N_SEQ, L=6, h=8, dh=64, n_out=1114):
-    fwd = 2 * (L * (N * P_LIN + h * dh * N * (N + 1)) + n_out * 1_049_600)
-    return 3 * fwd                                       # fwd + bwd
+    """F_fwd = 2 [L (N P_lin + h dh N (N + 1)) + N_out 1,049,600]; fwd + bwd = 3 F_fwd."""
+    fwd = 2 * (L * (N * P_LIN[h] + h * dh * N * (N + 1)) + n_out * 1_049_600)
+    return 3 * fwd
 
 
 T_START = time.perf_counter()
@@ -42,6 +50,217 @@ T_START = time.perf_counter()
 def progress(msg):
     if os.environ.get("RANK", "0") == "0":
         print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+class TrainLeg:
+    """One training configuration: model + stage + optimizer + captured micro-step, and its timed loop."""
+
+    def __init__(self, dev, dp, *, stage, dim, depth, heads, precision, batch, accum, use_graph, ds_kwargs=None, seed_rank=0):
+        from open_musiclm_amd import open_musiclm as M
+        from open_musiclm_amd.data import SyntheticTokenDataset
+        from open_musiclm_amd.graph import GraphedForwardBackward
+        from open_musiclm_amd.optimizer import get_linear_scheduler, get_optimizer
+        self.dev, self.dp, self.batch, self.accum, self.precision = dev, dp, batch, accum, precision
+        torch.manual_seed(0)                               # identical replicas on every rank
+        if stage == "coarse":
+            self.model = M.create_coarse_transformer(dim=dim, depth=depth, heads=heads, attn_dropout=0.0, ff_dropout=0.1,
+                                                     num_coarse_quantizers=3, precision=precision).to(dev)
+            self.stage = M.CoarseStage(coarse_transformer=self.model, cross_entropy_loss_weights=[0., 0., 1.])
+            self.keys = ("clap_token_ids", "semantic_token_ids", "coarse_token_ids")
+        elif stage == "fine":
+            self.model = M.create_fine_transformer(dim=dim, depth=depth, heads=heads, attn_dropout=0.0, ff_dropout=0.1,
+                                                   num_coarse_quantizers=3, num_fine_quantizers=5, precision=precision).to(dev)
+            self.stage = M.FineStage(fine_transformer=self.model, cross_entropy_loss_weights=[0., 0., 1.])
+            self.keys = ("clap_token_ids", "coarse_token_ids", "fine_token_ids")
+        else:
+            raise ValueError(stage)
+        self.stage.train()
+        self.optim = get_optimizer(self.model.parameters(), lr=3e-4, wd=0.01)
+        self.sched = get_linear_scheduler(self.optim, total_iters=6000)
+        assert batch % accum == 0
+        micro = batch // accum
+        ds = SyntheticTokenDataset(stage, length=1 << 20, seed=1234 + seed_rank, **(ds_kwargs or {}))
+
+        def make_batch(i):
+            items = [ds[i * micro + j] for j in range(micro)]
+            return [torch.cat([it[f] for it in items], 0).to(dev) for f in range(len(self.keys))]
+        self.batches = [make_batch(i) for i in range(4 * accum)]       # resident in HBM before timing
+        self.fb = GraphedForwardBackward(lambda **kw: self.stage(**kw, return_loss=True)[0], loss_scale=1.0 / accum,
+                                         enabled=use_graph)
+        self.optim.zero_grad()                                 # adopt the flat parameter / gradient buffers before capture
+
+        def discard():
+            self.optim.mark_grads_dirty()
+            self.optim.zero_grad()
+        self.fb.prepare(dict(zip(self.keys, self.batches[0])), after_warmup=discard)
+
+    def step(self, k, eager=False, exchange=True):
+        self.optim.zero_grad()
+        for a in range(self.accum):
+            kw = dict(zip(self.keys, self.batches[(k * self.accum + a) % len(self.batches)]))
+            loss = self.fb._eager(kw) if eager else self.fb(**kw)
+            self.optim.mark_grads_dirty()
+        if exchange:
+            self.dp.allreduce_sum_(self.optim.flat_grad)
+        self.optim.step(max_grad_norm=0.5, grad_scale=self.dp.grad_scale())
+        self.sched.step()
+        return loss
+
+    def timed(self, steps, warmup):
+        for k in range(warmup):
+            loss = self.step(k)
+            torch.cuda.synchronize()
+        self.dp.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            loss = self.step(warmup + k)
+        self.dp.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], device=self.dev)
+        if self.dp.is_distributed:
+            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        return float(tmax.item()), float(loss.item())
+
+    def gemm_roofline(self, k0, traffic=None):
+        """HIP events (torch events on the stream the kernels are launched on) around every MFMA GEMM launch of two extra,
+        eager, un-exchanged steps: algorithmic flops of the launches / their summed durations."""
+        from open_musiclm_amd import ops
+        import open_musiclm_amd.engine as E
+        ops_gemm, rec = ops.gemm, []
+
+        def timed_gemm(A, B, C_, *, M, N, K, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ops_gemm(A, B, C_, M=M, N=N, K=K, **kw)
+            e1.record()
+            rec.append((e0, e1, 2.0 * M * N * K))
+        E.ops.gemm = timed_gemm
+        try:
+            for k in range(2):
+                self.step(k0 + k, eager=True, exchange=False)
+            torch.cuda.synchronize()
+        finally:
+            E.ops.gemm = ops_gemm
+        tot_ms = sum(a.elapsed_time(b) for a, b, _ in rec)
+        tot_fl = sum(f for _, _, f in rec)
+        big = [(a.elapsed_time(b), f) for a, b, f in rec if f > 1e11]
+        ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        mult = 3 if self.precision == "bf16x3" else 1
+        return {"bound": "mfma", "kernel": "gemm kernels (all layouts, every GEMM launch of a train step)",
+                "achieved": round(ach, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS, 4),
+                "traffic": traffic, "launches": len(rec) // 2, "gemm_ms_per_step": round(tot_ms / 2, 3),
+                "mfma_issue_frac": round(mult * ach / PEAK_TFLOPS, 4),
+                "large_gemm_achieved": round(sum(f for _, f in big) / (sum(t for t, _ in big) * 1e-3) / 1e12, 2) if big else None}
+
+    def free(self):
+        self.fb = self.model = self.stage = self.optim = self.batches = None
+        import gc
+        gc.unfreeze()
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
+def cpu_baseline(progress_fn):
+    """The oracle (port of the reference arithmetic, torch CPU kernels) on this box's host cores: one warm-up + median
+    of 3 full micro-steps (forward + backward + global-norm clip + AdamW) at B = 1, N = 1116, fp32: a bounded sample of the
+    same workload (~30 s)."""
+    from oracle import musiclm_oracle as O
+    spec = O.coarse_spec(dim=1024, depth=6, heads=8)
+    sd = O.init_state_dict(spec, seed=0)
+    params = [v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and not k.endswith("beta")]
+    opt = torch.optim.AdamW(params, lr=3e-4, betas=(0.9, 0.99), weight_decay=0.01)
+    ids = O.synthetic_ids(spec, 1, [1, 199, 300], seed=1234)
+    noise = torch.randn(1, N_SEQ, generator=torch.Generator().manual_seed(1))
+    times = []
+    for it in range(4):
+        t1 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        l, _, _ = O.wrapper_forward_loss(sd, spec, ids, [0., 0., 1.], forget_noise=noise)
+        l.backward()
+        torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], 0.5)
+        opt.step()
+        times.append(time.perf_counter() - t1)
+        progress_fn(f"cpu baseline iteration {it}{' (warm-up)' if it == 0 else ''}: {times[-1]:.2f}s")
+    med = statistics.median(times[1:])
+    return {"value": round(1 / med, 4), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "host_cpu_count": os.cpu_count(),
+            "sample": "1 warm-up + median of 3 micro-steps (fwd + bwd + clip + AdamW) of B=1, N=1116, fp32, torch CPU kernels; "
+                      f"times {[round(t, 2) for t in times]} s"}
+
+
+def decode_leg(stage, dev, decode_ids):
+    """AR decode of the coarse stage, B = 1 and B = 8: KV-cached single-row steps (decode.py) and, for comparison, the
+    reference's own scheme (full re-forward per id, open_musiclm.py:299-319).  Rates include the prompt prefill."""
+    stage.eval()
+    g = torch.Generator().manual_seed(99)
+    clap = torch.randint(0, 1024, (1, 12, 1), generator=g).to(dev)
+    sem = torch.randint(0, 1024, (1, 199), generator=g).to(dev)
+    res = {}
+    for mode, use_cache, steps_new in (("kv_cache", True, 100), ("reforward", False, max(decode_ids // 3, 1))):
+        for label, primed in (("empty_context", 0), ("full_context", 300 - steps_new)):
+            prime = torch.randint(0, 1024, (1, primed, 3), generator=g).to(dev) if primed else None
+            tgt = primed + steps_new
+            kw = dict(clap_token_ids=clap, semantic_token_ids=sem, coarse_token_ids=prime, use_cache=use_cache)
+            stage.generate(max_time_steps=primed + 2, **kw)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            stage.generate(max_time_steps=tgt, **kw)
+            torch.cuda.synchronize()
+            res[f"{mode}_{label}"] = round(steps_new * 3 / (time.perf_counter() - t1), 2)
+    clap8 = torch.randint(0, 1024, (8, 12, 1), generator=g).to(dev)
+    sem8 = torch.randint(0, 1024, (8, 199), generator=g).to(dev)
+    kw8 = dict(clap_token_ids=clap8, semantic_token_ids=sem8, use_cache=True)
+    stage.generate(max_time_steps=2, **kw8)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    stage.generate(max_time_steps=50, **kw8)
+    torch.cuda.synchronize()
+    res["kv_cache_batch8_empty_context"] = round(8 * 50 * 3 / (time.perf_counter() - t1), 2)
+    stage.train()
+    return res
+
+
+def e2e_generate_leg(dev, seconds=10):
+    """BASELINE config 5: MusicLM.generate for `seconds` of audio with the three musiclm_small stages (random init) --
+    seeded synthetic 512-d conditioning embedding -> RVQ kernel (12 x 1024 x 512 seeded codebooks) -> semantic (50 Hz) ->
+    coarse (75 Hz x 3) -> fine (75 Hz x 5) sliding-window AR decode.  Encodec / CLAP towers are outside the path (weights
+    unobtainable offline): the rate covers the AR stack + RVQ only.  Floor: every sampled id streams its stage's trunk + one
+    head once (bf16)."""
+    from open_musiclm_amd import open_musiclm as M
+    from open_musiclm_amd.clap_quantized import ClapQuantized
+    torch.manual_seed(0)
+    kw = dict(dim=1024, depth=6, heads=8, precision="bf16")
+    sem = M.create_semantic_transformer(**kw).to(dev)
+    coarse = M.create_coarse_transformer(num_coarse_quantizers=3, **kw).to(dev)
+    fine = M.create_fine_transformer(num_coarse_quantizers=3, num_fine_quantizers=5, **kw).to(dev)
+    mlm = M.MusicLM(wav2vec=None, clap=None, neural_codec=None, semantic_transformer=sem, coarse_transformer=coarse,
+                    fine_transformer=fine)
+    cq = ClapQuantized(clap=None, codebook_size=1024, rq_num_quantizers=12, embed_dim=512).to(dev)
+    g = torch.Generator().manual_seed(5)
+    cq.rq.codebooks.copy_(torch.randn(12, 1024, 512, generator=g))
+    emb = torch.randn(1, 512, generator=g).to(dev)
+
+    def run(secs):
+        clap_ids = cq.quantize(emb)
+        return mlm.generate(clap_token_ids=clap_ids, output_seconds=secs, return_tokens=True)
+    run(1)                                                  # warm-up: weight prep, allocator, kernels loaded
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    s, c, f = run(seconds)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t1
+    n_ids = s.shape[1] + c.shape[1] * c.shape[2] + f.shape[1] * f.shape[2]
+    trunk_bytes = 58.06e6 * 2 + 1025 * 1024 * 2            # bf16 trunk + one logit head per sampled id (SURVEY.md §8d)
+    floor_s = n_ids * trunk_bytes / (HBM_ACHIEVABLE_TBS * 1e12)
+    return {"workload": f"MusicLM.generate output_seconds={seconds}, musiclm_small stages, B=1, bf16, KV-cached windows",
+            "sampled_ids": int(n_ids), "ids": {"semantic": int(s.shape[1]), "coarse": int(c.shape[1] * c.shape[2]),
+                                               "fine": int(f.shape[1] * f.shape[2])},
+            "seconds": round(dt, 3), "ids_per_sec": round(n_ids / dt, 1), "audio_seconds_per_sec": round(seconds / dt, 4),
+            "roofline": {"bound": "hbm", "achieved": round(n_ids * trunk_bytes / dt / 1e9, 1), "peak": HBM_ACHIEVABLE_TBS * 1e3,
+                         "unit": "GB/s", "frac": round(floor_s / dt, 4),
+                         "note": "weight-streaming floor: bf16 trunk + one head per sampled id over the achievable 6.3 TB/s"}}
 
 
 def main():
@@ -55,13 +274,12 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured HIP graph")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="skip the bf16x3 / large_fine / e2e_generate legs")
+    ap.add_argument("--legs", default="bf16x3,large_fine,e2e_generate")
+    ap.add_argument("--large-batch", type=int, default=16, help="samples per step of the large_fine leg")
     ap.add_argument("--decode-ids", type=int, default=48)
     args = ap.parse_args()
 
-    from open_musiclm_amd import open_musiclm as M
-    from open_musiclm_amd import ops
-    from open_musiclm_amd.data import SyntheticTokenDataset
-    from open_musiclm_amd.optimizer import get_linear_scheduler, get_optimizer
     from open_musiclm_amd.parallel import DataParallel
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -71,66 +289,19 @@ def main():
     dev = torch.device("cuda", local_rank)
     dp = DataParallel(device=dev)
     rank = dp.rank
+    legs = [] if (args.no_legs or world > 1) else [l for l in args.legs.split(",") if l]
 
-    torch.manual_seed(0)                                   # identical replicas on every rank
-    model = M.create_coarse_transformer(dim=1024, depth=6, heads=8, attn_dropout=0.0, ff_dropout=0.1,
-                                        num_coarse_quantizers=3, precision=args.precision).to(dev)
-    stage = M.CoarseStage(coarse_transformer=model, cross_entropy_loss_weights=[0., 0., 1.])
-    stage.train()
-    optim = get_optimizer(model.parameters(), lr=3e-4, wd=0.01)
-    sched = get_linear_scheduler(optim, total_iters=6000)
+    # ---- CPU baseline first (rank 0, N = 1): the GPU regions then run back to back at the end of the process
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        progress(f"cpu baseline on {torch.get_num_threads()} torch threads (os.cpu_count()={os.cpu_count()})")
+        cpu = cpu_baseline(progress)
 
-    assert args.batch % args.accum == 0
-    micro = args.batch // args.accum
-    ds = SyntheticTokenDataset("coarse", length=1 << 20, seed=1234 + rank)
-    n_micro = (args.steps + args.warmup + 2) * args.accum
-
-    def make_batch(i):
-        items = [ds[i * micro + j] for j in range(micro)]
-        return [torch.cat([it[f] for it in items], 0).to(dev) for f in range(3)]
-    batches = [make_batch(i) for i in range(min(n_micro, 8))]       # resident in HBM before timing
-
-    from open_musiclm_amd.graph import GraphedForwardBackward
-    fb = GraphedForwardBackward(lambda **kw: stage(**kw, return_loss=True)[0], loss_scale=1.0 / args.accum,
-                                enabled=not args.no_graph)
-    optim.zero_grad()                                      # adopt the flat parameter / gradient buffers before capture
-
-    def discard():
-        optim.mark_grads_dirty()
-        optim.zero_grad()
-    fb.prepare(dict(clap_token_ids=batches[0][0], semantic_token_ids=batches[0][1], coarse_token_ids=batches[0][2]),
-               after_warmup=discard)
-    progress(f"micro-step captured into a HIP graph: {fb.graph is not None}" + (f" ({fb.capture_error})" if fb.capture_error else ""))
-
-    def one_step(k):
-        optim.zero_grad()
-        for a in range(args.accum):
-            clap, sem, coarse = batches[(k * args.accum + a) % len(batches)]
-            loss = fb(clap_token_ids=clap, semantic_token_ids=sem, coarse_token_ids=coarse)
-            optim.mark_grads_dirty()
-        dp.allreduce_sum_(optim.flat_grad)
-        optim.step(max_grad_norm=0.5, grad_scale=dp.grad_scale())
-        sched.step()
-        return loss
-
-    progress(f"model + {len(batches)} resident batches ready (micro-batch {micro} x accum {args.accum})")
-    for k in range(args.warmup):
-        loss = one_step(k)
-        torch.cuda.synchronize()
-        progress(f"warmup step {k} done")
-    dp.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        loss = one_step(args.warmup + k)
-    dp.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], device=dev)
-    if dp.is_distributed:
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-    dt = float(tmax.item())
-    final_loss = float(loss.item())
+    main_leg = TrainLeg(dev, dp, stage="coarse", dim=1024, depth=6, heads=8, precision=args.precision, batch=args.batch,
+                        accum=args.accum, use_graph=not args.no_graph, seed_rank=rank)
+    progress(f"micro-step captured into a HIP graph: {main_leg.fb.graph is not None}" +
+             (f" ({main_leg.fb.capture_error})" if main_leg.fb.capture_error else ""))
+    dt, final_loss = main_leg.timed(args.steps, args.warmup)
     progress(f"timed region: {args.steps} steps in {dt:.3f}s")
 
     ms_per_step = 1e3 * dt / args.steps
@@ -138,7 +309,8 @@ def main():
     samples_per_s = steps_per_s * args.batch * world
     flops_step = algorithmic_flops_per_sample() * args.batch
     model_tflops_per_gpu = flops_step / (dt / args.steps) / 1e12
-
+    parity = {"bf16": "logits <= 1.2e-2 rel vs CPU reference (measured 6-7e-3; bf16 operands cannot meet 1e-3)",
+              "bf16x3": "logits <= 1e-3 rel vs CPU reference (measured ~7e-5)"}
     out = {
         "metric": "train steps/sec + AR tokens/sec, coarse-stage musiclm_small",
         "value": round(samples_per_s, 3), "unit": "samples/s",
@@ -149,154 +321,79 @@ def main():
                                "(3 start + 13 clap + 200 semantic + 900 coarse), forgetful mask 0.15, ff_dropout 0.1",
                    "global_batch": args.batch * world, "per_gpu_batch": args.batch, "grad_accum": args.accum,
                    "seq_len": N_SEQ, "parallelism": f"dp{world}", "precision": args.precision,
-                   "hip_graph": fb.graph is not None,
-                   "parity": "bf16x3: logits <=1e-3 vs CPU reference; bf16: <=3e-2 (tests/test_gpu_model.py)"},
+                   "hip_graph": main_leg.fb.graph is not None,
+                   "parity": parity[args.precision] + " (tests/test_gpu_model.py)"},
         "steps_per_sec": round(steps_per_s, 4),
         "model_tflops_per_gpu": round(model_tflops_per_gpu, 2),
-        "model_flops_frac_of_bf16_peak": round(model_tflops_per_gpu / PEAK_TFLOPS[args.precision], 4),
+        "model_flops_frac_of_bf16_peak": round(model_tflops_per_gpu / PEAK_TFLOPS, 4),
         "final_loss": round(final_loss, 4),
     }
-
-    if os.environ.get("BENCH_HOST_PROFILE") == "1":
-        import cProfile, pstats, io
-        batch = dict(clap_token_ids=batches[0][0], semantic_token_ids=batches[0][1], coarse_token_ids=batches[0][2])
-        fb._eager(batch); torch.cuda.synchronize()
-        pr = cProfile.Profile(); pr.enable()
-        fb._eager(batch)
-        pr.disable(); torch.cuda.synchronize()
-        sio = io.StringIO(); pstats.Stats(pr, stream=sio).sort_stats("tottime").print_stats(22)
-        print(sio.getvalue(), file=sys.stderr)
-
-    if os.environ.get("BENCH_HOST_TIMELINE") == "1":
-        # host-side phase stamps over consecutive un-synchronised steps (steady state, queues full)
-        import gc
-        stamps = []
-        torch.cuda.synchronize()
-        gc_was = gc.isenabled()
-        if os.environ.get("BENCH_GC_OFF") == "1":
-            gc.disable()
-        for k in range(6):
-            kk = args.warmup + args.steps + 20 + k
-            t = [time.perf_counter()]
-            optim.zero_grad(); t.append(time.perf_counter())
-            clap, sem, coarse = batches[kk % len(batches)]
-            loss = fb(clap_token_ids=clap, semantic_token_ids=sem, coarse_token_ids=coarse); t.append(time.perf_counter())
-            optim.mark_grads_dirty()
-            dp.allreduce_sum_(optim.flat_grad); t.append(time.perf_counter())
-            optim.step(max_grad_norm=0.5, grad_scale=dp.grad_scale()); t.append(time.perf_counter())
-            sched.step(); t.append(time.perf_counter())
-            del loss; t.append(time.perf_counter())
-            stamps.append(t)
-        torch.cuda.synchronize()
-        tend = time.perf_counter()
-        if gc_was:
-            gc.enable()
-        names = ["zero_grad", "fwd+bwd", "allreduce", "optim.step", "sched.step", "del loss"]
-        for k, t in enumerate(stamps):
-            progress(f"host timeline step {k}: start {1e3 * (t[0] - stamps[0][0]):7.1f} ms | " +
-                     " ".join(f"{n} {1e3 * (t[i + 1] - t[i]):.1f}" for i, n in enumerate(names)))
-        progress(f"host timeline: all 6 steps issued at {1e3 * (stamps[-1][-1] - stamps[0][0]):.1f} ms, GPU idle at {1e3 * (tend - stamps[0][0]):.1f} ms")
 
     if os.environ.get("BENCH_STEP_TIMES") == "1":
         for k in range(3):
             torch.cuda.synchronize()
             ta = time.perf_counter()
-            one_step(args.warmup + args.steps + 10 + k)
+            main_leg.step(args.warmup + args.steps + 10 + k)
             tb = time.perf_counter()
             torch.cuda.synchronize()
             tc = time.perf_counter()
             progress(f"diagnostic step {k}: host enqueue {1e3 * (tb - ta):.1f} ms, until GPU idle {1e3 * (tc - ta):.1f} ms")
 
     if rank == 0:
-        # ---- live roofline of the dominant kernel (the MFMA GEMM): HIP events around every GEMM launch of 2 extra steps
-        ops_gemm = ops.gemm
-        rec = []
-
-        def timed_gemm(A, B, C_, *, M, N, K, **kw):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            ops_gemm(A, B, C_, M=M, N=N, K=K, **kw)
-            e1.record()
-            rec.append((e0, e1, 2.0 * M * N * K))
-        import open_musiclm_amd.engine as E
-        E.ops.gemm = timed_gemm
-        def eager_step(k):                                # the graph replays recorded launches: instrument eager ones
-            optim.zero_grad()
-            for a in range(args.accum):
-                clap, sem, coarse = batches[(k * args.accum + a) % len(batches)]
-                fb._eager(dict(clap_token_ids=clap, semantic_token_ids=sem, coarse_token_ids=coarse))
-                optim.mark_grads_dirty()
-            optim.step(max_grad_norm=0.5, grad_scale=dp.grad_scale())
-        try:
-            for k in range(2):
-                eager_step(args.warmup + args.steps + k)
-            torch.cuda.synchronize()
-        finally:
-            E.ops.gemm = ops_gemm
-        tot_ms = sum(a.elapsed_time(b) for a, b, _ in rec)
-        progress(f"roofline probe: {len(rec)} GEMM launches, {tot_ms:.1f} ms")
-        tot_fl = sum(f for _, _, f in rec)
-        big = [(a.elapsed_time(b), f) for a, b, f in rec if f > 1e11]
-        ach = tot_fl / (tot_ms * 1e-3) / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel (all layouts, all GEMM launches of a train step)",
-                           "achieved": round(ach, 2), "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_TFLOPS[args.precision], 4), "traffic": None,
-                           "launches": len(rec) // 2, "gemm_ms_per_step": round(tot_ms / 2, 3),
-                           "large_gemm_achieved": round(sum(f for _, f in big) / (sum(t for t, _ in big) * 1e-3) / 1e12, 2) if big else None}
-
-        # ---- AR decode, B = 1: KV-cached single-row steps (decode.py) and, for comparison, the reference's own scheme
-        #      (full re-forward per id, open_musiclm.py:299-319).  Rates include the prompt prefill.
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")      # PMC passes (tools/pmc_gemm_traffic.sh), per train step
+        if os.path.exists(tpath) and args.precision == "bf16":
+            try:
+                traffic = json.load(open(tpath))
+            except Exception:
+                traffic = None
+        out["roofline"] = main_leg.gemm_roofline(args.warmup + args.steps, traffic)
+        progress(f"roofline probe: {out['roofline']['launches']} GEMM launches, {out['roofline']['gemm_ms_per_step']} ms per step")
         if not args.no_decode:
-            stage.eval()
-            g = torch.Generator().manual_seed(99)
-            clap = torch.randint(0, 1024, (1, 12, 1), generator=g).to(dev)
-            sem = torch.randint(0, 1024, (1, 199), generator=g).to(dev)
-            res = {}
-            for mode, use_cache, steps_new in (("kv_cache", True, 100), ("reforward", False, max(args.decode_ids // 3, 1))):
-                for label, primed in (("empty_context", 0), ("full_context", 300 - steps_new)):
-                    prime = torch.randint(0, 1024, (1, primed, 3), generator=g).to(dev) if primed else None
-                    tgt = primed + steps_new
-                    kw = dict(clap_token_ids=clap, semantic_token_ids=sem, coarse_token_ids=prime, use_cache=use_cache)
-                    stage.generate(max_time_steps=primed + 2, **kw)
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
-                    stage.generate(max_time_steps=tgt, **kw)
-                    torch.cuda.synchronize()
-                    res[f"{mode}_{label}"] = round(steps_new * 3 / (time.perf_counter() - t1), 2)
-            # batched decode (8 independent samples per step share every weight read): aggregate ids/s
-            clap8 = torch.randint(0, 1024, (8, 12, 1), generator=g).to(dev)
-            sem8 = torch.randint(0, 1024, (8, 199), generator=g).to(dev)
-            kw8 = dict(clap_token_ids=clap8, semantic_token_ids=sem8, use_cache=True)
-            stage.generate(max_time_steps=2, **kw8)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            stage.generate(max_time_steps=50, **kw8)
-            torch.cuda.synchronize()
-            res["kv_cache_batch8_empty_context"] = round(8 * 50 * 3 / (time.perf_counter() - t1), 2)
-            out["ar_tokens_per_sec"] = res
-            progress(f"decode {res}")
-            stage.train()
-
-        # ---- CPU baseline: the oracle (port of the reference arithmetic) on this box's host cores, bounded sample
-        if world == 1 and not args.no_cpu_baseline:
-            from oracle import musiclm_oracle as O
-            progress(f"cpu baseline on {torch.get_num_threads()} torch threads (os.cpu_count()={os.cpu_count()})")
-            spec = O.coarse_spec(dim=1024, depth=6, heads=8)
-            sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point and not k.endswith("beta"))
-                  for k, v in model.state_dict().items()}
-            ids = O.synthetic_ids(spec, 2, [1, 199, 300], seed=1234)
-            noise = torch.randn(2, N_SEQ, generator=torch.Generator().manual_seed(1))
-            times = []
-            for it in range(2):                              # ~30 s of CPU work on this box
-                t1 = time.perf_counter()
-                l, _, _ = O.wrapper_forward_loss(sd, spec, ids, [0., 0., 1.], forget_noise=noise)
-                torch.autograd.grad(l, [v for v in sd.values() if v.requires_grad], allow_unused=True)
-                times.append(time.perf_counter() - t1)
-                progress(f"cpu baseline iteration {it}: {times[-1]:.2f}s")
-            best = min(times)
-            out["cpu_baseline"] = {"value": round(2 / best, 4), "unit": "samples/s", "cores": torch.get_num_threads(),
-                                   "kind": "port",
-                                   "sample": f"{len(times)} fwd+bwd micro-steps of B=2, N=1116, fp32, torch CPU kernels (best; no optimizer step)"}
+            out["ar_tokens_per_sec"] = decode_leg(main_leg.stage, dev, args.decode_ids)
+            progress(f"decode {out['ar_tokens_per_sec']}")
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        if legs:
+            out["legs"] = {}
+            main_leg.free()
+        if "bf16x3" in legs and args.precision != "bf16x3":
+            leg = TrainLeg(dev, dp, stage="coarse", dim=1024, depth=6, heads=8, precision="bf16x3", batch=args.batch,
+                           accum=args.accum, use_graph=not args.no_graph)
+            k, w = min(args.steps, 5), 1
+            dt3, loss3 = leg.timed(k, w)
+            tf3 = flops_step / (dt3 / k) / 1e12
+            out["legs"]["bf16x3"] = {
+                "workload": "same train step, precision bf16x3 (fp32 operands split hi/lo on the bf16 matrix cores: the mode "
+                            "that meets the north-star 1e-3 logits tolerance)",
+                "dtype": "bf16x3", "parity": parity["bf16x3"], "value": round(args.batch * k / dt3, 3), "unit": "samples/s",
+                "steps": k, "warmup": w, "ms_per_step": round(1e3 * dt3 / k, 3), "model_tflops_per_gpu": round(tf3, 2),
+                "model_flops_frac_of_bf16_peak": round(tf3 / PEAK_TFLOPS, 4), "final_loss": round(loss3, 4),
+                "roofline": leg.gemm_roofline(k + w)}
+            progress(f"bf16x3 leg: {out['legs']['bf16x3']['ms_per_step']} ms/step")
+            leg.free()
+        if "large_fine" in legs:
+            Bl = args.large_batch
+            torch.cuda.reset_peak_memory_stats()
+            leg = TrainLeg(dev, dp, stage="fine", dim=1024, depth=24, heads=16, precision="bf16", batch=Bl, accum=1,
+                           use_graph=not args.no_graph, ds_kwargs=dict(fine_window_seconds=3))
+            k, w = 3, 1
+            dtl, lossl = leg.timed(k, w)
+            fl = algorithmic_flops_per_sample(N=1817, L=24, h=16, n_out=1815) * Bl
+            tfl = fl / (dtl / k) / 1e12
+            out["legs"]["large_fine"] = {
+                "workload": "musiclm_large fine-stage train step (BASELINE config 4): dim 1024, depth 24, heads 16, N=1817 "
+                            "(3 start + 13 clap + 676 coarse + 1125 fine), 5 fine quantizers, forgetful mask, ff_dropout 0.1",
+                "dtype": "bf16", "per_gpu_batch": Bl, "value": round(Bl * k / dtl, 3), "unit": "samples/s", "steps": k,
+                "warmup": w, "ms_per_step": round(1e3 * dtl / k, 3), "model_tflops_per_gpu": round(tfl, 2),
+                "model_flops_frac_of_bf16_peak": round(tfl / PEAK_TFLOPS, 4), "final_loss": round(lossl, 4),
+                "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+                "hip_graph": leg.fb.graph is not None, "roofline": leg.gemm_roofline(k + w)}
+            progress(f"large_fine leg: {out['legs']['large_fine']['ms_per_step']} ms/step, {out['legs']['large_fine']['peak_hbm_gb']} GB")
+            leg.free()
+        if "e2e_generate" in legs:
+            out["legs"]["e2e_generate"] = e2e_generate_leg(dev)
+            progress(f"e2e generate leg: {out['legs']['e2e_generate']['ids_per_sec']} ids/s")
         print(json.dumps(out), flush=True)
     dp.barrier()
     dp.shutdown()

@@ -201,8 +201,10 @@ def naive_attention(q, k, v, bias, keymask, H, scale=8.0):
     return out.permute(0, 2, 1, 3).reshape(B, N, H * 64)
 
 
+# the last two cases are musiclm_large's fine stage (BASELINE config 4): 16 heads, N = 1817 positions
 @pytest.mark.parametrize("dtype,B,N,H", [(torch.float32, 2, 77, 2), (torch.bfloat16, 2, 77, 2),
-                                         (torch.bfloat16, 1, 200, 5), (torch.float32, 1, 130, 8)])
+                                         (torch.bfloat16, 1, 200, 5), (torch.float32, 1, 130, 8),
+                                         (torch.bfloat16, 1, 1817, 16), (torch.float32, 1, 1817, 16)])
 def test_attention_fwd_bwd(ops, dev, dtype, B, N, H):
     g = torch.Generator().manual_seed(N + H)
     M = B * N

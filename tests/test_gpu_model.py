@@ -325,6 +325,68 @@ def test_full_size_other_stages_forward_loss_vs_oracle(dev, stage, lengths, N, k
     assert e_inf < TOL["bf16"]["logits"] and e_loss < TOL["bf16"]["loss"] and gfinite
 
 
+_LARGE_ORACLE = {}
+
+
+def _large_fine(dev, depth, precision, with_grads):
+    """musiclm_large fine stage (configs/model/musiclm_large.json:53-63: dim 1024, heads 16; 3 s windows -> clap 12x1,
+    coarse 225x3, fine 225x5 ids -> N = 1817), B = 1, against the CPU oracle."""
+    from open_musiclm_amd import open_musiclm as M
+    from oracle import musiclm_oracle as O
+    torch.manual_seed(2)
+    model = M.create_fine_transformer(dim=1024, depth=depth, heads=16, ff_dropout=0.0, num_coarse_quantizers=3,
+                                      num_fine_quantizers=5, precision=precision).to(dev)
+    spec = O.fine_spec(dim=1024, depth=depth, heads=16)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ids = O.synthetic_ids(spec, 1, [1, 225, 225], seed=777)
+    N = 1817
+    noise = torch.randn(1, N, generator=torch.Generator().manual_seed(13))
+    gnames = ["transformer.layers.0.0.to_q.weight", f"transformer.layers.{depth - 1}.2.1.weight", "logit_weights.2",
+              "transformer.rel_pos_bias.net.2.0.weight", "transformer.layers.0.0.to_kv.weight"] if with_grads else []
+    if depth not in _LARGE_ORACLE:                   # same seed -> same weights for both precisions: one oracle run per depth
+        sdo = {k: v.clone().requires_grad_(k in gnames) for k, v in sd.items()}
+        with torch.set_grad_enabled(with_grads):
+            o_loss, o_logits, _ = O.wrapper_forward_loss(sdo, spec, ids, [0., 0., 1.], forget_noise=noise)
+        o_grads = dict(zip(gnames, torch.autograd.grad(o_loss, [sdo[k] for k in gnames]))) if with_grads else {}
+        _LARGE_ORACLE[depth] = (o_loss.detach(), [l.detach() if l is not None else None for l in o_logits], o_grads)
+    o_loss, o_logits, o_grads = _LARGE_ORACLE[depth]
+    import open_musiclm_amd.open_musiclm as MM
+    orig = MM.generate_mask_with_prob
+    MM.generate_mask_with_prob = lambda shape, p, device: O.forgetful_mask_from_noise(noise, p).to(device)
+    try:
+        wrapper = M.TokenConditionedTransformerWrapper(transformer=model, unique_consecutive=False,
+                                                       cross_entropy_loss_weights=[0., 0., 1.], mask_prob=0.15)
+        wrapper.train()
+        loss, logits, _ = wrapper(all_token_ids=[t.to(dev) for t in ids], return_loss=True)
+        loss.backward()
+    finally:
+        MM.generate_mask_with_prob = orig
+    assert logits[-1].shape == o_logits[-1].shape and logits[-1].shape[-1] == 1126
+    e_inf, e_l2 = relerr(logits[-1], o_logits[-1].detach()), rel_l2(logits[-1], o_logits[-1].detach())
+    e_loss = abs(float(loss) - float(o_loss)) / float(o_loss)
+    params = dict(model.named_parameters())
+    g = {k: relerr(params[k].grad, o_grads[k]) for k in gnames}
+    gfinite = all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    report(f"large_fine[depth={depth},{precision}]", logits_inf=e_inf, logits_l2=e_l2, loss=e_loss, grads=g, N=N,
+           grads_finite=gfinite)
+    return e_inf, e_loss, g, gfinite
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_large_fine_stage_full_depth_forward_loss_vs_oracle(dev, precision):
+    """BASELINE config 4 (musiclm_large fine stage): all 24 layers, 16 heads, N = 1817: loss and logits vs the oracle."""
+    e_inf, e_loss, _, gfinite = _large_fine(dev, 24, precision, with_grads=False)
+    assert e_inf < TOL[precision]["logits"] and e_loss < TOL[precision]["loss"] and gfinite, (e_inf, e_loss)
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_large_fine_stage_gradients_vs_oracle(dev, precision):
+    """Same shapes (16 heads, N = 1817, 5 fine quantizers) at depth 2 so that the oracle's autograd fits a test: grads."""
+    e_inf, e_loss, g, _ = _large_fine(dev, 2, precision, with_grads=True)
+    assert e_inf < TOL[precision]["logits"] and e_loss < TOL[precision]["loss"], (e_inf, e_loss)
+    assert max(g.values()) < TOL[precision]["grad"], g
+
+
 def test_trainer_steps_and_checkpoint_roundtrip(dev, tmp_path):
     from open_musiclm_amd import open_musiclm as M
     from open_musiclm_amd.data import SyntheticTokenDataset

@@ -2,6 +2,7 @@
 
     python tools/prof_summary.py stats gpurun_out/prof8/r8_results.db profiles/r01_kernel_stats.md --steps 5
     python tools/prof_summary.py pmc   gpurun_out/pmc profiles/r01_gemm_pmc.md
+    python tools/prof_summary.py shapes gpurun_out/prof/x_results.db profiles/r02_gemm_shapes.md   (per kernel x grid)
 """
 import collections
 import csv
@@ -85,6 +86,26 @@ def pmc(root, out):
             f.write(f"| `{short(dm[name])}` | {grid} | {ctr} | {sum(x[0] for x in v) / len(v):.4g} | {sum(x[1] for x in v) / len(v) / 1e3:.1f} | {len(v)} |\n")
 
 
+def shapes(db, out, match="gemm"):
+    """Per (kernel instantiation, grid) durations: separates the GEMM shapes of a training step that share one kernel."""
+    c = sqlite3.connect(db)
+    rows = list(c.execute("select name, grid_x, grid_y, workgroup_x, start, end, lds_size, vgpr_count, accum_vgpr_count "
+                          "from kernels order by start"))
+    rows = rows[len(rows) // 3:]                     # skip warm-up / setup launches
+    dm = demangle(sorted({r[0] for r in rows}))
+    agg = collections.OrderedDict()
+    for n, gx, gy, wx, s, e, lds, vg, ag in rows:
+        if match not in n:
+            continue
+        agg.setdefault((short(dm[n]), gx // max(wx, 1), gy, lds, vg, ag), []).append((e - s) / 1e3)
+    tot = sum(sum(v) for v in agg.values())
+    with open(out, "w") as f:
+        f.write(f"# per-launch-shape durations of `{match}` kernels (steady-state part of `{db}`)\n\n")
+        f.write("| kernel | workgroups | grid.y | LDS B | VGPR | AGPR | launches | avg us | min us | share % |\n|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|\n")
+        for (name, wg, gy, lds, vg, ag), v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+            f.write(f"| `{name}` | {wg} | {gy} | {lds} | {vg} | {ag} | {len(v)} | {sum(v) / len(v):.1f} | {min(v):.1f} | {100 * sum(v) / tot:.1f} |\n")
+
+
 if __name__ == "__main__":
     mode = sys.argv[1]
     if mode == "stats":
@@ -92,5 +113,7 @@ if __name__ == "__main__":
         stats(sys.argv[2], sys.argv[3], steps)
     elif mode == "pmc":
         pmc(sys.argv[2], sys.argv[3])
+    elif mode == "shapes":
+        shapes(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else "gemm")
     else:
         raise SystemExit(__doc__)
