@@ -245,7 +245,7 @@ def e2e_generate_leg(dev, seconds=10):
     def run(secs):
         clap_ids = cq.quantize(emb)
         return mlm.generate(clap_token_ids=clap_ids, output_seconds=secs, return_tokens=True)
-    run(1)                                                  # warm-up: weight prep, allocator, kernels loaded
+    run(4)                                                  # warm-up (one coarse window, two fine windows): weight prep, allocator
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     s, c, f = run(seconds)

@@ -147,8 +147,8 @@ __device__ __forceinline__ void pack_acc(const f32x16& p, int s, bf16x8& hi, bf1
 // =============================================================================================================
 // forward
 // =============================================================================================================
-// AT_LEAN=1 (forward, the mask / bias part of the dQ kernel, the score loop of the dK/dV kernel; off until it has run through the
-// parity tests on the GPU): the ISA of the forward shows ~400 VALU
+// AT_LEAN=1 (forward, the mask / bias part of the dQ kernel, the score loop of the dK/dV kernel; default since it ran through
+// the parity tests on the GPU): the ISA of the forward shows ~400 VALU
 // instructions per 8 MFMAs (one 32-key subtile), i.e. the kernel is VALU-bound 3:1.  The lean variant removes, without changing
 // a single result bit except where noted:
 //   * 80 v_accvgpr_read/write per subtile: without an occupancy hint hipcc keeps the accumulators in AGPRs and copies them out
@@ -159,7 +159,7 @@ __device__ __forceinline__ void pack_acc(const f32x16& p, int s, bf16x8& hi, bf1
 //   * on subtiles entirely below the diagonal (all but one per query tile): the causal compare, the clamp of the bias index and
 //     the per-score address arithmetic (constant LDS offsets from one base), and the 64-bit mask-bit test (one 32-bit word).
 #ifndef AT_LEAN
-#define AT_LEAN 0
+#define AT_LEAN 1      /* round 2, first GPU call: parity tests identical, forward 206 -> 145 us, backward 694 -> 643 us per layer */
 #endif
 #if AT_LEAN
 #define AT_FWD_OCC __attribute__((amdgpu_waves_per_eu(2)))

@@ -276,7 +276,9 @@ def dropout_salt(tr, dev) -> torch.Tensor:
     seeds are fixed host constants; kernels combine both (omlm_ffmid_*: seed + *seed_dev * phi)."""
     st = tr.__dict__.get("_omlm_dropout")
     if st is None or st["counter"].device != dev:
-        g = torch.Generator().manual_seed(int(torch.initial_seed()) & 0x7FFFFFFF)
+        # the rank is mixed in: data-parallel replicas see different samples and must not share dropout masks
+        rank = int(os.environ.get("RANK", "0"))
+        g = torch.Generator().manual_seed((int(torch.initial_seed()) + 0x9E3779B1 * rank) & 0x7FFFFFFF)
         st = dict(counter=torch.zeros(1, dtype=torch.int64, device=dev),
                   seeds=[int(v) for v in torch.randint(1, 2 ** 62, (len(tr.layers),), generator=g)])
         tr.__dict__["_omlm_dropout"] = st

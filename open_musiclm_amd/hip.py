@@ -104,3 +104,9 @@ def require_gpu(t: torch.Tensor, what: str = "tensor"):
         raise RuntimeError(
             f"open_musiclm_amd: {what} is on {t.device}; the TokenConditionedTransformer path only runs on an "
             "MI355X through libomlm_hip.so (no CPU fallback). Move the model and inputs to 'cuda'.")
+    cur = torch.cuda.current_device()
+    if t.device.index != cur:
+        # kernels are launched on the current device's stream with raw pointers: a tensor of another GPU would be read through
+        # the wrong context (one process drives ONE GPU; under torchrun that is cuda:LOCAL_RANK)
+        raise RuntimeError(f"open_musiclm_amd: {what} lives on cuda:{t.device.index} but the current device is cuda:{cur}; "
+                           "call torch.cuda.set_device(LOCAL_RANK) and keep the model and its inputs on that device")

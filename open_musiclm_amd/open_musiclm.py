@@ -29,6 +29,11 @@ class TokenSequenceInfo():
     unique_consecutive: bool
 
 
+# Test hook: callable (n_draws, batch, V + 1) -> [n_draws, batch, V + 1] uniforms consumed by `generate` in place of the device
+# RNG when no `uniforms` argument is given (the golden test of MusicLM.forward replays the reference's draws through it).
+UNIFORM_SOURCE = None
+
+
 def _flat(t: torch.Tensor) -> torch.Tensor:
     return t.reshape(t.shape[0], -1)
 
@@ -178,7 +183,12 @@ class TokenConditionedTransformerWrapper(nn.Module):
             dec = decode.CachedDecoder(self.transformer, batch, rows, self.transformer._precision())
             last = dec.prefill(cond + [sampled])
             n0 = sampled.shape[-1]
-            U = uniforms[:n_new].to(device).float().contiguous() if exists(uniforms) else torch.rand(n_new, batch, V1, device=device)
+            if exists(uniforms):
+                U = uniforms[:n_new].to(device).float().contiguous()
+            elif UNIFORM_SOURCE is not None:
+                U = UNIFORM_SOURCE(n_new, batch, V1).to(device).float().contiguous()
+            else:
+                U = torch.rand(n_new, batch, V1, device=device)
             forbid = [(not allow_eos_in_output) or (ind != Q - 1) for ind in range(Q)]
             loop = decode.SamplingLoop(dec, last, U, n0, n_new, k, temperature, forbid, use_graph=kwargs.pop('use_graph', False))
             new_ids = loop.run()                                   # [n_new, B]
@@ -188,8 +198,12 @@ class TokenConditionedTransformerWrapper(nn.Module):
                 for ind in range(Q):
                     last = self.transformer.last_logits(cond + [sampled])
                     forbid = (not allow_eos_in_output) or (ind != Q - 1)
-                    u = uniforms[step].to(device).float().contiguous() if exists(uniforms) \
-                        else torch.empty(batch, V1, device=device).uniform_(0, 1)
+                    if exists(uniforms):
+                        u = uniforms[step].to(device).float().contiguous()
+                    elif UNIFORM_SOURCE is not None:
+                        u = UNIFORM_SOURCE(1, batch, V1)[0].to(device).float().contiguous()
+                    else:
+                        u = torch.empty(batch, V1, device=device).uniform_(0, 1)
                     ops.sample_topk_gumbel(last, u, nxt, V1, k, temperature, forbid)
                     sampled = torch.cat((sampled, nxt[:, None]), dim=-1)
                     step += 1

@@ -147,6 +147,29 @@ class FusedAdam(torch.optim.Optimizer):
     def mark_grads_dirty(self):
         self._grads_clean = False
 
+    @torch.no_grad()
+    def sync_replicas(self, dp, src: int = 0):
+        """Make every data-parallel replica start from rank `src`'s state (what DDP's constructor broadcast does in the
+        reference, trainer.py:286-304 via accelerator.prepare): ONE broadcast each of the flat parameter buffer and the two
+        Adam moment buffers, then the bf16 operand shadow is refreshed from the received masters."""
+        self._ensure_flat()
+        if not dp.is_distributed:
+            return
+        f = self._flat
+        for name in ('P', 'M', 'V'):
+            dp.broadcast_(f[name], src=src)
+        t = torch.tensor([self._t], device=f['P'].device, dtype=torch.int64)
+        dp.broadcast_(t, src=src)
+        self._t = int(t.item())
+        f['P16'].copy_(f['P'])
+        params = self._all_params()
+        if hasattr(torch._C, "_increment_version"):
+            torch._C._increment_version(params)
+        else:
+            torch._foreach_add_(params, 0.0)
+        for p in params:
+            p._omlm_bf16_version = p._version
+
     def state_dict(self):
         """torch.optim.Adam(W)-shaped state_dict so checkpoints interoperate with the reference's trainer."""
         self._ensure_flat()

@@ -27,7 +27,8 @@ class DataParallel:
             use_cuda = torch.cuda.is_available() and (device is None or torch.device(device).type == "cuda")
             if use_cuda:
                 torch.cuda.set_device(self.local_rank)
-            dist.init_process_group(backend=backend or ("nccl" if use_cuda else "gloo"),
+            backend = backend or os.environ.get("OMLM_DP_BACKEND") or ("nccl" if use_cuda else "gloo")
+            dist.init_process_group(backend=backend,
                                     rank=self.rank, world_size=self.world_size)
             self.owns_group = True
         if dist.is_initialized():

@@ -35,10 +35,14 @@ from .parallel import DataParallel
 from .utils import copy_file_to_folder, default, exists
 
 
-def cycle(dl):
+def cycle(dl, sampler=None):
+    epoch = 0
     while True:
+        if sampler is not None:                    # DistributedSampler: a new shuffle every pass (else every epoch repeats)
+            sampler.set_epoch(epoch)
         for data in dl:
             yield data
+        epoch += 1
 
 
 def yes_or_no(question):
@@ -91,6 +95,17 @@ class SingleStageTrainer(nn.Module):
         super().__init__()
         # accelerate_kwargs is accepted for script compatibility: log_with / logging_dir select the JSONL tracker
         self.dp = DataParallel(device=transformer.device)
+        if self.dp.is_distributed and transformer.device.type == 'cuda':
+            # One process drives ONE GPU: cuda:LOCAL_RANK.  The reference's scripts build the model with device='cuda' (= cuda:0
+            # on every rank) and rely on accelerator.prepare to place it (trainer.py:286-304); here the trainer moves the
+            # transformer and the frozen front-ends before the optimizer adopts the parameters.
+            target = torch.device('cuda', self.dp.local_rank)
+            torch.cuda.set_device(target)
+            if transformer.device != target:
+                transformer.to(target)
+                for m in (wav2vec, neural_codec, audio_conditioner):
+                    if isinstance(m, nn.Module):
+                        m.to(target)
         self.log_with = accelerate_kwargs.get('log_with')
         self.logging_dir = accelerate_kwargs.get('logging_dir') or accelerate_kwargs.get('project_dir')
 
@@ -163,7 +178,11 @@ class SingleStageTrainer(nn.Module):
             vsampler = DistributedSampler(self.valid_ds, num_replicas=self.dp.world_size, rank=self.dp.rank, shuffle=True)
         self.dl = make_dl(self.ds, batch_size=batch_size, shuffle=sampler is None, sampler=sampler)
         self.valid_dl = make_dl(self.valid_ds, batch_size=batch_size, shuffle=vsampler is None, sampler=vsampler)
-        self.dl_iter, self.valid_dl_iter = cycle(self.dl), cycle(self.valid_dl)
+        self.dl_iter, self.valid_dl_iter = cycle(self.dl, sampler), cycle(self.valid_dl, vsampler)
+        if self.dp.is_distributed and transformer.device.type == 'cuda':
+            # replicas start identical (rank 0's weights / moments), but draw different forgetful masks and dropout masks
+            self.optim.sync_replicas(self.dp)
+            torch.cuda.manual_seed(int(torch.initial_seed() + 7919 * (self.dp.rank + 1)) & 0x7FFFFFFFFFFF)
 
         self.save_model_every, self.save_results_every = save_model_every, save_results_every
         self.save_predicted_tokens, self.save_reconstructed_wave = save_predicted_tokens, save_reconstructed_wave
@@ -215,6 +234,8 @@ class SingleStageTrainer(nn.Module):
             assert scheduler_path.exists()
             self.scheduler.load_state_dict(torch.load(scheduler_path, map_location=self.device, weights_only=False))
         self._graphed = None        # weights changed under the captured graph: re-capture on the next micro-step
+        if self.dp.is_distributed and self.device.type == 'cuda':
+            self.optim.sync_replicas(self.dp)
         if steps > 0:
             assert int(self.steps.item()) == 0, 'steps should be 0 when loading a checkpoint for the first time'
             self.steps += steps

@@ -456,6 +456,25 @@ def test_rvq_and_kmeans_bit_exact(ops, dev, golden_dir):
     report("rvq_kmeans", exact=True)
 
 
+def test_kmeans_assign_real_dims_vs_sklearn(ops, dev):
+    """HfHubertWithKmeans assign step at the shipped dimensions (768-d MERT features, 1024 centroids, hubert_kmeans_cfg of
+    configs/model/musiclm_small.json) through the product class, against sklearn's MiniBatchKMeans.predict itself (the call the
+    reference makes, hf_hubert_kmeans.py:87) on clustered features.  The mismatch count is reported; the bar is bit-exact ids."""
+    from sklearn.cluster import MiniBatchKMeans
+    from open_musiclm_amd.hf_hubert_kmeans import HfHubertWithKmeans
+    rng = np.random.RandomState(0)
+    centers = rng.randn(1024, 768).astype(np.float32)
+    feats = (centers[rng.randint(0, 1024, 8192)] + 0.7 * rng.randn(8192, 768)).astype(np.float32)
+    km = MiniBatchKMeans(n_clusters=1024, batch_size=2048, n_init=1, random_state=0, max_iter=3).fit(feats)
+    x = (centers[rng.randint(0, 1024, 4096)] + 0.7 * rng.randn(4096, 768)).astype(np.float32)
+    ref = km.predict(x).astype(np.int64)
+    w2v = HfHubertWithKmeans(hubert=None, kmeans=km, normalize_embeds=False).to(dev)
+    got = w2v.kmeans.predict(torch.from_numpy(x).to(dev)).cpu().numpy()
+    mism = int((got != ref).sum())
+    report("kmeans_768x1024", mismatches=mism, n=len(x))
+    assert mism == 0, mism
+
+
 def test_sampler_matches_oracle(ops, dev):
     from oracle import musiclm_oracle as O
     B, V = 5, 1025

@@ -306,3 +306,45 @@ def test_reference_training_scripts_import_against_this_package(script):
     r = subprocess.run([sys.executable, "-c", probe], cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "--model_config" in r.stdout
+
+
+def test_preprocessed_dataset_matches_reference_crops(golden_dir):
+    """data.PreprocessedDataset against the REFERENCE class (data.py:304-429) on a token store written with the reference's own
+    sqlite adapters: same random.seed -> identical crops, item by item, for all three stages (oracle/make_golden_r2.py)."""
+    import ast
+    import random
+    import numpy as np
+    from open_musiclm_amd.data import PreprocessedDataset
+    z = np.load(os.path.join(golden_dir, "preprocessed_crops.npz"))
+    kw = ast.literal_eval(str(z["meta"]))
+    folder = os.path.join(golden_dir, "preprocessed")
+    for stage in ("semantic", "coarse", "fine"):
+        ds = PreprocessedDataset(folder, stage=stage, **kw)
+        assert len(ds) == 4
+        for seed in (0, 1, 2):
+            random.seed(1000 + seed)
+            for i in range(len(ds)):
+                item = ds[i]
+                for f, t in enumerate(item):
+                    ref = z[f"{stage}.{seed}.{i}.{f}"]
+                    assert tuple(t.shape) == ref.shape and t.dtype == torch.int32, (stage, seed, i, f, t.shape, ref.shape)
+                    assert np.array_equal(t.numpy(), ref), (stage, seed, i, f)
+
+
+def test_kmeans_assign_oracle_vs_sklearn_at_real_dims():
+    """hf_hubert_kmeans.py:87 calls sklearn MiniBatchKMeans.predict on 768-d MERT features against 1024 centroids
+    (configs/model/musiclm_small.json hubert_kmeans_cfg).  The oracle (sum (x - c)^2, lowest index on ties) is compared with
+    sklearn itself at those dimensions on clustered features; the mismatch count is reported, not assumed."""
+    import numpy as np
+    from sklearn.cluster import MiniBatchKMeans
+    from oracle import musiclm_oracle as O
+    rng = np.random.RandomState(0)
+    centers = rng.randn(1024, 768).astype(np.float32)
+    feats = (centers[rng.randint(0, 1024, 8192)] + 0.7 * rng.randn(8192, 768)).astype(np.float32)
+    km = MiniBatchKMeans(n_clusters=1024, batch_size=2048, n_init=1, random_state=0, max_iter=3).fit(feats)
+    x = (centers[rng.randint(0, 1024, 4096)] + 0.7 * rng.randn(4096, 768)).astype(np.float32)
+    ref = km.predict(x).astype(np.int64)
+    mine = O.kmeans_assign(x, km.cluster_centers_.astype(np.float32))
+    mism = int((ref != mine).sum())
+    print(f"kmeans 768 x 1024: {mism} mismatches / {len(x)}")
+    assert mism == 0, mism
