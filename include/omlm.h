@@ -62,8 +62,18 @@ int omlm_qk_norm_bwd(const float* dq, const float* dk, const float* dv, const fl
  * inputs as the xformers seam at :275-301, without materialising attn_bias).  bias: [N, bias_ld] fp32, row = i-j,
  * column = head (the un-gathered MLP output of RelativePositionBias, :60-64).  keymask: [B, N] uint8, 1 = attend.
  * lse: [B, H, N] (log2 domain).  bwd: dq [B*N, H*64], dk, dv [B*N, 64] fp32 overwritten; dbias += ; delta scratch [B,H,N]. */
-int omlm_mqa_attn_fwd(const void* q, const void* k, const void* v, const float* bias, const unsigned char* keymask,
-                      void* out, float* lse, int B, int N, int H, float scale, int bias_ld, int dtype, void* stream);
+int omlm_mqa_attn_fwd(const void* q, const void* k, const void* v, const float* bias, const float* biasT,
+                      const unsigned char* keymask, void* out, float* lse, int B, int N, int H, float scale, int bias_ld,
+                      int dtype, void* stream);
+/* biasT: the same table transposed to [ceil8(H)][ld'] with 64 leading zeros per row, zero tail, pre-multiplied by log2(e): the
+ * layout the bf16 kernels stream per key tile (omlm_attn_bias_table_floats floats; bias == NULL gives an all-zero table).
+ * Built once per forward for all layers; fp32 ("bf16x3") operands read `bias` directly and ignore biasT. */
+long long omlm_attn_bias_table_floats(int N, int H);
+/* q_scale / k_scale (64 floats each, optional: the learned scales of transformer.py:269-271) or qk_bound > 0 give the bound
+ * |q.k| <= max_d |q_scale_d k_scale_d| that lets the bf16 forward exponentiate against a fixed reference point
+ * (m_h = scale log2e bound + max bias_h, subtracted from the table) instead of a running maximum; neither: online softmax. */
+int omlm_attn_bias_prepare(const float* bias, float* biasT, int N, int H, int bias_ld, const float* q_scale,
+                           const float* k_scale, float qk_bound, float scale, void* stream);
 int omlm_mqa_attn_bwd(const void* q, const void* k, const void* v, const float* bias, const unsigned char* keymask,
                       const void* out, const void* dout, const float* lse, float* delta,
                       float* dq, float* dk, float* dv, float* dbias,
@@ -103,7 +113,8 @@ int omlm_cross_entropy_bwd(const float* logits, const int* labels, const float* 
                            float coef, void* dlogits, int R, int V, int ld, int ldd, int out_dtype, void* stream);
 
 /* clip_grad_norm_ + Adam/AdamW on flat buffers (optimizer.py:10-34; trainer.py:444-447). */
-int omlm_sumsq_accumulate(const float* g, long long n, float* out, void* stream);
+/* out[0] += sum g^2; partials (optional, >= 2048 floats) selects the bit-reproducible two-pass form (identical clip on every replica). */
+int omlm_sumsq_accumulate(const float* g, long long n, float* out, float* partials, void* stream);
 int omlm_adamw_clip_step(float* p, float* g, float* m, float* v, void* p16, long long n,
                          float lr, float beta1, float beta2, float eps, float wd, int step,
                          float gscale, const float* gnorm_sq, float max_norm, int decoupled, int zero_grad, void* stream);

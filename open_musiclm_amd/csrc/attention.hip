@@ -19,6 +19,7 @@
 //   * T = float inputs select the bf16x3 split (hi*hi + hi*lo + lo*hi) for the forward; the backward
 //     kernels always run single-pass bf16 MFMA with fp32 accumulation.
 #include "common.h"
+#include <stdlib.h>
 
 #define AT_THREADS 256
 #define TQ 32
@@ -685,13 +686,21 @@ static int set_lds(K kernel, size_t bytes) {
     return OMLM_OK;
 }
 
+int attn2_fwd_launch(const void* q, const void* k, const void* v, const float* biasT, const unsigned char* keymask,
+                     void* out, float* lse, int B, int N, int H, float scale, hipStream_t st);        // attention2.hip
+static bool attn_v1_forced() { static int f = -1; if (f < 0) { const char* e = getenv("OMLM_ATTN_V1"); f = (e && e[0] == '1') ? 1 : 0; } return f == 1; }
+
 // q [B*N, H*64], k, v [B*N, 64] (dtype), bias [N, bias_ld] fp32 (row = i - j, column = head) or null, keymask [B, N] uint8 or null (1 = attend)
-// out [B*N, H*64] (dtype), lse [B, H, N] fp32 (log2 domain)
-extern "C" int omlm_mqa_attn_fwd(const void* q, const void* k, const void* v, const float* bias, const unsigned char* keymask,
-                                 void* out, float* lse, int B, int N, int H, float scale, int bias_ld, int dtype, void* stream) {
+// biasT: the table prepared by omlm_attn_bias_prepare (bf16 operands take the attention2.hip kernel, which reads it; may be null
+// when bias is null).  out [B*N, H*64] (dtype), lse [B, H, N] fp32 (log2 domain)
+extern "C" int omlm_mqa_attn_fwd(const void* q, const void* k, const void* v, const float* bias, const float* biasT,
+                                 const unsigned char* keymask, void* out, float* lse, int B, int N, int H, float scale,
+                                 int bias_ld, int dtype, void* stream) {
     if (B <= 0 || N <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(q && k && v && out && lse, "null pointer");
     OMLM_CHECK_ARG(H >= 1 && (!bias || bias_ld >= H), "heads / bias pitch");
+    if (dtype == 1 && (biasT || !bias) && !attn_v1_forced())
+        return attn2_fwd_launch(q, k, v, biasT, keymask, out, lse, B, N, H, scale, as_stream(stream));
     dim3 grid((N + TQ - 1) / TQ, (H + 3) / 4, B), block(AT_THREADS);
     int rc;
     if (dtype == 0) {

@@ -1,0 +1,435 @@
+// Causal multi-query attention, second-generation kernels for bf16 operands (transformer.py:254-331 of the reference).
+//
+// What changed against attention.hip (whose kernels stay for fp32 / "bf16x3" operands), and why:
+//   * one workgroup = 8 waves = 8 HEADS of the same 32*QB queries: the single shared K/V head (MQA) is staged once per tile
+//     for all of them (the old geometry staged a tile for 4 heads through registers + ds_write behind two barriers per tile,
+//     and paid a global round trip for the key mask inside the loop: ~3.9 k cycles per 32x32 block for 8 MFMAs);
+//   * K / V tiles and the rel-pos bias window of the tile go HBM/L2 -> LDS by LDS-DMA (buffer_load ... lds) into a 3-stage
+//     ring: no VGPR staging, no ds_write, ONE barrier per 64-key tile, two tiles in flight behind counted vmcnt waits;
+//   * the key mask costs nothing per score: masked keys get ZERO V rows (the DMA reads them through an out-of-bounds
+//     offset) and the softmax denominator is produced by the matrix cores from a 1/0 "live" vector (2 extra MFMAs per block),
+//     so masked keys contribute to neither numerator nor denominator.  The running max may include masked keys' scores
+//     (they are bounded like the others: l2-normalised q, k); that only moves the reference point of the exponentials;
+//   * the causal compare exists only in the blocks that touch the diagonal;
+//   * the rel-pos bias is read from a per-tile window (LDS, 128 floats per head) with compile-time offsets from one lane base.
+// The arithmetic per score is: fma (scale * log2 e, bias), max, subtract, exp2, pack -- everything else is on the matrix cores.
+#include "common.h"
+
+#define A2_THREADS 512
+#define A2_TKV 64
+#define A2_PAD 64            /* zero entries in front of each row of the transposed bias table (rel >= -64) */
+#define A2_BWIN 128          /* floats per head in a tile's bias window */
+#define A2_NEG (-1.0e30f)
+#define A2_LOG2E 1.4426950408889634f
+#define A2_STAGE (8192 + 8192 + 8 * A2_BWIN * 4)     /* K rows | V blocked | bias window = 20 KiB */
+#define A2_NST 3
+#ifndef A2_ABLATE
+#define A2_ABLATE 0          /* profiling builds only: 1 = skip the tile arithmetic, 2 = skip the steady-state DMA, 4 = no exp2 */
+#endif
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+// [rows][64 dims] bf16 tile, 128 B per row; 16-B chunk index XOR ((row >> 1) & 7)   (same image as attention.hip)
+__device__ __forceinline__ int a2_tile_off(int row, int colbyte) {
+    return row * 128 + ((((colbyte >> 4) ^ ((row >> 1) & 7)) << 4) | (colbyte & 15));
+}
+__device__ __forceinline__ int a2_crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+__device__ __forceinline__ bf16x8 a2_frag_rows(const char* lds, int row0, int s, int lane) {
+    return *(const bf16x8*)(lds + a2_tile_off(row0 + (lane & 31), (2 * s + (lane >> 5)) * 16));
+}
+// transposed operand from the BLOCKED image (see attention.hip tile_off_blk): both reads are linear in the lane id
+__device__ __forceinline__ bf16x8 a2_frag_cols_tr(const char* lds, int row0, int s, int col0, int lane) {
+    const char* base = lds + ((((row0 >> 4) + s) << 1) + (col0 >> 5)) * 1024 + lane * 8;
+    s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base));
+    s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base + 512));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ bf16x8 a2_pack(const f32x16& p, int s) {
+    u32x4 h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h[e] = pack_bf16_rne(p[8 * s + 2 * e], p[8 * s + 2 * e + 1]);
+    return __builtin_bit_cast(bf16x8, h);
+}
+
+// ---- bias table [N, ld] (row = i - j, column = head) -> transposed, padded, pre-multiplied by log2 e: [H8][ldT] ----------
+// One workgroup per head.  With a bound on |q.k| (qk_max, from the learned scales or given) the fixed reference point
+// m_h = c qk_max + max_r table_h[r] is subtracted from every entry (pads included) and written to the row's tail
+// [ldT - 2] = 1.0 (flag), [ldT - 1] = m_h; without one, or if the exponent range could get near fp32's, the flag is 0.
+__global__ void attn2_bias_prep_kernel(const float* __restrict__ bias, float* __restrict__ biasT, int N, int H, int ld, int ldT,
+                                       const float* __restrict__ q_scale, const float* __restrict__ k_scale, float qk_bound, float c) {
+    __shared__ float red[8];
+    const int h = blockIdx.x, t = threadIdx.x;
+    float* row = biasT + (size_t)h * ldT;
+    const bool has = bias && h < H;
+    float bmax = has ? -3.0e38f : 0.f, bmin = has ? 3.0e38f : 0.f;
+    if (has) for (int r = t; r < N; r += 256) { const float x = bias[(size_t)r * ld + h] * A2_LOG2E; bmax = fmaxf(bmax, x); bmin = fminf(bmin, x); }
+    float qk = qk_bound;
+    if (q_scale && k_scale) { qk = 0.f; if (t < 64) qk = fabsf(q_scale[t] * k_scale[t]); }
+    bmax = wave_max(bmax); bmin = -wave_max(-bmin); qk = wave_max(qk);
+    __syncthreads();
+    if ((t & 63) == 0) { red[t >> 6] = bmax; red[4 + (t >> 6)] = bmin; }
+    __syncthreads();
+    bmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    bmin = fminf(fminf(red[4], red[5]), fminf(red[6], red[7]));
+    if (q_scale && k_scale) qk = __shfl(qk, 0, 64);      // wave 0 holds it; other waves recompute below
+    __syncthreads();
+    if (t == 0) red[0] = qk;
+    __syncthreads();
+    qk = (q_scale && k_scale) ? red[0] : qk_bound;
+    const float B = c * qk;
+    // all exponents lie in [-(2 B + bmax - bmin), 0]; keep them well inside the fp32 normal range
+    const bool fixed = qk > 0.f && (2.f * B + (bmax - bmin)) < 80.f;
+    const float m = fixed ? B + bmax : 0.f;
+    for (int x = t; x < ldT - 2; x += 256) {
+        const int r = x - A2_PAD;
+        const float v = (has && r >= 0 && r < N) ? bias[(size_t)r * ld + h] * A2_LOG2E : 0.f;
+        row[x] = v - m;
+    }
+    if (t == 0) { row[ldT - 2] = fixed ? 1.0f : 0.f; row[ldT - 1] = m; }
+}
+
+// One LDS-DMA wave-instruction = 1 KiB (64 lanes x 16 B), destination lane-linear (M0 = wave-uniform LDS byte address).
+// Issued as inline asm on purpose: with the builtin, hipcc tracks "a pending LDS write" and protects LDS reads it cannot
+// prove disjoint with s_waitcnt vmcnt(N) -- one build of this kernel waited for the K tile it had JUST requested in front
+// of every first MFMA of a tile (seen in the ISA), i.e. the 3-stage ring ran with zero tiles in flight.  The asm form is
+// invisible to that bookkeeping; ordering is by the counted s_waitcnt vmcnt + s_barrier at the top of the tile loop.
+typedef u32x4 a2_rsrc;
+__device__ __forceinline__ a2_rsrc a2_make_rsrc(const void* p, unsigned bytes) {     // wave-uniform inputs only
+    const unsigned long long a = (unsigned long long)p;
+    a2_rsrc r;
+    r[0] = (unsigned)a; r[1] = (unsigned)(a >> 32) & 0xFFFFu; r[2] = bytes; r[3] = 0x00020000u;
+    return r;
+}
+__device__ __forceinline__ void a2_dma(a2_rsrc rs, unsigned lds_dst, unsigned off) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(off), "s"(lds_dst), "s"(rs) : "memory");
+}
+
+struct A2Stager {
+    unsigned koff, voff, boff;       // per-lane source byte offsets relative to the tile (key j0) / window start
+    int vrow;                        // this lane's key row (0..63) in the V unit it issues
+    bool bias_wave;
+    __device__ __forceinline__ void init(int wave, int lane, int ldT) {
+        {   // K unit `wave`: rows 8 wave + (lane >> 3), slot lane & 7 holds chunk slot ^ ((row >> 1) & 7)
+            const int row = 8 * wave + (lane >> 3), ch = (lane & 7) ^ ((row >> 1) & 7);
+            koff = (unsigned)(row * 128 + ch * 16);
+        }
+        {   // V unit `wave` of the blocked image: unit = (row >> 4) * 2 + (col >> 5); lane = p * 8 + (row & 3) * 2 + ((col >> 3) & 1)
+            const int p = lane >> 3, rq = ((p >> 2) << 1) | ((p >> 1) & 1);
+            vrow = (wave >> 1) * 16 + rq * 4 + ((lane >> 1) & 3);
+            const int col = (wave & 1) * 32 + (p & 1) * 16 + (lane & 1) * 8;
+            voff = (unsigned)(vrow * 128 + col * 2);
+        }
+        {   // bias unit (wave & 3): heads 2 u, 2 u + 1; lane = (head & 1) * 32 + float4 index
+            const int u = wave & 3, hh = 2 * u + (lane >> 5);
+            boff = (unsigned)(((size_t)hh * ldT + 4 * (lane & 31)) * 4);
+            bias_wave = wave < 4;
+        }
+    }
+};
+
+template <int QB>
+struct A2Acc {
+    f32x16 acc[QB][2];      // O^T: [query block][d tile]
+    f32x16 accl;            // denominators; row parity (i & 1) == qb holds those of query block qb
+    float m[QB];            // running max (online path only)
+};
+
+// One 64-key tile against the wave's QB query blocks.
+//   FIXED: the exponentials are taken against a FIXED reference point instead of a running maximum.  q and k are l2-normalised
+//          vectors times learned scales (transformer.py:269-271), so |q.k| <= max_d |q_scale_d k_scale_d| =: qk_max and every
+//          score is <= m_h = scale log2(e) qk_max + max_rel bias_h.  omlm_attn_bias_prepare subtracts m_h from the table, so the
+//          work per score is ONE fma (score * c + table) and ONE exp2: no row maximum, no cross-lane step, no rescaling of
+//          the accumulators, no dependency between blocks other than the MFMA accumulation itself.  The result is the same
+//          softmax (numerator and denominator share the factor 2^-m_h); it is only selected while 2 c qk_max + the table's
+//          range stays far from the fp32 exponent range (flag in the table's tail), else the online path runs.
+//   FULL:  every block of the tile lies strictly below the diagonal for every query block: straight-line code, no compares.
+template <int QB, bool FIXED, bool FULL>
+__device__ __forceinline__ void a2_tile(A2Acc<QB>& A, const bf16x8 (&qf)[QB][4], const char* Ks, const bf16_t* livef_tile,
+                                        float c, int i0, int j0, int wave, int lane) {
+    const char* Vs = Ks + 8192;
+    const float* bw = (const float*)(Ks + 16384) + wave * A2_BWIN;
+    const int hi = lane >> 5, ql = lane & 31;
+    // both 32-key blocks in one straight line: the scheduler overlaps one block's exponentials with the other's MFMAs
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+        const int jb = j0 + 32 * sub;
+        if (!FULL && jb > i0 + 32 * QB - 1) break;              // above the diagonal for every query of the workgroup
+        bf16x8 kf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) kf[s] = a2_frag_rows(Ks, 32 * sub, s, lane);
+        bf16x8 pb[QB][2];
+        bool on[QB];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            on[qb] = FULL || jb <= i0 + 32 * qb + 31;           // wave-uniform
+            if (!on[qb]) continue;
+            f32x16 st;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) st[e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) st = MFMA16(kf[s], qf[qb][s], st);
+            // window index of (query, key): 64 + 32 qb + ql - 32 sub - 4 hi - cr   (cr = crow(r, 0))
+            const float* bp = bw + (64 + 32 * qb - 32 * sub) + ql - 4 * hi;
+            const bool diag = !FULL && !(jb + 31 <= i0 + 32 * qb);
+            const int d0 = (i0 + 32 * qb + ql) - (jb + 4 * hi);
+            if (FIXED) {
+                if (!diag) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) st[r] = (A2_ABLATE & 4) ? st[r] * c + bp[-((r & 3) + 8 * (r >> 2))] : __builtin_amdgcn_exp2f(st[r] * c + bp[-((r & 3) + 8 * (r >> 2))]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int cr = (r & 3) + 8 * (r >> 2);
+                        const float e2 = __builtin_amdgcn_exp2f(st[r] * c + bp[-cr]);
+                        st[r] = (d0 - cr >= 0) ? e2 : 0.f;
+                    }
+                }
+            } else {
+                float mloc = A2_NEG;
+                if (!diag) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        st[r] = st[r] * c + bp[-((r & 3) + 8 * (r >> 2))];
+                        mloc = fmaxf(mloc, st[r]);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int cr = (r & 3) + 8 * (r >> 2);
+                        const float val = st[r] * c + bp[-cr];
+                        st[r] = (d0 - cr >= 0) ? val : A2_NEG;
+                        mloc = fmaxf(mloc, st[r]);
+                    }
+                }
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+                const float mnew = fmaxf(A.m[qb], mloc);
+                const float alpha = __builtin_amdgcn_exp2f(A.m[qb] - mnew);
+                A.m[qb] = mnew;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[r] = __builtin_amdgcn_exp2f(st[r] - mnew);
+                if (!__all(alpha == 1.0f)) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { A.acc[qb][0][e] *= alpha; A.acc[qb][1][e] *= alpha; }
+                    A.accl[qb] *= alpha;                        // rows 0/4 (qb 0) and 1/5 (qb 1) are the ones read
+                }
+            }
+            pb[qb][0] = a2_pack(st, 0);
+            pb[qb][1] = a2_pack(st, 1);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            // live vector of the 16 keys of this k-step in MFMA k order: keys key0 + 4 hi + {0..3}, key0 + 8 + 4 hi + {0..3};
+            // A rows of parity qb carry it for query block qb, the others 0: ONE denominator accumulator for both blocks
+            const bf16_t* lp = livef_tile + 32 * sub + 16 * s + 4 * hi;
+            const u32x2 l0 = *(const u32x2*)lp, l1 = *(const u32x2*)(lp + 8);
+            const bf16x8 va0 = a2_frag_cols_tr(Vs, 32 * sub, s, 0, lane);
+            const bf16x8 va1 = a2_frag_cols_tr(Vs, 32 * sub, s, 32, lane);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                if (!on[qb]) continue;
+                const bool mine = QB == 1 || (ql & 1) == qb;
+                u32x4 lv4;
+                lv4[0] = mine ? l0[0] : 0u; lv4[1] = mine ? l0[1] : 0u; lv4[2] = mine ? l1[0] : 0u; lv4[3] = mine ? l1[1] : 0u;
+                A.acc[qb][0] = MFMA16(va0, pb[qb][s], A.acc[qb][0]);
+                A.acc[qb][1] = MFMA16(va1, pb[qb][s], A.acc[qb][1]);
+                A.accl = MFMA16(__builtin_bit_cast(bf16x8, lv4), pb[qb][s], A.accl);      // sum over live keys of P
+            }
+        }
+    }
+}
+
+#ifndef A2_OCC
+#define A2_OCC
+#endif
+template <int QB>
+__global__ __launch_bounds__(A2_THREADS) A2_OCC void attn2_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                               const bf16_t* __restrict__ v, const float* __restrict__ biasT, int ldT,
+                                                               const unsigned char* __restrict__ keymask, bf16_t* __restrict__ out,
+                                                               float* __restrict__ lse, int B, int N, int H, float scale) {
+    constexpr int TQW = 32 * QB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem;                                        // A2_NST stages
+    char* scratch = smem + A2_NST * A2_STAGE;                 // 4 KiB sink for the padding DMA of waves 4-7
+    bf16_t* livef = (bf16_t*)(scratch + 4096);                // [nkt_all * 64] 1.0 / 0.0 per key of this sample
+
+    const int nqt = (N + TQW - 1) / TQW, ny = (H + 7) / 8;
+    // XCD-aware, sample-major order: the workgroups of one sample (they share its K / V through the XCD's L2) are dealt to
+    // one XCD, heavy (late) query tiles first inside a sample.
+    int lg;
+    {
+        const int total = nqt * ny * B, lin = blockIdx.x;
+        const int qq = total >> 3, rr = total & 7, xcd = lin & 7, idx = lin >> 3;
+        lg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    }
+    const int b = lg / (nqt * ny);
+    const int rem = lg - b * (nqt * ny);
+    const int qt = nqt - 1 - rem / ny, hy = rem % ny;
+    const int lane = threadIdx.x & 63, hi = lane >> 5, ql = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = hy * 8 + wave;
+    const bool active = h < H;
+    const int i0 = qt * TQW;
+    const size_t rowbase = (size_t)b * N;
+    const int nkt = min((i0 + TQW + A2_TKV - 1) / A2_TKV, (N + A2_TKV - 1) / A2_TKV);   // key tiles this query tile needs
+
+    // ---- prologue: liveness of this sample's keys, as a bf16 1/0 array (denominator operand) and one ballot word per key tile
+    // (V rows of masked keys are DMA'd as zeros).  All byte loads are issued before the first wait: a rolled loop made hipcc
+    // wait for every load separately (one L2 round trip per key tile and workgroup: most of the kernel's time at first).
+    unsigned long long* livebits = (unsigned long long*)(livef + (size_t)((N + 63) / 64) * 64);     // [<= 64 tiles]
+    {
+        unsigned char mk[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) mk[it] = 1;
+        if (keymask) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) mk[it] = keymask[rowbase + min(it * A2_THREADS + (int)threadIdx.x, N - 1)];   // clamped: no branch per load
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int j = it * A2_THREADS + threadIdx.x;
+            if (it * A2_THREADS < nkt * A2_TKV) {               // uniform
+                const bool lv = j < N && mk[it] != 0;
+                const unsigned long long w = __ballot(lv);
+                if (j < nkt * A2_TKV) livef[j] = lv ? (bf16_t)1.0f : (bf16_t)0.0f;
+                if (lane == 0 && it * 8 + wave < nkt) livebits[it * 8 + wave] = w;
+            }
+        }
+    }
+    __syncthreads();                                          // livef / livebits visible; no LDS-DMA in flight yet
+    A2Stager stg;
+    stg.init(wave, lane, ldT);
+    const a2_rsrc rsK = a2_make_rsrc(k + rowbase * 64, (unsigned)N * 128u);
+    const a2_rsrc rsV = a2_make_rsrc(v + rowbase * 64, (unsigned)N * 128u);
+    const a2_rsrc rsB = a2_make_rsrc(biasT ? (const void*)(biasT + (size_t)hy * 8 * ldT) : (const void*)k, biasT ? (unsigned)(8 * ldT * 4) : 0u);
+    const unsigned ring_lds = (unsigned)(size_t)LDS_PTR(char, ring), scratch_lds = (unsigned)(size_t)LDS_PTR(char, scratch);
+
+    auto issue = [&](int t) {                                  // 3 DMA wave-instructions per wave per tile
+        const unsigned st = ring_lds + (unsigned)((t % A2_NST) * A2_STAGE);
+        const int j0 = t * A2_TKV;
+        const bool vl = (livebits[t] >> stg.vrow) & 1ull;      // one broadcast LDS read per tile
+        a2_dma(rsK, st + wave * 1024, (unsigned)(j0 * 128) + stg.koff);                 // rows >= N: beyond the descriptor -> zeros
+        a2_dma(rsV, st + 8192 + wave * 1024, vl ? (unsigned)(j0 * 128) + stg.voff : OOB_OFF);
+        // bias window of this tile: table index PAD + rel, rel from i0 - j0 - 64
+        const unsigned w0 = (unsigned)((A2_PAD + i0 - j0 - 64) * 4);
+        if (stg.bias_wave) a2_dma(rsB, st + 16384 + (wave & 3) * 1024, w0 + stg.boff);
+        else               a2_dma(rsB, scratch_lds + (wave & 3) * 1024, OOB_OFF);       // keeps every wave at 3 per tile
+    };
+
+    issue(0);
+    if (nkt > 1) issue(1);
+    // Q fragments (B operand of S^T = K Q^T): query i0 + 32 qb + ql, dims 16 s + 8 hi .. +7
+    bf16x8 qf[QB][4];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qi = i0 + 32 * qb + ql;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            u32x4 z = {0u, 0u, 0u, 0u};
+            const bf16_t* p = q + (rowbase + min(qi, N - 1)) * (size_t)(H * 64) + (size_t)(active ? h : 0) * 64 + 16 * s + 8 * hi;
+            u32x4 val = (active && qi < N) ? *(const u32x4*)p : z;
+            qf[qb][s] = __builtin_bit_cast(bf16x8, val);
+        }
+    }
+    // Consume the Q loads HERE: hipcc then waits for them before the loop.  Left to their first use inside the loop, its
+    // s_waitcnt vmcnt(0) sat in front of the first MFMA of every tile and drained the DMA ring each iteration (seen in the ISA).
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[qb][s]));
+
+    A2Acc<QB> A;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        A.m[qb] = A2_NEG;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { A.acc[qb][0][e] = 0.f; A.acc[qb][1][e] = 0.f; }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) A.accl[e] = 0.f;
+    const float c = scale * A2_LOG2E;
+    // fixed reference point (see a2_tile): the table prepared for this head carries its flag and value in the row's tail
+    float mfix = 0.f;
+    bool fixed = false;
+    if (biasT && active) {
+        const float* tail = biasT + (size_t)h * ldT + (ldT - 2);
+        fixed = __builtin_amdgcn_readfirstlane(__float_as_int(tail[0])) != 0;
+        mfix = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(tail[1])));
+    }
+    asm volatile("" : "+s"(mfix));                            // loaded (and waited for) before the tile loop
+
+    for (int t = 0; t < nkt; ++t) {
+        // own DMA of tile t retired (tile t+1's three may stay in flight), then everybody's; the barrier also says that all
+        // waves are done with tile t-1, whose stage tile t+2 is about to overwrite
+        if (t + 1 < nkt) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < nkt && !(A2_ABLATE & 2)) issue(t + 2);
+        if (!active || (A2_ABLATE & 1)) continue;
+        const char* Ks = ring + (t % A2_NST) * A2_STAGE;
+        const int j0 = t * A2_TKV;
+        const bool full = j0 + A2_TKV - 1 <= i0;               // every block of the tile lies below the diagonal of every query block
+        if (fixed) { if (full) a2_tile<QB, true, true>(A, qf, Ks, livef + j0, c, i0, j0, wave, lane);
+                     else      a2_tile<QB, true, false>(A, qf, Ks, livef + j0, c, i0, j0, wave, lane); }
+        else       { if (full) a2_tile<QB, false, true>(A, qf, Ks, livef + j0, c, i0, j0, wave, lane);
+                     else      a2_tile<QB, false, false>(A, qf, Ks, livef + j0, c, i0, j0, wave, lane); }
+    }
+    if (!active) return;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qi = i0 + 32 * qb + ql;
+        if (qi >= N) continue;
+        const float lsum = A.accl[qb];                  // element e = qb: row crow(qb, hi) has parity qb
+        const float mref = fixed ? mfix : A.m[qb];
+        // a query without any live causal key has no defined softmax: emit zeros and an lse that zeroes its backward
+        const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
+        bf16_t* orow = out + (rowbase + qi) * (size_t)(H * 64) + (size_t)h * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d = 32 * dt + 8 * g4 + 4 * hi;
+                store4_from_float(orow + d, A.acc[qb][dt][4 * g4] * inv, A.acc[qb][dt][4 * g4 + 1] * inv,
+                                  A.acc[qb][dt][4 * g4 + 2] * inv, A.acc[qb][dt][4 * g4 + 3] * inv);
+            }
+        if (hi == 0 && lse) lse[((size_t)b * H + h) * N + qi] = lsum > 0.f ? mref + log2f(lsum) : 1.0e30f;   // log2 domain
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------------------
+extern "C" long long omlm_attn_bias_table_floats(int N, int H) {
+    const int ldT = (A2_PAD + N + 2 * A2_BWIN + 3) / 4 * 4, H8 = (H + 7) / 8 * 8;
+    return (long long)H8 * ldT;
+}
+
+// biasT: omlm_attn_bias_table_floats(N, H) floats.  bias may be null (no rel-pos bias).  q_scale / k_scale (64 floats each, optional):
+// the learned per-dim scales applied after the l2 normalisation -- they give the bound max_d |q_scale_d k_scale_d| on |q.k| that
+// selects the fixed-reference softmax; alternatively qk_bound > 0 states the bound directly (callers with unit q, k: 1.0);
+// neither: online softmax.  scale: the attention scale (8).
+extern "C" int omlm_attn_bias_prepare(const float* bias, float* biasT, int N, int H, int bias_ld, const float* q_scale,
+                                      const float* k_scale, float qk_bound, float scale, void* stream) {
+    OMLM_CHECK_ARG(biasT && N > 0 && H > 0, "null table / sizes");
+    const int ldT = (A2_PAD + N + 2 * A2_BWIN + 3) / 4 * 4, H8 = (H + 7) / 8 * 8;
+    hipLaunchKernelGGL(attn2_bias_prep_kernel, dim3(H8), dim3(256), 0, as_stream(stream), bias, biasT, N, H, bias_ld, ldT, q_scale, k_scale,
+                       qk_bound, scale * A2_LOG2E);
+    return omlm_post_launch("omlm_attn_bias_prepare");
+}
+
+// bf16 forward.  biasT from omlm_attn_bias_prepare (or null: no bias).
+int attn2_fwd_launch(const void* q, const void* k, const void* v, const float* biasT, const unsigned char* keymask,
+                     void* out, float* lse, int B, int N, int H, float scale, hipStream_t st) {
+    const int ldT = (A2_PAD + N + 2 * A2_BWIN + 3) / 4 * 4;
+    constexpr int QB = 1;        // query blocks per wave (2 was measured slower and does not fit 256 registers with both key blocks unrolled)
+    const int TQW = 32 * QB, nqt = (N + TQW - 1) / TQW, ny = (H + 7) / 8;
+    const size_t lds = (size_t)A2_NST * A2_STAGE + 4096 + (size_t)((N + 63) / 64 * 64) * 2 + 64 * 8;
+    if (N > 64 * 64) { omlm_set_error("attention: N > 4096 keys per sample is not supported (liveness prologue covers 8 x 512 keys)"); return OMLM_ERR_UNSUPPORTED; }
+    dim3 grid(nqt * ny * B), block(A2_THREADS);
+    static bool a1 = false;
+    if (!a1) { (void)hipFuncSetAttribute((const void*)attn2_fwd_kernel<QB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a1 = true; }
+    hipLaunchKernelGGL(attn2_fwd_kernel<QB>, grid, block, lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, biasT, ldT, keymask, (bf16_t*)out, lse, B, N, H, scale);
+    return omlm_post_launch("omlm_mqa_attn_fwd");
+}

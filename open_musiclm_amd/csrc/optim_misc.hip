@@ -5,7 +5,8 @@
 // ---------------------------------------------------------------------------------------------------------
 // global grad-norm (sum of squares, one atomic per block) and fused clip + Adam/AdamW step on flat buffers
 // (reference optimizer.py:10-34 -> torch.optim.Adam/AdamW defaults; trainer.py:444-447 clip then step).
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n, float* __restrict__ out,
+                                                    float* __restrict__ partials) {
     __shared__ float red[4];
     float s = 0.f;
     const long long n4 = n / 4;
@@ -15,14 +16,26 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[n4 * 4 + threadIdx.x]; s += v * v; }
     s = block_sum<256>(s, red);
-    if (threadIdx.x == 0) unsafeAtomicAdd(out, s);
+    if (threadIdx.x == 0) { if (partials) partials[blockIdx.x] = s; else unsafeAtomicAdd(out, s); }
+}
+// second pass of the deterministic form: one workgroup adds the per-block partials in a fixed order
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ partials, int nb, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 256) s += partials[i];
+    s = block_sum<256>(s, red);
+    if (threadIdx.x == 0) out[0] += s;
 }
 
-extern "C" int omlm_sumsq_accumulate(const float* g, long long n, float* out, void* stream) {
+// out[0] += sum g^2.  partials (optional, >= 2048 floats): per-workgroup partial sums + a fixed-order final pass, so the result
+// is bit-reproducible -- data-parallel replicas then clip with the SAME coefficient and stay bit-identical; without it the
+// workgroups add to out[0] with float atomics (arrival order).
+extern "C" int omlm_sumsq_accumulate(const float* g, long long n, float* out, float* partials, void* stream) {
     if (n <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(g && out && ((uintptr_t)g % 16) == 0, "sumsq arguments");
     long long blocks = (n / 4 + 255) / 256; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), g, n, out);
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), g, n, out, partials);
+    if (partials) hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), partials, (int)blocks, out);
     return omlm_post_launch("omlm_sumsq_accumulate");
 }
 

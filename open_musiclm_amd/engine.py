@@ -315,7 +315,9 @@ def trunk_forward(tr, pw: PreparedWeights, x: torch.Tensor, keymask: Optional[to
         ops.qk_norm_fwd(q_raw, kv_raw, attn.q_scale.detach(), attn.k_scale.detach(), q, k, v, H)
         o = torch.empty(M, H * DIM_HEAD, dtype=T, device=dev)
         lse = torch.empty(B, H, N, device=dev)
-        ops.attn_fwd(q, k, v, table, keymask, o, lse, B, N, H, ATTN_SCALE)
+        # the layer's bias table in the kernels' layout, with the fixed softmax reference point its scales allow
+        abias = ops.AttnBias(table, N, H, dev, q_scale=attn.q_scale.detach(), k_scale=attn.k_scale.detach(), scale=ATTN_SCALE)
+        ops.attn_fwd(q, k, v, abias, keymask, o, lse, B, N, H, ATTN_SCALE)
         x1 = torch.empty(M, D, device=dev)
         ops.gemm(o, w["Wo"], x1, M=M, N=D, K=H * DIM_HEAD, Cin=x)
         # feed-forward

@@ -30,7 +30,9 @@ SIGNATURES = {
     "omlm_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp],
     "omlm_qk_norm_fwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "omlm_qk_norm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
-    "omlm_mqa_attn_fwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, vp],
+    "omlm_attn_bias_table_floats": [i32, i32],
+    "omlm_attn_bias_prepare": [vp, vp, i32, i32, i32, vp, vp, f32, f32, vp],
+    "omlm_mqa_attn_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, vp],
     "omlm_mqa_attn_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, vp],
     "omlm_ffmid_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, u64, vp, vp, i32, vp],
     "omlm_ffmid_bwd_workspace_bytes": [i32, i32],
@@ -40,7 +42,7 @@ SIGNATURES = {
     "omlm_embed_gather_bwd": [vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, f32, vp],
     "omlm_cross_entropy_fwd": [vp, vp, vp, vp, i32, i32, i32, vp],
     "omlm_cross_entropy_bwd": [vp, vp, vp, vp, f32, vp, i32, i32, i32, i32, i32, vp],
-    "omlm_sumsq_accumulate": [vp, i64, vp, vp],
+    "omlm_sumsq_accumulate": [vp, i64, vp, vp, vp],
     "omlm_adamw_clip_step": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp, f32, i32, i32, vp],
     "omlm_cast_pad": [vp, vp, i64, i32, i32, i32, i32, vp],
     "omlm_transpose_cast": [vp, vp, i32, i32, i32, i32, i32, vp],
@@ -58,6 +60,7 @@ SIGNATURES = {
     "omlm_probe_tr16": [vp, vp],
 }
 _RESTYPES = {"omlm_last_error": C.c_char_p, "omlm_ffmid_bwd_workspace_bytes": C.c_longlong,
+             "omlm_attn_bias_table_floats": C.c_longlong,
              "omlm_layernorm_bwd_workspace_bytes": C.c_longlong, "omlm_set_error": None}
 
 

@@ -194,14 +194,14 @@ class TokenConditionedTransformerWrapper(nn.Module):
             new_ids = loop.run()                                   # [n_new, B]
             sampled = torch.cat((sampled, new_ids.t()), dim=-1)
         else:
+            if not exists(uniforms) and UNIFORM_SOURCE is not None and n_new > 0:
+                uniforms = UNIFORM_SOURCE(n_new, batch, V1)
             for _t in tqdm(range(first_step, max_time_steps), desc='generating predicted tokens'):
                 for ind in range(Q):
                     last = self.transformer.last_logits(cond + [sampled])
                     forbid = (not allow_eos_in_output) or (ind != Q - 1)
                     if exists(uniforms):
                         u = uniforms[step].to(device).float().contiguous()
-                    elif UNIFORM_SOURCE is not None:
-                        u = UNIFORM_SOURCE(1, batch, V1)[0].to(device).float().contiguous()
                     else:
                         u = torch.empty(batch, V1, device=device).uniform_(0, 1)
                     ops.sample_topk_gumbel(last, u, nxt, V1, k, temperature, forbid)

@@ -88,12 +88,37 @@ def qk_norm_bwd(dq, dk, dv, q_raw, kv_raw, q_scale, k_scale, dq_raw, dkv_raw, dq
          ptr(dq_raw), ptr(dkv_raw), ptr(dq_scale), ptr(dk_scale), q_raw.shape[0], H, dcode(dq_raw.dtype), stream_ptr())
 
 
+class AttnBias:
+    """Rel-pos bias table of one attention layer in the two layouts the kernels read: `table` [N, ld] fp32 (row = i - j,
+    column = head) and `tableT`, its transposed / zero-padded / log2(e)-scaled form (omlm_attn_bias_prepare).
+
+    q_scale / k_scale (the layer's learned per-dim scales) or qk_bound (an explicit bound on |q . k|, e.g. 1.0 for unit vectors)
+    let the bf16 forward take its exponentials against a fixed reference point instead of a running maximum; without either the
+    online softmax runs."""
+
+    def __init__(self, table: Optional[torch.Tensor], N: int, H: int, device=None, q_scale=None, k_scale=None,
+                 qk_bound: float = 0.0, scale: float = 8.0):
+        self.table, self.N, self.H = table, N, H
+        dev = table.device if table is not None else device
+        self.tableT = torch.empty(int(hip.lib().omlm_attn_bias_table_floats(N, H)), device=dev)
+        call("omlm_attn_bias_prepare", ptr(table), ptr(self.tableT), N, H, table.shape[-1] if table is not None else 0,
+             ptr(q_scale), ptr(k_scale), float(qk_bound), float(scale), stream_ptr())
+
+
+def _attn_bias(bias, N, H, device) -> "AttnBias":
+    return bias if isinstance(bias, AttnBias) else AttnBias(bias, N, H, device)
+
+
 def attn_fwd(q, k, v, bias, keymask, out, lse, B, N, H, scale):
-    call("omlm_mqa_attn_fwd", ptr(q), ptr(k), ptr(v), ptr(bias), ptr(keymask), ptr(out), ptr(lse),
-         B, N, H, float(scale), bias.shape[-1] if bias is not None else 0, dcode(q.dtype), stream_ptr())
+    """bias: an AttnBias (built once per forward by the engine), a raw [N, ld] table, or None."""
+    ab = _attn_bias(bias, N, H, q.device)
+    call("omlm_mqa_attn_fwd", ptr(q), ptr(k), ptr(v), ptr(ab.table), ptr(ab.tableT), ptr(keymask), ptr(out), ptr(lse),
+         B, N, H, float(scale), ab.table.shape[-1] if ab.table is not None else 0, dcode(q.dtype), stream_ptr())
 
 
 def attn_bwd(q, k, v, bias, keymask, out, dout, lse, delta, dq, dk, dv, dbias, B, N, H, scale):
+    if isinstance(bias, AttnBias):
+        bias = bias.table
     call("omlm_mqa_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(bias), ptr(keymask), ptr(out), ptr(dout), ptr(lse),
          ptr(delta), ptr(dq), ptr(dk), ptr(dv), ptr(dbias), B, N, H, float(scale),
          bias.shape[-1] if bias is not None else 0, dcode(q.dtype), stream_ptr())
@@ -168,8 +193,9 @@ def ce_bwd(logits, labels, row_lse, gscale, coef, dlogits, V):
          R, V, ld, dlogits.shape[-1], dcode(dlogits.dtype), stream_ptr())
 
 
-def sumsq_accumulate(g, out):
-    call("omlm_sumsq_accumulate", ptr(g), g.numel(), ptr(out), stream_ptr())
+def sumsq_accumulate(g, out, partials=None):
+    """out[0] += sum g^2; with `partials` (>= 2048 floats) the reduction order is fixed (bit-reproducible)."""
+    call("omlm_sumsq_accumulate", ptr(g), g.numel(), ptr(out), ptr(partials), stream_ptr())
 
 
 def adamw_clip_step(p, g, m, v, p16, *, lr, beta1, beta2, eps, wd, step, gscale, gnorm_sq, max_norm,

@@ -73,6 +73,7 @@ class FusedAdam(torch.optim.Optimizer):
             p._omlm_bf16_version = p._version
         self._flat = dict(P=P, G=G, M=M, V=V, P16=P16, offs=offs, sizes=sizes, total=tot)
         self._gnorm_sq = torch.zeros(1, device=dev)
+        self._gnorm_partials = torch.empty(2048, device=dev)      # fixed-order grad-norm reduction: replicas clip identically
         # group ranges (groups are contiguous in the flat order by construction)
         r, k = [], 0
         for g in self.param_groups:
@@ -122,7 +123,7 @@ class FusedAdam(torch.optim.Optimizer):
         gn = None
         if max_grad_norm is not None and max_grad_norm > 0:
             self._gnorm_sq.zero_()
-            ops.sumsq_accumulate(f['G'], self._gnorm_sq)
+            ops.sumsq_accumulate(f['G'], self._gnorm_sq, self._gnorm_partials)
             gn = self._gnorm_sq
         self.last_grad_norm_sq = gn
         for g, (a, b) in zip(self.param_groups, f['ranges']):

@@ -231,6 +231,17 @@ def test_attention_fwd_bwd(ops, dev, dtype, B, N, H):
     e_f = relerr(out.view(B, N, -1), ref.detach())
     # fp32 operands: bf16x3 forward -> fp32-grade; bf16 operands: P and the output are rounded to bf16
     tol_f = 2e-5 if dtype == torch.float32 else 1e-2
+    if dtype == torch.bfloat16:
+        # the same forward with the fixed softmax reference point (q, k are unit vectors here: |q.k| <= 1): same softmax
+        ab = ops.AttnBias(bias, N, H, dev, qk_bound=1.0, scale=8.0)
+        assert float(ab.tableT.view(-1, ab.tableT.numel() // ((H + 7) // 8 * 8))[0, -2]) == 1.0      # the fixed path is taken
+        out2 = torch.empty_like(out); lse2 = torch.empty_like(lse)
+        ops.attn_fwd(qd, kd, vd, ab, keymask.to(torch.uint8), out2, lse2, B, N, H, 8.0)
+        e_f2 = relerr(out2.view(B, N, -1), ref.detach())
+        e_lse = float((lse2 - lse).abs().max())
+        report(f"attention_fixed_ref[{B},{N},{H}]", fwd=e_f2, lse_diff=e_lse)
+        # lse comes from the MFMA denominator (bf16-rounded P, like the numerator): log2-domain agreement to ~2^-7
+        assert e_f2 < tol_f and e_lse < 1e-2, (e_f2, e_lse)
     do = torch.randn(B, N, H * 64, generator=g).to(dev)
     ref.backward(do.double())
     dq = torch.empty(M, H * 64, device=dev)

@@ -9,15 +9,16 @@ CS=$ROOT/open_musiclm_amd/csrc
 case "$1" in
 build)
     src=$2; shift 2
+    name=${VARIANT:-variant}
     mkdir -p "$ROOT/.variants"
     make -C "$CS" >/dev/null
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-value "$@" -c "$CS/$src.hip" -o "/tmp/${src}_variant.o"
     objs=""
-    for o in gemm attention norm ffmid embed_ce optim_misc decode err; do
+    for o in gemm attention attention2 norm ffmid embed_ce optim_misc decode err; do
         if [ "$o" = "$src" ]; then objs="$objs /tmp/${src}_variant.o"; else objs="$objs $CS/$o.o"; fi
     done
-    hipcc --offload-arch=gfx950 -shared -fPIC $objs -o "$ROOT/.variants/libomlm_variant.so"
-    echo "built $ROOT/.variants/libomlm_variant.so ($src.hip with $*)"
+    hipcc --offload-arch=gfx950 -shared -fPIC $objs -o "$ROOT/.variants/libomlm_$name.so"
+    echo "built $ROOT/.variants/libomlm_$name.so ($src.hip with $*)"
     ;;
 run)
     sel=$2; probe=$3
