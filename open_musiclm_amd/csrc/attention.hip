@@ -102,6 +102,13 @@ struct KVRegs {
             if (PRECISE) *(bf16x8*)(lds_lo + tile_off(row, ch * 16)) = lo[i];
         }
     }
+    __device__ __forceinline__ void store_blk_hi(char* lds_hi) const {                 // blocked image of the hi plane only
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = threadIdx.x + AT_THREADS * i;
+            *(bf16x8*)(lds_hi + tile_off_blk(c >> 3, (c & 7) * 16)) = hi[i];
+        }
+    }
     __device__ __forceinline__ void store_blk(char* lds_hi, char* lds_lo) const {      // image for frag_cols_tr
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -497,6 +504,206 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
     }
 }
 
+// The same kernel for fp32 ("bf16x3") operands with hi/lo S and dP, kept as its own function so that the bf16 kernel's code and
+// register allocation (already at the 256-register limit) stay exactly as measured.
+template <typename T>
+__global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dq_precise_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                                 const T* __restrict__ v, const float* __restrict__ bias,
+                                                                 const unsigned char* __restrict__ keymask,
+                                                                 const T* __restrict__ out, const T* __restrict__ dout,
+                                                                 const float* __restrict__ lse, float* __restrict__ delta,
+                                                                 float* __restrict__ dq, float* __restrict__ dbias,
+                                                                 int B, int N, int H, float scale, int bias_ld) {
+    // fp32 operands ("bf16x3"): S and dP -- the two products the probabilities and d(bias) are made of -- are formed from
+    // hi/lo splits (3 MFMAs per product), so p, dS and the rel-pos bias gradient are fp32-grade; dQ = dS K itself stays a
+    // single bf16 pass (dS rounded once), like every other gradient GEMM operand of this mode's backward.
+    constexpr bool PRECISE = elt_traits<T>::precise;
+    constexpr int PLANE = TKV * 128;
+    constexpr int NPL = PRECISE ? 5 : 3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;                       // K rows  (S^T = K Q^T)
+    char* Vs = smem + PLANE;               // V rows  (dP^T = V dO^T)
+    char* Kt = smem + 2 * PLANE;           // K again, blocked for the transpose read (dQ^T += K^T dS^T)
+    char* Ksl = smem + 3 * PLANE;          // lo planes (PRECISE only)
+    char* Vsl = smem + 4 * PLANE;
+    const int nqt = (N + TQ - 1) / TQ;
+    const int qt = nqt - 1 - (int)blockIdx.x;
+    const int b = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
+    const int h = blockIdx.y * 4 + wave;
+    const bool active = h < H;
+    const int i0 = qt * TQ;
+    const int qi = i0 + (lane & 31);
+    const int nb = i0 + TQ;
+    float* bias_l = (float*)(smem + NPL * PLANE) + (size_t)wave * nb;              // [4][nb]
+    float* dbias_l = (float*)(smem + NPL * PLANE) + (size_t)(4 + wave) * nb;       // [4][nb]
+    // key-mask ballots of every 64-key tile, built once (a global load + ballot per k-tile stalled each iteration)
+    unsigned long long* mbits = (unsigned long long*)(smem + NPL * PLANE + (size_t)8 * (nqt * TQ) * sizeof(float));
+    const size_t rowbase = (size_t)b * N;
+    const size_t qrow = (rowbase + min(qi, N - 1)) * (size_t)(H * 64) + (active ? h : 0) * 64;
+
+    bf16x8 qf[4], dof[4], ql[4], dol[4], dummy;
+    float dl = 0.f, L = 0.f;
+    if (active) {
+        for (int r = lane; r < nb; r += 64) {
+            bias_l[r] = bias ? bias[(size_t)min(r, N - 1) * bias_ld + h] * LOG2E : 0.f;
+            dbias_l[r] = 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 of;
+            load_row8<T, PRECISE>(q + qrow + 16 * s + 8 * hi, qi < N, qf[s], ql[s]);
+            load_row8<T, PRECISE>(dout + qrow + 16 * s + 8 * hi, qi < N, dof[s], dol[s]);
+            // delta uses the unrounded tensors
+            if (qi < N) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    dl += load_as_float(dout + qrow + 16 * s + 8 * hi + e) * load_as_float(out + qrow + 16 * s + 8 * hi + e);
+            }
+        }
+        dl += __shfl_xor(dl, 32, 64);
+        L = lse[((size_t)b * H + h) * N + min(qi, N - 1)];
+        if (hi == 0 && qi < N) delta[((size_t)b * H + h) * N + qi] = dl;
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
+    const float c = scale * LOG2E;
+
+    const int nkt = (i0 + TQ + TKV - 1) / TKV;
+    KVRegs<T, PRECISE> kr, vr;
+    kr.load(k + rowbase * 64, 0, N);
+    vr.load(v + rowbase * 64, 0, N);
+    for (int ch = wave; ch < nkt; ch += 4) {
+        const int jk = ch * TKV + lane;
+        const bool live = jk < N && (keymask ? keymask[rowbase + jk] != 0 : true);
+        const unsigned long long bb = __ballot(live);
+        if (lane == 0) mbits[ch] = bb;
+    }
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int j0 = kt * TKV;
+        __syncthreads();
+        kr.store(Ks, Ksl);
+        kr.store_blk_hi(Kt);
+        vr.store(Vs, Vsl);
+        __syncthreads();
+        const unsigned long long bits = mbits[kt];
+        if (kt + 1 < nkt) {
+            kr.load(k + rowbase * 64, j0 + TKV, N);
+            vr.load(v + rowbase * 64, j0 + TKV, N);
+        }
+        if (!active) continue;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int jb = j0 + 32 * sub;
+            if (jb > i0 + TQ - 1) break;
+            f32x16 st, dp;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { st[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (PRECISE) {
+                    const bf16x8 ka = frag_rows(Ks, 32 * sub, s, lane), va = frag_rows(Vs, 32 * sub, s, lane);
+                    st = MFMA(frag_rows(Ksl, 32 * sub, s, lane), qf[s], st);
+                    st = MFMA(ka, ql[s], st);
+                    st = MFMA(ka, qf[s], st);
+                    dp = MFMA(frag_rows(Vsl, 32 * sub, s, lane), dof[s], dp);
+                    dp = MFMA(va, dol[s], dp);
+                    dp = MFMA(va, dof[s], dp);
+                } else {
+                    st = MFMA(frag_rows(Ks, 32 * sub, s, lane), qf[s], st);      // S^T  = K Q^T
+                    dp = MFMA(frag_rows(Vs, 32 * sub, s, lane), dof[s], dp);     // dP^T = V dO^T
+                }
+            }
+            // three straight passes (gather bias, arithmetic, scatter d(bias)): a fused per-element loop compiled to 16
+            // serialised LDS round trips (read -> wait -> exp -> atomic), ~3k cycles per 32x32 block
+#if AT_LEAN
+            float bv[16];
+            auto element = [&](int r, bool ok) {
+                const float p = __builtin_amdgcn_exp2f(ok ? st[r] * c + bv[r] - L : NEG_BIG);
+                bv[r] = p * (dp[r] - dl);
+                st[r] = bv[r] * scale;
+            };
+            if (jb + 31 <= i0) {
+                // subtile entirely below the diagonal (see the forward): constant LDS offsets from one base, one 32-bit mask word
+                const unsigned w32 = qi < N ? (unsigned)(bits >> (32 * sub)) >> (4 * hi) : 0u;
+                const float* bp = bias_l + (qi - jb - 4 * hi);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bv[r] = bp[-((r & 3) + 8 * (r >> 2))];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) element(r, (w32 >> ((r & 3) + 8 * (r >> 2))) & 1u);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bv[r] = bias_l[max(min(qi - (j0 + 32 * sub + crow(r, hi)), nb - 1), 0)];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kr = 32 * sub + crow(r, hi);
+                    const int rel = qi - (j0 + kr);
+                    element(r, (rel >= 0) && ((bits >> kr) & 1ull) && (qi < N));
+                }
+            }
+#else
+            float bv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bv[r] = bias_l[max(min(qi - (j0 + 32 * sub + crow(r, hi)), nb - 1), 0)];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kr = 32 * sub + crow(r, hi);
+                const int rel = qi - (j0 + kr);
+                const bool ok = (rel >= 0) && ((bits >> kr) & 1ull) && (qi < N);
+                const float p = __builtin_amdgcn_exp2f(ok ? st[r] * c + bv[r] - L : NEG_BIG);   // branch-free: 2^-inf = 0
+                bv[r] = p * (dp[r] - dl);                                     // dS (0 where masked)
+                st[r] = bv[r] * scale;
+            }
+#endif
+            if (dbias) {
+                // d(bias)[rel] = sum of dS over the diagonal rel = i - j.  LDS float atomics (one per element) cost 930 us
+                // per layer (measured: 1496 -> 565 us without them), so the 63 diagonals of the 32x32 block are summed in
+                // registers instead: output lane L stands for t = q - kr = L - 31 and pulls row kr's element from query
+                // column q = t + kr through the cross-lane permute (no LDS memory access); then ONE plain read-add-write
+                // of the wave-private table, predicated so that every lane owns a distinct bin.
+                float dsum = 0.f;
+#pragma unroll
+                for (int kr = 0; kr < 32; ++kr) {
+                    const int r = 4 * (kr >> 3) + (kr & 3), hh = (kr >> 2) & 1;
+                    const int src = lane - 31 + kr;
+                    const float got = __shfl(bv[r], (32 * hh + src) & 63, 64);
+                    dsum += (src >= 0 && src < 32) ? got : 0.f;
+                }
+                const int rel = (i0 - j0 - 32 * sub) + (lane - 31);
+                if (rel >= 0 && rel < nb) dbias_l[rel] += dsum;
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 dsb;
+                pack_acc<false>(st, s, dsb, dummy);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    acc[dt] = MFMA(frag_cols_tr(Kt, 32 * sub, s, 32 * dt, lane), dsb, acc[dt]);   // dQ^T += K^T dS^T
+            }
+        }
+    }
+    if (!active) return;
+    if (qi < N) {
+        float* drow = dq + (rowbase + qi) * (size_t)(H * 64) + h * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d = 32 * dt + 8 * g4 + 4 * hi;
+                *(float4*)(drow + d) = make_float4(acc[dt][4 * g4], acc[dt][4 * g4 + 1], acc[dt][4 * g4 + 2], acc[dt][4 * g4 + 3]);
+            }
+    }
+    if (dbias) {
+        // LDS atomics of this wave are complete in program order for this wave's own later reads
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        for (int r = lane; r < min(nb, N); r += 64) {
+            const float vv = dbias_l[r];
+            if (vv != 0.f) unsafeAtomicAdd(dbias + (size_t)r * bias_ld + h, vv);
+        }
+    }
+}
+
 // =============================================================================================================
 // backward, kernel A: dK, dV.  One workgroup per (sample, 32-key tile); its 4 waves split the (query tile, head)
 // work items and reduce their partial dK^T / dV^T through LDS at the end -- no atomics on dK / dV.
@@ -677,7 +884,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
 
 // =============================================================================================================
 static size_t fwd_lds(int N, bool precise) { return (size_t)(precise ? 4 : 2) * TKV * 128 + (size_t)4 * ((N + TQ - 1) / TQ * TQ) * sizeof(float); }
-static size_t dq_lds(int N) { return (size_t)3 * TKV * 128 + (size_t)8 * ((N + TQ - 1) / TQ * TQ) * sizeof(float) + (size_t)8 * ((N + TKV - 1) / TKV + 1); }
+static size_t dq_lds(int N, bool precise = false) { return (size_t)(precise ? 5 : 3) * TKV * 128 + (size_t)8 * ((N + TQ - 1) / TQ * TQ) * sizeof(float) + (size_t)8 * ((N + TKV - 1) / TKV + 1); }
 
 template <typename K>
 static int set_lds(K kernel, size_t bytes) {
@@ -723,13 +930,13 @@ extern "C" int omlm_mqa_attn_bwd(const void* q, const void* k, const void* v, co
     if (B <= 0 || N <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(q && k && v && out && dout && lse && delta && dq && dk && dv, "null pointer");
     dim3 gridq((N + TQ - 1) / TQ, (H + 3) / 4, B), gridk((N + 31) / 32, 1, B), block(AT_THREADS);
-    const size_t ldsq = dq_lds(N), ldsk = 32 * 1024 + (size_t)H * ((N + TQ - 1) / TQ * TQ) * sizeof(float) + (AT_LEAN ? 1024 : 0);
+    const size_t ldsq = dq_lds(N, dtype == 0), ldsk = 32 * 1024 + (size_t)H * ((N + TQ - 1) / TQ * TQ) * sizeof(float) + (AT_LEAN ? 1024 : 0);
     int rc;
     hipStream_t st = as_stream(stream);
     if (dtype == 0) {
-        if ((rc = set_lds(attn_bwd_dq_kernel<float>, ldsq))) return rc;
+        if ((rc = set_lds(attn_bwd_dq_precise_kernel<float>, ldsq))) return rc;
         if ((rc = set_lds(attn_bwd_dkv_kernel<float>, ldsk))) return rc;
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<float>, gridq, block, ldsq, st, (const float*)q, (const float*)k, (const float*)v, bias, keymask, (const float*)out, (const float*)dout, lse, delta, dq, dbias, B, N, H, scale, bias_ld);
+        hipLaunchKernelGGL(attn_bwd_dq_precise_kernel<float>, gridq, block, ldsq, st, (const float*)q, (const float*)k, (const float*)v, bias, keymask, (const float*)out, (const float*)dout, lse, delta, dq, dbias, B, N, H, scale, bias_ld);
         hipLaunchKernelGGL(attn_bwd_dkv_kernel<float>, gridk, block, ldsk, st, (const float*)q, (const float*)k, (const float*)v, bias, keymask, (const float*)dout, lse, delta, dk, dv, B, N, H, scale, bias_ld);
     } else {
         if ((rc = set_lds(attn_bwd_dq_kernel<bf16_t>, ldsq))) return rc;

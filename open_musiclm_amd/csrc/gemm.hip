@@ -54,6 +54,8 @@ struct GemmArgs {
     int lda, ldb, ldc, ldcin;
     float alpha;
     int kt_per_split;   // k-tiles handled by one blockIdx.y slice (split-K); gridDim.y == 1 -> all
+    int bal_ck;         // > 0: balanced split-K ("chunked stream-K"): gridDim.x workgroups share tiles x k-tiles evenly; k-tiles per K chunk
+    int bal_chunks;     //      number of K chunks
     int debug;          // profiling ablations only (OMLM_GEMM_DEBUG): bit 0 = skip the per-tile DMA, bit 1 = skip the MFMAs
 };
 
@@ -347,14 +349,13 @@ struct DmaStagerT {
 // row-contiguous stores: 8 bf16 / 4 fp32 per lane, full 128-byte lines per row.
 template <int MI, int NJ, int WN_, typename TOUT>
 __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16 (&acc)[MI][NJ], char* smem, int m0, int n0,
-                                              int wm, int wn, int wave, int lane, int dbg) {
+                                              int wm, int wn, int wave, int lane, int dbg, bool split) {
     constexpr int SROW = WN_ + 4;                                  // padded row (floats), keeps 16-B alignment
     float* stg = (float*)smem + (size_t)wave * 32 * SROW;
     constexpr int VEC = sizeof(TOUT) == 2 ? 8 : 4;                 // elements per 16-byte store
     constexpr int LPR = WN_ / VEC;                                 // lanes per row
     constexpr int RPP = 64 / LPR;                                  // rows per pass
     TOUT* C = (TOUT*)g.C;
-    const bool split = gridDim.y > 1;
     const bool vec_ok = (g.ldc % VEC == 0) && (((uintptr_t)g.C & 15) == 0) &&
                         (!g.Cin || ((g.ldcin % 4 == 0) && (((uintptr_t)g.Cin & 15) == 0)));
     const int hi = lane >> 5;
@@ -425,7 +426,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16 (&acc)[M
     }
 }
 
-template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ, bool B_KMAJ, typename TOUT, bool DBG, bool KMAP>
+template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ, bool B_KMAJ, typename TOUT, bool DBG, bool KMAP, bool BAL = false>
 __global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile_kernel(GemmArgs g) {
     const int dbg = DBG ? g.debug : 0;      // ablation switches exist only in the DBG instantiation (OMLM_GEMM_DEBUG set)
     constexpr int NWN = BN_ / WN_, NWAVES = (BM_ / WM_) * NWN;
@@ -436,113 +437,145 @@ __global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile
 
     const int tiles_m = (g.M + BM_ - 1) / BM_, tiles_n = (g.N + BN_ - 1) / BN_;
     const int nwg = tiles_m * tiles_n;
-    // XCD-aware order over the WHOLE grid (tiles x K-splits): workgroups are dealt round-robin to the 8 XCDs in linear
+    const int nk_all = (g.K + BK - 1) / BK;
+    constexpr bool bal = BAL;          // balanced split-K is its own instantiation: the plain kernels keep their code and registers
+    // XCD-aware order over the WHOLE grid (tiles x K-splits, split-major): workgroups are dealt round-robin to the 8 XCDs in linear
     // dispatch order, so XCD c is given one contiguous chunk of the logical (split-major) sequence.  For split-K GEMMs
     // this puts all co-resident workgroups of an XCD on the SAME K range (they share A and B panels through its L2);
     // with the tile-only remap an XCD held 3 unrelated K ranges at a time (measured L2 hit 48 % on the dW1 GEMM).
-    int bid, ksplit;
+    int lg;
     {
-        const int total = nwg * gridDim.y, lin = blockIdx.y * nwg + blockIdx.x;
+        const int total = bal ? (int)gridDim.x : nwg * (int)gridDim.y, lin = blockIdx.y * nwg + blockIdx.x;
         const int q = total >> 3, r = total & 7, xcd = lin & 7, idx = lin >> 3;
-        const int lg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        ksplit = lg / nwg;
-        bid = lg - ksplit * nwg;
+        lg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    // Balanced split-K: the (K chunk, tile, k-tile) units are numbered chunk-major and cut into gridDim.x equal contiguous
+    // ranges; a workgroup walks its range segment by segment (a segment = consecutive k-tiles of one output tile) and adds each
+    // partial tile to C.  Every workgroup does the same number of k-tiles (no partial last round), co-resident workgroups sit
+    // in the same K chunk (shared panels), and a tile receives ~chunks + 1 partial sums instead of one per split.
+    int u = 0, u1 = 0;                 // host guarantees tiles x k-tiles < 2^31 / workgroups
+    if (bal) {
+        const long long U = (long long)nwg * nk_all;
+        u = (int)(U * lg / gridDim.x);
+        u1 = (int)(U * (lg + 1) / gridDim.x);
+        if (u >= u1) return;
     }
 #ifndef OMLM_SUPER_ROWS
 #define OMLM_SUPER_ROWS 1024       /* C rows per super-tile (tile rows walked column-major inside it) */
 #endif
     constexpr int GROUP = OMLM_SUPER_ROWS / BM_;                       // tile rows per super-tile (same footprint as the 128 kernel's 8)
-    const int gsz = GROUP * tiles_n;
-    const int grp = bid / gsz, first_m = grp * GROUP;
-    const int rows_in = min(GROUP, tiles_m - first_m);
-    const int tm = first_m + (bid - grp * gsz) % rows_in, tn = (bid - grp * gsz) / rows_in;
-    const int m0 = tm * BM_, n0 = tn * BN_;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = (wave / NWN) * WM_, wn = (wave % NWN) * WN_;
-
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(g.A, (unsigned long long)g.a_rows * g.lda * 2);
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(g.B, (unsigned long long)g.b_rows * g.ldb * 2);
-    DmaStagerT<A_KMAJ, BM_, NWAVES> sa;
-    DmaStagerT<B_KMAJ, BN_, NWAVES> sb;
-    sa.init(g.a_map, g.lda, g.M, m0, wave, lane);
-    sb.init(g.b_map, g.ldb, g.N, n0, wave, lane);
 
-    f32x16 acc[MI][NJ];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const int nk_all = (g.K + BK - 1) / BK;
-    const int kt0 = ksplit * g.kt_per_split;
-    const int kt1 = min(nk_all, kt0 + g.kt_per_split);
-    if (kt0 < kt1) {
-        sa.template issue<KMAP>(rsA, g.a_map, g.lda, kt0 * BK, g.K, smem, wave);
-        sb.template issue<KMAP>(rsB, g.b_map, g.ldb, kt0 * BK, g.K, smem + A_BYTES, wave);
-    }
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int cur = (kt - kt0) & 1;
-        __syncthreads();          // waits vmcnt(0): tile kt landed everywhere, and the other stage is free
-        // The DMA of tile kt+1 is NOT issued in one burst here: a wave's instruction stream is in order, and a
-        // buffer_load..lds stalls at issue while the CU's vector-memory path is full, so a burst of 8 loads kept every
-        // wave out of its MFMAs for the whole transfer (measured: full time ~ DMA-only time + compute-only time).
-        // The loads are spread over the MFMAs of the first three k16 steps instead; the last step covers their latency.
-        const bool live = kt + 1 < kt1 && !(dbg & 1);
-        char* nxt = smem + (cur ^ 1) * STAGE;
-        const int knext = (kt + 1) * BK;
-        const char* As = smem + cur * STAGE;
-        const char* Bs = As + A_BYTES;
-        // software-pipelined fragments: the LDS reads of k16-step s+1 are issued BEFORE the MFMAs of step s, so their
-        // latency hides under the matrix pipe (hipcc's own schedule read-then-multiplied each step: MFMA busy 30 %)
-        bf16x8 a[2][MI], b[2][NJ];
-        if (dbg & 8) {
-            if (!(dbg & 16)) sa.template issue<KMAP>(rsA, g.a_map, g.lda, live ? knext : g.K, g.K, nxt, wave);
-            if (!(dbg & 32)) sb.template issue<KMAP>(rsB, g.b_map, g.ldb, live ? knext : g.K, g.K, nxt + A_BYTES, wave);
-            continue;
+    for (;;) {
+        int bid, kt0, kt1;
+        if (bal) {
+            const int per_chunk = nwg * g.bal_ck;
+            int c = u / per_chunk;
+            if (c > g.bal_chunks - 1) c = g.bal_chunks - 1;
+            const int len_c = min(g.bal_ck, nk_all - c * g.bal_ck);
+            const int r = u - c * per_chunk;
+            bid = r / len_c;
+            const int kk = r - bid * len_c;
+            const int seg_end = min(u1, u + (len_c - kk));
+            kt0 = c * g.bal_ck + kk;
+            kt1 = kt0 + (seg_end - u);
+            u = seg_end;
+        } else {
+            const int ksplit = lg / nwg;
+            bid = lg - ksplit * nwg;
+            kt0 = ksplit * g.kt_per_split;
+            kt1 = min(nk_all, kt0 + g.kt_per_split);
         }
+        const int gsz = GROUP * tiles_n;
+        const int grp = bid / gsz, first_m = grp * GROUP;
+        const int rows_in = min(GROUP, tiles_m - first_m);
+        const int tm = first_m + (bid - grp * gsz) % rows_in, tn = (bid - grp * gsz) / rows_in;
+        const int m0 = tm * BM_, n0 = tn * BN_;
+
+        DmaStagerT<A_KMAJ, BM_, NWAVES> sa;
+        DmaStagerT<B_KMAJ, BN_, NWAVES> sb;
+        sa.init(g.a_map, g.lda, g.M, m0, wave, lane);
+        sb.init(g.b_map, g.ldb, g.N, n0, wave, lane);
+
+        f32x16 acc[MI][NJ];
 #pragma unroll
-        for (int i = 0; i < MI; ++i) a[0][i] = read_frag<A_KMAJ>(As, wm + 32 * i, 0, lane);
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) b[0][j] = read_frag<B_KMAJ>(Bs, wn + 32 * j, 0, lane);
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            if (s < 3) {
-#pragma unroll
-                for (int i = 0; i < MI; ++i) a[(s + 1) & 1][i] = read_frag<A_KMAJ>(As, wm + 32 * i, s + 1, lane);
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) b[(s + 1) & 1][j] = read_frag<B_KMAJ>(Bs, wn + 32 * j, s + 1, lane);
-                __builtin_amdgcn_sched_barrier(0);                            // DS reads of step s+1 stay above ...
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+        if (kt0 < kt1) {
+            sa.template issue<KMAP>(rsA, g.a_map, g.lda, kt0 * BK, g.K, smem, wave);
+            sb.template issue<KMAP>(rsB, g.b_map, g.ldb, kt0 * BK, g.K, smem + A_BYTES, wave);
+        }
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const int cur = (kt - kt0) & 1;
+            __syncthreads();          // waits vmcnt(0): tile kt landed everywhere, and the other stage is free
+            // The DMA of tile kt+1 is NOT issued in one burst here: a wave's instruction stream is in order, and a
+            // buffer_load..lds stalls at issue while the CU's vector-memory path is full, so a burst of 8 loads kept every
+            // wave out of its MFMAs for the whole transfer (measured: full time ~ DMA-only time + compute-only time).
+            // The loads are spread over the MFMAs of the first three k16 steps instead; the last step covers their latency.
+            const bool live = kt + 1 < kt1 && !(dbg & 1);
+            char* nxt = smem + (cur ^ 1) * STAGE;
+            const int knext = (kt + 1) * BK;
+            const char* As = smem + cur * STAGE;
+            const char* Bs = As + A_BYTES;
+            // software-pipelined fragments: the LDS reads of k16-step s+1 are issued BEFORE the MFMAs of step s, so their
+            // latency hides under the matrix pipe (hipcc's own schedule read-then-multiplied each step: MFMA busy 30 %)
+            bf16x8 a[2][MI], b[2][NJ];
+            if (dbg & 8) {
+                if (!(dbg & 16)) sa.template issue<KMAP>(rsA, g.a_map, g.lda, live ? knext : g.K, g.K, nxt, wave);
+                if (!(dbg & 32)) sb.template issue<KMAP>(rsB, g.b_map, g.ldb, live ? knext : g.K, g.K, nxt + A_BYTES, wave);
+                continue;
             }
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < MI; ++i) a[0][i] = read_frag<A_KMAJ>(As, wm + 32 * i, 0, lane);
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    if (!(dbg & 2))
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s & 1][i], b[s & 1][j], acc[i][j], 0, 0, 0);
-                    else
-                        asm volatile("" :: "v"(a[s & 1][i]), "v"(b[s & 1][j]));
-                    constexpr int MPS = MI * NJ, NLOAD = UA + UB;
+            for (int j = 0; j < NJ; ++j) b[0][j] = read_frag<B_KMAJ>(Bs, wn + 32 * j, 0, lane);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (s < 3) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) a[(s + 1) & 1][i] = read_frag<A_KMAJ>(As, wm + 32 * i, s + 1, lane);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) b[(s + 1) & 1][j] = read_frag<B_KMAJ>(Bs, wn + 32 * j, s + 1, lane);
+                    __builtin_amdgcn_sched_barrier(0);                            // DS reads of step s+1 stay above ...
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        if (!(dbg & 2))
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s & 1][i], b[s & 1][j], acc[i][j], 0, 0, 0);
+                        else
+                            asm volatile("" :: "v"(a[s & 1][i]), "v"(b[s & 1][j]));
+                        constexpr int MPS = MI * NJ, NLOAD = UA + UB;
 #ifndef OMLM_DMA_SPREAD
 #define OMLM_DMA_SPREAD 3          /* k16 steps (of 4) over which the next tile's DMA issue is spread; tuned on the probe shapes */
 #endif
-                    constexpr int STRIDE = (OMLM_DMA_SPREAD * MPS) / NLOAD > 0 ? (OMLM_DMA_SPREAD * MPS) / NLOAD : 1;
-                    const int midx = s * MPS + i * NJ + j;                    // compile-time after unrolling
-                    if (midx % STRIDE == 0 && midx / STRIDE < NLOAD) {
-                        const int l = midx / STRIDE;
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (l < UA) { if (!(dbg & 16)) sa.template issue_one<KMAP>(l, rsA, g.a_map, g.lda, knext, g.K, nxt, wave, live, (dbg >> 6) & 3); }
-                        else        { if (!(dbg & 32)) sb.template issue_one<KMAP>(l - UA, rsB, g.b_map, g.ldb, knext, g.K, nxt + A_BYTES, wave, live, (dbg >> 6) & 3); }
-                        __builtin_amdgcn_sched_barrier(0);
+                        constexpr int STRIDE = (OMLM_DMA_SPREAD * MPS) / NLOAD > 0 ? (OMLM_DMA_SPREAD * MPS) / NLOAD : 1;
+                        const int midx = s * MPS + i * NJ + j;                    // compile-time after unrolling
+                        if (midx % STRIDE == 0 && midx / STRIDE < NLOAD) {
+                            const int l = midx / STRIDE;
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (l < UA) { if (!(dbg & 16)) sa.template issue_one<KMAP>(l, rsA, g.a_map, g.lda, knext, g.K, nxt, wave, live, (dbg >> 6) & 3); }
+                            else        { if (!(dbg & 32)) sb.template issue_one<KMAP>(l - UA, rsB, g.b_map, g.ldb, knext, g.K, nxt + A_BYTES, wave, live, (dbg >> 6) & 3); }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
-                }
-            __builtin_amdgcn_sched_barrier(0);                                // ... the MFMAs of step s
+                __builtin_amdgcn_sched_barrier(0);                                // ... the MFMAs of step s
+            }
         }
+        __syncthreads();
+        tile_epilogue<MI, NJ, WN_, TOUT>(g, acc, smem, m0, n0, wm, wn, wave, lane, dbg, bal || gridDim.y > 1);
+        if (!bal || u >= u1) break;
+        __syncthreads();              // the non-split epilogue stages through LDS; the next segment's DMA must not overtake it
     }
-    __syncthreads();
-    tile_epilogue<MI, NJ, WN_, TOUT>(g, acc, smem, m0, n0, wm, wn, wave, lane, dbg);
 }
 
 template <int BM_, int BN_, int WM_, int WN_, typename TOUT>
@@ -551,6 +584,7 @@ static int launch_tile(const GemmArgs& g, int a_kmaj, int b_kmaj, int splits, hi
     constexpr size_t LDS = 2 * (size_t)(BM_ + BN_) * BK * 2;
     const int tiles = ((g.M + BM_ - 1) / BM_) * ((g.N + BN_ - 1) / BN_);
     dim3 grid(tiles, splits), block(NTH);
+    if (g.bal_ck > 0) grid = dim3(splits, 1);          // balanced split-K: `splits` carries the workgroup count
     const bool need_kmap = (a_kmaj && g.a_map) || (b_kmaj && g.b_map);       // host routes these to the 128x128 tile
     if (need_kmap && BM_ != 128) { omlm_set_error("omlm_gemm: k-row maps are only built for the 128x128 tile"); return OMLM_ERR_UNSUPPORTED; }
 #define OMLM_TILE_LAUNCH(AK, BKM)                                                                                          \
@@ -558,14 +592,19 @@ static int launch_tile(const GemmArgs& g, int a_kmaj, int b_kmaj, int splits, hi
         auto kfn = gemm_bf16_tile_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT, false, false>;                                 \
         auto kdbg = gemm_bf16_tile_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT, true, false>;                                 \
         auto kmap = gemm_bf16_tile_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT, false, (AK || BKM) && BM_ == 128>;            \
+        auto kbal = gemm_bf16_tile_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT, false, false, sizeof(TOUT) == 4>;            \
+        auto kbalmap = gemm_bf16_tile_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT, false, (AK || BKM) && BM_ == 128, sizeof(TOUT) == 4>; \
         static bool attr = false;                                                                                           \
         if (!attr) {                                                                                                        \
             (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);             \
             (void)hipFuncSetAttribute((const void*)kdbg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);            \
             (void)hipFuncSetAttribute((const void*)kmap, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);            \
+            (void)hipFuncSetAttribute((const void*)kbal, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);            \
+            (void)hipFuncSetAttribute((const void*)kbalmap, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);         \
             attr = true;                                                                                                    \
         }                                                                                                                   \
-        if (need_kmap)    hipLaunchKernelGGL(kmap, grid, block, LDS, st, g);                                               \
+        if (g.bal_ck > 0 && sizeof(TOUT) == 4) hipLaunchKernelGGL(need_kmap ? kbalmap : kbal, grid, block, LDS, st, g);    \
+        else if (need_kmap) hipLaunchKernelGGL(kmap, grid, block, LDS, st, g);                                             \
         else if (g.debug) hipLaunchKernelGGL(kdbg, grid, block, LDS, st, g);                                               \
         else              hipLaunchKernelGGL(kfn, grid, block, LDS, st, g);                                                \
     } while (0)
@@ -654,6 +693,26 @@ extern "C" int omlm_gemm(const void* A, const void* B, void* C, const float* Cin
     { const char* e = getenv("OMLM_GEMM_SPLITS"); if (e && atoi(e) > 0 && splits > 1) splits = atoi(e); }     // tuning override
     g.kt_per_split = (nk + splits - 1) / splits;
     splits = (nk + g.kt_per_split - 1) / g.kt_per_split;
+    // Balanced split-K for the same GEMMs (bf16 tile kernels): one workgroup per slot, every workgroup the same number of k-tiles,
+    // K cut into round(slots / tiles) chunks so that co-resident workgroups read the same K range.
+    g.bal_ck = 0; g.bal_chunks = 0;
+    if (splits > 1 && in_dtype == 1) {
+        static int bal_on = -1;
+        // measured (MI355X, dW1: 88 tiles x 558 k-tiles): 665 us balanced vs 642 us with the 8-split grid, train step 36.9 vs 36.7 ms --
+        // the k-major main loop, not the partial last round or the atomic volume, is what holds these GEMMs at ~620 TFLOP/s.
+        // Off by default; OMLM_GEMM_BAL=1 selects it.
+        if (bal_on < 0) { const char* e = getenv("OMLM_GEMM_BAL"); bal_on = (e && e[0] == '1') ? 1 : 0; }
+        if (bal_on) {
+            const int slots = (bm == 256 ? 1 : 2) * ncu;
+            const long long U = (long long)tiles * nk;
+            long long G = slots;
+            if (U / 24 < G) G = U / 24 > 0 ? U / 24 : 1;            // at least ~24 k-tiles per workgroup: prologue + atomic epilogue amortised
+            int chunks = (int)((G + tiles / 2) / tiles); if (chunks < 1) chunks = 1; if (chunks > nk) chunks = nk;
+            g.bal_ck = (nk + chunks - 1) / chunks;
+            g.bal_chunks = (nk + g.bal_ck - 1) / g.bal_ck;
+            splits = (int)G;
+        }
+    }
     if (in_dtype == 0) {
         static bool attr_done = false;   // 64 KiB dynamic LDS needs the opt-in attribute once per kernel
         if (!attr_done) {
