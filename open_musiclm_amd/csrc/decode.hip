@@ -17,6 +17,7 @@
 // TW = bf16_t: weights are the bf16 operand copies ("bf16" mode; activations that the batched path rounds to bf16 before
 // its GEMMs are rounded here too, so both paths see the same operands); TW = float: fp32 weights, fp32 FMA chains.
 #include "common.h"
+#include <stdlib.h>
 
 #define DEC_T 256
 #define DEC_BMAX 8
@@ -243,6 +244,86 @@ __global__ __launch_bounds__(DEC_T) void dec_attn_kernel(const float* __restrict
     }
 }
 
+// ---- B1, second generation: the same partials from 8 waves (one head per wave and pass) with ONE barrier: every global load
+// (q, the 64-key K / V tiles, scales) is requested at the top; the new key is l2-normalised in registers by the 16 lanes that
+// loaded it (sum of squares through 4 lane swaps) before it goes to LDS and back to the cache; the probabilities reach the
+// P.V loop through the wave's own LDS row (same-wave LDS ordering, no barrier).
+#define DEC_AT2 512
+__global__ __launch_bounds__(DEC_AT2) void dec_attn2_kernel(const float* __restrict__ q, float* __restrict__ Kc,
+                                                           const float* __restrict__ Vc, const float* __restrict__ q_scale,
+                                                           const float* __restrict__ k_scale, const float* __restrict__ bias, int bias_ld,
+                                                           float* __restrict__ parts, int H, int Nmax, int nsplit,
+                                                           const int* __restrict__ pos_dev, float scale, int round_bf16) {
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    const int pos = *pos_dev;
+    const int s = blockIdx.x, b = blockIdx.y;
+    const int j0 = s * DEC_KS;
+    if (j0 > pos) return;
+    const int nk = min(DEC_KS, pos + 1 - j0);
+    float* Ks = dsm;                        // [64][65]
+    float* Vs = Ks + 64 * 65;               // [64][64]
+    float* qn = Vs + 64 * 64;               // [H][64]
+    float* sc = qn + H * 64;                // [8 waves][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* Kb = Kc + ((size_t)b * Nmax + j0) * 64;
+    const float* Vb = Vc + ((size_t)b * Nmax + j0) * 64;
+    // ---- all global loads first ----
+    float4 kk[2], vv[2];
+    const int c16 = threadIdx.x & 15;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int j = (threadIdx.x >> 4) + 32 * i;
+        const int jj = min(j, nk - 1);
+        kk[i] = ((const float4*)(Kb + (size_t)jj * 64))[c16];
+        vv[i] = ((const float4*)(Vb + (size_t)jj * 64))[c16];
+    }
+    const float4 ks4 = ((const float4*)k_scale)[c16];
+    float qv[2] = {0.f, 0.f};
+    const float qs = q_scale[lane];
+    for (int h = wave, i = 0; h < H; h += 8, ++i) qv[i] = q[(size_t)b * H * 64 + h * 64 + lane];
+    // ---- q: l2norm * q_scale per head (utils.py:68-69), one wave per head ----
+    for (int h = wave, i = 0; h < H; h += 8, ++i) {
+        const float nrm = fmaxf(sqrtf(wave_sum(qv[i] * qv[i])), 1e-12f);
+        qn[h * 64 + lane] = round_if(qv[i] / nrm * qs, round_bf16);
+    }
+    // ---- K / V tiles to LDS; the row written by dec_qkv this step is raw: normalise it here, keep it in the cache ----
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int j = (threadIdx.x >> 4) + 32 * i;
+        float4 kx = kk[i];
+        if (j == pos - j0) {                                    // uniform over the 16 lanes that hold this row
+            float ss = kx.x * kx.x + kx.y * kx.y + kx.z * kx.z + kx.w * kx.w;
+            ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64); ss += __shfl_xor(ss, 8, 64);
+            const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+            kx.x = round_if(kx.x * inv * ks4.x, round_bf16); kx.y = round_if(kx.y * inv * ks4.y, round_bf16);
+            kx.z = round_if(kx.z * inv * ks4.z, round_bf16); kx.w = round_if(kx.w * inv * ks4.w, round_bf16);
+            ((float4*)(Kb + (size_t)j * 64))[c16] = kx;
+        }
+        if (j < nk) {
+            Ks[j * 65 + 4 * c16] = kx.x; Ks[j * 65 + 4 * c16 + 1] = kx.y; Ks[j * 65 + 4 * c16 + 2] = kx.z; Ks[j * 65 + 4 * c16 + 3] = kx.w;
+            *(float4*)(Vs + j * 64 + 4 * c16) = vv[i];
+        }
+    }
+    __syncthreads();
+    for (int h = wave; h < H; h += 8) {                                   // lane = key, then lane = dim
+        float dot = 0.f;
+        if (lane < nk) {
+#pragma unroll 16
+            for (int d = 0; d < 64; ++d) dot += qn[h * 64 + d] * Ks[lane * 65 + d];
+        }
+        const float sv = lane < nk ? dot * scale + (bias ? bias[(size_t)(pos - j0 - lane) * bias_ld + h] : 0.f) : -3.0e38f;
+        const float m = wave_max(sv);
+        const float p = lane < nk ? __expf(sv - m) : 0.f;
+        const float l = wave_sum(p);
+        sc[wave * 64 + lane] = p;
+        float* pp = parts + (((size_t)b * nsplit + s) * H + h) * DEC_PART;
+        if (lane == 0) { pp[0] = m; pp[1] = l; }
+        float acc = 0.f;
+        for (int j = 0; j < nk; ++j) acc += sc[wave * 64 + j] * Vs[j * 64 + lane];
+        pp[2 + lane] = acc;
+    }
+}
+
 // ---- B2: out[b, n] = sum_k act[b, k] W[n, k] (+ res[b, n]); 16 output features per workgroup.
 //      act = LN?(in[b, :]) or (parts != null) the combined attention output ----
 template <typename TW>
@@ -312,6 +393,445 @@ __global__ __launch_bounds__(DEC_T) void dec_ffin_kernel(const float* __restrict
     }
 }
 
+// =========================================================================================================================
+// Second-generation step kernels (default; OMLM_DECODE_V1=1 selects the ones above).  The first generation measured 8-15 us per
+// launch for ~1 us of memory time, because every latency in a workgroup was serialised: stage the activation (global load ->
+// two block reductions for LayerNorm -> barrier), THEN start the weight loads, 16 rows per workgroup in a rolled loop of
+// load -> wait -> FMA (5.4 round trips for the FF-out rows), then 4 x B serial wave reductions.  Here
+//   * a workgroup owns FOUR weight rows (one per wave), so 4x as many workgroups stream at once, and a lane's whole share of
+//     its row (<= NI 16-byte pieces) is requested before anything else happens -- one memory round trip per launch;
+//   * the activation is staged raw, with its LayerNorm statistics taken in ONE pass (sum and sum of squares, one barrier);
+//     each lane normalises the pieces it multiplies on the fly;
+//   * the attention partials are combined with all their loads in flight at once.
+#define DEC2_ROWS 4
+
+template <typename TW> struct dec_wreg;
+template <> struct dec_wreg<bf16_t> { u32x4 r;
+    __device__ __forceinline__ void load(const bf16_t* p) { r = *(const u32x4*)p; }
+    __device__ __forceinline__ void zero() { r[0] = r[1] = r[2] = r[3] = 0u; }
+    __device__ __forceinline__ void unpack(float* w) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { w[2 * i] = bf16_lo_to_f(r[i]); w[2 * i + 1] = bf16_hi_to_f(r[i]); } } };
+template <> struct dec_wreg<float> { float4 a, b;
+    __device__ __forceinline__ void load(const float* p) { a = ((const float4*)p)[0]; b = ((const float4*)p)[1]; }
+    __device__ __forceinline__ void zero() { a = make_float4(0.f, 0.f, 0.f, 0.f); b = a; }
+    __device__ __forceinline__ void unpack(float* w) const { w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w; } };
+
+// activation staging with one-pass LayerNorm statistics: xs[b][0..K) <- in[b][0..K) (raw); stat[b] = (mean, rstd) over Kstat
+__device__ __forceinline__ void dec2_stage(const float* __restrict__ in, int ldin, int K, int Kstat, bool want_stats, float eps,
+                                           int B, float* xs, float* red /* [B][4][2] */, float* stat /* [B][2] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int b = 0; b < B; ++b) {
+        float s = 0.f, q = 0.f;
+        for (int i = threadIdx.x * 4; i < K; i += DEC_T * 4) {
+            const float4 v = *(const float4*)(in + (size_t)b * ldin + i);
+            *(float4*)(xs + (size_t)b * K + i) = v;
+            if (i + 0 < Kstat) { s += v.x; q += v.x * v.x; }
+            if (i + 1 < Kstat) { s += v.y; q += v.y * v.y; }
+            if (i + 2 < Kstat) { s += v.z; q += v.z * v.z; }
+            if (i + 3 < Kstat) { s += v.w; q += v.w * v.w; }
+        }
+        if (want_stats) {
+            s = wave_sum(s); q = wave_sum(q);
+            if (lane == 0) { red[(b * 4 + wave) * 2] = s; red[(b * 4 + wave) * 2 + 1] = q; }
+        }
+    }
+    __syncthreads();
+    if (want_stats && threadIdx.x < B) {
+        const int b = threadIdx.x;
+        float s = 0.f, q = 0.f;
+        for (int w = 0; w < 4; ++w) { s += red[(b * 4 + w) * 2]; q += red[(b * 4 + w) * 2 + 1]; }
+        const float mean = s / (float)Kstat;
+        const float var = fmaxf(q / (float)Kstat - mean * mean, 0.f);
+        stat[2 * b] = mean; stat[2 * b + 1] = rsqrtf(var + eps);
+    }
+    if (want_stats) __syncthreads();
+}
+
+// attention output of the new row from the per-split partials, all loads issued before the first use: xs[b][h * 64 + d]
+__device__ __forceinline__ void dec2_stage_attention(const float* __restrict__ parts, int nsplit, int H, int pos, int B, int round_bf16, float* xs) {
+    const int ns = pos / DEC_KS + 1;
+    for (int idx = threadIdx.x; idx < B * H * 64; idx += DEC_T) {
+        const int b = idx / (H * 64), hd = idx - b * H * 64, h = hd >> 6, d = hd & 63;
+        const float* pb = parts + ((size_t)b * nsplit * H + h) * DEC_PART;
+        float m = -3.0e38f, l = 0.f, o = 0.f;
+        for (int s0 = 0; s0 < ns; s0 += 8) {                    // 8 splits (512 keys) per batch of loads
+            float pm[8], pl[8], po[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float* p = pb + (size_t)min(s0 + j, ns - 1) * H * DEC_PART;
+                pm[j] = p[0]; pl[j] = p[1]; po[j] = p[2 + d];
+            }
+            float mb = m;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (s0 + j < ns) mb = fmaxf(mb, pm[j]);
+            const float resc = __expf(m - mb);
+            l *= resc; o *= resc; m = mb;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (s0 + j < ns) { const float w = __expf(pm[j] - m); l += w * pl[j]; o += w * po[j]; }
+        }
+        xs[idx] = round_if(o / l, round_bf16);
+    }
+    __syncthreads();
+}
+
+enum { DEC2_QKV = 0, DEC2_OUT = 1, DEC2_FFIN = 2, DEC2_LNGEMV = 3 };
+
+struct dec2_args {
+    const float* in; int ldin; int K, Kstat; const float* gamma; float eps;       // activation (+ LayerNorm over Kstat when gamma)
+    const float* parts; int nsplit, H; const int* pos_dev;                        // DEC2_OUT: attention partials instead
+    const void* W; const void* W2; long long ldw; int Nout;                       // weight rows (W2: the Wkv rows of DEC2_QKV)
+    const float* res; int ldres; float* out; int ldout;                           // out = dot (+ res)
+    float* q; float* Kc; float* Vc; int Nmax;                                     // DEC2_QKV destinations
+    const float* convw; float* hist; float* u; int Fp;                            // DEC2_FFIN
+    int B, round_bf16;
+};
+
+template <typename TW, int NI, int MODE>
+__global__ __launch_bounds__(DEC_T) void dec2_kernel(dec2_args a) {
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    const int B = a.B, K = a.K;
+    float* xs = dsm;                                   // [B][K]
+    float* red = xs + (size_t)B * K;                   // [B][4][2]
+    float* stat = red + DEC_BMAX * 8;                  // [B][2]
+    float* vals = stat + DEC_BMAX * 2;                 // [4][DEC_BMAX]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nch = K >> 3;
+    // ---- this wave's weight row, requested in full before anything else ----
+    int row;                                           // logical output index of this wave
+    const TW* wrow;
+    bool ln_row = a.gamma != nullptr;
+    if (MODE == DEC2_FFIN) {                           // waves 0,1: value rows c0, c0 + 1; waves 2,3: the gate rows of the same channels
+        const int c0 = blockIdx.x * 2;
+        row = c0 + (wave & 1);
+        wrow = (const TW*)a.W + (size_t)((wave < 2 ? 0 : a.Fp) + row) * a.ldw;
+    } else if (MODE == DEC2_QKV) {
+        row = blockIdx.x * DEC2_ROWS + wave;
+        const int HD = a.H * 64;
+        ln_row = row < HD;                             // K / V are projected from the un-normalised residual (transformer.py:228)
+        wrow = row < HD ? (const TW*)a.W + (size_t)row * a.ldw : (const TW*)a.W2 + (size_t)(row - HD) * a.ldw;
+    } else {
+        row = blockIdx.x * DEC2_ROWS + wave;
+        wrow = (const TW*)a.W + (size_t)min(row, a.Nout - 1) * a.ldw;
+    }
+    dec_wreg<TW> wr[NI];
+    float4 g0[NI], g1[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) wr[i].load(wrow + c * 8); else wr[i].zero();
+        if (a.gamma && c < nch) { g0[i] = *(const float4*)(a.gamma + c * 8); g1[i] = *(const float4*)(a.gamma + c * 8 + 4); }
+        else { g0[i] = make_float4(1.f, 1.f, 1.f, 1.f); g1[i] = g0[i]; }
+    }
+    // ---- activation ----
+    if (MODE == DEC2_OUT) dec2_stage_attention(a.parts, a.nsplit, a.H, *a.pos_dev, B, a.round_bf16, xs);
+    else dec2_stage(a.in, a.ldin, K, a.Kstat, a.gamma != nullptr, a.eps, B, xs, red, stat);
+    // ---- dot products: this lane's pieces of the row against every sample ----
+    float acc[DEC_BMAX];
+#pragma unroll
+    for (int b = 0; b < DEC_BMAX; ++b) acc[b] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            float w[8];
+            wr[i].unpack(w);
+#pragma unroll
+            for (int b = 0; b < DEC_BMAX; ++b) {
+                if (b < B) {
+                    const float4 x0 = *(const float4*)(xs + (size_t)b * K + c * 8), x1 = *(const float4*)(xs + (size_t)b * K + c * 8 + 4);
+                    float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                    if (MODE != DEC2_OUT) {
+                        if (ln_row) {
+                            const float mean = stat[2 * b], rstd = stat[2 * b + 1];
+                            const float gm[8] = {g0[i].x, g0[i].y, g0[i].z, g0[i].w, g1[i].x, g1[i].y, g1[i].z, g1[i].w};
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) x[e] = round_if((x[e] - mean) * rstd * gm[e], a.round_bf16);
+                        } else if (a.round_bf16) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) x[e] = round_if(x[e], 1);
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[b] += w[e] * x[e];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < DEC_BMAX; ++b) {
+        if (b < B) {
+            const float s = wave_sum(acc[b]);
+            if (lane == 0) vals[wave * DEC_BMAX + b] = s;
+        }
+    }
+    __syncthreads();
+    // ---- epilogue ----
+    if (MODE == DEC2_FFIN) {
+        const int ld = 2 * a.Fp;
+        for (int idx = threadIdx.x; idx < B * 2; idx += DEC_T) {
+            const int b = idx >> 1, cc = idx & 1, col = blockIdx.x * 2 + cc;
+            const float hv = round_if(vals[cc * DEC_BMAX + b], a.round_bf16);
+            const float hg = round_if(vals[(2 + cc) * DEC_BMAX + b], a.round_bf16);
+            float* h0 = a.hist + (size_t)(b * 2) * ld;       // row p-2
+            float* h1 = h0 + ld;                              // row p-1
+            const float uv = a.convw[col] * h0[col] + a.convw[ld + col] * h1[col] + a.convw[2 * (size_t)ld + col] * hv;
+            const float ug = a.convw[a.Fp + col] * h0[a.Fp + col] + a.convw[ld + a.Fp + col] * h1[a.Fp + col] + a.convw[2 * (size_t)ld + a.Fp + col] * hg;
+            a.u[(size_t)b * a.Fp + col] = dec_gelu(ug) * uv;
+            h0[col] = h1[col];       h0[a.Fp + col] = h1[a.Fp + col];
+            h1[col] = hv;            h1[a.Fp + col] = hg;
+        }
+    } else if (MODE == DEC2_QKV) {
+        const int pos = *a.pos_dev, HD = a.H * 64;
+        for (int idx = threadIdx.x; idx < B * DEC2_ROWS; idx += DEC_T) {
+            const int b = idx / DEC2_ROWS, r = idx - b * DEC2_ROWS, n = blockIdx.x * DEC2_ROWS + r;
+            const float v = vals[r * DEC_BMAX + b];
+            if (n < HD) a.q[(size_t)b * HD + n] = v;
+            else if (n < HD + 64) a.Kc[((size_t)b * a.Nmax + pos) * 64 + (n - HD)] = v;                  // raw: normalised by dec_attn
+            else a.Vc[((size_t)b * a.Nmax + pos) * 64 + (n - HD - 64)] = round_if(v, a.round_bf16);
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < B * DEC2_ROWS; idx += DEC_T) {
+            const int b = idx / DEC2_ROWS, r = idx - b * DEC2_ROWS, n = blockIdx.x * DEC2_ROWS + r;
+            if (n < a.Nout) {
+                float v = vals[r * DEC_BMAX + b];
+                if (a.res) v += a.res[(size_t)b * a.ldres + n];
+                a.out[(size_t)b * a.ldout + n] = v;
+            }
+        }
+    }
+}
+
+template <typename TW, int NI, int MODE>
+static void dec2_launch(const dec2_args& a, int grid, hipStream_t st) {
+    const size_t lds = ((size_t)a.B * a.K + DEC_BMAX * 8 + DEC_BMAX * 2 + 4 * DEC_BMAX) * sizeof(float);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)dec2_kernel<TW, NI, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL((dec2_kernel<TW, NI, MODE>), dim3(grid), dim3(DEC_T), lds, st, a);
+}
+
+// ---- B == 1 fast path: no LDS, no barrier.  Every wave loads the whole activation row itself (L2 hits; exactly the pieces its
+// dot product multiplies), takes the LayerNorm statistics with two wave reductions, and finishes its own output element:
+// one memory round trip between launch and store.  FF-in: a wave owns one CHANNEL (its value row and its gate row), so the
+// conv / GEGLU epilogue needs no exchange either.
+template <typename TW, int NI, int MODE>
+__global__ __launch_bounds__(DEC_T) void dec3_kernel(dec2_args a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int K = a.K, nch = K >> 3;
+    const int unit = blockIdx.x * 4 + wave;           // output row (FF-in: channel)
+    const int HD = a.H * 64;
+    if (unit >= (MODE == DEC2_FFIN ? a.Fp : a.Nout)) return;
+    bool ln_row = a.gamma != nullptr;
+    const TW* wrow;
+    const TW* wrow2 = nullptr;
+    if (MODE == DEC2_FFIN) { wrow = (const TW*)a.W + (size_t)unit * a.ldw; wrow2 = (const TW*)a.W + (size_t)(a.Fp + unit) * a.ldw; }
+    else if (MODE == DEC2_QKV) { ln_row = unit < HD; wrow = unit < HD ? (const TW*)a.W + (size_t)unit * a.ldw : (const TW*)a.W2 + (size_t)(unit - HD) * a.ldw; }
+    else wrow = (const TW*)a.W + (size_t)unit * a.ldw;
+    dec_wreg<TW> wr[NI], wr2[MODE == DEC2_FFIN ? NI : 1];
+    float4 g0[NI], g1[NI], x0[NI], x1[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int c = lane + 64 * i;
+        const bool ok = c < nch;
+        const int cc = ok ? c : 0;
+        wr[i].load(wrow + cc * 8);
+        if (MODE == DEC2_FFIN) wr2[i].load(wrow2 + cc * 8);
+        x0[i] = *(const float4*)(a.in + cc * 8); x1[i] = *(const float4*)(a.in + cc * 8 + 4);
+        if (a.gamma) { g0[i] = *(const float4*)(a.gamma + cc * 8); g1[i] = *(const float4*)(a.gamma + cc * 8 + 4); }
+        else { g0[i] = make_float4(1.f, 1.f, 1.f, 1.f); g1[i] = g0[i]; }
+        if (!ok) { wr[i].zero(); if (MODE == DEC2_FFIN) wr2[i].zero(); x0[i] = make_float4(0.f, 0.f, 0.f, 0.f); x1[i] = x0[i]; }
+    }
+    // epilogue operands requested now as well (lane 0 consumes them)
+    float resv = 0.f, h0v = 0.f, h0g = 0.f, h1v = 0.f, h1g = 0.f, cw[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int pos = 0;
+    const int ld = 2 * a.Fp;
+    if (lane == 0) {
+        if (MODE == DEC2_LNGEMV && a.res) resv = a.res[unit];
+        if (MODE == DEC2_QKV) pos = *a.pos_dev;
+        if (MODE == DEC2_FFIN) {
+            h0v = a.hist[unit]; h0g = a.hist[a.Fp + unit]; h1v = a.hist[ld + unit]; h1g = a.hist[ld + a.Fp + unit];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) { cw[t] = a.convw[(size_t)t * ld + unit]; cw[3 + t] = a.convw[(size_t)t * ld + a.Fp + unit]; }
+        }
+    }
+    float mean = 0.f, rstd = 1.f;
+    if (ln_row) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int e0 = (lane + 64 * i) * 8;
+            const float xv[8] = {x0[i].x, x0[i].y, x0[i].z, x0[i].w, x1[i].x, x1[i].y, x1[i].z, x1[i].w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (e0 + e < a.Kstat) { s += xv[e]; q += xv[e] * xv[e]; }
+        }
+        s = wave_sum(s); q = wave_sum(q);
+        mean = s / (float)a.Kstat;
+        rstd = rsqrtf(fmaxf(q / (float)a.Kstat - mean * mean, 0.f) + a.eps);
+    }
+    float acc = 0.f, acc2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        float w[8], w2[8];
+        wr[i].unpack(w);
+        if (MODE == DEC2_FFIN) wr2[i].unpack(w2);
+        float x[8] = {x0[i].x, x0[i].y, x0[i].z, x0[i].w, x1[i].x, x1[i].y, x1[i].z, x1[i].w};
+        if (ln_row) {
+            const float gm[8] = {g0[i].x, g0[i].y, g0[i].z, g0[i].w, g1[i].x, g1[i].y, g1[i].z, g1[i].w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = round_if((x[e] - mean) * rstd * gm[e], a.round_bf16);
+        } else if (a.round_bf16) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = round_if(x[e], 1);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { acc += w[e] * x[e]; if (MODE == DEC2_FFIN) acc2 += w2[e] * x[e]; }
+    }
+    acc = wave_sum(acc);
+    if (MODE == DEC2_FFIN) acc2 = wave_sum(acc2);
+    if (lane != 0) return;
+    if (MODE == DEC2_FFIN) {
+        const float hv = round_if(acc, a.round_bf16), hg = round_if(acc2, a.round_bf16);
+        const float uv = cw[0] * h0v + cw[1] * h1v + cw[2] * hv;
+        const float ug = cw[3] * h0g + cw[4] * h1g + cw[5] * hg;
+        a.u[unit] = dec_gelu(ug) * uv;
+        a.hist[unit] = h1v;            a.hist[a.Fp + unit] = h1g;
+        a.hist[ld + unit] = hv;        a.hist[ld + a.Fp + unit] = hg;
+    } else if (MODE == DEC2_QKV) {
+        if (unit < HD) a.q[unit] = acc;
+        else if (unit < HD + 64) a.Kc[(size_t)pos * 64 + (unit - HD)] = acc;                     // raw: normalised by dec_attn
+        else a.Vc[(size_t)pos * 64 + (unit - HD - 64)] = round_if(acc, a.round_bf16);
+    } else {
+        a.out[unit] = acc + resv;
+    }
+}
+
+// FF-in rows for B == 1 with CPW channels per wave: the wave's copy of LN(x1) (registers) is multiplied into 2 CPW weight rows, so the
+// L2 traffic of the activation / gamma reloads drops from 2x the weight bytes (one channel per wave) to 0.5x.
+template <typename TW, int CPW>
+__global__ __launch_bounds__(DEC_T) void dec3_ffin_kernel(dec2_args a) {
+    constexpr int NI = 2;                              // D = 1024: two 8-element pieces per lane
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = (blockIdx.x * 4 + wave) * CPW;      // first channel of this wave
+    if (c0 >= a.Fp) return;
+    const int ld = 2 * a.Fp;
+    dec_wreg<TW> wv[CPW][NI], wg[CPW][NI];
+    float4 g0[NI], g1[NI], x0[NI], x1[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int c = lane + 64 * i;
+#pragma unroll
+        for (int ch = 0; ch < CPW; ++ch) {
+            const int cc = min(c0 + ch, a.Fp - 1);
+            wv[ch][i].load((const TW*)a.W + (size_t)cc * a.ldw + c * 8);
+            wg[ch][i].load((const TW*)a.W + (size_t)(a.Fp + cc) * a.ldw + c * 8);
+        }
+        x0[i] = *(const float4*)(a.in + c * 8); x1[i] = *(const float4*)(a.in + c * 8 + 4);
+        g0[i] = *(const float4*)(a.gamma + c * 8); g1[i] = *(const float4*)(a.gamma + c * 8 + 4);
+    }
+    // epilogue operands: lane ch finishes channel c0 + ch
+    float h0v = 0.f, h0g = 0.f, h1v = 0.f, h1g = 0.f, cw[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int myc = c0 + lane;
+    const bool fin = lane < CPW && myc < a.Fp;
+    if (fin) {
+        h0v = a.hist[myc]; h0g = a.hist[a.Fp + myc]; h1v = a.hist[ld + myc]; h1g = a.hist[ld + a.Fp + myc];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { cw[t] = a.convw[(size_t)t * ld + myc]; cw[3 + t] = a.convw[(size_t)t * ld + a.Fp + myc]; }
+    }
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        s += (x0[i].x + x0[i].y) + (x0[i].z + x0[i].w) + (x1[i].x + x1[i].y) + (x1[i].z + x1[i].w);
+        q += x0[i].x * x0[i].x + x0[i].y * x0[i].y + x0[i].z * x0[i].z + x0[i].w * x0[i].w +
+             x1[i].x * x1[i].x + x1[i].y * x1[i].y + x1[i].z * x1[i].z + x1[i].w * x1[i].w;
+    }
+    s = wave_sum(s); q = wave_sum(q);
+    const float mean = s / (float)a.K;
+    const float rstd = rsqrtf(fmaxf(q / (float)a.K - mean * mean, 0.f) + a.eps);
+    float accv[CPW], accg[CPW];
+#pragma unroll
+    for (int ch = 0; ch < CPW; ++ch) { accv[ch] = 0.f; accg[ch] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        float x[8] = {x0[i].x, x0[i].y, x0[i].z, x0[i].w, x1[i].x, x1[i].y, x1[i].z, x1[i].w};
+        const float gm[8] = {g0[i].x, g0[i].y, g0[i].z, g0[i].w, g1[i].x, g1[i].y, g1[i].z, g1[i].w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = round_if((x[e] - mean) * rstd * gm[e], a.round_bf16);
+#pragma unroll
+        for (int ch = 0; ch < CPW; ++ch) {
+            float w[8], w2[8];
+            wv[ch][i].unpack(w); wg[ch][i].unpack(w2);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { accv[ch] += w[e] * x[e]; accg[ch] += w2[e] * x[e]; }
+        }
+    }
+    float myv = 0.f, myg = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < CPW; ++ch) {
+        const float tv = wave_sum(accv[ch]), tg = wave_sum(accg[ch]);
+        if (lane == ch) { myv = tv; myg = tg; }
+    }
+    if (!fin) return;
+    const float hv = round_if(myv, a.round_bf16), hg = round_if(myg, a.round_bf16);
+    const float uv = cw[0] * h0v + cw[1] * h1v + cw[2] * hv;
+    const float ug = cw[3] * h0g + cw[4] * h1g + cw[5] * hg;
+    a.u[myc] = dec_gelu(ug) * uv;
+    a.hist[myc] = h1v;            a.hist[a.Fp + myc] = h1g;
+    a.hist[ld + myc] = hv;        a.hist[ld + a.Fp + myc] = hg;
+}
+
+template <typename TW, int NI, int MODE>
+static void dec3_launch(const dec2_args& a, int units, hipStream_t st) {
+    hipLaunchKernelGGL((dec3_kernel<TW, NI, MODE>), dim3((units + 3) / 4), dim3(DEC_T), 0, st, a);
+}
+
+template <typename TW>
+static int decode_step2_t(const omlm_decode_args& a, const long long* ids, hipStream_t st) {
+    const int B = a.B, D = a.D, H = a.H, Fp = a.Fp, HD = H * 64;
+    const size_t lds_at2 = (size_t)(64 * 65 + 64 * 64 + H * 64 + 8 * 64) * sizeof(float);
+    if (a.emb_table)
+        hipLaunchKernelGGL(dec_embed_kernel, dim3(B), dim3(DEC_T), 0, st, ids, a.emb_table, a.emb_row_offset, a.emb_rows, a.x, D);
+    dec2_args g;
+    memset(&g, 0, sizeof(g));
+    g.B = B; g.round_bf16 = a.round_bf16; g.eps = a.eps; g.H = H; g.nsplit = a.nsplit; g.pos_dev = a.pos_dev; g.Nmax = a.Nmax; g.Fp = Fp;
+    for (int l = 0; l < a.L; ++l) {
+        dec2_args q = g;                                                               // q / k / v rows of the new token
+        q.in = a.x; q.ldin = D; q.K = D; q.Kstat = D; q.gamma = a.attn_gamma[l]; q.W = a.Wq[l]; q.W2 = a.Wkv[l]; q.ldw = D;
+        q.Nout = HD + 128; q.q = a.q; q.Kc = a.Kc[l]; q.Vc = a.Vc[l];
+        if (B == 1) dec3_launch<TW, 2, DEC2_QKV>(q, HD + 128, st);
+        else        dec2_launch<TW, 2, DEC2_QKV>(q, (HD + 128) / DEC2_ROWS, st);
+        hipLaunchKernelGGL(dec_attn2_kernel, dim3(a.nsplit, B), dim3(DEC_AT2), lds_at2, st, a.q, a.Kc[l], a.Vc[l], a.q_scale[l], a.k_scale[l],
+                           a.bias_table, a.bias_ld, a.parts, H, a.Nmax, a.nsplit, a.pos_dev, a.scale, a.round_bf16);
+        dec2_args o = g;                                                               // x1 = x + attn Wo^T
+        o.K = HD; o.parts = a.parts; o.W = a.Wo[l]; o.ldw = HD; o.Nout = D; o.res = a.x; o.ldres = D; o.out = a.x1; o.ldout = D;
+        if (HD <= 512) dec2_launch<TW, 1, DEC2_OUT>(o, (D + DEC2_ROWS - 1) / DEC2_ROWS, st);
+        else           dec2_launch<TW, 2, DEC2_OUT>(o, (D + DEC2_ROWS - 1) / DEC2_ROWS, st);
+        dec2_args f = g;                                                               // FF-in rows + conv + GEGLU
+        f.in = a.x1; f.ldin = D; f.K = D; f.Kstat = D; f.gamma = a.ffin_gamma[l]; f.W = a.W1p[l]; f.ldw = D; f.convw = a.convw[l];
+        f.hist = a.hist[l]; f.u = a.u;
+        if (B == 1) {
+            static int cpw = -1;
+            if (cpw < 0) { const char* e = getenv("OMLM_DECODE_CPW"); cpw = e ? atoi(e) : 4; }
+            if (cpw == 4)      hipLaunchKernelGGL((dec3_ffin_kernel<TW, 4>), dim3((Fp + 15) / 16), dim3(DEC_T), 0, st, f);
+            else if (cpw == 2) hipLaunchKernelGGL((dec3_ffin_kernel<TW, 2>), dim3((Fp + 7) / 8), dim3(DEC_T), 0, st, f);
+            else               dec3_launch<TW, 2, DEC2_FFIN>(f, Fp, st);
+        } else dec2_launch<TW, 2, DEC2_FFIN>(f, Fp / 2, st);
+        dec2_args w = g;                                                               // x = x1 + LN(u) W2^T
+        w.in = a.u; w.ldin = Fp; w.K = Fp; w.Kstat = a.F; w.gamma = a.mid_gamma[l]; w.W = a.W2p[l]; w.ldw = Fp; w.Nout = D;
+        w.res = a.x1; w.ldres = D; w.out = a.x; w.ldout = D;
+        if (B == 1 && Fp <= 3072) dec3_launch<TW, 6, DEC2_LNGEMV>(w, D, st);
+        else if (Fp <= 3072) dec2_launch<TW, 6, DEC2_LNGEMV>(w, (D + DEC2_ROWS - 1) / DEC2_ROWS, st);
+        else                 dec2_launch<TW, 8, DEC2_LNGEMV>(w, (D + DEC2_ROWS - 1) / DEC2_ROWS, st);
+    }
+    if (a.head_W) {
+        dec2_args h = g;
+        h.in = a.x; h.ldin = D; h.K = D; h.Kstat = D; h.gamma = a.final_gamma; h.W = a.head_W; h.ldw = D; h.Nout = a.V1;
+        h.out = a.logits; h.ldout = a.ldV;
+        if (B == 1) dec3_launch<TW, 2, DEC2_LNGEMV>(h, a.V1, st);
+        else        dec2_launch<TW, 2, DEC2_LNGEMV>(h, (a.V1 + DEC2_ROWS - 1) / DEC2_ROWS, st);
+    }
+    return omlm_post_launch("omlm_decode_step");
+}
+
 // ---- end of step: the row index (and the sampler's step counter) move on, on the device ----
 __global__ void dec_advance_kernel(int* pos_dev, int* step_dev) {
     if (threadIdx.x == 0) { if (pos_dev) pos_dev[0] += 1; if (step_dev) step_dev[0] += 1; }
@@ -371,6 +891,13 @@ extern "C" int omlm_decode_step(const omlm_decode_args* a, const long long* ids,
     OMLM_CHECK_ARG(a->nsplit * DEC_KS >= a->Nmax, "nsplit must cover Nmax keys");
     OMLM_CHECK_ARG((size_t)a->B * a->Fp * sizeof(float) + 1024 <= 150 * 1024, "B * Fp exceeds the LDS budget");
     OMLM_CHECK_ARG(!a->emb_table || ids, "ids required with an embedding table");
+    static int v1 = -1;
+    if (v1 < 0) { const char* e = getenv("OMLM_DECODE_V1"); v1 = (e && e[0] == '1') ? 1 : 0; }
+    const bool v2_ok = a->D == 1024 && a->H * 64 <= 1024 && a->Fp <= 4096 && a->Fp % 2 == 0 && (a->H * 64 + 128) % DEC2_ROWS == 0;
+    if (!v1 && v2_ok) {
+        if (a->w_dtype == 0) return decode_step2_t<float>(*a, ids, as_stream(stream));
+        return decode_step2_t<bf16_t>(*a, ids, as_stream(stream));
+    }
     if (a->w_dtype == 0) return decode_step_t<float>(*a, ids, as_stream(stream));
     return decode_step_t<bf16_t>(*a, ids, as_stream(stream));
 }
