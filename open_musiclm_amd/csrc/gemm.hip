@@ -285,6 +285,25 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs g) {
 // Measured on MI355X: the 128x128 kernel saturates the L2 -> LDS DMA path (~10-12 TB/s chip-wide) at ~600 TFLOP/s because
 // a 128x128x64 tile moves 32 KiB per 2.1 MFLOP (64 FLOP/B).  256x256 (8 waves of 128x64) doubles that to 128 FLOP/B,
 // 256x128 (8 waves of 64x64) gives 85 FLOP/B for the narrow-N GEMMs where 256-wide tiles would leave CUs idle.
+// LDS-DMA issued as inline asm.  With the builtin (raw_ptr_buffer_load_lds) hipcc tracks "a pending write to LDS" and protects
+// every LDS read it cannot prove disjoint: plain ds_read_b128 fragment reads pass, but the transpose-read builtin
+// (ds_read_b64_tr_b16: every fragment of a k-major operand) gets an s_waitcnt vmcnt(0) in front of it -- seen in the ISA of the
+// k-major kernels right after the DMA issue of each k16 step, i.e. the weight-gradient GEMMs waited for the tile they had just
+// requested four times per k-tile (~620 TFLOP/s against ~1000 for the same contraction with k-contiguous operands).  The asm
+// form is invisible to that bookkeeping; the k-loop's barrier is preceded by an explicit s_waitcnt vmcnt(0).
+typedef u32x4 dma_rsrc;
+__device__ __forceinline__ dma_rsrc make_dma_rsrc(const void* p, unsigned long long bytes) {      // wave-uniform inputs only
+    const unsigned long long a = (unsigned long long)p;
+    dma_rsrc r;
+    r[0] = (unsigned)a; r[1] = (unsigned)(a >> 32) & 0xFFFFu; r[2] = bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)bytes; r[3] = 0x00020000u;
+    return r;
+}
+__device__ __forceinline__ void dma_issue(dma_rsrc rs, unsigned lds_dst, unsigned off) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(off), "s"(lds_dst), "s"(rs) : "memory");
+}
+
 template <bool KMAJ, int ROWS, int NWAVES>
 struct DmaStagerT {
     static constexpr int UPW = (ROWS / 8) / NWAVES;       // 1-KiB units per wave per tile
@@ -317,7 +336,7 @@ struct DmaStagerT {
     // presence -- even behind a null-pointer test -- makes hipcc wait vmcnt(0) before every LDS-DMA issue and every
     // fragment read, which serialised the whole pipeline of the k-major GEMMs (2x slower; found in the ISA).
     template <bool KMAP>
-    __device__ __forceinline__ void issue_one(int i, __amdgpu_buffer_rsrc_t rs, const int* map, int ld, int k0, int K,
+    __device__ __forceinline__ void issue_one(int i, dma_rsrc rs, const int* map, int ld, int k0, int K,
                                               char* lds_tile, int wave, bool live, int aux = 0) {
         const int b = wave + NWAVES * i;
         unsigned off;
@@ -326,17 +345,15 @@ struct DmaStagerT {
         } else {
             const int gk = k0 + kidx[i];
             const bool ok = live && base[i] != OOB_OFF && gk < K;
-            long long pr = gk;
-            if (KMAP) { if (ok && map) pr = map[gk]; }
-            off = ok ? base[i] + (unsigned)(pr * ld * 2) : OOB_OFF;
+            unsigned pr = (unsigned)gk;
+            if (KMAP) { if (ok && map) pr = (unsigned)map[gk]; }
+            off = ok ? base[i] + pr * (unsigned)(ld * 2) : OOB_OFF;     // 32-bit: the host checks that the operand is < 4 GiB
         }
-        if (aux == 0)      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(void, lds_tile + b * 1024), 16, (int)off, 0, 0, 0);
-        else if (aux == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(void, lds_tile + b * 1024), 16, (int)off, 0, 0, 1);
-        else if (aux == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(void, lds_tile + b * 1024), 16, (int)off, 0, 0, 2);
-        else               __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(void, lds_tile + b * 1024), 16, (int)off, 0, 0, 3);
+        (void)aux;
+        dma_issue(rs, (unsigned)(size_t)LDS_PTR(char, lds_tile) + (unsigned)(b * 1024), off);
     }
     template <bool KMAP>
-    __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rs, const int* map, int ld, int k0, int K,
+    __device__ __forceinline__ void issue(dma_rsrc rs, const int* map, int ld, int k0, int K,
                                           char* lds_tile, int wave) {
 #pragma unroll
         for (int i = 0; i < UPW; ++i) issue_one<KMAP>(i, rs, map, ld, k0, K, lds_tile, wave, true);
@@ -467,8 +484,8 @@ __global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = (wave / NWN) * WM_, wn = (wave % NWN) * WN_;
-    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(g.A, (unsigned long long)g.a_rows * g.lda * 2);
-    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(g.B, (unsigned long long)g.b_rows * g.ldb * 2);
+    const dma_rsrc rsA = make_dma_rsrc(g.A, (unsigned long long)g.a_rows * g.lda * 2);
+    const dma_rsrc rsB = make_dma_rsrc(g.B, (unsigned long long)g.b_rows * g.ldb * 2);
 
     for (;;) {
         int bid, kt0, kt1;
@@ -515,7 +532,8 @@ __global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile
         }
         for (int kt = kt0; kt < kt1; ++kt) {
             const int cur = (kt - kt0) & 1;
-            __syncthreads();          // waits vmcnt(0): tile kt landed everywhere, and the other stage is free
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile kt have landed (the DMA is asm: hipcc does not wait for it)
+            __syncthreads();          // tile kt landed everywhere, and the other stage is free
             // The DMA of tile kt+1 is NOT issued in one burst here: a wave's instruction stream is in order, and a
             // buffer_load..lds stalls at issue while the CU's vector-memory path is full, so a burst of 8 loads kept every
             // wave out of its MFMAs for the whole transfer (measured: full time ~ DMA-only time + compute-only time).

@@ -26,6 +26,7 @@ ATTN_SCALE = 8.0
 DIM_HEAD = 64
 
 _PRECISIONS = {"bf16": torch.bfloat16, "bf16x3": torch.float32}
+_WT = os.environ.get("OMLM_WT", "0") == "1"
 
 
 def default_precision() -> str:
@@ -545,7 +546,10 @@ def run_forward(model, all_token_ids, self_attn_mask, only_final: bool, save: bo
     require_gpu(ids32, "token ids")
     B, N = ids32.shape
     lay = get_layout(model, B, lens, ids32.device, final_rows_only)
-    pw = prepared_weights(model, precision) if not save else PreparedWeights(model, precision, with_transposes=True)
+    # k-contiguous W^T copies for the input-gradient GEMMs were worth 795 vs 644 TFLOP/s while the k-major GEMM path stalled on
+    # its own DMA (gemm.hip: dma_issue); with that fixed, dX = dY W reads W k-major at the same rate (795 vs 778 TFLOP/s on the FF
+    # shape) and the per-step transposes (183 MB written, 52 launches) are skipped.  OMLM_WT=1 brings them back (A/B).
+    pw = prepared_weights(model, precision) if not save else PreparedWeights(model, precision, with_transposes=_WT)
     keymask = None
     if self_attn_mask is not None:
         assert self_attn_mask.shape == (B, N), f"self_attn_mask must be [{B}, {N}]"
