@@ -74,8 +74,8 @@ long long omlm_attn_bias_table_floats(int N, int H);
  * (m_h = scale log2e bound + max bias_h, subtracted from the table) instead of a running maximum; neither: online softmax. */
 int omlm_attn_bias_prepare(const float* bias, float* biasT, int N, int H, int bias_ld, const float* q_scale,
                            const float* k_scale, float qk_bound, float scale, void* stream);
-int omlm_mqa_attn_bwd(const void* q, const void* k, const void* v, const float* bias, const unsigned char* keymask,
-                      const void* out, const void* dout, const float* lse, float* delta,
+int omlm_mqa_attn_bwd(const void* q, const void* k, const void* v, const float* bias, const float* biasT,
+                      const unsigned char* keymask, const void* out, const void* dout, const float* lse, float* delta,
                       float* dq, float* dk, float* dv, float* dbias,
                       int B, int N, int H, float scale, int bias_ld, int dtype, void* stream);
 

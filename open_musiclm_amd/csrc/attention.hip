@@ -923,8 +923,12 @@ extern "C" int omlm_mqa_attn_fwd(const void* q, const void* k, const void* v, co
 }
 
 // dq [B*N, H*64] fp32, dk, dv [B*N, 64] fp32 (overwritten), dbias [N, bias_ld] fp32 (accumulated, +=), delta [B, H, N] scratch
-extern "C" int omlm_mqa_attn_bwd(const void* q, const void* k, const void* v, const float* bias, const unsigned char* keymask,
-                                 const void* out, const void* dout, const float* lse, float* delta,
+int attn2_bwd_dq_launch(const void* q, const void* k, const void* v, const float* biasT, const unsigned char* keymask,
+                        const void* out, const void* dout, const float* lse, float* delta, float* dq, float* dbias, int bias_ld,
+                        int B, int N, int H, float scale, hipStream_t st);                             // attention2.hip
+
+extern "C" int omlm_mqa_attn_bwd(const void* q, const void* k, const void* v, const float* bias, const float* biasT,
+                                 const unsigned char* keymask, const void* out, const void* dout, const float* lse, float* delta,
                                  float* dq, float* dk, float* dv, float* dbias,
                                  int B, int N, int H, float scale, int bias_ld, int dtype, void* stream) {
     if (B <= 0 || N <= 0) return OMLM_OK;
@@ -939,9 +943,22 @@ extern "C" int omlm_mqa_attn_bwd(const void* q, const void* k, const void* v, co
         hipLaunchKernelGGL(attn_bwd_dq_precise_kernel<float>, gridq, block, ldsq, st, (const float*)q, (const float*)k, (const float*)v, bias, keymask, (const float*)out, (const float*)dout, lse, delta, dq, dbias, B, N, H, scale, bias_ld);
         hipLaunchKernelGGL(attn_bwd_dkv_kernel<float>, gridk, block, ldsk, st, (const float*)q, (const float*)k, (const float*)v, bias, keymask, (const float*)dout, lse, delta, dk, dv, B, N, H, scale, bias_ld);
     } else {
-        if ((rc = set_lds(attn_bwd_dq_kernel<bf16_t>, ldsq))) return rc;
         if ((rc = set_lds(attn_bwd_dkv_kernel<bf16_t>, ldsk))) return rc;
+        // dQ / d(bias) / delta: the attention2.hip kernel when the prepared table is there and the sample fits its LDS plan
+        int r2 = 1;
+        // measured (B=32, N=1116, H=8): 334 us against 316 us for the first-generation kernel -- both spend ~160 us in the
+        // d(bias) diagonal sums (32 cross-lane permutes per 32x32 block) and ~170 us in everything else, so the LDS-DMA
+        // skeleton that took 30 % off the forward buys nothing here.  Kept behind OMLM_ATTN_DQ2=1.
+        static int dq2 = -1;
+        if (dq2 < 0) { const char* e = getenv("OMLM_ATTN_DQ2"); dq2 = (e && e[0] == '1') ? 1 : 0; }
+        if (dq2 && (biasT || !bias) && !attn_v1_forced()) {
+            r2 = attn2_bwd_dq_launch(q, k, v, biasT, keymask, out, dout, lse, delta, dq, dbias, bias_ld, B, N, H, scale, st);
+            if (r2 < 0) return r2;
+        }
+        if (r2 != 0) {
+        if ((rc = set_lds(attn_bwd_dq_kernel<bf16_t>, ldsq))) return rc;
         hipLaunchKernelGGL(attn_bwd_dq_kernel<bf16_t>, gridq, block, ldsq, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, bias, keymask, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, dq, dbias, B, N, H, scale, bias_ld);
+        }
         hipLaunchKernelGGL(attn_bwd_dkv_kernel<bf16_t>, gridk, block, ldsk, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, bias, keymask, (const bf16_t*)dout, lse, delta, dk, dv, B, N, H, scale, bias_ld);
     }
     return omlm_post_launch("omlm_mqa_attn_bwd");

@@ -400,6 +400,211 @@ __global__ __launch_bounds__(A2_THREADS) A2_OCC void attn2_fwd_kernel(const bf16
     }
 }
 
+// =========================================================================================================================
+// backward, dQ / d(bias) / delta kernel on the same skeleton: 8 heads x 32 queries per workgroup, 64-key tiles through the
+// 3-stage LDS-DMA ring -- per stage K as rows (S^T = K Q^T), K blocked (dQ^T += K^T dS^T), V as rows (dP^T = V dO^T) and the
+// bias window.  The key mask is an additive 0 / -1e30 vector in LDS (one aligned 16-byte read per 4 scores); the probabilities
+// come straight from the stored log-sum-exp (no maximum to track), so the blocks of a tile are independent.
+#define A2B_STAGE (3 * 8192 + 8 * A2_BWIN * 4)       /* 28 KiB */
+__global__ __launch_bounds__(A2_THREADS) void attn2_bwd_dq_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                                  const bf16_t* __restrict__ v, const float* __restrict__ biasT, int ldT,
+                                                                  const unsigned char* __restrict__ keymask, const bf16_t* __restrict__ out,
+                                                                  const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                                  float* __restrict__ delta, float* __restrict__ dq, float* __restrict__ dbias,
+                                                                  int bias_ld, int B, int N, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem;
+    char* scratch = smem + A2_NST * A2B_STAGE;
+    const int npad = (N + 63) / 64 * 64;
+    float* mb = (float*)(scratch + 4096);                     // [npad] 0 / -1e30 per key of this sample
+    float* dbl = mb + npad;                                   // [8 waves][nbp]
+    const int nqt = (N + 31) / 32, ny = (H + 7) / 8;
+    int lg;
+    {
+        const int total = nqt * ny * B, lin = blockIdx.x;
+        const int qq = total >> 3, rr = total & 7, xcd = lin & 7, idx = lin >> 3;
+        lg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    }
+    const int b = lg / (nqt * ny);
+    const int rem = lg - b * (nqt * ny);
+    const int qt = nqt - 1 - rem / ny, hy = rem % ny;
+    const int lane = threadIdx.x & 63, hi = lane >> 5, ql = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = hy * 8 + wave;
+    const bool active = h < H;
+    const int i0 = qt * 32, qi = i0 + ql;
+    const int nb = i0 + 32;                                   // rel in [0, i0 + 31]
+    const size_t rowbase = (size_t)b * N;
+    const int nkt = min((i0 + 32 + A2_TKV - 1) / A2_TKV, (N + A2_TKV - 1) / A2_TKV);
+    float* dbw = dbl + (size_t)wave * nb;
+
+    {   // additive key mask, all byte loads in flight at once; this wave's d(bias) bins zeroed
+        unsigned char mk[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) mk[it] = 1;
+        if (keymask) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) mk[it] = keymask[rowbase + min(it * A2_THREADS + (int)threadIdx.x, N - 1)];
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int j = it * A2_THREADS + threadIdx.x;
+            if (j < nkt * A2_TKV) mb[j] = (j < N && mk[it] != 0) ? 0.f : A2_NEG;
+        }
+        if (dbias) for (int r = lane; r < nb; r += 64) dbw[r] = 0.f;
+    }
+    __syncthreads();
+    // per-lane DMA source offsets: K rows and V rows use the row image, K blocked the blocked image (see A2Stager)
+    A2Stager stg;
+    stg.init(wave, lane, ldT);
+    const a2_rsrc rsK = a2_make_rsrc(k + rowbase * 64, (unsigned)N * 128u);
+    const a2_rsrc rsV = a2_make_rsrc(v + rowbase * 64, (unsigned)N * 128u);
+    const a2_rsrc rsB = a2_make_rsrc(biasT ? (const void*)(biasT + (size_t)hy * 8 * ldT) : (const void*)k, biasT ? (unsigned)(8 * ldT * 4) : 0u);
+    const unsigned ring_lds = (unsigned)(size_t)LDS_PTR(char, ring), scratch_lds = (unsigned)(size_t)LDS_PTR(char, scratch);
+    auto issue = [&](int t) {                                  // 4 DMA wave-instructions per wave per tile
+        const unsigned st = ring_lds + (unsigned)((t % A2_NST) * A2B_STAGE);
+        const int j0 = t * A2_TKV;
+        a2_dma(rsK, st + wave * 1024, (unsigned)(j0 * 128) + stg.koff);
+        a2_dma(rsK, st + 8192 + wave * 1024, (unsigned)(j0 * 128) + stg.voff);
+        a2_dma(rsV, st + 16384 + wave * 1024, (unsigned)(j0 * 128) + stg.koff);
+        const unsigned w0 = (unsigned)((A2_PAD + i0 - j0 - 64) * 4);
+        if (stg.bias_wave) a2_dma(rsB, st + 24576 + (wave & 3) * 1024, w0 + stg.boff);
+        else               a2_dma(rsB, scratch_lds + (wave & 3) * 1024, OOB_OFF);
+    };
+    issue(0);
+    if (nkt > 1) issue(1);
+
+    // Q and dO fragments (B operands), delta_i = sum_d dO O, the row's log-sum-exp relative to the table's reference point
+    bf16x8 qf[4], dof[4];
+    float dl = 0.f;
+    const size_t qrow = (rowbase + min(qi, N - 1)) * (size_t)(H * 64) + (size_t)(active ? h : 0) * 64;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        u32x4 z = {0u, 0u, 0u, 0u};
+        const bool ok = active && qi < N;
+        const u32x4 qv = ok ? *(const u32x4*)(q + qrow + 16 * s + 8 * hi) : z;
+        const u32x4 dv = ok ? *(const u32x4*)(dout + qrow + 16 * s + 8 * hi) : z;
+        const u32x4 ov = ok ? *(const u32x4*)(out + qrow + 16 * s + 8 * hi) : z;
+        qf[s] = __builtin_bit_cast(bf16x8, qv);
+        dof[s] = __builtin_bit_cast(bf16x8, dv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dl += bf16_lo_to_f(dv[e]) * bf16_lo_to_f(ov[e]) + bf16_hi_to_f(dv[e]) * bf16_hi_to_f(ov[e]);
+    }
+    dl += __shfl_xor(dl, 32, 64);
+    float Lp = 0.f;
+    if (active) {
+        Lp = lse[((size_t)b * H + h) * N + min(qi, N - 1)];
+        if (biasT) Lp -= biasT[(size_t)h * ldT + (ldT - 1)];     // the table is stored relative to its reference point m_h
+        if (hi == 0 && qi < N) delta[((size_t)b * H + h) * N + qi] = dl;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { asm volatile("" : "+v"(qf[s])); asm volatile("" : "+v"(dof[s])); }
+    asm volatile("" : "+v"(Lp), "+v"(dl));                    // every prologue load is consumed before the tile loop
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
+    const float c = scale * A2_LOG2E;
+
+    for (int t = 0; t < nkt; ++t) {
+        if (t + 1 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < nkt) issue(t + 2);
+        if (!active) continue;
+        const char* Kr = ring + (t % A2_NST) * A2B_STAGE;
+        const char* Kb = Kr + 8192;
+        const char* Vr = Kr + 16384;
+        const float* bw = (const float*)(Kr + 24576) + wave * A2_BWIN;
+        const int j0 = t * A2_TKV;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int jb = j0 + 32 * sub;
+            if (jb > i0 + 31) break;
+            f32x16 st, dp;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { st[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                st = MFMA16(a2_frag_rows(Kr, 32 * sub, s, lane), qf[s], st);      // S^T  = K Q^T
+                dp = MFMA16(a2_frag_rows(Vr, 32 * sub, s, lane), dof[s], dp);     // dP^T = V dO^T
+            }
+            const float* bp = bw + (64 - 32 * sub) + ql - 4 * hi;
+            const float* mp = mb + jb + 4 * hi;
+            float bv[16];
+            const bool diag = jb + 31 > i0;
+            const int d0 = qi - (jb + 4 * hi);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 m4 = *(const float4*)(mp + 8 * g);
+                const float mm[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e, cr = e + 8 * g;
+                    float x = st[r] * c + bp[-cr] + (mm[e] - Lp);
+                    if (diag) x = (d0 - cr >= 0) ? x : A2_NEG;
+                    const float pr = __builtin_amdgcn_exp2f(x);
+                    bv[r] = pr * (dp[r] - dl);                                    // dS (0 where masked)
+                    st[r] = bv[r] * scale;
+                }
+            }
+            if (dbias) {
+                // d(bias)[rel] = sum of dS over the diagonal rel = i - j: output lane L stands for t = q - kr = L - 31 and pulls row
+                // kr's element from query column q = t + kr through the cross-lane permute; then one read-add-write of this
+                // wave's private table (every lane owns a distinct bin)
+                float dsum = 0.f;
+#pragma unroll
+                for (int kr = 0; kr < 32; ++kr) {
+                    const int r = 4 * (kr >> 3) + (kr & 3), hh = (kr >> 2) & 1;
+                    const int src = lane - 31 + kr;
+                    const float got = __shfl(bv[r], (32 * hh + src) & 63, 64);
+                    dsum += (src >= 0 && src < 32) ? got : 0.f;
+                }
+                const int rel = (i0 - jb) + (lane - 31);
+                if (rel >= 0 && rel < nb) dbw[rel] += dsum;
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 dsb = a2_pack(st, s);
+                acc[0] = MFMA16(a2_frag_cols_tr(Kb, 32 * sub, s, 0, lane), dsb, acc[0]);       // dQ^T += K^T dS^T
+                acc[1] = MFMA16(a2_frag_cols_tr(Kb, 32 * sub, s, 32, lane), dsb, acc[1]);
+            }
+        }
+    }
+    if (!active) return;
+    if (qi < N) {
+        float* drow = dq + (rowbase + qi) * (size_t)(H * 64) + (size_t)h * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d = 32 * dt + 8 * g4 + 4 * hi;
+                *(float4*)(drow + d) = make_float4(acc[dt][4 * g4], acc[dt][4 * g4 + 1], acc[dt][4 * g4 + 2], acc[dt][4 * g4 + 3]);
+            }
+    }
+    if (dbias) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);                   // this wave's LDS updates are complete for its own reads
+        for (int r = lane; r < min(nb, N); r += 64) {
+            const float vv = dbw[r];
+            if (vv != 0.f) unsafeAtomicAdd(dbias + (size_t)r * bias_ld + h, vv);
+        }
+    }
+}
+
+int attn2_bwd_dq_launch(const void* q, const void* k, const void* v, const float* biasT, const unsigned char* keymask,
+                        const void* out, const void* dout, const float* lse, float* delta, float* dq, float* dbias, int bias_ld,
+                        int B, int N, int H, float scale, hipStream_t st) {
+    const int ldT = (A2_PAD + N + 2 * A2_BWIN + 3) / 4 * 4;
+    const int nqt = (N + 31) / 32, ny = (H + 7) / 8, npad = (N + 63) / 64 * 64;
+    const size_t lds = (size_t)A2_NST * A2B_STAGE + 4096 + (size_t)npad * 4 + (size_t)8 * (nqt * 32) * 4;
+    if (lds > 160 * 1024 || N > 4096) return 1;                // caller falls back to the first-generation kernel
+    static bool a1 = false;
+    if (!a1) { (void)hipFuncSetAttribute((const void*)attn2_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a1 = true; }
+    hipLaunchKernelGGL(attn2_bwd_dq_kernel, dim3(nqt * ny * B), dim3(A2_THREADS), lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+                       biasT, ldT, keymask, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, dq, dbias, bias_ld, B, N, H, scale);
+    return omlm_post_launch("omlm_mqa_attn_bwd");
+}
+
 // -------------------------------------------------------------------------------------------------------------------------
 extern "C" long long omlm_attn_bias_table_floats(int N, int H) {
     const int ldT = (A2_PAD + N + 2 * A2_BWIN + 3) / 4 * 4, H8 = (H + 7) / 8 * 8;

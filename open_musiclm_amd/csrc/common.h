@@ -96,10 +96,11 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 
 // Philox-4x32-10 counter RNG: the dropout mask of element e is a pure function of (seed, e),
 // so the backward kernel regenerates it instead of storing it.
+template <int ROUNDS = 10>
 __device__ __forceinline__ void philox4x32(unsigned c0, unsigned c1, unsigned c2, unsigned c3,
                                            unsigned k0, unsigned k1, unsigned out[4]) {
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < ROUNDS; ++r) {
         unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
         unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
         unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;

@@ -267,7 +267,7 @@ def relpos_backward(tr, n: int, saved, dtable: torch.Tensor):
 # trunk
 # ------------------------------------------------------------------------------------------------------
 class LayerSaved:
-    __slots__ = ("x", "m1", "r1", "xn", "xc", "q_raw", "kv_raw", "q", "k", "v", "o", "lse",
+    __slots__ = ("x", "m1", "r1", "xn", "xc", "q_raw", "kv_raw", "q", "k", "v", "o", "lse", "abias",
                  "x1", "m2", "r2", "xn2", "h1", "h2", "m3", "r3", "seed", "p", "drop_bits")
 
 
@@ -338,7 +338,7 @@ def trunk_forward(tr, pw: PreparedWeights, x: torch.Tensor, keymask: Optional[to
         ops.gemm(h2, w["W2p"], x2, M=M, N=D, K=Fp, Cin=x1)
         if save:
             sv.x, sv.m1, sv.r1, sv.xn, sv.xc = x, m1, r1, xn, xc
-            sv.q_raw, sv.kv_raw, sv.q, sv.k, sv.v, sv.o, sv.lse = q_raw, kv_raw, q, k, v, o, lse
+            sv.q_raw, sv.kv_raw, sv.q, sv.k, sv.v, sv.o, sv.lse, sv.abias = q_raw, kv_raw, q, k, v, o, lse, abias
             sv.x1, sv.m2, sv.r2, sv.xn2, sv.h1, sv.h2, sv.m3, sv.r3, sv.seed, sv.p = x1, m2, r2, xn2, h1, h2, m3, r3, seed, p
             sv.drop_bits = drop_bits
             saved_layers.append(sv)
@@ -405,7 +405,7 @@ def trunk_backward(tr, pw: PreparedWeights, saved, dy: torch.Tensor, B: int, N: 
         dk = torch.empty(M, DIM_HEAD, device=dev)
         dv = torch.empty(M, DIM_HEAD, device=dev)
         delta = torch.empty(B, H, N, device=dev)
-        ops.attn_bwd(sv.q, sv.k, sv.v, table, keymask, sv.o, do, sv.lse, delta, dq, dk, dv, dtable, B, N, H, ATTN_SCALE)
+        ops.attn_bwd(sv.q, sv.k, sv.v, sv.abias, keymask, sv.o, do, sv.lse, delta, dq, dk, dv, dtable, B, N, H, ATTN_SCALE)
         dq_raw = torch.empty(M, H * DIM_HEAD, dtype=T, device=dev)
         dkv_raw = torch.empty(M, 2 * DIM_HEAD, dtype=T, device=dev)
         ops.qk_norm_bwd(dq, dk, dv, sv.q_raw, sv.kv_raw, attn.q_scale.detach(), attn.k_scale.detach(),

@@ -117,9 +117,10 @@ def attn_fwd(q, k, v, bias, keymask, out, lse, B, N, H, scale):
 
 
 def attn_bwd(q, k, v, bias, keymask, out, dout, lse, delta, dq, dk, dv, dbias, B, N, H, scale):
-    if isinstance(bias, AttnBias):
-        bias = bias.table
-    call("omlm_mqa_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(bias), ptr(keymask), ptr(out), ptr(dout), ptr(lse),
+    """bias: the AttnBias the forward used (its tableT carries the reference point lse is relative to), a raw table, or None."""
+    ab = _attn_bias(bias, N, H, q.device)
+    bias = ab.table
+    call("omlm_mqa_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(bias), ptr(ab.tableT), ptr(keymask), ptr(out), ptr(dout), ptr(lse),
          ptr(delta), ptr(dq), ptr(dk), ptr(dv), ptr(dbias), B, N, H, float(scale),
          bias.shape[-1] if bias is not None else 0, dcode(q.dtype), stream_ptr())
 
