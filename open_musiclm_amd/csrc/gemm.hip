@@ -703,8 +703,10 @@ extern "C" int omlm_gemm(const void* A, const void* B, void* C, const float* Cin
         float best = -1.f;
         for (int sp = smin; sp <= smax; ++sp) {
             const int total = tiles * sp, rounds = (total + slots - 1) / slots;
-            // every split adds one atomic pass over C: ~1.2 % of the kernel each (probe: 88 tiles -> 5 / 8 / 11 splits = 651 / 631 / 676 us)
-            const float util = (float)total / (float)(rounds * slots) - 0.012f * (float)sp;
+            // every split adds one atomic pass over C.  Re-measured after the k-major DMA fix (tools/splitk_probe.py): with the k-loop
+            // faster the atomics weigh more -- 44 tiles (dW2): 5 / 11 splits = 233 / 267 us; 88 tiles (dW1): 5 / 8 / 11 = 479 / 478 / 515 us;
+            // 128x128 tiles (dWq, dWkv: 64 KiB partials) keep the old weight: 16 / 32 splits stay best there.
+            const float util = (float)total / (float)(rounds * slots) - (bm == 256 ? 0.02f : 0.012f) * (float)sp;
             if (util > best) { best = util; splits = sp; }
         }
     }
