@@ -714,7 +714,8 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
                                                                   const unsigned char* __restrict__ keymask,
                                                                   const T* __restrict__ dout, const float* __restrict__ lse,
                                                                   const float* __restrict__ delta, float* __restrict__ dk,
-                                                                  float* __restrict__ dv, int B, int N, int H, float scale, int bias_ld) {
+                                                                  float* __restrict__ dv, int B, int N, int H, float scale, int bias_ld,
+                                                                  const float* __restrict__ biasT, int ldT) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
     char* Qs = smem + wave * 8192;            // per-wave private [32][64] bf16 tiles (Q, dO) for the transpose reads
@@ -731,10 +732,15 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
     const float c = scale * LOG2E;
     const int nbk = nqt * TQ - j0;            // rel = i - kj <= nqt*TQ - 1 - j0
     bf16x8 dummy;
+    // WIN: the prepared table (omlm_attn_bias_prepare: [head][64 + rel], x log2 e, minus the head's reference point m_h) is there:
+    // an item's 63 bias values are one coalesced load per lane, fetched with the item's Q / dO and parked in a 64-float LDS patch
+    // per wave.  Without it the whole [H][N - j0] column set is staged below: 117 KiB for musiclm_large's fine stage
+    // (H = 16, N = 1817), i.e. ONE 4-wave workgroup per CU.
+    const bool WIN = AT_LEAN && biasT != nullptr;
 
     // The rel-pos column of every head goes to LDS once.  (Per-element global gathers of bias / lse / delta -- 48
     // dependent L2 round trips per work item -- were >95 % of this kernel: 26k cycles per item for 16 MFMAs.)
-    for (int idx = threadIdx.x; idx < H * nbk; idx += AT_THREADS) {
+    if (!WIN) for (int idx = threadIdx.x; idx < H * nbk; idx += AT_THREADS) {
         const int r = idx / H, hh = idx - r * H;
         bias_s[hh * nbk + r] = bias ? bias[(size_t)min(r, N - 1) * bias_ld + hh] * LOG2E : 0.f;
     }
@@ -756,8 +762,8 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
     // A-operand fragments (rows = queries i0 + (lane&31), dims 16 s + 8 hi) of Q and dO plus the tile's lse / delta
     // (one value per lane = per query); the NEXT item's are fetched while the current item is on the matrix cores.
     bf16x8 qa[4], doa[4], qn[4], don[4];
-    float La = 0.f, Da = 0.f, Ln = 0.f, Dn = 0.f;
-    auto fetch = [&](int item, bf16x8 (&fq)[4], bf16x8 (&fd)[4], float& fl, float& fdl) {
+    float La = 0.f, Da = 0.f, Ln = 0.f, Dn = 0.f, Ba = 0.f, Bn = 0.f;
+    auto fetch = [&](int item, bf16x8 (&fq)[4], bf16x8 (&fd)[4], float& fl, float& fdl, float& fb) {
         const int qi_ = (jt + item / H) * TQ + (lane & 31);
         const int hh = item % H;
         const size_t qrow_ = (rowbase + min(qi_, N - 1)) * (size_t)(H * 64) + hh * 64;
@@ -768,13 +774,18 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
         }
         fl = lse[((size_t)b * H + hh) * N + min(qi_, N - 1)];
         fdl = delta[((size_t)b * H + hh) * N + min(qi_, N - 1)];
+        if (WIN) {      // window of rel = i - j for the item: from (i0 - j0 - 31); table index 64 + rel; lse made relative to m_h
+            const float* row = biasT + (size_t)hh * ldT;
+            fb = row[64 + ((jt + item / H) * TQ - j0 - 31) + min(lane, 62)];
+            fl -= row[ldT - 1];
+        }
     };
-    if (wave < nitems) fetch(wave, qa, doa, La, Da);
+    if (wave < nitems) fetch(wave, qa, doa, La, Da, Ba);
     __syncthreads();                           // bias_s staged
     for (int item = wave; item < nitems; item += 4) {
         const int it = jt + item / H, h = item % H;
         const int i0 = it * TQ;
-        if (item + 4 < nitems) fetch(item + 4, qn, don, Ln, Dn);
+        if (item + 4 < nitems) fetch(item + 4, qn, don, Ln, Dn, Bn);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {        // park this item's tiles in LDS for the transpose reads
             *(bf16x8*)(Qs + tile_off_blk(lane & 31, (2 * s + hi) * 16)) = qa[s];
@@ -785,8 +796,11 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
         // 2 selects per score row, and items whose queries all follow this workgroup's keys (all but the first query tile) skip the
         // causal compare, the i < N compare and the clamp of the bias index (constant LDS offsets from one base)
         const float* bh = bias_s + h * nbk;
-        float* ld_l = (float*)(smem + 32768 + (size_t)H * (nqt * TQ) * sizeof(float)) + wave * 64;
+        float* ld_l = WIN ? (float*)(smem + 32768) + wave * 128 : (float*)(smem + 32768 + (size_t)H * (nqt * TQ) * sizeof(float)) + wave * 64;
         if (lane < 32) { ld_l[lane] = La; ld_l[32 + lane] = Da; }
+        if (WIN) ld_l[64 + lane] = Ba;
+        // window index of (query row crow(r, hi), this lane's key): cr + 4 hi - (lane & 31) + 31
+        const float* bwp = ld_l + 64 + 31 + 4 * hi - (lane & 31);
         f32x16 st, dp;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { st[e] = 0.f; dp[e] = 0.f; }
@@ -798,7 +812,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
         f32x16 pp;
         const float* lp = ld_l + 4 * hi;
         if (i0 >= j0 + 31 && i0 + 31 < N) {
-            const float* bp = bh + (i0 - kj + 4 * hi);
+            const float* bp = WIN ? bwp : bh + (i0 - kj + 4 * hi);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int cr = (r & 3) + 8 * (r >> 2);                     // crow(r, hi) - 4 hi
@@ -812,7 +826,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
                 const int cr = (r & 3) + 8 * (r >> 2);
                 const int i = i0 + crow(r, hi);
                 const bool ok = (i >= kj) && keylive && (i < N);
-                const float bvr = bh[max(min(i - kj, nbk - 1), 0)];
+                const float bvr = WIN ? bwp[cr] : bh[max(min(i - kj, nbk - 1), 0)];
                 const float p = __builtin_amdgcn_exp2f(ok ? st[r] * c + bvr - lp[cr] : NEG_BIG);
                 pp[r] = p;
                 st[r] = p * (dp[r] - lp[32 + cr]) * scale;
@@ -860,7 +874,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) { qa[s] = qn[s]; doa[s] = don[s]; }
-        La = Ln; Da = Dn;
+        La = Ln; Da = Dn; Ba = Bn;
     }
     // cross-wave reduction through LDS, one accumulator pair at a time
     for (int which = 0; which < 2; ++which) {
@@ -934,14 +948,21 @@ extern "C" int omlm_mqa_attn_bwd(const void* q, const void* k, const void* v, co
     if (B <= 0 || N <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(q && k && v && out && dout && lse && delta && dq && dk && dv, "null pointer");
     dim3 gridq((N + TQ - 1) / TQ, (H + 3) / 4, B), gridk((N + 31) / 32, 1, B), block(AT_THREADS);
-    const size_t ldsq = dq_lds(N, dtype == 0), ldsk = 32 * 1024 + (size_t)H * ((N + TQ - 1) / TQ * TQ) * sizeof(float) + (AT_LEAN ? 1024 : 0);
+    // windowed bias in the dK / dV kernel only where staging every head's column would cost occupancy (> 80 KiB: one workgroup per CU);
+    // below that the staged form measured 2 % faster (B=32, N=1116, H=8: 656 vs 670 us), above it 16 % slower (B=8, N=1817, H=16)
+    const size_t ldsk_staged = 32 * 1024 + (size_t)H * ((N + TQ - 1) / TQ * TQ) * sizeof(float) + (AT_LEAN ? 1024 : 0);
+    const bool win = AT_LEAN && biasT != nullptr && !attn_v1_forced() && ldsk_staged > 80 * 1024;
+    const int ldT = ((64 + N + 2 * 128 + 3) / 4) * 4;                      // layout of omlm_attn_bias_prepare (attention2.hip)
+    const size_t ldsq = dq_lds(N, dtype == 0);
+    const size_t ldsk = win ? 32 * 1024 + 4 * 128 * sizeof(float)
+                            : ldsk_staged;
     int rc;
     hipStream_t st = as_stream(stream);
     if (dtype == 0) {
         if ((rc = set_lds(attn_bwd_dq_precise_kernel<float>, ldsq))) return rc;
         if ((rc = set_lds(attn_bwd_dkv_kernel<float>, ldsk))) return rc;
         hipLaunchKernelGGL(attn_bwd_dq_precise_kernel<float>, gridq, block, ldsq, st, (const float*)q, (const float*)k, (const float*)v, bias, keymask, (const float*)out, (const float*)dout, lse, delta, dq, dbias, B, N, H, scale, bias_ld);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<float>, gridk, block, ldsk, st, (const float*)q, (const float*)k, (const float*)v, bias, keymask, (const float*)dout, lse, delta, dk, dv, B, N, H, scale, bias_ld);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<float>, gridk, block, ldsk, st, (const float*)q, (const float*)k, (const float*)v, bias, keymask, (const float*)dout, lse, delta, dk, dv, B, N, H, scale, bias_ld, win ? biasT : nullptr, ldT);
     } else {
         if ((rc = set_lds(attn_bwd_dkv_kernel<bf16_t>, ldsk))) return rc;
         // dQ / d(bias) / delta: the attention2.hip kernel when the prepared table is there and the sample fits its LDS plan
@@ -949,9 +970,12 @@ extern "C" int omlm_mqa_attn_bwd(const void* q, const void* k, const void* v, co
         // measured (B=32, N=1116, H=8): 334 us against 316 us for the first-generation kernel -- both spend ~160 us in the
         // d(bias) diagonal sums (32 cross-lane permutes per 32x32 block) and ~170 us in everything else, so the LDS-DMA
         // skeleton that took 30 % off the forward buys nothing here.  Kept behind OMLM_ATTN_DQ2=1.
+        // It IS selected where the first-generation kernel's LDS plan ([8][N] bias + d(bias) tables) leaves room for only one 4-wave
+        // workgroup per CU (N > ~1700: musiclm_large's fine stage): 8 waves per CU instead of 4.  OMLM_ATTN_DQ2=0/1 overrides.
         static int dq2 = -1;
-        if (dq2 < 0) { const char* e = getenv("OMLM_ATTN_DQ2"); dq2 = (e && e[0] == '1') ? 1 : 0; }
-        if (dq2 && (biasT || !bias) && !attn_v1_forced()) {
+        if (dq2 < 0) { const char* e = getenv("OMLM_ATTN_DQ2"); dq2 = e ? (e[0] == '1' ? 1 : 0) : 2; }
+        const bool use2 = dq2 == 1 || (dq2 == 2 && ldsq > 80 * 1024);
+        if (use2 && (biasT || !bias) && !attn_v1_forced()) {
             r2 = attn2_bwd_dq_launch(q, k, v, biasT, keymask, out, dout, lse, delta, dq, dbias, bias_ld, B, N, H, scale, st);
             if (r2 < 0) return r2;
         }
@@ -959,7 +983,7 @@ extern "C" int omlm_mqa_attn_bwd(const void* q, const void* k, const void* v, co
         if ((rc = set_lds(attn_bwd_dq_kernel<bf16_t>, ldsq))) return rc;
         hipLaunchKernelGGL(attn_bwd_dq_kernel<bf16_t>, gridq, block, ldsq, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, bias, keymask, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, dq, dbias, B, N, H, scale, bias_ld);
         }
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<bf16_t>, gridk, block, ldsk, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, bias, keymask, (const bf16_t*)dout, lse, delta, dk, dv, B, N, H, scale, bias_ld);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<bf16_t>, gridk, block, ldsk, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, bias, keymask, (const bf16_t*)dout, lse, delta, dk, dv, B, N, H, scale, bias_ld, win ? biasT : nullptr, ldT);
     }
     return omlm_post_launch("omlm_mqa_attn_bwd");
 }
