@@ -285,8 +285,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)       # == local_rank on a real node (one GPU per rank)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dp = DataParallel(device=dev)
     rank = dp.rank
     legs = [] if (args.no_legs or world > 1) else [l for l in args.legs.split(",") if l]

@@ -26,7 +26,9 @@ class DataParallel:
             os.environ.setdefault("MASTER_PORT", "29500")
             use_cuda = torch.cuda.is_available() and (device is None or torch.device(device).type == "cuda")
             if use_cuda:
-                torch.cuda.set_device(self.local_rank)
+                # one GPU per rank; a rank count above the visible GPUs (dry runs of the multi-process path on a 1-GPU box,
+                # gloo exchange) shares devices round-robin -- RCCL itself refuses two ranks on one GPU
+                torch.cuda.set_device(self.local_rank % max(torch.cuda.device_count(), 1))
             backend = backend or os.environ.get("OMLM_DP_BACKEND") or ("nccl" if use_cuda else "gloo")
             dist.init_process_group(backend=backend,
                                     rank=self.rank, world_size=self.world_size)

@@ -99,7 +99,7 @@ class SingleStageTrainer(nn.Module):
             # One process drives ONE GPU: cuda:LOCAL_RANK.  The reference's scripts build the model with device='cuda' (= cuda:0
             # on every rank) and rely on accelerator.prepare to place it (trainer.py:286-304); here the trainer moves the
             # transformer and the frozen front-ends before the optimizer adopts the parameters.
-            target = torch.device('cuda', self.dp.local_rank)
+            target = torch.device('cuda', self.dp.local_rank % max(torch.cuda.device_count(), 1))
             torch.cuda.set_device(target)
             if transformer.device != target:
                 transformer.to(target)
