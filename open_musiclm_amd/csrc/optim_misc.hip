@@ -163,13 +163,16 @@ __global__ void bias_add_kernel(const float* __restrict__ a, const float* __rest
     const int c = (int)(i % ld);
     out[i] = c < C ? a[i] + b[c] : 0.f;
 }
-// dw0[c] += sum_r r * ds[r, c]   (first-layer weight gradient), one thread per column
-__global__ void relpos_first_bwd_kernel(const float* __restrict__ ds, float* __restrict__ dw0, int n, int Hd) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= Hd) return;
+// dw0[c] += sum_r r * ds[r, c]   (first-layer weight gradient).  64 columns x 4 row lanes per workgroup, 16 row chunks in grid.y:
+// the first version walked all n rows with ONE thread per column (2 workgroups, 1116 dependent loads: 201 us per step).
+__global__ __launch_bounds__(256) void relpos_first_bwd_kernel(const float* __restrict__ ds, float* __restrict__ dw0, int n, int Hd) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
     float s = 0.f;
-    for (int r = 0; r < n; ++r) s += (float)r * ds[(size_t)r * Hd + c];
-    dw0[c] += s;
+    if (c < Hd) for (int r = blockIdx.y * 4 + rl; r < n; r += 4 * gridDim.y) s += (float)r * ds[(size_t)r * Hd + c];
+    red[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && c < Hd) unsafeAtomicAdd(dw0 + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 extern "C" int omlm_relpos_first_fwd(const float* w0, const float* b0, float* pre, float* z, int n, int Hd, void* stream) {
@@ -197,7 +200,7 @@ extern "C" int omlm_bias_add(const float* a, const float* b, float* out, int R, 
 }
 extern "C" int omlm_relpos_first_bwd(const float* ds, float* dw0, int n, int Hd, void* stream) {
     OMLM_CHECK_ARG(ds && dw0 && n > 0 && Hd > 0, "relpos_first_bwd arguments");
-    hipLaunchKernelGGL(relpos_first_bwd_kernel, dim3((Hd + 255) / 256), dim3(256), 0, as_stream(stream), ds, dw0, n, Hd);
+    hipLaunchKernelGGL(relpos_first_bwd_kernel, dim3((Hd + 63) / 64, 16), dim3(256), 0, as_stream(stream), ds, dw0, n, Hd);
     return omlm_post_launch("omlm_relpos_first_bwd");
 }
 
