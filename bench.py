@@ -341,14 +341,19 @@ def main():
             progress(f"diagnostic step {k}: host enqueue {1e3 * (tb - ta):.1f} ms, until GPU idle {1e3 * (tc - ta):.1f} ms")
 
     if rank == 0:
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")      # PMC passes (tools/pmc_gemm_traffic.sh), per train step
-        if os.path.exists(tpath) and args.precision == "bf16":
+        # HBM-side bytes of the same launches (all GEMMs of one step) from the committed PMC passes of tools/pmc_gemm_traffic.sh
+        # (separate FETCH_SIZE / WRITE_SIZE runs; counters cannot be read inside this process): B = 32 bf16 only
+        traffic = detail = None
+        tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
+        if os.path.exists(tpath) and args.precision == "bf16" and args.batch == 32 and args.accum == 1:
             try:
-                traffic = json.load(open(tpath))
+                detail = json.load(open(tpath))
+                traffic = detail["fetch_bytes"] + detail["write_bytes"]
             except Exception:
-                traffic = None
+                traffic = detail = None
         out["roofline"] = main_leg.gemm_roofline(args.warmup + args.steps, traffic)
+        if detail:
+            out["roofline"]["traffic_detail"] = detail
         progress(f"roofline probe: {out['roofline']['launches']} GEMM launches, {out['roofline']['gemm_ms_per_step']} ms per step")
         if not args.no_decode:
             out["ar_tokens_per_sec"] = decode_leg(main_leg.stage, dev, args.decode_ids)
