@@ -125,6 +125,16 @@ int omlm_cast_pad(const float* src, void* dst, long long R, int C, int ld_src, i
  * nn.Linear, transformer.py:203-212,144,149), refreshed once per optimizer step. */
 int omlm_transpose_cast(const float* src, void* dst, int R, int C, int ld_src, int ld_dst, int out_dtype, void* stream);
 
+/* All weight-gradient contractions of a backward pass in one launch (autograd of nn.Linear, transformer.py:203-212,144,149:
+ * dW += dY^T X).  Problem i: C_i [M_i, N_i] fp32 (accumulated, +=; c_map optional: physical row of logical row m, < 0 skips)
+ * from bf16 k-major operands A_i [K_i, M_i] (pitch lda) and B_i [K_i, N_i] (pitch ldb); pitches are multiples of 8 elements.
+ * splits: K-splits per output tile (0: chosen for whole machine rounds; > 1 accumulates with fp32 atomics). */
+typedef struct omlm_gemm_wgrad_desc {
+    const void* A; const void* B; float* C; const int* c_map;
+    int M, N, K, lda, ldb, ldc;
+} omlm_gemm_wgrad_desc;
+int omlm_gemm_wgrad_group(const omlm_gemm_wgrad_desc* problems, int count, int splits, void* stream);
+
 /* RelativePositionBias MLP helpers (transformer.py:55-64): SiLU layers around omlm_gemm. */
 int omlm_relpos_first_fwd(const float* w0, const float* b0, float* pre, float* z, int n, int Hd, void* stream);
 int omlm_relpos_first_bwd(const float* ds, float* dw0, int n, int Hd, void* stream);

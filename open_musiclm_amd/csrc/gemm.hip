@@ -443,38 +443,36 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16 (&acc)[M
     }
 }
 
-template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ, bool B_KMAJ, typename TOUT, bool DBG, bool KMAP, bool BAL = false>
-__global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile_kernel(GemmArgs g) {
+// XCD-aware order over a WHOLE grid of `total` workgroups: they are dealt round-robin to the 8 XCDs in linear dispatch order, so
+// XCD c is given one contiguous chunk of the logical sequence.
+__device__ __forceinline__ int xcd_logical_id(int lin, int total) {
+    const int q = total >> 3, r = total & 7, xcd = lin & 7, idx = lin >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// One workgroup's share of C = alpha A B^T (+ Cin).  lg: logical workgroup id inside this problem's (tiles x K-splits, split-major)
+// space; split: partial sums are added to fp32 C with atomics; bal_wgs: workgroup count of the balanced split-K form (BAL only).
+template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ, bool B_KMAJ, typename TOUT, bool DBG, bool KMAP, bool BAL>
+__device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, const bool split, const int bal_wgs, char* smem) {
     const int dbg = DBG ? g.debug : 0;      // ablation switches exist only in the DBG instantiation (OMLM_GEMM_DEBUG set)
     constexpr int NWN = BN_ / WN_, NWAVES = (BM_ / WM_) * NWN;
     constexpr int MI = WM_ / 32, NJ = WN_ / 32;
     constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BN_ * BK * 2, STAGE = A_BYTES + B_BYTES;
     constexpr int UA = (BM_ / 8) / NWAVES, UB = (BN_ / 8) / NWAVES;   // DMA wave-instructions per k-tile per wave
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A | B]
 
     const int tiles_m = (g.M + BM_ - 1) / BM_, tiles_n = (g.N + BN_ - 1) / BN_;
     const int nwg = tiles_m * tiles_n;
     const int nk_all = (g.K + BK - 1) / BK;
     constexpr bool bal = BAL;          // balanced split-K is its own instantiation: the plain kernels keep their code and registers
-    // XCD-aware order over the WHOLE grid (tiles x K-splits, split-major): workgroups are dealt round-robin to the 8 XCDs in linear
-    // dispatch order, so XCD c is given one contiguous chunk of the logical (split-major) sequence.  For split-K GEMMs
-    // this puts all co-resident workgroups of an XCD on the SAME K range (they share A and B panels through its L2);
-    // with the tile-only remap an XCD held 3 unrelated K ranges at a time (measured L2 hit 48 % on the dW1 GEMM).
-    int lg;
-    {
-        const int total = bal ? (int)gridDim.x : nwg * (int)gridDim.y, lin = blockIdx.y * nwg + blockIdx.x;
-        const int q = total >> 3, r = total & 7, xcd = lin & 7, idx = lin >> 3;
-        lg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    // Balanced split-K: the (K chunk, tile, k-tile) units are numbered chunk-major and cut into gridDim.x equal contiguous
+    // Balanced split-K: the (K chunk, tile, k-tile) units are numbered chunk-major and cut into bal_wgs equal contiguous
     // ranges; a workgroup walks its range segment by segment (a segment = consecutive k-tiles of one output tile) and adds each
     // partial tile to C.  Every workgroup does the same number of k-tiles (no partial last round), co-resident workgroups sit
     // in the same K chunk (shared panels), and a tile receives ~chunks + 1 partial sums instead of one per split.
     int u = 0, u1 = 0;                 // host guarantees tiles x k-tiles < 2^31 / workgroups
     if (bal) {
         const long long U = (long long)nwg * nk_all;
-        u = (int)(U * lg / gridDim.x);
-        u1 = (int)(U * (lg + 1) / gridDim.x);
+        u = (int)(U * lg / bal_wgs);
+        u1 = (int)(U * (lg + 1) / bal_wgs);
         if (u >= u1) return;
     }
 #ifndef OMLM_SUPER_ROWS
@@ -590,10 +588,45 @@ __global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile
             }
         }
         __syncthreads();
-        tile_epilogue<MI, NJ, WN_, TOUT>(g, acc, smem, m0, n0, wm, wn, wave, lane, dbg, bal || gridDim.y > 1);
+        tile_epilogue<MI, NJ, WN_, TOUT>(g, acc, smem, m0, n0, wm, wn, wave, lane, dbg, bal || split);
         if (!bal || u >= u1) break;
         __syncthreads();              // the non-split epilogue stages through LDS; the next segment's DMA must not overtake it
     }
+}
+
+// For split-K GEMMs the split-major XCD order puts all co-resident workgroups of an XCD on the SAME K range (they share A and B
+// panels through its L2); with a tile-only remap an XCD held 3 unrelated K ranges at a time (measured L2 hit 48 % on the dW1 GEMM).
+template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ, bool B_KMAJ, typename TOUT, bool DBG, bool KMAP, bool BAL = false>
+__global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A | B]
+    const int nwg = gridDim.x;                                     // tiles (plain) / workgroups (balanced)
+    const int total = BAL ? (int)gridDim.x : nwg * (int)gridDim.y;
+    const int lg = xcd_logical_id(blockIdx.y * nwg + blockIdx.x, total);
+    gemm_tile_body<BM_, BN_, WM_, WN_, A_KMAJ, B_KMAJ, TOUT, DBG, KMAP, BAL>(g, lg, gridDim.y > 1, (int)gridDim.x, smem);
+}
+
+// ---- grouped weight-gradient GEMM ------------------------------------------------------------------------------------
+// All dW += dY^T X contractions of a backward pass (same K = tokens, small outputs) as ONE launch: the 30 separate GEMMs of a
+// coarse-small step each had too few output tiles for 256 CUs and were split 5..31 ways along K with fp32 atomics
+// (dW2: 44 tiles x 11 splits, 640 TFLOP/s); together they are ~900 full-K tiles, i.e. 3-4 machine rounds with few or no atomics.
+// Nothing consumes a weight gradient before the optimizer, so the host defers them to the end of the backward.
+#define OMLM_GROUP_MAX 48
+struct omlm_gemm_wgrad_desc { const void* A; const void* B; float* C; const int* c_map; int M, N, K, lda, ldb, ldc; };   // include/omlm.h
+struct GroupProb { const void* A; const void* B; float* C; const int* c_map; int M, N, K, lda, ldb, ldc, kt_per_split, start; };
+struct GroupArgs { int n, total; GroupProb p[OMLM_GROUP_MAX]; };
+
+__global__ __launch_bounds__(512) void gemm_wgrad_group_kernel(GroupArgs ga) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lg = xcd_logical_id(blockIdx.x, ga.total);
+    int pi = 0;
+    for (int i = 1; i < ga.n; ++i) if (lg >= ga.p[i].start) pi = i;      // uniform scalar scan (starts ascend)
+    const GroupProb& q = ga.p[pi];
+    GemmArgs g;
+    g.A = q.A; g.B = q.B; g.C = q.C; g.Cin = q.C; g.a_map = nullptr; g.b_map = nullptr; g.c_map = q.c_map;
+    g.a_rows = q.K; g.b_rows = q.K; g.M = q.M; g.N = q.N; g.K = q.K; g.lda = q.lda; g.ldb = q.ldb; g.ldc = q.ldc; g.ldcin = q.ldc;
+    g.alpha = 1.f; g.kt_per_split = q.kt_per_split; g.bal_ck = 0; g.bal_chunks = 0; g.debug = 0;
+    const int nk = (q.K + BK - 1) / BK;
+    gemm_tile_body<256, 256, 128, 64, true, true, float, false, false, false>(g, lg - q.start, q.kt_per_split < nk, 0, smem);
 }
 
 template <int BM_, int BN_, int WM_, int WN_, typename TOUT>
@@ -778,4 +811,66 @@ extern "C" int omlm_gemm(const void* A, const void* B, void* C, const float* Cin
         }
     }
     return launch(g, bm, bn, splits);
+}
+
+// C_i[M_i, N_i] += A_i^T B_i for `count` problems with bf16 k-major operands A_i [K_i, M_i], B_i [K_i, N_i] in ONE launch of 256x256
+// full-K (or lightly split) tiles.  splits: K-splits per tile for every problem (0 = chosen here for whole machine rounds).
+extern "C" int omlm_gemm_wgrad_group(const omlm_gemm_wgrad_desc* d, int count, int splits, void* stream) {
+    if (count <= 0) return OMLM_OK;
+    OMLM_CHECK_ARG(d, "null descriptor array");
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ncu = n;
+        else ncu = 256;
+    }
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_wgrad_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); attr = true; }
+    { const char* e = getenv("OMLM_GROUP_SPLITS"); if (e && atoi(e) > 0) splits = atoi(e); }
+    for (int base = 0; base < count; base += OMLM_GROUP_MAX) {
+        const int n = count - base < OMLM_GROUP_MAX ? count - base : OMLM_GROUP_MAX;
+        long long units = 0;
+        int nk_min = 1 << 30;
+        for (int i = 0; i < n; ++i) {
+            const omlm_gemm_wgrad_desc& q = d[base + i];
+            OMLM_CHECK_ARG(q.A && q.B && q.C && q.M > 0 && q.N > 0 && q.K > 0, "wgrad group: bad problem");
+            OMLM_CHECK_ARG((q.lda % 8) == 0 && (q.ldb % 8) == 0 && q.lda >= ((q.M + 7) / 8) * 8 && q.ldb >= ((q.N + 7) / 8) * 8,
+                           "wgrad group: k-major operand pitches must be multiples of 8 covering the padded extent");
+            OMLM_CHECK_ARG(((uintptr_t)q.A % 16) == 0 && ((uintptr_t)q.B % 16) == 0, "wgrad group: operands must be 16-byte aligned");
+            OMLM_CHECK_ARG((unsigned long long)q.K * q.lda * 2 < 0xFFFFFFF0ull && (unsigned long long)q.K * q.ldb * 2 < 0xFFFFFFF0ull,
+                           "wgrad group: operand exceeds the 4 GiB buffer-descriptor window");
+            units += (long long)((q.M + 255) / 256) * ((q.N + 255) / 256);
+            const int nk = (q.K + BK - 1) / BK;
+            if (nk < nk_min) nk_min = nk;
+        }
+        int sp = splits;
+        if (sp <= 0) {
+            // a unit = one full-K tile; s splits cut it into s workgroups of 1/s the work and add s atomic passes over C
+            float best = -1.f;
+            sp = 1;
+            for (int s = 1; s <= 4; ++s) {
+                const long long wgs = units * s, rounds = (wgs + ncu - 1) / ncu;
+                const float util = (float)wgs / (float)(rounds * ncu) - 0.02f * (float)(s - 1);
+                if (util > best) { best = util; sp = s; }
+            }
+        }
+        if (sp > nk_min / 8) sp = nk_min / 8 > 0 ? nk_min / 8 : 1;
+        GroupArgs ga;
+        memset(&ga, 0, sizeof(ga));
+        ga.n = n;
+        int start = 0;
+        for (int i = 0; i < n; ++i) {
+            const omlm_gemm_wgrad_desc& q = d[base + i];
+            GroupProb& p = ga.p[i];
+            p.A = q.A; p.B = q.B; p.C = q.C; p.c_map = q.c_map; p.M = q.M; p.N = q.N; p.K = q.K; p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc;
+            const int nk = (q.K + BK - 1) / BK;
+            p.kt_per_split = (nk + sp - 1) / sp;
+            const int s_eff = (nk + p.kt_per_split - 1) / p.kt_per_split;
+            p.start = start;
+            start += ((q.M + 255) / 256) * ((q.N + 255) / 256) * s_eff;
+        }
+        ga.total = start;
+        hipLaunchKernelGGL(gemm_wgrad_group_kernel, dim3(start), dim3(512), 131072, as_stream(stream), ga);
+    }
+    return omlm_post_launch("omlm_gemm_wgrad_group");
 }

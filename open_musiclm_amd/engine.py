@@ -27,6 +27,7 @@ DIM_HEAD = 64
 
 _PRECISIONS = {"bf16": torch.bfloat16, "bf16x3": torch.float32}
 _WT = os.environ.get("OMLM_WT", "0") == "1"
+_WGRAD_GROUP = os.environ.get("OMLM_WGRAD_GROUP", "1") == "1"      # grouped weight-gradient GEMMs (0: one split-K GEMM per weight)
 
 
 def default_precision() -> str:
@@ -366,6 +367,18 @@ def trunk_backward(tr, pw: PreparedWeights, saved, dy: torch.Tensor, B: int, N: 
                       None if T == torch.float32 else dres_c, grad_of(tr.norm.gamma),
                       dx_scale=out_scale if nl == 0 else 1.0)
     ws = None
+    # weight gradients have no consumer before the optimizer: in bf16 mode they are collected and issued as grouped launches of
+    # full-K tiles (ops.WgradGroup) instead of 5 split-K GEMMs per layer; their operands stay alive until the flush
+    wg = ops.WgradGroup() if (T == torch.bfloat16 and _WGRAD_GROUP) else None
+
+    def wgrad(dY, X, dW, Mo, No, c_map=None):
+        if wg is not None:
+            wg.add(dY, X, dW, M=Mo, N=No, K=M, c_map=c_map)
+            if len(wg.items) >= 40:
+                wg.flush()
+        else:
+            ops.gemm(dY, X, dW, M=Mo, N=No, K=M, a_kmajor=True, b_kmajor=True, Cin=dW, c_map=c_map)
+
     for li in range(nl - 1, -1, -1):
         attn, _, ff = tr.layers[li]
         w, sv = pw.layers[li], saved["layers"][li]
@@ -375,7 +388,7 @@ def trunk_backward(tr, pw: PreparedWeights, saved, dy: torch.Tensor, B: int, N: 
         if "W2pT" in w: ops.gemm(dres_c, w["W2pT"], dh2, M=M, N=Fp, K=D)
         else: ops.gemm(dres_c, w["W2p"], dh2, M=M, N=Fp, K=D, b_kmajor=True)
         gW2 = grad_of(ff.w_out.weight)                                              # [D, F]
-        ops.gemm(dres_c, sv.h2, gW2, M=D, N=F, K=M, a_kmajor=True, b_kmajor=True, Cin=gW2)
+        wgrad(dres_c, sv.h2, gW2, D, F)
         if ws is None or ws.numel() < ops.ffmid_bwd_workspace_floats(F, Fp):
             ws = torch.empty(ops.ffmid_bwd_workspace_floats(F, Fp), device=dev)
         du = torch.empty(M, 2 * Fp, dtype=T, device=dev)
@@ -389,7 +402,7 @@ def trunk_backward(tr, pw: PreparedWeights, saved, dy: torch.Tensor, B: int, N: 
         if "W1pT" in w: ops.gemm(dh1, w["W1pT"], dxn2, M=M, N=D, K=2 * Fp)
         else: ops.gemm(dh1, w["W1p"], dxn2, M=M, N=D, K=2 * Fp, b_kmajor=True)
         gW1 = grad_of(ff.w_in.weight)                                               # [2F, D]
-        ops.gemm(dh1, sv.xn2, gW1, M=2 * Fp, N=D, K=M, a_kmajor=True, b_kmajor=True, Cin=gW1, c_map=w["dW1_cmap"])
+        wgrad(dh1, sv.xn2, gW1, 2 * Fp, D, c_map=w["dW1_cmap"])
         del dh1
         dx1 = torch.empty(M, D, device=dev)
         dx1_c = dx1 if T == torch.float32 else torch.empty(M, D, dtype=T, device=dev)
@@ -400,7 +413,7 @@ def trunk_backward(tr, pw: PreparedWeights, saved, dy: torch.Tensor, B: int, N: 
         if "WoT" in w: ops.gemm(dx1_c, w["WoT"], do, M=M, N=H * DIM_HEAD, K=D)
         else: ops.gemm(dx1_c, w["Wo"], do, M=M, N=H * DIM_HEAD, K=D, b_kmajor=True)
         gWo = grad_of(attn.to_out[0].weight)
-        ops.gemm(dx1_c, sv.o, gWo, M=D, N=H * DIM_HEAD, K=M, a_kmajor=True, b_kmajor=True, Cin=gWo)
+        wgrad(dx1_c, sv.o, gWo, D, H * DIM_HEAD)
         dq = torch.empty(M, H * DIM_HEAD, device=dev)
         dk = torch.empty(M, DIM_HEAD, device=dev)
         dv = torch.empty(M, DIM_HEAD, device=dev)
@@ -419,15 +432,17 @@ def trunk_backward(tr, pw: PreparedWeights, saved, dy: torch.Tensor, B: int, N: 
             ops.gemm(dq_raw, w["Wq"], dxn, M=M, N=D, K=H * DIM_HEAD, b_kmajor=True)
             ops.gemm(dkv_raw, w["Wkv"], tmp, M=M, N=D, K=2 * DIM_HEAD, b_kmajor=True, Cin=dx1)
         gWq = grad_of(attn.to_q.weight)
-        ops.gemm(dq_raw, sv.xn, gWq, M=H * DIM_HEAD, N=D, K=M, a_kmajor=True, b_kmajor=True, Cin=gWq)
+        wgrad(dq_raw, sv.xn, gWq, H * DIM_HEAD, D)
         gWkv = grad_of(attn.to_kv.weight)
-        ops.gemm(dkv_raw, sv.xc, gWkv, M=2 * DIM_HEAD, N=D, K=M, a_kmajor=True, b_kmajor=True, Cin=gWkv)
+        wgrad(dkv_raw, sv.xc, gWkv, 2 * DIM_HEAD, D)
         dres = torch.empty(M, D, device=dev)
         dres_c = dres if T == torch.float32 else torch.empty(M, D, dtype=T, device=dev)
         last = li == 0
         ops.layernorm_bwd(dxn, sv.x, attn.norm.gamma.detach(), sv.m1, sv.r1, tmp, dres,
                           None if (T == torch.float32 or last) else dres_c, grad_of(attn.norm.gamma),
                           dx_scale=out_scale if last else 1.0)
+    if wg is not None:
+        wg.flush()
     if dtable is not None and saved["rp"] is not None:
         relpos_backward(tr, N, saved["rp"], dtable)
     return dres

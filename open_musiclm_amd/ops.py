@@ -54,6 +54,36 @@ def gemm(A: torch.Tensor, B: torch.Tensor, C_: torch.Tensor, *, M: int, N: int, 
          dcode(A.dtype), dcode(C_.dtype), float(alpha), stream_ptr())
 
 
+class _WgradDesc(C.Structure):
+    """omlm_gemm_wgrad_desc (include/omlm.h)"""
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("c_map", C.c_void_p),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("lda", C.c_int), ("ldb", C.c_int), ("ldc", C.c_int)]
+
+
+class WgradGroup:
+    """Collects the weight-gradient contractions dW[M,N] += dY[K,M]^T X[K,N] of a backward pass (bf16 operands, rows = tokens)
+    and issues them as ONE grouped launch (omlm_gemm_wgrad_group).  The operands are kept alive until :meth:`flush`."""
+
+    def __init__(self):
+        self.items = []
+
+    def add(self, dY: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, *, M: int, N: int, K: int, c_map=None):
+        hip.require_gpu(dY, "dY")
+        assert dY.dtype == torch.bfloat16 and X.dtype == torch.bfloat16 and dW.dtype == torch.float32
+        self.items.append((dY, X, dW, c_map, M, N, K, dY.shape[-1], X.shape[-1], dW.shape[-1]))
+
+    def flush(self, splits: int = 0):
+        n = len(self.items)
+        if n == 0:
+            return
+        arr = (_WgradDesc * n)()
+        for d, (dY, X, dW, c_map, M, N, K, lda, ldb, ldc) in zip(arr, self.items):
+            d.A, d.B, d.C, d.c_map = ptr(dY), ptr(X), ptr(dW), ptr(c_map)
+            d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, lda, ldb, ldc
+        call("omlm_gemm_wgrad_group", C.cast(arr, C.c_void_p), n, int(splits), stream_ptr())
+        self.items = []
+
+
 def layernorm_fwd(x, gamma, y, xcast, mean, rstd, eps=1e-5):
     M, D = x.shape
     call("omlm_layernorm_fwd", ptr(x), ptr(gamma), ptr(y), ptr(xcast), ptr(mean), ptr(rstd),

@@ -125,6 +125,47 @@ def test_gemm_row_maps_and_bf16_out(ops, dev):
     assert e < 5e-3             # output rounded to bf16: 2^-9 relative
 
 
+@pytest.mark.parametrize("splits", [0, 1, 3])
+def test_gemm_wgrad_group(ops, dev, splits):
+    """Grouped weight-gradient launch (dW_i += dY_i^T X_i, all problems in one grid) vs fp64, with ragged extents (M = 130,
+    N = 2730: partial tiles, ldc not a multiple of 4), a scattering c_map with dropped rows, accumulation into existing
+    gradients, and forced K-splits (atomics) as well as the full-K form."""
+    g = torch.Generator().manual_seed(11 + splits)
+    K = 1500
+    shapes = [(512, 1024, None), (130, 1024, None), (1024, 2730, None), (704, 256, "map"), (1024, 512, None)]
+    grp = ops.WgradGroup()
+    keep = []
+    for M, N, cm in shapes:
+        ldM, ldN = (M + 7) // 8 * 8, (N + 7) // 8 * 8
+        dY = torch.randn(K, ldM, generator=g).to(dev).bfloat16()
+        X = torch.randn(K, ldN, generator=g).to(dev).bfloat16()
+        rowsC = M
+        c_map = None
+        if cm:
+            rowsC = M - 40
+            perm = torch.randperm(M, generator=g)
+            c_map = torch.full((M,), -1, dtype=torch.int32)
+            c_map[perm[:rowsC]] = torch.arange(rowsC, dtype=torch.int32)          # 40 logical rows are dropped
+            c_map = c_map.to(dev)
+        dW0 = torch.randn(rowsC, N, generator=g).to(dev)
+        dW = dW0.clone()
+        grp.add(dY, X, dW, M=M, N=N, K=K, c_map=c_map)
+        keep.append((dY, X, dW, dW0, c_map, M, N))
+    grp.flush(splits=splits)
+    worst = 0.0
+    for dY, X, dW, dW0, c_map, M, N in keep:
+        prod = dY.double()[:, :M].t() @ X.double()[:, :N]
+        ref = dW0.double().clone()
+        if c_map is None:
+            ref += prod
+        else:
+            sel = c_map.long() >= 0
+            ref[c_map.long()[sel]] += prod[sel]
+        worst = max(worst, relerr(dW, ref))
+    report(f"gemm_wgrad_group[splits={splits}]", relerr=worst)
+    assert worst < 2e-5, worst
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_layernorm_fwd_bwd(ops, dev, dtype):
     M, D = 333, 1024

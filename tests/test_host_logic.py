@@ -292,6 +292,25 @@ def test_decode_args_struct_layout_matches_header(tmp_path):
     assert out[1:] == [getattr(decode.DecodeArgs, f).offset for f in fields]
 
 
+def test_wgrad_desc_layout_matches_header(tmp_path):
+    """ctypes mirror of omlm_gemm_wgrad_desc vs the C header (gcc)."""
+    import ctypes
+    import subprocess
+    from open_musiclm_amd import ops
+    fields = [f[0] for f in ops._WgradDesc._fields_]
+    src = tmp_path / "wl.c"
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(ROOT, "include", "omlm.h")}"', 'int main(void) {',
+             '  printf("%zu\\n", sizeof(omlm_gemm_wgrad_desc));']
+    lines += [f'  printf("%zu\\n", offsetof(omlm_gemm_wgrad_desc, {f}));' for f in fields]
+    lines += ['  return 0; }']
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "wl"
+    subprocess.run(["gcc", "-std=c99", "-o", str(exe), str(src)], check=True)
+    out = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert out[0] == ctypes.sizeof(ops._WgradDesc)
+    assert out[1:] == [getattr(ops._WgradDesc, f).offset for f in fields]
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/scripts"), reason="reference checkout not present (GPU box)")
 @pytest.mark.parametrize("script", ["train_semantic_stage", "train_coarse_stage", "train_fine_stage"])
 def test_reference_training_scripts_import_against_this_package(script):
