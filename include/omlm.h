@@ -86,15 +86,17 @@ int omlm_mqa_attn_bwd(const void* q, const void* k, const void* v, const float* 
  * dconv is accumulated in the reference layout [2F, 3].  rows are b*nseq + t.  Dropout mask = Philox-4x32-10(seed', element
  * index / 8): one 16-bit draw per element, kept iff draw >= p * 65536; seed' = seed + *seed_dev * golden-ratio (seed_dev optional device word: lets a captured HIP graph draw a new mask
  * on every replay).  drop_bits (optional, [M, Fp/8] bytes): the forward stores the keep-mask, 1 bit per element, and the
- * backward reads it instead of regenerating it (null: the backward regenerates the mask from the same (seed, salt) pair). */
+ * backward reads it instead of regenerating it (null: the backward regenerates the mask from the same (seed, salt) pair).
+ * gh (optional, [M, Fp] in the operand dtype): the forward stores the normalised GEGLU output (before gamma and dropout); handed
+ * to the backward, its LayerNorm^T sums and d(gamma) are formed from it without recomputing the conv and the GELU. */
 int omlm_ffmid_fwd(const void* h1, const void* convw, const void* gamma, void* h2, float* mean, float* rstd,
                    int M, int nseq, int F, int Fp, float eps, float p, unsigned long long seed,
-                   const unsigned long long* seed_dev, unsigned char* drop_bits, int dtype, void* stream);
+                   const unsigned long long* seed_dev, unsigned char* drop_bits, void* gh, int dtype, void* stream);
 long long omlm_ffmid_bwd_workspace_bytes(int F, int Fp);
 int omlm_ffmid_bwd(const void* dh2, const void* h1, const void* convw, const void* gamma, const float* mean,
                    const float* rstd, void* du_tmp, void* dh1, float* dgamma, float* dconv, float* workspace,
                    int M, int nseq, int F, int Fp, float p, unsigned long long seed,
-                   const unsigned long long* seed_dev, const unsigned char* drop_bits, int dtype, void* stream);
+                   const unsigned long long* seed_dev, const unsigned char* drop_bits, const void* gh, int dtype, void* stream);
 int omlm_colsum_accumulate(const float* part, float* out, int P, int C, int ldp, void* stream);
 
 /* Embedding gather + start-token interleave + concat (open_musiclm.py:123-145; utils.get_embeds :126-143) and its
@@ -157,6 +159,13 @@ int omlm_sample_topk_gumbel(const float* logits, const float* uniform, long long
 int omlm_sample_topk_gumbel_at(const float* logits, const float* uniform_base, const int* step_dev, long long* out,
                                long long* hist, int B, int V, int ld, int k, float temperature, int forbid_last, void* stream);
 
+/* Sampler + embedding gather of the sampled id, x[b, :] = emb_table[id_b + emb_row_offset] (rows clamped to [0, emb_rows);
+ * open_musiclm.py:123-134): the decode step's first launch folded into the sampler (omlm_decode_step then runs with
+ * emb_table == NULL). */
+int omlm_sample_embed_at(const float* logits, const float* uniform_base, const int* step_dev, long long* out, long long* hist,
+                         int B, int V, int ld, int k, float temperature, int forbid_last,
+                         const float* emb_table, long long emb_row_offset, long long emb_rows, float* x, int D, void* stream);
+
 /* KV-cached AR decode step: ONE new row (index *pos_dev) per sample through all L layers and the logit head of the quantizer
  * that row predicts -- replaces the reference's full re-forward per sampled id (wrapper.generate, open_musiclm.py:301-321;
  * the trunk is strictly causal, so the logits are the same).  State owned by the caller, all fp32:
@@ -179,6 +188,8 @@ typedef struct omlm_decode_args {
     const float* final_gamma; const void* head_W; int V1; int ldV;
     const float* emb_table; long long emb_row_offset; long long emb_rows;
     float* x; float* x1; float* q; float* parts; float* u; float* logits;   /* scratch: parts [B, nsplit, H, 66] */
+    int* advance_pos; int* advance_step;   /* optional DEVICE counters (+= 1) bumped by the step's last kernel: pass pos_dev (and the
+                                            * sampler's step counter) here instead of launching omlm_decode_advance */
 } omlm_decode_args;
 int omlm_decode_step(const omlm_decode_args* args, const long long* ids, void* stream);
 /* *pos_dev += 1, *step_dev += 1 (either may be null): keeps the row / sampler-step counters on the device so that a

@@ -37,6 +37,7 @@ struct omlm_decode_args {
     const float* final_gamma; const void* head_W; int V1; int ldV;
     const float* emb_table; long long emb_row_offset; long long emb_rows;
     float* x; float* x1; float* q; float* parts; float* u; float* logits;
+    int* advance_pos; int* advance_step;
 };
 
 __device__ __forceinline__ float round_if(float v, int on) { return on ? (float)(bf16_t)v : v; }
@@ -485,6 +486,7 @@ struct dec2_args {
     float* q; float* Kc; float* Vc; int Nmax;                                     // DEC2_QKV destinations
     const float* convw; float* hist; float* u; int Fp;                            // DEC2_FFIN
     int B, round_bf16;
+    int* adv_pos; int* adv_step;                                                  // head launch only: counters bumped by its workgroup 0
 };
 
 template <typename TW, int NI, int MODE>
@@ -599,6 +601,10 @@ __global__ __launch_bounds__(DEC_T) void dec2_kernel(dec2_args a) {
                 a.out[(size_t)b * a.ldout + n] = v;
             }
         }
+        if (MODE == DEC2_LNGEMV && blockIdx.x == 0 && threadIdx.x == 0 && a.adv_pos) {      // see dec3_kernel
+            a.adv_pos[0] += 1;
+            if (a.adv_step) a.adv_step[0] += 1;
+        }
     }
 }
 
@@ -702,6 +708,9 @@ __global__ __launch_bounds__(DEC_T) void dec3_kernel(dec2_args a) {
         else a.Vc[(size_t)pos * 64 + (unit - HD - 64)] = round_if(acc, a.round_bf16);
     } else {
         a.out[unit] = acc + resv;
+        // last kernel of a step (the head): move the row index / sampler step on here instead of in a launch of its own.  Nothing in
+        // this kernel reads them, and every later kernel is ordered behind this one on the stream.
+        if (unit == 0 && a.adv_pos) { a.adv_pos[0] += 1; if (a.adv_step) a.adv_step[0] += 1; }
     }
 }
 
@@ -826,6 +835,7 @@ static int decode_step2_t(const omlm_decode_args& a, const long long* ids, hipSt
         dec2_args h = g;
         h.in = a.x; h.ldin = D; h.K = D; h.Kstat = D; h.gamma = a.final_gamma; h.W = a.head_W; h.ldw = D; h.Nout = a.V1;
         h.out = a.logits; h.ldout = a.ldV;
+        h.adv_pos = a.advance_pos; h.adv_step = a.advance_step;
         if (B == 1) dec3_launch<TW, 2, DEC2_LNGEMV>(h, a.V1, st);
         else        dec2_launch<TW, 2, DEC2_LNGEMV>(h, (a.V1 + DEC2_ROWS - 1) / DEC2_ROWS, st);
     }
@@ -882,7 +892,8 @@ static int decode_step_t(const omlm_decode_args& a, const long long* ids, hipStr
 }
 
 // One decode step for the row at index *pos_dev (see include/omlm.h).  ids: [B] int64 sampled in the previous step (used
-// when a->emb_table is set; otherwise a->x already holds the new row's embedding).  Does NOT advance *pos_dev.
+// when a->emb_table is set; otherwise a->x already holds the new row's embedding).  *pos_dev is advanced only through
+// a->advance_pos / a->advance_step (optional device counters bumped by the step's last kernel; pass pos_dev there to move on).
 extern "C" int omlm_decode_step(const omlm_decode_args* a, const long long* ids, void* stream) {
     OMLM_CHECK_ARG(a != nullptr, "null argument block");
     OMLM_CHECK_ARG(a->B >= 1 && a->B <= DEC_BMAX, "decode batch must be 1..8 (use the batched forward beyond that)");
@@ -895,9 +906,11 @@ extern "C" int omlm_decode_step(const omlm_decode_args* a, const long long* ids,
     if (v1 < 0) { const char* e = getenv("OMLM_DECODE_V1"); v1 = (e && e[0] == '1') ? 1 : 0; }
     const bool v2_ok = a->D == 1024 && a->H * 64 <= 1024 && a->Fp <= 4096 && a->Fp % 2 == 0 && (a->H * 64 + 128) % DEC2_ROWS == 0;
     if (!v1 && v2_ok) {
-        if (a->w_dtype == 0) return decode_step2_t<float>(*a, ids, as_stream(stream));
-        return decode_step2_t<bf16_t>(*a, ids, as_stream(stream));
+        const int rc = a->w_dtype == 0 ? decode_step2_t<float>(*a, ids, as_stream(stream)) : decode_step2_t<bf16_t>(*a, ids, as_stream(stream));
+        if (rc == OMLM_OK && a->advance_pos && !a->head_W) return omlm_decode_advance(a->advance_pos, a->advance_step, stream);
+        return rc;
     }
-    if (a->w_dtype == 0) return decode_step_t<float>(*a, ids, as_stream(stream));
-    return decode_step_t<bf16_t>(*a, ids, as_stream(stream));
+    const int rc = a->w_dtype == 0 ? decode_step_t<float>(*a, ids, as_stream(stream)) : decode_step_t<bf16_t>(*a, ids, as_stream(stream));
+    if (rc == OMLM_OK && a->advance_pos) return omlm_decode_advance(a->advance_pos, a->advance_step, stream);    // first-generation kernels: own launch
+    return rc;
 }

@@ -76,7 +76,18 @@ __device__ __forceinline__ float fast_erf(float x) {
     const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
     return copysignf(1.0f - poly * __expf(-ax * ax), x);
 }
+// same, also handing back exp(-x^2) of its argument: for x = u / sqrt(2) that is the exp(-u^2 / 2) of the GELU derivative
+__device__ __forceinline__ float fast_erf_exp(float x, float& ex) {
+    const float ax = fabsf(x);
+    const float t = ff_rcp(1.0f + 0.3275911f * ax);
+    const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+    ex = __expf(-ax * ax);
+    return copysignf(1.0f - poly * ex, x);
+}
 __device__ __forceinline__ float gelu_from_erf(float x, float e) { return 0.5f * x * (1.0f + e); }
+__device__ __forceinline__ float gelu_grad_from_erf_exp(float x, float e, float ex) {
+    return 0.5f * (1.0f + e) + x * 0.3989422804014327f * ex;
+}
 __device__ __forceinline__ float gelu_grad_from_erf(float x, float e) {
     return 0.5f * (1.0f + e) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
@@ -151,6 +162,19 @@ template <typename T> struct Bwd1In {
     }
 };
 
+// what the first backward sweep reads when the forward saved the normalised GEGLU output: dh2, gamma, gh, the keep-mask byte
+template <typename T> struct Bwd1Lite {
+    raw8<T> d, gm, gh;
+    unsigned bits;
+    __device__ __forceinline__ void load(const T* __restrict__ dh2, const T* __restrict__ gamma, const T* __restrict__ ghs,
+                                         const unsigned char* __restrict__ drop_bits, size_t row, int Fp, int ch) {
+        d.load(dh2 + row * Fp + ch);
+        gh.load(ghs + row * Fp + ch);
+        gm.load(gamma + ch);
+        bits = drop_bits ? drop_bits[row * (Fp >> 3) + (ch >> 3)] : 0xFFu;
+    }
+};
+
 // keep-mask * 1/(1-p) for 8 consecutive elements starting at element index e0 (multiple of 8).  ONE Philox-4x32-10 call per
 // 8 elements: each element gets a 16-bit draw (keep iff draw >= p * 65536).  The first version spent a 24-bit draw per
 // element = two calls per chunk, ~140 of the ~560 VALU instructions a row-chunk of the forward costs (350 -> 328 us).
@@ -202,7 +226,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffmid_fwd_kernel(const T* __res
                                                                   float* __restrict__ mean, float* __restrict__ rstd,
                                                                   int M, int nseq, int F, int Fp, float eps, float p,
                                                                   unsigned long long seed, const unsigned long long* __restrict__ seed_dev,
-                                                                  unsigned char* __restrict__ drop_bits) {
+                                                                  unsigned char* __restrict__ drop_bits, T* __restrict__ gh_out) {
     if (seed_dev) seed += seed_dev[0] * 0x9E3779B97F4A7C15ull;      // per-step salt from device memory (graph replays differ)
     extern __shared__ __attribute__((aligned(16))) float ff_lds[];     // [4 waves][Fp]: this wave's g row between the sweeps
     const int lane = threadIdx.x & 63;
@@ -272,16 +296,20 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffmid_fwd_kernel(const T* __res
                         drop_bits[(size_t)row * (Fp >> 3) + (ch >> 3)] = (unsigned char)bits;
                     }
                 }
-                vec8<T> o;
+                vec8<T> o, gh;
                 vec8<T> gm;
                 gm.load(gamma + ch);                               // padded gamma: 0 beyond F
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    float y = (gv[i] - mu) * rs * gm.v[i];
+                    gh.v[i] = ch + i < F ? (gv[i] - mu) * rs : 0.f;
+                    float y = gh.v[i] * gm.v[i];
                     if (p > 0.f) y *= m[i];
                     o.v[i] = y;
                 }
                 o.store(h2 + (size_t)row * Fp + ch);
+                // the normalised GEGLU output, for the backward: its first sweep (the two LayerNorm^T sums and d(gamma)) then needs
+                // neither the conv nor the erf again -- these kernels are VALU-bound with HBM to spare
+                if (gh_out) gh.store(gh_out + (size_t)row * Fp + ch);
             }
         }
     }
@@ -291,14 +319,14 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffmid_fwd_kernel(const T* __res
 // Wave per row, two sweeps over the row's chunks (sums first, outputs second; the second sweep re-reads the three
 // h1 rows and dh2 from L1/L2) so that nothing but the two reduction scalars lives across the sweep boundary.
 // dgamma is accumulated in an LDS array per workgroup (ds_add_f32) and written once as a partial row.
-template <typename T, int MAXC>
+template <typename T, int MAXC, bool GH>
 __global__ __launch_bounds__(FF_THREADS, 2) void ffmid_bwd1_kernel(const T* __restrict__ dh2, const T* __restrict__ h1,
                                                                 const T* __restrict__ convw, const T* __restrict__ gamma,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 T* __restrict__ du, float* __restrict__ part_dgamma,
                                                                 int M, int nseq, int F, int Fp, float p, unsigned long long seed,
                                                                 const unsigned long long* __restrict__ seed_dev,
-                                                                const unsigned char* __restrict__ drop_bits) {
+                                                                const unsigned char* __restrict__ drop_bits, const T* __restrict__ ghs) {
     if (seed_dev) seed += seed_dev[0] * 0x9E3779B97F4A7C15ull;
     // [4 waves][Fp]: each wave's PRIVATE d(gamma) partial, updated with plain vector read-add-write (a lane always owns
     // the same channels, so there is nothing to arbitrate).  The first version used one shared array with ds_add_f32 per
@@ -318,6 +346,42 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffmid_bwd1_kernel(const T* __re
         float s1 = 0.f, s2 = 0.f;
         constexpr bool PF = sizeof(T) == 2;                 // operand prefetch one chunk ahead (register budget: bf16 only)
         Bwd1In<T> cur, nxt;
+        if (GH) {
+            // sweep 1 from the saved normalised output gh: s1 = sum dy gamma, s2 = sum dy gamma gh, d(gamma) += dy gh
+            Bwd1Lite<T> lc, ln;
+            if (lane * 8 < Fp) lc.load(dh2, gamma, ghs, drop_bits, (size_t)row, Fp, lane * 8);
+#pragma unroll 1
+            for (int k = 0; k < MAXC; ++k) {
+                const int ch = (lane + 64 * k) * 8;
+                if (k + 1 < MAXC && ch + 512 < Fp) ln.load(dh2, gamma, ghs, drop_bits, (size_t)row, Fp, ch + 512);
+                if (ch < Fp) {
+                    float dv[8], gmv[8], ghv[8], m[8];
+                    lc.d.unpack(dv);
+                    lc.gm.unpack(gmv);
+                    lc.gh.unpack(ghv);
+                    if (p > 0.f) {
+                        if (drop_bits) dropout8_from_bits(lc.bits, p, m);
+                        else dropout8(seed, (unsigned long long)row * Fp + ch, p, m);
+                    }
+                    float dgv[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {               // pad columns: gamma == 0 and gh == 0 there
+                        float dyv = dv[i];
+                        if (p > 0.f) dyv *= m[i];
+                        dgv[i] = dyv * ghv[i];
+                        const float gy = dyv * gmv[i];
+                        s1 += gy;
+                        s2 += gy * ghv[i];
+                    }
+                    float4 a = ((float4*)(dgw + ch))[0], b = ((float4*)(dgw + ch))[1];
+                    a.x += dgv[0]; a.y += dgv[1]; a.z += dgv[2]; a.w += dgv[3];
+                    b.x += dgv[4]; b.y += dgv[5]; b.z += dgv[6]; b.w += dgv[7];
+                    ((float4*)(dgw + ch))[0] = a;
+                    ((float4*)(dgw + ch))[1] = b;
+                }
+                lc = ln;
+            }
+        } else {
         if (PF && lane * 8 < Fp) cur.load(h1, convw, dh2, gamma, drop_bits, (size_t)row, t, ld, Fp, lane * 8);
 #pragma unroll 1
         for (int k = 0; k < MAXC; ++k) {
@@ -357,6 +421,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffmid_bwd1_kernel(const T* __re
             }
             if (PF) cur = nxt;
         }
+        }
         const float m1 = wave_sum(s1) / (float)F;
         const float m2 = wave_sum(s2) / (float)F;
         if (PF && lane * 8 < Fp) cur.load(h1, convw, dh2, gamma, drop_bits, (size_t)row, t, ld, Fp, lane * 8);
@@ -376,9 +441,9 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffmid_bwd1_kernel(const T* __re
                     if (drop_bits) dropout8_from_bits(cur.bits, p, m);
                     else dropout8(seed, (unsigned long long)row * Fp + ch, p, m);
                 }
-                float ev[8];
+                float ev[8], ex[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) ev[i] = fast_erf(ug[i] * 0.70710678118654752f);
+                for (int i = 0; i < 8; ++i) ev[i] = fast_erf_exp(ug[i] * 0.70710678118654752f, ex[i]);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     float dx = 0.f, dgt = 0.f;
@@ -389,7 +454,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffmid_bwd1_kernel(const T* __re
                         if (p > 0.f) dyv *= m[i];
                         const float dg = rs * (dyv * gm.v[i] - m1 - gh * m2);
                         dx = dg * ge;
-                        dgt = dg * ux[i] * gelu_grad_from_erf(ug[i], ev[i]);
+                        dgt = dg * ux[i] * gelu_grad_from_erf_exp(ug[i], ev[i], ex[i]);
                     }
                     ox.v[i] = dx;
                     og.v[i] = dgt;
@@ -497,7 +562,7 @@ extern "C" long long omlm_ffmid_bwd_workspace_bytes(int F, int Fp) {
 
 extern "C" int omlm_ffmid_fwd(const void* h1, const void* convw, const void* gamma, void* h2, float* mean, float* rstd,
                               int M, int nseq, int F, int Fp, float eps, float p, unsigned long long seed,
-                              const unsigned long long* seed_dev, unsigned char* drop_bits, int dtype, void* stream) {
+                              const unsigned long long* seed_dev, unsigned char* drop_bits, void* gh, int dtype, void* stream) {
     if (M <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(h1 && convw && gamma && h2 && mean && rstd, "null pointer");
     OMLM_CHECK_ARG(Fp % 8 == 0 && Fp >= F && Fp <= 8192 && (size_t)5 * Fp * sizeof(float) <= 160 * 1024, "Fp must be F rounded up to 8 and <= 8192");
@@ -513,7 +578,7 @@ extern "C" int omlm_ffmid_fwd(const void* h1, const void* convw, const void* gam
         (void)hipFuncSetAttribute((const void*)ffmid_fwd_kernel<bf16_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)ffmid_fwd_kernel<bf16_t, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-#define FF_FWD(T_, MC_) hipLaunchKernelGGL((ffmid_fwd_kernel<T_, MC_>), grid, block, lds_fwd, st, (const T_*)h1, (const T_*)convw, (const T_*)gamma, (T_*)h2, mean, rstd, M, nseq, F, Fp, eps, p, seed, seed_dev, drop_bits)
+#define FF_FWD(T_, MC_) hipLaunchKernelGGL((ffmid_fwd_kernel<T_, MC_>), grid, block, lds_fwd, st, (const T_*)h1, (const T_*)convw, (const T_*)gamma, (T_*)h2, mean, rstd, M, nseq, F, Fp, eps, p, seed, seed_dev, drop_bits, (T_*)gh)
 #define FF_FWD_DISPATCH(T_) do { const int mc = (Fp / 8 + 63) / 64; \
         if (mc <= 2) FF_FWD(T_, 2); else if (mc <= 6) FF_FWD(T_, 6); else if (mc <= 8) FF_FWD(T_, 8); else FF_FWD(T_, 16); } while (0)
     if (dtype == 0) FF_FWD_DISPATCH(float); else FF_FWD_DISPATCH(bf16_t);
@@ -525,7 +590,8 @@ extern "C" int omlm_ffmid_fwd(const void* h1, const void* convw, const void* gam
 extern "C" int omlm_ffmid_bwd(const void* dh2, const void* h1, const void* convw, const void* gamma, const float* mean,
                               const float* rstd, void* du_tmp, void* dh1, float* dgamma, float* dconv, float* workspace,
                               int M, int nseq, int F, int Fp, float p, unsigned long long seed,
-                              const unsigned long long* seed_dev, const unsigned char* drop_bits, int dtype, void* stream) {
+                              const unsigned long long* seed_dev, const unsigned char* drop_bits, const void* gh, int dtype,
+                              void* stream) {
     if (M <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(dh2 && h1 && convw && gamma && mean && rstd && du_tmp && dh1 && workspace, "null pointer");
     OMLM_CHECK_ARG(Fp % 8 == 0 && Fp >= F && Fp <= 8192 && (size_t)5 * Fp * sizeof(float) <= 160 * 1024, "Fp must be F rounded up to 8 and <= 8192");
@@ -538,15 +604,14 @@ extern "C" int omlm_ffmid_bwd(const void* dh2, const void* h1, const void* convw
     const int strips = M < FF_BWD2_STRIPS ? M : FF_BWD2_STRIPS;
     dim3 g2((2 * Fp / 8 + FF_THREADS - 1) / FF_THREADS, strips);
     const size_t lds1 = (size_t)4 * Fp * sizeof(float);
+#define FF_B1_ATTR(T_, MC_) do { (void)hipFuncSetAttribute((const void*)ffmid_bwd1_kernel<T_, MC_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        (void)hipFuncSetAttribute((const void*)ffmid_bwd1_kernel<T_, MC_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); } while (0)
     if (lds1 > 48 * 1024) {
-        (void)hipFuncSetAttribute((const void*)ffmid_bwd1_kernel<float, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)ffmid_bwd1_kernel<float, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)ffmid_bwd1_kernel<float, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)ffmid_bwd1_kernel<bf16_t, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)ffmid_bwd1_kernel<bf16_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)ffmid_bwd1_kernel<bf16_t, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        FF_B1_ATTR(float, 6); FF_B1_ATTR(float, 8); FF_B1_ATTR(float, 16);
+        FF_B1_ATTR(bf16_t, 6); FF_B1_ATTR(bf16_t, 8); FF_B1_ATTR(bf16_t, 16);
     }
-#define FF_B1(T_, MC_) hipLaunchKernelGGL((ffmid_bwd1_kernel<T_, MC_>), dim3(b1), dim3(FF_THREADS), lds1, st, (const T_*)dh2, (const T_*)h1, (const T_*)convw, (const T_*)gamma, mean, rstd, (T_*)du_tmp, part_g, M, nseq, F, Fp, p, seed, seed_dev, drop_bits)
+#define FF_B1G(T_, MC_, GH_) hipLaunchKernelGGL((ffmid_bwd1_kernel<T_, MC_, GH_>), dim3(b1), dim3(FF_THREADS), lds1, st, (const T_*)dh2, (const T_*)h1, (const T_*)convw, (const T_*)gamma, mean, rstd, (T_*)du_tmp, part_g, M, nseq, F, Fp, p, seed, seed_dev, drop_bits, (const T_*)gh)
+#define FF_B1(T_, MC_) do { if (gh) FF_B1G(T_, MC_, true); else FF_B1G(T_, MC_, false); } while (0)
 #define FF_B1_DISPATCH(T_) do { const int mc = (Fp / 8 + 63) / 64; \
         if (mc <= 2) FF_B1(T_, 2); else if (mc <= 6) FF_B1(T_, 6); else if (mc <= 8) FF_B1(T_, 8); else FF_B1(T_, 16); } while (0)
     if (dtype == 0) {

@@ -275,75 +275,86 @@ extern "C" int omlm_nearest_centroid(const float* x, const float* centroids_T, i
 // like torch.topk + scatter (which keeps exactly k entries: the lowest indices among equals).
 __device__ __forceinline__ unsigned f_ord(float f) { unsigned u = f2u(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 
-__global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ logits, const float* __restrict__ uniform,
-                                                     long long* __restrict__ out, int V, int ld, int k, float temperature,
-                                                     int forbid_last, const int* __restrict__ step_dev, long long* __restrict__ hist) {
+// One WAVE per row: the row's logits sit in registers (V <= 2048 -> <= 32 per lane, element c = lane + 64 j), every count of the
+// radix descent is a ballot + popcount on the scalar unit -- no LDS, no barrier.  (The first version used 256 threads, an LDS
+// image and two barriers per bit: ~25 us of the ~200 us a sampled id costs at B = 1.)  Optionally gathers the embedding row of the
+// sampled id (open_musiclm.py:123-134: id + quantizer offset) into x, so the decode step needs no separate gather launch.
+#define SAMPLE_NV 32
+__global__ __launch_bounds__(64) void sample_kernel(const float* __restrict__ logits, const float* __restrict__ uniform,
+                                                    long long* __restrict__ out, int V, int ld, int k, float temperature,
+                                                    int forbid_last, const int* __restrict__ step_dev, long long* __restrict__ hist,
+                                                    const float* __restrict__ emb_table, long long emb_row_offset, long long emb_rows,
+                                                    float* __restrict__ x, int D) {
     if (step_dev) {          // graph-replayable form: this step's uniforms / history slot are selected by a DEVICE counter
         const long long sidx = step_dev[0];
         uniform += sidx * (long long)gridDim.x * V;
         if (hist) hist += sidx * gridDim.x;
     }
-    __shared__ unsigned keys[2048];
-    __shared__ int cnt[4];
-    __shared__ float bv[4];
-    __shared__ int bi[4];
-    const int row = blockIdx.x;
+    const int row = blockIdx.x, lane = threadIdx.x;
     const float* lr = logits + (size_t)row * ld;
-    for (int c = threadIdx.x; c < V; c += 256) {
-        float v = lr[c];
+    const float* ur = uniform + (size_t)row * V;
+    unsigned keys[SAMPLE_NV];
+    float lv[SAMPLE_NV];
+#pragma unroll
+    for (int j = 0; j < SAMPLE_NV; ++j) {
+        const int c = lane + 64 * j;
+        float v = c < V ? lr[c] : -INFINITY;
         if (forbid_last && c == V - 1) v = -INFINITY;
-        keys[c] = f_ord(v);
+        lv[j] = v;
+        keys[j] = c < V ? f_ord(v) : 0u;               // 0 sorts below every real key (f_ord(-inf) = 0x007fffff)
     }
-    __syncthreads();
+    const int nv = (V + 63) >> 6;                      // live register slots (uniform)
     // largest threshold t such that count(keys >= t) >= k
     unsigned t = 0;
     for (int bit = 31; bit >= 0; --bit) {
         const unsigned cand = t | (1u << bit);
-        int c0 = 0;
-        for (int c = threadIdx.x; c < V; c += 256) c0 += keys[c] >= cand;
-        c0 = (int)wave_sum((float)c0);
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = c0;
-        __syncthreads();
-        if (cnt[0] + cnt[1] + cnt[2] + cnt[3] >= k) t = cand;
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < SAMPLE_NV; ++j)
+            if (j < nv) cnt += __popcll(__ballot(keys[j] >= cand));
+        if (cnt >= k) t = cand;
     }
     // strictly-greater entries are all kept; of the entries equal to t keep the first (k - n_greater) by index
     int ng = 0;
-    for (int c = threadIdx.x; c < V; c += 256) ng += keys[c] > t;
-    ng = (int)wave_sum((float)ng);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = ng;
-    __syncthreads();
-    const int n_equal_keep = k - (cnt[0] + cnt[1] + cnt[2] + cnt[3]);
+#pragma unroll
+    for (int j = 0; j < SAMPLE_NV; ++j)
+        if (j < nv) ng += __popcll(__ballot(keys[j] > t));
+    const int n_equal_keep = k - ng;
     float best = -INFINITY;
     int besti = 0x7fffffff;
-    // sequential scan by one wave keeps the index order of equal entries cheaply (V <= 2048)
-    if (threadIdx.x < 64) {
-        int seen_eq = 0;
-        for (int base = 0; base < V; base += 64) {
-            const int c = base + threadIdx.x;
+    int seen_eq = 0;
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int j = 0; j < SAMPLE_NV; ++j) {
+        if (j < nv) {                                   // uniform
+            const int c = lane + 64 * j;
             const bool in = c < V;
-            const unsigned kk = in ? keys[c] : 0u;
-            const bool eq = in && kk == t;
+            const bool eq = in && keys[j] == t;
             const unsigned long long eqmask = __ballot(eq);
-            const int rank = seen_eq + __popcll(eqmask & ((1ull << threadIdx.x) - 1ull));
-            const bool keep = in && (kk > t || (eq && rank < n_equal_keep));
+            const int rank = seen_eq + __popcll(eqmask & below);
+            const bool keep = in && (keys[j] > t || (eq && rank < n_equal_keep));
             seen_eq += __popcll(eqmask);
             if (keep) {
-                float v = lr[c];
-                const float u = uniform[(size_t)row * V + c];
+                const float u = ur[c];
                 const float gum = -logf(-logf(u + 1e-20f) + 1e-20f);
-                v = v / temperature + gum;
+                const float v = lv[j] / temperature + gum;
                 if (v > best) { best = v; besti = c; }
             }
         }
+    }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(best, o, 64);
-            const int oi = __shfl_xor(besti, o, 64);
-            if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
-        }
-        if (threadIdx.x == 0) { out[row] = besti; if (hist) hist[row] = besti; }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(besti, o, 64);
+        if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+    }
+    if (lane == 0) { out[row] = besti; if (hist) hist[row] = besti; }
+    if (emb_table) {
+        long long r = (long long)besti + emb_row_offset;
+        r = r < 0 ? 0 : (r >= emb_rows ? emb_rows - 1 : r);
+        const float4* src = (const float4*)(emb_table + r * D);
+        float4* dst = (float4*)(x + (size_t)row * D);
+        for (int i = lane; i < D / 4; i += 64) dst[i] = src[i];
     }
 }
 
@@ -351,8 +362,8 @@ extern "C" int omlm_sample_topk_gumbel(const float* logits, const float* uniform
                                        int k, float temperature, int forbid_last, void* stream) {
     if (B <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(logits && uniform && out && V > 0 && V <= 2048 && k >= 1 && k <= V && temperature > 0.f, "sampler arguments");
-    hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(256), 0, as_stream(stream), logits, uniform, out, V, ld, k, temperature, forbid_last,
-                       (const int*)nullptr, (long long*)nullptr);
+    hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(64), 0, as_stream(stream), logits, uniform, out, V, ld, k, temperature, forbid_last,
+                       (const int*)nullptr, (long long*)nullptr, (const float*)nullptr, 0ll, 0ll, (float*)nullptr, 0);
     return omlm_post_launch("omlm_sample_topk_gumbel");
 }
 
@@ -362,9 +373,23 @@ extern "C" int omlm_sample_topk_gumbel_at(const float* logits, const float* unif
                                           void* stream) {
     if (B <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(logits && uniform_base && step_dev && out && V > 0 && V <= 2048 && k >= 1 && k <= V && temperature > 0.f, "sampler arguments");
-    hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(256), 0, as_stream(stream), logits, uniform_base, out, V, ld, k, temperature,
-                       forbid_last, step_dev, hist);
+    hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(64), 0, as_stream(stream), logits, uniform_base, out, V, ld, k, temperature,
+                       forbid_last, step_dev, hist, (const float*)nullptr, 0ll, 0ll, (float*)nullptr, 0);
     return omlm_post_launch("omlm_sample_topk_gumbel_at");
+}
+
+// Sampler + embedding gather of the sampled id (x[b, :] = emb_table[id_b + emb_row_offset], rows clamped to [0, emb_rows)):
+// the first launch of the next decode step folded into the sampler (then omlm_decode_step runs with emb_table == NULL).
+extern "C" int omlm_sample_embed_at(const float* logits, const float* uniform_base, const int* step_dev, long long* out,
+                                    long long* hist, int B, int V, int ld, int k, float temperature, int forbid_last,
+                                    const float* emb_table, long long emb_row_offset, long long emb_rows, float* x, int D,
+                                    void* stream) {
+    if (B <= 0) return OMLM_OK;
+    OMLM_CHECK_ARG(logits && uniform_base && step_dev && out && V > 0 && V <= 2048 && k >= 1 && k <= V && temperature > 0.f, "sampler arguments");
+    OMLM_CHECK_ARG(emb_table && x && D > 0 && D % 4 == 0 && emb_rows > 0, "embedding arguments");
+    hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(64), 0, as_stream(stream), logits, uniform_base, out, V, ld, k, temperature,
+                       forbid_last, step_dev, hist, emb_table, emb_row_offset, emb_rows, x, D);
+    return omlm_post_launch("omlm_sample_embed_at");
 }
 
 // ---------------------------------------------------------------------------------------------------------

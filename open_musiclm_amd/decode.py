@@ -35,7 +35,7 @@ class DecodeArgs(C.Structure):
                 [("bias_table", C.c_void_p), ("bias_ld", C.c_int),
                  ("final_gamma", C.c_void_p), ("head_W", C.c_void_p), ("V1", C.c_int), ("ldV", C.c_int),
                  ("emb_table", C.c_void_p), ("emb_row_offset", C.c_longlong), ("emb_rows", C.c_longlong)] +
-                [(n, C.c_void_p) for n in ("x", "x1", "q", "parts", "u", "logits")])
+                [(n, C.c_void_p) for n in ("x", "x1", "q", "parts", "u", "logits", "advance_pos", "advance_step")])
 
 
 def supports(model, batch: int) -> bool:
@@ -147,8 +147,9 @@ class CachedDecoder:
         a.head_W = head.data_ptr()
         ids = new_ids.contiguous()
         assert ids.dtype == torch.int64 and ids.numel() == self.B
+        a.emb_table = self.emb.data_ptr()
+        a.advance_pos, a.advance_step = self.pos_dev.data_ptr(), None        # the head kernel moves the row index on
         call("omlm_decode_step", C.addressof(a), ptr(ids), stream_ptr())
-        call("omlm_decode_advance", self.pos_dev.data_ptr(), None, stream_ptr())
         self.rows += 1
         return self.logits
 
@@ -180,13 +181,19 @@ class SamplingLoop:
         """Sample id number k (global index in the predicted sequence) from dec.logits, then compute its row."""
         dec, a = self.dec, self.dec.args
         phase = k % dec.Q
-        call("omlm_sample_topk_gumbel_at", ptr(dec.logits), ptr(self.U), ptr(self.step_dev), ptr(self.cur), ptr(self.hist),
-             dec.B, dec.V1, dec.ldV, self.topk, self.temperature, int(self.forbid[phase]), stream_ptr())
-        if with_decode:
-            a.emb_row_offset = dec.codebook * phase if dec.Q > 1 else 0
-            a.head_W = dec.pw.heads[-1][(k + 1) % dec.Q].data_ptr()
-            call("omlm_decode_step", C.addressof(a), ptr(self.cur), stream_ptr())
-            call("omlm_decode_advance", dec.pos_dev.data_ptr(), self.step_dev.data_ptr(), stream_ptr())
+        if not with_decode:
+            call("omlm_sample_topk_gumbel_at", ptr(dec.logits), ptr(self.U), ptr(self.step_dev), ptr(self.cur), ptr(self.hist),
+                 dec.B, dec.V1, dec.ldV, self.topk, self.temperature, int(self.forbid[phase]), stream_ptr())
+            return
+        # 32 launches per id: the sampler also gathers the embedding row of the id it picked (the step's first launch), and the
+        # head kernel (the step's last) moves the row index and the sampler's step counter on
+        call("omlm_sample_embed_at", ptr(dec.logits), ptr(self.U), ptr(self.step_dev), ptr(self.cur), ptr(self.hist),
+             dec.B, dec.V1, dec.ldV, self.topk, self.temperature, int(self.forbid[phase]),
+             dec.emb.data_ptr(), dec.codebook * phase if dec.Q > 1 else 0, dec.emb.shape[0], ptr(dec.x), dec.D, stream_ptr())
+        a.emb_table = None
+        a.head_W = dec.pw.heads[-1][(k + 1) % dec.Q].data_ptr()
+        a.advance_pos, a.advance_step = dec.pos_dev.data_ptr(), self.step_dev.data_ptr()
+        call("omlm_decode_step", C.addressof(a), ptr(self.cur), stream_ptr())
 
     def run(self) -> torch.Tensor:
         """Returns the [n_new, B] sampled ids."""

@@ -27,6 +27,7 @@ DIM_HEAD = 64
 
 _PRECISIONS = {"bf16": torch.bfloat16, "bf16x3": torch.float32}
 _WT = os.environ.get("OMLM_WT", "0") == "1"
+_FF_SAVE_GH = os.environ.get("OMLM_FF_SAVE_GH", "1") == "1"        # forward keeps the normalised GEGLU output for the backward (bf16 mode)
 _WGRAD_GROUP = os.environ.get("OMLM_WGRAD_GROUP", "1") == "1"      # grouped weight-gradient GEMMs (0: one split-K GEMM per weight)
 
 
@@ -269,7 +270,7 @@ def relpos_backward(tr, n: int, saved, dtable: torch.Tensor):
 # ------------------------------------------------------------------------------------------------------
 class LayerSaved:
     __slots__ = ("x", "m1", "r1", "xn", "xc", "q_raw", "kv_raw", "q", "k", "v", "o", "lse", "abias",
-                 "x1", "m2", "r2", "xn2", "h1", "h2", "m3", "r3", "seed", "p", "drop_bits")
+                 "x1", "m2", "r2", "xn2", "h1", "h2", "m3", "r3", "seed", "p", "drop_bits", "gh")
 
 
 def dropout_salt(tr, dev) -> torch.Tensor:
@@ -333,8 +334,10 @@ def trunk_forward(tr, pw: PreparedWeights, x: torch.Tensor, keymask: Optional[to
         p = float(ff.dropout_p) if training else 0.0
         seed = seeds[li] if (p > 0 and seeds is not None) else 0
         drop_bits = torch.empty(M, Fp // 8, dtype=torch.uint8, device=dev) if (p > 0 and save) else None
+        # bf16 mode: the normalised GEGLU output is saved for the backward's first sweep (its kernels are VALU-bound, not HBM-bound)
+        gh = torch.empty(M, Fp, dtype=T, device=dev) if (save and T == torch.bfloat16 and _FF_SAVE_GH) else None
         ops.ffmid_fwd(h1, w["convw"], w["gamma_mid"], h2, m3, r3, N, F, Fp, p, seed, seed_dev=salt if p > 0 else None,
-                      drop_bits=drop_bits)
+                      drop_bits=drop_bits, gh=gh)
         x2 = torch.empty(M, D, device=dev)
         ops.gemm(h2, w["W2p"], x2, M=M, N=D, K=Fp, Cin=x1)
         if save:
@@ -342,6 +345,7 @@ def trunk_forward(tr, pw: PreparedWeights, x: torch.Tensor, keymask: Optional[to
             sv.q_raw, sv.kv_raw, sv.q, sv.k, sv.v, sv.o, sv.lse, sv.abias = q_raw, kv_raw, q, k, v, o, lse, abias
             sv.x1, sv.m2, sv.r2, sv.xn2, sv.h1, sv.h2, sv.m3, sv.r3, sv.seed, sv.p = x1, m2, r2, xn2, h1, h2, m3, r3, seed, p
             sv.drop_bits = drop_bits
+            sv.gh = gh
             saved_layers.append(sv)
         x = x2
     mf = torch.empty(M, device=dev); rf = torch.empty(M, device=dev)
@@ -396,7 +400,7 @@ def trunk_backward(tr, pw: PreparedWeights, saved, dy: torch.Tensor, B: int, N: 
         gconv = grad_of(ff.conv_param()).view(-1) if ff.conv_param() is not None else None
         ops.ffmid_bwd(dh2, sv.h1, w["convw"], w["gamma_mid"], sv.m3, sv.r3, du, dh1,
                       grad_of(ff.norm_mid.gamma), gconv, ws, N, F, Fp, sv.p, sv.seed,
-                      seed_dev=saved["salt"] if sv.p > 0 else None, drop_bits=sv.drop_bits)
+                      seed_dev=saved["salt"] if sv.p > 0 else None, drop_bits=sv.drop_bits, gh=sv.gh)
         del du, dh2
         dxn2 = torch.empty(M, D, device=dev)
         if "W1pT" in w: ops.gemm(dh1, w["W1pT"], dxn2, M=M, N=D, K=2 * Fp)

@@ -35,9 +35,9 @@ SIGNATURES = {
     "omlm_attn_bias_prepare": [vp, vp, i32, i32, i32, vp, vp, f32, f32, vp],
     "omlm_mqa_attn_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, vp],
     "omlm_mqa_attn_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, vp],
-    "omlm_ffmid_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, u64, vp, vp, i32, vp],
+    "omlm_ffmid_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, u64, vp, vp, vp, i32, vp],
     "omlm_ffmid_bwd_workspace_bytes": [i32, i32],
-    "omlm_ffmid_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp, vp, i32, vp],
+    "omlm_ffmid_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp, vp, vp, i32, vp],
     "omlm_colsum_accumulate": [vp, vp, i32, i32, i32, vp],
     "omlm_embed_gather_fwd": [vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, vp],
     "omlm_embed_gather_bwd": [vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, f32, vp],
@@ -48,6 +48,7 @@ SIGNATURES = {
     "omlm_cast_pad": [vp, vp, i64, i32, i32, i32, i32, vp],
     "omlm_transpose_cast": [vp, vp, i32, i32, i32, i32, i32, vp],
     "omlm_sample_topk_gumbel_at": [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
+    "omlm_sample_embed_at": [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, i64, i64, vp, i32, vp],
     "omlm_decode_step": [vp, vp, vp],
     "omlm_decode_advance": [vp, vp, vp],
     "omlm_relpos_first_fwd": [vp, vp, vp, vp, i32, i32, vp],

@@ -169,12 +169,13 @@ def pad_vector(v: torch.Tensor, n: int) -> torch.Tensor:
     return out
 
 
-def ffmid_fwd(h1, convw, gamma, h2, mean, rstd, nseq, F, Fp, p, seed, eps=1e-5, seed_dev=None, drop_bits=None):
+def ffmid_fwd(h1, convw, gamma, h2, mean, rstd, nseq, F, Fp, p, seed, eps=1e-5, seed_dev=None, drop_bits=None, gh=None):
     """convw: packed taps [3, 2*Fp] (pack_conv_taps); gamma: padded [Fp] (pad_vector)."""
     assert convw.shape == (3, 2 * Fp) and gamma.numel() == Fp
     assert convw.dtype == h1.dtype and gamma.dtype == h1.dtype, "taps / gamma travel in the operand dtype of h1"
     call("omlm_ffmid_fwd", ptr(h1), ptr(convw), ptr(gamma), ptr(h2), ptr(mean), ptr(rstd),
-         h1.shape[0], nseq, F, Fp, float(eps), float(p), int(seed), ptr(seed_dev), ptr(drop_bits), dcode(h1.dtype), stream_ptr())
+         h1.shape[0], nseq, F, Fp, float(eps), float(p), int(seed), ptr(seed_dev), ptr(drop_bits), ptr(gh), dcode(h1.dtype),
+         stream_ptr())
 
 
 def ffmid_bwd_workspace_floats(F, Fp) -> int:
@@ -182,12 +183,12 @@ def ffmid_bwd_workspace_floats(F, Fp) -> int:
 
 
 def ffmid_bwd(dh2, h1, convw, gamma, mean, rstd, du_tmp, dh1, dgamma, dconv, workspace, nseq, F, Fp, p, seed, seed_dev=None,
-              drop_bits=None):
+              drop_bits=None, gh=None):
     assert convw.shape == (3, 2 * Fp) and gamma.numel() == Fp
     assert convw.dtype == h1.dtype and gamma.dtype == h1.dtype, "taps / gamma travel in the operand dtype of h1"
     call("omlm_ffmid_bwd", ptr(dh2), ptr(h1), ptr(convw), ptr(gamma), ptr(mean), ptr(rstd), ptr(du_tmp), ptr(dh1),
          ptr(dgamma), ptr(dconv), ptr(workspace), h1.shape[0], nseq, F, Fp, float(p), int(seed), ptr(seed_dev), ptr(drop_bits),
-         dcode(h1.dtype), stream_ptr())
+         ptr(gh), dcode(h1.dtype), stream_ptr())
 
 
 def _ptr_array(tensors: Sequence[Optional[torch.Tensor]]):

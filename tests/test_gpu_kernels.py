@@ -312,8 +312,10 @@ def ffmid_reference(h1, convw, gamma, F, Fp, nseq, drop=None):
     return y.reshape(M, F)
 
 
-@pytest.mark.parametrize("dtype,F", [(torch.float32, 341), (torch.bfloat16, 341), (torch.float32, 2730)])
-def test_ffmid_fwd_bwd(ops, dev, dtype, F):
+@pytest.mark.parametrize("dtype,F,save_gh", [(torch.float32, 341, False), (torch.bfloat16, 341, False), (torch.float32, 2730, False),
+                                             (torch.bfloat16, 341, True), (torch.bfloat16, 2730, True), (torch.float32, 341, True)])
+def test_ffmid_fwd_bwd(ops, dev, dtype, F, save_gh):
+    """save_gh: the forward also stores the normalised GEGLU output and the backward's first sweep runs from it."""
     nseq, Bn = 19, 3
     M = nseq * Bn
     Fp = (F + 7) // 8 * 8
@@ -328,7 +330,8 @@ def test_ffmid_fwd_bwd(ops, dev, dtype, F):
     h2 = torch.empty(M, Fp, device=dev, dtype=dtype)
     mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
     taps, gpad = ops.pack_conv_taps(convw, F, Fp).to(dtype), ops.pad_vector(gamma, Fp).to(dtype)
-    ops.ffmid_fwd(h1d, taps, gpad, h2, mean, rstd, nseq, F, Fp, 0.0, 0)
+    gh = torch.full((M, Fp), float("nan"), device=dev, dtype=dtype) if save_gh else None
+    ops.ffmid_fwd(h1d, taps, gpad, h2, mean, rstd, nseq, F, Fp, 0.0, 0, gh=gh)
     h1r = h1d.double().requires_grad_(True)
     cr, gr = convw.double().requires_grad_(True), gamma.double().requires_grad_(True)
     ref = ffmid_reference(h1r, cr, gr, F, Fp, nseq)
@@ -343,11 +346,13 @@ def test_ffmid_fwd_bwd(ops, dev, dtype, F):
     dh1 = torch.empty(M, 2 * Fp, device=dev, dtype=dtype)
     dgamma, dconv = torch.zeros(F, device=dev), torch.zeros(2 * F * 3, device=dev)
     ws = torch.empty(ops.ffmid_bwd_workspace_floats(F, Fp), device=dev)
-    ops.ffmid_bwd(dh2d, h1d, taps, gpad, mean, rstd, du, dh1, dgamma, dconv, ws, nseq, F, Fp, 0.0, 0)
+    ops.ffmid_bwd(dh2d, h1d, taps, gpad, mean, rstd, du, dh1, dgamma, dconv, ws, nseq, F, Fp, 0.0, 0, gh=gh)
+    if save_gh:
+        assert bool((gh[:, F:] == 0).all()) and not torch.isnan(gh.float()).any()
     gref = h1r.grad
     e_x = max(relerr(dh1[:, :F], gref[:, :F]), relerr(dh1[:, Fp:Fp + F], gref[:, Fp:Fp + F]))
     e_g, e_c = relerr(dgamma, gr.grad), relerr(dconv.view(2 * F, 3), cr.grad)
-    report(f"ffmid[{dtype},{F}]", fwd=e_f, dh1=e_x, dgamma=e_g, dconv=e_c, pad_zero=pad_zero)
+    report(f"ffmid[{dtype},{F},gh={save_gh}]", fwd=e_f, dh1=e_x, dgamma=e_g, dconv=e_c, pad_zero=pad_zero)
     assert pad_zero and e_f < tol and e_x < (2e-5 if dtype == torch.float32 else 2e-2)
     assert e_g < (1e-4 if dtype == torch.float32 else 2e-2) and e_c < (1e-4 if dtype == torch.float32 else 2e-2)
 
