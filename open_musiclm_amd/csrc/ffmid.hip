@@ -12,6 +12,7 @@
 // HBM-bound: forward reads h1 once (the two halo rows come from L2) and writes h2; nothing but the
 // per-row LN statistics is saved -- the backward recomputes u and g from h1.
 #include "common.h"
+#include <stdlib.h>
 
 #define FF_THREADS 256
 #define FF_MAXC_LIMIT 16   // 8-channel chunks per lane (wave-per-row kernels) -> Fp <= 8192
@@ -556,6 +557,28 @@ extern "C" int omlm_colsum_accumulate(const float* part, float* out, int P, int 
 #define FF_BWD1_BLOCKS 1024
 #define FF_BWD2_STRIPS 512
 
+// second-generation kernels for bf16 operands (ffmid2.hip: column strips, fused backward)
+bool ffmid2_supported(int Fp);
+int ffmid2_fwd_launch(const void* h1, const void* convw, const void* gamma, void* h2, float* mean, float* rstd, int M, int nseq,
+                      int F, int Fp, float eps, float p, unsigned long long seed, const unsigned long long* seed_dev,
+                      unsigned char* drop_bits, void* gh, hipStream_t st);
+int ffmid2_bwd_launch(const void* dh2, const void* h1, const void* convw, const void* gamma, const float* rstd, float* bc,
+                      void* dh1, float* part_g, int max_g_rows, float* part_c, int max_c_rows, int* g_rows, int* c_rows,
+                      int M, int nseq, int F, int Fp, float p, const unsigned char* drop_bits, const void* gh, hipStream_t st);
+// 1 (default): bf16 operands take the column-strip kernels; 0: the wave-per-row kernels for every dtype.  $OMLM_FFMID_IMPL or
+// omlm_ffmid_set_impl (A/B runs, tests).  The two generations share every buffer layout; their dropout streams differ
+// (the keep-mask travels from forward to backward as drop_bits, so a step may not mix them only when drop_bits is null).
+static int g_ffmid_impl = -1;
+extern "C" int omlm_ffmid_set_impl(int impl) {
+    OMLM_CHECK_ARG(impl == 0 || impl == 1, "impl: 0 = wave-per-row, 1 = column strips");
+    g_ffmid_impl = impl;
+    return OMLM_OK;
+}
+static int ffmid_impl() {
+    if (g_ffmid_impl < 0) { const char* e = getenv("OMLM_FFMID_IMPL"); g_ffmid_impl = (e && e[0] == '0') ? 0 : 1; }
+    return g_ffmid_impl;
+}
+
 extern "C" long long omlm_ffmid_bwd_workspace_bytes(int F, int Fp) {
     return (long long)sizeof(float) * ((long long)FF_BWD1_BLOCKS * Fp + (long long)FF_BWD2_STRIPS * 2 * F * 3);
 }
@@ -568,9 +591,11 @@ extern "C" int omlm_ffmid_fwd(const void* h1, const void* convw, const void* gam
     OMLM_CHECK_ARG(Fp % 8 == 0 && Fp >= F && Fp <= 8192 && (size_t)5 * Fp * sizeof(float) <= 160 * 1024, "Fp must be F rounded up to 8 and <= 8192");
     OMLM_CHECK_ARG(nseq > 0 && M % nseq == 0, "M must be batch * nseq");
     OMLM_CHECK_ARG(p >= 0.f && p < 1.f, "dropout p");
+    hipStream_t st = as_stream(stream);
+    if (dtype == 1 && ffmid_impl() == 1 && ffmid2_supported(Fp) && (p == 0.f || drop_bits))
+        return ffmid2_fwd_launch(h1, convw, gamma, h2, mean, rstd, M, nseq, F, Fp, eps, p, seed, seed_dev, drop_bits, gh, st);
     const int rows4 = (M + 3) / 4;
     dim3 grid(rows4 < 4096 ? rows4 : 4096), block(FF_THREADS);
-    hipStream_t st = as_stream(stream);
     const size_t lds_fwd = (size_t)4 * Fp * sizeof(float);
     if (lds_fwd > 48 * 1024) {
         (void)hipFuncSetAttribute((const void*)ffmid_fwd_kernel<float, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -599,6 +624,17 @@ extern "C" int omlm_ffmid_bwd(const void* dh2, const void* h1, const void* convw
     hipStream_t st = as_stream(stream);
     float* part_g = workspace;
     float* part_c = workspace + (size_t)FF_BWD1_BLOCKS * Fp;
+    if (dtype == 1 && ffmid_impl() == 1 && ffmid2_supported(Fp) && gh && (p == 0.f || drop_bits)) {
+        // du_tmp is not needed by the fused kernel: its first M * 2 floats carry the per-row LayerNorm^T sums
+        OMLM_CHECK_ARG(((uintptr_t)du_tmp % 8) == 0, "du_tmp must be 8-byte aligned");
+        int g_rows = 0, c_rows = 0;
+        int rc2 = ffmid2_bwd_launch(dh2, h1, convw, gamma, rstd, (float*)du_tmp, dh1, part_g, FF_BWD1_BLOCKS, part_c, FF_BWD2_STRIPS,
+                                    &g_rows, &c_rows, M, nseq, F, Fp, p, drop_bits, gh, st);
+        if (rc2) return rc2;
+        if (dgamma) { rc2 = omlm_colsum_accumulate(part_g, dgamma, g_rows, F, Fp, stream); if (rc2) return rc2; }
+        if (dconv)  { rc2 = omlm_colsum_accumulate(part_c, dconv, c_rows, 2 * F * 3, 2 * F * 3, stream); if (rc2) return rc2; }
+        return OMLM_OK;
+    }
     const int rows4 = (M + 3) / 4;
     const int b1 = rows4 < FF_BWD1_BLOCKS ? rows4 : FF_BWD1_BLOCKS;
     const int strips = M < FF_BWD2_STRIPS ? M : FF_BWD2_STRIPS;

@@ -1,0 +1,493 @@
+// Second-generation middle of ConvFeedForward for bf16 operands (reference transformer.py:122-150):
+//   h1 [M, 2*Fp] --causal depthwise conv k=3--> u --GEGLU--> g --LayerNorm(F)--> --Dropout(p)--> h2 [M, Fp]
+// Same contract, layouts and outputs as the wave-per-row kernels of ffmid.hip (which stay the fp32 / bf16x3 path and the
+// fallback); what changes is who owns what.
+//
+// The first generation gave a wave one row: every 8-channel chunk loaded 3 rows x 2 halves of h1 plus 6 tap vectors (12
+// loads) and converted all of them (12 bf16 -> fp32 conversions per element) before the first useful FMA, ~70 VALU
+// instructions per element.  At ~16 fp32 lanes per SIMD-cycle that is ~200 us of pure issue for the 97.5 M elements of a
+// coarse-small layer against an HBM time of ~160 us: these kernels were issue-bound (profiles/r02b_kernel_stats.md:
+// forward 309 us, backward 390 + 260 us).
+//
+// Here a THREAD owns a few channel pairs (value + gate) and walks DOWN the rows of a strip of one sample:
+//   * the conv window is two rows of fp32 registers (x[t-1], x[t-2]); each h1 element is loaded and converted once;
+//   * taps and gamma are converted once per strip and stay in registers as fp32;
+//   * the arithmetic is written on float2 so that hipcc emits v_pk_fma_f32 / v_pk_mul_f32 (two lanes' worth per issue);
+//   * forward: a workgroup covers ALL channels of its rows, the LayerNorm sums cross the waves through 1 KiB of LDS with
+//     one barrier per batch of 4 rows, g never leaves registers;
+//   * backward: the two row sums of LayerNorm^T come from a light prepass (reads dh2, the saved normalised output gh and
+//     the keep bits; also d(gamma)); the main kernel is then column-local -- dropout^T, LayerNorm^T, GEGLU^T, conv^T and
+//     d(conv taps) in ONE pass, du never exists in memory (first generation: bwd1 wrote it, bwd2 re-read it: 0.8 GB per
+//     layer).  conv^T runs as two pending output rows in registers; a strip recomputes du for the 2 rows past its end.
+#include "common.h"
+
+typedef f32x2 v2;
+
+__device__ __forceinline__ v2 mk2(float a, float b) { v2 r; r[0] = a; r[1] = b; return r; }
+__device__ __forceinline__ v2 splat2(float a) { return mk2(a, a); }
+__device__ __forceinline__ v2 bf2_to_f2(unsigned w) { return mk2(u2f(w << 16), u2f(w & 0xFFFF0000u)); }
+__device__ __forceinline__ unsigned f2_to_bf2(v2 v) { return pack_bf16_rne(v[0], v[1]); }
+__device__ __forceinline__ v2 fma2(v2 a, v2 b, v2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// GELU pieces of a gate pair u:  h = Phi(u) = 0.5 (1 + erf(u / sqrt 2)),  ex = exp(-u^2 / 2).
+// erf by Abramowitz-Stegun 7.1.26 like ffmid.hip (|abs err| <= 1.5e-7), with the 1/sqrt2 and the 0.5 folded into constants.
+__device__ __forceinline__ void gelu_parts(v2 u, v2& h, v2& ex) {
+    const v2 au = mk2(fabsf(u[0]), fabsf(u[1]));
+    const v2 d = fma2(au, splat2(0.23164189f), splat2(1.0f));                  // 1 + 0.3275911 |u| / sqrt 2
+    const v2 t = mk2(__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1]));
+    v2 poly = fma2(t, splat2(0.5f * 1.061405429f), splat2(0.5f * -1.453152027f));
+    poly = fma2(poly, t, splat2(0.5f * 1.421413741f));
+    poly = fma2(poly, t, splat2(0.5f * -0.284496736f));
+    poly = fma2(poly, t, splat2(0.5f * 0.254829592f));
+    poly = poly * t;
+    const v2 q = u * u;
+    ex = mk2(__builtin_amdgcn_exp2f(q[0] * -0.72134752f), __builtin_amdgcn_exp2f(q[1] * -0.72134752f));   // exp(-u^2/2)
+    const v2 hp = fma2(-poly, ex, splat2(0.5f));                                // 0.5 erf(|u| / sqrt 2), in [0, 0.5]
+    h = mk2(0.5f + copysignf(hp[0], u[0]), 0.5f + copysignf(hp[1], u[1]));
+}
+
+// 32-bit integer hash (lowbias32, Wellons) -- the dropout keep-mask of the bf16 kernels: 128 bits per 8 elements from one
+// full hash of the (row, chunk) counter and three xorshift-multiply steps; each element draws 16 bits, keep iff >= p * 65536.
+// (The fp32 kernels of ffmid.hip keep Philox: 4 quarter-rate 32-bit multiplies per round were ~12 issue slots per element.)
+__device__ __forceinline__ unsigned lowbias32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ void keep_words(unsigned long long seed, unsigned long long blk, unsigned w[4]) {
+    const unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+    unsigned x = lowbias32(((unsigned)blk ^ k0) + 0x9E3779B9u * ((unsigned)(blk >> 32) ^ k1));
+    x = lowbias32(x ^ k1);
+    w[0] = x;
+    x = (x ^ (x >> 15)) * 0x2c1b3c6du; w[1] = x ^ (x >> 13);
+    x = (x ^ (x >> 12)) * 0x297a2d39u; w[2] = x ^ (x >> 15);
+    x = (x ^ (x >> 14)) * 0x85ebca6bu; w[3] = x ^ (x >> 16);
+}
+
+#define FS_R 4            // rows per batch of the forward (one barrier per batch)
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward.  grid: B * strips workgroups of NT threads (NT = chunks of 8 channels rounded up to waves); strip s of sample b
+// covers rows [s * RB, min(nseq, (s + 1) * RB)).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(NT) void ffmid2_fwd_kernel(const bf16_t* __restrict__ h1, const bf16_t* __restrict__ convw,
+                                                        const bf16_t* __restrict__ gamma, bf16_t* __restrict__ h2,
+                                                        float* __restrict__ mean, float* __restrict__ rstd,
+                                                        int nseq, int F, int Fp, int RB, int strips, float eps, float p,
+                                                        unsigned long long seed, const unsigned long long* __restrict__ seed_dev,
+                                                        unsigned char* __restrict__ drop_bits, bf16_t* __restrict__ gh_out) {
+    constexpr int NW = NT / 64;
+    __shared__ float st[2][FS_R][NW][2];
+    if (seed_dev) seed += seed_dev[0] * 0x9E3779B97F4A7C15ull;
+    const int b = blockIdx.x / strips, s = blockIdx.x - b * strips;
+    const int t0 = s * RB, t1 = min(nseq, t0 + RB);
+    if (t0 >= t1) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = threadIdx.x * 8;
+    const bool act = col < Fp;
+    const int colc = act ? col : 0;
+    const int ld = 2 * Fp;
+    const size_t row0 = (size_t)b * nseq;
+    const float inv = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    const unsigned thr = (unsigned)(p * 65536.0f + 0.5f);
+
+    // taps / gamma: fp32 registers for the whole strip (zero for threads past the row: they only take part in the sums)
+    v2 wv[3][4], wg[3][4], gm[4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const u32x4 a = *(const u32x4*)(convw + (size_t)k * ld + colc);
+        const u32x4 c = *(const u32x4*)(convw + (size_t)k * ld + Fp + colc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            wv[k][i] = act ? bf2_to_f2(a[i]) : splat2(0.f);
+            wg[k][i] = act ? bf2_to_f2(c[i]) : splat2(0.f);
+        }
+    }
+    {
+        const u32x4 a = *(const u32x4*)(gamma + colc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gm[i] = bf2_to_f2(a[i]) * inv;          // dropout scale folded into gamma
+    }
+    // conv window: rows t0 - 1 and t0 - 2 of the same sample (zero before the sample starts, transformer.py:129)
+    v2 x1v[4], x1g[4], x2v[4], x2g[4];
+    {
+        u32x4 a = {0u, 0u, 0u, 0u}, c = a, d = a, e = a;
+        if (t0 >= 1) { a = *(const u32x4*)(h1 + (row0 + t0 - 1) * ld + colc); c = *(const u32x4*)(h1 + (row0 + t0 - 1) * ld + Fp + colc); }
+        if (t0 >= 2) { d = *(const u32x4*)(h1 + (row0 + t0 - 2) * ld + colc); e = *(const u32x4*)(h1 + (row0 + t0 - 2) * ld + Fp + colc); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x1v[i] = bf2_to_f2(a[i]); x1g[i] = bf2_to_f2(c[i]); x2v[i] = bf2_to_f2(d[i]); x2g[i] = bf2_to_f2(e[i]); }
+    }
+    u32x4 rv[FS_R], rg[FS_R];
+#pragma unroll
+    for (int r = 0; r < FS_R; ++r)
+        if (t0 + r < t1) {
+            rv[r] = *(const u32x4*)(h1 + (row0 + t0 + r) * ld + colc);
+            rg[r] = *(const u32x4*)(h1 + (row0 + t0 + r) * ld + Fp + colc);
+        }
+    const float invF = 1.0f / (float)F;
+    int it = 0;
+#pragma unroll 1
+    for (int tb = t0; tb < t1; tb += FS_R, ++it) {
+        v2 g[FS_R][4];
+        float ls[FS_R], lq[FS_R];
+        // sweep 1: conv + GEGLU of the batch, per-thread sums for LayerNorm
+#pragma unroll
+        for (int r = 0; r < FS_R; ++r) {
+            ls[r] = 0.f; lq[r] = 0.f;
+            if (tb + r < t1) {
+                v2 s2 = splat2(0.f), q2 = splat2(0.f);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const v2 xv = bf2_to_f2(rv[r][i]), xg = bf2_to_f2(rg[r][i]);
+                    const v2 uv = fma2(wv[2][i], xv, fma2(wv[1][i], x1v[i], wv[0][i] * x2v[i]));
+                    const v2 ug = fma2(wg[2][i], xg, fma2(wg[1][i], x1g[i], wg[0][i] * x2g[i]));
+                    x2v[i] = x1v[i]; x1v[i] = xv; x2g[i] = x1g[i]; x1g[i] = xg;
+                    v2 h, ex;
+                    gelu_parts(ug, h, ex);
+                    const v2 gv = (ug * h) * uv;
+                    g[r][i] = gv;
+                    s2 += gv;
+                    q2 = fma2(gv, gv, q2);
+                }
+                ls[r] = s2[0] + s2[1];
+                lq[r] = q2[0] + q2[1];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) g[r][i] = splat2(0.f);
+            }
+        }
+        // next batch's rows: in flight during the reduction and the second sweep
+#pragma unroll
+        for (int r = 0; r < FS_R; ++r)
+            if (tb + FS_R + r < t1) {
+                rv[r] = *(const u32x4*)(h1 + (row0 + tb + FS_R + r) * ld + colc);
+                rg[r] = *(const u32x4*)(h1 + (row0 + tb + FS_R + r) * ld + Fp + colc);
+            }
+#pragma unroll
+        for (int r = 0; r < FS_R; ++r) { ls[r] = wave_sum(ls[r]); lq[r] = wave_sum(lq[r]); }
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < FS_R; ++r) { st[it & 1][r][wave][0] = ls[r]; st[it & 1][r][wave][1] = lq[r]; }
+        }
+        __syncthreads();          // one barrier per batch: the other parity's slots are rewritten only after the next one
+        // sweep 2: normalise, gamma, dropout, store
+#pragma unroll
+        for (int r = 0; r < FS_R; ++r) {
+            if (tb + r >= t1) continue;
+            float S = 0.f, Q = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { S += st[it & 1][r][w][0]; Q += st[it & 1][r][w][1]; }
+            const float mu = S * invF;
+            const float var = fmaxf(Q * invF - mu * mu, 0.f);
+            const float rs = rsqrtf(var + eps);
+            const size_t row = row0 + tb + r;
+            if (threadIdx.x == 0) { mean[row] = mu; rstd[row] = rs; }
+            if (!act) continue;
+            const v2 nmr = splat2(-mu * rs), rs2 = splat2(rs);
+            v2 gh[4], y[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gh[i] = fma2(g[r][i], rs2, nmr);
+            if (col + 8 > F) {                                   // the chunk holding the F boundary: pad channels carry 0
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (col + 2 * i >= F) gh[i][0] = 0.f;
+                    if (col + 2 * i + 1 >= F) gh[i][1] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) y[i] = gh[i] * gm[i];
+            if (p > 0.f) {
+                unsigned w[4], bits = 0;
+                keep_words(seed, row * (unsigned long long)(Fp >> 3) + (unsigned)(col >> 3), w);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool k0 = (w[i] & 0xFFFFu) >= thr, k1 = (w[i] >> 16) >= thr;
+                    y[i][0] = k0 ? y[i][0] : 0.f;
+                    y[i][1] = k1 ? y[i][1] : 0.f;
+                    bits |= (k0 ? 1u : 0u) << (2 * i);
+                    bits |= (k1 ? 1u : 0u) << (2 * i + 1);
+                }
+                if (drop_bits) drop_bits[row * (size_t)(Fp >> 3) + (col >> 3)] = (unsigned char)bits;
+            }
+            u32x4 o, og;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { o[i] = f2_to_bf2(y[i]); og[i] = f2_to_bf2(gh[i]); }
+            *(u32x4*)(h2 + row * Fp + col) = o;
+            if (gh_out) *(u32x4*)(gh_out + row * Fp + col) = og;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward prepass: per row  bc[row] = (rstd * sum(gy) / F, rstd * sum(gy * gh) / F)  with gy = dropout^T(dh2) * gamma,
+// and per-workgroup partial rows of d(gamma) = sum_rows dropout^T(dh2) * gh.  Wave per row, 8 channels per lane and step.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int MAXC>
+__global__ __launch_bounds__(256) void ffmid2_rowsum_kernel(const bf16_t* __restrict__ dh2, const bf16_t* __restrict__ gamma,
+                                                            const bf16_t* __restrict__ ghs, const unsigned char* __restrict__ drop_bits,
+                                                            const float* __restrict__ rstd, float* __restrict__ bc,
+                                                            float* __restrict__ part_dgamma, int M, int F, int Fp, float p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float inv = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    const int nwaves = gridDim.x * 4;
+    v2 dg[MAXC][4], gmv[MAXC][4];
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+        const int ch = (lane + 64 * k) * 8;
+        u32x4 a = {0u, 0u, 0u, 0u};
+        if (ch < Fp) a = *(const u32x4*)(gamma + ch);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { dg[k][i] = splat2(0.f); gmv[k][i] = bf2_to_f2(a[i]); }
+    }
+    for (int row = blockIdx.x * 4 + wave; row < M; row += nwaves) {
+        v2 s1 = splat2(0.f), s2 = splat2(0.f);
+        u32x4 d[MAXC], gq[MAXC];
+        unsigned bits[MAXC];
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) {
+            const int ch = (lane + 64 * k) * 8;
+            if (ch < Fp) {
+                d[k] = *(const u32x4*)(dh2 + (size_t)row * Fp + ch);
+                gq[k] = *(const u32x4*)(ghs + (size_t)row * Fp + ch);
+                bits[k] = (p > 0.f) ? drop_bits[(size_t)row * (Fp >> 3) + (ch >> 3)] : 0xFFu;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) {
+            const int ch = (lane + 64 * k) * 8;
+            if (ch < Fp) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v2 dy = bf2_to_f2(d[k][i]) * inv;
+                    if (!((bits[k] >> (2 * i)) & 1u)) dy[0] = 0.f;
+                    if (!((bits[k] >> (2 * i + 1)) & 1u)) dy[1] = 0.f;
+                    const v2 gh = bf2_to_f2(gq[k][i]);
+                    dg[k][i] = fma2(dy, gh, dg[k][i]);                // pad columns: gh == 0 and gamma == 0
+                    const v2 gy = dy * gmv[k][i];
+                    s1 += gy;
+                    s2 = fma2(gy, gh, s2);
+                }
+            }
+        }
+        const float t1 = wave_sum(s1[0] + s1[1]), t2 = wave_sum(s2[0] + s2[1]);
+        if (lane == 0) {
+            const float rs = rstd[row] / (float)F;
+            bc[2 * (size_t)row] = rs * t1;
+            bc[2 * (size_t)row + 1] = rs * t2;
+        }
+    }
+    // the four waves' d(gamma) partials -> one partial row per workgroup
+    extern __shared__ __attribute__((aligned(16))) float red[];     // [4][Fp]
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+        const int ch = (lane + 64 * k) * 8;
+        if (ch < Fp) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { red[(size_t)wave * Fp + ch + 2 * i] = dg[k][i][0]; red[(size_t)wave * Fp + ch + 2 * i + 1] = dg[k][i][1]; }
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < Fp; c += 256)
+        part_dgamma[(size_t)blockIdx.x * Fp + c] = red[c] + red[Fp + c] + red[2 * Fp + c] + red[3 * Fp + c];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward main.  grid (column blocks of 256 threads x 4 channels, NY); workgroup y walks strips y, y + NY, ... keeping its
+// d(conv taps) sums in registers, and leaves ONE partial row per y.
+// ---------------------------------------------------------------------------------------------------------------------
+struct Bwd2Row { u32x2 dy, gh, xv, xg; unsigned bits; float a, b, c; };
+
+__global__ __launch_bounds__(256) void ffmid2_bwd_kernel(const bf16_t* __restrict__ dh2, const bf16_t* __restrict__ h1,
+                                                         const bf16_t* __restrict__ convw, const bf16_t* __restrict__ gamma,
+                                                         const float* __restrict__ rstd, const float* __restrict__ bc,
+                                                         const bf16_t* __restrict__ ghs, const unsigned char* __restrict__ drop_bits,
+                                                         bf16_t* __restrict__ dh1, float* __restrict__ part_dconv,
+                                                         int nseq, int F, int Fp, int RB, int strips, int total_strips, float p) {
+    const int c4 = blockIdx.x * 256 + threadIdx.x;
+    const int col = c4 * 4;
+    const bool act = col < Fp;
+    const int colc = act ? col : 0;
+    const int ld = 2 * Fp;
+    const float inv = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    const int nib = (c4 & 1) * 4;
+
+    v2 wv[3][2], wg[3][2], gm[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const u32x2 a = *(const u32x2*)(convw + (size_t)k * ld + colc);
+        const u32x2 c = *(const u32x2*)(convw + (size_t)k * ld + Fp + colc);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { wv[k][i] = act ? bf2_to_f2(a[i]) : splat2(0.f); wg[k][i] = act ? bf2_to_f2(c[i]) : splat2(0.f); }
+    }
+    {
+        const u32x2 a = *(const u32x2*)(gamma + colc);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) gm[i] = act ? bf2_to_f2(a[i]) * inv : splat2(0.f);
+    }
+    v2 dcv[3][2], dcg[3][2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { dcv[k][i] = splat2(0.f); dcg[k][i] = splat2(0.f); }
+
+    auto load_row = [&](Bwd2Row& R, size_t row) {
+        R.dy = *(const u32x2*)(dh2 + row * Fp + colc);
+        R.gh = *(const u32x2*)(ghs + row * Fp + colc);
+        R.xv = *(const u32x2*)(h1 + row * ld + colc);
+        R.xg = *(const u32x2*)(h1 + row * ld + Fp + colc);
+        R.bits = (p > 0.f) ? (unsigned)drop_bits[row * (size_t)(Fp >> 3) + (colc >> 3)] : 0xFFu;
+        R.a = rstd[row]; R.b = bc[2 * row]; R.c = bc[2 * row + 1];
+    };
+
+#pragma unroll 1
+    for (int strip = blockIdx.y; strip < total_strips; strip += gridDim.y) {
+        const int b = strip / strips, s = strip - b * strips;
+        const int t0 = s * RB, t1 = min(nseq, t0 + RB);
+        if (t0 >= t1) continue;
+        const size_t row0 = (size_t)b * nseq;
+        v2 x1v[2], x1g[2], x2v[2], x2g[2], p1v[2], p1g[2], p2v[2], p2g[2];
+        {
+            u32x2 a = {0u, 0u}, c = a, d = a, e = a;
+            if (t0 >= 1) { a = *(const u32x2*)(h1 + (row0 + t0 - 1) * ld + colc); c = *(const u32x2*)(h1 + (row0 + t0 - 1) * ld + Fp + colc); }
+            if (t0 >= 2) { d = *(const u32x2*)(h1 + (row0 + t0 - 2) * ld + colc); e = *(const u32x2*)(h1 + (row0 + t0 - 2) * ld + Fp + colc); }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                x1v[i] = bf2_to_f2(a[i]); x1g[i] = bf2_to_f2(c[i]); x2v[i] = bf2_to_f2(d[i]); x2g[i] = bf2_to_f2(e[i]);
+                p1v[i] = splat2(0.f); p1g[i] = splat2(0.f); p2v[i] = splat2(0.f); p2g[i] = splat2(0.f);
+            }
+        }
+        const int tend = t1 + 2;                      // rows t1, t1 + 1: du recomputed for the conv^T of this strip's last two rows
+        Bwd2Row cur, nxt;
+        load_row(cur, row0 + t0);
+#pragma unroll 1
+        for (int t = t0; t < tend; ++t) {
+            if (t + 1 < min(tend, nseq)) load_row(nxt, row0 + t + 1);
+            v2 duv[2], dug[2];
+            if (t < nseq) {
+                const float own = t < t1 ? 1.f : 0.f;
+                const unsigned kb = cur.bits >> nib;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    v2 gy = bf2_to_f2(cur.dy[i]) * gm[i];
+                    if (!((kb >> (2 * i)) & 1u)) gy[0] = 0.f;
+                    if (!((kb >> (2 * i + 1)) & 1u)) gy[1] = 0.f;
+                    const v2 gh = bf2_to_f2(cur.gh[i]);
+                    v2 dg = fma2(gy, splat2(cur.a), splat2(-cur.b));
+                    dg = fma2(gh, splat2(-cur.c), dg);
+                    const v2 xv = bf2_to_f2(cur.xv[i]), xg = bf2_to_f2(cur.xg[i]);
+                    const v2 uv = fma2(wv[2][i], xv, fma2(wv[1][i], x1v[i], wv[0][i] * x2v[i]));
+                    const v2 ug = fma2(wg[2][i], xg, fma2(wg[1][i], x1g[i], wg[0][i] * x2g[i]));
+                    v2 h, ex;
+                    gelu_parts(ug, h, ex);
+                    const v2 gp = fma2(ug * 0.3989422804f, ex, h);          // GELU'(u) = Phi(u) + u phi(u)
+                    const v2 a_ = dg * (ug * h);                             // d(value conv output)
+                    const v2 g_ = (dg * uv) * gp;                            // d(gate conv output)
+                    duv[i] = a_; dug[i] = g_;
+                    const v2 ao = a_ * own, go = g_ * own;                   // d(taps): owned rows only
+                    dcv[0][i] = fma2(ao, x2v[i], dcv[0][i]); dcv[1][i] = fma2(ao, x1v[i], dcv[1][i]); dcv[2][i] = fma2(ao, xv, dcv[2][i]);
+                    dcg[0][i] = fma2(go, x2g[i], dcg[0][i]); dcg[1][i] = fma2(go, x1g[i], dcg[1][i]); dcg[2][i] = fma2(go, xg, dcg[2][i]);
+                    x2v[i] = x1v[i]; x1v[i] = xv; x2g[i] = x1g[i]; x1g[i] = xg;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { duv[i] = splat2(0.f); dug[i] = splat2(0.f); }
+            }
+            // conv^T: dh1[t-2] = w2 du[t-2] + w1 du[t-1] + w0 du[t] is complete now
+            if (t - 2 >= t0 && act) {
+                u32x2 ov, og;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    ov[i] = f2_to_bf2(fma2(wv[0][i], duv[i], p2v[i]));
+                    og[i] = f2_to_bf2(fma2(wg[0][i], dug[i], p2g[i]));
+                }
+                *(u32x2*)(dh1 + (row0 + t - 2) * ld + col) = ov;
+                *(u32x2*)(dh1 + (row0 + t - 2) * ld + Fp + col) = og;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                p2v[i] = fma2(wv[1][i], duv[i], p1v[i]); p1v[i] = wv[2][i] * duv[i];
+                p2g[i] = fma2(wg[1][i], dug[i], p1g[i]); p1g[i] = wg[2][i] * dug[i];
+            }
+            cur = nxt;
+        }
+    }
+    // partial row of d(conv taps): layout [2F real channels][3] like the reference weight [2F, 1, 3]
+    if (act) {
+        float* pr = part_dconv + (size_t)blockIdx.y * 2 * F * 3;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int ch = col + 2 * i + e;
+                if (ch < F) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { pr[(size_t)ch * 3 + k] = dcv[k][i][e]; pr[(size_t)(F + ch) * 3 + k] = dcg[k][i][e]; }
+                }
+            }
+    }
+}
+
+// ---- host side (called by the C-ABI entry points of ffmid.hip) ----------------------------------------------------------
+static int strip_rows(int nseq, int target) {
+    const int n = (nseq + target - 1) / target;
+    return (nseq + n - 1) / n;
+}
+
+bool ffmid2_supported(int Fp) { return Fp % 8 == 0 && Fp / 8 <= 512; }
+
+int ffmid2_fwd_launch(const void* h1, const void* convw, const void* gamma, void* h2, float* mean, float* rstd, int M, int nseq,
+                      int F, int Fp, float eps, float p, unsigned long long seed, const unsigned long long* seed_dev,
+                      unsigned char* drop_bits, void* gh, hipStream_t st) {
+    const int B = M / nseq;
+    const int RB = strip_rows(nseq, 36);
+    const int strips = (nseq + RB - 1) / RB;
+    const int nt = ((Fp / 8 + 63) / 64) * 64;
+    dim3 grid(B * strips);
+#define FF2_FWD(NT_) hipLaunchKernelGGL(ffmid2_fwd_kernel<NT_>, grid, dim3(NT_), 0, st, (const bf16_t*)h1, (const bf16_t*)convw, \
+        (const bf16_t*)gamma, (bf16_t*)h2, mean, rstd, nseq, F, Fp, RB, strips, eps, p, seed, seed_dev, drop_bits, (bf16_t*)gh)
+    switch (nt) {
+        case 64: FF2_FWD(64); break;
+        case 128: FF2_FWD(128); break;
+        case 192: FF2_FWD(192); break;
+        case 256: FF2_FWD(256); break;
+        case 320: FF2_FWD(320); break;
+        case 384: FF2_FWD(384); break;
+        case 448: FF2_FWD(448); break;
+        default: FF2_FWD(512); break;
+    }
+#undef FF2_FWD
+    return omlm_post_launch("omlm_ffmid_fwd (strip)");
+}
+
+// bc: [M][2] floats of scratch; part_g: [>= rowsum blocks][Fp]; part_c: [>= NY][2F*3]
+int ffmid2_bwd_launch(const void* dh2, const void* h1, const void* convw, const void* gamma, const float* rstd, float* bc,
+                      void* dh1, float* part_g, int max_g_rows, float* part_c, int max_c_rows, int* g_rows, int* c_rows,
+                      int M, int nseq, int F, int Fp, float p, const unsigned char* drop_bits, const void* gh, hipStream_t st) {
+    const int B = M / nseq;
+    // prepass
+    const int rows4 = (M + 3) / 4;
+    const int b1 = rows4 < max_g_rows ? rows4 : max_g_rows;
+    const size_t lds = (size_t)4 * Fp * sizeof(float);
+    const int mc = (Fp / 8 + 63) / 64;
+#define FF2_RS(MC_) do { if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)ffmid2_rowsum_kernel<MC_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL(ffmid2_rowsum_kernel<MC_>, dim3(b1), dim3(256), lds, st, (const bf16_t*)dh2, (const bf16_t*)gamma, (const bf16_t*)gh, \
+                           drop_bits, rstd, bc, part_g, M, F, Fp, p); } while (0)
+    if (mc <= 1) FF2_RS(1); else if (mc <= 2) FF2_RS(2); else if (mc <= 4) FF2_RS(4); else if (mc <= 6) FF2_RS(6); else FF2_RS(8);
+#undef FF2_RS
+    int rc = omlm_post_launch("omlm_ffmid_bwd (row sums)");
+    if (rc) return rc;
+    // main
+    const int RB = strip_rows(nseq, 35);
+    const int strips = (nseq + RB - 1) / RB;
+    const int total = B * strips;
+    int per = (total + 255) / 256;                       // strips per workgroup-y: ~3 workgroups of 4 waves per CU
+    int ny = (total + per - 1) / per;
+    if (ny > max_c_rows) ny = max_c_rows;
+    dim3 grid((Fp / 4 + 255) / 256, ny);
+    hipLaunchKernelGGL(ffmid2_bwd_kernel, grid, dim3(256), 0, st, (const bf16_t*)dh2, (const bf16_t*)h1, (const bf16_t*)convw,
+                       (const bf16_t*)gamma, rstd, (const float*)bc, (const bf16_t*)gh, drop_bits, (bf16_t*)dh1, part_c,
+                       nseq, F, Fp, RB, strips, total, p);
+    *g_rows = b1;
+    *c_rows = ny;
+    return omlm_post_launch("omlm_ffmid_bwd (strip)");
+}

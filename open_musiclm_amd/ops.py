@@ -178,6 +178,11 @@ def ffmid_fwd(h1, convw, gamma, h2, mean, rstd, nseq, F, Fp, p, seed, eps=1e-5, 
          stream_ptr())
 
 
+def ffmid_set_impl(impl: int):
+    """0: wave-per-row kernels for every dtype; 1 (default): column-strip kernels for bf16 operands (csrc/ffmid2.hip)."""
+    call("omlm_ffmid_set_impl", int(impl))
+
+
 def ffmid_bwd_workspace_floats(F, Fp) -> int:
     return int(hip.lib().omlm_ffmid_bwd_workspace_bytes(F, Fp)) // 4
 

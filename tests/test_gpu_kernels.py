@@ -402,6 +402,110 @@ def test_ffmid_dropout_statistics_and_replay(ops, dev):
     assert relerr(outs[0][1], outs[1][1]) < 1e-5 and relerr(outs[0][2], outs[1][2]) < 1e-5   # atomically reduced partials
 
 
+@pytest.mark.parametrize("F,nseq,Bn,p", [(341, 80, 2, 0.0), (341, 80, 2, 0.1), (2730, 45, 2, 0.1), (1024, 37, 3, 0.1)])
+def test_ffmid_strip_kernels_bf16(ops, dev, F, nseq, Bn, p):
+    """Second-generation (column-strip) kernels: several strips per sample (conv / conv^T halos across strip boundaries), the chunk
+    holding the F boundary, dropout through the stored keep bits -- against fp64 autograd with the SAME mask, and against the
+    first-generation kernels on identical inputs."""
+    M = nseq * Bn
+    Fp = (F + 7) // 8 * 8
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(F + nseq)
+    h1 = torch.zeros(M, 2 * Fp)
+    h1[:, :F] = torch.randn(M, F, generator=g)
+    h1[:, Fp:Fp + F] = torch.randn(M, F, generator=g)
+    convw = (torch.randn(2 * F, 3, generator=g) * 0.5).to(dev).to(dtype).float()
+    gamma = (1 + 0.1 * torch.randn(F, generator=g)).to(dev).to(dtype).float()
+    h1d = h1.to(dev).to(dtype)
+    taps, gpad = ops.pack_conv_taps(convw, F, Fp).to(dtype), ops.pad_vector(gamma, Fp).to(dtype)
+    dh2 = torch.zeros(M, Fp)
+    dh2[:, :F] = torch.randn(M, F, generator=g)
+    dh2d = dh2.to(dev).to(dtype)
+    res = {}
+    try:
+        for impl in (1, 0):
+            ops.ffmid_set_impl(impl)
+            h2 = torch.full((M, Fp), float("nan"), device=dev, dtype=dtype)
+            gh = torch.full((M, Fp), float("nan"), device=dev, dtype=dtype)
+            mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+            bits = torch.zeros(M, Fp // 8, dtype=torch.uint8, device=dev) if p > 0 else None
+            ops.ffmid_fwd(h1d, taps, gpad, h2, mean, rstd, nseq, F, Fp, p, 4321, drop_bits=bits, gh=gh)
+            du = torch.empty(M, 2 * Fp, device=dev, dtype=dtype)
+            dh1 = torch.full((M, 2 * Fp), float("nan"), device=dev, dtype=dtype)
+            dgamma, dconv = torch.zeros(F, device=dev), torch.zeros(2 * F * 3, device=dev)
+            ws = torch.empty(ops.ffmid_bwd_workspace_floats(F, Fp), device=dev)
+            # the backward of BOTH generations runs from the strip forward's mask / gh, so their outputs are comparable
+            b_use, gh_use = (bits, gh) if impl == 1 else (res[1]["bits"], res[1]["gh"])
+            ops.ffmid_bwd(dh2d, h1d, taps, gpad, res[1]["mean"] if impl == 0 else mean, res[1]["rstd"] if impl == 0 else rstd,
+                          du, dh1, dgamma, dconv, ws, nseq, F, Fp, p, 4321, drop_bits=b_use, gh=gh_use)
+            res[impl] = dict(h2=h2, gh=gh, mean=mean, rstd=rstd, bits=bits, dh1=dh1, dgamma=dgamma, dconv=dconv)
+    finally:
+        ops.ffmid_set_impl(1)
+    new, old = res[1], res[0]
+    # fp64 reference with the new forward's mask
+    h1r = h1d.double().requires_grad_(True)
+    cr, gr = convw.double().requires_grad_(True), gamma.double().requires_grad_(True)
+    ref = ffmid_reference(h1r, cr, gr, F, Fp, nseq)
+    if p > 0:
+        keep = ((new["bits"][:, :, None] >> torch.arange(8, device=dev, dtype=torch.uint8)) & 1).reshape(M, Fp)[:, :F].double()
+        frac = 1.0 - float(keep.mean())
+        assert abs(frac - p) < 0.01, frac
+        refd = ref * keep / (1 - p)
+    else:
+        refd = ref
+    refd.backward(dh2d.double()[:, :F])
+    e_f = relerr(new["h2"][:, :F], refd.detach())
+    e_gh = relerr(new["gh"][:, :F], (ref / gr).detach())
+    gref = h1r.grad
+    e_x = max(relerr(new["dh1"][:, :F], gref[:, :F]), relerr(new["dh1"][:, Fp:Fp + F], gref[:, Fp:Fp + F]))
+    e_g, e_c = relerr(new["dgamma"], gr.grad), relerr(new["dconv"].view(2 * F, 3), cr.grad)
+    pads = bool((new["h2"][:, F:] == 0).all() and (new["gh"][:, F:] == 0).all() and (new["dh1"][:, F:Fp] == 0).all()
+                and (new["dh1"][:, Fp + F:] == 0).all())
+    e_stat = max(relerr(new["mean"], old["mean"]), relerr(new["rstd"], old["rstd"]))
+    e_ab = max(relerr(new["dh1"], old["dh1"].float()), relerr(new["dgamma"], old["dgamma"]), relerr(new["dconv"], old["dconv"]))
+    report(f"ffmid_strip[{F},{nseq},p={p}]", fwd=e_f, gh=e_gh, dh1=e_x, dgamma=e_g, dconv=e_c, stats_vs_gen1=e_stat,
+           bwd_vs_gen1=e_ab, pads_zero=pads)
+    assert pads and e_f < 8e-3 and e_gh < 8e-3 and e_x < 2e-2 and e_g < 2e-2 and e_c < 2e-2
+    assert e_stat < 1e-4 and e_ab < 2e-2
+    if p == 0:
+        assert relerr(new["h2"].float(), old["h2"].float()) < 8e-3
+
+
+def test_ffmid_strip_dropout_replay_bf16(ops, dev):
+    """The strip forward's keep-mask is a pure function of (seed, salt, element) and its stored bits are what it applied."""
+    F, nseq, Fp, M = 341, 40, 344, 80
+    g = torch.Generator().manual_seed(11)
+    h1 = torch.randn(M, 2 * Fp, generator=g).to(dev).bfloat16()
+    convw = ops.pack_conv_taps(torch.randn(2 * F, 3, generator=g).to(dev), F, Fp).bfloat16()
+    gamma = ops.pad_vector(torch.ones(F, device=dev), Fp).bfloat16()
+    mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+
+    def run(p, seed, salt=None):
+        out = torch.empty(M, Fp, device=dev, dtype=torch.bfloat16)
+        bits = torch.zeros(M, Fp // 8, dtype=torch.uint8, device=dev)
+        ops.ffmid_fwd(h1, convw, gamma, out, mean, rstd, nseq, F, Fp, p, seed, seed_dev=salt, drop_bits=bits)
+        return out, bits
+    base, _ = run(0.0, 0)
+    a, ba = run(0.1, 1234)
+    b, bb = run(0.1, 1234)
+    c, bc = run(0.1, 99)
+    assert torch.equal(a, b) and torch.equal(ba, bb) and not torch.equal(ba, bc)
+    salt = torch.tensor([5], dtype=torch.int64, device=dev)
+    d, bd = run(0.1, 1234, salt)
+    salt += 1
+    e, be = run(0.1, 1234, salt)
+    assert not torch.equal(bd, ba) and not torch.equal(bd, be)
+    keep = ((ba[:, :, None] >> torch.arange(8, device=dev, dtype=torch.uint8)) & 1).reshape(M, Fp)[:, :F].bool()
+    frac = 1 - keep.float().mean().item()
+    assert abs(frac - 0.1) < 0.01, frac
+    assert bool((a[:, :F][~keep] == 0).all())
+    scale = relerr(a[:, :F][keep].float(), (base[:, :F].float() / 0.9)[keep])
+    # neighbouring rows / chunks must not share masks (the counter really is (row, chunk))
+    assert float((ba[0] == ba[1]).float().mean()) < 0.2 and float((ba[:, 0] == ba[:, 1]).float().mean()) < 0.2
+    report("ffmid_strip_dropout", dropped_frac=frac, scale=scale)
+    assert scale < 1e-2          # bf16 rounding of y * (1 / 0.9) against the rounded base
+
+
 def test_embed_gather_fwd_bwd(ops, dev):
     B, D = 3, 64
     g = torch.Generator().manual_seed(3)

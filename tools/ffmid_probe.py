@@ -1,5 +1,5 @@
-"""Time the ConvFeedForward middle forward at the bench shape (coarse musiclm_small, micro-batch 32) and print checksums, so
-that two builds of the library (OMLM_LIB_PATH) can be compared from two runs."""
+"""Time the ConvFeedForward middle (forward, backward) at the bench shape (coarse musiclm_small, micro-batch 32) for both kernel
+generations in ONE process (ops.ffmid_set_impl), with HIP events, and print achieved HBM GB/s against the algorithmic bytes."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -18,26 +18,38 @@ h1[:, :F] = torch.randn(M, F, generator=g); h1[:, Fp:Fp + F] = torch.randn(M, F,
 h1 = h1.to(dev).to(dt)
 convw = ops.pack_conv_taps((torch.randn(2 * F, 3, generator=g) * 0.5).to(dev), F, Fp).to(dt)
 gamma = ops.pad_vector((1.0 + 0.1 * torch.randn(F, generator=g)).to(dev), Fp).to(dt)
+dh2 = torch.zeros(M, Fp)
+dh2[:, :F] = torch.randn(M, F, generator=g)
+dh2 = dh2.to(dev).to(dt)
+esz = 2 if dt == torch.bfloat16 else 4
 
-def fwd():
-    h2 = torch.full((M, Fp), float("nan"), device=dev, dtype=dt)
-    mean = torch.empty(M, device=dev); rstd = torch.empty(M, device=dev)
-    bits = torch.zeros(M, Fp // 8, device=dev, dtype=torch.uint8)
-    run = lambda: ops.ffmid_fwd(h1, convw, gamma, h2, mean, rstd, nseq, F, Fp, p, 1234, drop_bits=bits)
+
+def timed(run):
     run(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps): run()
     e1.record(); torch.cuda.synchronize()
-    return h2, mean, rstd, bits, e0.elapsed_time(e1) * 1e3 / reps
+    return e0.elapsed_time(e1) * 1e3 / reps
 
-h2, mean, rstd, bits, t = fwd()
-print(f"ffmid_fwd {t:8.1f} us | sum h2 {float(h2.float().sum()):.6e} sum|h2| {float(h2.float().abs().sum()):.6e} "
-      f"sum mean {float(mean.sum()):.6e} sum rstd {float(rstd.sum()):.6e} bits checksum {int(bits.long().sum())}", flush=True)
 
-if os.environ.get("RUN_TESTS") == "1":      # the kernel-level parity tests against the same library build, same process
-    import pytest
-    del h1, h2, bits
-    torch.cuda.empty_cache()
-    rc = pytest.main(["-q", "-x", "-m", "gpu", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "test_gpu_kernels.py"), "-k", "ffmid"])
-    print(f"pytest -k ffmid exit code {int(rc)}", flush=True)
+for impl in ([1, 0] if dt == torch.bfloat16 else [0]):
+    ops.ffmid_set_impl(impl)
+    h2 = torch.full((M, Fp), float("nan"), device=dev, dtype=dt)
+    gh = torch.empty(M, Fp, device=dev, dtype=dt)
+    mean = torch.empty(M, device=dev); rstd = torch.empty(M, device=dev)
+    bits = torch.zeros(M, Fp // 8, device=dev, dtype=torch.uint8)
+    t_f = timed(lambda: ops.ffmid_fwd(h1, convw, gamma, h2, mean, rstd, nseq, F, Fp, p, 1234, drop_bits=bits, gh=gh))
+    fwd_bytes = M * (2 * Fp + Fp + Fp) * esz + M * Fp // 8
+    du = torch.empty(M, 2 * Fp, device=dev, dtype=dt)
+    dh1 = torch.empty(M, 2 * Fp, device=dev, dtype=dt)
+    dgamma, dconv = torch.zeros(F, device=dev), torch.zeros(2 * F * 3, device=dev)
+    ws = torch.empty(ops.ffmid_bwd_workspace_floats(F, Fp), device=dev)
+    t_b = timed(lambda: ops.ffmid_bwd(dh2, h1, convw, gamma, mean, rstd, du, dh1, dgamma, dconv, ws, nseq, F, Fp, p, 1234,
+                                      drop_bits=bits, gh=gh))
+    bwd_bytes = M * (Fp + Fp + 2 * Fp + 2 * Fp) * esz + M * Fp // 8       # dh2, gh, h1 in; dh1 out (no du, no second reads)
+    print(f"impl {impl}: ffmid_fwd {t_f:7.1f} us ({fwd_bytes / t_f / 1e3:6.0f} GB/s of {fwd_bytes / 1e6:.0f} MB) | "
+          f"ffmid_bwd {t_b:7.1f} us ({bwd_bytes / t_b / 1e3:6.0f} GB/s of {bwd_bytes / 1e6:.0f} MB) | "
+          f"sum|h2| {float(h2.float().abs().sum()):.5e} sum|dh1| {float(dh1.float().abs().sum()):.5e} "
+          f"sum|dgamma| {float(dgamma.abs().sum()) / reps:.5e} drop {1 - float((h2[:, :F] != 0).float().mean()):.4f}", flush=True)
+ops.ffmid_set_impl(1)
