@@ -63,14 +63,19 @@ __device__ __forceinline__ void keep_words(unsigned long long seed, unsigned lon
     x = (x ^ (x >> 14)) * 0x85ebca6bu; w[3] = x ^ (x >> 16);
 }
 
+#ifndef FS_R
 #define FS_R 4            // rows per batch of the forward (one barrier per batch)
+#endif
+#ifndef FS_OCC
+#define FS_OCC 1          // workgroups per CU the forward's register budget is sized for
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------
 // forward.  grid: B * strips workgroups of NT threads (NT = chunks of 8 channels rounded up to waves); strip s of sample b
 // covers rows [s * RB, min(nseq, (s + 1) * RB)).
 // ---------------------------------------------------------------------------------------------------------------------
 template <int NT>
-__global__ __launch_bounds__(NT) void ffmid2_fwd_kernel(const bf16_t* __restrict__ h1, const bf16_t* __restrict__ convw,
+__global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kernel(const bf16_t* __restrict__ h1, const bf16_t* __restrict__ convw,
                                                         const bf16_t* __restrict__ gamma, bf16_t* __restrict__ h2,
                                                         float* __restrict__ mean, float* __restrict__ rstd,
                                                         int nseq, int F, int Fp, int RB, int strips, float eps, float p,
