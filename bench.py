@@ -125,7 +125,8 @@ class TrainLeg:
 
     def gemm_roofline(self, k0, traffic=None):
         """HIP events (torch events on the stream the kernels are launched on) around every MFMA GEMM launch of two extra,
-        eager, un-exchanged steps: algorithmic flops of the launches / their summed durations."""
+        eager, un-exchanged steps -- single GEMMs and the grouped weight-gradient launches alike: algorithmic flops of the
+        launches / their summed durations."""
         from open_musiclm_amd import ops
         import open_musiclm_amd.engine as E
         ops_gemm, rec = ops.gemm, []
@@ -136,13 +137,27 @@ class TrainLeg:
             ops_gemm(A, B, C_, M=M, N=N, K=K, **kw)
             e1.record()
             rec.append((e0, e1, 2.0 * M * N * K))
+        # the weight-gradient contractions of a backward go out as grouped launches (ops.WgradGroup.flush): same bookkeeping
+        group_flush = ops.WgradGroup.flush
+
+        def timed_flush(wg, splits=0):
+            if not wg.items:
+                return
+            fl = sum(2.0 * it[4] * it[5] * it[6] for it in wg.items)       # (dY, X, dW, c_map, M, N, K, ...)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            group_flush(wg, splits)
+            e1.record()
+            rec.append((e0, e1, fl))
         E.ops.gemm = timed_gemm
+        ops.WgradGroup.flush = timed_flush
         try:
             for k in range(2):
                 self.step(k0 + k, eager=True, exchange=False)
             torch.cuda.synchronize()
         finally:
             E.ops.gemm = ops_gemm
+            ops.WgradGroup.flush = group_flush
         tot_ms = sum(a.elapsed_time(b) for a, b, _ in rec)
         tot_fl = sum(f for _, _, f in rec)
         big = [(a.elapsed_time(b), f) for a, b, f in rec if f > 1e11]

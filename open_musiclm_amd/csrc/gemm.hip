@@ -452,12 +452,7 @@ __device__ __forceinline__ int xcd_logical_id(int lin, int total) {
 
 // One workgroup's share of C = alpha A B^T (+ Cin).  lg: logical workgroup id inside this problem's (tiles x K-splits, split-major)
 // space; split: partial sums are added to fp32 C with atomics; bal_wgs: workgroup count of the balanced split-K form (BAL only).
-// raw workgroup barrier pinned in the instruction stream (no fence semantics: LDS-DMA in flight survives it, the compiler's own
-// counted lgkmcnt waits stay where the data is used)
-#define PP_BARRIER() do { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); \
-                          asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-
-template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ, bool B_KMAJ, typename TOUT, bool DBG, bool KMAP, bool BAL, bool PP = false>
+template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ, bool B_KMAJ, typename TOUT, bool DBG, bool KMAP, bool BAL>
 __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, const bool split, const int bal_wgs, char* smem) {
     const int dbg = DBG ? g.debug : 0;      // ablation switches exist only in the DBG instantiation (OMLM_GEMM_DEBUG set)
     constexpr int NWN = BN_ / WN_, NWAVES = (BM_ / WM_) * NWN;
@@ -529,85 +524,6 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, 
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-        if constexpr (PP) {
-            // ---- two-group ("ping-pong") k-loop: 256x256 tile, 8 waves of 128x64 --------------------------------------------
-            // Waves 0-3 (group 0) and 4-7 (group 1) sit one per SIMD each.  A k-tile is four phases, one 64x32 quadrant of the
-            // wave's output per phase (8 MFMAs = 256 matrix-pipe cycles); a phase is [load section | barrier | MFMA section |
-            // barrier], and group 1 runs ONE barrier behind group 0, so on every SIMD one wave multiplies while the other
-            // reads its next fragments and issues its share of the next tile's LDS-DMA.  (The one-barrier-per-tile loop below
-            // keeps all 8 waves in lock-step: both waves of a SIMD want LDS, then both want the matrix pipe.)
-            // Barrier b0..b7 of tile t, group 0: L1 b0 M1 b1 L2 b2 M2 b3 L3 b4 M3 b5 L4 b6 M4 b7; group 1: L1 in b0-b1, ...,
-            // L3 in b4-b5, M3 b5-b6, L4 b6-b7, M4 b7-b8.  Fragment reads happen in L1..L3 only, so the stage of tile t-1 is
-            // dead for everybody after b6(t-1); tile t+1's DMA is issued into it in L1..L3 of tile t (both groups: after b7(t-1)),
-            // each wave waits for its own pieces before its last barrier ahead of b7(t) (group 1: end of L4, group 0: end of M4),
-            // and the first read of tile t+1 (group 0, L1) comes after b7(t).
-            static_assert(!PP || (BM_ == 256 && BN_ == 256 && WM_ == 128 && WN_ == 64), "ping-pong schedule: 256x256 tile of 128x64 waves");
-            const bool g1 = wave >= 4;
-            if (kt0 < kt1) {
-                sa.template issue<KMAP>(rsA, g.a_map, g.lda, kt0 * BK, g.K, smem, wave);
-                sb.template issue<KMAP>(rsB, g.b_map, g.ldb, kt0 * BK, g.K, smem + A_BYTES, wave);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            PP_BARRIER();                                   // first tile landed everywhere
-            if (g1) PP_BARRIER();                           // stagger: pairs with group 0's first phase barrier
-            for (int kt = kt0; kt < kt1; ++kt) {
-                const int cur = (kt - kt0) & 1;
-                const bool live = kt + 1 < kt1;
-                char* nxt = smem + (cur ^ 1) * STAGE;
-                const int knext = (kt + 1) * BK;
-                const char* As = smem + cur * STAGE;
-                const char* Bs = As + A_BYTES;
-                bf16x8 a[2][4], b0[4], b1[4];
-#define PP_DMA(L_) do { if ((L_) < UA) sa.template issue_one<KMAP>((L_), rsA, g.a_map, g.lda, knext, g.K, nxt, wave, live); \
-                        else sb.template issue_one<KMAP>((L_) - UA, rsB, g.b_map, g.ldb, knext, g.K, nxt + A_BYTES, wave, live); } while (0)
-                // MFMAs are register-only: nothing but operands orders them against the barriers.  Empty asm statements on the two
-                // accumulators keep both chains below the phase's first barrier and above its second one (hipcc otherwise sinks
-                // the whole section into the next load section); the fragment waits stay hipcc's own counted lgkmcnt ladder.
-#define PP_MMA(I0_, J_, B_) do { __builtin_amdgcn_s_setprio(1); asm volatile("" : "+v"(acc[I0_][J_])); asm volatile("" : "+v"(acc[I0_ + 1][J_])); \
-                        _Pragma("unroll") for (int s = 0; s < 4; ++s) { \
-                        acc[I0_][J_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][s], B_[s], acc[I0_][J_], 0, 0, 0); \
-                        acc[I0_ + 1][J_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][s], B_[s], acc[I0_ + 1][J_], 0, 0, 0); } \
-                        asm volatile("" : "+v"(acc[I0_][J_])); asm volatile("" : "+v"(acc[I0_ + 1][J_])); \
-                        __builtin_amdgcn_s_setprio(0); } while (0)
-                // phase 1: quadrant (rows 0-63, cols 0-31)
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    b0[s] = read_frag<B_KMAJ>(Bs, wn, s, lane);
-                    a[0][s] = read_frag<A_KMAJ>(As, wm, s, lane);
-                    a[1][s] = read_frag<A_KMAJ>(As, wm + 32, s, lane);
-                }
-                PP_DMA(0); PP_DMA(1);
-                PP_BARRIER();
-                PP_MMA(0, 0, b0);
-                PP_BARRIER();
-                // phase 2: (rows 0-63, cols 32-63)
-#pragma unroll
-                for (int s = 0; s < 4; ++s) b1[s] = read_frag<B_KMAJ>(Bs, wn + 32, s, lane);
-                PP_DMA(2); PP_DMA(3); PP_DMA(4);
-                PP_BARRIER();
-                PP_MMA(0, 1, b1);
-                PP_BARRIER();
-                // phase 3: (rows 64-127, cols 32-63)
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    a[0][s] = read_frag<A_KMAJ>(As, wm + 64, s, lane);
-                    a[1][s] = read_frag<A_KMAJ>(As, wm + 96, s, lane);
-                }
-                PP_DMA(5); PP_DMA(6); PP_DMA(7);
-                PP_BARRIER();
-                PP_MMA(2, 1, b1);
-                PP_BARRIER();
-                // phase 4: (rows 64-127, cols 0-31): operands already in registers
-                if (g1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                PP_BARRIER();
-                PP_MMA(2, 0, b0);
-                if (!g1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                PP_BARRIER();
-#undef PP_DMA
-#undef PP_MMA
-            }
-            if (!g1) PP_BARRIER();                          // group 0 waits for group 1's last phase
-        } else {
         if (kt0 < kt1) {
             sa.template issue<KMAP>(rsA, g.a_map, g.lda, kt0 * BK, g.K, smem, wave);
             sb.template issue<KMAP>(rsB, g.b_map, g.ldb, kt0 * BK, g.K, smem + A_BYTES, wave);
@@ -671,7 +587,6 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, 
                 __builtin_amdgcn_sched_barrier(0);                                // ... the MFMAs of step s
             }
         }
-        }
         __syncthreads();
         tile_epilogue<MI, NJ, WN_, TOUT>(g, acc, smem, m0, n0, wm, wn, wave, lane, dbg, bal || split);
         if (!bal || u >= u1) break;
@@ -681,13 +596,13 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, 
 
 // For split-K GEMMs the split-major XCD order puts all co-resident workgroups of an XCD on the SAME K range (they share A and B
 // panels through its L2); with a tile-only remap an XCD held 3 unrelated K ranges at a time (measured L2 hit 48 % on the dW1 GEMM).
-template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ, bool B_KMAJ, typename TOUT, bool DBG, bool KMAP, bool BAL = false, bool PP = false>
+template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ, bool B_KMAJ, typename TOUT, bool DBG, bool KMAP, bool BAL = false>
 __global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A | B]
     const int nwg = gridDim.x;                                     // tiles (plain) / workgroups (balanced)
     const int total = BAL ? (int)gridDim.x : nwg * (int)gridDim.y;
     const int lg = xcd_logical_id(blockIdx.y * nwg + blockIdx.x, total);
-    gemm_tile_body<BM_, BN_, WM_, WN_, A_KMAJ, B_KMAJ, TOUT, DBG, KMAP, BAL, PP>(g, lg, gridDim.y > 1, (int)gridDim.x, smem);
+    gemm_tile_body<BM_, BN_, WM_, WN_, A_KMAJ, B_KMAJ, TOUT, DBG, KMAP, BAL>(g, lg, gridDim.y > 1, (int)gridDim.x, smem);
 }
 
 // ---- grouped weight-gradient GEMM ------------------------------------------------------------------------------------
@@ -700,7 +615,6 @@ struct omlm_gemm_wgrad_desc { const void* A; const void* B; float* C; const int*
 struct GroupProb { const void* A; const void* B; float* C; const int* c_map; int M, N, K, lda, ldb, ldc, kt_per_split, start; };
 struct GroupArgs { int n, total; GroupProb p[OMLM_GROUP_MAX]; };
 
-template <bool PP>
 __global__ __launch_bounds__(512) void gemm_wgrad_group_kernel(GroupArgs ga) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lg = xcd_logical_id(blockIdx.x, ga.total);
@@ -712,17 +626,7 @@ __global__ __launch_bounds__(512) void gemm_wgrad_group_kernel(GroupArgs ga) {
     g.a_rows = q.K; g.b_rows = q.K; g.M = q.M; g.N = q.N; g.K = q.K; g.lda = q.lda; g.ldb = q.ldb; g.ldc = q.ldc; g.ldcin = q.ldc;
     g.alpha = 1.f; g.kt_per_split = q.kt_per_split; g.bal_ck = 0; g.bal_chunks = 0; g.debug = 0;
     const int nk = (q.K + BK - 1) / BK;
-    gemm_tile_body<256, 256, 128, 64, true, true, float, false, false, false, PP>(g, lg - q.start, q.kt_per_split < nk, 0, smem);
-}
-
-// two-group k-loop for the 256x256 tile ($OMLM_GEMM_PP: 1 on, 0 off)
-#ifndef OMLM_GEMM_PP_DEFAULT
-#define OMLM_GEMM_PP_DEFAULT 0
-#endif
-static bool gemm_pp_on() {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("OMLM_GEMM_PP"); on = e ? (e[0] == '1') : OMLM_GEMM_PP_DEFAULT; }
-    return on == 1;
+    gemm_tile_body<256, 256, 128, 64, true, true, float, false, false, false>(g, lg - q.start, q.kt_per_split < nk, 0, smem);
 }
 
 template <int BM_, int BN_, int WM_, int WN_, typename TOUT>
@@ -741,7 +645,6 @@ static int launch_tile(const GemmArgs& g, int a_kmaj, int b_kmaj, int splits, hi
         auto kmap = gemm_bf16_tile_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT, false, (AK || BKM) && BM_ == 128>;            \
         auto kbal = gemm_bf16_tile_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT, false, false, sizeof(TOUT) == 4>;            \
         auto kbalmap = gemm_bf16_tile_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT, false, (AK || BKM) && BM_ == 128, sizeof(TOUT) == 4>; \
-        auto kpp = gemm_bf16_tile_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT, false, false, false, BM_ == 256 && BN_ == 256>;  \
         static bool attr = false;                                                                                           \
         if (!attr) {                                                                                                        \
             (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);             \
@@ -749,13 +652,11 @@ static int launch_tile(const GemmArgs& g, int a_kmaj, int b_kmaj, int splits, hi
             (void)hipFuncSetAttribute((const void*)kmap, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);            \
             (void)hipFuncSetAttribute((const void*)kbal, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);            \
             (void)hipFuncSetAttribute((const void*)kbalmap, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);         \
-            (void)hipFuncSetAttribute((const void*)kpp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);             \
             attr = true;                                                                                                    \
         }                                                                                                                   \
         if (g.bal_ck > 0 && sizeof(TOUT) == 4) hipLaunchKernelGGL(need_kmap ? kbalmap : kbal, grid, block, LDS, st, g);    \
         else if (need_kmap) hipLaunchKernelGGL(kmap, grid, block, LDS, st, g);                                             \
         else if (g.debug) hipLaunchKernelGGL(kdbg, grid, block, LDS, st, g);                                               \
-        else if (BM_ == 256 && BN_ == 256 && gemm_pp_on()) hipLaunchKernelGGL(kpp, grid, block, LDS, st, g);               \
         else              hipLaunchKernelGGL(kfn, grid, block, LDS, st, g);                                                \
     } while (0)
     if (!a_kmaj && !b_kmaj)      OMLM_TILE_LAUNCH(false, false);
@@ -924,11 +825,7 @@ extern "C" int omlm_gemm_wgrad_group(const omlm_gemm_wgrad_desc* d, int count, i
         else ncu = 256;
     }
     static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_wgrad_group_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        (void)hipFuncSetAttribute((const void*)gemm_wgrad_group_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        attr = true;
-    }
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_wgrad_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); attr = true; }
     { const char* e = getenv("OMLM_GROUP_SPLITS"); if (e && atoi(e) > 0) splits = atoi(e); }
     for (int base = 0; base < count; base += OMLM_GROUP_MAX) {
         const int n = count - base < OMLM_GROUP_MAX ? count - base : OMLM_GROUP_MAX;
@@ -973,8 +870,7 @@ extern "C" int omlm_gemm_wgrad_group(const omlm_gemm_wgrad_desc* d, int count, i
             start += ((q.M + 255) / 256) * ((q.N + 255) / 256) * s_eff;
         }
         ga.total = start;
-        if (gemm_pp_on()) hipLaunchKernelGGL(gemm_wgrad_group_kernel<true>, dim3(start), dim3(512), 131072, as_stream(stream), ga);
-        else hipLaunchKernelGGL(gemm_wgrad_group_kernel<false>, dim3(start), dim3(512), 131072, as_stream(stream), ga);
+        hipLaunchKernelGGL(gemm_wgrad_group_kernel, dim3(start), dim3(512), 131072, as_stream(stream), ga);
     }
     return omlm_post_launch("omlm_gemm_wgrad_group");
 }

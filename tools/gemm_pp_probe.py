@@ -1,5 +1,5 @@
-"""Time and CHECK the large GEMM shapes of a coarse-small train step under the current $OMLM_GEMM_PP setting
-(0: one-barrier k-loop, 1: two-group ping-pong k-loop).  Each shape is verified against a torch bf16 matmul (fp32 accumulate)
+"""Time and CHECK the large GEMM shapes of a coarse-small train step.  (Written for the A/B of the two-group ping-pong k-loop,
+profiles/r02_gemm_pingpong_ab.md -- that loop was slower and is gone; $OMLM_GEMM_PP is only echoed now.)  Each shape is verified against a torch bf16 matmul (fp32 accumulate)
 on several seeds -- a race in the LDS staging shows up as a wrong tile -- then timed with HIP events.
 Run twice:  OMLM_GEMM_PP=0 python tools/gemm_pp_probe.py ; OMLM_GEMM_PP=1 python tools/gemm_pp_probe.py"""
 import os, sys
