@@ -29,6 +29,20 @@ _PRECISIONS = {"bf16": torch.bfloat16, "bf16x3": torch.float32}
 _WT = os.environ.get("OMLM_WT", "0") == "1"
 _FF_SAVE_GH = os.environ.get("OMLM_FF_SAVE_GH", "1") == "1"        # forward keeps the normalised GEGLU output for the backward (bf16 mode)
 _WGRAD_GROUP = os.environ.get("OMLM_WGRAD_GROUP", "1") == "1"      # grouped weight-gradient GEMMs (0: one split-K GEMM per weight)
+# The rel-pos-bias MLP (transformer.py:36-67: 3 x Linear(dim/2)+SiLU + Linear(heads) on N distances) is ~20 tiny fp32 kernels per
+# step, 4..36 workgroups each: ~0.4 ms of pure launch-to-launch latency when they sit in the trunk's stream.  They depend on
+# nothing but the weights (forward) / the finished d(table) (backward), so they run on a second HIP stream, forked and joined with
+# events (captured as a parallel branch of the micro-step graph).  OMLM_RELPOS_ASYNC=0 puts them back in line.
+_RELPOS_ASYNC = os.environ.get("OMLM_RELPOS_ASYNC", "1") == "1"
+_SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def side_stream(dev: torch.device) -> "torch.cuda.Stream":
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = _SIDE_STREAMS.get(idx)
+    if st is None:
+        st = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=dev)
+    return st
 
 
 def default_precision() -> str:
@@ -296,7 +310,15 @@ def trunk_forward(tr, pw: PreparedWeights, x: torch.Tensor, keymask: Optional[to
     dev = x.device
     M, D = x.shape
     H = tr.heads
-    table, rp_saved = relpos_forward(tr, N, save)
+    side = None
+    if _RELPOS_ASYNC and tr.rel_pos_bias is not None and tr.relative_position_bias_type != "t5":
+        main = torch.cuda.current_stream(dev)
+        side = side_stream(dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            table, rp_saved = relpos_forward(tr, N, save)       # joined in front of the first attention kernel
+    else:
+        table, rp_saved = relpos_forward(tr, N, save)
     saved_layers: List[LayerSaved] = []
     salt, seeds = (None, None)
     if training and any(float(ff.dropout_p) > 0 for _, _, ff in tr.layers):
@@ -318,6 +340,9 @@ def trunk_forward(tr, pw: PreparedWeights, x: torch.Tensor, keymask: Optional[to
         ops.qk_norm_fwd(q_raw, kv_raw, attn.q_scale.detach(), attn.k_scale.detach(), q, k, v, H)
         o = torch.empty(M, H * DIM_HEAD, dtype=T, device=dev)
         lse = torch.empty(B, H, N, device=dev)
+        if side is not None:
+            torch.cuda.current_stream(dev).wait_stream(side)
+            side = None
         # the layer's bias table in the kernels' layout, with the fixed softmax reference point its scales allow
         abias = ops.AttnBias(table, N, H, dev, q_scale=attn.q_scale.detach(), k_scale=attn.k_scale.detach(), scale=ATTN_SCALE)
         ops.attn_fwd(q, k, v, abias, keymask, o, lse, B, N, H, ATTN_SCALE)
@@ -348,6 +373,8 @@ def trunk_forward(tr, pw: PreparedWeights, x: torch.Tensor, keymask: Optional[to
             sv.gh = gh
             saved_layers.append(sv)
         x = x2
+    if side is not None:                                         # depth 0: nothing consumed the table
+        torch.cuda.current_stream(dev).wait_stream(side)
     mf = torch.empty(M, device=dev); rf = torch.empty(M, device=dev)
     y = torch.empty(M, D, dtype=T, device=dev)
     ops.layernorm_fwd(x, tr.norm.gamma.detach(), y, None, mf, rf)
@@ -365,6 +392,8 @@ def trunk_backward(tr, pw: PreparedWeights, saved, dy: torch.Tensor, B: int, N: 
     table, keymask = saved["table"], saved["keymask"]
     dtable = torch.zeros_like(table) if table is not None else None
     nl = len(saved["layers"])
+    rp_async = (_RELPOS_ASYNC and nl > 0 and dtable is not None and saved["rp"] is not None and saved["rp"][0] == "mlp")
+    rp_side = None
     dres = torch.empty(M, D, device=dev)
     dres_c = dres if T == torch.float32 else torch.empty(M, D, dtype=T, device=dev)
     ops.layernorm_bwd(dy, saved["xL"], tr.norm.gamma.detach(), saved["mf"], saved["rf"], None, dres,
@@ -423,6 +452,13 @@ def trunk_backward(tr, pw: PreparedWeights, saved, dy: torch.Tensor, B: int, N: 
         dv = torch.empty(M, DIM_HEAD, device=dev)
         delta = torch.empty(B, H, N, device=dev)
         ops.attn_bwd(sv.q, sv.k, sv.v, sv.abias, keymask, sv.o, do, sv.lse, delta, dq, dk, dv, dtable, B, N, H, ATTN_SCALE)
+        if li == 0 and rp_async:
+            # d(table) is complete: the MLP's backward leaves for the second stream while the trunk finishes this layer and the
+            # grouped weight gradients (dtable / saved["rp"] stay referenced until the join at the end of this function)
+            rp_side = side_stream(dev)
+            rp_side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(rp_side):
+                relpos_backward(tr, N, saved["rp"], dtable)
         dq_raw = torch.empty(M, H * DIM_HEAD, dtype=T, device=dev)
         dkv_raw = torch.empty(M, 2 * DIM_HEAD, dtype=T, device=dev)
         ops.qk_norm_bwd(dq, dk, dv, sv.q_raw, sv.kv_raw, attn.q_scale.detach(), attn.k_scale.detach(),
@@ -447,7 +483,9 @@ def trunk_backward(tr, pw: PreparedWeights, saved, dy: torch.Tensor, B: int, N: 
                           dx_scale=out_scale if last else 1.0)
     if wg is not None:
         wg.flush()
-    if dtable is not None and saved["rp"] is not None:
+    if rp_side is not None:
+        torch.cuda.current_stream(dev).wait_stream(rp_side)
+    elif dtable is not None and saved["rp"] is not None:
         relpos_backward(tr, N, saved["rp"], dtable)
     return dres
 
