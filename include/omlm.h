@@ -155,6 +155,18 @@ int omlm_bias_add(const float* a, const float* b, float* out, int R, int C, int 
 int omlm_rvq_encode(const float* x, const float* codebooks_T, int* indices, float* residual_out,
                     int n, int D, int C, int nstage, void* stream);
 int omlm_nearest_centroid(const float* x, const float* centroids_T, int* indices, int n, int D, int C, void* stream);
+int omlm_rvq_encode_strided(const float* x, const float* codebook_T, int* indices, int idx_stride, float* residual_out,
+                            int n, int D, int C, void* stream);
+/* Fitting side of the residual VQ (reference call sites: trainer.py:689-736 -> clap_quantized.py:75-84 with rq.train(True); the
+ * arithmetic is vector-quantize-pytorch's EuclideanCodebook, un-vendored: parity unpinned, oracle.rvq_fit_step restates it).
+ * accumulate: counts[k] += #rows assigned to k, sums[k, :] += those rows (caller zeroes both; indices[i * idx_stride]).
+ * kmeans_update: means[k] = sums[k] / counts[k] where counts[k] > 0 (Lloyd step), means_T [D, K] refreshed.
+ * ema_update: cluster_size = d cs + (1-d) counts; embed_avg = d avg + (1-d) sums; embed = embed_avg / Laplace-smoothed sizes
+ * ((cs + eps) / (sum cs + K eps) * sum cs); embed_T [D, K] refreshed; total_scratch: one device float. */
+int omlm_vq_accumulate(const float* x, const int* indices, int idx_stride, float* counts, float* sums, int n, int D, int K, void* stream);
+int omlm_vq_kmeans_update(float* means, float* means_T, const float* counts, const float* sums, int K, int D, void* stream);
+int omlm_vq_ema_update(float* cluster_size, float* embed_avg, float* embed, float* embed_T, const float* counts, const float* sums,
+                       float* total_scratch, int K, int D, float decay, float eps, void* stream);
 
 /* AR sampler: eos suppression + top_k(thres) + gumbel_sample (open_musiclm.py:309-316; utils.py:65-84). */
 int omlm_sample_topk_gumbel(const float* logits, const float* uniform, long long* out, int B, int V, int ld,

@@ -1,7 +1,9 @@
 """ClapQuantized (reference open_musiclm/clap_quantized.py).  The frozen CLAP towers are third-party pretrained
 networks outside the hot path; what IS on the path is ``quantize``: the residual-VQ nearest-codeword chain,
 which runs as one HIP kernel (omlm_rvq_encode) and is bit-exact against the stated definition in
-oracle/musiclm_oracle.py::rvq_encode (RVQ parity is unpinned against the un-vendored vector-quantize-pytorch)."""
+oracle/musiclm_oracle.py::rvq_encode (RVQ parity is unpinned against the un-vendored vector-quantize-pytorch).
+``learn_rvq=True`` fits the codebooks (what scripts/train_clap_rvq.py drives through ClapRVQTrainer) with the kernels of
+csrc/vq_fit.hip, checked against oracle.rvq_fit_step."""
 from __future__ import annotations
 
 from typing import List, Optional, Union
@@ -10,24 +12,59 @@ import torch
 from torch import nn
 
 from . import ops
+from .hip import require_gpu
 from .utils import exists
 
 
 class ResidualVQCodebooks(nn.Module):
-    """Inference-side stand-in for vector_quantize_pytorch.ResidualVQ: holds the codebooks under the
-    library's checkpoint keys (layers.{s}._codebook.embed [1, C, D]) and encodes with the HIP kernel."""
+    """Stand-in for vector_quantize_pytorch.ResidualVQ (un-vendored, un-pinned: parity unpinned, see oracle.rvq_fit_step): holds
+    the codebooks and their EMA statistics, reads / writes the library's checkpoint keys
+    (layers.{s}._codebook.{initted, cluster_size [1, K], embed [1, K, D], embed_avg [1, K, D]}), encodes with the HIP
+    nearest-codeword kernel and -- in training mode -- runs the library's fit step (k-means init on the first batch, EMA
+    codebook update, dead-code re-seeding) on the device (csrc/vq_fit.hip)."""
 
-    def __init__(self, *, dim, num_quantizers, codebook_size):
+    def __init__(self, *, dim, num_quantizers, codebook_size, decay: float = 0.95, eps: float = 1e-5, kmeans_iters: int = 10,
+                 threshold_ema_dead_code: float = 0.0):
         super().__init__()
         self.dim, self.num_quantizers, self.codebook_size = dim, num_quantizers, codebook_size
+        self.decay, self.eps, self.kmeans_iters, self.threshold_ema_dead_code = decay, eps, kmeans_iters, threshold_ema_dead_code
         self.register_buffer("codebooks", torch.zeros(num_quantizers, codebook_size, dim))
+        self.register_buffer("embed_avg", torch.zeros(num_quantizers, codebook_size, dim))
+        self.register_buffer("cluster_size", torch.zeros(num_quantizers, codebook_size))
+        self.register_buffer("initted", torch.zeros(num_quantizers, dtype=torch.bool))
         self._cbT = None
+        # test hooks: (n, K) -> LongTensor [K] of row indices (initial k-means means / dead-code re-seeds); default: device RNG
+        self.init_pick_source = None
+        self.expire_pick_source = None
+
+    # ---- checkpoints in the library's layout (what trainer.py:731 saves and clap_quantized.py:109 loads) -----------------
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        sd = destination if destination is not None else {}
+        for s in range(self.num_quantizers):
+            p = f"{prefix}layers.{s}._codebook."
+            sd[p + "initted"] = self.initted[s:s + 1].detach().clone()
+            sd[p + "cluster_size"] = self.cluster_size[s:s + 1].detach().clone()
+            sd[p + "embed"] = self.codebooks[s:s + 1].detach().clone()
+            sd[p + "embed_avg"] = self.embed_avg[s:s + 1].detach().clone()
+        return sd
 
     def load_state_dict(self, sd, strict=True):
-        if "codebooks" in sd:
-            return super().load_state_dict(sd, strict=strict)
+        if "codebooks" in sd:                                        # this module's own buffer names
+            for k in ("codebooks", "embed_avg", "cluster_size", "initted"):
+                if k in sd:
+                    getattr(self, k).copy_(sd[k])
+            if "initted" not in sd:
+                self.initted.fill_(True)
+            self._cbT = None
+            return None
         for s in range(self.num_quantizers):                      # vector-quantize-pytorch layout
-            self.codebooks[s].copy_(sd[f"layers.{s}._codebook.embed"].reshape(self.codebook_size, self.dim))
+            p = f"layers.{s}._codebook."
+            self.codebooks[s].copy_(sd[p + "embed"].reshape(self.codebook_size, self.dim))
+            if p + "embed_avg" in sd:
+                self.embed_avg[s].copy_(sd[p + "embed_avg"].reshape(self.codebook_size, self.dim))
+            if p + "cluster_size" in sd:
+                self.cluster_size[s].copy_(sd[p + "cluster_size"].reshape(self.codebook_size))
+            self.initted[s] = bool(sd[p + "initted"].reshape(-1)[0]) if p + "initted" in sd else True
         self._cbT = None
         return None
 
@@ -45,17 +82,71 @@ class ResidualVQCodebooks(nn.Module):
         ops.rvq_encode(x, self._transposed(), idx, None, n, self.dim, self.codebook_size, self.num_quantizers)
         return idx.long()
 
+    def _picks(self, source, n: int, device) -> torch.Tensor:
+        K = self.codebook_size
+        if source is not None:
+            return source(n, K).to(device).long()
+        if n >= K:
+            return torch.randperm(n, device=device)[:K]
+        return torch.randint(0, n, (K,), device=device)
+
+    @torch.no_grad()
+    def fit_step(self, x: torch.Tensor):
+        """Training-mode forward of the library (ClapQuantized.quantize with learn_rvq, clap_quantized.py:75-84): returns
+        (indices [n, S] int64, quantized sum [n, D]) and updates codebooks / EMA statistics in place."""
+        x = x.contiguous().float()
+        require_gpu(x, "RVQ embeddings")
+        n, D, K, S = x.shape[0], self.dim, self.codebook_size, self.num_quantizers
+        dev = x.device
+        idx = torch.empty(n, S, dtype=torch.int32, device=dev)
+        r = x.clone()
+        r_next = torch.empty_like(r)
+        counts = torch.empty(K, device=dev)
+        sums = torch.empty(K, D, device=dev)
+        total = torch.empty(1, device=dev)
+        cbT = self._transposed().clone()                               # [S, D, K]; kept in step with the codebooks below
+        one = torch.empty(n, dtype=torch.int32, device=dev)
+
+        def assign_accumulate(codes_T, out_idx, stride, resid):
+            ops.rvq_encode(r, codes_T, out_idx, resid, n, D, K, 1, idx_stride=stride)
+            counts.zero_(); sums.zero_()
+            ops.vq_accumulate(r, out_idx, stride, counts, sums, n, D, K)
+
+        for s in range(S):
+            if not bool(self.initted[s]):
+                self.codebooks[s].copy_(r[self._picks(self.init_pick_source, n, dev)])
+                cbT[s].copy_(self.codebooks[s].t())
+                for _ in range(self.kmeans_iters):
+                    assign_accumulate(cbT[s], one, 1, None)
+                    ops.vq_kmeans_update(self.codebooks[s], cbT[s], counts, sums, K, D)
+                self.cluster_size[s].copy_(counts)                     # the library's `bins`: bucket sizes of the last iteration
+                self.embed_avg[s].copy_(self.codebooks[s] * counts[:, None])
+                self.initted[s] = True
+            assign_accumulate(cbT[s], idx[:, s], S, r_next)            # r_next = r - e_idx with the codes BEFORE the update
+            ops.vq_ema_update(self.cluster_size[s], self.embed_avg[s], self.codebooks[s], cbT[s], counts, sums, total, K, D,
+                              self.decay, self.eps)
+            if self.threshold_ema_dead_code > 0:
+                dead = self.cluster_size[s] < self.threshold_ema_dead_code
+                if bool(dead.any()):
+                    samp = r[self._picks(self.expire_pick_source, n, dev)]
+                    self.codebooks[s][dead] = samp[dead]
+                    self.cluster_size[s][dead] = self.threshold_ema_dead_code
+                    self.embed_avg[s][dead] = samp[dead] * self.threshold_ema_dead_code
+                    cbT[s].copy_(self.codebooks[s].t())
+            r, r_next = r_next, r
+        self._cbT = None
+        return idx.long(), x - r
+
 
 class ClapQuantized(nn.Module):
     def __init__(self, *, clap=None, codebook_size: int = 1024, rq_num_quantizers: int = 12, rq_ema_decay: float = 0.95,
                  learn_rvq: bool = False, threshold_ema_dead_code: float = 0.0, embed_dim: Optional[int] = None):
         super().__init__()
-        if learn_rvq:
-            raise NotImplementedError("RVQ fitting (EMA k-means) is outside the hot path; load a trained codebook")
         self.clap, self.codebook_size, self.learn_rvq = clap, codebook_size, learn_rvq
         self.sample_rate = clap.model_cfg['audio_cfg']['sample_rate'] if exists(clap) else 48000
         dim = embed_dim if exists(embed_dim) else (clap.model.joint_embed_shape if exists(clap) else 512)
-        self.rq = ResidualVQCodebooks(dim=dim, num_quantizers=rq_num_quantizers, codebook_size=codebook_size)
+        self.rq = ResidualVQCodebooks(dim=dim, num_quantizers=rq_num_quantizers, codebook_size=codebook_size, decay=rq_ema_decay,
+                                      threshold_ema_dead_code=threshold_ema_dead_code)
 
     def forward(self, *, audio_input=None, text_input: Optional[List[str]] = None, return_embedding=False,
                 return_rvq_loss=False):
@@ -68,11 +159,17 @@ class ClapQuantized(nn.Module):
         return emb if return_embedding else self.quantize(emb, return_rvq_loss=return_rvq_loss)
 
     def quantize(self, embedding, return_rvq_loss=False):
-        """clap_quantized.py:75-87: [n, D] -> indices [n, num_quantizers, 1]."""
-        idx = self.rq.encode(embedding)
+        """clap_quantized.py:75-87: [n, D] -> indices [n, num_quantizers, 1].  With learn_rvq the residual VQ runs in training
+        mode (rq.train(True), :79-81): k-means init on the first batch, then one EMA codebook update per call."""
+        if self.learn_rvq:
+            idx, q = self.rq.fit_step(embedding)
+        else:
+            idx = self.rq.encode(embedding)
+            q = None
         if return_rvq_loss:
-            q = torch.stack([self.rq.codebooks[s][idx[:, s]] for s in range(idx.shape[1])]).sum(0)
-            return torch.nn.functional.mse_loss(q, embedding).item()
+            if q is None:
+                q = torch.stack([self.rq.codebooks[s][idx[:, s]] for s in range(idx.shape[1])]).sum(0)
+            return torch.nn.functional.mse_loss(q, embedding.float()).item()
         return idx.unsqueeze(-1)
 
 

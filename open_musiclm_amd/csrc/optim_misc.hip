@@ -212,7 +212,7 @@ extern "C" int omlm_relpos_first_bwd(const float* ds, float* dw0, int n, int Hd,
 // consecutive threads (codes) read consecutive addresses.
 __global__ __launch_bounds__(256) void rvq_kernel(const float* __restrict__ x, const float* __restrict__ cbT,
                                                   int* __restrict__ idx_out, float* __restrict__ resid_out,
-                                                  int n, int D, int C, int nstage) {
+                                                  int n, int D, int C, int nstage, int idx_stride) {
     extern __shared__ float r[];                  // [D] running residual
     __shared__ float bd[4];
     __shared__ int bi[4];
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void rvq_kernel(const float* __restrict__ x, c
             float b = bd[0]; int i0 = bi[0];
             for (int w = 1; w < 4; ++w) if (bd[w] < b || (bd[w] == b && bi[w] < i0)) { b = bd[w]; i0 = bi[w]; }
             chosen = i0;
-            idx_out[(size_t)row * nstage + s] = i0;
+            idx_out[(size_t)row * idx_stride + s] = i0;
         }
         __syncthreads();
         const int ci = chosen;
@@ -260,8 +260,18 @@ extern "C" int omlm_rvq_encode(const float* x, const float* codebooks_T, int* in
     if (n <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(x && codebooks_T && indices && D > 0 && C > 0 && nstage > 0, "rvq arguments");
     OMLM_CHECK_ARG((size_t)D * sizeof(float) <= 48 * 1024, "D too large");
-    hipLaunchKernelGGL(rvq_kernel, dim3(n), dim3(256), D * sizeof(float), as_stream(stream), x, codebooks_T, indices, residual_out, n, D, C, nstage);
+    hipLaunchKernelGGL(rvq_kernel, dim3(n), dim3(256), D * sizeof(float), as_stream(stream), x, codebooks_T, indices, residual_out, n, D, C, nstage, nstage);
     return omlm_post_launch("omlm_rvq_encode");
+}
+// one stage, index of row i written to indices[i * idx_stride] (a column of an [n, stages] table: the RVQ fit step walks the layers
+// one launch at a time because every layer's codebook changes between its assignment and the next layer's)
+extern "C" int omlm_rvq_encode_strided(const float* x, const float* codebook_T, int* indices, int idx_stride, float* residual_out,
+                                       int n, int D, int C, void* stream) {
+    if (n <= 0) return OMLM_OK;
+    OMLM_CHECK_ARG(x && codebook_T && indices && D > 0 && C > 0 && idx_stride >= 1, "rvq arguments");
+    OMLM_CHECK_ARG((size_t)D * sizeof(float) <= 48 * 1024, "D too large");
+    hipLaunchKernelGGL(rvq_kernel, dim3(n), dim3(256), D * sizeof(float), as_stream(stream), x, codebook_T, indices, residual_out, n, D, C, 1, idx_stride);
+    return omlm_post_launch("omlm_rvq_encode_strided");
 }
 extern "C" int omlm_nearest_centroid(const float* x, const float* centroids_T, int* indices, int n, int D, int C, void* stream) {
     return omlm_rvq_encode(x, centroids_T, indices, nullptr, n, D, C, 1, stream);

@@ -59,6 +59,10 @@ SIGNATURES = {
     "omlm_bias_add": [vp, vp, vp, i32, i32, i32, vp],
     "omlm_rvq_encode": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "omlm_nearest_centroid": [vp, vp, vp, i32, i32, i32, vp],
+    "omlm_rvq_encode_strided": [vp, vp, vp, i32, vp, i32, i32, i32, vp],
+    "omlm_vq_accumulate": [vp, vp, i32, vp, vp, i32, i32, i32, vp],
+    "omlm_vq_kmeans_update": [vp, vp, vp, vp, i32, i32, vp],
+    "omlm_vq_ema_update": [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, vp],
     "omlm_sample_topk_gumbel": [vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
     "omlm_probe_tr16": [vp, vp],
 }

@@ -275,8 +275,27 @@ def bias_add(a, b, out, R, C_, ld):
     call("omlm_bias_add", ptr(a), ptr(b), ptr(out), R, C_, ld, stream_ptr())
 
 
-def rvq_encode(x, codebooks_T, indices, residual_out, n, D, C_, nstage):
-    call("omlm_rvq_encode", ptr(x), ptr(codebooks_T), ptr(indices), ptr(residual_out), n, D, C_, nstage, stream_ptr())
+def rvq_encode(x, codebooks_T, indices, residual_out, n, D, C_, nstage, idx_stride=None):
+    """indices: int32 [n, nstage] (or, with nstage == 1, any int32 view whose rows are idx_stride elements apart)."""
+    if idx_stride is None or idx_stride == nstage:
+        call("omlm_rvq_encode", ptr(x), ptr(codebooks_T), ptr(indices), ptr(residual_out), n, D, C_, nstage, stream_ptr())
+    else:
+        assert nstage == 1
+        call("omlm_rvq_encode_strided", ptr(x), ptr(codebooks_T), ptr(indices), int(idx_stride), ptr(residual_out), n, D, C_,
+             stream_ptr())
+
+
+def vq_accumulate(x, indices, idx_stride, counts, sums, n, D, K):
+    call("omlm_vq_accumulate", ptr(x), ptr(indices), int(idx_stride), ptr(counts), ptr(sums), n, D, K, stream_ptr())
+
+
+def vq_kmeans_update(means, means_T, counts, sums, K, D):
+    call("omlm_vq_kmeans_update", ptr(means), ptr(means_T), ptr(counts), ptr(sums), K, D, stream_ptr())
+
+
+def vq_ema_update(cluster_size, embed_avg, embed, embed_T, counts, sums, total_scratch, K, D, decay, eps):
+    call("omlm_vq_ema_update", ptr(cluster_size), ptr(embed_avg), ptr(embed), ptr(embed_T), ptr(counts), ptr(sums),
+         ptr(total_scratch), K, D, float(decay), float(eps), stream_ptr())
 
 
 def sample_topk_gumbel(logits, uniform, out, V, k, temperature, forbid_last):

@@ -367,10 +367,119 @@ class SingleStageTrainer(nn.Module):
 
 
 class ClapRVQTrainer(nn.Module):
-    """Out of scope for the hot path: one-off quantizer fitting needing pretrained CLAP + audio."""
+    """Learn the residual vector quantizer that turns CLAP embeddings into discrete tokens (trainer.py:564-741).
 
-    def __init__(self, *a, **k):
-        raise NotImplementedError("ClapRVQTrainer is outside the MI355X TokenConditionedTransformer hot path")
+    Same constructor and step contract as the reference: every step accumulates ``accumulate_batches`` batches of embeddings,
+    concatenates them over ranks, and rank 0 runs ONE training-mode pass of the residual VQ over them
+    (``audio_conditioner.quantize(embeds, return_rvq_loss=True)`` with ``learn_rvq``: k-means init on the first pass, then EMA
+    codebook updates -- csrc/vq_fit.hip); ``clap.rvq.{steps}.pt`` checkpoints carry the library's key layout.
+    The CLAP towers are third-party pretrained networks that are not part of this build: when ``audio_conditioner.clap`` is None
+    the dataset must yield the embeddings themselves ([D] or [n, D] float tensors, e.g. precomputed CLAP embeddings)."""
+
+    def __init__(self, *, num_train_steps, batch_size, accumulate_batches: Optional[int] = None, audio_conditioner=None,
+                 dataset: Optional[Dataset] = None, ignore_files: Optional[List[str]] = None, ignore_load_errors: bool = True,
+                 folder=None, wd=0., max_grad_norm=0.5, data_max_length_seconds=10, valid_frac=0.05, random_split_seed=42,
+                 save_results_every=100, save_model_every=1000, results_folder='./results', accelerate_kwargs: dict = {},
+                 config_paths: Optional[List[str]] = None):
+        super().__init__()
+        assert exists(audio_conditioner), 'audio_conditioner (ClapQuantized) must be passed in'
+        dev = audio_conditioner.rq.codebooks.device
+        self.dp = DataParallel(device=dev)
+        self.log_with = accelerate_kwargs.get('log_with')
+        self.logging_dir = accelerate_kwargs.get('logging_dir') or accelerate_kwargs.get('project_dir')
+        self.audio_conditioner = audio_conditioner
+        self.embeds_in = not exists(getattr(audio_conditioner, 'clap', None))
+        self.ds = dataset
+        self.num_train_steps = num_train_steps
+        self.accumulate_batches = accumulate_batches
+        self.register_buffer('steps', torch.Tensor([0]))
+        if not exists(self.ds):
+            assert exists(folder), 'folder must be passed in, if not passing in a custom dataset for text conditioned audio synthesis training'
+            self.ds = SoundDataset(folder, max_length_seconds=data_max_length_seconds, target_sample_hz=audio_conditioner.sample_rate,
+                                   seq_len_multiple_of=None, ignore_files=default(ignore_files, []), ignore_load_errors=ignore_load_errors)
+        if valid_frac > 0:
+            train_size = int((1 - valid_frac) * len(self.ds))
+            valid_size = len(self.ds) - train_size
+            self.ds, self.valid_ds = random_split(self.ds, [train_size, valid_size],
+                                                  generator=torch.Generator().manual_seed(random_split_seed))
+            self.print(f'training with dataset of {len(self.ds)} samples and validating with randomly splitted {len(self.valid_ds)} samples')
+        else:
+            self.valid_ds = self.ds
+            self.print(f'training with shared training and valid dataset of {len(self.ds)} samples')
+        self.dl = get_dataloader(self.ds, batch_size=batch_size, shuffle=True)
+        self.valid_dl = get_dataloader(self.valid_ds, batch_size=batch_size, shuffle=True)
+        self.dl_iter, self.valid_dl_iter = cycle(self.dl), cycle(self.valid_dl)
+        self.save_model_every, self.save_results_every = save_model_every, save_results_every
+        self.results_folder = Path(results_folder)
+        if self.is_main and len([*self.results_folder.glob('**/*')]) > 0 and \
+                yes_or_no('do you want to clear previous experiment checkpoints and results?'):
+            rmtree(str(self.results_folder))
+        self.results_folder.mkdir(parents=True, exist_ok=True)
+        hps = {"num_train_steps": num_train_steps, "batch_size": batch_size, "accumulate_batches": accumulate_batches}
+        self.tracker = _JsonlTracker(self.logging_dir, "clap_rvq", hps, self.is_main and exists(self.log_with))
+        if self.is_main and exists(config_paths):
+            configs_folder = self.results_folder / "configs"
+            configs_folder.mkdir(parents=True, exist_ok=True)
+            for config_path in config_paths:
+                copy_file_to_folder(config_path, configs_folder)
+
+    def print(self, msg):
+        if self.is_main:
+            print(msg)
+
+    @property
+    def device(self):
+        return self.audio_conditioner.rq.codebooks.device
+
+    @property
+    def is_distributed(self):
+        return self.dp.is_distributed
+
+    @property
+    def is_main(self):
+        return self.dp.rank == 0
+
+    @property
+    def is_local_main(self):
+        return self.dp.local_rank == 0
+
+    def _embed(self, batch) -> torch.Tensor:
+        item = batch[0] if isinstance(batch, (list, tuple)) else batch
+        if self.embeds_in:
+            emb = item.to(self.device).float()
+            return emb.reshape(-1, emb.shape[-1])
+        return self.audio_conditioner.forward(audio_input=item.to(self.device), return_embedding=True)
+
+    def train_step(self):
+        steps = int(self.steps.item())
+        self.audio_conditioner.learn_rvq = True
+        iters = default(self.accumulate_batches, 1)
+        iters = -(-iters // self.dp.world_size)
+        embeds = torch.cat([self._embed(next(self.dl_iter)) for _ in range(iters)], dim=0)
+        embeds = self.dp.all_gather_cat(embeds.contiguous())
+        logs = {}
+        if self.is_main:
+            loss = self.audio_conditioner.quantize(embeds, return_rvq_loss=True)
+            self.print(f'loss: {loss}')
+            valid_loss = None
+            if not (steps % self.save_results_every):
+                with torch.no_grad():
+                    self.audio_conditioner.learn_rvq = False
+                    valid_loss = self.audio_conditioner.quantize(self._embed(next(self.valid_dl_iter)), return_rvq_loss=True)
+                self.print(f'{steps}: valid loss {valid_loss}')
+            logs = {"train_loss": loss, "valid_loss": valid_loss}
+            self.tracker.log(logs, step=steps)
+            if not (steps % self.save_model_every):
+                torch.save(self.audio_conditioner.rq.state_dict(), str(self.results_folder / f'clap.rvq.{steps}.pt'))
+                self.print(f'{steps}: saving model to {str(self.results_folder)}')
+        self.steps += 1
+        return logs
+
+    def train(self, log_fn=noop):
+        while self.steps < self.num_train_steps:
+            logs = self.train_step()
+            log_fn(logs)
+        self.print('training complete')
 
 
 class HfHubertKmeansTrainer(nn.Module):

@@ -510,6 +510,73 @@ def rvq_encode(x: np.ndarray, codebooks: np.ndarray) -> np.ndarray:
     return out
 
 
+def rvq_fit_step(state: Dict[str, Tensor], x: Tensor, *, decay: float = 0.95, eps: float = 1e-5, kmeans_iters: int = 10,
+                 threshold_dead: float = 0.0, init_picks: Optional[Sequence[Tensor]] = None,
+                 expire_picks: Optional[Sequence[Tensor]] = None) -> Tuple[Tensor, float]:
+    """One training-mode pass of the CLAP residual VQ: what ClapRVQTrainer.train_step (trainer.py:689-736) triggers through
+    ClapQuantized.quantize(embeds, return_rvq_loss=True) with rq.train(True) (clap_quantized.py:75-84).  The arithmetic lives
+    in the un-vendored, un-pinned vector-quantize-pytorch (setup.py:31 ">=1.2.2"; ctor at clap_quantized.py:38-46: euclidean
+    codebook, kmeans_init=True, kmeans_iters=10 (library default), decay=0.95, commitment_weight=0, threshold_ema_dead_code):
+    PARITY UNPINNED -- this restates the library's published algorithm (1.6-era EuclideanCodebook):
+
+      per layer, on the running residual r:
+        first batch: k-means (initial means = `init_picks[s]` rows of r -- the library draws randperm(n)[:K]; Lloyd iterations
+                     keep a mean whose bucket is empty), embed = means, cluster_size = bucket counts, embed_avg = embed * counts
+        idx = nearest code (squared distance, ties -> lowest index: nearest_code above);  q = embed[idx]  (codes BEFORE the update)
+        EMA:  cluster_size <- d cs + (1-d) counts;  embed_avg <- d avg + (1-d) sums;
+              embed <- embed_avg / ((cs + eps) / (sum cs + K eps) * sum cs)
+        dead codes (threshold_dead > 0): codes with cs < threshold are re-seeded from rows `expire_picks[s]` of r, cs <- threshold,
+              embed_avg <- sample * threshold
+        r <- r - q
+      loss = mse(sum of q, x)
+
+    state: embed [S, K, D], embed_avg [S, K, D], cluster_size [S, K] (fp32) and initted [S] (bool), updated in place.
+    Returns (indices [n, S] int64, loss)."""
+    emb, avg, cs, initted = state["embed"], state["embed_avg"], state["cluster_size"], state["initted"]
+    S, K, D = emb.shape
+    r = x.detach().to(torch.float32).clone()
+    n = r.shape[0]
+    out = torch.zeros(n, S, dtype=torch.int64)
+    qsum = torch.zeros_like(r)
+
+    def bucket(rr, codes):
+        idx = torch.from_numpy(nearest_code(rr.numpy(), codes.numpy()))
+        counts = torch.bincount(idx, minlength=K).to(torch.float32)
+        sums = torch.zeros(K, D, dtype=torch.float32).index_add_(0, idx, rr)
+        return idx, counts, sums
+
+    for s in range(S):
+        if not bool(initted[s]):
+            means = r[init_picks[s]].clone()
+            counts = torch.zeros(K)
+            for _ in range(kmeans_iters):
+                _, counts, sums = bucket(r, means)
+                means = torch.where((counts > 0)[:, None], sums / counts.clamp(min=1)[:, None], means)
+            emb[s] = means
+            cs[s] = counts
+            avg[s] = means * counts[:, None]
+            initted[s] = True
+        idx, counts, sums = bucket(r, emb[s])
+        q = emb[s][idx].clone()
+        cs[s] = cs[s] * decay + counts * (1 - decay)
+        avg[s] = avg[s] * decay + sums * (1 - decay)
+        tot = cs[s].sum()
+        smoothed = (cs[s] + eps) / (tot + K * eps) * tot
+        emb[s] = avg[s] / smoothed[:, None]
+        if threshold_dead > 0:
+            dead = cs[s] < threshold_dead
+            if bool(dead.any()):
+                samp = r[expire_picks[s]]
+                emb[s][dead] = samp[dead]
+                cs[s][dead] = threshold_dead
+                avg[s][dead] = samp[dead] * threshold_dead
+        out[:, s] = idx
+        qsum += q
+        r = r - q
+    loss = float(((qsum - x.to(torch.float32)) ** 2).mean())
+    return out, loss
+
+
 def kmeans_assign(x: np.ndarray, centroids: np.ndarray) -> np.ndarray:
     """hf_hubert_kmeans.py:78-87 assign step (MiniBatchKMeans.predict): nearest centroid."""
     return nearest_code(x, centroids)

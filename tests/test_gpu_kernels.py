@@ -649,3 +649,87 @@ def test_sampler_matches_oracle(ops, dev):
     ops.sample_topk_gumbel(logits.to(dev), u.to(dev), out, V, max(int(0.1 * V), 1), 0.95, True)
     report("sampler", equal=bool(torch.equal(out.cpu(), exp)))
     assert torch.equal(out.cpu(), exp)
+
+
+def test_rvq_fit_step_matches_oracle(ops, dev):
+    """Training-mode residual VQ on the device (csrc/vq_fit.hip + the nearest-codeword kernel) against oracle.rvq_fit_step with
+    the same initial picks: k-means init, EMA updates and dead-code re-seeding.  Sums are fp32 atomics on the device, so codes
+    agree to rounding and the assignments almost everywhere."""
+    from open_musiclm_amd.clap_quantized import ClapQuantized
+    from oracle import musiclm_oracle as O
+    S, K, D, n = 3, 64, 32, 1500
+    centers = torch.randn(K, D, generator=torch.Generator().manual_seed(9))
+
+    def batch(seed):
+        g = torch.Generator().manual_seed(seed)
+        return centers[torch.randint(0, K, (n,), generator=g)] + 0.1 * torch.randn(n, D, generator=g)
+    cq = ClapQuantized(clap=None, codebook_size=K, rq_num_quantizers=S, embed_dim=D, rq_ema_decay=0.9, learn_rvq=True,
+                       threshold_ema_dead_code=0.3).to(dev)
+    state = dict(embed=torch.zeros(S, K, D), embed_avg=torch.zeros(S, K, D), cluster_size=torch.zeros(S, K),
+                 initted=torch.zeros(S, dtype=torch.bool))
+    pick_log = []
+
+    def picks(nn_, k_):
+        g = torch.Generator().manual_seed(1000 + len(pick_log))
+        p = torch.randperm(nn_, generator=g)[:k_]
+        pick_log.append(p)
+        return p
+    worst_code, worst_loss, agree = 0.0, 0.0, 1.0
+    for step in range(4):
+        x = batch(50 + step)
+        pick_log.clear()
+        cq.rq.init_pick_source = picks
+        cq.rq.expire_pick_source = picks
+        idx, q = cq.rq.fit_step(x.to(dev))
+        loss = float(((q.cpu() - x) ** 2).mean())
+        # replay with the same picks in the same order of consumption (per layer: init pick if needed, then expiry pick if needed)
+        log = list(pick_log)
+
+        class Feed:
+            def __init__(self): self.i = 0
+            def __getitem__(self, s):
+                p = log[self.i]; self.i += 1
+                return p
+        feed = Feed()
+        # the oracle indexes init_picks[s] / expire_picks[s] exactly when the device path called its pick source
+        o_idx, o_loss = O.rvq_fit_step(state, x, decay=0.9, threshold_dead=0.3, init_picks=feed, expire_picks=feed)
+        assert feed.i == len(log), (feed.i, len(log))
+        worst_code = max(worst_code, relerr(cq.rq.codebooks.cpu(), state["embed"]))
+        worst_loss = max(worst_loss, abs(loss - o_loss) / o_loss)
+        agree = min(agree, float((idx.cpu() == o_idx).float().mean()))
+        assert relerr(cq.rq.cluster_size.cpu(), state["cluster_size"]) < 1e-3
+        # keep the two trajectories on the same codes: rounding-level differences must not compound through near-ties
+        state["embed"].copy_(cq.rq.codebooks.cpu()); state["embed_avg"].copy_(cq.rq.embed_avg.cpu())
+        state["cluster_size"].copy_(cq.rq.cluster_size.cpu())
+    report("rvq_fit", codes=worst_code, loss=worst_loss, index_agreement=agree)
+    assert bool(cq.rq.initted.all()) and worst_code < 1e-3 and worst_loss < 1e-3 and agree > 0.995
+    # eval-mode encode with the fitted codebooks stays bit-exact against the stated chain
+    cq.learn_rvq = False
+    x = batch(99)[:64]
+    got = cq.quantize(x.to(dev)).squeeze(-1).cpu()
+    assert torch.equal(got, torch.from_numpy(O.rvq_encode(x.numpy(), cq.rq.codebooks.cpu().numpy())))
+
+
+def test_clap_rvq_trainer_on_embeddings(dev, tmp_path):
+    """ClapRVQTrainer (trainer.py:564-741) with a dataset of precomputed embeddings: steps run, the loss falls, and the saved
+    checkpoint carries the library's key layout and reloads into a fresh quantizer that encodes identically."""
+    from open_musiclm_amd.clap_quantized import ClapQuantized
+    from open_musiclm_amd.trainer import ClapRVQTrainer
+    K, D, S = 32, 16, 4
+    centers = torch.randn(K, D, generator=torch.Generator().manual_seed(3))
+    g = torch.Generator().manual_seed(4)
+    data = centers[torch.randint(0, K, (2048,), generator=g)] + 0.05 * torch.randn(2048, D, generator=g)
+    cq = ClapQuantized(clap=None, codebook_size=K, rq_num_quantizers=S, embed_dim=D, learn_rvq=True).to(dev)
+    trainer = ClapRVQTrainer(num_train_steps=5, batch_size=256, accumulate_batches=2, audio_conditioner=cq,
+                             dataset=torch.utils.data.TensorDataset(data), valid_frac=0.05, save_model_every=2,
+                             save_results_every=2, results_folder=str(tmp_path / "rvq"))
+    logs = []
+    trainer.train(log_fn=logs.append)
+    assert len(logs) == 5 and logs[-1]["train_loss"] < 0.05 ** 2 * 6 and logs[0]["valid_loss"] is not None
+    ck = torch.load(str(tmp_path / "rvq" / "clap.rvq.4.pt"), map_location="cpu")
+    assert "layers.0._codebook.embed" in ck and ck["layers.3._codebook.embed"].shape == (1, K, D)
+    fresh = ClapQuantized(clap=None, codebook_size=K, rq_num_quantizers=S, embed_dim=D).to(dev)
+    fresh.rq.load_state_dict(ck)
+    cq.learn_rvq = False
+    x = data[:100].to(dev)
+    assert torch.equal(fresh.quantize(x), cq.quantize(x))

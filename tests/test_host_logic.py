@@ -367,3 +367,29 @@ def test_kmeans_assign_oracle_vs_sklearn_at_real_dims():
     mism = int((ref != mine).sum())
     print(f"kmeans 768 x 1024: {mism} mismatches / {len(x)}")
     assert mism == 0, mism
+
+
+def test_rvq_checkpoint_layout_roundtrip():
+    """ResidualVQCodebooks reads and writes vector-quantize-pytorch's ResidualVQ keys (what trainer.py:731 saves and
+    clap_quantized.py:109 loads): layers.{s}._codebook.{initted, cluster_size, embed, embed_avg}."""
+    from open_musiclm_amd.clap_quantized import ClapQuantized
+    cq = ClapQuantized(clap=None, codebook_size=16, rq_num_quantizers=3, embed_dim=8, rq_ema_decay=0.9, threshold_ema_dead_code=0.5)
+    g = torch.Generator().manual_seed(1)
+    cq.rq.codebooks.copy_(torch.randn(3, 16, 8, generator=g))
+    cq.rq.embed_avg.copy_(torch.randn(3, 16, 8, generator=g))
+    cq.rq.cluster_size.copy_(torch.rand(3, 16, generator=g))
+    cq.rq.initted.fill_(True)
+    sd = cq.rq.state_dict()
+    assert sorted(sd) == sorted(f"layers.{s}._codebook.{k}" for s in range(3) for k in ("initted", "cluster_size", "embed", "embed_avg"))
+    assert sd["layers.1._codebook.embed"].shape == (1, 16, 8) and sd["layers.1._codebook.cluster_size"].shape == (1, 16)
+    buf = io.BytesIO()
+    torch.save(sd, buf)
+    buf.seek(0)
+    other = ClapQuantized(clap=None, codebook_size=16, rq_num_quantizers=3, embed_dim=8)
+    other.rq.load_state_dict(torch.load(buf))
+    for name in ("codebooks", "embed_avg", "cluster_size", "initted"):
+        assert torch.equal(getattr(other.rq, name), getattr(cq.rq, name)), name
+    assert other.rq.decay == 0.95 and cq.rq.decay == 0.9 and cq.rq.threshold_ema_dead_code == 0.5
+    with pytest.raises(RuntimeError):                       # fitting runs on the device only: no CPU fallback
+        cq.learn_rvq = True
+        cq.quantize(torch.randn(4, 8))

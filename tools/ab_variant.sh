@@ -14,7 +14,7 @@ build)
     make -C "$CS" >/dev/null
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-value "$@" -c "$CS/$src.hip" -o "/tmp/${src}_variant.o"
     objs=""
-    for o in gemm attention attention2 norm ffmid ffmid2 embed_ce optim_misc decode err; do
+    for o in gemm attention attention2 norm ffmid ffmid2 embed_ce optim_misc decode vq_fit err; do
         if [ "$o" = "$src" ]; then objs="$objs /tmp/${src}_variant.o"; else objs="$objs $CS/$o.o"; fi
     done
     hipcc --offload-arch=gfx950 -shared -fPIC $objs -o "$ROOT/.variants/libomlm_$name.so"
