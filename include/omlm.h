@@ -107,16 +107,21 @@ int omlm_ffmid_set_impl(int impl);
 
 /* Embedding gather + start-token interleave + concat (open_musiclm.py:123-145; utils.get_embeds :126-143) and its
  * transpose with the grad_shrink factor (utils.py:60-61).  tables/starts/pos: HOST arrays of device pointers. */
+/* table_rows / pos_rows (optional HOST arrays, length nseq): row counts of the tables; an id or position past its table is
+ * skipped like a pad (never an out-of-bounds access) and ORed into *err_flag (optional DEVICE int: bit 0 token id, bit 1
+ * position, bit 2 label >= V from the cross entropy) -- torch's embedding raises a device assert in the same situation. */
 int omlm_embed_gather_fwd(const int* ids, const int* seg, const int* posidx,
                           const float* const* tables, const float* const* starts, const float* const* pos,
-                          int nseq, float* out, int B, int N, int D, void* stream);
+                          int nseq, float* out, int B, int N, int D,
+                          const long long* table_rows, const long long* pos_rows, int* err_flag, void* stream);
 int omlm_embed_gather_bwd(const int* ids, const int* seg, const int* posidx,
                           float* const* dtables, float* const* dstarts, float* const* dpos,
-                          int nseq, const float* dx, int B, int N, int D, float alpha, void* stream);
+                          int nseq, const float* dx, int B, int N, int D, float alpha,
+                          const long long* table_rows, const long long* pos_rows, int* err_flag, void* stream);
 
 /* F.cross_entropy(logits, labels) pieces (open_musiclm.py:401-405): per-row lse + NLL sum; (softmax-onehot)*coef*g. */
 int omlm_cross_entropy_fwd(const float* logits, const int* labels, float* row_lse, float* nll_sum,
-                           int R, int V, int ld, void* stream);
+                           int R, int V, int ld, int* err_flag, void* stream);
 int omlm_cross_entropy_bwd(const float* logits, const int* labels, const float* row_lse, const float* gscale,
                            float coef, void* dlogits, int R, int V, int ld, int ldd, int out_dtype, void* stream);
 

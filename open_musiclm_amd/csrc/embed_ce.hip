@@ -15,6 +15,9 @@ struct EmbedTables {
     float* dtable[MAX_SEQ];
     float* dstart[MAX_SEQ];
     float* dpos[MAX_SEQ];
+    long long rows[MAX_SEQ];        // table rows / position rows per sequence (0: unchecked)
+    long long prows[MAX_SEQ];
+    int* err;                       // device flag: bit 0 = token id past its table, bit 1 = position past its table, bit 2 = label >= V
 };
 
 // ids [B, N] int32: >= 0 table row (offsets already applied), -1 pad (zero row), -2 start token.
@@ -25,11 +28,17 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int* __restrict__ 
     const int nv = D / 4;
     for (long long row = blockIdx.x; row < (long long)B * N; row += gridDim.x) {
         const int n = (int)(row % N);
-        const int id = ids[row], s = seg[n];
+        int id = ids[row];
+        const int s = seg[n];
+        // an id / position past its table is a corrupted input (wrong codebook_size, damaged token store): torch's embedding
+        // raises a device assert there; here the row is treated as a pad and the caller's flag is raised (never an OOB access)
+        if (id >= 0 && t.rows[s] > 0 && id >= t.rows[s]) { if (t.err && threadIdx.x == 0) atomicOr(t.err, 1); id = -1; }
         const float4* src = nullptr;
         if (id >= 0) src = (const float4*)(t.table[s] + (size_t)id * D);
         else if (id == -2) src = (const float4*)t.start[s];
-        const float4* ps = (id >= 0 || id == -1) && t.pos[s] ? (const float4*)(t.pos[s] + (size_t)posidx[n] * D) : nullptr;
+        bool pos_ok = (id >= 0 || id == -1) && t.pos[s];
+        if (pos_ok && t.prows[s] > 0 && posidx[n] >= t.prows[s]) { if (t.err && threadIdx.x == 0) atomicOr(t.err, 2); pos_ok = false; }
+        const float4* ps = pos_ok ? (const float4*)(t.pos[s] + (size_t)posidx[n] * D) : nullptr;
         float4* dst = (float4*)(out + (size_t)row * D);
         for (int c = threadIdx.x; c < nv; c += 256) {
             float4 v = src ? src[c] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -44,11 +53,15 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int* __restrict__ 
                                                         const float* __restrict__ dx, int B, int N, int D, float alpha) {
     for (long long row = blockIdx.x; row < (long long)B * N; row += gridDim.x) {
         const int n = (int)(row % N);
-        const int id = ids[row], s = seg[n];
+        int id = ids[row];
+        const int s = seg[n];
+        if (id >= 0 && t.rows[s] > 0 && id >= t.rows[s]) { if (t.err && threadIdx.x == 0) atomicOr(t.err, 1); id = -1; }
         float* dst = nullptr;
         if (id >= 0) dst = t.dtable[s] ? t.dtable[s] + (size_t)id * D : nullptr;
         else if (id == -2) dst = t.dstart[s];
-        float* pd = (id >= 0 || id == -1) && t.dpos[s] ? t.dpos[s] + (size_t)posidx[n] * D : nullptr;
+        bool pos_ok = (id >= 0 || id == -1) && t.dpos[s];
+        if (pos_ok && t.prows[s] > 0 && posidx[n] >= t.prows[s]) { if (t.err && threadIdx.x == 0) atomicOr(t.err, 2); pos_ok = false; }
+        float* pd = pos_ok ? t.dpos[s] + (size_t)posidx[n] * D : nullptr;
         const float* src = dx + (size_t)row * D;
         for (int c = threadIdx.x; c < D; c += 256) {
             const float g = src[c] * alpha;
@@ -59,9 +72,13 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int* __restrict__ 
 }
 
 static int fill_tables(EmbedTables& t, const float* const* tables, const float* const* starts, const float* const* pos,
-                       float* const* dtables, float* const* dstarts, float* const* dpos, int nseq) {
+                       float* const* dtables, float* const* dstarts, float* const* dpos, int nseq,
+                       const long long* table_rows, const long long* pos_rows, int* err_flag) {
     memset(&t, 0, sizeof(t));
+    t.err = err_flag;
     for (int i = 0; i < nseq; ++i) {
+        if (table_rows) t.rows[i] = table_rows[i];
+        if (pos_rows) t.prows[i] = pos_rows[i];
         if (tables) t.table[i] = tables[i];
         if (starts) t.start[i] = starts[i];
         if (pos) t.pos[i] = pos[i];
@@ -72,17 +89,19 @@ static int fill_tables(EmbedTables& t, const float* const* tables, const float* 
     return 0;
 }
 
-// tables/starts/pos: host arrays (length nseq) of DEVICE pointers.
+// tables/starts/pos: host arrays (length nseq) of DEVICE pointers.  table_rows / pos_rows: host arrays (length nseq) of the tables'
+// row counts (null: unchecked); err_flag: device int (null: out-of-range rows are still skipped, silently).
 extern "C" int omlm_embed_gather_fwd(const int* ids, const int* seg, const int* posidx,
                                      const float* const* tables, const float* const* starts, const float* const* pos,
-                                     int nseq, float* out, int B, int N, int D, void* stream) {
+                                     int nseq, float* out, int B, int N, int D,
+                                     const long long* table_rows, const long long* pos_rows, int* err_flag, void* stream) {
     if (B <= 0 || N <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(ids && seg && tables && starts && out, "null pointer");
     OMLM_CHECK_ARG(nseq >= 1 && nseq <= MAX_SEQ, "1..4 token sequences supported");
     OMLM_CHECK_ARG(D % 4 == 0, "D % 4");
     OMLM_CHECK_ARG(!pos || posidx, "posidx required with position tables");
     EmbedTables t;
-    fill_tables(t, tables, starts, pos, nullptr, nullptr, nullptr, nseq);
+    fill_tables(t, tables, starts, pos, nullptr, nullptr, nullptr, nseq, table_rows, pos_rows, err_flag);
     long long rows = (long long)B * N;
     hipLaunchKernelGGL(embed_fwd_kernel, dim3((unsigned)(rows < 16384 ? rows : 16384)), dim3(256), 0, as_stream(stream), ids, seg, posidx, t, out, B, N, D);
     return omlm_post_launch("omlm_embed_gather_fwd");
@@ -91,12 +110,13 @@ extern "C" int omlm_embed_gather_fwd(const int* ids, const int* seg, const int* 
 // accumulates (+=) alpha * dx rows into the table / start-token / position gradients.
 extern "C" int omlm_embed_gather_bwd(const int* ids, const int* seg, const int* posidx,
                                      float* const* dtables, float* const* dstarts, float* const* dpos,
-                                     int nseq, const float* dx, int B, int N, int D, float alpha, void* stream) {
+                                     int nseq, const float* dx, int B, int N, int D, float alpha,
+                                     const long long* table_rows, const long long* pos_rows, int* err_flag, void* stream) {
     if (B <= 0 || N <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(ids && seg && dtables && dstarts && dx, "null pointer");
     OMLM_CHECK_ARG(nseq >= 1 && nseq <= MAX_SEQ, "1..4 token sequences supported");
     EmbedTables t;
-    fill_tables(t, nullptr, nullptr, nullptr, dtables, dstarts, dpos, nseq);
+    fill_tables(t, nullptr, nullptr, nullptr, dtables, dstarts, dpos, nseq, table_rows, pos_rows, err_flag);
     long long rows = (long long)B * N;
     hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)(rows < 16384 ? rows : 16384)), dim3(256), 0, as_stream(stream), ids, seg, posidx, t, dx, B, N, D, alpha);
     return omlm_post_launch("omlm_embed_gather_bwd");
@@ -108,7 +128,7 @@ extern "C" int omlm_embed_gather_bwd(const int* ids, const int* seg, const int* 
 // label < 0 -> row ignored (ignore_index semantics).
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, const int* __restrict__ labels,
                                                      float* __restrict__ row_lse, float* __restrict__ nll_sum,
-                                                     int R, int V, int ld) {
+                                                     int R, int V, int ld, int* __restrict__ err) {
     __shared__ float red[4];
     float local = 0.f;
     for (int row = blockIdx.x; row < R; row += gridDim.x) {
@@ -127,7 +147,8 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
         if (threadIdx.x == 0) {
             row_lse[row] = lse;
             const int lb = labels[row];
-            if (lb >= 0) local += lse - lr[lb];
+            if (lb >= V) { if (err) atomicOr(err, 4); }            // a label past the vocabulary: row ignored, flag raised
+            else if (lb >= 0) local += lse - lr[lb];
         }
     }
     if (threadIdx.x == 0 && local != 0.f) unsafeAtomicAdd(nll_sum, local);
@@ -146,17 +167,17 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
         const float lse = row_lse[row];
         for (int c = threadIdx.x; c < ldd; c += 256) {
             float v = 0.f;
-            if (c < V && lb >= 0) v = g * (__expf(lr[c] - lse) - (c == lb ? 1.0f : 0.0f));
+            if (c < V && lb >= 0 && lb < V) v = g * (__expf(lr[c] - lse) - (c == lb ? 1.0f : 0.0f));
             store_from_float(dr + c, v);
         }
     }
 }
 
 extern "C" int omlm_cross_entropy_fwd(const float* logits, const int* labels, float* row_lse, float* nll_sum,
-                                      int R, int V, int ld, void* stream) {
+                                      int R, int V, int ld, int* err_flag, void* stream) {
     if (R <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(logits && labels && row_lse && nll_sum && ld >= V, "cross entropy arguments");
-    hipLaunchKernelGGL(ce_fwd_kernel, dim3(R < 4096 ? R : 4096), dim3(256), 0, as_stream(stream), logits, labels, row_lse, nll_sum, R, V, ld);
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(R < 4096 ? R : 4096), dim3(256), 0, as_stream(stream), logits, labels, row_lse, nll_sum, R, V, ld, err_flag);
     return omlm_post_launch("omlm_cross_entropy_fwd");
 }
 

@@ -684,12 +684,13 @@ class LossFunction(torch.autograd.Function):
     softmax - onehot from the saved logits / row lse directly in the GEMM operand dtype."""
 
     @staticmethod
-    def forward(ctx, model, all_token_ids, labels, self_attn_mask, loss_weights, precision, *params):
+    def forward(ctx, model, all_token_ids, labels, self_attn_mask, loss_weights, ignore_negative, precision, *params):
         nseq = len(model.token_sequences)
         bufs, lay, st = run_forward(model, all_token_ids, self_attn_mask, False, True, precision,
                                     want=[True] * nseq)
         dev = bufs[-1].device
         total = 0
+        total_dev = None                       # device-side part of the normaliser: non-ignored labels of padded sequences
         nll = torch.zeros(nseq, device=dev)
         st.labels, st.lse_rows, st.coefs = [], [], []
         for s, (seq, buf, lb, w) in enumerate(zip(model.token_sequences, bufs, labels, loss_weights)):
@@ -698,18 +699,33 @@ class LossFunction(torch.autograd.Function):
                 assert lb32.numel() == buf.shape[0], (lb32.numel(), buf.shape)
                 lse_rows = torch.empty(buf.shape[0], device=dev)
                 ops.ce_fwd(buf, lb32, lse_rows, nll[s:s + 1], seq.codebook_size + 1)
-                total += lb32.numel()
+                if ignore_negative[s]:
+                    cnt = (lb32 >= 0).sum().to(torch.float32)
+                    total_dev = cnt if total_dev is None else total_dev + cnt
+                else:
+                    total += lb32.numel()
                 st.labels.append(lb32); st.lse_rows.append(lse_rows)
             else:
                 st.labels.append(None); st.lse_rows.append(None)
         # loss = sum_s w_s * nll_sum_s / total   (== sum_s mean_s * n_s * w_s / sum n_s, :407-410); python-scalar
         # multiplies only: nothing is uploaded from the host here (graph-capture safe)
         loss = None
-        for s, w in enumerate(loss_weights):
-            if w > 0:
-                term = nll[s] * (float(w) / float(total))
-                loss = term if loss is None else loss + term
-        st.coefs = [float(w) / float(total) if w > 0 else 0.0 for w in loss_weights]
+        if total_dev is None:
+            for s, w in enumerate(loss_weights):
+                if w > 0:
+                    term = nll[s] * (float(w) / float(total))
+                    loss = term if loss is None else loss + term
+            st.coefs = [float(w) / float(total) if w > 0 else 0.0 for w in loss_weights]
+            ctx.inv_total = None
+        else:
+            inv_total = 1.0 / (total_dev + float(total))             # device scalar: the count depends on the batch
+            for s, w in enumerate(loss_weights):
+                if w > 0:
+                    term = nll[s] * float(w)
+                    loss = term if loss is None else loss + term
+            loss = loss * inv_total
+            st.coefs = [float(w) if w > 0 else 0.0 for w in loss_weights]
+            ctx.inv_total = inv_total
         ctx.st = st
         ctx.nparams = len(params)
         views = logits_views(model, lay, bufs)
@@ -721,6 +737,8 @@ class LossFunction(torch.autograd.Function):
         st = ctx.st
         T = st.pw.T
         g = gloss.reshape(1).to(torch.float32).contiguous()
+        if ctx.inv_total is not None:
+            g = (g * ctx.inv_total).reshape(1).contiguous()
         dl = []
         for s, seq in enumerate(st.model.token_sequences):
             if st.labels[s] is None:
@@ -732,4 +750,4 @@ class LossFunction(torch.autograd.Function):
             dl.append(d)
         run_backward(st, dl)
         ctx.st = None
-        return (None,) * (6 + ctx.nparams)
+        return (None,) * (7 + ctx.nparams)

@@ -115,8 +115,11 @@ class TokenConditionedTransformer(nn.Module):
         bufs, _, _ = engine.run_forward(self, ids, None, True, False, self._precision(), final_rows_only=True)
         return bufs[-1]
 
-    def loss_and_logits(self, ids, labels, self_attn_mask, loss_weights):
-        return engine.LossFunction.apply(self, ids, labels, self_attn_mask, tuple(loss_weights), self._precision(),
+    def loss_and_logits(self, ids, labels, self_attn_mask, loss_weights, ignore_negative=None):
+        """ignore_negative[s]: labels < 0 of sequence s are ignore_index rows AND leave the loss normaliser (the padded labels of
+        a unique_consecutive sequence, open_musiclm.py:396-404)."""
+        ign = tuple(bool(v) for v in ignore_negative) if ignore_negative is not None else (False,) * len(labels)
+        return engine.LossFunction.apply(self, ids, labels, self_attn_mask, tuple(loss_weights), ign, self._precision(),
                                          *self.parameters())
 
 
@@ -243,16 +246,16 @@ class TokenConditionedTransformerWrapper(nn.Module):
         ids, labels, mask = self._prepare(all_token_ids, return_loss, input_has_eos)
         if not return_loss:
             return self.transformer(all_token_ids=ids, self_attn_mask=mask, **kwargs)
-        weights = []
-        for info, w in zip(self.token_sequences, self.cross_entropy_loss_weights):
-            if info.unique_consecutive and self.unique_consecutive and w > 0:
-                raise NotImplementedError("unique_consecutive sequences (padded labels) are not supported in the fused loss")
-            weights.append(float(w))
+        weights = [float(w) for w in self.cross_entropy_loss_weights]
+        # unique_consecutive sequences carry pad_id labels: F.cross_entropy(ignore_index=pad_id) and num_logits = (labels != pad_id)
+        # .sum() in the reference (:396-404); the fused loss ignores negative labels and counts the rest on the device
+        ignore = [bool(info.unique_consecutive and self.unique_consecutive) for info in self.token_sequences]
+        loss_labels = [lb.masked_fill(lb == self.pad_id, -1) if ig else lb for lb, ig in zip(labels, ignore)]
         if torch.is_grad_enabled():
-            loss, *logits = self.transformer.loss_and_logits(ids, labels, mask, weights)
+            loss, *logits = self.transformer.loss_and_logits(ids, loss_labels, mask, weights, ignore)
         else:
             with torch.enable_grad():
-                loss, *logits = self.transformer.loss_and_logits(ids, labels, mask, weights)
+                loss, *logits = self.transformer.loss_and_logits(ids, loss_labels, mask, weights, ignore)
             loss = loss.detach()
         all_logits = [l.transpose(1, 2) for l in logits]               # 'b n c -> b c n' (:389)
         return loss, all_logits, labels

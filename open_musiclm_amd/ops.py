@@ -203,12 +203,45 @@ def _ptr_array(tensors: Sequence[Optional[torch.Tensor]]):
     return arr
 
 
+_INDEX_ERR = {}
+
+
+def index_error_flag(device) -> torch.Tensor:
+    """Per-device int32 flag the gather / cross-entropy kernels OR into when they meet an index past its table (they skip the
+    row instead of reading out of bounds).  Reading it synchronises: see :func:`raise_on_index_error`."""
+    key = str(device)
+    if key not in _INDEX_ERR:
+        _INDEX_ERR[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _INDEX_ERR[key]
+
+
+def raise_on_index_error(device):
+    """Raise IndexError if any kernel since the last call met an out-of-range token id / position / label (torch's embedding and
+    cross entropy raise a device assert in the same situation).  Synchronises the device: call it where the host already waits
+    (the trainer does after every step's loss read-back)."""
+    flag = _INDEX_ERR.get(str(device))
+    if flag is None:
+        return
+    v = int(flag.item())
+    if v:
+        flag.zero_()
+        what = [n for b, n in ((1, "token id >= embedding rows"), (2, "position >= absolute position rows"), (4, "label >= vocabulary")) if v & b]
+        raise IndexError("open_musiclm_amd: " + ", ".join(what) + " (rows were skipped; check codebook sizes / the token store)")
+
+
+def _rows_array(tensors):
+    if tensors is None:
+        return None
+    return (C.c_longlong * len(tensors))(*[int(t.shape[0]) if t is not None else 0 for t in tensors])
+
+
 def embed_fwd(ids, seg, posidx, tables, starts, pos_tables, out):
     B, N = ids.shape
     D = out.shape[-1]
     pos_arr = _ptr_array(pos_tables) if pos_tables is not None else None
     call("omlm_embed_gather_fwd", ptr(ids), ptr(seg), ptr(posidx), _ptr_array(tables), _ptr_array(starts),
-         pos_arr, len(tables), ptr(out), B, N, D, stream_ptr())
+         pos_arr, len(tables), ptr(out), B, N, D, _rows_array(tables), _rows_array(pos_tables), ptr(index_error_flag(out.device)),
+         stream_ptr())
 
 
 def embed_bwd(ids, seg, posidx, dtables, dstarts, dpos_tables, dx, alpha):
@@ -216,12 +249,14 @@ def embed_bwd(ids, seg, posidx, dtables, dstarts, dpos_tables, dx, alpha):
     D = dx.shape[-1]
     pos_arr = _ptr_array(dpos_tables) if dpos_tables is not None else None
     call("omlm_embed_gather_bwd", ptr(ids), ptr(seg), ptr(posidx), _ptr_array(dtables), _ptr_array(dstarts),
-         pos_arr, len(dtables), ptr(dx), B, N, D, float(alpha), stream_ptr())
+         pos_arr, len(dtables), ptr(dx), B, N, D, float(alpha), _rows_array(dtables), _rows_array(dpos_tables),
+         ptr(index_error_flag(dx.device)), stream_ptr())
 
 
 def ce_fwd(logits, labels, row_lse, nll_sum, V):
     R, ld = logits.shape
-    call("omlm_cross_entropy_fwd", ptr(logits), ptr(labels), ptr(row_lse), ptr(nll_sum), R, V, ld, stream_ptr())
+    call("omlm_cross_entropy_fwd", ptr(logits), ptr(labels), ptr(row_lse), ptr(nll_sum), R, V, ld,
+         ptr(index_error_flag(logits.device)), stream_ptr())
 
 
 def ce_bwd(logits, labels, row_lse, gscale, coef, dlogits, V):

@@ -308,6 +308,11 @@ class SingleStageTrainer(nn.Module):
             loss_acc += self.micro_step(self._next_batch(self.dl_iter))
         self.optimizer_step()
         logs = {'loss': float(loss_acc.item()) / self.grad_accum_every}       # single host sync per optimizer step
+        if self.device.type == 'cuda':
+            # the host has just waited for the device: a token id / label past its table (wrong codebook size, damaged token store)
+            # was skipped by the kernels and flagged -- surface it like torch's device assert would
+            from . import ops
+            ops.raise_on_index_error(self.device)
         self.print(f"{steps}: loss: {logs['loss']}")
 
         valid_loss = valid_accuracy = None

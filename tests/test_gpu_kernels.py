@@ -733,3 +733,40 @@ def test_clap_rvq_trainer_on_embeddings(dev, tmp_path):
     cq.learn_rvq = False
     x = data[:100].to(dev)
     assert torch.equal(fresh.quantize(x), cq.quantize(x))
+
+
+def test_index_guards_skip_and_flag(ops, dev):
+    """A token id / position / label past its table is skipped (no out-of-bounds access) and flagged; torch's embedding and
+    cross entropy raise a device assert in the same situation (embed_ce.hip)."""
+    B, D = 2, 32
+    tables = [torch.randn(10, D, device=dev)]
+    starts = [torch.randn(D, device=dev)]
+    ids = torch.tensor([[-2, 3, 10, 9], [-2, 11, 0, -1]], dtype=torch.int32, device=dev)      # 10 and 11 are past the 10-row table
+    seg = torch.zeros(4, dtype=torch.int32, device=dev)
+    posidx = torch.zeros(4, dtype=torch.int32, device=dev)
+    out = torch.full((B, 4, D), float("nan"), device=dev)
+    ops.raise_on_index_error(dev)                                   # clear
+    ops.embed_fwd(ids, seg, posidx, tables, starts, None, out)
+    assert torch.equal(out[0, 1], tables[0][3]) and torch.equal(out[0, 3], tables[0][9])
+    assert bool((out[0, 2] == 0).all()) and bool((out[1, 1] == 0).all()) and torch.equal(out[1, 0], starts[0])
+    with pytest.raises(IndexError, match="token id"):
+        ops.raise_on_index_error(dev)
+    ops.raise_on_index_error(dev)                                   # flag was cleared by the raise
+    dt, ds = [torch.zeros(10, D, device=dev)], [torch.zeros(D, device=dev)]
+    dx = torch.ones(B, 4, D, device=dev)
+    ops.embed_bwd(ids, seg, posidx, dt, ds, None, dx, 1.0)
+    assert float(dt[0].sum()) == 3 * D and float(ds[0].sum()) == 2 * D      # rows 3, 9, 0 once each; the two bad ids nowhere
+    with pytest.raises(IndexError):
+        ops.raise_on_index_error(dev)
+    V, ld = 5, 8
+    logits = torch.randn(3, ld, device=dev)
+    labels = torch.tensor([1, 7, -1], dtype=torch.int32, device=dev)           # 7 >= V
+    lse, nll = torch.empty(3, device=dev), torch.zeros(1, device=dev)
+    ops.ce_fwd(logits, labels, lse, nll, V)
+    ref = torch.logsumexp(logits[0, :V], 0) - logits[0, 1]
+    assert abs(float(nll) - float(ref)) < 1e-5
+    with pytest.raises(IndexError, match="label"):
+        ops.raise_on_index_error(dev)
+    d = torch.full((3, ld), float("nan"), device=dev)
+    ops.ce_bwd(logits, labels, lse, None, 1.0, d, V)
+    assert bool((d[1] == 0).all()) and bool((d[2] == 0).all()) and torch.isfinite(d).all()

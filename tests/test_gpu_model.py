@@ -149,6 +149,41 @@ def test_logits_path_autograd_matches_fused_loss(golden_dir, dev, monkeypatch):
     assert worst[1] < 2e-2, worst      # both paths share the kernels; they differ only in how dlogits is rounded
 
 
+def test_fused_loss_with_unique_consecutive_padding(dev):
+    """unique_consecutive sequences (open_musiclm.py:349-353): runs of equal ids collapse, the tail is padded with pad_id, the
+    loss ignores those labels and the normaliser counts only the rest (:396-404) -- fused path vs logits + torch CE."""
+    from open_musiclm_amd import open_musiclm as M
+    torch.manual_seed(0)
+    seqs = [M.TokenSequenceInfo(32, 2, False), M.TokenSequenceInfo(32, 1, True)]
+    model = M.TokenConditionedTransformer(token_sequences=seqs, dim=64, depth=2, heads=2, ff_dropout=0.0,
+                                          precision="bf16x3").to(dev)
+    wrapper = M.TokenConditionedTransformerWrapper(transformer=model, unique_consecutive=True,
+                                                   cross_entropy_loss_weights=[0.5, 1.0], mask_prob=0.0)
+    wrapper.train()
+    g = torch.Generator().manual_seed(2)
+    a = torch.randint(0, 32, (3, 4, 2), generator=g).to(dev)
+    b = torch.randint(0, 4, (3, 12), generator=g).to(dev)           # few distinct values: plenty of repeated runs
+    loss, logits, labels = wrapper(all_token_ids=[a, b], return_loss=True)
+    assert int((labels[1] == -1).sum()) > 0                         # padding really occurred
+    loss.backward()
+    g1 = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    model.zero_grad(set_to_none=True)
+    ids, lbs, mask = wrapper._prepare([a, b], True, False)
+    lg = model(all_token_ids=ids, self_attn_mask=mask)
+    n0, n1 = lbs[0].numel(), int((lbs[1] != -1).sum())
+    ce0 = torch.nn.functional.cross_entropy(lg[0].transpose(1, 2), lbs[0])
+    ce1 = torch.nn.functional.cross_entropy(lg[1].transpose(1, 2), lbs[1], ignore_index=-1)
+    ref = (ce0 * n0 * 0.5 + ce1 * n1 * 1.0) / (n0 + n1)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) < 1e-5 * abs(float(ref)), (float(loss), float(ref))
+    gscale = max(float(v.abs().max()) for v in g1.values())
+    errs = {k: float((p.grad.double() - g1[k].double()).abs().max() / max(float(g1[k].abs().max()), 1e-3 * gscale))
+            for k, p in model.named_parameters() if k in g1 and p.grad is not None}
+    worst = max(errs.items(), key=lambda kv: kv[1])
+    report("unique_consecutive_loss", worst=worst, padded=int((labels[1] == -1).sum()))
+    assert worst[1] < 2e-2, worst
+
+
 @pytest.mark.parametrize("precision", ["bf16x3"])
 def test_generate_matches_reference_golden_ids(golden_dir, dev, precision):
     from open_musiclm_amd import open_musiclm as M
