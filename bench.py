@@ -132,6 +132,11 @@ class TrainLeg:
         ops_gemm, rec = ops.gemm, []
 
         def timed_gemm(A, B, C_, *, M, N, K, **kw):
+            if A.dtype == torch.float32 and ops._X3_PLANES and M * N * K >= ops._X3_MIN_MACS:
+                # bf16x3: the hi/lo plane split of the operands is its own (HBM-bound) kernel; the events bracket the GEMM launch
+                lda, ldb = kw.get("lda") or A.shape[-1], kw.get("ldb") or B.shape[-1]
+                ops.operand_planes(A, kw.get("a_rows") or A.numel() // lda, lda)
+                ops.operand_planes(B, kw.get("b_rows") or B.numel() // ldb, ldb)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             ops_gemm(A, B, C_, M=M, N=N, K=K, **kw)

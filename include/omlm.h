@@ -138,6 +138,16 @@ int omlm_cast_pad(const float* src, void* dst, long long R, int C, int ld_src, i
  * nn.Linear, transformer.py:203-212,144,149), refreshed once per optimizer step. */
 int omlm_transpose_cast(const float* src, void* dst, int R, int C, int ld_src, int ld_dst, int out_dtype, void* stream);
 
+/* fp32-grade GEMM ("bf16x3") on bf16 hi/lo operand planes through the bf16 LDS-DMA tile kernels: A and B point at bf16 hi planes
+ * laid out as omlm_gemm takes bf16 operands, the lo plane of each lies a_plane_bytes / b_plane_bytes behind it
+ * (omlm_split_planes: hi = fp32 truncated to bf16, lo = RNE(x - hi)).  One launch, k-loop three times as long:
+ * hi*hi + hi*lo + lo*hi with fp32 accumulation -- the products the fp32 path of omlm_gemm forms, at the bf16 kernels' rate.
+ * Row maps as in omlm_gemm; k-row maps (k-major operand with a map) are not supported. */
+int omlm_gemm_planes(const void* A, long long a_plane_bytes, const void* B, long long b_plane_bytes, void* C, const float* Cin,
+                     const int* a_map, const int* b_map, const int* c_map, long long a_rows, long long b_rows,
+                     int M, int N, int K, int lda, int ldb, int ldc, int ldcin,
+                     int a_kmajor, int b_kmajor, int out_dtype, float alpha, void* stream);
+int omlm_split_planes(const float* x, void* planes, long long n, long long plane_elems, void* stream);
 /* All weight-gradient contractions of a backward pass in one launch (autograd of nn.Linear, transformer.py:203-212,144,149:
  * dW += dY^T X).  Problem i: C_i [M_i, N_i] fp32 (accumulated, +=; c_map optional: physical row of logical row m, < 0 skips)
  * from bf16 k-major operands A_i [K_i, M_i] (pitch lda) and B_i [K_i, N_i] (pitch ldb); pitches are multiples of 8 elements.

@@ -57,6 +57,10 @@ struct GemmArgs {
     int bal_ck;         // > 0: balanced split-K ("chunked stream-K"): gridDim.x workgroups share tiles x k-tiles evenly; k-tiles per K chunk
     int bal_chunks;     //      number of K chunks
     int debug;          // profiling ablations only (OMLM_GEMM_DEBUG): bit 0 = skip the per-tile DMA, bit 1 = skip the MFMAs
+    // hi/lo operand planes ("bf16x3" through the bf16 tile kernels): A and B each point at a bf16 hi plane with the lo plane
+    // a_plane / b_plane BYTES behind it, and the k-loop runs 3 x the k-tiles: (A_hi, B_hi), (A_hi, B_lo), (A_lo, B_hi).
+    int split3;
+    unsigned a_plane, b_plane;
 };
 
 // ---- LDS images ---------------------------------------------------------------------------
@@ -335,28 +339,29 @@ struct DmaStagerT {
     // KMAP: a k-row map is honoured (an ORDINARY global load inside the k-loop).  It is a template switch because its mere
     // presence -- even behind a null-pointer test -- makes hipcc wait vmcnt(0) before every LDS-DMA issue and every
     // fragment read, which serialised the whole pipeline of the k-major GEMMs (2x slower; found in the ISA).
+    // poff: byte offset of the operand plane this k-tile reads (0, or the lo plane of a split3 GEMM)
     template <bool KMAP>
     __device__ __forceinline__ void issue_one(int i, dma_rsrc rs, const int* map, int ld, int k0, int K,
-                                              char* lds_tile, int wave, bool live, int aux = 0) {
+                                              char* lds_tile, int wave, bool live, int aux = 0, unsigned poff = 0u) {
         const int b = wave + NWAVES * i;
         unsigned off;
         if (!KMAJ) {
-            off = (live && base[i] != OOB_OFF && k0 + kidx[i] < K) ? base[i] + (unsigned)(k0 * 2) : OOB_OFF;
+            off = (live && base[i] != OOB_OFF && k0 + kidx[i] < K) ? base[i] + (unsigned)(k0 * 2) + poff : OOB_OFF;
         } else {
             const int gk = k0 + kidx[i];
             const bool ok = live && base[i] != OOB_OFF && gk < K;
             unsigned pr = (unsigned)gk;
             if (KMAP) { if (ok && map) pr = (unsigned)map[gk]; }
-            off = ok ? base[i] + pr * (unsigned)(ld * 2) : OOB_OFF;     // 32-bit: the host checks that the operand is < 4 GiB
+            off = ok ? base[i] + pr * (unsigned)(ld * 2) + poff : OOB_OFF;     // 32-bit: the host checks that the operand is < 4 GiB
         }
         (void)aux;
         dma_issue(rs, (unsigned)(size_t)LDS_PTR(char, lds_tile) + (unsigned)(b * 1024), off);
     }
     template <bool KMAP>
     __device__ __forceinline__ void issue(dma_rsrc rs, const int* map, int ld, int k0, int K,
-                                          char* lds_tile, int wave) {
+                                          char* lds_tile, int wave, unsigned poff = 0u) {
 #pragma unroll
-        for (int i = 0; i < UPW; ++i) issue_one<KMAP>(i, rs, map, ld, k0, K, lds_tile, wave, true);
+        for (int i = 0; i < UPW; ++i) issue_one<KMAP>(i, rs, map, ld, k0, K, lds_tile, wave, true, 0, poff);
     }
 };
 
@@ -452,7 +457,7 @@ __device__ __forceinline__ int xcd_logical_id(int lin, int total) {
 
 // One workgroup's share of C = alpha A B^T (+ Cin).  lg: logical workgroup id inside this problem's (tiles x K-splits, split-major)
 // space; split: partial sums are added to fp32 C with atomics; bal_wgs: workgroup count of the balanced split-K form (BAL only).
-template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ, bool B_KMAJ, typename TOUT, bool DBG, bool KMAP, bool BAL>
+template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ, bool B_KMAJ, typename TOUT, bool DBG, bool KMAP, bool BAL, bool SPLIT3 = false>
 __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, const bool split, const int bal_wgs, char* smem) {
     const int dbg = DBG ? g.debug : 0;      // ablation switches exist only in the DBG instantiation (OMLM_GEMM_DEBUG set)
     constexpr int NWN = BN_ / WN_, NWAVES = (BM_ / WM_) * NWN;
@@ -462,7 +467,8 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, 
 
     const int tiles_m = (g.M + BM_ - 1) / BM_, tiles_n = (g.N + BN_ - 1) / BN_;
     const int nwg = tiles_m * tiles_n;
-    const int nk_all = (g.K + BK - 1) / BK;
+    const int nk1 = (g.K + BK - 1) / BK;
+    const int nk_all = SPLIT3 ? 3 * nk1 : nk1;            // split3: k-tile t reads planes (t / nk1) at k = (t % nk1) * BK
     constexpr bool bal = BAL;          // balanced split-K is its own instantiation: the plain kernels keep their code and registers
     // Balanced split-K: the (K chunk, tile, k-tile) units are numbered chunk-major and cut into bal_wgs equal contiguous
     // ranges; a workgroup walks its range segment by segment (a segment = consecutive k-tiles of one output tile) and adds each
@@ -524,9 +530,24 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, 
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+        // k-tile index -> contraction offset and operand planes
+        // (SPLIT3 is its own instantiation: the plain kernels keep the code and register allocation they were measured with)
+        auto tile_at = [&](int t, unsigned& pa, unsigned& pb) -> int {
+            if constexpr (SPLIT3) {
+                const int which = t >= 2 * nk1 ? 2 : (t >= nk1 ? 1 : 0);
+                pa = which == 2 ? g.a_plane : 0u;
+                pb = which == 1 ? g.b_plane : 0u;
+                return (t - which * nk1) * BK;
+            } else {
+                pa = 0u; pb = 0u;
+                return t * BK;
+            }
+        };
         if (kt0 < kt1) {
-            sa.template issue<KMAP>(rsA, g.a_map, g.lda, kt0 * BK, g.K, smem, wave);
-            sb.template issue<KMAP>(rsB, g.b_map, g.ldb, kt0 * BK, g.K, smem + A_BYTES, wave);
+            unsigned pa, pb;
+            const int k00 = tile_at(kt0, pa, pb);
+            sa.template issue<KMAP>(rsA, g.a_map, g.lda, k00, g.K, smem, wave, pa);
+            sb.template issue<KMAP>(rsB, g.b_map, g.ldb, k00, g.K, smem + A_BYTES, wave, pb);
         }
         for (int kt = kt0; kt < kt1; ++kt) {
             const int cur = (kt - kt0) & 1;
@@ -538,7 +559,8 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, 
             // The loads are spread over the MFMAs of the first three k16 steps instead; the last step covers their latency.
             const bool live = kt + 1 < kt1 && !(dbg & 1);
             char* nxt = smem + (cur ^ 1) * STAGE;
-            const int knext = (kt + 1) * BK;
+            unsigned pan, pbn;
+            const int knext = tile_at(kt + 1, pan, pbn);
             const char* As = smem + cur * STAGE;
             const char* Bs = As + A_BYTES;
             // software-pipelined fragments: the LDS reads of k16-step s+1 are issued BEFORE the MFMAs of step s, so their
@@ -579,8 +601,8 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, 
                         if (midx % STRIDE == 0 && midx / STRIDE < NLOAD) {
                             const int l = midx / STRIDE;
                             __builtin_amdgcn_sched_barrier(0);
-                            if (l < UA) { if (!(dbg & 16)) sa.template issue_one<KMAP>(l, rsA, g.a_map, g.lda, knext, g.K, nxt, wave, live, (dbg >> 6) & 3); }
-                            else        { if (!(dbg & 32)) sb.template issue_one<KMAP>(l - UA, rsB, g.b_map, g.ldb, knext, g.K, nxt + A_BYTES, wave, live, (dbg >> 6) & 3); }
+                            if (l < UA) { if (!(dbg & 16)) sa.template issue_one<KMAP>(l, rsA, g.a_map, g.lda, knext, g.K, nxt, wave, live, (dbg >> 6) & 3, pan); }
+                            else        { if (!(dbg & 32)) sb.template issue_one<KMAP>(l - UA, rsB, g.b_map, g.ldb, knext, g.K, nxt + A_BYTES, wave, live, (dbg >> 6) & 3, pbn); }
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
@@ -596,13 +618,13 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, 
 
 // For split-K GEMMs the split-major XCD order puts all co-resident workgroups of an XCD on the SAME K range (they share A and B
 // panels through its L2); with a tile-only remap an XCD held 3 unrelated K ranges at a time (measured L2 hit 48 % on the dW1 GEMM).
-template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ, bool B_KMAJ, typename TOUT, bool DBG, bool KMAP, bool BAL = false>
+template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ, bool B_KMAJ, typename TOUT, bool DBG, bool KMAP, bool BAL = false, bool SPLIT3 = false>
 __global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A | B]
     const int nwg = gridDim.x;                                     // tiles (plain) / workgroups (balanced)
     const int total = BAL ? (int)gridDim.x : nwg * (int)gridDim.y;
     const int lg = xcd_logical_id(blockIdx.y * nwg + blockIdx.x, total);
-    gemm_tile_body<BM_, BN_, WM_, WN_, A_KMAJ, B_KMAJ, TOUT, DBG, KMAP, BAL>(g, lg, gridDim.y > 1, (int)gridDim.x, smem);
+    gemm_tile_body<BM_, BN_, WM_, WN_, A_KMAJ, B_KMAJ, TOUT, DBG, KMAP, BAL, SPLIT3>(g, lg, gridDim.y > 1, (int)gridDim.x, smem);
 }
 
 // ---- grouped weight-gradient GEMM ------------------------------------------------------------------------------------
@@ -624,7 +646,7 @@ __global__ __launch_bounds__(512) void gemm_wgrad_group_kernel(GroupArgs ga) {
     GemmArgs g;
     g.A = q.A; g.B = q.B; g.C = q.C; g.Cin = q.C; g.a_map = nullptr; g.b_map = nullptr; g.c_map = q.c_map;
     g.a_rows = q.K; g.b_rows = q.K; g.M = q.M; g.N = q.N; g.K = q.K; g.lda = q.lda; g.ldb = q.ldb; g.ldc = q.ldc; g.ldcin = q.ldc;
-    g.alpha = 1.f; g.kt_per_split = q.kt_per_split; g.bal_ck = 0; g.bal_chunks = 0; g.debug = 0;
+    g.alpha = 1.f; g.kt_per_split = q.kt_per_split; g.bal_ck = 0; g.bal_chunks = 0; g.debug = 0; g.split3 = 0; g.a_plane = 0; g.b_plane = 0;
     const int nk = (q.K + BK - 1) / BK;
     gemm_tile_body<256, 256, 128, 64, true, true, float, false, false, false>(g, lg - q.start, q.kt_per_split < nk, 0, smem);
 }
@@ -645,6 +667,7 @@ static int launch_tile(const GemmArgs& g, int a_kmaj, int b_kmaj, int splits, hi
         auto kmap = gemm_bf16_tile_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT, false, (AK || BKM) && BM_ == 128>;            \
         auto kbal = gemm_bf16_tile_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT, false, false, sizeof(TOUT) == 4>;            \
         auto kbalmap = gemm_bf16_tile_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT, false, (AK || BKM) && BM_ == 128, sizeof(TOUT) == 4>; \
+        auto ks3 = gemm_bf16_tile_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT, false, false, false, true>;                     \
         static bool attr = false;                                                                                           \
         if (!attr) {                                                                                                        \
             (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);             \
@@ -652,9 +675,11 @@ static int launch_tile(const GemmArgs& g, int a_kmaj, int b_kmaj, int splits, hi
             (void)hipFuncSetAttribute((const void*)kmap, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);            \
             (void)hipFuncSetAttribute((const void*)kbal, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);            \
             (void)hipFuncSetAttribute((const void*)kbalmap, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);         \
+            (void)hipFuncSetAttribute((const void*)ks3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);             \
             attr = true;                                                                                                    \
         }                                                                                                                   \
-        if (g.bal_ck > 0 && sizeof(TOUT) == 4) hipLaunchKernelGGL(need_kmap ? kbalmap : kbal, grid, block, LDS, st, g);    \
+        if (g.split3) hipLaunchKernelGGL(ks3, grid, block, LDS, st, g);                                                    \
+        else if (g.bal_ck > 0 && sizeof(TOUT) == 4) hipLaunchKernelGGL(need_kmap ? kbalmap : kbal, grid, block, LDS, st, g); \
         else if (need_kmap) hipLaunchKernelGGL(kmap, grid, block, LDS, st, g);                                             \
         else if (g.debug) hipLaunchKernelGGL(kdbg, grid, block, LDS, st, g);                                               \
         else              hipLaunchKernelGGL(kfn, grid, block, LDS, st, g);                                                \
@@ -682,11 +707,12 @@ static int launch_layout(const GemmArgs& g, int a_kmaj, int b_kmaj, int splits, 
 }
 
 // dtype codes shared with the Python host: 0 = fp32, 1 = bf16
-extern "C" int omlm_gemm(const void* A, const void* B, void* C, const float* Cin,
-                         const int* a_map, const int* b_map, const int* c_map,
-                         long long a_rows, long long b_rows,
-                         int M, int N, int K, int lda, int ldb, int ldc, int ldcin,
-                         int a_kmajor, int b_kmajor, int in_dtype, int out_dtype, float alpha, void* stream) {
+static int gemm_impl(const void* A, const void* B, void* C, const float* Cin,
+                     const int* a_map, const int* b_map, const int* c_map,
+                     long long a_rows, long long b_rows,
+                     int M, int N, int K, int lda, int ldb, int ldc, int ldcin,
+                     int a_kmajor, int b_kmajor, int in_dtype, int out_dtype, float alpha, void* stream,
+                     int split3, unsigned a_plane, unsigned b_plane) {
     if (M <= 0 || N <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(A && B && C, "null operand");
     OMLM_CHECK_ARG(K > 0, "K must be positive");
@@ -706,6 +732,7 @@ extern "C" int omlm_gemm(const void* A, const void* B, void* C, const float* Cin
     g.a_rows = a_rows; g.b_rows = b_rows; g.M = M; g.N = N; g.K = K;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldcin = ldcin; g.alpha = alpha;
     { const char* dbg = getenv("OMLM_GEMM_DEBUG"); g.debug = dbg ? atoi(dbg) : 0; }
+    g.split3 = split3; g.a_plane = a_plane; g.b_plane = b_plane;
     hipStream_t st = as_stream(stream);
     // tile shape (bf16 path): 256x256 when both output dims are wide, 256x128 for tall-narrow outputs, else 128x128
     int bm = BM, bn = BN;
@@ -726,7 +753,7 @@ extern "C" int omlm_gemm(const void* A, const void* B, void* C, const float* Cin
     // split-K only for accumulate-into-C GEMMs with few output tiles (the weight-gradient contractions).  The 256-wide
     // tiles run one workgroup per CU, so the split count is chosen for whole rounds of the machine: e.g. dW1 has 88 tiles;
     // 12 splits = 1056 workgroups = 4.1 rounds (82 % of the last 5 used), 11 splits = 968 = 3.8 rounds (95 %).
-    const int nk = (K + BK - 1) / BK;
+    const int nk = ((K + BK - 1) / BK) * (split3 ? 3 : 1);     // k-tiles of the loop (three plane pairs per real k-tile when split3)
     const int tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
     int splits = 1;
     if (Cin == (const float*)C && out_dtype == 0 && tiles < 512 && nk >= 16) {
@@ -749,7 +776,7 @@ extern "C" int omlm_gemm(const void* A, const void* B, void* C, const float* Cin
     // Balanced split-K for the same GEMMs (bf16 tile kernels): one workgroup per slot, every workgroup the same number of k-tiles,
     // K cut into round(slots / tiles) chunks so that co-resident workgroups read the same K range.
     g.bal_ck = 0; g.bal_chunks = 0;
-    if (splits > 1 && in_dtype == 1) {
+    if (splits > 1 && in_dtype == 1 && !split3) {
         static int bal_on = -1;
         // measured (MI355X, dW1: 88 tiles x 558 k-tiles): 665 us balanced vs 642 us with the 8-split grid, train step 36.9 vs 36.7 ms --
         // the k-major main loop, not the partial last round or the atomic volume, is what holds these GEMMs at ~620 TFLOP/s.
@@ -811,6 +838,70 @@ extern "C" int omlm_gemm(const void* A, const void* B, void* C, const float* Cin
         }
     }
     return launch(g, bm, bn, splits);
+}
+
+extern "C" int omlm_gemm(const void* A, const void* B, void* C, const float* Cin,
+                         const int* a_map, const int* b_map, const int* c_map,
+                         long long a_rows, long long b_rows,
+                         int M, int N, int K, int lda, int ldb, int ldc, int ldcin,
+                         int a_kmajor, int b_kmajor, int in_dtype, int out_dtype, float alpha, void* stream) {
+    return gemm_impl(A, B, C, Cin, a_map, b_map, c_map, a_rows, b_rows, M, N, K, lda, ldb, ldc, ldcin, a_kmajor, b_kmajor,
+                     in_dtype, out_dtype, alpha, stream, 0, 0u, 0u);
+}
+
+// fp32-grade GEMM on bf16 hi/lo planes ("bf16x3" through the LDS-DMA tile kernels).  A and B are bf16 hi planes in the layout
+// omlm_gemm takes for bf16 operands; the matching lo plane lies a_plane_bytes / b_plane_bytes behind each (omlm_split_planes
+// writes such a pair).  One launch whose k-loop is three times as long: hi*hi + hi*lo + lo*hi, accumulated in fp32 -- the same
+// three products per element as the register-staged fp32 path (gemm_kernel<float>), at the bf16 kernels' rate.
+extern "C" int omlm_gemm_planes(const void* A, long long a_plane_bytes, const void* B, long long b_plane_bytes, void* C, const float* Cin,
+                                const int* a_map, const int* b_map, const int* c_map, long long a_rows, long long b_rows,
+                                int M, int N, int K, int lda, int ldb, int ldc, int ldcin,
+                                int a_kmajor, int b_kmajor, int out_dtype, float alpha, void* stream) {
+    OMLM_CHECK_ARG(a_plane_bytes > 0 && b_plane_bytes > 0 && (a_plane_bytes % 16) == 0 && (b_plane_bytes % 16) == 0, "plane strides");
+    OMLM_CHECK_ARG(!(a_kmajor && a_map) && !(b_kmajor && b_map), "k-row maps are not supported on operand planes");
+    OMLM_CHECK_ARG((unsigned long long)a_plane_bytes + (unsigned long long)a_rows * lda * 2 < 0xFFFFFFF0ull &&
+                   (unsigned long long)b_plane_bytes + (unsigned long long)b_rows * ldb * 2 < 0xFFFFFFF0ull,
+                   "operand planes exceed the 4 GiB buffer-descriptor window");
+    // the descriptors must cover both planes: rows are counted up to the end of the lo plane
+    const long long a_rows2 = (a_plane_bytes / 2 + (long long)a_rows * lda + lda - 1) / lda;
+    const long long b_rows2 = (b_plane_bytes / 2 + (long long)b_rows * ldb + ldb - 1) / ldb;
+    return gemm_impl(A, B, C, Cin, a_map, b_map, c_map, a_rows2, b_rows2, M, N, K, lda, ldb, ldc, ldcin, a_kmajor, b_kmajor,
+                     1, out_dtype, alpha, stream, 1, (unsigned)a_plane_bytes, (unsigned)b_plane_bytes);
+}
+
+// x [n] fp32 -> planes: hi[i] = x truncated to bf16 at planes[i], lo[i] = RNE(x - hi) at planes[plane_elems + i]  (x ~= hi + lo to 2^-17)
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, unsigned short* __restrict__ planes,
+                                                           long long n, long long plane_elems) {
+    const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;
+    const long long stride = (long long)gridDim.x * 256 * 8;
+    for (long long i = i0; i < n; i += stride) {
+        if (i + 8 <= n) {
+            const float4 a = *(const float4*)(x + i), b = *(const float4*)(x + i + 4);
+            unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+            split_pair(a.x, a.y, h0, l0); split_pair(a.z, a.w, h1, l1);
+            split_pair(b.x, b.y, h2, l2); split_pair(b.z, b.w, h3, l3);
+            u32x4 hi, lo;
+            hi[0] = h0; hi[1] = h1; hi[2] = h2; hi[3] = h3; lo[0] = l0; lo[1] = l1; lo[2] = l2; lo[3] = l3;
+            *(u32x4*)(planes + i) = hi;
+            *(u32x4*)(planes + plane_elems + i) = lo;
+        } else {
+            for (long long j = i; j < n; ++j) {
+                const unsigned u = f2u(x[j]) & 0xFFFF0000u;
+                planes[j] = (unsigned short)(u >> 16);
+                planes[plane_elems + j] = (unsigned short)bf16_bits_rne(x[j] - u2f(u));
+            }
+        }
+    }
+}
+extern "C" int omlm_split_planes(const float* x, void* planes, long long n, long long plane_elems, void* stream) {
+    if (n <= 0) return OMLM_OK;
+    OMLM_CHECK_ARG(x && planes && plane_elems >= n && (plane_elems % 8) == 0, "split_planes arguments");
+    OMLM_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)planes % 16) == 0, "split_planes: 16-byte aligned buffers");
+    long long blocks = (n / 8 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, (unsigned short*)planes, n, plane_elems);
+    return omlm_post_launch("omlm_split_planes");
 }
 
 // C_i[M_i, N_i] += A_i^T B_i for `count` problems with bf16 k-major operands A_i [K_i, M_i], B_i [K_i, N_i] in ONE launch of 256x256

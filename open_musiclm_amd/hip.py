@@ -26,6 +26,8 @@ SIGNATURES = {
     "omlm_set_error": [C.c_char_p],
     "omlm_gemm": [vp, vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp],
     "omlm_gemm_wgrad_group": [vp, i32, i32, vp],
+    "omlm_gemm_planes": [vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp],
+    "omlm_split_planes": [vp, vp, i64, i64, vp],
     "omlm_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp],
     "omlm_layernorm_bwd_workspace_bytes": [i32],
     "omlm_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp],

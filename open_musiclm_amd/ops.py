@@ -5,6 +5,8 @@ dtype code convention: 0 = fp32 ("bf16x3" split for GEMM/attention operands), 1 
 from __future__ import annotations
 
 import ctypes as C
+import os
+import weakref
 from typing import Optional, Sequence
 
 import torch
@@ -33,6 +35,34 @@ def _chk(t: torch.Tensor, name: str):
         raise ValueError(f"{name} must be contiguous")
 
 
+# ---- bf16x3 through the bf16 tile kernels: fp32 operands are split once into bf16 hi / lo planes (omlm_split_planes) and the
+# three products run as ONE GEMM with a 3x longer k-loop (omlm_gemm_planes).  The register-staged fp32 kernel measured 169
+# TFLOP/s fp32-equivalent on the trunk shapes; the plane form runs at a third of the bf16 kernels' ~1 PFLOP/s.  Planes are cached
+# per tensor OBJECT (weak reference + version counter), so an activation feeding several GEMMs (forward, input gradient, weight
+# gradient) is split once.  OMLM_X3_PLANES=0 keeps every fp32 GEMM on the register-staged kernel.
+_X3_PLANES = os.environ.get("OMLM_X3_PLANES", "1") == "1"
+_X3_MIN_MACS = 1 << 26
+_PLANES = {}
+
+
+def operand_planes(t: torch.Tensor, rows: int, ld: int):
+    """(planes buffer, byte distance hi -> lo) for the fp32 region rows x ld at t's data pointer."""
+    n = int(rows) * int(ld)
+    key = id(t)
+    ent = _PLANES.get(key)
+    if ent is not None and ent[0]() is t and ent[1] == t._version and ent[2] == (t.data_ptr(), n):
+        return ent[3], ent[4]
+    pe = (n + 7) // 8 * 8
+    buf = torch.empty(2 * pe, dtype=torch.bfloat16, device=t.device)
+    call("omlm_split_planes", ptr(t), ptr(buf), n, pe, stream_ptr())
+    try:
+        ref = weakref.ref(t, lambda _r, k=key: _PLANES.pop(k, None))
+        _PLANES[key] = (ref, t._version, (t.data_ptr(), n), buf, pe * 2)
+    except TypeError:
+        pass
+    return buf, pe * 2
+
+
 def gemm(A: torch.Tensor, B: torch.Tensor, C_: torch.Tensor, *, M: int, N: int, K: int,
          lda: Optional[int] = None, ldb: Optional[int] = None, ldc: Optional[int] = None,
          a_kmajor: bool = False, b_kmajor: bool = False, Cin: Optional[torch.Tensor] = None,
@@ -49,6 +79,14 @@ def gemm(A: torch.Tensor, B: torch.Tensor, C_: torch.Tensor, *, M: int, N: int, 
         ldcin = ldcin if ldcin is not None else Cin.shape[-1]
     a_rows = a_rows if a_rows is not None else A.numel() // lda
     b_rows = b_rows if b_rows is not None else B.numel() // ldb
+    if (A.dtype == torch.float32 and _X3_PLANES and M * N * K >= _X3_MIN_MACS and not (a_kmajor and a_map is not None)
+            and not (b_kmajor and b_map is not None) and (a_kmajor and b_kmajor or K % 8 == 0)):
+        pa, sa = operand_planes(A, a_rows, lda)
+        pb, sb = operand_planes(B, b_rows, ldb)
+        call("omlm_gemm_planes", ptr(pa), sa, ptr(pb), sb, ptr(C_), ptr(Cin), ptr(a_map), ptr(b_map), ptr(c_map),
+             a_rows, b_rows, M, N, K, lda, ldb, ldc, ldcin or 0, int(a_kmajor), int(b_kmajor), dcode(C_.dtype), float(alpha),
+             stream_ptr())
+        return
     call("omlm_gemm", ptr(A), ptr(B), ptr(C_), ptr(Cin), ptr(a_map), ptr(b_map), ptr(c_map),
          a_rows, b_rows, M, N, K, lda, ldb, ldc, ldcin or 0, int(a_kmajor), int(b_kmajor),
          dcode(A.dtype), dcode(C_.dtype), float(alpha), stream_ptr())

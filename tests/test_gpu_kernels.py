@@ -105,6 +105,56 @@ def test_gemm_layouts(ops, dev, dtype, M, N, K, akm, bkm):
     assert e < 2e-5, e          # fp32-grade: bf16x3 split, or exact products of bf16 inputs, fp32 accumulation
 
 
+@pytest.mark.parametrize("M,N,K,akm,bkm,accumulate", [(1100, 520, 264, False, True, False), (600, 264, 5000, True, True, True),
+                                                       (777, 1032, 520, False, False, False), (300, 512, 2048, True, False, True)])
+def test_gemm_fp32_on_operand_planes(ops, dev, M, N, K, akm, bkm, accumulate):
+    """fp32 operands above the size threshold take the hi/lo-plane route (omlm_split_planes + omlm_gemm_planes: one bf16 tile-kernel
+    launch with a 3x k-loop) -- same fp32-grade bar as the register-staged kernel, all four layouts, in-place accumulation
+    (split-K) included, and both routes must agree."""
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    c8 = lambda x: (x + 7) // 8 * 8
+    Am, Bm = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    Kp = c8(K)
+
+    def store(mat, kmaj, n):
+        if kmaj:
+            st = torch.randn(K, c8(n), generator=g)
+            st[:, :n] = mat.t()
+            return st
+        st = torch.zeros(n, Kp)
+        st[:, :K] = mat
+        return st
+    A, B = store(Am, akm, M).to(dev), store(Bm, bkm, N).to(dev)
+    Kcall = K if (akm and bkm) else Kp
+    C0 = torch.randn(M, N, generator=g).to(dev)
+    ref = (Am.double() @ Bm.double().t()).to(dev) + C0.double()
+    outs = []
+    for planes in (True, False):
+        ops._X3_PLANES = planes
+        try:
+            if accumulate:
+                C = C0.clone()
+                ops.gemm(A, B, C, M=M, N=N, K=Kcall, a_kmajor=akm, b_kmajor=bkm, Cin=C, a_rows=K if akm else M, b_rows=K if bkm else N)
+            else:
+                C = torch.full((M, N), float("nan"), device=dev)
+                ops.gemm(A, B, C, M=M, N=N, K=Kcall, a_kmajor=akm, b_kmajor=bkm, Cin=C0, a_rows=K if akm else M, b_rows=K if bkm else N)
+        finally:
+            ops._X3_PLANES = True
+        outs.append(C)
+    e_planes, e_reg, e_ab = relerr(outs[0], ref), relerr(outs[1], ref), relerr(outs[0], outs[1])
+    report(f"gemm_planes[{M},{N},{K},{akm},{bkm}]", planes=e_planes, register_staged=e_reg, ab=e_ab)
+    assert not torch.isnan(outs[0]).any() and e_planes < 2e-5 and e_reg < 2e-5 and e_ab < 2e-5
+    # the plane cache: a second GEMM on the same tensor objects must not split again, a modified operand must
+    n_before = len(ops._PLANES)
+    C2 = torch.empty(M, N, device=dev)
+    ops.gemm(A, B, C2, M=M, N=N, K=Kcall, a_kmajor=akm, b_kmajor=bkm, a_rows=K if akm else M, b_rows=K if bkm else N)
+    assert len(ops._PLANES) == n_before
+    A.mul_(2.0)
+    C3 = torch.empty(M, N, device=dev)
+    ops.gemm(A, B, C3, M=M, N=N, K=Kcall, a_kmajor=akm, b_kmajor=bkm, a_rows=K if akm else M, b_rows=K if bkm else N)
+    assert relerr(C3, 2.0 * C2) < 2e-5
+
+
 def test_gemm_row_maps_and_bf16_out(ops, dev):
     g = torch.Generator().manual_seed(5)
     rows, D, V = 300, 128, 41
