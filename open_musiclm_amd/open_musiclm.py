@@ -178,13 +178,11 @@ class TokenConditionedTransformerWrapper(nn.Module):
         step = 0
         nxt = torch.empty(batch, device=device, dtype=torch.long)
         n_new = max(max_time_steps - first_step, 0) * Q
-        use_cache = kwargs.pop('use_cache', True) and decode.supports(self.transformer, batch) and n_new > 0
+        use_cache = kwargs.pop('use_cache', True) and decode.supports(self.transformer, 1) and n_new > 0
         if use_cache:
             # KV-cached decode (decode.py): one new row per sampled id instead of the reference's full re-forward.
             # Ids are sampled straight into a [steps, B] buffer that the next decode step reads: no per-step cat / copies.
             rows = sum(t.shape[-1] + 1 for t in cond) + 1 + sampled.shape[-1] + n_new
-            dec = decode.CachedDecoder(self.transformer, batch, rows, self.transformer._precision())
-            last = dec.prefill(cond + [sampled])
             n0 = sampled.shape[-1]
             if exists(uniforms):
                 U = uniforms[:n_new].to(device).float().contiguous()
@@ -193,9 +191,17 @@ class TokenConditionedTransformerWrapper(nn.Module):
             else:
                 U = torch.rand(n_new, batch, V1, device=device)
             forbid = [(not allow_eos_in_output) or (ind != Q - 1) for ind in range(Q)]
-            loop = decode.SamplingLoop(dec, last, U, n0, n_new, k, temperature, forbid, use_graph=kwargs.pop('use_graph', False))
-            new_ids = loop.run()                                   # [n_new, B]
-            sampled = torch.cat((sampled, new_ids.t()), dim=-1)
+            use_graph = kwargs.pop('use_graph', False)
+            # the step kernels hold up to MAX_DECODE_BATCH samples per call: larger batches run as consecutive groups (samples are
+            # independent; every group streams the weights once per id)
+            pieces = []
+            for b0 in range(0, batch, decode.MAX_DECODE_BATCH):
+                b1 = min(batch, b0 + decode.MAX_DECODE_BATCH)
+                dec = decode.CachedDecoder(self.transformer, b1 - b0, rows, self.transformer._precision())
+                last = dec.prefill([t[b0:b1] for t in cond] + [sampled[b0:b1]])
+                loop = decode.SamplingLoop(dec, last, U[:, b0:b1].contiguous(), n0, n_new, k, temperature, forbid, use_graph=use_graph)
+                pieces.append(loop.run().t())                      # [b, n_new]
+            sampled = torch.cat((sampled, torch.cat(pieces, dim=0)), dim=-1)
         else:
             if not exists(uniforms) and UNIFORM_SOURCE is not None and n_new > 0:
                 uniforms = UNIFORM_SOURCE(n_new, batch, V1)

@@ -241,6 +241,30 @@ def test_cached_decode_matches_full_reforward(golden_dir, dev, precision):
     assert err < TOL[precision]["logits"], err
 
 
+def test_cached_decode_batches_beyond_the_kernel_group(golden_dir, dev):
+    """generate() with more samples than one decode call holds (MAX_DECODE_BATCH) runs groups of samples through the KV-cached
+    path; samples are independent, so the ids equal the full re-forward path's for the same uniforms."""
+    from open_musiclm_amd import decode
+    from open_musiclm_amd import open_musiclm as M
+    z = np.load(os.path.join(golden_dir, "tiny_coarse_generate.npz"))
+    _, model = build_from_golden(golden_dir, "tiny_coarse", dev, "bf16x3")
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd.")}
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    wrapper = M.TokenConditionedTransformerWrapper(transformer=model, unique_consecutive=False)
+    B = decode.MAX_DECODE_BATCH + 3
+    g = torch.Generator().manual_seed(17)
+    c0, c1 = torch.from_numpy(z["cond.0"]), torch.from_numpy(z["cond.1"])
+    cond = [torch.randint(0, int(c0.max()) + 1, (B,) + tuple(c0.shape[1:]), generator=g).to(dev),
+            torch.randint(0, int(c1.max()) + 1, (B,) + tuple(c1.shape[1:]), generator=g).to(dev)]
+    steps, Q, V1 = 3, model.token_sequences[-1].num_quantizers, model.token_sequences[-1].codebook_size + 1
+    U = torch.rand(steps * Q, B, V1, generator=g)
+    kw = dict(conditioning_token_ids=cond, max_time_steps=steps, temperature=float(z["temperature"]), uniforms=U)
+    a = wrapper.generate(use_cache=True, **kw)
+    b = wrapper.generate(use_cache=False, **kw)
+    assert a.shape == (B, steps, Q) and torch.equal(a, b)
+
+
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
 @pytest.mark.parametrize("name", ["tiny_fine_allweights", "tiny_semantic_t5_plainff"])
 def test_cached_decode_other_stages(golden_dir, dev, name, precision):
