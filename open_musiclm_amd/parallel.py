@@ -30,6 +30,8 @@ class DataParallel:
                 # gloo exchange) shares devices round-robin -- RCCL itself refuses two ranks on one GPU
                 torch.cuda.set_device(self.local_rank % max(torch.cuda.device_count(), 1))
             backend = backend or os.environ.get("OMLM_DP_BACKEND") or ("nccl" if use_cuda else "gloo")
+            # the host driver only supports dmabuf IPC: without this RCCL's buffer exchange fails with hipIpcGetMemHandle errors
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             dist.init_process_group(backend=backend,
                                     rank=self.rank, world_size=self.world_size)
             self.owns_group = True
