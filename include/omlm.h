@@ -47,9 +47,9 @@ int omlm_gemm(const void* A, const void* B, void* C, const float* Cin,
 int omlm_layernorm_fwd(const float* x, const float* gamma, void* y, void* xcast, float* mean, float* rstd,
                        int M, int D, int ldy, float eps, int out_dtype, void* stream);
 long long omlm_layernorm_bwd_workspace_bytes(int D);
-int omlm_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+int omlm_layernorm_bwd(const void* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                        const float* dres, float* dx, void* dxcast, float* dgamma, float* workspace, int M, int D,
-                       float dx_scale, int cast_dtype, void* stream);
+                       float dx_scale, int cast_dtype, int dy_dtype, void* stream);   /* dy_dtype: 0 fp32, 1 bf16 (GEMM epilogue output) */
 
 /* q/k l2-normalise * learned per-dim scale, v pass-through (transformer.py:265-271; utils.py:68-69), dim_head 64. */
 int omlm_qk_norm_fwd(const float* q_raw, const float* kv_raw, const float* q_scale, const float* k_scale,

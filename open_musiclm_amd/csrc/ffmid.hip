@@ -625,7 +625,7 @@ extern "C" int omlm_ffmid_bwd(const void* dh2, const void* h1, const void* convw
     float* part_g = workspace;
     float* part_c = workspace + (size_t)FF_BWD1_BLOCKS * Fp;
     if (dtype == 1 && ffmid_impl() == 1 && ffmid2_supported(Fp) && gh && (p == 0.f || drop_bits)) {
-        // du_tmp is not needed by the fused kernel: its head carries the per-row, per-wave LayerNorm^T partial sums (M x waves x 2 floats)
+        // du_tmp is not needed by the fused kernel: its first M * 2 floats carry the per-row LayerNorm^T sums
         OMLM_CHECK_ARG(((uintptr_t)du_tmp % 8) == 0, "du_tmp must be 8-byte aligned");
         int g_rows = 0, c_rows = 0;
         int rc2 = ffmid2_bwd_launch(dh2, h1, convw, gamma, rstd, (float*)du_tmp, dh1, part_g, FF_BWD1_BLOCKS, part_c, FF_BWD2_STRIPS,

@@ -224,75 +224,76 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// backward prepass: the two LayerNorm^T row sums  sum(gy), sum(gy * gh)  with gy = dropout^T(dh2) * gamma, as per-wave partials
-// bcp[row][wave][2] (the main kernel adds the NT/64 partials of a row and scales by rstd / F: fixed order, no atomics), and
-// per-workgroup partial rows of d(gamma) = sum_rows dropout^T(dh2) * gh.  Same geometry as the forward: a thread owns 8 channels
-// and walks down a strip of rows with the next two rows' loads in flight (~50 VGPRs: 8 waves per SIMD cover the HBM latency;
-// the first version -- a wave per row with the whole row requested up front, 188 VGPRs -- waited 81 % of its cycles at 3.8 TB/s).
+// backward prepass: per row  bc[row] = (rstd * sum(gy) / F, rstd * sum(gy * gh) / F)  with gy = dropout^T(dh2) * gamma,
+// and per-workgroup partial rows of d(gamma) = sum_rows dropout^T(dh2) * gh.  Wave per row, 8 channels per lane and step.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NT>
-__global__ __launch_bounds__(NT) void ffmid2_rowsum_kernel(const bf16_t* __restrict__ dh2, const bf16_t* __restrict__ gamma,
-                                                           const bf16_t* __restrict__ ghs, const unsigned char* __restrict__ drop_bits,
-                                                           float* __restrict__ bcp, float* __restrict__ part_dgamma,
-                                                           int nseq, int F, int Fp, int RB, int strips, float p) {
-    constexpr int NW = NT / 64;
-    const int b = blockIdx.x / strips, s = blockIdx.x - b * strips;
-    const int t0 = s * RB, t1 = min(nseq, t0 + RB);
+template <int MAXC>
+__global__ __launch_bounds__(256) void ffmid2_rowsum_kernel(const bf16_t* __restrict__ dh2, const bf16_t* __restrict__ gamma,
+                                                            const bf16_t* __restrict__ ghs, const unsigned char* __restrict__ drop_bits,
+                                                            const float* __restrict__ rstd, float* __restrict__ bc,
+                                                            float* __restrict__ part_dgamma, int M, int F, int Fp, float p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int col = threadIdx.x * 8;
-    const bool act = col < Fp;
-    const int colc = act ? col : 0;
     const float inv = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
-    const size_t row0 = (size_t)b * nseq;
-    v2 gm[4], dg[4];
-    {
-        const u32x4 a = *(const u32x4*)(gamma + colc);
+    const int nwaves = gridDim.x * 4;
+    v2 dg[MAXC][4], gmv[MAXC][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { gm[i] = act ? bf2_to_f2(a[i]) * inv : splat2(0.f); dg[i] = splat2(0.f); }
+    for (int k = 0; k < MAXC; ++k) {
+        const int ch = (lane + 64 * k) * 8;
+        u32x4 a = {0u, 0u, 0u, 0u};
+        if (ch < Fp) a = *(const u32x4*)(gamma + ch);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { dg[k][i] = splat2(0.f); gmv[k][i] = bf2_to_f2(a[i]); }
     }
-    struct RowIn { u32x4 d, g; unsigned bits; };
-    auto load_row = [&](RowIn& R, size_t row) {
-        R.d = *(const u32x4*)(dh2 + row * Fp + colc);
-        R.g = *(const u32x4*)(ghs + row * Fp + colc);
-        R.bits = (p > 0.f) ? (unsigned)drop_bits[row * (size_t)(Fp >> 3) + (colc >> 3)] : 0xFFu;
-    };
-    RowIn r0, r1, r2;
-    if (t0 < t1) load_row(r0, row0 + t0);
-    if (t0 + 1 < t1) load_row(r1, row0 + t0 + 1);
-#pragma unroll 1
-    for (int t = t0; t < t1; ++t) {
-        if (t + 2 < t1) load_row(r2, row0 + t + 2);
+    for (int row = blockIdx.x * 4 + wave; row < M; row += nwaves) {
         v2 s1 = splat2(0.f), s2 = splat2(0.f);
+        u32x4 d[MAXC], gq[MAXC];
+        unsigned bits[MAXC];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            v2 gy = bf2_to_f2(r0.d[i]) * gm[i];                          // dropout scale is folded into gm
-            if (!((r0.bits >> (2 * i)) & 1u)) gy[0] = 0.f;
-            if (!((r0.bits >> (2 * i + 1)) & 1u)) gy[1] = 0.f;
-            const v2 gh = bf2_to_f2(r0.g[i]);
-            s1 += gy;
-            s2 = fma2(gy, gh, s2);
+        for (int k = 0; k < MAXC; ++k) {
+            const int ch = (lane + 64 * k) * 8;
+            if (ch < Fp) {
+                d[k] = *(const u32x4*)(dh2 + (size_t)row * Fp + ch);
+                gq[k] = *(const u32x4*)(ghs + (size_t)row * Fp + ch);
+                bits[k] = (p > 0.f) ? drop_bits[(size_t)row * (Fp >> 3) + (ch >> 3)] : 0xFFu;
+            }
         }
-        // d(gamma) += dropout^T(dh2) * gh  (gamma itself must not enter): recover dy * mask from gy only where gamma != 0 is
-        // not possible in general, so form it separately
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            v2 dy = bf2_to_f2(r0.d[i]) * inv;
-            if (!((r0.bits >> (2 * i)) & 1u)) dy[0] = 0.f;
-            if (!((r0.bits >> (2 * i + 1)) & 1u)) dy[1] = 0.f;
-            dg[i] = fma2(dy, bf2_to_f2(r0.g[i]), dg[i]);
+        for (int k = 0; k < MAXC; ++k) {
+            const int ch = (lane + 64 * k) * 8;
+            if (ch < Fp) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v2 dy = bf2_to_f2(d[k][i]) * inv;
+                    if (!((bits[k] >> (2 * i)) & 1u)) dy[0] = 0.f;
+                    if (!((bits[k] >> (2 * i + 1)) & 1u)) dy[1] = 0.f;
+                    const v2 gh = bf2_to_f2(gq[k][i]);
+                    dg[k][i] = fma2(dy, gh, dg[k][i]);                // pad columns: gh == 0 and gamma == 0
+                    const v2 gy = dy * gmv[k][i];
+                    s1 += gy;
+                    s2 = fma2(gy, gh, s2);
+                }
+            }
         }
-        const float a1 = wave_sum(s1[0] + s1[1]), a2 = wave_sum(s2[0] + s2[1]);
+        const float t1 = wave_sum(s1[0] + s1[1]), t2 = wave_sum(s2[0] + s2[1]);
         if (lane == 0) {
-            float* o = bcp + ((row0 + t) * NW + wave) * 2;
-            o[0] = a1; o[1] = a2;
+            const float rs = rstd[row] / (float)F;
+            bc[2 * (size_t)row] = rs * t1;
+            bc[2 * (size_t)row + 1] = rs * t2;
         }
-        r0 = r1; r1 = r2;
     }
-    if (act) {                                                             // one partial row of d(gamma) per workgroup
-        float* o = part_dgamma + (size_t)blockIdx.x * Fp + col;
-        *(float4*)o = make_float4(dg[0][0], dg[0][1], dg[1][0], dg[1][1]);
-        *(float4*)(o + 4) = make_float4(dg[2][0], dg[2][1], dg[3][0], dg[3][1]);
+    // the four waves' d(gamma) partials -> one partial row per workgroup
+    extern __shared__ __attribute__((aligned(16))) float red[];     // [4][Fp]
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+        const int ch = (lane + 64 * k) * 8;
+        if (ch < Fp) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { red[(size_t)wave * Fp + ch + 2 * i] = dg[k][i][0]; red[(size_t)wave * Fp + ch + 2 * i + 1] = dg[k][i][1]; }
+        }
     }
+    __syncthreads();
+    for (int c = threadIdx.x; c < Fp; c += 256)
+        part_dgamma[(size_t)blockIdx.x * Fp + c] = red[c] + red[Fp + c] + red[2 * Fp + c] + red[3 * Fp + c];
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -300,11 +301,10 @@ __global__ __launch_bounds__(NT) void ffmid2_rowsum_kernel(const bf16_t* __restr
 // d(conv taps) sums in registers, and leaves ONE partial row per y.
 // ---------------------------------------------------------------------------------------------------------------------
 struct Bwd2Row { u32x2 dy, gh, xv, xg; unsigned bits; float a, b, c; };
-#define FF2_MAX_NW 8      // waves per row in the prepass (Fp <= 4096)
 
 __global__ __launch_bounds__(256) void ffmid2_bwd_kernel(const bf16_t* __restrict__ dh2, const bf16_t* __restrict__ h1,
                                                          const bf16_t* __restrict__ convw, const bf16_t* __restrict__ gamma,
-                                                         const float* __restrict__ rstd, const float* __restrict__ bcp, int nw,
+                                                         const float* __restrict__ rstd, const float* __restrict__ bc,
                                                          const bf16_t* __restrict__ ghs, const unsigned char* __restrict__ drop_bits,
                                                          bf16_t* __restrict__ dh1, float* __restrict__ part_dconv,
                                                          int nseq, int F, int Fp, int RB, int strips, int total_strips, float p) {
@@ -315,7 +315,6 @@ __global__ __launch_bounds__(256) void ffmid2_bwd_kernel(const bf16_t* __restric
     const int ld = 2 * Fp;
     const float inv = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
     const int nib = (c4 & 1) * 4;
-    const float invF = 1.0f / (float)F;
 
     v2 wv[3][2], wg[3][2], gm[2];
 #pragma unroll
@@ -342,10 +341,7 @@ __global__ __launch_bounds__(256) void ffmid2_bwd_kernel(const bf16_t* __restric
         R.xv = *(const u32x2*)(h1 + row * ld + colc);
         R.xg = *(const u32x2*)(h1 + row * ld + Fp + colc);
         R.bits = (p > 0.f) ? (unsigned)drop_bits[row * (size_t)(Fp >> 3) + (colc >> 3)] : 0xFFu;
-        const float rs = rstd[row];
-        float t1 = 0.f, t2 = 0.f;
-        for (int w = 0; w < nw; ++w) { t1 += bcp[(row * nw + w) * 2]; t2 += bcp[(row * nw + w) * 2 + 1]; }      // uniform: scalar loads
-        R.a = rs; R.b = rs * invF * t1; R.c = rs * invF * t2;
+        R.a = rstd[row]; R.b = bc[2 * row]; R.c = bc[2 * row + 1];
     };
 
 #pragma unroll 1
@@ -468,30 +464,20 @@ int ffmid2_fwd_launch(const void* h1, const void* convw, const void* gamma, void
     return omlm_post_launch("omlm_ffmid_fwd (strip)");
 }
 
-// bcp: [M][NT/64][2] floats of scratch; part_g: [>= B * strips][Fp]; part_c: [>= NY][2F*3]
-int ffmid2_bwd_launch(const void* dh2, const void* h1, const void* convw, const void* gamma, const float* rstd, float* bcp,
+// bc: [M][2] floats of scratch; part_g: [>= rowsum blocks][Fp]; part_c: [>= NY][2F*3]
+int ffmid2_bwd_launch(const void* dh2, const void* h1, const void* convw, const void* gamma, const float* rstd, float* bc,
                       void* dh1, float* part_g, int max_g_rows, float* part_c, int max_c_rows, int* g_rows, int* c_rows,
                       int M, int nseq, int F, int Fp, float p, const unsigned char* drop_bits, const void* gh, hipStream_t st) {
     const int B = M / nseq;
-    // prepass: strips of the forward's geometry, at most max_g_rows workgroups (= partial rows of d(gamma))
-    int RBp = strip_rows(nseq, 36);
-    int stripsp = (nseq + RBp - 1) / RBp;
-    if (B * stripsp > max_g_rows) { stripsp = max_g_rows / B > 0 ? max_g_rows / B : 1; RBp = (nseq + stripsp - 1) / stripsp; stripsp = (nseq + RBp - 1) / RBp; }
-    if (B * stripsp > max_g_rows) { omlm_set_error("omlm_ffmid_bwd: batch exceeds the d(gamma) partial rows of the workspace"); return OMLM_ERR_UNSUPPORTED; }
-    const int nt = ((Fp / 8 + 63) / 64) * 64;
-    const int b1 = B * stripsp;
-#define FF2_RS(NT_) hipLaunchKernelGGL(ffmid2_rowsum_kernel<NT_>, dim3(b1), dim3(NT_), 0, st, (const bf16_t*)dh2, (const bf16_t*)gamma, \
-        (const bf16_t*)gh, drop_bits, bcp, part_g, nseq, F, Fp, RBp, stripsp, p)
-    switch (nt) {
-        case 64: FF2_RS(64); break;
-        case 128: FF2_RS(128); break;
-        case 192: FF2_RS(192); break;
-        case 256: FF2_RS(256); break;
-        case 320: FF2_RS(320); break;
-        case 384: FF2_RS(384); break;
-        case 448: FF2_RS(448); break;
-        default: FF2_RS(512); break;
-    }
+    // prepass
+    const int rows4 = (M + 3) / 4;
+    const int b1 = rows4 < max_g_rows ? rows4 : max_g_rows;
+    const size_t lds = (size_t)4 * Fp * sizeof(float);
+    const int mc = (Fp / 8 + 63) / 64;
+#define FF2_RS(MC_) do { if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)ffmid2_rowsum_kernel<MC_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL(ffmid2_rowsum_kernel<MC_>, dim3(b1), dim3(256), lds, st, (const bf16_t*)dh2, (const bf16_t*)gamma, (const bf16_t*)gh, \
+                           drop_bits, rstd, bc, part_g, M, F, Fp, p); } while (0)
+    if (mc <= 1) FF2_RS(1); else if (mc <= 2) FF2_RS(2); else if (mc <= 4) FF2_RS(4); else if (mc <= 6) FF2_RS(6); else FF2_RS(8);
 #undef FF2_RS
     int rc = omlm_post_launch("omlm_ffmid_bwd (row sums)");
     if (rc) return rc;
@@ -504,7 +490,7 @@ int ffmid2_bwd_launch(const void* dh2, const void* h1, const void* convw, const 
     if (ny > max_c_rows) ny = max_c_rows;
     dim3 grid((Fp / 4 + 255) / 256, ny);
     hipLaunchKernelGGL(ffmid2_bwd_kernel, grid, dim3(256), 0, st, (const bf16_t*)dh2, (const bf16_t*)h1, (const bf16_t*)convw,
-                       (const bf16_t*)gamma, rstd, (const float*)bcp, nt / 64, (const bf16_t*)gh, drop_bits, (bf16_t*)dh1, part_c,
+                       (const bf16_t*)gamma, rstd, (const float*)bc, (const bf16_t*)gh, drop_bits, (bf16_t*)dh1, part_c,
                        nseq, F, Fp, RB, strips, total, p);
     *g_rows = b1;
     *c_rows = ny;

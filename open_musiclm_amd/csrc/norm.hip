@@ -58,8 +58,15 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restr
 // dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma ; dgamma += dy * xhat
 // A thread owns fixed columns, so dgamma is accumulated in registers over the block's rows and
 // flushed with one atomic per column per block.
-template <typename T>
-__global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+// dy arrives as fp32 or -- in bf16 mode, straight from the input-gradient GEMM's epilogue -- as bf16: the GEMM accumulates in fp32
+// and rounds once (the same rounding every other GEMM operand of that mode gets); 73 MB less to write and to re-read per call
+__device__ __forceinline__ float4 load4f(const float* p, int c) { return ((const float4*)p)[c]; }
+__device__ __forceinline__ float4 load4f(const bf16_t* p, int c) {
+    const u32x2 w = ((const u32x2*)p)[c];
+    return make_float4(bf16_lo_to_f(w[0]), bf16_hi_to_f(w[0]), bf16_lo_to_f(w[1]), bf16_hi_to_f(w[1]));
+}
+template <typename T, typename TDY>
+__global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const TDY* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ dres,
                                                             float* __restrict__ dx, T* __restrict__ dxcast,
@@ -79,7 +86,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const float* __restr
             const int c = threadIdx.x + i * LN_THREADS;
             if (c < nv) {
                 const float4 xv = ((const float4*)(x + (size_t)row * D))[c];
-                const float4 dv = ((const float4*)(dy + (size_t)row * D))[c];
+                const float4 dv = load4f(dy + (size_t)row * D, c);
                 const float4 gm = ((const float4*)gamma)[c];
                 xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
                 g[i] = make_float4(dv.x * gm.x, dv.y * gm.y, dv.z * gm.z, dv.w * gm.w);
@@ -146,9 +153,9 @@ extern "C" int omlm_layernorm_fwd(const float* x, const float* gamma, void* y, v
 extern "C" int omlm_colsum_accumulate(const float* part, float* out, int P, int C, int ldp, void* stream);
 extern "C" long long omlm_layernorm_bwd_workspace_bytes(int D) { return (long long)2048 * D * sizeof(float); }
 
-extern "C" int omlm_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+extern "C" int omlm_layernorm_bwd(const void* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                                   const float* dres, float* dx, void* dxcast, float* dgamma, float* workspace, int M, int D,
-                                  float dx_scale, int cast_dtype, void* stream) {
+                                  float dx_scale, int cast_dtype, int dy_dtype, void* stream) {
     if (M <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(dy && x && gamma && mean && rstd && dx, "null pointer");
     OMLM_CHECK_ARG(D % 4 == 0 && D <= 4 * LN_THREADS * LN_MAXV, "D must be a multiple of 4 and <= 4096");
@@ -159,10 +166,15 @@ extern "C" int omlm_layernorm_bwd(const float* dy, const float* x, const float* 
     const int blocks = two_level ? (M < 2048 ? M : 2048) : (M < 512 ? M : 512);
     dim3 grid(blocks), block(LN_THREADS);
     float* part = two_level ? workspace : nullptr;
-    if (cast_dtype == 0)
-        hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, block, 0, as_stream(stream), dy, x, gamma, mean, rstd, dres, dx, (float*)dxcast, dgamma, part, M, D, dx_scale);
+    OMLM_CHECK_ARG(dy_dtype == 0 || dy_dtype == 1, "dy_dtype: 0 = fp32, 1 = bf16");
+    if (cast_dtype == 0 && dy_dtype == 0)
+        hipLaunchKernelGGL((ln_bwd_kernel<float, float>), grid, block, 0, as_stream(stream), (const float*)dy, x, gamma, mean, rstd, dres, dx, (float*)dxcast, dgamma, part, M, D, dx_scale);
+    else if (cast_dtype == 0)
+        hipLaunchKernelGGL((ln_bwd_kernel<float, bf16_t>), grid, block, 0, as_stream(stream), (const bf16_t*)dy, x, gamma, mean, rstd, dres, dx, (float*)dxcast, dgamma, part, M, D, dx_scale);
+    else if (dy_dtype == 0)
+        hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, float>), grid, block, 0, as_stream(stream), (const float*)dy, x, gamma, mean, rstd, dres, dx, (bf16_t*)dxcast, dgamma, part, M, D, dx_scale);
     else
-        hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, grid, block, 0, as_stream(stream), dy, x, gamma, mean, rstd, dres, dx, (bf16_t*)dxcast, dgamma, part, M, D, dx_scale);
+        hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, bf16_t>), grid, block, 0, as_stream(stream), (const bf16_t*)dy, x, gamma, mean, rstd, dres, dx, (bf16_t*)dxcast, dgamma, part, M, D, dx_scale);
     int rc = omlm_post_launch("omlm_layernorm_bwd");
     if (rc) return rc;
     if (two_level) return omlm_colsum_accumulate(part, dgamma, blocks, D, D, stream);

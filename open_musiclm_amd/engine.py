@@ -34,6 +34,9 @@ _WGRAD_GROUP = os.environ.get("OMLM_WGRAD_GROUP", "1") == "1"      # grouped wei
 # nothing but the weights (forward) / the finished d(table) (backward), so they run on a second HIP stream, forked and joined with
 # events (captured as a parallel branch of the micro-step graph).  OMLM_RELPOS_ASYNC=0 puts them back in line.
 _RELPOS_ASYNC = os.environ.get("OMLM_RELPOS_ASYNC", "1") == "1"
+# bf16 mode: d(LN output) leaves the input-gradient GEMMs as bf16 (fp32 accumulate, one rounding) instead of fp32 -- it is read once,
+# by the LayerNorm backward, and every other GEMM operand of that mode is rounded the same way.  OMLM_BF16_LN_GRAD=0: fp32 as before.
+_BF16_LN_GRAD = os.environ.get("OMLM_BF16_LN_GRAD", "1") == "1"
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 
 
@@ -431,7 +434,7 @@ def trunk_backward(tr, pw: PreparedWeights, saved, dy: torch.Tensor, B: int, N: 
                       grad_of(ff.norm_mid.gamma), gconv, ws, N, F, Fp, sv.p, sv.seed,
                       seed_dev=saved["salt"] if sv.p > 0 else None, drop_bits=sv.drop_bits, gh=sv.gh)
         del du, dh2
-        dxn2 = torch.empty(M, D, device=dev)
+        dxn2 = torch.empty(M, D, dtype=T if _BF16_LN_GRAD else torch.float32, device=dev)     # consumed only by the LayerNorm backward
         if "W1pT" in w: ops.gemm(dh1, w["W1pT"], dxn2, M=M, N=D, K=2 * Fp)
         else: ops.gemm(dh1, w["W1p"], dxn2, M=M, N=D, K=2 * Fp, b_kmajor=True)
         gW1 = grad_of(ff.w_in.weight)                                               # [2F, D]
@@ -463,7 +466,7 @@ def trunk_backward(tr, pw: PreparedWeights, saved, dy: torch.Tensor, B: int, N: 
         dkv_raw = torch.empty(M, 2 * DIM_HEAD, dtype=T, device=dev)
         ops.qk_norm_bwd(dq, dk, dv, sv.q_raw, sv.kv_raw, attn.q_scale.detach(), attn.k_scale.detach(),
                         dq_raw, dkv_raw, grad_of(attn.q_scale), grad_of(attn.k_scale), H)
-        dxn = torch.empty(M, D, device=dev)
+        dxn = torch.empty(M, D, dtype=T if _BF16_LN_GRAD else torch.float32, device=dev)
         tmp = torch.empty(M, D, device=dev)
         if "WqT" in w:
             ops.gemm(dq_raw, w["WqT"], dxn, M=M, N=D, K=H * DIM_HEAD)

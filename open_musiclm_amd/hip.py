@@ -30,7 +30,7 @@ SIGNATURES = {
     "omlm_split_planes": [vp, vp, i64, i64, vp],
     "omlm_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp],
     "omlm_layernorm_bwd_workspace_bytes": [i32],
-    "omlm_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp],
+    "omlm_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, i32, vp],
     "omlm_qk_norm_fwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "omlm_qk_norm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "omlm_attn_bias_table_floats": [i32, i32],

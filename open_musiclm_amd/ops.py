@@ -143,7 +143,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dx, dxcast, dgamma, dx_scale=1
     code = dcode(dxcast.dtype) if dxcast is not None else F32
     ws = _ln_workspace(D, x.device) if dgamma is not None else None       # stream-ordered reuse: one backward at a time
     call("omlm_layernorm_bwd", ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx),
-         ptr(dxcast), ptr(dgamma), ptr(ws), M, D, float(dx_scale), code, stream_ptr())
+         ptr(dxcast), ptr(dgamma), ptr(ws), M, D, float(dx_scale), code, dcode(dy.dtype), stream_ptr())
 
 
 def qk_norm_fwd(q_raw, kv_raw, q_scale, k_scale, q, k, v, H):

@@ -242,6 +242,16 @@ def test_layernorm_fwd_bwd(ops, dev, dtype):
     e_dg = relerr(dgamma, gr.grad)
     report(f"layernorm[{dtype}]", y=e_y, xcast=e_c, dx=e_dx, dgamma=e_dg, dxcast=relerr(dxc, dx))
     assert e_y < tol and e_c < tol and e_dx < 1e-5 and e_dg < 1e-4 and relerr(dxc, dx) < tol
+    if dtype == torch.bfloat16:
+        # dy handed over as bf16 (what the input-gradient GEMM's epilogue writes in bf16 mode): exact for the rounded values
+        dyb = dy.bfloat16()
+        xr2, gr2 = x.double().requires_grad_(True), gamma.double().requires_grad_(True)
+        torch.nn.functional.layer_norm(xr2, (D,), gr2, None, 1e-5).backward(dyb.double())
+        dx2, dg2 = torch.empty(M, D, device=dev), torch.zeros(D, device=dev)
+        ops.layernorm_bwd(dyb, x, gamma, mean, rstd, dres, dx2, None, dg2, dx_scale=0.1)
+        e2, eg2 = relerr(dx2, 0.1 * (xr2.grad + dres.double())), relerr(dg2, gr2.grad)
+        report("layernorm[bf16 dy]", dx=e2, dgamma=eg2)
+        assert e2 < 1e-5 and eg2 < 1e-4
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
