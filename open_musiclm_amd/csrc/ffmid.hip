@@ -561,11 +561,11 @@ extern "C" int omlm_colsum_accumulate(const float* part, float* out, int P, int 
 bool ffmid2_supported(int Fp);
 int ffmid2_fwd_launch(const void* h1, const void* convw, const void* gamma, void* h2, float* mean, float* rstd, int M, int nseq,
                       int F, int Fp, float eps, float p, unsigned long long seed, const unsigned long long* seed_dev,
-                      unsigned char* drop_bits, void* gh, hipStream_t st);
+                      unsigned char* drop_bits, void* gh, int dtype, hipStream_t st);
 int ffmid2_bwd_launch(const void* dh2, const void* h1, const void* convw, const void* gamma, const float* rstd, float* bc,
                       void* dh1, float* part_g, int max_g_rows, float* part_c, int max_c_rows, int* g_rows, int* c_rows,
-                      int M, int nseq, int F, int Fp, float p, const unsigned char* drop_bits, const void* gh, hipStream_t st);
-// 1 (default): bf16 operands take the column-strip kernels; 0: the wave-per-row kernels for every dtype.  $OMLM_FFMID_IMPL or
+                      int M, int nseq, int F, int Fp, float p, const unsigned char* drop_bits, const void* gh, int dtype, hipStream_t st);
+// 1 (default): the column-strip kernels (both operand dtypes) where their preconditions hold; 0: the wave-per-row kernels.  $OMLM_FFMID_IMPL or
 // omlm_ffmid_set_impl (A/B runs, tests).  The two generations share every buffer layout; their dropout streams differ
 // (the keep-mask travels from forward to backward as drop_bits, so a step may not mix them only when drop_bits is null).
 static int g_ffmid_impl = -1;
@@ -592,8 +592,8 @@ extern "C" int omlm_ffmid_fwd(const void* h1, const void* convw, const void* gam
     OMLM_CHECK_ARG(nseq > 0 && M % nseq == 0, "M must be batch * nseq");
     OMLM_CHECK_ARG(p >= 0.f && p < 1.f, "dropout p");
     hipStream_t st = as_stream(stream);
-    if (dtype == 1 && ffmid_impl() == 1 && ffmid2_supported(Fp) && (p == 0.f || drop_bits))
-        return ffmid2_fwd_launch(h1, convw, gamma, h2, mean, rstd, M, nseq, F, Fp, eps, p, seed, seed_dev, drop_bits, gh, st);
+    if (ffmid_impl() == 1 && ffmid2_supported(Fp) && (p == 0.f || drop_bits))
+        return ffmid2_fwd_launch(h1, convw, gamma, h2, mean, rstd, M, nseq, F, Fp, eps, p, seed, seed_dev, drop_bits, gh, dtype, st);
     const int rows4 = (M + 3) / 4;
     dim3 grid(rows4 < 4096 ? rows4 : 4096), block(FF_THREADS);
     const size_t lds_fwd = (size_t)4 * Fp * sizeof(float);
@@ -624,12 +624,12 @@ extern "C" int omlm_ffmid_bwd(const void* dh2, const void* h1, const void* convw
     hipStream_t st = as_stream(stream);
     float* part_g = workspace;
     float* part_c = workspace + (size_t)FF_BWD1_BLOCKS * Fp;
-    if (dtype == 1 && ffmid_impl() == 1 && ffmid2_supported(Fp) && gh && (p == 0.f || drop_bits)) {
+    if (ffmid_impl() == 1 && ffmid2_supported(Fp) && gh && (p == 0.f || drop_bits)) {
         // du_tmp is not needed by the fused kernel: its first M * 2 floats carry the per-row LayerNorm^T sums
         OMLM_CHECK_ARG(((uintptr_t)du_tmp % 8) == 0, "du_tmp must be 8-byte aligned");
         int g_rows = 0, c_rows = 0;
         int rc2 = ffmid2_bwd_launch(dh2, h1, convw, gamma, rstd, (float*)du_tmp, dh1, part_g, FF_BWD1_BLOCKS, part_c, FF_BWD2_STRIPS,
-                                    &g_rows, &c_rows, M, nseq, F, Fp, p, drop_bits, gh, st);
+                                    &g_rows, &c_rows, M, nseq, F, Fp, p, drop_bits, gh, dtype, st);
         if (rc2) return rc2;
         if (dgamma) { rc2 = omlm_colsum_accumulate(part_g, dgamma, g_rows, F, Fp, stream); if (rc2) return rc2; }
         if (dconv)  { rc2 = omlm_colsum_accumulate(part_c, dconv, c_rows, 2 * F * 3, 2 * F * 3, stream); if (rc2) return rc2; }

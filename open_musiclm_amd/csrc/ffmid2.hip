@@ -29,6 +29,51 @@ __device__ __forceinline__ v2 bf2_to_f2(unsigned w) { return mk2(u2f(w << 16), u
 __device__ __forceinline__ unsigned f2_to_bf2(v2 v) { return pack_bf16_rne(v[0], v[1]); }
 __device__ __forceinline__ v2 fma2(v2 a, v2 b, v2 c) { return __builtin_elementwise_fma(a, b, c); }
 
+// 8 / 4 consecutive channels as they sit in HBM (bf16: 16 / 8 bytes, fp32: 32 / 16 bytes), handed out as float2 pairs
+template <typename T> struct Ch8;
+template <> struct Ch8<bf16_t> {
+    u32x4 r;
+    __device__ __forceinline__ void load(const bf16_t* p) { r = *(const u32x4*)p; }
+    __device__ __forceinline__ void zero() { r[0] = 0u; r[1] = 0u; r[2] = 0u; r[3] = 0u; }
+    __device__ __forceinline__ v2 get(int i) const { return bf2_to_f2(r[i]); }
+    static __device__ __forceinline__ void store(bf16_t* p, const v2 (&y)[4]) {
+        u32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = f2_to_bf2(y[i]);
+        *(u32x4*)p = o;
+    }
+};
+template <> struct Ch8<float> {
+    float4 a, b;
+    __device__ __forceinline__ void load(const float* p) { a = ((const float4*)p)[0]; b = ((const float4*)p)[1]; }
+    __device__ __forceinline__ void zero() { a = make_float4(0.f, 0.f, 0.f, 0.f); b = a; }
+    __device__ __forceinline__ v2 get(int i) const {
+        return i == 0 ? mk2(a.x, a.y) : (i == 1 ? mk2(a.z, a.w) : (i == 2 ? mk2(b.x, b.y) : mk2(b.z, b.w)));
+    }
+    static __device__ __forceinline__ void store(float* p, const v2 (&y)[4]) {
+        ((float4*)p)[0] = make_float4(y[0][0], y[0][1], y[1][0], y[1][1]);
+        ((float4*)p)[1] = make_float4(y[2][0], y[2][1], y[3][0], y[3][1]);
+    }
+};
+template <typename T> struct Ch4;
+template <> struct Ch4<bf16_t> {
+    u32x2 r;
+    __device__ __forceinline__ void load(const bf16_t* p) { r = *(const u32x2*)p; }
+    __device__ __forceinline__ void zero() { r[0] = 0u; r[1] = 0u; }
+    __device__ __forceinline__ v2 get(int i) const { return bf2_to_f2(r[i]); }
+    static __device__ __forceinline__ void store(bf16_t* p, const v2 (&y)[2]) {
+        u32x2 o; o[0] = f2_to_bf2(y[0]); o[1] = f2_to_bf2(y[1]);
+        *(u32x2*)p = o;
+    }
+};
+template <> struct Ch4<float> {
+    float4 a;
+    __device__ __forceinline__ void load(const float* p) { a = *(const float4*)p; }
+    __device__ __forceinline__ void zero() { a = make_float4(0.f, 0.f, 0.f, 0.f); }
+    __device__ __forceinline__ v2 get(int i) const { return i == 0 ? mk2(a.x, a.y) : mk2(a.z, a.w); }
+    static __device__ __forceinline__ void store(float* p, const v2 (&y)[2]) { *(float4*)p = make_float4(y[0][0], y[0][1], y[1][0], y[1][1]); }
+};
+
 // GELU pieces of a gate pair u:  h = Phi(u) = 0.5 (1 + erf(u / sqrt 2)),  ex = exp(-u^2 / 2).
 // erf by Abramowitz-Stegun 7.1.26 like ffmid.hip (|abs err| <= 1.5e-7), with the 1/sqrt2 and the 0.5 folded into constants.
 __device__ __forceinline__ void gelu_parts(v2 u, v2& h, v2& ex) {
@@ -74,14 +119,15 @@ __device__ __forceinline__ void keep_words(unsigned long long seed, unsigned lon
 // forward.  grid: B * strips workgroups of NT threads (NT = chunks of 8 channels rounded up to waves); strip s of sample b
 // covers rows [s * RB, min(nseq, (s + 1) * RB)).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NT>
-__global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kernel(const bf16_t* __restrict__ h1, const bf16_t* __restrict__ convw,
-                                                        const bf16_t* __restrict__ gamma, bf16_t* __restrict__ h2,
+template <typename T, int NT>
+__global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kernel(const T* __restrict__ h1, const T* __restrict__ convw,
+                                                        const T* __restrict__ gamma, T* __restrict__ h2,
                                                         float* __restrict__ mean, float* __restrict__ rstd,
                                                         int nseq, int F, int Fp, int RB, int strips, float eps, float p,
                                                         unsigned long long seed, const unsigned long long* __restrict__ seed_dev,
-                                                        unsigned char* __restrict__ drop_bits, bf16_t* __restrict__ gh_out) {
+                                                        unsigned char* __restrict__ drop_bits, T* __restrict__ gh_out) {
     constexpr int NW = NT / 64;
+    constexpr int RB_ = sizeof(T) == 2 ? FS_R : (FS_R > 2 ? 2 : FS_R);        // rows per batch: fp32 rows cost twice the registers
     __shared__ float st[2][FS_R][NW][2];
     if (seed_dev) seed += seed_dev[0] * 0x9E3779B97F4A7C15ull;
     const int b = blockIdx.x / strips, s = blockIdx.x - b * strips;
@@ -100,50 +146,53 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
     v2 wv[3][4], wg[3][4], gm[4];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const u32x4 a = *(const u32x4*)(convw + (size_t)k * ld + colc);
-        const u32x4 c = *(const u32x4*)(convw + (size_t)k * ld + Fp + colc);
+        Ch8<T> a, c;
+        a.load(convw + (size_t)k * ld + colc);
+        c.load(convw + (size_t)k * ld + Fp + colc);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            wv[k][i] = act ? bf2_to_f2(a[i]) : splat2(0.f);
-            wg[k][i] = act ? bf2_to_f2(c[i]) : splat2(0.f);
+            wv[k][i] = act ? a.get(i) : splat2(0.f);
+            wg[k][i] = act ? c.get(i) : splat2(0.f);
         }
     }
     {
-        const u32x4 a = *(const u32x4*)(gamma + colc);
+        Ch8<T> a;
+        a.load(gamma + colc);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) gm[i] = bf2_to_f2(a[i]) * inv;          // dropout scale folded into gamma
+        for (int i = 0; i < 4; ++i) gm[i] = a.get(i) * inv;                  // dropout scale folded into gamma
     }
     // conv window: rows t0 - 1 and t0 - 2 of the same sample (zero before the sample starts, transformer.py:129)
     v2 x1v[4], x1g[4], x2v[4], x2g[4];
     {
-        u32x4 a = {0u, 0u, 0u, 0u}, c = a, d = a, e = a;
-        if (t0 >= 1) { a = *(const u32x4*)(h1 + (row0 + t0 - 1) * ld + colc); c = *(const u32x4*)(h1 + (row0 + t0 - 1) * ld + Fp + colc); }
-        if (t0 >= 2) { d = *(const u32x4*)(h1 + (row0 + t0 - 2) * ld + colc); e = *(const u32x4*)(h1 + (row0 + t0 - 2) * ld + Fp + colc); }
+        Ch8<T> a, c, d, e;
+        a.zero(); c.zero(); d.zero(); e.zero();
+        if (t0 >= 1) { a.load(h1 + (row0 + t0 - 1) * ld + colc); c.load(h1 + (row0 + t0 - 1) * ld + Fp + colc); }
+        if (t0 >= 2) { d.load(h1 + (row0 + t0 - 2) * ld + colc); e.load(h1 + (row0 + t0 - 2) * ld + Fp + colc); }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { x1v[i] = bf2_to_f2(a[i]); x1g[i] = bf2_to_f2(c[i]); x2v[i] = bf2_to_f2(d[i]); x2g[i] = bf2_to_f2(e[i]); }
+        for (int i = 0; i < 4; ++i) { x1v[i] = a.get(i); x1g[i] = c.get(i); x2v[i] = d.get(i); x2g[i] = e.get(i); }
     }
-    u32x4 rv[FS_R], rg[FS_R];
+    Ch8<T> rv[RB_], rg[RB_];
 #pragma unroll
-    for (int r = 0; r < FS_R; ++r)
+    for (int r = 0; r < RB_; ++r)
         if (t0 + r < t1) {
-            rv[r] = *(const u32x4*)(h1 + (row0 + t0 + r) * ld + colc);
-            rg[r] = *(const u32x4*)(h1 + (row0 + t0 + r) * ld + Fp + colc);
+            rv[r].load(h1 + (row0 + t0 + r) * ld + colc);
+            rg[r].load(h1 + (row0 + t0 + r) * ld + Fp + colc);
         }
     const float invF = 1.0f / (float)F;
     int it = 0;
 #pragma unroll 1
-    for (int tb = t0; tb < t1; tb += FS_R, ++it) {
-        v2 g[FS_R][4];
-        float ls[FS_R], lq[FS_R];
+    for (int tb = t0; tb < t1; tb += RB_, ++it) {
+        v2 g[RB_][4];
+        float ls[RB_], lq[RB_];
         // sweep 1: conv + GEGLU of the batch, per-thread sums for LayerNorm
 #pragma unroll
-        for (int r = 0; r < FS_R; ++r) {
+        for (int r = 0; r < RB_; ++r) {
             ls[r] = 0.f; lq[r] = 0.f;
             if (tb + r < t1) {
                 v2 s2 = splat2(0.f), q2 = splat2(0.f);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const v2 xv = bf2_to_f2(rv[r][i]), xg = bf2_to_f2(rg[r][i]);
+                    const v2 xv = rv[r].get(i), xg = rg[r].get(i);
                     const v2 uv = fma2(wv[2][i], xv, fma2(wv[1][i], x1v[i], wv[0][i] * x2v[i]));
                     const v2 ug = fma2(wg[2][i], xg, fma2(wg[1][i], x1g[i], wg[0][i] * x2g[i]));
                     x2v[i] = x1v[i]; x1v[i] = xv; x2g[i] = x1g[i]; x1g[i] = xg;
@@ -163,21 +212,21 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
         }
         // next batch's rows: in flight during the reduction and the second sweep
 #pragma unroll
-        for (int r = 0; r < FS_R; ++r)
-            if (tb + FS_R + r < t1) {
-                rv[r] = *(const u32x4*)(h1 + (row0 + tb + FS_R + r) * ld + colc);
-                rg[r] = *(const u32x4*)(h1 + (row0 + tb + FS_R + r) * ld + Fp + colc);
+        for (int r = 0; r < RB_; ++r)
+            if (tb + RB_ + r < t1) {
+                rv[r].load(h1 + (row0 + tb + RB_ + r) * ld + colc);
+                rg[r].load(h1 + (row0 + tb + RB_ + r) * ld + Fp + colc);
             }
 #pragma unroll
-        for (int r = 0; r < FS_R; ++r) { ls[r] = wave_sum(ls[r]); lq[r] = wave_sum(lq[r]); }
+        for (int r = 0; r < RB_; ++r) { ls[r] = wave_sum(ls[r]); lq[r] = wave_sum(lq[r]); }
         if (lane == 0) {
 #pragma unroll
-            for (int r = 0; r < FS_R; ++r) { st[it & 1][r][wave][0] = ls[r]; st[it & 1][r][wave][1] = lq[r]; }
+            for (int r = 0; r < RB_; ++r) { st[it & 1][r][wave][0] = ls[r]; st[it & 1][r][wave][1] = lq[r]; }
         }
         __syncthreads();          // one barrier per batch: the other parity's slots are rewritten only after the next one
         // sweep 2: normalise, gamma, dropout, store
 #pragma unroll
-        for (int r = 0; r < FS_R; ++r) {
+        for (int r = 0; r < RB_; ++r) {
             if (tb + r >= t1) continue;
             float S = 0.f, Q = 0.f;
 #pragma unroll
@@ -214,11 +263,8 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
                 }
                 if (drop_bits) drop_bits[row * (size_t)(Fp >> 3) + (col >> 3)] = (unsigned char)bits;
             }
-            u32x4 o, og;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { o[i] = f2_to_bf2(y[i]); og[i] = f2_to_bf2(gh[i]); }
-            *(u32x4*)(h2 + row * Fp + col) = o;
-            if (gh_out) *(u32x4*)(gh_out + row * Fp + col) = og;
+            Ch8<T>::store(h2 + row * Fp + col, y);
+            if (gh_out) Ch8<T>::store(gh_out + row * Fp + col, gh);
         }
     }
 }
@@ -227,9 +273,9 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
 // backward prepass: per row  bc[row] = (rstd * sum(gy) / F, rstd * sum(gy * gh) / F)  with gy = dropout^T(dh2) * gamma,
 // and per-workgroup partial rows of d(gamma) = sum_rows dropout^T(dh2) * gh.  Wave per row, 8 channels per lane and step.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int MAXC>
-__global__ __launch_bounds__(256) void ffmid2_rowsum_kernel(const bf16_t* __restrict__ dh2, const bf16_t* __restrict__ gamma,
-                                                            const bf16_t* __restrict__ ghs, const unsigned char* __restrict__ drop_bits,
+template <typename T, int MAXC>
+__global__ __launch_bounds__(256) void ffmid2_rowsum_kernel(const T* __restrict__ dh2, const T* __restrict__ gamma,
+                                                            const T* __restrict__ ghs, const unsigned char* __restrict__ drop_bits,
                                                             const float* __restrict__ rstd, float* __restrict__ bc,
                                                             float* __restrict__ part_dgamma, int M, int F, int Fp, float p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -239,21 +285,22 @@ __global__ __launch_bounds__(256) void ffmid2_rowsum_kernel(const bf16_t* __rest
 #pragma unroll
     for (int k = 0; k < MAXC; ++k) {
         const int ch = (lane + 64 * k) * 8;
-        u32x4 a = {0u, 0u, 0u, 0u};
-        if (ch < Fp) a = *(const u32x4*)(gamma + ch);
+        Ch8<T> a;
+        a.zero();
+        if (ch < Fp) a.load(gamma + ch);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { dg[k][i] = splat2(0.f); gmv[k][i] = bf2_to_f2(a[i]); }
+        for (int i = 0; i < 4; ++i) { dg[k][i] = splat2(0.f); gmv[k][i] = a.get(i); }
     }
     for (int row = blockIdx.x * 4 + wave; row < M; row += nwaves) {
         v2 s1 = splat2(0.f), s2 = splat2(0.f);
-        u32x4 d[MAXC], gq[MAXC];
+        Ch8<T> d[MAXC], gq[MAXC];
         unsigned bits[MAXC];
 #pragma unroll
         for (int k = 0; k < MAXC; ++k) {
             const int ch = (lane + 64 * k) * 8;
             if (ch < Fp) {
-                d[k] = *(const u32x4*)(dh2 + (size_t)row * Fp + ch);
-                gq[k] = *(const u32x4*)(ghs + (size_t)row * Fp + ch);
+                d[k].load(dh2 + (size_t)row * Fp + ch);
+                gq[k].load(ghs + (size_t)row * Fp + ch);
                 bits[k] = (p > 0.f) ? drop_bits[(size_t)row * (Fp >> 3) + (ch >> 3)] : 0xFFu;
             }
         }
@@ -263,10 +310,10 @@ __global__ __launch_bounds__(256) void ffmid2_rowsum_kernel(const bf16_t* __rest
             if (ch < Fp) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    v2 dy = bf2_to_f2(d[k][i]) * inv;
+                    v2 dy = d[k].get(i) * inv;
                     if (!((bits[k] >> (2 * i)) & 1u)) dy[0] = 0.f;
                     if (!((bits[k] >> (2 * i + 1)) & 1u)) dy[1] = 0.f;
-                    const v2 gh = bf2_to_f2(gq[k][i]);
+                    const v2 gh = gq[k].get(i);
                     dg[k][i] = fma2(dy, gh, dg[k][i]);                // pad columns: gh == 0 and gamma == 0
                     const v2 gy = dy * gmv[k][i];
                     s1 += gy;
@@ -300,13 +347,14 @@ __global__ __launch_bounds__(256) void ffmid2_rowsum_kernel(const bf16_t* __rest
 // backward main.  grid (column blocks of 256 threads x 4 channels, NY); workgroup y walks strips y, y + NY, ... keeping its
 // d(conv taps) sums in registers, and leaves ONE partial row per y.
 // ---------------------------------------------------------------------------------------------------------------------
-struct Bwd2Row { u32x2 dy, gh, xv, xg; unsigned bits; float a, b, c; };
+template <typename T> struct Bwd2Row { Ch4<T> dy, gh, xv, xg; unsigned bits; float a, b, c; };
 
-__global__ __launch_bounds__(256) void ffmid2_bwd_kernel(const bf16_t* __restrict__ dh2, const bf16_t* __restrict__ h1,
-                                                         const bf16_t* __restrict__ convw, const bf16_t* __restrict__ gamma,
+template <typename T>
+__global__ __launch_bounds__(256) void ffmid2_bwd_kernel(const T* __restrict__ dh2, const T* __restrict__ h1,
+                                                         const T* __restrict__ convw, const T* __restrict__ gamma,
                                                          const float* __restrict__ rstd, const float* __restrict__ bc,
-                                                         const bf16_t* __restrict__ ghs, const unsigned char* __restrict__ drop_bits,
-                                                         bf16_t* __restrict__ dh1, float* __restrict__ part_dconv,
+                                                         const T* __restrict__ ghs, const unsigned char* __restrict__ drop_bits,
+                                                         T* __restrict__ dh1, float* __restrict__ part_dconv,
                                                          int nseq, int F, int Fp, int RB, int strips, int total_strips, float p) {
     const int c4 = blockIdx.x * 256 + threadIdx.x;
     const int col = c4 * 4;
@@ -319,15 +367,17 @@ __global__ __launch_bounds__(256) void ffmid2_bwd_kernel(const bf16_t* __restric
     v2 wv[3][2], wg[3][2], gm[2];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const u32x2 a = *(const u32x2*)(convw + (size_t)k * ld + colc);
-        const u32x2 c = *(const u32x2*)(convw + (size_t)k * ld + Fp + colc);
+        Ch4<T> a, c;
+        a.load(convw + (size_t)k * ld + colc);
+        c.load(convw + (size_t)k * ld + Fp + colc);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) { wv[k][i] = act ? bf2_to_f2(a[i]) : splat2(0.f); wg[k][i] = act ? bf2_to_f2(c[i]) : splat2(0.f); }
+        for (int i = 0; i < 2; ++i) { wv[k][i] = act ? a.get(i) : splat2(0.f); wg[k][i] = act ? c.get(i) : splat2(0.f); }
     }
     {
-        const u32x2 a = *(const u32x2*)(gamma + colc);
+        Ch4<T> a;
+        a.load(gamma + colc);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) gm[i] = act ? bf2_to_f2(a[i]) * inv : splat2(0.f);
+        for (int i = 0; i < 2; ++i) gm[i] = act ? a.get(i) * inv : splat2(0.f);
     }
     v2 dcv[3][2], dcg[3][2];
 #pragma unroll
@@ -335,11 +385,11 @@ __global__ __launch_bounds__(256) void ffmid2_bwd_kernel(const bf16_t* __restric
 #pragma unroll
         for (int i = 0; i < 2; ++i) { dcv[k][i] = splat2(0.f); dcg[k][i] = splat2(0.f); }
 
-    auto load_row = [&](Bwd2Row& R, size_t row) {
-        R.dy = *(const u32x2*)(dh2 + row * Fp + colc);
-        R.gh = *(const u32x2*)(ghs + row * Fp + colc);
-        R.xv = *(const u32x2*)(h1 + row * ld + colc);
-        R.xg = *(const u32x2*)(h1 + row * ld + Fp + colc);
+    auto load_row = [&](Bwd2Row<T>& R, size_t row) {
+        R.dy.load(dh2 + row * Fp + colc);
+        R.gh.load(ghs + row * Fp + colc);
+        R.xv.load(h1 + row * ld + colc);
+        R.xg.load(h1 + row * ld + Fp + colc);
         R.bits = (p > 0.f) ? (unsigned)drop_bits[row * (size_t)(Fp >> 3) + (colc >> 3)] : 0xFFu;
         R.a = rstd[row]; R.b = bc[2 * row]; R.c = bc[2 * row + 1];
     };
@@ -352,17 +402,18 @@ __global__ __launch_bounds__(256) void ffmid2_bwd_kernel(const bf16_t* __restric
         const size_t row0 = (size_t)b * nseq;
         v2 x1v[2], x1g[2], x2v[2], x2g[2], p1v[2], p1g[2], p2v[2], p2g[2];
         {
-            u32x2 a = {0u, 0u}, c = a, d = a, e = a;
-            if (t0 >= 1) { a = *(const u32x2*)(h1 + (row0 + t0 - 1) * ld + colc); c = *(const u32x2*)(h1 + (row0 + t0 - 1) * ld + Fp + colc); }
-            if (t0 >= 2) { d = *(const u32x2*)(h1 + (row0 + t0 - 2) * ld + colc); e = *(const u32x2*)(h1 + (row0 + t0 - 2) * ld + Fp + colc); }
+            Ch4<T> a, c, d, e;
+            a.zero(); c.zero(); d.zero(); e.zero();
+            if (t0 >= 1) { a.load(h1 + (row0 + t0 - 1) * ld + colc); c.load(h1 + (row0 + t0 - 1) * ld + Fp + colc); }
+            if (t0 >= 2) { d.load(h1 + (row0 + t0 - 2) * ld + colc); e.load(h1 + (row0 + t0 - 2) * ld + Fp + colc); }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                x1v[i] = bf2_to_f2(a[i]); x1g[i] = bf2_to_f2(c[i]); x2v[i] = bf2_to_f2(d[i]); x2g[i] = bf2_to_f2(e[i]);
+                x1v[i] = a.get(i); x1g[i] = c.get(i); x2v[i] = d.get(i); x2g[i] = e.get(i);
                 p1v[i] = splat2(0.f); p1g[i] = splat2(0.f); p2v[i] = splat2(0.f); p2g[i] = splat2(0.f);
             }
         }
         const int tend = t1 + 2;                      // rows t1, t1 + 1: du recomputed for the conv^T of this strip's last two rows
-        Bwd2Row cur, nxt;
+        Bwd2Row<T> cur, nxt;
         load_row(cur, row0 + t0);
 #pragma unroll 1
         for (int t = t0; t < tend; ++t) {
@@ -373,13 +424,13 @@ __global__ __launch_bounds__(256) void ffmid2_bwd_kernel(const bf16_t* __restric
                 const unsigned kb = cur.bits >> nib;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    v2 gy = bf2_to_f2(cur.dy[i]) * gm[i];
+                    v2 gy = cur.dy.get(i) * gm[i];
                     if (!((kb >> (2 * i)) & 1u)) gy[0] = 0.f;
                     if (!((kb >> (2 * i + 1)) & 1u)) gy[1] = 0.f;
-                    const v2 gh = bf2_to_f2(cur.gh[i]);
+                    const v2 gh = cur.gh.get(i);
                     v2 dg = fma2(gy, splat2(cur.a), splat2(-cur.b));
                     dg = fma2(gh, splat2(-cur.c), dg);
-                    const v2 xv = bf2_to_f2(cur.xv[i]), xg = bf2_to_f2(cur.xg[i]);
+                    const v2 xv = cur.xv.get(i), xg = cur.xg.get(i);
                     const v2 uv = fma2(wv[2][i], xv, fma2(wv[1][i], x1v[i], wv[0][i] * x2v[i]));
                     const v2 ug = fma2(wg[2][i], xg, fma2(wg[1][i], x1g[i], wg[0][i] * x2g[i]));
                     v2 h, ex;
@@ -399,14 +450,14 @@ __global__ __launch_bounds__(256) void ffmid2_bwd_kernel(const bf16_t* __restric
             }
             // conv^T: dh1[t-2] = w2 du[t-2] + w1 du[t-1] + w0 du[t] is complete now
             if (t - 2 >= t0 && act) {
-                u32x2 ov, og;
+                v2 ov[2], og[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    ov[i] = f2_to_bf2(fma2(wv[0][i], duv[i], p2v[i]));
-                    og[i] = f2_to_bf2(fma2(wg[0][i], dug[i], p2g[i]));
+                    ov[i] = fma2(wv[0][i], duv[i], p2v[i]);
+                    og[i] = fma2(wg[0][i], dug[i], p2g[i]);
                 }
-                *(u32x2*)(dh1 + (row0 + t - 2) * ld + col) = ov;
-                *(u32x2*)(dh1 + (row0 + t - 2) * ld + Fp + col) = og;
+                Ch4<T>::store(dh1 + (row0 + t - 2) * ld + col, ov);
+                Ch4<T>::store(dh1 + (row0 + t - 2) * ld + Fp + col, og);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -440,16 +491,17 @@ static int strip_rows(int nseq, int target) {
 
 bool ffmid2_supported(int Fp) { return Fp % 8 == 0 && Fp / 8 <= 512; }
 
-int ffmid2_fwd_launch(const void* h1, const void* convw, const void* gamma, void* h2, float* mean, float* rstd, int M, int nseq,
-                      int F, int Fp, float eps, float p, unsigned long long seed, const unsigned long long* seed_dev,
-                      unsigned char* drop_bits, void* gh, hipStream_t st) {
+template <typename T>
+static int fwd_launch_t(const void* h1, const void* convw, const void* gamma, void* h2, float* mean, float* rstd, int M, int nseq,
+                        int F, int Fp, float eps, float p, unsigned long long seed, const unsigned long long* seed_dev,
+                        unsigned char* drop_bits, void* gh, hipStream_t st) {
     const int B = M / nseq;
     const int RB = strip_rows(nseq, 36);
     const int strips = (nseq + RB - 1) / RB;
     const int nt = ((Fp / 8 + 63) / 64) * 64;
     dim3 grid(B * strips);
-#define FF2_FWD(NT_) hipLaunchKernelGGL(ffmid2_fwd_kernel<NT_>, grid, dim3(NT_), 0, st, (const bf16_t*)h1, (const bf16_t*)convw, \
-        (const bf16_t*)gamma, (bf16_t*)h2, mean, rstd, nseq, F, Fp, RB, strips, eps, p, seed, seed_dev, drop_bits, (bf16_t*)gh)
+#define FF2_FWD(NT_) hipLaunchKernelGGL((ffmid2_fwd_kernel<T, NT_>), grid, dim3(NT_), 0, st, (const T*)h1, (const T*)convw, \
+        (const T*)gamma, (T*)h2, mean, rstd, nseq, F, Fp, RB, strips, eps, p, seed, seed_dev, drop_bits, (T*)gh)
     switch (nt) {
         case 64: FF2_FWD(64); break;
         case 128: FF2_FWD(128); break;
@@ -464,18 +516,27 @@ int ffmid2_fwd_launch(const void* h1, const void* convw, const void* gamma, void
     return omlm_post_launch("omlm_ffmid_fwd (strip)");
 }
 
+// dtype: 0 = fp32 operands ("bf16x3" mode), 1 = bf16
+int ffmid2_fwd_launch(const void* h1, const void* convw, const void* gamma, void* h2, float* mean, float* rstd, int M, int nseq,
+                      int F, int Fp, float eps, float p, unsigned long long seed, const unsigned long long* seed_dev,
+                      unsigned char* drop_bits, void* gh, int dtype, hipStream_t st) {
+    if (dtype == 0) return fwd_launch_t<float>(h1, convw, gamma, h2, mean, rstd, M, nseq, F, Fp, eps, p, seed, seed_dev, drop_bits, gh, st);
+    return fwd_launch_t<bf16_t>(h1, convw, gamma, h2, mean, rstd, M, nseq, F, Fp, eps, p, seed, seed_dev, drop_bits, gh, st);
+}
+
 // bc: [M][2] floats of scratch; part_g: [>= rowsum blocks][Fp]; part_c: [>= NY][2F*3]
-int ffmid2_bwd_launch(const void* dh2, const void* h1, const void* convw, const void* gamma, const float* rstd, float* bc,
-                      void* dh1, float* part_g, int max_g_rows, float* part_c, int max_c_rows, int* g_rows, int* c_rows,
-                      int M, int nseq, int F, int Fp, float p, const unsigned char* drop_bits, const void* gh, hipStream_t st) {
+template <typename T>
+static int bwd_launch_t(const void* dh2, const void* h1, const void* convw, const void* gamma, const float* rstd, float* bc,
+                        void* dh1, float* part_g, int max_g_rows, float* part_c, int max_c_rows, int* g_rows, int* c_rows,
+                        int M, int nseq, int F, int Fp, float p, const unsigned char* drop_bits, const void* gh, hipStream_t st) {
     const int B = M / nseq;
     // prepass
     const int rows4 = (M + 3) / 4;
     const int b1 = rows4 < max_g_rows ? rows4 : max_g_rows;
     const size_t lds = (size_t)4 * Fp * sizeof(float);
     const int mc = (Fp / 8 + 63) / 64;
-#define FF2_RS(MC_) do { if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)ffmid2_rowsum_kernel<MC_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        hipLaunchKernelGGL(ffmid2_rowsum_kernel<MC_>, dim3(b1), dim3(256), lds, st, (const bf16_t*)dh2, (const bf16_t*)gamma, (const bf16_t*)gh, \
+#define FF2_RS(MC_) do { if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)ffmid2_rowsum_kernel<T, MC_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL((ffmid2_rowsum_kernel<T, MC_>), dim3(b1), dim3(256), lds, st, (const T*)dh2, (const T*)gamma, (const T*)gh, \
                            drop_bits, rstd, bc, part_g, M, F, Fp, p); } while (0)
     if (mc <= 1) FF2_RS(1); else if (mc <= 2) FF2_RS(2); else if (mc <= 4) FF2_RS(4); else if (mc <= 6) FF2_RS(6); else FF2_RS(8);
 #undef FF2_RS
@@ -489,10 +550,20 @@ int ffmid2_bwd_launch(const void* dh2, const void* h1, const void* convw, const 
     int ny = (total + per - 1) / per;
     if (ny > max_c_rows) ny = max_c_rows;
     dim3 grid((Fp / 4 + 255) / 256, ny);
-    hipLaunchKernelGGL(ffmid2_bwd_kernel, grid, dim3(256), 0, st, (const bf16_t*)dh2, (const bf16_t*)h1, (const bf16_t*)convw,
-                       (const bf16_t*)gamma, rstd, (const float*)bc, (const bf16_t*)gh, drop_bits, (bf16_t*)dh1, part_c,
+    hipLaunchKernelGGL(ffmid2_bwd_kernel<T>, grid, dim3(256), 0, st, (const T*)dh2, (const T*)h1, (const T*)convw,
+                       (const T*)gamma, rstd, (const float*)bc, (const T*)gh, drop_bits, (T*)dh1, part_c,
                        nseq, F, Fp, RB, strips, total, p);
     *g_rows = b1;
     *c_rows = ny;
     return omlm_post_launch("omlm_ffmid_bwd (strip)");
+}
+
+int ffmid2_bwd_launch(const void* dh2, const void* h1, const void* convw, const void* gamma, const float* rstd, float* bc,
+                      void* dh1, float* part_g, int max_g_rows, float* part_c, int max_c_rows, int* g_rows, int* c_rows,
+                      int M, int nseq, int F, int Fp, float p, const unsigned char* drop_bits, const void* gh, int dtype, hipStream_t st) {
+    if (dtype == 0)
+        return bwd_launch_t<float>(dh2, h1, convw, gamma, rstd, bc, dh1, part_g, max_g_rows, part_c, max_c_rows, g_rows, c_rows,
+                                   M, nseq, F, Fp, p, drop_bits, gh, st);
+    return bwd_launch_t<bf16_t>(dh2, h1, convw, gamma, rstd, bc, dh1, part_g, max_g_rows, part_c, max_c_rows, g_rows, c_rows,
+                                M, nseq, F, Fp, p, drop_bits, gh, st);
 }

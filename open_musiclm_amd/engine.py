@@ -362,8 +362,9 @@ def trunk_forward(tr, pw: PreparedWeights, x: torch.Tensor, keymask: Optional[to
         p = float(ff.dropout_p) if training else 0.0
         seed = seeds[li] if (p > 0 and seeds is not None) else 0
         drop_bits = torch.empty(M, Fp // 8, dtype=torch.uint8, device=dev) if (p > 0 and save) else None
-        # bf16 mode: the normalised GEGLU output is saved for the backward's first sweep (its kernels are VALU-bound, not HBM-bound)
-        gh = torch.empty(M, Fp, dtype=T, device=dev) if (save and T == torch.bfloat16 and _FF_SAVE_GH) else None
+        # the normalised GEGLU output is saved for the backward: its row-sum prepass reads it instead of recomputing conv + GELU, and
+        # the fused second-generation backward (csrc/ffmid2.hip) requires it
+        gh = torch.empty(M, Fp, dtype=T, device=dev) if (save and _FF_SAVE_GH) else None
         ops.ffmid_fwd(h1, w["convw"], w["gamma_mid"], h2, m3, r3, N, F, Fp, p, seed, seed_dev=salt if p > 0 else None,
                       drop_bits=drop_bits, gh=gh)
         x2 = torch.empty(M, D, device=dev)
