@@ -551,7 +551,9 @@ def heads_forward(model, pw: PreparedWeights, y: torch.Tensor, lay: SeqLayout, w
         V1 = seq.codebook_size + 1
         ldV = ceil_to(V1, 8)
         n_s = lay.n_out[s]
-        buf = torch.zeros(lay.B if lay.final_only else lay.B * n_s, ldV, device=y.device)
+        # every row belongs to exactly one quantizer head and only the first V1 columns are ever read (CE, sampler, the views
+        # handed back): no 147 MB zero fill per step
+        buf = torch.empty(lay.B if lay.final_only else lay.B * n_s, ldV, device=y.device)
         for qq in range(seq.num_quantizers):
             ent = lay.head_maps.get((s, qq))
             if ent is None:
