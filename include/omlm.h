@@ -85,7 +85,7 @@ int omlm_mqa_attn_bwd(const void* q, const void* k, const void* v, const float* 
  * the operand dtype of h1 (they are re-read by every row, so in bf16 mode they travel as bf16 like every other operand);
  * dconv is accumulated in the reference layout [2F, 3].  rows are b*nseq + t.  Dropout mask = Philox-4x32-10(seed', element
  * index / 8): one 16-bit draw per element, kept iff draw >= p * 65536; seed' = seed + *seed_dev * golden-ratio (seed_dev optional device word: lets a captured HIP graph draw a new mask
- * on every replay).  bf16 operands with drop_bits given take the second-generation kernels (csrc/ffmid2.hip: a thread owns a few
+ * on every replay).  With drop_bits given (or p == 0) both operand dtypes take the second-generation kernels (csrc/ffmid2.hip: a thread owns a few
  * channel pairs and walks down a strip of rows -- conv window, taps and gamma in fp32 registers, packed fp32 arithmetic, and a
  * backward that fuses dropout^T .. conv^T in one pass behind a row-sum prepass: no du round trip); their keep-mask comes from a
  * 32-bit integer hash of (seed', element index / 8) with the same 16-bit draws, and always reaches the backward through drop_bits.  drop_bits (optional, [M, Fp/8] bytes): the forward stores the keep-mask, 1 bit per element, and the
@@ -101,8 +101,8 @@ int omlm_ffmid_bwd(const void* dh2, const void* h1, const void* convw, const voi
                    int M, int nseq, int F, int Fp, float p, unsigned long long seed,
                    const unsigned long long* seed_dev, const unsigned char* drop_bits, const void* gh, int dtype, void* stream);
 int omlm_colsum_accumulate(const float* part, float* out, int P, int C, int ldp, void* stream);
-/* 1 (default, or $OMLM_FFMID_IMPL): bf16 operands take the column-strip kernels where their preconditions hold (Fp <= 4096,
- * drop_bits present when p > 0, and gh present for the backward); 0: the wave-per-row kernels for every dtype (A/B runs, tests). */
+/* 1 (default, or $OMLM_FFMID_IMPL): the column-strip kernels where their preconditions hold (Fp <= 4096, drop_bits present when
+ * p > 0, and gh present for the backward); 0: the wave-per-row kernels (A/B runs, tests). */
 int omlm_ffmid_set_impl(int impl);
 
 /* Embedding gather + start-token interleave + concat (open_musiclm.py:123-145; utils.get_embeds :126-143) and its

@@ -1,7 +1,7 @@
-// Second-generation middle of ConvFeedForward for bf16 operands (reference transformer.py:122-150):
+// Second-generation middle of ConvFeedForward (reference transformer.py:122-150), templated on the operand type (bf16 / fp32):
 //   h1 [M, 2*Fp] --causal depthwise conv k=3--> u --GEGLU--> g --LayerNorm(F)--> --Dropout(p)--> h2 [M, Fp]
-// Same contract, layouts and outputs as the wave-per-row kernels of ffmid.hip (which stay the fp32 / bf16x3 path and the
-// fallback); what changes is who owns what.
+// Same contract, layouts and outputs as the wave-per-row kernels of ffmid.hip (which stay as the fallback: shapes beyond Fp = 4096,
+// a backward without the saved normalised output, regenerated Philox masks); what changes is who owns what.
 //
 // The first generation gave a wave one row: every 8-channel chunk loaded 3 rows x 2 halves of h1 plus 6 tap vectors (12
 // loads) and converted all of them (12 bf16 -> fp32 conversions per element) before the first useful FMA, ~70 VALU
@@ -91,9 +91,9 @@ __device__ __forceinline__ void gelu_parts(v2 u, v2& h, v2& ex) {
     h = mk2(0.5f + copysignf(hp[0], u[0]), 0.5f + copysignf(hp[1], u[1]));
 }
 
-// 32-bit integer hash (lowbias32, Wellons) -- the dropout keep-mask of the bf16 kernels: 128 bits per 8 elements from one
+// 32-bit integer hash (lowbias32, Wellons) -- the dropout keep-mask of these kernels: 128 bits per 8 elements from one
 // full hash of the (row, chunk) counter and three xorshift-multiply steps; each element draws 16 bits, keep iff >= p * 65536.
-// (The fp32 kernels of ffmid.hip keep Philox: 4 quarter-rate 32-bit multiplies per round were ~12 issue slots per element.)
+// (The first-generation kernels of ffmid.hip keep Philox: 4 quarter-rate 32-bit multiplies per round were ~12 issue slots per element.)
 __device__ __forceinline__ unsigned lowbias32(unsigned x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;

@@ -217,7 +217,7 @@ def ffmid_fwd(h1, convw, gamma, h2, mean, rstd, nseq, F, Fp, p, seed, eps=1e-5, 
 
 
 def ffmid_set_impl(impl: int):
-    """0: wave-per-row kernels for every dtype; 1 (default): column-strip kernels for bf16 operands (csrc/ffmid2.hip)."""
+    """0: wave-per-row kernels; 1 (default): column-strip kernels (csrc/ffmid2.hip) wherever their preconditions hold."""
     call("omlm_ffmid_set_impl", int(impl))
 
 
