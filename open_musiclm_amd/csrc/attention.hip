@@ -462,14 +462,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
                 // registers instead: output lane L stands for t = q - kr = L - 31 and pulls row kr's element from query
                 // column q = t + kr through the cross-lane permute (no LDS memory access); then ONE plain read-add-write
                 // of the wave-private table, predicated so that every lane owns a distinct bin.
-                float dsum = 0.f;
-#pragma unroll
-                for (int kr = 0; kr < 32; ++kr) {
-                    const int r = 4 * (kr >> 3) + (kr & 3), hh = (kr >> 2) & 1;
-                    const int src = lane - 31 + kr;
-                    const float got = __shfl(bv[r], (32 * hh + src) & 63, 64);
-                    dsum += (src >= 0 && src < 32) ? got : 0.f;
-                }
+                const float dsum = diag_sum_32x32(bv, lane);
                 const int rel = (i0 - j0 - 32 * sub) + (lane - 31);
                 if (rel >= 0 && rel < nb) dbias_l[rel] += dsum;
             }
@@ -662,14 +655,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
                 // registers instead: output lane L stands for t = q - kr = L - 31 and pulls row kr's element from query
                 // column q = t + kr through the cross-lane permute (no LDS memory access); then ONE plain read-add-write
                 // of the wave-private table, predicated so that every lane owns a distinct bin.
-                float dsum = 0.f;
-#pragma unroll
-                for (int kr = 0; kr < 32; ++kr) {
-                    const int r = 4 * (kr >> 3) + (kr & 3), hh = (kr >> 2) & 1;
-                    const int src = lane - 31 + kr;
-                    const float got = __shfl(bv[r], (32 * hh + src) & 63, 64);
-                    dsum += (src >= 0 && src < 32) ? got : 0.f;
-                }
+                const float dsum = diag_sum_32x32(bv, lane);
                 const int rel = (i0 - j0 - 32 * sub) + (lane - 31);
                 if (rel >= 0 && rel < nb) dbias_l[rel] += dsum;
             }

@@ -552,14 +552,7 @@ __global__ __launch_bounds__(A2_THREADS) void attn2_bwd_dq_kernel(const bf16_t* 
                 // d(bias)[rel] = sum of dS over the diagonal rel = i - j: output lane L stands for t = q - kr = L - 31 and pulls row
                 // kr's element from query column q = t + kr through the cross-lane permute; then one read-add-write of this
                 // wave's private table (every lane owns a distinct bin)
-                float dsum = 0.f;
-#pragma unroll
-                for (int kr = 0; kr < 32; ++kr) {
-                    const int r = 4 * (kr >> 3) + (kr & 3), hh = (kr >> 2) & 1;
-                    const int src = lane - 31 + kr;
-                    const float got = __shfl(bv[r], (32 * hh + src) & 63, 64);
-                    dsum += (src >= 0 && src < 32) ? got : 0.f;
-                }
+                const float dsum = diag_sum_32x32(bv, lane);
                 const int rel = (i0 - jb) + (lane - 31);
                 if (rel >= 0 && rel < nb) dbw[rel] += dsum;
             }

@@ -80,6 +80,54 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// d(bias) of the attention backward: the 63 diagonal sums of a 32x32 block of dS^T held in the MFMA C-layout (lane = query column
+// q = lane & 31, bv[r] = key row (r & 3) + 8 (r >> 2) + 4 (lane >> 5)).  Output lane L stands for t = q - kr = L - 31 and pulls row
+// kr's element from query column q = t + kr of the half-wave that holds that row: source lane (L - 31 + kr + 32 hh) mod 64 with
+// hh = (kr >> 2) & 1.  ds_bpermute_b32 adds its immediate offset to the byte address, so ONE address register (4 * lane) serves all 32
+// permutes; hipcc's __shfl form spends an index register plus two address VALU ops per permute (32 VGPRs, 64 of the ~130 VALU
+// instructions of the loop, seen in the ISA; with the asm form the bf16 dQ kernel stops spilling: 20 -> 0 VGPRs).  The permutes are
+// inline asm, i.e. invisible to hipcc's lgkmcnt bookkeeping: issued back to back and retired by the s_waitcnt of this function.
+// MEASURED (MI355X, B = 32, N = 1116, H = 8): parity green (6 / 6 attention tests), backward 665.6 us against 665.4 us with __shfl --
+// no gain: the ~150 us of d(bias) are the 32 LDS-crossbar permutes themselves, not their address arithmetic or the spills.  The asm
+// form is therefore OFF by default (a hidden load is a liability where registers spill: the fp32 kernel still spills 48);
+// -DOMLM_DIAG_ASM=1 selects it.
+#ifndef OMLM_DIAG_ASM
+#define OMLM_DIAG_ASM 0
+#endif
+#define OMLM_BPERM(KR) asm volatile("ds_bpermute_b32 %0, %1, %2 offset:%3" : "=v"(got[KR]) : "v"(base), \
+        "v"(bv[4 * ((KR) >> 3) + ((KR) & 3)]), "i"(4 * (((KR) - 31 + 32 * (((KR) >> 2) & 1)) & 63)))
+__device__ __forceinline__ float diag_sum_32x32(const float (&bv)[16], int lane) {
+    float dsum = 0.f;
+#if OMLM_DIAG_ASM
+    float got[32];
+    const int base = lane << 2;
+    OMLM_BPERM(0); OMLM_BPERM(1); OMLM_BPERM(2); OMLM_BPERM(3); OMLM_BPERM(4); OMLM_BPERM(5); OMLM_BPERM(6); OMLM_BPERM(7);
+    OMLM_BPERM(8); OMLM_BPERM(9); OMLM_BPERM(10); OMLM_BPERM(11); OMLM_BPERM(12); OMLM_BPERM(13); OMLM_BPERM(14); OMLM_BPERM(15);
+    OMLM_BPERM(16); OMLM_BPERM(17); OMLM_BPERM(18); OMLM_BPERM(19); OMLM_BPERM(20); OMLM_BPERM(21); OMLM_BPERM(22); OMLM_BPERM(23);
+    OMLM_BPERM(24); OMLM_BPERM(25); OMLM_BPERM(26); OMLM_BPERM(27); OMLM_BPERM(28); OMLM_BPERM(29); OMLM_BPERM(30); OMLM_BPERM(31);
+    // retire them: the wait names the first 16 destinations, the empty statement behind it the other 16, so that no consumer of
+    // any of them is scheduled above the wait (cdna_hip_programming.md 5.7: loads hidden from hipcc, form (ii))
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(got[0]), "+v"(got[1]), "+v"(got[2]), "+v"(got[3]), "+v"(got[4]), "+v"(got[5]), "+v"(got[6]),
+                 "+v"(got[7]), "+v"(got[8]), "+v"(got[9]), "+v"(got[10]), "+v"(got[11]), "+v"(got[12]), "+v"(got[13]), "+v"(got[14]), "+v"(got[15]));
+    asm volatile("" : "+v"(got[16]), "+v"(got[17]), "+v"(got[18]), "+v"(got[19]), "+v"(got[20]), "+v"(got[21]), "+v"(got[22]), "+v"(got[23]),
+                 "+v"(got[24]), "+v"(got[25]), "+v"(got[26]), "+v"(got[27]), "+v"(got[28]), "+v"(got[29]), "+v"(got[30]), "+v"(got[31]));
+#pragma unroll
+    for (int kr = 0; kr < 32; ++kr) {
+        const int src = lane - 31 + kr;
+        dsum += (src >= 0 && src < 32) ? got[kr] : 0.f;
+    }
+#else
+#pragma unroll
+    for (int kr = 0; kr < 32; ++kr) {
+        const int r = 4 * (kr >> 3) + (kr & 3), hh = (kr >> 2) & 1;
+        const int src = lane - 31 + kr;
+        const float got = __shfl(bv[r], (32 * hh + src) & 63, 64);
+        dsum += (src >= 0 && src < 32) ? got : 0.f;
+    }
+#endif
+    return dsum;
+}
+
 // block-wide sum for blockDim.x == NT (multiple of 64); `red` is >= NT/64 floats of LDS.
 template <int NT>
 __device__ __forceinline__ float block_sum(float v, float* red) {

@@ -519,10 +519,14 @@ def test_data_parallel_step_equals_single_process_accumulation(dev, tmp_path):
     assert a["world"] == 2 and c["world"] == 1
     assert torch.equal(a["param"], b["param"]), "replicas diverged"
     e_g = relerr(a["grad"], c["grad"])
-    e_p = float((a["param"] - c["param"]).abs().max())
-    report("dp_equivalence", grad_rel=e_g, param_abs=e_p)
+    dp = (a["param"] - c["param"]).abs()
+    e_p, e_mean, frac = float(dp.max()), float(dp.mean()), float((dp > 2e-4).float().mean())
+    report("dp_equivalence", grad_rel=e_g, param_abs=e_p, param_mean_abs=e_mean, frac_above_2e4=frac)
     assert e_g < 1e-4, e_g                       # same arithmetic, different summation order (atomics, all-reduce)
-    assert e_p < 2e-4, e_p                       # two AdamW steps at lr 1e-3: updates agree to a fraction of lr
+    # Two AdamW steps at lr 1e-3.  The first Adam update is lr * sign(g): an element whose gradient is at the rounding level of
+    # the two summation orders may take opposite signs (up to 2 * lr apart per step), so the maximum is bounded by 4 * lr and the
+    # comparison that carries information is how RARE such elements are and how small the mean difference is.
+    assert e_p <= 4.1e-3 and frac < 1e-3 and e_mean < 2e-5, (e_p, frac, e_mean)
 
 
 @pytest.mark.parametrize("use_cache", [True, False])
