@@ -166,3 +166,27 @@ def test_oracle_rvq_fit_step_learns_clustered_embeddings():
     x = _clustered(64, K, D, seed=7)
     enc = O.rvq_encode(x.numpy(), state["embed"].numpy())
     assert enc.shape == (64, S)
+
+
+def test_rvq_ids_do_not_depend_on_the_distance_formula_at_real_dims():
+    """The RVQ arithmetic lives in the un-vendored vector-quantize-pytorch (parity unpinned): its releases compute the code distances
+    either as -cdist(x, e) or in the expanded form -(|x|^2 - 2 x.e + |e|^2), both followed by argmax; the HIP kernel / oracle use
+    sum_d (x_d - e_d)^2 in index order.  Near-ties could flip an id between the three.  At the shipped dimensions (512-d, 1024 codes,
+    12 residual stages) on Gaussian data they do not: every id of every stage agrees."""
+    g = torch.Generator().manual_seed(0)
+    n, D, K, S = 512, 512, 1024, 12
+    x = torch.randn(n, D, generator=g)
+    cb = torch.randn(S, K, D, generator=g) * torch.logspace(0, -1.2, S)[:, None, None]     # shrinking codebooks like a fitted RVQ
+
+    def chain(fn):
+        r, out = x.clone(), []
+        for s in range(S):
+            idx = fn(r, cb[s])
+            out.append(idx)
+            r = r - cb[s][idx]
+        return torch.stack(out, 1)
+    stated = chain(lambda r, e: torch.from_numpy(O.nearest_code(r.numpy(), e.numpy())))
+    cdist = chain(lambda r, e: (-torch.cdist(r[None], e[None], p=2)[0]).argmax(-1))
+    expanded = chain(lambda r, e: (-((r * r).sum(-1, keepdim=True) - 2 * r @ e.t() + (e * e).sum(-1)[None])).argmax(-1))
+    assert torch.equal(stated, cdist) and torch.equal(stated, expanded)
+    assert torch.equal(stated, torch.from_numpy(O.rvq_encode(x.numpy(), cb.numpy())))
