@@ -74,6 +74,34 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// the same sum on the VALU: 4 DPP adds inside each row of 16 lanes + 4 readlanes, no LDS-crossbar round trips (six dependent
+// ds_bpermute steps are ~0.35 us of pure latency -- visible in kernels that are ONE dependent chain, like the decode GEMVs)
+template <int CTRL>
+__device__ __forceinline__ float dpp_add_step(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v = dpp_add_step<0xB1>(v);        // quad_perm [1,0,3,2]
+    v = dpp_add_step<0x4E>(v);        // quad_perm [2,3,0,1]
+    v = dpp_add_step<0x141>(v);       // row_half_mirror
+    v = dpp_add_step<0x140>(v);       // row_mirror: every lane holds its row's sum
+    const int i = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 16)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 48));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_max_step(float v) {
+    return fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false)));
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    v = dpp_max_step<0xB1>(v);
+    v = dpp_max_step<0x4E>(v);
+    v = dpp_max_step<0x141>(v);
+    v = dpp_max_step<0x140>(v);
+    const int i = __builtin_bit_cast(int, v);
+    return fmaxf(fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 0)), __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 16))),
+                 fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 32)), __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 48))));
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

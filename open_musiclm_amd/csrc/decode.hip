@@ -17,6 +17,17 @@
 // TW = bf16_t: weights are the bf16 operand copies ("bf16" mode; activations that the batched path rounds to bf16 before
 // its GEMMs are rounded here too, so both paths see the same operands); TW = float: fp32 weights, fp32 FMA chains.
 #include "common.h"
+// The step kernels are single dependent chains (load -> LayerNorm statistics -> dot products -> reduction -> store): the wave
+// reductions run on the VALU (DPP row steps + readlanes) instead of six dependent ds_bpermute round trips each.  Measured on the
+// B = 1 step (MI355X, tools/decode_probe.py, same box): 154.6 -> 145.8 us per id with the three reductions of the GEMV kernels alone.
+// -DDEC_DPP_SUM=0 restores the __shfl ladders.
+#ifndef DEC_DPP_SUM
+#define DEC_DPP_SUM 1
+#endif
+#if DEC_DPP_SUM
+#define wave_sum(x) wave_sum_dpp(x)
+#define wave_max(x) wave_max_dpp(x)
+#endif
 #include <stdlib.h>
 
 #define DEC_T 256
@@ -620,6 +631,7 @@ static void dec2_launch(const dec2_args& a, int grid, hipStream_t st) {
 // dot product multiplies), takes the LayerNorm statistics with two wave reductions, and finishes its own output element:
 // one memory round trip between launch and store.  FF-in: a wave owns one CHANNEL (its value row and its gate row), so the
 // conv / GEGLU epilogue needs no exchange either.
+
 template <typename TW, int NI, int MODE>
 __global__ __launch_bounds__(DEC_T) void dec3_kernel(dec2_args a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
