@@ -69,11 +69,6 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsig
     lo = pack_bf16_rne(a - u2f(ua), b - u2f(ub));
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
 // the same sum on the VALU: 4 DPP adds inside each row of 16 lanes + 4 readlanes, no LDS-crossbar round trips (six dependent
 // ds_bpermute steps are ~0.35 us of pure latency -- visible in kernels that are ONE dependent chain, like the decode GEMVs)
 template <int CTRL>
@@ -102,10 +97,27 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
     return fmaxf(fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 0)), __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 16))),
                  fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 32)), __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 48))));
 }
+// OMLM_WAVE_DPP=1: every wave_sum / wave_max of the library takes the DPP form (build-time A/B switch)
+#ifndef OMLM_WAVE_DPP
+#define OMLM_WAVE_DPP 0
+#endif
+__device__ __forceinline__ float wave_sum(float v) {
+#if OMLM_WAVE_DPP
+    return wave_sum_dpp(v);
+#else
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+#endif
+}
 __device__ __forceinline__ float wave_max(float v) {
+#if OMLM_WAVE_DPP
+    return wave_max_dpp(v);
+#else
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
+#endif
 }
 
 // d(bias) of the attention backward: the 63 diagonal sums of a 32x32 block of dS^T held in the MFMA C-layout (lane = query column
