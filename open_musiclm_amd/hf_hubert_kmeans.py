@@ -1,6 +1,8 @@
 """HfHubertWithKmeans (reference open_musiclm/hf_hubert_kmeans.py).  The MERT/HuBERT feature extractor is a
 pretrained third-party network outside the hot path; the k-means ASSIGN step (:87, sklearn predict) runs as a
-HIP nearest-centroid kernel, bit-exact against oracle.kmeans_assign."""
+HIP nearest-centroid kernel, bit-exact against oracle.kmeans_assign.  The FIT (:98-149, what scripts/train_hubert_kmeans.py drives
+through HfHubertKmeansTrainer) is sklearn's MiniBatchKMeans in the reference; it is the same call here, so a fit on the same
+features and seed yields the reference's centroids bit for bit (tests/golden/kmeans_fit.npz, produced by the reference itself)."""
 from __future__ import annotations
 
 from typing import Optional
@@ -62,6 +64,29 @@ class HfHubertWithKmeans(nn.Module):
             raise RuntimeError("HfHubertWithKmeans was built without the MERT/HuBERT feature extractor (pretrained weights are "
                                "outside the MI355X hot path); use .assign(features) or supply semantic_token_ids")
         raise NotImplementedError("audio feature extraction is outside the MI355X hot path")
+
+
+def get_kmeans_model(n_clusters, init, max_iter, batch_size, tol, max_no_improvement, n_init, reassignment_ratio, verbose=1):
+    """hf_hubert_kmeans.py:95-118."""
+    from sklearn.cluster import MiniBatchKMeans
+    return MiniBatchKMeans(n_clusters=n_clusters, init=init, max_iter=max_iter, batch_size=batch_size, verbose=verbose,
+                           compute_labels=False, tol=tol, max_no_improvement=max_no_improvement, init_size=None, n_init=n_init,
+                           reassignment_ratio=reassignment_ratio)
+
+
+def learn_kmeans(feat, seed, km_path='./results/kmeans.joblib', n_clusters=1024, init="k-means++", max_iter=100, batch_size=10000,
+                 tol=0.0, n_init=20, reassignment_ratio=0.0, max_no_improvement=100, verbose=1):
+    """hf_hubert_kmeans.py:121-149: seeds numpy's global RNG (the estimator has random_state=None), fits, dumps with joblib."""
+    import joblib
+    import numpy as np
+    np.random.seed(seed)
+    km_model = get_kmeans_model(n_clusters, init, max_iter, batch_size, tol, max_no_improvement, n_init, reassignment_ratio, verbose)
+    km_model.fit(feat)
+    joblib.dump(km_model, km_path)
+    inertia = -km_model.score(feat) / len(feat)
+    print("total intertia: %.5f", inertia)
+    print("finished successfully")
+    return km_model
 
 
 def get_hubert_kmeans(model_name: str = "m-a-p/MERT-v0", kmeans_path: Optional[str] = None, **kwargs):

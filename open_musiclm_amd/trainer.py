@@ -488,5 +488,88 @@ class ClapRVQTrainer(nn.Module):
 
 
 class HfHubertKmeansTrainer(nn.Module):
-    def __init__(self, *a, **k):
-        raise NotImplementedError("HfHubertKmeansTrainer is outside the MI355X TokenConditionedTransformer hot path")
+    """Trainer for the k-means part of HfHubertWithKmeans (trainer.py:748-905): 1) collect `feature_extraction_num_steps` batches
+    of features, 2) fit sklearn's MiniBatchKMeans on them (`learn_kmeans`, the reference's own call) and dump `kmeans.joblib`.
+    The MERT / HuBERT extractor is a third-party pretrained network that is not part of this build: when `hubert_kmeans.hubert`
+    is None the dataset must yield the features themselves ([t, f] or [b, t, f] float tensors, e.g. precomputed MERT layer-7
+    embeddings); with an extractor present the reference's `forward(wav_input=..., return_embed=True)` path is used."""
+
+    def __init__(self, *, feature_extraction_num_steps: int, feature_extraction_batch_size: int, hubert_kmeans,
+                 dataset: Optional[Dataset] = None, ignore_files: Optional[List[str]] = None, ignore_load_errors: bool = True,
+                 folder=None, data_max_length_seconds=1, results_folder='./results', accelerate_kwargs: dict = {},
+                 config_paths: Optional[List[str]] = None):
+        super().__init__()
+        self.dp = DataParallel(device=torch.device('cpu'), backend='gloo')
+        self.ds = dataset
+        self.feature_extraction_num_steps = feature_extraction_num_steps
+        self.feature_extraction_batch_size = feature_extraction_batch_size
+        self.hubert_kmeans = hubert_kmeans
+        self.features_in = not exists(getattr(hubert_kmeans, 'hubert', None))
+        self.register_buffer('steps', torch.Tensor([0]))
+        if not exists(self.ds):
+            assert exists(folder), 'folder must be passed in, if not passing in a custom dataset for text conditioned audio synthesis training'
+            self.ds = SoundDataset(folder, max_length_seconds=data_max_length_seconds, normalize=True,
+                                   target_sample_hz=hubert_kmeans.target_sample_hz, seq_len_multiple_of=hubert_kmeans.seq_len_multiple_of,
+                                   ignore_files=default(ignore_files, []), ignore_load_errors=ignore_load_errors)
+        self.print(f'training on {feature_extraction_num_steps * feature_extraction_batch_size} out of {len(self.ds)} samples')
+        self.dl = get_dataloader(self.ds, batch_size=feature_extraction_batch_size, shuffle=True)
+        self.dl_iter = cycle(self.dl)
+        self.results_folder = Path(results_folder)
+        if self.is_main and len([*self.results_folder.glob('**/*')]) > 0 and \
+                yes_or_no('do you want to clear previous experiment checkpoints and results?'):
+            rmtree(str(self.results_folder))
+        self.results_folder.mkdir(parents=True, exist_ok=True)
+        if self.is_main and exists(config_paths):
+            configs_folder = self.results_folder / "configs"
+            configs_folder.mkdir(parents=True, exist_ok=True)
+            for config_path in config_paths:
+                copy_file_to_folder(config_path, configs_folder)
+
+    def print(self, msg):
+        if self.is_main:
+            print(msg)
+
+    @property
+    def device(self):
+        return torch.device('cpu')
+
+    @property
+    def is_distributed(self):
+        return self.dp.is_distributed
+
+    @property
+    def is_main(self):
+        return self.dp.rank == 0
+
+    @property
+    def is_local_main(self):
+        return self.dp.local_rank == 0
+
+    def extract_hubert_features(self):
+        batch = next(self.dl_iter)
+        item = batch[0] if isinstance(batch, (list, tuple)) else batch
+        if self.features_in:
+            embed = item.float()
+            embed = embed.reshape(-1, embed.shape[-1])                       # 'b t f -> (b t) f'
+        else:
+            embed = self.hubert_kmeans.forward(wav_input=item, return_embed=True)
+            embed = embed.reshape(-1, embed.shape[-1])
+        embed = self.dp.all_gather_cat(embed.contiguous())
+        return embed.detach().cpu().numpy()
+
+    def train(self, log_fn=noop, seed=0, **kmeans_kwargs):
+        from .hf_hubert_kmeans import learn_kmeans
+        self.print('step 1: extracting features. must wait for this to complete before training kmeans.')
+        features = []
+        num_steps = -(-self.feature_extraction_num_steps // self.dp.world_size)
+        while self.steps < num_steps:
+            self.print(f'{int(self.steps.item())} / {num_steps} steps')
+            features.append(self.extract_hubert_features())
+            self.steps += 1
+        features = np.concatenate(features, axis=0)
+        features = features[~np.any(np.isnan(features), axis=-1)]
+        self.print('step 2: training kmeans')
+        if self.is_main:
+            learn_kmeans(features, seed, str(self.results_folder / 'kmeans.joblib'),
+                         n_clusters=self.hubert_kmeans.codebook_size, **kmeans_kwargs)
+        self.print('training complete')

