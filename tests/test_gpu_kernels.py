@@ -789,6 +789,7 @@ def test_clap_rvq_trainer_on_embeddings(dev, tmp_path):
     checkpoint carries the library's key layout and reloads into a fresh quantizer that encodes identically."""
     from open_musiclm_amd.clap_quantized import ClapQuantized
     from open_musiclm_amd.trainer import ClapRVQTrainer
+    torch.manual_seed(0)                             # k-means init picks and the loader shuffle come from the global generators
     K, D, S = 32, 16, 4
     centers = torch.randn(K, D, generator=torch.Generator().manual_seed(3))
     g = torch.Generator().manual_seed(4)
