@@ -421,3 +421,44 @@ def test_kmeans_fit_matches_the_reference(golden_dir, tmp_path):
     # the fitted model plugs into the assign side (centroids become the HIP kernel's table)
     hk2 = HfHubertWithKmeans(hubert=None, kmeans=fitted)
     assert hk2.codebook_size == kw["n_clusters"] and tuple(hk2.kmeans.centroids.shape) == want.shape
+
+
+KM_DP_SCRIPT = r"""
+import os, sys, numpy as np, torch, joblib
+sys.path.insert(0, %r)
+from open_musiclm_amd.hf_hubert_kmeans import HfHubertWithKmeans
+from open_musiclm_amd.trainer import HfHubertKmeansTrainer
+rank = int(os.environ["RANK"])
+rng = np.random.RandomState(100 + rank)                      # every rank extracts features from ITS OWN clips
+centers = np.random.RandomState(1).randn(8, 12).astype(np.float32) * 3
+feats = (centers[rng.randint(0, 8, 600)] + 0.1 * rng.randn(600, 12)).astype(np.float32)
+class Feats(torch.utils.data.Dataset):
+    def __len__(self): return 20
+    def __getitem__(self, i): return torch.from_numpy(feats[30 * i:30 * (i + 1)])
+hk = HfHubertWithKmeans(hubert=None, kmeans=None, codebook_size=8)
+tr = HfHubertKmeansTrainer(feature_extraction_num_steps=4, feature_extraction_batch_size=10, hubert_kmeans=hk, dataset=Feats(),
+                           results_folder=%r)
+assert tr.dp.world_size == 2
+tr.train(seed=3, verbose=0, n_init=2, max_iter=20, batch_size=256)
+tr.dp.barrier()
+if rank == 0:
+    km = joblib.load(os.path.join(%r, "kmeans.joblib"))
+    # 4 steps / 2 ranks = 2 steps per rank, each gathering 2 x 10 clips x 30 frames: the fit saw 1200 rows from BOTH ranks
+    d = np.linalg.norm(km.cluster_centers_[:, None] - centers[None], axis=-1).min(1)
+    assert km.cluster_centers_.shape == (8, 12) and float(d.max()) < 0.5, d
+tr.dp.shutdown()
+print('rank', rank, 'ok')
+"""
+
+
+def test_kmeans_trainer_world_size_2_gloo(tmp_path):
+    """HfHubertKmeansTrainer across two processes (gloo, CPU): the features of both ranks are gathered, rank 0 fits and writes."""
+    out = str(tmp_path / "km")
+    script = tmp_path / "km_dp.py"
+    script.write_text(KM_DP_SCRIPT % (ROOT, out, out))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("ok" in o for o in outs)
