@@ -51,8 +51,17 @@ def _np_from_blob(blob):
     return np.load(io.BytesIO(blob))
 
 
+def _blob_from_np(arr):
+    """The reference's adapt_array (data.py:33-40): the array's np.save image as a blob."""
+    out = io.BytesIO()
+    np.save(out, arr)
+    out.seek(0)
+    return sqlite3.Binary(out.read())
+
+
 def init_sqlite(path):
-    """Same adapters as the reference (data.py: array <-> np.save bytes)."""
+    """Same adapters as the reference (data.py:33-56: array <-> np.save bytes), for reading and for writing the token store."""
+    sqlite3.register_adapter(np.ndarray, _blob_from_np)
     sqlite3.register_converter("array", _np_from_blob)
     conn = sqlite3.connect(path, detect_types=sqlite3.PARSE_DECLTYPES)
     return conn, conn.cursor()

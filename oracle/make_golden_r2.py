@@ -134,6 +134,42 @@ def make_preprocessed(ref):
     print(f"[preprocessed] store + {len(out) - 1} reference crops written")
 
 
+
+def make_preprocess_store(ref):
+    """The token store as the REFERENCE's DataPreprocessor.process writes it (preprocess.py:252-284), tokenizers and audio batches
+    from oracle/preprocess_standins.py.  The reference's constructor needs torchaudio + an audio folder + accelerate, so the object
+    is assembled field by field and only its own generate_tokens_from_batch / process run; world size 1 and a 2-rank store."""
+    import types
+    from oracle import preprocess_standins as S
+    pp = importlib.import_module("open_musiclm.preprocess")
+    data = importlib.import_module("open_musiclm.data")
+    base = os.path.join(OUT, "preprocess_store")
+    shutil.rmtree(base, ignore_errors=True)
+
+    def run(folder, shards, clap_batch_size):
+        os.makedirs(folder)
+        for rank, items in enumerate(shards):
+            obj = pp.DataPreprocessor.__new__(pp.DataPreprocessor)
+            torch.nn.Module.__init__(obj)
+            obj.accelerator = types.SimpleNamespace(num_processes=len(shards), process_index=rank, unwrap_model=lambda m: m,
+                                                    is_main_process=rank == 0, print=print)
+            obj.wav2vec, obj.audio_conditioner, obj.neural_codec = S.Wav2Vec(), S.Clap(), S.Codec()
+            obj.num_coarse_quantizers, obj.clap_audio_length_seconds, obj.clap_batch_size = 3, S.WINDOW_S, clap_batch_size
+            obj.num_crops, obj.replace_existing = 1, False
+            obj.register_buffer("steps", torch.Tensor([0]))
+            obj.ds_fields = ("raw_wave_for_clap", "raw_wave_for_semantic", "raw_wave_for_acoustic")
+            obj.ds = list(range(len(shards) * len(items)))               # process() only takes its length (the UNsharded dataset's)
+            obj.dl_iter = pp.cycle(items)
+            obj.conn, obj.cursor = data.init_sqlite(os.path.join(folder, "preprocessed.db"))
+            obj.cursor.execute("CREATE TABLE IF NOT EXISTS tokens(idx integer primary key, path text, clap array, semantic array, coarse array, fine array)")
+            obj.process()
+            obj.conn.close()
+
+    items = S.batches()
+    run(os.path.join(base, "world1"), [items], clap_batch_size=2)
+    run(os.path.join(base, "world2"), [items[0:4:2], items[1:4:2]], clap_batch_size=32)
+    print("[preprocess_store] reference-written stores: world1 (5 files), world2 (2 ranks x 2 files)")
+
 def make_kmeans_fit(ref):
     import tempfile
     hk = importlib.import_module("open_musiclm.hf_hubert_kmeans")
@@ -160,3 +196,5 @@ if __name__ == "__main__":
         make_preprocessed(ref)
     if not only or "kmeans_fit" in only:
         make_kmeans_fit(ref)
+    if not only or "preprocess_store" in only:
+        make_preprocess_store(ref)

@@ -312,7 +312,8 @@ def test_wgrad_desc_layout_matches_header(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/scripts"), reason="reference checkout not present (GPU box)")
-@pytest.mark.parametrize("script", ["train_semantic_stage", "train_coarse_stage", "train_fine_stage"])
+@pytest.mark.parametrize("script", ["train_semantic_stage", "train_coarse_stage", "train_fine_stage", "train_clap_rvq",
+                                    "train_hubert_kmeans", "preprocess_data"])
 def test_reference_training_scripts_import_against_this_package(script):
     """Drop-in boundary: the reference's own entry scripts resolve `open_musiclm.*` to this repository (alias package) and
     get every name they import from it; `--help` stops before any GPU work."""
@@ -462,3 +463,110 @@ def test_kmeans_trainer_world_size_2_gloo(tmp_path):
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all("ok" in o for o in outs)
+
+
+def _raw_rows(db):
+    """Rows of a token store with the blobs as stored (no converter): idx, path and the four np.save images."""
+    conn = sqlite3.connect(db)
+    rows = conn.execute("SELECT idx, path, clap, semantic, coarse, fine FROM tokens ORDER BY idx").fetchall()
+    schema = conn.execute("SELECT sql FROM sqlite_master WHERE name='tokens'").fetchone()[0]
+    conn.close()
+    return [(r[0], r[1]) + tuple(bytes(b) for b in r[2:]) for r in rows], schema
+
+
+def _preprocessor(folder, items, **kw):
+    from oracle import preprocess_standins as S
+    from open_musiclm_amd.preprocess import DataPreprocessor
+    return DataPreprocessor(num_coarse_quantizers=3, wav2vec=S.Wav2Vec(), neural_codec=S.Codec(), audio_conditioner=S.Clap(),
+                            clap_audio_length_seconds=S.WINDOW_S, semantic_audio_length_seconds=S.WINDOW_S, dataset=items,
+                            results_folder=str(folder), **kw)
+
+
+def test_data_preprocessor_writes_the_reference_store(golden_dir, tmp_path):
+    """DataPreprocessor.process against the store the REFERENCE's process() wrote from the same stand-in tokenizers and batches
+    (tests/golden/preprocess_store, oracle/make_golden_r2.py::make_preprocess_store): same rows, same paths, the np.save blobs byte
+    for byte, same table; then the resume rule (rows present are skipped), replace_existing, and the store read back by
+    PreprocessedDataset."""
+    from oracle import preprocess_standins as S
+    from open_musiclm_amd.data import PreprocessedDataset
+    items = S.batches()
+    pp = _preprocessor(tmp_path / "w1", items, clap_batch_size=2)
+    pp.process()
+    got, schema = _raw_rows(str(tmp_path / "w1" / "preprocessed.db"))
+    want, want_schema = _raw_rows(os.path.join(golden_dir, "preprocess_store", "world1", "preprocessed.db"))
+    assert schema == want_schema and len(got) == 5 and got == want
+    # clap windows went through the conditioner in groups of clap_batch_size (6 s file, 4 s windows, 1 s hop -> 3 windows -> 2 + 1)
+    assert pp.audio_conditioner.calls[:2] == [2, 1] and int(pp.steps.item()) == 5
+    pp.conn.close()
+    arr = np.load(io.BytesIO(got[1][2]))
+    assert arr.dtype == np.uint16 and arr.shape == (9 - S.WINDOW_S + 1, 12, 1)
+
+    # resume: a second pass over a store that already holds the rows calls no tokenizer and changes nothing
+    pp2 = _preprocessor(tmp_path / "w1", items, clap_batch_size=2)
+    pp2.process()
+    assert pp2.audio_conditioner.calls == [] and _raw_rows(str(tmp_path / "w1" / "preprocessed.db"))[0] == want
+    pp2.conn.close()
+    # replace_existing recomputes and overwrites in place (the reference's plain INSERT raises on the primary key there)
+    pp3 = _preprocessor(tmp_path / "w1", items[::-1], clap_batch_size=32, replace_existing=True)
+    pp3.process()
+    pp3.conn.close()
+    redone, _ = _raw_rows(str(tmp_path / "w1" / "preprocessed.db"))
+    assert [r[0] for r in redone] == [0, 1, 2, 3, 4] and [r[1:] for r in redone] == [r[1:] for r in want[::-1]]
+
+    # and the reader side takes it: every stage crops from the written store
+    for stage in ("semantic", "coarse", "fine"):
+        ds = PreprocessedDataset(str(tmp_path / "w1"), stage=stage, semantic_window_seconds=S.WINDOW_S, coarse_window_seconds=2,
+                                 fine_window_seconds=1, semantic_steps_per_second=S.SEM_HZ, acoustic_steps_per_second=S.AC_HZ)
+        assert len(ds) == 5
+        for i in range(5):
+            out = ds[i]
+            assert out[0].shape == (1, 12, 1)
+        ds.conn.close()
+
+
+def test_data_preprocessor_needs_its_tokenizers_and_a_dataset(tmp_path):
+    from oracle import preprocess_standins as S
+    from open_musiclm_amd.preprocess import DataPreprocessor
+    with pytest.raises(AssertionError):
+        DataPreprocessor(dataset=S.batches(), results_folder=str(tmp_path / "a"))
+    with pytest.raises(ImportError, match="torchaudio"):
+        DataPreprocessor(wav2vec=S.Wav2Vec(), neural_codec=S.Codec(), audio_conditioner=S.Clap(), clap_audio_length_seconds=4,
+                         semantic_audio_length_seconds=4, folder=str(tmp_path), results_folder=str(tmp_path / "b"))
+    with pytest.raises(AssertionError, match="clap window"):
+        DataPreprocessor(wav2vec=S.Wav2Vec(), neural_codec=S.Codec(), audio_conditioner=S.Clap(), clap_audio_length_seconds=4,
+                         semantic_audio_length_seconds=10, dataset=S.batches(), results_folder=str(tmp_path / "c"))
+
+
+PP_DP_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, %r)
+from oracle import preprocess_standins as S
+from open_musiclm_amd.preprocess import DataPreprocessor
+rank = int(os.environ["RANK"])
+items = S.batches()[0:4]
+pp = DataPreprocessor(num_coarse_quantizers=3, wav2vec=S.Wav2Vec(), neural_codec=S.Codec(), audio_conditioner=S.Clap(),
+                      clap_audio_length_seconds=S.WINDOW_S, semantic_audio_length_seconds=S.WINDOW_S, dataset=items, shard_dataset=True,
+                      results_folder=%r)
+assert pp.dp.world_size == 2 and len(pp.ds) == 4
+pp.process()
+pp.dp.barrier()
+pp.conn.close()
+pp.dp.shutdown()
+print('rank', rank, 'ok')
+"""
+
+
+def test_data_preprocessor_world_size_2_gloo(golden_dir, tmp_path):
+    """Two ranks (gloo, CPU) write one store: rank r takes files r, r+2, ... and row idx = iteration * 2 + r, exactly the store the
+    reference's process() wrote with num_processes=2 (tests/golden/preprocess_store/world2)."""
+    out = str(tmp_path / "pp2")
+    script = tmp_path / "pp_dp.py"
+    script.write_text(PP_DP_SCRIPT % (ROOT, out))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29623", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    got, _ = _raw_rows(os.path.join(out, "preprocessed.db"))
+    want, _ = _raw_rows(os.path.join(golden_dir, "preprocess_store", "world2", "preprocessed.db"))
+    assert len(got) == 4 and got == want
