@@ -166,6 +166,9 @@ __device__ __forceinline__ void pack_acc(const f32x16& p, int s, bf16x8& hi, bf1
 //     which only masked scores reach (they are 0 either way);
 //   * on subtiles entirely below the diagonal (all but one per query tile): the causal compare, the clamp of the bias index and
 //     the per-score address arithmetic (constant LDS offsets from one base), and the 64-bit mask-bit test (one 32-bit word).
+#ifndef AT_DKV_FENCE
+#define AT_DKV_FENCE 1
+#endif
 #ifndef AT_LEAN
 #define AT_LEAN 1      /* round 2, first GPU call: parity tests identical, forward 206 -> 145 us, backward 694 -> 643 us per layer */
 #endif
@@ -748,8 +751,8 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
     // A-operand fragments (rows = queries i0 + (lane&31), dims 16 s + 8 hi) of Q and dO plus the tile's lse / delta
     // (one value per lane = per query); the NEXT item's are fetched while the current item is on the matrix cores.
     bf16x8 qa[4], doa[4], qn[4], don[4];
-    float La = 0.f, Da = 0.f, Ln = 0.f, Dn = 0.f, Ba = 0.f, Bn = 0.f;
-    auto fetch = [&](int item, bf16x8 (&fq)[4], bf16x8 (&fd)[4], float& fl, float& fdl, float& fb) {
+    float La = 0.f, Da = 0.f, Ln = 0.f, Dn = 0.f, Ba = 0.f, Bn = 0.f, Ma = 0.f, Mn = 0.f;
+    auto fetch = [&](int item, bf16x8 (&fq)[4], bf16x8 (&fd)[4], float& fl, float& fdl, float& fb, float& fm) {
         const int qi_ = (jt + item / H) * TQ + (lane & 31);
         const int hh = item % H;
         const size_t qrow_ = (rowbase + min(qi_, N - 1)) * (size_t)(H * 64) + hh * 64;
@@ -763,15 +766,28 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
         if (WIN) {      // window of rel = i - j for the item: from (i0 - j0 - 31); table index 64 + rel; lse made relative to m_h
             const float* row = biasT + (size_t)hh * ldT;
             fb = row[64 + ((jt + item / H) * TQ - j0 - 31) + min(lane, 62)];
+#if AT_DKV_FENCE
+            fm = row[ldT - 1];      // subtracted where the item is consumed: an arithmetic use here waits for every load issued above
+#else
             fl -= row[ldT - 1];
+#endif
         }
     };
-    if (wave < nitems) fetch(wave, qa, doa, La, Da, Ba);
+    if (wave < nitems) fetch(wave, qa, doa, La, Da, Ba, Ma);
+#if AT_DKV_FENCE
+    // Consume the first item's loads HERE.  Left pending into the loop, hipcc's wait-count pass has to assume at the loop header
+    // that qa / doa / La / Da may still be in flight from this block; its conservative counts (vmcnt(3) ... vmcnt(0) in front of
+    // the first MFMA of EVERY item, seen in the ISA) then also drain the NEXT item's loads that the loop has just issued: the
+    // prefetch ran with nothing in flight and every item paid a full memory round trip.
+#pragma unroll
+    for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qa[s]), "+v"(doa[s]));
+    asm volatile("" : "+v"(La), "+v"(Da), "+v"(Ba), "+v"(Ma));
+#endif
     __syncthreads();                           // bias_s staged
     for (int item = wave; item < nitems; item += 4) {
         const int it = jt + item / H, h = item % H;
         const int i0 = it * TQ;
-        if (item + 4 < nitems) fetch(item + 4, qn, don, Ln, Dn, Bn);
+        if (item + 4 < nitems) fetch(item + 4, qn, don, Ln, Dn, Bn, Mn);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {        // park this item's tiles in LDS for the transpose reads
             *(bf16x8*)(Qs + tile_off_blk(lane & 31, (2 * s + hi) * 16)) = qa[s];
@@ -783,7 +799,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
         // causal compare, the i < N compare and the clamp of the bias index (constant LDS offsets from one base)
         const float* bh = bias_s + h * nbk;
         float* ld_l = WIN ? (float*)(smem + 32768) + wave * 128 : (float*)(smem + 32768 + (size_t)H * (nqt * TQ) * sizeof(float)) + wave * 64;
-        if (lane < 32) { ld_l[lane] = La; ld_l[32 + lane] = Da; }
+        if (lane < 32) { ld_l[lane] = La - Ma; ld_l[32 + lane] = Da; }        // Ma: the head's reference point (WIN), else 0
         if (WIN) ld_l[64 + lane] = Ba;
         // window index of (query row crow(r, hi), this lane's key): cr + 4 hi - (lane & 31) + 31
         const float* bwp = ld_l + 64 + 31 + 4 * hi - (lane & 31);
@@ -860,7 +876,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) { qa[s] = qn[s]; doa[s] = don[s]; }
-        La = Ln; Da = Dn; Ba = Bn;
+        La = Ln; Da = Dn; Ba = Bn; Ma = Mn;
     }
     // cross-wave reduction through LDS, one accumulator pair at a time
     for (int which = 0; which < 2; ++which) {
