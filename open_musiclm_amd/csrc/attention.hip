@@ -815,6 +815,28 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
         const float* lp = ld_l + 4 * hi;
         if (i0 >= j0 + 31 && i0 + 31 < N) {
             const float* bp = WIN ? bwp : bh + (i0 - kj + 4 * hi);
+#if AT_DKV_FENCE
+            // gather pass, values pinned, then the arithmetic: with the reads inside `keylive ? ... : NEG_BIG` hipcc wrapped each
+            // element's two LDS reads in its own exec-masked block (read, read, wait, fma, wait, subtract: sixteen exposed LDS round
+            // trips per item, seen in the ISA); all indices are in range for every lane here, so the reads need no predicate
+            float bvv[16], lvv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cr = (r & 3) + 8 * (r >> 2);                     // crow(r, hi) - 4 hi
+                bvv[r] = bp[cr];
+                lvv[r] = lp[cr];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(bvv[r]), "+v"(lvv[r]));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cr = (r & 3) + 8 * (r >> 2);
+                const float x = st[r] * c + bvv[r] - lvv[r];
+                const float p = __builtin_amdgcn_exp2f(keylive ? x : NEG_BIG);
+                pp[r] = p;
+                st[r] = p * (dp[r] - lp[32 + cr]) * scale;
+            }
+#else
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int cr = (r & 3) + 8 * (r >> 2);                     // crow(r, hi) - 4 hi
@@ -822,7 +844,33 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
                 pp[r] = p;
                 st[r] = p * (dp[r] - lp[32 + cr]) * scale;
             }
+#endif
         } else {
+#if AT_DKV_FENCE
+            // diagonal / tail items (16 of a workgroup's items: the first query tile, and the last one when N % 32 != 0).  Written as
+            // one loop, `ok ? (expression with two LDS reads) : NEG_BIG` compiled to 16 branches, each around its own read -> wait ->
+            // read -> wait (seen in the ISA).  Two passes, the gathered values pinned in registers in between: straight-line code with
+            // counted waits like the branch above; same arithmetic per element.
+            float bvv[16], lvv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cr = (r & 3) + 8 * (r >> 2);
+                bvv[r] = WIN ? bwp[cr] : bh[max(min(i0 + crow(r, hi) - kj, nbk - 1), 0)];
+                lvv[r] = lp[cr];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(bvv[r]), "+v"(lvv[r]));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cr = (r & 3) + 8 * (r >> 2);
+                const int i = i0 + crow(r, hi);
+                const bool ok = (i >= kj) && keylive && (i < N);
+                const float x = st[r] * c + bvv[r] - lvv[r];
+                const float p = __builtin_amdgcn_exp2f(ok ? x : NEG_BIG);
+                pp[r] = p;
+                st[r] = p * (dp[r] - lp[32 + cr]) * scale;
+            }
+#else
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int cr = (r & 3) + 8 * (r >> 2);
@@ -833,6 +881,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
                 pp[r] = p;
                 st[r] = p * (dp[r] - lp[32 + cr]) * scale;
             }
+#endif
         }
 #else
         const float* bh = bias_s + h * nbk;
