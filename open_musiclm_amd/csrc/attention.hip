@@ -169,6 +169,9 @@ __device__ __forceinline__ void pack_acc(const f32x16& p, int s, bf16x8& hi, bf1
 #ifndef AT_DKV_FENCE
 #define AT_DKV_FENCE 1
 #endif
+#ifndef AT_DQ_BATCH
+#define AT_DQ_BATCH 1
+#endif
 #ifndef AT_LEAN
 #define AT_LEAN 1      /* round 2, first GPU call: parity tests identical, forward 206 -> 145 us, backward 694 -> 643 us per layer */
 #endif
@@ -413,11 +416,26 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
             f32x16 st, dp;
 #pragma unroll
             for (int e = 0; e < 16; ++e) { st[e] = 0.f; dp[e] = 0.f; }
+#if AT_DQ_BATCH
+            {   // all eight fragment reads in flight before the first MFMA, retired in two groups: left to hipcc (at the register
+                // ceiling here) every fragment went through the same four registers, one read -> wait -> MFMA at a time (ISA)
+                bf16x8 kfr[4], vfr[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { kfr[s] = frag_rows(Ks, 32 * sub, s, lane); vfr[s] = frag_rows(Vs, 32 * sub, s, lane); }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    if ((s & 1) == 0) asm volatile("" : "+v"(kfr[s]), "+v"(vfr[s]), "+v"(kfr[s + 1]), "+v"(vfr[s + 1]));
+                    st = MFMA(kfr[s], qf[s], st);                                // S^T  = K Q^T
+                    dp = MFMA(vfr[s], dof[s], dp);                               // dP^T = V dO^T
+                }
+            }
+#else
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 st = MFMA(frag_rows(Ks, 32 * sub, s, lane), qf[s], st);      // S^T  = K Q^T
                 dp = MFMA(frag_rows(Vs, 32 * sub, s, lane), dof[s], dp);     // dP^T = V dO^T
             }
+#endif
             // three straight passes (gather bias, arithmetic, scatter d(bias)): a fused per-element loop compiled to 16
             // serialised LDS round trips (read -> wait -> exp -> atomic), ~3k cycles per 32x32 block
 #if AT_LEAN
@@ -469,6 +487,23 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
                 const int rel = (i0 - j0 - 32 * sub) + (lane - 31);
                 if (rel >= 0 && rel < nb) dbias_l[rel] += dsum;
             }
+#if AT_DQ_BATCH
+            {   // the four K^T fragments requested together, the packing of dS under their latency, retired pair by pair
+                bf16x8 ktf[2][2], dsb[2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) ktf[s][dt] = frag_cols_tr(Kt, 32 * sub, s, 32 * dt, lane);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) pack_acc<false>(st, s, dsb[s], dummy);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    asm volatile("" : "+v"(ktf[s][0]), "+v"(ktf[s][1]));
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) acc[dt] = MFMA(ktf[s][dt], dsb[s], acc[dt]);   // dQ^T += K^T dS^T
+                }
+            }
+#else
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 bf16x8 dsb;
@@ -477,6 +512,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
                 for (int dt = 0; dt < 2; ++dt)
                     acc[dt] = MFMA(frag_cols_tr(Kt, 32 * sub, s, 32 * dt, lane), dsb, acc[dt]);   // dQ^T += K^T dS^T
             }
+#endif
         }
     }
     if (!active) return;

@@ -23,6 +23,9 @@
 #define A2_LOG2E 1.4426950408889634f
 #define A2_STAGE (8192 + 8192 + 8 * A2_BWIN * 4)     /* K rows | V blocked | bias window = 20 KiB */
 #define A2_NST 3
+#ifndef A2_DQ_BATCH
+#define A2_DQ_BATCH 1        /* backward dQ kernel: fragment / bias reads issued in batches (scheduling only, same arithmetic) */
+#endif
 #ifndef A2_ABLATE
 #define A2_ABLATE 0          /* profiling builds only: 1 = skip the tile arithmetic, 2 = skip the steady-state DMA, 4 = no exp2 */
 #endif
@@ -524,24 +527,53 @@ __global__ __launch_bounds__(A2_THREADS) void attn2_bwd_dq_kernel(const bf16_t* 
             f32x16 st, dp;
 #pragma unroll
             for (int e = 0; e < 16; ++e) { st[e] = 0.f; dp[e] = 0.f; }
+#if A2_DQ_BATCH
+            {   // all eight fragment reads in flight before the first MFMA, retired in two groups (hipcc issued them one at a time
+                // through the same four registers: read -> wait -> MFMA, seen in the ISA)
+                bf16x8 kfr[4], vfr[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { kfr[s] = a2_frag_rows(Kr, 32 * sub, s, lane); vfr[s] = a2_frag_rows(Vr, 32 * sub, s, lane); }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    if ((s & 1) == 0) asm volatile("" : "+v"(kfr[s]), "+v"(vfr[s]), "+v"(kfr[s + 1]), "+v"(vfr[s + 1]));
+                    st = MFMA16(kfr[s], qf[s], st);                               // S^T  = K Q^T
+                    dp = MFMA16(vfr[s], dof[s], dp);                              // dP^T = V dO^T
+                }
+            }
+#else
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 st = MFMA16(a2_frag_rows(Kr, 32 * sub, s, lane), qf[s], st);      // S^T  = K Q^T
                 dp = MFMA16(a2_frag_rows(Vr, 32 * sub, s, lane), dof[s], dp);     // dP^T = V dO^T
             }
+#endif
             const float* bp = bw + (64 - 32 * sub) + ql - 4 * hi;
             const float* mp = mb + jb + 4 * hi;
             float bv[16];
             const bool diag = jb + 31 > i0;
             const int d0 = qi - (jb + 4 * hi);
+            float4 m4s[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) m4s[g] = *(const float4*)(mp + 8 * g);
+#if A2_DQ_BATCH
+            float bpv[16];                     // bias window gathered in one pass (see m4s: nothing waits element by element)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bpv[r] = bp[-((r & 3) + 8 * (r >> 2))];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(bpv[r]));
+#endif
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float4 m4 = *(const float4*)(mp + 8 * g);
+                const float4 m4 = m4s[g];
                 const float mm[4] = {m4.x, m4.y, m4.z, m4.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g + e, cr = e + 8 * g;
+#if A2_DQ_BATCH
+                    float x = st[r] * c + bpv[r] + (mm[e] - Lp);
+#else
                     float x = st[r] * c + bp[-cr] + (mm[e] - Lp);
+#endif
                     if (diag) x = (d0 - cr >= 0) ? x : A2_NEG;
                     const float pr = __builtin_amdgcn_exp2f(x);
                     bv[r] = pr * (dp[r] - dl);                                    // dS (0 where masked)
@@ -556,12 +588,28 @@ __global__ __launch_bounds__(A2_THREADS) void attn2_bwd_dq_kernel(const bf16_t* 
                 const int rel = (i0 - jb) + (lane - 31);
                 if (rel >= 0 && rel < nb) dbw[rel] += dsum;
             }
+#if A2_DQ_BATCH
+            {
+                bf16x8 ktf[2][2], dsb[2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) { ktf[s][0] = a2_frag_cols_tr(Kb, 32 * sub, s, 0, lane); ktf[s][1] = a2_frag_cols_tr(Kb, 32 * sub, s, 32, lane); }
+#pragma unroll
+                for (int s = 0; s < 2; ++s) dsb[s] = a2_pack(st, s);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    asm volatile("" : "+v"(ktf[s][0]), "+v"(ktf[s][1]));
+                    acc[0] = MFMA16(ktf[s][0], dsb[s], acc[0]);                                // dQ^T += K^T dS^T
+                    acc[1] = MFMA16(ktf[s][1], dsb[s], acc[1]);
+                }
+            }
+#else
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const bf16x8 dsb = a2_pack(st, s);
                 acc[0] = MFMA16(a2_frag_cols_tr(Kb, 32 * sub, s, 0, lane), dsb, acc[0]);       // dQ^T += K^T dS^T
                 acc[1] = MFMA16(a2_frag_cols_tr(Kb, 32 * sub, s, 32, lane), dsb, acc[1]);
             }
+#endif
         }
     }
     if (!active) return;
