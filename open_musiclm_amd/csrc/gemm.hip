@@ -481,6 +481,9 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, 
         u1 = (int)(U * (lg + 1) / bal_wgs);
         if (u >= u1) return;
     }
+#ifndef OMLM_GEMM_ROTATE
+#define OMLM_GEMM_ROTATE 0          /* 1: rotated k-loop (last k16 step multiplied after the next tile's barrier); unmeasured, off */
+#endif
 #ifndef OMLM_SUPER_ROWS
 #define OMLM_SUPER_ROWS 1024       /* C rows per super-tile (tile rows walked column-major inside it) */
 #endif
@@ -549,6 +552,73 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, 
             sa.template issue<KMAP>(rsA, g.a_map, g.lda, k00, g.K, smem, wave, pa);
             sb.template issue<KMAP>(rsB, g.b_map, g.ldb, k00, g.K, smem + A_BYTES, wave, pb);
         }
+#if OMLM_GEMM_ROTATE
+        // Rotated k-loop: the MFMAs of a tile's LAST k16 step run AFTER the next tile's barrier and first fragment reads (their
+        // operands are in registers), so the matrix pipe has work while the barrier releases and the first LDS reads of the new
+        // tile are in flight; the next tile's DMA issue is spread over that deferred step and steps 0, 1, and step 2 covers its
+        // latency.  Same products in the same order per accumulator.
+        {
+            bf16x8 a[2][MI], b[2][NJ];
+            bool pending = false;                                                  // a[1], b[1] hold an unmultiplied last step
+            constexpr int MPS = MI * NJ, NLOAD = UA + UB;
+#ifndef OMLM_DMA_SPREAD
+#define OMLM_DMA_SPREAD 3
+#endif
+            constexpr int STRIDE = (OMLM_DMA_SPREAD * MPS) / NLOAD > 0 ? (OMLM_DMA_SPREAD * MPS) / NLOAD : 1;
+            for (int kt = kt0; kt < kt1; ++kt) {
+                const int cur = (kt - kt0) & 1;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();      // tile kt landed everywhere; every wave's reads of the other stage (incl. its last step) are complete
+                const bool live = kt + 1 < kt1;
+                char* nxt = smem + (cur ^ 1) * STAGE;
+                unsigned pan, pbn;
+                const int knext = tile_at(kt + 1, pan, pbn);
+                const char* As = smem + cur * STAGE;
+                const char* Bs = As + A_BYTES;
+                // phase ph in 0..3 = (deferred last step of tile kt-1, step 0, step 1, step 2) of this iteration; fi = fragment set
+                auto phase = [&](const int ph, const int fi, const bool mul) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) {
+                            if (mul) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[fi][i], b[fi][j], acc[i][j], 0, 0, 0);
+                            const int midx = ph * MPS + i * NJ + j;
+                            if (midx % STRIDE == 0 && midx / STRIDE < NLOAD) {
+                                const int l = midx / STRIDE;
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (l < UA) sa.template issue_one<KMAP>(l, rsA, g.a_map, g.lda, knext, g.K, nxt, wave, live, 0, pan);
+                                else        sb.template issue_one<KMAP>(l - UA, rsB, g.b_map, g.ldb, knext, g.K, nxt + A_BYTES, wave, live, 0, pbn);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                };
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a[0][i] = read_frag<A_KMAJ>(As, wm + 32 * i, 0, lane);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) b[0][j] = read_frag<B_KMAJ>(Bs, wn + 32 * j, 0, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                phase(0, 1, pending);                                              // last step of the previous tile (registers only)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int st = 0; st < 3; ++st) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) a[(st + 1) & 1][i] = read_frag<A_KMAJ>(As, wm + 32 * i, st + 1, lane);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) b[(st + 1) & 1][j] = read_frag<B_KMAJ>(Bs, wn + 32 * j, st + 1, lane);
+                    __builtin_amdgcn_sched_barrier(0);
+                    phase(st + 1, st & 1, true);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                pending = true;
+            }
+            if (pending) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], acc[i][j], 0, 0, 0);
+            }
+        }
+#else
         for (int kt = kt0; kt < kt1; ++kt) {
             const int cur = (kt - kt0) & 1;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile kt have landed (the DMA is asm: hipcc does not wait for it)
@@ -609,6 +679,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, 
                 __builtin_amdgcn_sched_barrier(0);                                // ... the MFMAs of step s
             }
         }
+#endif
         __syncthreads();
         tile_epilogue<MI, NJ, WN_, TOUT>(g, acc, smem, m0, n0, wm, wn, wave, lane, dbg, bal || split);
         if (!bal || u >= u1) break;
