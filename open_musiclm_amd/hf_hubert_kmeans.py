@@ -59,11 +59,27 @@ class HfHubertWithKmeans(nn.Module):
         b, t, d = embed.shape
         return self.kmeans.predict(embed.reshape(b * t, d)).reshape(b, t)
 
+    @torch.no_grad()
     def forward(self, wav_input, flatten=True, return_embed=False, input_sample_hz=None):
+        """hf_hubert_kmeans.py:54-93 with a supplied extractor: any module with HF HuBERT's call
+        (`hubert(input_values=, attention_mask=, output_hidden_states=True).hidden_states[layer]`).  The assignment to centroids
+        runs on the HIP nearest-centroid kernel (sklearn predict on the host in the reference); ids come back on the wave's device."""
         if not exists(self.hubert):
             raise RuntimeError("HfHubertWithKmeans was built without the MERT/HuBERT feature extractor (pretrained weights are "
                                "outside the MI355X hot path); use .assign(features) or supply semantic_token_ids")
-        raise NotImplementedError("audio feature extraction is outside the MI355X hot path")
+        assert return_embed or exists(self.kmeans), "kmeans model must be provided if return_embed==False"
+        if exists(input_sample_hz) and input_sample_hz != self.target_sample_hz:
+            raise ImportError("resampling needs torchaudio, which is not part of this build: feed audio at target_sample_hz")
+        if exists(self.seq_len_multiple_of):
+            from .utils import curtail_to_multiple
+            wav_input = curtail_to_multiple(wav_input, self.seq_len_multiple_of)
+        outputs = self.hubert(input_values=wav_input, attention_mask=torch.ones_like(wav_input), output_hidden_states=True)
+        embed = outputs.hidden_states[self.embed_layer]
+        if return_embed:
+            from .utils import zero_mean_unit_var_norm
+            return zero_mean_unit_var_norm(embed) if self.normalize_embeds else embed
+        ids = self.assign(embed)                                   # [B, T]; normalises inside
+        return ids.reshape(-1) if flatten else ids
 
 
 def get_kmeans_model(n_clusters, init, max_iter, batch_size, tol, max_no_improvement, n_init, reassignment_ratio, verbose=1):
@@ -94,4 +110,12 @@ def get_hubert_kmeans(model_name: str = "m-a-p/MERT-v0", kmeans_path: Optional[s
     if exists(kmeans_path):
         import joblib
         kmeans = joblib.load(kmeans_path)
-    return HfHubertWithKmeans(hubert=None, kmeans=kmeans, **kwargs)
+    # the reference downloads the checkpoint (hf_hubert_kmeans.py:152-160); here only a copy already in the local Hugging Face cache
+    # is used -- without one the wrapper still serves .assign(features) and every token-id path
+    hubert = None
+    try:
+        from transformers import HubertModel
+        hubert = HubertModel.from_pretrained(model_name, local_files_only=True)
+    except Exception:
+        hubert = None
+    return HfHubertWithKmeans(hubert=hubert, kmeans=kmeans, **kwargs)
