@@ -482,7 +482,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, 
         if (u >= u1) return;
     }
 #ifndef OMLM_GEMM_ROTATE
-#define OMLM_GEMM_ROTATE 0          /* 1: rotated k-loop (last k16 step multiplied after the next tile's barrier); unmeasured, off */
+#define OMLM_GEMM_ROTATE 1          /* rotated k-loop (last k16 step multiplied after the next tile's barrier); 0: the round-1/2 loop */
 #endif
 #ifndef OMLM_SUPER_ROWS
 #define OMLM_SUPER_ROWS 1024       /* C rows per super-tile (tile rows walked column-major inside it) */
@@ -561,10 +561,10 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, 
             bf16x8 a[2][MI], b[2][NJ];
             bool pending = false;                                                  // a[1], b[1] hold an unmultiplied last step
             constexpr int MPS = MI * NJ, NLOAD = UA + UB;
-#ifndef OMLM_DMA_SPREAD
-#define OMLM_DMA_SPREAD 3
+#ifndef OMLM_DMA_SPREAD_ROT
+#define OMLM_DMA_SPREAD_ROT 2      /* phases (of 4) over which the next tile's DMA issue is spread: 2 measured best (3: -1..+3 %, 4: worse) */
 #endif
-            constexpr int STRIDE = (OMLM_DMA_SPREAD * MPS) / NLOAD > 0 ? (OMLM_DMA_SPREAD * MPS) / NLOAD : 1;
+            constexpr int STRIDE = (OMLM_DMA_SPREAD_ROT * MPS) / NLOAD > 0 ? (OMLM_DMA_SPREAD_ROT * MPS) / NLOAD : 1;
             for (int kt = kt0; kt < kt1; ++kt) {
                 const int cur = (kt - kt0) & 1;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

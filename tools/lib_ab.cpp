@@ -1,0 +1,295 @@
+// Torch-free same-box A/B of two builds of libomlm_hip.so through the C ABI (include/omlm.h): attention backward and GEMM.
+// Loads both libraries with dlopen(RTLD_LOCAL), runs the same device inputs through each, compares the outputs bit for bit
+// (tolerance only where fp32 atomics make the order free: d(bias), split-K), and times each with HIP events.  A whole run is a few
+// seconds -- no Python import on the GPU box.
+//   build (here):  hipcc -O2 tools/lib_ab.cpp -o tools/lib_ab -ldl
+//   run (GPU box): tools/lib_ab <libA.so> <libB.so> [attn] [attn_large] [gemm]
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+typedef int (*fwd_t)(const void*, const void*, const void*, const float*, const float*, const unsigned char*, void*, float*, int, int, int, float, int, int, void*);
+typedef int (*bwd_t)(const void*, const void*, const void*, const float*, const float*, const unsigned char*, const void*, const void*, const float*, float*,
+                     float*, float*, float*, float*, int, int, int, float, int, int, void*);
+typedef int (*prep_t)(const float*, float*, int, int, int, const float*, const float*, float, float, void*);
+typedef long long (*tbl_t)(int, int);
+typedef int (*gemm_t)(const void*, const void*, void*, const float*, const int*, const int*, const int*, long long, long long, int, int, int, int, int, int, int,
+                      int, int, int, int, float, void*);
+typedef const char* (*err_t)(void);
+struct wgrad_desc { const void* A; const void* B; float* C; const int* c_map; int M, N, K, lda, ldb, ldc; };
+typedef int (*wgrad_t)(const wgrad_desc*, int, int, void*);
+typedef int (*planes_t)(const void*, long long, const void*, long long, void*, const float*, const int*, const int*, const int*, long long, long long,
+                        int, int, int, int, int, int, int, int, int, int, float, void*);
+
+struct Lib {
+    std::string path; void* h; fwd_t fwd; bwd_t bwd; prep_t prep; tbl_t tbl; gemm_t gemm; err_t err; wgrad_t wgrad; planes_t planes;
+    void load(const char* p) {
+        path = p;
+        h = dlopen(p, RTLD_NOW | RTLD_LOCAL);
+        if (!h) { fprintf(stderr, "dlopen %s: %s\n", p, dlerror()); exit(1); }
+        fwd = (fwd_t)dlsym(h, "omlm_mqa_attn_fwd"); bwd = (bwd_t)dlsym(h, "omlm_mqa_attn_bwd");
+        prep = (prep_t)dlsym(h, "omlm_attn_bias_prepare"); tbl = (tbl_t)dlsym(h, "omlm_attn_bias_table_floats");
+        gemm = (gemm_t)dlsym(h, "omlm_gemm"); err = (err_t)dlsym(h, "omlm_last_error"); wgrad = (wgrad_t)dlsym(h, "omlm_gemm_wgrad_group"); planes = (planes_t)dlsym(h, "omlm_gemm_planes");
+        if (!fwd || !bwd || !prep || !tbl || !gemm || !err) { fprintf(stderr, "%s: missing symbol\n", p); exit(1); }
+    }
+    void ok(int rc, const char* what) { if (rc != 0) { fprintf(stderr, "%s: %s failed (%d): %s\n", path.c_str(), what, rc, err()); exit(1); } }
+};
+
+static uint16_t bf16(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7FFFu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
+
+// cheap pseudo-random bf16 in (-1.73, 1.73) (unit variance): host generation must not dominate a GPU call
+static void fast_fill(std::vector<uint16_t>& v, float scale, uint64_t seed) {
+    uint64_t x = seed * 0x9E3779B97F4A7C15ull + 1;
+    for (auto& e : v) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; const float u = (float)((x >> 40) & 0xFFFFFF) * (1.0f / 16777216.0f); e = bf16((2.f * u - 1.f) * 1.7320508f * scale); }
+}
+
+template <typename T> static T* dev(const std::vector<T>& h) { T* d; CK(hipMalloc(&d, h.size() * sizeof(T))); CK(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice)); return d; }
+template <typename T> static T* dev_zero(size_t n) { T* d; CK(hipMalloc(&d, n * sizeof(T))); CK(hipMemset(d, 0, n * sizeof(T))); return d; }
+template <typename T> static std::vector<T> host(const T* d, size_t n) { std::vector<T> h(n); CK(hipMemcpy(h.data(), d, n * sizeof(T), hipMemcpyDeviceToHost)); return h; }
+
+template <typename F> static float time_us(F fn, int reps) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    fn(); CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < reps; ++i) fn();
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms * 1000.f / reps;
+}
+
+static std::string g_env_a, g_env_b;
+static void apply_env(const std::string& e) {       // "NAME=VALUE" or empty: (un)set before a library's first use of the switch
+    static std::string last;
+    if (!last.empty()) unsetenv(last.substr(0, last.find('=')).c_str());
+    last = e;
+    if (!e.empty()) setenv(e.substr(0, e.find('=')).c_str(), e.substr(e.find('=') + 1).c_str(), 1);
+}
+
+struct Cmp { size_t n = 0, diff = 0; double maxabs = 0, maxref = 0; bool finite = true; };
+static Cmp compare(const std::vector<float>& a, const std::vector<float>& b) {
+    Cmp c; c.n = a.size();
+    for (size_t i = 0; i < a.size(); ++i) {
+        if (memcmp(&a[i], &b[i], 4) != 0) c.diff++;
+        if (!std::isfinite(a[i]) || !std::isfinite(b[i])) c.finite = false;
+        c.maxabs = std::fmax(c.maxabs, std::fabs((double)a[i] - (double)b[i]));
+        c.maxref = std::fmax(c.maxref, std::fabs((double)b[i]));
+    }
+    return c;
+}
+static void report(const char* what, const Cmp& c, bool exact_expected) {
+    printf("  %-6s %zu values, %zu differ bitwise, max |a-b| %.3e (max |b| %.3e)%s%s\n", what, c.n, c.diff, c.maxabs, c.maxref,
+           c.finite ? "" : "  NON-FINITE", exact_expected ? (c.diff ? "  <-- EXPECTED IDENTICAL" : "  identical") : "");
+}
+
+static void attn_case(Lib& A, Lib& Bl, int B, int N, int H) {
+    printf("== attention backward  B=%d N=%d H=%d (bf16 operands)\n", B, N, H);
+    const size_t M = (size_t)B * N; const int ld = (H + 7) / 8 * 8; const float scale = 8.0f;
+    std::mt19937 g(1234); std::normal_distribution<float> nd(0.f, 1.f); std::uniform_real_distribution<float> ud(0.f, 1.f);
+    std::vector<uint16_t> q(M * H * 64), k(M * 64), v(M * 64), dout(M * H * 64);
+    auto unit = [&](uint16_t* dst) { float t[64]; double s = 0; for (int d = 0; d < 64; ++d) { t[d] = nd(g); s += (double)t[d] * t[d]; } const float r = 1.f / (float)std::sqrt(s); for (int d = 0; d < 64; ++d) dst[d] = bf16(t[d] * r); };
+    for (size_t r = 0; r < M * H; ++r) unit(&q[r * 64]);
+    for (size_t r = 0; r < M; ++r) unit(&k[r * 64]);
+    for (auto& x : v) x = bf16(nd(g));
+    for (auto& x : dout) x = bf16(nd(g));
+    std::vector<float> bias((size_t)N * ld, 0.f);
+    for (int r = 0; r < N; ++r) for (int h = 0; h < H; ++h) bias[(size_t)r * ld + h] = 0.1f * nd(g);
+    std::vector<unsigned char> mask(M);
+    for (size_t i = 0; i < M; ++i) mask[i] = (i % N == 0) ? 1 : (ud(g) > 0.15f);
+    uint16_t *dq_ = dev(q), *dk_ = dev(k), *dv_ = dev(v), *ddo = dev(dout);
+    float* dbias_in = dev(bias); unsigned char* dmask = dev(mask);
+    uint16_t* out = dev_zero<uint16_t>(M * H * 64);
+    float* lse = dev_zero<float>((size_t)B * H * N); float* delta = dev_zero<float>((size_t)B * H * N);
+    std::vector<float> res[2][4]; float us[2]; float fwd_us[2]; float us_nb[2];
+    Lib* libs[2] = {&A, &Bl};
+    for (int li = 0; li < 2; ++li) {
+        Lib& L = *libs[li];
+        apply_env(li ? g_env_b : g_env_a);
+        const long long tf = L.tbl(N, H);
+        float* biasT = dev_zero<float>((size_t)tf);
+        L.ok(L.prep(dbias_in, biasT, N, H, ld, nullptr, nullptr, 1.0f, scale, nullptr), "bias_prepare");
+        L.ok(L.fwd(dq_, dk_, dv_, dbias_in, biasT, dmask, out, lse, B, N, H, scale, ld, 1, nullptr), "attn_fwd");
+        CK(hipDeviceSynchronize());
+        float *gq = dev_zero<float>(M * H * 64), *gk = dev_zero<float>(M * 64), *gv = dev_zero<float>(M * 64), *gb = dev_zero<float>((size_t)N * ld);
+        L.ok(L.bwd(dq_, dk_, dv_, dbias_in, biasT, dmask, out, ddo, lse, delta, gq, gk, gv, gb, B, N, H, scale, ld, 1, nullptr), "attn_bwd");
+        CK(hipDeviceSynchronize());
+        res[li][0] = host(gq, M * H * 64); res[li][1] = host(gk, M * 64); res[li][2] = host(gv, M * 64); res[li][3] = host(gb, (size_t)N * ld);
+        float* scratch_b = dev_zero<float>((size_t)N * ld);
+        us[li] = time_us([&] { L.bwd(dq_, dk_, dv_, dbias_in, biasT, dmask, out, ddo, lse, delta, gq, gk, gv, scratch_b, B, N, H, scale, ld, 1, nullptr); }, 10);
+        us_nb[li] = time_us([&] { L.bwd(dq_, dk_, dv_, dbias_in, biasT, dmask, out, ddo, lse, delta, gq, gk, gv, nullptr, B, N, H, scale, ld, 1, nullptr); }, 10);
+        fwd_us[li] = time_us([&] { L.fwd(dq_, dk_, dv_, dbias_in, biasT, dmask, out, lse, B, N, H, scale, ld, 1, nullptr); }, 10);
+        CK(hipFree(gq)); CK(hipFree(gk)); CK(hipFree(gv)); CK(hipFree(gb)); CK(hipFree(scratch_b)); CK(hipFree(biasT));
+    }
+    const double flops = 4.0 * H * 64 * (double)N * (N + 1) / 2 * B;
+    printf("  A %-48s fwd %8.1f us  bwd %8.1f us (%6.1f TFLOP/s at 5 matmuls)  bwd without d(bias) %8.1f us\n", A.path.c_str(), fwd_us[0], us[0], 2.5 * flops / us[0] / 1e6, us_nb[0]);
+    printf("  B %-48s fwd %8.1f us  bwd %8.1f us (%6.1f TFLOP/s)               bwd without d(bias) %8.1f us\n", Bl.path.c_str(), fwd_us[1], us[1], 2.5 * flops / us[1] / 1e6, us_nb[1]);
+    report("dq", compare(res[0][0], res[1][0]), true);
+    report("dk", compare(res[0][1], res[1][1]), true);
+    report("dv", compare(res[0][2], res[1][2]), true);
+    report("dbias", compare(res[0][3], res[1][3]), false);     // cross-workgroup fp32 atomics: order is free
+    CK(hipFree(dq_)); CK(hipFree(dk_)); CK(hipFree(dv_)); CK(hipFree(ddo)); CK(hipFree(dbias_in)); CK(hipFree(dmask)); CK(hipFree(out)); CK(hipFree(lse)); CK(hipFree(delta));
+}
+
+static void gemm_case(Lib& A, Lib& Bl) {
+    const int M = 35712, D = 1024, F2 = 5472;
+    printf("== GEMM  M=%d D=%d F2=%d (bf16 operands)\n", M, D, F2);
+    std::mt19937 g(99); std::normal_distribution<float> nd(0.f, 1.f);
+    std::vector<uint16_t> X((size_t)M * D), W((size_t)F2 * D), dH((size_t)M * F2);
+    fast_fill(X, 1.f, 1); fast_fill(W, 0.03f, 2); fast_fill(dH, 1.f, 3);
+    uint16_t *dX_ = dev(X), *dW_ = dev(W), *ddH = dev(dH);
+    Lib* libs[2] = {&A, &Bl};
+    std::vector<float> r_nn[2], r_tn[2]; std::vector<uint16_t> r_nt[2]; float us[2][3];
+    for (int li = 0; li < 2; ++li) {
+        Lib& L = *libs[li];
+        apply_env(li ? g_env_b : g_env_a);
+        uint16_t* Hout = dev_zero<uint16_t>((size_t)M * F2); float* dXo = dev_zero<float>((size_t)M * D); float* dWo = dev_zero<float>((size_t)F2 * D);
+        auto nt = [&] { L.ok(L.gemm(dX_, dW_, Hout, nullptr, nullptr, nullptr, nullptr, M, F2, M, F2, D, D, D, F2, 0, 0, 0, 1, 1, 1.f, nullptr), "gemm NT"); };
+        auto nn = [&] { L.ok(L.gemm(ddH, dW_, dXo, nullptr, nullptr, nullptr, nullptr, M, F2, M, D, F2, F2, D, D, 0, 0, 1, 1, 0, 1.f, nullptr), "gemm NN"); };
+        auto tn = [&] { L.ok(L.gemm(ddH, dX_, dWo, dWo, nullptr, nullptr, nullptr, M, M, F2, D, M, F2, D, D, D, 1, 1, 1, 0, 1.f, nullptr), "gemm TN"); };
+        nt(); nn(); tn(); CK(hipDeviceSynchronize());
+        r_nt[li] = host(Hout, (size_t)M * F2); r_nn[li] = host(dXo, (size_t)M * D); r_tn[li] = host(dWo, (size_t)F2 * D);
+        us[li][0] = time_us(nt, 10); us[li][1] = time_us(nn, 10); us[li][2] = time_us(tn, 10);
+        CK(hipFree(Hout)); CK(hipFree(dXo)); CK(hipFree(dWo));
+    }
+    const double f = 2.0 * M * D * (double)F2;
+    for (int li = 0; li < 2; ++li)
+        printf("  %c %-40s ffin_NT %7.1f us %6.0f TF | dX_NN %7.1f us %6.0f TF | dW_TN %7.1f us %6.0f TF\n", li ? 'B' : 'A', libs[li]->path.c_str(),
+               us[li][0], f / us[li][0] / 1e6, us[li][1], f / us[li][1] / 1e6, us[li][2], f / us[li][2] / 1e6);
+    size_t d = 0; for (size_t i = 0; i < r_nt[0].size(); ++i) d += r_nt[0][i] != r_nt[1][i];
+    printf("  ffin_NT (bf16 out) %zu values, %zu differ bitwise%s\n", r_nt[0].size(), d, d ? "  <-- EXPECTED IDENTICAL" : "  identical");
+    report("dX_NN", compare(r_nn[0], r_nn[1]), true);
+    report("dW_TN", compare(r_tn[0], r_tn[1]), false);          // split-K fp32 atomics
+    CK(hipFree(dX_)); CK(hipFree(dW_)); CK(hipFree(ddH));
+}
+
+
+// Odd shapes through every layout / output type: B's results must equal A's bit for bit (no split-K here: K is small enough
+// that the host picks one slice, so there are no atomics).
+static void gemm_edge_case(Lib& A, Lib& Bl) {
+    printf("== GEMM edge shapes (bitwise B vs A)\n");
+    struct Sh { int M, N, K; };
+    const Sh shapes[] = {{300, 520, 200}, {257, 129, 72}, {1000, 1032, 1024}, {2232, 512, 1024}, {35, 40, 64}, {513, 1024, 2736}, {8, 8, 8}, {1116, 128, 1024}};
+    std::mt19937 g(7); std::normal_distribution<float> nd(0.f, 1.f);
+    Lib* libs[2] = {&A, &Bl};
+    size_t bad = 0, total = 0;
+    for (const Sh& sh : shapes)
+        for (int ak = 0; ak < 2; ++ak) for (int bk = 0; bk < 2; ++bk) for (int od = 0; od < 2; ++od) for (int withc = 0; withc < 2; ++withc) {
+            const int M = sh.M, N = sh.N, K = sh.K;
+            const int lda = ak ? (M + 7) / 8 * 8 : (K + 7) / 8 * 8, ldb = bk ? (N + 7) / 8 * 8 : (K + 7) / 8 * 8, ldc = (N + 7) / 8 * 8;
+            const long long ar = ak ? K : M, br = bk ? K : N;
+            std::vector<uint16_t> a((size_t)ar * lda), b((size_t)br * ldb);
+            for (auto& x : a) x = bf16(nd(g));
+            for (auto& x : b) x = bf16(nd(g));
+            std::vector<float> cin((size_t)M * ldc);
+            for (auto& x : cin) x = nd(g);
+            uint16_t *da = dev(a), *db = dev(b); float* dcin = dev(cin);
+            std::vector<unsigned char> out[2];
+            for (int li = 0; li < 2; ++li) {
+                apply_env(li ? g_env_b : g_env_a);
+                const size_t bytes = (size_t)M * ldc * (od ? 2 : 4);
+                unsigned char* dc = dev_zero<unsigned char>(bytes);
+                libs[li]->ok(libs[li]->gemm(da, db, dc, withc ? dcin : nullptr, nullptr, nullptr, nullptr, ar, br, M, N, K, lda, ldb, ldc, ldc, ak, bk, 1, od, 0.5f, nullptr), "gemm edge");
+                CK(hipDeviceSynchronize());
+                out[li] = host(dc, bytes);
+                CK(hipFree(dc));
+            }
+            ++total;
+            if (out[0] != out[1]) { ++bad; printf("  MISMATCH M=%d N=%d K=%d a_kmajor=%d b_kmajor=%d out=%s cin=%d\n", M, N, K, ak, bk, od ? "bf16" : "f32", withc); }
+            CK(hipFree(da)); CK(hipFree(db)); CK(hipFree(dcin));
+        }
+    // row maps (gathered A rows, scattered / skipped C rows) and the hi/lo-plane route (3x k-loop), a few shapes each
+    for (const Sh& sh : shapes) {
+        const int M = sh.M, N = sh.N, K = sh.K, lda = (K + 7) / 8 * 8, ldb = lda, ldc = (N + 7) / 8 * 8;
+        const long long arows = M + 37, crows = M + 5;
+        std::vector<uint16_t> a((size_t)arows * lda * 2), b((size_t)N * ldb * 2);          // two planes each (hi | lo)
+        for (auto& x : a) x = bf16(nd(g));
+        for (auto& x : b) x = bf16(nd(g));
+        std::vector<int> am(M), cm(M);
+        for (int r = 0; r < M; ++r) { am[r] = (int)(((long long)r * 7919 + 13) % arows); cm[r] = (r % 11 == 3) ? -1 : r; }   // gather; identity with skipped rows
+        uint16_t *da = dev(a), *db = dev(b); int *dam = dev(am), *dcm = dev(cm);
+        for (int mode = 0; mode < 2; ++mode) {                                                 // 0: maps through omlm_gemm, 1: planes
+            std::vector<float> out[2];
+            for (int li = 0; li < 2; ++li) {
+                apply_env(li ? g_env_b : g_env_a);
+                float* dc = dev_zero<float>((size_t)crows * ldc);
+                if (mode == 0) libs[li]->ok(libs[li]->gemm(da, db, dc, nullptr, dam, nullptr, dcm, arows, N, M, N, K, lda, ldb, ldc, 0, 0, 0, 1, 0, 1.f, nullptr), "gemm maps");
+                else libs[li]->ok(libs[li]->planes(da, (long long)arows * lda * 2, db, (long long)N * ldb * 2, dc, nullptr, nullptr, nullptr, nullptr, arows, N, M, N, K, lda, ldb, ldc, 0, 0, 0, 0, 1.f, nullptr), "gemm planes");
+                CK(hipDeviceSynchronize());
+                out[li] = host(dc, (size_t)crows * ldc);
+                CK(hipFree(dc));
+            }
+            ++total;
+            if (memcmp(out[0].data(), out[1].data(), out[0].size() * 4) != 0) { ++bad; printf("  MISMATCH %s M=%d N=%d K=%d\n", mode ? "planes" : "maps", M, N, K); }
+        }
+        CK(hipFree(da)); CK(hipFree(db)); CK(hipFree(dam)); CK(hipFree(dcm));
+    }
+    printf("  %zu configurations, %zu mismatching%s\n", total, bad, bad ? "  <-- EXPECTED IDENTICAL" : "  (all identical)");
+}
+
+// The grouped weight-gradient launch on one layer's five problems x `layers` (dW += dY^T X, K = B*N rows): same tile body as omlm_gemm.
+static void wgrad_case(Lib& A, Lib& Bl) {
+    const int K = 35712, D = 1024, layers = 3;
+    printf("== grouped weight gradients  K=%d, %d layers x 5 problems\n", K, layers);
+    const int Ms[5] = {512, 128, 1024, 5472, 1024}, Ns[5] = {1024, 1024, 512, 1024, 2736};
+    std::vector<uint16_t> big((size_t)K * 5472); fast_fill(big, 1.f, 11);
+    std::vector<uint16_t> big2((size_t)K * 2736); fast_fill(big2, 1.f, 12);
+    uint16_t *dA = dev(big), *dB = dev(big2);
+    Lib* libs[2] = {&A, &Bl};
+    std::vector<float> res[2]; float us[2];
+    size_t cfl = 0; for (int i = 0; i < 5; ++i) cfl += (size_t)Ms[i] * Ns[i];
+    double flops = 0; for (int i = 0; i < 5; ++i) flops += 2.0 * Ms[i] * Ns[i] * (double)K; flops *= layers;
+    for (int li = 0; li < 2; ++li) {
+        apply_env(li ? g_env_b : g_env_a);
+        float* C = dev_zero<float>(cfl * layers);
+        std::vector<wgrad_desc> pr;
+        size_t off = 0;
+        for (int l = 0; l < layers; ++l)
+            for (int i = 0; i < 5; ++i) {
+                wgrad_desc d; d.A = dA + 8 * l; d.B = dB + 8 * l; d.C = C + off; d.c_map = nullptr;      // k-major operands: [K, M] / [K, N] views of the big buffers
+                d.M = Ms[i]; d.N = Ns[i]; d.K = K - 8; d.lda = 5472; d.ldb = 2736; d.ldc = Ns[i];
+                off += (size_t)Ms[i] * Ns[i];
+                pr.push_back(d);
+            }
+        auto run = [&] { libs[li]->ok(libs[li]->wgrad(pr.data(), (int)pr.size(), 0, nullptr), "wgrad_group"); };
+        run(); CK(hipDeviceSynchronize());
+        res[li] = host(C, cfl * layers);
+        us[li] = time_us(run, 5);
+        CK(hipFree(C));
+    }
+    for (int li = 0; li < 2; ++li) printf("  %c %-48s %8.1f us  %6.0f TFLOP/s\n", li ? 'B' : 'A', libs[li]->path.c_str(), us[li], flops / us[li] / 1e6);
+    report("dW", compare(res[0], res[1]), false);
+    CK(hipFree(dA)); CK(hipFree(dB));
+}
+
+int main(int argc, char** argv) {
+    // usage: lib_ab base.so [NAME=VALUE@]variant.so ... -- case ...      (NAME=VALUE is exported before that library's first call:
+    //        the libraries cache their OMLM_* switches per instance, so the same code can be timed under two settings from two copies)
+    std::vector<Lib*> libs; std::vector<std::string> envs; int i = 1;
+    for (; i < argc && strcmp(argv[i], "--"); ++i) {
+        std::string a = argv[i], env;
+        const size_t at = a.find('@');
+        if (at != std::string::npos) { env = a.substr(0, at); a = a.substr(at + 1); }
+        Lib* L = new Lib; L->load(a.c_str()); if (!env.empty()) L->path = env + "@" + a;
+        libs.push_back(L); envs.push_back(env);
+    }
+    if (libs.size() < 2 || i >= argc) { fprintf(stderr, "usage: %s base.so [ENV=V@]variant.so ... -- attn|attn_large|gemm|gemm_edge ...\n", argv[0]); return 2; }
+    hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, 0)); printf("device: %s, %d CUs\n", pr.name, pr.multiProcessorCount);
+    for (++i; i < argc; ++i)
+        for (size_t v = 1; v < libs.size(); ++v) {
+            g_env_a = envs[0]; g_env_b = envs[v];
+            if (!strcmp(argv[i], "attn")) attn_case(*libs[0], *libs[v], 32, 1116, 8);
+            else if (!strcmp(argv[i], "attn_large")) attn_case(*libs[0], *libs[v], 8, 1817, 16);
+            else if (!strcmp(argv[i], "gemm")) gemm_case(*libs[0], *libs[v]);
+            else if (!strcmp(argv[i], "gemm_edge")) gemm_edge_case(*libs[0], *libs[v]);
+            else if (!strcmp(argv[i], "wgrad")) wgrad_case(*libs[0], *libs[v]);
+        }
+    return 0;
+}
