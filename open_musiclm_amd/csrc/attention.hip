@@ -172,6 +172,12 @@ __device__ __forceinline__ void pack_acc(const f32x16& p, int s, bf16x8& hi, bf1
 #ifndef AT_DQ_BATCH
 #define AT_DQ_BATCH 1
 #endif
+#ifndef AT_DBIAS_CARRY
+#define AT_DBIAS_CARRY 0   /* bf16 dQ kernel: d(bias) bins finalised in registers and stored once (no per-block LDS read-modify-write); unmeasured, off */
+#endif
+#ifndef AT_ABLATE
+#define AT_ABLATE 0        /* timing builds only (bf16 dQ kernel): 1 = no diagonal sums, 2 = no global d(bias) flush, 4 = no per-block table update */
+#endif
 #ifndef AT_LEAN
 #define AT_LEAN 1      /* round 2, first GPU call: parity tests identical, forward 206 -> 145 us, backward 694 -> 643 us per layer */
 #endif
@@ -385,6 +391,10 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
 #pragma unroll
     for (int e = 0; e < 16; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
     const float c = scale * LOG2E;
+#if AT_DBIAS_CARRY
+    float dcarry = 0.f;                    // lower half (t = -31..0) of the previous block's diagonal sums
+    int dcarry_base = i0 + 32;             // i0 - jb of that block (none yet: its bins lie above the table)
+#endif
 
     const int nkt = (i0 + TQ + TKV - 1) / TKV;
     KVRegs<T, false> kr, vr;
@@ -483,9 +493,24 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
                 // registers instead: output lane L stands for t = q - kr = L - 31 and pulls row kr's element from query
                 // column q = t + kr through the cross-lane permute (no LDS memory access); then ONE plain read-add-write
                 // of the wave-private table, predicated so that every lane owns a distinct bin.
-                const float dsum = diag_sum_32x32(bv, lane);
+                const float dsum = (AT_ABLATE & 1) ? bv[0] + bv[15] : diag_sum_32x32(bv, lane);
                 const int rel = (i0 - j0 - 32 * sub) + (lane - 31);
-                if (rel >= 0 && rel < nb) dbias_l[rel] += dsum;
+#if AT_DBIAS_CARRY
+                // A wave walks its key blocks in order (jb = 0, 32, ...), so a bin rel receives exactly two contributions: lanes
+                // 0..31 of one block (t = -31..0) and lanes 32..63 of the NEXT block (t = 1..32).  The lower half is carried in a
+                // register, moved to the upper lanes with one VALU half-swap and added there: every bin is then WRITTEN once (plain
+                // store) instead of read-modified-written per block (the read -> wait -> add -> write chain measured ~55 us per layer).
+                {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(0u, __float_as_uint(dcarry), false, false);   // [0].hi = dcarry.lo
+                    const float fin = dsum + __uint_as_float(sw[0]);
+                    if (lane >= 32 && rel >= 0 && rel < nb) dbias_l[rel] = fin;
+                    dcarry = dsum;
+                    dcarry_base = i0 - j0 - 32 * sub;
+                }
+#else
+                if (!(AT_ABLATE & 4) && rel >= 0 && rel < nb) dbias_l[rel] += dsum;
+                if (AT_ABLATE & 4) acc[0][0] += dsum * 1e-30f;
+#endif
             }
 #if AT_DQ_BATCH
             {   // the four K^T fragments requested together, the packing of dS under their latency, retired pair by pair
@@ -526,7 +551,13 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
                 *(float4*)(drow + d) = make_float4(acc[dt][4 * g4], acc[dt][4 * g4 + 1], acc[dt][4 * g4 + 2], acc[dt][4 * g4 + 3]);
             }
     }
-    if (dbias) {
+#if AT_DBIAS_CARRY
+    if (dbias) {        // the last block's lower half: bins dcarry_base - 31 .. dcarry_base (only rel >= 0 exist)
+        const int rel = dcarry_base + (lane - 31);
+        if (lane < 32 && rel >= 0 && rel < nb) dbias_l[rel] = dcarry;
+    }
+#endif
+    if (dbias && !(AT_ABLATE & 2)) {
         // LDS atomics of this wave are complete in program order for this wave's own later reads
         __builtin_amdgcn_s_waitcnt(0xc07f);
         for (int r = lane; r < min(nb, N); r += 64) {
