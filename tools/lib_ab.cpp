@@ -3,7 +3,7 @@
 // (tolerance only where fp32 atomics make the order free: d(bias), split-K), and times each with HIP events.  A whole run is a few
 // seconds -- no Python import on the GPU box.
 //   build (here):  hipcc -O2 tools/lib_ab.cpp -o tools/lib_ab -ldl
-//   run (GPU box): tools/lib_ab <libA.so> <libB.so> [attn] [attn_large] [gemm]
+//   run (GPU box): tools/lib_ab base.so [ENV=V@]variant.so ... -- attn attn_large gemm gemm_edge wgrad ffmid ln
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <cmath>
@@ -27,11 +27,19 @@ typedef int (*gemm_t)(const void*, const void*, void*, const float*, const int*,
 typedef const char* (*err_t)(void);
 struct wgrad_desc { const void* A; const void* B; float* C; const int* c_map; int M, N, K, lda, ldb, ldc; };
 typedef int (*wgrad_t)(const wgrad_desc*, int, int, void*);
+typedef int (*ffwd_t)(const void*, const void*, const void*, void*, float*, float*, int, int, int, int, float, float, unsigned long long,
+                      const unsigned long long*, unsigned char*, void*, int, void*);
+typedef long long (*fws_t)(int, int);
+typedef int (*fbwd_t)(const void*, const void*, const void*, const void*, const float*, const float*, void*, void*, float*, float*, float*,
+                      int, int, int, int, float, unsigned long long, const unsigned long long*, const unsigned char*, const void*, int, void*);
+typedef int (*lnf_t)(const float*, const float*, void*, void*, float*, float*, int, int, int, float, int, void*);
+typedef long long (*lnws_t)(int);
+typedef int (*lnb_t)(const void*, const float*, const float*, const float*, const float*, const float*, float*, void*, float*, float*, int, int, float, int, int, void*);
 typedef int (*planes_t)(const void*, long long, const void*, long long, void*, const float*, const int*, const int*, const int*, long long, long long,
                         int, int, int, int, int, int, int, int, int, int, float, void*);
 
 struct Lib {
-    std::string path; void* h; fwd_t fwd; bwd_t bwd; prep_t prep; tbl_t tbl; gemm_t gemm; err_t err; wgrad_t wgrad; planes_t planes;
+    std::string path; void* h; fwd_t fwd; bwd_t bwd; prep_t prep; tbl_t tbl; gemm_t gemm; err_t err; wgrad_t wgrad; planes_t planes; ffwd_t ffwd; fws_t fws; fbwd_t fbwd; lnf_t lnf; lnws_t lnws; lnb_t lnb;
     void load(const char* p) {
         path = p;
         h = dlopen(p, RTLD_NOW | RTLD_LOCAL);
@@ -39,6 +47,8 @@ struct Lib {
         fwd = (fwd_t)dlsym(h, "omlm_mqa_attn_fwd"); bwd = (bwd_t)dlsym(h, "omlm_mqa_attn_bwd");
         prep = (prep_t)dlsym(h, "omlm_attn_bias_prepare"); tbl = (tbl_t)dlsym(h, "omlm_attn_bias_table_floats");
         gemm = (gemm_t)dlsym(h, "omlm_gemm"); err = (err_t)dlsym(h, "omlm_last_error"); wgrad = (wgrad_t)dlsym(h, "omlm_gemm_wgrad_group"); planes = (planes_t)dlsym(h, "omlm_gemm_planes");
+        ffwd = (ffwd_t)dlsym(h, "omlm_ffmid_fwd"); fws = (fws_t)dlsym(h, "omlm_ffmid_bwd_workspace_bytes"); fbwd = (fbwd_t)dlsym(h, "omlm_ffmid_bwd");
+        lnf = (lnf_t)dlsym(h, "omlm_layernorm_fwd"); lnws = (lnws_t)dlsym(h, "omlm_layernorm_bwd_workspace_bytes"); lnb = (lnb_t)dlsym(h, "omlm_layernorm_bwd");
         if (!fwd || !bwd || !prep || !tbl || !gemm || !err) { fprintf(stderr, "%s: missing symbol\n", p); exit(1); }
     }
     void ok(int rc, const char* what) { if (rc != 0) { fprintf(stderr, "%s: %s failed (%d): %s\n", path.c_str(), what, rc, err()); exit(1); } }
@@ -269,6 +279,77 @@ static void wgrad_case(Lib& A, Lib& Bl) {
     CK(hipFree(dA)); CK(hipFree(dB));
 }
 
+static void fill_f32(std::vector<float>& v, float scale, uint64_t seed) {
+    uint64_t x = seed * 0x9E3779B97F4A7C15ull + 1;
+    for (auto& e : v) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; e = ((float)((x >> 40) & 0xFFFFFF) * (2.0f / 16777216.0f) - 1.f) * 1.7320508f * scale; }
+}
+template <typename T> static size_t count_diff(const std::vector<T>& a, const std::vector<T>& b) { size_t d = 0; for (size_t i = 0; i < a.size(); ++i) d += memcmp(&a[i], &b[i], sizeof(T)) != 0; return d; }
+
+// ConvFeedForward middle, bf16 operands, coarse-small micro-batch (M = 32 x 1116 rows, F = 2730 -> Fp = 2736), dropout 0.1 through
+// the stored keep bits, gh saved: the configuration of the training step.
+static void ffmid_case(Lib& A, Lib& Bl) {
+    const int nseq = 1116, B = 32, M = B * nseq, F = 2730, Fp = 2736;
+    printf("== ffmid  M=%d F=%d Fp=%d (bf16 operands, p = 0.1)\n", M, F, Fp);
+    std::vector<uint16_t> h1((size_t)M * 2 * Fp), cw((size_t)3 * 2 * Fp), gm(Fp), dh2((size_t)M * Fp);
+    fast_fill(h1, 1.f, 21); fast_fill(cw, 0.5f, 22); fast_fill(gm, 1.f, 23); fast_fill(dh2, 1.f, 24);
+    for (int c = F; c < Fp; ++c) gm[c] = 0;
+    uint16_t *dh1 = dev(h1), *dcw = dev(cw), *dgm = dev(gm), *ddh2 = dev(dh2);
+    Lib* libs[2] = {&A, &Bl};
+    std::vector<uint16_t> r_h2[2], r_gh[2], r_dh1[2]; std::vector<unsigned char> r_bits[2]; std::vector<float> r_stat[2], r_dg[2], r_dc[2]; float us[2][2];
+    for (int li = 0; li < 2; ++li) {
+        Lib& L = *libs[li];
+        apply_env(li ? g_env_b : g_env_a);
+        uint16_t *h2 = dev_zero<uint16_t>((size_t)M * Fp), *gh = dev_zero<uint16_t>((size_t)M * Fp), *du = dev_zero<uint16_t>((size_t)M * 2 * Fp), *g1 = dev_zero<uint16_t>((size_t)M * 2 * Fp);
+        float *stat = dev_zero<float>((size_t)2 * M), *dg = dev_zero<float>(Fp), *dc = dev_zero<float>((size_t)2 * F * 3);
+        unsigned char* bits = dev_zero<unsigned char>((size_t)M * Fp / 8);
+        const long long wsb = L.fws(F, Fp);
+        float* ws = dev_zero<float>((size_t)(wsb + 3) / 4 + 4);
+        auto fwd = [&] { L.ok(L.ffwd(dh1, dcw, dgm, h2, stat, stat + M, M, nseq, F, Fp, 1e-5f, 0.1f, 1234ull, nullptr, bits, gh, 1, nullptr), "ffmid_fwd"); };
+        auto bwd = [&] { L.ok(L.fbwd(ddh2, dh1, dcw, dgm, stat, stat + M, du, g1, dg, dc, ws, M, nseq, F, Fp, 0.1f, 1234ull, nullptr, bits, gh, 1, nullptr), "ffmid_bwd"); };
+        fwd(); bwd(); CK(hipDeviceSynchronize());
+        r_h2[li] = host(h2, (size_t)M * Fp); r_gh[li] = host(gh, (size_t)M * Fp); r_bits[li] = host(bits, (size_t)M * Fp / 8); r_stat[li] = host(stat, (size_t)2 * M);
+        r_dh1[li] = host(g1, (size_t)M * 2 * Fp); r_dg[li] = host(dg, (size_t)Fp); r_dc[li] = host(dc, (size_t)2 * F * 3);
+        us[li][0] = time_us(fwd, 10); us[li][1] = time_us(bwd, 10);
+        CK(hipFree(h2)); CK(hipFree(gh)); CK(hipFree(du)); CK(hipFree(g1)); CK(hipFree(stat)); CK(hipFree(dg)); CK(hipFree(dc)); CK(hipFree(bits)); CK(hipFree(ws));
+    }
+    for (int li = 0; li < 2; ++li) printf("  %c %-48s fwd %8.1f us  bwd %8.1f us\n", li ? 'B' : 'A', libs[li]->path.c_str(), us[li][0], us[li][1]);
+    printf("  differing values: h2 %zu, gh %zu, keep bits %zu, mean/rstd %zu, dh1 %zu (all expected 0)\n", count_diff(r_h2[0], r_h2[1]), count_diff(r_gh[0], r_gh[1]),
+           count_diff(r_bits[0], r_bits[1]), count_diff(r_stat[0], r_stat[1]), count_diff(r_dh1[0], r_dh1[1]));
+    report("dgamma", compare(r_dg[0], r_dg[1]), false);
+    report("dconv", compare(r_dc[0], r_dc[1]), false);
+    CK(hipFree(dh1)); CK(hipFree(dcw)); CK(hipFree(dgm)); CK(hipFree(ddh2));
+}
+
+// LayerNorm forward / backward at the residual-stream shape (M = 35712, D = 1024), bf16 output / bf16 dy as in the training step.
+static void ln_case(Lib& A, Lib& Bl) {
+    const int M = 35712, D = 1024;
+    printf("== layernorm  M=%d D=%d (fp32 x, bf16 y / dy)\n", M, D);
+    std::vector<float> x((size_t)M * D), gam(D), dres((size_t)M * D); std::vector<uint16_t> dy((size_t)M * D);
+    fill_f32(x, 1.f, 31); fill_f32(gam, 1.f, 32); fill_f32(dres, 1.f, 33); fast_fill(dy, 1.f, 34);
+    float *dx_ = dev(x), *dgam = dev(gam), *ddres = dev(dres); uint16_t* ddy = dev(dy);
+    Lib* libs[2] = {&A, &Bl};
+    std::vector<uint16_t> r_y[2], r_xc[2], r_dxc[2]; std::vector<float> r_st[2], r_dx[2], r_dg[2]; float us[2][2];
+    for (int li = 0; li < 2; ++li) {
+        Lib& L = *libs[li];
+        apply_env(li ? g_env_b : g_env_a);
+        uint16_t *y = dev_zero<uint16_t>((size_t)M * D), *xc = dev_zero<uint16_t>((size_t)M * D), *dxc = dev_zero<uint16_t>((size_t)M * D);
+        float *st = dev_zero<float>((size_t)2 * M), *dxo = dev_zero<float>((size_t)M * D), *dg = dev_zero<float>(D);
+        float* ws = dev_zero<float>((size_t)(L.lnws(D) + 3) / 4 + 4);
+        auto fwd = [&] { L.ok(L.lnf(dx_, dgam, y, xc, st, st + M, M, D, D, 1e-5f, 1, nullptr), "ln_fwd"); };
+        auto bwd = [&] { L.ok(L.lnb(ddy, dx_, dgam, st, st + M, ddres, dxo, dxc, dg, ws, M, D, 1.0f, 1, 1, nullptr), "ln_bwd"); };
+        fwd(); bwd(); CK(hipDeviceSynchronize());
+        r_y[li] = host(y, (size_t)M * D); r_xc[li] = host(xc, (size_t)M * D); r_dxc[li] = host(dxc, (size_t)M * D);
+        r_st[li] = host(st, (size_t)2 * M); r_dx[li] = host(dxo, (size_t)M * D); r_dg[li] = host(dg, (size_t)D);
+        us[li][0] = time_us(fwd, 10); us[li][1] = time_us(bwd, 10);
+        CK(hipFree(y)); CK(hipFree(xc)); CK(hipFree(dxc)); CK(hipFree(st)); CK(hipFree(dxo)); CK(hipFree(dg)); CK(hipFree(ws));
+    }
+    for (int li = 0; li < 2; ++li) printf("  %c %-48s fwd %8.1f us  bwd %8.1f us\n", li ? 'B' : 'A', libs[li]->path.c_str(), us[li][0], us[li][1]);
+    printf("  differing values: y %zu, xcast %zu, mean/rstd %zu, dx %zu, dxcast %zu (all expected 0)\n", count_diff(r_y[0], r_y[1]), count_diff(r_xc[0], r_xc[1]),
+           count_diff(r_st[0], r_st[1]), count_diff(r_dx[0], r_dx[1]), count_diff(r_dxc[0], r_dxc[1]));
+    report("dgamma", compare(r_dg[0], r_dg[1]), false);
+    CK(hipFree(dx_)); CK(hipFree(dgam)); CK(hipFree(ddres)); CK(hipFree(ddy));
+}
+
 int main(int argc, char** argv) {
     // usage: lib_ab base.so [NAME=VALUE@]variant.so ... -- case ...      (NAME=VALUE is exported before that library's first call:
     //        the libraries cache their OMLM_* switches per instance, so the same code can be timed under two settings from two copies)
@@ -280,7 +361,7 @@ int main(int argc, char** argv) {
         Lib* L = new Lib; L->load(a.c_str()); if (!env.empty()) L->path = env + "@" + a;
         libs.push_back(L); envs.push_back(env);
     }
-    if (libs.size() < 2 || i >= argc) { fprintf(stderr, "usage: %s base.so [ENV=V@]variant.so ... -- attn|attn_large|gemm|gemm_edge ...\n", argv[0]); return 2; }
+    if (libs.size() < 2 || i >= argc) { fprintf(stderr, "usage: %s base.so [ENV=V@]variant.so ... -- attn|attn_large|gemm|gemm_edge|wgrad|ffmid|ln ...\n", argv[0]); return 2; }
     hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, 0)); printf("device: %s, %d CUs\n", pr.name, pr.multiProcessorCount);
     for (++i; i < argc; ++i)
         for (size_t v = 1; v < libs.size(); ++v) {
@@ -290,6 +371,8 @@ int main(int argc, char** argv) {
             else if (!strcmp(argv[i], "gemm")) gemm_case(*libs[0], *libs[v]);
             else if (!strcmp(argv[i], "gemm_edge")) gemm_edge_case(*libs[0], *libs[v]);
             else if (!strcmp(argv[i], "wgrad")) wgrad_case(*libs[0], *libs[v]);
+            else if (!strcmp(argv[i], "ffmid")) ffmid_case(*libs[0], *libs[v]);
+            else if (!strcmp(argv[i], "ln")) ln_case(*libs[0], *libs[v]);
         }
     return 0;
 }
