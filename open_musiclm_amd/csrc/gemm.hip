@@ -481,6 +481,9 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, 
         u1 = (int)(U * (lg + 1) / bal_wgs);
         if (u >= u1) return;
     }
+#ifndef OMLM_GEMM_W4
+#define OMLM_GEMM_W4 0
+#endif
 #ifndef OMLM_GEMM_ROTATE
 #define OMLM_GEMM_ROTATE 1          /* rotated k-loop (last k16 step multiplied after the next tile's barrier); 0: the round-1/2 loop */
 #endif
@@ -877,9 +880,15 @@ static int gemm_impl(const void* A, const void* B, void* C, const float* Cin,
         return launch_layout<float, float>(g, a_kmajor, b_kmajor, splits, st);
     }
     auto launch = [&](const GemmArgs& ga, int tm_, int tn_, int sp) -> int {
+#if OMLM_GEMM_W4          /* experiment build: the 256x256 tile on FOUR waves of 128x128 (one per SIMD, 512 registers, a third less LDS read traffic) */
+        if (tm_ == 256 && tn_ == 256)
+            return out_dtype == 0 ? launch_tile<256, 256, 128, 128, float>(ga, a_kmajor, b_kmajor, sp, st)
+                                  : launch_tile<256, 256, 128, 128, bf16_t>(ga, a_kmajor, b_kmajor, sp, st);
+#else
         if (tm_ == 256 && tn_ == 256)
             return out_dtype == 0 ? launch_tile<256, 256, 128, 64, float>(ga, a_kmajor, b_kmajor, sp, st)
                                   : launch_tile<256, 256, 128, 64, bf16_t>(ga, a_kmajor, b_kmajor, sp, st);
+#endif
         if (tm_ == 256 && tn_ == 128)
             return out_dtype == 0 ? launch_tile<256, 128, 64, 64, float>(ga, a_kmajor, b_kmajor, sp, st)
                                   : launch_tile<256, 128, 64, 64, bf16_t>(ga, a_kmajor, b_kmajor, sp, st);

@@ -17,6 +17,10 @@ build)
     hipcc --offload-arch=gfx950 -shared -fPIC $(rest "attention attention2") /tmp/attention_old.o /tmp/attention2_old.o -o "$ROOT/.variants/libomlm_attn_old.so"
     hipcc $FL -DOMLM_GEMM_ROTATE=0 -c $CS/gemm.hip -o /tmp/gemm_old.o
     hipcc --offload-arch=gfx950 -shared -fPIC $(rest gemm) /tmp/gemm_old.o -o "$ROOT/.variants/libomlm_gemm_old.so"
+    # experiment: the 256x256 tile on four waves of 128x128 (one per SIMD; ~2 min to compile) -- rejected in round 1, before the
+    # DMA-wait fix and the rotated loop; tools/lib_ab makes the re-test a few seconds
+    hipcc $FL -DOMLM_GEMM_W4=1 -c $CS/gemm.hip -o /tmp/gemm_w4.o
+    hipcc --offload-arch=gfx950 -shared -fPIC $(rest gemm) /tmp/gemm_w4.o -o "$ROOT/.variants/libomlm_gemm_w4.so"
     hipcc -O2 "$ROOT/tools/lib_ab.cpp" -o "$ROOT/tools/lib_ab" -ldl
     echo "built .variants/libomlm_attn_old.so, .variants/libomlm_gemm_old.so, tools/lib_ab"
     ;;
@@ -24,7 +28,8 @@ run)
     cd "$ROOT"; out=gpurun_out/r3c1; mkdir -p $out
     timeout 60 tools/lib_ab .variants/libomlm_attn_old.so open_musiclm_amd/libomlm_hip.so -- attn attn_large > $out/lib_ab_attn.log 2>&1 || true
     timeout 60 tools/lib_ab .variants/libomlm_gemm_old.so open_musiclm_amd/libomlm_hip.so -- gemm_edge gemm wgrad > $out/lib_ab_gemm.log 2>&1 || true
-    cat $out/lib_ab_attn.log $out/lib_ab_gemm.log
+    timeout 60 tools/lib_ab open_musiclm_amd/libomlm_hip.so .variants/libomlm_gemm_w4.so -- gemm_edge gemm > $out/lib_ab_w4.log 2>&1 || true
+    cat $out/lib_ab_attn.log $out/lib_ab_gemm.log $out/lib_ab_w4.log
     timeout 600 python -m pytest tests -q -x -m gpu > $out/pytest.log 2>&1 || true
     tail -3 $out/pytest.log
     timeout 300 python bench.py > $out/bench.log 2> $out/bench.err || true
