@@ -172,6 +172,15 @@ __device__ __forceinline__ void pack_acc(const f32x16& p, int s, bf16x8& hi, bf1
 #ifndef AT_DQ_BATCH
 #define AT_DQ_BATCH 1
 #endif
+#ifndef AT_DQ_WPE
+#define AT_DQ_WPE 2        /* waves per SIMD the backward kernels are compiled for (2 = 256 registers; 1 = 512: experiment builds) */
+#endif
+#ifndef AT_DQP_WPE
+#define AT_DQP_WPE 2
+#endif
+#ifndef AT_DKV_WPE
+#define AT_DKV_WPE 2
+#endif
 #ifndef AT_DBIAS_CARRY
 #define AT_DBIAS_CARRY 0   /* bf16 dQ kernel: d(bias) bins finalised in registers and stored once (no per-block LDS read-modify-write); unmeasured, off */
 #endif
@@ -336,7 +345,7 @@ __global__ __launch_bounds__(AT_THREADS) AT_FWD_OCC void attn_fwd_kernel(const T
 // backward, kernel B: dQ, d(bias table), delta_i = sum_d dO[i,d] O[i,d]     (same geometry as the forward)
 // =============================================================================================================
 template <typename T>
-__global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k,
+__global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(AT_DQ_WPE))) void attn_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                                  const T* __restrict__ v, const float* __restrict__ bias,
                                                                  const unsigned char* __restrict__ keymask,
                                                                  const T* __restrict__ out, const T* __restrict__ dout,
@@ -570,7 +579,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
 // The same kernel for fp32 ("bf16x3") operands with hi/lo S and dP, kept as its own function so that the bf16 kernel's code and
 // register allocation (already at the 256-register limit) stay exactly as measured.
 template <typename T>
-__global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dq_precise_kernel(const T* __restrict__ q, const T* __restrict__ k,
+__global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(AT_DQP_WPE))) void attn_bwd_dq_precise_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                                  const T* __restrict__ v, const float* __restrict__ bias,
                                                                  const unsigned char* __restrict__ keymask,
                                                                  const T* __restrict__ out, const T* __restrict__ dout,
@@ -765,7 +774,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
 // work items and reduce their partial dK^T / dV^T through LDS at the end -- no atomics on dK / dV.
 // =============================================================================================================
 template <typename T>
-__global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k,
+__global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(AT_DKV_WPE))) void attn_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                                   const T* __restrict__ v, const float* __restrict__ bias,
                                                                   const unsigned char* __restrict__ keymask,
                                                                   const T* __restrict__ dout, const float* __restrict__ lse,

@@ -100,8 +100,15 @@ static void report(const char* what, const Cmp& c, bool exact_expected) {
            c.finite ? "" : "  NON-FINITE", exact_expected ? (c.diff ? "  <-- EXPECTED IDENTICAL" : "  identical") : "");
 }
 
-static void attn_case(Lib& A, Lib& Bl, int B, int N, int H) {
-    printf("== attention backward  B=%d N=%d H=%d (bf16 operands)\n", B, N, H);
+static float bf16_to_f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+static void* dev_as(const std::vector<uint16_t>& h, int dtype) {      // dtype 1: the bf16 words; 0: the same values as fp32 ("bf16x3" operands)
+    if (dtype == 1) return dev(h);
+    std::vector<float> f(h.size()); for (size_t i = 0; i < h.size(); ++i) f[i] = bf16_to_f(h[i]);
+    return dev(f);
+}
+
+static void attn_case(Lib& A, Lib& Bl, int B, int N, int H, int dtype = 1) {
+    printf("== attention backward  B=%d N=%d H=%d (%s operands)\n", B, N, H, dtype ? "bf16" : "fp32 / bf16x3");
     const size_t M = (size_t)B * N; const int ld = (H + 7) / 8 * 8; const float scale = 8.0f;
     std::mt19937 g(1234); std::normal_distribution<float> nd(0.f, 1.f); std::uniform_real_distribution<float> ud(0.f, 1.f);
     std::vector<uint16_t> q(M * H * 64), k(M * 64), v(M * 64), dout(M * H * 64);
@@ -114,9 +121,9 @@ static void attn_case(Lib& A, Lib& Bl, int B, int N, int H) {
     for (int r = 0; r < N; ++r) for (int h = 0; h < H; ++h) bias[(size_t)r * ld + h] = 0.1f * nd(g);
     std::vector<unsigned char> mask(M);
     for (size_t i = 0; i < M; ++i) mask[i] = (i % N == 0) ? 1 : (ud(g) > 0.15f);
-    uint16_t *dq_ = dev(q), *dk_ = dev(k), *dv_ = dev(v), *ddo = dev(dout);
+    void *dq_ = dev_as(q, dtype), *dk_ = dev_as(k, dtype), *dv_ = dev_as(v, dtype), *ddo = dev_as(dout, dtype);
     float* dbias_in = dev(bias); unsigned char* dmask = dev(mask);
-    uint16_t* out = dev_zero<uint16_t>(M * H * 64);
+    void* out = dev_zero<unsigned char>(M * H * 64 * (dtype ? 2 : 4));
     float* lse = dev_zero<float>((size_t)B * H * N); float* delta = dev_zero<float>((size_t)B * H * N);
     std::vector<float> res[2][4]; float us[2]; float fwd_us[2]; float us_nb[2];
     Lib* libs[2] = {&A, &Bl};
@@ -126,16 +133,16 @@ static void attn_case(Lib& A, Lib& Bl, int B, int N, int H) {
         const long long tf = L.tbl(N, H);
         float* biasT = dev_zero<float>((size_t)tf);
         L.ok(L.prep(dbias_in, biasT, N, H, ld, nullptr, nullptr, 1.0f, scale, nullptr), "bias_prepare");
-        L.ok(L.fwd(dq_, dk_, dv_, dbias_in, biasT, dmask, out, lse, B, N, H, scale, ld, 1, nullptr), "attn_fwd");
+        L.ok(L.fwd(dq_, dk_, dv_, dbias_in, biasT, dmask, out, lse, B, N, H, scale, ld, dtype, nullptr), "attn_fwd");
         CK(hipDeviceSynchronize());
         float *gq = dev_zero<float>(M * H * 64), *gk = dev_zero<float>(M * 64), *gv = dev_zero<float>(M * 64), *gb = dev_zero<float>((size_t)N * ld);
-        L.ok(L.bwd(dq_, dk_, dv_, dbias_in, biasT, dmask, out, ddo, lse, delta, gq, gk, gv, gb, B, N, H, scale, ld, 1, nullptr), "attn_bwd");
+        L.ok(L.bwd(dq_, dk_, dv_, dbias_in, biasT, dmask, out, ddo, lse, delta, gq, gk, gv, gb, B, N, H, scale, ld, dtype, nullptr), "attn_bwd");
         CK(hipDeviceSynchronize());
         res[li][0] = host(gq, M * H * 64); res[li][1] = host(gk, M * 64); res[li][2] = host(gv, M * 64); res[li][3] = host(gb, (size_t)N * ld);
         float* scratch_b = dev_zero<float>((size_t)N * ld);
-        us[li] = time_us([&] { L.bwd(dq_, dk_, dv_, dbias_in, biasT, dmask, out, ddo, lse, delta, gq, gk, gv, scratch_b, B, N, H, scale, ld, 1, nullptr); }, 10);
-        us_nb[li] = time_us([&] { L.bwd(dq_, dk_, dv_, dbias_in, biasT, dmask, out, ddo, lse, delta, gq, gk, gv, nullptr, B, N, H, scale, ld, 1, nullptr); }, 10);
-        fwd_us[li] = time_us([&] { L.fwd(dq_, dk_, dv_, dbias_in, biasT, dmask, out, lse, B, N, H, scale, ld, 1, nullptr); }, 10);
+        us[li] = time_us([&] { L.bwd(dq_, dk_, dv_, dbias_in, biasT, dmask, out, ddo, lse, delta, gq, gk, gv, scratch_b, B, N, H, scale, ld, dtype, nullptr); }, 10);
+        us_nb[li] = time_us([&] { L.bwd(dq_, dk_, dv_, dbias_in, biasT, dmask, out, ddo, lse, delta, gq, gk, gv, nullptr, B, N, H, scale, ld, dtype, nullptr); }, 10);
+        fwd_us[li] = time_us([&] { L.fwd(dq_, dk_, dv_, dbias_in, biasT, dmask, out, lse, B, N, H, scale, ld, dtype, nullptr); }, 10);
         CK(hipFree(gq)); CK(hipFree(gk)); CK(hipFree(gv)); CK(hipFree(gb)); CK(hipFree(scratch_b)); CK(hipFree(biasT));
     }
     const double flops = 4.0 * H * 64 * (double)N * (N + 1) / 2 * B;
@@ -361,13 +368,14 @@ int main(int argc, char** argv) {
         Lib* L = new Lib; L->load(a.c_str()); if (!env.empty()) L->path = env + "@" + a;
         libs.push_back(L); envs.push_back(env);
     }
-    if (libs.size() < 2 || i >= argc) { fprintf(stderr, "usage: %s base.so [ENV=V@]variant.so ... -- attn|attn_large|gemm|gemm_edge|wgrad|ffmid|ln ...\n", argv[0]); return 2; }
+    if (libs.size() < 2 || i >= argc) { fprintf(stderr, "usage: %s base.so [ENV=V@]variant.so ... -- attn|attn_large|attn32|gemm|gemm_edge|wgrad|ffmid|ln ...\n", argv[0]); return 2; }
     hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, 0)); printf("device: %s, %d CUs\n", pr.name, pr.multiProcessorCount);
     for (++i; i < argc; ++i)
         for (size_t v = 1; v < libs.size(); ++v) {
             g_env_a = envs[0]; g_env_b = envs[v];
             if (!strcmp(argv[i], "attn")) attn_case(*libs[0], *libs[v], 32, 1116, 8);
             else if (!strcmp(argv[i], "attn_large")) attn_case(*libs[0], *libs[v], 8, 1817, 16);
+            else if (!strcmp(argv[i], "attn32")) attn_case(*libs[0], *libs[v], 32, 1116, 8, 0);
             else if (!strcmp(argv[i], "gemm")) gemm_case(*libs[0], *libs[v]);
             else if (!strcmp(argv[i], "gemm_edge")) gemm_edge_case(*libs[0], *libs[v]);
             else if (!strcmp(argv[i], "wgrad")) wgrad_case(*libs[0], *libs[v]);
