@@ -5,6 +5,7 @@
 //   build (here):  hipcc -O2 tools/lib_ab.cpp -o tools/lib_ab -ldl
 //   run (GPU box): tools/lib_ab base.so [ENV=V@]variant.so ... -- attn attn_large gemm gemm_edge wgrad ffmid ln
 #include <hip/hip_runtime.h>
+#include "../include/omlm.h"        // struct layouts only (omlm_decode_args); every call goes through dlsym
 #include <dlfcn.h>
 #include <cmath>
 #include <cstdint>
@@ -35,11 +36,12 @@ typedef int (*fbwd_t)(const void*, const void*, const void*, const void*, const 
 typedef int (*lnf_t)(const float*, const float*, void*, void*, float*, float*, int, int, int, float, int, void*);
 typedef long long (*lnws_t)(int);
 typedef int (*lnb_t)(const void*, const float*, const float*, const float*, const float*, const float*, float*, void*, float*, float*, int, int, float, int, int, void*);
+typedef int (*dstep_t)(const omlm_decode_args*, const long long*, void*);
 typedef int (*planes_t)(const void*, long long, const void*, long long, void*, const float*, const int*, const int*, const int*, long long, long long,
                         int, int, int, int, int, int, int, int, int, int, float, void*);
 
 struct Lib {
-    std::string path; void* h; fwd_t fwd; bwd_t bwd; prep_t prep; tbl_t tbl; gemm_t gemm; err_t err; wgrad_t wgrad; planes_t planes; ffwd_t ffwd; fws_t fws; fbwd_t fbwd; lnf_t lnf; lnws_t lnws; lnb_t lnb;
+    std::string path; void* h; fwd_t fwd; bwd_t bwd; prep_t prep; tbl_t tbl; gemm_t gemm; err_t err; wgrad_t wgrad; planes_t planes; ffwd_t ffwd; fws_t fws; fbwd_t fbwd; lnf_t lnf; lnws_t lnws; lnb_t lnb; dstep_t dstep;
     void load(const char* p) {
         path = p;
         h = dlopen(p, RTLD_NOW | RTLD_LOCAL);
@@ -48,7 +50,7 @@ struct Lib {
         prep = (prep_t)dlsym(h, "omlm_attn_bias_prepare"); tbl = (tbl_t)dlsym(h, "omlm_attn_bias_table_floats");
         gemm = (gemm_t)dlsym(h, "omlm_gemm"); err = (err_t)dlsym(h, "omlm_last_error"); wgrad = (wgrad_t)dlsym(h, "omlm_gemm_wgrad_group"); planes = (planes_t)dlsym(h, "omlm_gemm_planes");
         ffwd = (ffwd_t)dlsym(h, "omlm_ffmid_fwd"); fws = (fws_t)dlsym(h, "omlm_ffmid_bwd_workspace_bytes"); fbwd = (fbwd_t)dlsym(h, "omlm_ffmid_bwd");
-        lnf = (lnf_t)dlsym(h, "omlm_layernorm_fwd"); lnws = (lnws_t)dlsym(h, "omlm_layernorm_bwd_workspace_bytes"); lnb = (lnb_t)dlsym(h, "omlm_layernorm_bwd");
+        lnf = (lnf_t)dlsym(h, "omlm_layernorm_fwd"); lnws = (lnws_t)dlsym(h, "omlm_layernorm_bwd_workspace_bytes"); lnb = (lnb_t)dlsym(h, "omlm_layernorm_bwd"); dstep = (dstep_t)dlsym(h, "omlm_decode_step");
         if (!fwd || !bwd || !prep || !tbl || !gemm || !err) { fprintf(stderr, "%s: missing symbol\n", p); exit(1); }
     }
     void ok(int rc, const char* what) { if (rc != 0) { fprintf(stderr, "%s: %s failed (%d): %s\n", path.c_str(), what, rc, err()); exit(1); } }
@@ -357,6 +359,58 @@ static void ln_case(Lib& A, Lib& Bl) {
     CK(hipFree(dx_)); CK(hipFree(dgam)); CK(hipFree(ddres)); CK(hipFree(ddy));
 }
 
+// One KV-cached decode step (coarse-small trunk: 6 layers, D = 1024, H = 8, F = 2730; bf16 weights) at row `pos` of an Nmax-row
+// cache, repeated without advancing the row: us per id as the sampling loop sees it (32 launches), logits compared bit for bit.
+static void decode_case(Lib& A, Lib& Bl, int B) {
+    const int L = 6, D = 1024, H = 8, F = 2730, Fp = 2736, Nmax = 1116, pos = 600, V1 = 1025, ldV = 1032, HD = H * 64;
+    printf("== decode step  B=%d  (row %d of %d, bf16 weights)\n", B, pos, Nmax);
+    std::vector<const void*> Wq(L), Wkv(L), Wo(L), W1(L), W2(L);
+    std::vector<const float*> ag(L), qs(L), ks(L), fg(L), cw(L), mg(L);
+    std::vector<float*> Kc(L), Vc(L), hist(L);
+    auto wdev = [&](size_t n, float sc, uint64_t seed) { std::vector<uint16_t> h(n); fast_fill(h, sc, seed); return (const void*)dev(h); };
+    auto fdev = [&](size_t n, float sc, uint64_t seed, float add) { std::vector<float> h(n); fill_f32(h, sc, seed); for (auto& x : h) x += add; return dev(h); };
+    for (int l = 0; l < L; ++l) {
+        Wq[l] = wdev((size_t)HD * D, 0.03f, 100 + l); Wkv[l] = wdev((size_t)128 * D, 0.03f, 110 + l); Wo[l] = wdev((size_t)D * HD, 0.03f, 120 + l);
+        W1[l] = wdev((size_t)2 * Fp * D, 0.03f, 130 + l); W2[l] = wdev((size_t)D * Fp, 0.02f, 140 + l);
+        ag[l] = fdev(D, 0.05f, 150 + l, 1.f); qs[l] = fdev(64, 0.05f, 160 + l, 1.f); ks[l] = fdev(64, 0.05f, 170 + l, 1.f); fg[l] = fdev(D, 0.05f, 180 + l, 1.f);
+        cw[l] = fdev((size_t)3 * 2 * Fp, 0.3f, 190 + l, 0.f);
+        { std::vector<float> g(Fp); fill_f32(g, 0.05f, 200 + l); for (int c = 0; c < Fp; ++c) g[c] = c < F ? g[c] + 1.f : 0.f; mg[l] = dev(g); }
+        Kc[l] = fdev((size_t)B * Nmax * 64, 0.1f, 210 + l, 0.f); Vc[l] = fdev((size_t)B * Nmax * 64, 1.f, 220 + l, 0.f); hist[l] = fdev((size_t)B * 2 * 2 * Fp, 1.f, 230 + l, 0.f);
+    }
+    // (the per-layer pointer arrays of omlm_decode_args are HOST arrays of device pointers)
+    float* table = fdev((size_t)Nmax * 8, 0.1f, 300, 0.f);
+    float* fgam = fdev(D, 0.05f, 301, 1.f);
+    const void* headW = wdev((size_t)ldV * D, 0.03f, 302);
+    float* emb = fdev((size_t)(1024 * 3 + 1) * D, 0.5f, 303, 0.f);
+    std::vector<long long> ids(B); for (int b = 0; b < B; ++b) ids[b] = 17 + 31 * b;
+    long long* dids = dev(ids);
+    std::vector<int> p1(1, pos); int* dpos = dev(p1);
+    const int nsplit = (Nmax + 63) / 64;
+    Lib* libs[2] = {&A, &Bl};
+    std::vector<float> res[2]; float us[2];
+    for (int li = 0; li < 2; ++li) {
+        apply_env(li ? g_env_b : g_env_a);
+        omlm_decode_args a; memset(&a, 0, sizeof(a));
+        a.B = B; a.D = D; a.H = H; a.L = L; a.F = F; a.Fp = Fp; a.Nmax = Nmax; a.w_dtype = 1; a.round_bf16 = 1; a.nsplit = nsplit;
+        a.eps = 1e-5f; a.scale = 8.0f; a.pos_dev = dpos;
+        a.Wq = Wq.data(); a.Wkv = Wkv.data(); a.Wo = Wo.data(); a.W1p = W1.data(); a.W2p = W2.data();
+        a.attn_gamma = ag.data(); a.q_scale = qs.data(); a.k_scale = ks.data(); a.ffin_gamma = fg.data(); a.convw = cw.data(); a.mid_gamma = mg.data();
+        a.Kc = Kc.data(); a.Vc = Vc.data(); a.hist = hist.data();
+        a.bias_table = table; a.bias_ld = 8; a.final_gamma = fgam; a.head_W = headW; a.V1 = V1; a.ldV = ldV;
+        a.emb_table = emb; a.emb_row_offset = 1024; a.emb_rows = 1024 * 3 + 1;
+        a.x = dev_zero<float>((size_t)B * D); a.x1 = dev_zero<float>((size_t)B * D); a.q = dev_zero<float>((size_t)B * HD);
+        a.parts = dev_zero<float>((size_t)B * nsplit * H * 66); a.u = dev_zero<float>((size_t)B * Fp); a.logits = dev_zero<float>((size_t)B * ldV);
+        a.advance_pos = nullptr; a.advance_step = nullptr;
+        auto step = [&] { libs[li]->ok(libs[li]->dstep(&a, dids, nullptr), "decode_step"); };
+        step(); CK(hipDeviceSynchronize());
+        res[li] = host(a.logits, (size_t)B * ldV);
+        us[li] = time_us(step, 50);
+        CK(hipFree(a.x)); CK(hipFree(a.x1)); CK(hipFree(a.q)); CK(hipFree(a.parts)); CK(hipFree(a.u)); CK(hipFree(a.logits));
+    }
+    for (int li = 0; li < 2; ++li) printf("  %c %-48s %8.1f us per step  (%6.0f ids/s)\n", li ? 'B' : 'A', libs[li]->path.c_str(), us[li], B * 1e6 / us[li]);
+    report("logits", compare(res[0], res[1]), true);
+}
+
 int main(int argc, char** argv) {
     // usage: lib_ab base.so [NAME=VALUE@]variant.so ... -- case ...      (NAME=VALUE is exported before that library's first call:
     //        the libraries cache their OMLM_* switches per instance, so the same code can be timed under two settings from two copies)
@@ -368,7 +422,7 @@ int main(int argc, char** argv) {
         Lib* L = new Lib; L->load(a.c_str()); if (!env.empty()) L->path = env + "@" + a;
         libs.push_back(L); envs.push_back(env);
     }
-    if (libs.size() < 2 || i >= argc) { fprintf(stderr, "usage: %s base.so [ENV=V@]variant.so ... -- attn|attn_large|attn32|gemm|gemm_edge|wgrad|ffmid|ln ...\n", argv[0]); return 2; }
+    if (libs.size() < 2 || i >= argc) { fprintf(stderr, "usage: %s base.so [ENV=V@]variant.so ... -- attn|attn_large|attn32|gemm|gemm_edge|wgrad|ffmid|ln|decode ...\n", argv[0]); return 2; }
     hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, 0)); printf("device: %s, %d CUs\n", pr.name, pr.multiProcessorCount);
     for (++i; i < argc; ++i)
         for (size_t v = 1; v < libs.size(); ++v) {
@@ -381,6 +435,7 @@ int main(int argc, char** argv) {
             else if (!strcmp(argv[i], "wgrad")) wgrad_case(*libs[0], *libs[v]);
             else if (!strcmp(argv[i], "ffmid")) ffmid_case(*libs[0], *libs[v]);
             else if (!strcmp(argv[i], "ln")) ln_case(*libs[0], *libs[v]);
+            else if (!strcmp(argv[i], "decode")) { decode_case(*libs[0], *libs[v], 1); decode_case(*libs[0], *libs[v], 8); }
         }
     return 0;
 }

@@ -26,7 +26,7 @@ build)
     ;;
 run)
     cd "$ROOT"; out=gpurun_out/r3c1; mkdir -p $out
-    timeout 60 tools/lib_ab .variants/libomlm_attn_old.so open_musiclm_amd/libomlm_hip.so -- attn attn_large > $out/lib_ab_attn.log 2>&1 || true
+    timeout 60 tools/lib_ab .variants/libomlm_attn_old.so open_musiclm_amd/libomlm_hip.so -- attn attn_large attn32 ffmid ln decode > $out/lib_ab_attn.log 2>&1 || true
     timeout 60 tools/lib_ab .variants/libomlm_gemm_old.so open_musiclm_amd/libomlm_hip.so -- gemm_edge gemm wgrad > $out/lib_ab_gemm.log 2>&1 || true
     timeout 60 tools/lib_ab open_musiclm_amd/libomlm_hip.so .variants/libomlm_gemm_w4.so -- gemm_edge gemm > $out/lib_ab_w4.log 2>&1 || true
     cat $out/lib_ab_attn.log $out/lib_ab_gemm.log $out/lib_ab_w4.log
