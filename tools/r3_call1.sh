@@ -30,6 +30,10 @@ run)
     timeout 60 tools/lib_ab .variants/libomlm_gemm_old.so open_musiclm_amd/libomlm_hip.so -- gemm_edge gemm wgrad > $out/lib_ab_gemm.log 2>&1 || true
     timeout 60 tools/lib_ab open_musiclm_amd/libomlm_hip.so .variants/libomlm_gemm_w4.so -- gemm_edge gemm > $out/lib_ab_w4.log 2>&1 || true
     cat $out/lib_ab_attn.log $out/lib_ab_gemm.log $out/lib_ab_w4.log
+    # SQ / LDS counters of the attention backward kernels through the torch-free harness (4 short passes): where the ~7 k cycles per
+    # 32x32 block per wave go now (waits, LDS bank conflicts, VALU / MFMA busy)
+    timeout 200 tools/pmc_kernel.sh attn_bwd tools/lib_ab open_musiclm_amd/libomlm_hip.so .variants/libomlm_attn_old.so -- attn > $out/pmc_attn_bwd.log 2>&1 || true
+    tail -60 $out/pmc_attn_bwd.log
     timeout 600 python -m pytest tests -q -x -m gpu > $out/pytest.log 2>&1 || true
     tail -3 $out/pytest.log
     timeout 300 python bench.py > $out/bench.log 2> $out/bench.err || true
