@@ -302,10 +302,22 @@ __device__ __forceinline__ dma_rsrc make_dma_rsrc(const void* p, unsigned long l
     r[0] = (unsigned)a; r[1] = (unsigned)(a >> 32) & 0xFFFFu; r[2] = bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)bytes; r[3] = 0x00020000u;
     return r;
 }
+#ifndef OMLM_DMA_LEAN
+#define OMLM_DMA_LEAN 0      /* experiment builds: 1 = one wait state after the M0 write instead of five; 2 = also no save / restore of M0 */
+#endif
 __device__ __forceinline__ void dma_issue(dma_rsrc rs, unsigned lds_dst, unsigned off) {
+#if OMLM_DMA_LEAN == 2
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds"
+                 :: "v"(off), "s"(lds_dst), "s"(rs) : "memory", "m0");
+#elif OMLM_DMA_LEAN == 1
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(off), "s"(lds_dst), "s"(rs) : "memory");
+#else
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(off), "s"(lds_dst), "s"(rs) : "memory");
+#endif
 }
 
 template <bool KMAJ, int ROWS, int NWAVES>
