@@ -22,7 +22,9 @@ build)
     hipcc $FL -DOMLM_GEMM_W4=1 -c $CS/gemm.hip -o /tmp/gemm_w4.o &
     # lean LDS-DMA issue: 1 = one wait state after the M0 write instead of five, 2 = also without saving / restoring M0
     for v in 1 2; do ( hipcc $FL -DOMLM_DMA_LEAN=$v -c $CS/gemm.hip -o /tmp/gemm_lean$v.o ) & done
+    ( hipcc $FL -DOMLM_DMA_SPREAD_ROT=1 -c $CS/gemm.hip -o /tmp/gemm_sp1.o ) &      # next tile's DMA all inside the deferred step (earliest possible)
     wait
+    hipcc --offload-arch=gfx950 -shared -fPIC $(rest gemm) /tmp/gemm_sp1.o -o "$ROOT/.variants/libomlm_gemm_sp1.so"
     hipcc --offload-arch=gfx950 -shared -fPIC $(rest gemm) /tmp/gemm_w4.o -o "$ROOT/.variants/libomlm_gemm_w4.so"
     for v in 1 2; do hipcc --offload-arch=gfx950 -shared -fPIC $(rest gemm) /tmp/gemm_lean$v.o -o "$ROOT/.variants/libomlm_gemm_lean$v.so"; done
     hipcc -O2 "$ROOT/tools/lib_ab.cpp" -o "$ROOT/tools/lib_ab" -ldl
@@ -32,7 +34,7 @@ run)
     cd "$ROOT"; out=gpurun_out/r3c1; mkdir -p $out
     timeout 60 tools/lib_ab .variants/libomlm_attn_old.so open_musiclm_amd/libomlm_hip.so -- attn attn_large attn32 ffmid ln decode > $out/lib_ab_attn.log 2>&1 || true
     timeout 60 tools/lib_ab .variants/libomlm_gemm_old.so open_musiclm_amd/libomlm_hip.so -- gemm_edge gemm wgrad > $out/lib_ab_gemm.log 2>&1 || true
-    timeout 90 tools/lib_ab open_musiclm_amd/libomlm_hip.so .variants/libomlm_gemm_w4.so .variants/libomlm_gemm_lean1.so .variants/libomlm_gemm_lean2.so -- gemm_edge gemm wgrad > $out/lib_ab_w4.log 2>&1 || true
+    timeout 90 tools/lib_ab open_musiclm_amd/libomlm_hip.so .variants/libomlm_gemm_w4.so .variants/libomlm_gemm_lean1.so .variants/libomlm_gemm_lean2.so .variants/libomlm_gemm_sp1.so -- gemm_edge gemm wgrad > $out/lib_ab_w4.log 2>&1 || true
     cat $out/lib_ab_attn.log $out/lib_ab_gemm.log $out/lib_ab_w4.log
     # SQ / LDS counters of the attention backward kernels through the torch-free harness (4 short passes): where the ~7 k cycles per
     # 32x32 block per wave go now (waits, LDS bank conflicts, VALU / MFMA busy)
