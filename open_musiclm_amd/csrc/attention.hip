@@ -181,6 +181,9 @@ __device__ __forceinline__ void pack_acc(const f32x16& p, int s, bf16x8& hi, bf1
 #ifndef AT_DKV_WPE
 #define AT_DKV_WPE 2
 #endif
+#ifndef AT_DQ_LATE_SCALE
+#define AT_DQ_LATE_SCALE 0
+#endif
 #ifndef AT_DBIAS_CARRY
 #define AT_DBIAS_CARRY 0   /* bf16 dQ kernel: d(bias) bins finalised in registers and stored once (no per-block LDS read-modify-write); unmeasured, off */
 #endif
@@ -462,7 +465,9 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(AT_D
             auto element = [&](int r, bool ok) {
                 const float p = __builtin_amdgcn_exp2f(ok ? st[r] * c + bv[r] - L : NEG_BIG);
                 bv[r] = p * (dp[r] - dl);
+#if !AT_DQ_LATE_SCALE
                 st[r] = bv[r] * scale;
+#endif
             };
             if (jb + 31 <= i0) {
                 // subtile entirely below the diagonal (see the forward): constant LDS offsets from one base, one 32-bit mask word
@@ -521,6 +526,11 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(AT_D
                 if (AT_ABLATE & 4) acc[0][0] += dsum * 1e-30f;
 #endif
             }
+#if AT_DQ_LATE_SCALE && AT_LEAN
+            // dS * scale formed only now: during the diagonal sums above only bv (unscaled dS) is live, not bv and st
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { asm volatile("" : "+v"(bv[r])); st[r] = bv[r] * scale; }
+#endif
 #if AT_DQ_BATCH
             {   // the four K^T fragments requested together, the packing of dS under their latency, retired pair by pair
                 bf16x8 ktf[2][2], dsb[2];

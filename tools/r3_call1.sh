@@ -15,6 +15,11 @@ build)
     rest() { o=""; for f in gemm attention attention2 norm ffmid ffmid2 embed_ce optim_misc decode vq_fit err; do case " $1 " in *" $f "*) ;; *) o="$o $CS/$f.o";; esac; done; echo $o; }
     for f in attention attention2; do hipcc $FL -DAT_DKV_FENCE=0 -DAT_DQ_BATCH=0 -DA2_DQ_BATCH=0 -c $CS/$f.hip -o /tmp/${f}_old.o; done
     hipcc --offload-arch=gfx950 -shared -fPIC $(rest "attention attention2") /tmp/attention_old.o /tmp/attention2_old.o -o "$ROOT/.variants/libomlm_attn_old.so"
+    # dQ kernel register diet: dS * scale formed after the diagonal sums (scratch 84 -> 40 B, same arithmetic); and at one wave per SIMD
+    hipcc $FL -DAT_DQ_LATE_SCALE=1 -c $CS/attention.hip -o /tmp/attention_ls.o
+    hipcc --offload-arch=gfx950 -shared -fPIC $(rest attention) /tmp/attention_ls.o -o "$ROOT/.variants/libomlm_attn_ls.so"
+    hipcc $FL -DAT_DQ_WPE=1 -DAT_DKV_WPE=1 -c $CS/attention.hip -o /tmp/attention_w1.o
+    hipcc --offload-arch=gfx950 -shared -fPIC $(rest attention) /tmp/attention_w1.o -o "$ROOT/.variants/libomlm_attn_w1.so"
     hipcc $FL -DOMLM_GEMM_ROTATE=0 -c $CS/gemm.hip -o /tmp/gemm_old.o
     hipcc --offload-arch=gfx950 -shared -fPIC $(rest gemm) /tmp/gemm_old.o -o "$ROOT/.variants/libomlm_gemm_old.so"
     # experiment: the 256x256 tile on four waves of 128x128 (one per SIMD; ~2 min to compile) -- rejected in round 1, before the
@@ -34,6 +39,8 @@ run)
     cd "$ROOT"; out=gpurun_out/r3c1; mkdir -p $out
     timeout 60 tools/lib_ab .variants/libomlm_attn_old.so open_musiclm_amd/libomlm_hip.so -- attn attn_large attn32 ffmid ln decode > $out/lib_ab_attn.log 2>&1 || true
     timeout 60 tools/lib_ab .variants/libomlm_gemm_old.so open_musiclm_amd/libomlm_hip.so -- gemm_edge gemm wgrad > $out/lib_ab_gemm.log 2>&1 || true
+    timeout 60 tools/lib_ab open_musiclm_amd/libomlm_hip.so .variants/libomlm_attn_ls.so .variants/libomlm_attn_w1.so -- attn > $out/lib_ab_attn_regs.log 2>&1 || true
+    cat $out/lib_ab_attn_regs.log
     timeout 90 tools/lib_ab open_musiclm_amd/libomlm_hip.so .variants/libomlm_gemm_w4.so .variants/libomlm_gemm_lean1.so .variants/libomlm_gemm_lean2.so .variants/libomlm_gemm_sp1.so -- gemm_edge gemm wgrad > $out/lib_ab_w4.log 2>&1 || true
     cat $out/lib_ab_attn.log $out/lib_ab_gemm.log $out/lib_ab_w4.log
     # SQ / LDS counters of the attention backward kernels through the torch-free harness (4 short passes): where the ~7 k cycles per
