@@ -584,7 +584,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, 
                 const int cur = (kt - kt0) & 1;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();      // tile kt landed everywhere; every wave's reads of the other stage (incl. its last step) are complete
-                const bool live = kt + 1 < kt1;
+                const bool live = kt + 1 < kt1 && !(dbg & 1);        // dbg (DBG instantiation only): bit 0 = no DMA after the first tile, bit 1 = no MFMAs
                 char* nxt = smem + (cur ^ 1) * STAGE;
                 unsigned pan, pbn;
                 const int knext = tile_at(kt + 1, pan, pbn);
@@ -596,7 +596,8 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, 
                     for (int i = 0; i < MI; ++i)
 #pragma unroll
                         for (int j = 0; j < NJ; ++j) {
-                            if (mul) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[fi][i], b[fi][j], acc[i][j], 0, 0, 0);
+                            if (mul && !(dbg & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[fi][i], b[fi][j], acc[i][j], 0, 0, 0);
+                            else if (mul) asm volatile("" :: "v"(a[fi][i]), "v"(b[fi][j]));
                             const int midx = ph * MPS + i * NJ + j;
                             if (midx % STRIDE == 0 && midx / STRIDE < NLOAD) {
                                 const int l = midx / STRIDE;

@@ -41,6 +41,11 @@ run)
     timeout 60 tools/lib_ab .variants/libomlm_gemm_old.so open_musiclm_amd/libomlm_hip.so -- gemm_edge gemm wgrad > $out/lib_ab_gemm.log 2>&1 || true
     timeout 60 tools/lib_ab open_musiclm_amd/libomlm_hip.so .variants/libomlm_attn_ls.so .variants/libomlm_attn_w1.so -- attn > $out/lib_ab_attn_regs.log 2>&1 || true
     cat $out/lib_ab_attn_regs.log
+    # hypothesis test: the same kernels with the per-tile DMA off (OMLM_GEMM_DEBUG=1: compute on stale LDS, results are
+    # garbage, time is what the k-loop costs without memory) and with the MFMAs off (=2: what the data movement alone costs)
+    cp open_musiclm_amd/libomlm_hip.so .variants/libomlm_dbg1.so; cp open_musiclm_amd/libomlm_hip.so .variants/libomlm_dbg2.so
+    timeout 60 tools/lib_ab open_musiclm_amd/libomlm_hip.so OMLM_GEMM_DEBUG=1@.variants/libomlm_dbg1.so OMLM_GEMM_DEBUG=2@.variants/libomlm_dbg2.so -- gemm > $out/lib_ab_gemm_ablate.log 2>&1 || true
+    grep -v "differ\|identical" $out/lib_ab_gemm_ablate.log
     timeout 90 tools/lib_ab open_musiclm_amd/libomlm_hip.so .variants/libomlm_gemm_w4.so .variants/libomlm_gemm_lean1.so .variants/libomlm_gemm_lean2.so .variants/libomlm_gemm_sp1.so -- gemm_edge gemm wgrad > $out/lib_ab_w4.log 2>&1 || true
     cat $out/lib_ab_attn.log $out/lib_ab_gemm.log $out/lib_ab_w4.log
     # SQ / LDS counters of the attention backward kernels through the torch-free harness (4 short passes): where the ~7 k cycles per
