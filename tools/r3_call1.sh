@@ -18,7 +18,7 @@ build)
     # dQ kernel register diet: dS * scale formed after the diagonal sums (scratch 84 -> 40 B, same arithmetic); and at one wave per SIMD
     hipcc $FL -DAT_DQ_LATE_SCALE=1 -c $CS/attention.hip -o /tmp/attention_ls.o
     hipcc --offload-arch=gfx950 -shared -fPIC $(rest attention) /tmp/attention_ls.o -o "$ROOT/.variants/libomlm_attn_ls.so"
-    hipcc $FL -DAT_DQ_WPE=1 -DAT_DKV_WPE=1 -c $CS/attention.hip -o /tmp/attention_w1.o
+    hipcc $FL -DAT_DQ_WPE=1 -DAT_DKV_WPE=1 -DAT_DQP_WPE=1 -c $CS/attention.hip -o /tmp/attention_w1.o
     hipcc --offload-arch=gfx950 -shared -fPIC $(rest attention) /tmp/attention_w1.o -o "$ROOT/.variants/libomlm_attn_w1.so"
     hipcc $FL -DOMLM_GEMM_ROTATE=0 -c $CS/gemm.hip -o /tmp/gemm_old.o
     hipcc --offload-arch=gfx950 -shared -fPIC $(rest gemm) /tmp/gemm_old.o -o "$ROOT/.variants/libomlm_gemm_old.so"
@@ -39,7 +39,7 @@ run)
     cd "$ROOT"; out=gpurun_out/r3c1; mkdir -p $out
     timeout 60 tools/lib_ab .variants/libomlm_attn_old.so open_musiclm_amd/libomlm_hip.so -- attn attn_large attn32 ffmid ln decode > $out/lib_ab_attn.log 2>&1 || true
     timeout 60 tools/lib_ab .variants/libomlm_gemm_old.so open_musiclm_amd/libomlm_hip.so -- gemm_edge gemm wgrad > $out/lib_ab_gemm.log 2>&1 || true
-    timeout 60 tools/lib_ab open_musiclm_amd/libomlm_hip.so .variants/libomlm_attn_ls.so .variants/libomlm_attn_w1.so -- attn > $out/lib_ab_attn_regs.log 2>&1 || true
+    timeout 60 tools/lib_ab open_musiclm_amd/libomlm_hip.so .variants/libomlm_attn_ls.so .variants/libomlm_attn_w1.so -- attn attn32 > $out/lib_ab_attn_regs.log 2>&1 || true
     cat $out/lib_ab_attn_regs.log
     # hypothesis test: the same kernels with the per-tile DMA off (OMLM_GEMM_DEBUG=1: compute on stale LDS, results are
     # garbage, time is what the k-loop costs without memory) and with the MFMAs off (=2: what the data movement alone costs)
