@@ -496,6 +496,9 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, 
 #ifndef OMLM_GEMM_W4
 #define OMLM_GEMM_W4 0
 #endif
+#ifndef OMLM_GEMM_BK32
+#define OMLM_GEMM_BK32 0
+#endif
 #ifndef OMLM_GEMM_ROTATE
 #define OMLM_GEMM_ROTATE 1          /* rotated k-loop (last k16 step multiplied after the next tile's barrier); 0: the round-1/2 loop */
 #endif
@@ -714,6 +717,209 @@ __global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile
     gemm_tile_body<BM_, BN_, WM_, WN_, A_KMAJ, B_KMAJ, TOUT, DBG, KMAP, BAL, SPLIT3>(g, lg, gridDim.y > 1, (int)gridDim.x, smem);
 }
 
+#if OMLM_GEMM_BK32
+// ---- experiment build: the 256x256 tile with 32-deep k-tiles in a FOUR-stage LDS ring --------------------------------------------
+// Same LDS (4 x 32 KiB), same DMA instruction count per byte, but three k-tiles (96 KiB) in flight per CU instead of one 64 KiB
+// stage, and a tile's DMA is issued three tiles (~3 x 1024 matrix-pipe cycles) before it is read instead of less than one: the test
+// of DESIGN 10.1's reading that the k-loop is bound by memory latency x bytes in flight.  One barrier per 32-deep tile; the rotated
+// schedule (the tile's second k16 step is multiplied after the next barrier) and the products' order per accumulator are the
+// production kernel's, so results must be bit-identical to it.  Plain launches only (no k-row maps, no balanced split, no planes).
+//
+// Row-major image of a 32-deep tile: [rows][32 k] bf16, 64 B per row, 16-B chunk index XOR ((row >> 2) & 3): a DMA unit (1 KiB,
+// lane-linear) is 16 rows; ds_read_b128 fragment reads are conflict-free (checked per lane group: profiles/r02d_isa_audit.md).
+// k-major image: the production panels, half as tall ([32 k][128 cols], 8 KiB per panel).
+__device__ __forceinline__ int lds_off_normal32(int row, int kchunk) { return row * 64 + ((kchunk ^ ((row >> 2) & 3)) << 4); }
+
+template <bool KMAJ>
+__device__ __forceinline__ bf16x8 read_frag32(const char* lds, int sub0, int s, int lane) {     // s in {0, 1}
+    if (!KMAJ) {
+        const int row = sub0 + (lane & 31);
+        const int kc = 2 * s + (lane >> 5);
+        return *(const bf16x8*)(lds + lds_off_normal32(row, kc));
+    } else {
+        const int i16 = lane & 15, grp = lane >> 4, r = i16 >> 2;
+        const int k = 16 * s + 8 * (grp >> 1) + r;
+        const char* base = lds + (sub0 >> 7) * 8192 + k * 256 + ((((sub0 >> 5) & 3) ^ r) << 6) + (16 * (grp & 1) + 4 * (i16 & 3)) * 2;
+        s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base));
+        s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base + 1024));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        s16x8 v = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, v);
+    }
+}
+
+template <bool KMAJ, int ROWS, int NWAVES>
+struct DmaStager32 {
+    static constexpr int UPW = (ROWS / 16) / NWAVES;      // 1-KiB units per wave per 32-deep tile
+    unsigned base[UPW];
+    int kidx[UPW];
+    __device__ __forceinline__ void init(const int* map, int ld, int nvalid, int r0, int wave, int lane) {
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) {
+            const int b = wave + NWAVES * i;
+            if (!KMAJ) {
+                const int row = 16 * b + (lane >> 2), slot = lane & 3;
+                const int kc = slot ^ ((row >> 2) & 3);
+                const int gr = r0 + row;
+                const bool ok = gr < nvalid;
+                const long long pr = (ok && map) ? (long long)map[gr] : (long long)gr;
+                base[i] = ok ? (unsigned)((pr * ld + kc * 8) * 2) : OOB_OFF;
+                kidx[i] = kc * 8;
+            } else {
+                // unit b = (panel b >> 3, k-group b & 7): 4 k-rows x 256 B, as in the production image
+                const int krow = 4 * (b & 7) + (lane >> 4);
+                const int piece = ((lane & 15) >> 2) ^ (lane >> 4);
+                const int gc = r0 + 128 * (b >> 3) + 32 * piece + 8 * (lane & 3);
+                base[i] = gc < nvalid ? (unsigned)(gc * 2) : OOB_OFF;
+                kidx[i] = krow;
+            }
+        }
+    }
+    __device__ __forceinline__ void issue_one(int i, dma_rsrc rs, int ld, int k0, int K, char* lds_tile, int wave, bool live) {
+        const int b = wave + NWAVES * i;
+        unsigned off;
+        if (!KMAJ) {
+            off = (live && base[i] != OOB_OFF && k0 + kidx[i] < K) ? base[i] + (unsigned)(k0 * 2) : OOB_OFF;
+        } else {
+            const int gk = k0 + kidx[i];
+            off = (live && base[i] != OOB_OFF && gk < K) ? base[i] + (unsigned)gk * (unsigned)(ld * 2) : OOB_OFF;
+        }
+        dma_issue(rs, (unsigned)(size_t)LDS_PTR(char, lds_tile) + (unsigned)(b * 1024), off);
+    }
+};
+
+template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ, bool B_KMAJ, typename TOUT>
+__global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile32_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];    // [4 stages][A | B]
+    constexpr int BKT = 32, NST = 4;
+    constexpr int NWN = BN_ / WN_, NWAVES = (BM_ / WM_) * NWN;
+    constexpr int MI = WM_ / 32, NJ = WN_ / 32;
+    constexpr int A_BYTES = BM_ * BKT * 2, B_BYTES = BN_ * BKT * 2, STAGE = A_BYTES + B_BYTES;
+    constexpr int UA = (BM_ / 16) / NWAVES, UB = (BN_ / 16) / NWAVES, NLOAD = UA + UB;
+    constexpr int MPS = MI * NJ;
+    static_assert(2 * NLOAD <= 63, "vmcnt immediate");
+    const int nwg = gridDim.x;
+    const int total = nwg * (int)gridDim.y;
+    const int lg = xcd_logical_id(blockIdx.y * nwg + blockIdx.x, total);
+    const bool split = gridDim.y > 1;
+    const int tiles_m = (g.M + BM_ - 1) / BM_, tiles_n = (g.N + BN_ - 1) / BN_;
+    const int ntile = tiles_m * tiles_n;
+    const int nk_all = (g.K + BKT - 1) / BKT;
+    const int ksplit = lg / ntile, bid = lg - ksplit * ntile;
+    const int kt0 = ksplit * g.kt_per_split * 2;                   // kt_per_split counts 64-deep tiles
+    const int kt1 = min(nk_all, kt0 + 2 * g.kt_per_split);
+    constexpr int GROUP = OMLM_SUPER_ROWS / BM_;
+    const int gsz = GROUP * tiles_n;
+    const int grp = bid / gsz, first_m = grp * GROUP;
+    const int rows_in = min(GROUP, tiles_m - first_m);
+    const int tm = first_m + (bid - grp * gsz) % rows_in, tn = (bid - grp * gsz) / rows_in;
+    const int m0 = tm * BM_, n0 = tn * BN_;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = (wave / NWN) * WM_, wn = (wave % NWN) * WN_;
+    const dma_rsrc rsA = make_dma_rsrc(g.A, (unsigned long long)g.a_rows * g.lda * 2);
+    const dma_rsrc rsB = make_dma_rsrc(g.B, (unsigned long long)g.b_rows * g.ldb * 2);
+    DmaStager32<A_KMAJ, BM_, NWAVES> sa;
+    DmaStager32<B_KMAJ, BN_, NWAVES> sb;
+    sa.init(g.a_map, g.lda, g.M, m0, wave, lane);
+    sb.init(g.b_map, g.ldb, g.N, n0, wave, lane);
+
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // one tile's NLOAD pieces of this wave; a tile past the end is requested out of bounds (zeros, no traffic) so that the number of
+    // outstanding pieces per tile is constant and the counted wait below is exact
+    auto issue_piece = [&](int l, int t) {
+        char* st = smem + ((t - kt0) & (NST - 1)) * STAGE;
+        const bool live = t < kt1;
+        if (l < UA) sa.issue_one(l, rsA, g.lda, t * BKT, g.K, st, wave, live);
+        else        sb.issue_one(l - UA, rsB, g.ldb, t * BKT, g.K, st + A_BYTES, wave, live);
+    };
+#pragma unroll
+    for (int d = 0; d < NST - 1; ++d)
+#pragma unroll
+        for (int l = 0; l < NLOAD; ++l) issue_piece(l, kt0 + d);
+
+    bf16x8 a[2][MI], b[2][NJ];
+    bool pending = false;
+#ifndef OMLM_BK32_SPREAD
+#define OMLM_BK32_SPREAD 2           /* phases (of 2) over which the DMA issue of tile t+3 is spread */
+#endif
+    constexpr int STRIDE = (OMLM_BK32_SPREAD * MPS) / NLOAD > 0 ? (OMLM_BK32_SPREAD * MPS) / NLOAD : 1;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        // this wave's pieces of tile kt have landed when at most the 2 * NLOAD younger ones (tiles kt+1, kt+2) are outstanding
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NLOAD) : "memory");
+        __syncthreads();              // tile kt landed everywhere; every wave's reads of tile kt-1 (whose stage tile kt+3 overwrites) are complete
+        const char* As = smem + ((kt - kt0) & (NST - 1)) * STAGE;
+        const char* Bs = As + A_BYTES;
+        auto phase = [&](const int ph, const int fi, const bool mul) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    if (mul) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[fi][i], b[fi][j], acc[i][j], 0, 0, 0);
+                    const int midx = ph * MPS + i * NJ + j;
+                    if (midx % STRIDE == 0 && midx / STRIDE < NLOAD) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue_piece(midx / STRIDE, kt + NST - 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+        };
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[0][i] = read_frag32<A_KMAJ>(As, wm + 32 * i, 0, lane);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) b[0][j] = read_frag32<B_KMAJ>(Bs, wn + 32 * j, 0, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        phase(0, 1, pending);                                      // second k16 step of the previous tile (registers only)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[1][i] = read_frag32<A_KMAJ>(As, wm + 32 * i, 1, lane);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) b[1][j] = read_frag32<B_KMAJ>(Bs, wn + 32 * j, 1, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        phase(1, 0, true);                                         // first k16 step of this tile
+        __builtin_amdgcn_sched_barrier(0);
+        pending = true;
+    }
+    if (pending) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the out-of-bounds tail requests still write zeros into the ring
+    __syncthreads();
+    tile_epilogue<MI, NJ, WN_, TOUT>(g, acc, smem, m0, n0, wm, wn, wave, lane, 0, split);
+}
+
+template <int BM_, int BN_, int WM_, int WN_, typename TOUT>
+static int launch_tile32(const GemmArgs& g, int a_kmaj, int b_kmaj, int splits, hipStream_t st) {
+    constexpr int NTH = (BM_ / WM_) * (BN_ / WN_) * 64;
+    constexpr size_t LDS = 4 * (size_t)(BM_ + BN_) * 32 * 2;
+    const int tiles = ((g.M + BM_ - 1) / BM_) * ((g.N + BN_ - 1) / BN_);
+    dim3 grid(tiles, splits), block(NTH);
+#define OMLM_TILE32_LAUNCH(AK, BKM)                                                                                        \
+    do {                                                                                                                    \
+        auto kfn = gemm_bf16_tile32_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT>;                                              \
+        static bool attr = false;                                                                                           \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); attr = true; } \
+        hipLaunchKernelGGL(kfn, grid, block, LDS, st, g);                                                                   \
+    } while (0)
+    if (!a_kmaj && !b_kmaj)      OMLM_TILE32_LAUNCH(false, false);
+    else if (!a_kmaj && b_kmaj)  OMLM_TILE32_LAUNCH(false, true);
+    else if (a_kmaj && b_kmaj)   OMLM_TILE32_LAUNCH(true, true);
+    else                         OMLM_TILE32_LAUNCH(true, false);
+#undef OMLM_TILE32_LAUNCH
+    return omlm_post_launch("omlm_gemm");
+}
+#endif   // OMLM_GEMM_BK32
+
 // ---- grouped weight-gradient GEMM ------------------------------------------------------------------------------------
 // All dW += dY^T X contractions of a backward pass (same K = tokens, small outputs) as ONE launch: the 30 separate GEMMs of a
 // coarse-small step each had too few output tiles for 256 CUs and were split 5..31 ways along K with fp32 atomics
@@ -893,6 +1099,12 @@ static int gemm_impl(const void* A, const void* B, void* C, const float* Cin,
         return launch_layout<float, float>(g, a_kmajor, b_kmajor, splits, st);
     }
     auto launch = [&](const GemmArgs& ga, int tm_, int tn_, int sp) -> int {
+#if OMLM_GEMM_BK32        /* experiment build: 32-deep k-tiles in a four-stage ring for the plain 256x256 launches */
+        if (tm_ == 256 && tn_ == 256 && !ga.split3 && ga.bal_ck == 0 && !ga.debug &&
+            !((a_kmajor && ga.a_map) || (b_kmajor && ga.b_map)))
+            return out_dtype == 0 ? launch_tile32<256, 256, 128, 64, float>(ga, a_kmajor, b_kmajor, sp, st)
+                                  : launch_tile32<256, 256, 128, 64, bf16_t>(ga, a_kmajor, b_kmajor, sp, st);
+#endif
 #if OMLM_GEMM_W4          /* experiment build: the 256x256 tile on FOUR waves of 128x128 (one per SIMD, 512 registers, a third less LDS read traffic) */
         if (tm_ == 256 && tn_ == 256)
             return out_dtype == 0 ? launch_tile<256, 256, 128, 128, float>(ga, a_kmajor, b_kmajor, sp, st)

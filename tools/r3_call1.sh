@@ -28,7 +28,9 @@ build)
     # lean LDS-DMA issue: 1 = one wait state after the M0 write instead of five, 2 = also without saving / restoring M0
     for v in 1 2; do ( hipcc $FL -DOMLM_DMA_LEAN=$v -c $CS/gemm.hip -o /tmp/gemm_lean$v.o ) & done
     ( hipcc $FL -DOMLM_DMA_SPREAD_ROT=1 -c $CS/gemm.hip -o /tmp/gemm_sp1.o ) &      # next tile's DMA all inside the deferred step (earliest possible)
+    ( hipcc $FL -DOMLM_GEMM_BK32=1 -c $CS/gemm.hip -o /tmp/gemm_bk32.o ) &            # 32-deep k-tiles, four-stage ring (three tiles in flight): never run
     wait
+    hipcc --offload-arch=gfx950 -shared -fPIC $(rest gemm) /tmp/gemm_bk32.o -o "$ROOT/.variants/libomlm_gemm_bk32.so"
     hipcc --offload-arch=gfx950 -shared -fPIC $(rest gemm) /tmp/gemm_sp1.o -o "$ROOT/.variants/libomlm_gemm_sp1.so"
     hipcc --offload-arch=gfx950 -shared -fPIC $(rest gemm) /tmp/gemm_w4.o -o "$ROOT/.variants/libomlm_gemm_w4.so"
     for v in 1 2; do hipcc --offload-arch=gfx950 -shared -fPIC $(rest gemm) /tmp/gemm_lean$v.o -o "$ROOT/.variants/libomlm_gemm_lean$v.so"; done
@@ -46,7 +48,7 @@ run)
     cp open_musiclm_amd/libomlm_hip.so .variants/libomlm_dbg1.so; cp open_musiclm_amd/libomlm_hip.so .variants/libomlm_dbg2.so
     timeout 60 tools/lib_ab open_musiclm_amd/libomlm_hip.so OMLM_GEMM_DEBUG=1@.variants/libomlm_dbg1.so OMLM_GEMM_DEBUG=2@.variants/libomlm_dbg2.so -- gemm > $out/lib_ab_gemm_ablate.log 2>&1 || true
     grep -v "differ\|identical" $out/lib_ab_gemm_ablate.log
-    timeout 90 tools/lib_ab open_musiclm_amd/libomlm_hip.so .variants/libomlm_gemm_w4.so .variants/libomlm_gemm_lean1.so .variants/libomlm_gemm_lean2.so .variants/libomlm_gemm_sp1.so -- gemm_edge gemm wgrad > $out/lib_ab_w4.log 2>&1 || true
+    timeout 90 tools/lib_ab open_musiclm_amd/libomlm_hip.so .variants/libomlm_gemm_w4.so .variants/libomlm_gemm_lean1.so .variants/libomlm_gemm_lean2.so .variants/libomlm_gemm_sp1.so .variants/libomlm_gemm_bk32.so -- gemm_edge gemm wgrad > $out/lib_ab_w4.log 2>&1 || true
     cat $out/lib_ab_attn.log $out/lib_ab_gemm.log $out/lib_ab_w4.log
     # SQ / LDS counters of the attention backward kernels through the torch-free harness (4 short passes): where the ~7 k cycles per
     # 32x32 block per wave go now (waits, LDS bank conflicts, VALU / MFMA busy)
