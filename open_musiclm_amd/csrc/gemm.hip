@@ -726,7 +726,7 @@ __global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile
 // production kernel's, so results must be bit-identical to it.  Plain launches only (no k-row maps, no balanced split, no planes).
 //
 // Row-major image of a 32-deep tile: [rows][32 k] bf16, 64 B per row, 16-B chunk index XOR ((row >> 2) & 3): a DMA unit (1 KiB,
-// lane-linear) is 16 rows; ds_read_b128 fragment reads are conflict-free (checked per lane group: profiles/r02d_isa_audit.md).
+// lane-linear) is 16 rows; ds_read_b128 fragment reads are conflict-free (checked per lane group: tools/lds_conflicts.py).
 // k-major image: the production panels, half as tall ([32 k][128 cols], 8 KiB per panel).
 __device__ __forceinline__ int lds_off_normal32(int row, int kchunk) { return row * 64 + ((kchunk ^ ((row >> 2) & 3)) << 4); }
 
