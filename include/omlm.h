@@ -166,14 +166,19 @@ int omlm_silu_bwd(const float* dz, const float* pre, float* ds, long long total,
 int omlm_bias_add(const float* a, const float* b, float* out, int R, int C, int ld, void* stream);
 
 /* Nearest-codeword kernels: ClapQuantized.quantize -> ResidualVQ eval path (clap_quantized.py:75-87) and
- * HfHubertWithKmeans assign (hf_hubert_kmeans.py:87).  codebooks_T: [nstage][D][C] (transposed); indices int32 [n, nstage]. */
+ * HfHubertWithKmeans assign (hf_hubert_kmeans.py:87).  codebooks_T: [nstage][D][C] (transposed); indices int32 [n, nstage].
+ * omlm_rvq_encode / _strided use the distance form of vector-quantize-pytorch's EuclideanCodebook -- argmax(-cdist(x, embed)),
+ * first maximum: dist = sqrt(max((|x|^2 + |e|^2) - 2 x.e, 0)) in fp32, IEEE root (distances whose roots round equal are a tie for
+ * the lowest index); pinned bit for bit against torch.cdist on exactly representable inputs (tests/rvq_cases.py).
+ * omlm_nearest_centroid uses sum_d (x_d - c_d)^2 (pinned against sklearn.MiniBatchKMeans.predict).  Ties -> lowest index. */
 int omlm_rvq_encode(const float* x, const float* codebooks_T, int* indices, float* residual_out,
                     int n, int D, int C, int nstage, void* stream);
 int omlm_nearest_centroid(const float* x, const float* centroids_T, int* indices, int n, int D, int C, void* stream);
 int omlm_rvq_encode_strided(const float* x, const float* codebook_T, int* indices, int idx_stride, float* residual_out,
                             int n, int D, int C, void* stream);
 /* Fitting side of the residual VQ (reference call sites: trainer.py:689-736 -> clap_quantized.py:75-84 with rq.train(True); the
- * arithmetic is vector-quantize-pytorch's EuclideanCodebook, un-vendored: parity unpinned, oracle.rvq_fit_step restates it).
+ * arithmetic is vector-quantize-pytorch's EuclideanCodebook, un-vendored: oracle.rvq_fit_step restates the published update rules;
+ * the assignment inside it is the -cdist form above).
  * accumulate: counts[k] += #rows assigned to k, sums[k, :] += those rows (caller zeroes both; indices[i * idx_stride]).
  * kmeans_update: means[k] = sums[k] / counts[k] where counts[k] > 0 (Lloyd step), means_T [D, K] refreshed.
  * ema_update: cluster_size = d cs + (1-d) counts; embed_avg = d avg + (1-d) sums; embed = embed_avg / Laplace-smoothed sizes

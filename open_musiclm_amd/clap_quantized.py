@@ -1,7 +1,8 @@
 """ClapQuantized (reference open_musiclm/clap_quantized.py).  The frozen CLAP towers are third-party pretrained
 networks outside the hot path; what IS on the path is ``quantize``: the residual-VQ nearest-codeword chain,
-which runs as one HIP kernel (omlm_rvq_encode) and is bit-exact against the stated definition in
-oracle/musiclm_oracle.py::rvq_encode (RVQ parity is unpinned against the un-vendored vector-quantize-pytorch).
+which runs as one HIP kernel (omlm_rvq_encode) in the distance form of vector-quantize-pytorch's EuclideanCodebook (-cdist,
+first maximum), bit-exact against oracle/musiclm_oracle.py::rvq_encode and -- on exactly representable inputs, where the
+summation order of a BLAS cannot matter -- against torch.cdist itself (the library is un-vendored; tests pin the form).
 ``learn_rvq=True`` fits the codebooks (what scripts/train_clap_rvq.py drives through ClapRVQTrainer) with the kernels of
 csrc/vq_fit.hip, checked against oracle.rvq_fit_step."""
 from __future__ import annotations
@@ -17,7 +18,8 @@ from .utils import exists
 
 
 class ResidualVQCodebooks(nn.Module):
-    """Stand-in for vector_quantize_pytorch.ResidualVQ (un-vendored, un-pinned: parity unpinned, see oracle.rvq_fit_step): holds
+    """Stand-in for vector_quantize_pytorch.ResidualVQ (un-vendored; distance form pinned against torch.cdist, fit step restated in
+    oracle.rvq_fit_step): holds
     the codebooks and their EMA statistics, reads / writes the library's checkpoint keys
     (layers.{s}._codebook.{initted, cluster_size [1, K], embed [1, K, D], embed_avg [1, K, D]}), encodes with the HIP
     nearest-codeword kernel and -- in training mode -- runs the library's fit step (k-means init on the first batch, EMA
@@ -38,35 +40,46 @@ class ResidualVQCodebooks(nn.Module):
         self.expire_pick_source = None
 
     # ---- checkpoints in the library's layout (what trainer.py:731 saves and clap_quantized.py:109 loads) -----------------
-    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
-        sd = destination if destination is not None else {}
-        for s in range(self.num_quantizers):
-            p = f"{prefix}layers.{s}._codebook."
-            sd[p + "initted"] = self.initted[s:s + 1].detach().clone()
-            sd[p + "cluster_size"] = self.cluster_size[s:s + 1].detach().clone()
-            sd[p + "embed"] = self.codebooks[s:s + 1].detach().clone()
-            sd[p + "embed_avg"] = self.embed_avg[s:s + 1].detach().clone()
-        return sd
+    # The key translation lives in the nn.Module hooks (_save_to_state_dict / _load_from_state_dict), so an enclosing module's
+    # state_dict() / load_state_dict() round-trips too (ClapQuantized.state_dict()["rq.layers.0._codebook.embed"], strict load).
+    def _lib_prefix(self, prefix, s):
+        return f"{prefix}layers.{s}._codebook."
 
-    def load_state_dict(self, sd, strict=True):
-        if "codebooks" in sd:                                        # this module's own buffer names
-            for k in ("codebooks", "embed_avg", "cluster_size", "initted"):
-                if k in sd:
-                    getattr(self, k).copy_(sd[k])
-            if "initted" not in sd:
-                self.initted.fill_(True)
-            self._cbT = None
-            return None
-        for s in range(self.num_quantizers):                      # vector-quantize-pytorch layout
-            p = f"layers.{s}._codebook."
-            self.codebooks[s].copy_(sd[p + "embed"].reshape(self.codebook_size, self.dim))
-            if p + "embed_avg" in sd:
-                self.embed_avg[s].copy_(sd[p + "embed_avg"].reshape(self.codebook_size, self.dim))
-            if p + "cluster_size" in sd:
-                self.cluster_size[s].copy_(sd[p + "cluster_size"].reshape(self.codebook_size))
-            self.initted[s] = bool(sd[p + "initted"].reshape(-1)[0]) if p + "initted" in sd else True
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        for s in range(self.num_quantizers):
+            p = self._lib_prefix(prefix, s)
+            destination[p + "initted"] = self.initted[s:s + 1].detach().clone()
+            destination[p + "cluster_size"] = self.cluster_size[s:s + 1].detach().clone()
+            destination[p + "embed"] = self.codebooks[s:s + 1].detach().clone()
+            destination[p + "embed_avg"] = self.embed_avg[s:s + 1].detach().clone()
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        own = ("codebooks", "embed_avg", "cluster_size", "initted")
+        with torch.no_grad():
+            if prefix + "codebooks" in state_dict:                   # this module's own buffer names (round-1 checkpoints)
+                for k in own:
+                    if prefix + k in state_dict:
+                        getattr(self, k).copy_(state_dict[prefix + k])
+                if prefix + "initted" not in state_dict:
+                    self.initted.fill_(True)
+            else:                                                    # vector-quantize-pytorch layout
+                for s in range(self.num_quantizers):
+                    p = self._lib_prefix(prefix, s)
+                    if p + "embed" not in state_dict:
+                        missing_keys.append(p + "embed")
+                        continue
+                    self.codebooks[s].copy_(state_dict[p + "embed"].reshape(self.codebook_size, self.dim))
+                    if p + "embed_avg" in state_dict:
+                        self.embed_avg[s].copy_(state_dict[p + "embed_avg"].reshape(self.codebook_size, self.dim))
+                    if p + "cluster_size" in state_dict:
+                        self.cluster_size[s].copy_(state_dict[p + "cluster_size"].reshape(self.codebook_size))
+                    self.initted[s] = bool(state_dict[p + "initted"].reshape(-1)[0]) if p + "initted" in state_dict else True
+        known = {prefix + k for k in own}
+        known |= {self._lib_prefix(prefix, s) + k for s in range(self.num_quantizers)
+                  for k in ("initted", "cluster_size", "embed", "embed_avg")}
+        if strict:
+            unexpected_keys.extend(k for k in state_dict if k.startswith(prefix) and k not in known)
         self._cbT = None
-        return None
 
     def _transposed(self):
         if self._cbT is None or self._cbT.device != self.codebooks.device:

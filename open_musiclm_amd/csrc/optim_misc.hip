@@ -206,10 +206,19 @@ extern "C" int omlm_relpos_first_bwd(const float* ds, float* dw0, int n, int Hd,
 
 // ---------------------------------------------------------------------------------------------------------
 // Residual-VQ / k-means nearest-codeword (clap_quantized.py:75-87 -> ResidualVQ eval path; hf_hubert_kmeans.py:87).
-// Bit-exact contract (oracle.nearest_code): dist(c) = sum_d (x_d - e_{c,d})^2 in fp32, d in index order, the
-// multiply and the add rounded separately (no FMA contraction), argmin with ties -> lowest index; then
-// r <- r - e_idx (one fp32 subtraction per element).  cbT is the codebook TRANSPOSED: [n_stage][D][C], so that
-// consecutive threads (codes) read consecutive addresses.
+// cbT is the codebook TRANSPOSED: [n_stage][D][C], so that consecutive threads (codes) read consecutive addresses.  Two stated
+// distance forms, both in fp32 with every multiply and add rounded separately (no FMA contraction), d in index order:
+//   FORM_SQ    dist(c) = sum_d (x_d - e_{c,d})^2                                  (oracle.nearest_code; the k-means assign step,
+//              pinned bit for bit against sklearn.MiniBatchKMeans.predict at the shipped dimensions)
+//   FORM_CDIST dist(c) = sqrt(max((x2 + e2_c) - 2 * xy_c, 0)),  x2 = sum x_d^2, e2_c = sum e_{c,d}^2, xy_c = sum x_d e_{c,d}
+//              (oracle.nearest_code_cdist) -- the form of vector-quantize-pytorch's EuclideanCodebook (`-cdist(x, embed)`, then
+//              argmax = first maximum): the expanded euclidean distance, square root INCLUDED (it merges distances that differ by
+//              less than a rounding of the root into ties, which the lowest index then wins).  Pinned against torch.cdist itself:
+//              on inputs whose products and sums are exact in fp32 every summation order gives the same bits, and the ids agree
+//              bit for bit (tests); on general inputs a BLAS's summation order is its own, and so are the library's ids.
+// argmin with ties -> lowest index; then r <- r - e_idx (one fp32 subtraction per element).
+enum { FORM_SQ = 0, FORM_CDIST = 1 };
+template <int FORM>
 __global__ __launch_bounds__(256) void rvq_kernel(const float* __restrict__ x, const float* __restrict__ cbT,
                                                   int* __restrict__ idx_out, float* __restrict__ resid_out,
                                                   int n, int D, int C, int nstage, int idx_stride) {
@@ -224,11 +233,27 @@ __global__ __launch_bounds__(256) void rvq_kernel(const float* __restrict__ x, c
         const float* cb = cbT + (size_t)s * D * C;
         float best = INFINITY;
         int besti = 0x7fffffff;
+        float x2 = 0.f;
+        if (FORM == FORM_CDIST)                   // every thread forms the same sequential sum (LDS broadcast reads)
+            for (int d = 0; d < D; ++d) x2 = __fadd_rn(x2, __fmul_rn(r[d], r[d]));
         for (int c = threadIdx.x; c < C; c += 256) {
-            float dist = 0.f;
-            for (int d = 0; d < D; ++d) {
-                const float diff = __fsub_rn(r[d], cb[(size_t)d * C + c]);
-                dist = __fadd_rn(dist, __fmul_rn(diff, diff));
+            float dist;
+            if (FORM == FORM_SQ) {
+                dist = 0.f;
+                for (int d = 0; d < D; ++d) {
+                    const float diff = __fsub_rn(r[d], cb[(size_t)d * C + c]);
+                    dist = __fadd_rn(dist, __fmul_rn(diff, diff));
+                }
+            } else {
+                float xy = 0.f, e2 = 0.f;
+                for (int d = 0; d < D; ++d) {
+                    const float e = cb[(size_t)d * C + c];
+                    xy = __fadd_rn(xy, __fmul_rn(r[d], e));
+                    e2 = __fadd_rn(e2, __fmul_rn(e, e));
+                }
+                // IEEE root: through fp64 (a correctly rounded fp64 root rounded to fp32 IS the correctly rounded fp32 root: 53 >= 2 * 24 + 2);
+                // HIP's __fsqrt_rn is the native 1-ulp v_sqrt_f32, which keeps root-merged near-ties apart
+                dist = (float)sqrt((double)fmaxf(__fsub_rn(__fadd_rn(x2, e2), __fmul_rn(2.f, xy)), 0.f));
             }
             if (dist < best) { best = dist; besti = c; }      // ascending c per thread: strict < keeps the lowest index
         }
@@ -255,26 +280,31 @@ __global__ __launch_bounds__(256) void rvq_kernel(const float* __restrict__ x, c
     if (resid_out) for (int d = threadIdx.x; d < D; d += 256) resid_out[(size_t)row * D + d] = r[d];
 }
 
+static int rvq_launch(int form, const float* x, const float* cbT, int* indices, float* residual_out, int n, int D, int C,
+                      int nstage, int idx_stride, void* stream, const char* what) {
+    if (n <= 0) return OMLM_OK;
+    OMLM_CHECK_ARG(x && cbT && indices && D > 0 && C > 0 && nstage > 0 && idx_stride >= 1, "rvq arguments");
+    OMLM_CHECK_ARG((size_t)D * sizeof(float) <= 48 * 1024, "D too large");
+    if (form == FORM_CDIST)
+        hipLaunchKernelGGL(rvq_kernel<FORM_CDIST>, dim3(n), dim3(256), D * sizeof(float), as_stream(stream), x, cbT, indices, residual_out, n, D, C, nstage, idx_stride);
+    else
+        hipLaunchKernelGGL(rvq_kernel<FORM_SQ>, dim3(n), dim3(256), D * sizeof(float), as_stream(stream), x, cbT, indices, residual_out, n, D, C, nstage, idx_stride);
+    return omlm_post_launch(what);
+}
+// residual-VQ chain of nstage codebooks in the library's distance form (FORM_CDIST)
 extern "C" int omlm_rvq_encode(const float* x, const float* codebooks_T, int* indices, float* residual_out,
                                int n, int D, int C, int nstage, void* stream) {
-    if (n <= 0) return OMLM_OK;
-    OMLM_CHECK_ARG(x && codebooks_T && indices && D > 0 && C > 0 && nstage > 0, "rvq arguments");
-    OMLM_CHECK_ARG((size_t)D * sizeof(float) <= 48 * 1024, "D too large");
-    hipLaunchKernelGGL(rvq_kernel, dim3(n), dim3(256), D * sizeof(float), as_stream(stream), x, codebooks_T, indices, residual_out, n, D, C, nstage, nstage);
-    return omlm_post_launch("omlm_rvq_encode");
+    return rvq_launch(FORM_CDIST, x, codebooks_T, indices, residual_out, n, D, C, nstage, nstage, stream, "omlm_rvq_encode");
 }
 // one stage, index of row i written to indices[i * idx_stride] (a column of an [n, stages] table: the RVQ fit step walks the layers
-// one launch at a time because every layer's codebook changes between its assignment and the next layer's)
+// one launch at a time because every layer's codebook changes between its assignment and the next layer's); same form
 extern "C" int omlm_rvq_encode_strided(const float* x, const float* codebook_T, int* indices, int idx_stride, float* residual_out,
                                        int n, int D, int C, void* stream) {
-    if (n <= 0) return OMLM_OK;
-    OMLM_CHECK_ARG(x && codebook_T && indices && D > 0 && C > 0 && idx_stride >= 1, "rvq arguments");
-    OMLM_CHECK_ARG((size_t)D * sizeof(float) <= 48 * 1024, "D too large");
-    hipLaunchKernelGGL(rvq_kernel, dim3(n), dim3(256), D * sizeof(float), as_stream(stream), x, codebook_T, indices, residual_out, n, D, C, 1, idx_stride);
-    return omlm_post_launch("omlm_rvq_encode_strided");
+    return rvq_launch(FORM_CDIST, x, codebook_T, indices, residual_out, n, D, C, 1, idx_stride, stream, "omlm_rvq_encode_strided");
 }
+// k-means assign (hf_hubert_kmeans.py:87): squared-difference form (FORM_SQ)
 extern "C" int omlm_nearest_centroid(const float* x, const float* centroids_T, int* indices, int n, int D, int C, void* stream) {
-    return omlm_rvq_encode(x, centroids_T, indices, nullptr, n, D, C, 1, stream);
+    return rvq_launch(FORM_SQ, x, centroids_T, indices, nullptr, n, D, C, 1, 1, stream, "omlm_nearest_centroid");
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -605,6 +605,7 @@ def run_forward(model, all_token_ids, self_attn_mask, only_final: bool, save: bo
         raise NotImplementedError("non_causal_prefix_size > 0 is not supported by the MI355X attention kernel "
                                   "(every shipped config uses 0)")
     require_gpu(model.start_tokens[0], "model parameters")
+    ops.planes_begin()                       # bf16x3 operand planes live for this forward (+ its backward) only: ops.operand_planes
     ids32, lens = build_ids(model, all_token_ids)
     require_gpu(ids32, "token ids")
     B, N = ids32.shape
@@ -627,6 +628,8 @@ def run_forward(model, all_token_ids, self_attn_mask, only_final: bool, save: bo
     if save:
         st = ForwardState()
         st.model, st.pw, st.ids32, st.lay, st.trunk, st.y, st.B, st.N, st.logits = model, pw, ids32, lay, tsaved, y, B, N, logits
+    else:
+        ops.planes_end()
     return logits, lay, st
 
 
@@ -636,6 +639,7 @@ def run_backward(st: ForwardState, dlogits: Sequence[Optional[torch.Tensor]]):
     alpha = float(model.transformer.grad_shrink_alpha)
     dx = trunk_backward(model.transformer, st.pw, st.trunk, dy, st.B, st.N, out_scale=alpha)
     embed_backward(model, st.ids32, st.lay, dx, 1.0)
+    ops.planes_end()
 
 
 def logits_views(model, lay: SeqLayout, bufs):

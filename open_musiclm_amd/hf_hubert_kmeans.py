@@ -31,7 +31,7 @@ class KmeansAssigner(nn.Module):
             self._cT = self.centroids.t().contiguous()                              # [D, C]
         feats = feats.contiguous().float()
         idx = torch.empty(feats.shape[0], 1, dtype=torch.int32, device=feats.device)
-        ops.rvq_encode(feats, self._cT, idx, None, feats.shape[0], feats.shape[1], self.centroids.shape[0], 1)
+        ops.nearest_centroid(feats, self._cT, idx, feats.shape[0], feats.shape[1], self.centroids.shape[0])
         return idx[:, 0].long()
 
 

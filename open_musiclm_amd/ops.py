@@ -37,29 +37,50 @@ def _chk(t: torch.Tensor, name: str):
 
 # ---- bf16x3 through the bf16 tile kernels: fp32 operands are split once into bf16 hi / lo planes (omlm_split_planes) and the
 # three products run as ONE GEMM with a 3x longer k-loop (omlm_gemm_planes).  The register-staged fp32 kernel measured 169
-# TFLOP/s fp32-equivalent on the trunk shapes; the plane form runs at a third of the bf16 kernels' ~1 PFLOP/s.  Planes are cached
-# per tensor OBJECT (weak reference + version counter), so an activation feeding several GEMMs (forward, input gradient, weight
-# gradient) is split once.  OMLM_X3_PLANES=0 keeps every fp32 GEMM on the register-staged kernel.
+# TFLOP/s fp32-equivalent on the trunk shapes; the plane form runs at a third of the bf16 kernels' ~1 PFLOP/s.
+# Planes are cached ONLY inside a plane scope (planes_begin .. planes_end: one forward + its backward, opened by the engine), so an
+# activation feeding its forward, input-gradient and weight-gradient GEMMs is split once -- and nothing survives the scope: the
+# kernels (and the fused optimizer) write tensors through raw pointers without bumping torch's version counter, so a cache that
+# outlives the step would hand out planes of last step's weights (a captured HIP graph would additionally have lost the split
+# launches: they ran during the eager warm-up).  Every scope starts empty, i.e. the split kernels of a captured micro-step are part
+# of its graph and read the current weights on every replay.  Outside a scope (direct ops.gemm calls) nothing is cached.
+# OMLM_X3_PLANES=0 keeps every fp32 GEMM on the register-staged kernel.
 _X3_PLANES = os.environ.get("OMLM_X3_PLANES", "1") == "1"
 _X3_MIN_MACS = 1 << 26
 _PLANES = {}
+_PLANE_SCOPE = [0]                 # > 0 while the engine sequences a forward / backward
+
+
+def planes_begin():
+    """Open a plane scope (engine.run_forward): the cache starts empty."""
+    _PLANES.clear()
+    _PLANE_SCOPE[0] = 1
+
+
+def planes_end():
+    """Close the scope (end of the backward, or of a forward that saves nothing): every cached plane is dropped."""
+    _PLANES.clear()
+    _PLANE_SCOPE[0] = 0
 
 
 def operand_planes(t: torch.Tensor, rows: int, ld: int):
     """(planes buffer, byte distance hi -> lo) for the fp32 region rows x ld at t's data pointer."""
     n = int(rows) * int(ld)
     key = id(t)
-    ent = _PLANES.get(key)
-    if ent is not None and ent[0]() is t and ent[1] == t._version and ent[2] == (t.data_ptr(), n):
-        return ent[3], ent[4]
+    scoped = _PLANE_SCOPE[0] > 0
+    if scoped:
+        ent = _PLANES.get(key)
+        if ent is not None and ent[0]() is t and ent[1] == t._version and ent[2] == (t.data_ptr(), n):
+            return ent[3], ent[4]
     pe = (n + 7) // 8 * 8
     buf = torch.empty(2 * pe, dtype=torch.bfloat16, device=t.device)
     call("omlm_split_planes", ptr(t), ptr(buf), n, pe, stream_ptr())
-    try:
-        ref = weakref.ref(t, lambda _r, k=key: _PLANES.pop(k, None))
-        _PLANES[key] = (ref, t._version, (t.data_ptr(), n), buf, pe * 2)
-    except TypeError:
-        pass
+    if scoped:
+        try:
+            ref = weakref.ref(t, lambda _r, k=key: _PLANES.pop(k, None))
+            _PLANES[key] = (ref, t._version, (t.data_ptr(), n), buf, pe * 2)
+        except TypeError:
+            pass
     return buf, pe * 2
 
 
@@ -349,13 +370,19 @@ def bias_add(a, b, out, R, C_, ld):
 
 
 def rvq_encode(x, codebooks_T, indices, residual_out, n, D, C_, nstage, idx_stride=None):
-    """indices: int32 [n, nstage] (or, with nstage == 1, any int32 view whose rows are idx_stride elements apart)."""
+    """Residual-VQ chain in the library's distance form (-cdist, first maximum; csrc/optim_misc.hip FORM_CDIST).
+    indices: int32 [n, nstage] (or, with nstage == 1, any int32 view whose rows are idx_stride elements apart)."""
     if idx_stride is None or idx_stride == nstage:
         call("omlm_rvq_encode", ptr(x), ptr(codebooks_T), ptr(indices), ptr(residual_out), n, D, C_, nstage, stream_ptr())
     else:
         assert nstage == 1
         call("omlm_rvq_encode_strided", ptr(x), ptr(codebooks_T), ptr(indices), int(idx_stride), ptr(residual_out), n, D, C_,
              stream_ptr())
+
+
+def nearest_centroid(x, centroids_T, indices, n, D, C_):
+    """k-means assign (sklearn MiniBatchKMeans.predict, hf_hubert_kmeans.py:87): squared-difference form; indices int32 [n]."""
+    call("omlm_nearest_centroid", ptr(x), ptr(centroids_T), ptr(indices), n, D, C_, stream_ptr())
 
 
 def vq_accumulate(x, indices, idx_stride, counts, sums, n, D, K):

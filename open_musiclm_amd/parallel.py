@@ -30,8 +30,11 @@ class DataParallel:
                 # gloo exchange) shares devices round-robin -- RCCL itself refuses two ranks on one GPU
                 torch.cuda.set_device(self.local_rank % max(torch.cuda.device_count(), 1))
             backend = backend or os.environ.get("OMLM_DP_BACKEND") or ("nccl" if use_cuda else "gloo")
-            # the host driver only supports dmabuf IPC: without this RCCL's buffer exchange fails with hipIpcGetMemHandle errors
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            # HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC; the HSA runtime reads it when it initialises) is exported at package import
+            # (open_musiclm_amd/__init__.py): too late here, the model is already on the GPU.  Fail loudly if something overrode it.
+            if backend == "nccl" and os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0") != "0":
+                raise RuntimeError("HSA_ENABLE_IPC_MODE_LEGACY must be 0 for RCCL on this platform (dmabuf IPC only); "
+                                   "export it in the launch environment")
             dist.init_process_group(backend=backend,
                                     rank=self.rank, world_size=self.world_size)
             self.owns_group = True

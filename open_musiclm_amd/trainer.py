@@ -45,6 +45,25 @@ def cycle(dl, sampler=None):
         epoch += 1
 
 
+def _rank_sampler(dp, ds):
+    """DistributedSampler over `ds` for this rank, or None in a single process."""
+    if not dp.is_distributed:
+        return None
+    from torch.utils.data.distributed import DistributedSampler
+    return DistributedSampler(ds, num_replicas=dp.world_size, rank=dp.rank, shuffle=True)
+
+
+def _gather_rows(dp, t: torch.Tensor) -> torch.Tensor:
+    """all-gather of [rows, d] along dim 0; a gloo group (CPU collectives) gets the tensor on the host and returns it to its device."""
+    if not dp.is_distributed:
+        return t
+    import torch.distributed as dist
+    dev = t.device
+    if dist.get_backend() == "gloo" and dev.type != "cpu":
+        return dp.all_gather_cat(t.cpu().contiguous()).to(dev)
+    return dp.all_gather_cat(t.contiguous())
+
+
 def yes_or_no(question):
     if not sys.stdin or not sys.stdin.isatty():       # non-interactive launch (torchrun, CI): keep existing results
         return False
@@ -411,9 +430,12 @@ class ClapRVQTrainer(nn.Module):
         else:
             self.valid_ds = self.ds
             self.print(f'training with shared training and valid dataset of {len(self.ds)} samples')
-        self.dl = get_dataloader(self.ds, batch_size=batch_size, shuffle=True)
+        # every rank draws ITS shard of the data (what accelerator.prepare(dl) gives the reference, trainer.py:664-669): with plain
+        # shuffle=True loaders identically seeded ranks would all contribute the same batches to the gather below
+        sampler = _rank_sampler(self.dp, self.ds)
+        self.dl = get_dataloader(self.ds, batch_size=batch_size, shuffle=sampler is None, sampler=sampler)
         self.valid_dl = get_dataloader(self.valid_ds, batch_size=batch_size, shuffle=True)
-        self.dl_iter, self.valid_dl_iter = cycle(self.dl), cycle(self.valid_dl)
+        self.dl_iter, self.valid_dl_iter = cycle(self.dl, sampler), cycle(self.valid_dl)
         self.save_model_every, self.save_results_every = save_model_every, save_results_every
         self.results_folder = Path(results_folder)
         if self.is_main and len([*self.results_folder.glob('**/*')]) > 0 and \
@@ -461,7 +483,7 @@ class ClapRVQTrainer(nn.Module):
         iters = default(self.accumulate_batches, 1)
         iters = -(-iters // self.dp.world_size)
         embeds = torch.cat([self._embed(next(self.dl_iter)) for _ in range(iters)], dim=0)
-        embeds = self.dp.all_gather_cat(embeds.contiguous())
+        embeds = _gather_rows(self.dp, embeds)
         logs = {}
         if self.is_main:
             loss = self.audio_conditioner.quantize(embeds, return_rvq_loss=True)
@@ -512,8 +534,9 @@ class HfHubertKmeansTrainer(nn.Module):
                                    target_sample_hz=hubert_kmeans.target_sample_hz, seq_len_multiple_of=hubert_kmeans.seq_len_multiple_of,
                                    ignore_files=default(ignore_files, []), ignore_load_errors=ignore_load_errors)
         self.print(f'training on {feature_extraction_num_steps * feature_extraction_batch_size} out of {len(self.ds)} samples')
-        self.dl = get_dataloader(self.ds, batch_size=feature_extraction_batch_size, shuffle=True)
-        self.dl_iter = cycle(self.dl)
+        sampler = _rank_sampler(self.dp, self.ds)                            # per-rank shard (trainer.py:812-815 in the reference)
+        self.dl = get_dataloader(self.ds, batch_size=feature_extraction_batch_size, shuffle=sampler is None, sampler=sampler)
+        self.dl_iter = cycle(self.dl, sampler)
         self.results_folder = Path(results_folder)
         if self.is_main and len([*self.results_folder.glob('**/*')]) > 0 and \
                 yes_or_no('do you want to clear previous experiment checkpoints and results?'):
@@ -552,10 +575,11 @@ class HfHubertKmeansTrainer(nn.Module):
             embed = item.float()
             embed = embed.reshape(-1, embed.shape[-1])                       # 'b t f -> (b t) f'
         else:
-            embed = self.hubert_kmeans.forward(wav_input=item, return_embed=True)
+            dev = next(self.hubert_kmeans.parameters(), item).device       # the waveform goes to the extractor's device
+            embed = self.hubert_kmeans.forward(wav_input=item.to(dev), return_embed=True)
             embed = embed.reshape(-1, embed.shape[-1])
-        embed = self.dp.all_gather_cat(embed.contiguous())
-        return embed.detach().cpu().numpy()
+        embed = _gather_rows(self.dp, embed.detach())
+        return embed.cpu().numpy()
 
     def train(self, log_fn=noop, seed=0, **kmeans_kwargs):
         from .hf_hubert_kmeans import learn_kmeans

@@ -220,13 +220,17 @@ def make_kmeans_case(name):
 
 
 def make_rvq_case(name):
-    # PARITY UNPINNED: no reference fixture, library not installed. Self-consistency vector only.
-    rng = np.random.RandomState(1)
-    cb = rng.randn(4, 64, 32).astype(np.float32)
-    x = rng.randn(16, 32).astype(np.float32)
-    idx = O.rvq_encode(x, cb)
+    """RVQ pin: the reference's arithmetic lives in the un-vendored vector-quantize-pytorch (`argmax(-cdist(x, embed))`), so the
+    fixture's ids are written by torch.cdist ITSELF on exactly representable inputs (tests/rvq_cases.py: on those every summation
+    order gives the same bits, so the ids are a property of the distance form)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+    import rvq_cases as RC
+    x, cb, info = RC.exact_rvq_case(24, 64, 24, 4, seed=1)       # both sides <= 25 rows: cdist's direct path, root-merged row included
+    idx = RC.cdist_chain(x, cb)
+    RC.check_engineered(idx, info)
+    assert np.array_equal(O.rvq_encode(x, cb), idx)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), x=x, codebooks=cb, indices=idx)
-    print(f"[{name}] rvq self-consistency vector written (parity unpinned)")
+    print(f"[{name}] rvq fixture written: ids by torch.cdist, oracle agrees bit for bit")
 
 
 def check_full_size(ref):
@@ -272,7 +276,7 @@ def main():
                     lengths=[1, 21], batch=3, seed=3, loss_weights=[0., 1.],
                     spec_kw=dict(use_conv_ff=False, relative_position_bias_type="t5"))
     make_kmeans_case("kmeans_assign")
-    make_rvq_case("rvq_selfcheck")
+    make_rvq_case("rvq_cdist_pin")
     if os.environ.get("GOLDEN_FULL", "1") == "1":
         check_full_size(ref)
 

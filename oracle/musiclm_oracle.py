@@ -484,7 +484,8 @@ def generate(sd: Dict[str, Tensor], spec: ModelSpec, conditioning_ids: Sequence[
 def nearest_code(x: np.ndarray, codebook: np.ndarray) -> np.ndarray:
     """argmin_c sum_d (x_d - e_{c,d})^2 in fp32, d accumulated in index order
     with one fp32 rounding per add (no FMA contraction), ties -> lowest index.
-    This is the *stated* definition the HIP kernel is bit-exact against."""
+    The k-means assign form (kmeans_assign below): pinned bit for bit against
+    sklearn.MiniBatchKMeans.predict (tests/golden/kmeans_assign.npz and at 768 x 1024)."""
     x = np.ascontiguousarray(x, dtype=np.float32)
     cb = np.ascontiguousarray(codebook, dtype=np.float32)
     n, d = x.shape
@@ -495,16 +496,49 @@ def nearest_code(x: np.ndarray, codebook: np.ndarray) -> np.ndarray:
     return dist.argmin(axis=1).astype(np.int64)
 
 
+def cdist_form(x: np.ndarray, codebook: np.ndarray) -> np.ndarray:
+    """[n, C] fp32 distances in the form of vector-quantize-pytorch's EuclideanCodebook (`dist = -cdist(flatten, embed)`
+    -- torch.cdist in the 1.2-1.5 releases, the library's own expanded-form `cdist` later; setup.py:31 allows both):
+
+        dist(c) = sqrt(max((x2 + e2_c) - 2 * xy_c, 0)),   x2 = sum_d x_d^2,  e2_c = sum_d e_{c,d}^2,  xy_c = sum_d x_d e_{c,d}
+
+    every product and sum rounded to fp32 separately, d in index order (the summation order of a BLAS is its own; on
+    inputs whose products and partial sums are exactly representable -- the pinning tests -- every order gives these bits)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    cb = np.ascontiguousarray(codebook, dtype=np.float32)
+    n, d = x.shape
+    x2 = np.zeros((n, 1), dtype=np.float32)
+    e2 = np.zeros((1, cb.shape[0]), dtype=np.float32)
+    xy = np.zeros((n, cb.shape[0]), dtype=np.float32)
+    for j in range(d):
+        xj, ej = x[:, j:j + 1], cb[None, :, j]
+        x2 = (x2 + (xj * xj).astype(np.float32)).astype(np.float32)
+        e2 = (e2 + (ej * ej).astype(np.float32)).astype(np.float32)
+        xy = (xy + (xj * ej).astype(np.float32)).astype(np.float32)
+    d2 = ((x2 + e2).astype(np.float32) - (np.float32(2.0) * xy).astype(np.float32)).astype(np.float32)
+    return np.sqrt(np.maximum(d2, np.float32(0.0))).astype(np.float32)
+
+
+def nearest_code_cdist(x: np.ndarray, codebook: np.ndarray) -> np.ndarray:
+    """The library's pick: argmax_c of -cdist_form (torch.argmax: first maximum) == first minimum of the distance.
+    The square root is part of the definition: distances that round to the same root are a tie for the lowest index."""
+    return cdist_form(x, codebook).argmin(axis=1).astype(np.int64)
+
+
 def rvq_encode(x: np.ndarray, codebooks: np.ndarray) -> np.ndarray:
     """Residual VQ eval path (clap_quantized.py:75-87 -> ResidualVQ.forward, third-party,
-    un-vendored: vector-quantize-pytorch>=1.2.2, setup.py:31).  PARITY UNPINNED.
+    un-vendored: vector-quantize-pytorch>=1.2.2, setup.py:31): per stage the code nearest to the running residual in
+    the library's distance form (nearest_code_cdist), then r <- r - e_idx.  Pinned against torch.cdist (an installed
+    third-party implementation of that form) on exactly-representable inputs incl. engineered ties and root-merged
+    near-ties (tests/test_oracle_golden.py); on general fp32 inputs the ids of any two implementations -- the library on
+    two BLAS back ends included -- differ wherever the summation order decides a near-tie.
 
     codebooks: [n_q, codebook_size, dim].  Returns indices [n, n_q] (the reference
     then rearranges 'n 1 c -> n c 1', :86)."""
     r = np.ascontiguousarray(x, dtype=np.float32).copy()
     out = np.zeros((r.shape[0], codebooks.shape[0]), dtype=np.int64)
     for s in range(codebooks.shape[0]):
-        idx = nearest_code(r, codebooks[s])
+        idx = nearest_code_cdist(r, codebooks[s])
         out[:, s] = idx
         r = (r - codebooks[s][idx].astype(np.float32)).astype(np.float32)
     return out
@@ -522,7 +556,7 @@ def rvq_fit_step(state: Dict[str, Tensor], x: Tensor, *, decay: float = 0.95, ep
       per layer, on the running residual r:
         first batch: k-means (initial means = `init_picks[s]` rows of r -- the library draws randperm(n)[:K]; Lloyd iterations
                      keep a mean whose bucket is empty), embed = means, cluster_size = bucket counts, embed_avg = embed * counts
-        idx = nearest code (squared distance, ties -> lowest index: nearest_code above);  q = embed[idx]  (codes BEFORE the update)
+        idx = nearest code (the library's -cdist form, first maximum: nearest_code_cdist above);  q = embed[idx]  (codes BEFORE the update)
         EMA:  cluster_size <- d cs + (1-d) counts;  embed_avg <- d avg + (1-d) sums;
               embed <- embed_avg / ((cs + eps) / (sum cs + K eps) * sum cs)
         dead codes (threshold_dead > 0): codes with cs < threshold are re-seeded from rows `expire_picks[s]` of r, cs <- threshold,
@@ -540,7 +574,7 @@ def rvq_fit_step(state: Dict[str, Tensor], x: Tensor, *, decay: float = 0.95, ep
     qsum = torch.zeros_like(r)
 
     def bucket(rr, codes):
-        idx = torch.from_numpy(nearest_code(rr.numpy(), codes.numpy()))
+        idx = torch.from_numpy(nearest_code_cdist(rr.numpy(), codes.numpy()))
         counts = torch.bincount(idx, minlength=K).to(torch.float32)
         sums = torch.zeros(K, D, dtype=torch.float32).index_add_(0, idx, rr)
         return idx, counts, sums

@@ -144,15 +144,32 @@ def test_gemm_fp32_on_operand_planes(ops, dev, M, N, K, akm, bkm, accumulate):
     e_planes, e_reg, e_ab = relerr(outs[0], ref), relerr(outs[1], ref), relerr(outs[0], outs[1])
     report(f"gemm_planes[{M},{N},{K},{akm},{bkm}]", planes=e_planes, register_staged=e_reg, ab=e_ab)
     assert not torch.isnan(outs[0]).any() and e_planes < 2e-5 and e_reg < 2e-5 and e_ab < 2e-5
-    # the plane cache: a second GEMM on the same tensor objects must not split again, a modified operand must
-    n_before = len(ops._PLANES)
+    # the plane cache lives only inside a scope (engine: one forward + its backward).  Outside: nothing is cached, so a tensor that a
+    # kernel rewrote through its raw pointer (no version bump) is split again; inside: one split per tensor, a torch in-place op
+    # (version bump) re-splits, and closing the scope drops everything.
+    kw = dict(M=M, N=N, K=Kcall, a_kmajor=akm, b_kmajor=bkm, a_rows=K if akm else M, b_rows=K if bkm else N)
+    assert len(ops._PLANES) == 0
     C2 = torch.empty(M, N, device=dev)
-    ops.gemm(A, B, C2, M=M, N=N, K=Kcall, a_kmajor=akm, b_kmajor=bkm, a_rows=K if akm else M, b_rows=K if bkm else N)
-    assert len(ops._PLANES) == n_before
-    A.mul_(2.0)
+    ops.gemm(A, B, C2, **kw)
+    assert len(ops._PLANES) == 0
+    ops.cast_pad((2.0 * A).contiguous(), A, A.shape[0], A.shape[1], A.shape[1], A.shape[1])      # raw-pointer rewrite of A (fp32 -> fp32 copy)
     C3 = torch.empty(M, N, device=dev)
-    ops.gemm(A, B, C3, M=M, N=N, K=Kcall, a_kmajor=akm, b_kmajor=bkm, a_rows=K if akm else M, b_rows=K if bkm else N)
+    ops.gemm(A, B, C3, **kw)
     assert relerr(C3, 2.0 * C2) < 2e-5
+    ops.planes_begin()
+    try:
+        ops.gemm(A, B, C3, **kw)
+        n_in = len(ops._PLANES)
+        assert n_in == 2
+        ops.gemm(A, B, C3, **kw)
+        assert len(ops._PLANES) == n_in
+        A.mul_(0.5)
+        C4 = torch.empty(M, N, device=dev)
+        ops.gemm(A, B, C4, **kw)
+        assert relerr(C4, C2) < 2e-5
+    finally:
+        ops.planes_end()
+    assert len(ops._PLANES) == 0
 
 
 def test_gemm_row_maps_and_bf16_out(ops, dev):
@@ -672,12 +689,12 @@ def test_rvq_and_kmeans_bit_exact(ops, dev, golden_dir):
     idx = torch.empty(33, 12, dtype=torch.int32, device=dev)
     res = torch.empty(33, 512, device=dev)
     ops.rvq_encode(torch.from_numpy(x).to(dev), cbT, idx, res, 33, 512, 256, 12)
-    assert np.array_equal(idx.cpu().numpy().astype(np.int64), exp)           # bit-exact ids (stated definition)
+    assert np.array_equal(idx.cpu().numpy().astype(np.int64), exp)           # bit-exact ids vs the oracle's fixed-order -cdist form
     z = np.load(os.path.join(golden_dir, "kmeans_assign.npz"))
     cT = torch.from_numpy(z["centroids"]).to(dev).t().contiguous()
-    out = torch.empty(len(z["x"]), 1, dtype=torch.int32, device=dev)
-    ops.rvq_encode(torch.from_numpy(z["x"]).to(dev), cT, out, None, len(z["x"]), z["x"].shape[1], cT.shape[1], 1)
-    assert np.array_equal(out[:, 0].cpu().numpy().astype(np.int64), z["assign"])   # == sklearn predict fixture
+    out = torch.empty(len(z["x"]), dtype=torch.int32, device=dev)
+    ops.nearest_centroid(torch.from_numpy(z["x"]).to(dev), cT, out, len(z["x"]), z["x"].shape[1], cT.shape[1])
+    assert np.array_equal(out.cpu().numpy().astype(np.int64), z["assign"])   # == sklearn predict fixture
     # ties -> lowest index; duplicated codeword
     cb2 = np.repeat(rng.randn(1, 4, 8).astype(np.float32), 1, axis=0)
     cb2[0, 3] = cb2[0, 1]
@@ -685,7 +702,33 @@ def test_rvq_and_kmeans_bit_exact(ops, dev, golden_dir):
     i2 = torch.empty(1, 1, dtype=torch.int32, device=dev)
     ops.rvq_encode(torch.from_numpy(x2).to(dev), torch.from_numpy(cb2).to(dev).transpose(1, 2).contiguous(), i2, None, 1, 8, 4, 1)
     assert int(i2) == 1
+    zz = np.load(os.path.join(golden_dir, "rvq_cdist_pin.npz"))              # ids written by torch.cdist (oracle/make_golden.py)
+    cq = torch.from_numpy(zz["codebooks"]).to(dev).transpose(1, 2).contiguous()
+    i3 = torch.empty(zz["indices"].shape, dtype=torch.int32, device=dev)
+    ops.rvq_encode(torch.from_numpy(zz["x"]).to(dev), cq, i3, None, *zz["x"].shape, zz["codebooks"].shape[1], zz["codebooks"].shape[0])
+    assert np.array_equal(i3.cpu().numpy().astype(np.int64), zz["indices"])
     report("rvq_kmeans", exact=True)
+
+
+def test_rvq_ids_bit_exact_against_torch_cdist_at_real_dims(ops, dev):
+    """The pin of SURVEY 8a row 16: ClapQuantized.quantize's ids (clap_quantized.py:75-87 -> vector-quantize-pytorch's
+    `argmax(-cdist(x, embed))`) from the HIP kernel against torch.cdist ITSELF at the shipped dimensions -- 512-d, 1024 codes, 12
+    residual stages, 10240 rows -- on exactly representable inputs (tests/rvq_cases.py: every summation order gives the same bits, so
+    the ids are a property of the distance form), with engineered exact ties and the root-merged near-tie.  0 flips allowed."""
+    import rvq_cases as RC
+    from open_musiclm_amd.clap_quantized import ClapQuantized
+    n, D, K, S = 10240, 512, 1024, 12
+    x, cb, info = RC.exact_rvq_case(n, D, K, S, seed=21)
+    want = RC.cdist_chain(x, cb)
+    cq = ClapQuantized(clap=None, codebook_size=K, rq_num_quantizers=S, embed_dim=D).to(dev)
+    cq.rq.codebooks.copy_(torch.from_numpy(cb))
+    got = cq.quantize(torch.from_numpy(x).to(dev))[..., 0].cpu().numpy()
+    rows = info["torch_rows"]
+    flips = int((got[rows] != want[rows]).any(1).sum())
+    report("rvq_vs_torch_cdist", rows=len(rows), stages=S, flipped_rows=flips)
+    assert flips == 0
+    RC.check_engineered(got, info)
+    assert np.array_equal(RC.expanded_chain(x, cb)[rows], want[rows])
 
 
 def test_kmeans_assign_real_dims_vs_sklearn(ops, dev):

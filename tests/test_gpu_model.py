@@ -478,6 +478,57 @@ def test_trainer_steps_and_checkpoint_roundtrip(dev, tmp_path):
     assert int(tr.steps.item()) == 6
 
 
+def test_graphed_bf16x3_training_tracks_eager_over_optimizer_steps(dev):
+    """bf16x3 at a size where the fp32 GEMMs take the hi/lo-plane route (M N K >= ops._X3_MIN_MACS), captured into a HIP graph,
+    over several optimizer steps: the replayed micro-step must read the CURRENT weights -- the planes of the persistent Parameter
+    objects (Wq / Wkv / Wo) are split inside the graph, not left over from the eager warm-up -- so its losses and final weights
+    track an eager run from the same start.  (lr is large so that stale projection weights would show within two steps.)"""
+    from open_musiclm_amd import open_musiclm as M
+    from open_musiclm_amd import ops
+    from open_musiclm_amd.graph import GraphedForwardBackward
+    from open_musiclm_amd.optimizer import get_optimizer
+    B, n_sem, n_coarse = 2, 199, 128
+    g = torch.Generator().manual_seed(3)
+    batches = [[torch.randint(0, 1024, (B, 12, 1), generator=g).to(dev), torch.randint(0, 1024, (B, n_sem), generator=g).to(dev),
+                torch.randint(0, 1024, (B, n_coarse, 3), generator=g).to(dev)] for _ in range(4)]
+    keys = ("clap_token_ids", "semantic_token_ids", "coarse_token_ids")
+    assert B * (3 + 13 + n_sem + 1 + 3 * n_coarse) * 256 * 256 >= ops._X3_MIN_MACS        # the to_q / to_out GEMMs are on the plane route
+
+    def run(use_graph):
+        torch.manual_seed(0)
+        model = M.create_coarse_transformer(dim=256, depth=2, heads=4, num_coarse_quantizers=3, ff_dropout=0.0,
+                                            precision="bf16x3").to(dev)
+        stage = M.CoarseStage(coarse_transformer=model, cross_entropy_loss_weights=[0., 0., 1.], mask_prob=0.0)
+        stage.train()
+        opt = get_optimizer(model.parameters(), lr=3e-3, wd=0.01)
+        opt.zero_grad()
+        fb = GraphedForwardBackward(lambda **kw: stage(**kw, return_loss=True)[0], enabled=use_graph, instances=1)
+
+        def discard():
+            opt.mark_grads_dirty()
+            opt.zero_grad()
+        fb.prepare(dict(zip(keys, batches[0])), after_warmup=discard)
+        assert (fb.graph is not None) == use_graph, fb.capture_error
+        losses = []
+        for k in range(4):
+            opt.zero_grad()
+            loss = fb(**dict(zip(keys, batches[k])))
+            opt.mark_grads_dirty()
+            opt.step(max_grad_norm=0.5)
+            losses.append(float(loss))
+        import gc
+        gc.unfreeze()
+        return losses, model.transformer.layers[0][0].to_q.weight.detach().clone(), model.transformer.layers[1][0].to_out[0].weight.detach().clone()
+
+    le, wq_e, wo_e = run(False)
+    lg, wq_g, wo_g = run(True)
+    report("graph_bf16x3_vs_eager", eager=le, graphed=lg)
+    assert le[0] != le[-1]
+    for a, b in zip(le, lg):
+        assert abs(a - b) <= 2e-4 * abs(a), (le, lg)
+    assert relerr(wq_g, wq_e) < 1e-3 and relerr(wo_g, wo_e) < 1e-3
+
+
 def test_musiclm_hierarchical_decode_tokens(dev):
     """MusicLM.forward window stitching on tiny stages: shapes of the 3-level token hierarchy."""
     from open_musiclm_amd import open_musiclm as M

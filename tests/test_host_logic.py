@@ -391,6 +391,20 @@ def test_rvq_checkpoint_layout_roundtrip():
     for name in ("codebooks", "embed_avg", "cluster_size", "initted"):
         assert torch.equal(getattr(other.rq, name), getattr(cq.rq, name)), name
     assert other.rq.decay == 0.95 and cq.rq.decay == 0.9 and cq.rq.threshold_ema_dead_code == 0.5
+    # the enclosing module round-trips too (strict), with the library's keys under the "rq." prefix
+    full = cq.state_dict()
+    assert "rq.layers.2._codebook.embed_avg" in full and not any(k.startswith("rq.codebooks") for k in full)
+    third = ClapQuantized(clap=None, codebook_size=16, rq_num_quantizers=3, embed_dim=8)
+    res = third.load_state_dict(full, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    for name in ("codebooks", "embed_avg", "cluster_size", "initted"):
+        assert torch.equal(getattr(third.rq, name), getattr(cq.rq, name)), name
+    with pytest.raises(RuntimeError):                       # a key of neither layout is reported by a strict load
+        third.load_state_dict({**full, "rq.layers.0._codebook.bogus": torch.zeros(1)}, strict=True)
+    own = {"codebooks": cq.rq.codebooks.clone(), "embed_avg": cq.rq.embed_avg.clone(), "cluster_size": cq.rq.cluster_size.clone()}
+    fourth = ClapQuantized(clap=None, codebook_size=16, rq_num_quantizers=3, embed_dim=8)
+    fourth.rq.load_state_dict(own)                          # round-1 checkpoints (this module's buffer names) still load
+    assert torch.equal(fourth.rq.codebooks, cq.rq.codebooks) and bool(fourth.rq.initted.all())
     with pytest.raises(RuntimeError):                       # fitting runs on the device only: no CPU fallback
         cq.learn_rvq = True
         cq.quantize(torch.randn(4, 8))

@@ -80,19 +80,28 @@ def test_oracle_kmeans_matches_sklearn_fixture(golden_dir):
     assert np.array_equal(O.kmeans_assign(z["x"], z["centroids"]), z["assign"])
 
 
-def test_oracle_rvq_selfcheck(golden_dir):
-    # PARITY UNPINNED (no reference fixture exists): only guards the restatement against drift.
-    z = np.load(os.path.join(golden_dir, "rvq_selfcheck.npz"))
-    idx = O.rvq_encode(z["x"], z["codebooks"])
-    assert np.array_equal(idx, z["indices"])
-    # definition check in fp64: every chosen code is a nearest code of the running residual
-    r = z["x"].astype(np.float64)
-    for s_ in range(z["codebooks"].shape[0]):
-        cb = z["codebooks"][s_].astype(np.float64)
-        d = ((r[:, None, :] - cb[None]) ** 2).sum(-1)
-        chosen = d[np.arange(len(r)), idx[:, s_]]
-        assert np.all(chosen <= d.min(axis=1) + 1e-4)
-        r = r - cb[idx[:, s_]]
+def test_oracle_rvq_pinned_against_torch_cdist(golden_dir):
+    """The RVQ pick is vector-quantize-pytorch's `argmax(-cdist(x, embed))` (clap_quantized.py:38-46,75-87; library un-vendored).
+    On exactly representable inputs (tests/rvq_cases.py) the ids are a property of the FORM: the oracle's fixed-order restatement
+    must equal torch.cdist's chain bit for bit at the shipped dimensions (512-d, 1024 codes, 12 stages), engineered exact ties and
+    the root-merged near-tie included -- and equal the committed fixture (ids written by torch.cdist, oracle/make_golden.py)."""
+    import rvq_cases as RC
+    z = np.load(os.path.join(golden_dir, "rvq_cdist_pin.npz"))
+    assert np.array_equal(O.rvq_encode(z["x"], z["codebooks"]), z["indices"])          # fixture = torch.cdist's ids
+    x, cb, info = RC.exact_rvq_case(96, 512, 1024, 12, seed=11)
+    rows = info["torch_rows"]                                                          # all but the root-merged row (rvq_cases)
+    want = RC.cdist_chain(x, cb)
+    assert np.array_equal(RC.expanded_chain(x, cb)[rows], want[rows])                  # both library forms agree where exact
+    got = O.rvq_encode(x, cb)
+    assert np.array_equal(got[rows], want[rows])
+    RC.check_engineered(got, info)
+    # the root-merged near-tie is what separates the forms: a squared-distance argmin picks the other code
+    assert O.nearest_code(x[:1], cb[0])[0] == info["merge_sq_id"] != info["merge_id"]
+    # small problem (torch.cdist's direct, non-GEMM path: both sides <= 25 rows)
+    xs, cbs, infos = RC.exact_rvq_case(8, 16, 24, 3, seed=5)
+    gots = O.rvq_encode(xs, cbs)
+    assert len(infos["torch_rows"]) == 8 and np.array_equal(gots, RC.cdist_chain(xs, cbs))   # root-merged row included
+    RC.check_engineered(gots, infos)
 
 
 def test_causality_prefix_property():
@@ -168,34 +177,35 @@ def test_oracle_rvq_fit_step_learns_clustered_embeddings():
     assert enc.shape == (64, S)
 
 
-def test_rvq_id_sensitivity_to_the_distance_formula_at_real_dims():
-    """The RVQ arithmetic lives in the un-vendored vector-quantize-pytorch (parity unpinned): its releases compute the code distances
-    either as -cdist(x, e) or in the expanded form -(|x|^2 - 2 x.e + |e|^2), both followed by argmax; the HIP kernel / oracle use
-    sum_d (x_d - e_d)^2 in index order.  A near-tie can flip an id between them (and the residual chain of that row then diverges).
-    This measures how often at the shipped dimensions (512-d, 1024 codes, 12 residual stages, Gaussian data): about one row in a
-    thousand -- the bound asserted here is 0.5 % of the rows, and the two library formulas agree with each other."""
-    rows_total = rows_cdist = rows_expanded = rows_between = 0
+def test_rvq_ids_on_general_inputs_differ_from_torch_only_at_near_ties():
+    """On general fp32 inputs the summation order of the GEMM inside torch.cdist is MKL's own (the library on another BLAS would
+    differ from it the same way), so ids can differ where two codes are within rounding of each other.  Measured here at the
+    shipped dimensions on Gaussian data with shrinking codebooks: every first disagreement of a row's chain must be such a
+    near-tie (both candidates within 4e-6 relative of each other in fp64), and the rows affected are counted and bounded."""
+    rows_total = rows_cdist = rows_expanded = 0
     for seed in (0, 2):
         g = torch.Generator().manual_seed(seed)
-        n, D, K, S = 384, 512, 1024, 12
+        n, D, K, S = 256, 512, 1024, 12
         x = torch.randn(n, D, generator=g)
         cb = torch.randn(S, K, D, generator=g) * torch.logspace(0, -1.2, S)[:, None, None]     # shrinking codebooks like a fitted RVQ
-
-        def chain(fn):
-            r, out = x.clone(), []
-            for s in range(S):
-                idx = fn(r, cb[s])
-                out.append(idx)
-                r = r - cb[s][idx]
-            return torch.stack(out, 1)
-        stated = chain(lambda r, e: torch.from_numpy(O.nearest_code(r.numpy(), e.numpy())))
-        cdist = chain(lambda r, e: (-torch.cdist(r[None], e[None], p=2)[0]).argmax(-1))
-        expanded = chain(lambda r, e: (-((r * r).sum(-1, keepdim=True) - 2 * r @ e.t() + (e * e).sum(-1)[None])).argmax(-1))
-        assert torch.equal(stated, torch.from_numpy(O.rvq_encode(x.numpy(), cb.numpy())))
+        import rvq_cases as RC
+        stated = torch.from_numpy(O.rvq_encode(x.numpy(), cb.numpy()))
+        for name, other in (("cdist", torch.from_numpy(RC.cdist_chain(x.numpy(), cb.numpy()))),
+                            ("expanded", torch.from_numpy(RC.expanded_chain(x.numpy(), cb.numpy())))):
+            bad = (stated != other).any(1).nonzero().flatten().tolist()
+            for row in bad:
+                s0 = int((stated[row] != other[row]).nonzero()[0])                      # first stage that differs: same residual so far
+                r = x[row].double()
+                for s in range(s0):
+                    r = r - cb[s][stated[row, s]].double()
+                da = (r - cb[s0][stated[row, s0]].double()).norm()
+                db = (r - cb[s0][other[row, s0]].double()).norm()
+                assert abs(float(da - db)) <= 4e-6 * float(da), (name, row, s0, float(da), float(db))
+            if name == "cdist":
+                rows_cdist += len(bad)
+            else:
+                rows_expanded += len(bad)
         rows_total += n
-        rows_cdist += int((stated != cdist).any(1).sum())
-        rows_expanded += int((stated != expanded).any(1).sum())
-        rows_between += int((cdist != expanded).any(1).sum())
-    print(f"rvq formula sensitivity: {rows_cdist} / {rows_expanded} of {rows_total} rows differ from the cdist / expanded forms; "
-          f"{rows_between} between the two library forms")
-    assert rows_cdist <= 0.005 * rows_total and rows_expanded <= 0.005 * rows_total
+    print(f"rvq on Gaussian data: {rows_cdist} / {rows_expanded} of {rows_total} rows differ from torch.cdist / the expanded form "
+          f"(all at near-ties)")
+    assert rows_cdist <= 0.01 * rows_total and rows_expanded <= 0.01 * rows_total

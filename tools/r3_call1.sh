@@ -58,6 +58,11 @@ run)
     tail -3 $out/pytest.log
     timeout 300 python bench.py > $out/bench.log 2> $out/bench.err || true
     tail -1 $out/bench.log
+    # kernel trace of the shipped library (profiles/r03a_kernel_stats.md, r03a_gemm_shapes.md)
+    ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pf && cd "$ROOT" && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/pf -o rf -- python bench.py --steps 5 --warmup 2 --no-decode --no-cpu-baseline --no-legs --no-graph > $out/prof.log 2>&1 ) || true
+    python tools/prof_summary.py stats /tmp/pf/rf_results.db $out/kernel_stats.md --steps 5 || true
+    python tools/prof_summary.py shapes /tmp/pf/rf_results.db $out/gemm_shapes.md gemm || true
+    head -40 $out/kernel_stats.md | cut -c1-160
     ;;
 *) echo "usage: $0 build | run"; exit 2;;
 esac
