@@ -12,8 +12,11 @@
  *   - all pointers are DEVICE pointers unless stated otherwise; the caller owns every buffer, including
  *     workspaces; the library never allocates device memory, never synchronises, never changes the device;
  *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it and the call returns at once;
- *   - dtype codes: 0 = fp32, 1 = bf16.  For GEMM / attention OPERANDS, fp32 selects the "bf16x3" split
- *     (hi*hi + hi*lo + lo*hi on the bf16 matrix cores, fp32 accumulation), bf16 the single-pass mode;
+ *   - dtype codes: 0 = fp32, 1 = bf16, 2 = fp16 (IEEE half).  For GEMM / attention OPERANDS, fp32 selects the "bf16x3" split
+ *     (hi*hi + hi*lo + lo*hi on the bf16 matrix cores, fp32 accumulation), bf16 / fp16 the single-pass modes
+ *     (v_mfma_f32_32x32x16_bf16 / _f16, same rate; precision modes "bf16x3" / "bf16" / "fp16" of the Python layer).  A call
+ *     uses ONE 16-bit type: bf16 operands give fp32 or bf16 outputs, fp16 operands fp32 or fp16 outputs.  The library holds
+ *     a bf16 and an fp16 copy of every 16-bit kernel; these entry points dispatch on the code;
  *   - row-major everywhere; "ld" = row pitch in elements.
  */
 #ifndef OMLM_H
@@ -49,7 +52,7 @@ int omlm_layernorm_fwd(const float* x, const float* gamma, void* y, void* xcast,
 long long omlm_layernorm_bwd_workspace_bytes(int D);
 int omlm_layernorm_bwd(const void* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                        const float* dres, float* dx, void* dxcast, float* dgamma, float* workspace, int M, int D,
-                       float dx_scale, int cast_dtype, int dy_dtype, void* stream);   /* dy_dtype: 0 fp32, 1 bf16 (GEMM epilogue output) */
+                       float dx_scale, int cast_dtype, int dy_dtype, void* stream);   /* dy_dtype: 0 fp32, 1 bf16 / 2 fp16 (GEMM epilogue output) */
 
 /* q/k l2-normalise * learned per-dim scale, v pass-through (transformer.py:265-271; utils.py:68-69), dim_head 64. */
 int omlm_qk_norm_fwd(const float* q_raw, const float* kv_raw, const float* q_scale, const float* k_scale,
@@ -130,7 +133,8 @@ int omlm_cross_entropy_bwd(const float* logits, const int* labels, const float* 
 int omlm_sumsq_accumulate(const float* g, long long n, float* out, float* partials, void* stream);
 int omlm_adamw_clip_step(float* p, float* g, float* m, float* v, void* p16, long long n,
                          float lr, float beta1, float beta2, float eps, float wd, int step,
-                         float gscale, const float* gnorm_sq, float max_norm, int decoupled, int zero_grad, void* stream);
+                         float gscale, const float* gnorm_sq, float max_norm, int decoupled, int zero_grad, int p16_dtype,
+                         void* stream);   /* p16 (optional): 16-bit shadow of p in p16_dtype (1 bf16 / 2 fp16); a non-finite *gnorm_sq skips the update */
 
 /* operand casts / weight repack */
 int omlm_cast_pad(const float* src, void* dst, long long R, int C, int ld_src, int ld_dst, int out_dtype, void* stream);
@@ -150,13 +154,13 @@ int omlm_gemm_planes(const void* A, long long a_plane_bytes, const void* B, long
 int omlm_split_planes(const float* x, void* planes, long long n, long long plane_elems, void* stream);
 /* All weight-gradient contractions of a backward pass in one launch (autograd of nn.Linear, transformer.py:203-212,144,149:
  * dW += dY^T X).  Problem i: C_i [M_i, N_i] fp32 (accumulated, +=; c_map optional: physical row of logical row m, < 0 skips)
- * from bf16 k-major operands A_i [K_i, M_i] (pitch lda) and B_i [K_i, N_i] (pitch ldb); pitches are multiples of 8 elements.
+ * from 16-bit k-major operands A_i [K_i, M_i] (pitch lda) and B_i [K_i, N_i] (pitch ldb); pitches are multiples of 8 elements.
  * splits: K-splits per output tile (0: chosen for whole machine rounds; > 1 accumulates with fp32 atomics). */
 typedef struct omlm_gemm_wgrad_desc {
     const void* A; const void* B; float* C; const int* c_map;
     int M, N, K, lda, ldb, ldc;
 } omlm_gemm_wgrad_desc;
-int omlm_gemm_wgrad_group(const omlm_gemm_wgrad_desc* problems, int count, int splits, void* stream);
+int omlm_gemm_wgrad_group(const omlm_gemm_wgrad_desc* problems, int count, int splits, int dtype, void* stream);   /* dtype: operands of ALL problems, 1 bf16 / 2 fp16 */
 
 /* RelativePositionBias MLP helpers (transformer.py:55-64): SiLU layers around omlm_gemm. */
 int omlm_relpos_first_fwd(const float* w0, const float* b0, float* pre, float* z, int n, int Hd, void* stream);

@@ -21,6 +21,8 @@
 #include "common.h"
 #include <stdlib.h>
 
+namespace OMLM_NS {
+
 #define AT_THREADS 256
 #define TQ 32
 #define TKV 64
@@ -48,25 +50,25 @@ __device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 
 
 // ---- global -> register fragment: 8 consecutive elements of one row as bf16 (hi, optional lo) -------------
 template <typename T, bool PRECISE>
-__device__ __forceinline__ void load_row8(const T* p, bool ok, bf16x8& hi, bf16x8& lo);
+__device__ __forceinline__ void load_row8(const T* p, bool ok, h16x8& hi, h16x8& lo);
 
 template <>
-__device__ __forceinline__ void load_row8<bf16_t, false>(const bf16_t* p, bool ok, bf16x8& hi, bf16x8& lo) {
+__device__ __forceinline__ void load_row8<h16_t, false>(const h16_t* p, bool ok, h16x8& hi, h16x8& lo) {
     u32x4 z = {0u, 0u, 0u, 0u};
     u32x4 v = ok ? *(const u32x4*)p : z;
-    hi = __builtin_bit_cast(bf16x8, v);
+    hi = __builtin_bit_cast(h16x8, v);
 }
 template <>
-__device__ __forceinline__ void load_row8<float, false>(const float* p, bool ok, bf16x8& hi, bf16x8& lo) {
+__device__ __forceinline__ void load_row8<float, false>(const float* p, bool ok, h16x8& hi, h16x8& lo) {
     float4 a = make_float4(0, 0, 0, 0), b = a;
     if (ok) { a = ((const float4*)p)[0]; b = ((const float4*)p)[1]; }
     u32x4 v;
-    v[0] = pack_bf16_rne(a.x, a.y); v[1] = pack_bf16_rne(a.z, a.w);
-    v[2] = pack_bf16_rne(b.x, b.y); v[3] = pack_bf16_rne(b.z, b.w);
-    hi = __builtin_bit_cast(bf16x8, v);
+    v[0] = pack_h16_rne(a.x, a.y); v[1] = pack_h16_rne(a.z, a.w);
+    v[2] = pack_h16_rne(b.x, b.y); v[3] = pack_h16_rne(b.z, b.w);
+    hi = __builtin_bit_cast(h16x8, v);
 }
 template <>
-__device__ __forceinline__ void load_row8<float, true>(const float* p, bool ok, bf16x8& hi, bf16x8& lo) {
+__device__ __forceinline__ void load_row8<float, true>(const float* p, bool ok, h16x8& hi, h16x8& lo) {
     float4 a = make_float4(0, 0, 0, 0), b = a;
     if (ok) { a = ((const float4*)p)[0]; b = ((const float4*)p)[1]; }
     u32x4 h, l;
@@ -75,8 +77,8 @@ __device__ __forceinline__ void load_row8<float, true>(const float* p, bool ok, 
     split_pair(a.z, a.w, h0, l0); h[1] = h0; l[1] = l0;
     split_pair(b.x, b.y, h0, l0); h[2] = h0; l[2] = l0;
     split_pair(b.z, b.w, h0, l0); h[3] = h0; l[3] = l0;
-    hi = __builtin_bit_cast(bf16x8, h);
-    lo = __builtin_bit_cast(bf16x8, l);
+    hi = __builtin_bit_cast(h16x8, h);
+    lo = __builtin_bit_cast(h16x8, l);
 }
 
 // K/V tile staging, split in two so the HBM latency of tile t+1 hides under the MFMA phase of tile t (guide T14):
@@ -84,7 +86,7 @@ __device__ __forceinline__ void load_row8<float, true>(const float* p, bool ok, 
 // A [TKV keys][64] tile is 512 chunks of 8 dims = 2 per thread; rows beyond N are zero.
 template <typename T, bool PRECISE>
 struct KVRegs {
-    bf16x8 hi[2], lo[2];
+    h16x8 hi[2], lo[2];
     __device__ __forceinline__ void load(const T* base /* row 0 of this sample, ld 64 */, int j0, int N) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -98,15 +100,15 @@ struct KVRegs {
         for (int i = 0; i < 2; ++i) {
             const int c = threadIdx.x + AT_THREADS * i;
             const int row = c >> 3, ch = c & 7;
-            *(bf16x8*)(lds_hi + tile_off(row, ch * 16)) = hi[i];
-            if (PRECISE) *(bf16x8*)(lds_lo + tile_off(row, ch * 16)) = lo[i];
+            *(h16x8*)(lds_hi + tile_off(row, ch * 16)) = hi[i];
+            if (PRECISE) *(h16x8*)(lds_lo + tile_off(row, ch * 16)) = lo[i];
         }
     }
     __device__ __forceinline__ void store_blk_hi(char* lds_hi) const {                 // blocked image of the hi plane only
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int c = threadIdx.x + AT_THREADS * i;
-            *(bf16x8*)(lds_hi + tile_off_blk(c >> 3, (c & 7) * 16)) = hi[i];
+            *(h16x8*)(lds_hi + tile_off_blk(c >> 3, (c & 7) * 16)) = hi[i];
         }
     }
     __device__ __forceinline__ void store_blk(char* lds_hi, char* lds_lo) const {      // image for frag_cols_tr
@@ -114,42 +116,42 @@ struct KVRegs {
         for (int i = 0; i < 2; ++i) {
             const int c = threadIdx.x + AT_THREADS * i;
             const int row = c >> 3, ch = c & 7;
-            *(bf16x8*)(lds_hi + tile_off_blk(row, ch * 16)) = hi[i];
-            if (PRECISE) *(bf16x8*)(lds_lo + tile_off_blk(row, ch * 16)) = lo[i];
+            *(h16x8*)(lds_hi + tile_off_blk(row, ch * 16)) = hi[i];
+            if (PRECISE) *(h16x8*)(lds_lo + tile_off_blk(row, ch * 16)) = lo[i];
         }
     }
 };
 
 // normal operand fragment: row = row0 + (lane & 31), dims 16 s + 8 (lane >> 5) .. +7
-__device__ __forceinline__ bf16x8 frag_rows(const char* lds, int row0, int s, int lane) {
-    return *(const bf16x8*)(lds + tile_off(row0 + (lane & 31), (2 * s + (lane >> 5)) * 16));
+__device__ __forceinline__ h16x8 frag_rows(const char* lds, int row0, int s, int lane) {
+    return *(const h16x8*)(lds + tile_off(row0 + (lane & 31), (2 * s + (lane >> 5)) * 16));
 }
 // transposed operand fragment from a [rows][64] tile: lane gets column (col0 + (lane & 31)) and the 8 tile rows
 // that MFMA k-index 8*(lane>>5)+e maps to under the accumulator row order:  row0 + 16 s + 8 (e>>2) + 4 (lane>>5) + (e&3)
-__device__ __forceinline__ bf16x8 frag_cols_tr(const char* lds, int row0, int s, int col0, int lane) {
+__device__ __forceinline__ h16x8 frag_cols_tr(const char* lds, int row0, int s, int col0, int lane) {
     // blocked image (tile_off_blk): both reads are linear in the lane id
     const char* base = lds + ((((row0 >> 4) + s) << 1) + (col0 >> 5)) * 1024 + lane * 8;
     s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base));
     s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base + 512));
     typedef __attribute__((ext_vector_type(8))) short s16x8;
     s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8, v);
+    return __builtin_bit_cast(h16x8, v);
 }
 
-#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#define MFMA(a, b, c) OMLM_MFMA_32x32x16(a, b, c)
 
 // pack accumulator registers 8s..8s+7 into a bf16 B-operand (RNE), optional residual (lo) operand
 template <bool PRECISE>
-__device__ __forceinline__ void pack_acc(const f32x16& p, int s, bf16x8& hi, bf16x8& lo) {
+__device__ __forceinline__ void pack_acc(const f32x16& p, int s, h16x8& hi, h16x8& lo) {
     u32x4 h, l;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const float a = p[8 * s + 2 * e], b = p[8 * s + 2 * e + 1];
         if (PRECISE) { unsigned hh, ll; split_pair(a, b, hh, ll); h[e] = hh; l[e] = ll; }
-        else h[e] = pack_bf16_rne(a, b);
+        else h[e] = pack_h16_rne(a, b);
     }
-    hi = __builtin_bit_cast(bf16x8, h);
-    if (PRECISE) lo = __builtin_bit_cast(bf16x8, l);
+    hi = __builtin_bit_cast(h16x8, h);
+    if (PRECISE) lo = __builtin_bit_cast(h16x8, l);
 }
 
 // =============================================================================================================
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(AT_THREADS) AT_FWD_OCC void attn_fwd_kernel(const T
         float* bl = bias_l + (size_t)wave * nb;
         for (int r = lane; r < nb; r += 64) bl[r] = bias ? bias[(size_t)min(r, N - 1) * bias_ld + h] * LOG2E : 0.f;
     }
-    bf16x8 qh[4], ql[4];
+    h16x8 qh[4], ql[4];
     if (active) {
 #pragma unroll
         for (int s = 0; s < 4; ++s)
@@ -269,9 +271,9 @@ __global__ __launch_bounds__(AT_THREADS) AT_FWD_OCC void attn_fwd_kernel(const T
             for (int e = 0; e < 16; ++e) st[e] = 0.f;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const bf16x8 ka = frag_rows(Kh, 32 * sub, s, lane);
+                const h16x8 ka = frag_rows(Kh, 32 * sub, s, lane);
                 if (PRECISE) {
-                    const bf16x8 kla = frag_rows(Kl, 32 * sub, s, lane);
+                    const h16x8 kla = frag_rows(Kl, 32 * sub, s, lane);
                     st = MFMA(kla, qh[s], st);
                     st = MFMA(ka, ql[s], st);
                 }
@@ -315,13 +317,13 @@ __global__ __launch_bounds__(AT_THREADS) AT_FWD_OCC void attn_fwd_kernel(const T
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                bf16x8 ph, pl;
+                h16x8 ph, pl;
                 pack_acc<PRECISE>(st, s, ph, pl);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    const bf16x8 va = frag_cols_tr(Vh, 32 * sub, s, 32 * dt, lane);
+                    const h16x8 va = frag_cols_tr(Vh, 32 * sub, s, 32 * dt, lane);
                     if (PRECISE) {
-                        const bf16x8 vla = frag_cols_tr(Vl, 32 * sub, s, 32 * dt, lane);
+                        const h16x8 vla = frag_cols_tr(Vl, 32 * sub, s, 32 * dt, lane);
                         acc[dt] = MFMA(vla, ph, acc[dt]);
                         acc[dt] = MFMA(va, pl, acc[dt]);
                     }
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(AT_D
     const size_t rowbase = (size_t)b * N;
     const size_t qrow = (rowbase + min(qi, N - 1)) * (size_t)(H * 64) + (active ? h : 0) * 64;
 
-    bf16x8 qf[4], dof[4], dummy;
+    h16x8 qf[4], dof[4], dummy;
     float dl = 0.f, L = 0.f;
     if (active) {
         for (int r = lane; r < nb; r += 64) {
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(AT_D
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            bf16x8 of;
+            h16x8 of;
             load_row8<T, false>(q + qrow + 16 * s + 8 * hi, qi < N, qf[s], dummy);
             load_row8<T, false>(dout + qrow + 16 * s + 8 * hi, qi < N, dof[s], dummy);
             // delta uses the unrounded tensors
@@ -441,7 +443,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(AT_D
 #if AT_DQ_BATCH
             {   // all eight fragment reads in flight before the first MFMA, retired in two groups: left to hipcc (at the register
                 // ceiling here) every fragment went through the same four registers, one read -> wait -> MFMA at a time (ISA)
-                bf16x8 kfr[4], vfr[4];
+                h16x8 kfr[4], vfr[4];
 #pragma unroll
                 for (int s = 0; s < 4; ++s) { kfr[s] = frag_rows(Ks, 32 * sub, s, lane); vfr[s] = frag_rows(Vs, 32 * sub, s, lane); }
 #pragma unroll
@@ -533,7 +535,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(AT_D
 #endif
 #if AT_DQ_BATCH
             {   // the four K^T fragments requested together, the packing of dS under their latency, retired pair by pair
-                bf16x8 ktf[2][2], dsb[2];
+                h16x8 ktf[2][2], dsb[2];
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(AT_D
 #else
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                bf16x8 dsb;
+                h16x8 dsb;
                 pack_acc<false>(st, s, dsb, dummy);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
@@ -624,7 +626,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(AT_D
     const size_t rowbase = (size_t)b * N;
     const size_t qrow = (rowbase + min(qi, N - 1)) * (size_t)(H * 64) + (active ? h : 0) * 64;
 
-    bf16x8 qf[4], dof[4], ql[4], dol[4], dummy;
+    h16x8 qf[4], dof[4], ql[4], dol[4], dummy;
     float dl = 0.f, L = 0.f;
     if (active) {
         for (int r = lane; r < nb; r += 64) {
@@ -633,7 +635,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(AT_D
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            bf16x8 of;
+            h16x8 of;
             load_row8<T, PRECISE>(q + qrow + 16 * s + 8 * hi, qi < N, qf[s], ql[s]);
             load_row8<T, PRECISE>(dout + qrow + 16 * s + 8 * hi, qi < N, dof[s], dol[s]);
             // delta uses the unrounded tensors
@@ -685,7 +687,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(AT_D
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 if (PRECISE) {
-                    const bf16x8 ka = frag_rows(Ks, 32 * sub, s, lane), va = frag_rows(Vs, 32 * sub, s, lane);
+                    const h16x8 ka = frag_rows(Ks, 32 * sub, s, lane), va = frag_rows(Vs, 32 * sub, s, lane);
                     st = MFMA(frag_rows(Ksl, 32 * sub, s, lane), qf[s], st);
                     st = MFMA(ka, ql[s], st);
                     st = MFMA(ka, qf[s], st);
@@ -750,7 +752,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(AT_D
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                bf16x8 dsb;
+                h16x8 dsb;
                 pack_acc<false>(st, s, dsb, dummy);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
@@ -806,7 +808,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(AT_D
     const size_t rowbase = (size_t)b * N;
     const float c = scale * LOG2E;
     const int nbk = nqt * TQ - j0;            // rel = i - kj <= nqt*TQ - 1 - j0
-    bf16x8 dummy;
+    h16x8 dummy;
     // WIN: the prepared table (omlm_attn_bias_prepare: [head][64 + rel], x log2 e, minus the head's reference point m_h) is there:
     // an item's 63 bias values are one coalesced load per lane, fetched with the item's Q / dO and parked in a 64-float LDS patch
     // per wave.  Without it the whole [H][N - j0] column set is staged below: 117 KiB for musiclm_large's fine stage
@@ -821,7 +823,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(AT_D
     }
 
     // K^T, V^T B-operands: lane n = key kj, dims 16 s + 8 hi .. +7 -- resident for the whole kernel
-    bf16x8 kf[4], vf[4];
+    h16x8 kf[4], vf[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         load_row8<T, false>(k + (rowbase + min(kj, N - 1)) * 64 + 16 * s + 8 * hi, kj < N, kf[s], dummy);
@@ -836,9 +838,9 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(AT_D
     const int nitems = (nqt - jt) * H;        // (query tile it >= jt) x head
     // A-operand fragments (rows = queries i0 + (lane&31), dims 16 s + 8 hi) of Q and dO plus the tile's lse / delta
     // (one value per lane = per query); the NEXT item's are fetched while the current item is on the matrix cores.
-    bf16x8 qa[4], doa[4], qn[4], don[4];
+    h16x8 qa[4], doa[4], qn[4], don[4];
     float La = 0.f, Da = 0.f, Ln = 0.f, Dn = 0.f, Ba = 0.f, Bn = 0.f, Ma = 0.f, Mn = 0.f;
-    auto fetch = [&](int item, bf16x8 (&fq)[4], bf16x8 (&fd)[4], float& fl, float& fdl, float& fb, float& fm) {
+    auto fetch = [&](int item, h16x8 (&fq)[4], h16x8 (&fd)[4], float& fl, float& fdl, float& fb, float& fm) {
         const int qi_ = (jt + item / H) * TQ + (lane & 31);
         const int hh = item % H;
         const size_t qrow_ = (rowbase + min(qi_, N - 1)) * (size_t)(H * 64) + hh * 64;
@@ -876,8 +878,8 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(AT_D
         if (item + 4 < nitems) fetch(item + 4, qn, don, Ln, Dn, Bn, Mn);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {        // park this item's tiles in LDS for the transpose reads
-            *(bf16x8*)(Qs + tile_off_blk(lane & 31, (2 * s + hi) * 16)) = qa[s];
-            *(bf16x8*)(dOs + tile_off_blk(lane & 31, (2 * s + hi) * 16)) = doa[s];
+            *(h16x8*)(Qs + tile_off_blk(lane & 31, (2 * s + hi) * 16)) = qa[s];
+            *(h16x8*)(dOs + tile_off_blk(lane & 31, (2 * s + hi) * 16)) = doa[s];
         }
 #if AT_LEAN
         // lean variant (see the forward): the tile's lse / delta go through a 64-float per-wave LDS patch instead of 4 v_readlane +
@@ -1000,7 +1002,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(AT_D
 #endif
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 pb, dsb;
+            h16x8 pb, dsb;
             pack_acc<false>(pp, s, pb, dummy);
             pack_acc<false>(st, s, dsb, dummy);
 #pragma unroll
@@ -1051,9 +1053,18 @@ static bool attn_v1_forced() { static int f = -1; if (f < 0) { const char* e = g
 // q [B*N, H*64], k, v [B*N, 64] (dtype), bias [N, bias_ld] fp32 (row = i - j, column = head) or null, keymask [B, N] uint8 or null (1 = attend)
 // biasT: the table prepared by omlm_attn_bias_prepare (bf16 operands take the attention2.hip kernel, which reads it; may be null
 // when bias is null).  out [B*N, H*64] (dtype), lse [B, H, N] fp32 (log2 domain)
-extern "C" int omlm_mqa_attn_fwd(const void* q, const void* k, const void* v, const float* bias, const float* biasT,
+// dtype: 0 = fp32 ("bf16x3"), 1 = bf16, 2 = fp16 (forwarded to the fp16 copy of this file; common.h)
+#if !OMLM_FP16
+extern "C" int omlm_mqa_attn_fwd_h(const void* q, const void* k, const void* v, const float* bias, const float* biasT,
+                                   const unsigned char* keymask, void* out, float* lse, int B, int N, int H, float scale,
+                                   int bias_ld, int dtype, void* stream);
+#endif
+extern "C" int OMLM_API(omlm_mqa_attn_fwd)(const void* q, const void* k, const void* v, const float* bias, const float* biasT,
                                  const unsigned char* keymask, void* out, float* lse, int B, int N, int H, float scale,
                                  int bias_ld, int dtype, void* stream) {
+#if !OMLM_FP16
+    if (dtype == OMLM_DT_F16) return omlm_mqa_attn_fwd_h(q, k, v, bias, biasT, keymask, out, lse, B, N, H, scale, bias_ld, 1, stream);
+#endif
     if (B <= 0 || N <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(q && k && v && out && lse, "null pointer");
     OMLM_CHECK_ARG(H >= 1 && (!bias || bias_ld >= H), "heads / bias pitch");
@@ -1062,13 +1073,18 @@ extern "C" int omlm_mqa_attn_fwd(const void* q, const void* k, const void* v, co
     dim3 grid((N + TQ - 1) / TQ, (H + 3) / 4, B), block(AT_THREADS);
     int rc;
     if (dtype == 0) {
+#if OMLM_FP16
+        omlm_set_error("omlm_mqa_attn_fwd: fp32 operands are served by the bf16 copy of the library");
+        return OMLM_ERR_UNSUPPORTED;
+#else
         const size_t lds = fwd_lds(N, true);
         if ((rc = set_lds(attn_fwd_kernel<float>, lds))) return rc;
         hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, block, lds, as_stream(stream), (const float*)q, (const float*)k, (const float*)v, bias, keymask, (float*)out, lse, B, N, H, scale, bias_ld);
+#endif
     } else {
         const size_t lds = fwd_lds(N, false);
-        if ((rc = set_lds(attn_fwd_kernel<bf16_t>, lds))) return rc;
-        hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, grid, block, lds, as_stream(stream), (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, bias, keymask, (bf16_t*)out, lse, B, N, H, scale, bias_ld);
+        if ((rc = set_lds(attn_fwd_kernel<h16_t>, lds))) return rc;
+        hipLaunchKernelGGL(attn_fwd_kernel<h16_t>, grid, block, lds, as_stream(stream), (const h16_t*)q, (const h16_t*)k, (const h16_t*)v, bias, keymask, (h16_t*)out, lse, B, N, H, scale, bias_ld);
     }
     return omlm_post_launch("omlm_mqa_attn_fwd");
 }
@@ -1078,10 +1094,20 @@ int attn2_bwd_dq_launch(const void* q, const void* k, const void* v, const float
                         const void* out, const void* dout, const float* lse, float* delta, float* dq, float* dbias, int bias_ld,
                         int B, int N, int H, float scale, hipStream_t st);                             // attention2.hip
 
-extern "C" int omlm_mqa_attn_bwd(const void* q, const void* k, const void* v, const float* bias, const float* biasT,
+#if !OMLM_FP16
+extern "C" int omlm_mqa_attn_bwd_h(const void* q, const void* k, const void* v, const float* bias, const float* biasT,
+                                   const unsigned char* keymask, const void* out, const void* dout, const float* lse, float* delta,
+                                   float* dq, float* dk, float* dv, float* dbias,
+                                   int B, int N, int H, float scale, int bias_ld, int dtype, void* stream);
+#endif
+extern "C" int OMLM_API(omlm_mqa_attn_bwd)(const void* q, const void* k, const void* v, const float* bias, const float* biasT,
                                  const unsigned char* keymask, const void* out, const void* dout, const float* lse, float* delta,
                                  float* dq, float* dk, float* dv, float* dbias,
                                  int B, int N, int H, float scale, int bias_ld, int dtype, void* stream) {
+#if !OMLM_FP16
+    if (dtype == OMLM_DT_F16)
+        return omlm_mqa_attn_bwd_h(q, k, v, bias, biasT, keymask, out, dout, lse, delta, dq, dk, dv, dbias, B, N, H, scale, bias_ld, 1, stream);
+#endif
     if (B <= 0 || N <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(q && k && v && out && dout && lse && delta && dq && dk && dv, "null pointer");
     dim3 gridq((N + TQ - 1) / TQ, (H + 3) / 4, B), gridk((N + 31) / 32, 1, B), block(AT_THREADS);
@@ -1096,12 +1122,17 @@ extern "C" int omlm_mqa_attn_bwd(const void* q, const void* k, const void* v, co
     int rc;
     hipStream_t st = as_stream(stream);
     if (dtype == 0) {
+#if OMLM_FP16
+        omlm_set_error("omlm_mqa_attn_bwd: fp32 operands are served by the bf16 copy of the library");
+        return OMLM_ERR_UNSUPPORTED;
+#else
         if ((rc = set_lds(attn_bwd_dq_precise_kernel<float>, ldsq))) return rc;
         if ((rc = set_lds(attn_bwd_dkv_kernel<float>, ldsk))) return rc;
         hipLaunchKernelGGL(attn_bwd_dq_precise_kernel<float>, gridq, block, ldsq, st, (const float*)q, (const float*)k, (const float*)v, bias, keymask, (const float*)out, (const float*)dout, lse, delta, dq, dbias, B, N, H, scale, bias_ld);
         hipLaunchKernelGGL(attn_bwd_dkv_kernel<float>, gridk, block, ldsk, st, (const float*)q, (const float*)k, (const float*)v, bias, keymask, (const float*)dout, lse, delta, dk, dv, B, N, H, scale, bias_ld, win ? biasT : nullptr, ldT);
+#endif
     } else {
-        if ((rc = set_lds(attn_bwd_dkv_kernel<bf16_t>, ldsk))) return rc;
+        if ((rc = set_lds(attn_bwd_dkv_kernel<h16_t>, ldsk))) return rc;
         // dQ / d(bias) / delta: the attention2.hip kernel when the prepared table is there and the sample fits its LDS plan
         int r2 = 1;
         // measured (B=32, N=1116, H=8): 334 us against 316 us for the first-generation kernel -- both spend ~160 us in the
@@ -1117,10 +1148,12 @@ extern "C" int omlm_mqa_attn_bwd(const void* q, const void* k, const void* v, co
             if (r2 < 0) return r2;
         }
         if (r2 != 0) {
-        if ((rc = set_lds(attn_bwd_dq_kernel<bf16_t>, ldsq))) return rc;
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<bf16_t>, gridq, block, ldsq, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, bias, keymask, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, dq, dbias, B, N, H, scale, bias_ld);
+        if ((rc = set_lds(attn_bwd_dq_kernel<h16_t>, ldsq))) return rc;
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<h16_t>, gridq, block, ldsq, st, (const h16_t*)q, (const h16_t*)k, (const h16_t*)v, bias, keymask, (const h16_t*)out, (const h16_t*)dout, lse, delta, dq, dbias, B, N, H, scale, bias_ld);
         }
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<bf16_t>, gridk, block, ldsk, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, bias, keymask, (const bf16_t*)dout, lse, delta, dk, dv, B, N, H, scale, bias_ld, win ? biasT : nullptr, ldT);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<h16_t>, gridk, block, ldsk, st, (const h16_t*)q, (const h16_t*)k, (const h16_t*)v, bias, keymask, (const h16_t*)dout, lse, delta, dk, dv, B, N, H, scale, bias_ld, win ? biasT : nullptr, ldT);
     }
     return omlm_post_launch("omlm_mqa_attn_bwd");
 }
+
+}   // namespace OMLM_NS

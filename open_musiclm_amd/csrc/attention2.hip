@@ -15,6 +15,8 @@
 // The arithmetic per score is: fma (scale * log2 e, bias), max, subtract, exp2, pack -- everything else is on the matrix cores.
 #include "common.h"
 
+namespace OMLM_NS {
+
 #define A2_THREADS 512
 #define A2_TKV 64
 #define A2_PAD 64            /* zero entries in front of each row of the transposed bias table (rel >= -64) */
@@ -30,7 +32,7 @@
 #define A2_ABLATE 0          /* profiling builds only: 1 = skip the tile arithmetic, 2 = skip the steady-state DMA, 4 = no exp2 */
 #endif
 
-#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#define MFMA16(a, b, c) OMLM_MFMA_32x32x16(a, b, c)
 
 // [rows][64 dims] bf16 tile, 128 B per row; 16-B chunk index XOR ((row >> 1) & 7)   (same image as attention.hip)
 __device__ __forceinline__ int a2_tile_off(int row, int colbyte) {
@@ -38,23 +40,23 @@ __device__ __forceinline__ int a2_tile_off(int row, int colbyte) {
 }
 __device__ __forceinline__ int a2_crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
-__device__ __forceinline__ bf16x8 a2_frag_rows(const char* lds, int row0, int s, int lane) {
-    return *(const bf16x8*)(lds + a2_tile_off(row0 + (lane & 31), (2 * s + (lane >> 5)) * 16));
+__device__ __forceinline__ h16x8 a2_frag_rows(const char* lds, int row0, int s, int lane) {
+    return *(const h16x8*)(lds + a2_tile_off(row0 + (lane & 31), (2 * s + (lane >> 5)) * 16));
 }
 // transposed operand from the BLOCKED image (see attention.hip tile_off_blk): both reads are linear in the lane id
-__device__ __forceinline__ bf16x8 a2_frag_cols_tr(const char* lds, int row0, int s, int col0, int lane) {
+__device__ __forceinline__ h16x8 a2_frag_cols_tr(const char* lds, int row0, int s, int col0, int lane) {
     const char* base = lds + ((((row0 >> 4) + s) << 1) + (col0 >> 5)) * 1024 + lane * 8;
     s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base));
     s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base + 512));
     typedef __attribute__((ext_vector_type(8))) short s16x8;
     s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8, v);
+    return __builtin_bit_cast(h16x8, v);
 }
-__device__ __forceinline__ bf16x8 a2_pack(const f32x16& p, int s) {
+__device__ __forceinline__ h16x8 a2_pack(const f32x16& p, int s) {
     u32x4 h;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) h[e] = pack_bf16_rne(p[8 * s + 2 * e], p[8 * s + 2 * e + 1]);
-    return __builtin_bit_cast(bf16x8, h);
+    for (int e = 0; e < 4; ++e) h[e] = pack_h16_rne(p[8 * s + 2 * e], p[8 * s + 2 * e + 1]);
+    return __builtin_bit_cast(h16x8, h);
 }
 
 // ---- bias table [N, ld] (row = i - j, column = head) -> transposed, padded, pre-multiplied by log2 e: [H8][ldT] ----------
@@ -152,7 +154,7 @@ struct A2Acc {
 //          range stays far from the fp32 exponent range (flag in the table's tail), else the online path runs.
 //   FULL:  every block of the tile lies strictly below the diagonal for every query block: straight-line code, no compares.
 template <int QB, bool FIXED, bool FULL>
-__device__ __forceinline__ void a2_tile(A2Acc<QB>& A, const bf16x8 (&qf)[QB][4], const char* Ks, const bf16_t* livef_tile,
+__device__ __forceinline__ void a2_tile(A2Acc<QB>& A, const h16x8 (&qf)[QB][4], const char* Ks, const h16_t* livef_tile,
                                         float c, int i0, int j0, int wave, int lane) {
     const char* Vs = Ks + 8192;
     const float* bw = (const float*)(Ks + 16384) + wave * A2_BWIN;
@@ -162,10 +164,10 @@ __device__ __forceinline__ void a2_tile(A2Acc<QB>& A, const bf16x8 (&qf)[QB][4],
     for (int sub = 0; sub < 2; ++sub) {
         const int jb = j0 + 32 * sub;
         if (!FULL && jb > i0 + 32 * QB - 1) break;              // above the diagonal for every query of the workgroup
-        bf16x8 kf[4];
+        h16x8 kf[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) kf[s] = a2_frag_rows(Ks, 32 * sub, s, lane);
-        bf16x8 pb[QB][2];
+        h16x8 pb[QB][2];
         bool on[QB];
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
@@ -228,10 +230,10 @@ __device__ __forceinline__ void a2_tile(A2Acc<QB>& A, const bf16x8 (&qf)[QB][4],
         for (int s = 0; s < 2; ++s) {
             // live vector of the 16 keys of this k-step in MFMA k order: keys key0 + 4 hi + {0..3}, key0 + 8 + 4 hi + {0..3};
             // A rows of parity qb carry it for query block qb, the others 0: ONE denominator accumulator for both blocks
-            const bf16_t* lp = livef_tile + 32 * sub + 16 * s + 4 * hi;
+            const h16_t* lp = livef_tile + 32 * sub + 16 * s + 4 * hi;
             const u32x2 l0 = *(const u32x2*)lp, l1 = *(const u32x2*)(lp + 8);
-            const bf16x8 va0 = a2_frag_cols_tr(Vs, 32 * sub, s, 0, lane);
-            const bf16x8 va1 = a2_frag_cols_tr(Vs, 32 * sub, s, 32, lane);
+            const h16x8 va0 = a2_frag_cols_tr(Vs, 32 * sub, s, 0, lane);
+            const h16x8 va1 = a2_frag_cols_tr(Vs, 32 * sub, s, 32, lane);
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
                 if (!on[qb]) continue;
@@ -240,7 +242,7 @@ __device__ __forceinline__ void a2_tile(A2Acc<QB>& A, const bf16x8 (&qf)[QB][4],
                 lv4[0] = mine ? l0[0] : 0u; lv4[1] = mine ? l0[1] : 0u; lv4[2] = mine ? l1[0] : 0u; lv4[3] = mine ? l1[1] : 0u;
                 A.acc[qb][0] = MFMA16(va0, pb[qb][s], A.acc[qb][0]);
                 A.acc[qb][1] = MFMA16(va1, pb[qb][s], A.acc[qb][1]);
-                A.accl = MFMA16(__builtin_bit_cast(bf16x8, lv4), pb[qb][s], A.accl);      // sum over live keys of P
+                A.accl = MFMA16(__builtin_bit_cast(h16x8, lv4), pb[qb][s], A.accl);      // sum over live keys of P
             }
         }
     }
@@ -250,15 +252,15 @@ __device__ __forceinline__ void a2_tile(A2Acc<QB>& A, const bf16x8 (&qf)[QB][4],
 #define A2_OCC
 #endif
 template <int QB>
-__global__ __launch_bounds__(A2_THREADS) A2_OCC void attn2_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
-                                                               const bf16_t* __restrict__ v, const float* __restrict__ biasT, int ldT,
-                                                               const unsigned char* __restrict__ keymask, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(A2_THREADS) A2_OCC void attn2_fwd_kernel(const h16_t* __restrict__ q, const h16_t* __restrict__ k,
+                                                               const h16_t* __restrict__ v, const float* __restrict__ biasT, int ldT,
+                                                               const unsigned char* __restrict__ keymask, h16_t* __restrict__ out,
                                                                float* __restrict__ lse, int B, int N, int H, float scale) {
     constexpr int TQW = 32 * QB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;                                        // A2_NST stages
     char* scratch = smem + A2_NST * A2_STAGE;                 // 4 KiB sink for the padding DMA of waves 4-7
-    bf16_t* livef = (bf16_t*)(scratch + 4096);                // [nkt_all * 64] 1.0 / 0.0 per key of this sample
+    h16_t* livef = (h16_t*)(scratch + 4096);                // [nkt_all * 64] 1.0 / 0.0 per key of this sample
 
     const int nqt = (N + TQW - 1) / TQW, ny = (H + 7) / 8;
     // XCD-aware, sample-major order: the workgroups of one sample (they share its K / V through the XCD's L2) are dealt to
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(A2_THREADS) A2_OCC void attn2_fwd_kernel(const bf16
             if (it * A2_THREADS < nkt * A2_TKV) {               // uniform
                 const bool lv = j < N && mk[it] != 0;
                 const unsigned long long w = __ballot(lv);
-                if (j < nkt * A2_TKV) livef[j] = lv ? (bf16_t)1.0f : (bf16_t)0.0f;
+                if (j < nkt * A2_TKV) livef[j] = lv ? (h16_t)1.0f : (h16_t)0.0f;
                 if (lane == 0 && it * 8 + wave < nkt) livebits[it * 8 + wave] = w;
             }
         }
@@ -326,16 +328,16 @@ __global__ __launch_bounds__(A2_THREADS) A2_OCC void attn2_fwd_kernel(const bf16
     issue(0);
     if (nkt > 1) issue(1);
     // Q fragments (B operand of S^T = K Q^T): query i0 + 32 qb + ql, dims 16 s + 8 hi .. +7
-    bf16x8 qf[QB][4];
+    h16x8 qf[QB][4];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         const int qi = i0 + 32 * qb + ql;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             u32x4 z = {0u, 0u, 0u, 0u};
-            const bf16_t* p = q + (rowbase + min(qi, N - 1)) * (size_t)(H * 64) + (size_t)(active ? h : 0) * 64 + 16 * s + 8 * hi;
+            const h16_t* p = q + (rowbase + min(qi, N - 1)) * (size_t)(H * 64) + (size_t)(active ? h : 0) * 64 + 16 * s + 8 * hi;
             u32x4 val = (active && qi < N) ? *(const u32x4*)p : z;
-            qf[qb][s] = __builtin_bit_cast(bf16x8, val);
+            qf[qb][s] = __builtin_bit_cast(h16x8, val);
         }
     }
     // Consume the Q loads HERE: hipcc then waits for them before the loop.  Left to their first use inside the loop, its
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(A2_THREADS) A2_OCC void attn2_fwd_kernel(const bf16
         const float mref = fixed ? mfix : A.m[qb];
         // a query without any live causal key has no defined softmax: emit zeros and an lse that zeroes its backward
         const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
-        bf16_t* orow = out + (rowbase + qi) * (size_t)(H * 64) + (size_t)h * 64;
+        h16_t* orow = out + (rowbase + qi) * (size_t)(H * 64) + (size_t)h * 64;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -409,10 +411,10 @@ __global__ __launch_bounds__(A2_THREADS) A2_OCC void attn2_fwd_kernel(const bf16
 // bias window.  The key mask is an additive 0 / -1e30 vector in LDS (one aligned 16-byte read per 4 scores); the probabilities
 // come straight from the stored log-sum-exp (no maximum to track), so the blocks of a tile are independent.
 #define A2B_STAGE (3 * 8192 + 8 * A2_BWIN * 4)       /* 28 KiB */
-__global__ __launch_bounds__(A2_THREADS) void attn2_bwd_dq_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
-                                                                  const bf16_t* __restrict__ v, const float* __restrict__ biasT, int ldT,
-                                                                  const unsigned char* __restrict__ keymask, const bf16_t* __restrict__ out,
-                                                                  const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+__global__ __launch_bounds__(A2_THREADS) void attn2_bwd_dq_kernel(const h16_t* __restrict__ q, const h16_t* __restrict__ k,
+                                                                  const h16_t* __restrict__ v, const float* __restrict__ biasT, int ldT,
+                                                                  const unsigned char* __restrict__ keymask, const h16_t* __restrict__ out,
+                                                                  const h16_t* __restrict__ dout, const float* __restrict__ lse,
                                                                   float* __restrict__ delta, float* __restrict__ dq, float* __restrict__ dbias,
                                                                   int bias_ld, int B, int N, int H, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -478,7 +480,7 @@ __global__ __launch_bounds__(A2_THREADS) void attn2_bwd_dq_kernel(const bf16_t* 
     if (nkt > 1) issue(1);
 
     // Q and dO fragments (B operands), delta_i = sum_d dO O, the row's log-sum-exp relative to the table's reference point
-    bf16x8 qf[4], dof[4];
+    h16x8 qf[4], dof[4];
     float dl = 0.f;
     const size_t qrow = (rowbase + min(qi, N - 1)) * (size_t)(H * 64) + (size_t)(active ? h : 0) * 64;
 #pragma unroll
@@ -488,10 +490,10 @@ __global__ __launch_bounds__(A2_THREADS) void attn2_bwd_dq_kernel(const bf16_t* 
         const u32x4 qv = ok ? *(const u32x4*)(q + qrow + 16 * s + 8 * hi) : z;
         const u32x4 dv = ok ? *(const u32x4*)(dout + qrow + 16 * s + 8 * hi) : z;
         const u32x4 ov = ok ? *(const u32x4*)(out + qrow + 16 * s + 8 * hi) : z;
-        qf[s] = __builtin_bit_cast(bf16x8, qv);
-        dof[s] = __builtin_bit_cast(bf16x8, dv);
+        qf[s] = __builtin_bit_cast(h16x8, qv);
+        dof[s] = __builtin_bit_cast(h16x8, dv);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dl += bf16_lo_to_f(dv[e]) * bf16_lo_to_f(ov[e]) + bf16_hi_to_f(dv[e]) * bf16_hi_to_f(ov[e]);
+        for (int e = 0; e < 4; ++e) dl += h16_lo_to_f(dv[e]) * h16_lo_to_f(ov[e]) + h16_hi_to_f(dv[e]) * h16_hi_to_f(ov[e]);
     }
     dl += __shfl_xor(dl, 32, 64);
     float Lp = 0.f;
@@ -530,7 +532,7 @@ __global__ __launch_bounds__(A2_THREADS) void attn2_bwd_dq_kernel(const bf16_t* 
 #if A2_DQ_BATCH
             {   // all eight fragment reads in flight before the first MFMA, retired in two groups (hipcc issued them one at a time
                 // through the same four registers: read -> wait -> MFMA, seen in the ISA)
-                bf16x8 kfr[4], vfr[4];
+                h16x8 kfr[4], vfr[4];
 #pragma unroll
                 for (int s = 0; s < 4; ++s) { kfr[s] = a2_frag_rows(Kr, 32 * sub, s, lane); vfr[s] = a2_frag_rows(Vr, 32 * sub, s, lane); }
 #pragma unroll
@@ -590,7 +592,7 @@ __global__ __launch_bounds__(A2_THREADS) void attn2_bwd_dq_kernel(const bf16_t* 
             }
 #if A2_DQ_BATCH
             {
-                bf16x8 ktf[2][2], dsb[2];
+                h16x8 ktf[2][2], dsb[2];
 #pragma unroll
                 for (int s = 0; s < 2; ++s) { ktf[s][0] = a2_frag_cols_tr(Kb, 32 * sub, s, 0, lane); ktf[s][1] = a2_frag_cols_tr(Kb, 32 * sub, s, 32, lane); }
 #pragma unroll
@@ -605,7 +607,7 @@ __global__ __launch_bounds__(A2_THREADS) void attn2_bwd_dq_kernel(const bf16_t* 
 #else
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const bf16x8 dsb = a2_pack(st, s);
+                const h16x8 dsb = a2_pack(st, s);
                 acc[0] = MFMA16(a2_frag_cols_tr(Kb, 32 * sub, s, 0, lane), dsb, acc[0]);       // dQ^T += K^T dS^T
                 acc[1] = MFMA16(a2_frag_cols_tr(Kb, 32 * sub, s, 32, lane), dsb, acc[1]);
             }
@@ -641,11 +643,12 @@ int attn2_bwd_dq_launch(const void* q, const void* k, const void* v, const float
     if (lds > 160 * 1024 || N > 4096) return 1;                // caller falls back to the first-generation kernel
     static bool a1 = false;
     if (!a1) { (void)hipFuncSetAttribute((const void*)attn2_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a1 = true; }
-    hipLaunchKernelGGL(attn2_bwd_dq_kernel, dim3(nqt * ny * B), dim3(A2_THREADS), lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
-                       biasT, ldT, keymask, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, dq, dbias, bias_ld, B, N, H, scale);
+    hipLaunchKernelGGL(attn2_bwd_dq_kernel, dim3(nqt * ny * B), dim3(A2_THREADS), lds, st, (const h16_t*)q, (const h16_t*)k, (const h16_t*)v,
+                       biasT, ldT, keymask, (const h16_t*)out, (const h16_t*)dout, lse, delta, dq, dbias, bias_ld, B, N, H, scale);
     return omlm_post_launch("omlm_mqa_attn_bwd");
 }
 
+#if !OMLM_FP16      /* the bias table is fp32 in every precision: prepared by the bf16 copy of this file */
 // -------------------------------------------------------------------------------------------------------------------------
 extern "C" long long omlm_attn_bias_table_floats(int N, int H) {
     const int ldT = (A2_PAD + N + 2 * A2_BWIN + 3) / 4 * 4, H8 = (H + 7) / 8 * 8;
@@ -665,6 +668,8 @@ extern "C" int omlm_attn_bias_prepare(const float* bias, float* biasT, int N, in
     return omlm_post_launch("omlm_attn_bias_prepare");
 }
 
+#endif
+
 // bf16 forward.  biasT from omlm_attn_bias_prepare (or null: no bias).
 int attn2_fwd_launch(const void* q, const void* k, const void* v, const float* biasT, const unsigned char* keymask,
                      void* out, float* lse, int B, int N, int H, float scale, hipStream_t st) {
@@ -676,6 +681,8 @@ int attn2_fwd_launch(const void* q, const void* k, const void* v, const float* b
     dim3 grid(nqt * ny * B), block(A2_THREADS);
     static bool a1 = false;
     if (!a1) { (void)hipFuncSetAttribute((const void*)attn2_fwd_kernel<QB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a1 = true; }
-    hipLaunchKernelGGL(attn2_fwd_kernel<QB>, grid, block, lds, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, biasT, ldT, keymask, (bf16_t*)out, lse, B, N, H, scale);
+    hipLaunchKernelGGL(attn2_fwd_kernel<QB>, grid, block, lds, st, (const h16_t*)q, (const h16_t*)k, (const h16_t*)v, biasT, ldT, keymask, (h16_t*)out, lse, B, N, H, scale);
     return omlm_post_launch("omlm_mqa_attn_fwd");
 }
+
+}   // namespace OMLM_NS

@@ -31,10 +31,37 @@ static inline int omlm_post_launch(const char* what) {
     return OMLM_OK;
 }
 
-typedef __bf16 bf16_t;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+// ---- the 16-bit GEMM / attention operand type of this build -----------------------------------------------------------------
+// Every source that touches 16-bit operands is compiled TWICE: once with h16_t = bf16 (precision "bf16"; also hosts the fp32 /
+// "bf16x3" instantiations) and once with -DOMLM_FP16=1, h16_t = IEEE half (precision "fp16": same v_mfma_f32_32x32x16 rate, 11
+// instead of 8 significand bits).  The two copies live in different namespaces (kernel host stubs of the same name must not
+// merge) and the fp16 copy's entry points are hidden `<name>_h` functions that the public entry point forwards to when it is
+// handed dtype code 2 (OMLM_DT_F16), so include/omlm.h has ONE function per operation.
+#ifndef OMLM_FP16
+#define OMLM_FP16 0
+#endif
+#define OMLM_DT_F32 0
+#define OMLM_DT_BF16 1
+#define OMLM_DT_F16 2
+// dtype code as the fp16 copy sees it: its 16-bit type is "code 1" there
+#define OMLM_H_CODE(c) ((c) == OMLM_DT_F16 ? 1 : (c))
+#if OMLM_FP16
+typedef _Float16 h16_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 h16x4;
+typedef __attribute__((ext_vector_type(2))) _Float16 h16x2;
+#define OMLM_NS omlm_f16
+#define OMLM_API(name) __attribute__((visibility("hidden"))) name##_h
+#define OMLM_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+#else
+typedef __bf16 h16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 h16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 h16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 h16x2;
+#define OMLM_NS omlm_bf16
+#define OMLM_API(name) name
+#define OMLM_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#endif
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -53,20 +80,29 @@ __device__ __forceinline__ unsigned bf16_bits_rne(float f) {
     u += 0x7FFFu + ((u >> 16) & 1u);
     return u >> 16;
 }
-__device__ __forceinline__ unsigned pack_bf16_rne(float lo, float hi) {
-    bf16x2 v;
-    v[0] = (__bf16)lo;
-    v[1] = (__bf16)hi;
+__device__ __forceinline__ unsigned pack_h16_rne(float lo, float hi) {
+    h16x2 v;
+    v[0] = (h16_t)lo;
+    v[1] = (h16_t)hi;
     return __builtin_bit_cast(unsigned, v);
 }
-__device__ __forceinline__ float bf16_lo_to_f(unsigned packed) { return u2f(packed << 16); }
-__device__ __forceinline__ float bf16_hi_to_f(unsigned packed) { return u2f(packed & 0xFFFF0000u); }
+#if OMLM_FP16
+__device__ __forceinline__ float h16_lo_to_f(unsigned packed) { return (float)__builtin_bit_cast(h16x2, packed)[0]; }
+__device__ __forceinline__ float h16_hi_to_f(unsigned packed) { return (float)__builtin_bit_cast(h16x2, packed)[1]; }
+#else
+__device__ __forceinline__ float h16_lo_to_f(unsigned packed) { return u2f(packed << 16); }
+__device__ __forceinline__ float h16_hi_to_f(unsigned packed) { return u2f(packed & 0xFFFF0000u); }
+#endif
 
 // split fp32 pair into packed (truncated) hi bf16 pair and RNE lo bf16 pair: x ~= hi + lo
 __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
     unsigned ua = f2u(a) & 0xFFFF0000u, ub = f2u(b) & 0xFFFF0000u;
     hi = ub | (ua >> 16);
-    lo = pack_bf16_rne(a - u2f(ua), b - u2f(ub));
+#if OMLM_FP16
+    lo = bf16_bits_rne(a - u2f(ua)) | (bf16_bits_rne(b - u2f(ub)) << 16);       // planes are bf16 by definition (the fp16 copy never runs them)
+#else
+    lo = pack_h16_rne(a - u2f(ua), b - u2f(ub));
+#endif
 }
 
 // the same sum on the VALU: 4 DPP adds inside each row of 16 lanes + 4 readlanes, no LDS-crossbar round trips (six dependent
@@ -208,19 +244,26 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
 
 template <typename T> struct elt_traits;
 template <> struct elt_traits<float> { static constexpr bool precise = true; };
-template <> struct elt_traits<bf16_t> { static constexpr bool precise = false; };
+template <> struct elt_traits<h16_t> { static constexpr bool precise = false; };
 
 __device__ __forceinline__ float load_as_float(const float* p) { return *p; }
-__device__ __forceinline__ float load_as_float(const bf16_t* p) { return (float)(*p); }
+__device__ __forceinline__ float load_as_float(const h16_t* p) { return (float)(*p); }
 __device__ __forceinline__ void store_from_float(float* p, float v) { *p = v; }
-__device__ __forceinline__ void store_from_float(bf16_t* p, float v) { *p = (bf16_t)v; }
+__device__ __forceinline__ void store_from_float(h16_t* p, float v) { *p = (h16_t)v; }
+
+#if !OMLM_FP16
+// Files that exist once (elementwise casts, the optimizer's 16-bit weight shadow, the loss gradient) serve fp16 outputs from the
+// same copy: dtype code 2 selects the half instantiation.
+typedef _Float16 f16_t;
+__device__ __forceinline__ void store_from_float(f16_t* p, float v) { *p = (f16_t)v; }
+#endif
 
 // 4 consecutive outputs as ONE store (16 B fp32 / 8 B bf16) -- scalar bf16 stores are 2-byte scatters
 __device__ __forceinline__ void store4_from_float(float* p, float a, float b, float c, float d) { *(float4*)p = make_float4(a, b, c, d); }
-__device__ __forceinline__ void store4_from_float(bf16_t* p, float a, float b, float c, float d) {
+__device__ __forceinline__ void store4_from_float(h16_t* p, float a, float b, float c, float d) {
     u32x2 o;
-    o[0] = pack_bf16_rne(a, b);
-    o[1] = pack_bf16_rne(c, d);
+    o[0] = pack_h16_rne(a, b);
+    o[1] = pack_h16_rne(c, d);
     *(u32x2*)p = o;
 }
 

@@ -14,7 +14,7 @@
 //   * the row index lives in DEVICE memory (*pos_dev), grids and LDS sizes do not depend on it, so a whole step
 //     (31 launches + sampler + advance) can be captured once into a HIP graph and replayed per sampled id.
 //
-// TW = bf16_t: weights are the bf16 operand copies ("bf16" mode; activations that the batched path rounds to bf16 before
+// TW = h16_t: weights are the bf16 operand copies ("bf16" mode; activations that the batched path rounds to bf16 before
 // its GEMMs are rounded here too, so both paths see the same operands); TW = float: fp32 weights, fp32 FMA chains.
 #include "common.h"
 // The step kernels are single dependent chains (load -> LayerNorm statistics -> dot products -> reduction -> store): the wave
@@ -29,6 +29,8 @@
 #define wave_max(x) wave_max_dpp(x)
 #endif
 #include <stdlib.h>
+
+namespace OMLM_NS {
 
 #define DEC_T 256
 #define DEC_BMAX 8
@@ -51,16 +53,16 @@ struct omlm_decode_args {
     int* advance_pos; int* advance_step;
 };
 
-__device__ __forceinline__ float round_if(float v, int on) { return on ? (float)(bf16_t)v : v; }
+__device__ __forceinline__ float round_if(float v, int on) { return on ? (float)(h16_t)v : v; }
 
 __device__ __forceinline__ void load_w8(const float* p, float* w) {
     const float4 a = ((const float4*)p)[0], b = ((const float4*)p)[1];
     w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
 }
-__device__ __forceinline__ void load_w8(const bf16_t* p, float* w) {
+__device__ __forceinline__ void load_w8(const h16_t* p, float* w) {
     const u32x4 a = *(const u32x4*)p;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { w[2 * i] = bf16_lo_to_f(a[i]); w[2 * i + 1] = bf16_hi_to_f(a[i]); }
+    for (int i = 0; i < 4; ++i) { w[2 * i] = h16_lo_to_f(a[i]); w[2 * i + 1] = h16_hi_to_f(a[i]); }
 }
 
 // vals[r * DEC_BMAX + b] = sum_k W[r, k] * xs[b * Kp + k]  for r < nrows <= 16 (weight rows of pitch ldw), b < B.
@@ -418,12 +420,12 @@ __global__ __launch_bounds__(DEC_T) void dec_ffin_kernel(const float* __restrict
 #define DEC2_ROWS 4
 
 template <typename TW> struct dec_wreg;
-template <> struct dec_wreg<bf16_t> { u32x4 r;
-    __device__ __forceinline__ void load(const bf16_t* p) { r = *(const u32x4*)p; }
+template <> struct dec_wreg<h16_t> { u32x4 r;
+    __device__ __forceinline__ void load(const h16_t* p) { r = *(const u32x4*)p; }
     __device__ __forceinline__ void zero() { r[0] = r[1] = r[2] = r[3] = 0u; }
     __device__ __forceinline__ void unpack(float* w) const {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { w[2 * i] = bf16_lo_to_f(r[i]); w[2 * i + 1] = bf16_hi_to_f(r[i]); } } };
+        for (int i = 0; i < 4; ++i) { w[2 * i] = h16_lo_to_f(r[i]); w[2 * i + 1] = h16_hi_to_f(r[i]); } } };
 template <> struct dec_wreg<float> { float4 a, b;
     __device__ __forceinline__ void load(const float* p) { a = ((const float4*)p)[0]; b = ((const float4*)p)[1]; }
     __device__ __forceinline__ void zero() { a = make_float4(0.f, 0.f, 0.f, 0.f); b = a; }
@@ -858,10 +860,14 @@ static int decode_step2_t(const omlm_decode_args& a, const long long* ids, hipSt
 __global__ void dec_advance_kernel(int* pos_dev, int* step_dev) {
     if (threadIdx.x == 0) { if (pos_dev) pos_dev[0] += 1; if (step_dev) step_dev[0] += 1; }
 }
+#if OMLM_FP16
+extern "C" int omlm_decode_advance(int* pos_dev, int* step_dev, void* stream);      // bf16 copy of this file
+#else
 extern "C" int omlm_decode_advance(int* pos_dev, int* step_dev, void* stream) {
     hipLaunchKernelGGL(dec_advance_kernel, dim3(1), dim3(64), 0, as_stream(stream), pos_dev, step_dev);
     return omlm_post_launch("omlm_decode_advance");
 }
+#endif
 
 template <typename TW>
 static int decode_step_t(const omlm_decode_args& a, const long long* ids, hipStream_t st) {
@@ -906,8 +912,21 @@ static int decode_step_t(const omlm_decode_args& a, const long long* ids, hipStr
 // One decode step for the row at index *pos_dev (see include/omlm.h).  ids: [B] int64 sampled in the previous step (used
 // when a->emb_table is set; otherwise a->x already holds the new row's embedding).  *pos_dev is advanced only through
 // a->advance_pos / a->advance_step (optional device counters bumped by the step's last kernel; pass pos_dev there to move on).
-extern "C" int omlm_decode_step(const omlm_decode_args* a, const long long* ids, void* stream) {
+// a->w_dtype: 0 = fp32 weights, 1 = bf16, 2 = fp16 (served by the fp16 copy of this file; a->round_bf16 then rounds to fp16).
+#if !OMLM_FP16
+extern "C" int omlm_decode_step_h(const omlm_decode_args* a, const long long* ids, void* stream);
+#endif
+extern "C" int OMLM_API(omlm_decode_step)(const omlm_decode_args* a, const long long* ids, void* stream) {
     OMLM_CHECK_ARG(a != nullptr, "null argument block");
+#if !OMLM_FP16
+    if (a->w_dtype == OMLM_DT_F16) {
+        omlm_decode_args b = *a;
+        b.w_dtype = 1;
+        return omlm_decode_step_h(&b, ids, stream);
+    }
+#else
+    OMLM_CHECK_ARG(a->w_dtype == 1, "the fp16 copy serves fp16 weights only");
+#endif
     OMLM_CHECK_ARG(a->B >= 1 && a->B <= DEC_BMAX, "decode batch must be 1..8 (use the batched forward beyond that)");
     OMLM_CHECK_ARG(a->D % 8 == 0 && a->Fp % 8 == 0 && a->pos_dev && a->parts, "decode geometry");
     OMLM_CHECK_ARG(a->H >= 1 && a->H <= 16 && (a->H * 64 + 128) % DEC_ROWS == 0, "heads");
@@ -918,11 +937,21 @@ extern "C" int omlm_decode_step(const omlm_decode_args* a, const long long* ids,
     if (v1 < 0) { const char* e = getenv("OMLM_DECODE_V1"); v1 = (e && e[0] == '1') ? 1 : 0; }
     const bool v2_ok = a->D == 1024 && a->H * 64 <= 1024 && a->Fp <= 4096 && a->Fp % 2 == 0 && (a->H * 64 + 128) % DEC2_ROWS == 0;
     if (!v1 && v2_ok) {
-        const int rc = a->w_dtype == 0 ? decode_step2_t<float>(*a, ids, as_stream(stream)) : decode_step2_t<bf16_t>(*a, ids, as_stream(stream));
+#if OMLM_FP16
+        const int rc = decode_step2_t<h16_t>(*a, ids, as_stream(stream));
+#else
+        const int rc = a->w_dtype == 0 ? decode_step2_t<float>(*a, ids, as_stream(stream)) : decode_step2_t<h16_t>(*a, ids, as_stream(stream));
+#endif
         if (rc == OMLM_OK && a->advance_pos && !a->head_W) return omlm_decode_advance(a->advance_pos, a->advance_step, stream);
         return rc;
     }
-    const int rc = a->w_dtype == 0 ? decode_step_t<float>(*a, ids, as_stream(stream)) : decode_step_t<bf16_t>(*a, ids, as_stream(stream));
+#if OMLM_FP16
+    const int rc = decode_step_t<h16_t>(*a, ids, as_stream(stream));
+#else
+    const int rc = a->w_dtype == 0 ? decode_step_t<float>(*a, ids, as_stream(stream)) : decode_step_t<h16_t>(*a, ids, as_stream(stream));
+#endif
     if (rc == OMLM_OK && a->advance_pos) return omlm_decode_advance(a->advance_pos, a->advance_step, stream);    // first-generation kernels: own launch
     return rc;
 }
+
+}   // namespace OMLM_NS

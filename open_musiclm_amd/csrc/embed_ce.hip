@@ -186,9 +186,12 @@ extern "C" int omlm_cross_entropy_bwd(const float* logits, const int* labels, co
     if (R <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(logits && labels && row_lse && dlogits && ld >= V && ldd >= V, "cross entropy arguments");
     dim3 grid(R < 8192 ? R : 8192), block(256);
+    OMLM_CHECK_ARG(out_dtype >= 0 && out_dtype <= 2, "out_dtype: 0 = fp32, 1 = bf16, 2 = fp16");
     if (out_dtype == 0)
         hipLaunchKernelGGL(ce_bwd_kernel<float>, grid, block, 0, as_stream(stream), logits, labels, row_lse, gscale, coef, (float*)dlogits, R, V, ld, ldd);
+    else if (out_dtype == OMLM_DT_F16)
+        hipLaunchKernelGGL(ce_bwd_kernel<f16_t>, grid, block, 0, as_stream(stream), logits, labels, row_lse, gscale, coef, (f16_t*)dlogits, R, V, ld, ldd);
     else
-        hipLaunchKernelGGL(ce_bwd_kernel<bf16_t>, grid, block, 0, as_stream(stream), logits, labels, row_lse, gscale, coef, (bf16_t*)dlogits, R, V, ld, ldd);
+        hipLaunchKernelGGL(ce_bwd_kernel<h16_t>, grid, block, 0, as_stream(stream), logits, labels, row_lse, gscale, coef, (h16_t*)dlogits, R, V, ld, ldd);
     return omlm_post_launch("omlm_cross_entropy_bwd");
 }

@@ -14,6 +14,8 @@
 #include "common.h"
 #include <stdlib.h>
 
+namespace OMLM_NS {
+
 #define FF_THREADS 256
 #define FF_MAXC_LIMIT 16   // 8-channel chunks per lane (wave-per-row kernels) -> Fp <= 8192
 
@@ -29,17 +31,17 @@ template <> struct vec8<float> {
         ((float4*)p)[1] = make_float4(v[4], v[5], v[6], v[7]);
     }
 };
-template <> struct vec8<bf16_t> {
+template <> struct vec8<h16_t> {
     float v[8];
-    __device__ __forceinline__ void load(const bf16_t* p) {
+    __device__ __forceinline__ void load(const h16_t* p) {
         const u32x4 a = *(const u32x4*)p;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { v[2 * i] = bf16_lo_to_f(a[i]); v[2 * i + 1] = bf16_hi_to_f(a[i]); }
+        for (int i = 0; i < 4; ++i) { v[2 * i] = h16_lo_to_f(a[i]); v[2 * i + 1] = h16_hi_to_f(a[i]); }
     }
-    __device__ __forceinline__ void store(bf16_t* p) const {
+    __device__ __forceinline__ void store(h16_t* p) const {
         u32x4 a;
-        a[0] = pack_bf16_rne(v[0], v[1]); a[1] = pack_bf16_rne(v[2], v[3]);
-        a[2] = pack_bf16_rne(v[4], v[5]); a[3] = pack_bf16_rne(v[6], v[7]);
+        a[0] = pack_h16_rne(v[0], v[1]); a[1] = pack_h16_rne(v[2], v[3]);
+        a[2] = pack_h16_rne(v[4], v[5]); a[3] = pack_h16_rne(v[6], v[7]);
         *(u32x4*)p = a;
     }
 };
@@ -113,13 +115,13 @@ __device__ __forceinline__ void conv_row(const T* __restrict__ h1, const T* __re
 // while the current chunk is computed: each wave walks its row chunk by chunk, and with only 2-3 waves per SIMD a chunk's
 // load latency (~1.7 us under load) was serialised with its ~1.7 us of arithmetic.
 template <typename T> struct raw8;
-template <> struct raw8<bf16_t> {
+template <> struct raw8<h16_t> {
     u32x4 r;
-    __device__ __forceinline__ void load(const bf16_t* p) { r = *(const u32x4*)p; }
+    __device__ __forceinline__ void load(const h16_t* p) { r = *(const u32x4*)p; }
     __device__ __forceinline__ void zero() { r[0] = 0u; r[1] = 0u; r[2] = 0u; r[3] = 0u; }
     __device__ __forceinline__ void unpack(float* v) const {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { v[2 * i] = bf16_lo_to_f(r[i]); v[2 * i + 1] = bf16_hi_to_f(r[i]); }
+        for (int i = 0; i < 4; ++i) { v[2 * i] = h16_lo_to_f(r[i]); v[2 * i + 1] = h16_hi_to_f(r[i]); }
     }
 };
 template <> struct raw8<float> {
@@ -546,6 +548,9 @@ __global__ void colsum_kernel(const float* __restrict__ part, float* __restrict_
     if (p1 > p0) unsafeAtomicAdd(out + c, s);
 }
 
+#if OMLM_FP16
+extern "C" int omlm_colsum_accumulate(const float* part, float* out, int P, int C, int ldp, void* stream);     // bf16 copy
+#else
 extern "C" int omlm_colsum_accumulate(const float* part, float* out, int P, int C, int ldp, void* stream) {
     if (P <= 0 || C <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(part && out && ldp >= C, "colsum arguments");
@@ -553,6 +558,8 @@ extern "C" int omlm_colsum_accumulate(const float* part, float* out, int P, int 
     hipLaunchKernelGGL(colsum_kernel, dim3((C + 255) / 256, ysplit), dim3(256), 0, as_stream(stream), part, out, P, C, ldp);
     return omlm_post_launch("omlm_colsum_accumulate");
 }
+
+#endif
 
 #define FF_BWD1_BLOCKS 1024
 #define FF_BWD2_STRIPS 512
@@ -569,23 +576,43 @@ int ffmid2_bwd_launch(const void* dh2, const void* h1, const void* convw, const 
 // omlm_ffmid_set_impl (A/B runs, tests).  The two generations share every buffer layout; their dropout streams differ
 // (the keep-mask travels from forward to backward as drop_bits, so a step may not mix them only when drop_bits is null).
 static int g_ffmid_impl = -1;
-extern "C" int omlm_ffmid_set_impl(int impl) {
+#if !OMLM_FP16
+extern "C" int omlm_ffmid_set_impl_h(int impl);
+#endif
+extern "C" int OMLM_API(omlm_ffmid_set_impl)(int impl) {
     OMLM_CHECK_ARG(impl == 0 || impl == 1, "impl: 0 = wave-per-row, 1 = column strips");
     g_ffmid_impl = impl;
+#if !OMLM_FP16
+    return omlm_ffmid_set_impl_h(impl);         // the fp16 copy of this file keeps its own switch
+#else
     return OMLM_OK;
+#endif
 }
 static int ffmid_impl() {
     if (g_ffmid_impl < 0) { const char* e = getenv("OMLM_FFMID_IMPL"); g_ffmid_impl = (e && e[0] == '0') ? 0 : 1; }
     return g_ffmid_impl;
 }
 
+#if !OMLM_FP16
 extern "C" long long omlm_ffmid_bwd_workspace_bytes(int F, int Fp) {
     return (long long)sizeof(float) * ((long long)FF_BWD1_BLOCKS * Fp + (long long)FF_BWD2_STRIPS * 2 * F * 3);
 }
+#endif
 
-extern "C" int omlm_ffmid_fwd(const void* h1, const void* convw, const void* gamma, void* h2, float* mean, float* rstd,
+// dtype: 0 = fp32 operands ("bf16x3"), 1 = bf16, 2 = fp16 (forwarded to the fp16 copy of this file)
+#if !OMLM_FP16
+extern "C" int omlm_ffmid_fwd_h(const void* h1, const void* convw, const void* gamma, void* h2, float* mean, float* rstd,
+                                int M, int nseq, int F, int Fp, float eps, float p, unsigned long long seed,
+                                const unsigned long long* seed_dev, unsigned char* drop_bits, void* gh, int dtype, void* stream);
+#endif
+extern "C" int OMLM_API(omlm_ffmid_fwd)(const void* h1, const void* convw, const void* gamma, void* h2, float* mean, float* rstd,
                               int M, int nseq, int F, int Fp, float eps, float p, unsigned long long seed,
                               const unsigned long long* seed_dev, unsigned char* drop_bits, void* gh, int dtype, void* stream) {
+#if !OMLM_FP16
+    if (dtype == OMLM_DT_F16) return omlm_ffmid_fwd_h(h1, convw, gamma, h2, mean, rstd, M, nseq, F, Fp, eps, p, seed, seed_dev, drop_bits, gh, 1, stream);
+#else
+    OMLM_CHECK_ARG(dtype == 1, "the fp16 copy serves fp16 operands only");
+#endif
     if (M <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(h1 && convw && gamma && h2 && mean && rstd, "null pointer");
     OMLM_CHECK_ARG(Fp % 8 == 0 && Fp >= F && Fp <= 8192 && (size_t)5 * Fp * sizeof(float) <= 160 * 1024, "Fp must be F rounded up to 8 and <= 8192");
@@ -598,25 +625,44 @@ extern "C" int omlm_ffmid_fwd(const void* h1, const void* convw, const void* gam
     dim3 grid(rows4 < 4096 ? rows4 : 4096), block(FF_THREADS);
     const size_t lds_fwd = (size_t)4 * Fp * sizeof(float);
     if (lds_fwd > 48 * 1024) {
+#if !OMLM_FP16
         (void)hipFuncSetAttribute((const void*)ffmid_fwd_kernel<float, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)ffmid_fwd_kernel<float, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)ffmid_fwd_kernel<bf16_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)ffmid_fwd_kernel<bf16_t, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#endif
+        (void)hipFuncSetAttribute((const void*)ffmid_fwd_kernel<h16_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)ffmid_fwd_kernel<h16_t, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
 #define FF_FWD(T_, MC_) hipLaunchKernelGGL((ffmid_fwd_kernel<T_, MC_>), grid, block, lds_fwd, st, (const T_*)h1, (const T_*)convw, (const T_*)gamma, (T_*)h2, mean, rstd, M, nseq, F, Fp, eps, p, seed, seed_dev, drop_bits, (T_*)gh)
 #define FF_FWD_DISPATCH(T_) do { const int mc = (Fp / 8 + 63) / 64; \
         if (mc <= 2) FF_FWD(T_, 2); else if (mc <= 6) FF_FWD(T_, 6); else if (mc <= 8) FF_FWD(T_, 8); else FF_FWD(T_, 16); } while (0)
-    if (dtype == 0) FF_FWD_DISPATCH(float); else FF_FWD_DISPATCH(bf16_t);
+#if !OMLM_FP16
+    if (dtype == 0) FF_FWD_DISPATCH(float); else
+#endif
+    FF_FWD_DISPATCH(h16_t);
     return omlm_post_launch("omlm_ffmid_fwd");
 }
 
 // du_tmp: [M, 2*Fp] scratch of the operand dtype; dh1: [M, 2*Fp] output; workspace: omlm_ffmid_bwd_workspace_bytes.
 // dgamma [F], dconv [2F*3] are accumulated into (+=).
-extern "C" int omlm_ffmid_bwd(const void* dh2, const void* h1, const void* convw, const void* gamma, const float* mean,
+#if !OMLM_FP16
+extern "C" int omlm_ffmid_bwd_h(const void* dh2, const void* h1, const void* convw, const void* gamma, const float* mean,
+                                const float* rstd, void* du_tmp, void* dh1, float* dgamma, float* dconv, float* workspace,
+                                int M, int nseq, int F, int Fp, float p, unsigned long long seed,
+                                const unsigned long long* seed_dev, const unsigned char* drop_bits, const void* gh, int dtype,
+                                void* stream);
+#endif
+extern "C" int OMLM_API(omlm_ffmid_bwd)(const void* dh2, const void* h1, const void* convw, const void* gamma, const float* mean,
                               const float* rstd, void* du_tmp, void* dh1, float* dgamma, float* dconv, float* workspace,
                               int M, int nseq, int F, int Fp, float p, unsigned long long seed,
                               const unsigned long long* seed_dev, const unsigned char* drop_bits, const void* gh, int dtype,
                               void* stream) {
+#if !OMLM_FP16
+    if (dtype == OMLM_DT_F16)
+        return omlm_ffmid_bwd_h(dh2, h1, convw, gamma, mean, rstd, du_tmp, dh1, dgamma, dconv, workspace, M, nseq, F, Fp, p, seed, seed_dev,
+                                drop_bits, gh, 1, stream);
+#else
+    OMLM_CHECK_ARG(dtype == 1, "the fp16 copy serves fp16 operands only");
+#endif
     if (M <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(dh2 && h1 && convw && gamma && mean && rstd && du_tmp && dh1 && workspace, "null pointer");
     OMLM_CHECK_ARG(Fp % 8 == 0 && Fp >= F && Fp <= 8192 && (size_t)5 * Fp * sizeof(float) <= 160 * 1024, "Fp must be F rounded up to 8 and <= 8192");
@@ -643,19 +689,24 @@ extern "C" int omlm_ffmid_bwd(const void* dh2, const void* h1, const void* convw
 #define FF_B1_ATTR(T_, MC_) do { (void)hipFuncSetAttribute((const void*)ffmid_bwd1_kernel<T_, MC_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
         (void)hipFuncSetAttribute((const void*)ffmid_bwd1_kernel<T_, MC_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); } while (0)
     if (lds1 > 48 * 1024) {
+#if !OMLM_FP16
         FF_B1_ATTR(float, 6); FF_B1_ATTR(float, 8); FF_B1_ATTR(float, 16);
-        FF_B1_ATTR(bf16_t, 6); FF_B1_ATTR(bf16_t, 8); FF_B1_ATTR(bf16_t, 16);
+#endif
+        FF_B1_ATTR(h16_t, 6); FF_B1_ATTR(h16_t, 8); FF_B1_ATTR(h16_t, 16);
     }
 #define FF_B1G(T_, MC_, GH_) hipLaunchKernelGGL((ffmid_bwd1_kernel<T_, MC_, GH_>), dim3(b1), dim3(FF_THREADS), lds1, st, (const T_*)dh2, (const T_*)h1, (const T_*)convw, (const T_*)gamma, mean, rstd, (T_*)du_tmp, part_g, M, nseq, F, Fp, p, seed, seed_dev, drop_bits, (const T_*)gh)
 #define FF_B1(T_, MC_) do { if (gh) FF_B1G(T_, MC_, true); else FF_B1G(T_, MC_, false); } while (0)
 #define FF_B1_DISPATCH(T_) do { const int mc = (Fp / 8 + 63) / 64; \
         if (mc <= 2) FF_B1(T_, 2); else if (mc <= 6) FF_B1(T_, 6); else if (mc <= 8) FF_B1(T_, 8); else FF_B1(T_, 16); } while (0)
+#if !OMLM_FP16
     if (dtype == 0) {
         FF_B1_DISPATCH(float);
         hipLaunchKernelGGL(ffmid_bwd2_kernel<float>, g2, dim3(FF_THREADS), 0, st, (const float*)du_tmp, (const float*)h1, (const float*)convw, (float*)dh1, part_c, M, nseq, F, Fp);
-    } else {
-        FF_B1_DISPATCH(bf16_t);
-        hipLaunchKernelGGL(ffmid_bwd2_kernel<bf16_t>, g2, dim3(FF_THREADS), 0, st, (const bf16_t*)du_tmp, (const bf16_t*)h1, (const bf16_t*)convw, (bf16_t*)dh1, part_c, M, nseq, F, Fp);
+    } else
+#endif
+    {
+        FF_B1_DISPATCH(h16_t);
+        hipLaunchKernelGGL(ffmid_bwd2_kernel<h16_t>, g2, dim3(FF_THREADS), 0, st, (const h16_t*)du_tmp, (const h16_t*)h1, (const h16_t*)convw, (h16_t*)dh1, part_c, M, nseq, F, Fp);
     }
     int rc = omlm_post_launch("omlm_ffmid_bwd");
     if (rc) return rc;
@@ -663,3 +714,5 @@ extern "C" int omlm_ffmid_bwd(const void* dh2, const void* h1, const void* convw
     if (dconv)  { rc = omlm_colsum_accumulate(part_c, dconv, strips, 2 * F * 3, 2 * F * 3, stream); if (rc) return rc; }
     return OMLM_OK;
 }
+
+}   // namespace OMLM_NS

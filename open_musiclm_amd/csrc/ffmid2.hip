@@ -21,22 +21,24 @@
 //     layer).  conv^T runs as two pending output rows in registers; a strip recomputes du for the 2 rows past its end.
 #include "common.h"
 
+namespace OMLM_NS {
+
 typedef f32x2 v2;
 
 __device__ __forceinline__ v2 mk2(float a, float b) { v2 r; r[0] = a; r[1] = b; return r; }
 __device__ __forceinline__ v2 splat2(float a) { return mk2(a, a); }
-__device__ __forceinline__ v2 bf2_to_f2(unsigned w) { return mk2(u2f(w << 16), u2f(w & 0xFFFF0000u)); }
-__device__ __forceinline__ unsigned f2_to_bf2(v2 v) { return pack_bf16_rne(v[0], v[1]); }
+__device__ __forceinline__ v2 bf2_to_f2(unsigned w) { return mk2(h16_lo_to_f(w), h16_hi_to_f(w)); }      // the build's 16-bit type (common.h)
+__device__ __forceinline__ unsigned f2_to_bf2(v2 v) { return pack_h16_rne(v[0], v[1]); }
 __device__ __forceinline__ v2 fma2(v2 a, v2 b, v2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 // 8 / 4 consecutive channels as they sit in HBM (bf16: 16 / 8 bytes, fp32: 32 / 16 bytes), handed out as float2 pairs
 template <typename T> struct Ch8;
-template <> struct Ch8<bf16_t> {
+template <> struct Ch8<h16_t> {
     u32x4 r;
-    __device__ __forceinline__ void load(const bf16_t* p) { r = *(const u32x4*)p; }
+    __device__ __forceinline__ void load(const h16_t* p) { r = *(const u32x4*)p; }
     __device__ __forceinline__ void zero() { r[0] = 0u; r[1] = 0u; r[2] = 0u; r[3] = 0u; }
     __device__ __forceinline__ v2 get(int i) const { return bf2_to_f2(r[i]); }
-    static __device__ __forceinline__ void store(bf16_t* p, const v2 (&y)[4]) {
+    static __device__ __forceinline__ void store(h16_t* p, const v2 (&y)[4]) {
         u32x4 o;
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = f2_to_bf2(y[i]);
@@ -56,12 +58,12 @@ template <> struct Ch8<float> {
     }
 };
 template <typename T> struct Ch4;
-template <> struct Ch4<bf16_t> {
+template <> struct Ch4<h16_t> {
     u32x2 r;
-    __device__ __forceinline__ void load(const bf16_t* p) { r = *(const u32x2*)p; }
+    __device__ __forceinline__ void load(const h16_t* p) { r = *(const u32x2*)p; }
     __device__ __forceinline__ void zero() { r[0] = 0u; r[1] = 0u; }
     __device__ __forceinline__ v2 get(int i) const { return bf2_to_f2(r[i]); }
-    static __device__ __forceinline__ void store(bf16_t* p, const v2 (&y)[2]) {
+    static __device__ __forceinline__ void store(h16_t* p, const v2 (&y)[2]) {
         u32x2 o; o[0] = f2_to_bf2(y[0]); o[1] = f2_to_bf2(y[1]);
         *(u32x2*)p = o;
     }
@@ -520,8 +522,10 @@ static int fwd_launch_t(const void* h1, const void* convw, const void* gamma, vo
 int ffmid2_fwd_launch(const void* h1, const void* convw, const void* gamma, void* h2, float* mean, float* rstd, int M, int nseq,
                       int F, int Fp, float eps, float p, unsigned long long seed, const unsigned long long* seed_dev,
                       unsigned char* drop_bits, void* gh, int dtype, hipStream_t st) {
+#if !OMLM_FP16
     if (dtype == 0) return fwd_launch_t<float>(h1, convw, gamma, h2, mean, rstd, M, nseq, F, Fp, eps, p, seed, seed_dev, drop_bits, gh, st);
-    return fwd_launch_t<bf16_t>(h1, convw, gamma, h2, mean, rstd, M, nseq, F, Fp, eps, p, seed, seed_dev, drop_bits, gh, st);
+#endif
+    return fwd_launch_t<h16_t>(h1, convw, gamma, h2, mean, rstd, M, nseq, F, Fp, eps, p, seed, seed_dev, drop_bits, gh, st);
 }
 
 // bc: [M][2] floats of scratch; part_g: [>= rowsum blocks][Fp]; part_c: [>= NY][2F*3]
@@ -561,9 +565,13 @@ static int bwd_launch_t(const void* dh2, const void* h1, const void* convw, cons
 int ffmid2_bwd_launch(const void* dh2, const void* h1, const void* convw, const void* gamma, const float* rstd, float* bc,
                       void* dh1, float* part_g, int max_g_rows, float* part_c, int max_c_rows, int* g_rows, int* c_rows,
                       int M, int nseq, int F, int Fp, float p, const unsigned char* drop_bits, const void* gh, int dtype, hipStream_t st) {
+#if !OMLM_FP16
     if (dtype == 0)
         return bwd_launch_t<float>(dh2, h1, convw, gamma, rstd, bc, dh1, part_g, max_g_rows, part_c, max_c_rows, g_rows, c_rows,
                                    M, nseq, F, Fp, p, drop_bits, gh, st);
-    return bwd_launch_t<bf16_t>(dh2, h1, convw, gamma, rstd, bc, dh1, part_g, max_g_rows, part_c, max_c_rows, g_rows, c_rows,
+#endif
+    return bwd_launch_t<h16_t>(dh2, h1, convw, gamma, rstd, bc, dh1, part_g, max_g_rows, part_c, max_c_rows, g_rows, c_rows,
                                 M, nseq, F, Fp, p, drop_bits, gh, st);
 }
+
+}   // namespace OMLM_NS

@@ -39,6 +39,8 @@
 #include "common.h"
 #include <stdlib.h>
 
+namespace OMLM_NS {
+
 #define BM 128
 #define BN 128
 #define BK 64
@@ -148,11 +150,11 @@ struct Stager {
 
 // fragment of a 32-wide sub-tile (rows/cols sub0..sub0+31 of the 128-wide tile), k16 step s
 template <bool KMAJ>
-__device__ __forceinline__ bf16x8 read_frag(const char* lds, int sub0, int s, int lane) {
+__device__ __forceinline__ h16x8 read_frag(const char* lds, int sub0, int s, int lane) {
     if (!KMAJ) {
         const int row = sub0 + (lane & 31);
         const int kc = 2 * s + (lane >> 5);
-        return *(const bf16x8*)(lds + lds_off_normal(row, kc));
+        return *(const h16x8*)(lds + lds_off_normal(row, kc));
     } else {
         // two transpose reads of 4 k each: the lane ends up with column sub0 + (lane & 31), k = 16s + 8*(lane>>5) + 0..7.
         // Lane i of a 16-lane group supplies the address of the 8-byte piece (k-row i>>2, cols 4*(i&3)..+3) of the group's
@@ -164,7 +166,7 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, int sub0, int s, in
         s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base + 1024));
         typedef __attribute__((ext_vector_type(8))) short s16x8;
         s16x8 v = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
-        return __builtin_bit_cast(bf16x8, v);
+        return __builtin_bit_cast(h16x8, v);
     }
 }
 
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs g) {
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            bf16x8 ah[2], bh[2], al[2], bl[2];
+            h16x8 ah[2], bh[2], al[2], bl[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 ah[i] = read_frag<A_KMAJ>(As_hi, wm + 32 * i, s, lane);
@@ -272,10 +274,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     if (PRECISE) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = OMLM_MFMA_32x32x16(al[i], bh[j], acc[i][j]);
+                        acc[i][j] = OMLM_MFMA_32x32x16(ah[i], bl[j], acc[i][j]);
                     }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = OMLM_MFMA_32x32x16(ah[i], bh[j], acc[i][j]);
                 }
         }
         __syncthreads();
@@ -302,22 +304,12 @@ __device__ __forceinline__ dma_rsrc make_dma_rsrc(const void* p, unsigned long l
     r[0] = (unsigned)a; r[1] = (unsigned)(a >> 32) & 0xFFFFu; r[2] = bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)bytes; r[3] = 0x00020000u;
     return r;
 }
-#ifndef OMLM_DMA_LEAN
-#define OMLM_DMA_LEAN 0      /* experiment builds: 1 = one wait state after the M0 write instead of five; 2 = also no save / restore of M0 */
-#endif
+// (measured and dropped, round 3 first call, profiles/r03a_lib_ab.md: one wait state instead of five after the M0 write and no M0
+// save / restore -- +-2 %, inside the run-to-run band of the probe)
 __device__ __forceinline__ void dma_issue(dma_rsrc rs, unsigned lds_dst, unsigned off) {
-#if OMLM_DMA_LEAN == 2
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds"
-                 :: "v"(off), "s"(lds_dst), "s"(rs) : "memory", "m0");
-#elif OMLM_DMA_LEAN == 1
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(off), "s"(lds_dst), "s"(rs) : "memory");
-#else
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(off), "s"(lds_dst), "s"(rs) : "memory");
-#endif
 }
 
 template <bool KMAJ, int ROWS, int NWAVES>
@@ -441,8 +433,8 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16 (&acc)[M
                 }
                 if (sizeof(TOUT) == 2) {
                     u32x4 o;
-                    o[0] = pack_bf16_rne(v[0], v[1]); o[1] = pack_bf16_rne(v[2], v[3]);
-                    o[2] = pack_bf16_rne(v[4 % VEC], v[5 % VEC]); o[3] = pack_bf16_rne(v[6 % VEC], v[7 % VEC]);
+                    o[0] = pack_h16_rne(v[0], v[1]); o[1] = pack_h16_rne(v[2], v[3]);
+                    o[2] = pack_h16_rne(v[4 % VEC], v[5 % VEC]); o[3] = pack_h16_rne(v[6 % VEC], v[7 % VEC]);
                     *(u32x4*)(C + prow * g.ldc + col) = o;
                 } else {
                     *(float4*)((float*)g.C + prow * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
@@ -493,15 +485,6 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, 
         u1 = (int)(U * (lg + 1) / bal_wgs);
         if (u >= u1) return;
     }
-#ifndef OMLM_GEMM_W4
-#define OMLM_GEMM_W4 0
-#endif
-#ifndef OMLM_GEMM_BK32
-#define OMLM_GEMM_BK32 0
-#endif
-#ifndef OMLM_GEMM_ROTATE
-#define OMLM_GEMM_ROTATE 1          /* rotated k-loop (last k16 step multiplied after the next tile's barrier); 0: the round-1/2 loop */
-#endif
 #ifndef OMLM_SUPER_ROWS
 #define OMLM_SUPER_ROWS 1024       /* C rows per super-tile (tile rows walked column-major inside it) */
 #endif
@@ -570,19 +553,16 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, 
             sa.template issue<KMAP>(rsA, g.a_map, g.lda, k00, g.K, smem, wave, pa);
             sb.template issue<KMAP>(rsB, g.b_map, g.ldb, k00, g.K, smem + A_BYTES, wave, pb);
         }
-#if OMLM_GEMM_ROTATE
         // Rotated k-loop: the MFMAs of a tile's LAST k16 step run AFTER the next tile's barrier and first fragment reads (their
         // operands are in registers), so the matrix pipe has work while the barrier releases and the first LDS reads of the new
         // tile are in flight; the next tile's DMA issue is spread over that deferred step and steps 0, 1, and step 2 covers its
         // latency.  Same products in the same order per accumulator.
         {
-            bf16x8 a[2][MI], b[2][NJ];
+            h16x8 a[2][MI], b[2][NJ];
             bool pending = false;                                                  // a[1], b[1] hold an unmultiplied last step
             constexpr int MPS = MI * NJ, NLOAD = UA + UB;
-#ifndef OMLM_DMA_SPREAD_ROT
-#define OMLM_DMA_SPREAD_ROT 2      /* phases (of 4) over which the next tile's DMA issue is spread: 2 measured best (3: -1..+3 %, 4: worse) */
-#endif
-            constexpr int STRIDE = (OMLM_DMA_SPREAD_ROT * MPS) / NLOAD > 0 ? (OMLM_DMA_SPREAD_ROT * MPS) / NLOAD : 1;
+            constexpr int SPREAD = 2;          // phases (of 4) over which the next tile's DMA issue is spread: 2 measured best (1: -5 %, 3: -1..+3 %, 4: worse)
+            constexpr int STRIDE = (SPREAD * MPS) / NLOAD > 0 ? (SPREAD * MPS) / NLOAD : 1;
             for (int kt = kt0; kt < kt1; ++kt) {
                 const int cur = (kt - kt0) & 1;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -599,7 +579,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, 
                     for (int i = 0; i < MI; ++i)
 #pragma unroll
                         for (int j = 0; j < NJ; ++j) {
-                            if (mul && !(dbg & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[fi][i], b[fi][j], acc[i][j], 0, 0, 0);
+                            if (mul && !(dbg & 2)) acc[i][j] = OMLM_MFMA_32x32x16(a[fi][i], b[fi][j], acc[i][j]);
                             else if (mul) asm volatile("" :: "v"(a[fi][i]), "v"(b[fi][j]));
                             const int midx = ph * MPS + i * NJ + j;
                             if (midx % STRIDE == 0 && midx / STRIDE < NLOAD) {
@@ -634,71 +614,9 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, 
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = OMLM_MFMA_32x32x16(a[1][i], b[1][j], acc[i][j]);
             }
         }
-#else
-        for (int kt = kt0; kt < kt1; ++kt) {
-            const int cur = (kt - kt0) & 1;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile kt have landed (the DMA is asm: hipcc does not wait for it)
-            __syncthreads();          // tile kt landed everywhere, and the other stage is free
-            // The DMA of tile kt+1 is NOT issued in one burst here: a wave's instruction stream is in order, and a
-            // buffer_load..lds stalls at issue while the CU's vector-memory path is full, so a burst of 8 loads kept every
-            // wave out of its MFMAs for the whole transfer (measured: full time ~ DMA-only time + compute-only time).
-            // The loads are spread over the MFMAs of the first three k16 steps instead; the last step covers their latency.
-            const bool live = kt + 1 < kt1 && !(dbg & 1);
-            char* nxt = smem + (cur ^ 1) * STAGE;
-            unsigned pan, pbn;
-            const int knext = tile_at(kt + 1, pan, pbn);
-            const char* As = smem + cur * STAGE;
-            const char* Bs = As + A_BYTES;
-            // software-pipelined fragments: the LDS reads of k16-step s+1 are issued BEFORE the MFMAs of step s, so their
-            // latency hides under the matrix pipe (hipcc's own schedule read-then-multiplied each step: MFMA busy 30 %)
-            bf16x8 a[2][MI], b[2][NJ];
-            if (dbg & 8) {
-                if (!(dbg & 16)) sa.template issue<KMAP>(rsA, g.a_map, g.lda, live ? knext : g.K, g.K, nxt, wave);
-                if (!(dbg & 32)) sb.template issue<KMAP>(rsB, g.b_map, g.ldb, live ? knext : g.K, g.K, nxt + A_BYTES, wave);
-                continue;
-            }
-#pragma unroll
-            for (int i = 0; i < MI; ++i) a[0][i] = read_frag<A_KMAJ>(As, wm + 32 * i, 0, lane);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) b[0][j] = read_frag<B_KMAJ>(Bs, wn + 32 * j, 0, lane);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                if (s < 3) {
-#pragma unroll
-                    for (int i = 0; i < MI; ++i) a[(s + 1) & 1][i] = read_frag<A_KMAJ>(As, wm + 32 * i, s + 1, lane);
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) b[(s + 1) & 1][j] = read_frag<B_KMAJ>(Bs, wn + 32 * j, s + 1, lane);
-                    __builtin_amdgcn_sched_barrier(0);                            // DS reads of step s+1 stay above ...
-                }
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) {
-                        if (!(dbg & 2))
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s & 1][i], b[s & 1][j], acc[i][j], 0, 0, 0);
-                        else
-                            asm volatile("" :: "v"(a[s & 1][i]), "v"(b[s & 1][j]));
-                        constexpr int MPS = MI * NJ, NLOAD = UA + UB;
-#ifndef OMLM_DMA_SPREAD
-#define OMLM_DMA_SPREAD 3          /* k16 steps (of 4) over which the next tile's DMA issue is spread; tuned on the probe shapes */
-#endif
-                        constexpr int STRIDE = (OMLM_DMA_SPREAD * MPS) / NLOAD > 0 ? (OMLM_DMA_SPREAD * MPS) / NLOAD : 1;
-                        const int midx = s * MPS + i * NJ + j;                    // compile-time after unrolling
-                        if (midx % STRIDE == 0 && midx / STRIDE < NLOAD) {
-                            const int l = midx / STRIDE;
-                            __builtin_amdgcn_sched_barrier(0);
-                            if (l < UA) { if (!(dbg & 16)) sa.template issue_one<KMAP>(l, rsA, g.a_map, g.lda, knext, g.K, nxt, wave, live, (dbg >> 6) & 3, pan); }
-                            else        { if (!(dbg & 32)) sb.template issue_one<KMAP>(l - UA, rsB, g.b_map, g.ldb, knext, g.K, nxt + A_BYTES, wave, live, (dbg >> 6) & 3, pbn); }
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
-                __builtin_amdgcn_sched_barrier(0);                                // ... the MFMAs of step s
-            }
-        }
-#endif
         __syncthreads();
         tile_epilogue<MI, NJ, WN_, TOUT>(g, acc, smem, m0, n0, wm, wn, wave, lane, dbg, bal || split);
         if (!bal || u >= u1) break;
@@ -717,208 +635,6 @@ __global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile
     gemm_tile_body<BM_, BN_, WM_, WN_, A_KMAJ, B_KMAJ, TOUT, DBG, KMAP, BAL, SPLIT3>(g, lg, gridDim.y > 1, (int)gridDim.x, smem);
 }
 
-#if OMLM_GEMM_BK32
-// ---- experiment build: the 256x256 tile with 32-deep k-tiles in a FOUR-stage LDS ring --------------------------------------------
-// Same LDS (4 x 32 KiB), same DMA instruction count per byte, but three k-tiles (96 KiB) in flight per CU instead of one 64 KiB
-// stage, and a tile's DMA is issued three tiles (~3 x 1024 matrix-pipe cycles) before it is read instead of less than one: the test
-// of DESIGN 10.1's reading that the k-loop is bound by memory latency x bytes in flight.  One barrier per 32-deep tile; the rotated
-// schedule (the tile's second k16 step is multiplied after the next barrier) and the products' order per accumulator are the
-// production kernel's, so results must be bit-identical to it.  Plain launches only (no k-row maps, no balanced split, no planes).
-//
-// Row-major image of a 32-deep tile: [rows][32 k] bf16, 64 B per row, 16-B chunk index XOR ((row >> 2) & 3): a DMA unit (1 KiB,
-// lane-linear) is 16 rows; ds_read_b128 fragment reads are conflict-free (checked per lane group: tools/lds_conflicts.py).
-// k-major image: the production panels, half as tall ([32 k][128 cols], 8 KiB per panel).
-__device__ __forceinline__ int lds_off_normal32(int row, int kchunk) { return row * 64 + ((kchunk ^ ((row >> 2) & 3)) << 4); }
-
-template <bool KMAJ>
-__device__ __forceinline__ bf16x8 read_frag32(const char* lds, int sub0, int s, int lane) {     // s in {0, 1}
-    if (!KMAJ) {
-        const int row = sub0 + (lane & 31);
-        const int kc = 2 * s + (lane >> 5);
-        return *(const bf16x8*)(lds + lds_off_normal32(row, kc));
-    } else {
-        const int i16 = lane & 15, grp = lane >> 4, r = i16 >> 2;
-        const int k = 16 * s + 8 * (grp >> 1) + r;
-        const char* base = lds + (sub0 >> 7) * 8192 + k * 256 + ((((sub0 >> 5) & 3) ^ r) << 6) + (16 * (grp & 1) + 4 * (i16 & 3)) * 2;
-        s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base));
-        s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base + 1024));
-        typedef __attribute__((ext_vector_type(8))) short s16x8;
-        s16x8 v = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
-        return __builtin_bit_cast(bf16x8, v);
-    }
-}
-
-template <bool KMAJ, int ROWS, int NWAVES>
-struct DmaStager32 {
-    static constexpr int UPW = (ROWS / 16) / NWAVES;      // 1-KiB units per wave per 32-deep tile
-    unsigned base[UPW];
-    int kidx[UPW];
-    __device__ __forceinline__ void init(const int* map, int ld, int nvalid, int r0, int wave, int lane) {
-#pragma unroll
-        for (int i = 0; i < UPW; ++i) {
-            const int b = wave + NWAVES * i;
-            if (!KMAJ) {
-                const int row = 16 * b + (lane >> 2), slot = lane & 3;
-                const int kc = slot ^ ((row >> 2) & 3);
-                const int gr = r0 + row;
-                const bool ok = gr < nvalid;
-                const long long pr = (ok && map) ? (long long)map[gr] : (long long)gr;
-                base[i] = ok ? (unsigned)((pr * ld + kc * 8) * 2) : OOB_OFF;
-                kidx[i] = kc * 8;
-            } else {
-                // unit b = (panel b >> 3, k-group b & 7): 4 k-rows x 256 B, as in the production image
-                const int krow = 4 * (b & 7) + (lane >> 4);
-                const int piece = ((lane & 15) >> 2) ^ (lane >> 4);
-                const int gc = r0 + 128 * (b >> 3) + 32 * piece + 8 * (lane & 3);
-                base[i] = gc < nvalid ? (unsigned)(gc * 2) : OOB_OFF;
-                kidx[i] = krow;
-            }
-        }
-    }
-    __device__ __forceinline__ void issue_one(int i, dma_rsrc rs, int ld, int k0, int K, char* lds_tile, int wave, bool live) {
-        const int b = wave + NWAVES * i;
-        unsigned off;
-        if (!KMAJ) {
-            off = (live && base[i] != OOB_OFF && k0 + kidx[i] < K) ? base[i] + (unsigned)(k0 * 2) : OOB_OFF;
-        } else {
-            const int gk = k0 + kidx[i];
-            off = (live && base[i] != OOB_OFF && gk < K) ? base[i] + (unsigned)gk * (unsigned)(ld * 2) : OOB_OFF;
-        }
-        dma_issue(rs, (unsigned)(size_t)LDS_PTR(char, lds_tile) + (unsigned)(b * 1024), off);
-    }
-};
-
-template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ, bool B_KMAJ, typename TOUT>
-__global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile32_kernel(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];    // [4 stages][A | B]
-    constexpr int BKT = 32, NST = 4;
-    constexpr int NWN = BN_ / WN_, NWAVES = (BM_ / WM_) * NWN;
-    constexpr int MI = WM_ / 32, NJ = WN_ / 32;
-    constexpr int A_BYTES = BM_ * BKT * 2, B_BYTES = BN_ * BKT * 2, STAGE = A_BYTES + B_BYTES;
-    constexpr int UA = (BM_ / 16) / NWAVES, UB = (BN_ / 16) / NWAVES, NLOAD = UA + UB;
-    constexpr int MPS = MI * NJ;
-    static_assert(2 * NLOAD <= 63, "vmcnt immediate");
-    const int nwg = gridDim.x;
-    const int total = nwg * (int)gridDim.y;
-    const int lg = xcd_logical_id(blockIdx.y * nwg + blockIdx.x, total);
-    const bool split = gridDim.y > 1;
-    const int tiles_m = (g.M + BM_ - 1) / BM_, tiles_n = (g.N + BN_ - 1) / BN_;
-    const int ntile = tiles_m * tiles_n;
-    const int nk_all = (g.K + BKT - 1) / BKT;
-    const int ksplit = lg / ntile, bid = lg - ksplit * ntile;
-    const int kt0 = ksplit * g.kt_per_split * 2;                   // kt_per_split counts 64-deep tiles
-    const int kt1 = min(nk_all, kt0 + 2 * g.kt_per_split);
-    constexpr int GROUP = OMLM_SUPER_ROWS / BM_;
-    const int gsz = GROUP * tiles_n;
-    const int grp = bid / gsz, first_m = grp * GROUP;
-    const int rows_in = min(GROUP, tiles_m - first_m);
-    const int tm = first_m + (bid - grp * gsz) % rows_in, tn = (bid - grp * gsz) / rows_in;
-    const int m0 = tm * BM_, n0 = tn * BN_;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = (wave / NWN) * WM_, wn = (wave % NWN) * WN_;
-    const dma_rsrc rsA = make_dma_rsrc(g.A, (unsigned long long)g.a_rows * g.lda * 2);
-    const dma_rsrc rsB = make_dma_rsrc(g.B, (unsigned long long)g.b_rows * g.ldb * 2);
-    DmaStager32<A_KMAJ, BM_, NWAVES> sa;
-    DmaStager32<B_KMAJ, BN_, NWAVES> sb;
-    sa.init(g.a_map, g.lda, g.M, m0, wave, lane);
-    sb.init(g.b_map, g.ldb, g.N, n0, wave, lane);
-
-    f32x16 acc[MI][NJ];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    // one tile's NLOAD pieces of this wave; a tile past the end is requested out of bounds (zeros, no traffic) so that the number of
-    // outstanding pieces per tile is constant and the counted wait below is exact
-    auto issue_piece = [&](int l, int t) {
-        char* st = smem + ((t - kt0) & (NST - 1)) * STAGE;
-        const bool live = t < kt1;
-        if (l < UA) sa.issue_one(l, rsA, g.lda, t * BKT, g.K, st, wave, live);
-        else        sb.issue_one(l - UA, rsB, g.ldb, t * BKT, g.K, st + A_BYTES, wave, live);
-    };
-#pragma unroll
-    for (int d = 0; d < NST - 1; ++d)
-#pragma unroll
-        for (int l = 0; l < NLOAD; ++l) issue_piece(l, kt0 + d);
-
-    bf16x8 a[2][MI], b[2][NJ];
-    bool pending = false;
-#ifndef OMLM_BK32_SPREAD
-#define OMLM_BK32_SPREAD 2           /* phases (of 2) over which the DMA issue of tile t+3 is spread */
-#endif
-    constexpr int STRIDE = (OMLM_BK32_SPREAD * MPS) / NLOAD > 0 ? (OMLM_BK32_SPREAD * MPS) / NLOAD : 1;
-    for (int kt = kt0; kt < kt1; ++kt) {
-        // this wave's pieces of tile kt have landed when at most the 2 * NLOAD younger ones (tiles kt+1, kt+2) are outstanding
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NLOAD) : "memory");
-        __syncthreads();              // tile kt landed everywhere; every wave's reads of tile kt-1 (whose stage tile kt+3 overwrites) are complete
-        const char* As = smem + ((kt - kt0) & (NST - 1)) * STAGE;
-        const char* Bs = As + A_BYTES;
-        auto phase = [&](const int ph, const int fi, const bool mul) {
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    if (mul) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[fi][i], b[fi][j], acc[i][j], 0, 0, 0);
-                    const int midx = ph * MPS + i * NJ + j;
-                    if (midx % STRIDE == 0 && midx / STRIDE < NLOAD) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        issue_piece(midx / STRIDE, kt + NST - 1);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-        };
-#pragma unroll
-        for (int i = 0; i < MI; ++i) a[0][i] = read_frag32<A_KMAJ>(As, wm + 32 * i, 0, lane);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) b[0][j] = read_frag32<B_KMAJ>(Bs, wn + 32 * j, 0, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        phase(0, 1, pending);                                      // second k16 step of the previous tile (registers only)
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < MI; ++i) a[1][i] = read_frag32<A_KMAJ>(As, wm + 32 * i, 1, lane);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) b[1][j] = read_frag32<B_KMAJ>(Bs, wn + 32 * j, 1, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        phase(1, 0, true);                                         // first k16 step of this tile
-        __builtin_amdgcn_sched_barrier(0);
-        pending = true;
-    }
-    if (pending) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], acc[i][j], 0, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the out-of-bounds tail requests still write zeros into the ring
-    __syncthreads();
-    tile_epilogue<MI, NJ, WN_, TOUT>(g, acc, smem, m0, n0, wm, wn, wave, lane, 0, split);
-}
-
-template <int BM_, int BN_, int WM_, int WN_, typename TOUT>
-static int launch_tile32(const GemmArgs& g, int a_kmaj, int b_kmaj, int splits, hipStream_t st) {
-    constexpr int NTH = (BM_ / WM_) * (BN_ / WN_) * 64;
-    constexpr size_t LDS = 4 * (size_t)(BM_ + BN_) * 32 * 2;
-    const int tiles = ((g.M + BM_ - 1) / BM_) * ((g.N + BN_ - 1) / BN_);
-    dim3 grid(tiles, splits), block(NTH);
-#define OMLM_TILE32_LAUNCH(AK, BKM)                                                                                        \
-    do {                                                                                                                    \
-        auto kfn = gemm_bf16_tile32_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT>;                                              \
-        static bool attr = false;                                                                                           \
-        if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); attr = true; } \
-        hipLaunchKernelGGL(kfn, grid, block, LDS, st, g);                                                                   \
-    } while (0)
-    if (!a_kmaj && !b_kmaj)      OMLM_TILE32_LAUNCH(false, false);
-    else if (!a_kmaj && b_kmaj)  OMLM_TILE32_LAUNCH(false, true);
-    else if (a_kmaj && b_kmaj)   OMLM_TILE32_LAUNCH(true, true);
-    else                         OMLM_TILE32_LAUNCH(true, false);
-#undef OMLM_TILE32_LAUNCH
-    return omlm_post_launch("omlm_gemm");
-}
-#endif   // OMLM_GEMM_BK32
 
 // ---- grouped weight-gradient GEMM ------------------------------------------------------------------------------------
 // All dW += dY^T X contractions of a backward pass (same K = tokens, small outputs) as ONE launch: the 30 separate GEMMs of a
@@ -953,29 +669,36 @@ static int launch_tile(const GemmArgs& g, int a_kmaj, int b_kmaj, int splits, hi
     if (g.bal_ck > 0) grid = dim3(splits, 1);          // balanced split-K: `splits` carries the workgroup count
     const bool need_kmap = (a_kmaj && g.a_map) || (b_kmaj && g.b_map);       // host routes these to the 128x128 tile
     if (need_kmap && BM_ != 128) { omlm_set_error("omlm_gemm: k-row maps are only built for the 128x128 tile"); return OMLM_ERR_UNSUPPORTED; }
+    // The fp16 copy of this file (common.h: OMLM_FP16) instantiates only the production kernel and its k-row-map form: the ablation
+    // (DBG), balanced split-K (BAL) and hi/lo-plane (SPLIT3) instantiations exist once, in the bf16 copy.
 #define OMLM_TILE_LAUNCH(AK, BKM)                                                                                          \
     do {                                                                                                                    \
         auto kfn = gemm_bf16_tile_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT, false, false>;                                 \
-        auto kdbg = gemm_bf16_tile_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT, true, false>;                                 \
         auto kmap = gemm_bf16_tile_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT, false, (AK || BKM) && BM_ == 128>;            \
-        auto kbal = gemm_bf16_tile_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT, false, false, sizeof(TOUT) == 4>;            \
-        auto kbalmap = gemm_bf16_tile_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT, false, (AK || BKM) && BM_ == 128, sizeof(TOUT) == 4>; \
-        auto ks3 = gemm_bf16_tile_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT, false, false, false, true>;                     \
         static bool attr = false;                                                                                           \
         if (!attr) {                                                                                                        \
             (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);             \
-            (void)hipFuncSetAttribute((const void*)kdbg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);            \
             (void)hipFuncSetAttribute((const void*)kmap, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);            \
-            (void)hipFuncSetAttribute((const void*)kbal, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);            \
-            (void)hipFuncSetAttribute((const void*)kbalmap, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);         \
-            (void)hipFuncSetAttribute((const void*)ks3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);             \
-            attr = true;                                                                                                    \
         }                                                                                                                   \
-        if (g.split3) hipLaunchKernelGGL(ks3, grid, block, LDS, st, g);                                                    \
-        else if (g.bal_ck > 0 && sizeof(TOUT) == 4) hipLaunchKernelGGL(need_kmap ? kbalmap : kbal, grid, block, LDS, st, g); \
-        else if (need_kmap) hipLaunchKernelGGL(kmap, grid, block, LDS, st, g);                                             \
-        else if (g.debug) hipLaunchKernelGGL(kdbg, grid, block, LDS, st, g);                                               \
-        else              hipLaunchKernelGGL(kfn, grid, block, LDS, st, g);                                                \
+        if constexpr (!OMLM_FP16) {                                                                                         \
+            auto kdbg = gemm_bf16_tile_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT, true, false>;                             \
+            auto kbal = gemm_bf16_tile_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT, false, false, sizeof(TOUT) == 4>;        \
+            auto kbalmap = gemm_bf16_tile_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT, false, (AK || BKM) && BM_ == 128, sizeof(TOUT) == 4>; \
+            auto ks3 = gemm_bf16_tile_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT, false, false, false, true>;                 \
+            if (!attr) {                                                                                                    \
+                (void)hipFuncSetAttribute((const void*)kdbg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);        \
+                (void)hipFuncSetAttribute((const void*)kbal, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);        \
+                (void)hipFuncSetAttribute((const void*)kbalmap, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);     \
+                (void)hipFuncSetAttribute((const void*)ks3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);         \
+            }                                                                                                               \
+            attr = true;                                                                                                    \
+            if (g.split3) { hipLaunchKernelGGL(ks3, grid, block, LDS, st, g); break; }                                     \
+            if (g.bal_ck > 0 && sizeof(TOUT) == 4) { hipLaunchKernelGGL(need_kmap ? kbalmap : kbal, grid, block, LDS, st, g); break; } \
+            if (g.debug && !need_kmap) { hipLaunchKernelGGL(kdbg, grid, block, LDS, st, g); break; }                       \
+        }                                                                                                                   \
+        attr = true;                                                                                                        \
+        if (need_kmap) hipLaunchKernelGGL(kmap, grid, block, LDS, st, g);                                                  \
+        else           hipLaunchKernelGGL(kfn, grid, block, LDS, st, g);                                                   \
     } while (0)
     if (!a_kmaj && !b_kmaj)      OMLM_TILE_LAUNCH(false, false);
     else if (!a_kmaj && b_kmaj)  OMLM_TILE_LAUNCH(false, true);
@@ -1075,7 +798,7 @@ static int gemm_impl(const void* A, const void* B, void* C, const float* Cin,
         // the k-major main loop, not the partial last round or the atomic volume, is what holds these GEMMs at ~620 TFLOP/s.
         // Off by default; OMLM_GEMM_BAL=1 selects it.
         if (bal_on < 0) { const char* e = getenv("OMLM_GEMM_BAL"); bal_on = (e && e[0] == '1') ? 1 : 0; }
-        if (bal_on) {
+        if (bal_on && !OMLM_FP16) {
             const int slots = (bm == 256 ? 1 : 2) * ncu;
             const long long U = (long long)tiles * nk;
             long long G = slots;
@@ -1087,6 +810,10 @@ static int gemm_impl(const void* A, const void* B, void* C, const float* Cin,
         }
     }
     if (in_dtype == 0) {
+#if OMLM_FP16
+        omlm_set_error("omlm_gemm: fp32 operands are served by the bf16 copy of the library");
+        return OMLM_ERR_UNSUPPORTED;
+#else
         static bool attr_done = false;   // 64 KiB dynamic LDS needs the opt-in attribute once per kernel
         if (!attr_done) {
             (void)hipFuncSetAttribute((const void*)gemm_kernel<float, false, false, float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
@@ -1097,28 +824,17 @@ static int gemm_impl(const void* A, const void* B, void* C, const float* Cin,
         }
         OMLM_CHECK_ARG(out_dtype == 0, "fp32 operands produce fp32 output");
         return launch_layout<float, float>(g, a_kmajor, b_kmajor, splits, st);
+#endif
     }
     auto launch = [&](const GemmArgs& ga, int tm_, int tn_, int sp) -> int {
-#if OMLM_GEMM_BK32        /* experiment build: 32-deep k-tiles in a four-stage ring for the plain 256x256 launches */
-        if (tm_ == 256 && tn_ == 256 && !ga.split3 && ga.bal_ck == 0 && !ga.debug &&
-            !((a_kmajor && ga.a_map) || (b_kmajor && ga.b_map)))
-            return out_dtype == 0 ? launch_tile32<256, 256, 128, 64, float>(ga, a_kmajor, b_kmajor, sp, st)
-                                  : launch_tile32<256, 256, 128, 64, bf16_t>(ga, a_kmajor, b_kmajor, sp, st);
-#endif
-#if OMLM_GEMM_W4          /* experiment build: the 256x256 tile on FOUR waves of 128x128 (one per SIMD, 512 registers, a third less LDS read traffic) */
-        if (tm_ == 256 && tn_ == 256)
-            return out_dtype == 0 ? launch_tile<256, 256, 128, 128, float>(ga, a_kmajor, b_kmajor, sp, st)
-                                  : launch_tile<256, 256, 128, 128, bf16_t>(ga, a_kmajor, b_kmajor, sp, st);
-#else
         if (tm_ == 256 && tn_ == 256)
             return out_dtype == 0 ? launch_tile<256, 256, 128, 64, float>(ga, a_kmajor, b_kmajor, sp, st)
-                                  : launch_tile<256, 256, 128, 64, bf16_t>(ga, a_kmajor, b_kmajor, sp, st);
-#endif
+                                  : launch_tile<256, 256, 128, 64, h16_t>(ga, a_kmajor, b_kmajor, sp, st);
         if (tm_ == 256 && tn_ == 128)
             return out_dtype == 0 ? launch_tile<256, 128, 64, 64, float>(ga, a_kmajor, b_kmajor, sp, st)
-                                  : launch_tile<256, 128, 64, 64, bf16_t>(ga, a_kmajor, b_kmajor, sp, st);
+                                  : launch_tile<256, 128, 64, 64, h16_t>(ga, a_kmajor, b_kmajor, sp, st);
         return out_dtype == 0 ? launch_tile<128, 128, 64, 64, float>(ga, a_kmajor, b_kmajor, sp, st)
-                              : launch_tile<128, 128, 64, 64, bf16_t>(ga, a_kmajor, b_kmajor, sp, st);
+                              : launch_tile<128, 128, 64, 64, h16_t>(ga, a_kmajor, b_kmajor, sp, st);
     };
     // Tail peeling for the one-workgroup-per-CU 256x256 tiles: dX-type GEMMs have 560 tiles = 2.19 rounds of 256 CUs, i.e. a
     // third round that is 19 % full.  The m-tile rows that fill whole rounds keep the 256x256 kernel; the remaining rows go to
@@ -1145,15 +861,30 @@ static int gemm_impl(const void* A, const void* B, void* C, const float* Cin,
     return launch(g, bm, bn, splits);
 }
 
-extern "C" int omlm_gemm(const void* A, const void* B, void* C, const float* Cin,
+// in_dtype / out_dtype: 0 = fp32, 1 = bf16, 2 = fp16 (include/omlm.h).  fp16 operands (with fp32 or fp16 output) are served by the
+// fp16 copy of this file; bf16 and fp32 operands here.
+#if !OMLM_FP16
+extern "C" int omlm_gemm_h(const void* A, const void* B, void* C, const float* Cin, const int* a_map, const int* b_map, const int* c_map,
+                           long long a_rows, long long b_rows, int M, int N, int K, int lda, int ldb, int ldc, int ldcin,
+                           int a_kmajor, int b_kmajor, int in_dtype, int out_dtype, float alpha, void* stream);
+#endif
+extern "C" int OMLM_API(omlm_gemm)(const void* A, const void* B, void* C, const float* Cin,
                          const int* a_map, const int* b_map, const int* c_map,
                          long long a_rows, long long b_rows,
                          int M, int N, int K, int lda, int ldb, int ldc, int ldcin,
                          int a_kmajor, int b_kmajor, int in_dtype, int out_dtype, float alpha, void* stream) {
+#if !OMLM_FP16
+    if (in_dtype == OMLM_DT_F16) {
+        OMLM_CHECK_ARG(out_dtype == OMLM_DT_F32 || out_dtype == OMLM_DT_F16, "fp16 operands produce fp32 or fp16 output");
+        return omlm_gemm_h(A, B, C, Cin, a_map, b_map, c_map, a_rows, b_rows, M, N, K, lda, ldb, ldc, ldcin, a_kmajor, b_kmajor,
+                           1, OMLM_H_CODE(out_dtype), alpha, stream);
+    }
+#endif
     return gemm_impl(A, B, C, Cin, a_map, b_map, c_map, a_rows, b_rows, M, N, K, lda, ldb, ldc, ldcin, a_kmajor, b_kmajor,
                      in_dtype, out_dtype, alpha, stream, 0, 0u, 0u);
 }
 
+#if !OMLM_FP16
 // fp32-grade GEMM on bf16 hi/lo planes ("bf16x3" through the LDS-DMA tile kernels).  A and B are bf16 hi planes in the layout
 // omlm_gemm takes for bf16 operands; the matching lo plane lies a_plane_bytes / b_plane_bytes behind each (omlm_split_planes
 // writes such a pair).  One launch whose k-loop is three times as long: hi*hi + hi*lo + lo*hi, accumulated in fp32 -- the same
@@ -1209,11 +940,21 @@ extern "C" int omlm_split_planes(const float* x, void* planes, long long n, long
     return omlm_post_launch("omlm_split_planes");
 }
 
-// C_i[M_i, N_i] += A_i^T B_i for `count` problems with bf16 k-major operands A_i [K_i, M_i], B_i [K_i, N_i] in ONE launch of 256x256
-// full-K (or lightly split) tiles.  splits: K-splits per tile for every problem (0 = chosen here for whole machine rounds).
-extern "C" int omlm_gemm_wgrad_group(const omlm_gemm_wgrad_desc* d, int count, int splits, void* stream) {
+#endif   // !OMLM_FP16 (operand planes: bf16 copy only)
+
+// C_i[M_i, N_i] += A_i^T B_i for `count` problems with 16-bit k-major operands A_i [K_i, M_i], B_i [K_i, N_i] in ONE launch of 256x256
+// full-K (or lightly split) tiles.  splits: K-splits per tile for every problem (0 = chosen here for whole machine rounds);
+// dtype: operand type of ALL problems (1 = bf16, 2 = fp16).
+#if !OMLM_FP16
+extern "C" int omlm_gemm_wgrad_group_h(const omlm_gemm_wgrad_desc* d, int count, int splits, int dtype, void* stream);
+#endif
+extern "C" int OMLM_API(omlm_gemm_wgrad_group)(const omlm_gemm_wgrad_desc* d, int count, int splits, int dtype, void* stream) {
     if (count <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(d, "null descriptor array");
+#if !OMLM_FP16
+    if (dtype == OMLM_DT_F16) return omlm_gemm_wgrad_group_h(d, count, splits, 1, stream);
+#endif
+    OMLM_CHECK_ARG(dtype == 1, "wgrad group: operand dtype must be 1 (bf16) or 2 (fp16)");
     static int ncu = 0;
     if (ncu == 0) {
         int dev = 0, n = 0;
@@ -1270,3 +1011,5 @@ extern "C" int omlm_gemm_wgrad_group(const omlm_gemm_wgrad_desc* d, int count, i
     }
     return omlm_post_launch("omlm_gemm_wgrad_group");
 }
+
+}   // namespace OMLM_NS

@@ -5,6 +5,8 @@
 // written in the same pass in the GEMM operand type T (bf16, or fp32 for the bf16x3 mode).
 #include "common.h"
 
+namespace OMLM_NS {
+
 #define LN_THREADS 256
 #define LN_MAXV 4   // float4 pieces per thread  -> D <= 4096
 
@@ -61,9 +63,9 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restr
 // dy arrives as fp32 or -- in bf16 mode, straight from the input-gradient GEMM's epilogue -- as bf16: the GEMM accumulates in fp32
 // and rounds once (the same rounding every other GEMM operand of that mode gets); 73 MB less to write and to re-read per call
 __device__ __forceinline__ float4 load4f(const float* p, int c) { return ((const float4*)p)[c]; }
-__device__ __forceinline__ float4 load4f(const bf16_t* p, int c) {
+__device__ __forceinline__ float4 load4f(const h16_t* p, int c) {
     const u32x2 w = ((const u32x2*)p)[c];
-    return make_float4(bf16_lo_to_f(w[0]), bf16_hi_to_f(w[0]), bf16_lo_to_f(w[1]), bf16_hi_to_f(w[1]));
+    return make_float4(h16_lo_to_f(w[0]), h16_hi_to_f(w[0]), h16_lo_to_f(w[1]), h16_hi_to_f(w[1]));
 }
 template <typename T, typename TDY>
 __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const TDY* __restrict__ dy, const float* __restrict__ x,
@@ -136,8 +138,14 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const TDY* __restric
 
 static int ln_grid(int M) { return M < 2048 ? M : 2048; }
 
-extern "C" int omlm_layernorm_fwd(const float* x, const float* gamma, void* y, void* xcast, float* mean, float* rstd,
+#if !OMLM_FP16
+extern "C" int omlm_layernorm_fwd_h(const float* x, const float* gamma, void* y, void* xcast, float* mean, float* rstd, int M, int D, int ldy, float eps, int out_dtype, void* stream);
+#endif
+extern "C" int OMLM_API(omlm_layernorm_fwd)(const float* x, const float* gamma, void* y, void* xcast, float* mean, float* rstd,
                                   int M, int D, int ldy, float eps, int out_dtype, void* stream) {
+#if !OMLM_FP16
+    if (out_dtype == OMLM_DT_F16) return omlm_layernorm_fwd_h(x, gamma, y, xcast, mean, rstd, M, D, ldy, eps, 1, stream);
+#endif
     if (M <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(x && gamma && y, "null pointer");
     OMLM_CHECK_ARG(D % 4 == 0 && D <= 4 * LN_THREADS * LN_MAXV, "D must be a multiple of 4 and <= 4096");
@@ -146,16 +154,24 @@ extern "C" int omlm_layernorm_fwd(const float* x, const float* gamma, void* y, v
     if (out_dtype == 0)
         hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, block, 0, as_stream(stream), x, gamma, (float*)y, (float*)xcast, mean, rstd, M, D, ldy, eps);
     else
-        hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, block, 0, as_stream(stream), x, gamma, (bf16_t*)y, (bf16_t*)xcast, mean, rstd, M, D, ldy, eps);
+        hipLaunchKernelGGL(ln_fwd_kernel<h16_t>, grid, block, 0, as_stream(stream), x, gamma, (h16_t*)y, (h16_t*)xcast, mean, rstd, M, D, ldy, eps);
     return omlm_post_launch("omlm_layernorm_fwd");
 }
 
 extern "C" int omlm_colsum_accumulate(const float* part, float* out, int P, int C, int ldp, void* stream);
+#if !OMLM_FP16
 extern "C" long long omlm_layernorm_bwd_workspace_bytes(int D) { return (long long)2048 * D * sizeof(float); }
+#endif
 
-extern "C" int omlm_layernorm_bwd(const void* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+#if !OMLM_FP16
+extern "C" int omlm_layernorm_bwd_h(const void* dy, const float* x, const float* gamma, const float* mean, const float* rstd, const float* dres, float* dx, void* dxcast, float* dgamma, float* workspace, int M, int D, float dx_scale, int cast_dtype, int dy_dtype, void* stream);
+#endif
+extern "C" int OMLM_API(omlm_layernorm_bwd)(const void* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                                   const float* dres, float* dx, void* dxcast, float* dgamma, float* workspace, int M, int D,
                                   float dx_scale, int cast_dtype, int dy_dtype, void* stream) {
+#if !OMLM_FP16
+    if (cast_dtype == OMLM_DT_F16 || dy_dtype == OMLM_DT_F16) return omlm_layernorm_bwd_h(dy, x, gamma, mean, rstd, dres, dx, dxcast, dgamma, workspace, M, D, dx_scale, OMLM_H_CODE(cast_dtype), OMLM_H_CODE(dy_dtype), stream);
+#endif
     if (M <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(dy && x && gamma && mean && rstd && dx, "null pointer");
     OMLM_CHECK_ARG(D % 4 == 0 && D <= 4 * LN_THREADS * LN_MAXV, "D must be a multiple of 4 and <= 4096");
@@ -166,15 +182,15 @@ extern "C" int omlm_layernorm_bwd(const void* dy, const float* x, const float* g
     const int blocks = two_level ? (M < 2048 ? M : 2048) : (M < 512 ? M : 512);
     dim3 grid(blocks), block(LN_THREADS);
     float* part = two_level ? workspace : nullptr;
-    OMLM_CHECK_ARG(dy_dtype == 0 || dy_dtype == 1, "dy_dtype: 0 = fp32, 1 = bf16");
+    OMLM_CHECK_ARG(dy_dtype == 0 || dy_dtype == 1, "dy_dtype: 0 = fp32, 1 = bf16, 2 = fp16 (same 16-bit type as the cast output)");
     if (cast_dtype == 0 && dy_dtype == 0)
         hipLaunchKernelGGL((ln_bwd_kernel<float, float>), grid, block, 0, as_stream(stream), (const float*)dy, x, gamma, mean, rstd, dres, dx, (float*)dxcast, dgamma, part, M, D, dx_scale);
     else if (cast_dtype == 0)
-        hipLaunchKernelGGL((ln_bwd_kernel<float, bf16_t>), grid, block, 0, as_stream(stream), (const bf16_t*)dy, x, gamma, mean, rstd, dres, dx, (float*)dxcast, dgamma, part, M, D, dx_scale);
+        hipLaunchKernelGGL((ln_bwd_kernel<float, h16_t>), grid, block, 0, as_stream(stream), (const h16_t*)dy, x, gamma, mean, rstd, dres, dx, (float*)dxcast, dgamma, part, M, D, dx_scale);
     else if (dy_dtype == 0)
-        hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, float>), grid, block, 0, as_stream(stream), (const float*)dy, x, gamma, mean, rstd, dres, dx, (bf16_t*)dxcast, dgamma, part, M, D, dx_scale);
+        hipLaunchKernelGGL((ln_bwd_kernel<h16_t, float>), grid, block, 0, as_stream(stream), (const float*)dy, x, gamma, mean, rstd, dres, dx, (h16_t*)dxcast, dgamma, part, M, D, dx_scale);
     else
-        hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, bf16_t>), grid, block, 0, as_stream(stream), (const bf16_t*)dy, x, gamma, mean, rstd, dres, dx, (bf16_t*)dxcast, dgamma, part, M, D, dx_scale);
+        hipLaunchKernelGGL((ln_bwd_kernel<h16_t, h16_t>), grid, block, 0, as_stream(stream), (const h16_t*)dy, x, gamma, mean, rstd, dres, dx, (h16_t*)dxcast, dgamma, part, M, D, dx_scale);
     int rc = omlm_post_launch("omlm_layernorm_bwd");
     if (rc) return rc;
     if (two_level) return omlm_colsum_accumulate(part, dgamma, blocks, D, D, stream);
@@ -193,7 +209,7 @@ __device__ __forceinline__ float group16_sum(float v) {
     return v;
 }
 __device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) { *(float4*)p = make_float4(a, b, c, d); }
-__device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, float d) { store4_from_float(p, a, b, c, d); }
+__device__ __forceinline__ void store4(h16_t* p, float a, float b, float c, float d) { store4_from_float(p, a, b, c, d); }
 
 template <typename T>
 __global__ __launch_bounds__(256) void qk_norm_fwd_kernel(const float* __restrict__ q_raw, const float* __restrict__ kv_raw,
@@ -280,8 +296,14 @@ __global__ __launch_bounds__(256) void qk_norm_bwd_kernel(const float* __restric
     }
 }
 
-extern "C" int omlm_qk_norm_fwd(const float* q_raw, const float* kv_raw, const float* q_scale, const float* k_scale,
+#if !OMLM_FP16
+extern "C" int omlm_qk_norm_fwd_h(const float* q_raw, const float* kv_raw, const float* q_scale, const float* k_scale, void* q, void* k, void* v, int M, int H, int out_dtype, void* stream);
+#endif
+extern "C" int OMLM_API(omlm_qk_norm_fwd)(const float* q_raw, const float* kv_raw, const float* q_scale, const float* k_scale,
                                 void* q, void* k, void* v, int M, int H, int out_dtype, void* stream) {
+#if !OMLM_FP16
+    if (out_dtype == OMLM_DT_F16) return omlm_qk_norm_fwd_h(q_raw, kv_raw, q_scale, k_scale, q, k, v, M, H, 1, stream);
+#endif
     if (M <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(q_raw && kv_raw && q_scale && k_scale && q && k && v, "null pointer");
     long long nvec = (long long)M * (H + 2);
@@ -289,13 +311,19 @@ extern "C" int omlm_qk_norm_fwd(const float* q_raw, const float* kv_raw, const f
     if (out_dtype == 0)
         hipLaunchKernelGGL(qk_norm_fwd_kernel<float>, dim3(blocks), dim3(256), 0, as_stream(stream), q_raw, kv_raw, q_scale, k_scale, (float*)q, (float*)k, (float*)v, M, H);
     else
-        hipLaunchKernelGGL(qk_norm_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, as_stream(stream), q_raw, kv_raw, q_scale, k_scale, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v, M, H);
+        hipLaunchKernelGGL(qk_norm_fwd_kernel<h16_t>, dim3(blocks), dim3(256), 0, as_stream(stream), q_raw, kv_raw, q_scale, k_scale, (h16_t*)q, (h16_t*)k, (h16_t*)v, M, H);
     return omlm_post_launch("omlm_qk_norm_fwd");
 }
 
-extern "C" int omlm_qk_norm_bwd(const float* dq, const float* dk, const float* dv, const float* q_raw, const float* kv_raw,
+#if !OMLM_FP16
+extern "C" int omlm_qk_norm_bwd_h(const float* dq, const float* dk, const float* dv, const float* q_raw, const float* kv_raw, const float* q_scale, const float* k_scale, void* dq_raw, void* dkv_raw, float* dq_scale, float* dk_scale, int M, int H, int out_dtype, void* stream);
+#endif
+extern "C" int OMLM_API(omlm_qk_norm_bwd)(const float* dq, const float* dk, const float* dv, const float* q_raw, const float* kv_raw,
                                 const float* q_scale, const float* k_scale, void* dq_raw, void* dkv_raw,
                                 float* dq_scale, float* dk_scale, int M, int H, int out_dtype, void* stream) {
+#if !OMLM_FP16
+    if (out_dtype == OMLM_DT_F16) return omlm_qk_norm_bwd_h(dq, dk, dv, q_raw, kv_raw, q_scale, k_scale, dq_raw, dkv_raw, dq_scale, dk_scale, M, H, 1, stream);
+#endif
     if (M <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(dq && dk && dv && q_raw && kv_raw && dq_raw && dkv_raw && dq_scale && dk_scale, "null pointer");
     long long nvec = (long long)M * (H + 2);
@@ -303,6 +331,8 @@ extern "C" int omlm_qk_norm_bwd(const float* dq, const float* dk, const float* d
     if (out_dtype == 0)
         hipLaunchKernelGGL(qk_norm_bwd_kernel<float>, dim3(blocks), dim3(256), 0, as_stream(stream), dq, dk, dv, q_raw, kv_raw, q_scale, k_scale, (float*)dq_raw, (float*)dkv_raw, dq_scale, dk_scale, M, H);
     else
-        hipLaunchKernelGGL(qk_norm_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, as_stream(stream), dq, dk, dv, q_raw, kv_raw, q_scale, k_scale, (bf16_t*)dq_raw, (bf16_t*)dkv_raw, dq_scale, dk_scale, M, H);
+        hipLaunchKernelGGL(qk_norm_bwd_kernel<h16_t>, dim3(blocks), dim3(256), 0, as_stream(stream), dq, dk, dv, q_raw, kv_raw, q_scale, k_scale, (h16_t*)dq_raw, (h16_t*)dkv_raw, dq_scale, dk_scale, M, H);
     return omlm_post_launch("omlm_qk_norm_bwd");
 }
+
+}   // namespace OMLM_NS

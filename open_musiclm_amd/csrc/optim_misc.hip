@@ -42,9 +42,11 @@ extern "C" int omlm_sumsq_accumulate(const float* g, long long n, float* out, fl
 // p, g, m, v: flat fp32.  g is first scaled by gscale (1/world_size for the DP mean) and by the clip coefficient
 // min(1, max_norm / (gscale * sqrt(*gnorm_sq) + 1e-6)) (torch.nn.utils.clip_grad_norm_), all on device: no host sync.
 // decoupled != 0 -> AdamW (p *= 1 - lr*wd); else Adam with L2 folded into the gradient (wd is 0 on the reference's Adam path).
-// p16 (optional) receives the bf16 copy of the updated parameters; zero_grad != 0 clears g in the same pass.
+// p16 (optional) receives the 16-bit copy of the updated parameters (p16_dtype: 1 = bf16, 2 = fp16: the GEMM operand type of the
+// model's precision mode); zero_grad != 0 clears g in the same pass.  gscale also carries 1 / loss-scale in fp16 mode.
+template <typename T16>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
-                                                    float* __restrict__ v, bf16_t* __restrict__ p16, long long n,
+                                                    float* __restrict__ v, T16* __restrict__ p16, long long n,
                                                     float lr, float beta1, float beta2, float eps, float wd,
                                                     float bc1, float bc2_sqrt, float gscale, const float* __restrict__ gnorm_sq,
                                                     float max_norm, int decoupled, int zero_grad) {
@@ -53,16 +55,21 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
         const float nrm = sqrtf(gnorm_sq[0]) * gscale;
         clip = fminf(1.0f, max_norm / (nrm + 1e-6f));
     }
+    // A non-finite gradient norm (an fp16 operand overflowed somewhere in the backward) must not reach the weights or the moments:
+    // the step is skipped on the device -- gradients are still cleared, the 16-bit shadow stays current -- and the host lowers its
+    // loss scale when it next reads the norm (optimizer.FusedAdam.step, precision "fp16").
+    const bool skip = gnorm_sq && !(gnorm_sq[0] < 3.0e38f);
     const float gs = gscale * clip;
     const float step = lr / bc1;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        if (skip) { if (zero_grad) g[i] = 0.f; continue; }
         float pi = p[i], gi = g[i] * gs;
         if (decoupled) pi *= (1.0f - lr * wd); else gi += wd * pi;
         const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
         const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
         pi -= step * mi / (sqrtf(vi) / bc2_sqrt + eps);
         p[i] = pi; m[i] = mi; v[i] = vi;
-        if (p16) p16[i] = (bf16_t)pi;
+        if (p16) p16[i] = (T16)pi;
         if (zero_grad) g[i] = 0.f;
     }
 }
@@ -70,13 +77,18 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
 extern "C" int omlm_adamw_clip_step(float* p, float* g, float* m, float* v, void* p16, long long n,
                                     float lr, float beta1, float beta2, float eps, float wd, int step,
                                     float gscale, const float* gnorm_sq, float max_norm, int decoupled, int zero_grad,
-                                    void* stream) {
+                                    int p16_dtype, void* stream) {
     if (n <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(p && g && m && v && step >= 1, "adamw arguments");
+    OMLM_CHECK_ARG(!p16 || p16_dtype == OMLM_DT_BF16 || p16_dtype == OMLM_DT_F16, "p16_dtype: 1 = bf16, 2 = fp16");
     const float bc1 = (float)(1.0 - pow((double)beta1, (double)step)), bc2 = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     long long blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), p, g, m, v, (bf16_t*)p16, n,
-                       lr, beta1, beta2, eps, wd, bc1, bc2, gscale, gnorm_sq, max_norm, decoupled, zero_grad);
+    if (p16 && p16_dtype == OMLM_DT_F16)
+        hipLaunchKernelGGL(adamw_kernel<f16_t>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), p, g, m, v, (f16_t*)p16, n,
+                           lr, beta1, beta2, eps, wd, bc1, bc2, gscale, gnorm_sq, max_norm, decoupled, zero_grad);
+    else
+        hipLaunchKernelGGL(adamw_kernel<h16_t>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), p, g, m, v, (h16_t*)p16, n,
+                           lr, beta1, beta2, eps, wd, bc1, bc2, gscale, gnorm_sq, max_norm, decoupled, zero_grad);
     return omlm_post_launch("omlm_adamw_clip_step");
 }
 
@@ -107,8 +119,10 @@ extern "C" int omlm_transpose_cast(const float* src, void* dst, int R, int C, in
     if (R <= 0 || C <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(src && dst && ld_src >= C && ld_dst >= R, "transpose_cast arguments");
     dim3 grid((C + 63) / 64, (R + 63) / 64), block(256);
+    OMLM_CHECK_ARG(out_dtype >= 0 && out_dtype <= 2, "out_dtype: 0 = fp32, 1 = bf16, 2 = fp16");
     if (out_dtype == 0) hipLaunchKernelGGL(transpose_cast_kernel<float>, grid, block, 0, as_stream(stream), src, (float*)dst, R, C, ld_src, ld_dst);
-    else hipLaunchKernelGGL(transpose_cast_kernel<bf16_t>, grid, block, 0, as_stream(stream), src, (bf16_t*)dst, R, C, ld_src, ld_dst);
+    else if (out_dtype == OMLM_DT_F16) hipLaunchKernelGGL(transpose_cast_kernel<f16_t>, grid, block, 0, as_stream(stream), src, (f16_t*)dst, R, C, ld_src, ld_dst);
+    else hipLaunchKernelGGL(transpose_cast_kernel<h16_t>, grid, block, 0, as_stream(stream), src, (h16_t*)dst, R, C, ld_src, ld_dst);
     return omlm_post_launch("omlm_transpose_cast");
 }
 
@@ -124,8 +138,10 @@ extern "C" int omlm_cast_pad(const float* src, void* dst, long long R, int C, in
     if (R <= 0 || C <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(src && dst && ld_src >= C && ld_dst >= C, "cast_pad arguments");
     dim3 grid((unsigned)(R < 8192 ? R : 8192)), block(256);
+    OMLM_CHECK_ARG(out_dtype >= 0 && out_dtype <= 2, "out_dtype: 0 = fp32, 1 = bf16, 2 = fp16");
     if (out_dtype == 0) hipLaunchKernelGGL(cast_pad_kernel<float>, grid, block, 0, as_stream(stream), src, (float*)dst, R, C, ld_src, ld_dst);
-    else hipLaunchKernelGGL(cast_pad_kernel<bf16_t>, grid, block, 0, as_stream(stream), src, (bf16_t*)dst, R, C, ld_src, ld_dst);
+    else if (out_dtype == OMLM_DT_F16) hipLaunchKernelGGL(cast_pad_kernel<f16_t>, grid, block, 0, as_stream(stream), src, (f16_t*)dst, R, C, ld_src, ld_dst);
+    else hipLaunchKernelGGL(cast_pad_kernel<h16_t>, grid, block, 0, as_stream(stream), src, (h16_t*)dst, R, C, ld_src, ld_dst);
     return omlm_post_launch("omlm_cast_pad");
 }
 

@@ -80,8 +80,8 @@ class CachedDecoder:
         a = DecodeArgs()
         a.B, a.D, a.H, a.L, a.F, a.Fp, a.Nmax, a.nsplit = B, D, H, L, F, Fp, Nmax, self.nsplit
         a.pos_dev = self.pos_dev.data_ptr()
-        a.w_dtype = 0 if self.T == torch.float32 else 1
-        a.round_bf16 = 0 if self.T == torch.float32 else 1
+        a.w_dtype = ops.dcode(self.T)                              # 0 fp32, 1 bf16, 2 fp16 (served by the library's fp16 copy)
+        a.round_bf16 = 0 if self.T == torch.float32 else 1         # round activations to the 16-bit operand type like the batched path
         a.eps, a.scale = 1e-5, float(engine.ATTN_SCALE)
 
         def arr(tensors: Sequence[torch.Tensor]):

@@ -25,7 +25,11 @@ from .hip import require_gpu
 ATTN_SCALE = 8.0
 DIM_HEAD = 64
 
-_PRECISIONS = {"bf16": torch.bfloat16, "bf16x3": torch.float32}
+# precision modes -> GEMM / attention operand type in HBM.  "fp16": IEEE half operands on the same v_mfma_f32_32x32x16 rate as bf16
+# (11 instead of 8 significand bits: meets the 1e-3 logits bar bf16 misses); its 5-bit exponent needs a loss scale in the
+# backward (loss_scale below), divided out by the fused optimizer.
+_PRECISIONS = {"bf16": torch.bfloat16, "bf16x3": torch.float32, "fp16": torch.float16}
+_H16 = (torch.bfloat16, torch.float16)
 _WT = os.environ.get("OMLM_WT", "0") == "1"
 _FF_SAVE_GH = os.environ.get("OMLM_FF_SAVE_GH", "1") == "1"        # forward keeps the normalised GEGLU output for the backward (bf16 mode)
 _WGRAD_GROUP = os.environ.get("OMLM_WGRAD_GROUP", "1") == "1"      # grouped weight-gradient GEMMs (0: one split-K GEMM per weight)
@@ -53,6 +57,33 @@ def default_precision() -> str:
     if p not in _PRECISIONS:
         raise ValueError(f"OMLM_PRECISION must be one of {list(_PRECISIONS)}, got {p}")
     return p
+
+
+def loss_scale(precision: str) -> float:
+    """Factor the backward of `precision` multiplies the loss gradient by.  1 except for "fp16", where gradients would fall below
+    half's range (the non-target logit gradients of a 28 k-token batch are ~3e-8; the smallest normal half is 6e-5): a static power
+    of two ($OMLM_FP16_LOSS_SCALE, default 4096).  Parameter gradients (param.grad, the optimizer's flat buffer) then carry that
+    factor; FusedAdam.step divides it out inside its kernel and skips a step whose gradient norm overflowed; anything else that
+    reads param.grad in this mode divides by engine.loss_scale("fp16") (unscale_grads_)."""
+    if precision != "fp16":
+        return 1.0
+    return float(os.environ.get("OMLM_FP16_LOSS_SCALE", "4096"))
+
+
+def tag_parameters(model, precision: Optional[str]):
+    """Mark the model's parameters with its precision mode: the fused optimizer picks its 16-bit shadow type and loss scale from it."""
+    for p in model.parameters():
+        p._omlm_precision = precision
+
+
+@torch.no_grad()
+def unscale_grads_(model, precision: Optional[str] = None):
+    """Divide the loss scale out of every param.grad (fp16 mode, for consumers other than FusedAdam).  Call once per optimizer step."""
+    s = loss_scale(precision or getattr(model, "precision", None) or default_precision())
+    if s != 1.0:
+        for p in model.parameters():
+            if p.grad is not None:
+                p.grad.mul_(1.0 / s)
 
 
 def ceil_to(x: int, m: int) -> int:
@@ -120,12 +151,12 @@ def build_layout(B: int, lens: Sequence[int], quantizers: Sequence[int], device,
 # ------------------------------------------------------------------------------------------------------
 # operand copies of the weights in the GEMM operand dtype / padded layouts
 # ------------------------------------------------------------------------------------------------------
-def bf16_operand(w: torch.Tensor) -> torch.Tensor:
-    """bf16 copy of a weight as GEMM operand: the optimizer's shadow if it is current, else a fresh cast."""
+def h16_operand(w: torch.Tensor, T: torch.dtype) -> torch.Tensor:
+    """16-bit copy (bf16 / fp16) of a weight as GEMM operand: the optimizer's shadow if it is current and of that type, else a fresh cast."""
     sh = getattr(w, "_omlm_bf16", None)
-    if sh is not None and getattr(w, "_omlm_bf16_version", -1) == w._version and sh.device == w.device:
+    if (sh is not None and sh.dtype == T and getattr(w, "_omlm_bf16_version", -1) == w._version and sh.device == w.device):
         return sh
-    c = torch.empty(w.shape, dtype=torch.bfloat16, device=w.device)
+    c = torch.empty(w.shape, dtype=T, device=w.device)
     ops.cast_pad(w.detach(), c, w.numel() // w.shape[-1], w.shape[-1], w.shape[-1], w.shape[-1])
     return c
 
@@ -149,14 +180,14 @@ class PreparedWeights:
                 ent["Wq"], ent["Wkv"], ent["Wo"] = attn.to_q.weight, attn.to_kv.weight, attn.to_out[0].weight
             else:
                 for name, w in (("Wq", attn.to_q.weight), ("Wkv", attn.to_kv.weight), ("Wo", attn.to_out[0].weight)):
-                    ent[name] = bf16_operand(w)
+                    ent[name] = h16_operand(w, T)
             W1p = torch.zeros(2 * Fp, D, dtype=T, device=dev)
             ops.cast_pad(w1, W1p, F, D, D, D)
             ops.cast_pad(w1[F:], W1p[Fp:], F, D, D, D)
             W2p = torch.empty(D, Fp, dtype=T, device=dev)
             ops.cast_pad(w2, W2p, D, F, F, Fp)
             ent["W1p"], ent["W2p"], ent["F"], ent["Fp"] = W1p, W2p, F, Fp
-            if T == torch.bfloat16 and with_transposes:
+            if T in _H16 and with_transposes:
                 # k-contiguous W^T copies: every input-gradient GEMM (dX = dY W) then runs in the fast NT form
                 def wt(w, R, C, rows_pad=None, cols_pad=None):
                     t = torch.zeros(rows_pad or C, cols_pad or R, dtype=T, device=dev)
@@ -189,7 +220,7 @@ class PreparedWeights:
             if T == torch.float32:
                 self.heads.append(w)
             else:
-                self.heads.append(bf16_operand(w))
+                self.heads.append(h16_operand(w, T))
                 if with_transposes:                                          # [Q, D, ldV], pad columns zero
                     Q, V1 = w.shape[0], w.shape[1]
                     ldV = ceil_to(V1, 8)
@@ -347,7 +378,11 @@ def trunk_forward(tr, pw: PreparedWeights, x: torch.Tensor, keymask: Optional[to
             torch.cuda.current_stream(dev).wait_stream(side)
             side = None
         # the layer's bias table in the kernels' layout, with the fixed softmax reference point its scales allow
-        abias = ops.AttnBias(table, N, H, dev, q_scale=attn.q_scale.detach(), k_scale=attn.k_scale.detach(), scale=ATTN_SCALE)
+        # (fp16: the fixed reference point is an upper bound, so typical probabilities sit around 2^-12 of it -- at the edge of half's
+        # normal range; the online softmax keeps every row's maximum at 1)
+        fixed_ok = T != torch.float16
+        abias = ops.AttnBias(table, N, H, dev, q_scale=attn.q_scale.detach() if fixed_ok else None,
+                             k_scale=attn.k_scale.detach() if fixed_ok else None, scale=ATTN_SCALE)
         ops.attn_fwd(q, k, v, abias, keymask, o, lse, B, N, H, ATTN_SCALE)
         x1 = torch.empty(M, D, device=dev)
         ops.gemm(o, w["Wo"], x1, M=M, N=D, K=H * DIM_HEAD, Cin=x)
@@ -406,7 +441,7 @@ def trunk_backward(tr, pw: PreparedWeights, saved, dy: torch.Tensor, B: int, N: 
     ws = None
     # weight gradients have no consumer before the optimizer: in bf16 mode they are collected and issued as grouped launches of
     # full-K tiles (ops.WgradGroup) instead of 5 split-K GEMMs per layer; their operands stay alive until the flush
-    wg = ops.WgradGroup() if (T == torch.bfloat16 and _WGRAD_GROUP) else None
+    wg = ops.WgradGroup() if (T in _H16 and _WGRAD_GROUP) else None
 
     def wgrad(dY, X, dW, Mo, No, c_map=None):
         if wg is not None:
@@ -661,6 +696,7 @@ class LogitsFunction(torch.autograd.Function):
         ctx.set_materialize_grads(False)          # unused logits -> None grads -> their head GEMMs are skipped
         ctx.st = st
         ctx.nparams = len(params)
+        ctx.gscale = loss_scale(precision)
         views = logits_views(model, lay, bufs)
         ctx.present = [v is not None for v in views]
         return tuple(v for v in views if v is not None)
@@ -679,6 +715,8 @@ class LogitsFunction(torch.autograd.Function):
             V1 = seq.codebook_size + 1
             ldV = ceil_to(V1, 8)
             g2 = g.reshape(-1, V1).to(torch.float32).contiguous()
+            if ctx.gscale != 1.0:
+                g2 = g2 * ctx.gscale
             d = torch.empty(g2.shape[0], ldV, dtype=T, device=g2.device)
             ops.cast_pad(g2, d, g2.shape[0], V1, V1, ldV)
             dl.append(d)
@@ -738,6 +776,7 @@ class LossFunction(torch.autograd.Function):
             ctx.inv_total = inv_total
         ctx.st = st
         ctx.nparams = len(params)
+        ctx.gscale = loss_scale(precision)
         views = logits_views(model, lay, bufs)
         ctx.mark_non_differentiable(*views)
         return (loss, *views)
@@ -749,6 +788,8 @@ class LossFunction(torch.autograd.Function):
         g = gloss.reshape(1).to(torch.float32).contiguous()
         if ctx.inv_total is not None:
             g = (g * ctx.inv_total).reshape(1).contiguous()
+        if ctx.gscale != 1.0:
+            g = g * ctx.gscale                                       # fp16: loss scale (engine.loss_scale), removed by the optimizer
         dl = []
         for s, seq in enumerate(st.model.token_sequences):
             if st.labels[s] is None:

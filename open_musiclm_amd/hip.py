@@ -25,7 +25,7 @@ SIGNATURES = {
     "omlm_last_error": [],
     "omlm_set_error": [C.c_char_p],
     "omlm_gemm": [vp, vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp],
-    "omlm_gemm_wgrad_group": [vp, i32, i32, vp],
+    "omlm_gemm_wgrad_group": [vp, i32, i32, i32, vp],
     "omlm_gemm_planes": [vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp],
     "omlm_split_planes": [vp, vp, i64, i64, vp],
     "omlm_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp],
@@ -47,7 +47,7 @@ SIGNATURES = {
     "omlm_cross_entropy_fwd": [vp, vp, vp, vp, i32, i32, i32, vp, vp],
     "omlm_cross_entropy_bwd": [vp, vp, vp, vp, f32, vp, i32, i32, i32, i32, i32, vp],
     "omlm_sumsq_accumulate": [vp, i64, vp, vp, vp],
-    "omlm_adamw_clip_step": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp, f32, i32, i32, vp],
+    "omlm_adamw_clip_step": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp, f32, i32, i32, i32, vp],
     "omlm_cast_pad": [vp, vp, i64, i32, i32, i32, i32, vp],
     "omlm_transpose_cast": [vp, vp, i32, i32, i32, i32, i32, vp],
     "omlm_sample_topk_gumbel_at": [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],

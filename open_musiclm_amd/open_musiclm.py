@@ -77,6 +77,7 @@ class TokenConditionedTransformer(nn.Module):
                                        cond_as_self_attn_prefix=cond_as_self_attn_prefix,
                                        grad_shrink_alpha=grad_shrink_alpha, **kwargs)
         self.transformer.__dict__["_omlm_owner"] = self
+        engine.tag_parameters(self, precision)      # the fused optimizer reads the precision mode off the parameters (16-bit shadow type, loss scale)
 
     @property
     def device(self):

@@ -1,6 +1,6 @@
 """Tensor-level wrappers over the C ABI (include/omlm.h).  No autograd, no fallbacks.
 
-dtype code convention: 0 = fp32 ("bf16x3" split for GEMM/attention operands), 1 = bf16.
+dtype code convention (include/omlm.h): 0 = fp32 ("bf16x3" split for GEMM/attention operands), 1 = bf16, 2 = fp16.
 """
 from __future__ import annotations
 
@@ -14,19 +14,20 @@ import torch
 from . import hip
 from .hip import call, ptr, stream_ptr
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
+_CODES = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
+H16 = (torch.bfloat16, torch.float16)            # the 16-bit GEMM / attention operand types (precision "bf16" / "fp16")
 
 
 def dcode(dtype: torch.dtype) -> int:
-    if dtype == torch.float32:
-        return F32
-    if dtype == torch.bfloat16:
-        return BF16
-    raise TypeError(f"unsupported operand dtype {dtype}")
+    try:
+        return _CODES[dtype]
+    except KeyError:
+        raise TypeError(f"unsupported operand dtype {dtype}") from None
 
 
 def tdtype(code: int) -> torch.dtype:
-    return torch.float32 if code == F32 else torch.bfloat16
+    return {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}[code]
 
 
 def _chk(t: torch.Tensor, name: str):
@@ -120,15 +121,18 @@ class _WgradDesc(C.Structure):
 
 
 class WgradGroup:
-    """Collects the weight-gradient contractions dW[M,N] += dY[K,M]^T X[K,N] of a backward pass (bf16 operands, rows = tokens)
-    and issues them as ONE grouped launch (omlm_gemm_wgrad_group).  The operands are kept alive until :meth:`flush`."""
+    """Collects the weight-gradient contractions dW[M,N] += dY[K,M]^T X[K,N] of a backward pass (16-bit operands of ONE type, rows =
+    tokens) and issues them as ONE grouped launch (omlm_gemm_wgrad_group).  The operands are kept alive until :meth:`flush`."""
 
     def __init__(self):
         self.items = []
+        self.dtype = None
 
     def add(self, dY: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, *, M: int, N: int, K: int, c_map=None):
         hip.require_gpu(dY, "dY")
-        assert dY.dtype == torch.bfloat16 and X.dtype == torch.bfloat16 and dW.dtype == torch.float32
+        assert dY.dtype in H16 and X.dtype == dY.dtype and dW.dtype == torch.float32
+        assert self.dtype in (None, dY.dtype), "one operand type per group"
+        self.dtype = dY.dtype
         self.items.append((dY, X, dW, c_map, M, N, K, dY.shape[-1], X.shape[-1], dW.shape[-1]))
 
     def flush(self, splits: int = 0):
@@ -139,7 +143,7 @@ class WgradGroup:
         for d, (dY, X, dW, c_map, M, N, K, lda, ldb, ldc) in zip(arr, self.items):
             d.A, d.B, d.C, d.c_map = ptr(dY), ptr(X), ptr(dW), ptr(c_map)
             d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, lda, ldb, ldc
-        call("omlm_gemm_wgrad_group", C.cast(arr, C.c_void_p), n, int(splits), stream_ptr())
+        call("omlm_gemm_wgrad_group", C.cast(arr, C.c_void_p), n, int(splits), dcode(self.dtype), stream_ptr())
         self.items = []
 
 
@@ -331,9 +335,10 @@ def sumsq_accumulate(g, out, partials=None):
 
 def adamw_clip_step(p, g, m, v, p16, *, lr, beta1, beta2, eps, wd, step, gscale, gnorm_sq, max_norm,
                     decoupled, zero_grad):
+    """p16: optional 16-bit shadow of p (bf16 or fp16: the operand type of the model's precision), written by the same kernel."""
     call("omlm_adamw_clip_step", ptr(p), ptr(g), ptr(m), ptr(v), ptr(p16), p.numel(), float(lr), float(beta1),
          float(beta2), float(eps), float(wd), int(step), float(gscale), ptr(gnorm_sq), float(max_norm or 0.0),
-         int(decoupled), int(zero_grad), stream_ptr())
+         int(decoupled), int(zero_grad), dcode(p16.dtype) if p16 is not None else BF16, stream_ptr())
 
 
 def cast_pad(src, dst, R, C_, ld_src, ld_dst):

@@ -35,6 +35,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._grads_clean = False
         self._gnorm_sq = None
         self.last_grad_norm_sq = None
+        self.loss_scale = 1.0           # what the backward multiplied the gradients by (engine.loss_scale: 1 unless precision "fp16")
 
     # ---- flat storage --------------------------------------------------------------------------------
     def _all_params(self) -> List[torch.Tensor]:
@@ -64,9 +65,14 @@ class FusedAdam(torch.optim.Optimizer):
                 V[o:o + n].copy_(old['V'][old['offs'][i]: old['offs'][i] + n])
             p.data = P[o:o + n].view(p.shape)
             p.grad = G[o:o + n].view(p.shape)
-        # bf16 shadow of every parameter, refreshed by the SAME kernel that updates the fp32 master (adamw p16 output):
-        # the engine's bf16 GEMM operands are views of it, so the per-step weight-cast launches disappear.
-        P16 = torch.empty(tot, device=dev, dtype=torch.bfloat16)
+        # 16-bit shadow of every parameter in the operand type of the model's precision (bf16; fp16 for precision "fp16" -- the
+        # model tags its parameters, engine.tag_parameters), refreshed by the SAME kernel that updates the fp32 master (adamw p16
+        # output): the engine's 16-bit GEMM operands are views of it, so the per-step weight-cast launches disappear.
+        from . import engine
+        prec = next((getattr(p, "_omlm_precision", None) for p in params if getattr(p, "_omlm_precision", None)), None)
+        prec = prec or engine.default_precision()
+        self.loss_scale = engine.loss_scale(prec)
+        P16 = torch.empty(tot, device=dev, dtype=torch.float16 if prec == "fp16" else torch.bfloat16)
         P16.copy_(P)                                    # one-off cast (cast_pad walks rows: a single 91M-element row is one workgroup)
         for p, o, n in zip(params, offs, sizes):
             p._omlm_bf16 = P16[o:o + n].view(p.shape)
@@ -116,10 +122,13 @@ class FusedAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None, max_grad_norm: Optional[float] = None, grad_scale: float = 1.0):
         """One optimizer step.  grad_scale multiplies every gradient first (1/world_size after a SUM all-reduce);
-        max_grad_norm clips by the global norm of the scaled gradients (torch clip_grad_norm_ semantics)."""
+        max_grad_norm clips by the global norm of the scaled gradients (torch clip_grad_norm_ semantics).  In precision "fp16" the
+        backward leaves loss_scale x the gradients in the flat buffer (engine.loss_scale); it is divided out here, and a step whose
+        gradient norm is not finite (an fp16 overflow) is skipped on the device (adamw kernel)."""
         self._ensure_flat()
         f = self._flat
         self._t += 1
+        grad_scale = grad_scale / self.loss_scale
         gn = None
         if max_grad_norm is not None and max_grad_norm > 0:
             self._gnorm_sq.zero_()

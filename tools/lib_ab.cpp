@@ -27,7 +27,7 @@ typedef int (*gemm_t)(const void*, const void*, void*, const float*, const int*,
                       int, int, int, int, float, void*);
 typedef const char* (*err_t)(void);
 struct wgrad_desc { const void* A; const void* B; float* C; const int* c_map; int M, N, K, lda, ldb, ldc; };
-typedef int (*wgrad_t)(const wgrad_desc*, int, int, void*);
+typedef int (*wgrad_t)(const wgrad_desc*, int, int, int, void*);
 typedef int (*ffwd_t)(const void*, const void*, const void*, void*, float*, float*, int, int, int, int, float, float, unsigned long long,
                       const unsigned long long*, unsigned char*, void*, int, void*);
 typedef long long (*fws_t)(int, int);
@@ -277,7 +277,7 @@ static void wgrad_case(Lib& A, Lib& Bl) {
                 off += (size_t)Ms[i] * Ns[i];
                 pr.push_back(d);
             }
-        auto run = [&] { libs[li]->ok(libs[li]->wgrad(pr.data(), (int)pr.size(), 0, nullptr), "wgrad_group"); };
+        auto run = [&] { libs[li]->ok(libs[li]->wgrad(pr.data(), (int)pr.size(), 0, 1, nullptr), "wgrad_group"); };
         run(); CK(hipDeviceSynchronize());
         res[li] = host(C, cfl * layers);
         us[li] = time_us(run, 5);
