@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REPORT = os.path.join(ROOT, "gpurun_out", "model_report.json")
 
 TOL = {"bf16x3": dict(logits=1e-3, loss=1e-4, grad=6e-2), "bf16": dict(logits=1.2e-2, loss=5e-3, grad=1.5e-1),
-       "fp16": dict(logits=2e-3, loss=1e-3, grad=6e-2)}
+       "fp16": dict(logits=1e-3, loss=1e-4, grad=1.5e-2)}      # measured at full size: logits 8.9e-4, loss 6e-6, grads <= 7.2e-3
 
 
 def grad_unscale(precision):
