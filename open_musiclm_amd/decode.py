@@ -40,7 +40,7 @@ class DecodeArgs(C.Structure):
 
 def supports(model, batch: int) -> bool:
     tr = model.transformer
-    return batch <= MAX_DECODE_BATCH and not model.use_absolute_position_embeddings and tr.non_causal_prefix_size == 0
+    return batch <= MAX_DECODE_BATCH and tr.non_causal_prefix_size == 0
 
 
 class CachedDecoder:
@@ -73,6 +73,10 @@ class CachedDecoder:
         self.logits = torch.zeros(B, self.ldV, **f32)
         self.codebook = seq.codebook_size
         self.emb = model.embeddings[-1].weight.detach()
+        # learned absolute position embeddings (open_musiclm.py:134-136: row p of the LAST sequence's table is added to the embedding of
+        # its p-th id): the single-row steps add the row of the id they embed
+        self.pos_emb = (model.absolute_position_embeddings[-1].weight.detach()
+                        if getattr(model, "use_absolute_position_embeddings", False) else None)
         # rel-pos table for every distance the cache can hold: [Nmax, ld] fp32 (row = i - j, column = head)
         self.table, _ = engine.relpos_forward(tr, Nmax, False)
         self.rows = 0                       # rows already in the caches == index of the next row
@@ -148,6 +152,11 @@ class CachedDecoder:
         ids = new_ids.contiguous()
         assert ids.dtype == torch.int64 and ids.numel() == self.B
         a.emb_table = self.emb.data_ptr()
+        if self.pos_emb is not None:
+            # the new row = token embedding (with the reference's offset / clamp rule of dec_embed_kernel) + position row k, formed here
+            rows = (ids + a.emb_row_offset).clamp_(0, self.emb.shape[0] - 1)
+            self.x.copy_(self.emb[rows] + self.pos_emb[k])
+            a.emb_table = None
         a.advance_pos, a.advance_step = self.pos_dev.data_ptr(), None        # the head kernel moves the row index on
         call("omlm_decode_step", C.addressof(a), ptr(ids), stream_ptr())
         self.rows += 1
@@ -190,6 +199,9 @@ class SamplingLoop:
         call("omlm_sample_embed_at", ptr(dec.logits), ptr(self.U), ptr(self.step_dev), ptr(self.cur), ptr(self.hist),
              dec.B, dec.V1, dec.ldV, self.topk, self.temperature, int(self.forbid[phase]),
              dec.emb.data_ptr(), dec.codebook * phase if dec.Q > 1 else 0, dec.emb.shape[0], ptr(dec.x), dec.D, stream_ptr())
+        if dec.pos_emb is not None:
+            # + absolute position row of id k = n0 + (device step counter): device-side indexing, so a captured cycle stays valid
+            dec.x.add_(dec.pos_emb.index_select(0, (self.step_dev + self.n0).long()))
         a.emb_table = None
         a.head_W = dec.pw.heads[-1][(k + 1) % dec.Q].data_ptr()
         a.advance_pos, a.advance_step = dec.pos_dev.data_ptr(), self.step_dev.data_ptr()

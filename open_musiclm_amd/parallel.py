@@ -54,9 +54,23 @@ class DataParallel:
         return self.local_rank == 0
 
     def allreduce_sum_(self, flat: torch.Tensor) -> torch.Tensor:
-        """THE gradient exchange: one SUM all-reduce of the flat buffer (mean is applied by the optimizer kernel)."""
-        if self.is_distributed:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        """THE gradient exchange: one SUM all-reduce of the flat buffer (mean is applied by the optimizer kernel).
+
+        $OMLM_DP_GRAD_DTYPE=bf16 sends the gradients as bf16 (half the bytes on the xGMI links: 183 MB instead of 366 MB for
+        coarse-small; one rounding of each rank's gradient to 8 significand bits and a bf16 ring sum -- replicas stay identical
+        because every rank receives the same reduced values, but the step no longer equals the single-process accumulation bit for
+        bit, so it is off by default)."""
+        if not self.is_distributed:
+            return flat
+        if os.environ.get("OMLM_DP_GRAD_DTYPE", "fp32") == "bf16":
+            buf = getattr(self, "_xbuf", None)
+            if buf is None or buf.numel() != flat.numel() or buf.device != flat.device:
+                buf = self._xbuf = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device)
+            buf.copy_(flat)
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            flat.copy_(buf)
+            return flat
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         return flat
 
     def grad_scale(self) -> float:

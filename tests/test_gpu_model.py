@@ -309,6 +309,46 @@ def test_cached_decode_other_stages(golden_dir, dev, name, precision):
     assert err < TOL[precision]["logits"], err
 
 
+def test_cached_decode_with_absolute_position_embeddings(dev):
+    """use_absolute_position_embeddings=True (open_musiclm.py:81-82,134-136): the KV-cached single-row steps add the position row of the
+    id they embed, so cached ids equal the re-forward ids (bf16x3) and the step logits equal last_logits of the growing sequence."""
+    from open_musiclm_amd import decode
+    from open_musiclm_amd import open_musiclm as M
+    from open_musiclm_amd.utils import append_eos_id
+    torch.manual_seed(0)
+    kw = dict(dim=128, depth=2, heads=2, ff_dropout=0.0, num_coarse_quantizers=3, clap_codebook_size=64, semantic_codebook_size=64,
+              acoustic_codebook_size=64, use_absolute_position_embeddings=True, max_absolute_position_embeddings=64)
+    model = M.create_coarse_transformer(precision="bf16x3", **kw).to(dev)
+    assert decode.supports(model, 2)
+    model.eval()
+    wrapper = M.TokenConditionedTransformerWrapper(transformer=model, unique_consecutive=False)
+    g = torch.Generator().manual_seed(3)
+    cond = [torch.randint(0, 64, (2, 12, 1), generator=g).to(dev), torch.randint(0, 64, (2, 9), generator=g).to(dev)]
+    Q, V1, steps = 3, 65, 4
+    U = torch.rand(steps * Q, 2, V1, generator=g)
+    kwg = dict(conditioning_token_ids=cond, max_time_steps=steps, uniforms=U)
+    a = wrapper.generate(use_cache=True, **kwg)
+    b = wrapper.generate(use_cache=False, **kwg)
+    assert torch.equal(a, b), (a.tolist(), b.tolist())
+    with torch.no_grad():
+        condx = [append_eos_id(t.reshape(t.shape[0], -1).long(), e) for t, e in zip(cond, wrapper.eos_ids)]
+        flat = a.reshape(2, -1)
+        n = flat.shape[1]
+        dec = decode.CachedDecoder(model, 2, sum(t.shape[-1] + 1 for t in condx) + 1 + n, "bf16x3")
+        got = [dec.prefill(condx + [flat[:, :0]]).clone()]
+        for k in range(n - 1):
+            got.append(dec.step(flat[:, k].contiguous(), k).clone())
+        want = [model.last_logits(condx + [flat[:, :k]]).clone() for k in range(n)]
+    err = max(relerr(x[:, :V1], y[:, :V1]) for x, y in zip(got, want))
+    report("cached_decode_abs_pos", max_rel_err=err, steps=n)
+    assert err < TOL["bf16x3"]["logits"], err
+    # and the position rows matter: zeroing them changes the logits
+    with torch.no_grad():
+        model.absolute_position_embeddings[-1].weight.zero_()
+        other = model.last_logits(condx + [flat[:, :3]])
+    assert relerr(other[:, :V1], want[3][:, :V1]) > 1e-3
+
+
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
 def test_full_size_coarse_small_vs_oracle(dev, precision):
     """BASELINE config 2 shapes: musiclm_small coarse stage, N = 1116, B = 2; logits, loss and grads vs the CPU oracle."""
@@ -550,6 +590,76 @@ def test_graphed_bf16x3_training_tracks_eager_over_optimizer_steps(dev):
     assert relerr(wq_g, wq_e) < 3e-2 and relerr(wo_g, wo_e) < 3e-2
 
 
+def test_train_coarse_stage_script_flow_on_a_preprocessed_store(dev, golden_dir, tmp_path):
+    """The call sequence of the reference's scripts/train_coarse_stage.py (:33-75) -- JSON configs -> load_model_config /
+    load_training_config -> create_coarse_transformer_from_config -> create_single_stage_trainer_from_config(..., accelerate_kwargs with
+    log_with / logging_dir, config_paths) -> trainer.train() -- on a sqlite token store written with the reference's own adapters
+    (tests/golden/preprocessed, oracle/make_golden_r2.py), `use_preprocessed_data` as in configs/training/train_fma_preprocess.json.
+    The script file itself cannot run here: it lives in /root/reference (absent on the GPU box) and constructs the `encodec`
+    package's model unconditionally (:51-52; not installed) -- a stand-in codec object takes that one slot; everything else is the
+    script's own sequence, through checkpoint files and a resume."""
+    import json
+    from open_musiclm_amd.config import (create_coarse_transformer_from_config, create_single_stage_trainer_from_config,
+                                         load_model_config, load_training_config)
+    stage_cfg = dict(dim=128, depth=2, heads=2, attn_dropout=0.0, ff_dropout=0.1, grad_shrink_alpha=0.1, non_causal_prefix_size=0,
+                     relative_position_bias_type="continuous", use_memory_efficient_attention=False)
+    model_cfg = {
+        "global_cfg": dict(semantic_audio_length_seconds=4.0, coarse_audio_length_seconds=2.0, fine_audio_length_seconds=1.0,
+                           clap_audio_length_seconds=4.0, num_coarse_quantizers=3, num_fine_quantizers=5),
+        "clap_rvq_cfg": dict(enable_fusion=False, rq_num_quantizers=12, codebook_size=1024, rq_ema_decay=0.95, threshold_ema_dead_code=0.5),
+        "hubert_kmeans_cfg": dict(model_name="m-a-p/MERT-v0", normalize_embeds=True, embed_layer=7, target_sample_hz=16000,
+                                  seq_len_multiple_of=320, codebook_size=1024, output_hz=5),
+        "encodec_cfg": dict(bandwidth=6.0, codebook_size=1024, output_hz=3),
+        "semantic_cfg": stage_cfg, "coarse_cfg": stage_cfg, "fine_cfg": stage_cfg}
+    stage_train = dict(folder=os.path.join(golden_dir, "preprocessed"), valid_frac=0.0, lr=3e-3, lr_warmup=2, batch_size=2,
+                       grad_accum_every=2, wd=0.01, max_grad_norm=0.5, num_train_steps=4, save_results_every=2, save_model_every=2,
+                       save_predicted_tokens=True, save_reconstructed_wave=False, use_preprocessed_data=True)
+    train_cfg = {
+        "clap_rvq_trainer_cfg": dict(folder="./data", num_train_steps=1, batch_size=2, accumulate_batches=1, save_model_every=10, save_results_every=5),
+        "hubert_kmeans_trainer_cfg": dict(folder="./data", feature_extraction_num_steps=1, feature_extraction_batch_size=2),
+        "semantic_trainer_cfg": dict(stage="semantic", cross_entropy_loss_weights=[0.0, 1.0], **stage_train),
+        "coarse_trainer_cfg": dict(stage="coarse", cross_entropy_loss_weights=[0.0, 0.0, 1.0], **stage_train),
+        "fine_trainer_cfg": dict(stage="fine", cross_entropy_loss_weights=[0.0, 0.0, 1.0], **stage_train),
+        "data_preprocessor_cfg": dict(folder="./data", metadata_folder="./meta", results_folder="./pre", max_audio_length_seconds=30,
+                                      random_crop=True, num_crops=1, clap_batch_size=32)}
+    mp, tp = tmp_path / "model.json", tmp_path / "train.json"
+    mp.write_text(json.dumps(model_cfg)); tp.write_text(json.dumps(train_cfg))
+    model_config, training_config = load_model_config(str(mp)), load_training_config(str(tp))
+    assert training_config.coarse_trainer_cfg.use_preprocessed_data
+
+    class Codec:                                  # the one slot the script fills from the `encodec` package
+        codebook_size, sample_rate, output_hz = 1024, 24000, 3
+
+        def to(self, device):
+            return self
+    torch.manual_seed(0)
+    results = tmp_path / "results" / "coarse"
+    coarse = create_coarse_transformer_from_config(model_config, None, dev)
+    trainer = create_single_stage_trainer_from_config(
+        model_config=model_config, training_config=training_config, stage="coarse", results_folder=str(results), transformer=coarse,
+        clap=None, wav2vec=None, encodec_wrapper=Codec(), device=dev,
+        accelerate_kwargs={"log_with": "tensorboard", "logging_dir": str(tmp_path / "logs")}, config_paths=[str(mp), str(tp)])
+    seen = []
+    trainer.train(log_fn=lambda logs: seen.append(dict(logs)))
+    assert int(trainer.steps.item()) == 4 and len(seen) == 4 and all(np.isfinite(l["loss"]) for l in seen)
+    assert seen[-1]["loss"] < seen[0]["loss"]
+    files = sorted(os.path.basename(str(f)) for f in results.glob("coarse.*.pt"))
+    assert "coarse.transformer.2.pt" in files and "coarse.optimizer.2.pt" in files, files
+    assert (results / "configs" / "model.json").exists()
+    # resume the way scripts/train_utils.load_checkpoint_from_args does: trainer.load(model, optim, scheduler, steps = step + 1)
+    sd_path = {n: str(results / f"coarse.{n}.2.pt") for n in ("transformer", "optimizer", "scheduler")}
+    coarse2 = create_coarse_transformer_from_config(model_config, None, dev)
+    trainer2 = create_single_stage_trainer_from_config(
+        model_config=model_config, training_config=training_config, stage="coarse", results_folder=str(tmp_path / "results2"),
+        transformer=coarse2, clap=None, wav2vec=None, encodec_wrapper=Codec(), device=dev, accelerate_kwargs={}, config_paths=None)
+    trainer2.load(sd_path["transformer"], sd_path["optimizer"], sd_path["scheduler"], steps=3)
+    assert int(trainer2.steps.item()) == 3
+    saved = torch.load(sd_path["transformer"], map_location="cpu")
+    for k, v in coarse2.state_dict().items():
+        assert torch.equal(v.cpu(), saved[k]), k
+    assert np.isfinite(trainer2.train_step()["loss"]) and int(trainer2.steps.item()) == 4
+
+
 def test_musiclm_hierarchical_decode_tokens(dev):
     """MusicLM.forward window stitching on tiny stages: shapes of the 3-level token hierarchy."""
     from open_musiclm_amd import open_musiclm as M
@@ -599,6 +709,27 @@ def test_data_parallel_step_equals_single_process_accumulation(dev, tmp_path):
     # the two summation orders may take opposite signs (up to 2 * lr apart per step), so the maximum is bounded by 4 * lr and the
     # comparison that carries information is how RARE such elements are and how small the mean difference is.
     assert e_p <= 4.1e-3 and frac < 1e-3 and e_mean < 2e-5, (e_p, frac, e_mean)
+
+
+def test_bench_two_rank_dry_run_on_one_gpu(dev):
+    """`bench.py --gpus 2` the way the driver launches it (torch.distributed.run, one rank per GPU) -- here both ranks share cuda:0 and
+    exchange through gloo (RCCL refuses two ranks on one device): rendezvous, per-rank data, the flat gradient all-reduce, the barrier /
+    max-over-ranks timing and ONE JSON line from rank 0 with n_gpus = 2 and the whole-job rate.  Says nothing about RCCL speed."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, OMLM_DP_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29677", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "2"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
+    assert abs(out["value"] - 4 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-2 * out["value"] and np.isfinite(out["final_loss"])
+    assert "legs" not in out and "cpu_baseline" not in out
 
 
 @pytest.mark.parametrize("use_cache", [True, False])

@@ -257,6 +257,17 @@ assert abs(float(m) - 0.5) < 1e-6
 cat = dp.all_gather_cat(torch.full((2, 3), dp.rank))
 assert cat.shape == (4, 3) and int(cat[0, 0]) == 0 and int(cat[3, 0]) == 1
 p = torch.full((5,), float(dp.rank)); dp.broadcast_(p, 0); assert float(p.sum()) == 0.0
+# optional bf16 exchange: the same sum to bf16 precision, identical on both ranks
+os.environ["OMLM_DP_GRAD_DTYPE"] = "bf16"
+torch.manual_seed(dp.rank)
+h = torch.randn(4096)
+want = torch.zeros(4096)
+for r in range(2):
+    torch.manual_seed(r); want += torch.randn(4096).bfloat16().float()
+dp.allreduce_sum_(h)
+assert float((h - want).abs().max()) <= 2.0 ** -7 * float(want.abs().max()), float((h - want).abs().max())
+both = dp.all_gather_cat(h[None]); assert torch.equal(both[0], both[1])
+os.environ["OMLM_DP_GRAD_DTYPE"] = "fp32"
 dp.barrier(); dp.shutdown()
 print('rank', dp.rank, 'ok')
 """
