@@ -53,6 +53,7 @@ typedef __attribute__((ext_vector_type(2))) _Float16 h16x2;
 #define OMLM_NS omlm_f16
 #define OMLM_API(name) __attribute__((visibility("hidden"))) name##_h
 #define OMLM_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+#define OMLM_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 #else
 typedef __bf16 h16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 h16x8;
@@ -61,6 +62,7 @@ typedef __attribute__((ext_vector_type(2))) __bf16 h16x2;
 #define OMLM_NS omlm_bf16
 #define OMLM_API(name) name
 #define OMLM_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#define OMLM_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 #endif
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;

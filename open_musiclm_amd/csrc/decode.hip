@@ -802,6 +802,235 @@ __global__ __launch_bounds__(DEC_T) void dec3_ffin_kernel(dec2_args a) {
     a.hist[ld + myc] = hv;        a.hist[ld + a.Fp + myc] = hg;
 }
 
+// =========================================================================================================================
+// Batched steps (2 <= B <= 16) on the matrix cores.  With B samples the VALU kernels above repeat every dot product, every
+// LayerNorm normalisation and every cross-lane reduction B times per weight row (measured: 506 us per step at B = 8 against 142 us
+// at B = 1 for the same weight bytes).  Here a workgroup owns 16 weight rows; the activations of all samples are normalised and
+// rounded ONCE into an LDS image [16][K + 8] of the operand type, and out[row, sample] = sum_k W[row, k] x[sample, k] is a chain of
+// v_mfma_f32_16x16x32 per wave: A = 16 rows x 32 k straight from the weight rows (one 16-byte load per lane: the MFMA operand layout
+// IS 8 consecutive k of one row), B = the samples (padded to 16 columns with zero operands).  The four waves take interleaved
+// 32-wide k-steps of the same rows (all of a wave's loads requested before anything else, as above) and their partial tiles meet in
+// LDS -- no cross-lane reductions at all.  Same products (16-bit x 16-bit, exact in fp32), fp32 accumulation in a different order.
+#define DEC4_T 256
+#define DEC4_ROWS 16
+#define DEC4_NB 16
+typedef __attribute__((ext_vector_type(4))) float dec4_acc;
+
+// Attention output of the new row from the per-split partials, ONCE per step: [B][H * 64] fp32 (rounded to the operand type).  The
+// VALU kernels combine inside the to_out launch, every workgroup for itself -- 64 workgroups x B x H x 64 elements x splits x 3
+// loads was 33 us of the B = 8 step; this is one launch of B x H wave-sized workgroups.
+__global__ __launch_bounds__(64) void dec_attn_combine_kernel(const float* __restrict__ parts, float* __restrict__ out, int nsplit, int H,
+                                                              const int* __restrict__ pos_dev, int round_bf16) {
+    const int b = blockIdx.y, h = blockIdx.x, d = threadIdx.x;
+    const int ns = *pos_dev / DEC_KS + 1;
+    const float* pb = parts + ((size_t)b * nsplit * H + h) * DEC_PART;
+    float m = -3.0e38f, l = 0.f, o = 0.f;
+    for (int s0 = 0; s0 < ns; s0 += 8) {
+        float pm[8], pl[8], po[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float* p = pb + (size_t)min(s0 + j, ns - 1) * H * DEC_PART;
+            pm[j] = p[0]; pl[j] = p[1]; po[j] = p[2 + d];
+        }
+        float mb = m;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (s0 + j < ns) mb = fmaxf(mb, pm[j]);
+        const float resc = __expf(m - mb);
+        l *= resc; o *= resc; m = mb;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (s0 + j < ns) { const float w = __expf(pm[j] - m); l += w * pl[j]; o += w * po[j]; }
+    }
+    out[((size_t)b * H + h) * 64 + d] = round_if(o / l, round_bf16);
+}
+
+template <int NS, int MODE>
+__global__ __launch_bounds__(DEC4_T) void dec4_kernel(dec2_args a) {
+    extern __shared__ __attribute__((aligned(16))) char dsm4[];
+    const int B = a.B, K = a.K, KP = K + 8;
+    h16_t* xs = (h16_t*)dsm4;                                   // [B][KP] operand image
+    float* red = (float*)(dsm4 + (((size_t)B * KP * 2 + 15) & ~(size_t)15));   // [DEC4_NB][4][2]
+    float* stat = red + DEC4_NB * 8;                            // [DEC4_NB][2]
+    float* part = stat + DEC4_NB * 2;                           // [4][16][16]
+    float* vals = part + 4 * 256;                               // [16 rows][16 samples]
+    float* xraw = vals + 256;                                   // [B][K] fp32 (LayerNorm inputs between the statistics and the rounding)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kq = lane >> 4;
+    const int HD = a.H * 64;
+    static_assert(MODE != DEC2_OUT, "the matrix-core path takes the combined attention output as a plain input (dec_attn_combine_kernel)");
+    // ---- this lane's weight row and its pieces, requested before anything else ----
+    int grow;                                                   // global output row of MFMA row r
+    const h16_t* wrow;
+    bool ln_rows = a.gamma != nullptr;                          // uniform per workgroup
+    if (MODE == DEC2_FFIN) {                                    // rows 0..7: value rows of channels c0..c0+7, rows 8..15: their gate rows
+        const int c = min(blockIdx.x * 8 + (r & 7), a.Fp - 1);
+        grow = c;
+        wrow = (const h16_t*)a.W + (size_t)((r < 8 ? 0 : a.Fp) + c) * a.ldw;
+    } else if (MODE == DEC2_QKV) {
+        grow = blockIdx.x * DEC4_ROWS + r;
+        ln_rows = blockIdx.x * DEC4_ROWS < HD;                  // HD is a multiple of 16: a workgroup holds q rows or k/v rows, never both
+        wrow = grow < HD ? (const h16_t*)a.W + (size_t)grow * a.ldw : (const h16_t*)a.W2 + (size_t)(grow - HD) * a.ldw;
+    } else {
+        grow = blockIdx.x * DEC4_ROWS + r;
+        wrow = (const h16_t*)a.W + (size_t)min(grow, a.Nout - 1) * a.ldw;
+    }
+    const int S = K >> 5;                                       // 32-wide k-steps (K is a multiple of 32)
+    u32x4 wr[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const int s = wave + 4 * j;
+        if (s < S) wr[j] = *(const u32x4*)(wrow + 32 * s + 8 * kq);
+        else { wr[j][0] = 0u; wr[j][1] = 0u; wr[j][2] = 0u; wr[j][3] = 0u; }
+    }
+    // ---- activations: normalised / rounded once per workgroup into the operand image.  All samples' loads of a chunk are in flight
+    // together (a per-sample loop of load -> reduce was 2 B dependent L2 round trips per launch: 12-20 us at B = 8) ----
+    {
+        constexpr int NBR = 8;                                  // samples per register batch
+        if (ln_rows) {
+            float s8[NBR], q8[NBR];
+#pragma unroll
+            for (int b = 0; b < NBR; ++b) { s8[b] = 0.f; q8[b] = 0.f; }
+            constexpr int NCH = (NS + 7) / 8;                       // 1024-element chunks of a row: K <= 128 NS
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int i = threadIdx.x * 4 + ch * DEC4_T * 4;
+                if (i >= K) break;
+                float4 v[NBR];
+#pragma unroll
+                for (int b = 0; b < NBR; ++b) v[b] = b < B ? *(const float4*)(a.in + (size_t)b * a.ldin + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int b = 0; b < NBR; ++b) {
+                    if (b < B) *(float4*)(xraw + (size_t)b * K + i) = v[b];
+                    if (i + 0 < a.Kstat) { s8[b] += v[b].x; q8[b] += v[b].x * v[b].x; }
+                    if (i + 1 < a.Kstat) { s8[b] += v[b].y; q8[b] += v[b].y * v[b].y; }
+                    if (i + 2 < a.Kstat) { s8[b] += v[b].z; q8[b] += v[b].z * v[b].z; }
+                    if (i + 3 < a.Kstat) { s8[b] += v[b].w; q8[b] += v[b].w * v[b].w; }
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < NBR; ++b) {
+                const float s = wave_sum(s8[b]), q = wave_sum(q8[b]);
+                if (lane == 0 && b < B) { red[(b * 4 + wave) * 2] = s; red[(b * 4 + wave) * 2 + 1] = q; }
+            }
+            __syncthreads();
+            if (threadIdx.x < B) {
+                const int b = threadIdx.x;
+                float s = 0.f, q = 0.f;
+                for (int w = 0; w < 4; ++w) { s += red[(b * 4 + w) * 2]; q += red[(b * 4 + w) * 2 + 1]; }
+                const float mean = s / (float)a.Kstat;
+                stat[2 * b] = mean; stat[2 * b + 1] = rsqrtf(fmaxf(q / (float)a.Kstat - mean * mean, 0.f) + a.eps);
+            }
+            __syncthreads();
+            for (int i = threadIdx.x * 4; i < K; i += DEC4_T * 4) {
+                const float4 g = *(const float4*)(a.gamma + i);
+#pragma unroll
+                for (int b = 0; b < NBR; ++b) {
+                    if (b < B) {
+                        const float mean = stat[2 * b], rstd = stat[2 * b + 1];
+                        const float4 v = *(const float4*)(xraw + (size_t)b * K + i);
+                        u32x2 o;
+                        o[0] = pack_h16_rne((v.x - mean) * rstd * g.x, (v.y - mean) * rstd * g.y);
+                        o[1] = pack_h16_rne((v.z - mean) * rstd * g.z, (v.w - mean) * rstd * g.w);
+                        *(u32x2*)(xs + (size_t)b * KP + i) = o;
+                    }
+                }
+            }
+        } else {
+            for (int i = threadIdx.x * 4; i < K; i += DEC4_T * 4) {
+                float4 v[NBR];
+#pragma unroll
+                for (int b = 0; b < NBR; ++b) v[b] = b < B ? *(const float4*)(a.in + (size_t)b * a.ldin + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int b = 0; b < NBR; ++b) {
+                    if (b < B) {
+                        u32x2 o;
+                        o[0] = pack_h16_rne(v[b].x, v[b].y);
+                        o[1] = pack_h16_rne(v[b].z, v[b].w);
+                        *(u32x2*)(xs + (size_t)b * KP + i) = o;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- the k-loop: one MFMA per 32-wide step; samples >= B are zero operands ----
+    dec4_acc acc = {0.f, 0.f, 0.f, 0.f};
+    const bool have = r < B;                                    // this lane's B-operand column is a real sample
+    const h16_t* xrow = xs + (size_t)(have ? r : 0) * KP + 8 * kq;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const int s = wave + 4 * j;
+        if (s < S) {
+            u32x4 xb = {0u, 0u, 0u, 0u};
+            if (have) xb = *(const u32x4*)(xrow + 32 * s);
+            acc = OMLM_MFMA_16x16x32(__builtin_bit_cast(h16x8, wr[j]), __builtin_bit_cast(h16x8, xb), acc);
+        }
+    }
+    // C layout: acc[e] = out[row 4 kq + e][sample r]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) part[(wave * 16 + 4 * kq + e) * 16 + r] = acc[e];
+    __syncthreads();
+    {
+        const int t = threadIdx.x;                              // (row, sample) = (t >> 4, t & 15)
+        vals[t] = part[t] + part[256 + t] + part[512 + t] + part[768 + t];
+    }
+    __syncthreads();
+    // ---- epilogue ----
+    if (MODE == DEC2_FFIN) {
+        const int ld = 2 * a.Fp;
+        for (int idx = threadIdx.x; idx < B * 8; idx += DEC4_T) {
+            const int b = idx >> 3, cc = idx & 7, col = blockIdx.x * 8 + cc;
+            if (col >= a.Fp) continue;
+            const float hv = round_if(vals[cc * 16 + b], a.round_bf16);
+            const float hg = round_if(vals[(8 + cc) * 16 + b], a.round_bf16);
+            float* h0 = a.hist + (size_t)(b * 2) * ld;          // row p-2
+            float* h1 = h0 + ld;                                 // row p-1
+            const float uv = a.convw[col] * h0[col] + a.convw[ld + col] * h1[col] + a.convw[2 * (size_t)ld + col] * hv;
+            const float ug = a.convw[a.Fp + col] * h0[a.Fp + col] + a.convw[ld + a.Fp + col] * h1[a.Fp + col] + a.convw[2 * (size_t)ld + a.Fp + col] * hg;
+            a.u[(size_t)b * a.Fp + col] = dec_gelu(ug) * uv;
+            h0[col] = h1[col];       h0[a.Fp + col] = h1[a.Fp + col];
+            h1[col] = hv;            h1[a.Fp + col] = hg;
+        }
+    } else if (MODE == DEC2_QKV) {
+        const int pos = *a.pos_dev;
+        for (int idx = threadIdx.x; idx < B * DEC4_ROWS; idx += DEC4_T) {
+            const int b = idx / DEC4_ROWS, rr = idx - b * DEC4_ROWS, n = blockIdx.x * DEC4_ROWS + rr;
+            const float v = vals[rr * 16 + b];
+            if (n < HD) a.q[(size_t)b * HD + n] = v;
+            else if (n < HD + 64) a.Kc[((size_t)b * a.Nmax + pos) * 64 + (n - HD)] = v;                  // raw: normalised by dec_attn
+            else if (n < HD + 128) a.Vc[((size_t)b * a.Nmax + pos) * 64 + (n - HD - 64)] = round_if(v, a.round_bf16);
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < B * DEC4_ROWS; idx += DEC4_T) {
+            const int b = idx / DEC4_ROWS, rr = idx - b * DEC4_ROWS, n = blockIdx.x * DEC4_ROWS + rr;
+            if (n < a.Nout) {
+                float v = vals[rr * 16 + b];
+                if (a.res) v += a.res[(size_t)b * a.ldres + n];
+                a.out[(size_t)b * a.ldout + n] = v;
+            }
+        }
+        if (MODE == DEC2_LNGEMV && blockIdx.x == 0 && threadIdx.x == 0 && a.adv_pos) {      // see dec3_kernel
+            a.adv_pos[0] += 1;
+            if (a.adv_step) a.adv_step[0] += 1;
+        }
+    }
+}
+
+template <int NS, int MODE>
+static void dec4_launch(const dec2_args& a, int grid, hipStream_t st) {
+    const size_t lds = (((size_t)a.B * (a.K + 8) * 2 + 15) & ~(size_t)15) + (size_t)(DEC4_NB * 8 + DEC4_NB * 2 + 4 * 256 + 256) * sizeof(float) +
+                       (a.gamma ? (size_t)a.B * a.K * sizeof(float) : 0);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)dec4_kernel<NS, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL((dec4_kernel<NS, MODE>), dim3(grid), dim3(DEC4_T), lds, st, a);
+}
+// the matrix-core step kernels serve 16-bit weights with D, H * 64, Fp multiples of 32 and k-loops of at most 4 x 24 steps
+static bool dec4_ok(const omlm_decode_args& a) {
+    static int off = -1;
+    if (off < 0) { const char* e = getenv("OMLM_DECODE_MFMA"); off = (e && e[0] == '0') ? 1 : 0; }
+    return !off && a.B >= 2 && a.B <= 8 && a.D % 32 == 0 && a.D <= 1024 && (a.H * 64) % 32 == 0 && a.H * 64 <= 1024 &&
+           a.Fp % 32 == 0 && a.Fp <= 3072 && a.Fp % 8 == 0;
+}
+
 template <typename TW, int NI, int MODE>
 static void dec3_launch(const dec2_args& a, int units, hipStream_t st) {
     hipLaunchKernelGGL((dec3_kernel<TW, NI, MODE>), dim3((units + 3) / 4), dim3(DEC_T), 0, st, a);
@@ -811,6 +1040,7 @@ template <typename TW>
 static int decode_step2_t(const omlm_decode_args& a, const long long* ids, hipStream_t st) {
     const int B = a.B, D = a.D, H = a.H, Fp = a.Fp, HD = H * 64;
     const size_t lds_at2 = (size_t)(64 * 65 + 64 * 64 + H * 64 + 8 * 64) * sizeof(float);
+    const bool mfma = sizeof(TW) == 2 && dec4_ok(a);              // 16-bit weights, B >= 2: the matrix-core step kernels
     if (a.emb_table)
         hipLaunchKernelGGL(dec_embed_kernel, dim3(B), dim3(DEC_T), 0, st, ids, a.emb_table, a.emb_row_offset, a.emb_rows, a.x, D);
     dec2_args g;
@@ -821,13 +1051,18 @@ static int decode_step2_t(const omlm_decode_args& a, const long long* ids, hipSt
         q.in = a.x; q.ldin = D; q.K = D; q.Kstat = D; q.gamma = a.attn_gamma[l]; q.W = a.Wq[l]; q.W2 = a.Wkv[l]; q.ldw = D;
         q.Nout = HD + 128; q.q = a.q; q.Kc = a.Kc[l]; q.Vc = a.Vc[l];
         if (B == 1) dec3_launch<TW, 2, DEC2_QKV>(q, HD + 128, st);
+        else if (mfma) dec4_launch<8, DEC2_QKV>(q, (HD + 128) / DEC4_ROWS, st);
         else        dec2_launch<TW, 2, DEC2_QKV>(q, (HD + 128) / DEC2_ROWS, st);
         hipLaunchKernelGGL(dec_attn2_kernel, dim3(a.nsplit, B), dim3(DEC_AT2), lds_at2, st, a.q, a.Kc[l], a.Vc[l], a.q_scale[l], a.k_scale[l],
                            a.bias_table, a.bias_ld, a.parts, H, a.Nmax, a.nsplit, a.pos_dev, a.scale, a.round_bf16);
         dec2_args o = g;                                                               // x1 = x + attn Wo^T
         o.K = HD; o.parts = a.parts; o.W = a.Wo[l]; o.ldw = HD; o.Nout = D; o.res = a.x; o.ldres = D; o.out = a.x1; o.ldout = D;
-        if (HD <= 512) dec2_launch<TW, 1, DEC2_OUT>(o, (D + DEC2_ROWS - 1) / DEC2_ROWS, st);
-        else           dec2_launch<TW, 2, DEC2_OUT>(o, (D + DEC2_ROWS - 1) / DEC2_ROWS, st);
+        if (mfma) {                                                                    // combine once, then a plain (no LayerNorm) row product
+            hipLaunchKernelGGL(dec_attn_combine_kernel, dim3(H, B), dim3(64), 0, st, a.parts, a.q, a.nsplit, H, a.pos_dev, a.round_bf16);
+            o.in = a.q; o.ldin = HD; o.Kstat = HD; o.gamma = nullptr; o.parts = nullptr;     // a.q is free again: the attention kernel consumed it
+            dec4_launch<8, DEC2_LNGEMV>(o, (D + DEC4_ROWS - 1) / DEC4_ROWS, st);
+        } else if (HD <= 512) dec2_launch<TW, 1, DEC2_OUT>(o, (D + DEC2_ROWS - 1) / DEC2_ROWS, st);
+        else                dec2_launch<TW, 2, DEC2_OUT>(o, (D + DEC2_ROWS - 1) / DEC2_ROWS, st);
         dec2_args f = g;                                                               // FF-in rows + conv + GEGLU
         f.in = a.x1; f.ldin = D; f.K = D; f.Kstat = D; f.gamma = a.ffin_gamma[l]; f.W = a.W1p[l]; f.ldw = D; f.convw = a.convw[l];
         f.hist = a.hist[l]; f.u = a.u;
@@ -837,11 +1072,13 @@ static int decode_step2_t(const omlm_decode_args& a, const long long* ids, hipSt
             if (cpw == 4)      hipLaunchKernelGGL((dec3_ffin_kernel<TW, 4>), dim3((Fp + 15) / 16), dim3(DEC_T), 0, st, f);
             else if (cpw == 2) hipLaunchKernelGGL((dec3_ffin_kernel<TW, 2>), dim3((Fp + 7) / 8), dim3(DEC_T), 0, st, f);
             else               dec3_launch<TW, 2, DEC2_FFIN>(f, Fp, st);
-        } else dec2_launch<TW, 2, DEC2_FFIN>(f, Fp / 2, st);
+        } else if (mfma) dec4_launch<8, DEC2_FFIN>(f, (Fp + 7) / 8, st);
+        else dec2_launch<TW, 2, DEC2_FFIN>(f, Fp / 2, st);
         dec2_args w = g;                                                               // x = x1 + LN(u) W2^T
         w.in = a.u; w.ldin = Fp; w.K = Fp; w.Kstat = a.F; w.gamma = a.mid_gamma[l]; w.W = a.W2p[l]; w.ldw = Fp; w.Nout = D;
         w.res = a.x1; w.ldres = D; w.out = a.x; w.ldout = D;
         if (B == 1 && Fp <= 3072) dec3_launch<TW, 6, DEC2_LNGEMV>(w, D, st);
+        else if (mfma) dec4_launch<24, DEC2_LNGEMV>(w, (D + DEC4_ROWS - 1) / DEC4_ROWS, st);
         else if (Fp <= 3072) dec2_launch<TW, 6, DEC2_LNGEMV>(w, (D + DEC2_ROWS - 1) / DEC2_ROWS, st);
         else                 dec2_launch<TW, 8, DEC2_LNGEMV>(w, (D + DEC2_ROWS - 1) / DEC2_ROWS, st);
     }
@@ -851,6 +1088,7 @@ static int decode_step2_t(const omlm_decode_args& a, const long long* ids, hipSt
         h.out = a.logits; h.ldout = a.ldV;
         h.adv_pos = a.advance_pos; h.adv_step = a.advance_step;
         if (B == 1) dec3_launch<TW, 2, DEC2_LNGEMV>(h, a.V1, st);
+        else if (mfma) dec4_launch<8, DEC2_LNGEMV>(h, (a.V1 + DEC4_ROWS - 1) / DEC4_ROWS, st);
         else        dec2_launch<TW, 2, DEC2_LNGEMV>(h, (a.V1 + DEC2_ROWS - 1) / DEC2_ROWS, st);
     }
     return omlm_post_launch("omlm_decode_step");

@@ -362,7 +362,7 @@ static void ln_case(Lib& A, Lib& Bl) {
 // One KV-cached decode step (coarse-small trunk: 6 layers, D = 1024, H = 8, F = 2730; bf16 weights) at row `pos` of an Nmax-row
 // cache, repeated without advancing the row: us per id as the sampling loop sees it (32 launches), logits compared bit for bit.
 static void decode_case(Lib& A, Lib& Bl, int B) {
-    const int L = 6, D = 1024, H = 8, F = 2730, Fp = 2736, Nmax = 1116, pos = 600, V1 = 1025, ldV = 1032, HD = H * 64;
+    const int L = 6, D = 1024, H = 8, F = 2730, Fp = 2752 /* engine: F rounded up to 64 */, Nmax = 1116, pos = 600, V1 = 1025, ldV = 1032, HD = H * 64;
     printf("== decode step  B=%d  (row %d of %d, bf16 weights)\n", B, pos, Nmax);
     std::vector<const void*> Wq(L), Wkv(L), Wo(L), W1(L), W2(L);
     std::vector<const float*> ag(L), qs(L), ks(L), fg(L), cw(L), mg(L);
@@ -375,8 +375,13 @@ static void decode_case(Lib& A, Lib& Bl, int B) {
         ag[l] = fdev(D, 0.05f, 150 + l, 1.f); qs[l] = fdev(64, 0.05f, 160 + l, 1.f); ks[l] = fdev(64, 0.05f, 170 + l, 1.f); fg[l] = fdev(D, 0.05f, 180 + l, 1.f);
         cw[l] = fdev((size_t)3 * 2 * Fp, 0.3f, 190 + l, 0.f);
         { std::vector<float> g(Fp); fill_f32(g, 0.05f, 200 + l); for (int c = 0; c < Fp; ++c) g[c] = c < F ? g[c] + 1.f : 0.f; mg[l] = dev(g); }
-        Kc[l] = fdev((size_t)B * Nmax * 64, 0.1f, 210 + l, 0.f); Vc[l] = fdev((size_t)B * Nmax * 64, 1.f, 220 + l, 0.f); hist[l] = fdev((size_t)B * 2 * 2 * Fp, 1.f, 230 + l, 0.f);
     }
+    // the step WRITES the cache row and shifts the conv history: every library starts from its own fresh copy
+    auto fresh_state = [&] {
+        for (int l = 0; l < L; ++l) {
+            Kc[l] = fdev((size_t)B * Nmax * 64, 0.1f, 210 + l, 0.f); Vc[l] = fdev((size_t)B * Nmax * 64, 1.f, 220 + l, 0.f); hist[l] = fdev((size_t)B * 2 * 2 * Fp, 1.f, 230 + l, 0.f);
+        }
+    };
     // (the per-layer pointer arrays of omlm_decode_args are HOST arrays of device pointers)
     float* table = fdev((size_t)Nmax * 8, 0.1f, 300, 0.f);
     float* fgam = fdev(D, 0.05f, 301, 1.f);
@@ -390,6 +395,7 @@ static void decode_case(Lib& A, Lib& Bl, int B) {
     std::vector<float> res[2]; float us[2];
     for (int li = 0; li < 2; ++li) {
         apply_env(li ? g_env_b : g_env_a);
+        fresh_state();
         omlm_decode_args a; memset(&a, 0, sizeof(a));
         a.B = B; a.D = D; a.H = H; a.L = L; a.F = F; a.Fp = Fp; a.Nmax = Nmax; a.w_dtype = 1; a.round_bf16 = 1; a.nsplit = nsplit;
         a.eps = 1e-5f; a.scale = 8.0f; a.pos_dev = dpos;
