@@ -77,9 +77,13 @@ long long omlm_attn_bias_table_floats(int N, int H);
  * (m_h = scale log2e bound + max bias_h, subtracted from the table) instead of a running maximum; neither: online softmax. */
 int omlm_attn_bias_prepare(const float* bias, float* biasT, int N, int H, int bias_ld, const float* q_scale,
                            const float* k_scale, float qk_bound, float scale, void* stream);
+/* dbias_ws (optional, omlm_mqa_attn_bwd_workspace_bytes(B, N, H) bytes, contents irrelevant on entry and exit): the dQ kernel leaves
+ * each wave's d(bias) bins there with plain stores and a small reduction adds them into dbias; without it every wave adds its bins into
+ * dbias with device-scope atomics (measured 290 us per layer slower at B = 8, N = 1817, H = 16). */
+long long omlm_mqa_attn_bwd_workspace_bytes(int B, int N, int H);
 int omlm_mqa_attn_bwd(const void* q, const void* k, const void* v, const float* bias, const float* biasT,
                       const unsigned char* keymask, const void* out, const void* dout, const float* lse, float* delta,
-                      float* dq, float* dk, float* dv, float* dbias,
+                      float* dq, float* dk, float* dv, float* dbias, float* dbias_ws,
                       int B, int N, int H, float scale, int bias_ld, int dtype, void* stream);
 
 /* Middle of ConvFeedForward: CausalDSConv -> GEGLU -> LayerNorm(F) -> Dropout (transformer.py:122-148).

@@ -356,7 +356,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(AT_D
                                                                  const T* __restrict__ out, const T* __restrict__ dout,
                                                                  const float* __restrict__ lse, float* __restrict__ delta,
                                                                  float* __restrict__ dq, float* __restrict__ dbias,
-                                                                 int B, int N, int H, float scale, int bias_ld) {
+                                                                 int B, int N, int H, float scale, int bias_ld, float* __restrict__ dpart) {
     constexpr int PLANE = TKV * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;                       // K rows  (S^T = K Q^T)
@@ -581,6 +581,13 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(AT_D
     if (dbias && !(AT_ABLATE & 2)) {
         // LDS atomics of this wave are complete in program order for this wave's own later reads
         __builtin_amdgcn_s_waitcnt(0xc07f);
+        if (dpart) {
+            // this wave's table as ONE row of the partial buffer [(b, h, query tile)][nqt * TQ]: plain coalesced stores.  Device-scope
+            // atomics into the shared [N, heads] table kept every wave alive until ~1800 contended read-modify-writes had drained
+            // (measured at B = 8, N = 1817, H = 16: 290 us of a 790 us backward); omlm_attn_dbias_reduce adds the rows up.
+            float* prow = dpart + (((size_t)b * H + h) * nqt + qt) * (size_t)(nqt * TQ);
+            for (int r = lane; r < nb; r += 64) prow[r] = dbias_l[r];
+        } else
         for (int r = lane; r < min(nb, N); r += 64) {
             const float vv = dbias_l[r];
             if (vv != 0.f) unsafeAtomicAdd(dbias + (size_t)r * bias_ld + h, vv);
@@ -597,7 +604,7 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(AT_D
                                                                  const T* __restrict__ out, const T* __restrict__ dout,
                                                                  const float* __restrict__ lse, float* __restrict__ delta,
                                                                  float* __restrict__ dq, float* __restrict__ dbias,
-                                                                 int B, int N, int H, float scale, int bias_ld) {
+                                                                 int B, int N, int H, float scale, int bias_ld, float* __restrict__ dpart) {
     // fp32 operands ("bf16x3"): S and dP -- the two products the probabilities and d(bias) are made of -- are formed from
     // hi/lo splits (3 MFMAs per product), so p, dS and the rel-pos bias gradient are fp32-grade; dQ = dS K itself stays a
     // single bf16 pass (dS rounded once), like every other gradient GEMM operand of this mode's backward.
@@ -774,6 +781,13 @@ __global__ __launch_bounds__(AT_THREADS) __attribute__((amdgpu_waves_per_eu(AT_D
     if (dbias) {
         // LDS atomics of this wave are complete in program order for this wave's own later reads
         __builtin_amdgcn_s_waitcnt(0xc07f);
+        if (dpart) {
+            // this wave's table as ONE row of the partial buffer [(b, h, query tile)][nqt * TQ]: plain coalesced stores.  Device-scope
+            // atomics into the shared [N, heads] table kept every wave alive until ~1800 contended read-modify-writes had drained
+            // (measured at B = 8, N = 1817, H = 16: 290 us of a 790 us backward); omlm_attn_dbias_reduce adds the rows up.
+            float* prow = dpart + (((size_t)b * H + h) * nqt + qt) * (size_t)(nqt * TQ);
+            for (int r = lane; r < nb; r += 64) prow[r] = dbias_l[r];
+        } else
         for (int r = lane; r < min(nb, N); r += 64) {
             const float vv = dbias_l[r];
             if (vv != 0.f) unsafeAtomicAdd(dbias + (size_t)r * bias_ld + h, vv);
@@ -1092,21 +1106,25 @@ extern "C" int OMLM_API(omlm_mqa_attn_fwd)(const void* q, const void* k, const v
 // dq [B*N, H*64] fp32, dk, dv [B*N, 64] fp32 (overwritten), dbias [N, bias_ld] fp32 (accumulated, +=), delta [B, H, N] scratch
 int attn2_bwd_dq_launch(const void* q, const void* k, const void* v, const float* biasT, const unsigned char* keymask,
                         const void* out, const void* dout, const float* lse, float* delta, float* dq, float* dbias, int bias_ld,
-                        int B, int N, int H, float scale, hipStream_t st);                             // attention2.hip
+                        float* dpart, int B, int N, int H, float scale, hipStream_t st);               // attention2.hip
+extern "C" int omlm_attn_dbias_reduce_launch(const float* dpart, float* dbias, int bias_ld, int B, int N, int H, void* stream);   // attention2.hip (bf16 copy)
 
+int attn3_bwd_dkv_launch(const void* q, const void* k, const void* v, const float* biasT, const unsigned char* keymask,
+                         const void* dout, const float* lse, const float* delta, float* dk, float* dv,
+                         int B, int N, int H, float scale, hipStream_t st);                            // attention3.hip
 #if !OMLM_FP16
 extern "C" int omlm_mqa_attn_bwd_h(const void* q, const void* k, const void* v, const float* bias, const float* biasT,
                                    const unsigned char* keymask, const void* out, const void* dout, const float* lse, float* delta,
-                                   float* dq, float* dk, float* dv, float* dbias,
+                                   float* dq, float* dk, float* dv, float* dbias, float* dbias_ws,
                                    int B, int N, int H, float scale, int bias_ld, int dtype, void* stream);
 #endif
 extern "C" int OMLM_API(omlm_mqa_attn_bwd)(const void* q, const void* k, const void* v, const float* bias, const float* biasT,
                                  const unsigned char* keymask, const void* out, const void* dout, const float* lse, float* delta,
-                                 float* dq, float* dk, float* dv, float* dbias,
+                                 float* dq, float* dk, float* dv, float* dbias, float* dbias_ws,
                                  int B, int N, int H, float scale, int bias_ld, int dtype, void* stream) {
 #if !OMLM_FP16
     if (dtype == OMLM_DT_F16)
-        return omlm_mqa_attn_bwd_h(q, k, v, bias, biasT, keymask, out, dout, lse, delta, dq, dk, dv, dbias, B, N, H, scale, bias_ld, 1, stream);
+        return omlm_mqa_attn_bwd_h(q, k, v, bias, biasT, keymask, out, dout, lse, delta, dq, dk, dv, dbias, dbias_ws, B, N, H, scale, bias_ld, 1, stream);
 #endif
     if (B <= 0 || N <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(q && k && v && out && dout && lse && delta && dq && dk && dv, "null pointer");
@@ -1121,6 +1139,7 @@ extern "C" int OMLM_API(omlm_mqa_attn_bwd)(const void* q, const void* k, const v
                             : ldsk_staged;
     int rc;
     hipStream_t st = as_stream(stream);
+    float* dpart = dbias ? dbias_ws : nullptr;      // per-(sample, head, query tile) d(bias) rows, summed by attn_dbias_reduce_launch below
     if (dtype == 0) {
 #if OMLM_FP16
         omlm_set_error("omlm_mqa_attn_bwd: fp32 operands are served by the bf16 copy of the library");
@@ -1128,7 +1147,8 @@ extern "C" int OMLM_API(omlm_mqa_attn_bwd)(const void* q, const void* k, const v
 #else
         if ((rc = set_lds(attn_bwd_dq_precise_kernel<float>, ldsq))) return rc;
         if ((rc = set_lds(attn_bwd_dkv_kernel<float>, ldsk))) return rc;
-        hipLaunchKernelGGL(attn_bwd_dq_precise_kernel<float>, gridq, block, ldsq, st, (const float*)q, (const float*)k, (const float*)v, bias, keymask, (const float*)out, (const float*)dout, lse, delta, dq, dbias, B, N, H, scale, bias_ld);
+        hipLaunchKernelGGL(attn_bwd_dq_precise_kernel<float>, gridq, block, ldsq, st, (const float*)q, (const float*)k, (const float*)v, bias, keymask, (const float*)out, (const float*)dout, lse, delta, dq, dbias, B, N, H, scale, bias_ld, dpart);
+        if (dpart && (rc = omlm_attn_dbias_reduce_launch(dpart, dbias, bias_ld, B, N, H, st))) return rc;
         hipLaunchKernelGGL(attn_bwd_dkv_kernel<float>, gridk, block, ldsk, st, (const float*)q, (const float*)k, (const float*)v, bias, keymask, (const float*)dout, lse, delta, dk, dv, B, N, H, scale, bias_ld, win ? biasT : nullptr, ldT);
 #endif
     } else {
@@ -1144,13 +1164,22 @@ extern "C" int OMLM_API(omlm_mqa_attn_bwd)(const void* q, const void* k, const v
         if (dq2 < 0) { const char* e = getenv("OMLM_ATTN_DQ2"); dq2 = e ? (e[0] == '1' ? 1 : 0) : 2; }
         const bool use2 = dq2 == 1 || (dq2 == 2 && ldsq > 80 * 1024);
         if (use2 && (biasT || !bias) && !attn_v1_forced()) {
-            r2 = attn2_bwd_dq_launch(q, k, v, biasT, keymask, out, dout, lse, delta, dq, dbias, bias_ld, B, N, H, scale, st);
+            r2 = attn2_bwd_dq_launch(q, k, v, biasT, keymask, out, dout, lse, delta, dq, dbias, bias_ld, dpart, B, N, H, scale, st);
             if (r2 < 0) return r2;
         }
         if (r2 != 0) {
         if ((rc = set_lds(attn_bwd_dq_kernel<h16_t>, ldsq))) return rc;
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<h16_t>, gridq, block, ldsq, st, (const h16_t*)q, (const h16_t*)k, (const h16_t*)v, bias, keymask, (const h16_t*)out, (const h16_t*)dout, lse, delta, dq, dbias, B, N, H, scale, bias_ld);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<h16_t>, gridq, block, ldsq, st, (const h16_t*)q, (const h16_t*)k, (const h16_t*)v, bias, keymask, (const h16_t*)out, (const h16_t*)dout, lse, delta, dq, dbias, B, N, H, scale, bias_ld, dpart);
         }
+        if (dpart && (rc = omlm_attn_dbias_reduce_launch(dpart, dbias, bias_ld, B, N, H, st))) return rc;
+        // dK / dV: the third-generation kernel (attention3.hip: 128 keys per workgroup, Q / dO staged once per workgroup by LDS-DMA) where the
+        // prepared table is there (or there is no bias); else the second-generation kernel
+        int r3 = 1;
+        if ((biasT || !bias) && !attn_v1_forced()) {
+            r3 = attn3_bwd_dkv_launch(q, k, v, biasT, keymask, dout, lse, delta, dk, dv, B, N, H, scale, st);
+            if (r3 < 0) return r3;
+        }
+        if (r3 != 0)
         hipLaunchKernelGGL(attn_bwd_dkv_kernel<h16_t>, gridk, block, ldsk, st, (const h16_t*)q, (const h16_t*)k, (const h16_t*)v, bias, keymask, (const h16_t*)dout, lse, delta, dk, dv, B, N, H, scale, bias_ld, win ? biasT : nullptr, ldT);
     }
     return omlm_post_launch("omlm_mqa_attn_bwd");

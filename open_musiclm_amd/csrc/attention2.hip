@@ -29,7 +29,7 @@ namespace OMLM_NS {
 #define A2_DQ_BATCH 1        /* backward dQ kernel: fragment / bias reads issued in batches (scheduling only, same arithmetic) */
 #endif
 #ifndef A2_ABLATE
-#define A2_ABLATE 0          /* profiling builds only: 1 = skip the tile arithmetic, 2 = skip the steady-state DMA, 4 = no exp2 */
+#define A2_ABLATE 0          /* profiling builds only: 1 = skip the tile arithmetic, 2 = skip the steady-state DMA, 4 = no exp2; dQ kernel: 8 = no diagonal sums, 16 = no per-block table update, 32 = no global d(bias) flush */
 #endif
 
 #define MFMA16(a, b, c) OMLM_MFMA_32x32x16(a, b, c)
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(A2_THREADS) void attn2_bwd_dq_kernel(const h16_t* _
                                                                   const unsigned char* __restrict__ keymask, const h16_t* __restrict__ out,
                                                                   const h16_t* __restrict__ dout, const float* __restrict__ lse,
                                                                   float* __restrict__ delta, float* __restrict__ dq, float* __restrict__ dbias,
-                                                                  int bias_ld, int B, int N, int H, float scale) {
+                                                                  int bias_ld, float* __restrict__ dpart, int B, int N, int H, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;
     char* scratch = smem + A2_NST * A2B_STAGE;
@@ -586,9 +586,10 @@ __global__ __launch_bounds__(A2_THREADS) void attn2_bwd_dq_kernel(const h16_t* _
                 // d(bias)[rel] = sum of dS over the diagonal rel = i - j: output lane L stands for t = q - kr = L - 31 and pulls row
                 // kr's element from query column q = t + kr through the cross-lane permute; then one read-add-write of this
                 // wave's private table (every lane owns a distinct bin)
-                const float dsum = diag_sum_32x32(bv, lane);
+                const float dsum = (A2_ABLATE & 8) ? bv[0] + bv[15] : diag_sum_32x32(bv, lane);
                 const int rel = (i0 - jb) + (lane - 31);
-                if (rel >= 0 && rel < nb) dbw[rel] += dsum;
+                if (!(A2_ABLATE & 16) && rel >= 0 && rel < nb) dbw[rel] += dsum;
+                if (A2_ABLATE & 16) acc[0][0] += dsum * 1e-30f;      // (ds_add_f32 instead of this read-add-write: measured 20 us per layer SLOWER)
             }
 #if A2_DQ_BATCH
             {
@@ -625,8 +626,12 @@ __global__ __launch_bounds__(A2_THREADS) void attn2_bwd_dq_kernel(const h16_t* _
                 *(float4*)(drow + d) = make_float4(acc[dt][4 * g4], acc[dt][4 * g4 + 1], acc[dt][4 * g4 + 2], acc[dt][4 * g4 + 3]);
             }
     }
-    if (dbias) {
+    if (dbias && !(A2_ABLATE & 32)) {
         __builtin_amdgcn_s_waitcnt(0xc07f);                   // this wave's LDS updates are complete for its own reads
+        if (dpart) {                                          // one row of the partial buffer (see attention.hip's dQ kernel): plain stores
+            float* prow = dpart + (((size_t)b * H + h) * nqt + qt) * (size_t)(nqt * 32);
+            for (int r = lane; r < nb; r += 64) prow[r] = dbw[r];
+        } else
         for (int r = lane; r < min(nb, N); r += 64) {
             const float vv = dbw[r];
             if (vv != 0.f) unsafeAtomicAdd(dbias + (size_t)r * bias_ld + h, vv);
@@ -636,7 +641,7 @@ __global__ __launch_bounds__(A2_THREADS) void attn2_bwd_dq_kernel(const h16_t* _
 
 int attn2_bwd_dq_launch(const void* q, const void* k, const void* v, const float* biasT, const unsigned char* keymask,
                         const void* out, const void* dout, const float* lse, float* delta, float* dq, float* dbias, int bias_ld,
-                        int B, int N, int H, float scale, hipStream_t st) {
+                        float* dpart, int B, int N, int H, float scale, hipStream_t st) {
     const int ldT = (A2_PAD + N + 2 * A2_BWIN + 3) / 4 * 4;
     const int nqt = (N + 31) / 32, ny = (H + 7) / 8, npad = (N + 63) / 64 * 64;
     const size_t lds = (size_t)A2_NST * A2B_STAGE + 4096 + (size_t)npad * 4 + (size_t)8 * (nqt * 32) * 4;
@@ -644,7 +649,7 @@ int attn2_bwd_dq_launch(const void* q, const void* k, const void* v, const float
     static bool a1 = false;
     if (!a1) { (void)hipFuncSetAttribute((const void*)attn2_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a1 = true; }
     hipLaunchKernelGGL(attn2_bwd_dq_kernel, dim3(nqt * ny * B), dim3(A2_THREADS), lds, st, (const h16_t*)q, (const h16_t*)k, (const h16_t*)v,
-                       biasT, ldT, keymask, (const h16_t*)out, (const h16_t*)dout, lse, delta, dq, dbias, bias_ld, B, N, H, scale);
+                       biasT, ldT, keymask, (const h16_t*)out, (const h16_t*)dout, lse, delta, dq, dbias, bias_ld, dpart, B, N, H, scale);
     return omlm_post_launch("omlm_mqa_attn_bwd");
 }
 
@@ -666,6 +671,43 @@ extern "C" int omlm_attn_bias_prepare(const float* bias, float* biasT, int N, in
     hipLaunchKernelGGL(attn2_bias_prep_kernel, dim3(H8), dim3(256), 0, as_stream(stream), bias, biasT, N, H, bias_ld, ldT, q_scale, k_scale,
                        qk_bound, scale * A2_LOG2E);
     return omlm_post_launch("omlm_attn_bias_prepare");
+}
+
+// d(bias) partial rows -> the [N, bias_ld] table.  The dQ kernels leave one fp32 row of nqt*32 bins per (sample, head, query tile) in
+// the workspace (bins [0, 32 (qt + 1)) of row qt are written; the rest is never read); a thread here owns one (bin, head) and adds
+// the rows of every S-th sample down its column -- coalesced along the bins -- then one atomic per thread folds the S sample groups.
+#define A2_DBR_S 8
+__global__ __launch_bounds__(256) void attn_dbias_reduce_kernel(const float* __restrict__ dpart, float* __restrict__ dbias, int bias_ld,
+                                                                int B, int N, int H, int nqt) {
+    const int r = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y, s = blockIdx.z;
+    if (r >= N) return;
+    const size_t NB = (size_t)nqt * 32;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int b = s; b < B; b += A2_DBR_S) {
+        const float* col = dpart + ((size_t)b * H + h) * nqt * NB + r;
+        int qt = r >> 5;
+        for (; qt + 4 <= nqt; qt += 4) {
+            a0 += col[(size_t)qt * NB];
+            a1 += col[(size_t)(qt + 1) * NB];
+            a2 += col[(size_t)(qt + 2) * NB];
+            a3 += col[(size_t)(qt + 3) * NB];
+        }
+        for (; qt < nqt; ++qt) a0 += col[(size_t)qt * NB];
+    }
+    const float t = (a0 + a1) + (a2 + a3);
+    if (t != 0.f) unsafeAtomicAdd(dbias + (size_t)r * bias_ld + h, t);
+}
+
+extern "C" long long omlm_mqa_attn_bwd_workspace_bytes(int B, int N, int H) {
+    const long long nqt = (N + 31) / 32;
+    return (long long)B * H * nqt * nqt * 32 * (long long)sizeof(float);
+}
+
+extern "C" int omlm_attn_dbias_reduce_launch(const float* dpart, float* dbias, int bias_ld, int B, int N, int H, void* stream) {
+    const int nqt = (N + 31) / 32;
+    hipLaunchKernelGGL(attn_dbias_reduce_kernel, dim3((N + 255) / 256, H, min(B, A2_DBR_S)), dim3(256), 0, as_stream(stream), dpart, dbias,
+                       bias_ld, B, N, H, nqt);
+    return omlm_post_launch("omlm_mqa_attn_bwd");
 }
 
 #endif

@@ -174,7 +174,48 @@ __device__ __forceinline__ float wave_max(float v) {
 #endif
 #define OMLM_BPERM(KR) asm volatile("ds_bpermute_b32 %0, %1, %2 offset:%3" : "=v"(got[KR]) : "v"(base), \
         "v"(bv[4 * ((KR) >> 3) + ((KR) & 3)]), "i"(4 * (((KR) - 31 + 32 * (((KR) >> 2) & 1)) & 63)))
+// Horner form on the VALU (no LDS crossbar): row kr's 32 values must move from lanes q (rows of the lower half-wave) / 32 + q (rows of
+// the upper half-wave) to lanes q - kr + 31.  For the lower rows that is a right shift by 31 - kr, for the upper rows a left shift by
+// kr + 1; taken in order of decreasing shift, each row is added after the running sum has been shifted by the difference (1 inside a
+// group of four rows, 5 between groups): two chains of 15 DPP adds + 16 plain DPP shifts (wave_shr:1 / wave_shl:1, zero fill) on
+// half-masked copies of the registers.  -DOMLM_DIAG_HORNER=1.
+#ifndef OMLM_DIAG_HORNER
+#define OMLM_DIAG_HORNER 1
+#endif
+template <int CTRL>
+__device__ __forceinline__ float dpp_shift1(float v) {       // CTRL 0x138: lane i <- lane i - 1 (lane 0 <- 0); 0x130: lane i <- lane i + 1
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float diag_sum_32x32_horner(const float (&bv)[16], int lane) {
+    const bool lo = lane < 32;
+    // chain A: rows of the lower half-wave, kr = (r & 3) + 8 (r >> 2) ascending = shift 31 - kr descending
+    float a = lo ? bv[0] : 0.f;
+#pragma unroll
+    for (int r = 1; r < 16; ++r) {
+        const int gap = (r & 3) == 0 ? 5 : 1;
+#pragma unroll
+        for (int g = 0; g < gap; ++g) a = dpp_shift1<0x138>(a);
+        a += lo ? bv[r] : 0.f;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) a = dpp_shift1<0x138>(a);    // the last row (kr = 27) needs 31 - 27
+    // chain B: rows of the upper half-wave, kr = 4 + (r & 3) + 8 (r >> 2); shift left by kr + 1, largest first
+    float b = lo ? 0.f : bv[15];
+#pragma unroll
+    for (int r = 14; r >= 0; --r) {
+        const int gap = (r & 3) == 3 ? 5 : 1;
+#pragma unroll
+        for (int g = 0; g < gap; ++g) b = dpp_shift1<0x130>(b);
+        b += lo ? 0.f : bv[r];
+    }
+#pragma unroll
+    for (int g = 0; g < 5; ++g) b = dpp_shift1<0x130>(b);    // the last row (kr = 4) needs 4 + 1
+    return a + b;
+}
 __device__ __forceinline__ float diag_sum_32x32(const float (&bv)[16], int lane) {
+#if OMLM_DIAG_HORNER
+    return diag_sum_32x32_horner(bv, lane);
+#endif
     float dsum = 0.f;
 #if OMLM_DIAG_ASM
     float got[32];

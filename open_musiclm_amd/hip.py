@@ -36,7 +36,8 @@ SIGNATURES = {
     "omlm_attn_bias_table_floats": [i32, i32],
     "omlm_attn_bias_prepare": [vp, vp, i32, i32, i32, vp, vp, f32, f32, vp],
     "omlm_mqa_attn_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, vp],
-    "omlm_mqa_attn_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, vp],
+    "omlm_mqa_attn_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, vp],
+    "omlm_mqa_attn_bwd_workspace_bytes": [i32, i32, i32],
     "omlm_ffmid_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, u64, vp, vp, vp, i32, vp],
     "omlm_ffmid_bwd_workspace_bytes": [i32, i32],
     "omlm_ffmid_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp, vp, vp, i32, vp],
@@ -69,7 +70,7 @@ SIGNATURES = {
     "omlm_probe_tr16": [vp, vp],
 }
 _RESTYPES = {"omlm_last_error": C.c_char_p, "omlm_ffmid_bwd_workspace_bytes": C.c_longlong,
-             "omlm_attn_bias_table_floats": C.c_longlong,
+             "omlm_attn_bias_table_floats": C.c_longlong, "omlm_mqa_attn_bwd_workspace_bytes": C.c_longlong,
              "omlm_layernorm_bwd_workspace_bytes": C.c_longlong, "omlm_set_error": None}
 
 

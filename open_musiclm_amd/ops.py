@@ -196,6 +196,14 @@ class AttnBias:
         self.tableT = torch.empty(int(hip.lib().omlm_attn_bias_table_floats(N, H)), device=dev)
         call("omlm_attn_bias_prepare", ptr(table), ptr(self.tableT), N, H, table.shape[-1] if table is not None else 0,
              ptr(q_scale), ptr(k_scale), float(qk_bound), float(scale), stream_ptr())
+        self._ws = None
+
+    def dbias_workspace(self, B: int, N: int, H: int) -> torch.Tensor:
+        """Scratch for the backward's d(bias) partial rows (omlm_mqa_attn_bwd_workspace_bytes), shared by the layers of one step."""
+        n = int(hip.lib().omlm_mqa_attn_bwd_workspace_bytes(B, N, H)) // 4
+        if self._ws is None or self._ws.numel() < n:
+            self._ws = torch.empty(n, device=self.tableT.device, dtype=torch.float32)
+        return self._ws
 
 
 def _attn_bias(bias, N, H, device) -> "AttnBias":
@@ -209,12 +217,14 @@ def attn_fwd(q, k, v, bias, keymask, out, lse, B, N, H, scale):
          B, N, H, float(scale), ab.table.shape[-1] if ab.table is not None else 0, dcode(q.dtype), stream_ptr())
 
 
-def attn_bwd(q, k, v, bias, keymask, out, dout, lse, delta, dq, dk, dv, dbias, B, N, H, scale):
-    """bias: the AttnBias the forward used (its tableT carries the reference point lse is relative to), a raw table, or None."""
+def attn_bwd(q, k, v, bias, keymask, out, dout, lse, delta, dq, dk, dv, dbias, B, N, H, scale, workspace=True):
+    """bias: the AttnBias the forward used (its tableT carries the reference point lse is relative to), a raw table, or None.
+    workspace=False: d(bias) by device-scope atomics straight into the table (the C ABI's null-workspace form; slower)."""
     ab = _attn_bias(bias, N, H, q.device)
     bias = ab.table
+    ws = ab.dbias_workspace(B, N, H) if dbias is not None and workspace else None
     call("omlm_mqa_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(bias), ptr(ab.tableT), ptr(keymask), ptr(out), ptr(dout), ptr(lse),
-         ptr(delta), ptr(dq), ptr(dk), ptr(dv), ptr(dbias), B, N, H, float(scale),
+         ptr(delta), ptr(dq), ptr(dk), ptr(dv), ptr(dbias), ptr(ws), B, N, H, float(scale),
          bias.shape[-1] if bias is not None else 0, dcode(q.dtype), stream_ptr())
 
 

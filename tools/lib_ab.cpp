@@ -21,6 +21,9 @@
 typedef int (*fwd_t)(const void*, const void*, const void*, const float*, const float*, const unsigned char*, void*, float*, int, int, int, float, int, int, void*);
 typedef int (*bwd_t)(const void*, const void*, const void*, const float*, const float*, const unsigned char*, const void*, const void*, const float*, float*,
                      float*, float*, float*, float*, int, int, int, float, int, int, void*);
+typedef int (*bwdw_t)(const void*, const void*, const void*, const float*, const float*, const unsigned char*, const void*, const void*, const float*, float*,
+                      float*, float*, float*, float*, float*, int, int, int, float, int, int, void*);      // with the d(bias) workspace (round 3c on)
+typedef long long (*bwsz_t)(int, int, int);
 typedef int (*prep_t)(const float*, float*, int, int, int, const float*, const float*, float, float, void*);
 typedef long long (*tbl_t)(int, int);
 typedef int (*gemm_t)(const void*, const void*, void*, const float*, const int*, const int*, const int*, long long, long long, int, int, int, int, int, int, int,
@@ -41,12 +44,13 @@ typedef int (*planes_t)(const void*, long long, const void*, long long, void*, c
                         int, int, int, int, int, int, int, int, int, int, float, void*);
 
 struct Lib {
-    std::string path; void* h; fwd_t fwd; bwd_t bwd; prep_t prep; tbl_t tbl; gemm_t gemm; err_t err; wgrad_t wgrad; planes_t planes; ffwd_t ffwd; fws_t fws; fbwd_t fbwd; lnf_t lnf; lnws_t lnws; lnb_t lnb; dstep_t dstep;
+    std::string path; void* h; fwd_t fwd; bwd_t bwd; bwdw_t bwdw; bwsz_t bwsz; prep_t prep; tbl_t tbl; gemm_t gemm; err_t err; wgrad_t wgrad; planes_t planes; ffwd_t ffwd; fws_t fws; fbwd_t fbwd; lnf_t lnf; lnws_t lnws; lnb_t lnb; dstep_t dstep;
     void load(const char* p) {
         path = p;
         h = dlopen(p, RTLD_NOW | RTLD_LOCAL);
         if (!h) { fprintf(stderr, "dlopen %s: %s\n", p, dlerror()); exit(1); }
-        fwd = (fwd_t)dlsym(h, "omlm_mqa_attn_fwd"); bwd = (bwd_t)dlsym(h, "omlm_mqa_attn_bwd");
+        fwd = (fwd_t)dlsym(h, "omlm_mqa_attn_fwd"); bwd = (bwd_t)dlsym(h, "omlm_mqa_attn_bwd"); bwdw = (bwdw_t)dlsym(h, "omlm_mqa_attn_bwd");
+        bwsz = (bwsz_t)dlsym(h, "omlm_mqa_attn_bwd_workspace_bytes");       // absent in libraries older than the workspace form
         prep = (prep_t)dlsym(h, "omlm_attn_bias_prepare"); tbl = (tbl_t)dlsym(h, "omlm_attn_bias_table_floats");
         gemm = (gemm_t)dlsym(h, "omlm_gemm"); err = (err_t)dlsym(h, "omlm_last_error"); wgrad = (wgrad_t)dlsym(h, "omlm_gemm_wgrad_group"); planes = (planes_t)dlsym(h, "omlm_gemm_planes");
         ffwd = (ffwd_t)dlsym(h, "omlm_ffmid_fwd"); fws = (fws_t)dlsym(h, "omlm_ffmid_bwd_workspace_bytes"); fbwd = (fbwd_t)dlsym(h, "omlm_ffmid_bwd");
@@ -138,14 +142,19 @@ static void attn_case(Lib& A, Lib& Bl, int B, int N, int H, int dtype = 1) {
         L.ok(L.fwd(dq_, dk_, dv_, dbias_in, biasT, dmask, out, lse, B, N, H, scale, ld, dtype, nullptr), "attn_fwd");
         CK(hipDeviceSynchronize());
         float *gq = dev_zero<float>(M * H * 64), *gk = dev_zero<float>(M * 64), *gv = dev_zero<float>(M * 64), *gb = dev_zero<float>((size_t)N * ld);
-        L.ok(L.bwd(dq_, dk_, dv_, dbias_in, biasT, dmask, out, ddo, lse, delta, gq, gk, gv, gb, B, N, H, scale, ld, dtype, nullptr), "attn_bwd");
+        float* wsb = L.bwsz && !getenv("LIB_AB_NO_DBIAS_WS") ? dev_zero<float>((size_t)L.bwsz(B, N, H) / 4) : nullptr;
+        auto bwd_call = [&](float* gbias) {
+            return L.bwsz ? L.bwdw(dq_, dk_, dv_, dbias_in, biasT, dmask, out, ddo, lse, delta, gq, gk, gv, gbias, wsb, B, N, H, scale, ld, dtype, nullptr)
+                          : L.bwd(dq_, dk_, dv_, dbias_in, biasT, dmask, out, ddo, lse, delta, gq, gk, gv, gbias, B, N, H, scale, ld, dtype, nullptr);
+        };
+        L.ok(bwd_call(gb), "attn_bwd");
         CK(hipDeviceSynchronize());
         res[li][0] = host(gq, M * H * 64); res[li][1] = host(gk, M * 64); res[li][2] = host(gv, M * 64); res[li][3] = host(gb, (size_t)N * ld);
         float* scratch_b = dev_zero<float>((size_t)N * ld);
-        us[li] = time_us([&] { L.bwd(dq_, dk_, dv_, dbias_in, biasT, dmask, out, ddo, lse, delta, gq, gk, gv, scratch_b, B, N, H, scale, ld, dtype, nullptr); }, 10);
-        us_nb[li] = time_us([&] { L.bwd(dq_, dk_, dv_, dbias_in, biasT, dmask, out, ddo, lse, delta, gq, gk, gv, nullptr, B, N, H, scale, ld, dtype, nullptr); }, 10);
+        us[li] = time_us([&] { bwd_call(scratch_b); }, 10);
+        us_nb[li] = time_us([&] { bwd_call(nullptr); }, 10);
         fwd_us[li] = time_us([&] { L.fwd(dq_, dk_, dv_, dbias_in, biasT, dmask, out, lse, B, N, H, scale, ld, dtype, nullptr); }, 10);
-        CK(hipFree(gq)); CK(hipFree(gk)); CK(hipFree(gv)); CK(hipFree(gb)); CK(hipFree(scratch_b)); CK(hipFree(biasT));
+        CK(hipFree(gq)); CK(hipFree(gk)); CK(hipFree(gv)); CK(hipFree(gb)); CK(hipFree(scratch_b)); CK(hipFree(biasT)); if (wsb) CK(hipFree(wsb));
     }
     const double flops = 4.0 * H * 64 * (double)N * (N + 1) / 2 * B;
     printf("  A %-48s fwd %8.1f us  bwd %8.1f us (%6.1f TFLOP/s at 5 matmuls)  bwd without d(bias) %8.1f us\n", A.path.c_str(), fwd_us[0], us[0], 2.5 * flops / us[0] / 1e6, us_nb[0]);
