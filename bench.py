@@ -86,7 +86,7 @@ class TrainLeg:
             items = [ds[i * micro + j] for j in range(micro)]
             return [torch.cat([it[f] for it in items], 0).to(dev) for f in range(len(self.keys))]
         self.batches = [make_batch(i) for i in range(4 * accum)]       # resident in HBM before timing
-        self.fb = GraphedForwardBackward(lambda **kw: self.stage(**kw, return_loss=True)[0], loss_scale=1.0 / accum,
+        self.fb = GraphedForwardBackward(lambda **kw: self.stage(**kw, return_loss=True, return_logits=False)[0], loss_scale=1.0 / accum,
                                          enabled=use_graph)
         self.optim.zero_grad()                                 # adopt the flat parameter / gradient buffers before capture
 
@@ -142,7 +142,7 @@ class TrainLeg:
             e0.record()
             ops_gemm(A, B, C_, M=M, N=N, K=K, **kw)
             e1.record()
-            rec.append((e0, e1, 2.0 * M * N * K))
+            rec.append((e0, e1, 2.0 * M * N * K, (M, N, K, str(A.dtype)[6:], str(C_.dtype)[6:], int(bool(kw.get('a_kmajor'))), int(bool(kw.get('b_kmajor'))))))
         # the weight-gradient contractions of a backward go out as grouped launches (ops.WgradGroup.flush): same bookkeeping
         group_flush = ops.WgradGroup.flush
 
@@ -154,7 +154,7 @@ class TrainLeg:
             e0.record()
             group_flush(wg, splits)
             e1.record()
-            rec.append((e0, e1, fl))
+            rec.append((e0, e1, fl, ('wgrad_group', len(wg.items), splits)))
         E.ops.gemm = timed_gemm
         ops.WgradGroup.flush = timed_flush
         try:
@@ -164,9 +164,18 @@ class TrainLeg:
         finally:
             E.ops.gemm = ops_gemm
             ops.WgradGroup.flush = group_flush
-        tot_ms = sum(a.elapsed_time(b) for a, b, _ in rec)
-        tot_fl = sum(f for _, _, f in rec)
-        big = [(a.elapsed_time(b), f) for a, b, f in rec if f > 1e11]
+        tot_ms = sum(a.elapsed_time(b) for a, b, _, _ in rec)
+        tot_fl = sum(f for _, _, f, _ in rec)
+        big = [(a.elapsed_time(b), f) for a, b, f, _ in rec if f > 1e11]
+        if os.environ.get("OMLM_BENCH_GEMM_TABLE"):        # per-shape table of the same launches (tools: profiles/*_gemm_calls.md)
+            agg = {}
+            for a, b, f, key in rec:
+                t = agg.setdefault(key, [0, 0.0, 0.0]); t[0] += 1; t[1] += a.elapsed_time(b); t[2] += f
+            rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+            with open(os.environ["OMLM_BENCH_GEMM_TABLE"], "w") as fh:
+                fh.write("| M, N, K, operands, out, A k-major, B k-major | launches / step | us / launch | TFLOP/s | ms / step |\n|---|---:|---:|---:|---:|\n")
+                for key, (n, ms, fl) in rows:
+                    fh.write(f"| {key} | {n / 2:g} | {ms / n * 1e3:.1f} | {fl / (ms * 1e-3) / 1e12:.0f} | {ms / 2:.3f} |\n")
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
         mult = 3 if self.precision == "bf16x3" else 1
         return {"bound": "mfma", "kernel": "gemm kernels (all layouts, every GEMM launch of a train step)",

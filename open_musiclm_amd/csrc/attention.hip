@@ -1155,14 +1155,13 @@ extern "C" int OMLM_API(omlm_mqa_attn_bwd)(const void* q, const void* k, const v
         if ((rc = set_lds(attn_bwd_dkv_kernel<h16_t>, ldsk))) return rc;
         // dQ / d(bias) / delta: the attention2.hip kernel when the prepared table is there and the sample fits its LDS plan
         int r2 = 1;
-        // measured (B=32, N=1116, H=8): 334 us against 316 us for the first-generation kernel -- both spend ~160 us in the
-        // d(bias) diagonal sums (32 cross-lane permutes per 32x32 block) and ~170 us in everything else, so the LDS-DMA
-        // skeleton that took 30 % off the forward buys nothing here.  Kept behind OMLM_ATTN_DQ2=1.
-        // It IS selected where the first-generation kernel's LDS plan ([8][N] bias + d(bias) tables) leaves room for only one 4-wave
-        // workgroup per CU (N > ~1700: musiclm_large's fine stage): 8 waves per CU instead of 4.  OMLM_ATTN_DQ2=0/1 overrides.
+        // The attention2.hip kernel (8 heads per workgroup sharing LDS-DMA-staged K / V tiles) wherever its LDS plan fits: with the Horner
+        // diagonal sums and the d(bias) workspace it is the faster one at both bench shapes (B=32, N=1116, H=8: whole backward 432 against
+        // 456 us; before those two changes both kernels spent ~160 us per layer in d(bias) and the first-generation kernel led 316 : 334).
+        // OMLM_ATTN_DQ2=0 keeps the first-generation kernel (A/B).
         static int dq2 = -1;
-        if (dq2 < 0) { const char* e = getenv("OMLM_ATTN_DQ2"); dq2 = e ? (e[0] == '1' ? 1 : 0) : 2; }
-        const bool use2 = dq2 == 1 || (dq2 == 2 && ldsq > 80 * 1024);
+        if (dq2 < 0) { const char* e = getenv("OMLM_ATTN_DQ2"); dq2 = (e && e[0] == '0') ? 0 : 1; }
+        const bool use2 = dq2 == 1;
         if (use2 && (biasT || !bias) && !attn_v1_forced()) {
             r2 = attn2_bwd_dq_launch(q, k, v, biasT, keymask, out, dout, lse, delta, dq, dbias, bias_ld, dpart, B, N, H, scale, st);
             if (r2 < 0) return r2;

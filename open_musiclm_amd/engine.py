@@ -732,11 +732,11 @@ class LossFunction(torch.autograd.Function):
     softmax - onehot from the saved logits / row lse directly in the GEMM operand dtype."""
 
     @staticmethod
-    def forward(ctx, model, all_token_ids, labels, self_attn_mask, loss_weights, ignore_negative, precision, *params):
+    def forward(ctx, model, all_token_ids, labels, self_attn_mask, loss_weights, ignore_negative, precision, all_logits, *params):
         nseq = len(model.token_sequences)
         bufs, lay, st = run_forward(model, all_token_ids, self_attn_mask, False, True, precision,
-                                    want=[True] * nseq)
-        dev = bufs[-1].device
+                                    want=[bool(all_logits) or w > 0 for w in loss_weights])
+        dev = next(b for b in bufs if b is not None).device
         total = 0
         total_dev = None                       # device-side part of the normaliser: non-ignored labels of padded sequences
         nll = torch.zeros(nseq, device=dev)
@@ -778,7 +778,7 @@ class LossFunction(torch.autograd.Function):
         ctx.nparams = len(params)
         ctx.gscale = loss_scale(precision)
         views = logits_views(model, lay, bufs)
-        ctx.mark_non_differentiable(*views)
+        ctx.mark_non_differentiable(*[v for v in views if v is not None])
         return (loss, *views)
 
     @staticmethod
@@ -801,4 +801,4 @@ class LossFunction(torch.autograd.Function):
             dl.append(d)
         run_backward(st, dl)
         ctx.st = None
-        return (None,) * (7 + ctx.nparams)
+        return (None,) * (8 + ctx.nparams)

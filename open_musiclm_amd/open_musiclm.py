@@ -116,12 +116,13 @@ class TokenConditionedTransformer(nn.Module):
         bufs, _, _ = engine.run_forward(self, ids, None, True, False, self._precision(), final_rows_only=True)
         return bufs[-1]
 
-    def loss_and_logits(self, ids, labels, self_attn_mask, loss_weights, ignore_negative=None):
+    def loss_and_logits(self, ids, labels, self_attn_mask, loss_weights, ignore_negative=None, all_logits=True):
         """ignore_negative[s]: labels < 0 of sequence s are ignore_index rows AND leave the loss normaliser (the padded labels of
-        a unique_consecutive sequence, open_musiclm.py:396-404)."""
+        a unique_consecutive sequence, open_musiclm.py:396-404).  all_logits=False: the heads of zero-weight sequences are not
+        evaluated (their logits come back as None)."""
         ign = tuple(bool(v) for v in ignore_negative) if ignore_negative is not None else (False,) * len(labels)
         return engine.LossFunction.apply(self, ids, labels, self_attn_mask, tuple(loss_weights), ign, self._precision(),
-                                         *self.parameters())
+                                         bool(all_logits), *self.parameters())
 
 
 @beartype_jit
@@ -248,7 +249,9 @@ class TokenConditionedTransformerWrapper(nn.Module):
         return ids, labels, mask
 
     def forward(self, *, all_token_ids: List[torch.Tensor], return_loss: bool = False, input_has_eos: bool = False,
-                **kwargs):
+                return_logits: bool = True, **kwargs):
+        """return_logits=False (extension, return_loss=True only): the logits of sequences whose loss weight is 0 are not computed
+        and come back as None -- the trainers' optimizer steps read only the loss (trainer.py:428-447)."""
         assert len(all_token_ids) == len(self.token_sequences)
         ids, labels, mask = self._prepare(all_token_ids, return_loss, input_has_eos)
         if not return_loss:
@@ -259,12 +262,12 @@ class TokenConditionedTransformerWrapper(nn.Module):
         ignore = [bool(info.unique_consecutive and self.unique_consecutive) for info in self.token_sequences]
         loss_labels = [lb.masked_fill(lb == self.pad_id, -1) if ig else lb for lb, ig in zip(labels, ignore)]
         if torch.is_grad_enabled():
-            loss, *logits = self.transformer.loss_and_logits(ids, loss_labels, mask, weights, ignore)
+            loss, *logits = self.transformer.loss_and_logits(ids, loss_labels, mask, weights, ignore, return_logits)
         else:
             with torch.enable_grad():
-                loss, *logits = self.transformer.loss_and_logits(ids, loss_labels, mask, weights, ignore)
+                loss, *logits = self.transformer.loss_and_logits(ids, loss_labels, mask, weights, ignore, return_logits)
             loss = loss.detach()
-        all_logits = [l.transpose(1, 2) for l in logits]               # 'b n c -> b c n' (:389)
+        all_logits = [l.transpose(1, 2) if l is not None else None for l in logits]               # 'b n c -> b c n' (:389)
         return loss, all_logits, labels
 
 

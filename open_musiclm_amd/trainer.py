@@ -293,7 +293,7 @@ class SingleStageTrainer(nn.Module):
         if self.use_hip_graph and self.device.type == 'cuda':
             if self._graphed is None:
                 from .graph import GraphedForwardBackward
-                self._graphed = GraphedForwardBackward(lambda **kw: self.train_wrapper(**kw, return_loss=True)[0],
+                self._graphed = GraphedForwardBackward(lambda **kw: self.train_wrapper(**kw, return_loss=True, return_logits=False)[0],
                                                        loss_scale=1.0 / self.grad_accum_every)
 
                 def discard():                          # warm-up steps really ran: throw their gradients away
@@ -305,7 +305,7 @@ class SingleStageTrainer(nn.Module):
             loss = self._graphed(**data_kwargs)
             self.optim.mark_grads_dirty()
             return loss.clone()
-        loss, _, _ = self.train_wrapper(**data_kwargs, return_loss=True)
+        loss, _, _ = self.train_wrapper(**data_kwargs, return_loss=True, return_logits=False)
         (loss / self.grad_accum_every).backward()
         self.optim.mark_grads_dirty()
         return loss.detach()

@@ -234,6 +234,31 @@ def test_gemm_wgrad_group(ops, dev, splits, dtype):
     assert worst < 2e-5, worst
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gemm_wgrad_group_at_bench_shape(ops, dev, dtype):
+    """The grouped launch at the shape bench.py times: K = 32 x 1116 tokens, the five weight gradients of two coarse-small layers
+    (dW1 5504 x 1024, dW2 1024 x 2752, dWq, dWkv, dWo) accumulated into existing gradients, against fp64 products."""
+    g = torch.Generator().manual_seed(5)
+    K = 32 * 1116
+    shapes = [(5504, 1024), (1024, 2752), (512, 1024), (128, 1024), (1024, 512)] * 2
+    grp = ops.WgradGroup()
+    keep = []
+    for M, N in shapes:
+        dY = torch.randn(K, M, generator=g).to(dev).to(dtype)
+        X = torch.randn(K, N, generator=g).to(dev).to(dtype)
+        dW0 = torch.randn(M, N, generator=g).to(dev)
+        dW = dW0.clone()
+        grp.add(dY, X, dW, M=M, N=N, K=K)
+        keep.append((dY, X, dW, dW0))
+    grp.flush()
+    worst = 0.0
+    for dY, X, dW, dW0 in keep:
+        ref = dW0.double() + dY.double().t() @ X.double()
+        worst = max(worst, relerr(dW, ref))
+    report(f"gemm_wgrad_group_bench_shape[{dtype}]", relerr=worst, K=K)
+    assert worst < 2e-5, worst
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_layernorm_fwd_bwd(ops, dev, dtype):
     M, D = 333, 1024
@@ -324,7 +349,9 @@ def naive_attention(q, k, v, bias, keymask, H, scale=8.0):
 @pytest.mark.parametrize("dtype,B,N,H", [(torch.float32, 2, 77, 2), (torch.bfloat16, 2, 77, 2),
                                          (torch.bfloat16, 1, 200, 5), (torch.float32, 1, 130, 8),
                                          (torch.bfloat16, 1, 1817, 16), (torch.float32, 1, 1817, 16),
-                                         (torch.float16, 2, 77, 2), (torch.float16, 1, 200, 5), (torch.float16, 1, 1817, 16)])
+                                         (torch.float16, 2, 77, 2), (torch.float16, 1, 200, 5), (torch.float16, 1, 1817, 16),
+                                         # the bench shapes themselves (BASELINE configs 2 and 4 at their per-GPU batch), fp64 reference on the GPU
+                                         (torch.bfloat16, 32, 1116, 8), (torch.float16, 32, 1116, 8), (torch.bfloat16, 8, 1817, 16)])
 def test_attention_fwd_bwd(ops, dev, dtype, B, N, H):
     g = torch.Generator().manual_seed(N + H)
     M = B * N

@@ -27,8 +27,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REPORT = os.path.join(ROOT, "gpurun_out", "model_report.json")
 
-TOL = {"bf16x3": dict(logits=1e-3, loss=1e-4, grad=6e-2), "bf16": dict(logits=1.2e-2, loss=5e-3, grad=1.5e-1),
-       "fp16": dict(logits=1e-3, loss=1e-4, grad=1.5e-2)}      # measured at full size: logits 8.9e-4, loss 6e-6, grads <= 7.2e-3
+# Bars = about 2x the worst value measured over every case of this file (profiles/r03c_model_report.json holds the measurements):
+#   bf16x3  logits <= 2.9e-4 (depth 24), loss <= 1.1e-5, per-tensor gradients <= 7.4e-3 of the tensor's largest entry
+#   bf16    logits <= 7.7e-3 at depth 6 (1.6e-2 at depth 24: its own bar below), loss <= 4.3e-4, gradients <= 7.2e-2
+#   fp16    logits <= 8.9e-4 at depth 6 (2.0e-3 at depth 24), loss <= 4.3e-5, gradients <= 7.2e-3
+# `invariant`: the analytically-zero gradient directions of the rel-pos bias (see the train test), in the same units.
+TOL = {"bf16x3": dict(logits=1e-3, loss=4e-5, grad=1.5e-2, invariant=1e-2), "bf16": dict(logits=1.2e-2, loss=1e-3, grad=1.5e-1, invariant=1.0),
+       "fp16": dict(logits=1e-3, loss=1e-4, grad=1.5e-2, invariant=0.25)}
 
 
 def grad_unscale(precision):
@@ -113,7 +118,8 @@ def test_training_step_matches_reference_golden(golden_dir, dev, monkeypatch, na
     invariant = {k: v for k, v in grads.items() if k.endswith("rel_pos_bias.net.3.bias") or k.endswith("relative_attention_bias.weight")}
     for k in invariant:
         grads.pop(k)
-    assert all(v < 5.0 for v in invariant.values()), invariant          # < 5e-3 of the largest gradient entry in the model
+    # measured: <= 3e-3 (bf16x3), 0.1 (fp16), 0.43 (bf16) of 1e-3 x the largest gradient entry in the model
+    assert all(v < tol["invariant"] for v in invariant.values()), invariant
     worst = max(grads.items(), key=lambda kv: kv[1])
     report(f"train[{name},{precision}]", loss=e_loss, logits=e_logits, worst_grad=worst, grads=grads, invariant=invariant)
     assert e_loss < tol["loss"], e_loss
@@ -125,6 +131,37 @@ def test_training_step_matches_reference_golden(golden_dir, dev, monkeypatch, na
         ev = wrapper(all_token_ids=ids, return_loss=False)
     e_ev = [relerr(l, torch.from_numpy(z[f"eval_logits.{i}"])) for i, l in enumerate(ev)]
     assert max(e_ev) < tol["logits"], e_ev
+
+
+def test_loss_only_step_skips_zero_weight_heads(golden_dir, dev, monkeypatch):
+    """return_logits=False (what the trainers' optimizer steps use): same loss and gradients, bit for bit, as the full call; the
+    logits of zero-weight sequences are not evaluated."""
+    from open_musiclm_amd import open_musiclm as M
+    from oracle import musiclm_oracle as O
+    z, model = build_from_golden(golden_dir, "tiny_coarse", dev, "bf16x3")
+    noise = torch.from_numpy(z["forget_noise"])
+    monkeypatch.setattr(M, "generate_mask_with_prob",
+                        lambda shape, p, device: O.forgetful_mask_from_noise(noise, p).to(device))
+    wrapper = M.TokenConditionedTransformerWrapper(transformer=model, unique_consecutive=False,
+                                                   cross_entropy_loss_weights=[0, 0, 1], mask_prob=0.15)
+    wrapper.train()
+    ids = [torch.from_numpy(z[f"ids.{i}"]).to(dev) for i in range(3)]
+    out = []
+    for full in (True, False):
+        model.zero_grad(set_to_none=True)
+        loss, logits, _ = wrapper(all_token_ids=ids, return_loss=True, return_logits=full)
+        loss.backward()
+        out.append((float(loss.detach()), logits, {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+    assert out[0][0] == out[1][0]
+    assert out[1][1][0] is None and out[1][1][1] is None and torch.equal(out[0][1][2], out[1][1][2])
+    assert all(v is not None for v in out[0][1])
+    # weight gradients meet in fp32 atomics (grouped split-K launches): equal to summation-order noise (tensors that are analytically
+    # zero -- the rel-pos bias's constant direction -- hold only that noise: measured against the model's largest gradient entry)
+    gscale = max(float(g.abs().max()) for g in out[0][2].values())
+    for k, g in out[0][2].items():
+        err = float((out[1][2][k] - g).abs().max()) / max(float(g.abs().max()), 1e-3 * gscale)
+        assert err < 1e-5, (k, err)
+    loss = float(out[0][0])
 
 
 def test_logits_path_autograd_matches_fused_loss(golden_dir, dev, monkeypatch):
