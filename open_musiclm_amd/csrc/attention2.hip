@@ -25,6 +25,10 @@ namespace OMLM_NS {
 #define A2_LOG2E 1.4426950408889634f
 #define A2_STAGE (8192 + 8192 + 8 * A2_BWIN * 4)     /* K rows | V blocked | bias window = 20 KiB */
 #define A2_NST 3
+#ifndef A2_DQ_PK
+#define A2_DQ_PK 1           /* backward dQ kernel: element arithmetic on register pairs (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32), -lse and -delta carried
+                                in by the accumulators' initial values, the softmax scale applied once to dQ instead of to every dS */
+#endif
 #ifndef A2_DQ_BATCH
 #define A2_DQ_BATCH 1        /* backward dQ kernel: fragment / bias reads issued in batches (scheduling only, same arithmetic) */
 #endif
@@ -510,6 +514,7 @@ __global__ __launch_bounds__(A2_THREADS) void attn2_bwd_dq_kernel(const h16_t* _
 #pragma unroll
     for (int e = 0; e < 16; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
     const float c = scale * A2_LOG2E;
+    const float qscale = (A2_DQ_PK && A2_DQ_BATCH) ? scale : 1.f;      // dQ = scale dS K: taken out of the element loop
 
     for (int t = 0; t < nkt; ++t) {
         if (t + 1 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -563,7 +568,32 @@ __global__ __launch_bounds__(A2_THREADS) void attn2_bwd_dq_kernel(const h16_t* _
             for (int r = 0; r < 16; ++r) bpv[r] = bp[-((r & 3) + 8 * (r >> 2))];
 #pragma unroll
             for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(bpv[r]));
+#if A2_DQ_PK
+            if (diag) {                        // the block on the diagonal: keys above it leave through the bias term (a real branch: one block in nkt)
+                int d0v = d0;
+                asm volatile("" : "+v"(d0v));             // the selects depend on a value defined inside the branch: hipcc otherwise hoists all 16 of them in front of it
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bpv[r] = (d0v - ((r & 3) + 8 * (r >> 2)) >= 0) ? bpv[r] : A2_NEG;
+            }
 #endif
+#endif
+#if A2_DQ_PK && A2_DQ_BATCH
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 m4 = m4s[g];
+                const f32x2 mm2[2] = {{m4.x, m4.y}, {m4.z, m4.w}};
+#pragma unroll
+                for (int pq = 0; pq < 2; ++pq) {
+                    const int r = 4 * g + 2 * pq, cr = 2 * pq + 8 * g;
+                    const f32x2 t2 = (f32x2{bpv[r], bpv[r + 1]} + mm2[pq]) - f32x2{Lp, Lp};
+                    const f32x2 x2 = __builtin_elementwise_fma(f32x2{st[r], st[r + 1]}, f32x2{c, c}, t2);
+                    const f32x2 pr2 = {__builtin_amdgcn_exp2f(x2[0]), __builtin_amdgcn_exp2f(x2[1])};
+                    const f32x2 ds2 = pr2 * (f32x2{dp[r], dp[r + 1]} - f32x2{dl, dl});   // dS = P (dP - delta), 0 where masked; scale: see the dQ store
+                    bv[r] = ds2[0]; bv[r + 1] = ds2[1];
+                    st[r] = ds2[0]; st[r + 1] = ds2[1];
+                }
+            }
+#else
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 m4 = m4s[g];
@@ -582,6 +612,7 @@ __global__ __launch_bounds__(A2_THREADS) void attn2_bwd_dq_kernel(const h16_t* _
                     st[r] = bv[r] * scale;
                 }
             }
+#endif
             if (dbias) {
                 // d(bias)[rel] = sum of dS over the diagonal rel = i - j: output lane L stands for t = q - kr = L - 31 and pulls row
                 // kr's element from query column q = t + kr through the cross-lane permute; then one read-add-write of this
@@ -623,7 +654,7 @@ __global__ __launch_bounds__(A2_THREADS) void attn2_bwd_dq_kernel(const h16_t* _
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int d = 32 * dt + 8 * g4 + 4 * hi;
-                *(float4*)(drow + d) = make_float4(acc[dt][4 * g4], acc[dt][4 * g4 + 1], acc[dt][4 * g4 + 2], acc[dt][4 * g4 + 3]);
+                *(float4*)(drow + d) = make_float4(qscale * acc[dt][4 * g4], qscale * acc[dt][4 * g4 + 1], qscale * acc[dt][4 * g4 + 2], qscale * acc[dt][4 * g4 + 3]);
             }
     }
     if (dbias && !(A2_ABLATE & 32)) {

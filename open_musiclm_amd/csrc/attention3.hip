@@ -187,30 +187,39 @@ void attn3_bwd_dkv_kernel(const h16_t* __restrict__ q, const h16_t* __restrict__
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) {
             const int cr = (rr & 3) + 8 * (rr >> 2);          // crow(rr, hi) - 4 hi
-            bvv[rr] = has_bias ? bwp[cr] : 0.f;
+            bvv[rr] = bwp[cr];                                // (no bias: overwritten below -- one branch, not one per element)
             lvv[rr] = lp[cr];
             dvv[rr] = lp[32 + cr];
         }
+        if (!has_bias) {
+            float z = 0.f;
+            asm volatile("" : "+v"(z));                       // (defined inside the branch: otherwise 16 selects on every item)
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) bvv[rr] = z;
+        }
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) asm volatile("" : "+v"(bvv[rr]), "+v"(lvv[rr]), "+v"(dvv[rr]));
-        if (i0 >= j0w + 31 && i0 + 31 < N) {                  // every query of the tile follows every key of this wave, no row past N
-#pragma unroll
-            for (int rr = 0; rr < 16; ++rr) {
-                const float x = st[rr] * c + bvv[rr] - (lvv[rr] - mh);
-                const float p = __builtin_amdgcn_exp2f(keylive ? x : A3_NEG);
-                pr[rr] = p;
-                st[rr] = p * (dp[rr] - dvv[rr]) * scale;
-            }
-        } else {
+        // Element arithmetic on register pairs (v_pk_add_f32 / v_pk_fma_f32 / v_pk_mul_f32).  A dead key (this lane's column) leaves through
+        // the reference point: mhk = m_h - 1e30 there, so x = c S + bias - (lse - mhk) = -1e30 and P = 0 without a select; dS carries no
+        // softmax scale here -- dK = scale dS^T Q takes it once, at the final store.
+        const float mhk = keylive ? mh : mh + A3_NEG;
+        if (!(i0 >= j0w + 31 && i0 + 31 < N)) {               // the tile touches the diagonal or runs past N: those rows leave through the bias term
+            int kjv = kj;
+            asm volatile("" : "+v"(kjv));                     // (defined inside the branch: hipcc otherwise hoists the 16 selects in front of it)
 #pragma unroll
             for (int rr = 0; rr < 16; ++rr) {
                 const int i = i0 + a3_crow(rr, hi);
-                const bool ok = (i >= kj) && keylive && (i < N);
-                const float x = st[rr] * c + bvv[rr] - (lvv[rr] - mh);
-                const float p = __builtin_amdgcn_exp2f(ok ? x : A3_NEG);
-                pr[rr] = p;
-                st[rr] = p * (dp[rr] - dvv[rr]) * scale;
+                bvv[rr] = (i >= kjv && i < N) ? bvv[rr] : A3_NEG;
             }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 16; rr += 2) {
+            const f32x2 t2 = f32x2{bvv[rr], bvv[rr + 1]} - (f32x2{lvv[rr], lvv[rr + 1]} - f32x2{mhk, mhk});
+            const f32x2 x2 = __builtin_elementwise_fma(f32x2{st[rr], st[rr + 1]}, f32x2{c, c}, t2);
+            const f32x2 p2 = {__builtin_amdgcn_exp2f(x2[0]), __builtin_amdgcn_exp2f(x2[1])};
+            const f32x2 ds2 = p2 * (f32x2{dp[rr], dp[rr + 1]} - f32x2{dvv[rr], dvv[rr + 1]});
+            pr[rr] = p2[0]; pr[rr + 1] = p2[1];
+            st[rr] = ds2[0]; st[rr + 1] = ds2[1];
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -231,7 +240,7 @@ void attn3_bwd_dkv_kernel(const h16_t* __restrict__ q, const h16_t* __restrict__
 #pragma unroll
             for (int rr = 0; rr < 16; ++rr) {
                 const int d = 32 * dt + a3_crow(rr, hi);
-                red[d * 33 + (lane & 31)] = which == 0 ? dkacc[dt][rr] : dvacc[dt][rr];
+                red[d * 33 + (lane & 31)] = which == 0 ? scale * dkacc[dt][rr] : dvacc[dt][rr];
             }
         __builtin_amdgcn_s_waitcnt(0xc07f);                   // this wave's own LDS writes, then its own reads below
         float* dst = which == 0 ? dk : dv;

@@ -187,26 +187,34 @@ __device__ __forceinline__ float dpp_shift1(float v) {       // CTRL 0x138: lane
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 __device__ __forceinline__ float diag_sum_32x32_horner(const float (&bv)[16], int lane) {
-    const bool lo = lane < 32;
+    // half-masked copies by packed multiplies with {1, 0} lane constants (16 v_pk_mul_f32 instead of 32 v_cndmask_b32; dS is finite)
+    const float mlo = lane < 32 ? 1.f : 0.f, mhi = 1.f - mlo;
+    float va[16], vb[16];
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const f32x2 v = {bv[r], bv[r + 1]};
+        const f32x2 x = v * f32x2{mlo, mlo}, y = v * f32x2{mhi, mhi};
+        va[r] = x[0]; va[r + 1] = x[1]; vb[r] = y[0]; vb[r + 1] = y[1];
+    }
     // chain A: rows of the lower half-wave, kr = (r & 3) + 8 (r >> 2) ascending = shift 31 - kr descending
-    float a = lo ? bv[0] : 0.f;
+    float a = va[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) {
         const int gap = (r & 3) == 0 ? 5 : 1;
 #pragma unroll
         for (int g = 0; g < gap; ++g) a = dpp_shift1<0x138>(a);
-        a += lo ? bv[r] : 0.f;
+        a += va[r];
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) a = dpp_shift1<0x138>(a);    // the last row (kr = 27) needs 31 - 27
     // chain B: rows of the upper half-wave, kr = 4 + (r & 3) + 8 (r >> 2); shift left by kr + 1, largest first
-    float b = lo ? 0.f : bv[15];
+    float b = vb[15];
 #pragma unroll
     for (int r = 14; r >= 0; --r) {
         const int gap = (r & 3) == 3 ? 5 : 1;
 #pragma unroll
         for (int g = 0; g < gap; ++g) b = dpp_shift1<0x130>(b);
-        b += lo ? 0.f : bv[r];
+        b += vb[r];
     }
 #pragma unroll
     for (int g = 0; g < 5; ++g) b = dpp_shift1<0x130>(b);    // the last row (kr = 4) needs 4 + 1
