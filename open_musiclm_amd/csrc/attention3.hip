@@ -24,7 +24,8 @@ namespace OMLM_NS {
 #define A3_KR 128                      /* keys per workgroup */
 #define A3_NST 3
 #define A3_AUX 2048                    /* per-wave aux piece: [0,1024) window DMA (window 256 B | table tail 16 B | filler), [1024,1280) lse | delta */
-#define A3_STAGE (4096 + 4096 + 4 * A3_AUX)
+#define A3_IMG (4096 + 256)            /* one [32][64] blocked image: the units of rows 16..31 sit 128 bytes further (see a3_blk_off) */
+#define A3_STAGE (2 * A3_IMG + 4 * A3_AUX)
 #define A3_NEG (-1.0e30f)
 #define A3_LOG2E 1.4426950408889634f
 #define A3_PAD 64                      /* zero entries in front of each row of the prepared bias table (attention2.hip: A2_PAD) */
@@ -37,7 +38,10 @@ __device__ __forceinline__ int a3_blk_off(int row, int colbyte) {
     const int col = colbyte >> 1;
     const int rq = (row >> 2) & 3;
     const int p = ((rq >> 1) << 2) | ((rq & 1) << 1) | ((col >> 4) & 1);
-    return (((row >> 4) << 1) + (col >> 5)) * 1024 + p * 128 + (row & 3) * 32 + (col & 15) * 2;
+    // + 128 bytes for rows 16..31: a 16-lane group of a row-fragment ds_read_b128 holds two row quads of each half, and with all units on
+    // 1-KiB boundaries the four quads met on the same 32 banks (4-way conflict, SQ_LDS_BANK_CONFLICT 8 % of the kernel's wave-cycles);
+    // shifted, the two halves use disjoint bank halves (2-way, the best this image allows: tools/lds_conflicts.py model)
+    return (((row >> 4) << 1) + (col >> 5)) * 1024 + (row >> 4) * 128 + p * 128 + (row & 3) * 32 + (col & 15) * 2;
 }
 // A-operand row fragment (row = row0 + (lane & 31), dims 16 s + 8 (lane >> 5) .. +7) out of the blocked image
 __device__ __forceinline__ h16x8 a3_frag_rows(const char* lds, int s, int lane) {
@@ -45,7 +49,7 @@ __device__ __forceinline__ h16x8 a3_frag_rows(const char* lds, int s, int lane) 
 }
 // transposed operand: lane gets column col0 + (lane & 31) and the 8 rows MFMA k-index 8 (lane >> 5) + e maps to (accumulator row order)
 __device__ __forceinline__ h16x8 a3_frag_cols_tr(const char* lds, int s, int col0, int lane) {
-    const char* base = lds + ((s << 1) + (col0 >> 5)) * 1024 + lane * 8;
+    const char* base = lds + ((s << 1) + (col0 >> 5)) * 1024 + s * 128 + lane * 8;
     s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base));
     s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base + 512));
     typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -65,13 +69,20 @@ __device__ __forceinline__ h16x8 a3_pack(const f32x16& p, int s) {
 __device__ __forceinline__ void a3_dma16(const void* gsrc, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(lds_dst) : "memory", "m0");
 }
+// the same with a wave-uniform base and a per-lane 32-bit byte offset (no 64-bit address arithmetic per item)
+__device__ __forceinline__ void a3_dma16s(const void* sbase, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
+}
 __device__ __forceinline__ void a3_dma4(const void* gsrc, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(gsrc), "s"(lds_dst) : "memory", "m0");
 }
 
 // grid: B x (workgroups per sample); a sample's workgroups walk its key ranges r = 0, 1, ... (128 keys each), range r being cut into
 // ceil((nqt - 4 r) / CH) chunks of CH query tiles.
-__global__ __launch_bounds__(A3_T) __attribute__((amdgpu_waves_per_eu(2)))
+#ifndef A3_WAVES
+#define A3_WAVES 2                     /* waves per SIMD the register allocation aims at */
+#endif
+__global__ __launch_bounds__(A3_T) __attribute__((amdgpu_waves_per_eu(A3_WAVES)))
 void attn3_bwd_dkv_kernel(const h16_t* __restrict__ q, const h16_t* __restrict__ k, const h16_t* __restrict__ v,
                           const unsigned char* __restrict__ keymask, const h16_t* __restrict__ dout,
                           const float* __restrict__ lse, const float* __restrict__ delta, float* __restrict__ dk, float* __restrict__ dv,
@@ -118,25 +129,29 @@ void attn3_bwd_dkv_kernel(const h16_t* __restrict__ q, const h16_t* __restrict__
     const int colu = (wave & 1) * 32 + (pp_ & 1) * 16 + (lane & 1) * 8;
     const unsigned ring_lds = (unsigned)(size_t)LDS_PTR(char, smem3);
 
-    // (it, h) of an item advance as counters: item / H and item % H by a runtime H were ~50 scalar instructions per item
-    auto issue = [&](int it, int h, int stage) {              // 4 DMA wave-instructions per wave per item
-        const unsigned st = ring_lds + (unsigned)(stage * A3_STAGE);
+    // (it, h) of an item advance as counters, and so do the per-lane source offsets of its four DMA pieces: byte offsets from the tensor
+    // bases (32 bits: the launch checks the extents), bumped by a constant per head and rebuilt once per query tile -- item / H, item % H
+    // and the 64-bit address products were ~130 scalar + ~25 vector instructions per item (SQ_INSTS_SALU 2.1e7 in the counters).
+    unsigned qoff = 0, boff = 0;                              // Q / dO piece; bias window piece (lanes 0-15) | table tail (the others)
+    const float* ldp = lse;                                   // lse (lanes 0-31) | delta (lanes 32-63) element of the item
+    const unsigned bstep = (unsigned)ldT * 4u;
+    auto tile_offsets = [&](int it) {                         // head 0 of query tile `it`
         const int qi = min(32 * it + rowu, N - 1);            // rows past N: clamped (their scores are masked below)
-        const size_t src = ((rowbase + qi) * (size_t)H + h) * 64 + colu;
-        a3_dma16(q + src, st + wave * 1024);
-        a3_dma16(dout + src, st + 4096 + wave * 1024);
-        const unsigned ax = st + 8192 + wave * A3_AUX;
-        {   // lanes 0-15: the item's bias window for this wave's keys, table index A3_PAD + rel - 1 from rel = 32 (it - jtw) - 31
-            // (one entry early: 16-byte aligned); lane 16: the row's tail [.., flag, m_h]; the other lanes repeat lane 16's address
-            const int w0 = max(A3_PAD + 32 * (it - jtw) - 32, 0);
-            const float* row = has_bias ? biasT + (size_t)h * ldT : lse;
-            const float* p = has_bias ? (lane < 16 ? row + w0 + 4 * lane : row + (ldT - 4)) : lse;
-            a3_dma16(p, ax);
-        }
-        {   // lanes 0-31: lse of the item's queries, lanes 32-63: their delta
-            const size_t e = ((size_t)b * H + h) * N + min(32 * it + (lane & 31), N - 1);
-            a3_dma4(hi ? delta + e : lse + e, ax + 1024);
-        }
+        qoff = (unsigned)((((int)rowbase + qi) * H) * 64 + colu) * 2u;
+        // lanes 0-15: the bias window for this wave's keys, table index A3_PAD + rel - 1 from rel = 32 (it - jtw) - 31 (one entry early:
+        // 16-byte aligned); lane 16: the row's tail [.., flag, m_h]; the other lanes repeat lane 16's address
+        const int w0 = max(A3_PAD + 32 * (it - jtw) - 32, 0);
+        boff = has_bias ? (unsigned)(lane < 16 ? w0 + 4 * lane : ldT - 4) * 4u : 0u;
+        ldp = (hi ? delta : lse) + ((size_t)b * H * N + min(32 * it + (lane & 31), N - 1));
+    };
+    auto issue = [&](int stage) {                             // 4 DMA wave-instructions per wave per item, then on to the next head
+        const unsigned st = ring_lds + (unsigned)(stage * A3_STAGE);
+        a3_dma16s(q, qoff, st + wave * 1024 + (wave >> 1) * 128);
+        a3_dma16s(dout, qoff, st + A3_IMG + wave * 1024 + (wave >> 1) * 128);
+        const unsigned ax = st + 2 * A3_IMG + wave * A3_AUX;
+        a3_dma16s(has_bias ? (const void*)biasT : (const void*)lse, boff, ax);
+        a3_dma4(ldp, ax + 1024);
+        qoff += 128u; boff += has_bias ? bstep : 0u; ldp += N;
     };
 
     f32x16 dkacc[2], dvacc[2];
@@ -144,9 +159,10 @@ void attn3_bwd_dkv_kernel(const h16_t* __restrict__ q, const h16_t* __restrict__
     for (int e = 0; e < 16; ++e) { dkacc[0][e] = 0.f; dkacc[1][e] = 0.f; dvacc[0][e] = 0.f; dvacc[1][e] = 0.f; }
 
     int it_i = it0, h_i = 0, st_i = 0;                        // the next item to be issued
+    tile_offsets(it0);
     auto issue_next = [&]() {
-        issue(it_i, h_i, st_i);
-        if (++h_i == H) { h_i = 0; ++it_i; }
+        issue(st_i);
+        if (++h_i == H) { h_i = 0; ++it_i; tile_offsets(it_i); }
         if (++st_i == A3_NST) st_i = 0;
     };
     if (nitems > 0) issue_next();
@@ -162,8 +178,8 @@ void attn3_bwd_dkv_kernel(const h16_t* __restrict__ q, const h16_t* __restrict__
         const int i0 = 32 * it;
         if (i0 + 31 < j0w) continue;                          // every query of the tile precedes every key of this wave (causal): nothing to do
         const char* Qs = smem3 + stage * A3_STAGE;
-        const char* dOs = Qs + 4096;
-        const float* axa = (const float*)(Qs + 8192 + wave * A3_AUX);
+        const char* dOs = Qs + A3_IMG;
+        const float* axa = (const float*)(Qs + 2 * A3_IMG + wave * A3_AUX);
         const float* axb = axa + 256;                         // lse[32] | delta[32]
         const float mh = has_bias ? axa[64 + 3] : 0.f;        // the head's reference point (table tail), 0 without a fixed one
         // window index of (query row crow(r, hi), this lane's key): rel - (32 (it - jtw) - 31) + 1 = cr + 4 hi - (lane & 31) + 32
@@ -273,7 +289,7 @@ int attn3_bwd_dkv_launch(const void* q, const void* k, const void* v, const floa
                          int B, int N, int H, float scale, hipStream_t st) {
     static int off = -1;
     if (off < 0) { const char* e = getenv("OMLM_ATTN_DKV3"); off = (e && e[0] == '0') ? 1 : 0; }
-    if (off || N < 32) return 1;
+    if (off || N < 32 || (long long)B * N * H * 128 >= (1ll << 32)) return 1;      // (32-bit byte offsets into q / dout)
     const int ldT = ((A3_PAD + N + 2 * 128 + 3) / 4) * 4;    // layout of omlm_attn_bias_prepare (attention2.hip)
     const int CH = a3_chunk(B, N);
     const int nqt = (N + 31) / 32, nr = (N + A3_KR - 1) / A3_KR;
