@@ -170,7 +170,10 @@ class PreparedWeights:
         dev = model.start_tokens[0].device
         D = tr.dim
         self.layers = []
-        for attn, _, ff in tr.layers:
+        # padded operand images are persistent per (layer, operand type): their pad rows / columns are zeroed once, a step only rewrites the
+        # real entries (was: an 11 MB zero fill + ~10 small torch launches per layer per step)
+        wbuf = model.__dict__.setdefault("_omlm_wbuf", {})
+        for li, (attn, _, ff) in enumerate(tr.layers):
             F = ff.inner_dim
             Fp = ceil_to(F, 64)      # 128-byte aligned bf16 rows for h1 / dh1 (2*Fp pitch) and whole k-tiles for FF-out
             w1 = ff.w_in.weight            # [2F, D]
@@ -181,10 +184,13 @@ class PreparedWeights:
             else:
                 for name, w in (("Wq", attn.to_q.weight), ("Wkv", attn.to_kv.weight), ("Wo", attn.to_out[0].weight)):
                     ent[name] = h16_operand(w, T)
-            W1p = torch.zeros(2 * Fp, D, dtype=T, device=dev)
+            bkey = (li, T, str(dev), F, D)
+            if bkey not in wbuf:
+                wbuf[bkey] = (torch.zeros(2 * Fp, D, dtype=T, device=dev), torch.zeros(D, Fp, dtype=T, device=dev),
+                              torch.zeros(3, 2 * Fp, dtype=T, device=dev), torch.zeros(Fp, dtype=T, device=dev))
+            W1p, W2p, convp, gammap = wbuf[bkey]
             ops.cast_pad(w1, W1p, F, D, D, D)
             ops.cast_pad(w1[F:], W1p[Fp:], F, D, D, D)
-            W2p = torch.empty(D, Fp, dtype=T, device=dev)
             ops.cast_pad(w2, W2p, D, F, F, Fp)
             ent["W1p"], ent["W2p"], ent["F"], ent["Fp"] = W1p, W2p, F, Fp
             if T in _H16 and with_transposes:
@@ -204,8 +210,11 @@ class PreparedWeights:
                 ent["W2pT"] = wt(w2, D, F, rows_pad=Fp, cols_pad=D)           # [Fp, D], rows >= F zero
             # taps [3, 2Fp] (identity taps for plain FeedForward) and the padded LN gamma travel in the operand dtype: they are
             # re-read for every row, and as fp32 they were 70 % of the L2->L1 bytes of the conv-GEGLU-LN kernels
-            ent["convw"] = ops.pack_conv_taps(ff.conv_weight().detach(), F, Fp).to(T)
-            ent["gamma_mid"] = ops.pad_vector(ff.norm_mid.gamma.detach(), Fp).to(T)
+            cw = ff.conv_weight().detach().reshape(2 * F, 3)                 # reference ds_conv.weight [2F, 1, 3] -> tap-major [3, 2Fp]
+            ops.transpose_cast(cw, convp, F, 3, 3, 2 * Fp)
+            ops.transpose_cast(cw[F:], convp[:, Fp:], F, 3, 3, 2 * Fp)
+            ops.cast_pad(ff.norm_mid.gamma.detach(), gammap, 1, F, F, Fp)
+            ent["convw"], ent["gamma_mid"] = convp, gammap
             cache = ff.__dict__.setdefault("_omlm_cmap", {})
             if (F, Fp, str(dev)) not in cache:            # static scatter map: uploaded once (no H2D inside graph capture)
                 cm = torch.full((2 * Fp,), -1, dtype=torch.int32)
@@ -421,7 +430,7 @@ def trunk_forward(tr, pw: PreparedWeights, x: torch.Tensor, keymask: Optional[to
     return y, saved
 
 
-def trunk_backward(tr, pw: PreparedWeights, saved, dy: torch.Tensor, B: int, N: int, out_scale: float):
+def trunk_backward(tr, pw: PreparedWeights, saved, dy: torch.Tensor, B: int, N: int, out_scale: float, head_wgrads=None):
     """dy: [M, D] fp32 gradient of the final LayerNorm output.  Accumulates parameter grads; returns
     d(trunk input) * out_scale (fp32).  out_scale carries the grad_shrink factor (utils.py:60-61)."""
     T = pw.T
@@ -442,6 +451,11 @@ def trunk_backward(tr, pw: PreparedWeights, saved, dy: torch.Tensor, B: int, N: 
     # weight gradients have no consumer before the optimizer: in bf16 mode they are collected and issued as grouped launches of
     # full-K tiles (ops.WgradGroup) instead of 5 split-K GEMMs per layer; their operands stay alive until the flush
     wg = ops.WgradGroup() if (T in _H16 and _WGRAD_GROUP) else None
+    for dYh, Xh, dWh, Mo, No in (head_wgrads or []):             # the logit heads' weight gradients (heads_backward) ride in the same launch
+        if wg is not None:
+            wg.add(dYh, Xh, dWh, M=Mo, N=No, K=dYh.shape[0])
+        else:
+            ops.gemm(dYh, Xh, dWh, M=Mo, N=No, K=dYh.shape[0], a_kmajor=True, b_kmajor=True, Cin=dWh)
 
     def wgrad(dY, X, dW, Mo, No, c_map=None):
         if wg is not None:
@@ -600,8 +614,12 @@ def heads_forward(model, pw: PreparedWeights, y: torch.Tensor, lay: SeqLayout, w
     return out
 
 
-def heads_backward(model, pw: PreparedWeights, y: torch.Tensor, lay: SeqLayout, dlogits: Sequence[Optional[torch.Tensor]]):
-    """dlogits[s]: [B*n_s, ldV] in the operand dtype with zeroed pad columns, or None.  Returns dy fp32 [B*N, D]."""
+def heads_backward(model, pw: PreparedWeights, y: torch.Tensor, lay: SeqLayout, dlogits: Sequence[Optional[torch.Tensor]],
+                   deferred: Optional[list] = None):
+    """dlogits[s]: [B*n_s, ldV] in the operand dtype with zeroed pad columns, or None.  Returns dy fp32 [B*N, D].
+    deferred (16-bit operands): the heads' weight gradients are not launched here but appended as (dY, X, dW, M, N) for the trunk's
+    grouped launch -- as their own row-mapped split-K GEMMs they ran at 158 TFLOP/s (3 x 128 us per step); gathered into contiguous
+    rows they are 60 more full-K tiles of the ~900-tile group."""
     D = model.dim
     dy = torch.zeros(y.shape[0], D, device=y.device)
     for s, seq in enumerate(model.token_sequences):
@@ -623,6 +641,9 @@ def heads_backward(model, pw: PreparedWeights, y: torch.Tensor, lay: SeqLayout, 
                 ops.gemm(dl, pw.heads[s][qq], dy, M=rows, N=D, K=ldV, b_kmajor=True, a_map=c_map, c_map=a_map,
                          a_rows=dl.shape[0], b_rows=V1)
             # dW_q += dlogits[rows]^T @ y[rows]
+            if deferred is not None and rows >= 1024:
+                deferred.append((dl.index_select(0, c_map), y.index_select(0, a_map), gW[qq], V1, D))
+                continue
             ops.gemm(dl, y, gW[qq], M=V1, N=D, K=rows, a_kmajor=True, b_kmajor=True, a_map=c_map, b_map=a_map,
                      Cin=gW[qq], lda=ldV, a_rows=dl.shape[0], b_rows=y.shape[0])
     return dy
@@ -670,9 +691,10 @@ def run_forward(model, all_token_ids, self_attn_mask, only_final: bool, save: bo
 
 def run_backward(st: ForwardState, dlogits: Sequence[Optional[torch.Tensor]]):
     model = st.model
-    dy = heads_backward(model, st.pw, st.y, st.lay, dlogits)
+    deferred = [] if (st.pw.T in _H16 and _WGRAD_GROUP) else None
+    dy = heads_backward(model, st.pw, st.y, st.lay, dlogits, deferred)
     alpha = float(model.transformer.grad_shrink_alpha)
-    dx = trunk_backward(model.transformer, st.pw, st.trunk, dy, st.B, st.N, out_scale=alpha)
+    dx = trunk_backward(model.transformer, st.pw, st.trunk, dy, st.B, st.N, out_scale=alpha, head_wgrads=deferred)
     embed_backward(model, st.ids32, st.lay, dx, 1.0)
     ops.planes_end()
 
