@@ -217,7 +217,9 @@ def cpu_baseline(progress_fn):
     return {"value": round(1 / med, 4), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
             "host_cpu_count": os.cpu_count(),
             "sample": "1 warm-up + median of 3 micro-steps (fwd + bwd + clip + AdamW) of B=1, N=1116, fp32, torch CPU kernels; "
-                      f"times {[round(t, 2) for t in times]} s"}
+                      f"times {[round(t, 2) for t in times]} s; threads = torch's default (one per physical core: 128 of the box's 256 "
+                      "hardware threads; the SMT siblings do not speed up its GEMM kernels); kind 'port' because /root/reference does not "
+                      "exist on the GPU box (the port is pinned to the reference by tests/golden); B = 1 keeps the leg at ~30 s"}
 
 
 def decode_leg(stage, dev, decode_ids):
@@ -385,6 +387,8 @@ def main():
         out["roofline"] = main_leg.gemm_roofline(args.warmup + args.steps, traffic)
         if detail:
             out["roofline"]["traffic_detail"] = detail
+            out["roofline"]["traffic_source"] = ("committed PMC passes (profiles/gemm_traffic.json, tools/pmc_gemm_traffic.sh over this bench.py's train step; "
+                                                 "counters cannot be read inside the timed process), build: " + str(detail.get("build", "see profiles/")))
         progress(f"roofline probe: {out['roofline']['launches']} GEMM launches, {out['roofline']['gemm_ms_per_step']} ms per step")
         if not args.no_decode:
             out["ar_tokens_per_sec"] = decode_leg(main_leg.stage, dev, args.decode_ids)
