@@ -199,6 +199,29 @@ static void gemm_case(Lib& A, Lib& Bl) {
 }
 
 
+// Calibration against the guide's reference ladder (cdna_hip_programming.md "Reference targets": square bf16 GEMMs on uniform random
+// operands, NT layout, bf16 output): 4096^3 and 8192^3.
+static void gemm_square_case(Lib& A, Lib& Bl) {
+    Lib* libs[2] = {&A, &Bl};
+    for (int n : {4096, 8192}) {
+        std::vector<uint16_t> X((size_t)n * n), W((size_t)n * n);
+        fast_fill(X, 1.f, 11); fast_fill(W, 1.f, 12);
+        uint16_t *dX_ = dev(X), *dW_ = dev(W);
+        printf("== GEMM %d^3 (bf16 operands, NT, bf16 out)\n", n);
+        for (int li = 0; li < 2; ++li) {
+            Lib& L = *libs[li];
+            apply_env(li ? g_env_b : g_env_a);
+            uint16_t* out = dev_zero<uint16_t>((size_t)n * n);
+            auto nt = [&] { L.ok(L.gemm(dX_, dW_, out, nullptr, nullptr, nullptr, nullptr, n, n, n, n, n, n, n, n, 0, 0, 0, 1, 1, 1.f, nullptr), "gemm NT"); };
+            nt(); CK(hipDeviceSynchronize());
+            const float us = time_us(nt, 20);
+            printf("  %c %-40s %8.1f us  %6.0f TFLOP/s\n", li ? 'B' : 'A', L.path.c_str(), us, 2.0 * n * (double)n * n / us / 1e6);
+            CK(hipFree(out));
+        }
+        CK(hipFree(dX_)); CK(hipFree(dW_));
+    }
+}
+
 // Odd shapes through every layout / output type: B's results must equal A's bit for bit (no split-K here: K is small enough
 // that the host picks one slice, so there are no atomics).
 static void gemm_edge_case(Lib& A, Lib& Bl) {
@@ -447,6 +470,7 @@ int main(int argc, char** argv) {
             else if (!strcmp(argv[i], "attn32")) attn_case(*libs[0], *libs[v], 32, 1116, 8, 0);
             else if (!strcmp(argv[i], "gemm")) gemm_case(*libs[0], *libs[v]);
             else if (!strcmp(argv[i], "gemm_edge")) gemm_edge_case(*libs[0], *libs[v]);
+            else if (!strcmp(argv[i], "gemm_sq")) gemm_square_case(*libs[0], *libs[v]);
             else if (!strcmp(argv[i], "wgrad")) wgrad_case(*libs[0], *libs[v]);
             else if (!strcmp(argv[i], "ffmid")) ffmid_case(*libs[0], *libs[v]);
             else if (!strcmp(argv[i], "ln")) ln_case(*libs[0], *libs[v]);
