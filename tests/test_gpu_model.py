@@ -152,7 +152,7 @@ def test_loss_only_step_skips_zero_weight_heads(golden_dir, dev, monkeypatch):
         loss, logits, _ = wrapper(all_token_ids=ids, return_loss=True, return_logits=full)
         loss.backward()
         out.append((float(loss.detach()), logits, {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
-    assert out[0][0] == out[1][0]
+    assert abs(out[0][0] - out[1][0]) <= 2e-6 * abs(out[0][0])      # the row losses meet in one fp32 atomic sum: order-free to an ulp
     assert out[1][1][0] is None and out[1][1][1] is None and torch.equal(out[0][1][2], out[1][1][2])
     assert all(v is not None for v in out[0][1])
     # weight gradients meet in fp32 atomics (grouped split-K launches): equal to summation-order noise (tensors that are analytically
