@@ -32,8 +32,8 @@ REPORT = os.path.join(ROOT, "gpurun_out", "model_report.json")
 #   bf16    logits <= 7.7e-3 at depth 6 (1.6e-2 at depth 24: its own bar below), loss <= 4.3e-4, gradients <= 7.2e-2
 #   fp16    logits <= 8.9e-4 at depth 6 (2.0e-3 at depth 24), loss <= 4.3e-5, gradients <= 7.2e-3
 # `invariant`: the analytically-zero gradient directions of the rel-pos bias (see the train test), in the same units.
-TOL = {"bf16x3": dict(logits=1e-3, loss=4e-5, grad=1.5e-2, invariant=1e-2), "bf16": dict(logits=1.2e-2, loss=1e-3, grad=1.5e-1, invariant=1.0),
-       "fp16": dict(logits=1e-3, loss=1e-4, grad=1.5e-2, invariant=0.25)}
+TOL = {"bf16x3": dict(logits=1e-3, loss=4e-5, grad=1.5e-2, invariant=1e-2), "bf16": dict(logits=1.2e-2, loss=1e-3, grad=1.5e-1, invariant=1.5),
+       "fp16": dict(logits=1e-3, loss=1e-4, grad=1.5e-2, invariant=0.3)}       # invariant: pure rounding noise, 3x its measured size
 
 
 def grad_unscale(precision):
