@@ -236,7 +236,12 @@ typedef struct omlm_decode_args {
     float* x; float* x1; float* q; float* parts; float* u; float* logits;   /* scratch: parts [B, nsplit, H, 66] */
     int* advance_pos; int* advance_step;   /* optional DEVICE counters (+= 1) bumped by the step's last kernel: pass pos_dev (and the
                                             * sampler's step counter) here instead of launching omlm_decode_advance */
+    float* ln_parts;                       /* optional scratch, 3 * OMLM_DECODE_LN_PARTS(D, Fp) floats: the batched matrix-core kernels
+                                            * (2 <= B <= 8) leave per-workgroup partial sums of their outputs there, and the kernel that
+                                            * applies the next LayerNorm adds them up instead of re-reducing every sample's row; null:
+                                            * every consumer reduces the rows itself */
 } omlm_decode_args;
+#define OMLM_DECODE_LN_PARTS(D, Fp) ((((D) + 15) / 16 > ((Fp) + 7) / 8 ? ((D) + 15) / 16 : ((Fp) + 7) / 8) * 16)
 int omlm_decode_step(const omlm_decode_args* args, const long long* ids, void* stream);
 /* *pos_dev += 1, *step_dev += 1 (either may be null): keeps the row / sampler-step counters on the device so that a
  * captured step can be replayed. */

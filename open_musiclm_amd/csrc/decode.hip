@@ -51,6 +51,7 @@ struct omlm_decode_args {
     const float* emb_table; long long emb_row_offset; long long emb_rows;
     float* x; float* x1; float* q; float* parts; float* u; float* logits;
     int* advance_pos; int* advance_step;
+    float* ln_parts;
 };
 
 __device__ __forceinline__ float round_if(float v, int on) { return on ? (float)(h16_t)v : v; }
@@ -153,12 +154,25 @@ __device__ void stage_attention(const float* __restrict__ parts, int nsplit, int
 }
 
 // ---- embedding gather of the ids sampled in the previous step (open_musiclm.py:123-134: id + quantizer offset) ----
+// stat_out (optional): the row's (sum, sum of squares) as LayerNorm partial 0 of sample b (layout [partial][8 samples][2], see dec4_kernel)
 __global__ __launch_bounds__(DEC_T) void dec_embed_kernel(const long long* __restrict__ ids, const float* __restrict__ table,
-                                                         long long row_off, long long rows, float* __restrict__ x, int D) {
+                                                         long long row_off, long long rows, float* __restrict__ x, int D,
+                                                         float* __restrict__ stat_out) {
+    __shared__ float red[2 * (DEC_T / 64)];
     const int b = blockIdx.x;
     long long r = ids[b] + row_off;
     r = r < 0 ? 0 : (r >= rows ? rows - 1 : r);
-    for (int i = threadIdx.x; i < D; i += DEC_T) x[(size_t)b * D + i] = table[r * D + i];
+    float s = 0.f, q = 0.f;
+    for (int i = threadIdx.x; i < D; i += DEC_T) { const float v = table[r * D + i]; x[(size_t)b * D + i] = v; s += v; q += v * v; }
+    if (!stat_out) return;
+    s = wave_sum(s); q = wave_sum(q);
+    if ((threadIdx.x & 63) == 0) { red[2 * (threadIdx.x >> 6)] = s; red[2 * (threadIdx.x >> 6) + 1] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float ts = 0.f, tq = 0.f;
+        for (int w = 0; w < DEC_T / 64; ++w) { ts += red[2 * w]; tq += red[2 * w + 1]; }
+        stat_out[b * 2] = ts; stat_out[b * 2 + 1] = tq;
+    }
 }
 
 // ---- A: raw projections of the new row: q_raw = LN(x) Wq^T -> q;  [k_raw | v] = x Wkv^T -> cache row pos ----
@@ -500,6 +514,9 @@ struct dec2_args {
     const float* convw; float* hist; float* u; int Fp;                            // DEC2_FFIN
     int B, round_bf16;
     int* adv_pos; int* adv_step;                                                  // head launch only: counters bumped by its workgroup 0
+    // matrix-core kernels: LayerNorm statistics from the producers' per-workgroup partial sums [partial][8 samples][2] instead of a
+    // reduction over every sample's row in every workgroup (stat_in, nstat_in partials); this launch's own partials (stat_out)
+    const float* stat_in; int nstat_in; float* stat_out;
 };
 
 template <typename TW, int NI, int MODE>
@@ -885,7 +902,65 @@ __global__ __launch_bounds__(DEC4_T) void dec4_kernel(dec2_args a) {
     // together (a per-sample loop of load -> reduce was 2 B dependent L2 round trips per launch: 12-20 us at B = 8) ----
     {
         constexpr int NBR = 8;                                  // samples per register batch
-        if (ln_rows) {
+        if (ln_rows && a.stat_in) {
+            // statistics from the producers' partial sums: every load of this launch (weights above, gamma, all samples' pieces of the
+            // row, the partials) is in flight together; the partials meet through LDS and every thread normalises its pieces straight from
+            // registers -- no reduction over the rows, no fp32 staging copy
+            constexpr int NCH = (NS + 7) / 8;
+            float4 v[NCH][NBR], gq[NCH];
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int i = threadIdx.x * 4 + ch * DEC4_T * 4;
+                const bool in = i < K;
+                gq[ch] = in ? *(const float4*)(a.gamma + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int b = 0; b < NBR; ++b)
+                    v[ch][b] = (in && b < B) ? *(const float4*)(a.in + (size_t)b * a.ldin + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            {   // lane = sample + 8 * slice, 32 slices per workgroup: all of a thread's partials requested at once (a rolled loop here
+                // was one L2 round trip per iteration: 43 of them for the FF-out launch)
+                constexpr int NPI = 11;                                  // <= 352 partials
+                const int b = lane & 7, sl = wave * 8 + (lane >> 3);
+                float2 pv[NPI];
+#pragma unroll
+                for (int it = 0; it < NPI; ++it) {
+                    const int pi = sl + 32 * it;
+                    pv[it] = pi < a.nstat_in ? *(const float2*)(a.stat_in + (pi * 8 + b) * 2) : make_float2(0.f, 0.f);
+                }
+                float ps = 0.f, pq = 0.f;
+#pragma unroll
+                for (int it = 0; it < NPI; ++it) { ps += pv[it].x; pq += pv[it].y; }
+#pragma unroll
+                for (int m = 8; m < 64; m <<= 1) { ps += __shfl_xor(ps, m, 64); pq += __shfl_xor(pq, m, 64); }
+                if (lane < 8) { red[(lane * 4 + wave) * 2] = ps; red[(lane * 4 + wave) * 2 + 1] = pq; }
+            }
+            __syncthreads();
+            if (threadIdx.x < 8) {
+                const int b = threadIdx.x;
+                float ps = 0.f, pq = 0.f;
+                for (int w = 0; w < 4; ++w) { ps += red[(b * 4 + w) * 2]; pq += red[(b * 4 + w) * 2 + 1]; }
+                const float mean = ps / (float)a.Kstat;
+                stat[2 * b] = mean; stat[2 * b + 1] = rsqrtf(fmaxf(pq / (float)a.Kstat - mean * mean, 0.f) + a.eps);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int i = threadIdx.x * 4 + ch * DEC4_T * 4;
+                if (i >= K) break;
+                const float4 g = gq[ch];
+#pragma unroll
+                for (int b = 0; b < NBR; ++b) {
+                    if (b < B) {
+                        const float mean = stat[2 * b], rstd = stat[2 * b + 1];
+                        const float4 x = v[ch][b];
+                        u32x2 o;
+                        o[0] = pack_h16_rne((x.x - mean) * rstd * g.x, (x.y - mean) * rstd * g.y);
+                        o[1] = pack_h16_rne((x.z - mean) * rstd * g.z, (x.w - mean) * rstd * g.w);
+                        *(u32x2*)(xs + (size_t)b * KP + i) = o;
+                    }
+                }
+            }
+        } else if (ln_rows) {
             float s8[NBR], q8[NBR];
 #pragma unroll
             for (int b = 0; b < NBR; ++b) { s8[b] = 0.f; q8[b] = 0.f; }
@@ -986,9 +1061,20 @@ __global__ __launch_bounds__(DEC4_T) void dec4_kernel(dec2_args a) {
             float* h1 = h0 + ld;                                 // row p-1
             const float uv = a.convw[col] * h0[col] + a.convw[ld + col] * h1[col] + a.convw[2 * (size_t)ld + col] * hv;
             const float ug = a.convw[a.Fp + col] * h0[a.Fp + col] + a.convw[ld + a.Fp + col] * h1[a.Fp + col] + a.convw[2 * (size_t)ld + a.Fp + col] * hg;
-            a.u[(size_t)b * a.Fp + col] = dec_gelu(ug) * uv;
+            const float uo = dec_gelu(ug) * uv;
+            a.u[(size_t)b * a.Fp + col] = uo;
             h0[col] = h1[col];       h0[a.Fp + col] = h1[a.Fp + col];
             h1[col] = hv;            h1[a.Fp + col] = hg;
+            part[idx] = uo;                                      // `part` is free again (its sums are in `vals`): read back below for the partial sums
+        }
+        if (a.stat_out) {                                       // this workgroup's 8 channels of every sample: LayerNorm partial of u
+            __syncthreads();
+            if (threadIdx.x < B) {
+                float ps = 0.f, pq = 0.f;
+                for (int cc = 0; cc < 8; ++cc)
+                    if (blockIdx.x * 8 + cc < a.Fp) { const float t = part[threadIdx.x * 8 + cc]; ps += t; pq += t * t; }
+                a.stat_out[(blockIdx.x * 8 + threadIdx.x) * 2] = ps; a.stat_out[(blockIdx.x * 8 + threadIdx.x) * 2 + 1] = pq;
+            }
         }
     } else if (MODE == DEC2_QKV) {
         const int pos = *a.pos_dev;
@@ -1002,10 +1088,20 @@ __global__ __launch_bounds__(DEC4_T) void dec4_kernel(dec2_args a) {
     } else {
         for (int idx = threadIdx.x; idx < B * DEC4_ROWS; idx += DEC4_T) {
             const int b = idx / DEC4_ROWS, rr = idx - b * DEC4_ROWS, n = blockIdx.x * DEC4_ROWS + rr;
+            float v = 0.f;
             if (n < a.Nout) {
-                float v = vals[rr * 16 + b];
+                v = vals[rr * 16 + b];
                 if (a.res) v += a.res[(size_t)b * a.ldres + n];
                 a.out[(size_t)b * a.ldout + n] = v;
+            }
+            if (a.stat_out) part[idx] = v;                      // (b, row) order; `part` is free again: its sums are in `vals`
+        }
+        if (a.stat_out) {                                       // this workgroup's 16 output rows of every sample: LayerNorm partial
+            __syncthreads();
+            if (threadIdx.x < B) {
+                float ps = 0.f, pq = 0.f;
+                for (int rr = 0; rr < DEC4_ROWS; ++rr) { const float t = part[threadIdx.x * DEC4_ROWS + rr]; ps += t; pq += t * t; }
+                a.stat_out[(blockIdx.x * 8 + threadIdx.x) * 2] = ps; a.stat_out[(blockIdx.x * 8 + threadIdx.x) * 2 + 1] = pq;
             }
         }
         if (MODE == DEC2_LNGEMV && blockIdx.x == 0 && threadIdx.x == 0 && a.adv_pos) {      // see dec3_kernel
@@ -1041,8 +1137,17 @@ static int decode_step2_t(const omlm_decode_args& a, const long long* ids, hipSt
     const int B = a.B, D = a.D, H = a.H, Fp = a.Fp, HD = H * 64;
     const size_t lds_at2 = (size_t)(64 * 65 + 64 * 64 + H * 64 + 8 * 64) * sizeof(float);
     const bool mfma = sizeof(TW) == 2 && dec4_ok(a);              // 16-bit weights, B >= 2: the matrix-core step kernels
-    if (a.emb_table)
-        hipLaunchKernelGGL(dec_embed_kernel, dim3(B), dim3(DEC_T), 0, st, ids, a.emb_table, a.emb_row_offset, a.emb_rows, a.x, D);
+    // LayerNorm partial sums of the matrix-core kernels (see dec2_args::stat_in): three regions of a.ln_parts -- x (written by the embedding
+    // gather and by every FF-out launch, read by the q rows and the head), x1 (to_out -> FF-in), u (FF-in -> FF-out)
+    const int npd = (D + DEC4_ROWS - 1) / DEC4_ROWS, npf = (Fp + 7) / 8, region = (npd > npf ? npd : npf) * 16;
+    float* st_x = (mfma && a.ln_parts) ? a.ln_parts : nullptr;
+    float* st_x1 = st_x ? st_x + region : nullptr;
+    float* st_u = st_x ? st_x + 2 * region : nullptr;
+    int n_x = 0;                                                  // partials of x that are valid right now
+    if (a.emb_table) {
+        hipLaunchKernelGGL(dec_embed_kernel, dim3(B), dim3(DEC_T), 0, st, ids, a.emb_table, a.emb_row_offset, a.emb_rows, a.x, D, st_x);
+        n_x = 1;
+    }
     dec2_args g;
     memset(&g, 0, sizeof(g));
     g.B = B; g.round_bf16 = a.round_bf16; g.eps = a.eps; g.H = H; g.nsplit = a.nsplit; g.pos_dev = a.pos_dev; g.Nmax = a.Nmax; g.Fp = Fp;
@@ -1050,6 +1155,7 @@ static int decode_step2_t(const omlm_decode_args& a, const long long* ids, hipSt
         dec2_args q = g;                                                               // q / k / v rows of the new token
         q.in = a.x; q.ldin = D; q.K = D; q.Kstat = D; q.gamma = a.attn_gamma[l]; q.W = a.Wq[l]; q.W2 = a.Wkv[l]; q.ldw = D;
         q.Nout = HD + 128; q.q = a.q; q.Kc = a.Kc[l]; q.Vc = a.Vc[l];
+        if (st_x && n_x > 0) { q.stat_in = st_x; q.nstat_in = n_x; }
         if (B == 1) dec3_launch<TW, 2, DEC2_QKV>(q, HD + 128, st);
         else if (mfma) dec4_launch<8, DEC2_QKV>(q, (HD + 128) / DEC4_ROWS, st);
         else        dec2_launch<TW, 2, DEC2_QKV>(q, (HD + 128) / DEC2_ROWS, st);
@@ -1060,12 +1166,14 @@ static int decode_step2_t(const omlm_decode_args& a, const long long* ids, hipSt
         if (mfma) {                                                                    // combine once, then a plain (no LayerNorm) row product
             hipLaunchKernelGGL(dec_attn_combine_kernel, dim3(H, B), dim3(64), 0, st, a.parts, a.q, a.nsplit, H, a.pos_dev, a.round_bf16);
             o.in = a.q; o.ldin = HD; o.Kstat = HD; o.gamma = nullptr; o.parts = nullptr;     // a.q is free again: the attention kernel consumed it
+            o.stat_out = st_x1;
             dec4_launch<8, DEC2_LNGEMV>(o, (D + DEC4_ROWS - 1) / DEC4_ROWS, st);
         } else if (HD <= 512) dec2_launch<TW, 1, DEC2_OUT>(o, (D + DEC2_ROWS - 1) / DEC2_ROWS, st);
         else                dec2_launch<TW, 2, DEC2_OUT>(o, (D + DEC2_ROWS - 1) / DEC2_ROWS, st);
         dec2_args f = g;                                                               // FF-in rows + conv + GEGLU
         f.in = a.x1; f.ldin = D; f.K = D; f.Kstat = D; f.gamma = a.ffin_gamma[l]; f.W = a.W1p[l]; f.ldw = D; f.convw = a.convw[l];
         f.hist = a.hist[l]; f.u = a.u;
+        if (st_x1) { f.stat_in = st_x1; f.nstat_in = npd; f.stat_out = st_u; }
         if (B == 1) {
             static int cpw = -1;
             if (cpw < 0) { const char* e = getenv("OMLM_DECODE_CPW"); cpw = e ? atoi(e) : 4; }
@@ -1077,6 +1185,7 @@ static int decode_step2_t(const omlm_decode_args& a, const long long* ids, hipSt
         dec2_args w = g;                                                               // x = x1 + LN(u) W2^T
         w.in = a.u; w.ldin = Fp; w.K = Fp; w.Kstat = a.F; w.gamma = a.mid_gamma[l]; w.W = a.W2p[l]; w.ldw = Fp; w.Nout = D;
         w.res = a.x1; w.ldres = D; w.out = a.x; w.ldout = D;
+        if (st_u) { w.stat_in = st_u; w.nstat_in = npf; w.stat_out = st_x; n_x = npd; }
         if (B == 1 && Fp <= 3072) dec3_launch<TW, 6, DEC2_LNGEMV>(w, D, st);
         else if (mfma) dec4_launch<24, DEC2_LNGEMV>(w, (D + DEC4_ROWS - 1) / DEC4_ROWS, st);
         else if (Fp <= 3072) dec2_launch<TW, 6, DEC2_LNGEMV>(w, (D + DEC2_ROWS - 1) / DEC2_ROWS, st);
@@ -1087,6 +1196,7 @@ static int decode_step2_t(const omlm_decode_args& a, const long long* ids, hipSt
         h.in = a.x; h.ldin = D; h.K = D; h.Kstat = D; h.gamma = a.final_gamma; h.W = a.head_W; h.ldw = D; h.Nout = a.V1;
         h.out = a.logits; h.ldout = a.ldV;
         h.adv_pos = a.advance_pos; h.adv_step = a.advance_step;
+        if (st_x && n_x > 0) { h.stat_in = st_x; h.nstat_in = n_x; }
         if (B == 1) dec3_launch<TW, 2, DEC2_LNGEMV>(h, a.V1, st);
         else if (mfma) dec4_launch<8, DEC2_LNGEMV>(h, (a.V1 + DEC4_ROWS - 1) / DEC4_ROWS, st);
         else        dec2_launch<TW, 2, DEC2_LNGEMV>(h, (a.V1 + DEC2_ROWS - 1) / DEC2_ROWS, st);
@@ -1125,7 +1235,7 @@ static int decode_step_t(const omlm_decode_args& a, const long long* ids, hipStr
     }
     const int HD = H * 64;
     if (a.emb_table)
-        hipLaunchKernelGGL(dec_embed_kernel, dim3(B), dim3(DEC_T), 0, st, ids, a.emb_table, a.emb_row_offset, a.emb_rows, a.x, D);
+        hipLaunchKernelGGL(dec_embed_kernel, dim3(B), dim3(DEC_T), 0, st, ids, a.emb_table, a.emb_row_offset, a.emb_rows, a.x, D, (float*)nullptr);
     for (int l = 0; l < a.L; ++l) {
         hipLaunchKernelGGL((dec_qkv_kernel<TW>), dim3((HD + 128) / DEC_ROWS), dim3(DEC_T), lds_d, st, a.x, a.attn_gamma[l],
                            (const TW*)a.Wq[l], (const TW*)a.Wkv[l], a.q, a.Kc[l], a.Vc[l], B, D, H, a.Nmax, a.pos_dev, a.eps, a.round_bf16);

@@ -35,7 +35,7 @@ class DecodeArgs(C.Structure):
                 [("bias_table", C.c_void_p), ("bias_ld", C.c_int),
                  ("final_gamma", C.c_void_p), ("head_W", C.c_void_p), ("V1", C.c_int), ("ldV", C.c_int),
                  ("emb_table", C.c_void_p), ("emb_row_offset", C.c_longlong), ("emb_rows", C.c_longlong)] +
-                [(n, C.c_void_p) for n in ("x", "x1", "q", "parts", "u", "logits", "advance_pos", "advance_step")])
+                [(n, C.c_void_p) for n in ("x", "x1", "q", "parts", "u", "logits", "advance_pos", "advance_step", "ln_parts")])
 
 
 def supports(model, batch: int) -> bool:
@@ -114,6 +114,9 @@ class CachedDecoder:
         a.emb_table, a.emb_rows = self.emb.data_ptr(), self.emb.shape[0]
         for n in ("x", "x1", "q", "parts", "u", "logits"):
             setattr(a, n, getattr(self, n).data_ptr())
+        # per-workgroup LayerNorm partial sums of the batched step kernels (OMLM_DECODE_LN_PARTS(D, Fp) floats x 3 producers)
+        self.ln_parts = torch.zeros(3 * max((a.D + 15) // 16, (a.Fp + 7) // 8) * 16, device=self.x.device)
+        a.ln_parts = self.ln_parts.data_ptr()
         self.args = a
 
     # ---- prompt: the batched forward over all known rows, keeping what the single-row steps need ---------------------

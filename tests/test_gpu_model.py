@@ -346,6 +346,35 @@ def test_cached_decode_other_stages(golden_dir, dev, name, precision):
     assert err < TOL[precision]["logits"], err
 
 
+@pytest.mark.parametrize("precision,B", [("bf16", 1), ("bf16", 4), ("bf16", 8), ("fp16", 8), ("bf16x3", 3)])
+def test_cached_decode_at_full_width(dev, precision, B):
+    """The step kernels the bench runs (dim 1024, 8 heads, F = 2730: dec3 at B = 1, the matrix-core dec4 kernels with their LayerNorm
+    partial sums at 2 <= B <= 8 in the 16-bit modes, the VALU dec2 kernels for fp32 weights) against the re-forward of the growing
+    sequence: same bars as the batched forward itself."""
+    from open_musiclm_amd import decode
+    from open_musiclm_amd import open_musiclm as M
+    from open_musiclm_amd.utils import append_eos_id
+    torch.manual_seed(0)
+    model = M.create_coarse_transformer(dim=1024, depth=2, heads=8, ff_dropout=0.0, num_coarse_quantizers=3, precision=precision).to(dev)
+    assert decode.supports(model, B)
+    model.eval()
+    wrapper = M.TokenConditionedTransformerWrapper(transformer=model, unique_consecutive=False)
+    g = torch.Generator().manual_seed(3)
+    cond = [torch.randint(0, 1024, (B, 12, 1), generator=g).to(dev), torch.randint(0, 1024, (B, 40), generator=g).to(dev)]
+    n, V1 = 9, 1025
+    flat = torch.randint(0, 1024, (B, n), generator=g).to(dev)
+    with torch.no_grad():
+        condx = [append_eos_id(t.reshape(t.shape[0], -1).long(), e) for t, e in zip(cond, wrapper.eos_ids)]
+        dec = decode.CachedDecoder(model, B, sum(t.shape[-1] + 1 for t in condx) + 1 + n, precision)
+        got = [dec.prefill(condx + [flat[:, :0]]).clone()]
+        for k in range(n - 1):
+            got.append(dec.step(flat[:, k].contiguous(), k).clone())
+        want = [model.last_logits(condx + [flat[:, :k]]).clone() for k in range(n)]
+    err = max(relerr(x[:, :V1], y[:, :V1]) for x, y in zip(got, want))
+    report(f"cached_decode_full_width[{precision},B={B}]", max_rel_err=err, steps=n)
+    assert err < TOL[precision]["logits"], err
+
+
 def test_cached_decode_with_absolute_position_embeddings(dev):
     """use_absolute_position_embeddings=True (open_musiclm.py:81-82,134-136): the KV-cached single-row steps add the position row of the
     id they embed, so cached ids equal the re-forward ids (bf16x3) and the step logits equal last_logits of the growing sequence."""

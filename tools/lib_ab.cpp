@@ -438,6 +438,7 @@ static void decode_case(Lib& A, Lib& Bl, int B) {
         a.emb_table = emb; a.emb_row_offset = 1024; a.emb_rows = 1024 * 3 + 1;
         a.x = dev_zero<float>((size_t)B * D); a.x1 = dev_zero<float>((size_t)B * D); a.q = dev_zero<float>((size_t)B * HD);
         a.parts = dev_zero<float>((size_t)B * nsplit * H * 66); a.u = dev_zero<float>((size_t)B * Fp); a.logits = dev_zero<float>((size_t)B * ldV);
+        if (!getenv("LIB_AB_NO_LN_PARTS")) a.ln_parts = dev_zero<float>((size_t)3 * OMLM_DECODE_LN_PARTS(D, Fp));      // (libraries older than the field never read it)
         a.advance_pos = nullptr; a.advance_step = nullptr;
         auto step = [&] { libs[li]->ok(libs[li]->dstep(&a, dids, nullptr), "decode_step"); };
         step(); CK(hipDeviceSynchronize());
