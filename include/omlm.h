@@ -53,6 +53,12 @@ long long omlm_layernorm_bwd_workspace_bytes(int D);
 int omlm_layernorm_bwd(const void* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                        const float* dres, float* dx, void* dxcast, float* dgamma, float* workspace, int M, int D,
                        float dx_scale, int cast_dtype, int dy_dtype, void* stream);   /* dy_dtype: 0 fp32, 1 bf16 / 2 fp16 (GEMM epilogue output) */
+/* the same with a second residual-gradient term dres2 [M, D] (optional) in the type cast_dtype names (dxcast may be null): the K/V
+ * projection's input gradient reaches the attention LayerNorm's backward as a 16-bit GEMM output instead of being added to the fp32
+ * residual gradient by the GEMM's own epilogue (146 MB read + 146 MB written per layer at B = 32). */
+int omlm_layernorm_bwd2(const void* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                        const float* dres, const void* dres2, float* dx, void* dxcast, float* dgamma, float* workspace, int M, int D,
+                        float dx_scale, int cast_dtype, int dy_dtype, void* stream);
 
 /* q/k l2-normalise * learned per-dim scale, v pass-through (transformer.py:265-271; utils.py:68-69), dim_head 64. */
 int omlm_qk_norm_fwd(const float* q_raw, const float* kv_raw, const float* q_scale, const float* k_scale,

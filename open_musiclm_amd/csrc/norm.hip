@@ -71,6 +71,7 @@ template <typename T, typename TDY>
 __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const TDY* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ dres,
+                                                            const T* __restrict__ dres2,
                                                             float* __restrict__ dx, T* __restrict__ dxcast,
                                                             float* __restrict__ dgamma, float* __restrict__ part, int M, int D,
                                                             float dx_scale) {
@@ -108,6 +109,10 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const TDY* __restric
                 if (dres) {
                     const float4 d0 = ((const float4*)(dres + (size_t)row * D))[c];
                     r.x += d0.x; r.y += d0.y; r.z += d0.z; r.w += d0.w;
+                }
+                if (dres2) {                // a second residual-gradient term in the cast type (the K/V input gradient: see omlm_layernorm_bwd2)
+                    const float4 d1 = load4f(dres2 + (size_t)row * D, c);
+                    r.x += d1.x; r.y += d1.y; r.z += d1.z; r.w += d1.w;
                 }
                 r.x *= dx_scale; r.y *= dx_scale; r.z *= dx_scale; r.w *= dx_scale;
                 ((float4*)(dx + (size_t)row * D))[c] = r;
@@ -164,13 +169,14 @@ extern "C" long long omlm_layernorm_bwd_workspace_bytes(int D) { return (long lo
 #endif
 
 #if !OMLM_FP16
-extern "C" int omlm_layernorm_bwd_h(const void* dy, const float* x, const float* gamma, const float* mean, const float* rstd, const float* dres, float* dx, void* dxcast, float* dgamma, float* workspace, int M, int D, float dx_scale, int cast_dtype, int dy_dtype, void* stream);
+extern "C" int omlm_layernorm_bwd2_h(const void* dy, const float* x, const float* gamma, const float* mean, const float* rstd, const float* dres, const void* dres2, float* dx, void* dxcast, float* dgamma, float* workspace, int M, int D, float dx_scale, int cast_dtype, int dy_dtype, void* stream);
 #endif
-extern "C" int OMLM_API(omlm_layernorm_bwd)(const void* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
-                                  const float* dres, float* dx, void* dxcast, float* dgamma, float* workspace, int M, int D,
+// dres2 (optional): a second residual-gradient term [M, D] in the type named by cast_dtype (dxcast itself may be null)
+extern "C" int OMLM_API(omlm_layernorm_bwd2)(const void* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                  const float* dres, const void* dres2, float* dx, void* dxcast, float* dgamma, float* workspace, int M, int D,
                                   float dx_scale, int cast_dtype, int dy_dtype, void* stream) {
 #if !OMLM_FP16
-    if (cast_dtype == OMLM_DT_F16 || dy_dtype == OMLM_DT_F16) return omlm_layernorm_bwd_h(dy, x, gamma, mean, rstd, dres, dx, dxcast, dgamma, workspace, M, D, dx_scale, OMLM_H_CODE(cast_dtype), OMLM_H_CODE(dy_dtype), stream);
+    if (cast_dtype == OMLM_DT_F16 || dy_dtype == OMLM_DT_F16) return omlm_layernorm_bwd2_h(dy, x, gamma, mean, rstd, dres, dres2, dx, dxcast, dgamma, workspace, M, D, dx_scale, OMLM_H_CODE(cast_dtype), OMLM_H_CODE(dy_dtype), stream);
 #endif
     if (M <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(dy && x && gamma && mean && rstd && dx, "null pointer");
@@ -184,18 +190,25 @@ extern "C" int OMLM_API(omlm_layernorm_bwd)(const void* dy, const float* x, cons
     float* part = two_level ? workspace : nullptr;
     OMLM_CHECK_ARG(dy_dtype == 0 || dy_dtype == 1, "dy_dtype: 0 = fp32, 1 = bf16, 2 = fp16 (same 16-bit type as the cast output)");
     if (cast_dtype == 0 && dy_dtype == 0)
-        hipLaunchKernelGGL((ln_bwd_kernel<float, float>), grid, block, 0, as_stream(stream), (const float*)dy, x, gamma, mean, rstd, dres, dx, (float*)dxcast, dgamma, part, M, D, dx_scale);
+        hipLaunchKernelGGL((ln_bwd_kernel<float, float>), grid, block, 0, as_stream(stream), (const float*)dy, x, gamma, mean, rstd, dres, (const float*)dres2, dx, (float*)dxcast, dgamma, part, M, D, dx_scale);
     else if (cast_dtype == 0)
-        hipLaunchKernelGGL((ln_bwd_kernel<float, h16_t>), grid, block, 0, as_stream(stream), (const h16_t*)dy, x, gamma, mean, rstd, dres, dx, (float*)dxcast, dgamma, part, M, D, dx_scale);
+        hipLaunchKernelGGL((ln_bwd_kernel<float, h16_t>), grid, block, 0, as_stream(stream), (const h16_t*)dy, x, gamma, mean, rstd, dres, (const float*)dres2, dx, (float*)dxcast, dgamma, part, M, D, dx_scale);
     else if (dy_dtype == 0)
-        hipLaunchKernelGGL((ln_bwd_kernel<h16_t, float>), grid, block, 0, as_stream(stream), (const float*)dy, x, gamma, mean, rstd, dres, dx, (h16_t*)dxcast, dgamma, part, M, D, dx_scale);
+        hipLaunchKernelGGL((ln_bwd_kernel<h16_t, float>), grid, block, 0, as_stream(stream), (const float*)dy, x, gamma, mean, rstd, dres, (const h16_t*)dres2, dx, (h16_t*)dxcast, dgamma, part, M, D, dx_scale);
     else
-        hipLaunchKernelGGL((ln_bwd_kernel<h16_t, h16_t>), grid, block, 0, as_stream(stream), (const h16_t*)dy, x, gamma, mean, rstd, dres, dx, (h16_t*)dxcast, dgamma, part, M, D, dx_scale);
+        hipLaunchKernelGGL((ln_bwd_kernel<h16_t, h16_t>), grid, block, 0, as_stream(stream), (const h16_t*)dy, x, gamma, mean, rstd, dres, (const h16_t*)dres2, dx, (h16_t*)dxcast, dgamma, part, M, D, dx_scale);
     int rc = omlm_post_launch("omlm_layernorm_bwd");
     if (rc) return rc;
     if (two_level) return omlm_colsum_accumulate(part, dgamma, blocks, D, D, stream);
     return OMLM_OK;
 }
+#if !OMLM_FP16
+extern "C" int omlm_layernorm_bwd(const void* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                  const float* dres, float* dx, void* dxcast, float* dgamma, float* workspace, int M, int D,
+                                  float dx_scale, int cast_dtype, int dy_dtype, void* stream) {
+    return omlm_layernorm_bwd2(dy, x, gamma, mean, rstd, dres, nullptr, dx, dxcast, dgamma, workspace, M, D, dx_scale, cast_dtype, dy_dtype, stream);
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // q/k l2norm * scale.  One wave per 64-wide vector, one element per lane (dim_head == 64).

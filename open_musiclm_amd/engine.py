@@ -41,6 +41,9 @@ _RELPOS_ASYNC = os.environ.get("OMLM_RELPOS_ASYNC", "1") == "1"
 # bf16 mode: d(LN output) leaves the input-gradient GEMMs as bf16 (fp32 accumulate, one rounding) instead of fp32 -- it is read once,
 # by the LayerNorm backward, and every other GEMM operand of that mode is rounded the same way.  OMLM_BF16_LN_GRAD=0: fp32 as before.
 _BF16_LN_GRAD = os.environ.get("OMLM_BF16_LN_GRAD", "1") == "1"
+# 16-bit modes: the K/V projection's input gradient leaves its GEMM as a 16-bit tensor and is added to the residual gradient inside the
+# attention LayerNorm's backward (ops.layernorm_bwd dres2) instead of by the GEMM's own fp32 read-add-write epilogue (0: that form)
+_KV_DGRAD_H16 = os.environ.get("OMLM_KV_DGRAD_H16", "1") == "1"
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 
 
@@ -517,13 +520,14 @@ def trunk_backward(tr, pw: PreparedWeights, saved, dy: torch.Tensor, B: int, N: 
         ops.qk_norm_bwd(dq, dk, dv, sv.q_raw, sv.kv_raw, attn.q_scale.detach(), attn.k_scale.detach(),
                         dq_raw, dkv_raw, grad_of(attn.q_scale), grad_of(attn.k_scale), H)
         dxn = torch.empty(M, D, dtype=T if _BF16_LN_GRAD else torch.float32, device=dev)
-        tmp = torch.empty(M, D, device=dev)
+        kv16 = T in _H16 and _KV_DGRAD_H16
+        tmp = torch.empty(M, D, dtype=T if kv16 else torch.float32, device=dev)      # kv16: the K/V term alone; else dx1 + the K/V term
         if "WqT" in w:
             ops.gemm(dq_raw, w["WqT"], dxn, M=M, N=D, K=H * DIM_HEAD)
-            ops.gemm(dkv_raw, w["WkvT"], tmp, M=M, N=D, K=2 * DIM_HEAD, Cin=dx1)
+            ops.gemm(dkv_raw, w["WkvT"], tmp, M=M, N=D, K=2 * DIM_HEAD, Cin=None if kv16 else dx1)
         else:
             ops.gemm(dq_raw, w["Wq"], dxn, M=M, N=D, K=H * DIM_HEAD, b_kmajor=True)
-            ops.gemm(dkv_raw, w["Wkv"], tmp, M=M, N=D, K=2 * DIM_HEAD, b_kmajor=True, Cin=dx1)
+            ops.gemm(dkv_raw, w["Wkv"], tmp, M=M, N=D, K=2 * DIM_HEAD, b_kmajor=True, Cin=None if kv16 else dx1)
         gWq = grad_of(attn.to_q.weight)
         wgrad(dq_raw, sv.xn, gWq, H * DIM_HEAD, D)
         gWkv = grad_of(attn.to_kv.weight)
@@ -531,9 +535,9 @@ def trunk_backward(tr, pw: PreparedWeights, saved, dy: torch.Tensor, B: int, N: 
         dres = torch.empty(M, D, device=dev)
         dres_c = dres if T == torch.float32 else torch.empty(M, D, dtype=T, device=dev)
         last = li == 0
-        ops.layernorm_bwd(dxn, sv.x, attn.norm.gamma.detach(), sv.m1, sv.r1, tmp, dres,
+        ops.layernorm_bwd(dxn, sv.x, attn.norm.gamma.detach(), sv.m1, sv.r1, dx1 if kv16 else tmp, dres,
                           None if (T == torch.float32 or last) else dres_c, grad_of(attn.norm.gamma),
-                          dx_scale=out_scale if last else 1.0)
+                          dx_scale=out_scale if last else 1.0, dres2=tmp if kv16 else None)
     if wg is not None:
         wg.flush()
     if rp_side is not None:

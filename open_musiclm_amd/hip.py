@@ -31,6 +31,7 @@ SIGNATURES = {
     "omlm_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp],
     "omlm_layernorm_bwd_workspace_bytes": [i32],
     "omlm_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, i32, vp],
+    "omlm_layernorm_bwd2": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, i32, vp],
     "omlm_qk_norm_fwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "omlm_qk_norm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "omlm_attn_bias_table_floats": [i32, i32],

@@ -163,11 +163,13 @@ def _ln_workspace(D: int, device) -> torch.Tensor:
     return _LN_WS[key]
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dx, dxcast, dgamma, dx_scale=1.0):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dx, dxcast, dgamma, dx_scale=1.0, dres2=None):
+    """dres2 (optional): a second residual-gradient term in the cast type (dxcast's dtype; with dxcast None its own dtype names it)."""
     M, D = x.shape
-    code = dcode(dxcast.dtype) if dxcast is not None else F32
+    code = dcode(dxcast.dtype) if dxcast is not None else (dcode(dres2.dtype) if dres2 is not None else F32)
+    assert dres2 is None or dcode(dres2.dtype) == code, "dres2 must have the cast type"
     ws = _ln_workspace(D, x.device) if dgamma is not None else None       # stream-ordered reuse: one backward at a time
-    call("omlm_layernorm_bwd", ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx),
+    call("omlm_layernorm_bwd2", ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dres2), ptr(dx),
          ptr(dxcast), ptr(dgamma), ptr(ws), M, D, float(dx_scale), code, dcode(dy.dtype), stream_ptr())
 
 

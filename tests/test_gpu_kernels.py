@@ -295,6 +295,18 @@ def test_layernorm_fwd_bwd(ops, dev, dtype):
         e2, eg2 = relerr(dx2, 0.1 * (xr2.grad + dres.double())), relerr(dg2, gr2.grad)
         report(f"layernorm[{dtype} dy]", dx=e2, dgamma=eg2)
         assert e2 < 1e-5 and eg2 < 1e-4
+    # a second residual-gradient term in the cast type (omlm_layernorm_bwd2: the K/V projection's input gradient), with and without a
+    # cast output: exact for the values handed over
+    d2 = torch.randn(M, D, generator=g).to(dev).to(dtype)
+    for with_cast in (True, False):
+        dx3, dg3 = torch.empty(M, D, device=dev), torch.zeros(D, device=dev)
+        dxc3 = torch.empty(M, D, device=dev, dtype=dtype) if with_cast else None
+        ops.layernorm_bwd(dy, x, gamma, mean, rstd, dres, dx3, dxc3, dg3, dx_scale=0.1, dres2=d2)
+        e3 = relerr(dx3, 0.1 * (xr.grad + dres.double() + d2.double()))
+        report(f"layernorm[{dtype} dres2 cast={with_cast}]", dx=e3)
+        assert e3 < 1e-5 and relerr(dg3, gr.grad) < 1e-4
+        if with_cast:
+            assert relerr(dxc3, dx3) < tol
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
