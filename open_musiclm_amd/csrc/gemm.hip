@@ -312,11 +312,19 @@ __device__ __forceinline__ void dma_issue(dma_rsrc rs, unsigned lds_dst, unsigne
                  : "=&s"(keep) : "v"(off), "s"(lds_dst), "s"(rs) : "memory");
 }
 
+// the same with a wave-uniform byte offset in the instruction's SGPR offset field: the per-lane offset register is loop-invariant
+__device__ __forceinline__ void dma_issue_s(dma_rsrc rs, unsigned lds_dst, unsigned voff, unsigned soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(rs), "s"(soff) : "memory");
+}
+
 template <bool KMAJ, int ROWS, int NWAVES>
 struct DmaStagerT {
     static constexpr int UPW = (ROWS / 8) / NWAVES;       // 1-KiB units per wave per tile
     unsigned base[UPW];
     int kidx[UPW];
+    unsigned vfast[UPW];      // whole-k-tile form (K % 64 == 0, no k-row map): per-lane offset of k-tile 0; the tile's k offset travels as an SGPR
     __device__ __forceinline__ void init(const int* map, int ld, int nvalid, int r0, int wave, int lane) {
 #pragma unroll
         for (int i = 0; i < UPW; ++i) {
@@ -329,6 +337,7 @@ struct DmaStagerT {
                 const long long pr = (ok && map) ? (long long)map[gr] : (long long)gr;
                 base[i] = ok ? (unsigned)((pr * ld + kc * 8) * 2) : OOB_OFF;
                 kidx[i] = kc * 8;
+                vfast[i] = base[i];
             } else {
                 // unit b = (panel b >> 4, k-group b & 15): 4 k-rows x 256 B; lane = (row lane >> 4, 16-B chunk lane & 15)
                 const int krow = 4 * (b & 15) + (lane >> 4);
@@ -336,6 +345,7 @@ struct DmaStagerT {
                 const int gc = r0 + 128 * (b >> 4) + 32 * piece + 8 * (lane & 3);
                 base[i] = gc < nvalid ? (unsigned)(gc * 2) : OOB_OFF;
                 kidx[i] = krow;
+                vfast[i] = gc < nvalid ? base[i] + (unsigned)krow * (unsigned)(ld * 2) : OOB_OFF;
             }
         }
     }
@@ -344,10 +354,17 @@ struct DmaStagerT {
     // presence -- even behind a null-pointer test -- makes hipcc wait vmcnt(0) before every LDS-DMA issue and every
     // fragment read, which serialised the whole pipeline of the k-major GEMMs (2x slower; found in the ISA).
     // poff: byte offset of the operand plane this k-tile reads (0, or the lo plane of a split3 GEMM)
-    template <bool KMAP>
+    template <bool KMAP, bool FAST = false>
     __device__ __forceinline__ void issue_one(int i, dma_rsrc rs, const int* map, int ld, int k0, int K,
                                               char* lds_tile, int wave, bool live, int aux = 0, unsigned poff = 0u) {
         const int b = wave + NWAVES * i;
+        if constexpr (!KMAP && FAST) {
+            // every k of the tile is inside K (host: K % 64 == 0): no per-piece compare / select / add chain (~6 VALU instructions per
+            // piece, 50 per k-tile per wave next to 32 MFMAs) -- one select for a dead tile (`live` false: past the last one)
+            dma_issue_s(rs, (unsigned)(size_t)LDS_PTR(char, lds_tile) + (unsigned)(b * 1024), live ? vfast[i] : OOB_OFF,
+                        (KMAJ ? (unsigned)k0 * (unsigned)(ld * 2) : (unsigned)(k0 * 2)) + poff);
+            return;
+        }
         unsigned off;
         if (!KMAJ) {
             off = (live && base[i] != OOB_OFF && k0 + kidx[i] < K) ? base[i] + (unsigned)(k0 * 2) + poff : OOB_OFF;
@@ -361,11 +378,11 @@ struct DmaStagerT {
         (void)aux;
         dma_issue(rs, (unsigned)(size_t)LDS_PTR(char, lds_tile) + (unsigned)(b * 1024), off);
     }
-    template <bool KMAP>
+    template <bool KMAP, bool FAST = false>
     __device__ __forceinline__ void issue(dma_rsrc rs, const int* map, int ld, int k0, int K,
                                           char* lds_tile, int wave, unsigned poff = 0u) {
 #pragma unroll
-        for (int i = 0; i < UPW; ++i) issue_one<KMAP>(i, rs, map, ld, k0, K, lds_tile, wave, true, 0, poff);
+        for (int i = 0; i < UPW; ++i) issue_one<KMAP, FAST>(i, rs, map, ld, k0, K, lds_tile, wave, true, 0, poff);
     }
 };
 
@@ -461,7 +478,8 @@ __device__ __forceinline__ int xcd_logical_id(int lin, int total) {
 
 // One workgroup's share of C = alpha A B^T (+ Cin).  lg: logical workgroup id inside this problem's (tiles x K-splits, split-major)
 // space; split: partial sums are added to fp32 C with atomics; bal_wgs: workgroup count of the balanced split-K form (BAL only).
-template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ, bool B_KMAJ, typename TOUT, bool DBG, bool KMAP, bool BAL, bool SPLIT3 = false>
+// FASTK: K is a multiple of the k-tile depth (host-checked): the DMA pieces take their k offset from an SGPR (DmaStagerT::issue_one)
+template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ, bool B_KMAJ, typename TOUT, bool DBG, bool KMAP, bool BAL, bool SPLIT3 = false, bool FASTK = false>
 __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, const bool split, const int bal_wgs, char* smem) {
     const int dbg = DBG ? g.debug : 0;      // ablation switches exist only in the DBG instantiation (OMLM_GEMM_DEBUG set)
     constexpr int NWN = BN_ / WN_, NWAVES = (BM_ / WM_) * NWN;
@@ -550,8 +568,8 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, 
         if (kt0 < kt1) {
             unsigned pa, pb;
             const int k00 = tile_at(kt0, pa, pb);
-            sa.template issue<KMAP>(rsA, g.a_map, g.lda, k00, g.K, smem, wave, pa);
-            sb.template issue<KMAP>(rsB, g.b_map, g.ldb, k00, g.K, smem + A_BYTES, wave, pb);
+            sa.template issue<KMAP, FASTK>(rsA, g.a_map, g.lda, k00, g.K, smem, wave, pa);
+            sb.template issue<KMAP, FASTK>(rsB, g.b_map, g.ldb, k00, g.K, smem + A_BYTES, wave, pb);
         }
         // Rotated k-loop: the MFMAs of a tile's LAST k16 step run AFTER the next tile's barrier and first fragment reads (their
         // operands are in registers), so the matrix pipe has work while the barrier releases and the first LDS reads of the new
@@ -585,8 +603,8 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, 
                             if (midx % STRIDE == 0 && midx / STRIDE < NLOAD) {
                                 const int l = midx / STRIDE;
                                 __builtin_amdgcn_sched_barrier(0);
-                                if (l < UA) sa.template issue_one<KMAP>(l, rsA, g.a_map, g.lda, knext, g.K, nxt, wave, live, 0, pan);
-                                else        sb.template issue_one<KMAP>(l - UA, rsB, g.b_map, g.ldb, knext, g.K, nxt + A_BYTES, wave, live, 0, pbn);
+                                if (l < UA) sa.template issue_one<KMAP, FASTK>(l, rsA, g.a_map, g.lda, knext, g.K, nxt, wave, live, 0, pan);
+                                else        sb.template issue_one<KMAP, FASTK>(l - UA, rsB, g.b_map, g.ldb, knext, g.K, nxt + A_BYTES, wave, live, 0, pbn);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                         }
@@ -626,13 +644,13 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, 
 
 // For split-K GEMMs the split-major XCD order puts all co-resident workgroups of an XCD on the SAME K range (they share A and B
 // panels through its L2); with a tile-only remap an XCD held 3 unrelated K ranges at a time (measured L2 hit 48 % on the dW1 GEMM).
-template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ, bool B_KMAJ, typename TOUT, bool DBG, bool KMAP, bool BAL = false, bool SPLIT3 = false>
+template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ, bool B_KMAJ, typename TOUT, bool DBG, bool KMAP, bool BAL = false, bool SPLIT3 = false, bool FASTK = false>
 __global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A | B]
     const int nwg = gridDim.x;                                     // tiles (plain) / workgroups (balanced)
     const int total = BAL ? (int)gridDim.x : nwg * (int)gridDim.y;
     const int lg = xcd_logical_id(blockIdx.y * nwg + blockIdx.x, total);
-    gemm_tile_body<BM_, BN_, WM_, WN_, A_KMAJ, B_KMAJ, TOUT, DBG, KMAP, BAL, SPLIT3>(g, lg, gridDim.y > 1, (int)gridDim.x, smem);
+    gemm_tile_body<BM_, BN_, WM_, WN_, A_KMAJ, B_KMAJ, TOUT, DBG, KMAP, BAL, SPLIT3, FASTK>(g, lg, gridDim.y > 1, (int)gridDim.x, smem);
 }
 
 
@@ -646,6 +664,14 @@ struct omlm_gemm_wgrad_desc { const void* A; const void* B; float* C; const int*
 struct GroupProb { const void* A; const void* B; float* C; const int* c_map; int M, N, K, lda, ldb, ldc, kt_per_split, start; };
 struct GroupArgs { int n, total; GroupProb p[OMLM_GROUP_MAX]; };
 
+// OMLM_GEMM_FASTK=0: the general DMA address form everywhere (A/B lever)
+static bool gemm_fastk_off() {
+    static int off = -1;
+    if (off < 0) { const char* e = getenv("OMLM_GEMM_FASTK"); off = (e && e[0] == '0') ? 1 : 0; }
+    return off == 1;
+}
+
+template <bool FASTK>
 __global__ __launch_bounds__(512) void gemm_wgrad_group_kernel(GroupArgs ga) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lg = xcd_logical_id(blockIdx.x, ga.total);
@@ -657,7 +683,7 @@ __global__ __launch_bounds__(512) void gemm_wgrad_group_kernel(GroupArgs ga) {
     g.a_rows = q.K; g.b_rows = q.K; g.M = q.M; g.N = q.N; g.K = q.K; g.lda = q.lda; g.ldb = q.ldb; g.ldc = q.ldc; g.ldcin = q.ldc;
     g.alpha = 1.f; g.kt_per_split = q.kt_per_split; g.bal_ck = 0; g.bal_chunks = 0; g.debug = 0; g.split3 = 0; g.a_plane = 0; g.b_plane = 0;
     const int nk = (q.K + BK - 1) / BK;
-    gemm_tile_body<256, 256, 128, 64, true, true, float, false, false, false>(g, lg - q.start, q.kt_per_split < nk, 0, smem);
+    gemm_tile_body<256, 256, 128, 64, true, true, float, false, false, false, false, FASTK>(g, lg - q.start, q.kt_per_split < nk, 0, smem);
 }
 
 template <int BM_, int BN_, int WM_, int WN_, typename TOUT>
@@ -675,9 +701,11 @@ static int launch_tile(const GemmArgs& g, int a_kmaj, int b_kmaj, int splits, hi
     do {                                                                                                                    \
         auto kfn = gemm_bf16_tile_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT, false, false>;                                 \
         auto kmap = gemm_bf16_tile_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT, false, (AK || BKM) && BM_ == 128>;            \
+        auto kfast = gemm_bf16_tile_kernel<BM_, BN_, WM_, WN_, AK, BKM, TOUT, false, false, false, false, true>;           \
         static bool attr = false;                                                                                           \
         if (!attr) {                                                                                                        \
             (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);             \
+            (void)hipFuncSetAttribute((const void*)kfast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);           \
             (void)hipFuncSetAttribute((const void*)kmap, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);            \
         }                                                                                                                   \
         if constexpr (!OMLM_FP16) {                                                                                         \
@@ -698,6 +726,7 @@ static int launch_tile(const GemmArgs& g, int a_kmaj, int b_kmaj, int splits, hi
         }                                                                                                                   \
         attr = true;                                                                                                        \
         if (need_kmap) hipLaunchKernelGGL(kmap, grid, block, LDS, st, g);                                                  \
+        else if (g.K % BK == 0 && !gemm_fastk_off()) hipLaunchKernelGGL(kfast, grid, block, LDS, st, g);                   \
         else           hipLaunchKernelGGL(kfn, grid, block, LDS, st, g);                                                   \
     } while (0)
     if (!a_kmaj && !b_kmaj)      OMLM_TILE_LAUNCH(false, false);
@@ -962,14 +991,20 @@ extern "C" int OMLM_API(omlm_gemm_wgrad_group)(const omlm_gemm_wgrad_desc* d, in
         else ncu = 256;
     }
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_wgrad_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); attr = true; }
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm_wgrad_group_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        (void)hipFuncSetAttribute((const void*)gemm_wgrad_group_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        attr = true;
+    }
     { const char* e = getenv("OMLM_GROUP_SPLITS"); if (e && atoi(e) > 0) splits = atoi(e); }
     for (int base = 0; base < count; base += OMLM_GROUP_MAX) {
         const int n = count - base < OMLM_GROUP_MAX ? count - base : OMLM_GROUP_MAX;
         long long units = 0;
         int nk_min = 1 << 30;
+        bool fastk = !gemm_fastk_off();                       // every problem's K a multiple of the k-tile depth: SGPR-offset DMA form
         for (int i = 0; i < n; ++i) {
             const omlm_gemm_wgrad_desc& q = d[base + i];
+            if (q.K % BK != 0) fastk = false;
             OMLM_CHECK_ARG(q.A && q.B && q.C && q.M > 0 && q.N > 0 && q.K > 0, "wgrad group: bad problem");
             OMLM_CHECK_ARG((q.lda % 8) == 0 && (q.ldb % 8) == 0 && q.lda >= ((q.M + 7) / 8) * 8 && q.ldb >= ((q.N + 7) / 8) * 8,
                            "wgrad group: k-major operand pitches must be multiples of 8 covering the padded extent");
@@ -1007,7 +1042,8 @@ extern "C" int OMLM_API(omlm_gemm_wgrad_group)(const omlm_gemm_wgrad_desc* d, in
             start += ((q.M + 255) / 256) * ((q.N + 255) / 256) * s_eff;
         }
         ga.total = start;
-        hipLaunchKernelGGL(gemm_wgrad_group_kernel, dim3(start), dim3(512), 131072, as_stream(stream), ga);
+        if (fastk) hipLaunchKernelGGL(gemm_wgrad_group_kernel<true>, dim3(start), dim3(512), 131072, as_stream(stream), ga);
+        else       hipLaunchKernelGGL(gemm_wgrad_group_kernel<false>, dim3(start), dim3(512), 131072, as_stream(stream), ga);
     }
     return omlm_post_launch("omlm_gemm_wgrad_group");
 }
