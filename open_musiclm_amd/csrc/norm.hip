@@ -256,42 +256,62 @@ __global__ __launch_bounds__(256) void qk_norm_bwd_kernel(const float* __restric
                                                           T* __restrict__ dkv_raw, float* __restrict__ dq_scale,
                                                           float* __restrict__ dk_scale, int M, int H) {
     const int lane = threadIdx.x & 63, sub = lane >> 4, d0 = 4 * (lane & 15);
-    const long long nvec = (long long)M * (H + 2);
+    const unsigned nvec = (unsigned)M * (unsigned)(H + 2), hp2 = (unsigned)(H + 2);      // host: M * (H + 2) < 2^31
     const float4 qs = *(const float4*)(q_scale + d0), ks = *(const float4*)(k_scale + d0);
     float aq[4] = {0.f, 0.f, 0.f, 0.f}, ak[4] = {0.f, 0.f, 0.f, 0.f};
-    for (long long base = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4; base < nvec; base += (long long)gridDim.x * 16) {
-        const long long vec = base + sub;
-        const bool live = vec < nvec;
-        const int row = live ? (int)(vec / (H + 2)) : 0, j = live ? (int)(vec % (H + 2)) : H + 1;
-        const bool isq = j < H, isk = j == H;
-        float4 x = make_float4(0.f, 0.f, 0.f, 0.f), dy = x;
-        if (live) {
-            if (isq)      { x = *(const float4*)(q_raw + (size_t)row * H * 64 + j * 64 + d0); dy = *(const float4*)(dq + (size_t)row * H * 64 + j * 64 + d0); }
-            else if (isk) { x = *(const float4*)(kv_raw + (size_t)row * 128 + d0);           dy = *(const float4*)(dk + (size_t)row * 64 + d0); }
-            else          { dy = *(const float4*)(dv + (size_t)row * 64 + d0); }
-        }
-        const float4 s = isq ? qs : ks;
-        const float n2 = group16_sum(x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w);
-        const float nr = sqrtf(n2);
-        const bool clamped = nr < 1e-12f;
-        const float inv = 1.0f / (clamped ? 1e-12f : nr);
-        const float xh[4] = {x.x * inv, x.y * inv, x.z * inv, x.w * inv};
-        const float gy[4] = {s.x * dy.x, s.y * dy.y, s.z * dy.z, s.w * dy.w};
-        float proj = group16_sum(xh[0] * gy[0] + xh[1] * gy[1] + xh[2] * gy[2] + xh[3] * gy[3]);
-        if (clamped) proj = 0.f;
-        if (!live) continue;
-        if (isq || isk) {
-            const float o0 = (gy[0] - xh[0] * proj) * inv, o1 = (gy[1] - xh[1] * proj) * inv;
-            const float o2 = (gy[2] - xh[2] * proj) * inv, o3 = (gy[3] - xh[3] * proj) * inv;
-            if (isq) {
-                store4(dq_raw + (size_t)row * H * 64 + j * 64 + d0, o0, o1, o2, o3);
-                aq[0] += dy.x * xh[0]; aq[1] += dy.y * xh[1]; aq[2] += dy.z * xh[2]; aq[3] += dy.w * xh[3];
-            } else {
-                store4(dkv_raw + (size_t)row * 128 + d0, o0, o1, o2, o3);
-                ak[0] += dy.x * xh[0]; ak[1] += dy.y * xh[1]; ak[2] += dy.z * xh[2]; ak[3] += dy.w * xh[3];
+    // several vectors per lane per trip, all their loads requested before the first reduction (one vector per trip with a 64-bit
+    // division in front of its loads ran at 2.7 TB/s -- 83 us at M = 35712, H = 8: one dependent round trip at a time per wave; now 51 us)
+#ifndef QKB_U
+#define QKB_U 4                 /* vectors per lane per trip */
+#endif
+#ifndef QKB_BLOCKS
+#define QKB_BLOCKS 512          /* workgroups: each ends with 128 atomics into the two scale gradients (2048 workgroups: 69 us, 512: 51 us) */
+#endif
+    constexpr int U = QKB_U;
+    const unsigned stride = gridDim.x * 16u;
+    for (unsigned base = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 4u; base < nvec; base += stride * U) {
+        bool live[U], isq[U], isk[U];
+        int row[U], j[U];
+        float4 x[U], dy[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned vec = base + u * stride + sub;
+            live[u] = vec < nvec;
+            row[u] = live[u] ? (int)(vec / hp2) : 0;
+            j[u] = live[u] ? (int)(vec - (unsigned)row[u] * hp2) : H + 1;
+            isq[u] = j[u] < H; isk[u] = j[u] == H;
+            x[u] = make_float4(0.f, 0.f, 0.f, 0.f); dy[u] = x[u];
+            if (live[u]) {
+                if (isq[u])      { x[u] = *(const float4*)(q_raw + (size_t)row[u] * H * 64 + j[u] * 64 + d0); dy[u] = *(const float4*)(dq + (size_t)row[u] * H * 64 + j[u] * 64 + d0); }
+                else if (isk[u]) { x[u] = *(const float4*)(kv_raw + (size_t)row[u] * 128 + d0);               dy[u] = *(const float4*)(dk + (size_t)row[u] * 64 + d0); }
+                else             { dy[u] = *(const float4*)(dv + (size_t)row[u] * 64 + d0); }
             }
-        } else {
-            store4(dkv_raw + (size_t)row * 128 + 64 + d0, dy.x, dy.y, dy.z, dy.w);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float4 s = isq[u] ? qs : ks;
+            const float n2 = group16_sum(x[u].x * x[u].x + x[u].y * x[u].y + x[u].z * x[u].z + x[u].w * x[u].w);
+            const float nr = sqrtf(n2);
+            const bool clamped = nr < 1e-12f;
+            const float inv = 1.0f / (clamped ? 1e-12f : nr);
+            const float xh[4] = {x[u].x * inv, x[u].y * inv, x[u].z * inv, x[u].w * inv};
+            const float gy[4] = {s.x * dy[u].x, s.y * dy[u].y, s.z * dy[u].z, s.w * dy[u].w};
+            float proj = group16_sum(xh[0] * gy[0] + xh[1] * gy[1] + xh[2] * gy[2] + xh[3] * gy[3]);
+            if (clamped) proj = 0.f;
+            if (!live[u]) continue;
+            if (isq[u] || isk[u]) {
+                const float o0 = (gy[0] - xh[0] * proj) * inv, o1 = (gy[1] - xh[1] * proj) * inv;
+                const float o2 = (gy[2] - xh[2] * proj) * inv, o3 = (gy[3] - xh[3] * proj) * inv;
+                if (isq[u]) {
+                    store4(dq_raw + (size_t)row[u] * H * 64 + j[u] * 64 + d0, o0, o1, o2, o3);
+                    aq[0] += dy[u].x * xh[0]; aq[1] += dy[u].y * xh[1]; aq[2] += dy[u].z * xh[2]; aq[3] += dy[u].w * xh[3];
+                } else {
+                    store4(dkv_raw + (size_t)row[u] * 128 + d0, o0, o1, o2, o3);
+                    ak[0] += dy[u].x * xh[0]; ak[1] += dy[u].y * xh[1]; ak[2] += dy[u].z * xh[2]; ak[3] += dy[u].w * xh[3];
+                }
+            } else {
+                store4(dkv_raw + (size_t)row[u] * 128 + 64 + d0, dy[u].x, dy[u].y, dy[u].z, dy[u].w);
+            }
         }
     }
     // fold the 4 sub-groups of the wave, then the 4 waves of the block through LDS, then one atomic per dim per block
@@ -340,7 +360,8 @@ extern "C" int OMLM_API(omlm_qk_norm_bwd)(const float* dq, const float* dk, cons
     if (M <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(dq && dk && dv && q_raw && kv_raw && dq_raw && dkv_raw && dq_scale && dk_scale, "null pointer");
     long long nvec = (long long)M * (H + 2);
-    int blocks = (int)((nvec + 15) / 16); if (blocks > 2048) blocks = 2048;
+    OMLM_CHECK_ARG(nvec < (1ll << 31), "qk_norm_bwd: M * (H + 2) must stay below 2^31 (32-bit vector index)");
+    int blocks = (int)((nvec + 15) / 16); if (blocks > QKB_BLOCKS) blocks = QKB_BLOCKS;
     if (out_dtype == 0)
         hipLaunchKernelGGL(qk_norm_bwd_kernel<float>, dim3(blocks), dim3(256), 0, as_stream(stream), dq, dk, dv, q_raw, kv_raw, q_scale, k_scale, (float*)dq_raw, (float*)dkv_raw, dq_scale, dk_scale, M, H);
     else
