@@ -124,7 +124,7 @@ class TrainLeg:
             torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         return float(tmax.item()), float(loss.item())
 
-    def gemm_roofline(self, k0, traffic=None):
+    def gemm_roofline(self, k0, traffic=None, tag=""):
         """HIP events (torch events on the stream the kernels are launched on) around every MFMA GEMM launch of two extra,
         eager, un-exchanged steps -- single GEMMs and the grouped weight-gradient launches alike: algorithmic flops of the
         launches / their summed durations."""
@@ -172,7 +172,8 @@ class TrainLeg:
             for a, b, f, key in rec:
                 t = agg.setdefault(key, [0, 0.0, 0.0]); t[0] += 1; t[1] += a.elapsed_time(b); t[2] += f
             rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
-            with open(os.environ["OMLM_BENCH_GEMM_TABLE"], "w") as fh:
+            tpath = os.environ["OMLM_BENCH_GEMM_TABLE"]
+            with open(tpath if not tag else tpath.replace(".md", f"_{tag}.md"), "w") as fh:
                 fh.write("| M, N, K, operands, out, A k-major, B k-major | launches / step | us / launch | TFLOP/s | ms / step |\n|---|---:|---:|---:|---:|\n")
                 for key, (n, ms, fl) in rows:
                     fh.write(f"| {key} | {n / 2:g} | {ms / n * 1e3:.1f} | {fl / (ms * 1e-3) / 1e12:.0f} | {ms / 2:.3f} |\n")
@@ -419,7 +420,7 @@ def main():
                 "unit": "samples/s", "steps": k, "warmup": w, "ms_per_step": round(1e3 * dt3 / k, 3),
                 "vs_headline_step": round((1e3 * dt3 / k) / ms_per_step, 4), "model_tflops_per_gpu": round(tf3, 2),
                 "model_flops_frac_of_bf16_peak": round(tf3 / PEAK_TFLOPS, 4), "final_loss": round(loss3, 4),
-                "hip_graph": leg.fb.graph is not None, "roofline": leg.gemm_roofline(k + w)}
+                "hip_graph": leg.fb.graph is not None, "roofline": leg.gemm_roofline(k + w, tag=prec)}
             progress(f"{prec} leg: {out['legs'][prec]['ms_per_step']} ms/step")
             leg.free()
         if "large_fine" in legs:
@@ -438,7 +439,7 @@ def main():
                 "warmup": w, "ms_per_step": round(1e3 * dtl / k, 3), "model_tflops_per_gpu": round(tfl, 2),
                 "model_flops_frac_of_bf16_peak": round(tfl / PEAK_TFLOPS, 4), "final_loss": round(lossl, 4),
                 "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
-                "hip_graph": leg.fb.graph is not None, "roofline": leg.gemm_roofline(k + w)}
+                "hip_graph": leg.fb.graph is not None, "roofline": leg.gemm_roofline(k + w, tag="large_fine")}
             progress(f"large_fine leg: {out['legs']['large_fine']['ms_per_step']} ms/step, {out['legs']['large_fine']['peak_hbm_gb']} GB")
             leg.free()
         if "e2e_generate" in legs:

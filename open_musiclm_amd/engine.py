@@ -646,7 +646,15 @@ def heads_backward(model, pw: PreparedWeights, y: torch.Tensor, lay: SeqLayout, 
                          a_rows=dl.shape[0], b_rows=V1)
             # dW_q += dlogits[rows]^T @ y[rows]
             if deferred is not None and rows >= 1024:
-                deferred.append((dl.index_select(0, c_map), y.index_select(0, a_map), gW[qq], V1, D))
+                # gathered into contiguous rows, zero-padded to whole 64-row k-tiles (the grouped launch then keeps its SGPR-offset DMA form)
+                rp = ceil_to(rows, 64)
+                gd = torch.empty(rp, dl.shape[-1], dtype=dl.dtype, device=dl.device)
+                gy = torch.empty(rp, y.shape[-1], dtype=y.dtype, device=y.device)
+                torch.index_select(dl, 0, c_map, out=gd[:rows])
+                torch.index_select(y, 0, a_map, out=gy[:rows])
+                if rp > rows:
+                    gd[rows:].zero_(); gy[rows:].zero_()
+                deferred.append((gd, gy, gW[qq], V1, D))
                 continue
             ops.gemm(dl, y, gW[qq], M=V1, N=D, K=rows, a_kmajor=True, b_kmajor=True, a_map=c_map, b_map=a_map,
                      Cin=gW[qq], lda=ldV, a_rows=dl.shape[0], b_rows=y.shape[0])
