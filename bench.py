@@ -251,6 +251,14 @@ def decode_leg(stage, dev, decode_ids):
     stage.generate(max_time_steps=50, **kw8)
     torch.cuda.synchronize()
     res["kv_cache_batch8_empty_context"] = round(8 * 50 * 3 / (time.perf_counter() - t1), 2)
+    kw16 = dict(clap_token_ids=torch.randint(0, 1024, (16, 12, 1), generator=g).to(dev),
+                semantic_token_ids=torch.randint(0, 1024, (16, 199), generator=g).to(dev), use_cache=True)
+    stage.generate(max_time_steps=2, **kw16)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    stage.generate(max_time_steps=50, **kw16)
+    torch.cuda.synchronize()
+    res["kv_cache_batch16_empty_context"] = round(16 * 50 * 3 / (time.perf_counter() - t1), 2)
     stage.train()
     return res
 
@@ -447,6 +455,8 @@ def main():
             progress(f"e2e generate leg: {out['legs']['e2e_generate']['ids_per_sec']} ids/s")
             out["legs"]["e2e_generate_b8"] = e2e_generate_leg(dev, batch=8)
             progress(f"e2e generate leg, 8 prompts: {out['legs']['e2e_generate_b8']['ids_per_sec']} ids/s")
+            out["legs"]["e2e_generate_b16"] = e2e_generate_leg(dev, batch=16)
+            progress(f"e2e generate leg, 16 prompts: {out['legs']['e2e_generate_b16']['ids_per_sec']} ids/s")
         print(json.dumps(out), flush=True)
     dp.barrier()
     dp.shutdown()

@@ -227,7 +227,7 @@ int omlm_sample_embed_at(const float* logits, const float* uniform_base, const i
  * round_bf16 = 1 rounds the activations the batched path keeps in bf16).  W1p [2*Fp, D] / W2p [D, Fp] / convw [3, 2*Fp] /
  * mid_gamma [Fp] are the padded layouts of omlm_ffmid_fwd.  emb_table (optional): x = emb_table[ids[b] + emb_row_offset]
  * first (open_musiclm.py:123-134); otherwise x must already hold the new row.  head_W (optional) [V1, D]: logits
- * [B, ldV] = LN(x_L) head_W^T.  B <= 8. */
+ * [B, ldV] = LN(x_L) head_W^T.  B <= 8; 16-bit weights with D = 1024 and ln_parts given: B <= 16 (matrix-core step kernels). */
 typedef struct omlm_decode_args {
     int B, D, H, L, F, Fp, Nmax, w_dtype, round_bf16, nsplit;     /* nsplit >= ceil(Nmax / 64): attention key ranges */
     float eps, scale;
@@ -247,7 +247,7 @@ typedef struct omlm_decode_args {
                                             * applies the next LayerNorm adds them up instead of re-reducing every sample's row; null:
                                             * every consumer reduces the rows itself */
 } omlm_decode_args;
-#define OMLM_DECODE_LN_PARTS(D, Fp) ((((D) + 15) / 16 > ((Fp) + 7) / 8 ? ((D) + 15) / 16 : ((Fp) + 7) / 8) * 16)
+#define OMLM_DECODE_LN_PARTS(D, Fp) ((((D) + 15) / 16 > ((Fp) + 7) / 8 ? ((D) + 15) / 16 : ((Fp) + 7) / 8) * 32)
 int omlm_decode_step(const omlm_decode_args* args, const long long* ids, void* stream);
 /* *pos_dev += 1, *step_dev += 1 (either may be null): keeps the row / sampler-step counters on the device so that a
  * captured step can be replayed. */

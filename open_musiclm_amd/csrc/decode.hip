@@ -29,6 +29,7 @@
 #define wave_max(x) wave_max_dpp(x)
 #endif
 #include <stdlib.h>
+#include <type_traits>
 
 namespace OMLM_NS {
 
@@ -165,6 +166,22 @@ __global__ __launch_bounds__(DEC_T) void dec_embed_kernel(const long long* __res
     float s = 0.f, q = 0.f;
     for (int i = threadIdx.x; i < D; i += DEC_T) { const float v = table[r * D + i]; x[(size_t)b * D + i] = v; s += v; q += v * v; }
     if (!stat_out) return;
+    s = wave_sum(s); q = wave_sum(q);
+    if ((threadIdx.x & 63) == 0) { red[2 * (threadIdx.x >> 6)] = s; red[2 * (threadIdx.x >> 6) + 1] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float ts = 0.f, tq = 0.f;
+        for (int w = 0; w < DEC_T / 64; ++w) { ts += red[2 * w]; tq += red[2 * w + 1]; }
+        stat_out[b * 2] = ts; stat_out[b * 2 + 1] = tq;
+    }
+}
+
+// (sum, sum of squares) of each sample's row of x as LayerNorm partial 0 (rows embedded by the caller)
+__global__ __launch_bounds__(DEC_T) void dec_rowstat_kernel(const float* __restrict__ x, int D, float* __restrict__ stat_out) {
+    __shared__ float red[2 * (DEC_T / 64)];
+    const int b = blockIdx.x;
+    float s = 0.f, q = 0.f;
+    for (int i = threadIdx.x; i < D; i += DEC_T) { const float v = x[(size_t)b * D + i]; s += v; q += v * v; }
     s = wave_sum(s); q = wave_sum(q);
     if ((threadIdx.x & 63) == 0) { red[2 * (threadIdx.x >> 6)] = s; red[2 * (threadIdx.x >> 6) + 1] = q; }
     __syncthreads();
@@ -907,35 +924,65 @@ __global__ __launch_bounds__(DEC4_T) void dec4_kernel(dec2_args a) {
             // row, the partials) is in flight together; the partials meet through LDS and every thread normalises its pieces straight from
             // registers -- no reduction over the rows, no fp32 staging copy
             constexpr int NCH = (NS + 7) / 8;
-            float4 v[NCH][NBR], gq[NCH];
+            constexpr int NB2 = NCH == 1 ? 16 : 8;                  // samples whose pieces a thread holds at once (register budget)
+            float4 v[NCH][NB2], gq[NCH];
+            auto load_half = [&](int h0) {
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) {
+                    const int i = threadIdx.x * 4 + ch * DEC4_T * 4;
+                    const bool in = i < K;
+#pragma unroll
+                    for (int b = 0; b < NB2; ++b)
+                        v[ch][b] = (in && h0 + b < B) ? *(const float4*)(a.in + (size_t)(h0 + b) * a.ldin + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            };
+            auto norm_half = [&](int h0) {
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) {
+                    const int i = threadIdx.x * 4 + ch * DEC4_T * 4;
+                    if (i >= K) break;
+                    const float4 g = gq[ch];
+#pragma unroll
+                    for (int b = 0; b < NB2; ++b) {
+                        if (h0 + b < B) {
+                            const float mean = stat[2 * (h0 + b)], rstd = stat[2 * (h0 + b) + 1];
+                            const float4 x = v[ch][b];
+                            u32x2 o;
+                            o[0] = pack_h16_rne((x.x - mean) * rstd * g.x, (x.y - mean) * rstd * g.y);
+                            o[1] = pack_h16_rne((x.z - mean) * rstd * g.z, (x.w - mean) * rstd * g.w);
+                            *(u32x2*)(xs + (size_t)(h0 + b) * KP + i) = o;
+                        }
+                    }
+                }
+            };
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
                 const int i = threadIdx.x * 4 + ch * DEC4_T * 4;
-                const bool in = i < K;
-                gq[ch] = in ? *(const float4*)(a.gamma + i) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int b = 0; b < NBR; ++b)
-                    v[ch][b] = (in && b < B) ? *(const float4*)(a.in + (size_t)b * a.ldin + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+                gq[ch] = i < K ? *(const float4*)(a.gamma + i) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            {   // lane = sample + 8 * slice, 32 slices per workgroup: all of a thread's partials requested at once (a rolled loop here
-                // was one L2 round trip per iteration: 43 of them for the FF-out launch)
-                constexpr int NPI = 11;                                  // <= 352 partials
-                const int b = lane & 7, sl = wave * 8 + (lane >> 3);
+            load_half(0);
+            // all of a thread's partials requested at once (a rolled loop here was one L2 round trip per iteration: 43 of them for the
+            // FF-out launch); lane = sample + SB * slice with SB = 8 (B <= 8: 32 slices per workgroup) or 16
+            auto reduce_parts = [&](auto sb_tag) {
+                constexpr int SB = decltype(sb_tag)::value, NSL = 256 / SB, NPI = (352 + NSL - 1) / NSL;
+                const int b = lane & (SB - 1), sl = wave * (64 / SB) + lane / SB;
                 float2 pv[NPI];
 #pragma unroll
                 for (int it = 0; it < NPI; ++it) {
-                    const int pi = sl + 32 * it;
-                    pv[it] = pi < a.nstat_in ? *(const float2*)(a.stat_in + (pi * 8 + b) * 2) : make_float2(0.f, 0.f);
+                    const int pi = sl + NSL * it;
+                    pv[it] = pi < a.nstat_in ? *(const float2*)(a.stat_in + (pi * DEC4_NB + b) * 2) : make_float2(0.f, 0.f);
                 }
                 float ps = 0.f, pq = 0.f;
 #pragma unroll
                 for (int it = 0; it < NPI; ++it) { ps += pv[it].x; pq += pv[it].y; }
 #pragma unroll
-                for (int m = 8; m < 64; m <<= 1) { ps += __shfl_xor(ps, m, 64); pq += __shfl_xor(pq, m, 64); }
-                if (lane < 8) { red[(lane * 4 + wave) * 2] = ps; red[(lane * 4 + wave) * 2 + 1] = pq; }
-            }
+                for (int m = SB; m < 64; m <<= 1) { ps += __shfl_xor(ps, m, 64); pq += __shfl_xor(pq, m, 64); }
+                if (lane < SB) { red[(lane * 4 + wave) * 2] = ps; red[(lane * 4 + wave) * 2 + 1] = pq; }
+            };
+            if (B <= 8) reduce_parts(std::integral_constant<int, 8>{});
+            else        reduce_parts(std::integral_constant<int, 16>{});
             __syncthreads();
-            if (threadIdx.x < 8) {
+            if (threadIdx.x < DEC4_NB) {
                 const int b = threadIdx.x;
                 float ps = 0.f, pq = 0.f;
                 for (int w = 0; w < 4; ++w) { ps += red[(b * 4 + w) * 2]; pq += red[(b * 4 + w) * 2 + 1]; }
@@ -943,23 +990,8 @@ __global__ __launch_bounds__(DEC4_T) void dec4_kernel(dec2_args a) {
                 stat[2 * b] = mean; stat[2 * b + 1] = rsqrtf(fmaxf(pq / (float)a.Kstat - mean * mean, 0.f) + a.eps);
             }
             __syncthreads();
-#pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) {
-                const int i = threadIdx.x * 4 + ch * DEC4_T * 4;
-                if (i >= K) break;
-                const float4 g = gq[ch];
-#pragma unroll
-                for (int b = 0; b < NBR; ++b) {
-                    if (b < B) {
-                        const float mean = stat[2 * b], rstd = stat[2 * b + 1];
-                        const float4 x = v[ch][b];
-                        u32x2 o;
-                        o[0] = pack_h16_rne((x.x - mean) * rstd * g.x, (x.y - mean) * rstd * g.y);
-                        o[1] = pack_h16_rne((x.z - mean) * rstd * g.z, (x.w - mean) * rstd * g.w);
-                        *(u32x2*)(xs + (size_t)b * KP + i) = o;
-                    }
-                }
-            }
+            norm_half(0);
+            if (B > NB2) { load_half(NB2); norm_half(NB2); }      // long rows (FF-out) at B > 8: the second eight samples in a second pass
         } else if (ln_rows) {
             float s8[NBR], q8[NBR];
 #pragma unroll
@@ -1010,17 +1042,18 @@ __global__ __launch_bounds__(DEC4_T) void dec4_kernel(dec2_args a) {
                 }
             }
         } else {
+            for (int h0 = 0; h0 < B; h0 += NBR)                 // (B > 8: the second eight samples in a second pass)
             for (int i = threadIdx.x * 4; i < K; i += DEC4_T * 4) {
                 float4 v[NBR];
 #pragma unroll
-                for (int b = 0; b < NBR; ++b) v[b] = b < B ? *(const float4*)(a.in + (size_t)b * a.ldin + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int b = 0; b < NBR; ++b) v[b] = h0 + b < B ? *(const float4*)(a.in + (size_t)(h0 + b) * a.ldin + i) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int b = 0; b < NBR; ++b) {
-                    if (b < B) {
+                    if (h0 + b < B) {
                         u32x2 o;
                         o[0] = pack_h16_rne(v[b].x, v[b].y);
                         o[1] = pack_h16_rne(v[b].z, v[b].w);
-                        *(u32x2*)(xs + (size_t)b * KP + i) = o;
+                        *(u32x2*)(xs + (size_t)(h0 + b) * KP + i) = o;
                     }
                 }
             }
@@ -1073,7 +1106,7 @@ __global__ __launch_bounds__(DEC4_T) void dec4_kernel(dec2_args a) {
                 float ps = 0.f, pq = 0.f;
                 for (int cc = 0; cc < 8; ++cc)
                     if (blockIdx.x * 8 + cc < a.Fp) { const float t = part[threadIdx.x * 8 + cc]; ps += t; pq += t * t; }
-                a.stat_out[(blockIdx.x * 8 + threadIdx.x) * 2] = ps; a.stat_out[(blockIdx.x * 8 + threadIdx.x) * 2 + 1] = pq;
+                a.stat_out[(blockIdx.x * DEC4_NB + threadIdx.x) * 2] = ps; a.stat_out[(blockIdx.x * DEC4_NB + threadIdx.x) * 2 + 1] = pq;
             }
         }
     } else if (MODE == DEC2_QKV) {
@@ -1101,7 +1134,7 @@ __global__ __launch_bounds__(DEC4_T) void dec4_kernel(dec2_args a) {
             if (threadIdx.x < B) {
                 float ps = 0.f, pq = 0.f;
                 for (int rr = 0; rr < DEC4_ROWS; ++rr) { const float t = part[threadIdx.x * DEC4_ROWS + rr]; ps += t; pq += t * t; }
-                a.stat_out[(blockIdx.x * 8 + threadIdx.x) * 2] = ps; a.stat_out[(blockIdx.x * 8 + threadIdx.x) * 2 + 1] = pq;
+                a.stat_out[(blockIdx.x * DEC4_NB + threadIdx.x) * 2] = ps; a.stat_out[(blockIdx.x * DEC4_NB + threadIdx.x) * 2 + 1] = pq;
             }
         }
         if (MODE == DEC2_LNGEMV && blockIdx.x == 0 && threadIdx.x == 0 && a.adv_pos) {      // see dec3_kernel
@@ -1114,7 +1147,7 @@ __global__ __launch_bounds__(DEC4_T) void dec4_kernel(dec2_args a) {
 template <int NS, int MODE>
 static void dec4_launch(const dec2_args& a, int grid, hipStream_t st) {
     const size_t lds = (((size_t)a.B * (a.K + 8) * 2 + 15) & ~(size_t)15) + (size_t)(DEC4_NB * 8 + DEC4_NB * 2 + 4 * 256 + 256) * sizeof(float) +
-                       (a.gamma ? (size_t)a.B * a.K * sizeof(float) : 0);
+                       ((a.gamma && !a.stat_in) ? (size_t)a.B * a.K * sizeof(float) : 0);      // fp32 staging copy: own-reduction path only (B <= 8)
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)dec4_kernel<NS, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     hipLaunchKernelGGL((dec4_kernel<NS, MODE>), dim3(grid), dim3(DEC4_T), lds, st, a);
@@ -1123,7 +1156,10 @@ static void dec4_launch(const dec2_args& a, int grid, hipStream_t st) {
 static bool dec4_ok(const omlm_decode_args& a) {
     static int off = -1;
     if (off < 0) { const char* e = getenv("OMLM_DECODE_MFMA"); off = (e && e[0] == '0') ? 1 : 0; }
-    return !off && a.B >= 2 && a.B <= 8 && a.D % 32 == 0 && a.D <= 1024 && (a.H * 64) % 32 == 0 && a.H * 64 <= 1024 &&
+    // B > 8: every LayerNorm in front of a matrix-core kernel must find its statistics in the producers' partials (the own-reduction
+    // path stages fp32 rows for at most 8 samples): a.ln_parts given
+    const bool wide_ok = a.B <= 8 || a.ln_parts != nullptr;
+    return !off && a.B >= 2 && a.B <= DEC4_NB && wide_ok && a.D % 32 == 0 && a.D <= 1024 && (a.H * 64) % 32 == 0 && a.H * 64 <= 1024 &&
            a.Fp % 32 == 0 && a.Fp <= 3072 && a.Fp % 8 == 0;
 }
 
@@ -1139,13 +1175,17 @@ static int decode_step2_t(const omlm_decode_args& a, const long long* ids, hipSt
     const bool mfma = sizeof(TW) == 2 && dec4_ok(a);              // 16-bit weights, B >= 2: the matrix-core step kernels
     // LayerNorm partial sums of the matrix-core kernels (see dec2_args::stat_in): three regions of a.ln_parts -- x (written by the embedding
     // gather and by every FF-out launch, read by the q rows and the head), x1 (to_out -> FF-in), u (FF-in -> FF-out)
-    const int npd = (D + DEC4_ROWS - 1) / DEC4_ROWS, npf = (Fp + 7) / 8, region = (npd > npf ? npd : npf) * 16;
+    const int npd = (D + DEC4_ROWS - 1) / DEC4_ROWS, npf = (Fp + 7) / 8, region = (npd > npf ? npd : npf) * 2 * DEC4_NB;
     float* st_x = (mfma && a.ln_parts) ? a.ln_parts : nullptr;
     float* st_x1 = st_x ? st_x + region : nullptr;
     float* st_u = st_x ? st_x + 2 * region : nullptr;
     int n_x = 0;                                                  // partials of x that are valid right now
     if (a.emb_table) {
         hipLaunchKernelGGL(dec_embed_kernel, dim3(B), dim3(DEC_T), 0, st, ids, a.emb_table, a.emb_row_offset, a.emb_rows, a.x, D, st_x);
+        n_x = 1;
+    } else if (st_x && B > DEC_BMAX) {
+        // the caller embedded the ids itself (sampler + gather kernel): one small launch leaves the rows' sums where the first q rows look for them
+        hipLaunchKernelGGL(dec_rowstat_kernel, dim3(B), dim3(DEC_T), 0, st, a.x, D, st_x);
         n_x = 1;
     }
     dec2_args g;
@@ -1275,11 +1315,13 @@ extern "C" int OMLM_API(omlm_decode_step)(const omlm_decode_args* a, const long 
 #else
     OMLM_CHECK_ARG(a->w_dtype == 1, "the fp16 copy serves fp16 weights only");
 #endif
-    OMLM_CHECK_ARG(a->B >= 1 && a->B <= DEC_BMAX, "decode batch must be 1..8 (use the batched forward beyond that)");
+    OMLM_CHECK_ARG(a->B >= 1 && a->B <= DEC4_NB, "decode batch must be 1..16");
+    OMLM_CHECK_ARG(a->B <= DEC_BMAX || (a->w_dtype != 0 && a->D == 1024 && dec4_ok(*a)),
+                   "decode batches of 9..16 run on the matrix-core kernels only: 16-bit weights, D = 1024, ln_parts given");
     OMLM_CHECK_ARG(a->D % 8 == 0 && a->Fp % 8 == 0 && a->pos_dev && a->parts, "decode geometry");
     OMLM_CHECK_ARG(a->H >= 1 && a->H <= 16 && (a->H * 64 + 128) % DEC_ROWS == 0, "heads");
     OMLM_CHECK_ARG(a->nsplit * DEC_KS >= a->Nmax, "nsplit must cover Nmax keys");
-    OMLM_CHECK_ARG((size_t)a->B * a->Fp * sizeof(float) + 1024 <= 150 * 1024, "B * Fp exceeds the LDS budget");
+    OMLM_CHECK_ARG(a->B > DEC_BMAX || (size_t)a->B * a->Fp * sizeof(float) + 1024 <= 150 * 1024, "B * Fp exceeds the LDS budget");
     OMLM_CHECK_ARG(!a->emb_table || ids, "ids required with an embedding table");
     static int v1 = -1;
     if (v1 < 0) { const char* e = getenv("OMLM_DECODE_V1"); v1 = (e && e[0] == '1') ? 1 : 0; }

@@ -14,7 +14,8 @@ counter advance; the row index lives on the device so that a step can be capture
 from __future__ import annotations
 
 import ctypes as C
-from typing import List, Sequence
+import os
+from typing import List, Optional, Sequence
 
 import torch
 
@@ -38,15 +39,26 @@ class DecodeArgs(C.Structure):
                 [(n, C.c_void_p) for n in ("x", "x1", "q", "parts", "u", "logits", "advance_pos", "advance_step", "ln_parts")])
 
 
-def supports(model, batch: int) -> bool:
+def max_batch(model, precision: str) -> int:
+    """Samples one decode call holds: 8 on the VALU step kernels; 16 where the matrix-core kernels serve the model (16-bit weights, dim 1024,
+    at most 16 heads, feed-forward width <= 3072: omlm_decode_step's own conditions)."""
     tr = model.transformer
-    return batch <= MAX_DECODE_BATCH and tr.non_causal_prefix_size == 0
+    inner = getattr(tr.layers[0][2], "inner_dim", 0) if len(tr.layers) else 0
+    wide = (precision in ("bf16", "fp16") and tr.dim == 1024 and tr.heads * engine.DIM_HEAD <= 1024 and 0 < engine.ceil_to(inner, 64) <= 3072
+            and os.environ.get("OMLM_DECODE_MFMA", "1") != "0")
+    return 16 if wide else MAX_DECODE_BATCH
+
+
+def supports(model, batch: int, precision: Optional[str] = None) -> bool:
+    tr = model.transformer
+    limit = max_batch(model, precision) if precision is not None else MAX_DECODE_BATCH
+    return batch <= limit and tr.non_causal_prefix_size == 0
 
 
 class CachedDecoder:
     def __init__(self, model, batch: int, max_rows: int, precision: str):
-        if batch > MAX_DECODE_BATCH:
-            raise ValueError(f"cached decode handles up to {MAX_DECODE_BATCH} samples per call; got {batch}")
+        if batch > max_batch(model, precision):
+            raise ValueError(f"cached decode handles up to {max_batch(model, precision)} samples per call here; got {batch}")
         self.model, self.B, self.Nmax, self.precision = model, batch, int(max_rows), precision
         tr = model.transformer
         dev = model.start_tokens[0].device
@@ -115,7 +127,7 @@ class CachedDecoder:
         for n in ("x", "x1", "q", "parts", "u", "logits"):
             setattr(a, n, getattr(self, n).data_ptr())
         # per-workgroup LayerNorm partial sums of the batched step kernels (OMLM_DECODE_LN_PARTS(D, Fp) floats x 3 producers)
-        self.ln_parts = torch.zeros(3 * max((a.D + 15) // 16, (a.Fp + 7) // 8) * 16, device=self.x.device)
+        self.ln_parts = torch.zeros(3 * max((a.D + 15) // 16, (a.Fp + 7) // 8) * 32, device=self.x.device)      # [partial][16 samples][2]
         a.ln_parts = self.ln_parts.data_ptr()
         self.args = a
 

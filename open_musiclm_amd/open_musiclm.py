@@ -197,8 +197,9 @@ class TokenConditionedTransformerWrapper(nn.Module):
             # the step kernels hold up to MAX_DECODE_BATCH samples per call: larger batches run as consecutive groups (samples are
             # independent; every group streams the weights once per id)
             pieces = []
-            for b0 in range(0, batch, decode.MAX_DECODE_BATCH):
-                b1 = min(batch, b0 + decode.MAX_DECODE_BATCH)
+            group = decode.max_batch(self.transformer, self.transformer._precision())
+            for b0 in range(0, batch, group):
+                b1 = min(batch, b0 + group)
                 dec = decode.CachedDecoder(self.transformer, b1 - b0, rows, self.transformer._precision())
                 last = dec.prefill([t[b0:b1] for t in cond] + [sampled[b0:b1]])
                 loop = decode.SamplingLoop(dec, last, U[:, b0:b1].contiguous(), n0, n_new, k, temperature, forbid, use_graph=use_graph)

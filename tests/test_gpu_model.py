@@ -347,17 +347,17 @@ def test_cached_decode_other_stages(golden_dir, dev, name, precision):
     assert err < TOL[precision]["logits"], err
 
 
-@pytest.mark.parametrize("precision,B", [("bf16", 1), ("bf16", 4), ("bf16", 8), ("fp16", 8), ("bf16x3", 3)])
+@pytest.mark.parametrize("precision,B", [("bf16", 1), ("bf16", 4), ("bf16", 8), ("fp16", 8), ("bf16x3", 3), ("bf16", 16), ("fp16", 11)])
 def test_cached_decode_at_full_width(dev, precision, B):
     """The step kernels the bench runs (dim 1024, 8 heads, F = 2730: dec3 at B = 1, the matrix-core dec4 kernels with their LayerNorm
-    partial sums at 2 <= B <= 8 in the 16-bit modes, the VALU dec2 kernels for fp32 weights) against the re-forward of the growing
+    partial sums at 2 <= B <= 16 in the 16-bit modes, the VALU dec2 kernels for fp32 weights) against the re-forward of the growing
     sequence: same bars as the batched forward itself."""
     from open_musiclm_amd import decode
     from open_musiclm_amd import open_musiclm as M
     from open_musiclm_amd.utils import append_eos_id
     torch.manual_seed(0)
     model = M.create_coarse_transformer(dim=1024, depth=2, heads=8, ff_dropout=0.0, num_coarse_quantizers=3, precision=precision).to(dev)
-    assert decode.supports(model, B)
+    assert decode.supports(model, B, precision)
     model.eval()
     wrapper = M.TokenConditionedTransformerWrapper(transformer=model, unique_consecutive=False)
     g = torch.Generator().manual_seed(3)
