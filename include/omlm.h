@@ -151,6 +151,10 @@ int omlm_cast_pad(const float* src, void* dst, long long R, int C, int ld_src, i
 /* dst[c, r] = cast(src[r, c]): k-contiguous W^T copies for the input-gradient GEMMs (the autograd transpose of
  * nn.Linear, transformer.py:203-212,144,149), refreshed once per optimizer step. */
 int omlm_transpose_cast(const float* src, void* dst, int R, int C, int ld_src, int ld_dst, int out_dtype, void* stream);
+/* The per-step weight re-packs of a model as ONE launch: problem i casts src [R, C] (pitch ld_src) into dst [R, ld_dst] with zero pad
+ * columns (omlm_cast_pad), or -- transpose != 0 -- writes dst[c, r] = src[r, c] (omlm_transpose_cast; pad entries untouched). */
+typedef struct omlm_cast_pad_desc { const float* src; void* dst; int R, C, ld_src, ld_dst, transpose, pad; } omlm_cast_pad_desc;
+int omlm_cast_pad_group(const omlm_cast_pad_desc* problems, int count, int out_dtype, void* stream);
 
 /* fp32-grade GEMM ("bf16x3") on bf16 hi/lo operand planes through the bf16 LDS-DMA tile kernels: A and B point at bf16 hi planes
  * laid out as omlm_gemm takes bf16 operands, the lo plane of each lies a_plane_bytes / b_plane_bytes behind it

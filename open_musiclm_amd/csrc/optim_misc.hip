@@ -1,5 +1,6 @@
 // Optimizer step, casts/repacks, small element-wise helpers, quantizer argmin and a hardware probe.
 #include "common.h"
+#include <string.h>
 #include <math.h>
 
 // ---------------------------------------------------------------------------------------------------------
@@ -124,6 +125,58 @@ extern "C" int omlm_transpose_cast(const float* src, void* dst, int R, int C, in
     else if (out_dtype == OMLM_DT_F16) hipLaunchKernelGGL(transpose_cast_kernel<f16_t>, grid, block, 0, as_stream(stream), src, (f16_t*)dst, R, C, ld_src, ld_dst);
     else hipLaunchKernelGGL(transpose_cast_kernel<h16_t>, grid, block, 0, as_stream(stream), src, (h16_t*)dst, R, C, ld_src, ld_dst);
     return omlm_post_launch("omlm_transpose_cast");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The per-step weight re-packs of a model (FF-in value / gate halves, FF-out rows at the padded pitch, conv taps transposed, padded
+// LayerNorm gammas: ~6 small launches per layer, 36 per coarse-small step) as ONE launch: problem i copies / casts src [R, C] (pitch
+// ld_src) to dst [R, ld_dst] with zero pad columns, or -- transpose set -- writes dst[c, r] = src[r, c] (pad untouched).
+#define OMLM_CAST_GROUP_MAX 64
+struct omlm_cast_pad_desc { const float* src; void* dst; int R, C, ld_src, ld_dst, transpose, pad; };            // include/omlm.h
+struct CastGroupArgs { int n; int start[OMLM_CAST_GROUP_MAX + 1]; omlm_cast_pad_desc d[OMLM_CAST_GROUP_MAX]; };
+template <typename T>
+__global__ __launch_bounds__(256) void cast_pad_group_kernel(CastGroupArgs ga) {
+    int pi = 0;
+    for (int i = 1; i < ga.n; ++i) if ((int)blockIdx.x >= ga.start[i]) pi = i;           // uniform scalar scan (starts ascend)
+    const omlm_cast_pad_desc q = ga.d[pi];
+    const int blk = blockIdx.x - ga.start[pi], nblk = ga.start[pi + 1] - ga.start[pi];
+    T* dst = (T*)q.dst;
+    if (q.transpose) {
+        for (long long e = (long long)blk * 256 + threadIdx.x; e < (long long)q.R * q.C; e += (long long)nblk * 256) {
+            const int r = (int)(e / q.C), c = (int)(e - (long long)r * q.C);
+            store_from_float(dst + (size_t)c * q.ld_dst + r, q.src[(size_t)r * q.ld_src + c]);
+        }
+    } else {
+        for (int r = blk; r < q.R; r += nblk)
+            for (int c = threadIdx.x; c < q.ld_dst; c += 256)
+                store_from_float(dst + (size_t)r * q.ld_dst + c, c < q.C ? q.src[(size_t)r * q.ld_src + c] : 0.f);
+    }
+}
+extern "C" int omlm_cast_pad_group(const omlm_cast_pad_desc* d, int count, int out_dtype, void* stream) {
+    if (count <= 0) return OMLM_OK;
+    OMLM_CHECK_ARG(d != nullptr, "null descriptor array");
+    OMLM_CHECK_ARG(out_dtype >= 0 && out_dtype <= 2, "out_dtype: 0 = fp32, 1 = bf16, 2 = fp16");
+    for (int base = 0; base < count; base += OMLM_CAST_GROUP_MAX) {
+        const int n = count - base < OMLM_CAST_GROUP_MAX ? count - base : OMLM_CAST_GROUP_MAX;
+        CastGroupArgs ga;
+        memset(&ga, 0, sizeof(ga));
+        ga.n = n;
+        int start = 0;
+        for (int i = 0; i < n; ++i) {
+            const omlm_cast_pad_desc& q = d[base + i];
+            OMLM_CHECK_ARG(q.src && q.dst && q.R > 0 && q.C > 0 && q.ld_src >= q.C && (q.transpose ? q.ld_dst >= q.R : q.ld_dst >= q.C), "cast_pad group: bad problem");
+            ga.d[i] = q;
+            ga.start[i] = start;
+            long long work = q.transpose ? ((long long)q.R * q.C + 255) / 256 : (long long)q.R;
+            int blocks = (int)(work < 1 ? 1 : (work > 1024 ? 1024 : work));
+            start += blocks;
+        }
+        ga.start[n] = start;
+        if (out_dtype == 0) hipLaunchKernelGGL(cast_pad_group_kernel<float>, dim3(start), dim3(256), 0, as_stream(stream), ga);
+        else if (out_dtype == OMLM_DT_F16) hipLaunchKernelGGL(cast_pad_group_kernel<f16_t>, dim3(start), dim3(256), 0, as_stream(stream), ga);
+        else hipLaunchKernelGGL(cast_pad_group_kernel<h16_t>, dim3(start), dim3(256), 0, as_stream(stream), ga);
+    }
+    return omlm_post_launch("omlm_cast_pad_group");
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -176,6 +176,7 @@ class PreparedWeights:
         # padded operand images are persistent per (layer, operand type): their pad rows / columns are zeroed once, a step only rewrites the
         # real entries (was: an 11 MB zero fill + ~10 small torch launches per layer per step)
         wbuf = model.__dict__.setdefault("_omlm_wbuf", {})
+        packs = ops.CastPadGroup()                 # every layer's re-packs leave as ONE launch at the end of this constructor
         for li, (attn, _, ff) in enumerate(tr.layers):
             F = ff.inner_dim
             Fp = ceil_to(F, 64)      # 128-byte aligned bf16 rows for h1 / dh1 (2*Fp pitch) and whole k-tiles for FF-out
@@ -192,9 +193,9 @@ class PreparedWeights:
                 wbuf[bkey] = (torch.zeros(2 * Fp, D, dtype=T, device=dev), torch.zeros(D, Fp, dtype=T, device=dev),
                               torch.zeros(3, 2 * Fp, dtype=T, device=dev), torch.zeros(Fp, dtype=T, device=dev))
             W1p, W2p, convp, gammap = wbuf[bkey]
-            ops.cast_pad(w1, W1p, F, D, D, D)
-            ops.cast_pad(w1[F:], W1p[Fp:], F, D, D, D)
-            ops.cast_pad(w2, W2p, D, F, F, Fp)
+            packs.add(w1.detach(), W1p, F, D, D, D)
+            packs.add(w1.detach()[F:], W1p[Fp:], F, D, D, D)
+            packs.add(w2.detach(), W2p, D, F, F, Fp)
             ent["W1p"], ent["W2p"], ent["F"], ent["Fp"] = W1p, W2p, F, Fp
             if T in _H16 and with_transposes:
                 # k-contiguous W^T copies: every input-gradient GEMM (dX = dY W) then runs in the fast NT form
@@ -214,9 +215,9 @@ class PreparedWeights:
             # taps [3, 2Fp] (identity taps for plain FeedForward) and the padded LN gamma travel in the operand dtype: they are
             # re-read for every row, and as fp32 they were 70 % of the L2->L1 bytes of the conv-GEGLU-LN kernels
             cw = ff.conv_weight().detach().reshape(2 * F, 3)                 # reference ds_conv.weight [2F, 1, 3] -> tap-major [3, 2Fp]
-            ops.transpose_cast(cw, convp, F, 3, 3, 2 * Fp)
-            ops.transpose_cast(cw[F:], convp[:, Fp:], F, 3, 3, 2 * Fp)
-            ops.cast_pad(ff.norm_mid.gamma.detach(), gammap, 1, F, F, Fp)
+            packs.add(cw, convp, F, 3, 3, 2 * Fp, transpose=True)
+            packs.add(cw[F:], convp[:, Fp:], F, 3, 3, 2 * Fp, transpose=True)
+            packs.add(ff.norm_mid.gamma.detach(), gammap, 1, F, F, Fp)
             ent["convw"], ent["gamma_mid"] = convp, gammap
             cache = ff.__dict__.setdefault("_omlm_cmap", {})
             if (F, Fp, str(dev)) not in cache:            # static scatter map: uploaded once (no H2D inside graph capture)
@@ -226,6 +227,7 @@ class PreparedWeights:
                 cache[(F, Fp, str(dev))] = cm.to(dev)
             ent["dW1_cmap"] = cache[(F, Fp, str(dev))]
             self.layers.append(ent)
+        packs.flush()
         self.heads = []
         self.headsT = []
         for w in model.logit_weights:

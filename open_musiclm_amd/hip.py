@@ -52,6 +52,7 @@ SIGNATURES = {
     "omlm_adamw_clip_step": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp, f32, i32, i32, i32, vp],
     "omlm_cast_pad": [vp, vp, i64, i32, i32, i32, i32, vp],
     "omlm_transpose_cast": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "omlm_cast_pad_group": [vp, i32, i32, vp],
     "omlm_sample_topk_gumbel_at": [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
     "omlm_sample_embed_at": [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, i64, i64, vp, i32, vp],
     "omlm_decode_step": [vp, vp, vp],

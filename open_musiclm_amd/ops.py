@@ -147,6 +147,40 @@ class WgradGroup:
         self.items = []
 
 
+class _CastDesc(C.Structure):
+    """omlm_cast_pad_desc (include/omlm.h)"""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("R", C.c_int), ("C", C.c_int), ("ld_src", C.c_int), ("ld_dst", C.c_int),
+                ("transpose", C.c_int), ("pad", C.c_int)]
+
+
+class CastPadGroup:
+    """Collects weight re-packs (cast_pad / transpose_cast problems with ONE output type) and issues them as one launch."""
+
+    def __init__(self):
+        self.items, self.dtype = [], None
+
+    def add(self, src, dst, R, C_, ld_src, ld_dst, transpose=False):
+        hip.require_gpu(src, "src")
+        assert src.dtype == torch.float32 and self.dtype in (None, dst.dtype), "fp32 sources, one output type per group"
+        self.dtype = dst.dtype
+        self.items.append((src, dst, int(R), int(C_), int(ld_src), int(ld_dst), int(bool(transpose))))
+
+    def flush(self):
+        n = len(self.items)
+        if n == 0:
+            return
+        if os.environ.get("OMLM_PACK_GROUP", "1") == "0":            # A/B lever: one launch per re-pack
+            for src, dst, R, C_, ld_src, ld_dst, tr in self.items:
+                (transpose_cast if tr else cast_pad)(src, dst, R, C_, ld_src, ld_dst)
+            self.items = []
+            return
+        arr = (_CastDesc * n)()
+        for d, (src, dst, R, C_, ld_src, ld_dst, tr) in zip(arr, self.items):
+            d.src, d.dst, d.R, d.C, d.ld_src, d.ld_dst, d.transpose, d.pad = ptr(src), ptr(dst), R, C_, ld_src, ld_dst, tr, 0
+        call("omlm_cast_pad_group", C.cast(arr, C.c_void_p), n, dcode(self.dtype), stream_ptr())
+        self.items = []
+
+
 def layernorm_fwd(x, gamma, y, xcast, mean, rstd, eps=1e-5):
     M, D = x.shape
     call("omlm_layernorm_fwd", ptr(x), ptr(gamma), ptr(y), ptr(xcast), ptr(mean), ptr(rstd),
