@@ -298,8 +298,13 @@ int attn3_bwd_dkv_launch(const void* q, const void* k, const void* v, const floa
     const size_t lds = (size_t)A3_NST * A3_STAGE;             // 48 KiB (the final transposes reuse it: 4 x 8448 B)
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)attn3_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    if (hipMemsetAsync(dk, 0, (size_t)B * N * 64 * sizeof(float), st) != hipSuccess) return OMLM_ERR_LAUNCH;
-    if (hipMemsetAsync(dv, 0, (size_t)B * N * 64 * sizeof(float), st) != hipSuccess) return OMLM_ERR_LAUNCH;
+    const size_t gbytes = (size_t)B * N * 64 * sizeof(float);
+    if ((char*)dv == (char*)dk + gbytes) {                    // one allocation (the host's usual case): one fill node instead of two
+        if (hipMemsetAsync(dk, 0, 2 * gbytes, st) != hipSuccess) return OMLM_ERR_LAUNCH;
+    } else {
+        if (hipMemsetAsync(dk, 0, gbytes, st) != hipSuccess) return OMLM_ERR_LAUNCH;
+        if (hipMemsetAsync(dv, 0, gbytes, st) != hipSuccess) return OMLM_ERR_LAUNCH;
+    }
     hipLaunchKernelGGL(attn3_bwd_dkv_kernel, dim3(B * wps), dim3(A3_T), lds, st, (const h16_t*)q, (const h16_t*)k, (const h16_t*)v, keymask,
                        (const h16_t*)dout, lse, delta, dk, dv, biasT, ldT, B, N, H, scale, CH, wps);
     return omlm_post_launch("omlm_mqa_attn_bwd");

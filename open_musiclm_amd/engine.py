@@ -506,8 +506,8 @@ def trunk_backward(tr, pw: PreparedWeights, saved, dy: torch.Tensor, B: int, N: 
         gWo = grad_of(attn.to_out[0].weight)
         wgrad(dx1_c, sv.o, gWo, D, H * DIM_HEAD)
         dq = torch.empty(M, H * DIM_HEAD, device=dev)
-        dk = torch.empty(M, DIM_HEAD, device=dev)
-        dv = torch.empty(M, DIM_HEAD, device=dev)
+        dkv = torch.empty(2, M, DIM_HEAD, device=dev)          # one allocation: the dK/dV kernel zero-fills both with one fill
+        dk, dv = dkv[0], dkv[1]
         delta = torch.empty(B, H, N, device=dev)
         ops.attn_bwd(sv.q, sv.k, sv.v, sv.abias, keymask, sv.o, do, sv.lse, delta, dq, dk, dv, dtable, B, N, H, ATTN_SCALE)
         if li == 0 and rp_async:
