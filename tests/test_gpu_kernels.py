@@ -260,6 +260,37 @@ def test_gemm_wgrad_group_at_bench_shape(ops, dev, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_cast_pad_group(ops, dev, dtype):
+    """The grouped weight re-pack (omlm_cast_pad_group) against torch: padded row copies with zero pad columns, sub-views with a storage
+    offset, transposed tap tables, a single-row gamma -- 70 problems, i.e. more than one launch of 64 descriptors."""
+    g = torch.Generator().manual_seed(4)
+    grp = ops.CastPadGroup()
+    checks = []
+    for i in range(14):
+        F, D = 37 + 3 * i, 24 + 8 * (i % 3)
+        Fp = (F + 7) // 8 * 8 + 8 * (i % 2)
+        w1 = torch.randn(2 * F, D, generator=g).to(dev)
+        W1p = torch.full((2 * Fp, D), 7.0, device=dev, dtype=dtype)
+        grp.add(w1, W1p, F, D, D, D)
+        grp.add(w1[F:], W1p[Fp:], F, D, D, D)
+        w2 = torch.randn(D, F, generator=g).to(dev)
+        W2p = torch.full((D, Fp), 7.0, device=dev, dtype=dtype)
+        grp.add(w2, W2p, D, F, F, Fp)
+        cw = torch.randn(2 * F, 3, generator=g).to(dev)
+        taps = torch.zeros(3, 2 * Fp, device=dev, dtype=dtype)
+        grp.add(cw, taps, F, 3, 3, 2 * Fp, transpose=True)
+        grp.add(cw[F:], taps[:, Fp:], F, 3, 3, 2 * Fp, transpose=True)
+        checks.append((w1, W1p, w2, W2p, cw, taps, F, Fp))
+    grp.flush()
+    for w1, W1p, w2, W2p, cw, taps, F, Fp in checks:
+        assert torch.equal(W1p[:F], w1[:F].to(dtype)) and torch.equal(W1p[Fp:Fp + F], w1[F:].to(dtype))
+        assert float((W1p[F:Fp] - 7.0).abs().max()) == 0.0                          # rows between the halves are not touched
+        assert torch.equal(W2p[:, :F], w2.to(dtype)) and float(W2p[:, F:].abs().max()) == 0.0     # pad columns zeroed
+        assert torch.equal(taps[:, :F], cw[:F].t().to(dtype)) and torch.equal(taps[:, Fp:Fp + F], cw[F:].t().to(dtype))
+        assert float(taps[:, F:Fp].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_layernorm_fwd_bwd(ops, dev, dtype):
     M, D = 333, 1024
     g = torch.Generator().manual_seed(1)
