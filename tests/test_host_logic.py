@@ -322,6 +322,37 @@ def test_wgrad_desc_layout_matches_header(tmp_path):
     assert out[1:] == [getattr(ops._WgradDesc, f).offset for f in fields]
 
 
+def test_cast_pad_desc_layout_matches_header(tmp_path):
+    """ctypes mirror of omlm_cast_pad_desc (the grouped weight re-pack) vs the C header (gcc)."""
+    import ctypes
+    import subprocess
+    from open_musiclm_amd import ops
+    fields = [f[0] for f in ops._CastDesc._fields_]
+    src = tmp_path / "cl.c"
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(ROOT, "include", "omlm.h")}"', 'int main(void) {',
+             '  printf("%zu\\n", sizeof(omlm_cast_pad_desc));']
+    lines += [f'  printf("%zu\\n", offsetof(omlm_cast_pad_desc, {f}));' for f in fields]
+    lines += ['  return 0; }']
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "cl"
+    subprocess.run(["gcc", "-std=c99", "-o", str(exe), str(src)], check=True)
+    out = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert out[0] == ctypes.sizeof(ops._CastDesc)
+    assert out[1:] == [getattr(ops._CastDesc, f).offset for f in fields]
+
+
+def test_decode_batch_limit_follows_the_kernels():
+    """decode.max_batch: 16 samples per call only where omlm_decode_step's matrix-core kernels serve the model (16-bit weights, dim 1024,
+    <= 16 heads, padded feed-forward width <= 3072); 8 everywhere else -- generate() groups larger batches accordingly."""
+    from open_musiclm_amd import decode
+    from open_musiclm_amd import open_musiclm as M
+    big = M.create_coarse_transformer(dim=1024, depth=1, heads=8, num_coarse_quantizers=3, precision="bf16")
+    small = M.create_coarse_transformer(dim=128, depth=1, heads=2, num_coarse_quantizers=3, precision="bf16")
+    assert decode.max_batch(big, "bf16") == 16 and decode.max_batch(big, "fp16") == 16
+    assert decode.max_batch(big, "bf16x3") == 8 and decode.max_batch(small, "bf16") == 8
+    assert decode.supports(big, 16, "bf16") and not decode.supports(big, 17, "bf16") and not decode.supports(big, 9)
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/scripts"), reason="reference checkout not present (GPU box)")
 @pytest.mark.parametrize("script", ["train_semantic_stage", "train_coarse_stage", "train_fine_stage", "train_clap_rvq",
                                     "train_hubert_kmeans", "preprocess_data"])
