@@ -133,7 +133,7 @@ class TrainLeg:
         ops_gemm, rec = ops.gemm, []
 
         def timed_gemm(A, B, C_, *, M, N, K, **kw):
-            if A.dtype == torch.float32 and ops._X3_PLANES and M * N * K >= ops._X3_MIN_MACS:
+            if A.dtype == torch.float32 and ops._X3_PLANES and kw.get("planes", True) and M * N * K >= ops._X3_MIN_MACS:
                 # bf16x3: the hi/lo plane split of the operands is its own (HBM-bound) kernel; the events bracket the GEMM launch
                 lda, ldb = kw.get("lda") or A.shape[-1], kw.get("ldb") or B.shape[-1]
                 ops.operand_planes(A, kw.get("a_rows") or A.numel() // lda, lda)
@@ -323,10 +323,26 @@ def main():
     ap.add_argument("--decode-ids", type=int, default=48)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU over RCCL; rank 0 prints the JSON line)
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("OMP_NUM_THREADS", "8")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        progress(f"no launcher environment: re-executing under torch.distributed.run with {args.gpus} ranks (port {port})")
+        sys.stdout.flush(); sys.stderr.flush()
+        os.execv(sys.executable, cmd)
+
     from open_musiclm_amd.parallel import DataParallel
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks "
+                         f"(use --nproc-per-node {args.gpus}, or run `python bench.py --gpus {args.gpus}` without a launcher)")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dev_index = local_rank % max(torch.cuda.device_count(), 1)       # == local_rank on a real node (one GPU per rank)
     torch.cuda.set_device(dev_index)
@@ -367,6 +383,9 @@ def main():
                    "global_batch": args.batch * world, "per_gpu_batch": args.batch, "grad_accum": args.accum,
                    "seq_len": N_SEQ, "parallelism": f"dp{world}", "precision": args.precision,
                    "hip_graph": main_leg.fb.graph is not None,
+                   "exchange": ("none (single GPU)" if world == 1 else
+                                f"one flat fp32 SUM all-reduce per step, torch.distributed backend {torch.distributed.get_backend()}"
+                                + (" -- DRY RUN: ranks share a GPU, not an RCCL / xGMI measurement" if dp.shared_gpu else " (RCCL over xGMI)")),
                    "parity": parity[args.precision] + " (tests/test_gpu_model.py)",
                    "tolerance_meeting_modes": "legs.fp16 (logits <= 1e-3 at ~1.02x this step: IEEE-half operands on the same matrix-core rate), "
                                               "legs.bf16x3 (fp32-grade, ~2.4x)"},

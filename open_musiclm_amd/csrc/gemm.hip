@@ -41,6 +41,9 @@
 
 namespace OMLM_NS {
 
+#ifndef OMLM_GEMM_TAIL_WAIT
+#define OMLM_GEMM_TAIL_WAIT 1
+#endif
 #define BM 128
 #define BN 128
 #define BK 64
@@ -635,6 +638,16 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, 
                     for (int j = 0; j < NJ; ++j) acc[i][j] = OMLM_MFMA_32x32x16(a[1][i], b[1][j], acc[i][j]);
             }
         }
+        // The last iteration issued its "next tile" DMA pieces with out-of-bounds offsets (`live` false): no memory traffic, but the
+        // hardware still writes their ZEROS into the other LDS stage -- the stage the epilogue below re-uses as its transpose patch
+        // (smem + 0 .. for an even k-tile count, e.g. K = 1024 / 512).  They are inline asm, i.e. invisible to hipcc's vmcnt
+        // bookkeeping, so without this wait nothing orders them before the epilogue's ds_writes: a late zero-fill wiped staged output
+        // values (round 3: intermittent 30-70 % error in the rel-pos MLP's gradient -- its GEMMs run on the second stream next to the
+        // trunk's HBM-bound kernels, whose traffic delays the pieces past the ~500 cycles the remaining MFMAs of a 128x128 tile take).
+        // -DOMLM_GEMM_TAIL_WAIT=0 rebuilds the old behaviour (tests/stress_gemm_tail.py reproduces the defect with it).
+#if OMLM_GEMM_TAIL_WAIT
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         __syncthreads();
         tile_epilogue<MI, NJ, WN_, TOUT>(g, acc, smem, m0, n0, wm, wn, wave, lane, dbg, bal || split);
         if (!bal || u >= u1) break;

@@ -38,6 +38,10 @@ _WGRAD_GROUP = os.environ.get("OMLM_WGRAD_GROUP", "1") == "1"      # grouped wei
 # nothing but the weights (forward) / the finished d(table) (backward), so they run on a second HIP stream, forked and joined with
 # events (captured as a parallel branch of the micro-step graph).  OMLM_RELPOS_ASYNC=0 puts them back in line.
 _RELPOS_ASYNC = os.environ.get("OMLM_RELPOS_ASYNC", "1") == "1"
+# The MLP's 0.3-GFLOP fp32 GEMMs stay on the register-staged fp32 kernel (csrc/gemm.hip gemm_kernel<float>): 42 us either way, and the
+# hi/lo plane route (ops.operand_planes: extra buffers + a cache shared with the trunk's stream) buys nothing at this size.
+# OMLM_RELPOS_PLANES=1: the plane route (what rounds 2-3 ran).
+_RELPOS_PLANES = os.environ.get("OMLM_RELPOS_PLANES", "0") == "1"
 # bf16 mode: d(LN output) leaves the input-gradient GEMMs as bf16 (fp32 accumulate, one rounding) instead of fp32 -- it is read once,
 # by the LayerNorm backward, and every other GEMM operand of that mode is rounded the same way.  OMLM_BF16_LN_GRAD=0: fp32 as before.
 _BF16_LN_GRAD = os.environ.get("OMLM_BF16_LN_GRAD", "1") == "1"
@@ -282,7 +286,7 @@ def relpos_forward(tr, n: int, save: bool):
     pres.append(pre); zs.append(z)
     for k in (1, 2):
         a = torch.empty(n, Hd, device=dev)
-        ops.gemm(zs[-1], lin[k].weight.detach(), a, M=n, N=Hd, K=Hd)
+        ops.gemm(zs[-1], lin[k].weight.detach(), a, M=n, N=Hd, K=Hd, planes=_RELPOS_PLANES)
         pre = torch.empty(n, Hd, device=dev)
         z = torch.empty(n, Hd, device=dev)
         ops.bias_silu_fwd(a, lin[k].bias.detach(), pre, z, n, Hd)
@@ -318,9 +322,9 @@ def relpos_backward(tr, n: int, saved, dtable: torch.Tensor):
         ops.silu_bwd(dz, pres[k], ds, n * Hd)
         ops.colsum_accumulate(ds, grad_of(lin[k].bias), n, Hd, Hd)
         gw = grad_of(lin[k].weight)
-        ops.gemm(ds, zs[k - 1], gw, M=Hd, N=Hd, K=n, a_kmajor=True, b_kmajor=True, Cin=gw)
+        ops.gemm(ds, zs[k - 1], gw, M=Hd, N=Hd, K=n, a_kmajor=True, b_kmajor=True, Cin=gw, planes=_RELPOS_PLANES)
         dz = torch.empty(n, Hd, device=dev)
-        ops.gemm(ds, lin[k].weight.detach(), dz, M=n, N=Hd, K=Hd, b_kmajor=True)
+        ops.gemm(ds, lin[k].weight.detach(), dz, M=n, N=Hd, K=Hd, b_kmajor=True, planes=_RELPOS_PLANES)
     ds = torch.empty(n, Hd, device=dev)
     ops.silu_bwd(dz, pres[0], ds, n * Hd)
     ops.colsum_accumulate(ds, grad_of(lin[0].bias), n, Hd, Hd)
@@ -390,6 +394,7 @@ def trunk_forward(tr, pw: PreparedWeights, x: torch.Tensor, keymask: Optional[to
         lse = torch.empty(B, H, N, device=dev)
         if side is not None:
             torch.cuda.current_stream(dev).wait_stream(side)
+            table.record_stream(torch.cuda.current_stream(dev))      # allocated under the side stream, read by the trunk's kernels
             side = None
         # the layer's bias table in the kernels' layout, with the fixed softmax reference point its scales allow
         # (fp16: the fixed reference point is an upper bound, so typical probabilities sit around 2^-12 of it -- at the edge of half's
@@ -428,6 +433,7 @@ def trunk_forward(tr, pw: PreparedWeights, x: torch.Tensor, keymask: Optional[to
         x = x2
     if side is not None:                                         # depth 0: nothing consumed the table
         torch.cuda.current_stream(dev).wait_stream(side)
+        table.record_stream(torch.cuda.current_stream(dev))
     mf = torch.empty(M, device=dev); rf = torch.empty(M, device=dev)
     y = torch.empty(M, D, dtype=T, device=dev)
     ops.layernorm_fwd(x, tr.norm.gamma.detach(), y, None, mf, rf)
@@ -514,7 +520,12 @@ def trunk_backward(tr, pw: PreparedWeights, saved, dy: torch.Tensor, B: int, N: 
             # d(table) is complete: the MLP's backward leaves for the second stream while the trunk finishes this layer and the
             # grouped weight gradients (dtable / saved["rp"] stay referenced until the join at the end of this function)
             rp_side = side_stream(dev)
+            for p_ in tr.rel_pos_bias.parameters():                # gradient buffers belong to the trunk's stream (allocated + zeroed
+                grad_of(p_)                                         # here, before the fork), whoever accumulates into them
             rp_side.wait_stream(torch.cuda.current_stream(dev))
+            dtable.record_stream(rp_side)
+            for p_ in tr.rel_pos_bias.parameters():
+                p_.grad.record_stream(rp_side)
             with torch.cuda.stream(rp_side):
                 relpos_backward(tr, N, saved["rp"], dtable)
         dq_raw = torch.empty(M, H * DIM_HEAD, dtype=T, device=dev)

@@ -89,8 +89,9 @@ def gemm(A: torch.Tensor, B: torch.Tensor, C_: torch.Tensor, *, M: int, N: int, 
          lda: Optional[int] = None, ldb: Optional[int] = None, ldc: Optional[int] = None,
          a_kmajor: bool = False, b_kmajor: bool = False, Cin: Optional[torch.Tensor] = None,
          ldcin: Optional[int] = None, a_map=None, b_map=None, c_map=None, alpha: float = 1.0,
-         a_rows: Optional[int] = None, b_rows: Optional[int] = None):
-    """C[m,n] = alpha * sum_k A(m,k) B(n,k) (+ Cin).  A, B share dtype (bf16 or fp32); C is fp32 or bf16."""
+         a_rows: Optional[int] = None, b_rows: Optional[int] = None, planes: bool = True):
+    """C[m,n] = alpha * sum_k A(m,k) B(n,k) (+ Cin).  A, B share dtype (bf16 or fp32); C is fp32 or bf16.
+    planes=False keeps fp32 operands on the register-staged kernel (no hi/lo plane buffers, no plane cache)."""
     hip.require_gpu(A, "A")
     assert A.dtype == B.dtype, (A.dtype, B.dtype)
     lda = lda if lda is not None else A.shape[-1]
@@ -101,7 +102,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, C_: torch.Tensor, *, M: int, N: int, 
         ldcin = ldcin if ldcin is not None else Cin.shape[-1]
     a_rows = a_rows if a_rows is not None else A.numel() // lda
     b_rows = b_rows if b_rows is not None else B.numel() // ldb
-    if (A.dtype == torch.float32 and _X3_PLANES and M * N * K >= _X3_MIN_MACS and not (a_kmajor and a_map is not None)
+    if (A.dtype == torch.float32 and planes and _X3_PLANES and M * N * K >= _X3_MIN_MACS and not (a_kmajor and a_map is not None)
             and not (b_kmajor and b_map is not None) and (a_kmajor and b_kmajor or K % 8 == 0)):
         pa, sa = operand_planes(A, a_rows, lda)
         pb, sb = operand_planes(B, b_rows, ldb)
@@ -217,6 +218,9 @@ def qk_norm_bwd(dq, dk, dv, q_raw, kv_raw, q_scale, k_scale, dq_raw, dkv_raw, dq
          ptr(dq_raw), ptr(dkv_raw), ptr(dq_scale), ptr(dk_scale), q_raw.shape[0], H, dcode(dq_raw.dtype), stream_ptr())
 
 
+_DBIAS_WS = {}
+
+
 class AttnBias:
     """Rel-pos bias table of one attention layer in the two layouts the kernels read: `table` [N, ld] fp32 (row = i - j,
     column = head) and `tableT`, its transposed / zero-padded / log2(e)-scaled form (omlm_attn_bias_prepare).
@@ -232,14 +236,18 @@ class AttnBias:
         self.tableT = torch.empty(int(hip.lib().omlm_attn_bias_table_floats(N, H)), device=dev)
         call("omlm_attn_bias_prepare", ptr(table), ptr(self.tableT), N, H, table.shape[-1] if table is not None else 0,
              ptr(q_scale), ptr(k_scale), float(qk_bound), float(scale), stream_ptr())
-        self._ws = None
 
     def dbias_workspace(self, B: int, N: int, H: int) -> torch.Tensor:
-        """Scratch for the backward's d(bias) partial rows (omlm_mqa_attn_bwd_workspace_bytes), shared by the layers of one step."""
+        """Scratch for the backward's d(bias) partial rows (omlm_mqa_attn_bwd_workspace_bytes): ONE buffer per device, shared by every
+        layer and every step (the reduction kernel of a layer consumes it before the next layer's dQ kernel writes it: stream order;
+        like _ln_workspace it assumes one backward at a time per device).  It is quadratic in N (B H ceil(N/32)^2 128 bytes: 40 MB at
+        B = 32, N = 1116), so one copy per layer was 24 x 53 MB for the musiclm_large leg."""
         n = int(hip.lib().omlm_mqa_attn_bwd_workspace_bytes(B, N, H)) // 4
-        if self._ws is None or self._ws.numel() < n:
-            self._ws = torch.empty(n, device=self.tableT.device, dtype=torch.float32)
-        return self._ws
+        key = str(self.tableT.device)
+        ws = _DBIAS_WS.get(key)
+        if ws is None or ws.numel() < n:
+            ws = _DBIAS_WS[key] = torch.empty(n, device=self.tableT.device, dtype=torch.float32)
+        return ws
 
 
 def _attn_bias(bias, N, H, device) -> "AttnBias":

@@ -9,6 +9,7 @@ Validation-only collectives (scalar mean, all-gather of predictions) mirror trai
 from __future__ import annotations
 
 import os
+import sys
 from typing import Optional
 
 import torch
@@ -21,6 +22,7 @@ class DataParallel:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.owns_group = False
+        self.shared_gpu = False
         if self.world_size > 1 and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
@@ -29,7 +31,18 @@ class DataParallel:
                 # one GPU per rank; a rank count above the visible GPUs (dry runs of the multi-process path on a 1-GPU box,
                 # gloo exchange) shares devices round-robin -- RCCL itself refuses two ranks on one GPU
                 torch.cuda.set_device(self.local_rank % max(torch.cuda.device_count(), 1))
-            backend = backend or os.environ.get("OMLM_DP_BACKEND") or ("nccl" if use_cuda else "gloo")
+            backend = backend or os.environ.get("OMLM_DP_BACKEND")
+            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", self.world_size))
+            self.shared_gpu = bool(use_cuda and local_world > torch.cuda.device_count())
+            if backend is None:
+                backend = "nccl" if use_cuda else "gloo"
+                if self.shared_gpu:
+                    # more local ranks than visible GPUs: a dry run of the multi-process path (RCCL refuses two ranks on one device)
+                    backend = "gloo"
+                    if self.rank == 0:
+                        print(f"open_musiclm_amd.parallel: {self.world_size} ranks on {torch.cuda.device_count()} visible GPU(s) -- "
+                              "ranks share devices and exchange through gloo (a dry run of the data-parallel path, not an RCCL measurement)",
+                              file=sys.stderr, flush=True)
             # HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC; the HSA runtime reads it when it initialises) is exported at package import
             # (open_musiclm_amd/__init__.py): too late here, the model is already on the GPU.  Fail loudly if something overrode it.
             if backend == "nccl" and os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0") != "0":

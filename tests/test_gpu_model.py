@@ -799,6 +799,27 @@ def test_bench_two_rank_dry_run_on_one_gpu(dev):
     assert "legs" not in out and "cpu_baseline" not in out
 
 
+def test_bench_self_launches_without_a_launcher(dev):
+    """`python bench.py --gpus 2 ...` with NO launcher environment (the form the round-3 driver used): bench.py re-executes itself under
+    torch.distributed.run; on this 1-GPU box the ranks share cuda:0 and DataParallel falls back to gloo by itself (and says so in the line)."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "OMLM_DP_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-legs", "--batch", "2"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
+    if torch.cuda.device_count() < 2:
+        assert "DRY RUN" in out["config"]["exchange"] and "gloo" in out["config"]["exchange"]
+    else:
+        assert "nccl" in out["config"]["exchange"]
+    assert np.isfinite(out["final_loss"])
+
+
 @pytest.mark.parametrize("use_cache", [True, False])
 def test_musiclm_forward_matches_reference_golden_tokens(golden_dir, dev, monkeypatch, use_cache):
     """MusicLM.forward (open_musiclm.py:864-1035 of the reference) token-level parity: the reference ran on tiny stages with
