@@ -25,12 +25,9 @@ sys.path.insert(0, ROOT)
 from open_musiclm_amd import hip, ops            # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--iters", type=int, default=300)
-    ap.add_argument("--burst", type=int, default=12)
-    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "stress_gemm_tail.json"))
-    args = ap.parse_args()
+def run(iters=300, burst=12):
+    import types
+    args = types.SimpleNamespace(iters=iters, burst=burst)
     dev = torch.device("cuda:0")
     hip.lib()
     g = torch.Generator().manual_seed(0)
@@ -102,6 +99,16 @@ def main():
     res = dict(lib=hip.LIB_PATH, iters=args.iters, burst=args.burst, seconds=round(time.time() - t0, 1),
                cases=[{k: c[k] for k in ("name", "launches", "bad_launches", "bad_elems", "zeroed_elems")} for c in cases])
     res["bad_launches_total"] = sum(c["bad_launches"] for c in cases)
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=300)
+    ap.add_argument("--burst", type=int, default=12)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "stress_gemm_tail.json"))
+    args = ap.parse_args()
+    res = run(args.iters, args.burst)
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     json.dump(res, open(args.out, "w"), indent=1)
     print(json.dumps(res, indent=1))

@@ -54,9 +54,13 @@ def report(name, **metrics):
     json.dump(data, open(REPORT, "w"), indent=1, default=float)
 
 
-def relerr(a, b):
+def relerr(a, b, floor=0.0):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
-    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+    return float((a - b).abs().max() / max(float(b.abs().max()), floor, 1e-30))
+
+
+RELPOS_TENSORS = [f"transformer.rel_pos_bias.net.{i}.0.{wb}" for i in range(3) for wb in ("weight", "bias")] + \
+                 ["transformer.rel_pos_bias.net.3.weight", "transformer.rel_pos_bias.net.3.bias"]
 
 
 def rel_l2(a, b):
@@ -433,6 +437,8 @@ def test_full_size_coarse_small_vs_oracle(dev, precision):
                                              "transformer.rel_pos_bias.net.1.0.weight",
                                              "transformer.layers.3.0.to_kv.weight",
                                              "transformer.layers.2.2.2.ds_conv.weight")) for k, v in sd.items()}
+    for k in RELPOS_TENSORS:                      # every tensor of the rel-pos MLP (round 3's defect lived in one of eight, and one was checked)
+        sdo[k].requires_grad_(True)
     o_loss, o_logits, _ = O.wrapper_forward_loss(sdo, spec, ids, [0., 0., 1.], forget_noise=noise)
     names = [k for k, v in sdo.items() if v.requires_grad]
     o_grads = dict(zip(names, torch.autograd.grad(o_loss, [sdo[k] for k in names])))
@@ -452,7 +458,11 @@ def test_full_size_coarse_small_vs_oracle(dev, precision):
     e_l2 = rel_l2(logits[-1], o_logits[-1])
     e_loss = abs(float(loss) - float(o_loss)) / float(o_loss)
     top1 = float((logits[-1].argmax(1).cpu() == o_logits[-1].argmax(1)).float().mean())
-    g = {k: relerr(dict(model.named_parameters())[k].grad * grad_unscale(precision), o_grads[k]) for k in names}
+    gmax = max(float(v.abs().max()) for v in o_grads.values())
+    # the MLP's biases are near-invariant directions (a per-head constant of the bias cancels in the softmax: their gradients are 1e-3 of
+    # the weights'), judged against 1e-2 of the largest gradient instead of their own size
+    g = {k: relerr(dict(model.named_parameters())[k].grad * grad_unscale(precision), o_grads[k],
+                   floor=1e-2 * gmax if (k in RELPOS_TENSORS and k.endswith("bias")) else 0.0) for k in names}
     print(g)
     report(f"full_coarse_small[{precision}]", logits_inf=e_inf, logits_l2=e_l2, loss=e_loss, top1_agree=top1, grads=g,
            loss_value=float(loss))
@@ -460,6 +470,56 @@ def test_full_size_coarse_small_vs_oracle(dev, precision):
     assert e_inf < tol["logits"], (e_inf, e_l2)
     assert e_loss < tol["loss"]
     assert max(g.values()) < tol["grad"], g
+
+
+@pytest.mark.parametrize("precision,bar", [("bf16x3", 1e-5), ("bf16", 2e-2)])
+def test_full_size_backward_is_reproducible(dev, precision, bar):
+    """Ten forward + backward passes of the full-size coarse step on the same inputs: every rel-pos gradient and three trunk gradients
+    agree run to run.  fp32-operand mode: to the order-of-addition noise of the fp32 atomics (split-K / d(bias) / dK, dV: ~1e-7); bf16
+    mode: that noise passes through bf16 roundings of dK / dV / dq (one flipped 2^-9 ulp somewhere upstream) and reaches ~2e-3 of a
+    tensor's largest entry (measured by tests/hammer_relpos.py) -- the bar is 10x that, far below round 3's 30-70 % defect."""
+    from open_musiclm_amd import open_musiclm as M
+    from oracle import musiclm_oracle as O
+    torch.manual_seed(0)
+    model = M.create_coarse_transformer(dim=1024, depth=6, heads=8, num_coarse_quantizers=3, ff_dropout=0.0, precision=precision).to(dev)
+    spec = O.coarse_spec(dim=1024, depth=6, heads=8)
+    ids = [t.to(dev) for t in O.synthetic_ids(spec, 2, [1, 199, 300], seed=1234)]
+    wrapper = M.TokenConditionedTransformerWrapper(transformer=model, unique_consecutive=False, cross_entropy_loss_weights=[0., 0., 1.],
+                                                   mask_prob=0.0)
+    wrapper.train()
+    names = RELPOS_TENSORS + ["transformer.layers.0.2.1.weight", "transformer.layers.5.0.to_q.weight", "transformer.layers.3.0.to_kv.weight"]
+    params = dict(model.named_parameters())
+    first, worst = None, 0.0
+    for rep in range(10):
+        for p in model.parameters():
+            p.grad = None
+        if rep % 3 == 2:                     # recycled, non-zero memory for every torch.empty of the step
+            junk = [torch.full((n,), float("nan"), device=dev) for n in (571392, 1142784, 262144, 1 << 22, 1 << 24)]
+            del junk
+        loss, _, _ = wrapper(all_token_ids=ids, return_loss=True)
+        loss.backward()
+        got = {k: params[k].grad.detach().clone() for k in names}
+        if first is None:
+            first = got
+            gmax = max(float(v.abs().max()) for v in got.values())
+            continue
+        for k in names:
+            worst = max(worst, relerr(got[k], first[k], floor=1e-2 * gmax))
+    report(f"backward_reproducible[{precision}]", worst_run_to_run=worst)
+    assert worst < bar, worst
+
+
+def test_gemm_epilogue_survives_concurrent_streams(dev):
+    """The GEMM tail race of round 3: non-split GEMMs launched on a second stream next to HBM-bound copies must
+    return bit for bit what the same launch returns on an idle GPU (tests/stress_gemm_tail.py; the library built with
+    -DOMLM_GEMM_TAIL_WAIT=0 fails ~45 % of these launches, profiles/r04_stress_gemm_tail_unfixed.json)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("stress_gemm_tail", os.path.join(ROOT, "tests", "stress_gemm_tail.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.run(iters=150, burst=10)
+    report("gemm_tail_stress", **{c["name"]: c["bad_launches"] for c in res["cases"]})
+    assert res["bad_launches_total"] == 0, res["cases"]
 
 
 @pytest.mark.parametrize("stage,lengths,N,kw", [("semantic", [1, 499], 514, {}),
@@ -517,7 +577,7 @@ def _large_fine(dev, depth, precision, with_grads):
     N = 1817
     noise = torch.randn(1, N, generator=torch.Generator().manual_seed(13))
     gnames = ["transformer.layers.0.0.to_q.weight", f"transformer.layers.{depth - 1}.2.1.weight", "logit_weights.2",
-              "transformer.rel_pos_bias.net.2.0.weight", "transformer.layers.0.0.to_kv.weight"] if with_grads else []
+              "transformer.layers.0.0.to_kv.weight"] + [k for k in RELPOS_TENSORS if k.endswith("weight")] if with_grads else []
     if depth not in _LARGE_ORACLE:                   # same seed -> same weights for both precisions: one oracle run per depth
         sdo = {k: v.clone().requires_grad_(k in gnames) for k, v in sd.items()}
         with torch.set_grad_enabled(with_grads):
