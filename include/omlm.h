@@ -144,7 +144,15 @@ int omlm_sumsq_accumulate(const float* g, long long n, float* out, float* partia
 int omlm_adamw_clip_step(float* p, float* g, float* m, float* v, void* p16, long long n,
                          float lr, float beta1, float beta2, float eps, float wd, int step,
                          float gscale, const float* gnorm_sq, float max_norm, int decoupled, int zero_grad, int p16_dtype,
-                         void* stream);   /* p16 (optional): 16-bit shadow of p in p16_dtype (1 bf16 / 2 fp16); a non-finite *gnorm_sq skips the update */
+                         const float* ls_state, void* stream);
+/* p16 (optional): 16-bit shadow of p in p16_dtype (1 bf16 / 2 fp16); a non-finite *gnorm_sq skips the update (gradients still cleared).
+   ls_state (optional, precision "fp16"): 4 floats on the device {loss scale, good steps since its last change, skipped steps, applied
+   steps}: gradients are divided by ls_state[0] and the bias corrections use step = ls_state[3] + 1 instead of `step`. */
+/* after the last parameter group of a step: non-finite *gnorm_sq -> scale = max(scale * backoff, scale_min), skipped += 1; else applied += 1
+   and after `interval` consecutive good steps scale = min(scale * growth, scale_max).  (No reference counterpart: the reference trains in
+   fp32, trainer.py:444-447; this is torch.cuda.amp.GradScaler's rule kept on the device so that the captured step never reads the norm.) */
+int omlm_loss_scale_update(float* ls_state, const float* gnorm_sq, float growth, float backoff, int interval,
+                           float scale_min, float scale_max, void* stream);
 
 /* operand casts / weight repack */
 int omlm_cast_pad(const float* src, void* dst, long long R, int C, int ld_src, int ld_dst, int out_dtype, void* stream);

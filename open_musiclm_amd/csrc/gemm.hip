@@ -423,15 +423,33 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16 (&acc)[M
             }
         return;
     }
+    constexpr int NP = 32 / RPP;                                   // passes per 32-row strip
+    const bool cin_pref = g.Cin != nullptr && vec_ok && g.c_map == nullptr;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
+        // Residual (Cin) pieces of the whole strip are requested BEFORE the LDS transposition: one memory round trip per strip, hidden
+        // behind the ds_write / ds_read pass.  (Round 4: with the loads inside the pass loop -- behind its row / column early-outs -- every
+        // pass waited for its own piece: 32 dependent round trips per 256x256 tile, to_out (K = 512) 130 us against a 60 us HBM floor at
+        // every tile size, FF-out ~80 us of epilogue.)
+        float4 cinv[NP][VEC / 4];
+        if (cin_pref) {
+#pragma unroll
+            for (int pass = 0; pass < NP; ++pass) {
+                const int r = pass * RPP + lane / LPR, c = (lane % LPR) * VEC;
+                const int row = m0 + wm + 32 * i + r, col = n0 + wn + c;
+                const bool ok = row < g.M && col + VEC <= g.N;
+                const float* src = g.Cin + (long long)(ok ? row : 0) * g.ldcin + (ok ? col : 0);
+#pragma unroll
+                for (int x = 0; x < VEC / 4; ++x) cinv[pass][x] = *(const float4*)(src + 4 * x);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e)
                 stg[((e & 3) + 8 * (e >> 2) + 4 * hi) * SROW + 32 * j + (lane & 31)] = g.alpha * acc[i][j][e];
 #pragma unroll
-        for (int pass = 0; pass < 32 / RPP; ++pass) {
+        for (int pass = 0; pass < NP; ++pass) {
             const int r = pass * RPP + lane / LPR, c = (lane % LPR) * VEC;
             const int row = m0 + wm + 32 * i + r, col = n0 + wn + c;
             float v[VEC];
@@ -444,7 +462,13 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16 (&acc)[M
             const long long prow = g.c_map ? (long long)g.c_map[row] : (long long)row;
             if (prow < 0) continue;
             if (vec_ok && col + VEC <= g.N) {
-                if (g.Cin) {
+                if (cin_pref) {
+#pragma unroll
+                    for (int x = 0; x < VEC; x += 4) {
+                        const float4 t = cinv[pass][x / 4];
+                        v[x] += t.x; v[x + 1] += t.y; v[x + 2] += t.z; v[x + 3] += t.w;
+                    }
+                } else if (g.Cin) {
 #pragma unroll
                     for (int x = 0; x < VEC; x += 4) {
                         const float4 t = *(const float4*)(g.Cin + prow * g.ldcin + col + x);

@@ -50,15 +50,24 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
                                                     float* __restrict__ v, T16* __restrict__ p16, long long n,
                                                     float lr, float beta1, float beta2, float eps, float wd,
                                                     float bc1, float bc2_sqrt, float gscale, const float* __restrict__ gnorm_sq,
-                                                    float max_norm, int decoupled, int zero_grad) {
+                                                    float max_norm, int decoupled, int zero_grad, const float* __restrict__ ls_state) {
+    // ls_state (precision "fp16", optional): {loss scale, good steps since its last change, skipped steps, applied steps}, all on the
+    // device: the backward multiplied the loss gradient by ls_state[0] (engine.LossFunction), this kernel divides it out, and the bias
+    // corrections count APPLIED steps (ls_state[3] + 1), so a skipped step leaves the Adam clock where it was.
+    if (ls_state) {
+        gscale /= ls_state[0];
+        const double t = (double)ls_state[3] + 1.0;
+        bc1 = (float)(1.0 - pow((double)beta1, t));
+        bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, t));
+    }
     float clip = 1.0f;
     if (gnorm_sq && max_norm > 0.f) {
         const float nrm = sqrtf(gnorm_sq[0]) * gscale;
         clip = fminf(1.0f, max_norm / (nrm + 1e-6f));
     }
     // A non-finite gradient norm (an fp16 operand overflowed somewhere in the backward) must not reach the weights or the moments:
-    // the step is skipped on the device -- gradients are still cleared, the 16-bit shadow stays current -- and the host lowers its
-    // loss scale when it next reads the norm (optimizer.FusedAdam.step, precision "fp16").
+    // the step is skipped on the device -- gradients are still cleared, the 16-bit shadow stays current -- and omlm_loss_scale_update
+    // (launched by the host after the last parameter group) halves the loss scale.
     const bool skip = gnorm_sq && !(gnorm_sq[0] < 3.0e38f);
     const float gs = gscale * clip;
     const float step = lr / bc1;
@@ -78,7 +87,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
 extern "C" int omlm_adamw_clip_step(float* p, float* g, float* m, float* v, void* p16, long long n,
                                     float lr, float beta1, float beta2, float eps, float wd, int step,
                                     float gscale, const float* gnorm_sq, float max_norm, int decoupled, int zero_grad,
-                                    int p16_dtype, void* stream) {
+                                    int p16_dtype, const float* ls_state, void* stream) {
     if (n <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(p && g && m && v && step >= 1, "adamw arguments");
     OMLM_CHECK_ARG(!p16 || p16_dtype == OMLM_DT_BF16 || p16_dtype == OMLM_DT_F16, "p16_dtype: 1 = bf16, 2 = fp16");
@@ -86,11 +95,31 @@ extern "C" int omlm_adamw_clip_step(float* p, float* g, float* m, float* v, void
     long long blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
     if (p16 && p16_dtype == OMLM_DT_F16)
         hipLaunchKernelGGL(adamw_kernel<f16_t>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), p, g, m, v, (f16_t*)p16, n,
-                           lr, beta1, beta2, eps, wd, bc1, bc2, gscale, gnorm_sq, max_norm, decoupled, zero_grad);
+                           lr, beta1, beta2, eps, wd, bc1, bc2, gscale, gnorm_sq, max_norm, decoupled, zero_grad, ls_state);
     else
         hipLaunchKernelGGL(adamw_kernel<h16_t>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), p, g, m, v, (h16_t*)p16, n,
-                           lr, beta1, beta2, eps, wd, bc1, bc2, gscale, gnorm_sq, max_norm, decoupled, zero_grad);
+                           lr, beta1, beta2, eps, wd, bc1, bc2, gscale, gnorm_sq, max_norm, decoupled, zero_grad, ls_state);
     return omlm_post_launch("omlm_adamw_clip_step");
+}
+
+// Dynamic loss scale of precision "fp16", entirely on the device (no host read of the norm): after the parameter groups of a step,
+// a non-finite norm halves the scale (the step was skipped by adamw_kernel), `interval` consecutive good steps double it.
+__global__ void loss_scale_update_kernel(float* st, const float* __restrict__ gnorm_sq, float growth, float backoff, float interval,
+                                         float smin, float smax) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (!(gnorm_sq[0] < 3.0e38f)) { st[0] = fmaxf(st[0] * backoff, smin); st[1] = 0.f; st[2] += 1.f; }
+    else {
+        st[3] += 1.f; st[1] += 1.f;
+        if (interval > 0.f && st[1] >= interval) { st[0] = fminf(st[0] * growth, smax); st[1] = 0.f; }
+    }
+}
+extern "C" int omlm_loss_scale_update(float* ls_state, const float* gnorm_sq, float growth, float backoff, int interval,
+                                      float scale_min, float scale_max, void* stream) {
+    OMLM_CHECK_ARG(ls_state && gnorm_sq && growth >= 1.f && backoff > 0.f && backoff <= 1.f && scale_min > 0.f && scale_max >= scale_min,
+                   "loss_scale_update arguments");
+    hipLaunchKernelGGL(loss_scale_update_kernel, dim3(1), dim3(64), 0, as_stream(stream), ls_state, gnorm_sq, growth, backoff, (float)interval,
+                       scale_min, scale_max);
+    return omlm_post_launch("omlm_loss_scale_update");
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -403,16 +432,25 @@ __global__ __launch_bounds__(64) void sample_kernel(const float* __restrict__ lo
     const float* lr = logits + (size_t)row * ld;
     const float* ur = uniform + (size_t)row * V;
     unsigned keys[SAMPLE_NV];
-    float lv[SAMPLE_NV];
+    float lv[SAMPLE_NV], uv[SAMPLE_NV];
+    const int nv = (V + 63) >> 6;                      // live register slots (uniform)
+    // every load of the row -- logits AND uniforms -- is requested before anything waits.  (Round 4 kernel trace: 43.9 us per call at
+    // B = 1, a quarter of a decode step: the uniforms were loaded inside `if (keep)`, one dependent memory round trip per register
+    // slot, 17 in a row behind the running arg-max.)
 #pragma unroll
     for (int j = 0; j < SAMPLE_NV; ++j) {
         const int c = lane + 64 * j;
-        float v = c < V ? lr[c] : -INFINITY;
+        lv[j] = (j < nv && c < V) ? lr[c] : -INFINITY;
+        uv[j] = (j < nv && c < V) ? ur[c] : 0.5f;
+    }
+#pragma unroll
+    for (int j = 0; j < SAMPLE_NV; ++j) {
+        const int c = lane + 64 * j;
+        float v = lv[j];
         if (forbid_last && c == V - 1) v = -INFINITY;
         lv[j] = v;
         keys[j] = c < V ? f_ord(v) : 0u;               // 0 sorts below every real key (f_ord(-inf) = 0x007fffff)
     }
-    const int nv = (V + 63) >> 6;                      // live register slots (uniform)
     // largest threshold t such that count(keys >= t) >= k
     unsigned t = 0;
     for (int bit = 31; bit >= 0; --bit) {
@@ -444,7 +482,7 @@ __global__ __launch_bounds__(64) void sample_kernel(const float* __restrict__ lo
             const bool keep = in && (keys[j] > t || (eq && rank < n_equal_keep));
             seen_eq += __popcll(eqmask);
             if (keep) {
-                const float u = ur[c];
+                const float u = uv[j];
                 const float gum = -logf(-logf(u + 1e-20f) + 1e-20f);
                 const float v = lv[j] / temperature + gum;
                 if (v > best) { best = v; besti = c; }

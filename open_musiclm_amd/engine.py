@@ -66,27 +66,52 @@ def default_precision() -> str:
     return p
 
 
-def loss_scale(precision: str) -> float:
-    """Factor the backward of `precision` multiplies the loss gradient by.  1 except for "fp16", where gradients would fall below
-    half's range (the non-target logit gradients of a 28 k-token batch are ~3e-8; the smallest normal half is 6e-5): a static power
-    of two ($OMLM_FP16_LOSS_SCALE, default 4096).  Parameter gradients (param.grad, the optimizer's flat buffer) then carry that
-    factor; FusedAdam.step divides it out inside its kernel and skips a step whose gradient norm overflowed; anything else that
-    reads param.grad in this mode divides by engine.loss_scale("fp16") (unscale_grads_)."""
+def loss_scale_initial() -> float:
+    return float(os.environ.get("OMLM_FP16_LOSS_SCALE", "4096"))
+
+
+def loss_scale_state(model) -> torch.Tensor:
+    """The loss-scale block of a precision-"fp16" model: 4 floats on its device {scale, good steps since its last change, skipped
+    steps, applied steps}.  It lives on the device because the training micro-step is a captured HIP graph: the backward multiplies the
+    loss gradient by element 0 with a tensor op (LossFunction.backward), the fused optimizer divides it out, skips a step whose gradient
+    norm overflowed, counts the applied steps (its Adam clock) and halves / doubles the scale -- all without a host read
+    (FusedAdam.step -> omlm_loss_scale_update; GradScaler's rule: x0.5 on overflow, x2 after $OMLM_FP16_GROWTH_INTERVAL = 2000 good
+    steps, within [1, 65536]).  $OMLM_FP16_DYNAMIC=0 keeps the scale at its initial value ($OMLM_FP16_LOSS_SCALE, default 4096: the
+    non-target logit gradients of a 28 k-token batch are ~3e-8, half's smallest normal is 6e-5)."""
+    dev = model.start_tokens[0].device
+    st = model.__dict__.get("_omlm_ls_state")
+    if st is None or st.device != dev:
+        st = torch.tensor([loss_scale_initial(), 0.0, 0.0, 0.0], device=dev, dtype=torch.float32)
+        model.__dict__["_omlm_ls_state"] = st
+    return st
+
+
+def loss_scale(precision: str, model=None) -> float:
+    """Factor the backward of `precision` multiplies the loss gradient by: 1 except for "fp16" (gradients would fall below half's range),
+    where it is the CURRENT value of the model's device-side block (reading it synchronises; without a model, or before its first
+    optimizer step: the initial value).  Parameter gradients (param.grad, the optimizer's flat buffer) carry that factor until
+    FusedAdam.step divides it out inside its kernel; anything else that reads param.grad in this mode divides by this (unscale_grads_)."""
     if precision != "fp16":
         return 1.0
-    return float(os.environ.get("OMLM_FP16_LOSS_SCALE", "4096"))
+    if model is None or "_omlm_ls_state" not in model.__dict__:
+        return loss_scale_initial()
+    return float(model.__dict__["_omlm_ls_state"][0].item())
 
 
 def tag_parameters(model, precision: Optional[str]):
     """Mark the model's parameters with its precision mode: the fused optimizer picks its 16-bit shadow type and loss scale from it."""
+    import weakref
+    ref = weakref.ref(model)
     for p in model.parameters():
         p._omlm_precision = precision
+        p._omlm_model = ref                     # the fused optimizer finds the model's loss-scale block through it (precision "fp16")
 
 
 @torch.no_grad()
 def unscale_grads_(model, precision: Optional[str] = None):
-    """Divide the loss scale out of every param.grad (fp16 mode, for consumers other than FusedAdam).  Call once per optimizer step."""
-    s = loss_scale(precision or getattr(model, "precision", None) or default_precision())
+    """Divide the loss scale out of every param.grad (fp16 mode, for consumers other than FusedAdam: torch optimizers, clip_grad_norm_,
+    gradient logging).  Call once per optimizer step, before anything reads the gradients."""
+    s = loss_scale(precision or getattr(model, "precision", None) or default_precision(), model)
     if s != 1.0:
         for p in model.parameters():
             if p.grad is not None:
@@ -743,7 +768,7 @@ class LogitsFunction(torch.autograd.Function):
         ctx.set_materialize_grads(False)          # unused logits -> None grads -> their head GEMMs are skipped
         ctx.st = st
         ctx.nparams = len(params)
-        ctx.gscale = loss_scale(precision)
+        ctx.ls = loss_scale_state(model) if precision == "fp16" else None
         views = logits_views(model, lay, bufs)
         ctx.present = [v is not None for v in views]
         return tuple(v for v in views if v is not None)
@@ -762,8 +787,8 @@ class LogitsFunction(torch.autograd.Function):
             V1 = seq.codebook_size + 1
             ldV = ceil_to(V1, 8)
             g2 = g.reshape(-1, V1).to(torch.float32).contiguous()
-            if ctx.gscale != 1.0:
-                g2 = g2 * ctx.gscale
+            if ctx.ls is not None:
+                g2 = g2 * ctx.ls[0:1]                                # fp16: the device-side loss scale, removed by the optimizer
             d = torch.empty(g2.shape[0], ldV, dtype=T, device=g2.device)
             ops.cast_pad(g2, d, g2.shape[0], V1, V1, ldV)
             dl.append(d)
@@ -823,7 +848,7 @@ class LossFunction(torch.autograd.Function):
             ctx.inv_total = inv_total
         ctx.st = st
         ctx.nparams = len(params)
-        ctx.gscale = loss_scale(precision)
+        ctx.ls = loss_scale_state(model) if precision == "fp16" else None
         views = logits_views(model, lay, bufs)
         ctx.mark_non_differentiable(*[v for v in views if v is not None])
         return (loss, *views)
@@ -835,8 +860,8 @@ class LossFunction(torch.autograd.Function):
         g = gloss.reshape(1).to(torch.float32).contiguous()
         if ctx.inv_total is not None:
             g = (g * ctx.inv_total).reshape(1).contiguous()
-        if ctx.gscale != 1.0:
-            g = g * ctx.gscale                                       # fp16: loss scale (engine.loss_scale), removed by the optimizer
+        if ctx.ls is not None:
+            g = (g * ctx.ls[0:1]).contiguous()                       # fp16: the device-side loss scale (loss_scale_state), removed by the optimizer
         dl = []
         for s, seq in enumerate(st.model.token_sequences):
             if st.labels[s] is None:

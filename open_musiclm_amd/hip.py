@@ -49,7 +49,8 @@ SIGNATURES = {
     "omlm_cross_entropy_fwd": [vp, vp, vp, vp, i32, i32, i32, vp, vp],
     "omlm_cross_entropy_bwd": [vp, vp, vp, vp, f32, vp, i32, i32, i32, i32, i32, vp],
     "omlm_sumsq_accumulate": [vp, i64, vp, vp, vp],
-    "omlm_adamw_clip_step": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp, f32, i32, i32, i32, vp],
+    "omlm_adamw_clip_step": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp, f32, i32, i32, i32, vp, vp],
+    "omlm_loss_scale_update": [vp, vp, f32, f32, i32, f32, f32, vp],
     "omlm_cast_pad": [vp, vp, i64, i32, i32, i32, i32, vp],
     "omlm_transpose_cast": [vp, vp, i32, i32, i32, i32, i32, vp],
     "omlm_cast_pad_group": [vp, i32, i32, vp],

@@ -388,11 +388,17 @@ def sumsq_accumulate(g, out, partials=None):
 
 
 def adamw_clip_step(p, g, m, v, p16, *, lr, beta1, beta2, eps, wd, step, gscale, gnorm_sq, max_norm,
-                    decoupled, zero_grad):
-    """p16: optional 16-bit shadow of p (bf16 or fp16: the operand type of the model's precision), written by the same kernel."""
+                    decoupled, zero_grad, ls_state=None):
+    """p16: optional 16-bit shadow of p (bf16 or fp16: the operand type of the model's precision), written by the same kernel.
+    ls_state: the device-side loss-scale block of precision "fp16" (engine.loss_scale_state)."""
     call("omlm_adamw_clip_step", ptr(p), ptr(g), ptr(m), ptr(v), ptr(p16), p.numel(), float(lr), float(beta1),
          float(beta2), float(eps), float(wd), int(step), float(gscale), ptr(gnorm_sq), float(max_norm or 0.0),
-         int(decoupled), int(zero_grad), dcode(p16.dtype) if p16 is not None else BF16, stream_ptr())
+         int(decoupled), int(zero_grad), dcode(p16.dtype) if p16 is not None else BF16, ptr(ls_state), stream_ptr())
+
+
+def loss_scale_update(ls_state, gnorm_sq, *, growth=2.0, backoff=0.5, interval=2000, scale_min=1.0, scale_max=65536.0):
+    call("omlm_loss_scale_update", ptr(ls_state), ptr(gnorm_sq), float(growth), float(backoff), int(interval), float(scale_min),
+         float(scale_max), stream_ptr())
 
 
 def cast_pad(src, dst, R, C_, ld_src, ld_dst):

@@ -10,6 +10,8 @@ Numerics follow torch.optim.Adam / AdamW (non-amsgrad, eps outside the bias-corr
 """
 from __future__ import annotations
 
+import os
+
 from typing import Iterable, List, Optional
 
 import torch
@@ -35,7 +37,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._grads_clean = False
         self._gnorm_sq = None
         self.last_grad_norm_sq = None
-        self.loss_scale = 1.0           # what the backward multiplied the gradients by (engine.loss_scale: 1 unless precision "fp16")
+        self._ls_state = None           # precision "fp16": the device-side loss-scale block (engine.loss_scale_state), else None
 
     # ---- flat storage --------------------------------------------------------------------------------
     def _all_params(self) -> List[torch.Tensor]:
@@ -71,7 +73,13 @@ class FusedAdam(torch.optim.Optimizer):
         from . import engine
         prec = next((getattr(p, "_omlm_precision", None) for p in params if getattr(p, "_omlm_precision", None)), None)
         prec = prec or engine.default_precision()
-        self.loss_scale = engine.loss_scale(prec)
+        self._ls_state = None
+        if prec == "fp16":
+            mref = next((getattr(p, "_omlm_model", None) for p in params if getattr(p, "_omlm_model", None) is not None), None)
+            owner = mref() if mref is not None else None
+            if owner is None:
+                raise RuntimeError("FusedAdam: fp16 parameters without their model (engine.tag_parameters): the loss-scale block is the model's")
+            self._ls_state = engine.loss_scale_state(owner)
         P16 = torch.empty(tot, device=dev, dtype=torch.float16 if prec == "fp16" else torch.bfloat16)
         P16.copy_(P)                                    # one-off cast (cast_pad walks rows: a single 91M-element row is one workgroup)
         for p, o, n in zip(params, offs, sizes):
@@ -127,21 +135,27 @@ class FusedAdam(torch.optim.Optimizer):
         gradient norm is not finite (an fp16 overflow) is skipped on the device (adamw kernel)."""
         self._ensure_flat()
         f = self._flat
-        self._t += 1
-        grad_scale = grad_scale / self.loss_scale
+        self._t += 1                    # fp16: counts attempted steps; the Adam clock of that mode is the device's applied-step counter
+        ls = self._ls_state
         gn = None
-        if max_grad_norm is not None and max_grad_norm > 0:
+        if (max_grad_norm is not None and max_grad_norm > 0) or ls is not None:
+            # fp16: the norm is ALWAYS formed -- it is the overflow detector (a non-finite norm skips the step on the device), with
+            # max_norm = 0 meaning "guard only, no clipping"
             self._gnorm_sq.zero_()
             ops.sumsq_accumulate(f['G'], self._gnorm_sq, self._gnorm_partials)
             gn = self._gnorm_sq
-        self.last_grad_norm_sq = gn
+        self._last_gnorm_sq_raw = gn
         for g, (a, b) in zip(self.param_groups, f['ranges']):
             if b <= a:
                 continue
             beta1, beta2 = g['betas']
             ops.adamw_clip_step(f['P'][a:b], f['G'][a:b], f['M'][a:b], f['V'][a:b], f['P16'][a:b], lr=g['lr'], beta1=beta1,
                                 beta2=beta2, eps=g['eps'], wd=g['weight_decay'], step=self._t, gscale=grad_scale,
-                                gnorm_sq=gn, max_norm=max_grad_norm or 0.0, decoupled=g['decoupled'], zero_grad=True)
+                                gnorm_sq=gn, max_norm=max_grad_norm or 0.0, decoupled=g['decoupled'], zero_grad=True, ls_state=ls)
+        if ls is not None:
+            dyn = os.environ.get("OMLM_FP16_DYNAMIC", "1") != "0"
+            ops.loss_scale_update(ls, gn, growth=2.0 if dyn else 1.0, backoff=0.5 if dyn else 1.0,
+                                  interval=int(os.environ.get("OMLM_FP16_GROWTH_INTERVAL", "2000")), scale_min=1.0, scale_max=65536.0)
         self._grads_clean = True
         params = self._all_params()                     # the kernels wrote through raw pointers: tell autograd.
         # NB: _increment_version takes an ITERABLE of tensors; handing it one tensor iterates its rows (unbind), which
@@ -157,6 +171,32 @@ class FusedAdam(torch.optim.Optimizer):
     def mark_grads_dirty(self):
         self._grads_clean = False
 
+    @property
+    def last_grad_norm_sq(self):
+        """Squared global gradient norm of the last step in TRUE gradient units (the loss scale of precision "fp16" divided out; still
+        multiplied by any grad_scale the caller passed), as a device tensor; None if the step formed no norm."""
+        gn = getattr(self, "_last_gnorm_sq_raw", None)
+        if gn is None or self._ls_state is None:
+            return gn
+        return gn / (self._ls_state[0] * self._ls_state[0])      # note: after the step's scale update; exact while the scale did not move
+
+    @last_grad_norm_sq.setter
+    def last_grad_norm_sq(self, v):
+        self._last_gnorm_sq_raw = v
+
+    @property
+    def loss_scale(self) -> float:
+        """Current loss scale (1 unless precision "fp16"; reading it synchronises)."""
+        return float(self._ls_state[0].item()) if self._ls_state is not None else 1.0
+
+    def loss_scale_report(self) -> dict:
+        """fp16 mode: {'scale', 'skipped_steps', 'applied_steps'} read from the device (synchronises: call it where the host already waits,
+        e.g. next to the trainer's loss read-back); {} otherwise."""
+        if self._ls_state is None:
+            return {}
+        sc, _, sk, ap = [float(v) for v in self._ls_state.tolist()]
+        return dict(scale=sc, skipped_steps=int(sk), applied_steps=int(ap))
+
     @torch.no_grad()
     def sync_replicas(self, dp, src: int = 0):
         """Make every data-parallel replica start from rank `src`'s state (what DDP's constructor broadcast does in the
@@ -171,6 +211,8 @@ class FusedAdam(torch.optim.Optimizer):
         t = torch.tensor([self._t], device=f['P'].device, dtype=torch.int64)
         dp.broadcast_(t, src=src)
         self._t = int(t.item())
+        if self._ls_state is not None:
+            dp.broadcast_(self._ls_state, src=src)
         f['P16'].copy_(f['P'])
         params = self._all_params()
         if hasattr(torch._C, "_increment_version"):
@@ -186,17 +228,22 @@ class FusedAdam(torch.optim.Optimizer):
         f = self._flat
         state, k = {}, 0
         groups = []
+        # the Adam clock: attempted steps, except in precision "fp16" where skipped (overflowed) steps do not count (device counter)
+        t_now = self._t if self._ls_state is None else int(self._ls_state[3].item())
         for g in self.param_groups:
             idx = []
             for _ in g['params']:
                 o, n = f['offs'][k], f['sizes'][k]
                 shape = self._all_params()[k].shape
-                state[k] = dict(step=torch.tensor(float(self._t)), exp_avg=f['M'][o:o + n].view(shape).clone(),
+                state[k] = dict(step=torch.tensor(float(t_now)), exp_avg=f['M'][o:o + n].view(shape).clone(),
                                 exp_avg_sq=f['V'][o:o + n].view(shape).clone())
                 idx.append(k)
                 k += 1
             groups.append({**{kk: vv for kk, vv in g.items() if kk != 'params'}, 'params': idx})
-        return dict(state=state if self._t > 0 else {}, param_groups=groups)
+        out = dict(state=state if t_now > 0 else {}, param_groups=groups)
+        if self._ls_state is not None:                  # extra top-level key (torch's Optimizer.load_state_dict ignores it)
+            out["omlm_loss_scale"] = self.loss_scale_report()
+        return out
 
     def load_state_dict(self, sd):
         self._ensure_flat()
@@ -215,6 +262,12 @@ class FusedAdam(torch.optim.Optimizer):
             f['V'][o:o + n].copy_(st['exp_avg_sq'].reshape(-1).to(f['V'].device))
             t = max(t, int(float(st['step'])))
         self._t = t
+        if self._ls_state is not None:
+            self._ls_state[3] = float(t)
+            rep = sd.get("omlm_loss_scale")
+            if rep:
+                self._ls_state[0] = float(rep.get("scale", self._ls_state[0].item()))
+                self._ls_state[2] = float(rep.get("skipped_steps", 0))
 
 
 def get_optimizer(params: Iterable[torch.Tensor], lr=1e-4, wd=1e-2, betas=(0.9, 0.99), eps=1e-8,

@@ -332,6 +332,13 @@ class SingleStageTrainer(nn.Module):
             # was skipped by the kernels and flagged -- surface it like torch's device assert would
             from . import ops
             ops.raise_on_index_error(self.device)
+            rep = self.optim.loss_scale_report() if hasattr(self.optim, "loss_scale_report") else {}
+            if rep:                                  # precision "fp16": overflowed steps are skipped on the device -- say so
+                logs.update(loss_scale=rep["scale"], skipped_steps=rep["skipped_steps"])
+                if rep["skipped_steps"] > getattr(self, "_skipped_seen", 0):
+                    self.print(f"{steps}: fp16 gradient overflow -- optimizer step skipped ({rep['skipped_steps']} so far), "
+                               f"loss scale now {rep['scale']:g}")
+                    self._skipped_seen = rep["skipped_steps"]
         self.print(f"{steps}: loss: {logs['loss']}")
 
         valid_loss = valid_accuracy = None
