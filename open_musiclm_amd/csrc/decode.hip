@@ -1326,6 +1326,9 @@ extern "C" int OMLM_API(omlm_decode_step)(const omlm_decode_args* a, const long 
     static int v1 = -1;
     if (v1 < 0) { const char* e = getenv("OMLM_DECODE_V1"); v1 = (e && e[0] == '1') ? 1 : 0; }
     const bool v2_ok = a->D == 1024 && a->H * 64 <= 1024 && a->Fp <= 4096 && a->Fp % 2 == 0 && (a->H * 64 + 128) % DEC2_ROWS == 0;
+    // batches of 9..16 exist only on the second-generation path's matrix-core kernels: the first-generation kernels below are sized for
+    // DEC_BMAX samples (LDS B * Fp floats, DEC_ROWS * DEC_BMAX tail) -- refuse instead of overrunning them (OMLM_DECODE_V1=1, odd geometries)
+    OMLM_CHECK_ARG(a->B <= DEC_BMAX || (!v1 && v2_ok), "decode batches above 8 need the second-generation step kernels (D = 1024, OMLM_DECODE_V1 unset)");
     if (!v1 && v2_ok) {
 #if OMLM_FP16
         const int rc = decode_step2_t<h16_t>(*a, ids, as_stream(stream));

@@ -437,16 +437,20 @@ __global__ __launch_bounds__(64) void sample_kernel(const float* __restrict__ lo
     // every load of the row -- logits AND uniforms -- is requested before anything waits.  (Round 4 kernel trace: 43.9 us per call at
     // B = 1, a quarter of a decode step: the uniforms were loaded inside `if (keep)`, one dependent memory round trip per register
     // slot, 17 in a row behind the running arg-max.)
+    // (hipcc sank each uniform's first log next to its predicated load, with a vmcnt(0) in between -- seen in the ISA: the loads are
+    // therefore unconditional (clamped index, no branch) and all consumed by the empty asm below before any arithmetic.)
 #pragma unroll
     for (int j = 0; j < SAMPLE_NV; ++j) {
-        const int c = lane + 64 * j;
-        lv[j] = (j < nv && c < V) ? lr[c] : -INFINITY;
-        uv[j] = (j < nv && c < V) ? ur[c] : 0.5f;
+        const int c = lane + 64 * j, cc = c < V ? c : V - 1;
+        lv[j] = lr[cc];
+        uv[j] = ur[cc];
     }
 #pragma unroll
+    for (int j = 0; j < SAMPLE_NV; ++j) asm volatile("" : "+v"(lv[j]), "+v"(uv[j]));
+#pragma unroll
     for (int j = 0; j < SAMPLE_NV; ++j) {
         const int c = lane + 64 * j;
-        float v = lv[j];
+        float v = c < V ? lv[j] : -INFINITY;
         if (forbid_last && c == V - 1) v = -INFINITY;
         lv[j] = v;
         keys[j] = c < V ? f_ord(v) : 0u;               // 0 sorts below every real key (f_ord(-inf) = 0x007fffff)

@@ -45,7 +45,7 @@ def max_batch(model, precision: str) -> int:
     tr = model.transformer
     inner = getattr(tr.layers[0][2], "inner_dim", 0) if len(tr.layers) else 0
     wide = (precision in ("bf16", "fp16") and tr.dim == 1024 and tr.heads * engine.DIM_HEAD <= 1024 and 0 < engine.ceil_to(inner, 64) <= 3072
-            and os.environ.get("OMLM_DECODE_MFMA", "1") != "0")
+            and os.environ.get("OMLM_DECODE_MFMA", "1") != "0" and os.environ.get("OMLM_DECODE_V1", "0") != "1")
     return 16 if wide else MAX_DECODE_BATCH
 
 
