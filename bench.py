@@ -143,6 +143,14 @@ class TrainLeg:
             ops_gemm(A, B, C_, M=M, N=N, K=K, **kw)
             e1.record()
             rec.append((e0, e1, 2.0 * M * N * K, (M, N, K, str(A.dtype)[6:], str(C_.dtype)[6:], int(bool(kw.get('a_kmajor'))), int(bool(kw.get('b_kmajor'))))))
+        ops_qkn = ops.gemm_qknorm
+
+        def timed_qkn(A, B, C_, scale, norm_out, groups, *, M, N, K, **kw):      # q / k projections with the l2-norm epilogue: GEMM launches too
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ops_qkn(A, B, C_, scale, norm_out, groups, M=M, N=N, K=K, **kw)
+            e1.record()
+            rec.append((e0, e1, 2.0 * M * N * K, (M, N, K, str(A.dtype)[6:], str(C_.dtype)[6:] + "+l2norm", 0, 0)))
         # the weight-gradient contractions of a backward go out as grouped launches (ops.WgradGroup.flush): same bookkeeping
         group_flush = ops.WgradGroup.flush
 
@@ -156,6 +164,7 @@ class TrainLeg:
             e1.record()
             rec.append((e0, e1, fl, ('wgrad_group', len(wg.items), splits)))
         E.ops.gemm = timed_gemm
+        E.ops.gemm_qknorm = timed_qkn
         ops.WgradGroup.flush = timed_flush
         try:
             for k in range(2):
@@ -163,6 +172,7 @@ class TrainLeg:
             torch.cuda.synchronize()
         finally:
             E.ops.gemm = ops_gemm
+            E.ops.gemm_qknorm = ops_qkn
             ops.WgradGroup.flush = group_flush
         tot_ms = sum(a.elapsed_time(b) for a, b, _, _ in rec)
         tot_fl = sum(f for _, _, f, _ in rec)

@@ -67,6 +67,20 @@ int omlm_qk_norm_bwd(const float* dq, const float* dk, const float* dv, const fl
                      const float* q_scale, const float* k_scale, void* dq_raw, void* dkv_raw,
                      float* dq_scale, float* dk_scale, int M, int H, int out_dtype, void* stream);
 
+/* Attention q / k projections with the l2-norm + learned scale of transformer.py:265-271 folded into the GEMM epilogue (16-bit modes):
+   C [M, N] = per 64-wide head h < groups: (A B^T)[:, h] / max(|.|, 1e-12) * scale[0..63]; heads >= groups pass through; columns
+   >= c2_col0 go to C2 (pitch ldc2) when C2 is given (v of the k | v projection); norm_out [M, ldnorm] fp32 receives the norms.
+   A [M, K], B [N, K] row-major, dtype 1 = bf16 / 2 = fp16 (operands and outputs).  Replaces to_q / to_kv + l2norm + scale
+   (transformer.py:254,265-271) without the fp32 pre-norm tensors. */
+int omlm_gemm_qknorm(const void* A, const void* B, void* C, void* C2, int c2_col0, int ldc2, const float* scale, float* norm_out,
+                     int ldnorm, int groups, long long a_rows, long long b_rows, int M, int N, int K, int lda, int ldb, int ldc,
+                     int dtype, void* stream);
+/* its backward, from the normalised 16-bit q / k and the saved norms (qn [M, H], kn [M]) instead of the fp32 pre-norm projections;
+   outputs as omlm_qk_norm_bwd (dq_raw [M, H*64], dkv_raw [M, 128] 16-bit; dq_scale / dk_scale [64] fp32, accumulated). */
+int omlm_qk_norm_bwd2(const float* dq, const float* dk, const float* dv, const void* q, const void* k, const float* qn, const float* kn,
+                      const float* q_scale, const float* k_scale, void* dq_raw, void* dkv_raw, float* dq_scale, float* dk_scale,
+                      int M, int H, int dtype, void* stream);
+
 /* Causal multi-query attention with rel-pos bias table and key mask (transformer.py:303-331; the same logical
  * inputs as the xformers seam at :275-301, without materialising attn_bias).  bias: [N, bias_ld] fp32, row = i-j,
  * column = head (the un-gathered MLP output of RelativePositionBias, :60-64).  keymask: [B, N] uint8, 1 = attend.

@@ -1107,7 +1107,7 @@ extern "C" int OMLM_API(omlm_mqa_attn_fwd)(const void* q, const void* k, const v
 int attn2_bwd_dq_launch(const void* q, const void* k, const void* v, const float* biasT, const unsigned char* keymask,
                         const void* out, const void* dout, const float* lse, float* delta, float* dq, float* dbias, int bias_ld,
                         float* dpart, int B, int N, int H, float scale, hipStream_t st);               // attention2.hip
-extern "C" int omlm_attn_dbias_reduce_launch(const float* dpart, float* dbias, int bias_ld, int B, int N, int H, void* stream);   // attention2.hip (bf16 copy)
+extern "C" __attribute__((visibility("hidden"))) int omlm_attn_dbias_reduce_launch(const float* dpart, float* dbias, int bias_ld, int B, int N, int H, void* stream);   // attention2.hip (bf16 copy)
 
 int attn3_bwd_dkv_launch(const void* q, const void* k, const void* v, const float* biasT, const unsigned char* keymask,
                          const void* dout, const float* lse, const float* delta, float* dk, float* dv,

@@ -734,7 +734,7 @@ extern "C" long long omlm_mqa_attn_bwd_workspace_bytes(int B, int N, int H) {
     return (long long)B * H * nqt * nqt * 32 * (long long)sizeof(float);
 }
 
-extern "C" int omlm_attn_dbias_reduce_launch(const float* dpart, float* dbias, int bias_ld, int B, int N, int H, void* stream) {
+extern "C" __attribute__((visibility("hidden"))) int omlm_attn_dbias_reduce_launch(const float* dpart, float* dbias, int bias_ld, int B, int N, int H, void* stream) {
     const int nqt = (N + 31) / 32;
     hipLaunchKernelGGL(attn_dbias_reduce_kernel, dim3((N + 255) / 256, H, min(B, A2_DBR_S)), dim3(256), 0, as_stream(stream), dpart, dbias,
                        bias_ld, B, N, H, nqt);

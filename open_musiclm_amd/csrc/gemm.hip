@@ -66,6 +66,11 @@ struct GemmArgs {
     // a_plane / b_plane BYTES behind it, and the k-loop runs 3 x the k-tiles: (A_hi, B_hi), (A_hi, B_lo), (A_lo, B_hi).
     int split3;
     unsigned a_plane, b_plane;
+    // l2-norm epilogue (EPI == 1 instantiations, omlm_gemm_qknorm): the first epi_groups 64-column groups of a row leave the kernel as
+    // v / max(|v|, 1e-12) * epi_scale[col & 63] with the norm written to epi_norm[row * epi_ldnorm + group]; columns >= c2_col0 (if C2) go
+    // to C2 + row * ldc2 + (col - c2_col0)
+    const float* epi_scale; float* epi_norm; int epi_groups, epi_ldnorm;
+    void* C2; int c2_col0, ldc2;
 };
 
 // ---- LDS images ---------------------------------------------------------------------------
@@ -393,7 +398,7 @@ struct DmaStagerT {
 // scatters (measured: ~480 of 650 us of the FF-in GEMM).  Each 32-row strip of the wave's tile is therefore transposed
 // through a per-wave LDS patch (the k-loop stages are dead: the caller has passed a barrier) and written as 16-byte
 // row-contiguous stores: 8 bf16 / 4 fp32 per lane, full 128-byte lines per row.
-template <int MI, int NJ, int WN_, typename TOUT>
+template <int MI, int NJ, int WN_, typename TOUT, int EPI = 0>
 __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16 (&acc)[MI][NJ], char* smem, int m0, int n0,
                                               int wm, int wn, int wave, int lane, int dbg, bool split) {
     constexpr int SROW = WN_ + 4;                                  // padded row (floats), keeps 16-B alignment
@@ -424,7 +429,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16 (&acc)[M
         return;
     }
     constexpr int NP = 32 / RPP;                                   // passes per 32-row strip
-    const bool cin_pref = g.Cin != nullptr && vec_ok && g.c_map == nullptr;
+    const bool cin_pref = g.Cin != nullptr && vec_ok;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         // Residual (Cin) pieces of the whole strip are requested BEFORE the LDS transposition: one memory round trip per strip, hidden
@@ -432,13 +437,22 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16 (&acc)[M
         // pass waited for its own piece: 32 dependent round trips per 256x256 tile, to_out (K = 512) 130 us against a 60 us HBM floor at
         // every tile size, FF-out ~80 us of epilogue.)
         float4 cinv[NP][VEC / 4];
+        int prows[NP];                                             // physical C rows of the strip's passes (scatter map), -1: dropped
         if (cin_pref) {
+            if (g.c_map) {                                         // the map entries of all passes in flight together, then the pieces
+#pragma unroll
+                for (int pass = 0; pass < NP; ++pass) {
+                    const int row = m0 + wm + 32 * i + pass * RPP + lane / LPR;
+                    prows[pass] = g.c_map[row < g.M ? row : 0];
+                }
+            }
 #pragma unroll
             for (int pass = 0; pass < NP; ++pass) {
                 const int r = pass * RPP + lane / LPR, c = (lane % LPR) * VEC;
                 const int row = m0 + wm + 32 * i + r, col = n0 + wn + c;
-                const bool ok = row < g.M && col + VEC <= g.N;
-                const float* src = g.Cin + (long long)(ok ? row : 0) * g.ldcin + (ok ? col : 0);
+                if (!g.c_map) prows[pass] = row;
+                const bool ok = row < g.M && col + VEC <= g.N && prows[pass] >= 0;
+                const float* src = g.Cin + (long long)(ok ? prows[pass] : 0) * g.ldcin + (ok ? col : 0);
 #pragma unroll
                 for (int x = 0; x < VEC / 4; ++x) cinv[pass][x] = *(const float4*)(src + 4 * x);
             }
@@ -459,8 +473,32 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16 (&acc)[M
                 v[x] = t.x; v[x + 1] = t.y; v[x + 2] = t.z; v[x + 3] = t.w;
             }
             if (row >= g.M || col >= g.N) continue;
-            const long long prow = g.c_map ? (long long)g.c_map[row] : (long long)row;
+            const long long prow = cin_pref ? (long long)prows[pass] : (g.c_map ? (long long)g.c_map[row] : (long long)row);
             if (prow < 0) continue;
+            if constexpr (EPI == 1) {
+                // q / k of the attention (transformer.py:265-271): l2-normalise each 64-wide head and apply the learned per-dim scale
+                // here, in fp32 on the accumulator values -- the wave's 64 columns ARE one head (WN_ == 64, host: N % 64 == 0), a row's
+                // eight lanes hold it whole.  Rows >= M left above as whole 8-lane groups, so the shuffles below see complete rows.
+                static_assert(WN_ == 64 && VEC == 8, "the l2-norm epilogue needs one head per wave row and 16-bit output");
+                const int grp = (n0 + wn) >> 6;
+                if (grp < g.epi_groups) {
+                    float ss = 0.f;
+#pragma unroll
+                    for (int x = 0; x < VEC; ++x) ss += v[x] * v[x];
+                    ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
+                    const float nrm = fmaxf(sqrtf(ss), 1e-12f), inv = 1.0f / nrm;
+                    const float4 s0 = *(const float4*)(g.epi_scale + c), s1 = *(const float4*)(g.epi_scale + c + 4);
+                    v[0] = v[0] * inv * s0.x; v[1] = v[1] * inv * s0.y; v[2] = v[2] * inv * s0.z; v[3] = v[3] * inv * s0.w;
+                    v[4] = v[4] * inv * s1.x; v[5] = v[5] * inv * s1.y; v[6] = v[6] * inv * s1.z; v[7] = v[7] * inv * s1.w;
+                    if ((lane % LPR) == 0) g.epi_norm[prow * g.epi_ldnorm + grp] = nrm;
+                }
+                TOUT* dst = (g.C2 && col >= g.c2_col0) ? (TOUT*)g.C2 + prow * g.ldc2 + (col - g.c2_col0) : C + prow * g.ldc + col;
+                u32x4 o;
+                o[0] = pack_h16_rne(v[0], v[1]); o[1] = pack_h16_rne(v[2], v[3]);
+                o[2] = pack_h16_rne(v[4 % VEC], v[5 % VEC]); o[3] = pack_h16_rne(v[6 % VEC], v[7 % VEC]);
+                *(u32x4*)dst = o;
+                continue;
+            }
             if (vec_ok && col + VEC <= g.N) {
                 if (cin_pref) {
 #pragma unroll
@@ -506,7 +544,7 @@ __device__ __forceinline__ int xcd_logical_id(int lin, int total) {
 // One workgroup's share of C = alpha A B^T (+ Cin).  lg: logical workgroup id inside this problem's (tiles x K-splits, split-major)
 // space; split: partial sums are added to fp32 C with atomics; bal_wgs: workgroup count of the balanced split-K form (BAL only).
 // FASTK: K is a multiple of the k-tile depth (host-checked): the DMA pieces take their k offset from an SGPR (DmaStagerT::issue_one)
-template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ, bool B_KMAJ, typename TOUT, bool DBG, bool KMAP, bool BAL, bool SPLIT3 = false, bool FASTK = false>
+template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ, bool B_KMAJ, typename TOUT, bool DBG, bool KMAP, bool BAL, bool SPLIT3 = false, bool FASTK = false, int EPI = 0>
 __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, const bool split, const int bal_wgs, char* smem) {
     const int dbg = DBG ? g.debug : 0;      // ablation switches exist only in the DBG instantiation (OMLM_GEMM_DEBUG set)
     constexpr int NWN = BN_ / WN_, NWAVES = (BM_ / WM_) * NWN;
@@ -673,7 +711,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         __syncthreads();
-        tile_epilogue<MI, NJ, WN_, TOUT>(g, acc, smem, m0, n0, wm, wn, wave, lane, dbg, bal || split);
+        tile_epilogue<MI, NJ, WN_, TOUT, EPI>(g, acc, smem, m0, n0, wm, wn, wave, lane, dbg, bal || split);
         if (!bal || u >= u1) break;
         __syncthreads();              // the non-split epilogue stages through LDS; the next segment's DMA must not overtake it
     }
@@ -681,13 +719,13 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, 
 
 // For split-K GEMMs the split-major XCD order puts all co-resident workgroups of an XCD on the SAME K range (they share A and B
 // panels through its L2); with a tile-only remap an XCD held 3 unrelated K ranges at a time (measured L2 hit 48 % on the dW1 GEMM).
-template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ, bool B_KMAJ, typename TOUT, bool DBG, bool KMAP, bool BAL = false, bool SPLIT3 = false, bool FASTK = false>
+template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ, bool B_KMAJ, typename TOUT, bool DBG, bool KMAP, bool BAL = false, bool SPLIT3 = false, bool FASTK = false, int EPI = 0>
 __global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A | B]
     const int nwg = gridDim.x;                                     // tiles (plain) / workgroups (balanced)
     const int total = BAL ? (int)gridDim.x : nwg * (int)gridDim.y;
     const int lg = xcd_logical_id(blockIdx.y * nwg + blockIdx.x, total);
-    gemm_tile_body<BM_, BN_, WM_, WN_, A_KMAJ, B_KMAJ, TOUT, DBG, KMAP, BAL, SPLIT3, FASTK>(g, lg, gridDim.y > 1, (int)gridDim.x, smem);
+    gemm_tile_body<BM_, BN_, WM_, WN_, A_KMAJ, B_KMAJ, TOUT, DBG, KMAP, BAL, SPLIT3, FASTK, EPI>(g, lg, gridDim.y > 1, (int)gridDim.x, smem);
 }
 
 
@@ -719,6 +757,7 @@ __global__ __launch_bounds__(512) void gemm_wgrad_group_kernel(GroupArgs ga) {
     g.A = q.A; g.B = q.B; g.C = q.C; g.Cin = q.C; g.a_map = nullptr; g.b_map = nullptr; g.c_map = q.c_map;
     g.a_rows = q.K; g.b_rows = q.K; g.M = q.M; g.N = q.N; g.K = q.K; g.lda = q.lda; g.ldb = q.ldb; g.ldc = q.ldc; g.ldcin = q.ldc;
     g.alpha = 1.f; g.kt_per_split = q.kt_per_split; g.bal_ck = 0; g.bal_chunks = 0; g.debug = 0; g.split3 = 0; g.a_plane = 0; g.b_plane = 0;
+    g.epi_scale = nullptr; g.epi_norm = nullptr; g.epi_groups = 0; g.epi_ldnorm = 0; g.C2 = nullptr; g.c2_col0 = 0; g.ldc2 = 0;
     const int nk = (q.K + BK - 1) / BK;
     gemm_tile_body<256, 256, 128, 64, true, true, float, false, false, false, false, FASTK>(g, lg - q.start, q.kt_per_split < nk, 0, smem);
 }
@@ -815,6 +854,7 @@ static int gemm_impl(const void* A, const void* B, void* C, const float* Cin,
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldcin = ldcin; g.alpha = alpha;
     { const char* dbg = getenv("OMLM_GEMM_DEBUG"); g.debug = dbg ? atoi(dbg) : 0; }
     g.split3 = split3; g.a_plane = a_plane; g.b_plane = b_plane;
+    g.epi_scale = nullptr; g.epi_norm = nullptr; g.epi_groups = 0; g.epi_ldnorm = 0; g.C2 = nullptr; g.c2_col0 = 0; g.ldc2 = 0;
     hipStream_t st = as_stream(stream);
     // tile shape (bf16 path): 256x256 when both output dims are wide, 256x128 for tall-narrow outputs, else 128x128
     int bm = BM, bn = BN;
@@ -823,7 +863,8 @@ static int gemm_impl(const void* A, const void* B, void* C, const float* Cin,
     if (in_dtype == 1 && !need_kmap) {
         if (force && force[0]) { if (!strcmp(force, "256x256")) { bm = 256; bn = 256; } else if (!strcmp(force, "256x128")) { bm = 256; bn = 128; } }
         else if (M >= 1024 && N >= 1024) { bm = 256; bn = 256; }   // measured (probe, N = 1024): 256x256 514 us, 128x128 543, 256x128 657
-        else if (M >= 2048 && N >= 256) { bm = 256; bn = 128; }
+        // N = 512 outputs (q-proj, d(o)): 128x128 (two workgroups per CU) measured 54 / 54 us against 60 / 59 for 256x128 (round 4 tile probe)
+        else if (M >= 2048 && N > 512) { bm = 256; bn = 128; }
         else if (N >= 2048 && M >= 256) { bm = 256; bn = 256; }
     }
     static int ncu = 0;
@@ -948,6 +989,49 @@ extern "C" int OMLM_API(omlm_gemm)(const void* A, const void* B, void* C, const 
 #endif
     return gemm_impl(A, B, C, Cin, a_map, b_map, c_map, a_rows, b_rows, M, N, K, lda, ldb, ldc, ldcin, a_kmajor, b_kmajor,
                      in_dtype, out_dtype, alpha, stream, 0, 0u, 0u);
+}
+
+// q / k projections with the attention's l2-norm + learned scale folded into the epilogue (transformer.py:254-271): C = 16-bit
+// [M, N] (+ C2 for columns >= c2_col0, e.g. v of the fused k | v projection), epi_groups leading 64-column heads normalised, their norms
+// to norm_out [M, ldnorm] fp32 (what the backward needs instead of the fp32 pre-norm projections).  A [M, K], B [N, K] row-major 16-bit.
+#if !OMLM_FP16
+extern "C" int omlm_gemm_qknorm_h(const void* A, const void* B, void* C, void* C2, int c2_col0, int ldc2, const float* scale, float* norm_out,
+                                  int ldnorm, int groups, long long a_rows, long long b_rows, int M, int N, int K, int lda, int ldb, int ldc,
+                                  int dtype, void* stream);
+#endif
+extern "C" int OMLM_API(omlm_gemm_qknorm)(const void* A, const void* B, void* C, void* C2, int c2_col0, int ldc2, const float* scale,
+                                          float* norm_out, int ldnorm, int groups, long long a_rows, long long b_rows, int M, int N, int K,
+                                          int lda, int ldb, int ldc, int dtype, void* stream) {
+#if !OMLM_FP16
+    if (dtype == OMLM_DT_F16) return omlm_gemm_qknorm_h(A, B, C, C2, c2_col0, ldc2, scale, norm_out, ldnorm, groups, a_rows, b_rows, M, N, K, lda, ldb, ldc, 1, stream);
+#endif
+    if (M <= 0 || N <= 0) return OMLM_OK;
+    OMLM_CHECK_ARG(dtype == 1, "gemm_qknorm: operand dtype 1 (bf16) or 2 (fp16)");
+    OMLM_CHECK_ARG(A && B && C && scale && norm_out && K > 0 && (K % 8) == 0, "gemm_qknorm: null operand / K");
+    OMLM_CHECK_ARG((N % 64) == 0 && groups >= 0 && groups * 64 <= N && ldnorm >= groups, "gemm_qknorm: N must be whole 64-wide heads");
+    OMLM_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0 && (ldc % 8) == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0,
+                   "gemm_qknorm: 16-byte aligned operands, pitches multiples of 8");
+    OMLM_CHECK_ARG(!C2 || ((c2_col0 % 64) == 0 && (ldc2 % 8) == 0 && ((uintptr_t)C2 % 16) == 0), "gemm_qknorm: second output");
+    OMLM_CHECK_ARG((unsigned long long)a_rows * lda * 2 < 0xFFFFFFF0ull && (unsigned long long)b_rows * ldb * 2 < 0xFFFFFFF0ull, "operand exceeds the 4 GiB window");
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.B = B; g.C = C; g.a_rows = a_rows; g.b_rows = b_rows; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.alpha = 1.f; g.epi_scale = scale; g.epi_norm = norm_out; g.epi_groups = groups; g.epi_ldnorm = ldnorm; g.C2 = C2; g.c2_col0 = c2_col0; g.ldc2 = ldc2;
+    const int nk = (K + BK - 1) / BK;
+    g.kt_per_split = nk;
+    constexpr size_t LDS = 2 * (size_t)(128 + 128) * BK * 2;
+    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    auto kfast = gemm_bf16_tile_kernel<128, 128, 64, 64, false, false, h16_t, false, false, false, false, true, 1>;
+    auto kgen = gemm_bf16_tile_kernel<128, 128, 64, 64, false, false, h16_t, false, false, false, false, false, 1>;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)kfast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        (void)hipFuncSetAttribute((const void*)kgen, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        attr = true;
+    }
+    if (K % BK == 0 && !gemm_fastk_off()) hipLaunchKernelGGL(kfast, dim3(tiles, 1), dim3(256), LDS, as_stream(stream), g);
+    else                                   hipLaunchKernelGGL(kgen, dim3(tiles, 1), dim3(256), LDS, as_stream(stream), g);
+    return omlm_post_launch("omlm_gemm_qknorm");
 }
 
 #if !OMLM_FP16

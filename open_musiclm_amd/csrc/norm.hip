@@ -329,6 +329,102 @@ __global__ __launch_bounds__(256) void qk_norm_bwd_kernel(const float* __restric
     }
 }
 
+// The same backward from what the fused projection epilogue (omlm_gemm_qknorm) leaves behind: y = s * x / n in the 16-bit operand type
+// and n = max(|x|, 1e-12) in fp32 -- xh = y / s (one operand rounding, like every other operand of the 16-bit modes; a zero scale
+// gives xh = 0: its dx is 0 anyway, only its d(scale) is lost).  No fp32 pre-norm projections are read (146 -> 64 MB per layer).
+template <typename T>
+__global__ __launch_bounds__(256) void qk_norm_bwd2_kernel(const float* __restrict__ dq, const float* __restrict__ dk,
+                                                           const float* __restrict__ dv, const T* __restrict__ q, const T* __restrict__ k,
+                                                           const float* __restrict__ qn, const float* __restrict__ kn,
+                                                           const float* __restrict__ q_scale, const float* __restrict__ k_scale,
+                                                           T* __restrict__ dq_raw, T* __restrict__ dkv_raw, float* __restrict__ dq_scale,
+                                                           float* __restrict__ dk_scale, int M, int H) {
+    const int lane = threadIdx.x & 63, sub = lane >> 4, d0 = 4 * (lane & 15);
+    const unsigned nvec = (unsigned)M * (unsigned)(H + 2), hp2 = (unsigned)(H + 2);
+    const float4 qs = *(const float4*)(q_scale + d0), ks = *(const float4*)(k_scale + d0);
+    auto rcp0 = [](float v) { return v != 0.f ? 1.0f / v : 0.f; };
+    const float4 qsi = make_float4(rcp0(qs.x), rcp0(qs.y), rcp0(qs.z), rcp0(qs.w)), ksi = make_float4(rcp0(ks.x), rcp0(ks.y), rcp0(ks.z), rcp0(ks.w));
+    float aq[4] = {0.f, 0.f, 0.f, 0.f}, ak[4] = {0.f, 0.f, 0.f, 0.f};
+    constexpr int U = QKB_U;
+    const unsigned stride = gridDim.x * 16u;
+    for (unsigned base = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 4u; base < nvec; base += stride * U) {
+        bool live[U], isq[U], isk[U];
+        int row[U], j[U];
+        float4 y[U], dy[U];
+        float nr[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned vec = base + u * stride + sub;
+            live[u] = vec < nvec;
+            row[u] = live[u] ? (int)(vec / hp2) : 0;
+            j[u] = live[u] ? (int)(vec - (unsigned)row[u] * hp2) : H + 1;
+            isq[u] = j[u] < H; isk[u] = j[u] == H;
+            y[u] = make_float4(0.f, 0.f, 0.f, 0.f); dy[u] = y[u]; nr[u] = 1.f;
+            if (live[u]) {
+                if (isq[u])      { y[u] = load4f(q + (size_t)row[u] * H * 64 + j[u] * 64, d0 >> 2); dy[u] = *(const float4*)(dq + (size_t)row[u] * H * 64 + j[u] * 64 + d0); nr[u] = qn[(size_t)row[u] * H + j[u]]; }
+                else if (isk[u]) { y[u] = load4f(k + (size_t)row[u] * 64, d0 >> 2);               dy[u] = *(const float4*)(dk + (size_t)row[u] * 64 + d0); nr[u] = kn[row[u]]; }
+                else             { dy[u] = *(const float4*)(dv + (size_t)row[u] * 64 + d0); }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float4 s = isq[u] ? qs : ks, si = isq[u] ? qsi : ksi;
+            const bool clamped = nr[u] <= 1e-12f;
+            const float inv = 1.0f / nr[u];
+            const float xh[4] = {y[u].x * si.x, y[u].y * si.y, y[u].z * si.z, y[u].w * si.w};
+            const float gy[4] = {s.x * dy[u].x, s.y * dy[u].y, s.z * dy[u].z, s.w * dy[u].w};
+            float proj = group16_sum(xh[0] * gy[0] + xh[1] * gy[1] + xh[2] * gy[2] + xh[3] * gy[3]);      // all lanes take part
+            if (clamped) proj = 0.f;
+            if (!live[u]) continue;
+            if (isq[u] || isk[u]) {
+                const float o0 = (gy[0] - xh[0] * proj) * inv, o1 = (gy[1] - xh[1] * proj) * inv;
+                const float o2 = (gy[2] - xh[2] * proj) * inv, o3 = (gy[3] - xh[3] * proj) * inv;
+                if (isq[u]) {
+                    store4(dq_raw + (size_t)row[u] * H * 64 + j[u] * 64 + d0, o0, o1, o2, o3);
+                    aq[0] += dy[u].x * xh[0]; aq[1] += dy[u].y * xh[1]; aq[2] += dy[u].z * xh[2]; aq[3] += dy[u].w * xh[3];
+                } else {
+                    store4(dkv_raw + (size_t)row[u] * 128 + d0, o0, o1, o2, o3);
+                    ak[0] += dy[u].x * xh[0]; ak[1] += dy[u].y * xh[1]; ak[2] += dy[u].z * xh[2]; ak[3] += dy[u].w * xh[3];
+                }
+            } else {
+                store4(dkv_raw + (size_t)row[u] * 128 + 64 + d0, dy[u].x, dy[u].y, dy[u].z, dy[u].w);
+            }
+        }
+    }
+    __shared__ float sq[4][64], sk[4][64];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        aq[i] += __shfl_xor(aq[i], 16, 64); aq[i] += __shfl_xor(aq[i], 32, 64);
+        ak[i] += __shfl_xor(ak[i], 16, 64); ak[i] += __shfl_xor(ak[i], 32, 64);
+        if (lane < 16) { sq[threadIdx.x >> 6][d0 + i] = aq[i]; sk[threadIdx.x >> 6][d0 + i] = ak[i]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        unsafeAtomicAdd(dq_scale + lane, sq[0][lane] + sq[1][lane] + sq[2][lane] + sq[3][lane]);
+        unsafeAtomicAdd(dk_scale + lane, sk[0][lane] + sk[1][lane] + sk[2][lane] + sk[3][lane]);
+    }
+}
+
+#if !OMLM_FP16
+extern "C" int omlm_qk_norm_bwd2_h(const float* dq, const float* dk, const float* dv, const void* q, const void* k, const float* qn, const float* kn, const float* q_scale, const float* k_scale, void* dq_raw, void* dkv_raw, float* dq_scale, float* dk_scale, int M, int H, int dtype, void* stream);
+#endif
+extern "C" int OMLM_API(omlm_qk_norm_bwd2)(const float* dq, const float* dk, const float* dv, const void* q, const void* k, const float* qn,
+                                           const float* kn, const float* q_scale, const float* k_scale, void* dq_raw, void* dkv_raw,
+                                           float* dq_scale, float* dk_scale, int M, int H, int dtype, void* stream) {
+#if !OMLM_FP16
+    if (dtype == OMLM_DT_F16) return omlm_qk_norm_bwd2_h(dq, dk, dv, q, k, qn, kn, q_scale, k_scale, dq_raw, dkv_raw, dq_scale, dk_scale, M, H, 1, stream);
+#endif
+    if (M <= 0) return OMLM_OK;
+    OMLM_CHECK_ARG(dtype == 1, "qk_norm_bwd2: 16-bit operand types only (1 = bf16, 2 = fp16)");
+    OMLM_CHECK_ARG(dq && dk && dv && q && k && qn && kn && dq_raw && dkv_raw && dq_scale && dk_scale, "null pointer");
+    long long nvec = (long long)M * (H + 2);
+    OMLM_CHECK_ARG(nvec < (1ll << 31), "qk_norm_bwd2: M * (H + 2) must stay below 2^31 (32-bit vector index)");
+    int blocks = (int)((nvec + 15) / 16); if (blocks > QKB_BLOCKS) blocks = QKB_BLOCKS;
+    hipLaunchKernelGGL(qk_norm_bwd2_kernel<h16_t>, dim3(blocks), dim3(256), 0, as_stream(stream), dq, dk, dv, (const h16_t*)q, (const h16_t*)k, qn, kn,
+                       q_scale, k_scale, (h16_t*)dq_raw, (h16_t*)dkv_raw, dq_scale, dk_scale, M, H);
+    return omlm_post_launch("omlm_qk_norm_bwd2");
+}
+
 #if !OMLM_FP16
 extern "C" int omlm_qk_norm_fwd_h(const float* q_raw, const float* kv_raw, const float* q_scale, const float* k_scale, void* q, void* k, void* v, int M, int H, int out_dtype, void* stream);
 #endif

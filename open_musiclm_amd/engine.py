@@ -48,6 +48,10 @@ _BF16_LN_GRAD = os.environ.get("OMLM_BF16_LN_GRAD", "1") == "1"
 # 16-bit modes: the K/V projection's input gradient leaves its GEMM as a 16-bit tensor and is added to the residual gradient inside the
 # attention LayerNorm's backward (ops.layernorm_bwd dres2) instead of by the GEMM's own fp32 read-add-write epilogue (0: that form)
 _KV_DGRAD_H16 = os.environ.get("OMLM_KV_DGRAD_H16", "1") == "1"
+# 16-bit modes: the attention's l2-norm + learned scale of q / k (transformer.py:265-271) is the epilogue of the projection GEMMs
+# (ops.gemm_qknorm): q, k, v leave them in the operand type with the per-(row, head) norms in fp32 -- no fp32 q_raw / kv_raw, no qk_norm
+# forward launch, and the backward derives xh = y / scale from the saved operand.  OMLM_QKNORM_FUSED=0: separate kernels on fp32 projections.
+_QKNORM_FUSED = os.environ.get("OMLM_QKNORM_FUSED", "1") == "1"
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 
 
@@ -407,14 +411,22 @@ def trunk_forward(tr, pw: PreparedWeights, x: torch.Tensor, keymask: Optional[to
         xn = torch.empty(M, D, dtype=T, device=dev)
         xc = x if T == torch.float32 else torch.empty(M, D, dtype=T, device=dev)
         ops.layernorm_fwd(x, attn.norm.gamma.detach(), xn, None if T == torch.float32 else xc, m1, r1)
-        q_raw = torch.empty(M, H * DIM_HEAD, device=dev)
-        kv_raw = torch.empty(M, 2 * DIM_HEAD, device=dev)
-        ops.gemm(xn, w["Wq"], q_raw, M=M, N=H * DIM_HEAD, K=D)
-        ops.gemm(xc, w["Wkv"], kv_raw, M=M, N=2 * DIM_HEAD, K=D)      # K/V from the un-normalised residual (:228)
         q = torch.empty(M, H * DIM_HEAD, dtype=T, device=dev)
         k = torch.empty(M, DIM_HEAD, dtype=T, device=dev)
         v = torch.empty(M, DIM_HEAD, dtype=T, device=dev)
-        ops.qk_norm_fwd(q_raw, kv_raw, attn.q_scale.detach(), attn.k_scale.detach(), q, k, v, H)
+        fused_qk = T in _H16 and _QKNORM_FUSED
+        if fused_qk:
+            qn = torch.empty(M, H, device=dev)
+            kn = torch.empty(M, device=dev)
+            q_raw, kv_raw = qn, kn                                     # what the backward needs in place of the fp32 projections
+            ops.gemm_qknorm(xn, w["Wq"], q, attn.q_scale.detach(), qn, H, M=M, N=H * DIM_HEAD, K=D)
+            ops.gemm_qknorm(xc, w["Wkv"], k, attn.k_scale.detach(), kn, 1, M=M, N=2 * DIM_HEAD, K=D, C2=v, c2_col0=DIM_HEAD)   # K/V from the un-normalised residual (:228)
+        else:
+            q_raw = torch.empty(M, H * DIM_HEAD, device=dev)
+            kv_raw = torch.empty(M, 2 * DIM_HEAD, device=dev)
+            ops.gemm(xn, w["Wq"], q_raw, M=M, N=H * DIM_HEAD, K=D)
+            ops.gemm(xc, w["Wkv"], kv_raw, M=M, N=2 * DIM_HEAD, K=D)      # K/V from the un-normalised residual (:228)
+            ops.qk_norm_fwd(q_raw, kv_raw, attn.q_scale.detach(), attn.k_scale.detach(), q, k, v, H)
         o = torch.empty(M, H * DIM_HEAD, dtype=T, device=dev)
         lse = torch.empty(B, H, N, device=dev)
         if side is not None:
@@ -555,8 +567,12 @@ def trunk_backward(tr, pw: PreparedWeights, saved, dy: torch.Tensor, B: int, N: 
                 relpos_backward(tr, N, saved["rp"], dtable)
         dq_raw = torch.empty(M, H * DIM_HEAD, dtype=T, device=dev)
         dkv_raw = torch.empty(M, 2 * DIM_HEAD, dtype=T, device=dev)
-        ops.qk_norm_bwd(dq, dk, dv, sv.q_raw, sv.kv_raw, attn.q_scale.detach(), attn.k_scale.detach(),
-                        dq_raw, dkv_raw, grad_of(attn.q_scale), grad_of(attn.k_scale), H)
+        if T in _H16 and _QKNORM_FUSED:                                  # sv.q_raw / sv.kv_raw hold the norms [M, H] / [M]
+            ops.qk_norm_bwd2(dq, dk, dv, sv.q, sv.k, sv.q_raw, sv.kv_raw, attn.q_scale.detach(), attn.k_scale.detach(),
+                             dq_raw, dkv_raw, grad_of(attn.q_scale), grad_of(attn.k_scale), H)
+        else:
+            ops.qk_norm_bwd(dq, dk, dv, sv.q_raw, sv.kv_raw, attn.q_scale.detach(), attn.k_scale.detach(),
+                            dq_raw, dkv_raw, grad_of(attn.q_scale), grad_of(attn.k_scale), H)
         dxn = torch.empty(M, D, dtype=T if _BF16_LN_GRAD else torch.float32, device=dev)
         kv16 = T in _H16 and _KV_DGRAD_H16
         tmp = torch.empty(M, D, dtype=T if kv16 else torch.float32, device=dev)      # kv16: the K/V term alone; else dx1 + the K/V term

@@ -221,6 +221,21 @@ def qk_norm_bwd(dq, dk, dv, q_raw, kv_raw, q_scale, k_scale, dq_raw, dkv_raw, dq
 _DBIAS_WS = {}
 
 
+def gemm_qknorm(A, B, C_, scale, norm_out, groups, *, M, N, K, C2=None, c2_col0=0):
+    """C = per-head l2-normalised, scaled A B^T in the 16-bit operand type (omlm_gemm_qknorm); norm_out [M, >= groups] fp32."""
+    hip.require_gpu(A, "A")
+    assert A.dtype in H16 and B.dtype == A.dtype and C_.dtype == A.dtype and norm_out.dtype == torch.float32 and scale.dtype == torch.float32
+    assert C2 is None or C2.dtype == A.dtype
+    call("omlm_gemm_qknorm", ptr(A), ptr(B), ptr(C_), ptr(C2), int(c2_col0), C2.shape[-1] if C2 is not None else 0, ptr(scale), ptr(norm_out),
+         norm_out.shape[-1] if norm_out.dim() > 1 else 1, int(groups), A.numel() // A.shape[-1], B.numel() // B.shape[-1], M, N, K,
+         A.shape[-1], B.shape[-1], C_.shape[-1], dcode(A.dtype), stream_ptr())
+
+
+def qk_norm_bwd2(dq, dk, dv, q, k, qn, kn, q_scale, k_scale, dq_raw, dkv_raw, dq_scale, dk_scale, H):
+    call("omlm_qk_norm_bwd2", ptr(dq), ptr(dk), ptr(dv), ptr(q), ptr(k), ptr(qn), ptr(kn), ptr(q_scale), ptr(k_scale),
+         ptr(dq_raw), ptr(dkv_raw), ptr(dq_scale), ptr(dk_scale), q.shape[0], H, dcode(dq_raw.dtype), stream_ptr())
+
+
 class AttnBias:
     """Rel-pos bias table of one attention layer in the two layouts the kernels read: `table` [N, ld] fp32 (row = i - j,
     column = head) and `tableT`, its transposed / zero-padded / log2(e)-scaled form (omlm_attn_bias_prepare).

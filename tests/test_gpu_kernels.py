@@ -372,6 +372,48 @@ def test_qk_norm_fwd_bwd(ops, dev, dtype):
     assert e < tol and eb < tol and es < 1e-4
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,K", [(300, 1024), (129, 200), (35, 64)])
+def test_gemm_qknorm_fused_projection_and_its_backward(ops, dev, dtype, M, K):
+    """The q / k projections with l2-norm + learned scale as GEMM epilogue (omlm_gemm_qknorm: q with H = 3 heads; k | v with v passed
+    through into its own buffer) against fp64 on the same 16-bit operands, and omlm_qk_norm_bwd2 (the backward from the normalised
+    16-bit outputs + saved norms) against autograd of the fp64 formula.  Ragged M (128-row tiles), K with and without whole 64-deep k-tiles."""
+    H = 3
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(M, K, generator=g).to(dev).to(dtype)
+    A2 = torch.randn(M, K, generator=g).to(dev).to(dtype)
+    Wq = (torch.randn(H * 64, K, generator=g) / math.sqrt(K)).to(dev).to(dtype)
+    Wkv = (torch.randn(128, K, generator=g) / math.sqrt(K)).to(dev).to(dtype)
+    qs = (1 + 0.2 * torch.randn(64, generator=g)).to(dev)
+    ks = (1 + 0.2 * torch.randn(64, generator=g)).to(dev)
+    q = torch.full((M, H * 64), 7.0, device=dev, dtype=dtype)
+    k = torch.full((M, 64), 7.0, device=dev, dtype=dtype)
+    v = torch.full((M, 64), 7.0, device=dev, dtype=dtype)
+    qn, kn = torch.zeros(M, H, device=dev), torch.zeros(M, device=dev)
+    ops.gemm_qknorm(A, Wq, q, qs, qn, H, M=M, N=H * 64, K=K)
+    ops.gemm_qknorm(A2, Wkv, k, ks, kn, 1, M=M, N=128, K=K, C2=v, c2_col0=64)
+    qr = (A.double() @ Wq.double().t()).requires_grad_(True)
+    kvr = (A2.double() @ Wkv.double().t()).requires_grad_(True)
+    qsr, ksr = qs.double().requires_grad_(True), ks.double().requires_grad_(True)
+    q_ref = torch.nn.functional.normalize(qr.view(M, H, 64), dim=-1) * qsr
+    k_ref = torch.nn.functional.normalize(kvr[:, :64], dim=-1) * ksr
+    v_ref = kvr[:, 64:]
+    tol = 5e-3 if dtype == torch.bfloat16 else 7e-4                  # one rounding of the outputs to the operand type
+    e = max(relerr(q, q_ref.reshape(M, -1).detach()), relerr(k, k_ref.detach()), relerr(v, v_ref.detach()))
+    en = max(relerr(qn, qr.detach().view(M, H, 64).norm(dim=-1)), relerr(kn, kvr.detach()[:, :64].norm(dim=-1)))
+    dq, dk, dv = (torch.randn(M, H * 64, generator=g).to(dev), torch.randn(M, 64, generator=g).to(dev), torch.randn(M, 64, generator=g).to(dev))
+    (q_ref.reshape(M, -1) * dq.double()).sum().add((k_ref * dk.double()).sum()).add((v_ref * dv.double()).sum()).backward()
+    dq_raw = torch.empty(M, H * 64, device=dev, dtype=dtype)
+    dkv_raw = torch.empty(M, 128, device=dev, dtype=dtype)
+    dqs, dks = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+    ops.qk_norm_bwd2(dq, dk, dv, q, k, qn, kn, qs, ks, dq_raw, dkv_raw, dqs, dks, H)
+    eb = max(relerr(dq_raw, qr.grad), relerr(dkv_raw, kvr.grad))
+    es = max(relerr(dqs, qsr.grad), relerr(dks, ksr.grad))
+    report(f"gemm_qknorm[{dtype},{M},{K}]", fwd=e, norms=en, bwd=eb, dscale=es)
+    # backward: xh comes from the ROUNDED outputs (2^-9 / 2^-11 per element) -- the projection term carries that rounding
+    assert e < tol and en < 2e-5 and eb < 3 * tol and es < 3 * tol, (e, en, eb, es)
+
+
 def naive_attention(q, k, v, bias, keymask, H, scale=8.0):
     """q [B,N,H*64], k,v [B,N,64] double; bias [N, >=H]; keymask [B,N] bool."""
     B, N, _ = q.shape
