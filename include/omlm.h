@@ -146,6 +146,16 @@ int omlm_embed_gather_bwd(const int* ids, const int* seg, const int* posidx,
                           int nseq, const float* dx, int B, int N, int D, float alpha,
                           const long long* table_rows, const long long* pos_rows, int* err_flag, void* stream);
 
+/* Training-batch preparation as one launch: eos append + labels + last-token drop + conditioning pad / eos masking + key mask
+   (TokenConditionedTransformerWrapper.forward, open_musiclm.py:340-376), per-quantizer offsets + start markers + concatenation
+   (TokenConditionedTransformer.forward, :116-130,:139-145) and the forgetful mask (generate_mask_with_prob, utils.py:49-56: the n_drop
+   largest of scores[b, 1:] are dropped).  ids[s]: int64 [B, len[s]]; labels[s]: int32 [B, len[s] + 1] or null; ids32 int32 [B, N]
+   (-2 = start token, offsets applied); keymask uint8 [B, N]; scores fp32 [B, N] or null (no forgetful mask);
+   N = sum_s (len[s] + 1) + (nseq - 1). */
+int omlm_prepare_train_batch(const long long* const* ids, int* const* labels, const int* len, const int* eos, const int* Q,
+                             const int* codebook, int nseq, int B, int pad_id, const float* scores, int n_drop,
+                             int* ids32, unsigned char* keymask, int N, void* stream);
+
 /* F.cross_entropy(logits, labels) pieces (open_musiclm.py:401-405): per-row lse + NLL sum; (softmax-onehot)*coef*g. */
 int omlm_cross_entropy_fwd(const float* logits, const int* labels, float* row_lse, float* nll_sum,
                            int R, int V, int ld, int* err_flag, void* stream);

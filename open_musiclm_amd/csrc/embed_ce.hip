@@ -195,3 +195,123 @@ extern "C" int omlm_cross_entropy_bwd(const float* logits, const int* labels, co
         hipLaunchKernelGGL(ce_bwd_kernel<h16_t>, grid, block, 0, as_stream(stream), logits, labels, row_lse, gscale, coef, (h16_t*)dlogits, R, V, ld, ldd);
     return omlm_post_launch("omlm_cross_entropy_bwd");
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Training-batch preparation of TokenConditionedTransformerWrapper.forward (open_musiclm.py:340-376) + the id flattening of
+// TokenConditionedTransformer.forward (:116-130) + generate_mask_with_prob (utils.py:49-56) as ONE launch: the reference's (and, until
+// round 4, this repo's) ~45 small torch kernels per step -- eos append, label clones, conditioning-pad / eos masking, per-quantizer
+// offsets, start markers, concatenations, the top-k of a randn row and its scatter -- were 0.3-0.6 ms of launch latency inside the
+// captured step.  One WAVE per sample:
+//   ids32 [B, N]   -2 start marker | conditioning sequences: (raw id, eos appended) with pad (-1) / eos positions -> 0, + codebook * (p mod Q)
+//                  | last sequence: raw ids (+ offsets), its appended eos dropped (:356)
+//   labels_s [B, L_s + 1] int32  raw ids with eos appended (:347,:355), per sequence (null pointer: not wanted)
+//   keymask [B, N] uint8  1 start tokens, live conditioning ids, every position of the last sequence; AND the forgetful mask: the n_drop
+//                  largest of scores[b, 1:] are dropped (position 0 never is; ties by lowest index, like the sampler)
+#define PREP_NV 64                                   /* register slots per lane: N <= 4096 */
+struct PrepSeq { const long long* ids; int* labels; int len; int eos; int Q; int codebook; int start; };
+struct PrepArgs { PrepSeq s[MAX_SEQ]; int nseq; int B; int N; int pad_id; const float* scores; int n_drop; int* ids32; unsigned char* keymask; };
+
+__device__ __forceinline__ unsigned prep_ord(float v) { const unsigned u = f2u(v); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+
+__global__ __launch_bounds__(64) void prepare_train_batch_kernel(PrepArgs a) {
+    const int b = blockIdx.x, lane = threadIdx.x, N = a.N;
+    int* idrow = a.ids32 + (size_t)b * N;
+    unsigned char* mrow = a.keymask + (size_t)b * N;
+    // ---- forgetful mask: threshold of the n_drop largest scores (radix descent on ballots, all in registers) ----
+    unsigned keys[PREP_NV];
+    const int nv = (N + 63) >> 6;
+    unsigned thr = 0xFFFFFFFFu;
+    int n_eq_keep = 0;
+    const bool forget = a.scores != nullptr && a.n_drop > 0;
+    if (forget) {
+        const float* sr = a.scores + (size_t)b * N;
+        float sv[PREP_NV];
+#pragma unroll
+        for (int j = 0; j < PREP_NV; ++j) { const int c = lane + 64 * j; sv[j] = sr[c < N ? c : N - 1]; }
+#pragma unroll
+        for (int j = 0; j < PREP_NV; ++j) {
+            const int c = lane + 64 * j;
+            keys[j] = (c < N && c > 0) ? prep_ord(sv[j]) : 0u;          // position 0 (and the tail) can never be among the top scores
+        }
+        unsigned t = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const unsigned cand = t | (1u << bit);
+            int cnt = 0;
+#pragma unroll
+            for (int j = 0; j < PREP_NV; ++j)
+                if (j < nv) cnt += __popcll(__ballot(keys[j] >= cand));
+            if (cnt >= a.n_drop) t = cand;
+        }
+        int ng = 0;
+#pragma unroll
+        for (int j = 0; j < PREP_NV; ++j)
+            if (j < nv) ng += __popcll(__ballot(keys[j] > t));
+        thr = t; n_eq_keep = a.n_drop - ng;
+    }
+    // ---- ids / labels / mask ----
+    int seen_eq = 0;
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int j = 0; j < PREP_NV; ++j) {
+        if (j >= nv) break;                                              // uniform
+        const int n = lane + 64 * j;
+        bool drop = false;
+        if (forget) {
+            const bool eq = keys[j] == thr && n < N && n > 0;
+            const unsigned long long eqmask = __ballot(eq);
+            const int rank = seen_eq + __popcll(eqmask & below);
+            drop = n < N && n > 0 && (keys[j] > thr || (eq && rank < n_eq_keep));
+            seen_eq += __popcll(eqmask);
+        }
+        if (n >= N) continue;
+        int si = 0;
+#pragma unroll
+        for (int q = 1; q < MAX_SEQ; ++q) if (q < a.nseq && n >= a.s[q].start) si = q;
+        const PrepSeq& sq = a.s[si];
+        const int p = n - sq.start - 1;                                  // index inside the sequence (-1: its start token)
+        const bool last = si == a.nseq - 1;
+        int id = -2;
+        unsigned char live = 1;
+        if (p >= 0) {
+            long long raw = p < sq.len ? sq.ids[(size_t)b * sq.len + p] : (long long)sq.eos;      // p == len: the appended eos (conditioning sequences only)
+            if (!last) {
+                live = (raw != a.pad_id && raw != sq.eos) ? 1 : 0;
+                if (!live) raw = 0;
+            }
+            id = (int)raw + (sq.Q > 1 ? sq.codebook * (p % sq.Q) : 0);
+        }
+        idrow[n] = id;
+        mrow[n] = (live && !drop) ? 1 : 0;
+    }
+    // labels: every sequence's ids with the eos appended
+    for (int q = 0; q < a.nseq; ++q) {
+        const PrepSeq& sq = a.s[q];
+        if (!sq.labels) continue;
+        int* lr = sq.labels + (size_t)b * (sq.len + 1);
+        for (int p = lane; p <= sq.len; p += 64) lr[p] = p < sq.len ? (int)sq.ids[(size_t)b * sq.len + p] : sq.eos;
+    }
+}
+
+// ids[s]: int64 [B, len[s]] (flattened 'b ... -> b (...)'); labels[s]: int32 [B, len[s] + 1] or null; ids32 / keymask: [B, N] with
+// N = sum_s (len[s] + 1) + (nseq - 1) ... i.e. one start token per sequence, an appended eos for every sequence but the last.
+extern "C" int omlm_prepare_train_batch(const long long* const* ids, int* const* labels, const int* len, const int* eos, const int* Q,
+                                        const int* codebook, int nseq, int B, int pad_id, const float* scores, int n_drop,
+                                        int* ids32, unsigned char* keymask, int N, void* stream) {
+    if (B <= 0) return OMLM_OK;
+    OMLM_CHECK_ARG(ids && len && eos && Q && codebook && ids32 && keymask && nseq >= 1 && nseq <= MAX_SEQ, "prepare_train_batch arguments");
+    OMLM_CHECK_ARG(N >= 1 && N <= 64 * PREP_NV, "prepare_train_batch: N must be 1..4096");
+    PrepArgs a;
+    memset(&a, 0, sizeof(a));
+    int pos = 0;
+    for (int s = 0; s < nseq; ++s) {
+        OMLM_CHECK_ARG(ids[s] && len[s] >= 0 && Q[s] >= 1, "prepare_train_batch: bad sequence");
+        a.s[s].ids = ids[s]; a.s[s].labels = labels ? labels[s] : nullptr; a.s[s].len = len[s]; a.s[s].eos = eos[s]; a.s[s].Q = Q[s];
+        a.s[s].codebook = codebook[s]; a.s[s].start = pos;
+        pos += 1 + len[s] + (s < nseq - 1 ? 1 : 0);
+    }
+    OMLM_CHECK_ARG(pos == N, "prepare_train_batch: N does not match the sequence lengths");
+    OMLM_CHECK_ARG(!scores || (n_drop >= 0 && n_drop < N), "prepare_train_batch: n_drop");
+    a.nseq = nseq; a.B = B; a.N = N; a.pad_id = pad_id; a.scores = scores; a.n_drop = scores ? n_drop : 0; a.ids32 = ids32; a.keymask = keymask;
+    hipLaunchKernelGGL(prepare_train_batch_kernel, dim3(B), dim3(64), 0, as_stream(stream), a);
+    return omlm_post_launch("omlm_prepare_train_batch");
+}

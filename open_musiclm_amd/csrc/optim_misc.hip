@@ -417,7 +417,11 @@ __device__ __forceinline__ unsigned f_ord(float f) { unsigned u = f2u(f); return
 // radix descent is a ballot + popcount on the scalar unit -- no LDS, no barrier.  (The first version used 256 threads, an LDS
 // image and two barriers per bit: ~25 us of the ~200 us a sampled id costs at B = 1.)  Optionally gathers the embedding row of the
 // sampled id (open_musiclm.py:123-134: id + quantizer offset) into x, so the decode step needs no separate gather launch.
-#define SAMPLE_NV 32
+// SAMPLE_NV (template): register slots per lane, 17 for V <= 1088 (the 1025-entry heads of every shipped model), 32 up to 2048.  A
+// single wave is a serial instruction stream (~5-8 cycles per dependent instruction): the round-4 trace showed 43.9 us per call with the
+// slot loops unrolled to 32 behind `j < nv` branches (32 bits x 32 slots of compare / branch / count), so the slot count is a compile-time
+// constant and the descent stops at the first threshold that cuts exactly k keys.
+template <int SAMPLE_NV>
 __global__ __launch_bounds__(64) void sample_kernel(const float* __restrict__ logits, const float* __restrict__ uniform,
                                                     long long* __restrict__ out, int V, int ld, int k, float temperature,
                                                     int forbid_last, const int* __restrict__ step_dev, long long* __restrict__ hist,
@@ -433,7 +437,7 @@ __global__ __launch_bounds__(64) void sample_kernel(const float* __restrict__ lo
     const float* ur = uniform + (size_t)row * V;
     unsigned keys[SAMPLE_NV];
     float lv[SAMPLE_NV], uv[SAMPLE_NV];
-    const int nv = (V + 63) >> 6;                      // live register slots (uniform)
+    constexpr int nv = SAMPLE_NV;                      // every slot is live or clamped: no per-slot branches
     // every load of the row -- logits AND uniforms -- is requested before anything waits.  (Round 4 kernel trace: 43.9 us per call at
     // B = 1, a quarter of a decode step: the uniforms were loaded inside `if (keep)`, one dependent memory round trip per register
     // slot, 17 in a row behind the running arg-max.)
@@ -457,41 +461,39 @@ __global__ __launch_bounds__(64) void sample_kernel(const float* __restrict__ lo
     }
     // largest threshold t such that count(keys >= t) >= k
     unsigned t = 0;
+    bool exact = false;                                 // count(keys >= t) == k: the kept set is exactly {keys >= t}
     for (int bit = 31; bit >= 0; --bit) {
         const unsigned cand = t | (1u << bit);
         int cnt = 0;
 #pragma unroll
-        for (int j = 0; j < SAMPLE_NV; ++j)
-            if (j < nv) cnt += __popcll(__ballot(keys[j] >= cand));
+        for (int j = 0; j < SAMPLE_NV; ++j) cnt += __popcll(__ballot(keys[j] >= cand));
         if (cnt >= k) t = cand;
+        if (cnt == k) { exact = true; break; }
     }
     // strictly-greater entries are all kept; of the entries equal to t keep the first (k - n_greater) by index
     int ng = 0;
+    if (!exact) {
 #pragma unroll
-    for (int j = 0; j < SAMPLE_NV; ++j)
-        if (j < nv) ng += __popcll(__ballot(keys[j] > t));
-    const int n_equal_keep = k - ng;
+        for (int j = 0; j < SAMPLE_NV; ++j) ng += __popcll(__ballot(keys[j] > t));
+    }
+    const int n_equal_keep = exact ? 0x7fffffff : k - ng;
     float best = -INFINITY;
     int besti = 0x7fffffff;
     int seen_eq = 0;
     const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
     for (int j = 0; j < SAMPLE_NV; ++j) {
-        if (j < nv) {                                   // uniform
-            const int c = lane + 64 * j;
-            const bool in = c < V;
-            const bool eq = in && keys[j] == t;
-            const unsigned long long eqmask = __ballot(eq);
-            const int rank = seen_eq + __popcll(eqmask & below);
-            const bool keep = in && (keys[j] > t || (eq && rank < n_equal_keep));
-            seen_eq += __popcll(eqmask);
-            if (keep) {
-                const float u = uv[j];
-                const float gum = -logf(-logf(u + 1e-20f) + 1e-20f);
-                const float v = lv[j] / temperature + gum;
-                if (v > best) { best = v; besti = c; }
-            }
-        }
+        const int c = lane + 64 * j;
+        const bool in = c < V;
+        const bool eq = in && keys[j] == t;
+        const unsigned long long eqmask = __ballot(eq);
+        const int rank = seen_eq + __popcll(eqmask & below);
+        const bool keep = in && (keys[j] > t || (eq && rank < n_equal_keep));
+        seen_eq += __popcll(eqmask);
+        // branch-free: the Gumbel term of every slot is formed (2 logs per slot), dead slots lose the comparison
+        const float gum = -logf(-logf(uv[j] + 1e-20f) + 1e-20f);
+        const float v = keep ? lv[j] / temperature + gum : -INFINITY;
+        if (v > best) { best = v; besti = c; }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -513,8 +515,10 @@ extern "C" int omlm_sample_topk_gumbel(const float* logits, const float* uniform
                                        int k, float temperature, int forbid_last, void* stream) {
     if (B <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(logits && uniform && out && V > 0 && V <= 2048 && k >= 1 && k <= V && temperature > 0.f, "sampler arguments");
-    hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(64), 0, as_stream(stream), logits, uniform, out, V, ld, k, temperature, forbid_last,
-                       (const int*)nullptr, (long long*)nullptr, (const float*)nullptr, 0ll, 0ll, (float*)nullptr, 0);
+    if (V <= 64 * 17) hipLaunchKernelGGL(sample_kernel<17>, dim3(B), dim3(64), 0, as_stream(stream), logits, uniform, out, V, ld, k, temperature, forbid_last,
+                                         (const int*)nullptr, (long long*)nullptr, (const float*)nullptr, 0ll, 0ll, (float*)nullptr, 0);
+    else hipLaunchKernelGGL(sample_kernel<32>, dim3(B), dim3(64), 0, as_stream(stream), logits, uniform, out, V, ld, k, temperature, forbid_last,
+                            (const int*)nullptr, (long long*)nullptr, (const float*)nullptr, 0ll, 0ll, (float*)nullptr, 0);
     return omlm_post_launch("omlm_sample_topk_gumbel");
 }
 
@@ -524,8 +528,10 @@ extern "C" int omlm_sample_topk_gumbel_at(const float* logits, const float* unif
                                           void* stream) {
     if (B <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(logits && uniform_base && step_dev && out && V > 0 && V <= 2048 && k >= 1 && k <= V && temperature > 0.f, "sampler arguments");
-    hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(64), 0, as_stream(stream), logits, uniform_base, out, V, ld, k, temperature,
-                       forbid_last, step_dev, hist, (const float*)nullptr, 0ll, 0ll, (float*)nullptr, 0);
+    if (V <= 64 * 17) hipLaunchKernelGGL(sample_kernel<17>, dim3(B), dim3(64), 0, as_stream(stream), logits, uniform_base, out, V, ld, k, temperature,
+                                         forbid_last, step_dev, hist, (const float*)nullptr, 0ll, 0ll, (float*)nullptr, 0);
+    else hipLaunchKernelGGL(sample_kernel<32>, dim3(B), dim3(64), 0, as_stream(stream), logits, uniform_base, out, V, ld, k, temperature,
+                            forbid_last, step_dev, hist, (const float*)nullptr, 0ll, 0ll, (float*)nullptr, 0);
     return omlm_post_launch("omlm_sample_topk_gumbel_at");
 }
 
@@ -538,8 +544,10 @@ extern "C" int omlm_sample_embed_at(const float* logits, const float* uniform_ba
     if (B <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(logits && uniform_base && step_dev && out && V > 0 && V <= 2048 && k >= 1 && k <= V && temperature > 0.f, "sampler arguments");
     OMLM_CHECK_ARG(emb_table && x && D > 0 && D % 4 == 0 && emb_rows > 0, "embedding arguments");
-    hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(64), 0, as_stream(stream), logits, uniform_base, out, V, ld, k, temperature,
-                       forbid_last, step_dev, hist, emb_table, emb_row_offset, emb_rows, x, D);
+    if (V <= 64 * 17) hipLaunchKernelGGL(sample_kernel<17>, dim3(B), dim3(64), 0, as_stream(stream), logits, uniform_base, out, V, ld, k, temperature,
+                                         forbid_last, step_dev, hist, emb_table, emb_row_offset, emb_rows, x, D);
+    else hipLaunchKernelGGL(sample_kernel<32>, dim3(B), dim3(64), 0, as_stream(stream), logits, uniform_base, out, V, ld, k, temperature,
+                            forbid_last, step_dev, hist, emb_table, emb_row_offset, emb_rows, x, D);
     return omlm_post_launch("omlm_sample_embed_at");
 }
 

@@ -36,8 +36,10 @@ _WGRAD_GROUP = os.environ.get("OMLM_WGRAD_GROUP", "1") == "1"      # grouped wei
 # The rel-pos-bias MLP (transformer.py:36-67: 3 x Linear(dim/2)+SiLU + Linear(heads) on N distances) is ~20 tiny fp32 kernels per
 # step, 4..36 workgroups each: ~0.4 ms of pure launch-to-launch latency when they sit in the trunk's stream.  They depend on
 # nothing but the weights (forward) / the finished d(table) (backward), so they run on a second HIP stream, forked and joined with
-# events (captured as a parallel branch of the micro-step graph).  OMLM_RELPOS_ASYNC=0 puts them back in line.
-_RELPOS_ASYNC = os.environ.get("OMLM_RELPOS_ASYNC", "1") == "1"
+# events (captured as a parallel branch of the micro-step graph): OMLM_RELPOS_ASYNC=1.  OFF since round 4: with the trunk's kernels now
+# filling the machine the branch contends for CUs more than it hides (same-box A/B, graph replay: 24.81 ms with it, 24.58 without), and
+# a single stream has no cross-stream hazards at all.
+_RELPOS_ASYNC = os.environ.get("OMLM_RELPOS_ASYNC", "0") == "1"
 # The MLP's 0.3-GFLOP fp32 GEMMs stay on the register-staged fp32 kernel (csrc/gemm.hip gemm_kernel<float>): 42 us either way, and the
 # hi/lo plane route (ops.operand_planes: extra buffers + a cache shared with the trunk's stream) buys nothing at this size.
 # OMLM_RELPOS_PLANES=1: the plane route (what rounds 2-3 ran).
@@ -618,6 +620,15 @@ def build_ids(model, all_token_ids: Sequence[torch.Tensor]) -> Tuple[torch.Tenso
     return torch.cat(parts, dim=1).contiguous(), lens
 
 
+class PreparedIds:
+    """ids32 [B, N] (start markers, offsets, conditioning masking already applied: ops.prepare_train_batch) + the per-sequence token counts,
+    handed to run_forward in place of the list of id tensors."""
+    __slots__ = ("ids32", "lens")
+
+    def __init__(self, ids32: torch.Tensor, lens: Sequence[int]):
+        self.ids32, self.lens = ids32, list(lens)
+
+
 def get_layout(model, B: int, lens: Sequence[int], device, final_rows_only: bool) -> SeqLayout:
     cache = model.__dict__.setdefault("_omlm_layouts", {})
     key = (B, tuple(lens), str(device), final_rows_only)
@@ -728,7 +739,10 @@ def run_forward(model, all_token_ids, self_attn_mask, only_final: bool, save: bo
                                   "(every shipped config uses 0)")
     require_gpu(model.start_tokens[0], "model parameters")
     ops.planes_begin()                       # bf16x3 operand planes live for this forward (+ its backward) only: ops.operand_planes
-    ids32, lens = build_ids(model, all_token_ids)
+    if isinstance(all_token_ids, PreparedIds):
+        ids32, lens = all_token_ids.ids32, all_token_ids.lens
+    else:
+        ids32, lens = build_ids(model, all_token_ids)
     require_gpu(ids32, "token ids")
     B, N = ids32.shape
     lay = get_layout(model, B, lens, ids32.device, final_rows_only)

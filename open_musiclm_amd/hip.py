@@ -48,6 +48,7 @@ SIGNATURES = {
     "omlm_ffmid_set_impl": [i32],
     "omlm_embed_gather_fwd": [vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, vp, vp, vp, vp],
     "omlm_embed_gather_bwd": [vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, f32, vp, vp, vp, vp],
+    "omlm_prepare_train_batch": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, i32, vp, vp, i32, vp],
     "omlm_cross_entropy_fwd": [vp, vp, vp, vp, i32, i32, i32, vp, vp],
     "omlm_cross_entropy_bwd": [vp, vp, vp, vp, f32, vp, i32, i32, i32, i32, i32, vp],
     "omlm_sumsq_accumulate": [vp, i64, vp, vp, vp],

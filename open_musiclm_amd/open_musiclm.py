@@ -7,6 +7,7 @@ sliding-window hierarchical decode.  Everything floating point goes through ``en
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -125,6 +126,9 @@ class TokenConditionedTransformer(nn.Module):
                                          bool(all_logits), *self.parameters())
 
 
+_GENERATE_MASK_ORIG = generate_mask_with_prob
+
+
 @beartype_jit
 class TokenConditionedTransformerWrapper(nn.Module):
     """open_musiclm.py:219-410."""
@@ -222,6 +226,44 @@ class TokenConditionedTransformerWrapper(nn.Module):
         sampled = mask_out_after_eos_id(sampled, pred_eos_id, keep_eos=include_eos_in_output)
         return sampled.reshape(batch, -1, Q)
 
+    # ---- the trainers' optimizer-step path: id / label / mask construction as ONE kernel launch -------------------------------------
+    def _fused_prepare_ok(self, all_token_ids, input_has_eos) -> bool:
+        """return_loss=True, return_logits=False on GPU tensors without unique_consecutive sequences (shipped configs: False) and with the
+        module's own generate_mask_with_prob (tests inject masks by replacing it: they take the torch path).  OMLM_FUSED_PREP=0: off."""
+        if input_has_eos or os.environ.get("OMLM_FUSED_PREP", "1") == "0" or generate_mask_with_prob is not _GENERATE_MASK_ORIG:
+            return False
+        if self.unique_consecutive and any(info.unique_consecutive for info in self.token_sequences):
+            return False
+        n_tot = sum(int(t.numel() // t.shape[0]) + 1 for t in all_token_ids) + len(all_token_ids) - 1
+        return all(t.is_cuda for t in all_token_ids) and n_tot <= 4096
+
+    def _forward_loss_fused(self, all_token_ids):
+        """Same arithmetic as _prepare + TokenConditionedTransformer.forward's id flattening + generate_mask_with_prob, in one launch
+        (ops.prepare_train_batch); consumes the RNG exactly like the torch path (one randn of the mask's shape).  Labels come back as
+        int32 tensors [B, len + 1]."""
+        device = self.device
+        ids = [_flat(t).to(device).long().contiguous() for t in all_token_ids]
+        B = ids[0].shape[0]
+        N = sum(t.shape[1] + 1 for t in ids) + len(ids) - 1
+        scores, n_drop = None, 0
+        if self.mask_prob > 0 and self.training:
+            n_drop = min(int(N * self.mask_prob), N - 1)
+            scores = torch.randn((B, N), device=device)
+        weights = [float(w) for w in self.cross_entropy_loss_weights]
+        seqs = self.token_sequences
+        ids32, keymask, labels, lens = ops.prepare_train_batch(ids, [int(e) for e in self.eos_ids], [s.num_quantizers for s in seqs],
+                                                               [s.codebook_size for s in seqs], self.pad_id, scores, n_drop,
+                                                               [True] * len(ids))
+        prepared = engine.PreparedIds(ids32, lens)
+        ignore = [False] * len(ids)
+        if torch.is_grad_enabled():
+            loss, *logits = self.transformer.loss_and_logits(prepared, labels, keymask, weights, ignore, False)
+        else:
+            with torch.enable_grad():
+                loss, *logits = self.transformer.loss_and_logits(prepared, labels, keymask, weights, ignore, False)
+            loss = loss.detach()
+        return loss, [l.transpose(1, 2) if l is not None else None for l in logits], labels
+
     def _prepare(self, all_token_ids, return_loss, input_has_eos):
         """eos append, labels, last-token drop, key mask (open_musiclm.py:340-376)."""
         batch, device = all_token_ids[0].shape[0], self.device
@@ -254,6 +296,8 @@ class TokenConditionedTransformerWrapper(nn.Module):
         """return_logits=False (extension, return_loss=True only): the logits of sequences whose loss weight is 0 are not computed
         and come back as None -- the trainers' optimizer steps read only the loss (trainer.py:428-447)."""
         assert len(all_token_ids) == len(self.token_sequences)
+        if return_loss and not return_logits and self._fused_prepare_ok(all_token_ids, input_has_eos):
+            return self._forward_loss_fused(all_token_ids)
         ids, labels, mask = self._prepare(all_token_ids, return_loss, input_has_eos)
         if not return_loss:
             return self.transformer(all_token_ids=ids, self_attn_mask=mask, **kwargs)

@@ -385,6 +385,26 @@ def embed_bwd(ids, seg, posidx, dtables, dstarts, dpos_tables, dx, alpha):
          ptr(index_error_flag(dx.device)), stream_ptr())
 
 
+def prepare_train_batch(raw_ids, eos_ids, quantizers, codebooks, pad_id, scores, n_drop, want_labels):
+    """One launch for the wrapper's id / label / key-mask construction (omlm_prepare_train_batch).  raw_ids: list of int64 [B, len_s]
+    contiguous; returns (ids32 [B, N], keymask uint8 [B, N], labels: list of int32 [B, len_s + 1] or None, lens: the per-sequence token
+    counts the engine's layout wants -- len_s + 1 for conditioning sequences, len_last for the predicted one)."""
+    n = len(raw_ids)
+    B, dev = raw_ids[0].shape[0], raw_ids[0].device
+    for t in raw_ids:
+        hip.require_gpu(t, "token ids")
+        assert t.dtype == torch.int64 and t.dim() == 2 and t.is_contiguous() and t.shape[0] == B
+    lens = [int(t.shape[1]) for t in raw_ids]
+    N = sum(l + 1 for l in lens) + (n - 1)
+    ids32 = torch.empty(B, N, dtype=torch.int32, device=dev)
+    keymask = torch.empty(B, N, dtype=torch.uint8, device=dev)
+    labels = [torch.empty(B, l + 1, dtype=torch.int32, device=dev) if w else None for l, w in zip(lens, want_labels)]
+    arr_i = lambda v: (C.c_int * n)(*[int(x) for x in v])
+    call("omlm_prepare_train_batch", _ptr_array(raw_ids), _ptr_array(labels), arr_i(lens), arr_i(eos_ids), arr_i(quantizers), arr_i(codebooks),
+         n, B, int(pad_id), ptr(scores), int(n_drop), ptr(ids32), ptr(keymask), N, stream_ptr())
+    return ids32, keymask, labels, [l + 1 for l in lens[:-1]] + [lens[-1]]
+
+
 def ce_fwd(logits, labels, row_lse, nll_sum, V):
     R, ld = logits.shape
     call("omlm_cross_entropy_fwd", ptr(logits), ptr(labels), ptr(row_lse), ptr(nll_sum), R, V, ld,

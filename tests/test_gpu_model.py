@@ -917,6 +917,130 @@ def test_bench_self_launches_without_a_launcher(dev):
     assert np.isfinite(out["final_loss"])
 
 
+@pytest.mark.parametrize("stage,B", [("coarse", 5), ("fine", 2), ("semantic", 3)])
+def test_fused_batch_preparation_equals_the_torch_path(dev, stage, B, monkeypatch):
+    """omlm_prepare_train_batch (one launch) against the wrapper's torch construction (open_musiclm.py:340-376 + :116-130 + utils.py:49-56
+    restated in _prepare / engine.build_ids / generate_mask_with_prob): ids32, key mask (with the forgetful mask from the SAME randn
+    draw, pads in the conditioning sequences, engineered ties in the scores) and labels bit for bit; then the training loss of the two
+    paths from the same RNG state is the same number."""
+    from open_musiclm_amd import engine, ops
+    from open_musiclm_amd import open_musiclm as M
+    from open_musiclm_amd.utils import generate_mask_with_prob
+    torch.manual_seed(0)
+    kw = dict(dim=64, depth=1, heads=1, ff_dropout=0.0, precision="bf16")
+    if stage == "coarse":
+        model = M.create_coarse_transformer(num_coarse_quantizers=3, **kw).to(dev)
+        shapes, weights = [(B, 12, 1), (B, 37), (B, 40, 3)], [0., 0., 1.]
+    elif stage == "fine":
+        model = M.create_fine_transformer(num_coarse_quantizers=3, num_fine_quantizers=5, **kw).to(dev)
+        shapes, weights = [(B, 12, 1), (B, 21, 3), (B, 21, 5)], [0., 0., 1.]
+    else:
+        model = M.create_semantic_transformer(**kw).to(dev)
+        shapes, weights = [(B, 12, 1), (B, 131)], [0., 1.]
+    g = torch.Generator().manual_seed(11)
+    raw = [torch.randint(0, 1024, sh, generator=g).to(dev) for sh in shapes]
+    raw[0][0, 3:] = -1                                     # padded conditioning ids
+    wrapper = M.TokenConditionedTransformerWrapper(transformer=model, unique_consecutive=False, cross_entropy_loss_weights=weights, mask_prob=0.15)
+    wrapper.train()
+    flat = [t.reshape(B, -1).long().contiguous() for t in raw]
+    N = sum(t.shape[1] + 1 for t in flat) + len(flat) - 1
+    n_drop = min(int(N * 0.15), N - 1)
+    scores = torch.randn(B, N, generator=g).to(dev)
+    scores[1, 5:9] = scores[1].topk(n_drop).values[-1]     # ties at the threshold: exactly n_drop positions must still go
+    seqs = model.token_sequences
+    ids32, keymask, labels, lens = ops.prepare_train_batch(flat, [int(e) for e in wrapper.eos_ids], [s_.num_quantizers for s_ in seqs],
+                                                           [s_.codebook_size for s_ in seqs], wrapper.pad_id, scores, n_drop, [True] * len(flat))
+    # torch path on the same scores
+    monkeypatch.setattr(M, "generate_mask_with_prob", lambda shape, p, device: torch.ones(shape, device=device, dtype=torch.bool))
+    t_ids, t_labels, t_mask = wrapper._prepare(raw, True, False)
+    t_ids32, t_lens = engine.build_ids(model, t_ids)
+    sc = scores.clone(); sc[:, 0] = torch.finfo(sc.dtype).min
+    assert torch.equal(ids32, t_ids32) and list(lens) == list(t_lens)
+    for a_, b_ in zip(labels, t_labels):
+        assert torch.equal(a_.long(), b_)
+    assert int((keymask == 0).sum()) >= B * n_drop and torch.equal(keymask[:, 0], torch.ones(B, dtype=torch.uint8, device=dev))
+    for b in range(B):
+        dropped = (~keymask[b].bool()) & t_mask[b]         # positions the forgetful mask removed
+        assert int(dropped.sum()) + int((~t_mask[b]).sum() - ((~t_mask[b]) & keymask[b].bool()).sum()) >= 0
+        kth = sc[b].topk(n_drop).values[-1]
+        forgot = torch.zeros(N, dtype=torch.bool, device=dev)
+        forgot[(sc[b] > kth).nonzero().flatten()] = True
+        eq = (sc[b] == kth).nonzero().flatten()
+        forgot[eq[: n_drop - int(forgot.sum())]] = True     # ties: lowest indices first
+        assert int(forgot.sum()) == n_drop
+        assert torch.equal(keymask[b].bool(), t_mask[b] & ~forgot), b
+    monkeypatch.undo()
+    # end to end: both paths draw the same randn -> the same loss
+    torch.manual_seed(123)
+    loss_f, logits_f, labels_f = wrapper(all_token_ids=raw, return_loss=True, return_logits=False)
+    monkeypatch.setenv("OMLM_FUSED_PREP", "0")
+    torch.manual_seed(123)
+    loss_t, _, _ = wrapper(all_token_ids=raw, return_loss=True, return_logits=False)
+    assert labels_f[-1].dtype == torch.int32 and float(loss_f) == float(loss_t), (float(loss_f), float(loss_t))
+    loss_f.backward()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
+def test_generate_top_match_ranks_samples_by_clap_similarity(dev, monkeypatch):
+    """MusicLM.generate_top_match (open_musiclm.py:1039-1071): num_samples waves per prompt through the hierarchical decode, re-embedded
+    by CLAP and ranked by cosine similarity with the prompt's text embedding.  The towers are stand-ins (weights unobtainable offline):
+    a text -> ids / text -> embedding / audio -> embedding object with the reference's call signature, a codec that turns ids into a
+    waveform, and a pass-through `torchaudio.functional.resample` (equal rates).  Checked: shapes, the returned similarities are the
+    top-k of ALL samples' similarities recomputed here from the returned order, sorted descending, and the waves are the matching rows."""
+    import sys
+    import types
+    from open_musiclm_amd import open_musiclm as M
+    ta, taf = types.ModuleType("torchaudio"), types.ModuleType("torchaudio.functional")
+    taf.resample = lambda wave, a, b: wave if a == b else torch.nn.functional.interpolate(wave[:, None], scale_factor=b / a, mode="linear")[:, 0]
+    ta.functional = taf
+    monkeypatch.setitem(sys.modules, "torchaudio", ta)
+    monkeypatch.setitem(sys.modules, "torchaudio.functional", taf)
+    torch.manual_seed(0)
+    tiny = dict(dim=64, depth=1, heads=1, ff_dropout=0.0)
+    cb = dict(clap_codebook_size=32, semantic_codebook_size=48, acoustic_codebook_size=40)
+    sem = M.create_semantic_transformer(**tiny, clap_codebook_size=32, semantic_codebook_size=48, precision="bf16x3").to(dev)
+    coarse = M.create_coarse_transformer(**tiny, num_coarse_quantizers=3, precision="bf16x3", **cb).to(dev)
+    fine = M.create_fine_transformer(**tiny, num_coarse_quantizers=3, num_fine_quantizers=5, clap_codebook_size=32, acoustic_codebook_size=40,
+                                     precision="bf16x3").to(dev)
+
+    class Clap:                                     # ClapQuantized's call signature (clap_quantized.py:57-87)
+        sample_rate = 16000
+        seen_audio = []
+
+        def __call__(self, *, text_input=None, audio_input=None, return_embedding=False):
+            if text_input is not None:
+                h = torch.tensor([[sum(map(ord, t)) % 29 + i for i in range(12)] for t in text_input], device=dev)
+                if not return_embedding:
+                    return (h % 32)[:, :, None]                                  # [B, 12, 1] conditioning ids
+                return torch.nn.functional.normalize(h.float(), dim=-1)
+            assert return_embedding and audio_input.dim() == 2
+            Clap.seen_audio.append(audio_input.clone())
+            feats = torch.stack([audio_input[:, i::12].mean(-1) for i in range(12)], dim=-1)
+            return feats + 0.01
+
+    class Codec:
+        sample_rate = 16000
+
+        def decode_from_codebook_indices(self, ids):                             # [B, T, Q] -> [B, 1, T * 8]: any deterministic map will do
+            w = (ids.float().mean(-1) / 40.0 - 0.5 + 0.05 * ids[..., 0].float().sin())
+            return w.repeat_interleave(8, dim=-1)[:, None]
+    mlm = M.MusicLM(wav2vec=None, clap=Clap(), neural_codec=Codec(), semantic_transformer=sem, coarse_transformer=coarse, fine_transformer=fine)
+    kw = dict(output_seconds=4, semantic_window_seconds=2, coarse_window_seconds=2, fine_window_seconds=1, semantic_steps_per_second=6,
+              acoustic_steps_per_second=4)                   # the window arithmetic of the golden MusicLM.forward case
+    waves, sims = mlm.generate_top_match(text=["a slow piano", "drums"], num_samples=4, num_top_matches=2, **kw)
+    assert len(waves) == len(sims) == 2 and len(Clap.seen_audio) == 2
+    for p, (w, sm, audio) in enumerate(zip(waves, sims, Clap.seen_audio)):
+        assert w.shape[0] == 2 and sm.shape == (2,) and w.shape[1] == audio.shape[1]
+        text_lat = Clap()(text_input=[["a slow piano", "drums"][p]], return_embedding=True).repeat(4, 1)
+        all_sim = torch.nn.functional.cosine_similarity(text_lat, Clap()(audio_input=audio, return_embedding=True), dim=-1).cpu()
+        Clap.seen_audio.pop()                                                    # the recomputation above logged itself
+        top = all_sim.topk(2, sorted=True)
+        assert torch.allclose(sm, top.values, atol=1e-6) and sm[0] >= sm[1]
+        # int16 round trip of the reference (utils.int16_to_float32(float32_to_int16(.))) is what CLAP saw; the returned waves are the raw rows
+        assert w.shape == (2, audio.shape[1])
+    report("generate_top_match", sims=[[float(v) for v in s_] for s_ in sims])
+
+
 @pytest.mark.parametrize("use_cache", [True, False])
 def test_musiclm_forward_matches_reference_golden_tokens(golden_dir, dev, monkeypatch, use_cache):
     """MusicLM.forward (open_musiclm.py:864-1035 of the reference) token-level parity: the reference ran on tiny stages with
