@@ -207,19 +207,22 @@ extern "C" int omlm_cross_entropy_bwd(const float* logits, const int* labels, co
 //   labels_s [B, L_s + 1] int32  raw ids with eos appended (:347,:355), per sequence (null pointer: not wanted)
 //   keymask [B, N] uint8  1 start tokens, live conditioning ids, every position of the last sequence; AND the forgetful mask: the n_drop
 //                  largest of scores[b, 1:] are dropped (position 0 never is; ties by lowest index, like the sampler)
-#define PREP_NV 64                                   /* register slots per lane: N <= 4096 */
+#define PREP_NV_MAX 64                               /* register slots per lane: N <= 4096 */
 struct PrepSeq { const long long* ids; int* labels; int len; int eos; int Q; int codebook; int start; };
 struct PrepArgs { PrepSeq s[MAX_SEQ]; int nseq; int B; int N; int pad_id; const float* scores; int n_drop; int* ids32; unsigned char* keymask; };
 
 __device__ __forceinline__ unsigned prep_ord(float v) { const unsigned u = f2u(v); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 
+// PREP_NV: slots per lane as a compile-time constant (a lone wave is a serial instruction stream: with 64 slots behind `j < nv` tests the
+// radix descent alone was ~70 us at N = 1116); the descent stops at the first threshold that cuts exactly n_drop keys.
+template <int PREP_NV>
 __global__ __launch_bounds__(64) void prepare_train_batch_kernel(PrepArgs a) {
     const int b = blockIdx.x, lane = threadIdx.x, N = a.N;
     int* idrow = a.ids32 + (size_t)b * N;
     unsigned char* mrow = a.keymask + (size_t)b * N;
     // ---- forgetful mask: threshold of the n_drop largest scores (radix descent on ballots, all in registers) ----
     unsigned keys[PREP_NV];
-    const int nv = (N + 63) >> 6;
+    constexpr int nv = PREP_NV;
     unsigned thr = 0xFFFFFFFFu;
     int n_eq_keep = 0;
     const bool forget = a.scores != nullptr && a.n_drop > 0;
@@ -234,26 +237,27 @@ __global__ __launch_bounds__(64) void prepare_train_batch_kernel(PrepArgs a) {
             keys[j] = (c < N && c > 0) ? prep_ord(sv[j]) : 0u;          // position 0 (and the tail) can never be among the top scores
         }
         unsigned t = 0;
+        bool exact = false;
         for (int bit = 31; bit >= 0; --bit) {
             const unsigned cand = t | (1u << bit);
             int cnt = 0;
 #pragma unroll
-            for (int j = 0; j < PREP_NV; ++j)
-                if (j < nv) cnt += __popcll(__ballot(keys[j] >= cand));
+            for (int j = 0; j < PREP_NV; ++j) cnt += __popcll(__ballot(keys[j] >= cand));
             if (cnt >= a.n_drop) t = cand;
+            if (cnt == a.n_drop) { exact = true; break; }
         }
         int ng = 0;
+        if (!exact) {
 #pragma unroll
-        for (int j = 0; j < PREP_NV; ++j)
-            if (j < nv) ng += __popcll(__ballot(keys[j] > t));
-        thr = t; n_eq_keep = a.n_drop - ng;
+            for (int j = 0; j < PREP_NV; ++j) ng += __popcll(__ballot(keys[j] > t));
+        }
+        thr = t; n_eq_keep = exact ? 0x7fffffff : a.n_drop - ng;
     }
     // ---- ids / labels / mask ----
     int seen_eq = 0;
     const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
     for (int j = 0; j < PREP_NV; ++j) {
-        if (j >= nv) break;                                              // uniform
         const int n = lane + 64 * j;
         bool drop = false;
         if (forget) {
@@ -299,7 +303,7 @@ extern "C" int omlm_prepare_train_batch(const long long* const* ids, int* const*
                                         int* ids32, unsigned char* keymask, int N, void* stream) {
     if (B <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(ids && len && eos && Q && codebook && ids32 && keymask && nseq >= 1 && nseq <= MAX_SEQ, "prepare_train_batch arguments");
-    OMLM_CHECK_ARG(N >= 1 && N <= 64 * PREP_NV, "prepare_train_batch: N must be 1..4096");
+    OMLM_CHECK_ARG(N >= 1 && N <= 64 * PREP_NV_MAX, "prepare_train_batch: N must be 1..4096");
     PrepArgs a;
     memset(&a, 0, sizeof(a));
     int pos = 0;
@@ -312,6 +316,10 @@ extern "C" int omlm_prepare_train_batch(const long long* const* ids, int* const*
     OMLM_CHECK_ARG(pos == N, "prepare_train_batch: N does not match the sequence lengths");
     OMLM_CHECK_ARG(!scores || (n_drop >= 0 && n_drop < N), "prepare_train_batch: n_drop");
     a.nseq = nseq; a.B = B; a.N = N; a.pad_id = pad_id; a.scores = scores; a.n_drop = scores ? n_drop : 0; a.ids32 = ids32; a.keymask = keymask;
-    hipLaunchKernelGGL(prepare_train_batch_kernel, dim3(B), dim3(64), 0, as_stream(stream), a);
+    const int nv = (N + 63) / 64;
+    if (nv <= 9)       hipLaunchKernelGGL(prepare_train_batch_kernel<9>, dim3(B), dim3(64), 0, as_stream(stream), a);
+    else if (nv <= 18) hipLaunchKernelGGL(prepare_train_batch_kernel<18>, dim3(B), dim3(64), 0, as_stream(stream), a);
+    else if (nv <= 32) hipLaunchKernelGGL(prepare_train_batch_kernel<32>, dim3(B), dim3(64), 0, as_stream(stream), a);
+    else               hipLaunchKernelGGL(prepare_train_batch_kernel<64>, dim3(B), dim3(64), 0, as_stream(stream), a);
     return omlm_post_launch("omlm_prepare_train_batch");
 }

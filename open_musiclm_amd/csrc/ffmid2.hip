@@ -116,6 +116,9 @@ __device__ __forceinline__ void keep_words(unsigned long long seed, unsigned lon
 #ifndef FS_OCC
 #define FS_OCC 1          // workgroups per CU the forward's register budget is sized for
 #endif
+#ifndef FS_EARLY
+#define FS_EARLY 1        // 1: a row's registers are re-requested (next batch) the moment sweep 1 has consumed them -- the loads are in flight
+#endif                    //    through the rest of the sweep too, not only through the reduction / barrier / store phase (0: the round-2 order)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // forward.  grid: B * strips workgroups of NT threads (NT = chunks of 8 channels rounded up to waves); strip s of sample b
@@ -211,7 +214,14 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
 #pragma unroll
                 for (int i = 0; i < 4; ++i) g[r][i] = splat2(0.f);
             }
+#if FS_EARLY
+            if (tb + RB_ + r < t1) {                     // this row's registers are free: the next batch's row r leaves now
+                rv[r].load(h1 + (row0 + tb + RB_ + r) * ld + colc);
+                rg[r].load(h1 + (row0 + tb + RB_ + r) * ld + Fp + colc);
+            }
+#endif
         }
+#if !FS_EARLY
         // next batch's rows: in flight during the reduction and the second sweep
 #pragma unroll
         for (int r = 0; r < RB_; ++r)
@@ -219,6 +229,7 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
                 rv[r].load(h1 + (row0 + tb + RB_ + r) * ld + colc);
                 rg[r].load(h1 + (row0 + tb + RB_ + r) * ld + Fp + colc);
             }
+#endif
 #pragma unroll
         for (int r = 0; r < RB_; ++r) { ls[r] = wave_sum(ls[r]); lq[r] = wave_sum(lq[r]); }
         if (lane == 0) {
@@ -293,19 +304,32 @@ __global__ __launch_bounds__(256) void ffmid2_rowsum_kernel(const T* __restrict_
 #pragma unroll
         for (int i = 0; i < 4; ++i) { dg[k][i] = splat2(0.f); gmv[k][i] = a.get(i); }
     }
+    // Software-pipelined over the wave's rows without a second register set: chunk k of the NEXT row is requested the moment chunk k of
+    // this row has been consumed, and the row's rstd travels with its data -- the reductions and the store of a row overlap the next row's
+    // loads (round 3: every row paid two serial round trips, its data and then, behind the reductions, rstd[row]: 3.8 TB/s).
+    Ch8<T> d[MAXC], gq[MAXC];
+    unsigned bits[MAXC];
+    float rs_next = 0.f;
+    auto request = [&](int row, int k) {
+        const int ch = (lane + 64 * k) * 8;
+        if (ch < Fp) {
+            d[k].load(dh2 + (size_t)row * Fp + ch);
+            gq[k].load(ghs + (size_t)row * Fp + ch);
+            bits[k] = (p > 0.f) ? drop_bits[(size_t)row * (Fp >> 3) + (ch >> 3)] : 0xFFu;
+        }
+    };
+    {
+        const int row0 = blockIdx.x * 4 + wave;
+        if (row0 < M) {
+#pragma unroll
+            for (int k = 0; k < MAXC; ++k) request(row0, k);
+            rs_next = rstd[row0];
+        }
+    }
     for (int row = blockIdx.x * 4 + wave; row < M; row += nwaves) {
         v2 s1 = splat2(0.f), s2 = splat2(0.f);
-        Ch8<T> d[MAXC], gq[MAXC];
-        unsigned bits[MAXC];
-#pragma unroll
-        for (int k = 0; k < MAXC; ++k) {
-            const int ch = (lane + 64 * k) * 8;
-            if (ch < Fp) {
-                d[k].load(dh2 + (size_t)row * Fp + ch);
-                gq[k].load(ghs + (size_t)row * Fp + ch);
-                bits[k] = (p > 0.f) ? drop_bits[(size_t)row * (Fp >> 3) + (ch >> 3)] : 0xFFu;
-            }
-        }
+        const int nxt = row + nwaves;
+        const float rs_cur = rs_next;
 #pragma unroll
         for (int k = 0; k < MAXC; ++k) {
             const int ch = (lane + 64 * k) * 8;
@@ -322,10 +346,12 @@ __global__ __launch_bounds__(256) void ffmid2_rowsum_kernel(const T* __restrict_
                     s2 = fma2(gy, gh, s2);
                 }
             }
+            if (nxt < M) request(nxt, k);
         }
+        if (nxt < M) rs_next = rstd[nxt];
         const float t1 = wave_sum(s1[0] + s1[1]), t2 = wave_sum(s2[0] + s2[1]);
         if (lane == 0) {
-            const float rs = rstd[row] / (float)F;
+            const float rs = rs_cur / (float)F;
             bc[2 * (size_t)row] = rs * t1;
             bc[2 * (size_t)row + 1] = rs * t2;
         }
