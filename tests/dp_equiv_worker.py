@@ -16,6 +16,8 @@ sys.path.insert(0, ROOT)
 
 
 def main():
+    import faulthandler
+    faulthandler.dump_traceback_later(150, exit=True)          # a hung collective / kernel: say where, then die (the test kills the peer)
     mode, out_path = sys.argv[1], sys.argv[2]
     from open_musiclm_amd import open_musiclm as M
     from open_musiclm_amd.data import SyntheticTokenDataset
