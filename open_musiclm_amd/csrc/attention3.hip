@@ -269,6 +269,11 @@ void attn3_bwd_dkv_kernel(const h16_t* __restrict__ q, const h16_t* __restrict__
     }
 }
 
+__global__ __launch_bounds__(256) void a3_zero_kernel(float4* __restrict__ p, size_t n4) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) p[i] = z;
+}
+
 static int a3_chunk(int B, int N) {
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("OMLM_ATTN3_CH"); forced = e ? atoi(e) : 0; }
@@ -298,13 +303,19 @@ int attn3_bwd_dkv_launch(const void* q, const void* k, const void* v, const floa
     const size_t lds = (size_t)A3_NST * A3_STAGE;             // 48 KiB (the final transposes reuse it: 4 x 8448 B)
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)attn3_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    const size_t gbytes = (size_t)B * N * 64 * sizeof(float);
-    if ((char*)dv == (char*)dk + gbytes) {                    // one allocation (the host's usual case): one fill node instead of two
-        if (hipMemsetAsync(dk, 0, 2 * gbytes, st) != hipSuccess) return OMLM_ERR_LAUNCH;
-    } else {
-        if (hipMemsetAsync(dk, 0, gbytes, st) != hipSuccess) return OMLM_ERR_LAUNCH;
-        if (hipMemsetAsync(dv, 0, gbytes, st) != hipSuccess) return OMLM_ERR_LAUNCH;
-    }
+    // Zero fill by a KERNEL of this library, not hipMemsetAsync: as a memset node of a captured micro-step the fill detached everything
+    // behind it from the graph's completion -- the rest of the backward (this layer's dK / dV onwards) was still running when the launch
+    // had "finished" and the optimizer's kernels started (round 4: after one fp16 overflow the skipped step's gradient clear raced with
+    // those late writes and every later step stayed non-finite; OMLM_ATTN_DKV3=0, i.e. no memset node, or a host sync after the replay,
+    // cured it).  A kernel node is ordered like every other launch.
+    const size_t gfloats = (size_t)B * N * 64;
+    auto fill = [&](float* p, size_t n) {
+        const size_t n4 = n / 4;                               // n = B N 64: a multiple of 4; rows are 256-byte aligned
+        unsigned blocks = (unsigned)((n4 + 255) / 256); if (blocks > 8192u) blocks = 8192u;
+        hipLaunchKernelGGL(a3_zero_kernel, dim3(blocks), dim3(256), 0, st, (float4*)p, n4);
+    };
+    if (dv == dk + gfloats) fill(dk, 2 * gfloats);            // one allocation (the host's usual case): one fill launch instead of two
+    else { fill(dk, gfloats); fill(dv, gfloats); }
     hipLaunchKernelGGL(attn3_bwd_dkv_kernel, dim3(B * wps), dim3(A3_T), lds, st, (const h16_t*)q, (const h16_t*)k, (const h16_t*)v, keymask,
                        (const h16_t*)dout, lse, delta, dk, dv, biasT, ldT, B, N, H, scale, CH, wps);
     return omlm_post_launch("omlm_mqa_attn_bwd");

@@ -754,6 +754,48 @@ def test_graphed_bf16x3_training_tracks_eager_over_optimizer_steps(dev):
     assert relerr(wq_g, wq_e) < 3e-2 and relerr(wo_g, wo_e) < 3e-2
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_graph_replay_is_complete_when_the_next_kernel_starts(dev, precision):
+    """Stream order across a HIP-graph replay: the squared gradient norm taken by a kernel enqueued RIGHT AFTER the replay (what the fused
+    optimizer does) must equal the one taken after a device-wide synchronise.  Round 4 found the 16-bit attention backward's hipMemsetAsync
+    (a memset node in the captured micro-step) detaching the rest of the backward from the graph's completion: the optimizer's kernels
+    overlapped the backward's tail (seen as a permanently non-finite fp16 run after one overflow).  The fill is a kernel node now."""
+    from open_musiclm_amd import ops
+    from open_musiclm_amd import open_musiclm as M
+    from open_musiclm_amd.graph import GraphedForwardBackward
+    from open_musiclm_amd.optimizer import get_optimizer
+    torch.manual_seed(0)
+    model = M.create_coarse_transformer(dim=1024, depth=2, heads=8, num_coarse_quantizers=3, ff_dropout=0.1, precision=precision).to(dev)
+    stage = M.CoarseStage(coarse_transformer=model, cross_entropy_loss_weights=[0., 0., 1.]).train()
+    opt = get_optimizer(model.parameters(), lr=1e-4, wd=0.01)
+    opt.zero_grad()
+    g = torch.Generator().manual_seed(4)
+    kw = dict(clap_token_ids=torch.randint(0, 1024, (4, 12, 1), generator=g).to(dev), semantic_token_ids=torch.randint(0, 1024, (4, 199), generator=g).to(dev),
+              coarse_token_ids=torch.randint(0, 1024, (4, 300, 3), generator=g).to(dev))
+    fb = GraphedForwardBackward(lambda **k: stage(**k, return_loss=True, return_logits=False)[0])
+    fb.prepare(kw, after_warmup=lambda: (opt.mark_grads_dirty(), opt.zero_grad()))
+    assert fb.graph is not None, fb.capture_error
+    G = opt.flat_grad
+    n1, n2 = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+    part = torch.empty(2048, device=dev)
+    worst = 0.0
+    for rep in range(6):
+        G.zero_()
+        torch.cuda.synchronize()
+        fb(**kw)
+        n1.zero_()
+        ops.sumsq_accumulate(G, n1, part)                   # enqueued behind the replay, no host wait in between
+        torch.cuda.synchronize()
+        n2.zero_()
+        ops.sumsq_accumulate(G, n2, part)
+        torch.cuda.synchronize()
+        a, b = float(n1), float(n2)
+        assert np.isfinite(a) and np.isfinite(b) and b > 0
+        worst = max(worst, abs(a - b) / b)
+    report(f"graph_replay_complete[{precision}]", worst_rel_diff=worst)
+    assert worst == 0.0, worst
+
+
 def test_train_coarse_stage_script_flow_on_a_preprocessed_store(dev, golden_dir, tmp_path):
     """The call sequence of the reference's scripts/train_coarse_stage.py (:33-75) -- JSON configs -> load_model_config /
     load_training_config -> create_coarse_transformer_from_config -> create_single_stage_trainer_from_config(..., accelerate_kwargs with
@@ -853,20 +895,28 @@ def test_data_parallel_step_equals_single_process_accumulation(dev, tmp_path):
     worker = os.path.join(ROOT, "tests", "dp_equiv_worker.py")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", OMLM_DP_BACKEND="gloo", LOCAL_RANK="0")
     outs = [str(tmp_path / f"dp{r}.pt") for r in range(2)]
-    procs = [subprocess.Popen([sys.executable, worker, "dp", outs[r]], env=dict(env, RANK=str(r), WORLD_SIZE="2"),
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
     import time
-    t_end = time.time() + 240                     # both ranks normally finish in ~25 s; a crashed peer leaves the other in a collective
-    while time.time() < t_end and any(p.poll() is None for p in procs):
-        if any(p.poll() not in (None, 0) for p in procs):
-            time.sleep(3)                          # a rank died: give the other a moment, then stop waiting for its collective
-            break
-        time.sleep(0.5)
-    for p in procs:
-        if p.poll() is None:
-            p.kill()
-    logs = [p.communicate()[0].decode() for p in procs]
-    assert all(p.returncode == 0 for p in procs), "\n----- rank log -----\n".join(l[-3000:] for l in logs)
+
+    def run_pair(port):
+        procs = [subprocess.Popen([sys.executable, worker, "dp", outs[r]], env=dict(env, RANK=str(r), WORLD_SIZE="2", MASTER_PORT=str(port)),
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+        t_end = time.time() + 200                 # both ranks normally finish in ~25 s; the worker dumps its stacks and exits after 150 s
+        while time.time() < t_end and any(p.poll() is None for p in procs):
+            if any(p.poll() not in (None, 0) for p in procs):
+                time.sleep(3)                      # a rank died: give the other a moment, then stop waiting for its collective
+                break
+            time.sleep(0.5)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        return [p.returncode for p in procs], [p.communicate()[0].decode() for p in procs]
+    rcs, logs = run_pair(29731)
+    if any(rc != 0 for rc in rcs):
+        # Two processes time-sharing ONE GPU with a gloo exchange is a test-only arrangement (the product runs one rank per GPU over RCCL);
+        # round 4 saw it stall once in ~20 runs right after the rendezvous.  One retry on a fresh port; the first attempt's stacks are kept.
+        report("dp_equivalence_first_attempt", returncodes=str(rcs), tail0=logs[0][-1500:], tail1=logs[1][-1500:])
+        rcs, logs = run_pair(29741)
+    assert all(rc == 0 for rc in rcs), "\n----- rank log -----\n".join(l[-3000:] for l in logs)
     single = str(tmp_path / "single.pt")
     r = subprocess.run([sys.executable, worker, "single", single], env=dict(env, RANK="0", WORLD_SIZE="1"),
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
@@ -986,7 +1036,8 @@ def test_fused_batch_preparation_equals_the_torch_path(dev, stage, B, monkeypatc
     monkeypatch.setenv("OMLM_FUSED_PREP", "0")
     torch.manual_seed(123)
     loss_t, _, _ = wrapper(all_token_ids=raw, return_loss=True, return_logits=False)
-    assert labels_f[-1].dtype == torch.int32 and float(loss_f) == float(loss_t), (float(loss_f), float(loss_t))
+    # (the loss sums its rows with atomics: equal up to the order of addition)
+    assert labels_f[-1].dtype == torch.int32 and abs(float(loss_f) - float(loss_t)) < 2e-6 * abs(float(loss_t)), (float(loss_f), float(loss_t))
     loss_f.backward()
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
 
