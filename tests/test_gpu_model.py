@@ -689,7 +689,8 @@ def test_fp16_overflow_is_skipped_and_the_loss_scale_backs_off(dev, tmp_path):
     report("fp16_overflow", **rep, first_loss=losses[0], last_loss=losses[-1])
 
 
-def test_graphed_bf16x3_training_tracks_eager_over_optimizer_steps(dev):
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
+def test_graphed_bf16x3_training_tracks_eager_over_optimizer_steps(dev, precision):
     """bf16x3 at a size where the fp32 GEMMs take the hi/lo-plane route (M N K >= ops._X3_MIN_MACS), captured into a HIP graph,
     over several optimizer steps: the replayed micro-step must read the CURRENT weights -- the planes of the persistent Parameter
     objects (Wq / Wkv / Wo) are split inside the graph, not left over from the eager warm-up -- so its losses and final weights
@@ -708,7 +709,7 @@ def test_graphed_bf16x3_training_tracks_eager_over_optimizer_steps(dev):
     def run(use_graph):
         torch.manual_seed(0)
         model = M.create_coarse_transformer(dim=256, depth=2, heads=4, num_coarse_quantizers=3, ff_dropout=0.0,
-                                            precision="bf16x3").to(dev)
+                                            precision=precision).to(dev)
         stage = M.CoarseStage(coarse_transformer=model, cross_entropy_loss_weights=[0., 0., 1.], mask_prob=0.0)
         stage.train()
         opt = get_optimizer(model.parameters(), lr=3e-3, wd=0.01)
@@ -738,7 +739,7 @@ def test_graphed_bf16x3_training_tracks_eager_over_optimizer_steps(dev):
             kw = dict(zip(keys, batches[1]))
             l_replay = float(fb(**kw))
             l_eager = float(fb._eager({k: v.clone() for k, v in kw.items()}))
-            assert abs(l_replay - l_eager) <= 1e-5 * abs(l_eager), (l_replay, l_eager)
+            assert abs(l_replay - l_eager) <= (1e-5 if precision == "bf16x3" else 1e-4) * abs(l_eager), (l_replay, l_eager)
             assert abs(l_replay - losses[1]) > 1e-3 * abs(l_eager), "the rewritten weights must matter for this check to mean anything"
         import gc
         gc.unfreeze()
@@ -746,12 +747,15 @@ def test_graphed_bf16x3_training_tracks_eager_over_optimizer_steps(dev):
 
     le, wq_e, wo_e = run(False)
     lg, wq_g, wo_g = run(True)
-    report("graph_bf16x3_vs_eager", eager=le, graphed=lg)
+    report(f"graph_{precision}_vs_eager", eager=le, graphed=lg, wq=relerr(wq_g, wq_e), wo=relerr(wo_g, wo_e))
     assert le[0] != le[-1]
+    # 16-bit modes (round 4: they are the ones whose attention backward carried a memset node in the captured step): the order-of-addition
+    # noise of the atomics passes through operand roundings, so two runs agree to ~1e-3 in the loss after three Adam steps at lr 3e-3
     for a, b in zip(le, lg):
-        assert abs(a - b) <= 2e-4 * abs(a), (le, lg)
+        assert abs(a - b) <= (2e-4 if precision == "bf16x3" else 5e-3) * abs(a), (le, lg)
     # Adam's normalised update amplifies the atomics' summation-order noise on near-zero gradients: weights agree to ~lr, not to rounding
-    assert relerr(wq_g, wq_e) < 3e-2 and relerr(wo_g, wo_e) < 3e-2
+    wbar = 3e-2 if precision == "bf16x3" else 0.15
+    assert relerr(wq_g, wq_e) < wbar and relerr(wo_g, wo_e) < wbar
 
 
 @pytest.mark.parametrize("precision", ["bf16", "fp16"])
