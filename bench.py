@@ -205,15 +205,16 @@ class TrainLeg:
 
 def cpu_baseline(progress_fn):
     """The oracle (port of the reference arithmetic, torch CPU kernels) on this box's host cores: one warm-up + median
-    of 3 full micro-steps (forward + backward + global-norm clip + AdamW) at B = 1, N = 1116, fp32: a bounded sample of the
-    same workload (~30 s)."""
+    of 3 full micro-steps (forward + backward + global-norm clip + AdamW) at B = 2, N = 1116, fp32: a bounded
+    sample of the same workload (~60 s)."""
     from oracle import musiclm_oracle as O
     spec = O.coarse_spec(dim=1024, depth=6, heads=8)
     sd = O.init_state_dict(spec, seed=0)
     params = [v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and not k.endswith("beta")]
     opt = torch.optim.AdamW(params, lr=3e-4, betas=(0.9, 0.99), weight_decay=0.01)
-    ids = O.synthetic_ids(spec, 1, [1, 199, 300], seed=1234)
-    noise = torch.randn(1, N_SEQ, generator=torch.Generator().manual_seed(1))
+    CB = 2                                                 # SURVEY.md section 8d: the configs' own batch (train_musiclm_fma.json:39)
+    ids = O.synthetic_ids(spec, CB, [1, 199, 300], seed=1234)
+    noise = torch.randn(CB, N_SEQ, generator=torch.Generator().manual_seed(1))
     times = []
     for it in range(4):
         t1 = time.perf_counter()
@@ -225,12 +226,12 @@ def cpu_baseline(progress_fn):
         times.append(time.perf_counter() - t1)
         progress_fn(f"cpu baseline iteration {it}{' (warm-up)' if it == 0 else ''}: {times[-1]:.2f}s")
     med = statistics.median(times[1:])
-    return {"value": round(1 / med, 4), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": round(CB / med, 4), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
             "host_cpu_count": os.cpu_count(),
-            "sample": "1 warm-up + median of 3 micro-steps (fwd + bwd + clip + AdamW) of B=1, N=1116, fp32, torch CPU kernels; "
-                      f"times {[round(t, 2) for t in times]} s; threads = torch's default (one per physical core: 128 of the box's 256 "
-                      "hardware threads; the SMT siblings do not speed up its GEMM kernels); kind 'port' because /root/reference does not "
-                      "exist on the GPU box (the port is pinned to the reference by tests/golden); B = 1 keeps the leg at ~30 s"}
+            "sample": f"1 warm-up + median of 3 micro-steps (fwd + bwd + clip + AdamW) of B={CB}, N=1116, fp32, torch CPU kernels; "
+                      f"times {[round(t, 2) for t in times]} s; threads = torch's default ({torch.get_num_threads()} of the box's "
+                      f"{os.cpu_count()} hardware threads: one per physical core); kind 'port' because /root/reference does not "
+                      "exist on the GPU box (the port is pinned to the reference by tests/golden)"}
 
 
 def decode_leg(stage, dev, decode_ids):
