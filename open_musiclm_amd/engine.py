@@ -200,7 +200,10 @@ def h16_operand(w: torch.Tensor, T: torch.dtype) -> torch.Tensor:
 
 
 class PreparedWeights:
-    def __init__(self, model, precision: str, with_transposes: bool = False):
+    def __init__(self, model, precision: str, with_transposes: bool = False, persistent: bool = True):
+        """persistent: the padded FF / tap / gamma images live in per-model buffers that EVERY persistent instance rewrites in place (the
+        training step: one instance alive at a time, forward -> backward).  Instances that outlive a step (the no_grad cache below, a
+        CachedDecoder) take persistent=False: private images, so a later training step cannot change the weights under them."""
         tr = model.transformer
         self.precision = precision
         self.T = _PRECISIONS[precision]
@@ -224,10 +227,14 @@ class PreparedWeights:
                 for name, w in (("Wq", attn.to_q.weight), ("Wkv", attn.to_kv.weight), ("Wo", attn.to_out[0].weight)):
                     ent[name] = h16_operand(w, T)
             bkey = (li, T, str(dev), F, D)
-            if bkey not in wbuf:
-                wbuf[bkey] = (torch.zeros(2 * Fp, D, dtype=T, device=dev), torch.zeros(D, Fp, dtype=T, device=dev),
-                              torch.zeros(3, 2 * Fp, dtype=T, device=dev), torch.zeros(Fp, dtype=T, device=dev))
-            W1p, W2p, convp, gammap = wbuf[bkey]
+            if not persistent:
+                W1p, W2p, convp, gammap = (torch.zeros(2 * Fp, D, dtype=T, device=dev), torch.zeros(D, Fp, dtype=T, device=dev),
+                                           torch.zeros(3, 2 * Fp, dtype=T, device=dev), torch.zeros(Fp, dtype=T, device=dev))
+            else:
+                if bkey not in wbuf:
+                    wbuf[bkey] = (torch.zeros(2 * Fp, D, dtype=T, device=dev), torch.zeros(D, Fp, dtype=T, device=dev),
+                                  torch.zeros(3, 2 * Fp, dtype=T, device=dev), torch.zeros(Fp, dtype=T, device=dev))
+                W1p, W2p, convp, gammap = wbuf[bkey]
             packs.add(w1.detach(), W1p, F, D, D, D)
             packs.add(w1.detach()[F:], W1p[Fp:], F, D, D, D)
             packs.add(w2.detach(), W2p, D, F, F, Fp)
@@ -286,7 +293,7 @@ def prepared_weights(model, precision: str) -> PreparedWeights:
     cache = getattr(model, "_omlm_prepared", None)
     if cache is not None and cache[0] == key:
         return cache[1]
-    pw = PreparedWeights(model, precision)
+    pw = PreparedWeights(model, precision, persistent=False)
     object.__setattr__(model, "_omlm_prepared", (key, pw))
     return pw
 
