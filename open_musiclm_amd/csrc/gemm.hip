@@ -879,9 +879,12 @@ static int gemm_impl(const void* A, const void* B, void* C, const float* Cin,
     const int nk = ((K + BK - 1) / BK) * (split3 ? 3 : 1);     // k-tiles of the loop (three plane pairs per real k-tile when split3)
     const int tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
     int splits = 1;
-    if (Cin == (const float*)C && out_dtype == 0 && tiles < 512 && nk >= 16) {
+    // fp32 operands (register-staged kernel: the rel-pos MLP's 0.3-GFLOP GEMMs, 36 / 16 output tiles) are latency-bound per k-tile, not per byte:
+    // they split down to TWO k-tiles per workgroup (54 -> ~20 us per launch; round 4), the 16-bit tile kernels keep their >= 8 k-tiles per split
+    const bool fine = in_dtype == 0 && !split3;
+    if (Cin == (const float*)C && out_dtype == 0 && tiles < 512 && nk >= (fine ? 4 : 16)) {
         const int slots = (bm == 256 ? 1 : 2) * ncu;              // co-resident workgroups (LDS: 128 KiB tiles 1 / CU, 64 KiB 2 / CU)
-        int smax = nk / 8; if (smax > 32) smax = 32; if (smax < 1) smax = 1;
+        int smax = fine ? nk / 2 : nk / 8; if (smax > 32) smax = 32; if (smax < 1) smax = 1;
         int smin = (slots + tiles - 1) / tiles; if (smin > smax) smin = smax; if (smin < 1) smin = 1;      // at least one full round
         float best = -1.f;
         for (int sp = smin; sp <= smax; ++sp) {
