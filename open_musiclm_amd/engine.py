@@ -323,15 +323,16 @@ def relpos_forward(tr, n: int, save: bool):
     ops.relpos_first_fwd(lin[0].weight.detach().reshape(-1), lin[0].bias.detach(), pre, z, n, Hd)
     pres.append(pre); zs.append(z)
     for k in (1, 2):
-        # zero-filled and accumulated into (Cin == C): that is what lets the fp32 GEMM split its K over more workgroups (gemm.hip: `fine`)
-        a = torch.zeros(n, Hd, device=dev)
-        ops.gemm(zs[-1], lin[k].weight.detach(), a, M=n, N=Hd, K=Hd, Cin=a, planes=_RELPOS_PLANES)
+        # (the FORWARD GEMMs stay unsplit: a split-K sum is order-of-arrival, and 1e-7 of noise in the table is amplified by the 16-bit
+        # roundings downstream -- run-to-run d(table) went from 2e-3 to 2e-2 in bf16 when they were split; the backward's GEMMs below do split)
+        a = torch.empty(n, Hd, device=dev)
+        ops.gemm(zs[-1], lin[k].weight.detach(), a, M=n, N=Hd, K=Hd, planes=_RELPOS_PLANES)
         pre = torch.empty(n, Hd, device=dev)
         z = torch.empty(n, Hd, device=dev)
         ops.bias_silu_fwd(a, lin[k].bias.detach(), pre, z, n, Hd)
         pres.append(pre); zs.append(z)
     a = torch.zeros(n, ldb, device=dev)
-    ops.gemm(zs[-1], lin[3].weight.detach(), a, M=n, N=H, K=Hd, ldc=ldb, Cin=a)
+    ops.gemm(zs[-1], lin[3].weight.detach(), a, M=n, N=H, K=Hd, ldc=ldb)
     table = torch.empty(n, ldb, device=dev)
     ops.bias_add(a, lin[3].bias.detach(), table, n, H, ldb)
     return table, (("mlp", pres, zs) if save else None)
@@ -362,7 +363,7 @@ def relpos_backward(tr, n: int, saved, dtable: torch.Tensor):
         ops.colsum_accumulate(ds, grad_of(lin[k].bias), n, Hd, Hd)
         gw = grad_of(lin[k].weight)
         ops.gemm(ds, zs[k - 1], gw, M=Hd, N=Hd, K=n, a_kmajor=True, b_kmajor=True, Cin=gw, planes=_RELPOS_PLANES)
-        dz = torch.zeros(n, Hd, device=dev)
+        dz = torch.zeros(n, Hd, device=dev)        # zero-filled + Cin == C: lets the fp32 GEMM split its K over more workgroups (gemm.hip: `fine`)
         ops.gemm(ds, lin[k].weight.detach(), dz, M=n, N=Hd, K=Hd, b_kmajor=True, Cin=dz, planes=_RELPOS_PLANES)
     ds = torch.empty(n, Hd, device=dev)
     ops.silu_bwd(dz, pres[0], ds, n * Hd)
