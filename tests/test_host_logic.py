@@ -692,3 +692,67 @@ def test_hubert_wrapper_with_a_supplied_extractor():
         hk(wave, flatten=False)
     with pytest.raises(RuntimeError, match="feature extractor"):
         HfHubertWithKmeans(hubert=None, kmeans=centers.numpy(), codebook_size=8)(wave)
+
+
+def test_data_parallel_backend_choice_and_shared_gpu_flag(monkeypatch):
+    """parallel.DataParallel: the exchange backend is nccl (= RCCL) with one GPU per local rank, and falls back to gloo BY ITSELF -- flagged as
+    a dry run -- when the local ranks outnumber the visible GPUs; $OMLM_DP_BACKEND overrides; the legacy HSA IPC mode is refused for RCCL."""
+    import torch.distributed as dist
+    from open_musiclm_amd import parallel
+    seen = {}
+    monkeypatch.setattr(dist, "is_initialized", lambda: False)
+    monkeypatch.setattr(dist, "init_process_group", lambda backend, rank, world_size: seen.update(backend=backend, rank=rank, world=world_size))
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda i: seen.update(device=i))
+    for k, v in dict(WORLD_SIZE="2", RANK="1", LOCAL_RANK="1", LOCAL_WORLD_SIZE="2").items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.delenv("OMLM_DP_BACKEND", raising=False)
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    dp = parallel.DataParallel(device=torch.device("cuda", 1))
+    assert seen["backend"] == "nccl" and seen["device"] == 1 and not dp.shared_gpu and dp.owns_group
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    dp = parallel.DataParallel(device=torch.device("cuda", 0))
+    assert seen["backend"] == "gloo" and seen["device"] == 0 and dp.shared_gpu           # two ranks on one visible GPU: dry run over gloo
+    monkeypatch.setenv("OMLM_DP_BACKEND", "nccl")
+    dp = parallel.DataParallel(device=torch.device("cuda", 0))
+    assert seen["backend"] == "nccl" and dp.shared_gpu                                   # explicit choice is honoured (RCCL itself will refuse)
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "1")
+    with pytest.raises(RuntimeError, match="HSA_ENABLE_IPC_MODE_LEGACY"):
+        parallel.DataParallel(device=torch.device("cuda", 0))
+
+
+def test_bench_refuses_a_rank_count_that_disagrees_with_its_launcher():
+    """bench.py under a launcher whose WORLD_SIZE differs from --gpus: one clear message and a non-zero exit (it used to be a bare assert);
+    without WORLD_SIZE and with --gpus > 1 it would re-execute itself under torch.distributed.run (covered on the GPU box)."""
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=3" in (r.stderr + r.stdout) and "--gpus 2" in (r.stderr + r.stdout)
+
+
+def test_fused_batch_preparation_is_only_taken_where_it_is_equivalent(monkeypatch):
+    """Wrapper._fused_prepare_ok: CPU tensors, unique_consecutive sequences, ids that already carry eos, a replaced generate_mask_with_prob
+    (how tests inject masks) and $OMLM_FUSED_PREP=0 all keep the torch construction."""
+    from open_musiclm_amd import open_musiclm as M
+    model = tiny()
+    w = M.TokenConditionedTransformerWrapper(transformer=model, unique_consecutive=False, cross_entropy_loss_weights=[0., 0., 1.])
+    ids = [torch.zeros(2, 12, 1, dtype=torch.long), torch.zeros(2, 9, dtype=torch.long), torch.zeros(2, 6, 3, dtype=torch.long)]
+    assert not w._fused_prepare_ok(ids, False)                                           # CPU tensors
+    fake = [t.to("meta") for t in ids]
+    monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True))
+    assert w._fused_prepare_ok(fake, False)
+    assert not w._fused_prepare_ok(fake, True)                                           # input_has_eos
+    monkeypatch.setenv("OMLM_FUSED_PREP", "0")
+    assert not w._fused_prepare_ok(fake, False)
+    monkeypatch.delenv("OMLM_FUSED_PREP")
+    monkeypatch.setattr(M, "generate_mask_with_prob", lambda *a, **k: None)
+    assert not w._fused_prepare_ok(fake, False)                                          # injected mask source
+    monkeypatch.undo()
+    monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True))
+    model.token_sequences[1].unique_consecutive = True
+    w2 = M.TokenConditionedTransformerWrapper(transformer=model, unique_consecutive=True, cross_entropy_loss_weights=[0., 0., 1.])
+    assert not w2._fused_prepare_ok(fake, False)
+    too_long = [torch.zeros(1, 5000, dtype=torch.long, device="meta")] * 3
+    w3 = M.TokenConditionedTransformerWrapper(transformer=tiny(), unique_consecutive=False, cross_entropy_loss_weights=[0., 0., 1.])
+    assert not w3._fused_prepare_ok(too_long, False)                                     # N > 4096: past the kernel's register slots
