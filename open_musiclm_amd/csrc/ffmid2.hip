@@ -20,6 +20,7 @@
 //     d(conv taps) in ONE pass, du never exists in memory (first generation: bwd1 wrote it, bwd2 re-read it: 0.8 GB per
 //     layer).  conv^T runs as two pending output rows in registers; a strip recomputes du for the 2 rows past its end.
 #include "common.h"
+#include <type_traits>
 
 namespace OMLM_NS {
 
@@ -76,6 +77,9 @@ template <> struct Ch4<float> {
     static __device__ __forceinline__ void store(float* p, const v2 (&y)[2]) { *(float4*)p = make_float4(y[0][0], y[0][1], y[1][0], y[1][1]); }
 };
 
+__device__ __forceinline__ void pin_regs(Ch8<h16_t>& a, Ch8<h16_t>& b) { asm volatile("" : "+v"(a.r), "+v"(b.r)); }
+__device__ __forceinline__ void pin_regs(Ch8<float>&, Ch8<float>&) {}
+
 // GELU pieces of a gate pair u:  h = Phi(u) = 0.5 (1 + erf(u / sqrt 2)),  ex = exp(-u^2 / 2).
 // erf by Abramowitz-Stegun 7.1.26 like ffmid.hip (|abs err| <= 1.5e-7), with the 1/sqrt2 and the 0.5 folded into constants.
 __device__ __forceinline__ void gelu_parts(v2 u, v2& h, v2& ex) {
@@ -116,6 +120,18 @@ __device__ __forceinline__ void keep_words(unsigned long long seed, unsigned lon
 #ifndef FS_OCC
 #define FS_OCC 1          // workgroups per CU the forward's register budget is sized for
 #endif
+#ifndef FS_SPLIT
+#define FS_SPLIT 1        // 1: full batches run in a steady-state loop without row conditions (counted waits), the general body takes the strip's tail
+#endif
+#ifndef FS_DIAG
+#define FS_DIAG 0         // diagnostic builds only (tools/ab_variant.sh): forward -- 1 / 2 / 4 = the keep-bit / h2 / normalised-output stores are skipped at run
+#endif                    // time (values still computed), 8 = no GELU and no hash arithmetic
+#ifndef FS_PACKW
+#define FS_PACKW 0        // 1: the forward keeps the conv taps of 16-bit operands packed (see the kernel)
+#endif
+#ifndef FS_PIN
+#define FS_PIN 1          // 1: the early re-requests of the steady-state loop are pinned behind their row's arithmetic
+#endif
 #ifndef FS_EARLY
 #define FS_EARLY 1        // 1: a row's registers are re-requested (next batch) the moment sweep 1 has consumed them -- the loads are in flight
 #endif                    //    through the rest of the sweep too, not only through the reduction / barrier / store phase (0: the round-2 order)
@@ -124,7 +140,7 @@ __device__ __forceinline__ void keep_words(unsigned long long seed, unsigned lon
 // forward.  grid: B * strips workgroups of NT threads (NT = chunks of 8 channels rounded up to waves); strip s of sample b
 // covers rows [s * RB, min(nseq, (s + 1) * RB)).
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T, int NT>
+template <typename T, int NT, bool TRAIN>
 __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kernel(const T* __restrict__ h1, const T* __restrict__ convw,
                                                         const T* __restrict__ gamma, T* __restrict__ h2,
                                                         float* __restrict__ mean, float* __restrict__ rstd,
@@ -139,30 +155,36 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
     const int t0 = s * RB, t1 = min(nseq, t0 + RB);
     if (t0 >= t1) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // The launch has EXACTLY Fp / 8 threads (one per 8-channel chunk; the last wave may be partial): there is no thread without a chunk,
+    // so no memory instruction of the row loop sits under a divergent branch and hipcc's s_waitcnt bookkeeping can count the stores that
+    // follow a load instead of assuming none (see the steady-state loop below).  Lanes the hardware never started read as 0 in the
+    // ds_bpermute steps of wave_sum.
     const int col = threadIdx.x * 8;
-    const bool act = col < Fp;
-    const int colc = act ? col : 0;
     const int ld = 2 * Fp;
     const size_t row0 = (size_t)b * nseq;
     const float inv = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
     const unsigned thr = (unsigned)(p * 65536.0f + 0.5f);
 
-    // taps / gamma: fp32 registers for the whole strip (zero for threads past the row: they only take part in the sums)
-    v2 wv[3][4], wg[3][4], gm[4];
+    // taps / gamma: registers for the whole strip.  FS_PACKW (16-bit operands): the taps stay PACKED (24 registers instead of 48) and are
+    // unpacked where they are used -- 2 VALU instructions per pair and use, ~12 % more issue, for a register budget that admits a
+    // second workgroup per CU (6 + 6 waves = 3 per SIMD instead of the 2 / 2 / 1 / 1 of a lone 6-wave workgroup).
+    constexpr bool PACKW = FS_PACKW && sizeof(T) == 2;
+    v2 wv[PACKW ? 1 : 3][4], wg[PACKW ? 1 : 3][4], gm[4];
+    Ch8<T> tv[3], tg[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        Ch8<T> a, c;
-        a.load(convw + (size_t)k * ld + colc);
-        c.load(convw + (size_t)k * ld + Fp + colc);
+        tv[k].load(convw + (size_t)k * ld + col);
+        tg[k].load(convw + (size_t)k * ld + Fp + col);
+        if constexpr (!PACKW) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            wv[k][i] = act ? a.get(i) : splat2(0.f);
-            wg[k][i] = act ? c.get(i) : splat2(0.f);
+            for (int i = 0; i < 4; ++i) { wv[k][i] = tv[k].get(i); wg[k][i] = tg[k].get(i); }
         }
     }
+    auto WV = [&](int k, int i) -> v2 { if constexpr (PACKW) return tv[k].get(i); else return wv[k][i]; };
+    auto WG = [&](int k, int i) -> v2 { if constexpr (PACKW) return tg[k].get(i); else return wg[k][i]; };
     {
         Ch8<T> a;
-        a.load(gamma + colc);
+        a.load(gamma + col);
 #pragma unroll
         for (int i = 0; i < 4; ++i) gm[i] = a.get(i) * inv;                  // dropout scale folded into gamma
     }
@@ -171,8 +193,8 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
     {
         Ch8<T> a, c, d, e;
         a.zero(); c.zero(); d.zero(); e.zero();
-        if (t0 >= 1) { a.load(h1 + (row0 + t0 - 1) * ld + colc); c.load(h1 + (row0 + t0 - 1) * ld + Fp + colc); }
-        if (t0 >= 2) { d.load(h1 + (row0 + t0 - 2) * ld + colc); e.load(h1 + (row0 + t0 - 2) * ld + Fp + colc); }
+        if (t0 >= 1) { a.load(h1 + (row0 + t0 - 1) * ld + col); c.load(h1 + (row0 + t0 - 1) * ld + Fp + col); }
+        if (t0 >= 2) { d.load(h1 + (row0 + t0 - 2) * ld + col); e.load(h1 + (row0 + t0 - 2) * ld + Fp + col); }
 #pragma unroll
         for (int i = 0; i < 4; ++i) { x1v[i] = a.get(i); x1g[i] = c.get(i); x2v[i] = d.get(i); x2g[i] = e.get(i); }
     }
@@ -180,29 +202,42 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
 #pragma unroll
     for (int r = 0; r < RB_; ++r)
         if (t0 + r < t1) {
-            rv[r].load(h1 + (row0 + t0 + r) * ld + colc);
-            rg[r].load(h1 + (row0 + t0 + r) * ld + Fp + colc);
+            rv[r].load(h1 + (row0 + t0 + r) * ld + col);
+            rg[r].load(h1 + (row0 + t0 + r) * ld + Fp + col);
         }
     const float invF = 1.0f / (float)F;
-    int it = 0;
-#pragma unroll 1
-    for (int tb = t0; tb < t1; tb += RB_, ++it) {
+
+    // One batch of RB_ rows.  FULL: every row of this batch and of the next one exists -- no row condition is left, every load and store of
+    // the body is issued on every path, and the waits hipcc places in front of a row's first use become counted (`vmcnt(n)` with the batch's
+    // stores and the later rows' loads still in flight).  The general body (strip tails, short strips) keeps the conditions; with them the
+    // fewest-operations path has nothing behind a load, so every batch ended in `vmcnt(0)`: a full drain of the 12 stores just issued, with
+    // one workgroup per CU and nothing else to run (round 4: 46 % of the wave cycles parked, 3.3 TB/s).
+    auto batch = [&](auto full_tag, const int tb, const int it) {
+        constexpr bool FULL = decltype(full_tag)::value;
         v2 g[RB_][4];
         float ls[RB_], lq[RB_];
         // sweep 1: conv + GEGLU of the batch, per-thread sums for LayerNorm
 #pragma unroll
         for (int r = 0; r < RB_; ++r) {
             ls[r] = 0.f; lq[r] = 0.f;
-            if (tb + r < t1) {
+            if (FULL || tb + r < t1) {
                 v2 s2 = splat2(0.f), q2 = splat2(0.f);
+                if constexpr (PACKW) {                   // opaque per row: the unpacked taps must not be hoisted back into loop-invariant registers
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) pin_regs(tv[k], tg[k]);
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const v2 xv = rv[r].get(i), xg = rg[r].get(i);
-                    const v2 uv = fma2(wv[2][i], xv, fma2(wv[1][i], x1v[i], wv[0][i] * x2v[i]));
-                    const v2 ug = fma2(wg[2][i], xg, fma2(wg[1][i], x1g[i], wg[0][i] * x2g[i]));
+                    const v2 uv = fma2(WV(2, i), xv, fma2(WV(1, i), x1v[i], WV(0, i) * x2v[i]));
+                    const v2 ug = fma2(WG(2, i), xg, fma2(WG(1, i), x1g[i], WG(0, i) * x2g[i]));
                     x2v[i] = x1v[i]; x1v[i] = xv; x2g[i] = x1g[i]; x1g[i] = xg;
                     v2 h, ex;
+#if FS_DIAG & 8
+                    h = ug; ex = ug;                     // diagnostic build: no GELU arithmetic
+#else
                     gelu_parts(ug, h, ex);
+#endif
                     const v2 gv = (ug * h) * uv;
                     g[r][i] = gv;
                     s2 += gv;
@@ -215,9 +250,15 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
                 for (int i = 0; i < 4; ++i) g[r][i] = splat2(0.f);
             }
 #if FS_EARLY
-            if (tb + RB_ + r < t1) {                     // this row's registers are free: the next batch's row r leaves now
-                rv[r].load(h1 + (row0 + tb + RB_ + r) * ld + colc);
-                rg[r].load(h1 + (row0 + tb + RB_ + r) * ld + Fp + colc);
+            if (FULL || tb + RB_ + r < t1) {             // this row's registers are free: the next batch's row r leaves now
+#if FS_PIN
+                if (FULL) __builtin_amdgcn_sched_barrier(0);     // (hipcc's scheduler otherwise sinks the four requests below the whole sweep)
+#endif
+                rv[r].load(h1 + (row0 + tb + RB_ + r) * ld + col);
+                rg[r].load(h1 + (row0 + tb + RB_ + r) * ld + Fp + col);
+#if FS_PIN
+                if (FULL) __builtin_amdgcn_sched_barrier(0);
+#endif
             }
 #endif
         }
@@ -225,9 +266,9 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
         // next batch's rows: in flight during the reduction and the second sweep
 #pragma unroll
         for (int r = 0; r < RB_; ++r)
-            if (tb + RB_ + r < t1) {
-                rv[r].load(h1 + (row0 + tb + RB_ + r) * ld + colc);
-                rg[r].load(h1 + (row0 + tb + RB_ + r) * ld + Fp + colc);
+            if (FULL || tb + RB_ + r < t1) {
+                rv[r].load(h1 + (row0 + tb + RB_ + r) * ld + col);
+                rg[r].load(h1 + (row0 + tb + RB_ + r) * ld + Fp + col);
             }
 #endif
 #pragma unroll
@@ -238,9 +279,10 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
         }
         __syncthreads();          // one barrier per batch: the other parity's slots are rewritten only after the next one
         // sweep 2: normalise, gamma, dropout, store
+        float mu_r[RB_], rs_r[RB_];
 #pragma unroll
         for (int r = 0; r < RB_; ++r) {
-            if (tb + r >= t1) continue;
+            if (!FULL && tb + r >= t1) continue;
             float S = 0.f, Q = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) { S += st[it & 1][r][w][0]; Q += st[it & 1][r][w][1]; }
@@ -248,8 +290,8 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
             const float var = fmaxf(Q * invF - mu * mu, 0.f);
             const float rs = rsqrtf(var + eps);
             const size_t row = row0 + tb + r;
-            if (threadIdx.x == 0) { mean[row] = mu; rstd[row] = rs; }
-            if (!act) continue;
+            if (FULL) { mu_r[r] = mu; rs_r[r] = rs; }
+            else if (threadIdx.x == 0) { mean[row] = mu; rstd[row] = rs; }
             const v2 nmr = splat2(-mu * rs), rs2 = splat2(rs);
             v2 gh[4], y[4];
 #pragma unroll
@@ -263,9 +305,13 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) y[i] = gh[i] * gm[i];
-            if (p > 0.f) {
+            if (TRAIN || p > 0.f) {
                 unsigned w[4], bits = 0;
+#if FS_DIAG & 8
+                w[0] = w[1] = w[2] = w[3] = (unsigned)row * 0x9E3779B9u + (unsigned)col;     // diagnostic build: no hash
+#else
                 keep_words(seed, row * (unsigned long long)(Fp >> 3) + (unsigned)(col >> 3), w);
+#endif
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const bool k0 = (w[i] & 0xFFFFu) >= thr, k1 = (w[i] >> 16) >= thr;
@@ -274,12 +320,43 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
                     bits |= (k0 ? 1u : 0u) << (2 * i);
                     bits |= (k1 ? 1u : 0u) << (2 * i + 1);
                 }
-                if (drop_bits) drop_bits[row * (size_t)(Fp >> 3) + (col >> 3)] = (unsigned char)bits;
+#if FS_DIAG
+                asm volatile("" :: "v"(bits));           // diagnostic builds: the value stays computed although its store may be skipped
+                if (!(FS_DIAG & 1) || eps < 0.f)
+#endif
+                if (TRAIN || drop_bits) drop_bits[row * (size_t)(Fp >> 3) + (col >> 3)] = (unsigned char)bits;
             }
+#if FS_DIAG
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(y[i]), "v"(gh[i]));
+            if (!(FS_DIAG & 2) || eps < 0.f) Ch8<T>::store(h2 + row * Fp + col, y);
+            if (!(FS_DIAG & 4) || eps < 0.f) { if (TRAIN || gh_out) Ch8<T>::store(gh_out + row * Fp + col, gh); }
+#else
             Ch8<T>::store(h2 + row * Fp + col, y);
-            if (gh_out) Ch8<T>::store(gh_out + row * Fp + col, gh);
+            if (TRAIN || gh_out) Ch8<T>::store(gh_out + row * Fp + col, gh);
+#endif
         }
-    }
+        if (FULL) {
+            // the batch's statistics: lane l of EVERY wave stores row (l mod RB_)'s pair -- the same values to the same addresses from
+            // every wave, two store instructions per batch on every path (a `threadIdx.x == 0` region is a second, shorter path)
+            const int q = lane % RB_;
+            float m = mu_r[0], s_ = rs_r[0];
+#pragma unroll
+            for (int r = 1; r < RB_; ++r) { m = q == r ? mu_r[r] : m; s_ = q == r ? rs_r[r] : s_; }
+            mean[row0 + tb + q] = m;
+            rstd[row0 + tb + q] = s_;
+        }
+    };
+    int it = 0, tb = t0;
+#if FS_SPLIT
+    // The loop header joins the entry edge with the back edge: with the prologue's (conditional) loads still pending on entry, the join
+    // would again see "nothing behind this load" for every iteration.  Draining them once per strip leaves the back edge's counts.
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                        // vmcnt(0)
+#pragma unroll 1
+    for (; tb + 2 * RB_ <= t1; tb += RB_, ++it) batch(std::true_type{}, tb, it);
+#endif
+#pragma unroll 1
+    for (; tb < t1; tb += RB_, ++it) batch(std::false_type{}, tb, it);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -526,10 +603,14 @@ static int fwd_launch_t(const void* h1, const void* convw, const void* gamma, vo
     const int B = M / nseq;
     const int RB = strip_rows(nseq, 36);
     const int strips = (nseq + RB - 1) / RB;
-    const int nt = ((Fp / 8 + 63) / 64) * 64;
+    const int nt = ((Fp / 8 + 63) / 64) * 64;                                  // kernel instantiation: whole waves
+    const int nthr = Fp / 8;                                                   // threads launched: one per chunk
     dim3 grid(B * strips);
-#define FF2_FWD(NT_) hipLaunchKernelGGL((ffmid2_fwd_kernel<T, NT_>), grid, dim3(NT_), 0, st, (const T*)h1, (const T*)convw, \
-        (const T*)gamma, (T*)h2, mean, rstd, nseq, F, Fp, RB, strips, eps, p, seed, seed_dev, drop_bits, (T*)gh)
+    const bool train = p > 0.f && drop_bits != nullptr && gh != nullptr;       // the training call: all three row stores are unconditional
+#define FF2_FWD(NT_) do { if (train) hipLaunchKernelGGL((ffmid2_fwd_kernel<T, NT_, true>), grid, dim3(nthr), 0, st, (const T*)h1, (const T*)convw, \
+        (const T*)gamma, (T*)h2, mean, rstd, nseq, F, Fp, RB, strips, eps, p, seed, seed_dev, drop_bits, (T*)gh); \
+    else hipLaunchKernelGGL((ffmid2_fwd_kernel<T, NT_, false>), grid, dim3(nthr), 0, st, (const T*)h1, (const T*)convw, \
+        (const T*)gamma, (T*)h2, mean, rstd, nseq, F, Fp, RB, strips, eps, p, seed, seed_dev, drop_bits, (T*)gh); } while (0)
     switch (nt) {
         case 64: FF2_FWD(64); break;
         case 128: FF2_FWD(128); break;

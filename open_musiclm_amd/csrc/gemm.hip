@@ -44,6 +44,9 @@ namespace OMLM_NS {
 #ifndef OMLM_GEMM_TAIL_WAIT
 #define OMLM_GEMM_TAIL_WAIT 1
 #endif
+#ifndef OMLM_EPI_CIN_AHEAD
+#define OMLM_EPI_CIN_AHEAD 1       // epilogue: the residual pieces of strip i + 1 are requested before the stores of strip i (tile_epilogue)
+#endif
 #define BM 128
 #define BN 128
 #define BK 64
@@ -398,11 +401,11 @@ struct DmaStagerT {
 // scatters (measured: ~480 of 650 us of the FF-in GEMM).  Each 32-row strip of the wave's tile is therefore transposed
 // through a per-wave LDS patch (the k-loop stages are dead: the caller has passed a barrier) and written as 16-byte
 // row-contiguous stores: 8 bf16 / 4 fp32 per lane, full 128-byte lines per row.
-template <int MI, int NJ, int WN_, typename TOUT, int EPI = 0>
+template <int MI, int NJ, int WN_, typename TOUT, int EPI = 0, bool AHEAD = (OMLM_EPI_CIN_AHEAD != 0) && (MI * NJ <= 4)>
 __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16 (&acc)[MI][NJ], char* smem, int m0, int n0,
-                                              int wm, int wn, int wave, int lane, int dbg, bool split) {
+                                              int wm, int wn, int wave, int lane, int dbg, bool split, float* patch = nullptr) {
     constexpr int SROW = WN_ + 4;                                  // padded row (floats), keeps 16-B alignment
-    float* stg = (float*)smem + (size_t)wave * 32 * SROW;
+    float* stg = patch ? patch : (float*)smem + (size_t)wave * 32 * SROW;      // (persistent kernel: the patch sits where no DMA lands)
     constexpr int VEC = sizeof(TOUT) == 2 ? 8 : 4;                 // elements per 16-byte store
     constexpr int LPR = WN_ / VEC;                                 // lanes per row
     constexpr int RPP = 64 / LPR;                                  // rows per pass
@@ -430,38 +433,59 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16 (&acc)[M
     }
     constexpr int NP = 32 / RPP;                                   // passes per 32-row strip
     const bool cin_pref = g.Cin != nullptr && vec_ok;
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        // Residual (Cin) pieces of the whole strip are requested BEFORE the LDS transposition: one memory round trip per strip, hidden
-        // behind the ds_write / ds_read pass.  (Round 4: with the loads inside the pass loop -- behind its row / column early-outs -- every
-        // pass waited for its own piece: 32 dependent round trips per 256x256 tile, to_out (K = 512) 130 us against a 60 us HBM floor at
-        // every tile size, FF-out ~80 us of epilogue.)
-        float4 cinv[NP][VEC / 4];
-        int prows[NP];                                             // physical C rows of the strip's passes (scatter map), -1: dropped
-        if (cin_pref) {
-            if (g.c_map) {                                         // the map entries of all passes in flight together, then the pieces
-#pragma unroll
-                for (int pass = 0; pass < NP; ++pass) {
-                    const int row = m0 + wm + 32 * i + pass * RPP + lane / LPR;
-                    prows[pass] = g.c_map[row < g.M ? row : 0];
-                }
-            }
+    // Residual (Cin) pieces of a whole strip are requested BEFORE its LDS transposition: one memory round trip per strip, hidden behind
+    // the ds_write / ds_read pass.  (Round 4: with the loads inside the pass loop -- behind its row / column early-outs -- every pass
+    // waited for its own piece: 32 dependent round trips per 256x256 tile, to_out (K = 512) 130 us against a 60 us HBM floor at every
+    // tile size, FF-out ~80 us of epilogue.)  AHEAD (64x64 wave tiles only: the 128x64 ones have no registers for it -- 32 to 64 spills): strip
+    // i + 1's pieces leave before strip i's stores (second register set).  Requested after them, their first use is a `vmcnt` that also covers the older stores: every strip drained the previous
+    // strip's stores (a write round trip per strip) before it could add its residual.
+    float4 cinv[2][NP][VEC / 4];
+    int prows[2][NP];                                              // physical C rows of a strip's passes (scatter map), -1: dropped
+    auto request = [&](const int i, const int slot) {
+        if (g.c_map) {                                             // the map entries of all passes in flight together, then the pieces
 #pragma unroll
             for (int pass = 0; pass < NP; ++pass) {
-                const int r = pass * RPP + lane / LPR, c = (lane % LPR) * VEC;
-                const int row = m0 + wm + 32 * i + r, col = n0 + wn + c;
-                if (!g.c_map) prows[pass] = row;
-                const bool ok = row < g.M && col + VEC <= g.N && prows[pass] >= 0;
-                const float* src = g.Cin + (long long)(ok ? prows[pass] : 0) * g.ldcin + (ok ? col : 0);
-#pragma unroll
-                for (int x = 0; x < VEC / 4; ++x) cinv[pass][x] = *(const float4*)(src + 4 * x);
+                const int row = m0 + wm + 32 * i + pass * RPP + lane / LPR;
+                prows[slot][pass] = g.c_map[row < g.M ? row : 0];
             }
+        }
+#pragma unroll
+        for (int pass = 0; pass < NP; ++pass) {
+            const int r = pass * RPP + lane / LPR, c = (lane % LPR) * VEC;
+            const int row = m0 + wm + 32 * i + r, col = n0 + wn + c;
+            if (!g.c_map) prows[slot][pass] = row;
+            const bool ok = row < g.M && col + VEC <= g.N && prows[slot][pass] >= 0;
+            const float* src = g.Cin + (long long)(ok ? prows[slot][pass] : 0) * g.ldcin + (ok ? col : 0);
+#pragma unroll
+            for (int x = 0; x < VEC / 4; ++x) cinv[slot][pass][x] = *(const float4*)(src + 4 * x);
+        }
+    };
+    if (AHEAD && cin_pref) request(0, 0);
+    // l2-norm epilogue: a lane's eight scale values are the same in every pass and strip (its column inside the head) -- loaded once.  Inside
+    // the pass loop each load's wait also covered the stores of the pass before: one write round trip per pass.
+    float4 es0 = make_float4(0.f, 0.f, 0.f, 0.f), es1 = es0;
+    if constexpr (EPI == 1) {
+        const int c = (lane % LPR) * VEC;
+        es0 = *(const float4*)(g.epi_scale + c);
+        es1 = *(const float4*)(g.epi_scale + c + 4);
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        if (cin_pref) {
+            if (!AHEAD) request(i, i & 1);
+            else if (i + 1 < MI) request(i + 1, (i + 1) & 1);
         }
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e)
                 stg[((e & 3) + 8 * (e >> 2) + 4 * hi) * SROW + 32 * j + (lane & 31)] = g.alpha * acc[i][j][e];
+        if constexpr (EPI == 1) {
+            // the scale values are consumed HERE, on every path, behind the first strip's LDS writes: one wait, before any store exists.
+            // (Left to their first use inside the pass loop -- a conditional region -- hipcc repeats the wait in every pass, and there
+            // it covers the stores of the pass before.)
+            if (i == 0) asm volatile("" : "+v"(es0.x), "+v"(es0.y), "+v"(es0.z), "+v"(es0.w), "+v"(es1.x), "+v"(es1.y), "+v"(es1.z), "+v"(es1.w));
+        }
 #pragma unroll
         for (int pass = 0; pass < NP; ++pass) {
             const int r = pass * RPP + lane / LPR, c = (lane % LPR) * VEC;
@@ -473,7 +497,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16 (&acc)[M
                 v[x] = t.x; v[x + 1] = t.y; v[x + 2] = t.z; v[x + 3] = t.w;
             }
             if (row >= g.M || col >= g.N) continue;
-            const long long prow = cin_pref ? (long long)prows[pass] : (g.c_map ? (long long)g.c_map[row] : (long long)row);
+            const long long prow = cin_pref ? (long long)prows[i & 1][pass] : (g.c_map ? (long long)g.c_map[row] : (long long)row);
             if (prow < 0) continue;
             if constexpr (EPI == 1) {
                 // q / k of the attention (transformer.py:265-271): l2-normalise each 64-wide head and apply the learned per-dim scale
@@ -487,7 +511,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16 (&acc)[M
                     for (int x = 0; x < VEC; ++x) ss += v[x] * v[x];
                     ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
                     const float nrm = fmaxf(sqrtf(ss), 1e-12f), inv = 1.0f / nrm;
-                    const float4 s0 = *(const float4*)(g.epi_scale + c), s1 = *(const float4*)(g.epi_scale + c + 4);
+                    const float4 s0 = es0, s1 = es1;
                     v[0] = v[0] * inv * s0.x; v[1] = v[1] * inv * s0.y; v[2] = v[2] * inv * s0.z; v[3] = v[3] * inv * s0.w;
                     v[4] = v[4] * inv * s1.x; v[5] = v[5] * inv * s1.y; v[6] = v[6] * inv * s1.z; v[7] = v[7] * inv * s1.w;
                     if ((lane % LPR) == 0) g.epi_norm[prow * g.epi_ldnorm + grp] = nrm;
@@ -503,7 +527,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16 (&acc)[M
                 if (cin_pref) {
 #pragma unroll
                     for (int x = 0; x < VEC; x += 4) {
-                        const float4 t = cinv[pass][x / 4];
+                        const float4 t = cinv[i & 1][pass][x / 4];
                         v[x] += t.x; v[x + 1] += t.y; v[x + 2] += t.z; v[x + 3] += t.w;
                     }
                 } else if (g.Cin) {
@@ -729,6 +753,203 @@ __global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile
 }
 
 
+// ---- persistent form of the wide tile kernel -----------------------------------------------------------------------------
+// The 256x256 tiles run ONE workgroup per CU (128 KiB of LDS), so nothing overlaps a workgroup's prologue (first k-tile: a full L2 / HBM
+// round trip), its epilogue and the dispatch of its successor: ~12 % of a K = 1024 tile (16 k-tiles), 32.5 us per tile against 28.6 us
+// at the rate of the k-loop (round 4).  Here G = gridDim.x workgroups (one per CU, G a multiple of 8) each walk the tiles
+// lin, lin + G, lin + 2G, ... of the XCD-aware order (lin & 7 is constant, so the walk stays inside its XCD's chunk and the 32 workgroups
+// of an XCD move through consecutive super-tile patches together), and the LAST k-iteration of a tile requests the FIRST k-tile of the
+// next one -- in the slots where the one-tile kernel issues its dead pieces -- so that tile's first round trip runs under this tile's
+// epilogue.  The request lands in the stage the last k-tile did not use; the epilogue's transpose patches therefore live in the
+// stage of the last k-tile (seven waves) and in 8.5 KiB behind the two stages (the eighth), never under a landing DMA piece.
+// Order: [k-loop ... last iteration: DMA(next tile, k-tile 0) -> stage X] barrier [epilogue: patches in stage X^1 / behind] [next
+// tile, iteration 0: vmcnt wait + barrier, DMA(k-tile 1) -> stage X^1, multiply from stage X].  The barrier of iteration 0 is what
+// orders every wave's patch traffic before the first piece of k-tile 1 lands in stage X^1.
+// Only the shape the host sends here is built: whole k-tiles (K % 64 == 0), no row / k-row / scatter maps, no split-K, plain epilogue.
+#ifndef OMLM_PERSIST_COUNTED
+#define OMLM_PERSIST_COUNTED 1     // 1: iteration 0 of a follow-up tile waits for its DMA pieces only (counted), not for the epilogue's stores behind them
+#endif
+// CIN: the epilogue adds a residual.  It is a template switch because the residual loads are what hipcc has to protect in the NEXT
+// tile's first iteration (their registers are re-used; paths that skip a row leave a load unconsumed): with them in the code,
+// iteration 0 carries compiler waits that drain the epilogue's stores whatever the run-time pointer is (seen in the ISA).
+template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ, bool B_KMAJ, typename TOUT, bool CIN, int EPI = 0>
+__global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile_persist_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A | B] + one transpose patch
+    constexpr int NWN = BN_ / WN_, NWAVES = (BM_ / WM_) * NWN;
+    constexpr int MI = WM_ / 32, NJ = WN_ / 32;
+    constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BN_ * BK * 2, STAGE = A_BYTES + B_BYTES;
+    constexpr int UA = (BM_ / 8) / NWAVES, UB = (BN_ / 8) / NWAVES;
+    constexpr int PATCH = 32 * (WN_ + 4) * 4;                      // one wave's transpose patch (tile_epilogue: 32 rows x SROW floats)
+    static_assert((NWAVES - 1) * PATCH <= STAGE, "all but the last wave's patch must fit inside one stage");
+    constexpr int GROUP = OMLM_SUPER_ROWS / BM_;
+    constexpr int VEC = sizeof(TOUT) == 2 ? 8 : 4, NSTORE = MI * (32 / (64 / (WN_ / VEC)));   // 16-byte stores per wave of a full tile's epilogue
+
+    const int tiles_m = (g.M + BM_ - 1) / BM_, tiles_n = (g.N + BN_ - 1) / BN_;
+    const int total = tiles_m * tiles_n;
+    const int nk = g.K / BK;                                       // host: K % 64 == 0, K > 0
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = (wave / NWN) * WM_, wn = (wave % NWN) * WN_;
+    const dma_rsrc rsA = make_dma_rsrc(g.A, (unsigned long long)g.a_rows * g.lda * 2);
+    const dma_rsrc rsB = make_dma_rsrc(g.B, (unsigned long long)g.b_rows * g.ldb * 2);
+    const unsigned smem_lds = (unsigned)(size_t)LDS_PTR(char, smem);
+
+    auto origin = [&](int lin, int& m0, int& n0) {                 // the one-tile kernel's order (xcd_logical_id + super-tiles)
+        const int bid = xcd_logical_id(lin, total);
+        const int gsz = GROUP * tiles_n;
+        const int grp = bid / gsz, first_m = grp * GROUP;
+        const int rows_in = min(GROUP, tiles_m - first_m);
+        m0 = (first_m + (bid - grp * gsz) % rows_in) * BM_;
+        n0 = ((bid - grp * gsz) / rows_in) * BN_;
+    };
+    // one 1-KiB piece of k-tile k0 (same address form as DmaStagerT::issue_one<false, true>)
+    auto piece = [&](int l, const unsigned (&va)[UA], const unsigned (&vb)[UB], int k0, unsigned stage_lds, bool live) {
+        if (l < UA) {
+            const int b = wave + NWAVES * l;
+            dma_issue_s(rsA, stage_lds + (unsigned)(b * 1024), live ? va[l] : OOB_OFF,
+                        A_KMAJ ? (unsigned)k0 * (unsigned)(g.lda * 2) : (unsigned)(k0 * 2));
+        } else {
+            const int b = wave + NWAVES * (l - UA);
+            dma_issue_s(rsB, stage_lds + (unsigned)A_BYTES + (unsigned)(b * 1024), live ? vb[l - UA] : OOB_OFF,
+                        B_KMAJ ? (unsigned)k0 * (unsigned)(g.ldb * 2) : (unsigned)(k0 * 2));
+        }
+    };
+
+    int lin = blockIdx.x;
+    const int G = gridDim.x;
+    if (lin >= total) return;
+    int m0, n0;
+    origin(lin, m0, n0);
+    unsigned va[UA], vb[UB];                                       // per-lane byte offsets of this tile's pieces at k = 0
+    {
+        DmaStagerT<A_KMAJ, BM_, NWAVES> sa;
+        DmaStagerT<B_KMAJ, BN_, NWAVES> sb;
+        sa.init(nullptr, g.lda, g.M, m0, wave, lane);
+        sb.init(nullptr, g.ldb, g.N, n0, wave, lane);
+#pragma unroll
+        for (int i = 0; i < UA; ++i) va[i] = sa.vfast[i];
+#pragma unroll
+        for (int i = 0; i < UB; ++i) vb[i] = sb.vfast[i];
+    }
+    int par = 0;                                                   // stage of the current tile's k-tile 0
+#pragma unroll
+    for (int l = 0; l < UA + UB; ++l) piece(l, va, vb, 0, smem_lds, true);
+    bool counted = false;                                          // the pieces of k-tile 0 are older than >= NSTORE stores of the previous epilogue
+
+    for (;;) {
+        const int lin_n = lin + G;
+        const bool has_next = lin_n < total;
+        int m0n = m0, n0n = n0;
+        if (has_next) origin(lin_n, m0n, n0n);
+        unsigned van[UA], vbn[UB];
+        {
+            DmaStagerT<A_KMAJ, BM_, NWAVES> sa;
+            DmaStagerT<B_KMAJ, BN_, NWAVES> sb;
+            sa.init(nullptr, g.lda, g.M, m0n, wave, lane);
+            sb.init(nullptr, g.ldb, g.N, n0n, wave, lane);
+#pragma unroll
+            for (int i = 0; i < UA; ++i) van[i] = sa.vfast[i];
+#pragma unroll
+            for (int i = 0; i < UB; ++i) vbn[i] = sb.vfast[i];
+        }
+        f32x16 acc[MI][NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        {   // the rotated k-loop of gemm_tile_body (same products in the same order per accumulator)
+            h16x8 a[2][MI], b[2][NJ];
+            bool pending = false;
+            constexpr int MPS = MI * NJ, NLOAD = UA + UB;
+            constexpr int SPREAD = 2;
+            constexpr int STRIDE = (SPREAD * MPS) / NLOAD > 0 ? (SPREAD * MPS) / NLOAD : 1;
+            for (int kt = 0; kt < nk; ++kt) {
+                const int cur = (par + kt) & 1;
+                if (OMLM_PERSIST_COUNTED && kt == 0 && counted) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NSTORE) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                const bool last = kt + 1 == nk;
+                const bool live = !last || has_next;
+                const unsigned nxt = smem_lds + (unsigned)((cur ^ 1) * STAGE);
+                const int knext = last ? 0 : (kt + 1) * BK;
+                const char* As = smem + cur * STAGE;
+                const char* Bs = As + A_BYTES;
+                auto phase = [&](const int ph, const int fi, const bool mul) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) {
+                            if (mul) acc[i][j] = OMLM_MFMA_32x32x16(a[fi][i], b[fi][j], acc[i][j]);
+                            const int midx = ph * MPS + i * NJ + j;
+                            if (midx % STRIDE == 0 && midx / STRIDE < NLOAD) {
+                                const int l = midx / STRIDE;
+                                __builtin_amdgcn_sched_barrier(0);
+                                unsigned v;
+                                if (l < UA) v = last ? van[l] : va[l]; else v = last ? vbn[l - UA] : vb[l - UA];
+                                {
+                                    unsigned one_a[UA], one_b[UB];
+#pragma unroll
+                                    for (int x = 0; x < UA; ++x) one_a[x] = v;
+#pragma unroll
+                                    for (int x = 0; x < UB; ++x) one_b[x] = v;
+                                    piece(l, one_a, one_b, knext, nxt, live);
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                };
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a[0][i] = read_frag<A_KMAJ>(As, wm + 32 * i, 0, lane);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) b[0][j] = read_frag<B_KMAJ>(Bs, wn + 32 * j, 0, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                phase(0, 1, pending);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int st = 0; st < 3; ++st) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) a[(st + 1) & 1][i] = read_frag<A_KMAJ>(As, wm + 32 * i, st + 1, lane);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) b[(st + 1) & 1][j] = read_frag<B_KMAJ>(Bs, wn + 32 * j, st + 1, lane);
+                    __builtin_amdgcn_sched_barrier(0);
+                    phase(st + 1, st & 1, true);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                pending = true;
+            }
+            if (pending) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = OMLM_MFMA_32x32x16(a[1][i], b[1][j], acc[i][j]);
+            }
+        }
+        const int cur_last = (par + nk - 1) & 1;
+        // Last tile of the walk: its final iteration issued dead pieces (zeros) into the other stage, which nothing reads or patches again;
+        // they are waited for all the same, so that the kernel never ends with LDS writes in flight.
+        if (!has_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                           // every wave's fragment reads of the last k-tile's stage are complete
+        float* patch = wave < NWAVES - 1 ? (float*)(smem + cur_last * STAGE + wave * PATCH) : (float*)(smem + 2 * STAGE);
+        GemmArgs ge = g;
+        ge.c_map = nullptr;                                        // host: no scatter map on this route
+        if constexpr (!CIN) ge.Cin = nullptr;
+        tile_epilogue<MI, NJ, WN_, TOUT, EPI, false>(ge, acc, smem, m0, n0, wm, wn, wave, lane, 0, false, patch);    // (no second residual set: registers)
+        if (!has_next) break;
+        // a full interior tile's epilogue issued exactly NSTORE 16-byte stores per wave behind the next tile's pieces (more on the scalar
+        // path): `vmcnt(NSTORE)` then covers the pieces; an edge tile skips stores, so its successor drains everything
+        counted = m0 + BM_ <= g.M && n0 + BN_ <= g.N;
+        par = (par + nk) & 1;
+        lin = lin_n; m0 = m0n; n0 = n0n;
+#pragma unroll
+        for (int i = 0; i < UA; ++i) va[i] = van[i];
+#pragma unroll
+        for (int i = 0; i < UB; ++i) vb[i] = vbn[i];
+    }
+}
+
+
 // ---- grouped weight-gradient GEMM ------------------------------------------------------------------------------------
 // All dW += dY^T X contractions of a backward pass (same K = tokens, small outputs) as ONE launch: the 30 separate GEMMs of a
 // coarse-small step each had too few output tiles for 256 CUs and were split 5..31 ways along K with fp32 atomics
@@ -760,6 +981,28 @@ __global__ __launch_bounds__(512) void gemm_wgrad_group_kernel(GroupArgs ga) {
     g.epi_scale = nullptr; g.epi_norm = nullptr; g.epi_groups = 0; g.epi_ldnorm = 0; g.C2 = nullptr; g.c2_col0 = 0; g.ldc2 = 0;
     const int nk = (q.K + BK - 1) / BK;
     gemm_tile_body<256, 256, 128, 64, true, true, float, false, false, false, false, FASTK>(g, lg - q.start, q.kt_per_split < nk, 0, smem);
+}
+
+#ifdef OMLM_ISA_ONLY       /* tools/isa_audit.py-style inspection builds: the persistent kernels alone (seconds instead of minutes) */
+template __global__ void gemm_bf16_tile_persist_kernel<256, 256, 128, 64, false, false, h16_t, false>(GemmArgs);
+template __global__ void gemm_bf16_tile_persist_kernel<256, 256, 128, 64, false, true, h16_t, false>(GemmArgs);
+template __global__ void gemm_bf16_tile_persist_kernel<256, 256, 128, 64, false, false, float, true>(GemmArgs);
+template __global__ void gemm_bf16_tile_persist_kernel<256, 256, 128, 64, false, true, float, true>(GemmArgs);
+template __global__ void gemm_bf16_tile_persist_kernel<128, 128, 64, 64, false, false, h16_t, false>(GemmArgs);
+template __global__ void gemm_bf16_tile_persist_kernel<128, 128, 64, 64, false, false, float, true>(GemmArgs);
+template __global__ void gemm_bf16_tile_persist_kernel<128, 128, 64, 64, false, false, h16_t, false, 1>(GemmArgs);
+}   // namespace
+#else
+// workgroups of the persistent walk: one per CU, rounded down to a multiple of 8 (the walk's stride must keep a workgroup on its XCD);
+// 0 = switched off (OMLM_GEMM_PERSIST=0)
+static int gemm_persist_slots() {
+    static int ncu8 = -1;
+    if (ncu8 < 0) {
+        int dev = 0, n = 0;
+        ncu8 = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n >= 8) ? n / 8 * 8 : 0;
+    }
+    const char* e = getenv("OMLM_GEMM_PERSIST");                   // read per call like the other levers: tests toggle it inside one process
+    return (e && e[0] == '0') ? 0 : ncu8;
 }
 
 template <int BM_, int BN_, int WM_, int WN_, typename TOUT>
@@ -805,6 +1048,29 @@ static int launch_tile(const GemmArgs& g, int a_kmaj, int b_kmaj, int splits, hi
         else if (g.K % BK == 0 && !gemm_fastk_off()) hipLaunchKernelGGL(kfast, grid, block, LDS, st, g);                   \
         else           hipLaunchKernelGGL(kfn, grid, block, LDS, st, g);                                                   \
     } while (0)
+    // Persistent walk (gemm_bf16_tile_persist_kernel) for the wide tile when the problem is more than one round of the machine:
+    // whole k-tiles, k-contiguous A, no maps on the k side, no split, no ablation / plane modes.  OMLM_GEMM_PERSIST=0 keeps the one-tile grid.
+    if constexpr ((BM_ == 256 && BN_ == 256) || (BM_ == 128 && BN_ == 128)) {
+        const int slots = gemm_persist_slots() * (BM_ == 128 ? 2 : 1);             // 64 KiB tiles: two workgroups per CU
+        if (slots > 0 && !a_kmaj && splits == 1 && g.bal_ck == 0 && !g.split3 && !g.debug && !g.a_map && !g.b_map && !g.c_map && g.K % BK == 0 &&
+            !gemm_fastk_off() && tiles > slots) {
+            constexpr size_t LDSP = LDS + 32 * (WN_ + 4) * 4;
+            static bool pattr = false;
+            auto k0 = gemm_bf16_tile_persist_kernel<BM_, BN_, WM_, WN_, false, false, TOUT, false>;
+            auto k1 = gemm_bf16_tile_persist_kernel<BM_, BN_, WM_, WN_, false, true, TOUT, false>;
+            auto k0c = gemm_bf16_tile_persist_kernel<BM_, BN_, WM_, WN_, false, false, TOUT, true>;
+            auto k1c = gemm_bf16_tile_persist_kernel<BM_, BN_, WM_, WN_, false, true, TOUT, true>;
+            if (!pattr) {
+                (void)hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDSP);
+                (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDSP);
+                (void)hipFuncSetAttribute((const void*)k0c, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDSP);
+                (void)hipFuncSetAttribute((const void*)k1c, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDSP);
+                pattr = true;
+            }
+            hipLaunchKernelGGL(g.Cin ? (b_kmaj ? k1c : k0c) : (b_kmaj ? k1 : k0), dim3(slots), block, LDSP, st, g);
+            return omlm_post_launch("omlm_gemm");
+        }
+    }
     if (!a_kmaj && !b_kmaj)      OMLM_TILE_LAUNCH(false, false);
     else if (!a_kmaj && b_kmaj)  OMLM_TILE_LAUNCH(false, true);
     else if (a_kmaj && b_kmaj)   OMLM_TILE_LAUNCH(true, true);
@@ -1032,8 +1298,16 @@ extern "C" int OMLM_API(omlm_gemm_qknorm)(const void* A, const void* B, void* C,
         (void)hipFuncSetAttribute((const void*)kgen, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
         attr = true;
     }
-    if (K % BK == 0 && !gemm_fastk_off()) hipLaunchKernelGGL(kfast, dim3(tiles, 1), dim3(256), LDS, as_stream(stream), g);
-    else                                   hipLaunchKernelGGL(kgen, dim3(tiles, 1), dim3(256), LDS, as_stream(stream), g);
+    const int slots = 2 * gemm_persist_slots();                    // persistent walk, two workgroups per CU (see gemm_bf16_tile_persist_kernel)
+    if (slots > 0 && tiles > slots && K % BK == 0 && !gemm_fastk_off()) {
+        constexpr size_t LDSP = LDS + 32 * (64 + 4) * 4;
+        auto kp = gemm_bf16_tile_persist_kernel<128, 128, 64, 64, false, false, h16_t, false, 1>;
+        static bool pattr = false;
+        if (!pattr) { (void)hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDSP); pattr = true; }
+        hipLaunchKernelGGL(kp, dim3(slots), dim3(256), LDSP, as_stream(stream), g);
+    }
+    else if (K % BK == 0 && !gemm_fastk_off()) hipLaunchKernelGGL(kfast, dim3(tiles, 1), dim3(256), LDS, as_stream(stream), g);
+    else                                        hipLaunchKernelGGL(kgen, dim3(tiles, 1), dim3(256), LDS, as_stream(stream), g);
     return omlm_post_launch("omlm_gemm_qknorm");
 }
 
@@ -1173,3 +1447,4 @@ extern "C" int OMLM_API(omlm_gemm_wgrad_group)(const omlm_gemm_wgrad_desc* d, in
 }
 
 }   // namespace OMLM_NS
+#endif   // OMLM_ISA_ONLY

@@ -52,7 +52,11 @@ def run(iters=300, burst=12):
              case_planes(1116, 512, 512, False),          # its forward a = z W^T
              case_h16(1116, 512, 512, torch.float32, False),
              case_h16(2048, 1024, 1024, torch.float32, True),      # 256x256 tiles, 16 k-tiles, fp32 + residual epilogue
-             case_h16(2048, 2048, 1024, torch.bfloat16, False)]
+             case_h16(2048, 2048, 1024, torch.bfloat16, False),
+             # more than one round of 256x256 tiles: the persistent walk (gemm_bf16_tile_persist_kernel) -- the next tile's first k-tile lands
+             # in one LDS stage while the epilogue patches the other; late pieces (second stream's traffic) must not meet a patch
+             case_h16(8192, 4096, 1024, torch.bfloat16, False),
+             case_h16(8192, 4096, 576, torch.float32, True)]         # 9 k-tiles (odd: the stage parity alternates between tiles), fp32 + residual
 
     def launch(c, out):
         ops.gemm(c["A"], c["B"], out, M=c["M"], N=c["N"], K=c["K"], Cin=c.get("Cin"), **c["kw"])

@@ -105,6 +105,58 @@ def test_gemm_layouts(ops, dev, dtype, M, N, K, akm, bkm):
     assert e < 2e-5, e          # fp32-grade: bf16x3 split, or exact products of bf16 inputs, fp32 accumulation
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,bkm,out16,resid", [
+    (8192, 4096, 1024, False, True, False),      # 512 whole tiles: two per workgroup, counted first-iteration waits
+    (8200, 4104, 192, True, True, False),        # ragged on both sides: edge tiles (drained waits), odd k-tile count (the stage parity flips per tile)
+    (7700, 4100, 128, False, True, False),       # row pitch not a multiple of 8: the element-wise store path behind the counted wait
+    (13000, 2752, 1024, True, True, False),      # the d(h2) shape class: 11 tile columns, walk of 2..3 tiles per workgroup
+    (9000, 3000, 320, False, False, True),       # fp32 output + residual (the CIN instantiation), 5 k-tiles
+])
+def test_gemm_persistent_walk_equals_the_one_tile_grid(ops, dev, dtype, M, N, K, bkm, out16, resid):
+    """The persistent form of the 256x256 kernel (one workgroup per CU walks several tiles; the next tile's first k-tile is requested under the
+    current tile's epilogue) must produce the same bits as the one-tile grid (OMLM_GEMM_PERSIST=0) -- same products, same order -- and
+    both must match fp64 on the rounded operands.  Repeated so that a race between the epilogue's LDS patches and the landing DMA pieces
+    (or a short counted wait) would show as run-to-run differences."""
+    g = torch.Generator(device="cpu").manual_seed(M + 3 * N + K)
+    A = torch.randn(M, K, generator=g).to(dtype).to(dev)
+    Bm = torch.randn(N, K, generator=g).to(dtype)
+    if bkm:                                                 # [K, N padded to 8]
+        B = torch.zeros(K, (N + 7) // 8 * 8, dtype=dtype)
+        B[:, :N] = Bm.t()
+        B = B.to(dev)
+    else:
+        B = Bm.to(dev)
+    Cin = torch.randn(M, N, generator=g).to(dev) if resid else None
+    odt = dtype if out16 else torch.float32
+    ref = A.double() @ Bm.to(dev).double().t()
+    if resid:
+        ref = ref + Cin.double()
+    outs = {}
+    old = os.environ.get("OMLM_GEMM_PERSIST")
+    try:
+        for mode in ("0", "1"):
+            os.environ["OMLM_GEMM_PERSIST"] = mode
+            runs = []
+            for rep in range(6 if mode == "1" else 1):
+                C = torch.full((M, N), float("nan"), device=dev, dtype=odt)
+                ops.gemm(A, B, C, M=M, N=N, K=K, a_kmajor=False, b_kmajor=bkm, Cin=Cin, a_rows=M, b_rows=K if bkm else N)
+                runs.append(C)
+            outs[mode] = runs
+    finally:
+        if old is None:
+            os.environ.pop("OMLM_GEMM_PERSIST", None)
+        else:
+            os.environ["OMLM_GEMM_PERSIST"] = old
+    torch.cuda.synchronize()
+    e = relerr(outs["1"][0].float(), ref)
+    same = all(torch.equal(outs["0"][0], c) for c in outs["1"])
+    report(f"gemm_persist[{dtype},{M},{N},{K},{bkm},{out16},{resid}]", relerr=e, bit_equal_to_one_tile_grid=same)
+    assert not torch.isnan(outs["1"][0].float()).any()
+    assert same, "persistent walk differs from the one-tile grid (or from itself between runs)"
+    assert e < (8e-3 if out16 else 2e-5), e      # 16-bit output: one rounding of the result (2^-8 / 2^-11 of the row's scale); fp32: accumulation order only
+
+
 @pytest.mark.parametrize("M,N,K,akm,bkm,accumulate", [(1100, 520, 264, False, True, False), (600, 264, 5000, True, True, True),
                                                        (777, 1032, 520, False, False, False), (300, 512, 2048, True, False, True)])
 def test_gemm_fp32_on_operand_planes(ops, dev, M, N, K, akm, bkm, accumulate):

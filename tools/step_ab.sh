@@ -1,0 +1,17 @@
+#!/bin/bash
+# same-box A/B of the training step: library variants / environment levers, one bench line each
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+O=gpurun_out/${1:-r4ab}; mkdir -p $O
+B="python bench.py --no-cpu-baseline --no-legs --no-decode --steps 20 --warmup 5"
+run() { name=$1; shift; echo "== $name" | tee -a $O/step_ab.log; env "$@" timeout 300 $B 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l); r = d['roofline']
+        print('ms_per_step', d['ms_per_step'], 'gemm_ms', r['gemm_ms_per_step'], 'frac', r['frac'], 'large', r.get('large_gemm_achieved'), 'loss', d.get('final_loss'))
+" | tee -a $O/step_ab.log; }
+run head_lib OMLM_LIB_PATH=$PWD/.variants/libomlm_r4head.so
+run new_nopersist OMLM_GEMM_PERSIST=0
+run new X=1
+run head_lib OMLM_LIB_PATH=$PWD/.variants/libomlm_r4head.so
+run new X=1
