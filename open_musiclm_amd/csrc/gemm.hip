@@ -1128,6 +1128,12 @@ static int gemm_impl(const void* A, const void* B, void* C, const float* Cin,
     const bool need_kmap = (a_kmajor && a_map) || (b_kmajor && b_map);
     if (in_dtype == 1 && !need_kmap) {
         if (force && force[0]) { if (!strcmp(force, "256x256")) { bm = 256; bn = 256; } else if (!strcmp(force, "256x128")) { bm = 256; bn = 128; } }
+        // Short contractions onto narrow outputs (to_out, d(xn), d(x) of k | v: K <= 512, N <= 1024): with the persistent walk the 128x128
+        // tiles (two walkers per CU, 4 x the tiles to balance) beat the wide ones -- to_out 103 -> 92 us, d(xn) 57 -> 50 us (round 4 probe).
+        // OMLM_GEMM_SMALLK=0 keeps the old choice.
+        else if (K <= 512 && N <= 1024 && K % BK == 0 && !a_kmajor && !a_map && !b_map && !c_map && !split3 && Cin != (const float*)C &&
+                 ((M + 127) / 128) * ((N + 127) / 128) > 2 * gemm_persist_slots() && gemm_persist_slots() > 0 && !gemm_fastk_off() &&
+                 !(getenv("OMLM_GEMM_SMALLK") && getenv("OMLM_GEMM_SMALLK")[0] == '0')) { bm = 128; bn = 128; }
         else if (M >= 1024 && N >= 1024) { bm = 256; bn = 256; }   // measured (probe, N = 1024): 256x256 514 us, 128x128 543, 256x128 657
         // N = 512 outputs (q-proj, d(o)): 128x128 (two workgroups per CU) measured 54 / 54 us against 60 / 59 for 256x128 (round 4 tile probe)
         else if (M >= 2048 && N > 512) { bm = 256; bn = 128; }

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void qk_norm_bwd_kernel(const float* __restric
 // and n = max(|x|, 1e-12) in fp32 -- xh = y / s (one operand rounding, like every other operand of the 16-bit modes; a zero scale
 // gives xh = 0: its dx is 0 anyway, only its d(scale) is lost).  No fp32 pre-norm projections are read (146 -> 64 MB per layer).
 template <typename T>
-__global__ __launch_bounds__(256) void qk_norm_bwd2_kernel(const float* __restrict__ dq, const float* __restrict__ dk,
+__global__ __launch_bounds__(256) void qk_norm_bwd2_mixed_kernel(const float* __restrict__ dq, const float* __restrict__ dk,
                                                            const float* __restrict__ dv, const T* __restrict__ q, const T* __restrict__ k,
                                                            const float* __restrict__ qn, const float* __restrict__ kn,
                                                            const float* __restrict__ q_scale, const float* __restrict__ k_scale,
@@ -405,6 +405,125 @@ __global__ __launch_bounds__(256) void qk_norm_bwd2_kernel(const float* __restri
     }
 }
 
+
+// Round 4, second form (QKB2_STREAM, default): the mixed kernel above walks one list of (row, head | k | v) vectors, so every load and
+// store of its trip sits behind a per-vector kind test; hipcc's s_waitcnt bookkeeping then has to assume the shortest path ("nothing
+// was issued behind this load") and the four vectors of a trip were in fact requested one after the other, each wait also draining
+// the stores before it (seen in the ISA: vmcnt(0) between the units; 62 us per layer = 2.9 TB/s).  Here the q vectors are what they
+// are in memory -- ONE contiguous stream of M * H 64-wide vectors with identical work -- and a unit is 8 consecutive vectors: lane l
+// holds elements 8 (l & 7) .. + 7 of vector (l >> 3), a wave-instruction reads 1 KiB of q / 2 x 1 KiB of dq contiguously.  Whole units
+// run two at a time without a single condition (counted waits); the ragged tail and the k | v rows (1 / (H + 1) of the bytes) take
+// the predicated body.
+struct QkUnit { u32x4 y; float4 d0, d1; float nr; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void qk_norm_bwd2_kernel(const float* __restrict__ dq, const float* __restrict__ dk,
+                                                           const float* __restrict__ dv, const T* __restrict__ q, const T* __restrict__ k,
+                                                           const float* __restrict__ qn, const float* __restrict__ kn,
+                                                           const float* __restrict__ q_scale, const float* __restrict__ k_scale,
+                                                           T* __restrict__ dq_raw, T* __restrict__ dkv_raw, float* __restrict__ dq_scale,
+                                                           float* __restrict__ dk_scale, int M, int H) {
+    static_assert(sizeof(T) == 2, "16-bit operands");
+    const int lane = threadIdx.x & 63, slot = lane >> 3, d0 = 8 * (lane & 7);
+    const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    auto rcp0 = [](float v) { return v != 0.f ? 1.0f / v : 0.f; };
+    float sc[8], sci[8], acc[8];
+    auto take_scale = [&](const float* p) {
+        const float4 a = *(const float4*)(p + d0), b = *(const float4*)(p + d0 + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sc[e] = v[e]; sci[e] = rcp0(v[e]); acc[e] = 0.f; }
+    };
+    auto load = [&](QkUnit& U, const T* y, const float* dy, const float* nrm, long long vec) {
+        U.y = *(const u32x4*)(y + vec * 64 + d0);
+        U.d0 = *(const float4*)(dy + vec * 64 + d0);
+        U.d1 = *(const float4*)(dy + vec * 64 + d0 + 4);
+        U.nr = nrm[vec];
+    };
+    // dx of one vector from its normalised output: xh = y / s, gy = s dy, dx = (gy - xh <xh, gy>) / n; d(scale) += dy xh
+    auto finish = [&](const QkUnit& U, T* dst, const bool live) {
+        const float dy[8] = {U.d0.x, U.d0.y, U.d0.z, U.d0.w, U.d1.x, U.d1.y, U.d1.z, U.d1.w};
+        float xh[8], gy[8], part = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            xh[2 * e] = h16_lo_to_f(U.y[e]) * sci[2 * e];
+            xh[2 * e + 1] = h16_hi_to_f(U.y[e]) * sci[2 * e + 1];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { gy[e] = sc[e] * dy[e]; part += xh[e] * gy[e]; }
+        part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 4, 64);      // the vector's 8 lanes
+        const float proj = U.nr <= 1e-12f ? 0.f : part;
+        const float inv = 1.0f / U.nr;
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            o[e] = pack_h16_rne((gy[2 * e] - xh[2 * e] * proj) * inv, (gy[2 * e + 1] - xh[2 * e + 1] * proj) * inv);
+        if (live) {
+            *(u32x4*)dst = o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += dy[e] * xh[e];
+        }
+    };
+    __shared__ float red[4][64];
+    auto flush = [&](float* dscale) {                       // this workgroup's share of d(scale): 8 slots -> 4 waves -> 64 atomics
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = acc[e];
+            v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+            if (lane < 8) red[threadIdx.x >> 6][d0 + e] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) unsafeAtomicAdd(dscale + lane, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+        __syncthreads();
+    };
+
+    // ---- q: M * H vectors, one contiguous stream ------------------------------------------------------------------------
+    take_scale(q_scale);
+    const long long nq = (long long)M * H;
+    const int nfull = (int)(nq >> 3), nunits = (int)((nq + 7) >> 3);          // host: M * (H + 2) < 2^31
+    int u = wave_g;
+#pragma unroll 1
+    for (; u + nwaves < nfull; u += 2 * nwaves) {          // two whole units per trip, nothing predicated
+        QkUnit A, B;
+        const long long va = (long long)u * 8 + slot, vb = (long long)(u + nwaves) * 8 + slot;
+        load(A, q, dq, qn, va);
+        load(B, q, dq, qn, vb);
+        __builtin_amdgcn_sched_barrier(0);                 // all eight requests leave before the first use (hipcc otherwise sinks each load to its use)
+        finish(A, dq_raw + va * 64 + d0, true);
+        finish(B, dq_raw + vb * 64 + d0, true);
+    }
+#pragma unroll 1
+    for (; u < nunits; u += nwaves) {                      // the last whole unit of a wave and the ragged one
+        QkUnit A;
+        const long long va = (long long)u * 8 + slot;
+        const bool live = va < nq;
+        load(A, q, dq, qn, live ? va : 0);
+        __builtin_amdgcn_sched_barrier(0);
+        finish(A, dq_raw + (live ? va : 0) * 64 + d0, live);
+    }
+    flush(dq_scale);
+    // ---- k | v: one k vector (norm backward) and one v vector (cast) per row, into the [M, 128] kv gradient ----------------
+    take_scale(k_scale);
+    const int nurow = (M + 7) >> 3;
+#pragma unroll 1
+    for (int r = wave_g; r < nurow; r += nwaves) {
+        const long long row = (long long)r * 8 + slot;
+        const bool live = row < M;
+        const long long rc = live ? row : 0;
+        QkUnit A;
+        load(A, k, dk, kn, rc);
+        const float4 v0 = *(const float4*)(dv + rc * 64 + d0), v1 = *(const float4*)(dv + rc * 64 + d0 + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        finish(A, dkv_raw + rc * 128 + d0, live);
+        if (live) {
+            u32x4 o;
+            o[0] = pack_h16_rne(v0.x, v0.y); o[1] = pack_h16_rne(v0.z, v0.w); o[2] = pack_h16_rne(v1.x, v1.y); o[3] = pack_h16_rne(v1.z, v1.w);
+            *(u32x4*)(dkv_raw + rc * 128 + 64 + d0) = o;
+        }
+    }
+    flush(dk_scale);
+}
+
 #if !OMLM_FP16
 extern "C" int omlm_qk_norm_bwd2_h(const float* dq, const float* dk, const float* dv, const void* q, const void* k, const float* qn, const float* kn, const float* q_scale, const float* k_scale, void* dq_raw, void* dkv_raw, float* dq_scale, float* dk_scale, int M, int H, int dtype, void* stream);
 #endif
@@ -419,9 +538,22 @@ extern "C" int OMLM_API(omlm_qk_norm_bwd2)(const float* dq, const float* dk, con
     OMLM_CHECK_ARG(dq && dk && dv && q && k && qn && kn && dq_raw && dkv_raw && dq_scale && dk_scale, "null pointer");
     long long nvec = (long long)M * (H + 2);
     OMLM_CHECK_ARG(nvec < (1ll << 31), "qk_norm_bwd2: M * (H + 2) must stay below 2^31 (32-bit vector index)");
-    int blocks = (int)((nvec + 15) / 16); if (blocks > QKB_BLOCKS) blocks = QKB_BLOCKS;
+#ifndef QKB2_STREAM
+#define QKB2_STREAM 1           /* 1: the stream form (qk_norm_bwd2_kernel), 0: the mixed-vector form of round 4's first half */
+#endif
+#ifndef QKB2_BLOCKS
+#define QKB2_BLOCKS 1024        /* workgroups of the stream form (4 waves each; 128 atomics per workgroup at the end) */
+#endif
+#if QKB2_STREAM
+    long long want = ((long long)M * H / 8 + 7) / 8;               // ~2 units per wave at least
+    int blocks = want > QKB2_BLOCKS ? QKB2_BLOCKS : (want < 1 ? 1 : (int)want);
     hipLaunchKernelGGL(qk_norm_bwd2_kernel<h16_t>, dim3(blocks), dim3(256), 0, as_stream(stream), dq, dk, dv, (const h16_t*)q, (const h16_t*)k, qn, kn,
                        q_scale, k_scale, (h16_t*)dq_raw, (h16_t*)dkv_raw, dq_scale, dk_scale, M, H);
+#else
+    int blocks = (int)((nvec + 15) / 16); if (blocks > QKB_BLOCKS) blocks = QKB_BLOCKS;
+    hipLaunchKernelGGL(qk_norm_bwd2_mixed_kernel<h16_t>, dim3(blocks), dim3(256), 0, as_stream(stream), dq, dk, dv, (const h16_t*)q, (const h16_t*)k, qn, kn,
+                       q_scale, k_scale, (h16_t*)dq_raw, (h16_t*)dkv_raw, dq_scale, dk_scale, M, H);
+#endif
     return omlm_post_launch("omlm_qk_norm_bwd2");
 }
 

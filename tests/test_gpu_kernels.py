@@ -112,6 +112,8 @@ def test_gemm_layouts(ops, dev, dtype, M, N, K, akm, bkm):
     (7700, 4100, 128, False, True, False),       # row pitch not a multiple of 8: the element-wise store path behind the counted wait
     (13000, 2752, 1024, True, True, False),      # the d(h2) shape class: 11 tile columns, walk of 2..3 tiles per workgroup
     (9000, 3000, 320, False, False, True),       # fp32 output + residual (the CIN instantiation), 5 k-tiles
+    (40000, 512, 256, False, True, False),       # 128x128 tiles, two workgroups per CU: 1252 tiles on 512 walkers
+    (33000, 512, 192, True, False, True),        # the same route with fp32 output + residual, ragged last row tile, odd k-tile count
 ])
 def test_gemm_persistent_walk_equals_the_one_tile_grid(ops, dev, dtype, M, N, K, bkm, out16, resid):
     """The persistent form of the 256x256 kernel (one workgroup per CU walks several tiles; the next tile's first k-tile is requested under the
@@ -464,6 +466,43 @@ def test_gemm_qknorm_fused_projection_and_its_backward(ops, dev, dtype, M, K):
     report(f"gemm_qknorm[{dtype},{M},{K}]", fwd=e, norms=en, bwd=eb, dscale=es)
     # backward: xh comes from the ROUNDED outputs (2^-9 / 2^-11 per element) -- the projection term carries that rounding
     assert e < tol and en < 2e-5 and eb < 3 * tol and es < 3 * tol, (e, en, eb, es)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gemm_qknorm_persistent_walk_equals_the_one_tile_grid(ops, dev, dtype):
+    """omlm_gemm_qknorm on more tiles than two per CU takes the persistent walk (l2-norm epilogue instantiation): same bits as the
+    one-tile grid for the normalised outputs, the pass-through columns and the saved norms, run to run."""
+    M, K, H = 20000, 256, 8
+    g = torch.Generator().manual_seed(9)
+    A = torch.randn(M, K, generator=g).to(dev).to(dtype)
+    W = (torch.randn(H * 64 + 64, K, generator=g) / math.sqrt(K)).to(dev).to(dtype)      # 8 normalised heads + 64 pass-through columns
+    qs = (1 + 0.2 * torch.randn(64, generator=g)).to(dev)
+    res = {}
+    old = os.environ.get("OMLM_GEMM_PERSIST")
+    try:
+        for mode in ("0", "1"):
+            os.environ["OMLM_GEMM_PERSIST"] = mode
+            runs = []
+            for rep in range(4 if mode == "1" else 1):
+                q = torch.full((M, H * 64), 7.0, device=dev, dtype=dtype)
+                v = torch.full((M, 64), 7.0, device=dev, dtype=dtype)
+                qn = torch.zeros(M, H, device=dev)
+                ops.gemm_qknorm(A, W, q, qs, qn, H, M=M, N=H * 64 + 64, K=K, C2=v, c2_col0=H * 64)
+                runs.append((q, v, qn))
+            res[mode] = runs
+    finally:
+        if old is None:
+            os.environ.pop("OMLM_GEMM_PERSIST", None)
+        else:
+            os.environ["OMLM_GEMM_PERSIST"] = old
+    torch.cuda.synchronize()
+    ref = res["0"][0]
+    same = all(torch.equal(a, b) for r in res["1"] for a, b in zip(r, ref))
+    raw = A.double() @ W.double().t()
+    q_ref = torch.nn.functional.normalize(raw[:, :H * 64].view(M, H, 64), dim=-1) * qs.double()
+    e = max(relerr(ref[0], q_ref.reshape(M, -1)), relerr(ref[1], raw[:, H * 64:]))
+    report(f"gemm_qknorm_persist[{dtype}]", fwd=e, bit_equal_to_one_tile_grid=same)
+    assert same and e < (5e-3 if dtype == torch.bfloat16 else 7e-4), (same, e)
 
 
 def naive_attention(q, k, v, bias, keymask, H, scale=8.0):

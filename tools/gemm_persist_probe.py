@@ -19,20 +19,36 @@ rnd = lambda r, c, dt=bf: (torch.randn(r, c, generator=g) * 0.05).to(dev).to(dt)
 SHAPES = [("FF-in    -> bf16", 5504, 1024, bf, False, False),
           ("d(h2)    dres W2 (B k-major)", 2752, 1024, bf, False, True),
           ("d(xn2)   dh1 W1 (B k-major)", 1024, 5504, bf, False, True),
-          ("FF-out   x2 = x1 + h2 W2^T", 1024, 2752, torch.float32, True, False)]
+          ("FF-out   x2 = x1 + h2 W2^T", 1024, 2752, torch.float32, True, False),
+          # 128x128 tiles (two workgroups per CU)
+          ("q-proj   -> bf16 (plain epilogue)", 512, 1024, bf, False, False),
+          ("q-proj   -> bf16 + l2-norm epilogue", 512, 1024, "qknorm", False, False),
+          ("d(o)     dx1 Wo (B k-major)", 512, 1024, bf, False, True),
+          ("to_out   x1 = x + o Wo^T", 1024, 512, torch.float32, True, False),
+          ("d(xn)    dq Wq (B k-major)", 1024, 512, bf, False, True),
+          ("d(x) kv  dkv Wkv (B k-major)", 1024, 128, bf, False, True)]
+# the last three: "one-tile grid" column = OMLM_GEMM_PERSIST=0 (wide tiles, the host's choice without the walk), "persistent" = the default
 reps = int(os.environ.get("REPS", "20"))
 lines = ["| GEMM (M = %d) | N | K | one-tile grid us (TFLOP/s) | persistent walk us (TFLOP/s) | ratio |" % M, "|---|---:|---:|---:|---:|---:|"]
 for name, N, K, odt, resid, bk in SHAPES:
     A = rnd(M, K)
     B = rnd(K, N) if bk else rnd(N, K)
+    qk = odt == "qknorm"
+    if qk:
+        odt = bf
+        scale, norms = torch.rand(64, device=dev) + 0.5, torch.empty(M, N // 64, device=dev)
     C = torch.empty(M, N, dtype=odt, device=dev)
     Cin = rnd(M, N, torch.float32) if resid else None
+    os.environ["OMLM_GEMM_TILE"] = "128x128" if "forced 128x128" in name else ""
     t = {"0": [], "1": []}
     outs = {}
     for rnd_i in range(2):
         for mode in ("0", "1"):
             os.environ["OMLM_GEMM_PERSIST"] = mode
-            fn = lambda: ops.gemm(A, B, C, M=M, N=N, K=K, b_kmajor=bk, Cin=Cin)
+            if qk:
+                fn = lambda: ops.gemm_qknorm(A, B, C, scale, norms, N // 64, M=M, N=N, K=K)
+            else:
+                fn = lambda: ops.gemm(A, B, C, M=M, N=N, K=K, b_kmajor=bk, Cin=Cin)
             fn(); fn(); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -48,6 +64,7 @@ for name, N, K, odt, resid, bk in SHAPES:
     lines.append(f"| {name} | {N} | {K} | {a:.1f} ({fl / a / 1e6:.0f}) | {b:.1f} ({fl / b / 1e6:.0f}) | {b / a:.3f} |" + ("" if same else " DIFFERENT RESULTS"))
     del A, B, C, Cin
 os.environ.pop("OMLM_GEMM_PERSIST", None)
+os.environ.pop("OMLM_GEMM_TILE", None)
 text = "\n".join(lines)
 print(text)
 if len(sys.argv) > 1:
