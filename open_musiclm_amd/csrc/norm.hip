@@ -57,6 +57,58 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restr
     }
 }
 
+// The same forward for D == 4 * LN_THREADS (d = 1024), round 4: gamma stays in registers (the general kernel re-reads it per row, behind the
+// reductions: a dependent round trip per row), the NEXT row is requested before this one is reduced (two register sets, rows alternate),
+// the two reductions use parity-double-buffered LDS slots (two barriers per row instead of four), and no memory instruction sits under a
+// column test or a thread test (the row's statistics are stored by every thread: same value, same address).  XC: cast copy of x wanted.
+// Same summation order as the general kernel: identical bits.
+template <typename T, bool XC>
+__global__ __launch_bounds__(LN_THREADS) void ln_fwd_row1_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                 T* __restrict__ y, T* __restrict__ xcast,
+                                                                 float* __restrict__ mean, float* __restrict__ rstd, int M, int ldy, float eps) {
+    constexpr int D = 4 * LN_THREADS, NW = LN_THREADS / 64;
+    __shared__ float red[2][2][NW];
+    const int c = threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, G = gridDim.x;
+    const float4 g = ((const float4*)gamma)[c];
+    auto process = [&](const float4 v, const int row, const int par) {
+        const float s = wave_sum((v.x + v.y) + (v.z + v.w));
+        if (lane == 0) red[par][0][wave] = s;
+        __syncthreads();
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += red[par][0][w];
+        const float mu = t / (float)D;
+        const float a = v.x - mu, b = v.y - mu, cc = v.z - mu, d = v.w - mu;
+        const float q = wave_sum((a * a + b * b) + (cc * cc + d * d));
+        if (lane == 0) red[par][1][wave] = q;
+        __syncthreads();                                           // parity `par` is rewritten two rows later, two barriers past its last read
+        float u = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) u += red[par][1][w];
+        const float rs = rsqrtf(u / (float)D + eps);
+        mean[row] = mu; rstd[row] = rs;
+        store4_from_float(y + (size_t)row * ldy + 4 * c, a * rs * g.x, b * rs * g.y, cc * rs * g.z, d * rs * g.w);
+        if constexpr (XC) store4_from_float(xcast + (size_t)row * D + 4 * c, v.x, v.y, v.z, v.w);
+    };
+    int row = blockIdx.x;
+    if (row >= M) return;
+    float4 A = ((const float4*)(x + (size_t)row * D))[c], B;
+#pragma unroll 1
+    for (;;) {
+        const int r1 = row + G;
+        B = ((const float4*)(x + (size_t)(r1 < M ? r1 : row) * D))[c];         // past the end: a redundant re-read instead of a conditional request
+        __builtin_amdgcn_sched_barrier(0);
+        process(A, row, 0);
+        if (r1 >= M) break;
+        const int r2 = r1 + G;
+        A = ((const float4*)(x + (size_t)(r2 < M ? r2 : r1) * D))[c];
+        __builtin_amdgcn_sched_barrier(0);
+        process(B, r1, 1);
+        if (r2 >= M) break;
+        row = r2;
+    }
+}
+
 // dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma ; dgamma += dy * xhat
 // A thread owns fixed columns, so dgamma is accumulated in registers over the block's rows and
 // flushed with one atomic per column per block.
@@ -141,6 +193,101 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const TDY* __restric
     }
 }
 
+// four consecutive elements as they sit in memory (fp32: 16 bytes, 16-bit: 8 bytes), converted on demand
+template <typename TT> struct Raw4;
+template <> struct Raw4<float> {
+    float4 v;
+    __device__ __forceinline__ void load(const float* p, int c) { v = ((const float4*)p)[c]; }
+    __device__ __forceinline__ void zero() { v = make_float4(0.f, 0.f, 0.f, 0.f); }
+    __device__ __forceinline__ float4 get() const { return v; }
+};
+template <> struct Raw4<h16_t> {
+    u32x2 w;
+    __device__ __forceinline__ void load(const h16_t* p, int c) { w = ((const u32x2*)p)[c]; }
+    __device__ __forceinline__ void zero() { w[0] = 0u; w[1] = 0u; }
+    __device__ __forceinline__ float4 get() const { return make_float4(h16_lo_to_f(w[0]), h16_hi_to_f(w[0]), h16_lo_to_f(w[1]), h16_hi_to_f(w[1])); }
+};
+
+// The same backward for D == 4 * LN_THREADS (one float4 per thread: d = 1024, every trunk LayerNorm of both model sizes), round 4.
+// The general kernel above makes each row a chain of dependent round trips: x / dy, then two block reductions of two barriers each,
+// then the residual-gradient row, then the store; its rate comes from 20 waves per CU hiding that (5.45 TB/s).  Here a row is one
+// thread's registers, so: the NEXT row's x / dy / residual pieces / statistics are requested before this row is reduced (a clamped row
+// index keeps the request unconditional), the two sums cross the waves through one parity-double-buffered LDS slot pair with ONE
+// barrier per row, and no memory instruction sits under a column test.
+// FL: bit 0 = dres, bit 1 = dres2, bit 2 = dxcast present.  Template switches, not pointer tests: a request or store behind a run-time test
+// is a second, shorter path, and hipcc's s_waitcnt count for "this row's pieces have landed" is taken from the shortest one -- with
+// the optional pieces really in flight that count stalls every row on the requests it has just issued (seen in the ISA: vmcnt(2) behind
+// four loads).
+template <typename T, typename TDY, int FL>
+__global__ __launch_bounds__(LN_THREADS) void ln_bwd_row1_kernel(const TDY* __restrict__ dy, const float* __restrict__ x,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd, const float* __restrict__ dres,
+                                                                 const T* __restrict__ dres2, float* __restrict__ dx, T* __restrict__ dxcast,
+                                                                 float* __restrict__ dgamma, float* __restrict__ part, int M, float dx_scale) {
+    constexpr int D = 4 * LN_THREADS, NW = LN_THREADS / 64;
+    __shared__ float red[2][NW][2];
+    const int c = threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, G = gridDim.x;
+    const float4 gm = ((const float4*)gamma)[c];
+    float4 dg = make_float4(0.f, 0.f, 0.f, 0.f);
+    // the 16-bit pieces stay RAW until they are used: a conversion next to the request is a wait next to the request
+    struct Row { float4 xv, d0; Raw4<TDY> dv; Raw4<T> d1; float mu, rs; };
+    auto request = [&](Row& R, int row) {
+        R.xv = ((const float4*)(x + (size_t)row * D))[c];
+        R.dv.load(dy + (size_t)row * D, c);
+        if constexpr (FL & 1) R.d0 = ((const float4*)(dres + (size_t)row * D))[c]; else R.d0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (FL & 2) R.d1.load(dres2 + (size_t)row * D, c); else R.d1.zero();
+        R.mu = mean[row]; R.rs = rstd[row];
+    };
+    auto process = [&](const Row& cur, const int row, const int it) {
+        const float mu = cur.mu, rs = cur.rs;
+        const float4 dv = cur.dv.get();
+        const float4 xh = make_float4((cur.xv.x - mu) * rs, (cur.xv.y - mu) * rs, (cur.xv.z - mu) * rs, (cur.xv.w - mu) * rs);
+        const float4 g = make_float4(dv.x * gm.x, dv.y * gm.y, dv.z * gm.z, dv.w * gm.w);
+        dg.x += dv.x * xh.x; dg.y += dv.y * xh.y; dg.z += dv.z * xh.z; dg.w += dv.w * xh.w;
+        float s1 = wave_sum((g.x + g.y) + (g.z + g.w));
+        float s2 = wave_sum((g.x * xh.x + g.y * xh.y) + (g.z * xh.z + g.w * xh.w));
+        if (lane == 0) { red[it & 1][wave][0] = s1; red[it & 1][wave][1] = s2; }
+        __syncthreads();                                           // the other parity's slots are rewritten only after the next barrier
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { t1 += red[it & 1][w][0]; t2 += red[it & 1][w][1]; }
+        const float m1 = t1 / (float)D, m2 = t2 / (float)D;
+        float4 r = make_float4(rs * (g.x - m1 - xh.x * m2), rs * (g.y - m1 - xh.y * m2), rs * (g.z - m1 - xh.z * m2), rs * (g.w - m1 - xh.w * m2));
+        r.x += cur.d0.x; r.y += cur.d0.y; r.z += cur.d0.z; r.w += cur.d0.w;
+        const float4 d1 = cur.d1.get();
+        r.x += d1.x; r.y += d1.y; r.z += d1.z; r.w += d1.w;
+        r.x *= dx_scale; r.y *= dx_scale; r.z *= dx_scale; r.w *= dx_scale;
+        ((float4*)(dx + (size_t)row * D))[c] = r;
+        if constexpr (FL & 4) store4_from_float(dxcast + (size_t)row * D + 4 * c, r.x, r.y, r.z, r.w);
+    };
+    int row = blockIdx.x;
+    if (row < M) {
+        // two register sets, rows alternate between them: a set is requested one whole row (reduction, barrier, stores) before it is used,
+        // and never copied -- a `cur = nxt` at the end of the trip is a wait for the requests of that same trip
+        Row A, B;
+        request(A, row);
+#pragma unroll 1
+        for (;;) {
+            const int r1 = row + G;
+            request(B, r1 < M ? r1 : row);                         // past the end: a redundant re-read instead of a conditional request
+            __builtin_amdgcn_sched_barrier(0);
+            process(A, row, 0);
+            if (r1 >= M) break;
+            const int r2 = r1 + G;
+            request(A, r2 < M ? r2 : r1);
+            __builtin_amdgcn_sched_barrier(0);
+            process(B, r1, 1);
+            if (r2 >= M) break;
+            row = r2;
+        }
+    }
+    if (part) ((float4*)(part + (size_t)blockIdx.x * D))[c] = dg;
+    else if (dgamma) {
+        unsafeAtomicAdd(dgamma + 4 * c + 0, dg.x); unsafeAtomicAdd(dgamma + 4 * c + 1, dg.y);
+        unsafeAtomicAdd(dgamma + 4 * c + 2, dg.z); unsafeAtomicAdd(dgamma + 4 * c + 3, dg.w);
+    }
+}
+
 static int ln_grid(int M) { return M < 2048 ? M : 2048; }
 
 #if !OMLM_FP16
@@ -156,6 +303,19 @@ extern "C" int OMLM_API(omlm_layernorm_fwd)(const float* x, const float* gamma, 
     OMLM_CHECK_ARG(D % 4 == 0 && D <= 4 * LN_THREADS * LN_MAXV, "D must be a multiple of 4 and <= 4096");
     OMLM_CHECK_ARG(ldy >= D, "ldy < D");
     dim3 grid(ln_grid(M)), block(LN_THREADS);
+#ifndef OMLM_LN_ROW1
+#define OMLM_LN_ROW1 1          /* 1: D == 1024 rows take the row-pair kernels (next-row prefetch, fewer barriers); 0: the general kernels */
+#endif
+    if (OMLM_LN_ROW1 && D == 4 * LN_THREADS && mean && rstd) {
+        if (out_dtype == 0) {
+            if (xcast) hipLaunchKernelGGL((ln_fwd_row1_kernel<float, true>), grid, block, 0, as_stream(stream), x, gamma, (float*)y, (float*)xcast, mean, rstd, M, ldy, eps);
+            else       hipLaunchKernelGGL((ln_fwd_row1_kernel<float, false>), grid, block, 0, as_stream(stream), x, gamma, (float*)y, (float*)xcast, mean, rstd, M, ldy, eps);
+        } else {
+            if (xcast) hipLaunchKernelGGL((ln_fwd_row1_kernel<h16_t, true>), grid, block, 0, as_stream(stream), x, gamma, (h16_t*)y, (h16_t*)xcast, mean, rstd, M, ldy, eps);
+            else       hipLaunchKernelGGL((ln_fwd_row1_kernel<h16_t, false>), grid, block, 0, as_stream(stream), x, gamma, (h16_t*)y, (h16_t*)xcast, mean, rstd, M, ldy, eps);
+        }
+        return omlm_post_launch("omlm_layernorm_fwd");
+    }
     if (out_dtype == 0)
         hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, block, 0, as_stream(stream), x, gamma, (float*)y, (float*)xcast, mean, rstd, M, D, ldy, eps);
     else
@@ -189,6 +349,23 @@ extern "C" int OMLM_API(omlm_layernorm_bwd2)(const void* dy, const float* x, con
     dim3 grid(blocks), block(LN_THREADS);
     float* part = two_level ? workspace : nullptr;
     OMLM_CHECK_ARG(dy_dtype == 0 || dy_dtype == 1, "dy_dtype: 0 = fp32, 1 = bf16, 2 = fp16 (same 16-bit type as the cast output)");
+#ifndef OMLM_LN_ROW1
+#define OMLM_LN_ROW1 1          /* 1: D == 1024 rows take ln_bwd_row1_kernel (next-row prefetch, one barrier per row) */
+#endif
+    if (OMLM_LN_ROW1 && D == 4 * LN_THREADS) {
+        const int fl = (dres ? 1 : 0) | (dres2 ? 2 : 0) | (dxcast ? 4 : 0);
+#define LN_ROW1(TT, TD, F) hipLaunchKernelGGL((ln_bwd_row1_kernel<TT, TD, F>), grid, block, 0, as_stream(stream), (const TD*)dy, x, gamma, mean, rstd, dres, \
+                                              (const TT*)dres2, dx, (TT*)dxcast, dgamma, part, M, dx_scale)
+#define LN_ROW1_FL(TT, TD) do { switch (fl) { case 0: LN_ROW1(TT, TD, 0); break; case 1: LN_ROW1(TT, TD, 1); break; case 2: LN_ROW1(TT, TD, 2); break; \
+        case 3: LN_ROW1(TT, TD, 3); break; case 4: LN_ROW1(TT, TD, 4); break; case 5: LN_ROW1(TT, TD, 5); break; case 6: LN_ROW1(TT, TD, 6); break; \
+        default: LN_ROW1(TT, TD, 7); break; } } while (0)
+        if (cast_dtype == 0 && dy_dtype == 0) LN_ROW1_FL(float, float);
+        else if (cast_dtype == 0)              LN_ROW1_FL(float, h16_t);
+        else if (dy_dtype == 0)                LN_ROW1_FL(h16_t, float);
+        else                                   LN_ROW1_FL(h16_t, h16_t);
+#undef LN_ROW1_FL
+#undef LN_ROW1
+    } else
     if (cast_dtype == 0 && dy_dtype == 0)
         hipLaunchKernelGGL((ln_bwd_kernel<float, float>), grid, block, 0, as_stream(stream), (const float*)dy, x, gamma, mean, rstd, dres, (const float*)dres2, dx, (float*)dxcast, dgamma, part, M, D, dx_scale);
     else if (cast_dtype == 0)
@@ -414,10 +591,14 @@ __global__ __launch_bounds__(256) void qk_norm_bwd2_mixed_kernel(const float* __
 // holds elements 8 (l & 7) .. + 7 of vector (l >> 3), a wave-instruction reads 1 KiB of q / 2 x 1 KiB of dq contiguously.  Whole units
 // run two at a time without a single condition (counted waits); the ragged tail and the k | v rows (1 / (H + 1) of the bytes) take
 // the predicated body.
+#ifndef QKB2_THREADS
+#define QKB2_THREADS 1024       /* 16 waves per workgroup: a quarter of the atomics of 256-thread workgroups at the same waves per CU (1024 workgroups x 128 atomics onto 128
+                                   addresses were ~10 us of serialised tail) */
+#endif
 struct QkUnit { u32x4 y; float4 d0, d1; float nr; };
 
 template <typename T>
-__global__ __launch_bounds__(256) void qk_norm_bwd2_kernel(const float* __restrict__ dq, const float* __restrict__ dk,
+__global__ __launch_bounds__(QKB2_THREADS) void qk_norm_bwd2_kernel(const float* __restrict__ dq, const float* __restrict__ dk,
                                                            const float* __restrict__ dv, const T* __restrict__ q, const T* __restrict__ k,
                                                            const float* __restrict__ qn, const float* __restrict__ kn,
                                                            const float* __restrict__ q_scale, const float* __restrict__ k_scale,
@@ -425,7 +606,8 @@ __global__ __launch_bounds__(256) void qk_norm_bwd2_kernel(const float* __restri
                                                            float* __restrict__ dk_scale, int M, int H) {
     static_assert(sizeof(T) == 2, "16-bit operands");
     const int lane = threadIdx.x & 63, slot = lane >> 3, d0 = 8 * (lane & 7);
-    const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    constexpr int NW = QKB2_THREADS / 64;
+    const int wave_g = blockIdx.x * NW + (threadIdx.x >> 6), nwaves = gridDim.x * NW;
     auto rcp0 = [](float v) { return v != 0.f ? 1.0f / v : 0.f; };
     float sc[8], sci[8], acc[8];
     auto take_scale = [&](const float* p) {
@@ -464,8 +646,8 @@ __global__ __launch_bounds__(256) void qk_norm_bwd2_kernel(const float* __restri
             for (int e = 0; e < 8; ++e) acc[e] += dy[e] * xh[e];
         }
     };
-    __shared__ float red[4][64];
-    auto flush = [&](float* dscale) {                       // this workgroup's share of d(scale): 8 slots -> 4 waves -> 64 atomics
+    __shared__ float red[NW][64];
+    auto flush = [&](float* dscale) {                       // this workgroup's share of d(scale): 8 slots -> NW waves -> 64 atomics
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float v = acc[e];
@@ -473,7 +655,12 @@ __global__ __launch_bounds__(256) void qk_norm_bwd2_kernel(const float* __restri
             if (lane < 8) red[threadIdx.x >> 6][d0 + e] = v;
         }
         __syncthreads();
-        if (threadIdx.x < 64) unsafeAtomicAdd(dscale + lane, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+        if (threadIdx.x < 64) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t += red[w][lane];
+            unsafeAtomicAdd(dscale + lane, t);
+        }
         __syncthreads();
     };
 
@@ -542,12 +729,12 @@ extern "C" int OMLM_API(omlm_qk_norm_bwd2)(const float* dq, const float* dk, con
 #define QKB2_STREAM 1           /* 1: the stream form (qk_norm_bwd2_kernel), 0: the mixed-vector form of round 4's first half */
 #endif
 #ifndef QKB2_BLOCKS
-#define QKB2_BLOCKS 1024        /* workgroups of the stream form (4 waves each; 128 atomics per workgroup at the end) */
+#define QKB2_BLOCKS 256         /* workgroups of the stream form (QKB2_THREADS / 64 waves each; 128 atomics per workgroup at the end) */
 #endif
 #if QKB2_STREAM
-    long long want = ((long long)M * H / 8 + 7) / 8;               // ~2 units per wave at least
+    long long want = ((long long)M * H / 8 + 2 * (QKB2_THREADS / 64) - 1) / (2 * (QKB2_THREADS / 64));      // ~2 units per wave at least
     int blocks = want > QKB2_BLOCKS ? QKB2_BLOCKS : (want < 1 ? 1 : (int)want);
-    hipLaunchKernelGGL(qk_norm_bwd2_kernel<h16_t>, dim3(blocks), dim3(256), 0, as_stream(stream), dq, dk, dv, (const h16_t*)q, (const h16_t*)k, qn, kn,
+    hipLaunchKernelGGL(qk_norm_bwd2_kernel<h16_t>, dim3(blocks), dim3(QKB2_THREADS), 0, as_stream(stream), dq, dk, dv, (const h16_t*)q, (const h16_t*)k, qn, kn,
                        q_scale, k_scale, (h16_t*)dq_raw, (h16_t*)dkv_raw, dq_scale, dk_scale, M, H);
 #else
     int blocks = (int)((nvec + 15) / 16); if (blocks > QKB_BLOCKS) blocks = QKB_BLOCKS;

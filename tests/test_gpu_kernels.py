@@ -344,9 +344,9 @@ def test_cast_pad_group(ops, dev, dtype):
         assert float(taps[:, F:Fp].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
-def test_layernorm_fwd_bwd(ops, dev, dtype):
-    M, D = 333, 1024
+@pytest.mark.parametrize("M,D", [(333, 1024), (6700, 1024), (333, 768)])       # one row per workgroup; 3-4 rows per workgroup (the row-pair walk of the
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])   # d = 1024 backward: both register sets, both LDS parities); the general kernel
+def test_layernorm_fwd_bwd(ops, dev, dtype, M, D):
     g = torch.Generator().manual_seed(1)
     x = (torch.randn(M, D, generator=g) * 3 + 1).to(dev)
     gamma = (1 + 0.1 * torch.randn(D, generator=g)).to(dev)
@@ -368,7 +368,7 @@ def test_layernorm_fwd_bwd(ops, dev, dtype):
     ops.layernorm_bwd(dy, x, gamma, mean, rstd, dres, dx, dxc, dgamma, dx_scale=0.1)
     e_dx = relerr(dx, 0.1 * (xr.grad + dres.double()))
     e_dg = relerr(dgamma, gr.grad)
-    report(f"layernorm[{dtype}]", y=e_y, xcast=e_c, dx=e_dx, dgamma=e_dg, dxcast=relerr(dxc, dx))
+    report(f"layernorm[{dtype},{M},{D}]", y=e_y, xcast=e_c, dx=e_dx, dgamma=e_dg, dxcast=relerr(dxc, dx))
     assert e_y < tol and e_c < tol and e_dx < 1e-5 and e_dg < 1e-4 and relerr(dxc, dx) < tol
     if dtype in (torch.bfloat16, torch.float16):
         # dy handed over in the 16-bit operand type (what the input-gradient GEMM's epilogue writes in bf16 / fp16 mode): exact for the rounded values
@@ -378,8 +378,11 @@ def test_layernorm_fwd_bwd(ops, dev, dtype):
         dx2, dg2 = torch.empty(M, D, device=dev), torch.zeros(D, device=dev)
         ops.layernorm_bwd(dyb, x, gamma, mean, rstd, dres, dx2, None, dg2, dx_scale=0.1)
         e2, eg2 = relerr(dx2, 0.1 * (xr2.grad + dres.double())), relerr(dg2, gr2.grad)
-        report(f"layernorm[{dtype} dy]", dx=e2, dgamma=eg2)
+        report(f"layernorm[{dtype},{M},{D} dy]", dx=e2, dgamma=eg2)
         assert e2 < 1e-5 and eg2 < 1e-4
+    dx0, dg0 = torch.empty(M, D, device=dev), torch.zeros(D, device=dev)        # no incoming residual gradient (the final LayerNorm of the trunk)
+    ops.layernorm_bwd(dy, x, gamma, mean, rstd, None, dx0, None, dg0)
+    assert relerr(dx0, xr.grad) < 1e-5 and relerr(dg0, gr.grad) < 1e-4
     # a second residual-gradient term in the cast type (omlm_layernorm_bwd2: the K/V projection's input gradient), with and without a
     # cast output: exact for the values handed over
     d2 = torch.randn(M, D, generator=g).to(dev).to(dtype)
@@ -388,7 +391,7 @@ def test_layernorm_fwd_bwd(ops, dev, dtype):
         dxc3 = torch.empty(M, D, device=dev, dtype=dtype) if with_cast else None
         ops.layernorm_bwd(dy, x, gamma, mean, rstd, dres, dx3, dxc3, dg3, dx_scale=0.1, dres2=d2)
         e3 = relerr(dx3, 0.1 * (xr.grad + dres.double() + d2.double()))
-        report(f"layernorm[{dtype} dres2 cast={with_cast}]", dx=e3)
+        report(f"layernorm[{dtype},{M},{D} dres2 cast={with_cast}]", dx=e3)
         assert e3 < 1e-5 and relerr(dg3, gr.grad) < 1e-4
         if with_cast:
             assert relerr(dxc3, dx3) < tol

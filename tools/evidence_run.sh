@@ -9,6 +9,8 @@ OMLM_BENCH_GEMM_TABLE=$out/gemm_calls.md timeout 900 python bench.py > $out/benc
 ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pf && cd "$ROOT" && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/pf -o rf -- python bench.py --steps 5 --warmup 2 --no-decode --no-cpu-baseline --no-legs --no-graph > $out/prof.log 2>&1 )
 python tools/prof_summary.py stats /tmp/pf/rf_results.db $out/kernel_stats.md --steps 5 > /dev/null
 python tools/prof_summary.py shapes /tmp/pf/rf_results.db $out/gemm_shapes.md gemm > /dev/null
+if [ -z "$EVIDENCE_LIGHT" ]; then      # EVIDENCE_LIGHT=1: without the PMC traffic passes and the attention / decode lib_ab lines (~4 GPU-minutes)
 timeout 1300 tools/pmc_gemm_traffic.sh > $out/gemm_traffic.log 2>&1; cp gpurun_out/gemm_traffic.json gpurun_out/gemm_traffic.md $out/ 2>/dev/null
 timeout 120 tools/lib_ab open_musiclm_amd/libomlm_hip.so open_musiclm_amd/libomlm_hip.so -- attn attn_large attn32 decode 2>&1 | grep -v "^  d" > $out/lib_ab.log
 tail -4 $out/gemm_traffic.log | cut -c1-400
+fi
