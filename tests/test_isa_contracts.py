@@ -1,0 +1,111 @@
+"""CPU: what the round-4 kernels rely on hipcc to emit, checked in the gfx950 ISA (hipcc cross-compiles without a GPU; ~20 s).
+
+The second half of round 4 was won by reading `s_waitcnt` placement: a memory instruction under a row / kind / pointer test makes hipcc's
+wait-count pass assume the SHORTEST path ("nothing was issued behind this load"), and the wait meant for one load becomes a full drain of
+the stores before it.  These tests pin the emitted form of the kernels that were rebuilt around that:
+  * the ConvFeedForward forward's steady-state loop waits with counts that leave the batch's stores in flight, without spills;
+  * the persistent GEMM walk (no-residual instantiation) contains no compiler-placed vector-memory wait at all -- only the counted /
+    full waits written in its source -- and fits its registers;
+  * the q/k-norm backward requests both units of a trip before its first wait.
+A compiler that regresses one of these still produces correct code; the kernels would just be back at their old speed.
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CS = os.path.join(ROOT, "open_musiclm_amd", "csrc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-Wno-unused-value", "-Wno-inline-asm", "-S", "--cuda-device-only"]
+
+pytestmark = pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+
+
+def compile_asm(tmp_path, src, *defs):
+    out = str(tmp_path / (os.path.basename(src) + ".s"))
+    subprocess.run(["hipcc", *FLAGS, *defs, os.path.join(CS, src), "-o", out], check=True, stderr=subprocess.DEVNULL, cwd=CS, timeout=600)
+    return open(out).read().split("\n")
+
+
+def kernel_body(lines, name_re):
+    """(instructions of the first kernel whose mangled name matches, its .vgpr_spill_count / .sgpr_spill_count / .vgpr_count)"""
+    start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w*:", l) and re.search(name_re, l))
+    sym = lines[start].split(":")[0]
+    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    meta = {}
+    at = next(i for i, l in enumerate(lines) if l.strip().startswith(".name:") and sym in l)
+    for l in lines[at:at + 40]:
+        m = re.match(r"\s*\.(vgpr_spill_count|sgpr_spill_count|vgpr_count):\s*(\d+)", l)
+        if m:
+            meta[m.group(1)] = int(m.group(2))
+    return lines[start:end + 1], meta
+
+
+def loop_at(body, head):
+    """instructions of the loop whose header label sits at body[head]: every basic block hipcc annotates as belonging to it (the
+    latch of a rotated loop is laid out BEFORE its header)"""
+    label = body[head].split(":")[0].strip()                     # .LBB26_18
+    tag = "Header=" + label[2:]                                  # "in Loop: Header=BB26_18"
+    out, inside = [], False
+    for l in body:
+        if re.match(r"^(\.LBB\d+_\d+:|; %bb\.\d+:)", l):
+            inside = l.startswith(label + ":") or tag in l
+        elif inside:
+            out.append(l)
+    assert out, f"no blocks of loop {label}"
+    return out
+
+
+def vmcnt(line):
+    m = re.search(r"s_waitcnt[^;]*vmcnt\((\d+)\)", line)
+    return int(m.group(1)) if m else None
+
+
+def test_ffmid_forward_steady_state_loop_keeps_its_stores_in_flight(tmp_path):
+    lines = compile_asm(tmp_path, "ffmid2.hip")
+    body, meta = kernel_body(lines, r"ffmid2_fwd_kernelIDF16bLi384ELb1")          # bf16 operands, 384-thread instantiation, training call
+    assert meta["vgpr_spill_count"] == 0 and meta["sgpr_spill_count"] <= 2 and meta["vgpr_count"] <= 256, meta
+    heads = [i for i, l in enumerate(body) if "Loop Header" in l]
+    assert len(heads) >= 2, "steady-state loop + general loop expected"
+    loop = loop_at(body, heads[0])
+    waits = [vmcnt(l) for l in loop if vmcnt(l) is not None]
+    stores = sum(1 for l in loop if "global_store" in l)
+    loads = sum(1 for l in loop if "global_load" in l)
+    assert loads == 8 and stores >= 12, (loads, stores)                             # 4 rows x (value, gate) requests; 4 x (bits, h2, gh) + statistics
+    assert waits and min(waits) >= 12, f"a wait of the steady-state loop drains the batch's stores: {waits}"
+
+
+def test_persistent_gemm_walk_has_only_its_own_waits(tmp_path):
+    lines = compile_asm(tmp_path, "gemm.hip", "-DOMLM_ISA_ONLY")
+    body, meta = kernel_body(lines, r"gemm_bf16_tile_persist_kernelILi256ELi256ELi128ELi64ELb0ELb0EDF16bLb0")     # bf16 out, no residual
+    assert meta["vgpr_spill_count"] == 0 and meta["vgpr_count"] <= 256, meta
+    in_asm, own, foreign = False, [], []
+    for l in body:
+        if "#ASMSTART" in l:
+            in_asm = True
+        elif "#ASMEND" in l:
+            in_asm = False
+        elif vmcnt(l) is not None:
+            (own if in_asm else foreign).append(l.strip())
+    assert not foreign, f"compiler-placed vector-memory waits in the walk (they drain the epilogue's stores): {foreign}"
+    assert any(vmcnt(l) == 16 for l in own), own                                    # iteration 0 behind a full tile: pieces only (16 stores stay in flight)
+    assert sum(1 for l in body if "v_mfma_f32_32x32x16" in l) >= 40
+    # the residual-adding instantiation fits too (its epilogue keeps ONE residual register set)
+    body2, meta2 = kernel_body(lines, r"gemm_bf16_tile_persist_kernelILi256ELi256ELi128ELi64ELb0ELb0EfLb1")
+    assert meta2["vgpr_spill_count"] == 0 and meta2["vgpr_count"] <= 256, meta2
+
+
+def test_qknorm_backward_requests_a_whole_trip_before_its_first_wait(tmp_path):
+    lines = compile_asm(tmp_path, "norm.hip")
+    body, meta = kernel_body(lines, r"qk_norm_bwd2_kernelIDF16b")
+    assert meta["vgpr_spill_count"] == 0 and meta["vgpr_count"] <= 128, meta         # 1024-thread workgroups: four waves per SIMD
+    head = next(i for i, l in enumerate(body) if "Loop Header" in l)
+    n = 0
+    for l in loop_at(body, head):
+        if "global_load" in l:
+            n += 1
+        elif vmcnt(l) is not None:
+            break
+    assert n == 8, f"{n} requests before the first wait of the q stream's loop (two units x y, dy, dy, norm = 8)"
