@@ -17,13 +17,15 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             n = r["Kernel_Name"]
             if "gemm" not in n: continue
             m = re.search(r"<(\d+), (\d+), \d+, \d+, (true|false), (true|false), (\w+)", n) or re.search(r"ILi(\d+)ELi(\d+)ELi\d+ELi\d+ELb(\d)ELb(\d)E(DF16b|f)", n)
+            if "wgrad_group" in n: m = None; n = "gemm_wgrad_group_kernel (all weight gradients of a backward)"
             key = ("x".join(m.groups()[:2]) + (" A-kmajor" if m.group(3) in ("1", "true") else "") + (" B-kmajor" if m.group(4) in ("1", "true") else "") +
-                   (" bf16out" if m.group(5) in ("DF16b", "bf16") else " f32out")) if m else n[:40]
+                   (" bf16out" if m.group(5) in ("DF16b", "bf16") else " f32out") + (" walk" if "persist" in n else "")) if m else n[:70]
             agg[(key, r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
             agg[(key, r["Grid_Size"])]["dur_" + c].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-# steps in the trace: the FF-in forward (3058 workgroups of 512 threads) is launched once per layer (6) per step
-ffin = [v for (k, g), v in agg.items() if g == str(3058 * 512)]
-steps = len(ffin[0]["FETCH_SIZE"]) / 6.0 if ffin else 5.0
+# steps in the trace: the grouped weight-gradient kernel is launched once per micro-step (the FF-in grid no longer identifies a launch:
+# the wide tiles run as a persistent walk of #CUs workgroups since round 4)
+wg = [v for (k, g), v in agg.items() if "wgrad_group" in k]
+steps = float(sum(len(v["FETCH_SIZE"]) for v in wg)) if wg else 3.0
 lines = ["| tile / layout | grid | launches | fetch MB (x2-corrected) | write MB | avg us |", "|---|---:|---:|---:|---:|---:|"]
 tot_f = tot_w = 0.0
 for (k, grid), d in sorted(agg.items(), key=lambda kv: -sum(kv[1].get("dur_FETCH_SIZE", [0]))):
