@@ -18,6 +18,12 @@
  *     uses ONE 16-bit type: bf16 operands give fp32 or bf16 outputs, fp16 operands fp32 or fp16 outputs.  The library holds
  *     a bf16 and an fp16 copy of every 16-bit kernel; these entry points dispatch on the code;
  *   - row-major everywhere; "ld" = row pitch in elements.
+ *
+ * Not in this library: the data-parallel gradient exchange.  SURVEY.md 8b sketches an `omlm_allreduce_flat` export; it does not exist --
+ * the exchange is ONE torch.distributed (backend "nccl" = RCCL over xGMI) SUM all-reduce of the flat fp32 gradient buffer per optimizer
+ * step, issued by the Python host between the captured micro-step and omlm_adamw_clip_step (open_musiclm_amd/parallel.py:
+ * DataParallel.allreduce_sum_; the reference: accelerate / DDP bucketed all-reduces on every micro-batch backward, trainer.py:154-155,439).
+ * A collective is a host-side call on a communicator the host owns; nothing of it would gain from crossing this C ABI.
  */
 #ifndef OMLM_H
 #define OMLM_H
