@@ -183,9 +183,9 @@ class SamplingLoop:
 
     All per-step state (row index, step counter, uniforms, id history) is device resident, so the cycle of each quantizer
     phase can be captured into a HIP graph (``use_graph=True``: after one eager cycle per phase, the remaining ids are graph
-    replays, ~1 host launch per id instead of ~35).  Measured on MI355X the step is GPU-bound (≈35 dependent ~9 us kernels)
-    and graph replay is ~5 % SLOWER than back-to-back eager launches (2.65 k vs 2.81 k ids/s at B = 1), so eager is the
-    default; the graph path is kept (and tested) for hosts that cannot keep up."""
+    replays, ~1 host launch per id instead of ~32).  Measured on MI355X the step is GPU-bound (32 dependent kernels per id) and
+    graph replay is no faster than back-to-back eager launches, so eager is the default; the graph path
+    is kept (and tested) for hosts that cannot keep up."""
 
     def __init__(self, dec: CachedDecoder, first_logits: torch.Tensor, uniforms: torch.Tensor, n0: int, n_new: int, topk: int,
                  temperature: float, forbid_by_phase: Sequence[bool], use_graph: bool = True):

@@ -32,8 +32,12 @@ class DataParallel:
                 # gloo exchange) shares devices round-robin -- RCCL itself refuses two ranks on one GPU
                 torch.cuda.set_device(self.local_rank % max(torch.cuda.device_count(), 1))
             backend = backend or os.environ.get("OMLM_DP_BACKEND")
-            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", self.world_size))
-            self.shared_gpu = bool(use_cuda and local_world > torch.cuda.device_count())
+            # ranks share a GPU only on EVIDENCE: the launcher says so (LOCAL_WORLD_SIZE above the visible devices) or this rank's
+            # LOCAL_RANK has no device of its own.  WORLD_SIZE alone proves nothing: a multi-node launch that exports only RANK /
+            # WORLD_SIZE / LOCAL_RANK (srun, mpirun) has WORLD_SIZE = nodes x GPUs and must stay on RCCL.
+            ndev = torch.cuda.device_count() if use_cuda else 0
+            lws = os.environ.get("LOCAL_WORLD_SIZE")
+            self.shared_gpu = bool(use_cuda and ((lws is not None and int(lws) > ndev) or self.local_rank >= ndev))
             if backend is None:
                 backend = "nccl" if use_cuda else "gloo"
                 if self.shared_gpu:

@@ -159,11 +159,16 @@ def zero_mean_unit_var_norm(x):
 
 
 def prepare_audio(data, sample_hz, target_sample_hz, normalize=True, target_length_seconds=None):
-    """utils.py:157-166.  Needs torchaudio's resampler (audio front-end, outside the hot path)."""
-    try:
-        from torchaudio.functional import resample
-    except ImportError as e:  # pragma: no cover
-        raise ImportError("prepare_audio needs torchaudio (audio front-end is outside the MI355X hot path)") from e
+    """utils.py:157-166.  Resampling needs torchaudio (audio front-end, outside the hot path); equal rates need nothing
+    (torchaudio.functional.resample returns its input unchanged when orig_freq == new_freq)."""
+    if int(sample_hz) == int(target_sample_hz):
+        def resample(x, *_a, **_k):
+            return x
+    else:
+        try:
+            from torchaudio.functional import resample
+        except ImportError as e:  # pragma: no cover
+            raise ImportError("prepare_audio needs torchaudio to resample (audio front-end is outside the MI355X hot path)") from e
     if data.shape[0] > 1:
         data = torch.mean(data, dim=0).unsqueeze(0)
     if normalize:

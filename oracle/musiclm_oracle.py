@@ -23,12 +23,14 @@ key list in SURVEY.md §8b), the arithmetic of
   ``MiniBatchKMeans.predict``).
 
 Parity pinning: the transformer functions are pinned against the reference's
-own modules by ``oracle/make_golden.py`` (which imports /root/reference in the
-build container and writes ``tests/golden/*.npz``).  The RVQ function has no
-reference fixture and the third-party library is not installed:
-**RVQ parity unpinned** (it is pinned only against its own stated definition:
-fp32, squared distance accumulated as sum((r-e)^2) in index order, ties ->
-lowest index).  The k-means assign is pinned against sklearn's ``predict``.
+own modules by ``oracle/make_golden.py`` / ``make_golden_r2.py`` / ``make_golden_r5.py``
+(which import /root/reference in the build container and write ``tests/golden/*.npz``).
+The RVQ nearest-code step lives in the un-vendored, un-installed vector-quantize-pytorch:
+no reference-held vector can exist offline, so it restates the library's published
+``argmax(-cdist(x, embed))`` form (``cdist_form`` below) and is pinned bit for bit against
+``torch.cdist`` itself (tests/golden/rvq_cdist_pin.npz) -- **pinned to the distance form,
+not to the library**.  RVQ *fitting* (``rvq_fit_step``): **parity unpinned**.
+The k-means assign is pinned against sklearn's ``predict``.
 
 All functions run in whatever dtype the state dict / inputs carry (fp32 for
 parity with the reference, fp64 for a tighter yardstick).  They are written
@@ -451,11 +453,15 @@ def mask_out_after_eos(t: Tensor, eos_id: int, keep_eos: bool) -> Tensor:
 
 def generate(sd: Dict[str, Tensor], spec: ModelSpec, conditioning_ids: Sequence[Tensor],
              max_time_steps: int, uniforms: Tensor, pred_ids: Optional[Tensor] = None,
-             temperature: float = 1.0, filter_thres: float = 0.9) -> Tensor:
+             temperature: float = 1.0, filter_thres: float = 0.9,
+             allow_eos_in_output: bool = False, include_eos_in_output: bool = False) -> Tensor:
     """TokenConditionedTransformerWrapper.generate open_musiclm.py:253-326.
 
     Full re-forward per sampled id (no KV cache), exactly like the reference.
     ``uniforms[step]`` is the [B, V+1] uniform draw of sampling step ``step``.
+    allow_eos_in_output: the eos logit survives on the LAST quantizer of a time step only (:309-313); sampling goes on after an
+    eos (the loop never stops early: a sampled eos id is embedded like any id, with the offset aliasing of :126-130), and
+    everything behind the first eos -- the eos itself too unless include_eos_in_output -- leaves as -1 (:321-322, utils.py:86-93).
     """
     b = conditioning_ids[0].shape[0]
     cond = [append_eos(t.reshape(b, -1).long(), e) for t, e in zip(conditioning_ids, spec.eos_ids)]
@@ -469,11 +475,12 @@ def generate(sd: Dict[str, Tensor], spec: ModelSpec, conditioning_ids: Sequence[
         for _ind in range(q):
             lg = token_conditioned_forward(sd, spec, cond + [sampled], None, only_final=True)[-1]
             last = lg[:, -1].clone()
-            last[:, -1] = float("-inf")                                       # :311-313 (eos never allowed here)
+            if not allow_eos_in_output or _ind != q - 1:
+                last[:, -1] = float("-inf")                                   # :309-313
             nxt = gumbel_argmax(top_k_filter(last, filter_thres), uniforms[step], temperature)
             sampled = torch.cat([sampled, nxt[:, None]], dim=-1)
             step += 1
-    sampled = mask_out_after_eos(sampled, spec.eos_ids[-1], keep_eos=False)
+    sampled = mask_out_after_eos(sampled, spec.eos_ids[-1], keep_eos=include_eos_in_output)
     return sampled.reshape(b, -1, q)
 
 

@@ -361,7 +361,8 @@ def test_reference_training_scripts_import_against_this_package(script):
     get every name they import from it; `--help` stops before any GPU work."""
     import subprocess
     import sys
-    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    # (the reference mount stays untouched: no __pycache__ next to its scripts)
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), PYTHONDONTWRITEBYTECODE="1")
     probe = ("import runpy, sys, open_musiclm; assert open_musiclm.__file__.startswith(%r), open_musiclm.__file__; "
              "sys.argv = [%r, '--help']; runpy.run_path(%r, run_name='__main__')") % (
                  ROOT, script, f"/root/reference/scripts/{script}.py")
@@ -714,6 +715,17 @@ def test_data_parallel_backend_choice_and_shared_gpu_flag(monkeypatch):
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
     dp = parallel.DataParallel(device=torch.device("cuda", 0))
     assert seen["backend"] == "gloo" and seen["device"] == 0 and dp.shared_gpu           # two ranks on one visible GPU: dry run over gloo
+    # a multi-node launch without LOCAL_WORLD_SIZE (srun / mpirun export RANK, WORLD_SIZE, LOCAL_RANK only): 2 nodes x 8 GPUs is NOT a dry run
+    monkeypatch.delenv("LOCAL_WORLD_SIZE")
+    monkeypatch.setenv("WORLD_SIZE", "16"); monkeypatch.setenv("RANK", "11"); monkeypatch.setenv("LOCAL_RANK", "3")
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    dp = parallel.DataParallel(device=torch.device("cuda", 3))
+    assert seen["backend"] == "nccl" and seen["device"] == 3 and not dp.shared_gpu
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)                            # ... but a LOCAL_RANK without a device of its own is evidence
+    dp = parallel.DataParallel(device=torch.device("cuda", 1))
+    assert seen["backend"] == "gloo" and dp.shared_gpu
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "2"); monkeypatch.setenv("WORLD_SIZE", "2"); monkeypatch.setenv("RANK", "1"); monkeypatch.setenv("LOCAL_RANK", "1")
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
     monkeypatch.setenv("OMLM_DP_BACKEND", "nccl")
     dp = parallel.DataParallel(device=torch.device("cuda", 0))
     assert seen["backend"] == "nccl" and dp.shared_gpu                                   # explicit choice is honoured (RCCL itself will refuse)

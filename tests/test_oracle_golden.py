@@ -75,6 +75,27 @@ def test_oracle_matches_reference_generate(golden_dir):
     assert np.array_equal(out2.numpy(), z["generated_primed"])
 
 
+def test_oracle_matches_reference_generate_with_eos_flags(golden_dir):
+    """open_musiclm.py:309-313 (eos allowed on the last quantizer of a time step only), :321-322 (masking behind the first eos, eos kept
+    or not): the reference's outputs for allow_eos_in_output=True x include_eos_in_output False / True and for the default flags on
+    the SAME recorded draws (oracle/make_golden_r5.py)."""
+    z = np.load(os.path.join(golden_dir, "generate_eos.npz"))
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd.")}
+    spec = spec_from("coarse", ast.literal_eval(str(z["meta.kwargs"])), sd)
+    cond = [torch.from_numpy(z["cond.0"]), torch.from_numpy(z["cond.1"])]
+    kw = dict(temperature=float(z["temperature"]), filter_thres=float(z["filter_thres"]))
+    U = torch.from_numpy(z["uniforms"])
+    eos = spec.eos_ids[-1]
+    assert (z["generated_allow_include"] == eos).any() and (z["generated_allow"] == -1).any() and not (z["generated_default"] == eos).any()
+    with torch.no_grad():
+        a = O.generate(sd, spec, cond, int(z["max_time_steps"]), U, allow_eos_in_output=True, **kw)
+        b = O.generate(sd, spec, cond, int(z["max_time_steps"]), U, allow_eos_in_output=True, include_eos_in_output=True, **kw)
+        c = O.generate(sd, spec, cond, int(z["max_time_steps"]), U, **kw)
+    assert np.array_equal(a.numpy(), z["generated_allow"])
+    assert np.array_equal(b.numpy(), z["generated_allow_include"])
+    assert np.array_equal(c.numpy(), z["generated_default"])
+
+
 def test_oracle_kmeans_matches_sklearn_fixture(golden_dir):
     z = np.load(os.path.join(golden_dir, "kmeans_assign.npz"))
     assert np.array_equal(O.kmeans_assign(z["x"], z["centroids"]), z["assign"])
