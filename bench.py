@@ -203,6 +203,17 @@ class TrainLeg:
         torch.cuda.empty_cache()
 
 
+def gemm_source_sha16():
+    """Identity of the GEMM kernels a committed traffic measurement belongs to: the first 16 hex digits of sha256 over csrc/gemm.hip +
+    csrc/common.h (tools/pmc_gemm_traffic.sh records it; roofline.traffic is only attached while it matches the tree)."""
+    import hashlib
+    m = hashlib.sha256()
+    for f in ("gemm.hip", "common.h"):
+        with open(os.path.join(ROOT, "open_musiclm_amd", "csrc", f), "rb") as fh:
+            m.update(fh.read())
+    return m.hexdigest()[:16]
+
+
 def cpu_baseline(progress_fn):
     """The oracle (port of the reference arithmetic, torch CPU kernels) on this box's host cores: one warm-up + median
     of 3 full micro-steps (forward + backward + global-norm clip + AdamW) at B = 2, N = 1116, fp32: a bounded
@@ -425,6 +436,11 @@ def main():
             try:
                 detail = json.load(open(tpath))
                 traffic = detail["fetch_bytes"] + detail["write_bytes"]
+                if detail.get("gemm_source_sha16") != gemm_source_sha16():
+                    # the GEMM kernels changed since the PMC passes were taken: a stale byte count is worse than none
+                    progress(f"profiles/gemm_traffic.json belongs to GEMM sources {detail.get('gemm_source_sha16')}, the tree has "
+                             f"{gemm_source_sha16()}: roofline.traffic left null (re-run tools/pmc_gemm_traffic.sh)")
+                    traffic = detail = None
             except Exception:
                 traffic = detail = None
         out["roofline"] = main_leg.gemm_roofline(args.warmup + args.steps, traffic)

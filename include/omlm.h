@@ -176,8 +176,9 @@ int omlm_adamw_clip_step(float* p, float* g, float* m, float* v, void* p16, long
                          float gscale, const float* gnorm_sq, float max_norm, int decoupled, int zero_grad, int p16_dtype,
                          const float* ls_state, void* stream);
 /* p16 (optional): 16-bit shadow of p in p16_dtype (1 bf16 / 2 fp16); a non-finite *gnorm_sq skips the update (gradients still cleared).
-   ls_state (optional, precision "fp16"): 4 floats on the device {loss scale, good steps since its last change, skipped steps, applied
-   steps}: gradients are divided by ls_state[0] and the bias corrections use step = ls_state[3] + 1 instead of `step`. */
+   ls_state (optional, precision "fp16"): 5 floats on the device {loss scale, good steps since its last change, skipped steps, applied
+   steps, scale of the last finished step}: gradients are divided by ls_state[0] and the bias corrections use step = ls_state[3] + 1
+   instead of `step`; omlm_loss_scale_update copies ls_state[0] to ls_state[4] before it halves / doubles the scale. */
 /* after the last parameter group of a step: non-finite *gnorm_sq -> scale = max(scale * backoff, scale_min), skipped += 1; else applied += 1
    and after `interval` consecutive good steps scale = min(scale * growth, scale_max).  (No reference counterpart: the reference trains in
    fp32, trainer.py:444-447; this is torch.cuda.amp.GradScaler's rule kept on the device so that the captured step never reads the norm.) */

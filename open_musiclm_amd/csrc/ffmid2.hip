@@ -159,6 +159,11 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
     // so no memory instruction of the row loop sits under a divergent branch and hipcc's s_waitcnt bookkeeping can count the stores that
     // follow a load instead of assuming none (see the steady-state loop below).  Lanes the hardware never started read as 0 in the
     // ds_bpermute steps of wave_sum.
+#if OMLM_WAVE_DPP
+    // wave_sum_dpp finishes with v_readlane of lanes 16 / 32 / 48, which ignores EXEC: in a PARTIAL last wave (Fp = 2752: 24 lanes) it would
+    // read the never-written registers of absent lanes -- wrong LayerNorm statistics.  This forward needs the bpermute ladder.
+#error "ffmid2_fwd_kernel launches a partial last wave: build it with the ds_bpermute wave_sum (OMLM_WAVE_DPP=0)"
+#endif
     const int col = threadIdx.x * 8;
     const int ld = 2 * Fp;
     const size_t row0 = (size_t)b * nseq;

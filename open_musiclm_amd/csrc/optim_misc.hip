@@ -51,14 +51,21 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
                                                     float lr, float beta1, float beta2, float eps, float wd,
                                                     float bc1, float bc2_sqrt, float gscale, const float* __restrict__ gnorm_sq,
                                                     float max_norm, int decoupled, int zero_grad, const float* __restrict__ ls_state) {
-    // ls_state (precision "fp16", optional): {loss scale, good steps since its last change, skipped steps, applied steps}, all on the
-    // device: the backward multiplied the loss gradient by ls_state[0] (engine.LossFunction), this kernel divides it out, and the bias
+    // ls_state (precision "fp16", optional): {loss scale, good steps since its last change, skipped steps, applied steps, the scale the
+    // LAST step's gradients carried (written by omlm_loss_scale_update before it moves the scale)}, all on the device: the backward multiplied the loss gradient by ls_state[0] (engine.LossFunction), this kernel divides it out, and the bias
     // corrections count APPLIED steps (ls_state[3] + 1), so a skipped step leaves the Adam clock where it was.
     if (ls_state) {
         gscale /= ls_state[0];
-        const double t = (double)ls_state[3] + 1.0;
-        bc1 = (float)(1.0 - pow((double)beta1, t));
-        bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, t));
+        // the bias corrections of the APPLIED-step clock: formed once per workgroup (two double-precision pow per THREAD before round 5)
+        __shared__ float sbc[2];
+        if (threadIdx.x == 0) {
+            const double t = (double)ls_state[3] + 1.0;
+            sbc[0] = (float)(1.0 - pow((double)beta1, t));
+            sbc[1] = (float)sqrt(1.0 - pow((double)beta2, t));
+        }
+        __syncthreads();
+        bc1 = sbc[0];
+        bc2_sqrt = sbc[1];
     }
     float clip = 1.0f;
     if (gnorm_sq && max_norm > 0.f) {
@@ -107,6 +114,7 @@ extern "C" int omlm_adamw_clip_step(float* p, float* g, float* m, float* v, void
 __global__ void loss_scale_update_kernel(float* st, const float* __restrict__ gnorm_sq, float growth, float backoff, float interval,
                                          float smin, float smax) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    st[4] = st[0];                 // the scale this step's gradients (and its norm) carried: readers of the norm divide by THIS, not by the updated scale
     if (!(gnorm_sq[0] < 3.0e38f)) { st[0] = fmaxf(st[0] * backoff, smin); st[1] = 0.f; st[2] += 1.f; }
     else {
         st[3] += 1.f; st[1] += 1.f;

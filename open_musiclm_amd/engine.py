@@ -77,8 +77,8 @@ def loss_scale_initial() -> float:
 
 
 def loss_scale_state(model) -> torch.Tensor:
-    """The loss-scale block of a precision-"fp16" model: 4 floats on its device {scale, good steps since its last change, skipped
-    steps, applied steps}.  It lives on the device because the training micro-step is a captured HIP graph: the backward multiplies the
+    """The loss-scale block of a precision-"fp16" model: 5 floats on its device {scale, good steps since its last change, skipped
+    steps, applied steps, scale the last finished step's gradients carried}.  It lives on the device because the training micro-step is a captured HIP graph: the backward multiplies the
     loss gradient by element 0 with a tensor op (LossFunction.backward), the fused optimizer divides it out, skips a step whose gradient
     norm overflowed, counts the applied steps (its Adam clock) and halves / doubles the scale -- all without a host read
     (FusedAdam.step -> omlm_loss_scale_update; GradScaler's rule: x0.5 on overflow, x2 after $OMLM_FP16_GROWTH_INTERVAL = 2000 good
@@ -87,7 +87,7 @@ def loss_scale_state(model) -> torch.Tensor:
     dev = model.start_tokens[0].device
     st = model.__dict__.get("_omlm_ls_state")
     if st is None or st.device != dev:
-        st = torch.tensor([loss_scale_initial(), 0.0, 0.0, 0.0], device=dev, dtype=torch.float32)
+        st = torch.tensor([loss_scale_initial(), 0.0, 0.0, 0.0, loss_scale_initial()], device=dev, dtype=torch.float32)
         model.__dict__["_omlm_ls_state"] = st
     return st
 
@@ -104,13 +104,28 @@ def loss_scale(precision: str, model=None) -> float:
     return float(model.__dict__["_omlm_ls_state"][0].item())
 
 
+_MODEL_OF: Dict[int, tuple] = {}               # id(parameter) -> (weakref(parameter), weakref(model))
+
+
 def tag_parameters(model, precision: Optional[str]):
-    """Mark the model's parameters with its precision mode: the fused optimizer picks its 16-bit shadow type and loss scale from it."""
+    """Mark the model's parameters with its precision mode: the fused optimizer picks its 16-bit shadow type and loss scale from it.
+    The parameter -> model link (the optimizer finds the model's loss-scale block through it) lives in a module-level registry, NOT on
+    the Parameter: Parameter.__reduce_ex__ pickles the tensor's __dict__, and a weakref there broke torch.save(model) / pickle /
+    spawn-based multiprocessing of every TokenConditionedTransformer."""
     import weakref
     ref = weakref.ref(model)
     for p in model.parameters():
         p._omlm_precision = precision
-        p._omlm_model = ref                     # the fused optimizer finds the model's loss-scale block through it (precision "fp16")
+        key = id(p)
+        _MODEL_OF[key] = (weakref.ref(p, lambda _r, k=key: _MODEL_OF.pop(k, None)), ref)
+
+
+def model_of(p) -> Optional[torch.nn.Module]:
+    """The TokenConditionedTransformer that tagged parameter p (None if it is gone or p was never tagged)."""
+    ent = _MODEL_OF.get(id(p))
+    if ent is None or ent[0]() is not p:
+        return None
+    return ent[1]()
 
 
 @torch.no_grad()

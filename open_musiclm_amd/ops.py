@@ -219,6 +219,7 @@ def qk_norm_bwd(dq, dk, dv, q_raw, kv_raw, q_scale, k_scale, dq_raw, dkv_raw, dq
 
 
 _DBIAS_WS = {}
+_DBIAS_RETIRED = []            # outgrown workspaces stay alive (captured graphs may still point at them)
 
 
 def gemm_qknorm(A, B, C_, scale, norm_out, groups, *, M, N, K, C2=None, c2_col0=0):
@@ -261,6 +262,10 @@ class AttnBias:
         key = str(self.tableT.device)
         ws = _DBIAS_WS.get(key)
         if ws is None or ws.numel() < n:
+            if ws is not None:
+                # a captured HIP graph (graph.py) holds the OLD buffer's address in its kernel nodes: a regrown workspace must not free
+                # it, or later replays would write d(bias) partials into memory the allocator has handed to someone else
+                _DBIAS_RETIRED.append(ws)
             ws = _DBIAS_WS[key] = torch.empty(n, device=self.tableT.device, dtype=torch.float32)
         return ws
 

@@ -75,8 +75,7 @@ class FusedAdam(torch.optim.Optimizer):
         prec = prec or engine.default_precision()
         self._ls_state = None
         if prec == "fp16":
-            mref = next((getattr(p, "_omlm_model", None) for p in params if getattr(p, "_omlm_model", None) is not None), None)
-            owner = mref() if mref is not None else None
+            owner = next((m for m in (engine.model_of(p) for p in params) if m is not None), None)
             if owner is None:
                 raise RuntimeError("FusedAdam: fp16 parameters without their model (engine.tag_parameters): the loss-scale block is the model's")
             self._ls_state = engine.loss_scale_state(owner)
@@ -178,7 +177,7 @@ class FusedAdam(torch.optim.Optimizer):
         gn = getattr(self, "_last_gnorm_sq_raw", None)
         if gn is None or self._ls_state is None:
             return gn
-        return gn / (self._ls_state[0] * self._ls_state[0])      # note: after the step's scale update; exact while the scale did not move
+        return gn / (self._ls_state[4] * self._ls_state[4])      # slot 4: the scale THAT step's gradients carried (snapshot taken by omlm_loss_scale_update before it moves the scale)
 
     @last_grad_norm_sq.setter
     def last_grad_norm_sq(self, v):
@@ -194,7 +193,7 @@ class FusedAdam(torch.optim.Optimizer):
         e.g. next to the trainer's loss read-back); {} otherwise."""
         if self._ls_state is None:
             return {}
-        sc, _, sk, ap = [float(v) for v in self._ls_state.tolist()]
+        sc, _, sk, ap = [float(v) for v in self._ls_state.tolist()[:4]]
         return dict(scale=sc, skipped_steps=int(sk), applied_steps=int(ap))
 
     @torch.no_grad()

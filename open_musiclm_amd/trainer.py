@@ -311,11 +311,24 @@ class SingleStageTrainer(nn.Module):
         return loss.detach()
 
     def optimizer_step(self):
-        """ONE gradient exchange + fused clip/Adam(W)/zero_grad + scheduler tick."""
+        """ONE gradient exchange + fused clip/Adam(W)/zero_grad + scheduler tick.  Precision "fp16": a step whose gradients overflowed is
+        skipped ON THE DEVICE (no host read here), so the tick happens regardless; train_step, which reads the skip counter next to its loss
+        read-back anyway, takes the tick back (_rewind_scheduler) -- warm-up and decay then advance with the Adam clock, on applied steps only."""
         self.dp.allreduce_sum_(self.optim.flat_grad)
         self.optim.step(max_grad_norm=self.max_grad_norm, grad_scale=self.dp.grad_scale())
         if exists(self.scheduler):
             self.scheduler.step()
+
+    def _rewind_scheduler(self, n: int):
+        """Take back the scheduler ticks of n optimizer steps the device skipped (fp16 overflow): LinearLR is a closed form of last_epoch."""
+        sch = self.scheduler
+        if not exists(sch) or n <= 0 or not hasattr(sch, "_get_closed_form_lr"):
+            return
+        sch.last_epoch = max(sch.last_epoch - n, 0)
+        lrs = sch._get_closed_form_lr()
+        for g, lr in zip(sch.optimizer.param_groups, lrs):
+            g['lr'] = lr
+        sch._last_lr = list(lrs)
 
     def train_step(self):
         steps = int(self.steps.item())
@@ -338,6 +351,7 @@ class SingleStageTrainer(nn.Module):
                 if rep["skipped_steps"] > getattr(self, "_skipped_seen", 0):
                     self.print(f"{steps}: fp16 gradient overflow -- optimizer step skipped ({rep['skipped_steps']} so far), "
                                f"loss scale now {rep['scale']:g}")
+                    self._rewind_scheduler(rep["skipped_steps"] - getattr(self, "_skipped_seen", 0))
                     self._skipped_seen = rep["skipped_steps"]
         self.print(f"{steps}: loss: {logs['loss']}")
 

@@ -768,3 +768,36 @@ def test_fused_batch_preparation_is_only_taken_where_it_is_equivalent(monkeypatc
     too_long = [torch.zeros(1, 5000, dtype=torch.long, device="meta")] * 3
     w3 = M.TokenConditionedTransformerWrapper(transformer=tiny(), unique_consecutive=False, cross_entropy_loss_weights=[0., 0., 1.])
     assert not w3._fused_prepare_ok(too_long, False)                                     # N > 4096: past the kernel's register slots
+
+
+def test_model_pickles_and_the_parameter_registry_finds_it():
+    """the parameter -> model link of precision "fp16" must not live on the Parameter (its __dict__ is pickled):
+    torch.save(model) / pickle / spawn-based multiprocessing work, and the registry still resolves every parameter to its model."""
+    import io
+    import pickle
+    from open_musiclm_amd import engine, open_musiclm as M
+    m = M.create_coarse_transformer(dim=64, depth=1, heads=2, num_coarse_quantizers=3, precision="fp16")
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    pickle.dumps(next(m.parameters()))
+    assert all(engine.model_of(p) is m for p in m.parameters())
+    m2 = torch.load(io.BytesIO(buf.getvalue()), weights_only=False)
+    assert sorted(m2.state_dict()) == sorted(m.state_dict())
+
+
+def test_scheduler_rewind_after_device_skipped_steps():
+    """trainer._rewind_scheduler: LinearLR ticks taken back for optimizer steps the device skipped (fp16 overflow) -- the warm-up then
+    advances with the Adam clock (applied steps)."""
+    from open_musiclm_amd.optimizer import get_linear_scheduler
+    from open_musiclm_amd.trainer import SingleStageTrainer
+    w = torch.nn.Parameter(torch.zeros(3))
+    opt = torch.optim.SGD([w], lr=1.0)
+    sch = get_linear_scheduler(opt, total_iters=10, start_factor=0.1)
+    lrs = [opt.param_groups[0]["lr"]]
+    for _ in range(4):
+        opt.step(); sch.step(); lrs.append(opt.param_groups[0]["lr"])
+    holder = type("T", (), {"scheduler": sch})()
+    SingleStageTrainer._rewind_scheduler(holder, 2)
+    assert sch.last_epoch == 2 and abs(opt.param_groups[0]["lr"] - lrs[2]) < 1e-12 and abs(sch.get_last_lr()[0] - lrs[2]) < 1e-12
+    opt.step(); sch.step()
+    assert abs(opt.param_groups[0]["lr"] - lrs[3]) < 1e-12
