@@ -38,11 +38,15 @@
 // into C (these GEMMs are "C += ..." by construction: gradients accumulate over micro-batches).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace OMLM_NS {
 
 #ifndef OMLM_GEMM_TAIL_WAIT
 #define OMLM_GEMM_TAIL_WAIT 1
+#endif
+#ifndef OMLM_GEMM_T8_DEFAULT
+#define OMLM_GEMM_T8_DEFAULT 2     // round 5: gemm_tile8_body for the 256 x 256 tiles (see gemm_t8_mode): 2 = where it measured faster
 #endif
 #ifndef OMLM_EPI_CIN_AHEAD
 #define OMLM_EPI_CIN_AHEAD 1       // epilogue: the residual pieces of strip i + 1 are requested before the stores of strip i (tile_epilogue)
@@ -950,6 +954,175 @@ __global__ __launch_bounds__((BM_ / WM_) * (BN_ / WN_) * 64) void gemm_bf16_tile
 }
 
 
+// ---- round 5: the wide tile on a half-tile ring with counted waits (two staggered wave groups) ----------------------------------
+// What the k-loops above still pay (rounds 1-4): ONE barrier and a full `s_waitcnt vmcnt(0)` per k-tile with ONE tile of DMA in flight -- the
+// youngest piece of k-tile t + 1 has ~1.5 of tile t's 4 k16 steps to land, so every L2 miss (and, under load, many hits) is exposed, and
+// after each barrier all eight waves of the one workgroup per CU wait for their first fragments together (MFMA pipe busy 47 %).
+// This body keeps the 256 x 256 x 64 tile, the LDS images and the fragment reads, and changes the schedule:
+//   * the unit of staging is a HALF-tile (128 rows or columns x 64 k = 16 KiB = two 1-KiB DMA pieces per wave); LDS holds two k-tiles =
+//     8 half-tile slots, and a slot is re-requested two phases after its last fragment read -- FIVE half-tiles (80 KiB) are in flight
+//     behind a counted `s_waitcnt vmcnt(10)` per phase, never 0: every piece has ~5 phases (~1300 MFMA cycles) to land;
+//   * a k-tile is four PHASES, one 64 x 32 quadrant of the wave's output per phase (8 MFMAs = 256 matrix-pipe cycles): the wave owns
+//     rows ha * 128 + wr * 64 + [0, 64) and columns hb * 128 + wc * 32 + [0, 32) for ha, hb in {0, 1}, so quadrant (ha, hb) needs exactly
+//     half-tiles A_ha and B_hb; quadrant order (0,0) (0,1) (1,1) (1,0): a phase reads ONE new half (A0: 8 ds_read_b128, B1: 4, A1: 8, and
+//     in the last phase B0 of the NEXT k-tile: 4 -- the B fragments rotate through three register sets), requests one half-tile, waits
+//     (counted) for the half the next phase reads, `s_barrier`, multiplies, `s_barrier`;
+//   * waves 4-7 run ONE barrier behind waves 0-3: on every SIMD one wave is on the matrix pipe while its partner reads fragments and
+//     issues DMA -- the fragment latency is covered by the partner's MFMAs instead of by a rotated loop.
+// Event order (e_n: 4T = B0(T), 4T+1 = A0(T), 4T+2 = B1(T), 4T+3 = A1(T)): e_n is read in phase n - 1 and requested in phase n - 7
+// (prologue: e_0 .. e_6); at the wait of phase g, e_(g+2) must have landed and e_(g+3) .. e_(g+7) stay in flight: vmcnt(10).
+//   RAW: a wave's own pieces are covered by its counted wait, the other waves' by the barrier(s) behind their waits -- group 1's wait of
+//        phase g sits one barrier later than group 0's, still in front of the barrier that opens group 0's phase g + 1 reads;
+//   WAR: e_(g+7) overwrites the slot last read in phase g - 2 (A0: 4T -> requested in 4T + 2, etc.): both groups' reads of that phase have
+//        been retired by their `lgkmcnt(0)` behind the phase's first barrier, two and one barriers before the request respectively.
+// Requests past the last k-tile are issued dead (out-of-bounds offset: zeros, no traffic) so that the counts stay uniform; they are
+// drained in front of the epilogue (the tail race of round 4).  Whole k-tiles only (K % 64 == 0), no row maps on the operands.
+#ifndef OMLM_T8_SETPRIO
+#define OMLM_T8_SETPRIO 1
+#endif
+template <bool A_KMAJ, bool B_KMAJ, typename TOUT, bool SPLIT3 = false>
+__device__ __forceinline__ void gemm_tile8_body(const GemmArgs& g, const int m0, const int n0, const int kt0, const int kt1, const bool split, char* smem) {
+    constexpr int A_BYTES = 256 * BK * 2, STAGE = 2 * A_BYTES;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const dma_rsrc rsA = make_dma_rsrc(g.A, (unsigned long long)g.a_rows * g.lda * 2);
+    const dma_rsrc rsB = make_dma_rsrc(g.B, (unsigned long long)g.b_rows * g.ldb * 2);
+    DmaStagerT<A_KMAJ, 256, 8> sa;          // unit i of a wave is 1-KiB unit b = wave + 8 i of the tile image: i < 2 -> rows / columns [0, 128) = half 0
+    DmaStagerT<B_KMAJ, 256, 8> sb;
+    sa.init(nullptr, g.lda, g.M, m0, wave, lane);
+    sb.init(nullptr, g.ldb, g.N, n0, wave, lane);
+    const int nk = kt1 - kt0;
+    const unsigned smem_lds = (unsigned)(size_t)LDS_PTR(char, smem);
+
+    f32x16 acc[2][2][2];                    // [ha][hb][i]: rows ha * 128 + wr * 64 + 32 i, columns hb * 128 + wc * 32
+#pragma unroll
+    for (int x = 0; x < 8; ++x)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[x >> 2][(x >> 1) & 1][x & 1][e] = 0.f;
+
+    // request event e_n, n = 4 T + J (J a compile-time constant): two pieces per wave
+    auto stage = [&](auto JC, const int T) {
+        constexpr int J = decltype(JC)::value;
+        constexpr bool isA = (J & 1) != 0;
+        constexpr int h = J >> 1;
+        const bool live = T < nk;
+        unsigned k0 = (unsigned)(kt0 + T) * BK, poff = 0u;
+        if constexpr (SPLIT3) {
+            // hi/lo operand planes ("bf16x3"): loop tile t reads planes (A_hi, B_hi), (A_hi, B_lo), (A_lo, B_hi) at k = (t mod nk1) * 64 -- gemm_tile_body's tile_at
+            const int t = kt0 + T, nk1 = g.K / BK;
+            const int which = t >= 2 * nk1 ? 2 : (t >= nk1 ? 1 : 0);
+            k0 = (unsigned)(t - which * nk1) * BK;
+            poff = isA ? (which == 2 ? g.a_plane : 0u) : (which == 1 ? g.b_plane : 0u);
+        }
+        const unsigned base = smem_lds + (unsigned)((T & 1) * STAGE) + (isA ? 0u : (unsigned)A_BYTES);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = 2 * h + u;
+            const int b = wave + 8 * i;
+            if constexpr (isA) dma_issue_s(rsA, base + (unsigned)(b * 1024), live ? sa.vfast[i] : OOB_OFF, (A_KMAJ ? k0 * (unsigned)(g.lda * 2) : k0 * 2u) + poff);
+            else               dma_issue_s(rsB, base + (unsigned)(b * 1024), live ? sb.vfast[i] : OOB_OFF, (B_KMAJ ? k0 * (unsigned)(g.ldb * 2) : k0 * 2u) + poff);
+        }
+    };
+    using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>;
+    using J2 = std::integral_constant<int, 2>; using J3 = std::integral_constant<int, 3>;
+
+    h16x8 a[2][4], bX[4], bY[4], bZ[4];
+    auto read_a = [&](const int T, const int ha) {
+        const char* As = smem + (T & 1) * STAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int st = 0; st < 4; ++st) a[i][st] = read_frag<A_KMAJ>(As, ha * 128 + wr * 64 + 32 * i, st, lane);
+    };
+    auto read_b = [&](h16x8 (&b)[4], const int T, const int hb) {
+        const char* Bs = smem + (T & 1) * STAGE + A_BYTES;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) b[st] = read_frag<B_KMAJ>(Bs, hb * 128 + wc * 32, st, lane);
+    };
+    auto mma = [&](f32x16 (&c)[2], const h16x8 (&b)[4]) {
+#if OMLM_T8_SETPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) c[i] = OMLM_MFMA_32x32x16(a[i][st], b[st], c[i]);
+#if OMLM_T8_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+    };
+    // the synchronisation of one phase: (reads and the request were just issued) counted wait -> barrier -> fragments in -> MFMAs -> barrier
+#define T8_SYNC_IN()                                                           \
+    do {                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                     \
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                      \
+        __builtin_amdgcn_s_barrier();                                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     \
+        __builtin_amdgcn_sched_barrier(0);                                     \
+    } while (0)
+#define T8_SYNC_OUT()                                                          \
+    do {                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                     \
+        __builtin_amdgcn_s_barrier();                                          \
+        __builtin_amdgcn_sched_barrier(0);                                     \
+    } while (0)
+
+    // prologue: e_0 .. e_6 = all of k-tile 0 and B0, A0, B1 of k-tile 1
+    stage(J0{}, 0); stage(J1{}, 0); stage(J2{}, 0); stage(J3{}, 0);
+    stage(J0{}, 1); stage(J1{}, 1); stage(J2{}, 1);
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                          // e_0 (B0 of k-tile 0) and e_1 (A0) are in
+    __builtin_amdgcn_s_barrier();
+    read_b(bX, 0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                         // (retired before anyone may re-request that slot: phase 1)
+    __builtin_amdgcn_sched_barrier(0);
+    if (wr == 1) __builtin_amdgcn_s_barrier();                                 // waves 4-7 run one barrier behind from here on
+
+    // one k-tile: b0 holds B0 of this tile (read in the previous tile's last phase), bn receives B0 of the next tile
+    auto ktile = [&](h16x8 (&b0)[4], h16x8 (&bn)[4], const int T) {
+        read_a(T, 0);             stage(J3{}, T + 1);  T8_SYNC_IN();  mma(acc[0][0], b0);  T8_SYNC_OUT();     // phase 0: A0 -> (0, 0); request A1(T + 1)
+        read_b(bY, T, 1);         stage(J0{}, T + 2);  T8_SYNC_IN();  mma(acc[0][1], bY);  T8_SYNC_OUT();     // phase 1: B1 -> (0, 1); request B0(T + 2)
+        read_a(T, 1);             stage(J1{}, T + 2);  T8_SYNC_IN();  mma(acc[1][1], bY);  T8_SYNC_OUT();     // phase 2: A1 -> (1, 1); request A0(T + 2)
+        read_b(bn, T + 1, 0);     stage(J2{}, T + 2);  T8_SYNC_IN();  mma(acc[1][0], b0);  T8_SYNC_OUT();     // phase 3: B0(T + 1) for later; (1, 0); request B1(T + 2)
+    };
+    for (int T = 0; T < nk; T += 2) {
+        ktile(bX, bZ, T);
+        if (T + 1 < nk) ktile(bZ, bX, T + 1);
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();                                 // waves 0-3 wait for the others' last phase
+#undef T8_SYNC_IN
+#undef T8_SYNC_OUT
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           // the dead requests of the last phases (zeros into LDS) are drained
+    __syncthreads();
+    // epilogue: the wave's four 64 x 32 quadrants through its LDS patch (tile_epilogue, 32-column form)
+#pragma unroll
+    for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+            tile_epilogue<2, 1, 32, TOUT>(g, reinterpret_cast<f32x16 (&)[2][1]>(acc[ha][hb]), smem, m0, n0, ha * 128 + wr * 64, hb * 128 + wc * 32,
+                                          wave, lane, 0, split);
+}
+
+// one output tile per workgroup, the tile / split order of gemm_bf16_tile_kernel
+template <bool A_KMAJ, bool B_KMAJ, typename TOUT, bool SPLIT3 = false>
+__global__ __launch_bounds__(512) void gemm_tile8_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 k-tiles][A | B]
+    const int nwg = gridDim.x;
+    const int lg = xcd_logical_id(blockIdx.y * nwg + blockIdx.x, nwg * (int)gridDim.y);
+    const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + 255) / 256;
+    const int ksplit = lg / nwg, bid = lg - ksplit * nwg;
+    const int nk_all = (SPLIT3 ? 3 : 1) * (g.K / BK);
+    const int kt0 = ksplit * g.kt_per_split, kt1 = min(nk_all, kt0 + g.kt_per_split);
+    constexpr int GROUP = OMLM_SUPER_ROWS / 256;
+    const int gsz = GROUP * tiles_n;
+    const int grp = bid / gsz, first_m = grp * GROUP;
+    const int rows_in = min(GROUP, tiles_m - first_m);
+    const int tm = first_m + (bid - grp * gsz) % rows_in, tn = (bid - grp * gsz) / rows_in;
+    if (kt0 >= kt1) return;
+    gemm_tile8_body<A_KMAJ, B_KMAJ, TOUT, SPLIT3>(g, tm * 256, tn * 256, kt0, kt1, gridDim.y > 1, smem);
+}
+
+
 // ---- grouped weight-gradient GEMM ------------------------------------------------------------------------------------
 // All dW += dY^T X contractions of a backward pass (same K = tokens, small outputs) as ONE launch: the 30 separate GEMMs of a
 // coarse-small step each had too few output tiles for 256 CUs and were split 5..31 ways along K with fp32 atomics
@@ -967,7 +1140,7 @@ static bool gemm_fastk_off() {
     return off == 1;
 }
 
-template <bool FASTK>
+template <bool FASTK, bool T8 = false>
 __global__ __launch_bounds__(512) void gemm_wgrad_group_kernel(GroupArgs ga) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lg = xcd_logical_id(blockIdx.x, ga.total);
@@ -980,8 +1153,23 @@ __global__ __launch_bounds__(512) void gemm_wgrad_group_kernel(GroupArgs ga) {
     g.alpha = 1.f; g.kt_per_split = q.kt_per_split; g.bal_ck = 0; g.bal_chunks = 0; g.debug = 0; g.split3 = 0; g.a_plane = 0; g.b_plane = 0;
     g.epi_scale = nullptr; g.epi_norm = nullptr; g.epi_groups = 0; g.epi_ldnorm = 0; g.C2 = nullptr; g.c2_col0 = 0; g.ldc2 = 0;
     const int nk = (q.K + BK - 1) / BK;
-    gemm_tile_body<256, 256, 128, 64, true, true, float, false, false, false, false, FASTK>(g, lg - q.start, q.kt_per_split < nk, 0, smem);
+    if constexpr (T8) {
+        // the half-tile-ring schedule (round 5), same tile / split numbering as gemm_tile_body
+        const int lq = lg - q.start;
+        const int tiles_m = (q.M + 255) / 256, tiles_n = (q.N + 255) / 256, nwg = tiles_m * tiles_n;
+        const int ksplit = lq / nwg, bid = lq - ksplit * nwg;
+        const int kt0 = ksplit * q.kt_per_split, kt1 = min(nk, kt0 + q.kt_per_split);
+        constexpr int GROUP = OMLM_SUPER_ROWS / 256;
+        const int gsz = GROUP * tiles_n;
+        const int grp = bid / gsz, first_m = grp * GROUP;
+        const int rows_in = min(GROUP, tiles_m - first_m);
+        const int tm = first_m + (bid - grp * gsz) % rows_in, tn = (bid - grp * gsz) / rows_in;
+        if (kt0 < kt1) gemm_tile8_body<true, true, float>(g, tm * 256, tn * 256, kt0, kt1, q.kt_per_split < nk, smem);
+    } else {
+        gemm_tile_body<256, 256, 128, 64, true, true, float, false, false, false, false, FASTK>(g, lg - q.start, q.kt_per_split < nk, 0, smem);
+    }
 }
+
 
 #ifdef OMLM_ISA_ONLY       /* tools/isa_audit.py-style inspection builds: the persistent kernels alone (seconds instead of minutes) */
 template __global__ void gemm_bf16_tile_persist_kernel<256, 256, 128, 64, false, false, h16_t, false>(GemmArgs);
@@ -991,6 +1179,10 @@ template __global__ void gemm_bf16_tile_persist_kernel<256, 256, 128, 64, false,
 template __global__ void gemm_bf16_tile_persist_kernel<128, 128, 64, 64, false, false, h16_t, false>(GemmArgs);
 template __global__ void gemm_bf16_tile_persist_kernel<128, 128, 64, 64, false, false, float, true>(GemmArgs);
 template __global__ void gemm_bf16_tile_persist_kernel<128, 128, 64, 64, false, false, h16_t, false, 1>(GemmArgs);
+template __global__ void gemm_tile8_kernel<false, false, h16_t>(GemmArgs);
+template __global__ void gemm_tile8_kernel<false, true, h16_t>(GemmArgs);
+template __global__ void gemm_tile8_kernel<false, false, float>(GemmArgs);
+template __global__ void gemm_tile8_kernel<true, true, float>(GemmArgs);
 }   // namespace
 #else
 // workgroups of the persistent walk: one per CU, rounded down to a multiple of 8 (the walk's stride must keep a workgroup on its XCD);
@@ -1005,12 +1197,54 @@ static int gemm_persist_slots() {
     return (e && e[0] == '0') ? 0 : ncu8;
 }
 
+// OMLM_GEMM_T8: the half-tile-ring schedule (gemm_tile8_body) for the 256 x 256 tiles: 0 = off, 1 = every eligible launch, 2 (default) =
+// where it measured faster (profiles/r05b_gemm_t8_ab.md, same box, bit-identical results): the grouped weight gradients (557 k-tiles per
+// tile: +6 %) and multi-round launches with K >= 2048 (d(xn2), K = 5504: +3 %; FF-out, K = 2752: +2 %; 8192^3: +15 %).  Short contractions
+// (K = 1024: 16 k-tiles per tile) stay on the persistent walk of the rotated loop, which hides the per-tile prologue / epilogue that this
+// one-tile-per-workgroup form exposes (FF-in 373 vs 399 us).  Read per call like the other levers (tests and tools/lib_ab toggle it).
+static int gemm_t8_mode() {
+    const char* e = getenv("OMLM_GEMM_T8");
+    return e ? atoi(e) : OMLM_GEMM_T8_DEFAULT;
+}
+static bool gemm_t8_wanted(int K, int tiles, int splits) {
+    const int mode = gemm_t8_mode();
+    if (mode <= 0) return false;
+    if (mode == 1) return true;
+    return splits == 1 && K >= 2048 && tiles > gemm_persist_slots();
+}
+
 template <int BM_, int BN_, int WM_, int WN_, typename TOUT>
 static int launch_tile(const GemmArgs& g, int a_kmaj, int b_kmaj, int splits, hipStream_t st) {
     constexpr int NTH = (BM_ / WM_) * (BN_ / WN_) * 64;
     constexpr size_t LDS = 2 * (size_t)(BM_ + BN_) * BK * 2;
     const int tiles = ((g.M + BM_ - 1) / BM_) * ((g.N + BN_ - 1) / BN_);
     dim3 grid(tiles, splits), block(NTH);
+    if constexpr (BM_ == 256 && BN_ == 256) {
+        // whole k-tiles, no maps on the operand side (a scatter map of C and split-K are fine), no ablation / plane / balanced modes
+        // (the hi/lo-plane route runs a 3x k-loop: K >= 704 already is a long contraction for it; its instantiations exist in the bf16 copy only)
+        if (gemm_t8_wanted(g.split3 ? 3 * g.K : g.K, tiles, splits) && g.K % BK == 0 && !g.a_map && !g.b_map && g.bal_ck == 0 && !g.debug && !gemm_fastk_off() &&
+            (!g.split3 || !OMLM_FP16)) {
+#define OMLM_T8_LAUNCH(AK, BKM)                                                                                       \
+            do {                                                                                                       \
+                auto k8 = gemm_tile8_kernel<AK, BKM, TOUT>;                                                            \
+                static bool attr8 = false;                                                                             \
+                if (!attr8) { (void)hipFuncSetAttribute((const void*)k8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); attr8 = true; } \
+                if constexpr (!OMLM_FP16) {                                                                            \
+                    auto k83 = gemm_tile8_kernel<AK, BKM, TOUT, true>;                                                 \
+                    static bool attr83 = false;                                                                        \
+                    if (!attr83) { (void)hipFuncSetAttribute((const void*)k83, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); attr83 = true; } \
+                    if (g.split3) { hipLaunchKernelGGL(k83, grid, block, LDS, st, g); break; }                         \
+                }                                                                                                      \
+                hipLaunchKernelGGL(k8, grid, block, LDS, st, g);                                                       \
+            } while (0)
+            if (!a_kmaj && !b_kmaj)      OMLM_T8_LAUNCH(false, false);
+            else if (!a_kmaj && b_kmaj)  OMLM_T8_LAUNCH(false, true);
+            else if (a_kmaj && b_kmaj)   OMLM_T8_LAUNCH(true, true);
+            else                         OMLM_T8_LAUNCH(true, false);
+#undef OMLM_T8_LAUNCH
+            return omlm_post_launch("omlm_gemm");
+        }
+    }
     if (g.bal_ck > 0) grid = dim3(splits, 1);          // balanced split-K: `splits` carries the workgroup count
     const bool need_kmap = (a_kmaj && g.a_map) || (b_kmaj && g.b_map);       // host routes these to the 128x128 tile
     if (need_kmap && BM_ != 128) { omlm_set_error("omlm_gemm: k-row maps are only built for the 128x128 tile"); return OMLM_ERR_UNSUPPORTED; }
@@ -1398,6 +1632,7 @@ extern "C" int OMLM_API(omlm_gemm_wgrad_group)(const omlm_gemm_wgrad_desc* d, in
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)gemm_wgrad_group_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         (void)hipFuncSetAttribute((const void*)gemm_wgrad_group_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        (void)hipFuncSetAttribute((const void*)gemm_wgrad_group_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         attr = true;
     }
     { const char* e = getenv("OMLM_GROUP_SPLITS"); if (e && atoi(e) > 0) splits = atoi(e); }
@@ -1446,7 +1681,8 @@ extern "C" int OMLM_API(omlm_gemm_wgrad_group)(const omlm_gemm_wgrad_desc* d, in
             start += ((q.M + 255) / 256) * ((q.N + 255) / 256) * s_eff;
         }
         ga.total = start;
-        if (fastk) hipLaunchKernelGGL(gemm_wgrad_group_kernel<true>, dim3(start), dim3(512), 131072, as_stream(stream), ga);
+        if (fastk && gemm_t8_mode() > 0) hipLaunchKernelGGL((gemm_wgrad_group_kernel<true, true>), dim3(start), dim3(512), 131072, as_stream(stream), ga);
+        else if (fastk) hipLaunchKernelGGL(gemm_wgrad_group_kernel<true>, dim3(start), dim3(512), 131072, as_stream(stream), ga);
         else       hipLaunchKernelGGL(gemm_wgrad_group_kernel<false>, dim3(start), dim3(512), 131072, as_stream(stream), ga);
     }
     return omlm_post_launch("omlm_gemm_wgrad_group");

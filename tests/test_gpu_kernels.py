@@ -159,6 +159,100 @@ def test_gemm_persistent_walk_equals_the_one_tile_grid(ops, dev, dtype, M, N, K,
     assert e < (8e-3 if out16 else 2e-5), e      # 16-bit output: one rounding of the result (2^-8 / 2^-11 of the row's scale); fp32: accumulation order only
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,akm,bkm,out16,resid", [
+    (4096, 2048, 1024, False, False, True, False),     # NT, 16-bit out: 16 k-tiles (even)
+    (3000, 1100, 192, False, True, True, False),       # NN, ragged M and N (edge tiles: out-of-range rows / columns staged as zeros), 3 k-tiles (odd: the B0 register sets swap roles)
+    (2048, 1300, 64, False, False, False, True),       # ONE k-tile: prologue -> four phases -> drain; fp32 out + residual
+    (1500, 1024, 2752, False, False, False, True),     # FF-out's K = 43 k-tiles, fp32 out + residual, ragged M
+    (1280, 1536, 4096, True, True, False, False),      # both operands k-major (the weight-gradient layout), full-K tiles, plain fp32 store
+    (1032, 1288, 128, True, False, True, False),       # k-major A, k-contiguous B, ragged, 2 k-tiles
+])
+def test_gemm_half_tile_ring_schedule_equals_the_rotated_loop(ops, dev, dtype, M, N, K, akm, bkm, out16, resid):
+    """gemm_tile8_body (round 5: half-tile ring, counted vmcnt(10) per phase, two wave groups one barrier apart) multiplies the same
+    fragments in the same order per accumulator as the rotated loop it replaces on long contractions: OMLM_GEMM_T8=1 (every eligible
+    256 x 256 launch) must equal OMLM_GEMM_T8=0 BIT FOR BIT in every layout / output form, and fp64 on the rounded operands.  Six
+    repeats: a short counted wait or a slot re-requested too early would show as run-to-run differences."""
+    g = torch.Generator(device="cpu").manual_seed(M + 5 * N + K)
+    c8 = lambda x: (x + 7) // 8 * 8
+    Am, Bm = torch.randn(M, K, generator=g).to(dtype), torch.randn(N, K, generator=g).to(dtype)
+
+    def store(mat, kmaj, n):
+        if kmaj:
+            st = torch.randn(K, c8(n), generator=g).to(dtype)
+            st[:, :n] = mat.t()
+            return st
+        return mat.contiguous()
+    A, B = store(Am, akm, M).to(dev), store(Bm, bkm, N).to(dev)
+    Cin = torch.randn(M, N, generator=g).to(dev) if resid else None
+    odt = dtype if out16 else torch.float32
+    ref = Am.to(dev).double() @ Bm.to(dev).double().t()
+    if resid:
+        ref = ref + Cin.double()
+    outs = {}
+    old = {k: os.environ.get(k) for k in ("OMLM_GEMM_T8", "OMLM_GEMM_TILE")}
+    try:
+        os.environ["OMLM_GEMM_TILE"] = "256x256"           # the wide tile whatever the host's shape rule says
+        for mode in ("0", "1"):
+            os.environ["OMLM_GEMM_T8"] = mode
+            runs = []
+            for rep in range(6 if mode == "1" else 1):
+                C = torch.full((M, c8(N)), float("nan"), device=dev, dtype=odt)
+                ops.gemm(A, B, C, M=M, N=N, K=K, a_kmajor=akm, b_kmajor=bkm, Cin=Cin, ldcin=N if resid else None,
+                         a_rows=K if akm else M, b_rows=K if bkm else N)
+                runs.append(C[:, :N].clone())
+            outs[mode] = runs
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    torch.cuda.synchronize()
+    e = relerr(outs["1"][0].float(), ref)
+    same = all(torch.equal(outs["0"][0], c) for c in outs["1"])
+    report(f"gemm_t8[{dtype},{M},{N},{K},{akm},{bkm},{out16},{resid}]", relerr=e, bit_equal_to_rotated_loop=same)
+    assert not torch.isnan(outs["1"][0].float()).any()
+    assert same, "the half-tile-ring schedule differs from the rotated loop (or from itself between runs)"
+    assert e < (8e-3 if out16 else 2e-5), e
+
+
+def test_gemm_half_tile_ring_on_operand_planes_and_split_k(ops, dev):
+    """The same schedule under the hi/lo-plane route (3x k-loop through three plane pairs: 'bf16x3') and with split-K partial sums
+    (fp32 atomics into C: order is free, values agree to rounding)."""
+    g = torch.Generator(device="cpu").manual_seed(99)
+    M, N, K = 2048, 1024, 1024
+    A, B = torch.randn(M, K, generator=g).to(dev), torch.randn(N, K, generator=g).to(dev)
+    outs = {}
+    old = {k: os.environ.get(k) for k in ("OMLM_GEMM_T8", "OMLM_GEMM_TILE")}
+    try:
+        os.environ["OMLM_GEMM_TILE"] = "256x256"
+        for mode in ("0", "1"):
+            os.environ["OMLM_GEMM_T8"] = mode
+            C = torch.full((M, N), float("nan"), device=dev)
+            ops.gemm(A, B, C, M=M, N=N, K=K)                                  # fp32 operands above the plane threshold
+            # split-K: accumulate-into-C with few tiles and a long contraction (a weight-gradient shape, k-major fp16 operands)
+            dY, X = torch.randn(16384, 512, generator=g).half().to(dev), torch.randn(16384, 768, generator=g).half().to(dev)
+            dW = torch.zeros(512, 768, device=dev)
+            ops.gemm(dY, X, dW, M=512, N=768, K=16384, a_kmajor=True, b_kmajor=True, Cin=dW)
+            outs[mode] = (C, dW, dY, X)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    torch.cuda.synchronize()
+    ref = A.double() @ B.double().t()
+    e3 = relerr(outs["1"][0], ref)
+    same3 = torch.equal(outs["0"][0], outs["1"][0])
+    refw = outs["1"][2].double().t() @ outs["1"][3].double()
+    ew = relerr(outs["1"][1], refw)
+    report("gemm_t8_planes_splitk", planes_relerr=e3, planes_bit_equal=same3, splitk_relerr=ew, splitk_vs_rotated=relerr(outs["1"][1], outs["0"][1].double()))
+    assert same3 and e3 < 2e-5, (same3, e3)
+    assert ew < 2e-5 and relerr(outs["1"][1], outs["0"][1].double()) < 1e-5
+
+
 @pytest.mark.parametrize("M,N,K,akm,bkm,accumulate", [(1100, 520, 264, False, True, False), (600, 264, 5000, True, True, True),
                                                        (777, 1032, 520, False, False, False), (300, 512, 2048, True, False, True)])
 def test_gemm_fp32_on_operand_planes(ops, dev, M, N, K, akm, bkm, accumulate):

@@ -286,9 +286,9 @@ static void gemm_edge_case(Lib& A, Lib& Bl) {
 }
 
 // The grouped weight-gradient launch on one layer's five problems x `layers` (dW += dY^T X, K = B*N rows): same tile body as omlm_gemm.
-static void wgrad_case(Lib& A, Lib& Bl) {
+static void wgrad_case(Lib& A, Lib& Bl, int kcut = 8) {
     const int K = 35712, D = 1024, layers = 3;
-    printf("== grouped weight gradients  K=%d, %d layers x 5 problems\n", K, layers);
+    printf("== grouped weight gradients  K=%d, %d layers x 5 problems\n", K - kcut, layers);
     const int Ms[5] = {512, 128, 1024, 5472, 1024}, Ns[5] = {1024, 1024, 512, 1024, 2736};
     std::vector<uint16_t> big((size_t)K * 5472); fast_fill(big, 1.f, 11);
     std::vector<uint16_t> big2((size_t)K * 2736); fast_fill(big2, 1.f, 12);
@@ -305,7 +305,7 @@ static void wgrad_case(Lib& A, Lib& Bl) {
         for (int l = 0; l < layers; ++l)
             for (int i = 0; i < 5; ++i) {
                 wgrad_desc d; d.A = dA + 8 * l; d.B = dB + 8 * l; d.C = C + off; d.c_map = nullptr;      // k-major operands: [K, M] / [K, N] views of the big buffers
-                d.M = Ms[i]; d.N = Ns[i]; d.K = K - 8; d.lda = 5472; d.ldb = 2736; d.ldc = Ns[i];
+                d.M = Ms[i]; d.N = Ns[i]; d.K = K - kcut; d.lda = 5472; d.ldb = 2736; d.ldc = Ns[i];
                 off += (size_t)Ms[i] * Ns[i];
                 pr.push_back(d);
             }
@@ -325,6 +325,47 @@ static void fill_f32(std::vector<float>& v, float scale, uint64_t seed) {
     for (auto& e : v) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; e = ((float)((x >> 40) & 0xFFFFFF) * (2.0f / 16777216.0f) - 1.f) * 1.7320508f * scale; }
 }
 template <typename T> static size_t count_diff(const std::vector<T>& a, const std::vector<T>& b) { size_t d = 0; for (size_t i = 0; i < a.size(); ++i) d += memcmp(&a[i], &b[i], sizeof(T)) != 0; return d; }
+
+// Round-5 shapes of the coarse-small step (Fp = 2752: every K a whole number of 64-deep k-tiles): the four large non-grouped GEMMs of a layer,
+// A vs B bitwise (same products in the same order per accumulator) and timed in interleaved rounds.
+static void gemm5_case(Lib& A, Lib& Bl) {
+    const int M = 35712, D = 1024, Fp = 2752, F2 = 2 * Fp;
+    printf("== GEMM round-5 shapes  M=%d D=%d Fp=%d (bf16 operands)\n", M, D, Fp);
+    std::vector<uint16_t> X((size_t)M * D), W1((size_t)F2 * D), H1((size_t)M * F2), H2((size_t)M * Fp), W2((size_t)D * Fp);
+    fast_fill(X, 1.f, 1); fast_fill(W1, 0.03f, 2); fast_fill(H1, 1.f, 3); fast_fill(H2, 1.f, 4); fast_fill(W2, 0.02f, 5);
+    std::vector<float> R((size_t)M * D); fill_f32(R, 1.f, 6);
+    uint16_t *dX = dev(X), *dW1 = dev(W1), *dH1 = dev(H1), *dH2 = dev(H2), *dW2 = dev(W2); float* dR = dev(R);
+    Lib* libs[2] = {&A, &Bl};
+    uint16_t *o_ffin[2], *o_dh2[2], *o_dxn2[2]; float* o_ffout[2];
+    for (int li = 0; li < 2; ++li) { o_ffin[li] = dev_zero<uint16_t>((size_t)M * F2); o_dh2[li] = dev_zero<uint16_t>((size_t)M * Fp); o_dxn2[li] = dev_zero<uint16_t>((size_t)M * D); o_ffout[li] = dev_zero<float>((size_t)M * D); }
+    auto ffin = [&](int li) { libs[li]->ok(libs[li]->gemm(dX, dW1, o_ffin[li], nullptr, nullptr, nullptr, nullptr, M, F2, M, F2, D, D, D, F2, 0, 0, 0, 1, 1, 1.f, nullptr), "ffin"); };
+    auto dh2 = [&](int li) { libs[li]->ok(libs[li]->gemm(dX, dW2, o_dh2[li], nullptr, nullptr, nullptr, nullptr, M, D, M, Fp, D, D, Fp, Fp, 0, 0, 1, 1, 1, 1.f, nullptr), "dh2"); };       // dres [M, D] x W2p [D, Fp] k-major
+    auto dxn2 = [&](int li) { libs[li]->ok(libs[li]->gemm(dH1, dW1, o_dxn2[li], nullptr, nullptr, nullptr, nullptr, M, F2, M, D, F2, F2, D, D, 0, 0, 1, 1, 1, 1.f, nullptr), "dxn2"); };  // dh1 [M, 2Fp] x W1p [2Fp, D] k-major
+    auto ffout = [&](int li) { libs[li]->ok(libs[li]->gemm(dH2, dW2, o_ffout[li], dR, nullptr, nullptr, nullptr, M, D, M, D, Fp, Fp, Fp, D, D, 0, 0, 1, 0, 1.f, nullptr), "ffout"); };
+    const char* names[4] = {"ffin_NT 16b", "dh2_NN 16b", "dxn2_NN 16b", "ffout_NT f32+res"};
+    const double fl[4] = {2.0 * M * D * (double)F2, 2.0 * M * D * (double)Fp, 2.0 * M * D * (double)F2, 2.0 * M * D * (double)Fp};
+    double best[2][4]; for (auto& r : best) for (auto& v : r) v = 1e30;
+    double sum[2][4] = {{0}};
+    const int rounds = 4;
+    for (int r = 0; r < rounds + 1; ++r)
+        for (int li = 0; li < 2; ++li) {
+            apply_env(li ? g_env_b : g_env_a);
+            for (int c = 0; c < 4; ++c) {
+                auto fn = [&] { if (c == 0) ffin(li); else if (c == 1) dh2(li); else if (c == 2) dxn2(li); else ffout(li); };
+                const float us = time_us(fn, 5);
+                if (r > 0) { best[li][c] = std::fmin(best[li][c], (double)us); sum[li][c] += us; }
+            }
+        }
+    CK(hipDeviceSynchronize());
+    for (int c = 0; c < 4; ++c)
+        printf("  %-18s A %7.1f us (min %7.1f) %5.0f TF | B %7.1f us (min %7.1f) %5.0f TF | B/A time %.3f\n", names[c], sum[0][c] / rounds, best[0][c], fl[c] / (sum[0][c] / rounds) / 1e6,
+               sum[1][c] / rounds, best[1][c], fl[c] / (sum[1][c] / rounds) / 1e6, sum[1][c] / sum[0][c]);
+    auto cmp16 = [&](const char* n, uint16_t* a, uint16_t* b, size_t cnt) { auto ha = host(a, cnt), hb = host(b, cnt); size_t d = count_diff(ha, hb); size_t nz = 0; for (auto v : hb) nz += v != 0; printf("  %-12s %zu values (%zu non-zero), %zu differ bitwise%s\n", n, cnt, nz, d, d ? "  <-- EXPECTED IDENTICAL" : "  identical"); };
+    cmp16("ffin", o_ffin[0], o_ffin[1], (size_t)M * F2); cmp16("dh2", o_dh2[0], o_dh2[1], (size_t)M * Fp); cmp16("dxn2", o_dxn2[0], o_dxn2[1], (size_t)M * D);
+    { auto ha = host(o_ffout[0], (size_t)M * D), hb = host(o_ffout[1], (size_t)M * D); report("ffout", compare(ha, hb), true); }
+    for (int li = 0; li < 2; ++li) { CK(hipFree(o_ffin[li])); CK(hipFree(o_dh2[li])); CK(hipFree(o_dxn2[li])); CK(hipFree(o_ffout[li])); }
+    CK(hipFree(dX)); CK(hipFree(dW1)); CK(hipFree(dH1)); CK(hipFree(dH2)); CK(hipFree(dW2)); CK(hipFree(dR));
+}
 
 // ConvFeedForward middle, bf16 operands, coarse-small micro-batch (M = 32 x 1116 rows, F = 2730 -> Fp = 2736), dropout 0.1 through
 // the stored keep bits, gh saved: the configuration of the training step.
@@ -472,7 +513,9 @@ int main(int argc, char** argv) {
             else if (!strcmp(argv[i], "gemm")) gemm_case(*libs[0], *libs[v]);
             else if (!strcmp(argv[i], "gemm_edge")) gemm_edge_case(*libs[0], *libs[v]);
             else if (!strcmp(argv[i], "gemm_sq")) gemm_square_case(*libs[0], *libs[v]);
+            else if (!strcmp(argv[i], "gemm5")) gemm5_case(*libs[0], *libs[v]);
             else if (!strcmp(argv[i], "wgrad")) wgrad_case(*libs[0], *libs[v]);
+            else if (!strcmp(argv[i], "wgrad5")) wgrad_case(*libs[0], *libs[v], 64);        // K = 35648: whole 64-deep k-tiles (the step's own K = 35712 is one too)
             else if (!strcmp(argv[i], "ffmid")) ffmid_case(*libs[0], *libs[v]);
             else if (!strcmp(argv[i], "ln")) ln_case(*libs[0], *libs[v]);
             else if (!strcmp(argv[i], "decode")) { decode_case(*libs[0], *libs[v], 1); decode_case(*libs[0], *libs[v], 8); }
