@@ -221,6 +221,18 @@ int omlm_relpos_first_bwd(const float* ds, float* dw0, int n, int Hd, void* stre
 int omlm_bias_silu_fwd(const float* a, const float* b, float* pre, float* z, long long R, int C, void* stream);
 int omlm_silu_bwd(const float* dz, const float* pre, float* ds, long long total, void* stream);
 int omlm_bias_add(const float* a, const float* b, float* out, int R, int C, int ld, void* stream);
+/* The whole MLP as ONE forward launch and TWO backward launches (round 5; Hd = 256 or 512, H <= 16: every shipped config), replacing the
+ * 21 launches of the layer-by-layer path above.  RelativePositionBias.forward (transformer.py:55-64) restricted to the n causal distances
+ * 0 .. n - 1: table[r, h] = net(r)[h].  w0 = net.0.0.weight viewed [Hd]; W1 / W2 = net.1.0 / net.2.0 weights [Hd, Hd]; W3 = net.3.weight
+ * [H, Hd].  pre* / z* [n, Hd] are the layers' pre-activations / SiLU outputs, written by the forward when non-null (all or none) and
+ * read by the backward; table / dtable are [n, ldb] (ldb <= 16, pad columns zero).  The backward ACCUMULATES into the g* buffers
+ * (deterministic: one owner thread per element, rows summed in ascending order); scratch holds 3 * n * Hd floats. */
+int omlm_relpos_mlp_fwd(const float* w0, const float* b0, const float* W1, const float* b1, const float* W2, const float* b2,
+                        const float* W3, const float* b3, float* pre0, float* z0, float* pre1, float* z1, float* pre2, float* z2,
+                        float* table, int n, int Hd, int H, int ldb, void* stream);
+int omlm_relpos_mlp_bwd(const float* dtable, const float* W1, const float* W2, const float* W3, const float* pre0, const float* z0,
+                        const float* pre1, const float* z1, const float* pre2, const float* z2, float* scratch, float* gw0, float* gb0,
+                        float* gW1, float* gb1, float* gW2, float* gb2, float* gW3, float* gb3, int n, int Hd, int H, int ldb, void* stream);
 
 /* Nearest-codeword kernels: ClapQuantized.quantize -> ResidualVQ eval path (clap_quantized.py:75-87) and
  * HfHubertWithKmeans assign (hf_hubert_kmeans.py:87).  codebooks_T: [nstage][D][C] (transposed); indices int32 [n, nstage].

@@ -311,6 +311,321 @@ extern "C" int omlm_relpos_first_bwd(const float* ds, float* dw0, int n, int Hd,
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Fused rel-pos MLP (round 5).  The continuous relative-position bias (reference transformer.py:36-67) is Linear(1, Hd) + SiLU,
+// 2 x [Linear(Hd, Hd) + SiLU], Linear(Hd, H) on the n causal distances 0 .. n - 1: 0.6 GMAC forward for coarse-small -- which ran as
+// 7 forward and 14 backward launches (three latency-bound register-staged fp32 GEMMs each way, 25-50 us apiece at 12-19 TFLOP/s, plus
+// element-wise and column-sum kernels: ~0.4 ms of the 23.5 ms step).  Rows are independent, so a workgroup carries RB rows through ALL
+// layers with its activations in LDS: ONE forward launch and, for the backward, one row-chain launch (d(pre) of every layer) plus one
+// launch for every weight / bias gradient (each output element owned by one thread: plain += into the gradient buffers, fixed
+// summation order -- deterministic, which the 16-bit modes downstream need: DESIGN.md section 4.1, round 4).  True fp32 FMAs.
+// Hd must be a multiple of 256 (512 in every shipped config); other widths keep the launch-per-layer path (engine.relpos_forward).
+struct relpos_mlp_params {
+    const float *w0, *b0, *W1, *b1, *W2, *b2, *W3, *b3;      // net.0.0.weight [Hd] (as a vector), .bias; net.1.0 / net.2.0 [Hd, Hd]; net.3 [H, Hd], [H]
+    float *pre0, *z0, *pre1, *z1, *pre2, *z2;                // [n, Hd] each: saved for the backward (forward: written when non-null)
+    float* table;                                            // forward out [n, ldb] (pad columns zeroed)
+    const float* dtable;                                     // backward in [n, ldb]
+    float *ds0, *ds1, *ds2;                                  // backward scratch [n, Hd]: d(pre) of layers 0 .. 2
+    float *gw0, *gb0, *gW1, *gb1, *gW2, *gb2, *gW3, *gb3;    // gradient buffers (accumulated into)
+    int n, Hd, H, ldb;
+};
+__device__ __forceinline__ float silu_f(float s) { return s / (1.0f + __expf(-s)); }
+__device__ __forceinline__ float silu_grad_f(float s) { const float sg = 1.0f / (1.0f + __expf(-s)); return sg * (1.0f + s * (1.0f - sg)); }
+
+template <int CPT, int RB>
+__global__ __launch_bounds__(256) void relpos_mlp_fwd_kernel(relpos_mlp_params a) {
+    constexpr int KC = 32, WP = KC + 1, Hd = 256 * CPT;
+    extern __shared__ float rp_sm[];
+    float* zA = rp_sm;                      // [RB][Hd]
+    float* zB = zA + RB * Hd;               // [RB][Hd]
+    float* wt = zB + RB * Hd;               // [Hd][WP]: a k-chunk of the layer's weight, row = output column
+    const int t = threadIdx.x, r0 = blockIdx.x * RB;
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int c = t + 256 * j, row = r0 + r;
+            const float s = (float)row * a.w0[c] + a.b0[c], z = silu_f(s);
+            zA[r * Hd + c] = z;
+            if (a.pre0 && row < a.n) { a.pre0[(size_t)row * Hd + c] = s; a.z0[(size_t)row * Hd + c] = z; }
+        }
+    __syncthreads();
+#pragma unroll 1
+    for (int layer = 1; layer <= 2; ++layer) {
+        const float* W = layer == 1 ? a.W1 : a.W2;
+        const float* bias = layer == 1 ? a.b1 : a.b2;
+        const float* zin = layer == 1 ? zA : zB;
+        float* zout = layer == 1 ? zB : zA;
+        float* pre = layer == 1 ? a.pre1 : a.pre2;
+        float* zsv = layer == 1 ? a.z1 : a.z2;
+        float acc[RB][CPT];
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) acc[r][j] = 0.f;
+#pragma unroll 1
+        for (int k0 = 0; k0 < Hd; k0 += KC) {
+            // W[:, k0 .. k0 + 32) -> wt (128-byte row segments, coalesced; pitch 33 floats: conflict-free column reads below)
+#pragma unroll
+            for (int i = 0; i < (Hd * KC / 4) / 256; ++i) {
+                const int idx = t + 256 * i, row = idx >> 3, q = idx & 7;
+                const float4 v = *(const float4*)(W + (size_t)row * Hd + k0 + 4 * q);
+                float* d = wt + row * WP + 4 * q;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < KC; kk += 4) {
+                float4 zv[RB];
+#pragma unroll
+                for (int r = 0; r < RB; ++r) zv[r] = *(const float4*)(zin + r * Hd + k0 + kk);      // same address in every lane: broadcast
+#pragma unroll
+                for (int j = 0; j < CPT; ++j) {
+                    const float* wr = wt + (t + 256 * j) * WP + kk;
+                    const float w0_ = wr[0], w1_ = wr[1], w2_ = wr[2], w3_ = wr[3];
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) {
+                        float v = acc[r][j];
+                        v = fmaf(zv[r].x, w0_, v); v = fmaf(zv[r].y, w1_, v); v = fmaf(zv[r].z, w2_, v); v = fmaf(zv[r].w, w3_, v);
+                        acc[r][j] = v;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) {
+                const int c = t + 256 * j, row = r0 + r;
+                const float s = acc[r][j] + bias[c], z = silu_f(s);
+                zout[r * Hd + c] = z;
+                if (pre && row < a.n) { pre[(size_t)row * Hd + c] = s; zsv[(size_t)row * Hd + c] = z; }
+            }
+        __syncthreads();
+    }
+    // last layer: table[row][h] = z2[row] . W3[h] + b3[h]; (row, h) pairs over groups of 4 lanes (each a quarter of k), fixed order
+    const float* zf = zA;                   // layer 2 wrote zA
+    for (int o = t >> 2; o < RB * a.ldb; o += 64) {
+        const int r = o / a.ldb, h = o - r * a.ldb, part = t & 3, row = r0 + r;
+        float v = 0.f;
+        if (h < a.H) {
+            const float* w = a.W3 + (size_t)h * Hd + part * (Hd / 4);
+            const float* z = zf + r * Hd + part * (Hd / 4);
+            for (int k = 0; k < Hd / 4; ++k) v = fmaf(z[k], w[k], v);
+        }
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        if (part == 0 && row < a.n) a.table[(size_t)row * a.ldb + h] = h < a.H ? v + a.b3[h] : 0.f;
+    }
+}
+
+// backward, row chain: ds2 = (dtable W3) * silu'(pre2); ds1 = (ds2 W2) * silu'(pre1); ds0 = (ds1 W1) * silu'(pre0).  A thread owns CPT input
+// columns k and streams the weight rows W[c][k] (coalesced along k) against the row block's d(pre) values broadcast from LDS.
+template <int CPT, int RB>
+__global__ __launch_bounds__(256) void relpos_mlp_bwd_rows_kernel(relpos_mlp_params a) {
+    constexpr int Hd = 256 * CPT;
+    extern __shared__ float rp_sm[];
+    float* dA = rp_sm;                      // [RB][Hd]
+    float* dB = dA + RB * Hd;               // [RB][Hd]
+    float* dt = dB + RB * Hd;               // [RB][16]: the block's dtable rows (H <= 16)
+    const int t = threadIdx.x, r0 = blockIdx.x * RB;
+    if (t < RB * 16) {
+        const int r = t >> 4, h = t & 15, row = r0 + r;
+        dt[t] = (h < a.H && row < a.n) ? a.dtable[(size_t)row * a.ldb + h] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int k = t + 256 * j;
+        float acc[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r] = 0.f;
+        for (int h = 0; h < a.H; ++h) {
+            const float w = a.W3[(size_t)h * Hd + k];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) acc[r] = fmaf(dt[r * 16 + h], w, acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int row = r0 + r;
+            const float ds = row < a.n ? acc[r] * silu_grad_f(a.pre2[(size_t)row * Hd + k]) : 0.f;
+            dA[r * Hd + k] = ds;
+            if (row < a.n) a.ds2[(size_t)row * Hd + k] = ds;
+        }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int layer = 2; layer >= 1; --layer) {
+        const float* W = layer == 2 ? a.W2 : a.W1;           // dz_{layer-1}[r][k] = sum_c ds_layer[r][c] W[c][k]
+        const float* din = layer == 2 ? dA : dB;
+        float* dout = layer == 2 ? dB : dA;
+        const float* pre = layer == 2 ? a.pre1 : a.pre0;
+        float* dsg = layer == 2 ? a.ds1 : a.ds0;
+        float acc[RB][CPT];
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) acc[r][j] = 0.f;
+#pragma unroll 2
+        for (int c0 = 0; c0 < Hd; c0 += 4) {
+            float w[4][CPT];
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int j = 0; j < CPT; ++j) w[x][j] = W[(size_t)(c0 + x) * Hd + t + 256 * j];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const float4 d = *(const float4*)(din + r * Hd + c0);
+#pragma unroll
+                for (int j = 0; j < CPT; ++j) {
+                    float v = acc[r][j];
+                    v = fmaf(d.x, w[0][j], v); v = fmaf(d.y, w[1][j], v); v = fmaf(d.z, w[2][j], v); v = fmaf(d.w, w[3][j], v);
+                    acc[r][j] = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) {
+                const int k = t + 256 * j, row = r0 + r;
+                const float ds = row < a.n ? acc[r][j] * silu_grad_f(pre[(size_t)row * Hd + k]) : 0.f;
+                dout[r * Hd + k] = ds;
+                if (row < a.n) dsg[(size_t)row * Hd + k] = ds;
+            }
+        __syncthreads();
+    }
+}
+
+// backward, parameter gradients.  blockIdx.x enumerates 64 x 64 output tiles: [0, T2) of gW2 (+ gb2 on its first tile column), [T2, 2 T2) of
+// gW1 (+ gb1), then Hd / 64 workgroups for gW3 / gb3 (8 .. 16 x 64 columns) and Hd / 64 for gw0 / gb0.  Every output element belongs to
+// one thread and is accumulated over the n rows in ascending order.
+__global__ __launch_bounds__(256) void relpos_mlp_bwd_params_kernel(relpos_mlp_params a) {
+    __shared__ float sd[16][64 + 1], sz[16][64 + 1];
+    const int Hd = a.Hd, TPD = Hd / 64, T2 = TPD * TPD;
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    int b = blockIdx.x;
+    if (b < 2 * T2) {
+        const bool second = b >= T2;
+        if (second) b -= T2;
+        const float* ds = second ? a.ds1 : a.ds2;            // [n, Hd] rows = tokens, cols = output feature c
+        const float* z = second ? a.z0 : a.z1;               // [n, Hd] cols = input feature k
+        float* gW = second ? a.gW1 : a.gW2;
+        float* gb = second ? a.gb1 : a.gb2;
+        const int c0 = (b / TPD) * 64, k0 = (b % TPD) * 64;
+        float acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+        float bacc = 0.f;                                    // thread t < 64 of a k0 == 0 tile: column sum of ds (the bias gradient)
+        for (int r0 = 0; r0 < a.n; r0 += 16) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                    // 16 rows x 64 cols of each operand: 1024 floats / 256 threads
+                const int idx = t + 256 * i, rr = idx >> 6, cc = idx & 63, row = r0 + rr;
+                sd[rr][cc] = row < a.n ? ds[(size_t)row * Hd + c0 + cc] : 0.f;
+                sz[rr][cc] = row < a.n ? z[(size_t)row * Hd + k0 + cc] : 0.f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                float dv[4], zv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { dv[i] = sd[rr][ty + 16 * i]; zv[i] = sz[rr][tx + 16 * i]; }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(dv[i], zv[j], acc[i][j]);
+                if (k0 == 0 && t < 64) bacc += sd[rr][t];
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gW[(size_t)(c0 + ty + 16 * i) * Hd + k0 + tx + 16 * j] += acc[i][j];
+        if (k0 == 0 && t < 64) gb[c0 + t] += bacc;
+        return;
+    }
+    b -= 2 * T2;
+    if (b < TPD) {
+        // gW3[h][k] += sum_r dtable[r][h] z2[r][k] for 64 columns k; gb3[h] += sum_r dtable[r][h] (first of these workgroups)
+        const int k = b * 64 + (t & 63), hq = t >> 6;          // 4 head groups of up to 4 heads
+        float acc[4] = {0.f, 0.f, 0.f, 0.f}, bsum = 0.f;
+        for (int r = 0; r < a.n; ++r) {
+            const float zv = a.z2[(size_t)r * Hd + k];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const int h = hq * 4 + i; if (h < a.H) acc[i] = fmaf(a.dtable[(size_t)r * a.ldb + h], zv, acc[i]); }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int h = hq * 4 + i; if (h < a.H) a.gW3[(size_t)h * Hd + k] += acc[i]; }
+        if (b == 0 && t < a.H) { for (int r = 0; r < a.n; ++r) bsum += a.dtable[(size_t)r * a.ldb + t]; a.gb3[t] += bsum; }
+        return;
+    }
+    b -= TPD;
+    {   // gw0[c] += sum_r r ds0[r][c]; gb0[c] += sum_r ds0[r][c]: 64 columns, 4 row lanes, combined in a fixed order
+        __shared__ float red[2][4][64];
+        const int c = b * 64 + (t & 63), rl = t >> 6;
+        float sw = 0.f, sb = 0.f;
+        for (int r = rl; r < a.n; r += 4) { const float v = a.ds0[(size_t)r * Hd + c]; sw = fmaf((float)r, v, sw); sb += v; }
+        red[0][rl][t & 63] = sw; red[1][rl][t & 63] = sb;
+        __syncthreads();
+        if (rl == 0) {
+            a.gw0[c] += (red[0][0][t] + red[0][1][t]) + (red[0][2][t] + red[0][3][t]);
+            a.gb0[c] += (red[1][0][t] + red[1][1][t]) + (red[1][2][t] + red[1][3][t]);
+        }
+    }
+}
+
+extern "C" int omlm_relpos_mlp_fwd(const float* w0, const float* b0, const float* W1, const float* b1, const float* W2, const float* b2,
+                                   const float* W3, const float* b3, float* pre0, float* z0, float* pre1, float* z1, float* pre2, float* z2,
+                                   float* table, int n, int Hd, int H, int ldb, void* stream) {
+    OMLM_CHECK_ARG(w0 && b0 && W1 && b1 && W2 && b2 && W3 && b3 && table && n > 0, "relpos_mlp_fwd: null argument");
+    OMLM_CHECK_ARG((Hd == 256 || Hd == 512) && H >= 1 && H <= 16 && ldb >= H && ldb <= 16, "relpos_mlp_fwd: Hd must be 256 or 512, H <= 16");
+    OMLM_CHECK_ARG(!pre0 || (z0 && pre1 && z1 && pre2 && z2), "relpos_mlp_fwd: save buffers come all or none");
+    relpos_mlp_params a;
+    memset(&a, 0, sizeof(a));
+    a.w0 = w0; a.b0 = b0; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3;
+    a.pre0 = pre0; a.z0 = z0; a.pre1 = pre1; a.z1 = z1; a.pre2 = pre2; a.z2 = z2; a.table = table; a.n = n; a.Hd = Hd; a.H = H; a.ldb = ldb;
+    constexpr int RB = 8;
+    const size_t lds = (size_t)(2 * RB * Hd + Hd * 33) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)relpos_mlp_fwd_kernel<2, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((2 * RB * 512 + 512 * 33) * 4));
+        (void)hipFuncSetAttribute((const void*)relpos_mlp_fwd_kernel<1, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((2 * RB * 256 + 256 * 33) * 4));
+        attr = true;
+    }
+    const dim3 grid((n + RB - 1) / RB);
+    if (Hd == 512) hipLaunchKernelGGL((relpos_mlp_fwd_kernel<2, RB>), grid, dim3(256), lds, as_stream(stream), a);
+    else           hipLaunchKernelGGL((relpos_mlp_fwd_kernel<1, RB>), grid, dim3(256), lds, as_stream(stream), a);
+    return omlm_post_launch("omlm_relpos_mlp_fwd");
+}
+
+// scratch: 3 * n * Hd floats (ds0 | ds1 | ds2).  Gradients are ACCUMULATED into g* (fp32, the optimizer's flat buffer views).
+extern "C" int omlm_relpos_mlp_bwd(const float* dtable, const float* W1, const float* W2, const float* W3, const float* pre0, const float* z0,
+                                   const float* pre1, const float* z1, const float* pre2, const float* z2, float* scratch, float* gw0, float* gb0,
+                                   float* gW1, float* gb1, float* gW2, float* gb2, float* gW3, float* gb3, int n, int Hd, int H, int ldb, void* stream) {
+    OMLM_CHECK_ARG(dtable && W1 && W2 && W3 && pre0 && z0 && pre1 && z1 && pre2 && z2 && scratch && gw0 && gb0 && gW1 && gb1 && gW2 && gb2 && gW3 && gb3 && n > 0,
+                   "relpos_mlp_bwd: null argument");
+    OMLM_CHECK_ARG((Hd == 256 || Hd == 512) && H >= 1 && H <= 16 && ldb >= H && ldb <= 16, "relpos_mlp_bwd: Hd must be 256 or 512, H <= 16");
+    relpos_mlp_params a;
+    memset(&a, 0, sizeof(a));
+    a.W1 = W1; a.W2 = W2; a.W3 = W3; a.pre0 = (float*)pre0; a.z0 = (float*)z0; a.pre1 = (float*)pre1; a.z1 = (float*)z1; a.pre2 = (float*)pre2; a.z2 = (float*)z2;
+    a.dtable = dtable; a.ds0 = scratch; a.ds1 = scratch + (size_t)n * Hd; a.ds2 = scratch + 2 * (size_t)n * Hd;
+    a.gw0 = gw0; a.gb0 = gb0; a.gW1 = gW1; a.gb1 = gb1; a.gW2 = gW2; a.gb2 = gb2; a.gW3 = gW3; a.gb3 = gb3; a.n = n; a.Hd = Hd; a.H = H; a.ldb = ldb;
+    constexpr int RB = 8;
+    const size_t lds = (size_t)(2 * RB * Hd + RB * 16) * sizeof(float);
+    const dim3 grid((n + RB - 1) / RB);
+    if (Hd == 512) hipLaunchKernelGGL((relpos_mlp_bwd_rows_kernel<2, RB>), grid, dim3(256), lds, as_stream(stream), a);
+    else           hipLaunchKernelGGL((relpos_mlp_bwd_rows_kernel<1, RB>), grid, dim3(256), lds, as_stream(stream), a);
+    int rc = omlm_post_launch("omlm_relpos_mlp_bwd (rows)");
+    if (rc) return rc;
+    const int tpd = Hd / 64;
+    hipLaunchKernelGGL(relpos_mlp_bwd_params_kernel, dim3(2 * tpd * tpd + 2 * tpd), dim3(256), 0, as_stream(stream), a);
+    return omlm_post_launch("omlm_relpos_mlp_bwd (parameters)");
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Residual-VQ / k-means nearest-codeword (clap_quantized.py:75-87 -> ResidualVQ eval path; hf_hubert_kmeans.py:87).
 // cbT is the codebook TRANSPOSED: [n_stage][D][C], so that consecutive threads (codes) read consecutive addresses.  Two stated
 // distance forms, both in fp32 with every multiply and add rounded separately (no FMA contraction), d in index order:

@@ -54,6 +54,9 @@ _KV_DGRAD_H16 = os.environ.get("OMLM_KV_DGRAD_H16", "1") == "1"
 # (ops.gemm_qknorm): q, k, v leave them in the operand type with the per-(row, head) norms in fp32 -- no fp32 q_raw / kv_raw, no qk_norm
 # forward launch, and the backward derives xh = y / scale from the saved operand.  OMLM_QKNORM_FUSED=0: separate kernels on fp32 projections.
 _QKNORM_FUSED = os.environ.get("OMLM_QKNORM_FUSED", "1") == "1"
+# The rel-pos MLP as one fused forward launch + two backward launches (round 5; Hd = 256 / 512).  OMLM_RELPOS_FUSED=0: the layer-by-layer path
+# (7 + 14 launches, three register-staged fp32 GEMMs each way).
+_RELPOS_FUSED = os.environ.get("OMLM_RELPOS_FUSED", "1") == "1"
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 
 
@@ -332,6 +335,13 @@ def relpos_forward(tr, n: int, save: bool):
         return table, ("t5", bucket)
     lin = [rp.net[0][0], rp.net[1][0], rp.net[2][0], rp.net[3]]
     Hd = lin[0].weight.shape[0]
+    if _RELPOS_FUSED and Hd in (256, 512) and H <= 16 and len(rp.net) == 4:
+        # one launch for the whole MLP (csrc/optim_misc.hip relpos_mlp_fwd_kernel; round 5): a workgroup carries 8 rows through all layers
+        saves = [torch.empty(n, Hd, device=dev) for _ in range(6)] if save else None
+        table = torch.empty(n, ldb, device=dev)
+        ops.relpos_mlp_fwd(lin[0].weight.detach().reshape(-1), lin[0].bias.detach(), lin[1].weight.detach(), lin[1].bias.detach(),
+                           lin[2].weight.detach(), lin[2].bias.detach(), lin[3].weight.detach(), lin[3].bias.detach(), saves, table, n, Hd, H, ldb)
+        return table, (("mlp_fused", saves) if save else None)
     pres, zs = [], []
     pre = torch.empty(n, Hd, device=dev)
     z = torch.empty(n, Hd, device=dev)
@@ -363,9 +373,15 @@ def relpos_backward(tr, n: int, saved, dtable: torch.Tensor):
         g = grad_of(rp.relative_attention_bias.weight)
         g.index_add_(0, saved[1], dtable[:, :H])
         return
-    _, pres, zs = saved
     lin = [rp.net[0][0], rp.net[1][0], rp.net[2][0], rp.net[3]]
     Hd = lin[0].weight.shape[0]
+    if saved[0] == "mlp_fused":
+        scratch = torch.empty(3 * n * Hd, device=dev)
+        grads = [grad_of(lin[0].weight).view(-1), grad_of(lin[0].bias), grad_of(lin[1].weight), grad_of(lin[1].bias),
+                 grad_of(lin[2].weight), grad_of(lin[2].bias), grad_of(lin[3].weight), grad_of(lin[3].bias)]
+        ops.relpos_mlp_bwd(dtable, lin[1].weight.detach(), lin[2].weight.detach(), lin[3].weight.detach(), saved[1], scratch, grads, n, Hd, H, ldb)
+        return
+    _, pres, zs = saved
     # last layer: table = z2 @ W3^T + b3
     ops.colsum_accumulate(dtable, grad_of(lin[3].bias), n, H, ldb)
     gw = grad_of(lin[3].weight)                                           # [H, Hd]

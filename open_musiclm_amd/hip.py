@@ -66,6 +66,8 @@ SIGNATURES = {
     "omlm_bias_silu_fwd": [vp, vp, vp, vp, i64, i32, vp],
     "omlm_silu_bwd": [vp, vp, vp, i64, vp],
     "omlm_bias_add": [vp, vp, vp, i32, i32, i32, vp],
+    "omlm_relpos_mlp_fwd": [vp] * 15 + [i32, i32, i32, i32, vp],
+    "omlm_relpos_mlp_bwd": [vp] * 19 + [i32, i32, i32, i32, vp],
     "omlm_rvq_encode": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "omlm_nearest_centroid": [vp, vp, vp, i32, i32, i32, vp],
     "omlm_rvq_encode_strided": [vp, vp, vp, i32, vp, i32, i32, i32, vp],

@@ -474,6 +474,19 @@ def bias_add(a, b, out, R, C_, ld):
     call("omlm_bias_add", ptr(a), ptr(b), ptr(out), R, C_, ld, stream_ptr())
 
 
+def relpos_mlp_fwd(w0, b0, W1, b1, W2, b2, W3, b3, saves, table, n, Hd, H, ldb):
+    """The whole rel-pos MLP as one launch (omlm_relpos_mlp_fwd).  saves: None or [pre0, z0, pre1, z1, pre2, z2] ([n, Hd] fp32 each)."""
+    sv = saves if saves is not None else [None] * 6
+    call("omlm_relpos_mlp_fwd", ptr(w0), ptr(b0), ptr(W1), ptr(b1), ptr(W2), ptr(b2), ptr(W3), ptr(b3), *[ptr(t) for t in sv], ptr(table),
+         int(n), int(Hd), int(H), int(ldb), stream_ptr())
+
+
+def relpos_mlp_bwd(dtable, W1, W2, W3, saves, scratch, grads, n, Hd, H, ldb):
+    """Backward of the fused MLP: saves = [pre0, z0, pre1, z1, pre2, z2]; grads = [gw0, gb0, gW1, gb1, gW2, gb2, gW3, gb3] (accumulated into)."""
+    call("omlm_relpos_mlp_bwd", ptr(dtable), ptr(W1), ptr(W2), ptr(W3), *[ptr(t) for t in saves], ptr(scratch), *[ptr(g) for g in grads],
+         int(n), int(Hd), int(H), int(ldb), stream_ptr())
+
+
 def rvq_encode(x, codebooks_T, indices, residual_out, n, D, C_, nstage, idx_stride=None):
     """Residual-VQ chain in the library's distance form (-cdist, first maximum; csrc/optim_misc.hip FORM_CDIST).
     indices: int32 [n, nstage] (or, with nstage == 1, any int32 view whose rows are idx_stride elements apart)."""

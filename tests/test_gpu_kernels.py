@@ -223,6 +223,7 @@ def test_gemm_half_tile_ring_on_operand_planes_and_split_k(ops, dev):
     g = torch.Generator(device="cpu").manual_seed(99)
     M, N, K = 2048, 1024, 1024
     A, B = torch.randn(M, K, generator=g).to(dev), torch.randn(N, K, generator=g).to(dev)
+    dY, X = torch.randn(16384, 512, generator=g).half().to(dev), torch.randn(16384, 768, generator=g).half().to(dev)
     outs = {}
     old = {k: os.environ.get(k) for k in ("OMLM_GEMM_T8", "OMLM_GEMM_TILE")}
     try:
@@ -232,7 +233,6 @@ def test_gemm_half_tile_ring_on_operand_planes_and_split_k(ops, dev):
             C = torch.full((M, N), float("nan"), device=dev)
             ops.gemm(A, B, C, M=M, N=N, K=K)                                  # fp32 operands above the plane threshold
             # split-K: accumulate-into-C with few tiles and a long contraction (a weight-gradient shape, k-major fp16 operands)
-            dY, X = torch.randn(16384, 512, generator=g).half().to(dev), torch.randn(16384, 768, generator=g).half().to(dev)
             dW = torch.zeros(512, 768, device=dev)
             ops.gemm(dY, X, dW, M=512, N=768, K=16384, a_kmajor=True, b_kmajor=True, Cin=dW)
             outs[mode] = (C, dW, dY, X)
@@ -1200,3 +1200,49 @@ def test_index_guards_skip_and_flag(ops, dev):
     d = torch.full((3, ld), float("nan"), device=dev)
     ops.ce_bwd(logits, labels, lse, None, 1.0, d, V)
     assert bool((d[1] == 0).all()) and bool((d[2] == 0).all()) and torch.isfinite(d).all()
+
+
+@pytest.mark.parametrize("n,Hd,H", [(1116, 512, 8), (1817, 512, 16), (37, 256, 3)])
+def test_relpos_mlp_fused_kernels_vs_fp64(ops, dev, n, Hd, H):
+    """The rel-pos MLP (transformer.py:36-67) as one forward launch and two backward launches (round 5, csrc/optim_misc.hip) against torch
+    autograd in fp64 with nn.Linear-scale weights: the bias table, the saved activations' consistency (backward from the forward's own
+    saves) and all eight parameter gradients, ACCUMULATED onto non-zero buffers; the launches are deterministic (bit-equal repeats)."""
+    g = torch.Generator(device="cpu").manual_seed(n + Hd + H)
+    ldb = (H + 7) // 8 * 8
+    u = lambda *shape, fan: ((torch.rand(*shape, generator=g) * 2 - 1) / fan ** 0.5)
+    w0, b0 = u(Hd, fan=1), u(Hd, fan=1)
+    W1, b1, W2, b2 = u(Hd, Hd, fan=Hd), u(Hd, fan=Hd), u(Hd, Hd, fan=Hd), u(Hd, fan=Hd)
+    W3, b3 = u(H, Hd, fan=Hd), u(H, fan=Hd)
+    dtab = torch.zeros(n, ldb)
+    dtab[:, :H] = torch.randn(n, H, generator=g)
+    P = [t.double().requires_grad_(True) for t in (w0, b0, W1, b1, W2, b2, W3, b3)]
+    x = torch.arange(n, dtype=torch.float64)[:, None]
+    silu = torch.nn.functional.silu
+    h = silu(x * P[0][None, :] + P[1])
+    h = silu(h @ P[2].t() + P[3])
+    h = silu(h @ P[4].t() + P[5])
+    tab = h @ P[6].t() + P[7]
+    tab.backward(dtab[:, :H].double())
+    D = [t.to(dev) for t in (w0, b0, W1, b1, W2, b2, W3, b3)]
+    saves = [torch.empty(n, Hd, device=dev) for _ in range(6)]
+    table = torch.full((n, ldb), float("nan"), device=dev)
+    ops.relpos_mlp_fwd(*D, saves, table, n, Hd, H, ldb)
+    table2 = torch.full((n, ldb), float("nan"), device=dev)
+    ops.relpos_mlp_fwd(*D, None, table2, n, Hd, H, ldb)                      # the no-save form (decode / eval)
+    e_tab = relerr(table[:, :H], tab.detach())
+    init = [torch.randn(t.shape, generator=g) for t in (w0, b0, W1, b1, W2, b2, W3, b3)]
+    runs = []
+    for rep in range(2):
+        grads = [t.clone().to(dev) for t in init]
+        scratch = torch.empty(3 * n * Hd, device=dev)
+        ops.relpos_mlp_bwd(dtab.to(dev), D[2], D[4], D[6], saves, scratch, grads, n, Hd, H, ldb)
+        runs.append(grads)
+    torch.cuda.synchronize()
+    errs = {nm: relerr(gk.cpu().double() - i0.double(), p.grad) for nm, gk, i0, p in zip("w0 b0 W1 b1 W2 b2 W3 b3".split(), runs[0], init, P)}
+    same = all(torch.equal(a_, b_) for a_, b_ in zip(runs[0], runs[1]))
+    report(f"relpos_mlp_fused[{n},{Hd},{H}]", table=e_tab, grads=errs, deterministic=same)
+    assert torch.equal(table, table2) and not torch.isnan(table).any()
+    assert (table[:, H:] == 0).all()
+    assert e_tab < 2e-6, e_tab
+    assert same
+    assert max(errs.values()) < 5e-5, errs            # fp32 accumulation over up to 1817 rows, added to O(1) initial values
