@@ -2,7 +2,7 @@
 """Benchmark of the MI355X TokenConditionedTransformer hot path (BASELINE.json metric:
 "train steps/sec + AR tokens/sec, coarse-stage musiclm_small, 1/2/4/8 MI355X").
 
-    python bench.py --gpus N --steps K --warmup W [--precision bf16|fp16|bf16x3] [--batch B] [--accum A]
+    python bench.py --gpus N --steps K --warmup W [--precision fp16|bf16|bf16x3] [--batch B] [--accum A]
 
 One "step" = one optimizer step of the coarse stage of musiclm_small (dim 1024, depth 6, heads 8, conv-GEGLU FF,
 N = 1116 positions = 3 start + 13 clap + 200 semantic + 900 coarse ids -- the exact length the reference's data
@@ -11,10 +11,12 @@ forward + backward (forgetful mask on, FF dropout 0.1 on) + ONE gradient all-red
 are synthetic (seeded U{0..1023}) and already resident in HBM when the timed region starts; weights are the
 reference's random init (no checkpoints offline).  For N > 1 launch with torch.distributed.run (one rank per GPU).
 
-`value` = whole-job training samples/s (global batch * steps / s, max over ranks) of BASELINE config 2 in the
-precision it names ("bf16").  At N = 1 the same JSON line carries, under "legs", the other configurations of
-BASELINE.json measured in the same run:
-  legs.fp16         the same train step with IEEE-half operands (same MFMA rate as bf16): meets the north-star 1e-3 logits tolerance
+`value` = whole-job training samples/s (global batch * steps / s, max over ranks) of BASELINE config 2 in precision "fp16" since
+round 5: IEEE-half operands on the same matrix-core rate and the same bytes as the "bf16" the config names, and the 16-bit mode whose
+logits meet north_star's 1e-3 against the CPU reference at this model size (measured 8.1e-4 .. 9.5e-4 over 5 seeds and at the benchmarked
+batch; bf16 operands measure 7e-3 .. 8e-3 and cannot meet it).  At N = 1 the same JSON line carries, under "legs", the other
+configurations of BASELINE.json measured in the same run:
+  legs.bf16         the same train step with bf16 operands (the dtype BASELINE config 2 names; logits 7e-3 .. 8e-3: outside the tolerance)
   legs.bf16x3       the same train step with fp32 operands split hi/lo on the bf16 matrix cores (fp32-grade products)
   legs.large_fine   BASELINE config 4: musiclm_large fine stage (depth 24, heads 16, N = 1817, 5 fine quantizers)
   legs.e2e_generate BASELINE config 5: MusicLM.generate, 10 s (RVQ + 500 semantic + 2250 coarse + 3750 fine ids)
@@ -333,14 +335,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--precision", default=os.environ.get("OMLM_PRECISION", "bf16"), choices=["bf16", "fp16", "bf16x3"])
+    ap.add_argument("--precision", default=os.environ.get("OMLM_BENCH_PRECISION", "fp16"), choices=["bf16", "fp16", "bf16x3"])
     ap.add_argument("--batch", type=int, default=32, help="samples per GPU per optimizer step")
     ap.add_argument("--accum", type=int, default=1, help="micro-batches per optimizer step")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured HIP graph")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the fp16 / bf16x3 / large_fine / e2e_generate legs")
-    ap.add_argument("--legs", default="fp16,bf16x3,large_fine,e2e_generate")
+    ap.add_argument("--legs", default="bf16,bf16x3,large_fine,e2e_generate")
     ap.add_argument("--large-batch", type=int, default=16, help="samples per step of the large_fine leg")
     ap.add_argument("--decode-ids", type=int, default=48)
     args = ap.parse_args()
@@ -391,9 +393,10 @@ def main():
     samples_per_s = steps_per_s * args.batch * world
     flops_step = algorithmic_flops_per_sample() * args.batch
     model_tflops_per_gpu = flops_step / (dt / args.steps) / 1e12
-    parity = {"bf16": "logits <= 1.2e-2 rel vs CPU reference (measured 7.1e-3; bf16 operands cannot meet 1e-3)",
-              "fp16": "logits <= 1e-3 rel vs CPU reference (measured 8.9e-4 at this size; gradients <= 7.2e-3 of each tensor's max)",
-              "bf16x3": "logits <= 1e-3 rel vs CPU reference (measured 7.1e-5)"}
+    parity = {"bf16": "logits <= 1.2e-2 rel vs CPU reference (measured 7.1e-3 at B = 2, 7.8e-3 at the benchmarked B = 32; bf16 operands cannot meet 1e-3)",
+              "fp16": "logits <= 1e-3 rel vs CPU reference (measured 8.1e-4 .. 9.5e-4 over 5 seeds, 9.1e-4 at the benchmarked B = 32; "
+                      "every parameter gradient <= 1.5e-2 of its tensor's max; musiclm_large depth 24: 1.5e-3 .. 1.8e-3, profiles/r05_error_budget.md)",
+              "bf16x3": "logits <= 1e-3 rel vs CPU reference (measured 7.1e-5; 2.9e-4 at musiclm_large depth 24)"}
     out = {
         "metric": "train steps/sec + AR tokens/sec, coarse-stage musiclm_small",
         "value": round(samples_per_s, 3), "unit": "samples/s",
@@ -409,8 +412,8 @@ def main():
                                 f"one flat fp32 SUM all-reduce per step, torch.distributed backend {torch.distributed.get_backend()}"
                                 + (" -- DRY RUN: ranks share a GPU, not an RCCL / xGMI measurement" if dp.shared_gpu else " (RCCL over xGMI)")),
                    "parity": parity[args.precision] + " (tests/test_gpu_model.py)",
-                   "tolerance_meeting_modes": "legs.fp16 (logits <= 1e-3 at ~1.02x this step: IEEE-half operands on the same matrix-core rate), "
-                                              "legs.bf16x3 (fp32-grade, ~2.4x)"},
+                   "other_modes": "legs.bf16 (the dtype BASELINE config 2 names: ~0.98x this step, logits 7e-3 .. 8e-3 -- outside north_star's 1e-3), "
+                                  "legs.bf16x3 (fp32-grade products, ~2.5x: the mode that also meets 1e-3 at musiclm_large depth)"},
         "steps_per_sec": round(steps_per_s, 4),
         "model_tflops_per_gpu": round(model_tflops_per_gpu, 2),
         "model_flops_frac_of_bf16_peak": round(model_tflops_per_gpu / PEAK_TFLOPS, 4),
@@ -432,11 +435,11 @@ def main():
         # (separate FETCH_SIZE / WRITE_SIZE runs; counters cannot be read inside this process): B = 32 bf16 only
         traffic = detail = None
         tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
-        if os.path.exists(tpath) and args.precision == "bf16" and args.batch == 32 and args.accum == 1:
+        if os.path.exists(tpath) and args.precision in ("bf16", "fp16") and args.batch == 32 and args.accum == 1:
             try:
                 detail = json.load(open(tpath))
                 traffic = detail["fetch_bytes"] + detail["write_bytes"]
-                if detail.get("gemm_source_sha16") != gemm_source_sha16():
+                if detail.get("gemm_source_sha16") != gemm_source_sha16() or detail.get("precision", "bf16") != args.precision:
                     # the GEMM kernels changed since the PMC passes were taken: a stale byte count is worse than none
                     progress(f"profiles/gemm_traffic.json belongs to GEMM sources {detail.get('gemm_source_sha16')}, the tree has "
                              f"{gemm_source_sha16()}: roofline.traffic left null (re-run tools/pmc_gemm_traffic.sh)")
@@ -459,16 +462,18 @@ def main():
             main_leg.free()
         leg_notes = {
             "fp16": "same train step, precision fp16: IEEE-half operands on v_mfma_f32_32x32x16_f16 (the bf16 MFMA rate, 11 instead of 8 "
-                    "significand bits), static loss scale 4096 divided out inside the fused AdamW kernel: the 16-bit mode that meets "
-                    "the north-star 1e-3 logits tolerance",
+                    "significand bits), device-side dynamic loss scale divided out inside the fused AdamW kernel: the 16-bit mode that meets "
+                    "the north-star 1e-3 logits tolerance at musiclm_small depth",
+            "bf16": "same train step, precision bf16 (the dtype BASELINE config 2 names): bf16 operands on v_mfma_f32_32x32x16_bf16 -- same rate, "
+                    "same bytes, 8 significand bits: logits 7e-3 .. 8e-3 against the CPU reference",
             "bf16x3": "same train step, precision bf16x3 (fp32 operands split hi/lo on the bf16 matrix cores: fp32-grade products at a "
                       "third of the MFMA rate)"}
-        for prec in ("fp16", "bf16x3"):
+        for prec in ("bf16", "fp16", "bf16x3"):
             if prec not in legs or args.precision == prec:
                 continue
             leg = TrainLeg(dev, dp, stage="coarse", dim=1024, depth=6, heads=8, precision=prec, batch=args.batch,
                            accum=args.accum, use_graph=not args.no_graph)
-            k, w = (min(args.steps, 10), 2) if prec == "fp16" else (min(args.steps, 5), 1)
+            k, w = (min(args.steps, 10), 2) if prec in ("fp16", "bf16") else (min(args.steps, 5), 1)
             dt3, loss3 = leg.timed(k, w)
             tf3 = flops_step / (dt3 / k) / 1e12
             out["legs"][prec] = {

@@ -362,17 +362,26 @@ __global__ __launch_bounds__(256) void relpos_mlp_fwd_kernel(relpos_mlp_params a
         for (int r = 0; r < RB; ++r)
 #pragma unroll
             for (int j = 0; j < CPT; ++j) acc[r][j] = 0.f;
+        // the layer's weight streams through LDS in chunks of 32 k: W[:, k0 .. k0 + 32) -> wt (128-byte row segments, coalesced; pitch 33
+        // floats: conflict-free column reads below).  The NEXT chunk is requested into registers before this chunk's FMAs (its L2 round trip
+        // runs under them) and written to LDS behind them.
+        constexpr int NV = (Hd * KC / 4) / 256;
+        float4 wreg[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { const int idx = t + 256 * i; wreg[i] = *(const float4*)(W + (size_t)(idx >> 3) * Hd + 4 * (idx & 7)); }
 #pragma unroll 1
         for (int k0 = 0; k0 < Hd; k0 += KC) {
-            // W[:, k0 .. k0 + 32) -> wt (128-byte row segments, coalesced; pitch 33 floats: conflict-free column reads below)
 #pragma unroll
-            for (int i = 0; i < (Hd * KC / 4) / 256; ++i) {
-                const int idx = t + 256 * i, row = idx >> 3, q = idx & 7;
-                const float4 v = *(const float4*)(W + (size_t)row * Hd + k0 + 4 * q);
-                float* d = wt + row * WP + 4 * q;
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            for (int i = 0; i < NV; ++i) {
+                const int idx = t + 256 * i;
+                float* d = wt + (idx >> 3) * WP + 4 * (idx & 7);
+                d[0] = wreg[i].x; d[1] = wreg[i].y; d[2] = wreg[i].z; d[3] = wreg[i].w;
             }
             __syncthreads();
+            if (k0 + KC < Hd) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) { const int idx = t + 256 * i; wreg[i] = *(const float4*)(W + (size_t)(idx >> 3) * Hd + k0 + KC + 4 * (idx & 7)); }
+            }
 #pragma unroll
             for (int kk = 0; kk < KC; kk += 4) {
                 float4 zv[RB];
@@ -466,20 +475,34 @@ __global__ __launch_bounds__(256) void relpos_mlp_bwd_rows_kernel(relpos_mlp_par
         for (int r = 0; r < RB; ++r)
 #pragma unroll
             for (int j = 0; j < CPT; ++j) acc[r][j] = 0.f;
-#pragma unroll 2
-        for (int c0 = 0; c0 < Hd; c0 += 4) {
-            float w[4][CPT];
+        float wn[8][CPT];                                     // weight rows c0 .. c0 + 7 of the NEXT step, requested one step ahead
 #pragma unroll
-            for (int x = 0; x < 4; ++x)
+        for (int x = 0; x < 8; ++x)
 #pragma unroll
-                for (int j = 0; j < CPT; ++j) w[x][j] = W[(size_t)(c0 + x) * Hd + t + 256 * j];
+            for (int j = 0; j < CPT; ++j) wn[x][j] = W[(size_t)x * Hd + t + 256 * j];
+#pragma unroll 1
+        for (int c0 = 0; c0 < Hd; c0 += 8) {
+            float w[8][CPT];
+#pragma unroll
+            for (int x = 0; x < 8; ++x)
+#pragma unroll
+                for (int j = 0; j < CPT; ++j) w[x][j] = wn[x][j];
+            if (c0 + 8 < Hd) {
+#pragma unroll
+                for (int x = 0; x < 8; ++x)
+#pragma unroll
+                    for (int j = 0; j < CPT; ++j) wn[x][j] = W[(size_t)(c0 + 8 + x) * Hd + t + 256 * j];
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
-                const float4 d = *(const float4*)(din + r * Hd + c0);
+                const float4 d = *(const float4*)(din + r * Hd + c0 + 4 * half);
 #pragma unroll
                 for (int j = 0; j < CPT; ++j) {
                     float v = acc[r][j];
-                    v = fmaf(d.x, w[0][j], v); v = fmaf(d.y, w[1][j], v); v = fmaf(d.z, w[2][j], v); v = fmaf(d.w, w[3][j], v);
+                    v = fmaf(d.x, w[4 * half + 0][j], v); v = fmaf(d.y, w[4 * half + 1][j], v);
+                    v = fmaf(d.z, w[4 * half + 2][j], v); v = fmaf(d.w, w[4 * half + 3][j], v);
                     acc[r][j] = v;
                 }
             }
@@ -549,30 +572,55 @@ __global__ __launch_bounds__(256) void relpos_mlp_bwd_params_kernel(relpos_mlp_p
     }
     b -= 2 * T2;
     if (b < TPD) {
-        // gW3[h][k] += sum_r dtable[r][h] z2[r][k] for 64 columns k; gb3[h] += sum_r dtable[r][h] (first of these workgroups)
-        const int k = b * 64 + (t & 63), hq = t >> 6;          // 4 head groups of up to 4 heads
-        float acc[4] = {0.f, 0.f, 0.f, 0.f}, bsum = 0.f;
-        for (int r = 0; r < a.n; ++r) {
-            const float zv = a.z2[(size_t)r * Hd + k];
+        // gW3[h][k] += sum_r dtable[r][h] z2[r][k] for 64 columns k (H <= 16 rows h); gb3[h] += sum_r dtable[r][h] (first of these
+        // workgroups).  Same row-chunk staging as above: thread (h = t >> 4, 4 columns).
+        const int k0 = b * 64, h = t >> 4, kx = t & 15;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f}, bacc = 0.f;
+        for (int r0 = 0; r0 < a.n; r0 += 16) {
+            {
+                const int rr = t >> 4, hh = t & 15, row = r0 + rr;            // 16 rows x 16 (padded) heads
+                sd[rr][hh] = (row < a.n && hh < a.H) ? a.dtable[(size_t)row * a.ldb + hh] : 0.f;
+            }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { const int h = hq * 4 + i; if (h < a.H) acc[i] = fmaf(a.dtable[(size_t)r * a.ldb + h], zv, acc[i]); }
+            for (int i = 0; i < 4; ++i) {
+                const int idx = t + 256 * i, rr = idx >> 6, cc = idx & 63, row = r0 + rr;
+                sz[rr][cc] = row < a.n ? a.z2[(size_t)row * Hd + k0 + cc] : 0.f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const float dv = sd[rr][h];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = fmaf(dv, sz[rr][kx + 16 * j], acc[j]);
+                if (b == 0 && t < 16) bacc += sd[rr][t];
+            }
+            __syncthreads();
         }
+        if (h < a.H) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { const int h = hq * 4 + i; if (h < a.H) a.gW3[(size_t)h * Hd + k] += acc[i]; }
-        if (b == 0 && t < a.H) { for (int r = 0; r < a.n; ++r) bsum += a.dtable[(size_t)r * a.ldb + t]; a.gb3[t] += bsum; }
+            for (int j = 0; j < 4; ++j) a.gW3[(size_t)h * Hd + k0 + kx + 16 * j] += acc[j];
+        }
+        if (b == 0 && t < a.H) a.gb3[t] += bacc;
         return;
     }
     b -= TPD;
-    {   // gw0[c] += sum_r r ds0[r][c]; gb0[c] += sum_r ds0[r][c]: 64 columns, 4 row lanes, combined in a fixed order
+    {   // gw0[c] += sum_r r ds0[r][c]; gb0[c] += sum_r ds0[r][c]: 64 columns per workgroup, rows staged 64 at a time, four row lanes
+        // combined in a fixed order
         __shared__ float red[2][4][64];
-        const int c = b * 64 + (t & 63), rl = t >> 6;
+        const int c0 = b * 64, cx = t & 63, rl = t >> 6;
         float sw = 0.f, sb = 0.f;
-        for (int r = rl; r < a.n; r += 4) { const float v = a.ds0[(size_t)r * Hd + c]; sw = fmaf((float)r, v, sw); sb += v; }
-        red[0][rl][t & 63] = sw; red[1][rl][t & 63] = sb;
+        for (int r0 = 0; r0 < a.n; r0 += 64) {
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { const int row = r0 + rl + 4 * i; v[i] = row < a.n ? a.ds0[(size_t)row * Hd + c0 + cx] : 0.f; }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { sw = fmaf((float)(r0 + rl + 4 * i), v[i], sw); sb += v[i]; }
+        }
+        red[0][rl][cx] = sw; red[1][rl][cx] = sb;
         __syncthreads();
         if (rl == 0) {
-            a.gw0[c] += (red[0][0][t] + red[0][1][t]) + (red[0][2][t] + red[0][3][t]);
-            a.gb0[c] += (red[1][0][t] + red[1][1][t]) + (red[1][2][t] + red[1][3][t]);
+            a.gw0[c0 + t] += (red[0][0][t] + red[0][1][t]) + (red[0][2][t] + red[0][3][t]);
+            a.gb0[c0 + t] += (red[1][0][t] + red[1][1][t]) + (red[1][2][t] + red[1][3][t]);
         }
     }
 }

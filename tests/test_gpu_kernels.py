@@ -1229,7 +1229,7 @@ def test_relpos_mlp_fused_kernels_vs_fp64(ops, dev, n, Hd, H):
     ops.relpos_mlp_fwd(*D, saves, table, n, Hd, H, ldb)
     table2 = torch.full((n, ldb), float("nan"), device=dev)
     ops.relpos_mlp_fwd(*D, None, table2, n, Hd, H, ldb)                      # the no-save form (decode / eval)
-    e_tab = relerr(table[:, :H], tab.detach())
+    e_tab = relerr(table[:, :H].cpu(), tab.detach())
     init = [torch.randn(t.shape, generator=g) for t in (w0, b0, W1, b1, W2, b2, W3, b3)]
     runs = []
     for rep in range(2):
@@ -1240,7 +1240,17 @@ def test_relpos_mlp_fused_kernels_vs_fp64(ops, dev, n, Hd, H):
     torch.cuda.synchronize()
     errs = {nm: relerr(gk.cpu().double() - i0.double(), p.grad) for nm, gk, i0, p in zip("w0 b0 W1 b1 W2 b2 W3 b3".split(), runs[0], init, P)}
     same = all(torch.equal(a_, b_) for a_, b_ in zip(runs[0], runs[1]))
-    report(f"relpos_mlp_fused[{n},{Hd},{H}]", table=e_tab, grads=errs, deterministic=same)
+    times = {}
+    for nm, fn in (("fwd_us", lambda: ops.relpos_mlp_fwd(*D, saves, table, n, Hd, H, ldb)),
+                   ("bwd_us", lambda: ops.relpos_mlp_bwd(dtab.to(dev), D[2], D[4], D[6], saves, scratch, grads, n, Hd, H, ldb))):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        times[nm] = e0.elapsed_time(e1) * 100.0
+    report(f"relpos_mlp_fused[{n},{Hd},{H}]", table=e_tab, grads=errs, deterministic=same, **times)
     assert torch.equal(table, table2) and not torch.isnan(table).any()
     assert (table[:, H:] == 0).all()
     assert e_tab < 2e-6, e_tab
