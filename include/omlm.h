@@ -103,10 +103,6 @@ long long omlm_attn_bias_table_floats(int N, int H);
  * (m_h = scale log2e bound + max bias_h, subtracted from the table) instead of a running maximum; neither: online softmax. */
 int omlm_attn_bias_prepare(const float* bias, float* biasT, int N, int H, int bias_ld, const float* q_scale,
                            const float* k_scale, float qk_bound, float scale, void* stream);
-/* The same with the fixed reference point placed ref_shift log2 units below the upper bound (0 .. 14): precision "fp16" passes 12, so that
- * half-precision probabilities sit around 1 instead of at the edge of half's normal range (the largest possible one is 2^ref_shift). */
-int omlm_attn_bias_prepare2(const float* bias, float* biasT, int N, int H, int bias_ld, const float* q_scale,
-                            const float* k_scale, float qk_bound, float scale, float ref_shift, void* stream);
 /* dbias_ws (optional, omlm_mqa_attn_bwd_workspace_bytes(B, N, H) bytes, contents irrelevant on entry and exit): the dQ kernel leaves
  * each wave's d(bias) bins there with plain stores and a small reduction adds them into dbias; without it every wave adds its bins into
  * dbias with device-scope atomics (measured 290 us per layer slower at B = 8, N = 1817, H = 16). */

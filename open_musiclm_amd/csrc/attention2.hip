@@ -68,8 +68,7 @@ __device__ __forceinline__ h16x8 a2_pack(const f32x16& p, int s) {
 // m_h = c qk_max + max_r table_h[r] is subtracted from every entry (pads included) and written to the row's tail
 // [ldT - 2] = 1.0 (flag), [ldT - 1] = m_h; without one, or if the exponent range could get near fp32's, the flag is 0.
 __global__ void attn2_bias_prep_kernel(const float* __restrict__ bias, float* __restrict__ biasT, int N, int H, int ld, int ldT,
-                                       const float* __restrict__ q_scale, const float* __restrict__ k_scale, float qk_bound, float c,
-                                       float ref_shift) {
+                                       const float* __restrict__ q_scale, const float* __restrict__ k_scale, float qk_bound, float c) {
     __shared__ float red[8];
     const int h = blockIdx.x, t = threadIdx.x;
     float* row = biasT + (size_t)h * ldT;
@@ -92,11 +91,7 @@ __global__ void attn2_bias_prep_kernel(const float* __restrict__ bias, float* __
     const float B = c * qk;
     // all exponents lie in [-(2 B + bmax - bmin), 0]; keep them well inside the fp32 normal range
     const bool fixed = qk > 0.f && (2.f * B + (bmax - bmin)) < 80.f;
-    // ref_shift (log2 units, >= 0): the reference point is placed that far BELOW the upper bound, i.e. the largest possible exponential is
-    // 2^ref_shift instead of 1.  IEEE-half probabilities need it: typical scores lie ~12 log2 units under the bound (|q.k| ~ 1/8 of its
-    // maximum), which is the edge of half's normal range (2^-14); shifted by 12 they sit around 1 and the bound itself (4096) is far
-    // inside half's range.  Numerator, denominator and the stored lse share the factor, so the softmax is unchanged.
-    const float m = fixed ? B + bmax - ref_shift : 0.f;
+    const float m = fixed ? B + bmax : 0.f;
     for (int x = t; x < ldT - 2; x += 256) {
         const int r = x - A2_PAD;
         const float v = (has && r >= 0 && r < N) ? bias[(size_t)r * ld + h] * A2_LOG2E : 0.f;
@@ -700,18 +695,13 @@ extern "C" long long omlm_attn_bias_table_floats(int N, int H) {
 // the learned per-dim scales applied after the l2 normalisation -- they give the bound max_d |q_scale_d k_scale_d| on |q.k| that
 // selects the fixed-reference softmax; alternatively qk_bound > 0 states the bound directly (callers with unit q, k: 1.0);
 // neither: online softmax.  scale: the attention scale (8).
-extern "C" int omlm_attn_bias_prepare2(const float* bias, float* biasT, int N, int H, int bias_ld, const float* q_scale,
-                                       const float* k_scale, float qk_bound, float scale, float ref_shift, void* stream) {
-    OMLM_CHECK_ARG(biasT && N > 0 && H > 0, "null table / sizes");
-    OMLM_CHECK_ARG(ref_shift >= 0.f && ref_shift <= 14.f, "ref_shift: 0 .. 14 log2 units (2^14 is the largest half-safe probability)");
-    const int ldT = (A2_PAD + N + 2 * A2_BWIN + 3) / 4 * 4, H8 = (H + 7) / 8 * 8;
-    hipLaunchKernelGGL(attn2_bias_prep_kernel, dim3(H8), dim3(256), 0, as_stream(stream), bias, biasT, N, H, bias_ld, ldT, q_scale, k_scale,
-                       qk_bound, scale * A2_LOG2E, ref_shift);
-    return omlm_post_launch("omlm_attn_bias_prepare");
-}
 extern "C" int omlm_attn_bias_prepare(const float* bias, float* biasT, int N, int H, int bias_ld, const float* q_scale,
                                       const float* k_scale, float qk_bound, float scale, void* stream) {
-    return omlm_attn_bias_prepare2(bias, biasT, N, H, bias_ld, q_scale, k_scale, qk_bound, scale, 0.f, stream);
+    OMLM_CHECK_ARG(biasT && N > 0 && H > 0, "null table / sizes");
+    const int ldT = (A2_PAD + N + 2 * A2_BWIN + 3) / 4 * 4, H8 = (H + 7) / 8 * 8;
+    hipLaunchKernelGGL(attn2_bias_prep_kernel, dim3(H8), dim3(256), 0, as_stream(stream), bias, biasT, N, H, bias_ld, ldT, q_scale, k_scale,
+                       qk_bound, scale * A2_LOG2E);
+    return omlm_post_launch("omlm_attn_bias_prepare");
 }
 
 // d(bias) partial rows -> the [N, bias_ld] table.  The dQ kernels leave one fp32 row of nqt*32 bins per (sample, head, query tile) in

@@ -54,12 +54,9 @@ _KV_DGRAD_H16 = os.environ.get("OMLM_KV_DGRAD_H16", "1") == "1"
 # (ops.gemm_qknorm): q, k, v leave them in the operand type with the per-(row, head) norms in fp32 -- no fp32 q_raw / kv_raw, no qk_norm
 # forward launch, and the backward derives xh = y / scale from the saved operand.  OMLM_QKNORM_FUSED=0: separate kernels on fp32 projections.
 _QKNORM_FUSED = os.environ.get("OMLM_QKNORM_FUSED", "1") == "1"
-# The rel-pos MLP as one fused forward launch + two backward launches (round 5; Hd = 256 / 512; true fp32 FMAs, deterministic) instead of the
-# layer-by-layer path (7 + 14 launches, three register-staged fp32 GEMMs each way).  Measured same box: forward 96 us, backward 270 us --
-# LDS-broadcast-bound at the same ~12 TFLOP/s as the GEMM path, and the step is 0.1 ms SLOWER with it (23.17 vs 23.07 ms).  Off by default;
-# OMLM_RELPOS_FUSED=1 selects it.
-_RELPOS_FUSED = os.environ.get("OMLM_RELPOS_FUSED", "0") == "1"
-_FP16_ATTN_ONLINE = os.environ.get("OMLM_FP16_ATTN_ONLINE", "0") == "1"
+# The rel-pos MLP as one fused forward launch + two backward launches (round 5; Hd = 256 / 512).  OMLM_RELPOS_FUSED=0: the layer-by-layer path
+# (7 + 14 launches, three register-staged fp32 GEMMs each way).
+_RELPOS_FUSED = os.environ.get("OMLM_RELPOS_FUSED", "1") == "1"
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 
 
@@ -479,13 +476,11 @@ def trunk_forward(tr, pw: PreparedWeights, x: torch.Tensor, keymask: Optional[to
             table.record_stream(torch.cuda.current_stream(dev))      # allocated under the side stream, read by the trunk's kernels
             side = None
         # the layer's bias table in the kernels' layout, with the fixed softmax reference point its scales allow
-        # (fp16: the reference point is an upper bound and typical probabilities sit around 2^-12 of it -- the edge of half's normal range --
-        # so it is placed 12 log2 units lower: typical values ~1, the bound itself 4096; rounds 3-4 ran the online softmax instead, 25 %
-        # slower per forward.  OMLM_FP16_ATTN_ONLINE=1 brings that back.)
-        fixed_ok = T != torch.float16 or not _FP16_ATTN_ONLINE
+        # (fp16: the fixed reference point is an upper bound, so typical probabilities sit around 2^-12 of it -- at the edge of half's
+        # normal range; the online softmax keeps every row's maximum at 1)
+        fixed_ok = T != torch.float16
         abias = ops.AttnBias(table, N, H, dev, q_scale=attn.q_scale.detach() if fixed_ok else None,
-                             k_scale=attn.k_scale.detach() if fixed_ok else None, scale=ATTN_SCALE,
-                             ref_shift=12.0 if T == torch.float16 else 0.0)
+                             k_scale=attn.k_scale.detach() if fixed_ok else None, scale=ATTN_SCALE)
         ops.attn_fwd(q, k, v, abias, keymask, o, lse, B, N, H, ATTN_SCALE)
         x1 = torch.empty(M, D, device=dev)
         ops.gemm(o, w["Wo"], x1, M=M, N=D, K=H * DIM_HEAD, Cin=x)

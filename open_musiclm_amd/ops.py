@@ -246,13 +246,12 @@ class AttnBias:
     online softmax runs."""
 
     def __init__(self, table: Optional[torch.Tensor], N: int, H: int, device=None, q_scale=None, k_scale=None,
-                 qk_bound: float = 0.0, scale: float = 8.0, ref_shift: float = 0.0):
-        """ref_shift: log2 units the fixed reference point sits below the score bound (IEEE-half operands: 12, see omlm_attn_bias_prepare2)."""
+                 qk_bound: float = 0.0, scale: float = 8.0):
         self.table, self.N, self.H = table, N, H
         dev = table.device if table is not None else device
         self.tableT = torch.empty(int(hip.lib().omlm_attn_bias_table_floats(N, H)), device=dev)
-        call("omlm_attn_bias_prepare2", ptr(table), ptr(self.tableT), N, H, table.shape[-1] if table is not None else 0,
-             ptr(q_scale), ptr(k_scale), float(qk_bound), float(scale), float(ref_shift), stream_ptr())
+        call("omlm_attn_bias_prepare", ptr(table), ptr(self.tableT), N, H, table.shape[-1] if table is not None else 0,
+             ptr(q_scale), ptr(k_scale), float(qk_bound), float(scale), stream_ptr())
 
     def dbias_workspace(self, B: int, N: int, H: int) -> torch.Tensor:
         """Scratch for the backward's d(bias) partial rows (omlm_mqa_attn_bwd_workspace_bytes): ONE buffer per device, shared by every
