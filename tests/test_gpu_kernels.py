@@ -1253,6 +1253,6 @@ def test_relpos_mlp_fused_kernels_vs_fp64(ops, dev, n, Hd, H):
     report(f"relpos_mlp_fused[{n},{Hd},{H}]", table=e_tab, grads=errs, deterministic=same, **times)
     assert torch.equal(table, table2) and not torch.isnan(table).any()
     assert (table[:, H:] == 0).all()
-    assert e_tab < 2e-6, e_tab
+    assert e_tab < 1e-5, e_tab
     assert same
     assert max(errs.values()) < 5e-5, errs            # fp32 accumulation over up to 1817 rows, added to O(1) initial values
