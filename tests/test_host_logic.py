@@ -801,3 +801,13 @@ def test_scheduler_rewind_after_device_skipped_steps():
     assert sch.last_epoch == 2 and abs(opt.param_groups[0]["lr"] - lrs[2]) < 1e-12 and abs(sch.get_last_lr()[0] - lrs[2]) < 1e-12
     opt.step(); sch.step()
     assert abs(opt.param_groups[0]["lr"] - lrs[3]) < 1e-12
+
+
+def test_gemm_half_tile_ring_schedule_model():
+    """The synchronisation of csrc/gemm.hip's gemm_tile8_body as a barrier-epoch model (tools/sim_gemm_t8_schedule.py): equal barrier counts
+    for both wave groups, every fragment read behind every wave's counted wait, every slot re-requested >= 2 barriers after its last read."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sim_t8", os.path.join(ROOT, "tools", "sim_gemm_t8_schedule.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert [m.check(nk) for nk in range(1, 9)] == [2 + 8 * nk for nk in range(1, 9)]
