@@ -56,7 +56,11 @@ def run(iters=300, burst=12):
              # more than one round of 256x256 tiles: the persistent walk (gemm_bf16_tile_persist_kernel) -- the next tile's first k-tile lands
              # in one LDS stage while the epilogue patches the other; late pieces (second stream's traffic) must not meet a patch
              case_h16(8192, 4096, 1024, torch.bfloat16, False),
-             case_h16(8192, 4096, 576, torch.float32, True)]         # 9 k-tiles (odd: the stage parity alternates between tiles), fp32 + residual
+             case_h16(8192, 4096, 576, torch.float32, True),         # 9 k-tiles (odd: the stage parity alternates between tiles), fp32 + residual
+             # long contractions on more than one round of tiles: the half-tile-ring schedule (gemm_tile8_body, round 5) by default -- five
+             # half-tiles in flight behind counted waits; a slot re-requested too early or a short wait would meet late pieces here
+             case_h16(8192, 4096, 2752, torch.float32, True),
+             case_h16(9000, 4096, 2048, torch.bfloat16, False)]       # ragged last tile row
 
     def launch(c, out):
         ops.gemm(c["A"], c["B"], out, M=c["M"], N=c["N"], K=c["K"], Cin=c.get("Cin"), **c["kw"])
