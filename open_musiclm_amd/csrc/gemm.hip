@@ -1210,7 +1210,12 @@ static bool gemm_t8_wanted(int K, int tiles, int splits) {
     const int mode = gemm_t8_mode();
     if (mode <= 0) return false;
     if (mode == 1) return true;
-    return splits == 1 && K >= 2048 && tiles > gemm_persist_slots();
+    static int ncu = 0;                                            // more than one round of one-workgroup-per-CU tiles (whatever OMLM_GEMM_PERSIST says)
+    if (ncu == 0) {
+        int dev = 0, n = 0;
+        ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return splits == 1 && K >= 2048 && tiles > ncu;
 }
 
 template <int BM_, int BN_, int WM_, int WN_, typename TOUT>
