@@ -314,11 +314,17 @@ extern "C" int omlm_relpos_first_bwd(const float* ds, float* dw0, int n, int Hd,
 // Fused rel-pos MLP (round 5).  The continuous relative-position bias (reference transformer.py:36-67) is Linear(1, Hd) + SiLU,
 // 2 x [Linear(Hd, Hd) + SiLU], Linear(Hd, H) on the n causal distances 0 .. n - 1: 0.6 GMAC forward for coarse-small -- which ran as
 // 7 forward and 14 backward launches (three latency-bound register-staged fp32 GEMMs each way, 25-50 us apiece at 12-19 TFLOP/s, plus
-// element-wise and column-sum kernels: ~0.4 ms of the 23.5 ms step).  Rows are independent, so a workgroup carries RB rows through ALL
+// element-wise and column-sum kernels: ~0.4 ms of the 23.5 ms step).  Rows are independent, so a workgroup carries 16 rows through ALL
 // layers with its activations in LDS: ONE forward launch and, for the backward, one row-chain launch (d(pre) of every layer) plus one
-// launch for every weight / bias gradient (each output element owned by one thread: plain += into the gradient buffers, fixed
-// summation order -- deterministic, which the 16-bit modes downstream need: DESIGN.md section 4.1, round 4).  True fp32 FMAs.
-// Hd must be a multiple of 256 (512 in every shipped config); other widths keep the launch-per-layer path (engine.relpos_forward).
+// launch for every weight / bias gradient (each output element owned by one lane: plain += into the gradient buffers, fixed summation
+// order -- deterministic, which the 16-bit modes downstream need: DESIGN.md section 4.1, round 4).
+// The contractions run on the EXACT fp32 matrix instruction v_mfma_f32_16x16x4_f32 (a k-ordered fmaf chain, bitwise: guide section 3):
+// the first version of these kernels did them as VALU FMAs against activations broadcast from LDS and was bound by that broadcast at
+// the same ~12 TFLOP/s as the GEMM path (forward 96 us, backward 270 us: no gain).  Operand maps of the instruction (lane l, i = l & 15,
+// g = l >> 4): A[i][k = g], B[k = g][j = i], D[row = 4 g + reg][col = i].  Which four k a step takes is free (any fixed order is a fixed
+// sum): where an operand's k runs along a lane's own row the step m takes k = 8 g + m (two 16-byte reads give a lane its 8 steps), where k
+// runs across rows it takes k = 4 m + g.
+// Hd must be 256 or 512 (512 in every shipped config); other widths keep the launch-per-layer path (engine.relpos_forward).
 struct relpos_mlp_params {
     const float *w0, *b0, *W1, *b1, *W2, *b2, *W3, *b3;      // net.0.0.weight [Hd] (as a vector), .bias; net.1.0 / net.2.0 [Hd, Hd]; net.3 [H, Hd], [H]
     float *pre0, *z0, *pre1, *z1, *pre2, *z2;                // [n, Hd] each: saved for the backward (forward: written when non-null)
@@ -330,24 +336,24 @@ struct relpos_mlp_params {
 };
 __device__ __forceinline__ float silu_f(float s) { return s / (1.0f + __expf(-s)); }
 __device__ __forceinline__ float silu_grad_f(float s) { const float sg = 1.0f / (1.0f + __expf(-s)); return sg * (1.0f + s * (1.0f - sg)); }
+#define RP_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define RP_RB 16                                             /* rows per workgroup = one MFMA tile row */
 
-template <int CPT, int RB>
+template <int HD>
 __global__ __launch_bounds__(256) void relpos_mlp_fwd_kernel(relpos_mlp_params a) {
-    constexpr int KC = 32, WP = KC + 1, Hd = 256 * CPT;
-    extern __shared__ float rp_sm[];
-    float* zA = rp_sm;                      // [RB][Hd]
-    float* zB = zA + RB * Hd;               // [RB][Hd]
-    float* wt = zB + RB * Hd;               // [Hd][WP]: a k-chunk of the layer's weight, row = output column
-    const int t = threadIdx.x, r0 = blockIdx.x * RB;
-#pragma unroll
-    for (int r = 0; r < RB; ++r)
-#pragma unroll
-        for (int j = 0; j < CPT; ++j) {
-            const int c = t + 256 * j, row = r0 + r;
-            const float s = (float)row * a.w0[c] + a.b0[c], z = silu_f(s);
-            zA[r * Hd + c] = z;
-            if (a.pre0 && row < a.n) { a.pre0[(size_t)row * Hd + c] = s; a.z0[(size_t)row * Hd + c] = z; }
-        }
+    constexpr int KC = 32, WP = KC + 4, ZP = HD + 4, NT = HD / 64;      // wt pitch 36 floats / z pitch HD + 4: 16-byte rows, conflict-free 16-lane b128 reads
+    extern __shared__ __attribute__((aligned(16))) float rp_sm[];
+    float* zA = rp_sm;                      // [16][ZP]
+    float* zB = zA + RP_RB * ZP;            // [16][ZP]
+    float* wt = zB + RP_RB * ZP;            // [HD][WP]: a 32-k chunk of the layer's weight, row = output column
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lg = lane >> 4, r0 = blockIdx.x * RP_RB;
+    const int colbase = wave * (HD / 4);
+    for (int e = t; e < RP_RB * HD; e += 256) {
+        const int r = e / HD, c = e - r * HD, row = r0 + r;
+        const float s = (float)row * a.w0[c] + a.b0[c], z = silu_f(s);
+        zA[r * ZP + c] = z;
+        if (a.pre0 && row < a.n) { a.pre0[(size_t)row * HD + c] = s; a.z0[(size_t)row * HD + c] = z; }
+    }
     __syncthreads();
 #pragma unroll 1
     for (int layer = 1; layer <= 2; ++layer) {
@@ -357,70 +363,56 @@ __global__ __launch_bounds__(256) void relpos_mlp_fwd_kernel(relpos_mlp_params a
         float* zout = layer == 1 ? zB : zA;
         float* pre = layer == 1 ? a.pre1 : a.pre2;
         float* zsv = layer == 1 ? a.z1 : a.z2;
-        float acc[RB][CPT];
+        f32x4 acc[NT];
 #pragma unroll
-        for (int r = 0; r < RB; ++r)
+        for (int x = 0; x < NT; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // the weight streams through LDS in chunks of 32 k; the NEXT chunk is requested into registers before this chunk's MFMAs
+        constexpr int NV = (HD * KC / 4) / 256;
+        f32x4 wreg[NV];
 #pragma unroll
-            for (int j = 0; j < CPT; ++j) acc[r][j] = 0.f;
-        // the layer's weight streams through LDS in chunks of 32 k: W[:, k0 .. k0 + 32) -> wt (128-byte row segments, coalesced; pitch 33
-        // floats: conflict-free column reads below).  The NEXT chunk is requested into registers before this chunk's FMAs (its L2 round trip
-        // runs under them) and written to LDS behind them.
-        constexpr int NV = (Hd * KC / 4) / 256;
-        float4 wreg[NV];
-#pragma unroll
-        for (int i = 0; i < NV; ++i) { const int idx = t + 256 * i; wreg[i] = *(const float4*)(W + (size_t)(idx >> 3) * Hd + 4 * (idx & 7)); }
+        for (int i = 0; i < NV; ++i) { const int idx = t + 256 * i; wreg[i] = *(const f32x4*)(W + (size_t)(idx >> 3) * HD + 4 * (idx & 7)); }
 #pragma unroll 1
-        for (int k0 = 0; k0 < Hd; k0 += KC) {
+        for (int k0 = 0; k0 < HD; k0 += KC) {
 #pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const int idx = t + 256 * i;
-                float* d = wt + (idx >> 3) * WP + 4 * (idx & 7);
-                d[0] = wreg[i].x; d[1] = wreg[i].y; d[2] = wreg[i].z; d[3] = wreg[i].w;
-            }
+            for (int i = 0; i < NV; ++i) { const int idx = t + 256 * i; *(f32x4*)(wt + (idx >> 3) * WP + 4 * (idx & 7)) = wreg[i]; }
             __syncthreads();
-            if (k0 + KC < Hd) {
+            if (k0 + KC < HD) {
 #pragma unroll
-                for (int i = 0; i < NV; ++i) { const int idx = t + 256 * i; wreg[i] = *(const float4*)(W + (size_t)(idx >> 3) * Hd + k0 + KC + 4 * (idx & 7)); }
+                for (int i = 0; i < NV; ++i) { const int idx = t + 256 * i; wreg[i] = *(const f32x4*)(W + (size_t)(idx >> 3) * HD + k0 + KC + 4 * (idx & 7)); }
             }
+            // step m of this chunk contracts k = k0 + 8 g + m: lane (i, g) holds A = z[i][k0 + 8 g + m] and B = W[col][k0 + 8 g + m]
+            const float4 a0 = *(const float4*)(zin + li * ZP + k0 + 8 * lg), a1 = *(const float4*)(zin + li * ZP + k0 + 8 * lg + 4);
+            const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
-            for (int kk = 0; kk < KC; kk += 4) {
-                float4 zv[RB];
+            for (int x = 0; x < NT; ++x) {
+                const float* wr = wt + (colbase + 16 * x + li) * WP + 8 * lg;
+                const float4 b0 = *(const float4*)wr, b1 = *(const float4*)(wr + 4);
+                const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-                for (int r = 0; r < RB; ++r) zv[r] = *(const float4*)(zin + r * Hd + k0 + kk);      // same address in every lane: broadcast
-#pragma unroll
-                for (int j = 0; j < CPT; ++j) {
-                    const float* wr = wt + (t + 256 * j) * WP + kk;
-                    const float w0_ = wr[0], w1_ = wr[1], w2_ = wr[2], w3_ = wr[3];
-#pragma unroll
-                    for (int r = 0; r < RB; ++r) {
-                        float v = acc[r][j];
-                        v = fmaf(zv[r].x, w0_, v); v = fmaf(zv[r].y, w1_, v); v = fmaf(zv[r].z, w2_, v); v = fmaf(zv[r].w, w3_, v);
-                        acc[r][j] = v;
-                    }
-                }
+                for (int m = 0; m < 8; ++m) acc[x] = RP_MFMA(av[m], bv[m], acc[x]);
             }
             __syncthreads();
         }
 #pragma unroll
-        for (int r = 0; r < RB; ++r)
+        for (int x = 0; x < NT; ++x)
 #pragma unroll
-            for (int j = 0; j < CPT; ++j) {
-                const int c = t + 256 * j, row = r0 + r;
-                const float s = acc[r][j] + bias[c], z = silu_f(s);
-                zout[r * Hd + c] = z;
-                if (pre && row < a.n) { pre[(size_t)row * Hd + c] = s; zsv[(size_t)row * Hd + c] = z; }
+            for (int reg = 0; reg < 4; ++reg) {
+                const int r = 4 * lg + reg, c = colbase + 16 * x + li, row = r0 + r;
+                const float s = acc[x][reg] + bias[c], z = silu_f(s);
+                zout[r * ZP + c] = z;
+                if (pre && row < a.n) { pre[(size_t)row * HD + c] = s; zsv[(size_t)row * HD + c] = z; }
             }
         __syncthreads();
     }
     // last layer: table[row][h] = z2[row] . W3[h] + b3[h]; (row, h) pairs over groups of 4 lanes (each a quarter of k), fixed order
     const float* zf = zA;                   // layer 2 wrote zA
-    for (int o = t >> 2; o < RB * a.ldb; o += 64) {
+    for (int o = t >> 2; o < RP_RB * a.ldb; o += 64) {
         const int r = o / a.ldb, h = o - r * a.ldb, part = t & 3, row = r0 + r;
         float v = 0.f;
         if (h < a.H) {
-            const float* w = a.W3 + (size_t)h * Hd + part * (Hd / 4);
-            const float* z = zf + r * Hd + part * (Hd / 4);
-            for (int k = 0; k < Hd / 4; ++k) v = fmaf(z[k], w[k], v);
+            const float* w = a.W3 + (size_t)h * HD + part * (HD / 4);
+            const float* z = zf + r * ZP + part * (HD / 4);
+            for (int k = 0; k < HD / 4; ++k) v = fmaf(z[k], w[k], v);
         }
         v += __shfl_xor(v, 1, 64);
         v += __shfl_xor(v, 2, 64);
@@ -428,39 +420,46 @@ __global__ __launch_bounds__(256) void relpos_mlp_fwd_kernel(relpos_mlp_params a
     }
 }
 
-// backward, row chain: ds2 = (dtable W3) * silu'(pre2); ds1 = (ds2 W2) * silu'(pre1); ds0 = (ds1 W1) * silu'(pre0).  A thread owns CPT input
-// columns k and streams the weight rows W[c][k] (coalesced along k) against the row block's d(pre) values broadcast from LDS.
-template <int CPT, int RB>
+// backward, row chain: ds2 = (dtable W3) * silu'(pre2); ds1 = (ds2 W2) * silu'(pre1); ds0 = (ds1 W1) * silu'(pre0).  The weight rows W[c][:]
+// (c = the contraction index here) stream through LDS 32 at a time; step m of a chunk contracts c = c0 + 4 m + g.
+template <int HD>
 __global__ __launch_bounds__(256) void relpos_mlp_bwd_rows_kernel(relpos_mlp_params a) {
-    constexpr int Hd = 256 * CPT;
-    extern __shared__ float rp_sm[];
-    float* dA = rp_sm;                      // [RB][Hd]
-    float* dB = dA + RB * Hd;               // [RB][Hd]
-    float* dt = dB + RB * Hd;               // [RB][16]: the block's dtable rows (H <= 16)
-    const int t = threadIdx.x, r0 = blockIdx.x * RB;
-    if (t < RB * 16) {
+    constexpr int KC = 32, ZP = HD + 4, WP2 = HD + 16, NT = HD / 64;       // wt2 pitch HD + 16: rows 4 m + g of the two lane groups of a half-wave sit 16 banks apart
+    extern __shared__ __attribute__((aligned(16))) float rp_sm[];
+    float* dA = rp_sm;                      // [16][ZP]
+    float* dB = dA + RP_RB * ZP;            // [16][ZP]
+    float* wt2 = dB + RP_RB * ZP;           // [32][WP2]: weight rows c0 .. c0 + 31
+    float* dt = wt2 + KC * WP2;             // [16][16]: the block's dtable rows (H <= 16)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lg = lane >> 4, r0 = blockIdx.x * RP_RB;
+    const int colbase = wave * (HD / 4);
+    {
         const int r = t >> 4, h = t & 15, row = r0 + r;
         dt[t] = (h < a.H && row < a.n) ? a.dtable[(size_t)row * a.ldb + h] : 0.f;
     }
     __syncthreads();
+    {   // dz2 = dtable W3: contraction over the (padded) 16 heads = 4 steps, h = 4 m + g; W3 rows straight from global (coalesced along k)
+        f32x4 acc[NT];
 #pragma unroll
-    for (int j = 0; j < CPT; ++j) {
-        const int k = t + 256 * j;
-        float acc[RB];
+        for (int x = 0; x < NT; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < RB; ++r) acc[r] = 0.f;
-        for (int h = 0; h < a.H; ++h) {
-            const float w = a.W3[(size_t)h * Hd + k];
+        for (int m = 0; m < 4; ++m) {
+            const int h = 4 * m + lg;
+            const float av = dt[li * 16 + h];
 #pragma unroll
-            for (int r = 0; r < RB; ++r) acc[r] = fmaf(dt[r * 16 + h], w, acc[r]);
+            for (int x = 0; x < NT; ++x) {
+                const float bv = h < a.H ? a.W3[(size_t)h * HD + colbase + 16 * x + li] : 0.f;
+                acc[x] = RP_MFMA(av, bv, acc[x]);
+            }
         }
 #pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            const int row = r0 + r;
-            const float ds = row < a.n ? acc[r] * silu_grad_f(a.pre2[(size_t)row * Hd + k]) : 0.f;
-            dA[r * Hd + k] = ds;
-            if (row < a.n) a.ds2[(size_t)row * Hd + k] = ds;
-        }
+        for (int x = 0; x < NT; ++x)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int r = 4 * lg + reg, k = colbase + 16 * x + li, row = r0 + r;
+                const float ds = row < a.n ? acc[x][reg] * silu_grad_f(a.pre2[(size_t)row * HD + k]) : 0.f;
+                dA[r * ZP + k] = ds;
+                if (row < a.n) a.ds2[(size_t)row * HD + k] = ds;
+            }
     }
     __syncthreads();
 #pragma unroll 1
@@ -470,129 +469,129 @@ __global__ __launch_bounds__(256) void relpos_mlp_bwd_rows_kernel(relpos_mlp_par
         float* dout = layer == 2 ? dB : dA;
         const float* pre = layer == 2 ? a.pre1 : a.pre0;
         float* dsg = layer == 2 ? a.ds1 : a.ds0;
-        float acc[RB][CPT];
+        f32x4 acc[NT];
 #pragma unroll
-        for (int r = 0; r < RB; ++r)
+        for (int x = 0; x < NT; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+        constexpr int NV = (KC * HD / 4) / 256;              // float4 pieces of a 32-row chunk per thread
+        f32x4 wreg[NV];
 #pragma unroll
-            for (int j = 0; j < CPT; ++j) acc[r][j] = 0.f;
-        float wn[8][CPT];                                     // weight rows c0 .. c0 + 7 of the NEXT step, requested one step ahead
-#pragma unroll
-        for (int x = 0; x < 8; ++x)
-#pragma unroll
-            for (int j = 0; j < CPT; ++j) wn[x][j] = W[(size_t)x * Hd + t + 256 * j];
+        for (int i = 0; i < NV; ++i) { const int idx = t + 256 * i; wreg[i] = *(const f32x4*)(W + (size_t)(idx / (HD / 4)) * HD + 4 * (idx % (HD / 4))); }
 #pragma unroll 1
-        for (int c0 = 0; c0 < Hd; c0 += 8) {
-            float w[8][CPT];
+        for (int c0 = 0; c0 < HD; c0 += KC) {
 #pragma unroll
-            for (int x = 0; x < 8; ++x)
+            for (int i = 0; i < NV; ++i) { const int idx = t + 256 * i; *(f32x4*)(wt2 + (idx / (HD / 4)) * WP2 + 4 * (idx % (HD / 4))) = wreg[i]; }
+            __syncthreads();
+            if (c0 + KC < HD) {
 #pragma unroll
-                for (int j = 0; j < CPT; ++j) w[x][j] = wn[x][j];
-            if (c0 + 8 < Hd) {
-#pragma unroll
-                for (int x = 0; x < 8; ++x)
-#pragma unroll
-                    for (int j = 0; j < CPT; ++j) wn[x][j] = W[(size_t)(c0 + 8 + x) * Hd + t + 256 * j];
+                for (int i = 0; i < NV; ++i) { const int idx = t + 256 * i; wreg[i] = *(const f32x4*)(W + (size_t)(c0 + KC + idx / (HD / 4)) * HD + 4 * (idx % (HD / 4))); }
             }
 #pragma unroll
-            for (int half = 0; half < 2; ++half)
+            for (int m = 0; m < 8; ++m) {
+                const int cc = 4 * m + lg;                   // row of the chunk this lane group contributes in step m
+                const float av = din[li * ZP + c0 + cc];
 #pragma unroll
-            for (int r = 0; r < RB; ++r) {
-                const float4 d = *(const float4*)(din + r * Hd + c0 + 4 * half);
-#pragma unroll
-                for (int j = 0; j < CPT; ++j) {
-                    float v = acc[r][j];
-                    v = fmaf(d.x, w[4 * half + 0][j], v); v = fmaf(d.y, w[4 * half + 1][j], v);
-                    v = fmaf(d.z, w[4 * half + 2][j], v); v = fmaf(d.w, w[4 * half + 3][j], v);
-                    acc[r][j] = v;
-                }
+                for (int x = 0; x < NT; ++x) acc[x] = RP_MFMA(av, wt2[cc * WP2 + colbase + 16 * x + li], acc[x]);
             }
+            __syncthreads();
         }
 #pragma unroll
-        for (int r = 0; r < RB; ++r)
+        for (int x = 0; x < NT; ++x)
 #pragma unroll
-            for (int j = 0; j < CPT; ++j) {
-                const int k = t + 256 * j, row = r0 + r;
-                const float ds = row < a.n ? acc[r][j] * silu_grad_f(pre[(size_t)row * Hd + k]) : 0.f;
-                dout[r * Hd + k] = ds;
-                if (row < a.n) dsg[(size_t)row * Hd + k] = ds;
+            for (int reg = 0; reg < 4; ++reg) {
+                const int r = 4 * lg + reg, k = colbase + 16 * x + li, row = r0 + r;
+                const float ds = row < a.n ? acc[x][reg] * silu_grad_f(pre[(size_t)row * HD + k]) : 0.f;
+                dout[r * ZP + k] = ds;
+                if (row < a.n) dsg[(size_t)row * HD + k] = ds;
             }
         __syncthreads();
     }
 }
 
 // backward, parameter gradients.  blockIdx.x enumerates 64 x 64 output tiles: [0, T2) of gW2 (+ gb2 on its first tile column), [T2, 2 T2) of
-// gW1 (+ gb1), then Hd / 64 workgroups for gW3 / gb3 (8 .. 16 x 64 columns) and Hd / 64 for gw0 / gb0.  Every output element belongs to
-// one thread and is accumulated over the n rows in ascending order.
+// gW1 (+ gb1), then Hd / 64 workgroups for gW3 / gb3 and Hd / 64 for gw0 / gb0.  gW[c][k] += sum_r ds[r][c] z[r][k]: the rows r are the
+// contraction (64 staged per trip, step m of a 16-row group takes r = 4 m + g); wave w owns output rows c0 + 16 w .. + 15 and four 16-column
+// tiles.  Every output element belongs to one lane and is accumulated over the n rows in a fixed order.
 __global__ __launch_bounds__(256) void relpos_mlp_bwd_params_kernel(relpos_mlp_params a) {
-    __shared__ float sd[16][64 + 1], sz[16][64 + 1];
+    constexpr int RC = 64, SP = 64 + 16;                     // rows per trip; pitch 80 floats: rows 4 m + g of a half-wave's two groups 16 banks apart
+    __shared__ __attribute__((aligned(16))) float sd[RC * SP];
+    __shared__ __attribute__((aligned(16))) float sz[RC * SP];
     const int Hd = a.Hd, TPD = Hd / 64, T2 = TPD * TPD;
-    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lg = lane >> 4;
     int b = blockIdx.x;
     if (b < 2 * T2) {
         const bool second = b >= T2;
         if (second) b -= T2;
-        const float* ds = second ? a.ds1 : a.ds2;            // [n, Hd] rows = tokens, cols = output feature c
+        const float* ds = second ? a.ds1 : a.ds2;            // [n, Hd] rows = distances, cols = output feature c
         const float* z = second ? a.z0 : a.z1;               // [n, Hd] cols = input feature k
         float* gW = second ? a.gW1 : a.gW2;
         float* gb = second ? a.gb1 : a.gb2;
         const int c0 = (b / TPD) * 64, k0 = (b % TPD) * 64;
-        float acc[4][4];
+        f32x4 acc[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+        for (int x = 0; x < 4; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
         float bacc = 0.f;                                    // thread t < 64 of a k0 == 0 tile: column sum of ds (the bias gradient)
-        for (int r0 = 0; r0 < a.n; r0 += 16) {
+        float4 rd[4], rz[4];                                 // 64 rows x 64 cols of each operand = 1024 float4 / 256 threads, requested one trip ahead
+        auto request = [&](int r0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {                    // 16 rows x 64 cols of each operand: 1024 floats / 256 threads
-                const int idx = t + 256 * i, rr = idx >> 6, cc = idx & 63, row = r0 + rr;
-                sd[rr][cc] = row < a.n ? ds[(size_t)row * Hd + c0 + cc] : 0.f;
-                sz[rr][cc] = row < a.n ? z[(size_t)row * Hd + k0 + cc] : 0.f;
+            for (int i = 0; i < 4; ++i) {
+                const int idx = t + 256 * i, rr = idx >> 4, q = idx & 15, row = r0 + rr;
+                rd[i] = row < a.n ? *(const float4*)(ds + (size_t)row * Hd + c0 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                rz[i] = row < a.n ? *(const float4*)(z + (size_t)row * Hd + k0 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        request(0);
+        for (int r0 = 0; r0 < a.n; r0 += RC) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = t + 256 * i, rr = idx >> 4, q = idx & 15;
+                *(float4*)(sd + rr * SP + 4 * q) = rd[i];
+                *(float4*)(sz + rr * SP + 4 * q) = rz[i];
             }
             __syncthreads();
+            if (r0 + RC < a.n) request(r0 + RC);
 #pragma unroll
-            for (int rr = 0; rr < 16; ++rr) {
-                float dv[4], zv[4];
+            for (int m = 0; m < RC / 4; ++m) {
+                const int rr = 4 * m + lg;
+                const float av = sd[rr * SP + 16 * wave + li];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { dv[i] = sd[rr][ty + 16 * i]; zv[i] = sz[rr][tx + 16 * i]; }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(dv[i], zv[j], acc[i][j]);
-                if (k0 == 0 && t < 64) bacc += sd[rr][t];
+                for (int x = 0; x < 4; ++x) acc[x] = RP_MFMA(av, sz[rr * SP + 16 * x + li], acc[x]);
+            }
+            if (k0 == 0 && t < 64) {
+#pragma unroll 8
+                for (int rr = 0; rr < RC; ++rr) bacc += sd[rr * SP + t];
             }
             __syncthreads();
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int x = 0; x < 4; ++x)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) gW[(size_t)(c0 + ty + 16 * i) * Hd + k0 + tx + 16 * j] += acc[i][j];
+            for (int reg = 0; reg < 4; ++reg) gW[(size_t)(c0 + 16 * wave + 4 * lg + reg) * Hd + k0 + 16 * x + li] += acc[x][reg];
         if (k0 == 0 && t < 64) gb[c0 + t] += bacc;
         return;
     }
     b -= 2 * T2;
     if (b < TPD) {
         // gW3[h][k] += sum_r dtable[r][h] z2[r][k] for 64 columns k (H <= 16 rows h); gb3[h] += sum_r dtable[r][h] (first of these
-        // workgroups).  Same row-chunk staging as above: thread (h = t >> 4, 4 columns).
+        // workgroups).  Rows staged 16 at a time: thread (h = t >> 4, 4 columns).
         const int k0 = b * 64, h = t >> 4, kx = t & 15;
         float acc[4] = {0.f, 0.f, 0.f, 0.f}, bacc = 0.f;
         for (int r0 = 0; r0 < a.n; r0 += 16) {
             {
                 const int rr = t >> 4, hh = t & 15, row = r0 + rr;            // 16 rows x 16 (padded) heads
-                sd[rr][hh] = (row < a.n && hh < a.H) ? a.dtable[(size_t)row * a.ldb + hh] : 0.f;
+                sd[rr * SP + hh] = (row < a.n && hh < a.H) ? a.dtable[(size_t)row * a.ldb + hh] : 0.f;
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int idx = t + 256 * i, rr = idx >> 6, cc = idx & 63, row = r0 + rr;
-                sz[rr][cc] = row < a.n ? a.z2[(size_t)row * Hd + k0 + cc] : 0.f;
+                sz[rr * SP + cc] = row < a.n ? a.z2[(size_t)row * Hd + k0 + cc] : 0.f;
             }
             __syncthreads();
 #pragma unroll
             for (int rr = 0; rr < 16; ++rr) {
-                const float dv = sd[rr][h];
+                const float dv = sd[rr * SP + h];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = fmaf(dv, sz[rr][kx + 16 * j], acc[j]);
-                if (b == 0 && t < 16) bacc += sd[rr][t];
+                for (int j = 0; j < 4; ++j) acc[j] = fmaf(dv, sz[rr * SP + kx + 16 * j], acc[j]);
+                if (b == 0 && t < 16) bacc += sd[rr * SP + t];
             }
             __syncthreads();
         }
@@ -604,9 +603,9 @@ __global__ __launch_bounds__(256) void relpos_mlp_bwd_params_kernel(relpos_mlp_p
         return;
     }
     b -= TPD;
-    {   // gw0[c] += sum_r r ds0[r][c]; gb0[c] += sum_r ds0[r][c]: 64 columns per workgroup, rows staged 64 at a time, four row lanes
-        // combined in a fixed order
-        __shared__ float red[2][4][64];
+    {   // gw0[c] += sum_r r ds0[r][c]; gb0[c] += sum_r ds0[r][c]: 64 columns per workgroup, rows 64 at a time, four row lanes combined in a
+        // fixed order
+        float* red = sd;                                     // [2][4][64]
         const int c0 = b * 64, cx = t & 63, rl = t >> 6;
         float sw = 0.f, sb = 0.f;
         for (int r0 = 0; r0 < a.n; r0 += 64) {
@@ -616,11 +615,11 @@ __global__ __launch_bounds__(256) void relpos_mlp_bwd_params_kernel(relpos_mlp_p
 #pragma unroll
             for (int i = 0; i < 16; ++i) { sw = fmaf((float)(r0 + rl + 4 * i), v[i], sw); sb += v[i]; }
         }
-        red[0][rl][cx] = sw; red[1][rl][cx] = sb;
+        red[rl * 64 + cx] = sw; red[256 + rl * 64 + cx] = sb;
         __syncthreads();
         if (rl == 0) {
-            a.gw0[c0 + t] += (red[0][0][t] + red[0][1][t]) + (red[0][2][t] + red[0][3][t]);
-            a.gb0[c0 + t] += (red[1][0][t] + red[1][1][t]) + (red[1][2][t] + red[1][3][t]);
+            a.gw0[c0 + t] += (red[t] + red[64 + t]) + (red[128 + t] + red[192 + t]);
+            a.gb0[c0 + t] += (red[256 + t] + red[320 + t]) + (red[384 + t] + red[448 + t]);
         }
     }
 }
@@ -635,17 +634,16 @@ extern "C" int omlm_relpos_mlp_fwd(const float* w0, const float* b0, const float
     memset(&a, 0, sizeof(a));
     a.w0 = w0; a.b0 = b0; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.W3 = W3; a.b3 = b3;
     a.pre0 = pre0; a.z0 = z0; a.pre1 = pre1; a.z1 = z1; a.pre2 = pre2; a.z2 = z2; a.table = table; a.n = n; a.Hd = Hd; a.H = H; a.ldb = ldb;
-    constexpr int RB = 8;
-    const size_t lds = (size_t)(2 * RB * Hd + Hd * 33) * sizeof(float);
+    const size_t lds = (size_t)(2 * RP_RB * (Hd + 4) + Hd * 36) * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)relpos_mlp_fwd_kernel<2, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((2 * RB * 512 + 512 * 33) * 4));
-        (void)hipFuncSetAttribute((const void*)relpos_mlp_fwd_kernel<1, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((2 * RB * 256 + 256 * 33) * 4));
+        (void)hipFuncSetAttribute((const void*)relpos_mlp_fwd_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((2 * RP_RB * 516 + 512 * 36) * 4));
+        (void)hipFuncSetAttribute((const void*)relpos_mlp_fwd_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((2 * RP_RB * 260 + 256 * 36) * 4));
         attr = true;
     }
-    const dim3 grid((n + RB - 1) / RB);
-    if (Hd == 512) hipLaunchKernelGGL((relpos_mlp_fwd_kernel<2, RB>), grid, dim3(256), lds, as_stream(stream), a);
-    else           hipLaunchKernelGGL((relpos_mlp_fwd_kernel<1, RB>), grid, dim3(256), lds, as_stream(stream), a);
+    const dim3 grid((n + RP_RB - 1) / RP_RB);
+    if (Hd == 512) hipLaunchKernelGGL(relpos_mlp_fwd_kernel<512>, grid, dim3(256), lds, as_stream(stream), a);
+    else           hipLaunchKernelGGL(relpos_mlp_fwd_kernel<256>, grid, dim3(256), lds, as_stream(stream), a);
     return omlm_post_launch("omlm_relpos_mlp_fwd");
 }
 
@@ -661,11 +659,16 @@ extern "C" int omlm_relpos_mlp_bwd(const float* dtable, const float* W1, const f
     a.W1 = W1; a.W2 = W2; a.W3 = W3; a.pre0 = (float*)pre0; a.z0 = (float*)z0; a.pre1 = (float*)pre1; a.z1 = (float*)z1; a.pre2 = (float*)pre2; a.z2 = (float*)z2;
     a.dtable = dtable; a.ds0 = scratch; a.ds1 = scratch + (size_t)n * Hd; a.ds2 = scratch + 2 * (size_t)n * Hd;
     a.gw0 = gw0; a.gb0 = gb0; a.gW1 = gW1; a.gb1 = gb1; a.gW2 = gW2; a.gb2 = gb2; a.gW3 = gW3; a.gb3 = gb3; a.n = n; a.Hd = Hd; a.H = H; a.ldb = ldb;
-    constexpr int RB = 8;
-    const size_t lds = (size_t)(2 * RB * Hd + RB * 16) * sizeof(float);
-    const dim3 grid((n + RB - 1) / RB);
-    if (Hd == 512) hipLaunchKernelGGL((relpos_mlp_bwd_rows_kernel<2, RB>), grid, dim3(256), lds, as_stream(stream), a);
-    else           hipLaunchKernelGGL((relpos_mlp_bwd_rows_kernel<1, RB>), grid, dim3(256), lds, as_stream(stream), a);
+    const size_t lds = (size_t)(2 * RP_RB * (Hd + 4) + 32 * (Hd + 16) + 256) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)relpos_mlp_bwd_rows_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((2 * RP_RB * 516 + 32 * 528 + 256) * 4));
+        (void)hipFuncSetAttribute((const void*)relpos_mlp_bwd_rows_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((2 * RP_RB * 260 + 32 * 272 + 256) * 4));
+        attr = true;
+    }
+    const dim3 grid((n + RP_RB - 1) / RP_RB);
+    if (Hd == 512) hipLaunchKernelGGL(relpos_mlp_bwd_rows_kernel<512>, grid, dim3(256), lds, as_stream(stream), a);
+    else           hipLaunchKernelGGL(relpos_mlp_bwd_rows_kernel<256>, grid, dim3(256), lds, as_stream(stream), a);
     int rc = omlm_post_launch("omlm_relpos_mlp_bwd (rows)");
     if (rc) return rc;
     const int tpd = Hd / 64;
