@@ -54,11 +54,13 @@ _KV_DGRAD_H16 = os.environ.get("OMLM_KV_DGRAD_H16", "1") == "1"
 # (ops.gemm_qknorm): q, k, v leave them in the operand type with the per-(row, head) norms in fp32 -- no fp32 q_raw / kv_raw, no qk_norm
 # forward launch, and the backward derives xh = y / scale from the saved operand.  OMLM_QKNORM_FUSED=0: separate kernels on fp32 projections.
 _QKNORM_FUSED = os.environ.get("OMLM_QKNORM_FUSED", "1") == "1"
-# The rel-pos MLP as one fused forward launch + two backward launches (round 5; Hd = 256 / 512; true fp32 FMAs, deterministic) instead of the
-# layer-by-layer path (7 + 14 launches, three register-staged fp32 GEMMs each way).  Measured same box: forward 96 us, backward 270 us --
-# LDS-broadcast-bound at the same ~12 TFLOP/s as the GEMM path, and the step is 0.1 ms SLOWER with it (23.17 vs 23.07 ms).  Off by default;
-# OMLM_RELPOS_FUSED=1 selects it.
-_RELPOS_FUSED = os.environ.get("OMLM_RELPOS_FUSED", "0") == "1"
+# The rel-pos MLP as one fused forward launch + two backward launches (round 5; Hd = 256 / 512; exact fp32 matrix instruction, every
+# gradient element owned by one lane: deterministic) instead of the layer-by-layer path (7 + 14 launches, three register-staged fp32 GEMMs
+# each way, split-K atomics in the backward).  Measured same box: forward 93 us, backward 276 us, the step equal within noise (23.60 / 23.74
+# vs 23.62 / 23.66 ms): a row-block workgroup has to stream both 1 MB weight matrices through its own L2 -> CU path (~2 MB at ~40 GB/s per
+# CU), which bounds it whatever does the arithmetic (VALU FMAs and MFMAs measured the same).  On by default for the launch count and the
+# determinism; OMLM_RELPOS_FUSED=0: the layer-by-layer path.
+_RELPOS_FUSED = os.environ.get("OMLM_RELPOS_FUSED", "1") == "1"
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 
 
