@@ -134,6 +134,10 @@ int omlm_ffmid_bwd(const void* dh2, const void* h1, const void* convw, const voi
                    int M, int nseq, int F, int Fp, float p, unsigned long long seed,
                    const unsigned long long* seed_dev, const unsigned char* drop_bits, const void* gh, int dtype, void* stream);
 int omlm_colsum_accumulate(const float* part, float* out, int P, int C, int ldp, void* stream);
+/* out_i[c] += sum_p part_i[p * ldp_i + c] for `count` problems in ONE launch: the d(gamma) partial rows of every LayerNorm of a backward
+ * pass (omlm_layernorm_bwd2 with dgamma NULL and a workspace leaves its [min(M, 2048), D] partial rows there instead of summing them). */
+typedef struct omlm_colsum_desc { const float* part; float* out; int P, C, ldp; } omlm_colsum_desc;
+int omlm_colsum_group(const omlm_colsum_desc* problems, int count, void* stream);
 /* 1 (default, or $OMLM_FFMID_IMPL): the column-strip kernels where their preconditions hold (Fp <= 4096, drop_bits present when
  * p > 0, and gh present for the backward); 0: the wave-per-row kernels (A/B runs, tests). */
 int omlm_ffmid_set_impl(int impl);

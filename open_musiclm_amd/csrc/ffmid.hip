@@ -548,9 +548,47 @@ __global__ void colsum_kernel(const float* __restrict__ part, float* __restrict_
     if (p1 > p0) unsafeAtomicAdd(out + c, s);
 }
 
+// several column sums as ONE launch (round 5): the LayerNorm backward's d(gamma) partial rows of a whole backward pass (13 launches of
+// ~8 us each in the coarse-small step) and the two of every ConvFeedForward backward.  blockIdx.z = problem.
+struct omlm_colsum_desc { const float* part; float* out; int P, C, ldp; };      // include/omlm.h
+#define OMLM_COLSUM_MAX 32
+struct ColsumGroupArgs { int n; omlm_colsum_desc p[OMLM_COLSUM_MAX]; };
+__global__ void colsum_group_kernel(ColsumGroupArgs ga) {
+    const omlm_colsum_desc& q = ga.p[blockIdx.z];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= q.C) return;
+    const int per = (q.P + gridDim.y - 1) / gridDim.y;
+    const int p0 = blockIdx.y * per, p1 = min(q.P, p0 + per);
+    float s = 0.f;
+    for (int p = p0; p < p1; ++p) s += q.part[(size_t)p * q.ldp + c];
+    if (p1 > p0) unsafeAtomicAdd(q.out + c, s);
+}
+
 #if OMLM_FP16
 extern "C" int omlm_colsum_accumulate(const float* part, float* out, int P, int C, int ldp, void* stream);     // bf16 copy
+extern "C" int omlm_colsum_group(const omlm_colsum_desc* d, int count, void* stream);
 #else
+extern "C" int omlm_colsum_group(const omlm_colsum_desc* d, int count, void* stream) {
+    if (count <= 0) return OMLM_OK;
+    OMLM_CHECK_ARG(d, "colsum_group: null descriptor array");
+    for (int base = 0; base < count; base += OMLM_COLSUM_MAX) {
+        ColsumGroupArgs ga;
+        memset(&ga, 0, sizeof(ga));
+        ga.n = count - base < OMLM_COLSUM_MAX ? count - base : OMLM_COLSUM_MAX;
+        int cmax = 0, pmax = 0;
+        for (int i = 0; i < ga.n; ++i) {
+            const omlm_colsum_desc& q = d[base + i];
+            OMLM_CHECK_ARG(q.part && q.out && q.P > 0 && q.C > 0 && q.ldp >= q.C, "colsum_group: bad problem");
+            ga.p[i] = q;
+            if (q.C > cmax) cmax = q.C;
+            if (q.P > pmax) pmax = q.P;
+        }
+        const int ysplit = pmax >= 1024 ? 128 : (pmax >= 64 ? 16 : 1);
+        hipLaunchKernelGGL(colsum_group_kernel, dim3((cmax + 255) / 256, ysplit, ga.n), dim3(256), 0, as_stream(stream), ga);
+    }
+    return omlm_post_launch("omlm_colsum_group");
+}
+
 extern "C" int omlm_colsum_accumulate(const float* part, float* out, int P, int C, int ldp, void* stream) {
     if (P <= 0 || C <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(part && out && ldp >= C, "colsum arguments");
@@ -677,6 +715,10 @@ extern "C" int OMLM_API(omlm_ffmid_bwd)(const void* dh2, const void* h1, const v
         int rc2 = ffmid2_bwd_launch(dh2, h1, convw, gamma, rstd, (float*)du_tmp, dh1, part_g, FF_BWD1_BLOCKS, part_c, FF_BWD2_STRIPS,
                                     &g_rows, &c_rows, M, nseq, F, Fp, p, drop_bits, gh, dtype, st);
         if (rc2) return rc2;
+        if (dgamma && dconv) {
+            const omlm_colsum_desc two[2] = {{part_g, dgamma, g_rows, F, Fp}, {part_c, dconv, c_rows, 2 * F * 3, 2 * F * 3}};
+            return omlm_colsum_group(two, 2, stream);
+        }
         if (dgamma) { rc2 = omlm_colsum_accumulate(part_g, dgamma, g_rows, F, Fp, stream); if (rc2) return rc2; }
         if (dconv)  { rc2 = omlm_colsum_accumulate(part_c, dconv, c_rows, 2 * F * 3, 2 * F * 3, stream); if (rc2) return rc2; }
         return OMLM_OK;
@@ -710,6 +752,10 @@ extern "C" int OMLM_API(omlm_ffmid_bwd)(const void* dh2, const void* h1, const v
     }
     int rc = omlm_post_launch("omlm_ffmid_bwd");
     if (rc) return rc;
+    if (dgamma && dconv) {
+        const omlm_colsum_desc two[2] = {{part_g, dgamma, b1, F, Fp}, {part_c, dconv, strips, 2 * F * 3, 2 * F * 3}};
+        return omlm_colsum_group(two, 2, stream);
+    }
     if (dgamma) { rc = omlm_colsum_accumulate(part_g, dgamma, b1, F, Fp, stream); if (rc) return rc; }
     if (dconv)  { rc = omlm_colsum_accumulate(part_c, dconv, strips, 2 * F * 3, 2 * F * 3, stream); if (rc) return rc; }
     return OMLM_OK;

@@ -344,7 +344,9 @@ extern "C" int OMLM_API(omlm_layernorm_bwd2)(const void* dy, const float* x, con
     // Each row is a dependent chain (load -> two block reductions -> load dres -> store), so the rate is set by the rows
     // in flight.  With a workspace (omlm_layernorm_bwd_workspace_bytes) 2048 workgroups each leave one partial dgamma row
     // for colsum; without it dgamma is accumulated with atomics, which only scale to 512 workgroups (2048: 194 -> 273 us).
-    const bool two_level = workspace != nullptr && dgamma != nullptr;
+    // dgamma null WITH a workspace (round 5): the partial rows are left in the workspace ([min(M, 2048), D]) and the caller sums them later --
+    // engine.trunk_backward folds the column sums of all LayerNorms of a backward pass into one omlm_colsum_group launch.
+    const bool two_level = workspace != nullptr;
     const int blocks = two_level ? (M < 2048 ? M : 2048) : (M < 512 ? M : 512);
     dim3 grid(blocks), block(LN_THREADS);
     float* part = two_level ? workspace : nullptr;
@@ -376,7 +378,7 @@ extern "C" int OMLM_API(omlm_layernorm_bwd2)(const void* dy, const float* x, con
         hipLaunchKernelGGL((ln_bwd_kernel<h16_t, h16_t>), grid, block, 0, as_stream(stream), (const h16_t*)dy, x, gamma, mean, rstd, dres, (const h16_t*)dres2, dx, (h16_t*)dxcast, dgamma, part, M, D, dx_scale);
     int rc = omlm_post_launch("omlm_layernorm_bwd");
     if (rc) return rc;
-    if (two_level) return omlm_colsum_accumulate(part, dgamma, blocks, D, D, stream);
+    if (two_level && dgamma) return omlm_colsum_accumulate(part, dgamma, blocks, D, D, stream);
     return OMLM_OK;
 }
 #if !OMLM_FP16

@@ -61,6 +61,7 @@ _QKNORM_FUSED = os.environ.get("OMLM_QKNORM_FUSED", "1") == "1"
 # CU), which bounds it whatever does the arithmetic (VALU FMAs and MFMAs measured the same).  On by default for the launch count and the
 # determinism; OMLM_RELPOS_FUSED=0: the layer-by-layer path.
 _RELPOS_FUSED = os.environ.get("OMLM_RELPOS_FUSED", "1") == "1"
+_LN_COLSUM_GROUP = os.environ.get("OMLM_LN_COLSUM_GROUP", "1") == "1"    # 0: every LayerNorm backward sums its own d(gamma) partial rows
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 
 
@@ -538,9 +539,11 @@ def trunk_backward(tr, pw: PreparedWeights, saved, dy: torch.Tensor, B: int, N: 
     rp_side = None
     dres = torch.empty(M, D, device=dev)
     dres_c = dres if T == torch.float32 else torch.empty(M, D, dtype=T, device=dev)
+    # the d(gamma) partial rows of every LayerNorm backward of this pass are summed by ONE launch at its end (13 launches of ~8 us before)
+    cg = ops.ColsumGroup() if _LN_COLSUM_GROUP else None
     ops.layernorm_bwd(dy, saved["xL"], tr.norm.gamma.detach(), saved["mf"], saved["rf"], None, dres,
                       None if T == torch.float32 else dres_c, grad_of(tr.norm.gamma),
-                      dx_scale=out_scale if nl == 0 else 1.0)
+                      dx_scale=out_scale if nl == 0 else 1.0, defer=cg)
     ws = None
     # weight gradients have no consumer before the optimizer: in bf16 mode they are collected and issued as grouped launches of
     # full-K tiles (ops.WgradGroup) instead of 5 split-K GEMMs per layer; their operands stay alive until the flush
@@ -587,7 +590,7 @@ def trunk_backward(tr, pw: PreparedWeights, saved, dy: torch.Tensor, B: int, N: 
         dx1 = torch.empty(M, D, device=dev)
         dx1_c = dx1 if T == torch.float32 else torch.empty(M, D, dtype=T, device=dev)
         ops.layernorm_bwd(dxn2, sv.x1, ff.norm_in.gamma.detach(), sv.m2, sv.r2, dres, dx1,
-                          None if T == torch.float32 else dx1_c, grad_of(ff.norm_in.gamma))
+                          None if T == torch.float32 else dx1_c, grad_of(ff.norm_in.gamma), defer=cg)
         # ---- attention block: x1 = x + o Wo^T ----
         do = torch.empty(M, H * DIM_HEAD, dtype=T, device=dev)
         if "WoT" in w: ops.gemm(dx1_c, w["WoT"], do, M=M, N=H * DIM_HEAD, K=D)
@@ -637,7 +640,9 @@ def trunk_backward(tr, pw: PreparedWeights, saved, dy: torch.Tensor, B: int, N: 
         last = li == 0
         ops.layernorm_bwd(dxn, sv.x, attn.norm.gamma.detach(), sv.m1, sv.r1, dx1 if kv16 else tmp, dres,
                           None if (T == torch.float32 or last) else dres_c, grad_of(attn.norm.gamma),
-                          dx_scale=out_scale if last else 1.0, dres2=tmp if kv16 else None)
+                          dx_scale=out_scale if last else 1.0, dres2=tmp if kv16 else None, defer=cg)
+    if cg is not None:
+        cg.flush()
     if wg is not None:
         wg.flush()
     if rp_side is not None:

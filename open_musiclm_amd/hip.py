@@ -45,6 +45,7 @@ SIGNATURES = {
     "omlm_ffmid_bwd_workspace_bytes": [i32, i32],
     "omlm_ffmid_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, u64, vp, vp, vp, i32, vp],
     "omlm_colsum_accumulate": [vp, vp, i32, i32, i32, vp],
+    "omlm_colsum_group": [vp, i32, vp],
     "omlm_ffmid_set_impl": [i32],
     "omlm_embed_gather_fwd": [vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, vp, vp, vp, vp],
     "omlm_embed_gather_bwd": [vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, f32, vp, vp, vp, vp],

@@ -198,11 +198,45 @@ def _ln_workspace(D: int, device) -> torch.Tensor:
     return _LN_WS[key]
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dx, dxcast, dgamma, dx_scale=1.0, dres2=None):
-    """dres2 (optional): a second residual-gradient term in the cast type (dxcast's dtype; with dxcast None its own dtype names it)."""
+class _ColsumDesc(C.Structure):
+    """omlm_colsum_desc (include/omlm.h)"""
+    _fields_ = [("part", C.c_void_p), ("out", C.c_void_p), ("P", C.c_int), ("C", C.c_int), ("ldp", C.c_int)]
+
+
+class ColsumGroup:
+    """Collects column sums out[c] += sum_p part[p, c] (the d(gamma) partial rows of the LayerNorm backwards of one backward pass) and issues
+    them as ONE launch (omlm_colsum_group).  The partial buffers are kept alive until :meth:`flush`."""
+
+    def __init__(self):
+        self.items = []
+
+    def add(self, part: torch.Tensor, out: torch.Tensor, P: int, C_: int, ldp: int):
+        self.items.append((part, out, int(P), int(C_), int(ldp)))
+
+    def flush(self):
+        n = len(self.items)
+        if n == 0:
+            return
+        arr = (_ColsumDesc * n)()
+        for d, (part, out, P, C_, ldp) in zip(arr, self.items):
+            d.part, d.out, d.P, d.C, d.ldp = ptr(part), ptr(out), P, C_, ldp
+        call("omlm_colsum_group", C.cast(arr, C.c_void_p), n, stream_ptr())
+        self.items = []
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dx, dxcast, dgamma, dx_scale=1.0, dres2=None, defer: Optional["ColsumGroup"] = None):
+    """dres2 (optional): a second residual-gradient term in the cast type (dxcast's dtype; with dxcast None its own dtype names it).
+    defer: the d(gamma) partial rows stay in a workspace of this call's own and their column sum joins the group's one launch."""
     M, D = x.shape
     code = dcode(dxcast.dtype) if dxcast is not None else (dcode(dres2.dtype) if dres2 is not None else F32)
     assert dres2 is None or dcode(dres2.dtype) == code, "dres2 must have the cast type"
+    if dgamma is not None and defer is not None:
+        rows = min(M, 2048)
+        ws = torch.empty(int(hip.lib().omlm_layernorm_bwd_workspace_bytes(D)) // 4, device=x.device)     # private: alive until the group's flush
+        call("omlm_layernorm_bwd2", ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dres2), ptr(dx),
+             ptr(dxcast), None, ptr(ws), M, D, float(dx_scale), code, dcode(dy.dtype), stream_ptr())
+        defer.add(ws, dgamma, rows, D, D)
+        return
     ws = _ln_workspace(D, x.device) if dgamma is not None else None       # stream-ordered reuse: one backward at a time
     call("omlm_layernorm_bwd2", ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dres2), ptr(dx),
          ptr(dxcast), ptr(dgamma), ptr(ws), M, D, float(dx_scale), code, dcode(dy.dtype), stream_ptr())

@@ -491,6 +491,40 @@ def test_layernorm_fwd_bwd(ops, dev, dtype, M, D):
             assert relerr(dxc3, dx3) < tol
 
 
+def test_layernorm_bwd_grouped_column_sums(ops, dev):
+    """Round 5: LayerNorm backwards whose d(gamma) partial rows are summed by ONE omlm_colsum_group launch (engine.trunk_backward's
+    ColsumGroup) give the same dx bit for bit and the same d(gamma) as the call that sums its own rows -- three problems of different
+    row counts and widths in one group, accumulated onto non-zero d(gamma) buffers."""
+    g = torch.Generator().manual_seed(9)
+    grp = ops.ColsumGroup()
+    cases = []
+    for M, D in ((333, 1024), (6700, 1024), (150, 768)):
+        x = (torch.randn(M, D, generator=g) * 2 + 0.5).to(dev)
+        gamma = (1 + 0.1 * torch.randn(D, generator=g)).to(dev)
+        y = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
+        mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+        ops.layernorm_fwd(x, gamma, y, None, mean, rstd)
+        dy, dres = torch.randn(M, D, generator=g).to(dev), torch.randn(M, D, generator=g).to(dev)
+        start = torch.randn(D, generator=g).to(dev)
+        dx_a, dg_a = torch.empty(M, D, device=dev), start.clone()
+        ops.layernorm_bwd(dy, x, gamma, mean, rstd, dres, dx_a, None, dg_a)
+        dx_b, dg_b = torch.empty(M, D, device=dev), start.clone()
+        ops.layernorm_bwd(dy, x, gamma, mean, rstd, dres, dx_b, None, dg_b, defer=grp)
+        assert torch.equal(dg_b, start)                                   # nothing summed before the flush
+        xr, gr = x.double().requires_grad_(True), gamma.double().requires_grad_(True)
+        torch.nn.functional.layer_norm(xr, (D,), gr, None, 1e-5).backward(dy.double())
+        cases.append((M, D, dx_a, dg_a, dx_b, dg_b, start, gr.grad))
+    assert len(grp.items) == 3
+    grp.flush()
+    assert not grp.items
+    for M, D, dx_a, dg_a, dx_b, dg_b, start, ref in cases:
+        assert torch.equal(dx_a, dx_b)
+        e_own, e_grp = relerr(dg_a - start, ref), relerr(dg_b - start, ref)
+        report(f"layernorm grouped colsum[{M},{D}]", own=e_own, grouped=e_grp)
+        assert e_grp < 1e-4 and e_own < 1e-4
+    grp.flush()                                                           # empty group: no launch, no error
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_qk_norm_fwd_bwd(ops, dev, dtype):
     M, H = 150, 3

@@ -341,6 +341,25 @@ def test_cast_pad_desc_layout_matches_header(tmp_path):
     assert out[1:] == [getattr(ops._CastDesc, f).offset for f in fields]
 
 
+def test_colsum_desc_layout_matches_header(tmp_path):
+    """ctypes mirror of omlm_colsum_desc (the grouped column sums of a backward pass) vs the C header (gcc)."""
+    import ctypes
+    import subprocess
+    from open_musiclm_amd import ops
+    fields = [f[0] for f in ops._ColsumDesc._fields_]
+    src = tmp_path / "cs.c"
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(ROOT, "include", "omlm.h")}"', 'int main(void) {',
+             '  printf("%zu\\n", sizeof(omlm_colsum_desc));']
+    lines += [f'  printf("%zu\\n", offsetof(omlm_colsum_desc, {f}));' for f in fields]
+    lines += ['  return 0; }']
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "cs"
+    subprocess.run(["gcc", "-std=c99", "-o", str(exe), str(src)], check=True)
+    out = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert out[0] == ctypes.sizeof(ops._ColsumDesc)
+    assert out[1:] == [getattr(ops._ColsumDesc, f).offset for f in fields]
+
+
 def test_decode_batch_limit_follows_the_kernels():
     """decode.max_batch: 16 samples per call only where omlm_decode_step's matrix-core kernels serve the model (16-bit weights, dim 1024,
     <= 16 heads, padded feed-forward width <= 3072); 8 everywhere else -- generate() groups larger batches accordingly."""
