@@ -55,6 +55,10 @@ int omlm_gemm(const void* A, const void* B, void* C, const float* Cin,
  *      omlm_layernorm_bwd_workspace_bytes): per-workgroup dgamma partials instead of contended atomics. */
 int omlm_layernorm_fwd(const float* x, const float* gamma, void* y, void* xcast, float* mean, float* rstd,
                        int M, int D, int ldy, float eps, int out_dtype, void* stream);
+/* the same forward with the result as hi/lo planes of the 16-bit type out_dtype (1 = bf16, 2 = fp16): y = rne16(v), y_lo = rne16(v - y), both
+ * at pitch ldy (precision "fp16ff": the FF-in omlm_gemm_planes16 reads both, the backward reads y) */
+int omlm_layernorm_fwd_planes(const float* x, const float* gamma, void* y, void* y_lo, float* mean, float* rstd,
+                              int M, int D, int ldy, float eps, int out_dtype, void* stream);
 long long omlm_layernorm_bwd_workspace_bytes(int D);
 int omlm_layernorm_bwd(const void* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                        const float* dres, float* dx, void* dxcast, float* dgamma, float* workspace, int M, int D,
@@ -128,6 +132,13 @@ int omlm_mqa_attn_bwd(const void* q, const void* k, const void* v, const float* 
 int omlm_ffmid_fwd(const void* h1, const void* convw, const void* gamma, void* h2, float* mean, float* rstd,
                    int M, int nseq, int F, int Fp, float eps, float p, unsigned long long seed,
                    const unsigned long long* seed_dev, unsigned char* drop_bits, void* gh, int dtype, void* stream);
+/* The same forward on hi/lo planes of the 16-bit type `dtype` (1 = bf16, 2 = fp16; precision "fp16ff"): h1 (what omlm_gemm_planes16 left), the
+ * conv taps and gamma are read as hi + lo (each *_lo plane in its hi plane's layout), h2 leaves as planes (h2 = rne16(y), h2_lo = rne16(y - h2))
+ * for the FF-out omlm_gemm_planes16; gh, statistics and keep bits as above.  Strip kernels only: Fp <= 4096, drop_bits required when p > 0.
+ * The backward is omlm_ffmid_bwd on the hi planes. */
+int omlm_ffmid_fwd_planes(const void* h1, const void* h1_lo, const void* convw, const void* convw_lo, const void* gamma, const void* gamma_lo,
+                          void* h2, void* h2_lo, float* mean, float* rstd, int M, int nseq, int F, int Fp, float eps, float p,
+                          unsigned long long seed, const unsigned long long* seed_dev, unsigned char* drop_bits, void* gh, int dtype, void* stream);
 long long omlm_ffmid_bwd_workspace_bytes(int F, int Fp);
 int omlm_ffmid_bwd(const void* dh2, const void* h1, const void* convw, const void* gamma, const float* mean,
                    const float* rstd, void* du_tmp, void* dh1, float* dgamma, float* dconv, float* workspace,
@@ -195,8 +206,10 @@ int omlm_cast_pad(const float* src, void* dst, long long R, int C, int ld_src, i
  * nn.Linear, transformer.py:203-212,144,149), refreshed once per optimizer step. */
 int omlm_transpose_cast(const float* src, void* dst, int R, int C, int ld_src, int ld_dst, int out_dtype, void* stream);
 /* The per-step weight re-packs of a model as ONE launch: problem i casts src [R, C] (pitch ld_src) into dst [R, ld_dst] with zero pad
- * columns (omlm_cast_pad), or -- transpose != 0 -- writes dst[c, r] = src[r, c] (omlm_transpose_cast; pad entries untouched). */
-typedef struct omlm_cast_pad_desc { const float* src; void* dst; int R, C, ld_src, ld_dst, transpose, pad; } omlm_cast_pad_desc;
+ * columns (omlm_cast_pad), or -- transpose != 0 -- writes dst[c, r] = src[r, c] (omlm_transpose_cast; pad entries untouched).
+ * lo != 0: dst receives the LO PLANE of the cast, rne16(v - rne16(v)), instead of the cast itself (the hi/lo weight planes of precision
+ * "fp16ff": omlm_gemm_planes16, omlm_ffmid_fwd_planes). */
+typedef struct omlm_cast_pad_desc { const float* src; void* dst; int R, C, ld_src, ld_dst, transpose, lo; } omlm_cast_pad_desc;
 int omlm_cast_pad_group(const omlm_cast_pad_desc* problems, int count, int out_dtype, void* stream);
 
 /* fp32-grade GEMM ("bf16x3") on bf16 hi/lo operand planes through the bf16 LDS-DMA tile kernels: A and B point at bf16 hi planes
@@ -209,6 +222,13 @@ int omlm_gemm_planes(const void* A, long long a_plane_bytes, const void* B, long
                      int M, int N, int K, int lda, int ldb, int ldc, int ldcin,
                      int a_kmajor, int b_kmajor, int out_dtype, float alpha, void* stream);
 int omlm_split_planes(const float* x, void* planes, long long n, long long plane_elems, void* stream);
+/* Precision "fp16ff" (round 5): the forward of the two ConvFeedForward linears (transformer.py:144,149 -- 86-88 % of the fp16 logits-error
+ * variance, profiles/r05_error_budget.md) on hi/lo planes of the 16-bit operand type `dtype` (1 = bf16, 2 = fp16).  C = A B^T (+ Cin), A [M, K]
+ * and B [N, K] row-major, every *_lo plane in its hi plane's layout (separate allocations are fine); one launch, hi*hi + hi*lo + lo*hi with
+ * fp32 accumulation.  C_lo NULL: C is fp32 (Cin optional).  C_lo given: C = rne16(v) and C_lo = rne16(v - C) in `dtype` (no Cin) -- the next
+ * forward kernel reads the un-rounded value hi + lo, the 16-bit backward reads C alone. */
+int omlm_gemm_planes16(const void* A, const void* A_lo, const void* B, const void* B_lo, void* C, void* C_lo, const float* Cin,
+                       long long a_rows, long long b_rows, int M, int N, int K, int lda, int ldb, int ldc, int ldcin, int dtype, void* stream);
 /* All weight-gradient contractions of a backward pass in one launch (autograd of nn.Linear, transformer.py:203-212,144,149:
  * dW += dY^T X).  Problem i: C_i [M_i, N_i] fp32 (accumulated, +=; c_map optional: physical row of logical row m, < 0 skips)
  * from 16-bit k-major operands A_i [K_i, M_i] (pitch lda) and B_i [K_i, N_i] (pitch ldb); pitches are multiples of 8 elements.

@@ -680,6 +680,37 @@ extern "C" int OMLM_API(omlm_ffmid_fwd)(const void* h1, const void* convw, const
     return omlm_post_launch("omlm_ffmid_fwd");
 }
 
+// The same forward on hi/lo planes of the 16-bit type `dtype` (1 = bf16, 2 = fp16; precision "fp16ff"): h1, the conv taps and gamma are read
+// as hi + lo (each *_lo plane has its hi plane's layout), h2 leaves as planes h2 = rne16(y), h2_lo = rne16(y - h2); gh, the statistics and
+// the keep bits as in omlm_ffmid_fwd.  The strip kernels only (Fp <= 4096, drop_bits present when p > 0).
+int ffmid2_fwd_planes_launch(const void* h1, const void* h1_lo, const void* convw, const void* convw_lo, const void* gamma, const void* gamma_lo,
+                             void* h2, void* h2_lo, float* mean, float* rstd, int M, int nseq, int F, int Fp, float eps, float p,
+                             unsigned long long seed, const unsigned long long* seed_dev, unsigned char* drop_bits, void* gh, hipStream_t st);
+#if !OMLM_FP16
+extern "C" int omlm_ffmid_fwd_planes_h(const void* h1, const void* h1_lo, const void* convw, const void* convw_lo, const void* gamma, const void* gamma_lo,
+                                       void* h2, void* h2_lo, float* mean, float* rstd, int M, int nseq, int F, int Fp, float eps, float p,
+                                       unsigned long long seed, const unsigned long long* seed_dev, unsigned char* drop_bits, void* gh, int dtype, void* stream);
+#endif
+extern "C" int OMLM_API(omlm_ffmid_fwd_planes)(const void* h1, const void* h1_lo, const void* convw, const void* convw_lo, const void* gamma,
+                                               const void* gamma_lo, void* h2, void* h2_lo, float* mean, float* rstd, int M, int nseq, int F, int Fp,
+                                               float eps, float p, unsigned long long seed, const unsigned long long* seed_dev,
+                                               unsigned char* drop_bits, void* gh, int dtype, void* stream) {
+#if !OMLM_FP16
+    if (dtype == OMLM_DT_F16)
+        return omlm_ffmid_fwd_planes_h(h1, h1_lo, convw, convw_lo, gamma, gamma_lo, h2, h2_lo, mean, rstd, M, nseq, F, Fp, eps, p, seed, seed_dev, drop_bits, gh, 1, stream);
+#endif
+    OMLM_CHECK_ARG(dtype == 1, "ffmid_fwd_planes: dtype 1 (bf16) or 2 (fp16)");
+    if (M <= 0) return OMLM_OK;
+    OMLM_CHECK_ARG(h1 && h1_lo && convw && convw_lo && gamma && gamma_lo && h2 && h2_lo && mean && rstd, "null pointer");
+    OMLM_CHECK_ARG(Fp % 8 == 0 && Fp >= F && ffmid2_supported(Fp), "ffmid_fwd_planes: Fp must be F rounded up to 8 and <= 4096");
+    OMLM_CHECK_ARG(nseq > 0 && M % nseq == 0, "M must be batch * nseq");
+    OMLM_CHECK_ARG(p >= 0.f && p < 1.f && (p == 0.f || drop_bits), "dropout p (keep bits required when p > 0)");
+    OMLM_CHECK_ARG((((uintptr_t)h1 | (uintptr_t)h1_lo | (uintptr_t)convw | (uintptr_t)convw_lo | (uintptr_t)gamma | (uintptr_t)gamma_lo |
+                     (uintptr_t)h2 | (uintptr_t)h2_lo) % 16) == 0, "ffmid_fwd_planes: 16-byte aligned planes");
+    return ffmid2_fwd_planes_launch(h1, h1_lo, convw, convw_lo, gamma, gamma_lo, h2, h2_lo, mean, rstd, M, nseq, F, Fp, eps, p, seed, seed_dev,
+                                    drop_bits, gh, as_stream(stream));
+}
+
 // du_tmp: [M, 2*Fp] scratch of the operand dtype; dh1: [M, 2*Fp] output; workspace: omlm_ffmid_bwd_workspace_bytes.
 // dgamma [F], dconv [2F*3] are accumulated into (+=).
 #if !OMLM_FP16

@@ -77,6 +77,31 @@ template <> struct Ch4<float> {
     static __device__ __forceinline__ void store(float* p, const v2 (&y)[2]) { *(float4*)p = make_float4(y[0][0], y[0][1], y[1][0], y[1][1]); }
 };
 
+// 8 channels of an operand that may arrive as hi/lo planes of the 16-bit type (precision "fp16ff": the forward reads the un-rounded h1,
+// taps and gamma as hi + lo and leaves h2 as planes; `lo` = element distance from the hi plane to the lo plane).  PL false: Ch8<T> itself.
+template <typename T, bool PL> struct Row8 {
+    Ch8<T> h;
+    __device__ __forceinline__ void load(const T* p, long long) { h.load(p); }
+    __device__ __forceinline__ void zero() { h.zero(); }
+    __device__ __forceinline__ v2 get(int i) const { return h.get(i); }
+};
+template <typename T> struct Row8<T, true> {
+    Ch8<T> h, l;
+    __device__ __forceinline__ void load(const T* p, long long lo) { h.load(p); l.load(p + lo); }
+    __device__ __forceinline__ void zero() { h.zero(); l.zero(); }
+    __device__ __forceinline__ v2 get(int i) const { return h.get(i) + l.get(i); }
+};
+// y as planes: hi = rne16(y), lo = rne16(y - hi)
+__device__ __forceinline__ void store_planes8(h16_t* hi, h16_t* lo, const v2 (&y)[4]) {
+    u32x4 o, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[i] = f2_to_bf2(y[i]); l[i] = f2_to_bf2(y[i] - bf2_to_f2(o[i])); }
+    *(u32x4*)hi = o;
+    *(u32x4*)lo = l;
+}
+__device__ __forceinline__ void store_planes8(float*, float*, const v2 (&)[4]) {}          // (fp32 operands have no planes)
+struct FfPlanes { long long h1_lo, convw_lo, gamma_lo; void* h2_lo; };      // element distances hi -> lo of the inputs; lo plane of h2
+
 __device__ __forceinline__ void pin_regs(Ch8<h16_t>& a, Ch8<h16_t>& b) { asm volatile("" : "+v"(a.r), "+v"(b.r)); }
 __device__ __forceinline__ void pin_regs(Ch8<float>&, Ch8<float>&) {}
 
@@ -140,15 +165,15 @@ __device__ __forceinline__ void keep_words(unsigned long long seed, unsigned lon
 // forward.  grid: B * strips workgroups of NT threads (NT = chunks of 8 channels rounded up to waves); strip s of sample b
 // covers rows [s * RB, min(nseq, (s + 1) * RB)).
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T, int NT, bool TRAIN>
+template <typename T, int NT, bool TRAIN, bool PL = false>
 __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kernel(const T* __restrict__ h1, const T* __restrict__ convw,
                                                         const T* __restrict__ gamma, T* __restrict__ h2,
                                                         float* __restrict__ mean, float* __restrict__ rstd,
                                                         int nseq, int F, int Fp, int RB, int strips, float eps, float p,
                                                         unsigned long long seed, const unsigned long long* __restrict__ seed_dev,
-                                                        unsigned char* __restrict__ drop_bits, T* __restrict__ gh_out) {
+                                                        unsigned char* __restrict__ drop_bits, T* __restrict__ gh_out, const FfPlanes pl) {
     constexpr int NW = NT / 64;
-    constexpr int RB_ = sizeof(T) == 2 ? FS_R : (FS_R > 2 ? 2 : FS_R);        // rows per batch: fp32 rows cost twice the registers
+    constexpr int RB_ = (sizeof(T) == 2 && !PL) ? FS_R : (FS_R > 2 ? 2 : FS_R);        // rows per batch: fp32 rows (and hi + lo rows) cost twice the registers
     __shared__ float st[2][FS_R][NW][2];
     if (seed_dev) seed += seed_dev[0] * 0x9E3779B97F4A7C15ull;
     const int b = blockIdx.x / strips, s = blockIdx.x - b * strips;
@@ -173,13 +198,13 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
     // taps / gamma: registers for the whole strip.  FS_PACKW (16-bit operands): the taps stay PACKED (24 registers instead of 48) and are
     // unpacked where they are used -- 2 VALU instructions per pair and use, ~12 % more issue, for a register budget that admits a
     // second workgroup per CU (6 + 6 waves = 3 per SIMD instead of the 2 / 2 / 1 / 1 of a lone 6-wave workgroup).
-    constexpr bool PACKW = FS_PACKW && sizeof(T) == 2;
+    constexpr bool PACKW = FS_PACKW && sizeof(T) == 2 && !PL;
     v2 wv[PACKW ? 1 : 3][4], wg[PACKW ? 1 : 3][4], gm[4];
-    Ch8<T> tv[3], tg[3];
+    Row8<T, PL> tv[3], tg[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        tv[k].load(convw + (size_t)k * ld + col);
-        tg[k].load(convw + (size_t)k * ld + Fp + col);
+        tv[k].load(convw + (size_t)k * ld + col, pl.convw_lo);
+        tg[k].load(convw + (size_t)k * ld + Fp + col, pl.convw_lo);
         if constexpr (!PACKW) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) { wv[k][i] = tv[k].get(i); wg[k][i] = tg[k].get(i); }
@@ -188,27 +213,27 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
     auto WV = [&](int k, int i) -> v2 { if constexpr (PACKW) return tv[k].get(i); else return wv[k][i]; };
     auto WG = [&](int k, int i) -> v2 { if constexpr (PACKW) return tg[k].get(i); else return wg[k][i]; };
     {
-        Ch8<T> a;
-        a.load(gamma + col);
+        Row8<T, PL> a;
+        a.load(gamma + col, pl.gamma_lo);
 #pragma unroll
         for (int i = 0; i < 4; ++i) gm[i] = a.get(i) * inv;                  // dropout scale folded into gamma
     }
     // conv window: rows t0 - 1 and t0 - 2 of the same sample (zero before the sample starts, transformer.py:129)
     v2 x1v[4], x1g[4], x2v[4], x2g[4];
     {
-        Ch8<T> a, c, d, e;
+        Row8<T, PL> a, c, d, e;
         a.zero(); c.zero(); d.zero(); e.zero();
-        if (t0 >= 1) { a.load(h1 + (row0 + t0 - 1) * ld + col); c.load(h1 + (row0 + t0 - 1) * ld + Fp + col); }
-        if (t0 >= 2) { d.load(h1 + (row0 + t0 - 2) * ld + col); e.load(h1 + (row0 + t0 - 2) * ld + Fp + col); }
+        if (t0 >= 1) { a.load(h1 + (row0 + t0 - 1) * ld + col, pl.h1_lo); c.load(h1 + (row0 + t0 - 1) * ld + Fp + col, pl.h1_lo); }
+        if (t0 >= 2) { d.load(h1 + (row0 + t0 - 2) * ld + col, pl.h1_lo); e.load(h1 + (row0 + t0 - 2) * ld + Fp + col, pl.h1_lo); }
 #pragma unroll
         for (int i = 0; i < 4; ++i) { x1v[i] = a.get(i); x1g[i] = c.get(i); x2v[i] = d.get(i); x2g[i] = e.get(i); }
     }
-    Ch8<T> rv[RB_], rg[RB_];
+    Row8<T, PL> rv[RB_], rg[RB_];
 #pragma unroll
     for (int r = 0; r < RB_; ++r)
         if (t0 + r < t1) {
-            rv[r].load(h1 + (row0 + t0 + r) * ld + col);
-            rg[r].load(h1 + (row0 + t0 + r) * ld + Fp + col);
+            rv[r].load(h1 + (row0 + t0 + r) * ld + col, pl.h1_lo);
+            rg[r].load(h1 + (row0 + t0 + r) * ld + Fp + col, pl.h1_lo);
         }
     const float invF = 1.0f / (float)F;
 
@@ -229,7 +254,7 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
                 v2 s2 = splat2(0.f), q2 = splat2(0.f);
                 if constexpr (PACKW) {                   // opaque per row: the unpacked taps must not be hoisted back into loop-invariant registers
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) pin_regs(tv[k], tg[k]);
+                    for (int k = 0; k < 3; ++k) pin_regs(tv[k].h, tg[k].h);
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -259,8 +284,8 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
 #if FS_PIN
                 if (FULL) __builtin_amdgcn_sched_barrier(0);     // (hipcc's scheduler otherwise sinks the four requests below the whole sweep)
 #endif
-                rv[r].load(h1 + (row0 + tb + RB_ + r) * ld + col);
-                rg[r].load(h1 + (row0 + tb + RB_ + r) * ld + Fp + col);
+                rv[r].load(h1 + (row0 + tb + RB_ + r) * ld + col, pl.h1_lo);
+                rg[r].load(h1 + (row0 + tb + RB_ + r) * ld + Fp + col, pl.h1_lo);
 #if FS_PIN
                 if (FULL) __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -272,8 +297,8 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
 #pragma unroll
         for (int r = 0; r < RB_; ++r)
             if (FULL || tb + RB_ + r < t1) {
-                rv[r].load(h1 + (row0 + tb + RB_ + r) * ld + col);
-                rg[r].load(h1 + (row0 + tb + RB_ + r) * ld + Fp + col);
+                rv[r].load(h1 + (row0 + tb + RB_ + r) * ld + col, pl.h1_lo);
+                rg[r].load(h1 + (row0 + tb + RB_ + r) * ld + Fp + col, pl.h1_lo);
             }
 #endif
 #pragma unroll
@@ -337,7 +362,8 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
             if (!(FS_DIAG & 2) || eps < 0.f) Ch8<T>::store(h2 + row * Fp + col, y);
             if (!(FS_DIAG & 4) || eps < 0.f) { if (TRAIN || gh_out) Ch8<T>::store(gh_out + row * Fp + col, gh); }
 #else
-            Ch8<T>::store(h2 + row * Fp + col, y);
+            if constexpr (PL) store_planes8(h2 + row * Fp + col, (T*)pl.h2_lo + row * Fp + col, y);
+            else Ch8<T>::store(h2 + row * Fp + col, y);
             if (TRAIN || gh_out) Ch8<T>::store(gh_out + row * Fp + col, gh);
 #endif
         }
@@ -601,10 +627,10 @@ static int strip_rows(int nseq, int target) {
 
 bool ffmid2_supported(int Fp) { return Fp % 8 == 0 && Fp / 8 <= 512; }
 
-template <typename T>
+template <typename T, bool PL = false>
 static int fwd_launch_t(const void* h1, const void* convw, const void* gamma, void* h2, float* mean, float* rstd, int M, int nseq,
                         int F, int Fp, float eps, float p, unsigned long long seed, const unsigned long long* seed_dev,
-                        unsigned char* drop_bits, void* gh, hipStream_t st) {
+                        unsigned char* drop_bits, void* gh, hipStream_t st, const FfPlanes pl = FfPlanes{0, 0, 0, nullptr}) {
     const int B = M / nseq;
     const int RB = strip_rows(nseq, 36);
     const int strips = (nseq + RB - 1) / RB;
@@ -612,10 +638,10 @@ static int fwd_launch_t(const void* h1, const void* convw, const void* gamma, vo
     const int nthr = Fp / 8;                                                   // threads launched: one per chunk
     dim3 grid(B * strips);
     const bool train = p > 0.f && drop_bits != nullptr && gh != nullptr;       // the training call: all three row stores are unconditional
-#define FF2_FWD(NT_) do { if (train) hipLaunchKernelGGL((ffmid2_fwd_kernel<T, NT_, true>), grid, dim3(nthr), 0, st, (const T*)h1, (const T*)convw, \
-        (const T*)gamma, (T*)h2, mean, rstd, nseq, F, Fp, RB, strips, eps, p, seed, seed_dev, drop_bits, (T*)gh); \
-    else hipLaunchKernelGGL((ffmid2_fwd_kernel<T, NT_, false>), grid, dim3(nthr), 0, st, (const T*)h1, (const T*)convw, \
-        (const T*)gamma, (T*)h2, mean, rstd, nseq, F, Fp, RB, strips, eps, p, seed, seed_dev, drop_bits, (T*)gh); } while (0)
+#define FF2_FWD(NT_) do { if (train) hipLaunchKernelGGL((ffmid2_fwd_kernel<T, NT_, true, PL>), grid, dim3(nthr), 0, st, (const T*)h1, (const T*)convw, \
+        (const T*)gamma, (T*)h2, mean, rstd, nseq, F, Fp, RB, strips, eps, p, seed, seed_dev, drop_bits, (T*)gh, pl); \
+    else hipLaunchKernelGGL((ffmid2_fwd_kernel<T, NT_, false, PL>), grid, dim3(nthr), 0, st, (const T*)h1, (const T*)convw, \
+        (const T*)gamma, (T*)h2, mean, rstd, nseq, F, Fp, RB, strips, eps, p, seed, seed_dev, drop_bits, (T*)gh, pl); } while (0)
     switch (nt) {
         case 64: FF2_FWD(64); break;
         case 128: FF2_FWD(128); break;
@@ -638,6 +664,18 @@ int ffmid2_fwd_launch(const void* h1, const void* convw, const void* gamma, void
     if (dtype == 0) return fwd_launch_t<float>(h1, convw, gamma, h2, mean, rstd, M, nseq, F, Fp, eps, p, seed, seed_dev, drop_bits, gh, st);
 #endif
     return fwd_launch_t<h16_t>(h1, convw, gamma, h2, mean, rstd, M, nseq, F, Fp, eps, p, seed, seed_dev, drop_bits, gh, st);
+}
+
+// the same forward on hi/lo planes of the 16-bit type (omlm_ffmid_fwd_planes): h1, taps and gamma are read as hi + lo, h2 leaves as planes
+int ffmid2_fwd_planes_launch(const void* h1, const void* h1_lo, const void* convw, const void* convw_lo, const void* gamma, const void* gamma_lo,
+                             void* h2, void* h2_lo, float* mean, float* rstd, int M, int nseq, int F, int Fp, float eps, float p,
+                             unsigned long long seed, const unsigned long long* seed_dev, unsigned char* drop_bits, void* gh, hipStream_t st) {
+    FfPlanes pl;
+    pl.h1_lo = (const h16_t*)h1_lo - (const h16_t*)h1;
+    pl.convw_lo = (const h16_t*)convw_lo - (const h16_t*)convw;
+    pl.gamma_lo = (const h16_t*)gamma_lo - (const h16_t*)gamma;
+    pl.h2_lo = h2_lo;
+    return fwd_launch_t<h16_t, true>(h1, convw, gamma, h2, mean, rstd, M, nseq, F, Fp, eps, p, seed, seed_dev, drop_bits, gh, st, pl);
 }
 
 // bc: [M][2] floats of scratch; part_g: [>= rowsum blocks][Fp]; part_c: [>= NY][2F*3]

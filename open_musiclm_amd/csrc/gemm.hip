@@ -69,10 +69,12 @@ struct GemmArgs {
     int bal_ck;         // > 0: balanced split-K ("chunked stream-K"): gridDim.x workgroups share tiles x k-tiles evenly; k-tiles per K chunk
     int bal_chunks;     //      number of K chunks
     int debug;          // profiling ablations only (OMLM_GEMM_DEBUG): bit 0 = skip the per-tile DMA, bit 1 = skip the MFMAs
-    // hi/lo operand planes ("bf16x3" through the bf16 tile kernels): A and B each point at a bf16 hi plane with the lo plane
-    // a_plane / b_plane BYTES behind it, and the k-loop runs 3 x the k-tiles: (A_hi, B_hi), (A_hi, B_lo), (A_lo, B_hi).
+    // hi/lo operand planes ("bf16x3" through the tile kernels; round 5: the ConvFeedForward forward of "fp16ff" on IEEE-half planes): A and B
+    // point at a 16-bit hi plane, A_lo / B_lo at the matching lo plane (same layout, its own buffer descriptor: the planes may be separate
+    // allocations), and the k-loop runs 3 x the k-tiles: (A_hi, B_hi), (A_hi, B_lo), (A_lo, B_hi).  C_lo (TOUT = h16pl_t instantiations):
+    // the result leaves as planes too -- C = rne16(v), C_lo = rne16(v - C) at the same pitch.
     int split3;
-    unsigned a_plane, b_plane;
+    const void* A_lo; const void* B_lo; void* C_lo;
     // l2-norm epilogue (EPI == 1 instantiations, omlm_gemm_qknorm): the first epi_groups 64-column groups of a row leave the kernel as
     // v / max(|v|, 1e-12) * epi_scale[col & 63] with the norm written to epi_norm[row * epi_ldnorm + group]; columns >= c2_col0 (if C2) go
     // to C2 + row * ldc2 + (col - c2_col0)
@@ -401,6 +403,9 @@ struct DmaStagerT {
     }
 };
 
+// Output type tag of the plane-output instantiations: 16-bit elements, C receives rne16(v) and GemmArgs::C_lo receives rne16(v - C).
+struct h16pl_t { h16_t v; };
+
 // Epilogue shared by the tile kernels.  In the MFMA C-layout a lane owns ONE column and 16 rows, so direct stores are 2- or 4-byte
 // scatters (measured: ~480 of 650 us of the FF-in GEMM).  Each 32-row strip of the wave's tile is therefore transposed
 // through a per-wave LDS patch (the k-loop stages are dead: the caller has passed a barrier) and written as 16-byte
@@ -413,7 +418,9 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16 (&acc)[M
     constexpr int VEC = sizeof(TOUT) == 2 ? 8 : 4;                 // elements per 16-byte store
     constexpr int LPR = WN_ / VEC;                                 // lanes per row
     constexpr int RPP = 64 / LPR;                                  // rows per pass
-    TOUT* C = (TOUT*)g.C;
+    constexpr bool PLANES = std::is_same<TOUT, h16pl_t>::value;
+    using TST = std::conditional_t<PLANES, h16_t, TOUT>;           // element type of the stores
+    TST* C = (TST*)g.C;
     const bool vec_ok = (g.ldc % VEC == 0) && (((uintptr_t)g.C & 15) == 0) &&
                         (!g.Cin || ((g.ldcin % 4 == 0) && (((uintptr_t)g.Cin & 15) == 0)));
     const int hi = lane >> 5;
@@ -520,7 +527,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16 (&acc)[M
                     v[4] = v[4] * inv * s1.x; v[5] = v[5] * inv * s1.y; v[6] = v[6] * inv * s1.z; v[7] = v[7] * inv * s1.w;
                     if ((lane % LPR) == 0) g.epi_norm[prow * g.epi_ldnorm + grp] = nrm;
                 }
-                TOUT* dst = (g.C2 && col >= g.c2_col0) ? (TOUT*)g.C2 + prow * g.ldc2 + (col - g.c2_col0) : C + prow * g.ldc + col;
+                TST* dst = (g.C2 && col >= g.c2_col0) ? (TST*)g.C2 + prow * g.ldc2 + (col - g.c2_col0) : C + prow * g.ldc + col;
                 u32x4 o;
                 o[0] = pack_h16_rne(v[0], v[1]); o[1] = pack_h16_rne(v[2], v[3]);
                 o[2] = pack_h16_rne(v[4 % VEC], v[5 % VEC]); o[3] = pack_h16_rne(v[6 % VEC], v[7 % VEC]);
@@ -546,6 +553,13 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16 (&acc)[M
                     o[0] = pack_h16_rne(v[0], v[1]); o[1] = pack_h16_rne(v[2], v[3]);
                     o[2] = pack_h16_rne(v[4 % VEC], v[5 % VEC]); o[3] = pack_h16_rne(v[6 % VEC], v[7 % VEC]);
                     *(u32x4*)(C + prow * g.ldc + col) = o;
+                    if constexpr (PLANES) {
+                        u32x4 l;
+#pragma unroll
+                        for (int x = 0; x < 4; ++x)
+                            l[x] = pack_h16_rne(v[(2 * x) % VEC] - h16_lo_to_f(o[x]), v[(2 * x + 1) % VEC] - h16_hi_to_f(o[x]));
+                        *(u32x4*)((h16_t*)g.C_lo + prow * g.ldc + col) = l;
+                    }
                 } else {
                     *(float4*)((float*)g.C + prow * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
                 }
@@ -556,6 +570,10 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16 (&acc)[M
                         float o = v[x];
                         if (g.Cin) o += g.Cin[prow * g.ldcin + col + x];
                         store_from_float(C + prow * g.ldc + col + x, o);
+                        if constexpr (PLANES) {
+                            const h16_t hi = (h16_t)o;
+                            store_from_float((h16_t*)g.C_lo + prow * g.ldc + col + x, o - (float)hi);
+                        }
                     }
             }
         }
@@ -605,6 +623,8 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, 
     const int wm = (wave / NWN) * WM_, wn = (wave % NWN) * WN_;
     const dma_rsrc rsA = make_dma_rsrc(g.A, (unsigned long long)g.a_rows * g.lda * 2);
     const dma_rsrc rsB = make_dma_rsrc(g.B, (unsigned long long)g.b_rows * g.ldb * 2);
+    const dma_rsrc rsAl = make_dma_rsrc(SPLIT3 ? g.A_lo : g.A, (unsigned long long)g.a_rows * g.lda * 2);      // (plain kernels: never used)
+    const dma_rsrc rsBl = make_dma_rsrc(SPLIT3 ? g.B_lo : g.B, (unsigned long long)g.b_rows * g.ldb * 2);
 
     for (;;) {
         int bid, kt0, kt1;
@@ -647,22 +667,23 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, 
 
         // k-tile index -> contraction offset and operand planes
         // (SPLIT3 is its own instantiation: the plain kernels keep the code and register allocation they were measured with)
-        auto tile_at = [&](int t, unsigned& pa, unsigned& pb) -> int {
+        // pa / pb: the k-tile reads A's / B's lo plane (uniform: the descriptor is chosen by scalar selects)
+        auto tile_at = [&](int t, bool& pa, bool& pb) -> int {
             if constexpr (SPLIT3) {
                 const int which = t >= 2 * nk1 ? 2 : (t >= nk1 ? 1 : 0);
-                pa = which == 2 ? g.a_plane : 0u;
-                pb = which == 1 ? g.b_plane : 0u;
+                pa = which == 2;
+                pb = which == 1;
                 return (t - which * nk1) * BK;
             } else {
-                pa = 0u; pb = 0u;
+                pa = false; pb = false;
                 return t * BK;
             }
         };
         if (kt0 < kt1) {
-            unsigned pa, pb;
+            bool pa, pb;
             const int k00 = tile_at(kt0, pa, pb);
-            sa.template issue<KMAP, FASTK>(rsA, g.a_map, g.lda, k00, g.K, smem, wave, pa);
-            sb.template issue<KMAP, FASTK>(rsB, g.b_map, g.ldb, k00, g.K, smem + A_BYTES, wave, pb);
+            sa.template issue<KMAP, FASTK>(SPLIT3 && pa ? rsAl : rsA, g.a_map, g.lda, k00, g.K, smem, wave);
+            sb.template issue<KMAP, FASTK>(SPLIT3 && pb ? rsBl : rsB, g.b_map, g.ldb, k00, g.K, smem + A_BYTES, wave);
         }
         // Rotated k-loop: the MFMAs of a tile's LAST k16 step run AFTER the next tile's barrier and first fragment reads (their
         // operands are in registers), so the matrix pipe has work while the barrier releases and the first LDS reads of the new
@@ -680,8 +701,9 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, 
                 __syncthreads();      // tile kt landed everywhere; every wave's reads of the other stage (incl. its last step) are complete
                 const bool live = kt + 1 < kt1 && !(dbg & 1);        // dbg (DBG instantiation only): bit 0 = no DMA after the first tile, bit 1 = no MFMAs
                 char* nxt = smem + (cur ^ 1) * STAGE;
-                unsigned pan, pbn;
+                bool pan, pbn;
                 const int knext = tile_at(kt + 1, pan, pbn);
+                const dma_rsrc rsAn = SPLIT3 && pan ? rsAl : rsA, rsBn = SPLIT3 && pbn ? rsBl : rsB;
                 const char* As = smem + cur * STAGE;
                 const char* Bs = As + A_BYTES;
                 // phase ph in 0..3 = (deferred last step of tile kt-1, step 0, step 1, step 2) of this iteration; fi = fragment set
@@ -696,8 +718,8 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, 
                             if (midx % STRIDE == 0 && midx / STRIDE < NLOAD) {
                                 const int l = midx / STRIDE;
                                 __builtin_amdgcn_sched_barrier(0);
-                                if (l < UA) sa.template issue_one<KMAP, FASTK>(l, rsA, g.a_map, g.lda, knext, g.K, nxt, wave, live, 0, pan);
-                                else        sb.template issue_one<KMAP, FASTK>(l - UA, rsB, g.b_map, g.ldb, knext, g.K, nxt + A_BYTES, wave, live, 0, pbn);
+                                if (l < UA) sa.template issue_one<KMAP, FASTK>(l, rsAn, g.a_map, g.lda, knext, g.K, nxt, wave, live);
+                                else        sb.template issue_one<KMAP, FASTK>(l - UA, rsBn, g.b_map, g.ldb, knext, g.K, nxt + A_BYTES, wave, live);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                         }
@@ -988,6 +1010,8 @@ __device__ __forceinline__ void gemm_tile8_body(const GemmArgs& g, const int m0,
     const int wr = wave >> 2, wc = wave & 3;
     const dma_rsrc rsA = make_dma_rsrc(g.A, (unsigned long long)g.a_rows * g.lda * 2);
     const dma_rsrc rsB = make_dma_rsrc(g.B, (unsigned long long)g.b_rows * g.ldb * 2);
+    const dma_rsrc rsAl = make_dma_rsrc(SPLIT3 ? g.A_lo : g.A, (unsigned long long)g.a_rows * g.lda * 2);      // (plain kernels: never used)
+    const dma_rsrc rsBl = make_dma_rsrc(SPLIT3 ? g.B_lo : g.B, (unsigned long long)g.b_rows * g.ldb * 2);
     DmaStagerT<A_KMAJ, 256, 8> sa;          // unit i of a wave is 1-KiB unit b = wave + 8 i of the tile image: i < 2 -> rows / columns [0, 128) = half 0
     DmaStagerT<B_KMAJ, 256, 8> sb;
     sa.init(nullptr, g.lda, g.M, m0, wave, lane);
@@ -1007,21 +1031,24 @@ __device__ __forceinline__ void gemm_tile8_body(const GemmArgs& g, const int m0,
         constexpr bool isA = (J & 1) != 0;
         constexpr int h = J >> 1;
         const bool live = T < nk;
-        unsigned k0 = (unsigned)(kt0 + T) * BK, poff = 0u;
+        unsigned k0 = (unsigned)(kt0 + T) * BK;
+        bool lo = false;                        // this event reads its operand's lo plane (uniform)
         if constexpr (SPLIT3) {
             // hi/lo operand planes ("bf16x3"): loop tile t reads planes (A_hi, B_hi), (A_hi, B_lo), (A_lo, B_hi) at k = (t mod nk1) * 64 -- gemm_tile_body's tile_at
             const int t = kt0 + T, nk1 = g.K / BK;
             const int which = t >= 2 * nk1 ? 2 : (t >= nk1 ? 1 : 0);
             k0 = (unsigned)(t - which * nk1) * BK;
-            poff = isA ? (which == 2 ? g.a_plane : 0u) : (which == 1 ? g.b_plane : 0u);
+            lo = isA ? which == 2 : which == 1;
         }
+        const dma_rsrc rs = isA ? (SPLIT3 && lo ? rsAl : rsA) : (SPLIT3 && lo ? rsBl : rsB);
+        if constexpr (SPLIT3) k0 = (unsigned)__builtin_amdgcn_readfirstlane((int)k0);      // (hipcc keeps the plane arithmetic on the VALU: the offset must reach the DMA in an SGPR)
         const unsigned base = smem_lds + (unsigned)((T & 1) * STAGE) + (isA ? 0u : (unsigned)A_BYTES);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int i = 2 * h + u;
             const int b = wave + 8 * i;
-            if constexpr (isA) dma_issue_s(rsA, base + (unsigned)(b * 1024), live ? sa.vfast[i] : OOB_OFF, (A_KMAJ ? k0 * (unsigned)(g.lda * 2) : k0 * 2u) + poff);
-            else               dma_issue_s(rsB, base + (unsigned)(b * 1024), live ? sb.vfast[i] : OOB_OFF, (B_KMAJ ? k0 * (unsigned)(g.ldb * 2) : k0 * 2u) + poff);
+            if constexpr (isA) dma_issue_s(rs, base + (unsigned)(b * 1024), live ? sa.vfast[i] : OOB_OFF, A_KMAJ ? k0 * (unsigned)(g.lda * 2) : k0 * 2u);
+            else               dma_issue_s(rs, base + (unsigned)(b * 1024), live ? sb.vfast[i] : OOB_OFF, B_KMAJ ? k0 * (unsigned)(g.ldb * 2) : k0 * 2u);
         }
     };
     using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>;
@@ -1150,7 +1177,7 @@ __global__ __launch_bounds__(512) void gemm_wgrad_group_kernel(GroupArgs ga) {
     GemmArgs g;
     g.A = q.A; g.B = q.B; g.C = q.C; g.Cin = q.C; g.a_map = nullptr; g.b_map = nullptr; g.c_map = q.c_map;
     g.a_rows = q.K; g.b_rows = q.K; g.M = q.M; g.N = q.N; g.K = q.K; g.lda = q.lda; g.ldb = q.ldb; g.ldc = q.ldc; g.ldcin = q.ldc;
-    g.alpha = 1.f; g.kt_per_split = q.kt_per_split; g.bal_ck = 0; g.bal_chunks = 0; g.debug = 0; g.split3 = 0; g.a_plane = 0; g.b_plane = 0;
+    g.alpha = 1.f; g.kt_per_split = q.kt_per_split; g.bal_ck = 0; g.bal_chunks = 0; g.debug = 0; g.split3 = 0; g.A_lo = nullptr; g.B_lo = nullptr; g.C_lo = nullptr;
     g.epi_scale = nullptr; g.epi_norm = nullptr; g.epi_groups = 0; g.epi_ldnorm = 0; g.C2 = nullptr; g.c2_col0 = 0; g.ldc2 = 0;
     const int nk = (q.K + BK - 1) / BK;
     if constexpr (T8) {
@@ -1318,6 +1345,31 @@ static int launch_tile(const GemmArgs& g, int a_kmaj, int b_kmaj, int splits, hi
     return omlm_post_launch("omlm_gemm");
 }
 
+// The hi/lo-plane route of omlm_gemm_planes16 (row-major A [M, K] and B [N, K], no maps, no split-K): the half-tile-ring kernel for the
+// 256 x 256 tiles (whole k-tiles), the rotated-loop SPLIT3 kernel otherwise.  Both copies of the file build it (TOUT: float, or h16pl_t =
+// the result leaves as planes too).
+template <int BM_, int BN_, int WM_, int WN_, typename TOUT>
+static int launch_tile_s3(const GemmArgs& g, hipStream_t st) {
+    constexpr int NTH = (BM_ / WM_) * (BN_ / WN_) * 64;
+    constexpr size_t LDS = 2 * (size_t)(BM_ + BN_) * BK * 2;
+    const int tiles = ((g.M + BM_ - 1) / BM_) * ((g.N + BN_ - 1) / BN_);
+    dim3 grid(tiles, 1), block(NTH);
+    if constexpr (BM_ == 256 && BN_ == 256) {
+        if (gemm_t8_mode() > 0 && g.K % BK == 0 && !gemm_fastk_off()) {
+            auto k8 = gemm_tile8_kernel<false, false, TOUT, true>;
+            static bool attr8 = false;
+            if (!attr8) { (void)hipFuncSetAttribute((const void*)k8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); attr8 = true; }
+            hipLaunchKernelGGL(k8, grid, block, LDS, st, g);
+            return omlm_post_launch("omlm_gemm_planes16");
+        }
+    }
+    auto ks3 = gemm_bf16_tile_kernel<BM_, BN_, WM_, WN_, false, false, TOUT, false, false, false, true>;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)ks3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); attr = true; }
+    hipLaunchKernelGGL(ks3, grid, block, LDS, st, g);
+    return omlm_post_launch("omlm_gemm_planes16");
+}
+
 template <typename T, typename TOUT>
 static int launch_layout(const GemmArgs& g, int a_kmaj, int b_kmaj, int splits, hipStream_t st) {
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
@@ -1338,7 +1390,7 @@ static int gemm_impl(const void* A, const void* B, void* C, const float* Cin,
                      long long a_rows, long long b_rows,
                      int M, int N, int K, int lda, int ldb, int ldc, int ldcin,
                      int a_kmajor, int b_kmajor, int in_dtype, int out_dtype, float alpha, void* stream,
-                     int split3, unsigned a_plane, unsigned b_plane) {
+                     int split3, const void* A_lo, const void* B_lo, void* C_lo = nullptr, bool s3_route = false) {
     if (M <= 0 || N <= 0) return OMLM_OK;
     OMLM_CHECK_ARG(A && B && C, "null operand");
     OMLM_CHECK_ARG(K > 0, "K must be positive");
@@ -1358,7 +1410,7 @@ static int gemm_impl(const void* A, const void* B, void* C, const float* Cin,
     g.a_rows = a_rows; g.b_rows = b_rows; g.M = M; g.N = N; g.K = K;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldcin = ldcin; g.alpha = alpha;
     { const char* dbg = getenv("OMLM_GEMM_DEBUG"); g.debug = dbg ? atoi(dbg) : 0; }
-    g.split3 = split3; g.a_plane = a_plane; g.b_plane = b_plane;
+    g.split3 = split3; g.A_lo = A_lo; g.B_lo = B_lo; g.C_lo = C_lo;
     g.epi_scale = nullptr; g.epi_norm = nullptr; g.epi_groups = 0; g.epi_ldnorm = 0; g.C2 = nullptr; g.c2_col0 = 0; g.ldc2 = 0;
     hipStream_t st = as_stream(stream);
     // tile shape (bf16 path): 256x256 when both output dims are wide, 256x128 for tall-narrow outputs, else 128x128
@@ -1448,6 +1500,13 @@ static int gemm_impl(const void* A, const void* B, void* C, const float* Cin,
 #endif
     }
     auto launch = [&](const GemmArgs& ga, int tm_, int tn_, int sp) -> int {
+        if (s3_route) {                  // omlm_gemm_planes16: splits == 1 (no accumulate-into-C form), out = fp32 or 16-bit planes
+            if (tm_ == 256 && tn_ == 256)
+                return ga.C_lo ? launch_tile_s3<256, 256, 128, 64, h16pl_t>(ga, st) : launch_tile_s3<256, 256, 128, 64, float>(ga, st);
+            if (tm_ == 256 && tn_ == 128)
+                return ga.C_lo ? launch_tile_s3<256, 128, 64, 64, h16pl_t>(ga, st) : launch_tile_s3<256, 128, 64, 64, float>(ga, st);
+            return ga.C_lo ? launch_tile_s3<128, 128, 64, 64, h16pl_t>(ga, st) : launch_tile_s3<128, 128, 64, 64, float>(ga, st);
+        }
         if (tm_ == 256 && tn_ == 256)
             return out_dtype == 0 ? launch_tile<256, 256, 128, 64, float>(ga, a_kmajor, b_kmajor, sp, st)
                                   : launch_tile<256, 256, 128, 64, h16_t>(ga, a_kmajor, b_kmajor, sp, st);
@@ -1473,6 +1532,8 @@ static int gemm_impl(const void* A, const void* B, void* C, const float* Cin,
             g2.A = (const char*)A + (size_t)M1 * lda * 2;
             g2.a_rows = a_rows - M1;
             g2.C = (char*)C + (size_t)M1 * ldc * osz;
+            if (g.A_lo && !a_kmajor) g2.A_lo = (const char*)g.A_lo + (size_t)M1 * lda * 2;
+            if (g.C_lo) g2.C_lo = (char*)g.C_lo + (size_t)M1 * ldc * osz;
             if (Cin) g2.Cin = Cin + (size_t)M1 * ldcin;
             const int rc = launch(g1, 256, 256, 1);
             if (rc != OMLM_OK) return rc;
@@ -1502,7 +1563,7 @@ extern "C" int OMLM_API(omlm_gemm)(const void* A, const void* B, void* C, const 
     }
 #endif
     return gemm_impl(A, B, C, Cin, a_map, b_map, c_map, a_rows, b_rows, M, N, K, lda, ldb, ldc, ldcin, a_kmajor, b_kmajor,
-                     in_dtype, out_dtype, alpha, stream, 0, 0u, 0u);
+                     in_dtype, out_dtype, alpha, stream, 0, nullptr, nullptr);
 }
 
 // q / k projections with the attention's l2-norm + learned scale folded into the epilogue (transformer.py:254-271): C = 16-bit
@@ -1556,6 +1617,30 @@ extern "C" int OMLM_API(omlm_gemm_qknorm)(const void* A, const void* B, void* C,
     return omlm_post_launch("omlm_gemm_qknorm");
 }
 
+// C = A B^T (+ Cin) with BOTH operands as hi/lo planes of the 16-bit type `dtype` (1 = bf16, 2 = fp16): A [M, K] and B [N, K] row-major with
+// their lo planes A_lo / B_lo in the same layout (separate allocations are fine), three products hi*hi + hi*lo + lo*hi accumulated in fp32
+// in ONE launch (3 x the k-tiles).  The result is fp32 (C_lo NULL; Cin optional), or -- C_lo given -- leaves as planes of the same type:
+// C = rne16(v), C_lo = rne16(v - C), so that the next consumer reads the un-rounded value and a 16-bit backward reads C alone.
+// Precision "fp16ff" (round 5): the two ConvFeedForward GEMMs of the forward, which carry 86-88 % of the fp16 logits-error variance
+// (profiles/r05_error_budget.md).
+#if !OMLM_FP16
+extern "C" int omlm_gemm_planes16_h(const void* A, const void* A_lo, const void* B, const void* B_lo, void* C, void* C_lo, const float* Cin,
+                                    long long a_rows, long long b_rows, int M, int N, int K, int lda, int ldb, int ldc, int ldcin, int dtype, void* stream);
+#endif
+extern "C" int OMLM_API(omlm_gemm_planes16)(const void* A, const void* A_lo, const void* B, const void* B_lo, void* C, void* C_lo, const float* Cin,
+                                            long long a_rows, long long b_rows, int M, int N, int K, int lda, int ldb, int ldc, int ldcin,
+                                            int dtype, void* stream) {
+#if !OMLM_FP16
+    if (dtype == OMLM_DT_F16) return omlm_gemm_planes16_h(A, A_lo, B, B_lo, C, C_lo, Cin, a_rows, b_rows, M, N, K, lda, ldb, ldc, ldcin, 1, stream);
+#endif
+    OMLM_CHECK_ARG(dtype == 1, "gemm_planes16: operand dtype 1 (bf16) or 2 (fp16)");
+    OMLM_CHECK_ARG(A_lo && B_lo, "gemm_planes16: null lo plane");
+    OMLM_CHECK_ARG(((uintptr_t)A_lo % 16) == 0 && ((uintptr_t)B_lo % 16) == 0 && ((uintptr_t)C_lo % 16) == 0, "gemm_planes16: 16-byte aligned planes");
+    OMLM_CHECK_ARG(!(C_lo && Cin), "gemm_planes16: plane output takes no residual");
+    return gemm_impl(A, B, C, Cin, nullptr, nullptr, nullptr, a_rows, b_rows, M, N, K, lda, ldb, ldc, ldcin, 0, 0,
+                     1, C_lo ? 1 : 0, 1.0f, stream, 1, A_lo, B_lo, C_lo, true);
+}
+
 #if !OMLM_FP16
 // fp32-grade GEMM on bf16 hi/lo planes ("bf16x3" through the LDS-DMA tile kernels).  A and B are bf16 hi planes in the layout
 // omlm_gemm takes for bf16 operands; the matching lo plane lies a_plane_bytes / b_plane_bytes behind each (omlm_split_planes
@@ -1567,14 +1652,9 @@ extern "C" int omlm_gemm_planes(const void* A, long long a_plane_bytes, const vo
                                 int a_kmajor, int b_kmajor, int out_dtype, float alpha, void* stream) {
     OMLM_CHECK_ARG(a_plane_bytes > 0 && b_plane_bytes > 0 && (a_plane_bytes % 16) == 0 && (b_plane_bytes % 16) == 0, "plane strides");
     OMLM_CHECK_ARG(!(a_kmajor && a_map) && !(b_kmajor && b_map), "k-row maps are not supported on operand planes");
-    OMLM_CHECK_ARG((unsigned long long)a_plane_bytes + (unsigned long long)a_rows * lda * 2 < 0xFFFFFFF0ull &&
-                   (unsigned long long)b_plane_bytes + (unsigned long long)b_rows * ldb * 2 < 0xFFFFFFF0ull,
-                   "operand planes exceed the 4 GiB buffer-descriptor window");
-    // the descriptors must cover both planes: rows are counted up to the end of the lo plane
-    const long long a_rows2 = (a_plane_bytes / 2 + (long long)a_rows * lda + lda - 1) / lda;
-    const long long b_rows2 = (b_plane_bytes / 2 + (long long)b_rows * ldb + ldb - 1) / ldb;
-    return gemm_impl(A, B, C, Cin, a_map, b_map, c_map, a_rows2, b_rows2, M, N, K, lda, ldb, ldc, ldcin, a_kmajor, b_kmajor,
-                     1, out_dtype, alpha, stream, 1, (unsigned)a_plane_bytes, (unsigned)b_plane_bytes);
+    // each plane has its own buffer descriptor (round 5): the lo planes are addressed by pointer, not by an offset inside A's / B's window
+    return gemm_impl(A, B, C, Cin, a_map, b_map, c_map, a_rows, b_rows, M, N, K, lda, ldb, ldc, ldcin, a_kmajor, b_kmajor,
+                     1, out_dtype, alpha, stream, 1, (const char*)A + a_plane_bytes, (const char*)B + b_plane_bytes);
 }
 
 // x [n] fp32 -> planes: hi[i] = x truncated to bf16 at planes[i], lo[i] = RNE(x - hi) at planes[plane_elems + i]  (x ~= hi + lo to 2^-17)

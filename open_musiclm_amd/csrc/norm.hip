@@ -12,7 +12,20 @@ namespace OMLM_NS {
 
 // y = (x - mean) * rstd * gamma ; optionally also emit cast(x) (the K/V projection reads the
 // un-normalised residual: reference transformer.py:228 binds kv_input before the pre-norm :250).
-template <typename T>
+// four outputs as hi/lo planes of the 16-bit type: y = rne16(v), ylo = rne16(v - y)  (precision "fp16ff": the FF-in GEMM reads both)
+__device__ __forceinline__ void store4_planes(h16_t* y, h16_t* ylo, float a, float b, float c, float d) {
+    u32x2 o, l;
+    o[0] = pack_h16_rne(a, b);
+    o[1] = pack_h16_rne(c, d);
+    l[0] = pack_h16_rne(a - h16_lo_to_f(o[0]), b - h16_hi_to_f(o[0]));
+    l[1] = pack_h16_rne(c - h16_lo_to_f(o[1]), d - h16_hi_to_f(o[1]));
+    *(u32x2*)y = o;
+    *(u32x2*)ylo = l;
+}
+__device__ __forceinline__ void store4_planes(float*, float*, float, float, float, float) {}      // (fp32 output has no planes)
+
+// LO: `xcast` is the LO PLANE of y (pitch ldy) instead of a cast copy of x
+template <typename T, bool LO = false>
 __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             T* __restrict__ y, T* __restrict__ xcast,
                                                             float* __restrict__ mean, float* __restrict__ rstd,
@@ -47,6 +60,10 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restr
             if (c < nv) {
                 const float4 g = ((const float4*)gamma)[c];
                 T* yo = y + (size_t)row * ldy + 4 * c;
+                if constexpr (LO) {
+                    store4_planes(yo, xcast + (size_t)row * ldy + 4 * c, (v[i].x - mu) * rs * g.x, (v[i].y - mu) * rs * g.y, (v[i].z - mu) * rs * g.z, (v[i].w - mu) * rs * g.w);
+                    continue;
+                }
                 store4_from_float(yo, (v[i].x - mu) * rs * g.x, (v[i].y - mu) * rs * g.y, (v[i].z - mu) * rs * g.z, (v[i].w - mu) * rs * g.w);
                 if (xcast) {
                     T* xo = xcast + (size_t)row * D + 4 * c;
@@ -62,7 +79,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restr
 // the two reductions use parity-double-buffered LDS slots (two barriers per row instead of four), and no memory instruction sits under a
 // column test or a thread test (the row's statistics are stored by every thread: same value, same address).  XC: cast copy of x wanted.
 // Same summation order as the general kernel: identical bits.
-template <typename T, bool XC>
+template <typename T, bool XC, bool LO = false>
 __global__ __launch_bounds__(LN_THREADS) void ln_fwd_row1_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                                  T* __restrict__ y, T* __restrict__ xcast,
                                                                  float* __restrict__ mean, float* __restrict__ rstd, int M, int ldy, float eps) {
@@ -87,7 +104,8 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_row1_kernel(const float* __
         for (int w = 0; w < NW; ++w) u += red[par][1][w];
         const float rs = rsqrtf(u / (float)D + eps);
         mean[row] = mu; rstd[row] = rs;
-        store4_from_float(y + (size_t)row * ldy + 4 * c, a * rs * g.x, b * rs * g.y, cc * rs * g.z, d * rs * g.w);
+        if constexpr (LO) store4_planes(y + (size_t)row * ldy + 4 * c, xcast + (size_t)row * ldy + 4 * c, a * rs * g.x, b * rs * g.y, cc * rs * g.z, d * rs * g.w);
+        else store4_from_float(y + (size_t)row * ldy + 4 * c, a * rs * g.x, b * rs * g.y, cc * rs * g.z, d * rs * g.w);
         if constexpr (XC) store4_from_float(xcast + (size_t)row * D + 4 * c, v.x, v.y, v.z, v.w);
     };
     int row = blockIdx.x;
@@ -321,6 +339,29 @@ extern "C" int OMLM_API(omlm_layernorm_fwd)(const float* x, const float* gamma, 
     else
         hipLaunchKernelGGL(ln_fwd_kernel<h16_t>, grid, block, 0, as_stream(stream), x, gamma, (h16_t*)y, (h16_t*)xcast, mean, rstd, M, D, ldy, eps);
     return omlm_post_launch("omlm_layernorm_fwd");
+}
+
+// The same forward with the result as hi/lo planes of the 16-bit type (1 = bf16, 2 = fp16): y = rne16(v), y_lo = rne16(v - y), both at
+// pitch ldy (precision "fp16ff": the FF-in GEMM of the forward reads both planes, the backward reads y alone).
+#if !OMLM_FP16
+extern "C" int omlm_layernorm_fwd_planes_h(const float* x, const float* gamma, void* y, void* y_lo, float* mean, float* rstd, int M, int D, int ldy, float eps, int out_dtype, void* stream);
+#endif
+extern "C" int OMLM_API(omlm_layernorm_fwd_planes)(const float* x, const float* gamma, void* y, void* y_lo, float* mean, float* rstd,
+                                                   int M, int D, int ldy, float eps, int out_dtype, void* stream) {
+#if !OMLM_FP16
+    if (out_dtype == OMLM_DT_F16) return omlm_layernorm_fwd_planes_h(x, gamma, y, y_lo, mean, rstd, M, D, ldy, eps, 1, stream);
+#endif
+    if (M <= 0) return OMLM_OK;
+    OMLM_CHECK_ARG(out_dtype == 1, "layernorm_fwd_planes: out_dtype 1 (bf16) or 2 (fp16)");
+    OMLM_CHECK_ARG(x && gamma && y && y_lo && mean && rstd, "null pointer");
+    OMLM_CHECK_ARG(D % 4 == 0 && D <= 4 * LN_THREADS * LN_MAXV, "D must be a multiple of 4 and <= 4096");
+    OMLM_CHECK_ARG(ldy >= D && ldy % 4 == 0, "ldy < D");
+    dim3 grid(ln_grid(M)), block(LN_THREADS);
+    if (D == 4 * LN_THREADS)
+        hipLaunchKernelGGL((ln_fwd_row1_kernel<h16_t, false, true>), grid, block, 0, as_stream(stream), x, gamma, (h16_t*)y, (h16_t*)y_lo, mean, rstd, M, ldy, eps);
+    else
+        hipLaunchKernelGGL((ln_fwd_kernel<h16_t, true>), grid, block, 0, as_stream(stream), x, gamma, (h16_t*)y, (h16_t*)y_lo, mean, rstd, M, D, ldy, eps);
+    return omlm_post_launch("omlm_layernorm_fwd_planes");
 }
 
 extern "C" int omlm_colsum_accumulate(const float* part, float* out, int P, int C, int ldp, void* stream);

@@ -169,7 +169,7 @@ extern "C" int omlm_transpose_cast(const float* src, void* dst, int R, int C, in
 // LayerNorm gammas: ~6 small launches per layer, 36 per coarse-small step) as ONE launch: problem i copies / casts src [R, C] (pitch
 // ld_src) to dst [R, ld_dst] with zero pad columns, or -- transpose set -- writes dst[c, r] = src[r, c] (pad untouched).
 #define OMLM_CAST_GROUP_MAX 64
-struct omlm_cast_pad_desc { const float* src; void* dst; int R, C, ld_src, ld_dst, transpose, pad; };            // include/omlm.h
+struct omlm_cast_pad_desc { const float* src; void* dst; int R, C, ld_src, ld_dst, transpose, lo; };             // include/omlm.h
 struct CastGroupArgs { int n; int start[OMLM_CAST_GROUP_MAX + 1]; omlm_cast_pad_desc d[OMLM_CAST_GROUP_MAX]; };
 template <typename T>
 __global__ __launch_bounds__(256) void cast_pad_group_kernel(CastGroupArgs ga) {
@@ -178,15 +178,17 @@ __global__ __launch_bounds__(256) void cast_pad_group_kernel(CastGroupArgs ga) {
     const omlm_cast_pad_desc q = ga.d[pi];
     const int blk = blockIdx.x - ga.start[pi], nblk = ga.start[pi + 1] - ga.start[pi];
     T* dst = (T*)q.dst;
+    // lo (round 5, precision "fp16ff"): dst receives the LO PLANE of the cast, rne(v - rne(v)) -- the un-rounded weight is hi + lo
+    auto val = [&](float v) -> float { return q.lo ? v - (float)(T)v : v; };
     if (q.transpose) {
         for (long long e = (long long)blk * 256 + threadIdx.x; e < (long long)q.R * q.C; e += (long long)nblk * 256) {
             const int r = (int)(e / q.C), c = (int)(e - (long long)r * q.C);
-            store_from_float(dst + (size_t)c * q.ld_dst + r, q.src[(size_t)r * q.ld_src + c]);
+            store_from_float(dst + (size_t)c * q.ld_dst + r, val(q.src[(size_t)r * q.ld_src + c]));
         }
     } else {
         for (int r = blk; r < q.R; r += nblk)
             for (int c = threadIdx.x; c < q.ld_dst; c += 256)
-                store_from_float(dst + (size_t)r * q.ld_dst + c, c < q.C ? q.src[(size_t)r * q.ld_src + c] : 0.f);
+                store_from_float(dst + (size_t)r * q.ld_dst + c, c < q.C ? val(q.src[(size_t)r * q.ld_src + c]) : 0.f);
     }
 }
 extern "C" int omlm_cast_pad_group(const omlm_cast_pad_desc* d, int count, int out_dtype, void* stream) {

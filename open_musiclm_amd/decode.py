@@ -44,7 +44,7 @@ def max_batch(model, precision: str) -> int:
     at most 16 heads, feed-forward width <= 3072: omlm_decode_step's own conditions)."""
     tr = model.transformer
     inner = getattr(tr.layers[0][2], "inner_dim", 0) if len(tr.layers) else 0
-    wide = (precision in ("bf16", "fp16") and tr.dim == 1024 and tr.heads * engine.DIM_HEAD <= 1024 and 0 < engine.ceil_to(inner, 64) <= 3072
+    wide = (precision in ("bf16", "fp16", "fp16ff") and tr.dim == 1024 and tr.heads * engine.DIM_HEAD <= 1024 and 0 < engine.ceil_to(inner, 64) <= 3072
             and os.environ.get("OMLM_DECODE_MFMA", "1") != "0" and os.environ.get("OMLM_DECODE_V1", "0") != "1")
     return 16 if wide else MAX_DECODE_BATCH
 
@@ -59,6 +59,8 @@ class CachedDecoder:
     def __init__(self, model, batch: int, max_rows: int, precision: str):
         if batch > max_batch(model, precision):
             raise ValueError(f"cached decode handles up to {max_batch(model, precision)} samples per call here; got {batch}")
+        if precision == "fp16ff":          # the cached decode step is a weight-streaming GEMV chain: it runs the fp16 kernels (hi planes)
+            precision = "fp16"
         self.model, self.B, self.Nmax, self.precision = model, batch, int(max_rows), precision
         tr = model.transformer
         dev = model.start_tokens[0].device

@@ -28,7 +28,15 @@ DIM_HEAD = 64
 # precision modes -> GEMM / attention operand type in HBM.  "fp16": IEEE half operands on the same v_mfma_f32_32x32x16 rate as bf16
 # (11 instead of 8 significand bits: meets the 1e-3 logits bar bf16 misses); its 5-bit exponent needs a loss scale in the
 # backward (loss_scale below), divided out by the fused optimizer.
-_PRECISIONS = {"bf16": torch.bfloat16, "bf16x3": torch.float32, "fp16": torch.float16}
+# "fp16ff" (round 5): "fp16" whose two ConvFeedForward linears run the FORWARD on hi/lo half planes (three products, omlm_gemm_planes16) with
+# h1 / h2 un-rounded in between (omlm_ffmid_fwd_planes): those two GEMMs carry 86-88 % of the fp16 logits-error variance at depth 6 and 24
+# (profiles/r05_error_budget.md).  Everything else, and the whole backward (which reads the hi planes), is "fp16".
+_PRECISIONS = {"bf16": torch.bfloat16, "bf16x3": torch.float32, "fp16": torch.float16, "fp16ff": torch.float16}
+
+
+def is_half(precision: str) -> bool:
+    """The IEEE-half modes: loss scale in the backward, fp16 weight shadow in the optimizer, fp16 decode kernels."""
+    return precision in ("fp16", "fp16ff")
 _H16 = (torch.bfloat16, torch.float16)
 _WT = os.environ.get("OMLM_WT", "0") == "1"
 _FF_SAVE_GH = os.environ.get("OMLM_FF_SAVE_GH", "1") == "1"        # forward keeps the normalised GEGLU output for the backward (bf16 mode)
@@ -105,7 +113,7 @@ def loss_scale(precision: str, model=None) -> float:
     where it is the CURRENT value of the model's device-side block (reading it synchronises; without a model, or before its first
     optimizer step: the initial value).  Parameter gradients (param.grad, the optimizer's flat buffer) carry that factor until
     FusedAdam.step divides it out inside its kernel; anything else that reads param.grad in this mode divides by this (unscale_grads_)."""
-    if precision != "fp16":
+    if not is_half(precision):
         return 1.0
     if model is None or "_omlm_ls_state" not in model.__dict__:
         return loss_scale_initial()
@@ -230,6 +238,7 @@ class PreparedWeights:
         tr = model.transformer
         self.precision = precision
         self.T = _PRECISIONS[precision]
+        self.ff3 = precision == "fp16ff"          # FF forward on hi/lo planes: lo planes of W1p / W2p / taps / gamma next to the usual images
         T = self.T
         dev = model.start_tokens[0].device
         D = tr.dim
@@ -262,6 +271,20 @@ class PreparedWeights:
             packs.add(w1.detach()[F:], W1p[Fp:], F, D, D, D)
             packs.add(w2.detach(), W2p, D, F, F, Fp)
             ent["W1p"], ent["W2p"], ent["F"], ent["Fp"] = W1p, W2p, F, Fp
+            if self.ff3:
+                lkey = bkey + ("lo",)
+                if not persistent or lkey not in wbuf:
+                    lo = (torch.zeros(2 * Fp, D, dtype=T, device=dev), torch.zeros(D, Fp, dtype=T, device=dev),
+                          torch.zeros(3, 2 * Fp, dtype=T, device=dev), torch.zeros(Fp, dtype=T, device=dev))
+                    if persistent:
+                        wbuf[lkey] = lo
+                else:
+                    lo = wbuf[lkey]
+                W1l, W2l, convl, gammal = lo
+                packs.add(w1.detach(), W1l, F, D, D, D, lo=True)
+                packs.add(w1.detach()[F:], W1l[Fp:], F, D, D, D, lo=True)
+                packs.add(w2.detach(), W2l, D, F, F, Fp, lo=True)
+                ent["W1p_lo"], ent["W2p_lo"], ent["convw_lo"], ent["gamma_mid_lo"] = W1l, W2l, convl, gammal
             if T in _H16 and with_transposes:
                 # k-contiguous W^T copies: every input-gradient GEMM (dX = dY W) then runs in the fast NT form
                 def wt(w, R, C, rows_pad=None, cols_pad=None):
@@ -284,6 +307,10 @@ class PreparedWeights:
             packs.add(cw[F:], convp[:, Fp:], F, 3, 3, 2 * Fp, transpose=True)
             packs.add(ff.norm_mid.gamma.detach(), gammap, 1, F, F, Fp)
             ent["convw"], ent["gamma_mid"] = convp, gammap
+            if self.ff3:
+                packs.add(cw, ent["convw_lo"], F, 3, 3, 2 * Fp, transpose=True, lo=True)
+                packs.add(cw[F:], ent["convw_lo"][:, Fp:], F, 3, 3, 2 * Fp, transpose=True, lo=True)
+                packs.add(ff.norm_mid.gamma.detach(), ent["gamma_mid_lo"], 1, F, F, Fp, lo=True)
             cache = ff.__dict__.setdefault("_omlm_cmap", {})
             if (F, Fp, str(dev)) not in cache:            # static scatter map: uploaded once (no H2D inside graph capture)
                 cm = torch.full((2 * Fp,), -1, dtype=torch.int32)
@@ -492,9 +519,17 @@ def trunk_forward(tr, pw: PreparedWeights, x: torch.Tensor, keymask: Optional[to
         # feed-forward
         m2 = torch.empty(M, device=dev); r2 = torch.empty(M, device=dev)
         xn2 = torch.empty(M, D, dtype=T, device=dev)
-        ops.layernorm_fwd(x1, ff.norm_in.gamma.detach(), xn2, None, m2, r2)
         h1 = torch.empty(M, 2 * Fp, dtype=T, device=dev)
-        ops.gemm(xn2, w["W1p"], h1, M=M, N=2 * Fp, K=D)
+        if pw.ff3:
+            # "fp16ff": LN output, h1 and h2 exist as hi/lo planes during this layer's forward; the lo planes die with the layer (their
+            # consumers are the next launches of this stream), the hi planes are what the fp16 backward keeps
+            xn2_lo = torch.empty(M, D, dtype=T, device=dev)
+            ops.layernorm_fwd_planes(x1, ff.norm_in.gamma.detach(), xn2, xn2_lo, m2, r2)
+            h1_lo = torch.empty(M, 2 * Fp, dtype=T, device=dev)
+            ops.gemm_planes16(xn2, xn2_lo, w["W1p"], w["W1p_lo"], h1, h1_lo, M=M, N=2 * Fp, K=D)
+        else:
+            ops.layernorm_fwd(x1, ff.norm_in.gamma.detach(), xn2, None, m2, r2)
+            ops.gemm(xn2, w["W1p"], h1, M=M, N=2 * Fp, K=D)
         h2 = torch.empty(M, Fp, dtype=T, device=dev)
         m3 = torch.empty(M, device=dev); r3 = torch.empty(M, device=dev)
         p = float(ff.dropout_p) if training else 0.0
@@ -503,10 +538,17 @@ def trunk_forward(tr, pw: PreparedWeights, x: torch.Tensor, keymask: Optional[to
         # the normalised GEGLU output is saved for the backward: its row-sum prepass reads it instead of recomputing conv + GELU, and
         # the fused second-generation backward (csrc/ffmid2.hip) requires it
         gh = torch.empty(M, Fp, dtype=T, device=dev) if (save and _FF_SAVE_GH) else None
-        ops.ffmid_fwd(h1, w["convw"], w["gamma_mid"], h2, m3, r3, N, F, Fp, p, seed, seed_dev=salt if p > 0 else None,
-                      drop_bits=drop_bits, gh=gh)
         x2 = torch.empty(M, D, device=dev)
-        ops.gemm(h2, w["W2p"], x2, M=M, N=D, K=Fp, Cin=x1)
+        if pw.ff3:
+            h2_lo = torch.empty(M, Fp, dtype=T, device=dev)
+            ops.ffmid_fwd_planes(h1, h1_lo, w["convw"], w["convw_lo"], w["gamma_mid"], w["gamma_mid_lo"], h2, h2_lo, m3, r3, N, F, Fp, p, seed,
+                                 seed_dev=salt if p > 0 else None, drop_bits=drop_bits, gh=gh)
+            ops.gemm_planes16(h2, h2_lo, w["W2p"], w["W2p_lo"], x2, M=M, N=D, K=Fp, Cin=x1)
+            del xn2_lo, h1_lo, h2_lo
+        else:
+            ops.ffmid_fwd(h1, w["convw"], w["gamma_mid"], h2, m3, r3, N, F, Fp, p, seed, seed_dev=salt if p > 0 else None,
+                          drop_bits=drop_bits, gh=gh)
+            ops.gemm(h2, w["W2p"], x2, M=M, N=D, K=Fp, Cin=x1)
         if save:
             sv.x, sv.m1, sv.r1, sv.xn, sv.xc = x, m1, r1, xn, xc
             sv.q_raw, sv.kv_raw, sv.q, sv.k, sv.v, sv.o, sv.lse, sv.abias = q_raw, kv_raw, q, k, v, o, lse, abias
@@ -847,7 +889,7 @@ class LogitsFunction(torch.autograd.Function):
         ctx.set_materialize_grads(False)          # unused logits -> None grads -> their head GEMMs are skipped
         ctx.st = st
         ctx.nparams = len(params)
-        ctx.ls = loss_scale_state(model) if precision == "fp16" else None
+        ctx.ls = loss_scale_state(model) if is_half(precision) else None
         views = logits_views(model, lay, bufs)
         ctx.present = [v is not None for v in views]
         return tuple(v for v in views if v is not None)
@@ -927,7 +969,7 @@ class LossFunction(torch.autograd.Function):
             ctx.inv_total = inv_total
         ctx.st = st
         ctx.nparams = len(params)
-        ctx.ls = loss_scale_state(model) if precision == "fp16" else None
+        ctx.ls = loss_scale_state(model) if is_half(precision) else None
         views = logits_views(model, lay, bufs)
         ctx.mark_non_differentiable(*[v for v in views if v is not None])
         return (loss, *views)

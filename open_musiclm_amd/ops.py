@@ -115,6 +115,21 @@ def gemm(A: torch.Tensor, B: torch.Tensor, C_: torch.Tensor, *, M: int, N: int, 
          dcode(A.dtype), dcode(C_.dtype), float(alpha), stream_ptr())
 
 
+def gemm_planes16(A, A_lo, B, B_lo, C_, C_lo=None, *, M: int, N: int, K: int, Cin: Optional[torch.Tensor] = None):
+    """C = A B^T (+ Cin) with both operands as hi/lo planes of ONE 16-bit type (A [M, K], B [N, K] row-major; omlm_gemm_planes16): three
+    products, fp32 accumulation.  C_lo None: C is fp32.  C_lo given: C / C_lo receive the result as planes of the operand type."""
+    hip.require_gpu(A, "A")
+    assert A.dtype in H16 and A_lo.dtype == A.dtype and B.dtype == A.dtype and B_lo.dtype == A.dtype
+    assert A_lo.shape == A.shape and B_lo.shape == B.shape
+    if C_lo is None:
+        assert C_.dtype == torch.float32 and (Cin is None or Cin.dtype == torch.float32)
+    else:
+        assert C_.dtype == A.dtype and C_lo.dtype == A.dtype and C_lo.shape == C_.shape and Cin is None
+    lda, ldb, ldc = A.shape[-1], B.shape[-1], C_.shape[-1]
+    call("omlm_gemm_planes16", ptr(A), ptr(A_lo), ptr(B), ptr(B_lo), ptr(C_), ptr(C_lo), ptr(Cin), A.numel() // lda, B.numel() // ldb,
+         M, N, K, lda, ldb, ldc, Cin.shape[-1] if Cin is not None else 0, dcode(A.dtype), stream_ptr())
+
+
 class _WgradDesc(C.Structure):
     """omlm_gemm_wgrad_desc (include/omlm.h)"""
     _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("c_map", C.c_void_p),
@@ -151,7 +166,7 @@ class WgradGroup:
 class _CastDesc(C.Structure):
     """omlm_cast_pad_desc (include/omlm.h)"""
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("R", C.c_int), ("C", C.c_int), ("ld_src", C.c_int), ("ld_dst", C.c_int),
-                ("transpose", C.c_int), ("pad", C.c_int)]
+                ("transpose", C.c_int), ("lo", C.c_int)]
 
 
 class CastPadGroup:
@@ -160,24 +175,26 @@ class CastPadGroup:
     def __init__(self):
         self.items, self.dtype = [], None
 
-    def add(self, src, dst, R, C_, ld_src, ld_dst, transpose=False):
+    def add(self, src, dst, R, C_, ld_src, ld_dst, transpose=False, lo=False):
+        """lo: dst receives the lo plane rne16(v - rne16(v)) of the cast (the hi/lo weight planes of precision "fp16ff")."""
         hip.require_gpu(src, "src")
         assert src.dtype == torch.float32 and self.dtype in (None, dst.dtype), "fp32 sources, one output type per group"
         self.dtype = dst.dtype
-        self.items.append((src, dst, int(R), int(C_), int(ld_src), int(ld_dst), int(bool(transpose))))
+        self.items.append((src, dst, int(R), int(C_), int(ld_src), int(ld_dst), int(bool(transpose)), int(bool(lo))))
 
     def flush(self):
         n = len(self.items)
         if n == 0:
             return
         if os.environ.get("OMLM_PACK_GROUP", "1") == "0":            # A/B lever: one launch per re-pack
-            for src, dst, R, C_, ld_src, ld_dst, tr in self.items:
+            assert not any(it[7] for it in self.items), "lo planes exist in the grouped launch only"
+            for src, dst, R, C_, ld_src, ld_dst, tr, _ in self.items:
                 (transpose_cast if tr else cast_pad)(src, dst, R, C_, ld_src, ld_dst)
             self.items = []
             return
         arr = (_CastDesc * n)()
-        for d, (src, dst, R, C_, ld_src, ld_dst, tr) in zip(arr, self.items):
-            d.src, d.dst, d.R, d.C, d.ld_src, d.ld_dst, d.transpose, d.pad = ptr(src), ptr(dst), R, C_, ld_src, ld_dst, tr, 0
+        for d, (src, dst, R, C_, ld_src, ld_dst, tr, lo) in zip(arr, self.items):
+            d.src, d.dst, d.R, d.C, d.ld_src, d.ld_dst, d.transpose, d.lo = ptr(src), ptr(dst), R, C_, ld_src, ld_dst, tr, lo
         call("omlm_cast_pad_group", C.cast(arr, C.c_void_p), n, dcode(self.dtype), stream_ptr())
         self.items = []
 
@@ -185,6 +202,14 @@ class CastPadGroup:
 def layernorm_fwd(x, gamma, y, xcast, mean, rstd, eps=1e-5):
     M, D = x.shape
     call("omlm_layernorm_fwd", ptr(x), ptr(gamma), ptr(y), ptr(xcast), ptr(mean), ptr(rstd),
+         M, D, y.shape[-1], float(eps), dcode(y.dtype), stream_ptr())
+
+
+def layernorm_fwd_planes(x, gamma, y, y_lo, mean, rstd, eps=1e-5):
+    """layernorm_fwd with the result as hi/lo planes of y's 16-bit type: y = rne16(v), y_lo = rne16(v - y) (omlm_layernorm_fwd_planes)."""
+    M, D = x.shape
+    assert y.dtype in H16 and y_lo.dtype == y.dtype and y_lo.shape == y.shape
+    call("omlm_layernorm_fwd_planes", ptr(x), ptr(gamma), ptr(y), ptr(y_lo), ptr(mean), ptr(rstd),
          M, D, y.shape[-1], float(eps), dcode(y.dtype), stream_ptr())
 
 
@@ -346,6 +371,18 @@ def ffmid_fwd(h1, convw, gamma, h2, mean, rstd, nseq, F, Fp, p, seed, eps=1e-5, 
     assert convw.dtype == h1.dtype and gamma.dtype == h1.dtype, "taps / gamma travel in the operand dtype of h1"
     call("omlm_ffmid_fwd", ptr(h1), ptr(convw), ptr(gamma), ptr(h2), ptr(mean), ptr(rstd),
          h1.shape[0], nseq, F, Fp, float(eps), float(p), int(seed), ptr(seed_dev), ptr(drop_bits), ptr(gh), dcode(h1.dtype),
+         stream_ptr())
+
+
+def ffmid_fwd_planes(h1, h1_lo, convw, convw_lo, gamma, gamma_lo, h2, h2_lo, mean, rstd, nseq, F, Fp, p, seed, eps=1e-5, seed_dev=None,
+                     drop_bits=None, gh=None):
+    """ffmid_fwd on hi/lo planes (precision "fp16ff"): h1, taps and gamma are read as hi + lo, h2 leaves as planes (omlm_ffmid_fwd_planes)."""
+    assert convw.shape == (3, 2 * Fp) and gamma.numel() == Fp and h1.dtype in H16
+    for t in (h1_lo, convw, convw_lo, gamma, gamma_lo, h2, h2_lo):
+        assert t.dtype == h1.dtype, "every plane travels in the operand dtype of h1"
+    assert h1_lo.shape == h1.shape and h2_lo.shape == h2.shape and convw_lo.shape == convw.shape
+    call("omlm_ffmid_fwd_planes", ptr(h1), ptr(h1_lo), ptr(convw), ptr(convw_lo), ptr(gamma), ptr(gamma_lo), ptr(h2), ptr(h2_lo), ptr(mean),
+         ptr(rstd), h1.shape[0], nseq, F, Fp, float(eps), float(p), int(seed), ptr(seed_dev), ptr(drop_bits), ptr(gh), dcode(h1.dtype),
          stream_ptr())
 
 

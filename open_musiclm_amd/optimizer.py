@@ -74,12 +74,12 @@ class FusedAdam(torch.optim.Optimizer):
         prec = next((getattr(p, "_omlm_precision", None) for p in params if getattr(p, "_omlm_precision", None)), None)
         prec = prec or engine.default_precision()
         self._ls_state = None
-        if prec == "fp16":
+        if engine.is_half(prec):
             owner = next((m for m in (engine.model_of(p) for p in params) if m is not None), None)
             if owner is None:
                 raise RuntimeError("FusedAdam: fp16 parameters without their model (engine.tag_parameters): the loss-scale block is the model's")
             self._ls_state = engine.loss_scale_state(owner)
-        P16 = torch.empty(tot, device=dev, dtype=torch.float16 if prec == "fp16" else torch.bfloat16)
+        P16 = torch.empty(tot, device=dev, dtype=torch.float16 if engine.is_half(prec) else torch.bfloat16)
         P16.copy_(P)                                    # one-off cast (cast_pad walks rows: a single 91M-element row is one workgroup)
         for p, o, n in zip(params, offs, sizes):
             p._omlm_bf16 = P16[o:o + n].view(p.shape)

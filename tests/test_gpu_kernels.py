@@ -1290,3 +1290,143 @@ def test_relpos_mlp_fused_kernels_vs_fp64(ops, dev, n, Hd, H):
     assert e_tab < 1e-5, e_tab
     assert same
     assert max(errs.values()) < 5e-5, errs            # fp32 accumulation over up to 1817 rows, added to O(1) initial values
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# precision "fp16ff" (round 5): the ConvFeedForward forward on hi/lo planes of the 16-bit operand type
+# ---------------------------------------------------------------------------------------------------------------------
+def hilo(x, dtype):
+    """x fp32 -> (hi, lo) planes of `dtype`: hi = rne(x), lo = rne(x - hi)."""
+    hi = x.to(dtype)
+    return hi, (x - hi.float()).to(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,planes_out", [(1100, 1280, 1024, True),      # 256 x 256 tiles on the half-tile-ring kernel, ragged M
+                                              (2300, 1024, 2752, False),     # FF-out form: fp32 result + residual, 256 x 256 with a peeled tail of m-tiles
+                                              (200, 136, 72, True),          # 128 x 128 tile, ragged everything, K not a whole k-tile
+                                              (2100, 600, 320, False),       # 256 x 128 tile
+                                              (333, 5504, 1024, True)])      # FF-in width at a short M (N >= 2048: 256 x 256)
+def test_gemm_planes16_vs_fp64(ops, dev, dtype, M, N, K, planes_out):
+    """omlm_gemm_planes16: C = A B^T (+ Cin) with both operands as hi/lo planes -- three products, fp32 accumulation.  Against the fp64
+    product of the values the planes hold (hi + lo).  The bar is the accumulation's: 16-bit operand rounding is gone (fp16 planes carry
+    ~21 bits, bf16 planes 16: the lo * lo product that is left out is 2^-22 / 2^-16 relative to a term)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A, B = torch.randn(M, K, generator=g).to(dev), (torch.randn(N, K, generator=g) * 0.05).to(dev)
+    Ah, Al = hilo(A, dtype)
+    Bh, Bl = hilo(B, dtype)
+    ref = (Ah.double() + Al.double()) @ (Bh.double() + Bl.double()).t()
+    bar = 3e-6 if dtype == torch.float16 else 6e-5
+    if planes_out:
+        C, Cl = torch.full((M, N), float("nan"), device=dev, dtype=dtype), torch.full((M, N), float("nan"), device=dev, dtype=dtype)
+        ops.gemm_planes16(Ah, Al, Bh, Bl, C, Cl, M=M, N=N, K=K)
+        e_sum = relerr(C.double() + Cl.double(), ref)
+        # the hi plane is the correctly rounded result (up to the accumulation error moving a value across a rounding boundary)
+        e_hi = relerr(C, ref)
+        flips = float((C != ref.to(dtype)).float().mean())
+        report(f"gemm_planes16[{dtype},{M},{N},{K},planes]", hi_plus_lo=e_sum, hi=e_hi, hi_not_rne_frac=flips)
+        # hi + lo: the result to ~2^-21 (fp16 planes; lo may be subnormal below 6e-5) / 2^-16 (bf16 planes)
+        assert e_sum < (4e-6 if dtype == torch.float16 else 6e-5), e_sum
+        assert e_hi < (6e-4 if dtype == torch.float16 else 5e-3) and flips < (2e-3 if dtype == torch.float16 else 1e-2)      # (bf16 planes: 2^-16 against an ulp of 2^-8)
+    else:
+        Cin = torch.randn(M, N, generator=g).to(dev)
+        C = torch.full((M, N), float("nan"), device=dev)
+        ops.gemm_planes16(Ah, Al, Bh, Bl, C, M=M, N=N, K=K, Cin=Cin)
+        e = relerr(C, ref + Cin.double())
+        # what single-plane operands give on the same data, for the report
+        C1 = torch.empty(M, N, device=dev)
+        ops.gemm(Ah, Bh, C1, M=M, N=N, K=K, Cin=Cin)
+        report(f"gemm_planes16[{dtype},{M},{N},{K},fp32]", err=e, single_plane_err=relerr(C1, ref + Cin.double()))
+        assert e < bar, e
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,D", [(333, 1024), (6700, 1024), (150, 768)])
+def test_layernorm_fwd_planes(ops, dev, dtype, M, D):
+    """omlm_layernorm_fwd_planes: the hi plane is bit for bit omlm_layernorm_fwd's output, hi + lo is the fp32 result to the lo plane's
+    rounding; statistics identical."""
+    g = torch.Generator().manual_seed(M)
+    x = (torch.randn(M, D, generator=g) * 3 + 1).to(dev)
+    gamma = (1 + 0.1 * torch.randn(D, generator=g)).to(dev)
+    y0 = torch.empty(M, D, device=dev, dtype=dtype)
+    m0, r0 = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    ops.layernorm_fwd(x, gamma, y0, None, m0, r0)
+    y, yl = torch.full((M, D), float("nan"), device=dev, dtype=dtype), torch.full((M, D), float("nan"), device=dev, dtype=dtype)
+    m1, r1 = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    ops.layernorm_fwd_planes(x, gamma, y, yl, m1, r1)
+    ref = torch.nn.functional.layer_norm(x.double(), (D,), gamma.double(), None, 1e-5)
+    e = relerr(y.double() + yl.double(), ref)
+    report(f"layernorm_fwd_planes[{dtype},{M},{D}]", hi_plus_lo=e, hi=relerr(y, ref))
+    assert torch.equal(y, y0) and torch.equal(m0, m1) and torch.equal(r0, r1)
+    assert e < (3e-6 if dtype == torch.float16 else 3e-5), e
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("F,nseq,Bn,p", [(341, 80, 2, 0.0), (2730, 45, 2, 0.1), (1024, 37, 3, 0.1)])
+def test_ffmid_fwd_planes_vs_fp64(ops, dev, dtype, F, nseq, Bn, p):
+    """omlm_ffmid_fwd_planes: conv3 + GEGLU + LayerNorm(F) + dropout on h1 / taps / gamma read as hi + lo, h2 left as planes.  Against fp64
+    on the values the planes hold, with the kernel's own keep mask; statistics, keep bits and gh against the single-plane forward's."""
+    M = nseq * Bn
+    Fp = (F + 63) // 64 * 64
+    g = torch.Generator().manual_seed(F + nseq)
+    h1 = torch.zeros(M, 2 * Fp)
+    h1[:, :F] = torch.randn(M, F, generator=g)
+    h1[:, Fp:Fp + F] = torch.randn(M, F, generator=g)
+    convw = (torch.randn(2 * F, 3, generator=g) * 0.5).to(dev)
+    gamma = (1 + 0.1 * torch.randn(F, generator=g)).to(dev)
+    h1h, h1l = hilo(h1.to(dev), dtype)
+    taps32, g32 = ops.pack_conv_taps(convw, F, Fp), ops.pad_vector(gamma, Fp)
+    tph, tpl = hilo(taps32, dtype)
+    gph, gpl = hilo(g32, dtype)
+    h2, h2l = (torch.full((M, Fp), float("nan"), device=dev, dtype=dtype) for _ in range(2))
+    gh = torch.full((M, Fp), float("nan"), device=dev, dtype=dtype)
+    mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    bits = torch.zeros(M, Fp // 8, dtype=torch.uint8, device=dev) if p > 0 else None
+    ops.ffmid_fwd_planes(h1h, h1l, tph, tpl, gph, gpl, h2, h2l, mean, rstd, nseq, F, Fp, p, 4321, drop_bits=bits, gh=gh)
+    # reference on the plane values
+    cw = (tph.double() + tpl.double())                                   # [3, 2Fp] tap-major
+    cwr = torch.cat([cw[:, :F], cw[:, Fp:Fp + F]], dim=1).t().contiguous()                 # [2F, 3]
+    gmr = (gph.double() + gpl.double())[:F]
+    ref_gh = ffmid_reference(h1h.double() + h1l.double(), cwr, torch.ones(F, dtype=torch.float64, device=dev), F, Fp, nseq)
+    ref = ref_gh * gmr
+    if p > 0:
+        keep = ((bits[:, :, None] >> torch.arange(8, device=dev, dtype=torch.uint8)) & 1).reshape(M, Fp).bool()[:, :F]
+        ref = torch.where(keep, ref / (1 - p), torch.zeros_like(ref))
+        frac = 1 - keep.float().mean().item()
+        assert abs(frac - p) < 0.02, frac
+    e = relerr(h2[:, :F].double() + h2l[:, :F].double(), ref)
+    e_gh = relerr(gh[:, :F], ref_gh)
+    # the single-plane forward on the hi planes: same keep bits (a function of seed and position), statistics within its operand rounding
+    h2s = torch.empty(M, Fp, device=dev, dtype=dtype)
+    ms, rs = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    bits_s = torch.zeros(M, Fp // 8, dtype=torch.uint8, device=dev) if p > 0 else None
+    ops.ffmid_fwd(h1h, tph, gph, h2s, ms, rs, nseq, F, Fp, p, 4321, drop_bits=bits_s, gh=None)
+    e_single = relerr(h2s[:, :F], ref)
+    report(f"ffmid_fwd_planes[{dtype},{F},{nseq},{p}]", hi_plus_lo=e, gh=e_gh, single_plane=e_single)
+    assert bool((h2[:, F:] == 0).all()) and bool((h2l[:, F:] == 0).all())
+    if p > 0:
+        assert torch.equal(bits, bits_s)
+    # erf by A&S 7.1.26 (1.5e-7 abs) bounds the kernel at ~2e-6 of the output range; the single-plane forward sits at its operand rounding
+    assert e < (1e-5 if dtype == torch.float16 else 6e-5), e
+    assert e_gh < (1e-3 if dtype == torch.float16 else 8e-3) and e < 0.05 * e_single
+
+
+def test_cast_pad_group_lo_planes(ops, dev):
+    """The grouped weight re-pack with lo set leaves rne16(v - rne16(v)) in the same padded / transposed layouts: hi + lo carries the fp32
+    weight to the lo plane's rounding."""
+    g = torch.Generator().manual_seed(5)
+    for dtype in (torch.float16, torch.bfloat16):
+        w = (torch.randn(300, 200, generator=g) * 0.03).to(dev)
+        hi, lo = torch.zeros(300, 256, device=dev, dtype=dtype), torch.full((300, 256), 7.0, device=dev, dtype=dtype)
+        thi, tlo = torch.zeros(200, 304, device=dev, dtype=dtype), torch.zeros(200, 304, device=dev, dtype=dtype)
+        grp = ops.CastPadGroup()
+        grp.add(w, hi, 300, 200, 200, 256)
+        grp.add(w, lo, 300, 200, 200, 256, lo=True)
+        grp.add(w, thi, 300, 200, 200, 304, transpose=True)
+        grp.add(w, tlo, 300, 200, 200, 304, transpose=True, lo=True)
+        grp.flush()
+        assert torch.equal(hi[:, :200], w.to(dtype)) and torch.equal(lo[:, :200], (w - w.to(dtype).float()).to(dtype))
+        assert float(lo[:, 200:].abs().max()) == 0.0                      # pad columns of a lo plane are zero like the hi plane's
+        assert torch.equal(thi[:, :300], w.t().to(dtype)) and torch.equal(tlo[:, :300], (w - w.to(dtype).float()).t().to(dtype))
+        e = relerr(hi[:, :200].double() + lo[:, :200].double(), w)
+        assert e < (2e-6 if dtype == torch.float16 else 2e-5), e

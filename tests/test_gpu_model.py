@@ -33,7 +33,10 @@ REPORT = os.path.join(ROOT, "gpurun_out", "model_report.json")
 #   fp16    logits <= 8.9e-4 at depth 6 (2.0e-3 at depth 24), loss <= 4.3e-5, gradients <= 7.2e-3
 # `invariant`: the analytically-zero gradient directions of the rel-pos bias (see the train test), in the same units.
 TOL = {"bf16x3": dict(logits=1e-3, loss=4e-5, grad=1.5e-2, invariant=1e-2), "bf16": dict(logits=1.2e-2, loss=1e-3, grad=1.5e-1, invariant=1.5),
-       "fp16": dict(logits=1e-3, loss=1e-4, grad=1.5e-2, invariant=0.3)}       # invariant: pure rounding noise, 3x its measured size
+       "fp16": dict(logits=1e-3, loss=1e-4, grad=1.5e-2, invariant=0.3),       # invariant: pure rounding noise, 3x its measured size
+       # "fp16ff" (round 5: the ConvFeedForward forward on hi/lo half planes): VERDICT round 4's bars -- 5e-4 at depth 6, 1e-3 at depth 24 (own bar
+       # in the depth-24 test); its backward is fp16's
+       "fp16ff": dict(logits=5e-4, loss=1e-4, grad=1.5e-2, invariant=0.3)}
 
 
 def grad_unscale(precision):
@@ -86,7 +89,7 @@ def build_from_golden(golden_dir, name, dev, precision):
     return z, model.to(dev)
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16", "fp16ff"])
 @pytest.mark.parametrize("name", ["tiny_coarse", "tiny_fine_allweights", "tiny_semantic_t5_plainff"])
 def test_training_step_matches_reference_golden(golden_dir, dev, monkeypatch, name, precision):
     from open_musiclm_amd import open_musiclm as M
@@ -253,7 +256,7 @@ def test_generate_matches_reference_golden_ids(golden_dir, dev, precision):
     assert np.array_equal(out2.cpu().numpy(), z["generated_primed"])
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16", "fp16ff"])
 def test_cached_decode_matches_full_reforward(golden_dir, dev, precision):
     """KV-cached single-row decode (csrc/decode.hip) vs the reference-style full re-forward of the same model: the logits
     of every step agree to the precision mode's tolerance, and the sampled ids are identical for the same uniforms."""
@@ -287,7 +290,7 @@ def test_cached_decode_matches_full_reforward(golden_dir, dev, precision):
     V1 = dec.V1
     err = max(relerr(g[:, :V1], w[:, :V1]) for g, w in zip(got, want))
     report("cached_decode_" + precision, max_rel_err=err, steps=n)
-    assert err < TOL[precision]["logits"], err
+    assert err < TOL["fp16" if precision == "fp16ff" else precision]["logits"], err       # (fp16ff decodes on the fp16 step kernels)
 
 
 def test_cached_decode_batches_beyond_the_kernel_group(golden_dir, dev):
@@ -420,7 +423,7 @@ def test_cached_decode_with_absolute_position_embeddings(dev):
     assert relerr(other[:, :V1], want[3][:, :V1]) > 1e-3
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16", "fp16ff"])
 def test_full_size_coarse_small_vs_oracle(dev, precision):
     """BASELINE config 2 shapes: musiclm_small coarse stage, N = 1116, B = 2; logits, loss and grads vs the CPU oracle."""
     from open_musiclm_amd import open_musiclm as M
@@ -608,16 +611,17 @@ def _large_fine(dev, depth, precision, with_grads):
     return e_inf, e_loss, g, gfinite
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16", "fp16ff"])
 def test_large_fine_stage_full_depth_forward_loss_vs_oracle(dev, precision):
     """BASELINE config 4 (musiclm_large fine stage): all 24 layers, 16 heads, N = 1817: loss and logits vs the oracle."""
     e_inf, e_loss, _, gfinite = _large_fine(dev, 24, precision, with_grads=False)
     # bf16 operand rounding accumulates with depth: 24 layers measured 1.55e-2 (6 layers: 7e-3); the bar for this depth is 2.5e-2
-    bar = 2.5e-2 if precision == "bf16" else (4e-3 if precision == "fp16" else TOL[precision]["logits"])
+    # fp16ff: FF-in + FF-out exact removes 88 % of fp16's error variance at this depth (profiles/r05_error_budget.md: 1.7e-3 -> 6.1e-4); bar 1e-3
+    bar = {"bf16": 2.5e-2, "fp16": 4e-3, "fp16ff": 1e-3}.get(precision, TOL[precision]["logits"])
     assert e_inf < bar and e_loss < TOL[precision]["loss"] and gfinite, (e_inf, e_loss)
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16", "fp16ff"])
 def test_large_fine_stage_gradients_vs_oracle(dev, precision):
     """Same shapes (16 heads, N = 1817, 5 fine quantizers) at depth 2 so that the oracle's autograd fits a test: grads."""
     e_inf, e_loss, g, _ = _large_fine(dev, 2, precision, with_grads=True)
@@ -689,7 +693,7 @@ def test_fp16_overflow_is_skipped_and_the_loss_scale_backs_off(dev, tmp_path):
     report("fp16_overflow", **rep, first_loss=losses[0], last_loss=losses[-1])
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16", "fp16ff"])
 def test_graphed_bf16x3_training_tracks_eager_over_optimizer_steps(dev, precision):
     """bf16x3 at a size where the fp32 GEMMs take the hi/lo-plane route (M N K >= ops._X3_MIN_MACS), captured into a HIP graph,
     over several optimizer steps: the replayed micro-step must read the CURRENT weights -- the planes of the persistent Parameter
@@ -1276,7 +1280,7 @@ def test_rccl_allreduce_of_the_flat_gradient_buffer_after_a_graph_replay(dev, tm
     assert np.isfinite(rep["loss"]) and np.isfinite(rep["grad_norm_sq"]) and rep["grad_norm_sq"] > 0
 
 
-HEADLINE_MODES = ["bf16", "fp16"]
+HEADLINE_MODES = ["bf16", "fp16", "fp16ff"]
 
 
 @pytest.mark.parametrize("precision", HEADLINE_MODES)
