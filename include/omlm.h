@@ -226,9 +226,11 @@ int omlm_split_planes(const float* x, void* planes, long long n, long long plane
  * variance, profiles/r05_error_budget.md) on hi/lo planes of the 16-bit operand type `dtype` (1 = bf16, 2 = fp16).  C = A B^T (+ Cin), A [M, K]
  * and B [N, K] row-major, every *_lo plane in its hi plane's layout (separate allocations are fine); one launch, hi*hi + hi*lo + lo*hi with
  * fp32 accumulation.  C_lo NULL: C is fp32 (Cin optional).  C_lo given: C = rne16(v) and C_lo = rne16(v - C) in `dtype` (no Cin) -- the next
- * forward kernel reads the un-rounded value hi + lo, the 16-bit backward reads C alone. */
+ * forward kernel reads the un-rounded value hi + lo, the 16-bit backward reads C alone.  a_map / c_map (optional): row maps as in omlm_gemm
+ * (the logit heads of the same mode, open_musiclm.py:163-186). */
 int omlm_gemm_planes16(const void* A, const void* A_lo, const void* B, const void* B_lo, void* C, void* C_lo, const float* Cin,
-                       long long a_rows, long long b_rows, int M, int N, int K, int lda, int ldb, int ldc, int ldcin, int dtype, void* stream);
+                       const int* a_map, const int* c_map, long long a_rows, long long b_rows, int M, int N, int K,
+                       int lda, int ldb, int ldc, int ldcin, int dtype, void* stream);
 /* All weight-gradient contractions of a backward pass in one launch (autograd of nn.Linear, transformer.py:203-212,144,149:
  * dW += dY^T X).  Problem i: C_i [M_i, N_i] fp32 (accumulated, +=; c_map optional: physical row of logical row m, < 0 skips)
  * from 16-bit k-major operands A_i [K_i, M_i] (pitch lda) and B_i [K_i, N_i] (pitch ldb); pitches are multiples of 8 elements.

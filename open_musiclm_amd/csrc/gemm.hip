@@ -1355,7 +1355,7 @@ static int launch_tile_s3(const GemmArgs& g, hipStream_t st) {
     const int tiles = ((g.M + BM_ - 1) / BM_) * ((g.N + BN_ - 1) / BN_);
     dim3 grid(tiles, 1), block(NTH);
     if constexpr (BM_ == 256 && BN_ == 256) {
-        if (gemm_t8_mode() > 0 && g.K % BK == 0 && !gemm_fastk_off()) {
+        if (gemm_t8_mode() > 0 && g.K % BK == 0 && !gemm_fastk_off() && !g.a_map) {
             auto k8 = gemm_tile8_kernel<false, false, TOUT, true>;
             static bool attr8 = false;
             if (!attr8) { (void)hipFuncSetAttribute((const void*)k8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); attr8 = true; }
@@ -1625,19 +1625,21 @@ extern "C" int OMLM_API(omlm_gemm_qknorm)(const void* A, const void* B, void* C,
 // (profiles/r05_error_budget.md).
 #if !OMLM_FP16
 extern "C" int omlm_gemm_planes16_h(const void* A, const void* A_lo, const void* B, const void* B_lo, void* C, void* C_lo, const float* Cin,
-                                    long long a_rows, long long b_rows, int M, int N, int K, int lda, int ldb, int ldc, int ldcin, int dtype, void* stream);
+                                    const int* a_map, const int* c_map, long long a_rows, long long b_rows, int M, int N, int K,
+                                    int lda, int ldb, int ldc, int ldcin, int dtype, void* stream);
 #endif
 extern "C" int OMLM_API(omlm_gemm_planes16)(const void* A, const void* A_lo, const void* B, const void* B_lo, void* C, void* C_lo, const float* Cin,
-                                            long long a_rows, long long b_rows, int M, int N, int K, int lda, int ldb, int ldc, int ldcin,
-                                            int dtype, void* stream) {
+                                            const int* a_map, const int* c_map, long long a_rows, long long b_rows, int M, int N, int K,
+                                            int lda, int ldb, int ldc, int ldcin, int dtype, void* stream) {
 #if !OMLM_FP16
-    if (dtype == OMLM_DT_F16) return omlm_gemm_planes16_h(A, A_lo, B, B_lo, C, C_lo, Cin, a_rows, b_rows, M, N, K, lda, ldb, ldc, ldcin, 1, stream);
+    if (dtype == OMLM_DT_F16) return omlm_gemm_planes16_h(A, A_lo, B, B_lo, C, C_lo, Cin, a_map, c_map, a_rows, b_rows, M, N, K, lda, ldb, ldc, ldcin, 1, stream);
 #endif
     OMLM_CHECK_ARG(dtype == 1, "gemm_planes16: operand dtype 1 (bf16) or 2 (fp16)");
     OMLM_CHECK_ARG(A_lo && B_lo, "gemm_planes16: null lo plane");
     OMLM_CHECK_ARG(((uintptr_t)A_lo % 16) == 0 && ((uintptr_t)B_lo % 16) == 0 && ((uintptr_t)C_lo % 16) == 0, "gemm_planes16: 16-byte aligned planes");
     OMLM_CHECK_ARG(!(C_lo && Cin), "gemm_planes16: plane output takes no residual");
-    return gemm_impl(A, B, C, Cin, nullptr, nullptr, nullptr, a_rows, b_rows, M, N, K, lda, ldb, ldc, ldcin, 0, 0,
+    // a_map / c_map (optional): physical row of logical row m in A (both planes) / in C and Cin, as in omlm_gemm -- the logit heads
+    return gemm_impl(A, B, C, Cin, a_map, nullptr, c_map, a_rows, b_rows, M, N, K, lda, ldb, ldc, ldcin, 0, 0,
                      1, C_lo ? 1 : 0, 1.0f, stream, 1, A_lo, B_lo, C_lo, true);
 }
 

@@ -319,6 +319,12 @@ class PreparedWeights:
                 cache[(F, Fp, str(dev))] = cm.to(dev)
             ent["dW1_cmap"] = cache[(F, Fp, str(dev))]
             self.layers.append(ent)
+        self.heads_lo = []
+        if self.ff3:                               # the logit heads of "fp16ff" run on planes too (1.7 % of the FLOPs, 5-6 % of the error variance)
+            for w in model.logit_weights:
+                lo = torch.empty(w.shape, dtype=T, device=dev)
+                packs.add(w.detach().reshape(-1, D), lo.view(-1, D), w.numel() // D, D, D, D, lo=True)
+                self.heads_lo.append(lo)
         packs.flush()
         self.heads = []
         self.headsT = []
@@ -562,7 +568,12 @@ def trunk_forward(tr, pw: PreparedWeights, x: torch.Tensor, keymask: Optional[to
         table.record_stream(torch.cuda.current_stream(dev))
     mf = torch.empty(M, device=dev); rf = torch.empty(M, device=dev)
     y = torch.empty(M, D, dtype=T, device=dev)
-    ops.layernorm_fwd(x, tr.norm.gamma.detach(), y, None, mf, rf)
+    if pw.ff3:                                                   # the lo plane rides on the tensor until heads_forward has read it
+        y_lo = torch.empty(M, D, dtype=T, device=dev)
+        ops.layernorm_fwd_planes(x, tr.norm.gamma.detach(), y, y_lo, mf, rf)
+        y._omlm_lo = y_lo
+    else:
+        ops.layernorm_fwd(x, tr.norm.gamma.detach(), y, None, mf, rf)
     saved = dict(layers=saved_layers, xL=x, mf=mf, rf=rf, table=table, rp=rp_saved, keymask=keymask, salt=salt) if save else None
     return y, saved
 
@@ -753,6 +764,7 @@ def heads_forward(model, pw: PreparedWeights, y: torch.Tensor, lay: SeqLayout, w
     position j of a sequence is scored by quantizer head j mod Q.)"""
     D = model.dim
     out = []
+    y_lo = y.__dict__.pop("_omlm_lo", None) if pw.ff3 else None          # "fp16ff": trunk_forward left the final LayerNorm's lo plane on y
     for s, seq in enumerate(model.token_sequences):
         if not want[s]:
             out.append(None)
@@ -768,6 +780,10 @@ def heads_forward(model, pw: PreparedWeights, y: torch.Tensor, lay: SeqLayout, w
             if ent is None:
                 continue
             a_map, c_map, rows = ent
+            if y_lo is not None:
+                ops.gemm_planes16(y, y_lo, pw.heads[s][qq], pw.heads_lo[s][qq], buf, M=rows, N=V1, K=D, a_map=a_map, c_map=c_map, ldc=ldV,
+                                  a_rows=y.shape[0], b_rows=V1)
+                continue
             ops.gemm(y, pw.heads[s][qq], buf, M=rows, N=V1, K=D, a_map=a_map, c_map=c_map, ldc=ldV,
                      a_rows=y.shape[0], b_rows=V1)
         out.append(buf)

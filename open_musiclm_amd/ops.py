@@ -115,9 +115,11 @@ def gemm(A: torch.Tensor, B: torch.Tensor, C_: torch.Tensor, *, M: int, N: int, 
          dcode(A.dtype), dcode(C_.dtype), float(alpha), stream_ptr())
 
 
-def gemm_planes16(A, A_lo, B, B_lo, C_, C_lo=None, *, M: int, N: int, K: int, Cin: Optional[torch.Tensor] = None):
+def gemm_planes16(A, A_lo, B, B_lo, C_, C_lo=None, *, M: int, N: int, K: int, Cin: Optional[torch.Tensor] = None, a_map=None, c_map=None,
+                  ldc: Optional[int] = None, a_rows: Optional[int] = None, b_rows: Optional[int] = None):
     """C = A B^T (+ Cin) with both operands as hi/lo planes of ONE 16-bit type (A [M, K], B [N, K] row-major; omlm_gemm_planes16): three
-    products, fp32 accumulation.  C_lo None: C is fp32.  C_lo given: C / C_lo receive the result as planes of the operand type."""
+    products, fp32 accumulation.  C_lo None: C is fp32.  C_lo given: C / C_lo receive the result as planes of the operand type.
+    a_map / c_map: row maps as in gemm (physical row of logical row m in A's planes / in C and Cin)."""
     hip.require_gpu(A, "A")
     assert A.dtype in H16 and A_lo.dtype == A.dtype and B.dtype == A.dtype and B_lo.dtype == A.dtype
     assert A_lo.shape == A.shape and B_lo.shape == B.shape
@@ -125,8 +127,10 @@ def gemm_planes16(A, A_lo, B, B_lo, C_, C_lo=None, *, M: int, N: int, K: int, Ci
         assert C_.dtype == torch.float32 and (Cin is None or Cin.dtype == torch.float32)
     else:
         assert C_.dtype == A.dtype and C_lo.dtype == A.dtype and C_lo.shape == C_.shape and Cin is None
-    lda, ldb, ldc = A.shape[-1], B.shape[-1], C_.shape[-1]
-    call("omlm_gemm_planes16", ptr(A), ptr(A_lo), ptr(B), ptr(B_lo), ptr(C_), ptr(C_lo), ptr(Cin), A.numel() // lda, B.numel() // ldb,
+    lda, ldb = A.shape[-1], B.shape[-1]
+    ldc = ldc if ldc is not None else C_.shape[-1]
+    call("omlm_gemm_planes16", ptr(A), ptr(A_lo), ptr(B), ptr(B_lo), ptr(C_), ptr(C_lo), ptr(Cin), ptr(a_map), ptr(c_map),
+         a_rows if a_rows is not None else A.numel() // lda, b_rows if b_rows is not None else B.numel() // ldb,
          M, N, K, lda, ldb, ldc, Cin.shape[-1] if Cin is not None else 0, dcode(A.dtype), stream_ptr())
 
 

@@ -207,7 +207,9 @@ class _TrunkFunction(torch.autograd.Function):
         xf = x.detach().reshape(B * N, D).contiguous().float()
         y, saved = engine.trunk_forward(tr, pw, xf, keymask, B, N, True, tr.training)
         ctx.tr, ctx.pw, ctx.saved, ctx.B, ctx.N, ctx.np = tr, pw, saved, B, N, len(params)
-        return y.float().view(B, N, D)
+        lo = y.__dict__.pop("_omlm_lo", None)            # precision "fp16ff": the final LayerNorm's output arrives as hi/lo planes
+        out = y.float() if lo is None else y.float() + lo.float()
+        return out.view(B, N, D)
 
     @staticmethod
     def backward(ctx, dy):

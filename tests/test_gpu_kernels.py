@@ -1430,3 +1430,25 @@ def test_cast_pad_group_lo_planes(ops, dev):
         assert torch.equal(thi[:, :300], w.t().to(dtype)) and torch.equal(tlo[:, :300], (w - w.to(dtype).float()).t().to(dtype))
         e = relerr(hi[:, :200].double() + lo[:, :200].double(), w)
         assert e < (2e-6 if dtype == torch.float16 else 2e-5), e
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_gemm_planes16_with_row_maps(ops, dev, dtype):
+    """The logit-head form of omlm_gemm_planes16: logical row m reads A's planes at row a_map[m] and lands in C at row c_map[m]
+    (open_musiclm.py:163-186: every hidden row is scored by one quantizer head), ragged N = 1025 at pitch 1032, rows beyond the maps untouched."""
+    g = torch.Generator().manual_seed(3)
+    R, K, N, ldc, M = 2500, 1024, 1025, 1032, 800
+    A, B = torch.randn(R, K, generator=g).to(dev), (torch.randn(N, K, generator=g) * 0.05).to(dev)
+    Ah, Al = hilo(A, dtype)
+    Bh, Bl = hilo(B, dtype)
+    a_map = torch.randperm(R, generator=g)[:M].to(torch.int32).to(dev)
+    c_map = torch.randperm(1000, generator=g)[:M].to(torch.int32).to(dev)
+    C = torch.full((1000, ldc), 7.0, device=dev)
+    ops.gemm_planes16(Ah, Al, Bh, Bl, C, M=M, N=N, K=K, a_map=a_map, c_map=c_map, ldc=ldc, a_rows=R, b_rows=N)
+    ref = (Ah.double() + Al.double())[a_map.long()] @ (Bh.double() + Bl.double()).t()
+    e = relerr(C[c_map.long(), :N], ref)
+    untouched = torch.ones(1000, dtype=torch.bool, device=dev)
+    untouched[c_map.long()] = False
+    report(f"gemm_planes16_maps[{dtype}]", err=e)
+    assert e < (3e-6 if dtype == torch.float16 else 6e-5), e
+    assert bool((C[untouched] == 7.0).all()) and bool((C[:, N:] == 7.0).all())

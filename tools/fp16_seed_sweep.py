@@ -13,7 +13,7 @@ for name, kw, mk in (("coarse6", dict(dim=1024, depth=6, heads=8), lambda **k: M
                      ("fine24", dict(dim=1024, depth=24, heads=16), lambda **k: M.create_fine_transformer(num_coarse_quantizers=3, num_fine_quantizers=5, ff_dropout=0.0, **k))):
     for path in sorted(glob.glob(os.path.join(root, ".bigfix", f"{name}_seed*.pt"))):
         z = torch.load(path)
-        for prec in ("bf16", "fp16", "bf16x3"):
+        for prec in ("bf16", "fp16", "fp16ff", "bf16x3"):
             torch.manual_seed(100 + z["seed"])
             model = mk(precision=prec, **kw).to(dev)
             wrapper = M.TokenConditionedTransformerWrapper(transformer=model, unique_consecutive=False, cross_entropy_loss_weights=[0., 0., 1.], mask_prob=0.0)
@@ -31,7 +31,7 @@ with open(out, "w") as fh:
     fh.write("Logits error max|d| / max|ref| against the CPU oracle, B = 1, eval forward, per weight / id seed (tools/make_seed_oracles.py, tools/fp16_seed_sweep.py)\n\n")
     fh.write("| config | precision | seeds | max | mean | per seed |\n|---|---|---:|---:|---:|---|\n")
     for cfg in ("coarse6", "fine24"):
-        for prec in ("bf16", "fp16", "bf16x3"):
+        for prec in ("bf16", "fp16", "fp16ff", "bf16x3"):
             v = [r["logits_err"] for r in rows if r["config"] == cfg and r["precision"] == prec]
             if v:
                 fh.write(f"| {cfg} | {prec} | {len(v)} | {max(v):.2e} | {sum(v) / len(v):.2e} | {', '.join(f'{x:.2e}' for x in v)} |\n")
