@@ -370,6 +370,23 @@ def test_decode_batch_limit_follows_the_kernels():
     assert decode.max_batch(big, "bf16") == 16 and decode.max_batch(big, "fp16") == 16
     assert decode.max_batch(big, "bf16x3") == 8 and decode.max_batch(small, "bf16") == 8
     assert decode.supports(big, 16, "bf16") and not decode.supports(big, 17, "bf16") and not decode.supports(big, 9)
+    assert decode.max_batch(big, "fp16ff") == 16              # fp16ff decodes on the fp16 step kernels (the hi planes)
+
+
+def test_precision_modes_and_their_half_family(monkeypatch):
+    """engine: the four precision names, which of them carry the loss scale / the fp16 weight shadow (is_half), the operand type each
+    keeps in HBM, and the error for an unknown $OMLM_PRECISION."""
+    import torch
+    from open_musiclm_amd import engine
+    assert set(engine._PRECISIONS) == {"bf16", "fp16", "fp16ff", "bf16x3"}
+    assert engine._PRECISIONS["fp16ff"] is torch.float16 and engine._PRECISIONS["fp16"] is torch.float16
+    assert [engine.is_half(p) for p in ("bf16", "fp16", "fp16ff", "bf16x3")] == [False, True, True, False]
+    assert engine.loss_scale("bf16") == 1.0 and engine.loss_scale("fp16ff") == engine.loss_scale_initial() == engine.loss_scale("fp16")
+    monkeypatch.setenv("OMLM_PRECISION", "fp16ff")
+    assert engine.default_precision() == "fp16ff"
+    monkeypatch.setenv("OMLM_PRECISION", "fp8")
+    with pytest.raises(ValueError):
+        engine.default_precision()
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/scripts"), reason="reference checkout not present (GPU box)")
