@@ -48,6 +48,18 @@ def run(iters=300, burst=12):
             c["Cin"] = torch.randn(M, N, generator=g).to(dev)
         return c
 
+    def case_p16(M, N, K, planes_out):
+        """omlm_gemm_planes16 (precision fp16ff): fp16 hi/lo operand planes, three products; plane output (ref = the hi plane, the lo plane is
+        checked through `extra`) or fp32 + residual"""
+        T = torch.float16
+        A32, B32 = torch.randn(M, K, generator=g).to(dev), (torch.randn(N, K, generator=g) * 0.05).to(dev)
+        A, B = A32.to(T), B32.to(T)
+        c = dict(name=f"fp16 hi/lo planes M={M} N={N} K={K} out={'planes' if planes_out else 'float32 + residual'}", A=A, B=B, M=M, N=N, K=K, kw={},
+                 out_dtype=T if planes_out else torch.float32, A_lo=(A32 - A.float()).to(T), B_lo=(B32 - B.float()).to(T), planes_out=planes_out)
+        if not planes_out:
+            c["Cin"] = torch.randn(M, N, generator=g).to(dev)
+        return c
+
     cases = [case_planes(1116, 512, 512, True),           # dz = ds W of the rel-pos MLP's backward (24 k-tiles: even)
              case_planes(1116, 512, 512, False),          # its forward a = z W^T
              case_h16(1116, 512, 512, torch.float32, False),
@@ -60,14 +72,27 @@ def run(iters=300, burst=12):
              # long contractions on more than one round of tiles: the half-tile-ring schedule (gemm_tile8_body, round 5) by default -- five
              # half-tiles in flight behind counted waits; a slot re-requested too early or a short wait would meet late pieces here
              case_h16(8192, 4096, 2752, torch.float32, True),
-             case_h16(9000, 4096, 2048, torch.bfloat16, False)]       # ragged last tile row
+             case_h16(9000, 4096, 2048, torch.bfloat16, False),       # ragged last tile row
+             # the hi/lo-plane route of precision fp16ff (round 5, second half): 3 x the k-tiles on the half-tile ring with a descriptor per plane,
+             # the plane-output epilogue (two stores per piece), and the peeled tail of m-tiles on the rotated SPLIT3 loop
+             case_p16(3428, 5504, 1024, True),             # 308 tiles: 11 full-round m-tile rows on the ring + a 612-row tail
+             case_p16(17920, 1024, 2752, False)]           # 280 tiles: 64 m-tile rows + a 1536-row tail
 
     def launch(c, out):
+        if "A_lo" in c:
+            if c["planes_out"]:
+                ops.gemm_planes16(c["A"], c["A_lo"], c["B"], c["B_lo"], out, c["lo_out"], M=c["M"], N=c["N"], K=c["K"])
+                out.view(torch.int16).bitwise_xor_(c["lo_out"].view(torch.int16))     # one tensor to compare: hi XOR lo (both planes deterministic)
+            else:
+                ops.gemm_planes16(c["A"], c["A_lo"], c["B"], c["B_lo"], out, M=c["M"], N=c["N"], K=c["K"], Cin=c["Cin"])
+            return
         ops.gemm(c["A"], c["B"], out, M=c["M"], N=c["N"], K=c["K"], Cin=c.get("Cin"), **c["kw"])
 
     # reference results on an idle GPU
     for c in cases:
         ref = torch.empty(c["M"], c["N"], dtype=c["out_dtype"], device=dev)
+        if c.get("planes_out"):
+            c["lo_out"] = torch.empty_like(ref)      # (shared by the burst's launches: stream-ordered, folded into `out` by the launch itself)
         launch(c, ref)
         torch.cuda.synchronize()
         ref2 = torch.empty_like(ref)
