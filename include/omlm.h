@@ -231,6 +231,12 @@ int omlm_split_planes(const float* x, void* planes, long long n, long long plane
 int omlm_gemm_planes16(const void* A, const void* A_lo, const void* B, const void* B_lo, void* C, void* C_lo, const float* Cin,
                        const int* a_map, const int* c_map, long long a_rows, long long b_rows, int M, int N, int K,
                        int lda, int ldb, int ldc, int ldcin, int dtype, void* stream);
+/* Workspace for the deterministic split-K of a GEMM's peeled tail (the m-tile rows behind the last full round of 256 x 256 tiles: their K range is
+ * cut into slices that fill the machine, each slice stores its partial tile to its own plane of the workspace, a reduction kernel adds the planes
+ * in a fixed order with the residual and writes the output type).  `bytes` of device memory on the current device, kept alive by the caller (64 MiB
+ * covers the training step's shapes; a tail that needs more keeps the one-launch form); NULL / 0 switches the form off.  One stream at a time per
+ * device may run such GEMMs.  $OMLM_GEMM_TAIL_SPLIT=0: off. */
+int omlm_gemm_set_tail_workspace(void* workspace, long long bytes);
 /* All weight-gradient contractions of a backward pass in one launch (autograd of nn.Linear, transformer.py:203-212,144,149:
  * dW += dY^T X).  Problem i: C_i [M_i, N_i] fp32 (accumulated, +=; c_map optional: physical row of logical row m, < 0 skips)
  * from 16-bit k-major operands A_i [K_i, M_i] (pitch lda) and B_i [K_i, N_i] (pitch ldb); pitches are multiples of 8 elements.

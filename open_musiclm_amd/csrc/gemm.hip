@@ -75,6 +75,9 @@ struct GemmArgs {
     // the result leaves as planes too -- C = rne16(v), C_lo = rne16(v - C) at the same pitch.
     int split3;
     const void* A_lo; const void* B_lo; void* C_lo;
+    // split-K into SLICES instead of atomics (the peeled tail, gemm_impl): split s stores its fp32 partial tile to C + s * c_split_stride
+    // (elements); a reduction kernel adds the slices in a fixed order -- deterministic, and no pre-filled C
+    long long c_split_stride;
     // l2-norm epilogue (EPI == 1 instantiations, omlm_gemm_qknorm): the first epi_groups 64-column groups of a row leave the kernel as
     // v / max(|v|, 1e-12) * epi_scale[col & 63] with the norm written to epi_norm[row * epi_ldnorm + group]; columns >= c2_col0 (if C2) go
     // to C2 + row * ldc2 + (col - c2_col0)
@@ -412,7 +415,7 @@ struct h16pl_t { h16_t v; };
 // row-contiguous stores: 8 bf16 / 4 fp32 per lane, full 128-byte lines per row.
 template <int MI, int NJ, int WN_, typename TOUT, int EPI = 0, bool AHEAD = (OMLM_EPI_CIN_AHEAD != 0) && (MI * NJ <= 4)>
 __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16 (&acc)[MI][NJ], char* smem, int m0, int n0,
-                                              int wm, int wn, int wave, int lane, int dbg, bool split, float* patch = nullptr) {
+                                              int wm, int wn, int wave, int lane, int dbg, bool split, float* patch = nullptr, int ksplit = 0) {
     constexpr int SROW = WN_ + 4;                                  // padded row (floats), keeps 16-B alignment
     float* stg = patch ? patch : (float*)smem + (size_t)wave * 32 * SROW;      // (persistent kernel: the patch sits where no DMA lands)
     constexpr int VEC = sizeof(TOUT) == 2 ? 8 : 4;                 // elements per 16-byte store
@@ -437,7 +440,9 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16 (&acc)[M
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     const int col = n0 + wn + 32 * j + (lane & 31);
-                    if (col < g.N) unsafeAtomicAdd((float*)g.C + prow * g.ldc + col, g.alpha * acc[i][j][e]);
+                    if (col >= g.N) continue;
+                    if (g.c_split_stride) ((float*)g.C + (long long)ksplit * g.c_split_stride)[prow * g.ldc + col] = g.alpha * acc[i][j][e];
+                    else unsafeAtomicAdd((float*)g.C + prow * g.ldc + col, g.alpha * acc[i][j][e]);
                 }
             }
         return;
@@ -627,7 +632,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, 
     const dma_rsrc rsBl = make_dma_rsrc(SPLIT3 ? g.B_lo : g.B, (unsigned long long)g.b_rows * g.ldb * 2);
 
     for (;;) {
-        int bid, kt0, kt1;
+        int bid, kt0, kt1, ksplit_id = 0;
         if (bal) {
             const int per_chunk = nwg * g.bal_ck;
             int c = u / per_chunk;
@@ -642,6 +647,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, 
             u = seg_end;
         } else {
             const int ksplit = lg / nwg;
+            ksplit_id = ksplit;
             bid = lg - ksplit * nwg;
             kt0 = ksplit * g.kt_per_split;
             kt1 = min(nk_all, kt0 + g.kt_per_split);
@@ -761,7 +767,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         __syncthreads();
-        tile_epilogue<MI, NJ, WN_, TOUT, EPI>(g, acc, smem, m0, n0, wm, wn, wave, lane, dbg, bal || split);
+        tile_epilogue<MI, NJ, WN_, TOUT, EPI>(g, acc, smem, m0, n0, wm, wn, wave, lane, dbg, bal || split, nullptr, ksplit_id);
         if (!bal || u >= u1) break;
         __syncthreads();              // the non-split epilogue stages through LDS; the next segment's DMA must not overtake it
     }
@@ -1177,7 +1183,7 @@ __global__ __launch_bounds__(512) void gemm_wgrad_group_kernel(GroupArgs ga) {
     GemmArgs g;
     g.A = q.A; g.B = q.B; g.C = q.C; g.Cin = q.C; g.a_map = nullptr; g.b_map = nullptr; g.c_map = q.c_map;
     g.a_rows = q.K; g.b_rows = q.K; g.M = q.M; g.N = q.N; g.K = q.K; g.lda = q.lda; g.ldb = q.ldb; g.ldc = q.ldc; g.ldcin = q.ldc;
-    g.alpha = 1.f; g.kt_per_split = q.kt_per_split; g.bal_ck = 0; g.bal_chunks = 0; g.debug = 0; g.split3 = 0; g.A_lo = nullptr; g.B_lo = nullptr; g.C_lo = nullptr;
+    g.alpha = 1.f; g.kt_per_split = q.kt_per_split; g.bal_ck = 0; g.bal_chunks = 0; g.debug = 0; g.split3 = 0; g.A_lo = nullptr; g.B_lo = nullptr; g.C_lo = nullptr; g.c_split_stride = 0;
     g.epi_scale = nullptr; g.epi_norm = nullptr; g.epi_groups = 0; g.epi_ldnorm = 0; g.C2 = nullptr; g.c2_col0 = 0; g.ldc2 = 0;
     const int nk = (q.K + BK - 1) / BK;
     if constexpr (T8) {
@@ -1349,13 +1355,13 @@ static int launch_tile(const GemmArgs& g, int a_kmaj, int b_kmaj, int splits, hi
 // 256 x 256 tiles (whole k-tiles), the rotated-loop SPLIT3 kernel otherwise.  Both copies of the file build it (TOUT: float, or h16pl_t =
 // the result leaves as planes too).
 template <int BM_, int BN_, int WM_, int WN_, typename TOUT>
-static int launch_tile_s3(const GemmArgs& g, hipStream_t st) {
+static int launch_tile_s3(const GemmArgs& g, hipStream_t st, int splits = 1) {
     constexpr int NTH = (BM_ / WM_) * (BN_ / WN_) * 64;
     constexpr size_t LDS = 2 * (size_t)(BM_ + BN_) * BK * 2;
     const int tiles = ((g.M + BM_ - 1) / BM_) * ((g.N + BN_ - 1) / BN_);
-    dim3 grid(tiles, 1), block(NTH);
+    dim3 grid(tiles, splits), block(NTH);
     if constexpr (BM_ == 256 && BN_ == 256) {
-        if (gemm_t8_mode() > 0 && g.K % BK == 0 && !gemm_fastk_off() && !g.a_map) {
+        if (gemm_t8_mode() > 0 && g.K % BK == 0 && !gemm_fastk_off() && !g.a_map && splits == 1) {
             auto k8 = gemm_tile8_kernel<false, false, TOUT, true>;
             static bool attr8 = false;
             if (!attr8) { (void)hipFuncSetAttribute((const void*)k8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); attr8 = true; }
@@ -1384,6 +1390,53 @@ static int launch_layout(const GemmArgs& g, int a_kmaj, int b_kmaj, int splits, 
     return omlm_post_launch("omlm_gemm");
 }
 
+// ---- the peeled tail as a deterministic split-K (round 5) -------------------------------------------------------------------------
+// The m-tile rows behind the last full round of 256 x 256 tiles run on 128 x 128 tiles (gemm_impl below): 48 ... 190 workgroups whose
+// k-loops (86 k-tiles for d(xn2), 129 loop tiles for the FF-out plane route) are one serial chain each on a fraction of the machine
+// (80 / 121 us for ~35 / ~50 us of work at the chip's rate).  With a workspace (omlm_gemm_set_tail_workspace) the tail's K range is cut
+// into S slices that fill the 2-per-CU slots, every slice STORES its fp32 partial tile to its own plane of the workspace (no atomics, no
+// pre-filled C), and gemm_tail_reduce_kernel adds the planes in a fixed order together with the residual and writes the output type
+// (fp32, 16-bit, or 16-bit hi/lo planes): deterministic, two launches.  One stream at a time per device may run peeled GEMMs (the
+// workspace is shared): true of the training / eval step; OMLM_GEMM_TAIL_SPLIT=0 or no workspace keeps the one-launch tail.
+static float* g_tail_ws = nullptr;
+static long long g_tail_ws_bytes = 0;
+static int g_tail_ws_dev = -1;
+
+// MODE 0: fp32 out; 1: 16-bit out; 2: 16-bit hi/lo planes out.  One thread = 4 consecutive columns of a row.
+template <int MODE>
+__global__ __launch_bounds__(256) void gemm_tail_reduce_kernel(const float* __restrict__ ws, int S, long long stride, int M, int N, int ldw,
+                                                               void* __restrict__ C, void* __restrict__ C_lo, int ldc,
+                                                               const float* __restrict__ Cin, int ldcin) {
+    const int nq = (N + 3) >> 2;
+    const long long total = (long long)M * nq;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int r = (int)(i / nq), c = (int)(i - (long long)r * nq) * 4;
+        float4 v = *(const float4*)(ws + (size_t)r * ldw + c);                  // ldw % 4 == 0: whole pieces (columns >= N hold what the tile kernel left: never stored)
+        for (int s = 1; s < S; ++s) {
+            const float4 t = *(const float4*)(ws + (size_t)s * stride + (size_t)r * ldw + c);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            if (c + x >= N) break;
+            float u = o[x];
+            if (Cin) u += Cin[(size_t)r * ldcin + c + x];
+            if constexpr (MODE == 0) ((float*)C)[(size_t)r * ldc + c + x] = u;
+            else {
+                const h16_t hi = (h16_t)u;
+                ((h16_t*)C)[(size_t)r * ldc + c + x] = hi;
+                if constexpr (MODE == 2) ((h16_t*)C_lo)[(size_t)r * ldc + c + x] = (h16_t)(u - (float)hi);
+            }
+        }
+    }
+}
+
+static bool gemm_tail_split_on() {
+    const char* e = getenv("OMLM_GEMM_TAIL_SPLIT");                // read per call like the other levers
+    return !(e && e[0] == '0');
+}
+
 // dtype codes shared with the Python host: 0 = fp32, 1 = bf16
 static int gemm_impl(const void* A, const void* B, void* C, const float* Cin,
                      const int* a_map, const int* b_map, const int* c_map,
@@ -1410,7 +1463,7 @@ static int gemm_impl(const void* A, const void* B, void* C, const float* Cin,
     g.a_rows = a_rows; g.b_rows = b_rows; g.M = M; g.N = N; g.K = K;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldcin = ldcin; g.alpha = alpha;
     { const char* dbg = getenv("OMLM_GEMM_DEBUG"); g.debug = dbg ? atoi(dbg) : 0; }
-    g.split3 = split3; g.A_lo = A_lo; g.B_lo = B_lo; g.C_lo = C_lo;
+    g.split3 = split3; g.A_lo = A_lo; g.B_lo = B_lo; g.C_lo = C_lo; g.c_split_stride = 0;
     g.epi_scale = nullptr; g.epi_norm = nullptr; g.epi_groups = 0; g.epi_ldnorm = 0; g.C2 = nullptr; g.c2_col0 = 0; g.ldc2 = 0;
     hipStream_t st = as_stream(stream);
     // tile shape (bf16 path): 256x256 when both output dims are wide, 256x128 for tall-narrow outputs, else 128x128
@@ -1537,10 +1590,58 @@ static int gemm_impl(const void* A, const void* B, void* C, const float* Cin,
             if (Cin) g2.Cin = Cin + (size_t)M1 * ldcin;
             const int rc = launch(g1, 256, 256, 1);
             if (rc != OMLM_OK) return rc;
+            // the tail: deterministic split-K through the workspace when it pays (see gemm_tail_reduce_kernel)
+            int dev_now = -2;
+            if (g_tail_ws && gemm_tail_split_on() && alpha == 1.0f && hipGetDevice(&dev_now) == hipSuccess && dev_now == g_tail_ws_dev) {
+                const int Mt = g2.M, Nw = (N + 3) / 4 * 4;
+                const int tiles_t = ((Mt + 127) / 128) * ((N + 127) / 128);
+                int S = (2 * ncu) / tiles_t;
+                if (S > nk / 8) S = nk / 8;
+                if (S > 8) S = 8;
+                if (S >= 2) {
+                    const int ktps = (nk + S - 1) / S;
+                    S = (nk + ktps - 1) / ktps;
+                    const long long slice = (long long)Mt * Nw;
+                    if (S >= 2 && (long long)S * slice * 4 <= g_tail_ws_bytes) {
+                        GemmArgs gw = g2;
+                        gw.C = g_tail_ws; gw.C_lo = nullptr; gw.Cin = nullptr; gw.ldc = Nw; gw.ldcin = 0;
+                        gw.c_split_stride = slice; gw.kt_per_split = ktps;
+                        const int rc2 = s3_route ? launch_tile_s3<128, 128, 64, 64, float>(gw, st, S)
+                                                 : launch_tile<128, 128, 64, 64, float>(gw, a_kmajor, b_kmajor, S, st);
+                        if (rc2 != OMLM_OK) return rc2;
+                        const long long quads = (long long)Mt * (Nw / 4);
+                        const int blocks = (int)((quads + 255) / 256 > 4096 ? 4096 : (quads + 255) / 256);
+                        if (out_dtype == 0)
+                            hipLaunchKernelGGL(gemm_tail_reduce_kernel<0>, dim3(blocks), dim3(256), 0, st, g_tail_ws, S, slice, Mt, N, Nw, g2.C, nullptr, ldc, g2.Cin, ldcin);
+                        else if (g2.C_lo)
+                            hipLaunchKernelGGL(gemm_tail_reduce_kernel<2>, dim3(blocks), dim3(256), 0, st, g_tail_ws, S, slice, Mt, N, Nw, g2.C, g2.C_lo, ldc, g2.Cin, ldcin);
+                        else
+                            hipLaunchKernelGGL(gemm_tail_reduce_kernel<1>, dim3(blocks), dim3(256), 0, st, g_tail_ws, S, slice, Mt, N, Nw, g2.C, nullptr, ldc, g2.Cin, ldcin);
+                        return omlm_post_launch("omlm_gemm (tail reduce)");
+                    }
+                }
+            }
             return launch(g2, 128, 128, 1);
         }
     }
     return launch(g, bm, bn, splits);
+}
+
+// Workspace of the peeled tail's deterministic split-K (both copies of the file hold the pointer): `bytes` of device memory on the CURRENT
+// device, kept alive by the caller; NULL / 0 switches the form off.  64 MiB covers the step's shapes.
+#if !OMLM_FP16
+extern "C" int omlm_gemm_set_tail_workspace_h(void* workspace, long long bytes);
+#endif
+extern "C" int OMLM_API(omlm_gemm_set_tail_workspace)(void* workspace, long long bytes) {
+    OMLM_CHECK_ARG((workspace == nullptr) == (bytes == 0) && bytes >= 0 && ((uintptr_t)workspace % 16) == 0, "tail workspace: 16-byte aligned buffer and its size, or NULL / 0");
+    int dev = -1;
+    if (workspace && hipGetDevice(&dev) != hipSuccess) { omlm_set_error("omlm_gemm_set_tail_workspace: no current device"); return OMLM_ERR_LAUNCH; }
+    g_tail_ws = (float*)workspace; g_tail_ws_bytes = bytes; g_tail_ws_dev = dev;
+#if !OMLM_FP16
+    return omlm_gemm_set_tail_workspace_h(workspace, bytes);
+#else
+    return OMLM_OK;
+#endif
 }
 
 // in_dtype / out_dtype: 0 = fp32, 1 = bf16, 2 = fp16 (include/omlm.h).  fp16 operands (with fp32 or fp16 output) are served by the

@@ -540,7 +540,8 @@ def trunk_forward(tr, pw: PreparedWeights, x: torch.Tensor, keymask: Optional[to
         m3 = torch.empty(M, device=dev); r3 = torch.empty(M, device=dev)
         p = float(ff.dropout_p) if training else 0.0
         seed = seeds[li] if (p > 0 and seeds is not None) else 0
-        drop_bits = torch.empty(M, Fp // 8, dtype=torch.uint8, device=dev) if (p > 0 and save) else None
+        # (the plane forward of "fp16ff" exists on the strip kernels only, which hand the keep mask over through drop_bits: present whenever p > 0)
+        drop_bits = torch.empty(M, Fp // 8, dtype=torch.uint8, device=dev) if (p > 0 and (save or pw.ff3)) else None
         # the normalised GEGLU output is saved for the backward: its row-sum prepass reads it instead of recomputing conv + GELU, and
         # the fused second-generation backward (csrc/ffmid2.hip) requires it
         gh = torch.empty(M, Fp, dtype=T, device=dev) if (save and _FF_SAVE_GH) else None

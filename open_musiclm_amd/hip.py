@@ -28,6 +28,7 @@ SIGNATURES = {
     "omlm_gemm_wgrad_group": [vp, i32, i32, i32, vp],
     "omlm_gemm_planes": [vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp],
     "omlm_split_planes": [vp, vp, i64, i64, vp],
+    "omlm_gemm_set_tail_workspace": [vp, i64],
     "omlm_gemm_planes16": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "omlm_layernorm_fwd_planes": [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp],
     "omlm_ffmid_fwd_planes": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, u64, vp, vp, vp, i32, vp],

@@ -85,6 +85,25 @@ def operand_planes(t: torch.Tensor, rows: int, ld: int):
     return buf, pe * 2
 
 
+_TAIL_WS = {}                  # device index -> workspace of the GEMM tails' deterministic split-K (omlm_gemm_set_tail_workspace)
+_TAIL_WS_CURRENT = [None]
+_TAIL_WS_BYTES = int(os.environ.get("OMLM_GEMM_TAIL_WS_MB", "64")) << 20
+
+
+def _ensure_tail_workspace(device: torch.device):
+    """The library keeps ONE (pointer, device) pair: hand it this device's buffer whenever the device of the launches changes."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if _TAIL_WS_CURRENT[0] == idx:
+        return
+    if _TAIL_WS_BYTES > 0:
+        if idx not in _TAIL_WS:
+            if torch.cuda.is_current_stream_capturing():      # never from a graph's private pool: the first eager launch will bring it
+                return
+            _TAIL_WS[idx] = torch.empty(_TAIL_WS_BYTES // 4, device=device)
+        call("omlm_gemm_set_tail_workspace", ptr(_TAIL_WS[idx]), _TAIL_WS_BYTES)
+    _TAIL_WS_CURRENT[0] = idx
+
+
 def gemm(A: torch.Tensor, B: torch.Tensor, C_: torch.Tensor, *, M: int, N: int, K: int,
          lda: Optional[int] = None, ldb: Optional[int] = None, ldc: Optional[int] = None,
          a_kmajor: bool = False, b_kmajor: bool = False, Cin: Optional[torch.Tensor] = None,
@@ -102,6 +121,8 @@ def gemm(A: torch.Tensor, B: torch.Tensor, C_: torch.Tensor, *, M: int, N: int, 
         ldcin = ldcin if ldcin is not None else Cin.shape[-1]
     a_rows = a_rows if a_rows is not None else A.numel() // lda
     b_rows = b_rows if b_rows is not None else B.numel() // ldb
+    if A.dtype in H16:
+        _ensure_tail_workspace(A.device)
     if (A.dtype == torch.float32 and planes and _X3_PLANES and M * N * K >= _X3_MIN_MACS and not (a_kmajor and a_map is not None)
             and not (b_kmajor and b_map is not None) and (a_kmajor and b_kmajor or K % 8 == 0)):
         pa, sa = operand_planes(A, a_rows, lda)
@@ -129,6 +150,7 @@ def gemm_planes16(A, A_lo, B, B_lo, C_, C_lo=None, *, M: int, N: int, K: int, Ci
         assert C_.dtype == A.dtype and C_lo.dtype == A.dtype and C_lo.shape == C_.shape and Cin is None
     lda, ldb = A.shape[-1], B.shape[-1]
     ldc = ldc if ldc is not None else C_.shape[-1]
+    _ensure_tail_workspace(A.device)
     call("omlm_gemm_planes16", ptr(A), ptr(A_lo), ptr(B), ptr(B_lo), ptr(C_), ptr(C_lo), ptr(Cin), ptr(a_map), ptr(c_map),
          a_rows if a_rows is not None else A.numel() // lda, b_rows if b_rows is not None else B.numel() // ldb,
          M, N, K, lda, ldb, ldc, Cin.shape[-1] if Cin is not None else 0, dcode(A.dtype), stream_ptr())

@@ -1452,3 +1452,57 @@ def test_gemm_planes16_with_row_maps(ops, dev, dtype):
     report(f"gemm_planes16_maps[{dtype}]", err=e)
     assert e < (3e-6 if dtype == torch.float16 else 6e-5), e
     assert bool((C[untouched] == 7.0).all()) and bool((C[:, N:] == 7.0).all())
+
+
+@pytest.mark.parametrize("case", ["fp16 B-kmajor 16-bit out", "bf16 fp32 + residual", "fp16 planes -> planes", "fp16 planes -> fp32 + residual"])
+def test_gemm_peeled_tail_as_deterministic_split_k(ops, dev, case, monkeypatch):
+    """The m-tile rows behind the last full round of 256 x 256 tiles (gemm_impl: tail peeling) as a split-K through the workspace + a fixed-order
+    reduction (round 5): equal to the one-launch tail up to the summation order (bar: fp32 accumulation noise; 16-bit outputs equal except where
+    that noise crosses a rounding boundary), bit-reproducible from launch to launch, and inside the fp64 bar of the one-launch form."""
+    g = torch.Generator().manual_seed(17)
+    planes = "planes" in case
+    dtype = torch.bfloat16 if case.startswith("bf16") else torch.float16
+    if case == "fp16 B-kmajor 16-bit out":
+        M, N, K = 17920, 1024, 5504                 # d(xn2)'s form: 280 tiles = 64 m-tile rows + a 1536-row tail, 86 k-tiles
+    elif case == "fp16 planes -> planes":
+        M, N, K = 3428, 5504, 1024                  # 308 tiles: 11 m-tile rows on the ring + a 612-row tail, 48 loop tiles
+    else:
+        M, N, K = 17920, 1024, 2752                 # FF-out's form
+    A32 = torch.randn(M, K, generator=g).to(dev)
+    bk = case == "fp16 B-kmajor 16-bit out"
+    B32 = ((torch.randn(K, N, generator=g) if bk else torch.randn(N, K, generator=g)) * 0.05).to(dev)
+    A, B = A32.to(dtype), B32.to(dtype)
+    Al, Bl = (A32 - A.float()).to(dtype), (B32 - B.float()).to(dtype)
+    Cin = torch.randn(M, N, generator=g).to(dev) if "residual" in case else None
+    out16 = case in ("fp16 B-kmajor 16-bit out", "fp16 planes -> planes")
+
+    def run():
+        C = torch.full((M, N), float("nan"), device=dev, dtype=dtype if out16 else torch.float32)
+        Cl = torch.full((M, N), float("nan"), device=dev, dtype=dtype) if case == "fp16 planes -> planes" else None
+        if planes:
+            ops.gemm_planes16(A, Al, B, Bl, C, Cl, M=M, N=N, K=K, Cin=Cin)
+        else:
+            ops.gemm(A, B, C, M=M, N=N, K=K, b_kmajor=bk, Cin=Cin)
+        return C, Cl
+
+    monkeypatch.setenv("OMLM_GEMM_TAIL_SPLIT", "0")
+    one, one_lo = run()
+    monkeypatch.setenv("OMLM_GEMM_TAIL_SPLIT", "1")
+    two, two_lo = run()
+    again, again_lo = run()
+    assert torch.equal(two, again) and (two_lo is None or torch.equal(two_lo, again_lo))          # deterministic
+    Bm = B.double().t() if not bk else B.double()
+    if planes:
+        ref = (A.double() + Al.double()) @ ((B.double() + Bl.double()).t())
+    else:
+        ref = A.double() @ Bm
+    if Cin is not None:
+        ref = ref + Cin.double()
+    val = (lambda c, l: c.double() + l.double()) if two_lo is not None else (lambda c, l: c.double())
+    e_one, e_two = relerr(val(one, one_lo), ref), relerr(val(two, two_lo), ref)
+    differ = float((one != two).float().mean())
+    head = bool(torch.equal(one[:256], two[:256]))                      # the full-round rows never see the tail's path
+    report(f"gemm_tail_split[{case}]", one_launch=e_one, split=e_two, differing_frac=differ)
+    assert head and e_two <= 1.5 * e_one + 1e-7, (e_one, e_two)
+    assert differ < (0.02 if out16 else 0.6)       # fp32 outputs: the last bit moves with the summation order; 16-bit: only across rounding boundaries
+    assert differ > 0 or M * N == 0               # (the split form did run: some bit of some tail element differs)

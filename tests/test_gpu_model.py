@@ -172,6 +172,30 @@ def test_loss_only_step_skips_zero_weight_heads(golden_dir, dev, monkeypatch):
     loss = float(out[0][0])
 
 
+@pytest.mark.parametrize("precision", ["fp16", "fp16ff"])
+def test_train_mode_forward_without_autograd_keeps_dropout_on(golden_dir, dev, precision):
+    """A train-mode forward under no_grad (validation loops that forget .eval(); the reference applies dropout there too, transformer.py:147):
+    nothing is saved for a backward, FF dropout is still drawn -- fp16 takes the kernels that regenerate the mask, fp16ff (whose plane forward
+    exists on the strip kernels only) hands the mask through keep bits of its own.  The loss moves with the draw and stays finite; with
+    dropout off the call equals the grad-enabled one bit for bit."""
+    from open_musiclm_amd import open_musiclm as M
+    z, model = build_from_golden(golden_dir, "tiny_coarse", dev, precision)
+    wrapper = M.TokenConditionedTransformerWrapper(transformer=model, unique_consecutive=False, cross_entropy_loss_weights=[0, 0, 1], mask_prob=0.0)
+    wrapper.train()
+    ids = [torch.from_numpy(z[f"ids.{i}"]).to(dev) for i in range(3)]
+    loss_g, logits_g, _ = wrapper(all_token_ids=ids, return_loss=True)
+    with torch.no_grad():
+        loss_n, logits_n, _ = wrapper(all_token_ids=ids, return_loss=True)
+    assert torch.equal(logits_g[-1], logits_n[-1]) and float(loss_g) == float(loss_n)       # ff_dropout 0 in the golden model
+    for _, _, ff in model.transformer.layers:
+        ff[ff._idx["dropout"]].p = 0.3
+    with torch.no_grad():
+        a = float(wrapper(all_token_ids=ids, return_loss=True)[0])
+        b = float(wrapper(all_token_ids=ids, return_loss=True)[0])
+    assert np.isfinite(a) and np.isfinite(b) and a != b and a != float(loss_n)              # a new mask per forward
+    assert abs(a - float(loss_n)) < 0.5 * float(loss_n)
+
+
 def test_logits_path_autograd_matches_fused_loss(golden_dir, dev, monkeypatch):
     """TokenConditionedTransformer.forward (logits with grad) + torch CE == the fused loss path."""
     from open_musiclm_amd import open_musiclm as M
