@@ -186,7 +186,8 @@ def test_train_mode_forward_without_autograd_keeps_dropout_on(golden_dir, dev, p
     loss_g, logits_g, _ = wrapper(all_token_ids=ids, return_loss=True)
     with torch.no_grad():
         loss_n, logits_n, _ = wrapper(all_token_ids=ids, return_loss=True)
-    assert torch.equal(logits_g[-1], logits_n[-1]) and float(loss_g) == float(loss_n)       # ff_dropout 0 in the golden model
+    # ff_dropout is 0 in the golden model: same logits bit for bit; the row losses meet in one fp32 atomic sum (order-free to an ulp)
+    assert torch.equal(logits_g[-1], logits_n[-1]) and abs(float(loss_g) - float(loss_n)) <= 2e-6 * abs(float(loss_n))
     for _, _, ff in model.transformer.layers:
         ff[ff._idx["dropout"]].p = 0.3
     with torch.no_grad():
