@@ -33,10 +33,11 @@ REPORT = os.path.join(ROOT, "gpurun_out", "model_report.json")
 #   fp16    logits <= 8.9e-4 at depth 6 (2.0e-3 at depth 24), loss <= 4.3e-5, gradients <= 7.2e-3
 # `invariant`: the analytically-zero gradient directions of the rel-pos bias (see the train test), in the same units.
 TOL = {"bf16x3": dict(logits=1e-3, loss=4e-5, grad=1.5e-2, invariant=1e-2), "bf16": dict(logits=1.2e-2, loss=1e-3, grad=1.5e-1, invariant=1.5),
-       "fp16": dict(logits=1e-3, loss=1e-4, grad=1.5e-2, invariant=0.3),       # invariant: pure rounding noise, 3x its measured size
+       "fp16": dict(logits=1e-3, loss=1e-4, grad=1.5e-2, invariant=0.3),       # invariant: pure rounding noise, 3x its measured size (round 5: <= 0.086; bf16 <= 0.43 against 1.5)
        # "fp16ff" (round 5: the ConvFeedForward forward on hi/lo half planes): VERDICT round 4's bars -- 5e-4 at depth 6, 1e-3 at depth 24 (own bar
        # in the depth-24 test); its backward is fp16's
-       "fp16ff": dict(logits=5e-4, loss=1e-4, grad=1.5e-2, invariant=0.3)}
+       # (gradients measured <= 4.8e-3 over every tensor at full size: bar 1e-2)
+       "fp16ff": dict(logits=5e-4, loss=1e-4, grad=1e-2, invariant=0.3)}
 
 
 def grad_unscale(precision):
@@ -1399,5 +1400,6 @@ def test_full_size_gradients_of_every_parameter_vs_oracle(dev, precision):
     report(f"all_parameter_gradients[{precision}]", tensors=len(errs), zero_grad_tensors=len(zero), worst=worst,
            loss=abs(float(loss) - float(o_loss)) / float(o_loss))
     assert len(errs) + len(zero) == len(pnames) and len(errs) >= 80          # coarse-small: 84 tensors, 2 of them zero-weight heads
-    # bar: 2 x the worst value measured at B = 1 (logit_weights.2: 1.48e-2; every other tensor <= 7.9e-3 -- profiles/r05a_model_report.json)
-    assert worst[0][1] < 3e-2 and worst[1][1] < TOL[precision]["grad"], worst
+    # bar: ~2-3 x the worst values measured at B = 1 in fp16ff (rel-pos MLP weights 4.8e-3 / 4.6e-3, profiles/r05g_model_report.json; in plain fp16 the
+    # head logit_weights.2 led with 1.48e-2 -- its forward now runs on planes)
+    assert worst[0][1] < 1.5e-2 and worst[1][1] < TOL[precision]["grad"], worst
