@@ -411,8 +411,8 @@ def main():
     parity = {"bf16": "logits <= 1.2e-2 rel vs CPU reference (measured 7.1e-3 at B = 2, 7.8e-3 at the benchmarked B = 32; bf16 operands cannot meet 1e-3)",
               "fp16": "logits <= 1e-3 rel vs CPU reference (measured 8.1e-4 .. 9.8e-4 over 5 seeds, 9.1e-4 at the benchmarked B = 32; "
                       "every parameter gradient <= 1.5e-2 of its tensor's max; musiclm_large depth 24: 1.5e-3 .. 1.8e-3, profiles/r05_error_budget.md)",
-              "fp16ff": "logits <= 5e-4 rel vs CPU reference at musiclm_small depth (measured 3.2e-4 .. 3.6e-4 over 5 seeds, 3.6e-4 at the benchmarked "
-                        "B = 32) and <= 1e-3 at musiclm_large depth 24 (4.7e-4 .. 6.3e-4 over 3 seeds); every checked gradient <= 1.5e-2 of its "
+              "fp16ff": "logits <= 5e-4 rel vs CPU reference at musiclm_small depth (measured 1.3e-4 .. 1.8e-4 over 5 seeds, 1.6e-4 at the benchmarked "
+                        "B = 32) and <= 1e-3 at musiclm_large depth 24 (4.6e-4 .. 5.5e-4 over 3 seeds); every checked gradient <= 1.5e-2 of its "
                         "tensor's max (the ConvFeedForward forward on hi/lo half planes, everything else and the backward as fp16)",
               "bf16x3": "logits <= 1e-3 rel vs CPU reference (measured 7.1e-5; 2.9e-4 at musiclm_large depth 24)"}
     out = {
@@ -525,7 +525,7 @@ def main():
             out["legs"]["large_fine"] = {
                 "workload": "musiclm_large fine-stage train step (BASELINE config 4): dim 1024, depth 24, heads 16, N=1817 "
                             "(3 start + 13 clap + 676 coarse + 1125 fine), 5 fine quantizers, forgetful mask, ff_dropout 0.1",
-                "dtype": "fp16ff", "parity": "logits 4.7e-4 .. 6.3e-4 vs CPU reference over 3 seeds at this depth (profiles/r05_seed_sweep.md; fp16 1.6e-3, bf16 1.3e-2)",
+                "dtype": "fp16ff", "parity": "logits 4.6e-4 .. 5.5e-4 vs CPU reference over 3 seeds at this depth (profiles/r05_seed_sweep.md; fp16 1.6e-3, bf16 1.3e-2)",
                 "per_gpu_batch": Bl, "value": round(Bl * k / dtl, 3), "unit": "samples/s", "steps": k,
                 "warmup": w, "ms_per_step": round(1e3 * dtl / k, 3), "bf16_ms_per_step": round(1e3 * dtb / k, 3), "model_tflops_per_gpu": round(tfl, 2),
                 "model_flops_frac_of_bf16_peak": round(tfl / PEAK_TFLOPS, 4), "final_loss": round(lossl, 4),
