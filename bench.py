@@ -12,10 +12,10 @@ are synthetic (seeded U{0..1023}) and already resident in HBM when the timed reg
 reference's random init (no checkpoints offline).  For N > 1 launch with torch.distributed.run (one rank per GPU).
 
 `value` = whole-job training samples/s (global batch * steps / s, max over ranks) of BASELINE config 2 in precision "fp16ff" since
-round 5: IEEE-half operands everywhere, with the forward of the two ConvFeedForward linears on hi/lo half planes (three products; they carry
-86-88 % of the fp16 logits-error variance) -- the mode whose logits meet north_star's 1e-3 against the CPU reference WITH MARGIN at both
-model depths (3.2e-4 .. 3.6e-4 over 5 seeds at this model, 3.6e-4 at the benchmarked batch; 4.7e-4 .. 6.3e-4 at musiclm_large depth 24), at
-1.28x the fp16 step.  Plain fp16 measures 8.7e-4 .. 9.8e-4 here (inside 1e-3 by a few per cent) and 1.6e-3 at depth 24; bf16, the dtype the
+round 5: IEEE-half operands everywhere, with the forward of the two ConvFeedForward linears and of the logit heads on hi/lo half planes (three
+products; the two linears carry 86-88 % of the fp16 logits-error variance) -- the mode whose logits meet north_star's 1e-3 against the CPU reference
+WITH MARGIN at both model depths (1.3e-4 .. 1.8e-4 over 5 seeds at this model, 1.6e-4 at the benchmarked batch; 4.6e-4 .. 5.5e-4 at musiclm_large
+depth 24), at 1.3x the fp16 step.  Plain fp16 measures 8.7e-4 .. 9.8e-4 here (inside 1e-3 by a few per cent) and 1.6e-3 at depth 24; bf16, the dtype the
 config names, 7e-3 .. 8e-3.  At N = 1 the same JSON line carries, under "legs", the other modes and configurations of BASELINE.json measured
 in the same run:
   legs.fp16         the same train step in plain fp16 (logits 8.7e-4 .. 9.8e-4: inside the tolerance at this depth, without margin)
