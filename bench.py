@@ -210,7 +210,12 @@ class TrainLeg:
                 "achieved": round(ach, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS, 4),
                 "traffic": traffic, "launches": len(rec) // 2, "gemm_ms_per_step": round(tot_ms / 2, 3),
                 "mfma_issue_frac": round(issued_fl / (tot_ms * 1e-3) / 1e12 / PEAK_TFLOPS, 4),
-                "large_gemm_achieved": round(sum(f for _, f in big) / (sum(t for t, _ in big) * 1e-3) / 1e12, 2) if big else None}
+                "large_gemm_achieved": round(sum(f for _, f in big) / (sum(t for t, _ in big) * 1e-3) / 1e12, 2) if big else None,
+                "single_product_achieved": (round(sum(r[2] for r in rec if len(r) <= 4) / (sum(r[0].elapsed_time(r[1]) for r in rec if len(r) <= 4) * 1e-3) / 1e12, 2)
+                                            if any(len(r) > 4 for r in rec) else None),
+                "note": ("achieved / frac count ALGORITHMIC flops (2 M N K per linear); the hi/lo-plane launches of fp16ff (FF-in, FF-out, heads forward) issue three "
+                         "products each: mfma_issue_frac counts those; single_product_achieved = every other GEMM launch of the step")
+                        if any(len(r) > 4 for r in rec) else "achieved / frac count algorithmic flops (2 M N K per linear)"}
 
     def free(self):
         self.fb = self.model = self.stage = self.optim = self.batches = None
