@@ -413,7 +413,9 @@ struct h16pl_t { h16_t v; };
 // scatters (measured: ~480 of 650 us of the FF-in GEMM).  Each 32-row strip of the wave's tile is therefore transposed
 // through a per-wave LDS patch (the k-loop stages are dead: the caller has passed a barrier) and written as 16-byte
 // row-contiguous stores: 8 bf16 / 4 fp32 per lane, full 128-byte lines per row.
-template <int MI, int NJ, int WN_, typename TOUT, int EPI = 0, bool AHEAD = (OMLM_EPI_CIN_AHEAD != 0) && (MI * NJ <= 4)>
+// SLICE: the instantiation may be launched as the slice-storing split-K of a peeled tail (GemmArgs::c_split_stride; 128 x 128 fp32-output kernels
+// only -- every other kernel keeps the code and registers it was measured with)
+template <int MI, int NJ, int WN_, typename TOUT, int EPI = 0, bool AHEAD = (OMLM_EPI_CIN_AHEAD != 0) && (MI * NJ <= 4), bool SLICE = false>
 __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16 (&acc)[MI][NJ], char* smem, int m0, int n0,
                                               int wm, int wn, int wave, int lane, int dbg, bool split, float* patch = nullptr, int ksplit = 0) {
     constexpr int SROW = WN_ + 4;                                  // padded row (floats), keeps 16-B alignment
@@ -441,7 +443,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16 (&acc)[M
                 for (int j = 0; j < NJ; ++j) {
                     const int col = n0 + wn + 32 * j + (lane & 31);
                     if (col >= g.N) continue;
-                    if (g.c_split_stride) ((float*)g.C + (long long)ksplit * g.c_split_stride)[prow * g.ldc + col] = g.alpha * acc[i][j][e];
+                    if (SLICE && g.c_split_stride) ((float*)g.C + (long long)ksplit * g.c_split_stride)[prow * g.ldc + col] = g.alpha * acc[i][j][e];
                     else unsafeAtomicAdd((float*)g.C + prow * g.ldc + col, g.alpha * acc[i][j][e]);
                 }
             }
@@ -767,7 +769,9 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, const int lg, 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         __syncthreads();
-        tile_epilogue<MI, NJ, WN_, TOUT, EPI>(g, acc, smem, m0, n0, wm, wn, wave, lane, dbg, bal || split, nullptr, ksplit_id);
+        constexpr bool SLICE = BM_ == 128 && BN_ == 128 && std::is_same<TOUT, float>::value && !BAL && EPI == 0;
+        tile_epilogue<MI, NJ, WN_, TOUT, EPI, (OMLM_EPI_CIN_AHEAD != 0) && (MI * NJ <= 4), SLICE>(g, acc, smem, m0, n0, wm, wn, wave, lane, dbg, bal || split, nullptr,
+                                                                                                   SLICE ? ksplit_id : 0);
         if (!bal || u >= u1) break;
         __syncthreads();              // the non-split epilogue stages through LDS; the next segment's DMA must not overtake it
     }
@@ -1216,6 +1220,8 @@ template __global__ void gemm_tile8_kernel<false, false, h16_t>(GemmArgs);
 template __global__ void gemm_tile8_kernel<false, true, h16_t>(GemmArgs);
 template __global__ void gemm_tile8_kernel<false, false, float>(GemmArgs);
 template __global__ void gemm_tile8_kernel<true, true, float>(GemmArgs);
+template __global__ void gemm_tile8_kernel<false, false, h16pl_t, true>(GemmArgs);      // the plane route of fp16ff: 3 products, planes out / fp32 out
+template __global__ void gemm_tile8_kernel<false, false, float, true>(GemmArgs);
 }   // namespace
 #else
 // workgroups of the persistent walk: one per CU, rounded down to a multiple of 8 (the walk's stride must keep a workgroup on its XCD);

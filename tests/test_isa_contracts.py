@@ -109,3 +109,23 @@ def test_qknorm_backward_requests_a_whole_trip_before_its_first_wait(tmp_path):
         elif vmcnt(l) is not None:
             break
     assert n == 8, f"{n} requests before the first wait of the q stream's loop (two units x y, dy, dy, norm = 8)"
+
+
+def test_plane_route_ring_kernel_fits_and_keeps_its_dma_offsets_scalar(tmp_path):
+    """The 3-product half-tile-ring kernel of precision fp16ff (gemm_tile8_kernel<.., SPLIT3>, fp16 copy): hipcc moves the plane arithmetic of
+    the k-tile index to the VALU, and the LDS-DMA's offset operand must be an SGPR (the source forces it back with readfirstlane; a VGPR there
+    does not assemble).  Pinned: both instantiations build without spills inside 256 VGPRs, the k-loop holds three products' worth of matrix
+    instructions per accumulator set, and the plane-output epilogue stores twice the 16-byte pieces of the fp32 one's 16-bit twin."""
+    lines = compile_asm(tmp_path, "gemm.hip", "-DOMLM_ISA_ONLY", "-DOMLM_FP16=1")
+    planes, meta = kernel_body(lines, r"gemm_tile8_kernelILb0ELb0ENS_7h16pl_tELb1E")
+    assert meta["vgpr_spill_count"] == 0 and meta["sgpr_spill_count"] == 0 and meta["vgpr_count"] <= 256, meta
+    f32, meta2 = kernel_body(lines, r"gemm_tile8_kernelILb0ELb0EfLb1E")
+    assert meta2["vgpr_spill_count"] == 0 and meta2["vgpr_count"] <= 256, meta2
+    single, _ = kernel_body(lines, r"gemm_tile8_kernelILb0ELb0EDF16_Lb0E")
+    for body in (planes, f32):
+        dma = [l for l in body if "buffer_load_dwordx4" in l and " lds" in l]
+        assert len(dma) >= 16 and all(re.search(r"s\[\d+:\d+\],\s*s\d+\s+offen", l) for l in dma), dma[:3]      # descriptor and offset both scalar
+        assert any("v_readfirstlane_b32" in l for l in body)
+        assert sum(1 for l in body if "v_mfma_f32_32x32x16_f16" in l) == sum(1 for l in single if "v_mfma_f32_32x32x16_f16" in l)   # same loop body, 3 x the trips
+    st = lambda body: sum(1 for l in body if "global_store_dwordx4" in l)
+    assert st(planes) == 2 * st(single), (st(planes), st(single))
