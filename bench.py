@@ -44,8 +44,10 @@ HBM_ACHIEVABLE_TBS = 6.3                                # measured streaming rat
 P_LIN = {8: 9_566_208, 16: 10_614_784}                  # linear MACs / token / layer by head count
 
 
-def algorithmic_flops_per_sample(N=N_SEQ, L=6, h=8, dh=64, n_out=1114):
-    """F_fwd = 2 [L (N P_lin + h dh N (N + 1)) + N_out 1,049,600]; fwd + bwd = 3 F_fwd."""
+def algorithmic_flops_per_sample(N=N_SEQ, L=6, h=8, dh=64, n_out=901):
+    """F_fwd = 2 [L (N P_lin + h dh N (N + 1)) + N_out 1,049,600]; fwd + bwd = 3 F_fwd.  N_out counts the logit rows the
+    timed step COMPUTES: the trainers' call (return_logits=False) evaluates only the heads of sequences with a loss weight -- the predicted
+    sequence's 1 + 900 rows of the 1114 (the two conditioning sequences' zero-weight heads add nothing to loss or gradients and are skipped)."""
     fwd = 2 * (L * (N * P_LIN[h] + h * dh * N * (N + 1)) + n_out * 1_049_600)
     return 3 * fwd
 
@@ -307,16 +309,16 @@ def decode_leg(stage, dev, decode_ids):
     return res
 
 
-def e2e_generate_leg(dev, seconds=10, batch=1):
+def e2e_generate_leg(dev, seconds=10, batch=1, precision="fp16ff"):
     """BASELINE config 5: MusicLM.generate for `seconds` of audio with the three musiclm_small stages (random init) --
     seeded synthetic 512-d conditioning embedding -> RVQ kernel (12 x 1024 x 512 seeded codebooks) -> semantic (50 Hz) ->
     coarse (75 Hz x 3) -> fine (75 Hz x 5) sliding-window AR decode.  Encodec / CLAP towers are outside the path (weights
     unobtainable offline): the rate covers the AR stack + RVQ only.  Floor: every sampled id streams its stage's trunk + one
-    head once (bf16)."""
+    head once (16-bit weights; the headline precision fp16ff additionally streams the lo planes of the FF-in / FF-out / head weights)."""
     from open_musiclm_amd import open_musiclm as M
     from open_musiclm_amd.clap_quantized import ClapQuantized
     torch.manual_seed(0)
-    kw = dict(dim=1024, depth=6, heads=8, precision="bf16")
+    kw = dict(dim=1024, depth=6, heads=8, precision=precision)
     sem = M.create_semantic_transformer(**kw).to(dev)
     coarse = M.create_coarse_transformer(num_coarse_quantizers=3, **kw).to(dev)
     fine = M.create_fine_transformer(num_coarse_quantizers=3, num_fine_quantizers=5, **kw).to(dev)
@@ -339,15 +341,18 @@ def e2e_generate_leg(dev, seconds=10, batch=1):
     assert s.shape[0] == batch
     n_steps = s.shape[1] + c.shape[1] * c.shape[2] + f.shape[1] * f.shape[2]      # decode steps = ids per prompt
     n_ids = n_steps * batch
-    trunk_bytes = 58.06e6 * 2 + 1025 * 1024 * 2            # bf16 trunk + one logit head per decode step
+    trunk_bytes = 58.06e6 * 2 + 1025 * 1024 * 2            # 16-bit trunk + one logit head per decode step
+    if precision == "fp16ff":                              # + the lo planes of W1 / W2 (6 x 8.39 M entries) and of the head
+        trunk_bytes += 6 * 8_386_560 * 2 + 1025 * 1024 * 2
     floor_s = n_steps * trunk_bytes / (HBM_ACHIEVABLE_TBS * 1e12)
-    return {"workload": f"MusicLM.generate output_seconds={seconds}, musiclm_small stages, B={batch}, bf16, KV-cached windows",
+    return {"workload": f"MusicLM.generate output_seconds={seconds}, musiclm_small stages, B={batch}, {precision}, KV-cached windows",
+            "precision": precision,
             "batch": batch, "sampled_ids": int(n_ids),
             "ids_per_prompt": {"semantic": int(s.shape[1]), "coarse": int(c.shape[1] * c.shape[2]), "fine": int(f.shape[1] * f.shape[2])},
             "seconds": round(dt, 3), "ids_per_sec": round(n_ids / dt, 1), "audio_seconds_per_sec": round(batch * seconds / dt, 4),
             "roofline": {"bound": "hbm", "achieved": round(n_steps * trunk_bytes / dt / 1e9, 1), "peak": HBM_ACHIEVABLE_TBS * 1e3,
                          "unit": "GB/s", "frac": round(floor_s / dt, 4),
-                         "note": "weight-streaming floor: bf16 trunk + one head per decode step (a step serves the whole batch) over the achievable 6.3 TB/s"}}
+                         "note": "weight-streaming floor: the 16-bit trunk (+ the lo planes fp16ff reads) + one head per decode step (a step serves the whole batch) over the achievable 6.3 TB/s"}}
 
 
 def main():
@@ -478,6 +483,8 @@ def main():
         progress(f"roofline probe: {out['roofline']['launches']} GEMM launches, {out['roofline']['gemm_ms_per_step']} ms per step")
         if not args.no_decode:
             out["ar_tokens_per_sec"] = decode_leg(main_leg.stage, dev, args.decode_ids)
+            out["ar_tokens_per_sec"]["precision"] = args.precision + (" (cached steps: FF-in / FF-out / head on hi + lo weight planes, activations un-rounded)"
+                                                                       if args.precision == "fp16ff" else "")
             progress(f"decode {out['ar_tokens_per_sec']}")
         if cpu is not None:
             out["cpu_baseline"] = cpu
@@ -525,7 +532,7 @@ def main():
             leg = TrainLeg(dev, dp, stage="fine", dim=1024, depth=24, heads=16, precision="fp16ff", batch=Bl, accum=1,
                            use_graph=not args.no_graph, ds_kwargs=dict(fine_window_seconds=3))
             dtl, lossl = leg.timed(k, w)
-            fl = algorithmic_flops_per_sample(N=1817, L=24, h=16, n_out=1815) * Bl
+            fl = algorithmic_flops_per_sample(N=1817, L=24, h=16, n_out=1126) * Bl
             tfl = fl / (dtl / k) / 1e12
             out["legs"]["large_fine"] = {
                 "workload": "musiclm_large fine-stage train step (BASELINE config 4): dim 1024, depth 24, heads 16, N=1817 "
@@ -539,12 +546,15 @@ def main():
             progress(f"large_fine leg: {out['legs']['large_fine']['ms_per_step']} ms/step, {out['legs']['large_fine']['peak_hbm_gb']} GB")
             leg.free()
         if "e2e_generate" in legs:
-            out["legs"]["e2e_generate"] = e2e_generate_leg(dev)
+            out["legs"]["e2e_generate"] = e2e_generate_leg(dev, precision=args.precision)
             progress(f"e2e generate leg: {out['legs']['e2e_generate']['ids_per_sec']} ids/s")
-            out["legs"]["e2e_generate_b8"] = e2e_generate_leg(dev, batch=8)
+            out["legs"]["e2e_generate_b8"] = e2e_generate_leg(dev, batch=8, precision=args.precision)
             progress(f"e2e generate leg, 8 prompts: {out['legs']['e2e_generate_b8']['ids_per_sec']} ids/s")
-            out["legs"]["e2e_generate_b16"] = e2e_generate_leg(dev, batch=16)
+            out["legs"]["e2e_generate_b16"] = e2e_generate_leg(dev, batch=16, precision=args.precision)
             progress(f"e2e generate leg, 16 prompts: {out['legs']['e2e_generate_b16']['ids_per_sec']} ids/s")
+            if args.precision != "bf16":                   # the dtype BASELINE config 5's sibling configs name, for comparison (outside the tolerance)
+                out["legs"]["e2e_generate_bf16"] = e2e_generate_leg(dev, precision="bf16")
+                progress(f"e2e generate leg, bf16: {out['legs']['e2e_generate_bf16']['ids_per_sec']} ids/s")
         print(json.dumps(out), flush=True)
     dp.barrier()
     dp.shutdown()

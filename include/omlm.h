@@ -333,6 +333,11 @@ typedef struct omlm_decode_args {
                                             * (2 <= B <= 8) leave per-workgroup partial sums of their outputs there, and the kernel that
                                             * applies the next LayerNorm adds them up instead of re-reducing every sample's row; null:
                                             * every consumer reduces the rows itself */
+    /* precision "fp16ff" (optional; all NULL: the plain 16-bit step): lo planes of the FF-in / FF-out / head weights in the layout of
+     * W1p / W2p / head_W.  With them those three launches read W = hi + lo and keep LayerNorm outputs and h1 un-rounded -- the arithmetic of
+     * the batched forward's omlm_gemm_planes16 (open_musiclm.py:299-319 evaluated fp32-grade where the error budget puts the error).
+     * B >= 2: needs the matrix-core kernels (16-bit weights, D = 1024, ln_parts given, L >= 1), Fp <= 3072. */
+    const void* const* W1p_lo; const void* const* W2p_lo; const void* head_W_lo;
 } omlm_decode_args;
 #define OMLM_DECODE_LN_PARTS(D, Fp) ((((D) + 15) / 16 > ((Fp) + 7) / 8 ? ((D) + 15) / 16 : ((Fp) + 7) / 8) * 32)
 int omlm_decode_step(const omlm_decode_args* args, const long long* ids, void* stream);

@@ -53,6 +53,9 @@ struct omlm_decode_args {
     float* x; float* x1; float* q; float* parts; float* u; float* logits;
     int* advance_pos; int* advance_step;
     float* ln_parts;
+    // precision "fp16ff": lo planes of the FF-in / FF-out / head weights (W = hi + lo, fp32-grade); with them the three launches keep their
+    // activation rows and h1 un-rounded, like the three-product forward of the batched path (W1p_lo == NULL: plain 16-bit step)
+    const void* const* W1p_lo; const void* const* W2p_lo; const void* head_W_lo;
 };
 
 __device__ __forceinline__ float round_if(float v, int on) { return on ? (float)(h16_t)v : v; }
@@ -69,8 +72,10 @@ __device__ __forceinline__ void load_w8(const h16_t* p, float* w) {
 
 // vals[r * DEC_BMAX + b] = sum_k W[r, k] * xs[b * Kp + k]  for r < nrows <= 16 (weight rows of pitch ldw), b < B.
 // Each wave owns 4 rows (4 independent load streams per lane); a lane owns the 8-element chunks lane, lane+64, ...
+// Wlo (optional, uniform): the weights' lo plane -- the row is W + Wlo, summed in fp32
 template <typename TW>
-__device__ void wg_gemv(const TW* __restrict__ W, long long ldw, int K, int nrows, const float* xs, int Kp, int B, float* vals) {
+__device__ void wg_gemv(const TW* __restrict__ W, long long ldw, int K, int nrows, const float* xs, int Kp, int B, float* vals,
+                        const TW* __restrict__ Wlo = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = K >> 3;
     const int r0 = wave * 4;
@@ -83,11 +88,23 @@ __device__ void wg_gemv(const TW* __restrict__ W, long long ldw, int K, int nrow
     const TW* wr[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) wr[i] = W + (long long)min(r0 + i, nrows - 1) * ldw;     // clamped rows are dropped below
+    const TW* wrl[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wrl[i] = (Wlo ? Wlo : W) + (long long)min(r0 + i, nrows - 1) * ldw;
 #pragma unroll 2
     for (int c = lane; c < nch; c += 64) {
         float w[4][8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) load_w8(wr[i] + c * 8, w[i]);
+        if (Wlo) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float wl[8];
+                load_w8(wrl[i] + c * 8, wl);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) w[i][e] += wl[e];
+            }
+        }
 #pragma unroll
         for (int b = 0; b < DEC_BMAX; ++b) {
             if (b < B) {
@@ -376,7 +393,8 @@ __global__ __launch_bounds__(DEC_T) void dec_gemv_kernel(const float* __restrict
                                                         int Kstat, float eps, const float* __restrict__ parts, int nsplit, int H,
                                                         const int* __restrict__ pos_dev, const TW* __restrict__ W, long long ldw,
                                                         int K, int Nout, const float* __restrict__ res, int ldres,
-                                                        float* __restrict__ out, int ldout, int B, int round_bf16) {
+                                                        float* __restrict__ out, int ldout, int B, int round_bf16,
+                                                        const TW* __restrict__ Wlo = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float dsm[];
     float* xs = dsm;
     float* vals = xs + (size_t)B * K;
@@ -385,7 +403,7 @@ __global__ __launch_bounds__(DEC_T) void dec_gemv_kernel(const float* __restrict
     else stage_activation(in, ldin, K, Kstat, gamma, eps, B, round_bf16, xs, red);
     const int n0 = blockIdx.x * DEC_ROWS;
     const int rows = min(DEC_ROWS, Nout - n0);
-    wg_gemv<TW>(W + (size_t)n0 * ldw, ldw, K, rows, xs, K, B, vals);
+    wg_gemv<TW>(W + (size_t)n0 * ldw, ldw, K, rows, xs, K, B, vals, Wlo ? Wlo + (size_t)n0 * ldw : nullptr);
     __syncthreads();
     for (int idx = threadIdx.x; idx < B * rows; idx += DEC_T) {
         const int b = idx / rows, r = idx - b * rows;
@@ -409,7 +427,7 @@ template <typename TW>
 __global__ __launch_bounds__(DEC_T) void dec_ffin_kernel(const float* __restrict__ x1, const float* __restrict__ gamma,
                                                         const TW* __restrict__ W1p, const float* __restrict__ convw,
                                                         float* __restrict__ hist, float* __restrict__ u,
-                                                        int B, int D, int Fp, float eps, int round_bf16) {
+                                                        int B, int D, int Fp, float eps, int round_bf16, const TW* __restrict__ W1lo = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float dsm[];
     float* xs = dsm;
     float* vals = xs + (size_t)B * D;
@@ -419,8 +437,8 @@ __global__ __launch_bounds__(DEC_T) void dec_ffin_kernel(const float* __restrict
     // waves 0,1 -> the 8 value rows, waves 2,3 -> the 8 gate rows
     const int wave = threadIdx.x >> 6;
     {
-        const TW* W = W1p + (size_t)((wave < 2 ? c0 : Fp + c0 - 8)) * D;   // row r of this call = W[r]: gate rows start at r = 8
-        wg_gemv<TW>(W, D, D, DEC_ROWS, xs, D, B, vals);
+        const size_t roff = (size_t)((wave < 2 ? c0 : Fp + c0 - 8)) * D;      // row r of this call = W[r]: gate rows start at r = 8
+        wg_gemv<TW>(W1p + roff, D, D, DEC_ROWS, xs, D, B, vals, W1lo ? W1lo + roff : nullptr);
     }
     __syncthreads();
     const int ld = 2 * Fp;
@@ -526,6 +544,7 @@ struct dec2_args {
     const float* in; int ldin; int K, Kstat; const float* gamma; float eps;       // activation (+ LayerNorm over Kstat when gamma)
     const float* parts; int nsplit, H; const int* pos_dev;                        // DEC2_OUT: attention partials instead
     const void* W; const void* W2; long long ldw; int Nout;                       // weight rows (W2: the Wkv rows of DEC2_QKV)
+    const void* Wlo;                                                              // PL instantiations ("fp16ff"): lo plane of W, same layout -- the row is W + Wlo
     const float* res; int ldres; float* out; int ldout;                           // out = dot (+ res)
     float* q; float* Kc; float* Vc; int Nmax;                                     // DEC2_QKV destinations
     const float* convw; float* hist; float* u; int Fp;                            // DEC2_FFIN
@@ -668,7 +687,7 @@ static void dec2_launch(const dec2_args& a, int grid, hipStream_t st) {
 // one memory round trip between launch and store.  FF-in: a wave owns one CHANNEL (its value row and its gate row), so the
 // conv / GEGLU epilogue needs no exchange either.
 
-template <typename TW, int NI, int MODE>
+template <typename TW, int NI, int MODE, bool PL = false>
 __global__ __launch_bounds__(DEC_T) void dec3_kernel(dec2_args a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int K = a.K, nch = K >> 3;
@@ -681,7 +700,8 @@ __global__ __launch_bounds__(DEC_T) void dec3_kernel(dec2_args a) {
     if (MODE == DEC2_FFIN) { wrow = (const TW*)a.W + (size_t)unit * a.ldw; wrow2 = (const TW*)a.W + (size_t)(a.Fp + unit) * a.ldw; }
     else if (MODE == DEC2_QKV) { ln_row = unit < HD; wrow = unit < HD ? (const TW*)a.W + (size_t)unit * a.ldw : (const TW*)a.W2 + (size_t)(unit - HD) * a.ldw; }
     else wrow = (const TW*)a.W + (size_t)unit * a.ldw;
-    dec_wreg<TW> wr[NI], wr2[MODE == DEC2_FFIN ? NI : 1];
+    static_assert(!PL || MODE == DEC2_LNGEMV, "lo planes: the LayerNorm + row-product launches (FF-out, head); FF-in has dec3_ffin_kernel");
+    dec_wreg<TW> wr[NI], wr2[MODE == DEC2_FFIN ? NI : 1], wl[PL ? NI : 1];
     float4 g0[NI], g1[NI], x0[NI], x1[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -689,6 +709,7 @@ __global__ __launch_bounds__(DEC_T) void dec3_kernel(dec2_args a) {
         const bool ok = c < nch;
         const int cc = ok ? c : 0;
         wr[i].load(wrow + cc * 8);
+        if (PL) { wl[i].load((const TW*)a.Wlo + (size_t)unit * a.ldw + cc * 8); if (!ok) wl[i].zero(); }
         if (MODE == DEC2_FFIN) wr2[i].load(wrow2 + cc * 8);
         x0[i] = *(const float4*)(a.in + cc * 8); x1[i] = *(const float4*)(a.in + cc * 8 + 4);
         if (a.gamma) { g0[i] = *(const float4*)(a.gamma + cc * 8); g1[i] = *(const float4*)(a.gamma + cc * 8 + 4); }
@@ -727,6 +748,12 @@ __global__ __launch_bounds__(DEC_T) void dec3_kernel(dec2_args a) {
     for (int i = 0; i < NI; ++i) {
         float w[8], w2[8];
         wr[i].unpack(w);
+        if (PL) {
+            float wlo[8];
+            wl[i].unpack(wlo);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[e] += wlo[e];
+        }
         if (MODE == DEC2_FFIN) wr2[i].unpack(w2);
         float x[8] = {x0[i].x, x0[i].y, x0[i].z, x0[i].w, x1[i].x, x1[i].y, x1[i].z, x1[i].w};
         if (ln_row) {
@@ -764,14 +791,14 @@ __global__ __launch_bounds__(DEC_T) void dec3_kernel(dec2_args a) {
 
 // FF-in rows for B == 1 with CPW channels per wave: the wave's copy of LN(x1) (registers) is multiplied into 2 CPW weight rows, so the
 // L2 traffic of the activation / gamma reloads drops from 2x the weight bytes (one channel per wave) to 0.5x.
-template <typename TW, int CPW>
+template <typename TW, int CPW, bool PL = false>
 __global__ __launch_bounds__(DEC_T) void dec3_ffin_kernel(dec2_args a) {
     constexpr int NI = 2;                              // D = 1024: two 8-element pieces per lane
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c0 = (blockIdx.x * 4 + wave) * CPW;      // first channel of this wave
     if (c0 >= a.Fp) return;
     const int ld = 2 * a.Fp;
-    dec_wreg<TW> wv[CPW][NI], wg[CPW][NI];
+    dec_wreg<TW> wv[CPW][NI], wg[CPW][NI], wvl[PL ? CPW : 1][NI], wgl[PL ? CPW : 1][NI];
     float4 g0[NI], g1[NI], x0[NI], x1[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -781,6 +808,10 @@ __global__ __launch_bounds__(DEC_T) void dec3_ffin_kernel(dec2_args a) {
             const int cc = min(c0 + ch, a.Fp - 1);
             wv[ch][i].load((const TW*)a.W + (size_t)cc * a.ldw + c * 8);
             wg[ch][i].load((const TW*)a.W + (size_t)(a.Fp + cc) * a.ldw + c * 8);
+            if (PL) {
+                wvl[ch][i].load((const TW*)a.Wlo + (size_t)cc * a.ldw + c * 8);
+                wgl[ch][i].load((const TW*)a.Wlo + (size_t)(a.Fp + cc) * a.ldw + c * 8);
+            }
         }
         x0[i] = *(const float4*)(a.in + c * 8); x1[i] = *(const float4*)(a.in + c * 8 + 4);
         g0[i] = *(const float4*)(a.gamma + c * 8); g1[i] = *(const float4*)(a.gamma + c * 8 + 4);
@@ -817,6 +848,12 @@ __global__ __launch_bounds__(DEC_T) void dec3_ffin_kernel(dec2_args a) {
         for (int ch = 0; ch < CPW; ++ch) {
             float w[8], w2[8];
             wv[ch][i].unpack(w); wg[ch][i].unpack(w2);
+            if (PL) {
+                float l1[8], l2[8];
+                wvl[ch][i].unpack(l1); wgl[ch][i].unpack(l2);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { w[e] += l1[e]; w2[e] += l2[e]; }
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) { accv[ch] += w[e] * x[e]; accg[ch] += w2[e] * x[e]; }
         }
@@ -877,12 +914,17 @@ __global__ __launch_bounds__(64) void dec_attn_combine_kernel(const float* __res
     out[((size_t)b * H + h) * 64 + d] = round_if(o / l, round_bf16);
 }
 
-template <int NS, int MODE>
+// PL ("fp16ff": FF-in, FF-out, head): the weights are hi + lo planes and the normalised activations keep a lo image next to the hi one -- three
+// MFMAs per k-step (hi hi + hi lo + lo hi, the batched forward's omlm_gemm_planes16 arithmetic).  The images hold DEC4_IMG(NS) samples; a
+// larger batch (FF-out rows at B > 8) runs its k-loop twice.  Needs the producers' LayerNorm partials (stat_in).
+#define DEC4_IMG(NS) ((((NS) + 7) / 8) == 1 ? 16 : 8)
+template <int NS, int MODE, bool PL = false>
 __global__ __launch_bounds__(DEC4_T) void dec4_kernel(dec2_args a) {
     extern __shared__ __attribute__((aligned(16))) char dsm4[];
     const int B = a.B, K = a.K, KP = K + 8;
-    h16_t* xs = (h16_t*)dsm4;                                   // [B][KP] operand image
-    float* red = (float*)(dsm4 + (((size_t)B * KP * 2 + 15) & ~(size_t)15));   // [DEC4_NB][4][2]
+    h16_t* xs = (h16_t*)dsm4;                                   // [B][KP] operand image (PL: [DEC4_IMG][KP] hi, then the lo image)
+    h16_t* xs_lo = xs + (size_t)DEC4_IMG(NS) * KP;
+    float* red = (float*)(dsm4 + (((size_t)(PL ? 2 * DEC4_IMG(NS) : B) * KP * 2 + 15) & ~(size_t)15));   // [DEC4_NB][4][2]
     float* stat = red + DEC4_NB * 8;                            // [DEC4_NB][2]
     float* part = stat + DEC4_NB * 2;                           // [4][16][16]
     float* vals = part + 4 * 256;                               // [16 rows][16 samples]
@@ -908,13 +950,40 @@ __global__ __launch_bounds__(DEC4_T) void dec4_kernel(dec2_args a) {
         wrow = (const h16_t*)a.W + (size_t)min(grow, a.Nout - 1) * a.ldw;
     }
     const int S = K >> 5;                                       // 32-wide k-steps (K is a multiple of 32)
-    u32x4 wr[NS];
+    u32x4 wr[NS], wl[PL ? NS : 1];
+    static_assert(!PL || MODE == DEC2_FFIN || MODE == DEC2_LNGEMV, "lo planes: FF-in, FF-out, head");
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
         const int s = wave + 4 * j;
         if (s < S) wr[j] = *(const u32x4*)(wrow + 32 * s + 8 * kq);
         else { wr[j][0] = 0u; wr[j][1] = 0u; wr[j][2] = 0u; wr[j][3] = 0u; }
+        if constexpr (PL) {
+            const h16_t* wlrow = (const h16_t*)a.Wlo + (wrow - (const h16_t*)a.W);
+            if (s < S) wl[j] = *(const u32x4*)(wlrow + 32 * s + 8 * kq);
+            else { wl[j][0] = 0u; wl[j][1] = 0u; wl[j][2] = 0u; wl[j][3] = 0u; }
+        }
     }
+    // the k-loop: one MFMA per 32-wide step (PL: three); samples >= nhave are zero operands
+    auto kloop = [&](dec4_acc& acc, const int nhave) {
+        const bool have = r < nhave;                            // this lane's B-operand column is a real sample
+        const h16_t* xrow = xs + (size_t)(have ? r : 0) * KP + 8 * kq;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const int s = wave + 4 * j;
+            if (s < S) {
+                u32x4 xb = {0u, 0u, 0u, 0u};
+                if (have) xb = *(const u32x4*)(xrow + 32 * s);
+                acc = OMLM_MFMA_16x16x32(__builtin_bit_cast(h16x8, wr[j]), __builtin_bit_cast(h16x8, xb), acc);
+                if constexpr (PL) {
+                    u32x4 xl = {0u, 0u, 0u, 0u};
+                    if (have) xl = *(const u32x4*)(xrow + (size_t)DEC4_IMG(NS) * KP + 32 * s);
+                    acc = OMLM_MFMA_16x16x32(__builtin_bit_cast(h16x8, wr[j]), __builtin_bit_cast(h16x8, xl), acc);
+                    acc = OMLM_MFMA_16x16x32(__builtin_bit_cast(h16x8, wl[j]), __builtin_bit_cast(h16x8, xb), acc);
+                }
+            }
+        }
+    };
+    dec4_acc acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
     // ---- activations: normalised / rounded once per workgroup into the operand image.  All samples' loads of a chunk are in flight
     // together (a per-sample loop of load -> reduce was 2 B dependent L2 round trips per launch: 12-20 us at B = 8) ----
     {
@@ -947,10 +1016,19 @@ __global__ __launch_bounds__(DEC4_T) void dec4_kernel(dec2_args a) {
                         if (h0 + b < B) {
                             const float mean = stat[2 * (h0 + b)], rstd = stat[2 * (h0 + b) + 1];
                             const float4 x = v[ch][b];
+                            const float y0 = (x.x - mean) * rstd * g.x, y1 = (x.y - mean) * rstd * g.y;
+                            const float y2 = (x.z - mean) * rstd * g.z, y3 = (x.w - mean) * rstd * g.w;
                             u32x2 o;
-                            o[0] = pack_h16_rne((x.x - mean) * rstd * g.x, (x.y - mean) * rstd * g.y);
-                            o[1] = pack_h16_rne((x.z - mean) * rstd * g.z, (x.w - mean) * rstd * g.w);
-                            *(u32x2*)(xs + (size_t)(h0 + b) * KP + i) = o;
+                            o[0] = pack_h16_rne(y0, y1);
+                            o[1] = pack_h16_rne(y2, y3);
+                            const int rb = PL ? b : h0 + b;                       // (PL: the image holds one batch of NB2 samples at a time)
+                            *(u32x2*)(xs + (size_t)rb * KP + i) = o;
+                            if constexpr (PL) {
+                                u32x2 l;
+                                l[0] = pack_h16_rne(y0 - h16_lo_to_f(o[0]), y1 - h16_hi_to_f(o[0]));
+                                l[1] = pack_h16_rne(y2 - h16_lo_to_f(o[1]), y3 - h16_hi_to_f(o[1]));
+                                *(u32x2*)(xs_lo + (size_t)rb * KP + i) = l;
+                            }
                         }
                     }
                 }
@@ -990,8 +1068,21 @@ __global__ __launch_bounds__(DEC4_T) void dec4_kernel(dec2_args a) {
                 stat[2 * b] = mean; stat[2 * b + 1] = rsqrtf(fmaxf(pq / (float)a.Kstat - mean * mean, 0.f) + a.eps);
             }
             __syncthreads();
+            static_assert(NB2 == DEC4_IMG(NS), "image rows");
             norm_half(0);
-            if (B > NB2) { load_half(NB2); norm_half(NB2); }      // long rows (FF-out) at B > 8: the second eight samples in a second pass
+            if constexpr (PL) {
+                __syncthreads();
+                kloop(acc, B < NB2 ? B : NB2);
+                if (B > NB2) {                                    // the second batch of samples through the same images
+                    load_half(NB2);
+                    __syncthreads();
+                    norm_half(NB2);
+                    __syncthreads();
+                    kloop(acc2, B - NB2);
+                }
+            } else {
+                if (B > NB2) { load_half(NB2); norm_half(NB2); }  // long rows (FF-out) at B > 8: the second eight samples in a second pass
+            }
         } else if (ln_rows) {
             float s8[NBR], q8[NBR];
 #pragma unroll
@@ -1059,23 +1150,20 @@ __global__ __launch_bounds__(DEC4_T) void dec4_kernel(dec2_args a) {
             }
         }
     }
-    __syncthreads();
-    // ---- the k-loop: one MFMA per 32-wide step; samples >= B are zero operands ----
-    dec4_acc acc = {0.f, 0.f, 0.f, 0.f};
-    const bool have = r < B;                                    // this lane's B-operand column is a real sample
-    const h16_t* xrow = xs + (size_t)(have ? r : 0) * KP + 8 * kq;
-#pragma unroll
-    for (int j = 0; j < NS; ++j) {
-        const int s = wave + 4 * j;
-        if (s < S) {
-            u32x4 xb = {0u, 0u, 0u, 0u};
-            if (have) xb = *(const u32x4*)(xrow + 32 * s);
-            acc = OMLM_MFMA_16x16x32(__builtin_bit_cast(h16x8, wr[j]), __builtin_bit_cast(h16x8, xb), acc);
-        }
+    if constexpr (!PL) {
+        __syncthreads();
+        kloop(acc, B);
     }
     // C layout: acc[e] = out[row 4 kq + e][sample r]
+    if constexpr (PL && DEC4_IMG(NS) == 8) {
+        if (r < 8) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) part[(wave * 16 + 4 * kq + e) * 16 + r] = acc[e];
+            for (int e = 0; e < 4; ++e) { part[(wave * 16 + 4 * kq + e) * 16 + r] = acc[e]; part[(wave * 16 + 4 * kq + e) * 16 + 8 + r] = acc2[e]; }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part[(wave * 16 + 4 * kq + e) * 16 + r] = acc[e];
+    }
     __syncthreads();
     {
         const int t = threadIdx.x;                              // (row, sample) = (t >> 4, t & 15)
@@ -1144,13 +1232,13 @@ __global__ __launch_bounds__(DEC4_T) void dec4_kernel(dec2_args a) {
     }
 }
 
-template <int NS, int MODE>
+template <int NS, int MODE, bool PL = false>
 static void dec4_launch(const dec2_args& a, int grid, hipStream_t st) {
-    const size_t lds = (((size_t)a.B * (a.K + 8) * 2 + 15) & ~(size_t)15) + (size_t)(DEC4_NB * 8 + DEC4_NB * 2 + 4 * 256 + 256) * sizeof(float) +
+    const size_t lds = (((size_t)(PL ? 2 * DEC4_IMG(NS) : a.B) * (a.K + 8) * 2 + 15) & ~(size_t)15) + (size_t)(DEC4_NB * 8 + DEC4_NB * 2 + 4 * 256 + 256) * sizeof(float) +
                        ((a.gamma && !a.stat_in) ? (size_t)a.B * a.K * sizeof(float) : 0);      // fp32 staging copy: own-reduction path only (B <= 8)
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)dec4_kernel<NS, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-    hipLaunchKernelGGL((dec4_kernel<NS, MODE>), dim3(grid), dim3(DEC4_T), lds, st, a);
+    if (!attr) { (void)hipFuncSetAttribute((const void*)dec4_kernel<NS, MODE, PL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL((dec4_kernel<NS, MODE, PL>), dim3(grid), dim3(DEC4_T), lds, st, a);
 }
 // the matrix-core step kernels serve 16-bit weights with D, H * 64, Fp multiples of 32 and k-loops of at most 4 x 24 steps
 static bool dec4_ok(const omlm_decode_args& a) {
@@ -1191,6 +1279,13 @@ static int decode_step2_t(const omlm_decode_args& a, const long long* ids, hipSt
     dec2_args g;
     memset(&g, 0, sizeof(g));
     g.B = B; g.round_bf16 = a.round_bf16; g.eps = a.eps; g.H = H; g.nsplit = a.nsplit; g.pos_dev = a.pos_dev; g.Nmax = a.Nmax; g.Fp = Fp;
+    // "fp16ff": FF-in / FF-out / head read W = hi + lo and keep their activations and h1 un-rounded (round_bf16 = 0 for those launches)
+    const bool pl = a.W1p_lo != nullptr;
+    if (pl) {
+        OMLM_CHECK_ARG(sizeof(TW) == 2 && a.W2p_lo && (!a.head_W || a.head_W_lo), "lo planes: 16-bit weights, all three families");
+        OMLM_CHECK_ARG(B == 1 || (mfma && st_x), "lo planes at B >= 2 run on the matrix-core step kernels (ln_parts given, OMLM_DECODE_MFMA unset)");
+        OMLM_CHECK_ARG(Fp <= 3072, "lo planes: feed-forward width <= 3072");
+    }
     for (int l = 0; l < a.L; ++l) {
         dec2_args q = g;                                                               // q / k / v rows of the new token
         q.in = a.x; q.ldin = D; q.K = D; q.Kstat = D; q.gamma = a.attn_gamma[l]; q.W = a.Wq[l]; q.W2 = a.Wkv[l]; q.ldw = D;
@@ -1214,7 +1309,13 @@ static int decode_step2_t(const omlm_decode_args& a, const long long* ids, hipSt
         f.in = a.x1; f.ldin = D; f.K = D; f.Kstat = D; f.gamma = a.ffin_gamma[l]; f.W = a.W1p[l]; f.ldw = D; f.convw = a.convw[l];
         f.hist = a.hist[l]; f.u = a.u;
         if (st_x1) { f.stat_in = st_x1; f.nstat_in = npd; f.stat_out = st_u; }
-        if (B == 1) {
+        if (pl) { f.Wlo = a.W1p_lo[l]; f.round_bf16 = 0; }
+        if constexpr (sizeof(TW) == 2) {
+            if (pl && B == 1) hipLaunchKernelGGL((dec3_ffin_kernel<TW, 2, true>), dim3((Fp + 7) / 8), dim3(DEC_T), 0, st, f);
+            else if (pl)      dec4_launch<8, DEC2_FFIN, true>(f, (Fp + 7) / 8, st);
+        }
+        if (pl) {
+        } else if (B == 1) {
             static int cpw = -1;
             if (cpw < 0) { const char* e = getenv("OMLM_DECODE_CPW"); cpw = e ? atoi(e) : 4; }
             if (cpw == 4)      hipLaunchKernelGGL((dec3_ffin_kernel<TW, 4>), dim3((Fp + 15) / 16), dim3(DEC_T), 0, st, f);
@@ -1226,7 +1327,13 @@ static int decode_step2_t(const omlm_decode_args& a, const long long* ids, hipSt
         w.in = a.u; w.ldin = Fp; w.K = Fp; w.Kstat = a.F; w.gamma = a.mid_gamma[l]; w.W = a.W2p[l]; w.ldw = Fp; w.Nout = D;
         w.res = a.x1; w.ldres = D; w.out = a.x; w.ldout = D;
         if (st_u) { w.stat_in = st_u; w.nstat_in = npf; w.stat_out = st_x; n_x = npd; }
-        if (B == 1 && Fp <= 3072) dec3_launch<TW, 6, DEC2_LNGEMV>(w, D, st);
+        if (pl) { w.Wlo = a.W2p_lo[l]; w.round_bf16 = 0; }
+        if constexpr (sizeof(TW) == 2) {
+            if (pl && B == 1) hipLaunchKernelGGL((dec3_kernel<TW, 6, DEC2_LNGEMV, true>), dim3((D + 3) / 4), dim3(DEC_T), 0, st, w);
+            else if (pl)      dec4_launch<24, DEC2_LNGEMV, true>(w, (D + DEC4_ROWS - 1) / DEC4_ROWS, st);
+        }
+        if (pl) {
+        } else if (B == 1 && Fp <= 3072) dec3_launch<TW, 6, DEC2_LNGEMV>(w, D, st);
         else if (mfma) dec4_launch<24, DEC2_LNGEMV>(w, (D + DEC4_ROWS - 1) / DEC4_ROWS, st);
         else if (Fp <= 3072) dec2_launch<TW, 6, DEC2_LNGEMV>(w, (D + DEC2_ROWS - 1) / DEC2_ROWS, st);
         else                 dec2_launch<TW, 8, DEC2_LNGEMV>(w, (D + DEC2_ROWS - 1) / DEC2_ROWS, st);
@@ -1237,7 +1344,16 @@ static int decode_step2_t(const omlm_decode_args& a, const long long* ids, hipSt
         h.out = a.logits; h.ldout = a.ldV;
         h.adv_pos = a.advance_pos; h.adv_step = a.advance_step;
         if (st_x && n_x > 0) { h.stat_in = st_x; h.nstat_in = n_x; }
-        if (B == 1) dec3_launch<TW, 2, DEC2_LNGEMV>(h, a.V1, st);
+        if (pl) {
+            OMLM_CHECK_ARG(B == 1 || h.stat_in, "lo planes: the head needs the LayerNorm partials of the last FF-out launch (L >= 1)");
+            h.Wlo = a.head_W_lo; h.round_bf16 = 0;
+        }
+        if constexpr (sizeof(TW) == 2) {
+            if (pl && B == 1) hipLaunchKernelGGL((dec3_kernel<TW, 2, DEC2_LNGEMV, true>), dim3((a.V1 + 3) / 4), dim3(DEC_T), 0, st, h);
+            else if (pl)      dec4_launch<8, DEC2_LNGEMV, true>(h, (a.V1 + DEC4_ROWS - 1) / DEC4_ROWS, st);
+        }
+        if (pl) {
+        } else if (B == 1) dec3_launch<TW, 2, DEC2_LNGEMV>(h, a.V1, st);
         else if (mfma) dec4_launch<8, DEC2_LNGEMV>(h, (a.V1 + DEC4_ROWS - 1) / DEC4_ROWS, st);
         else        dec2_launch<TW, 2, DEC2_LNGEMV>(h, (a.V1 + DEC2_ROWS - 1) / DEC2_ROWS, st);
     }
@@ -1274,6 +1390,8 @@ static int decode_step_t(const omlm_decode_args& a, const long long* ids, hipStr
         attr = true;
     }
     const int HD = H * 64;
+    const bool pl = a.W1p_lo != nullptr;
+    if (pl) OMLM_CHECK_ARG(a.W2p_lo && (!a.head_W || a.head_W_lo), "lo planes: all three families");
     if (a.emb_table)
         hipLaunchKernelGGL(dec_embed_kernel, dim3(B), dim3(DEC_T), 0, st, ids, a.emb_table, a.emb_row_offset, a.emb_rows, a.x, D, (float*)nullptr);
     for (int l = 0; l < a.L; ++l) {
@@ -1284,16 +1402,17 @@ static int decode_step_t(const omlm_decode_args& a, const long long* ids, hipStr
         hipLaunchKernelGGL((dec_gemv_kernel<TW>), dim3((D + DEC_ROWS - 1) / DEC_ROWS), dim3(DEC_T), lds_hd, st, (const float*)nullptr, 0,
                            (const float*)nullptr, 0, a.eps, a.parts, a.nsplit, H, a.pos_dev, (const TW*)a.Wo[l], (long long)HD, HD, D,
                            a.x, D, a.x1, D, B, a.round_bf16);
+        // (pl, "fp16ff": W = hi + lo for FF-in / FF-out / head, their activations and h1 un-rounded)
         hipLaunchKernelGGL((dec_ffin_kernel<TW>), dim3(Fp / 8), dim3(DEC_T), lds_d, st, a.x1, a.ffin_gamma[l], (const TW*)a.W1p[l],
-                           a.convw[l], a.hist[l], a.u, B, D, Fp, a.eps, a.round_bf16);
+                           a.convw[l], a.hist[l], a.u, B, D, Fp, a.eps, pl ? 0 : a.round_bf16, pl ? (const TW*)a.W1p_lo[l] : (const TW*)nullptr);
         hipLaunchKernelGGL((dec_gemv_kernel<TW>), dim3((D + DEC_ROWS - 1) / DEC_ROWS), dim3(DEC_T), lds_fp, st, a.u, Fp, a.mid_gamma[l],
                            a.F, a.eps, (const float*)nullptr, 0, 0, (const int*)nullptr, (const TW*)a.W2p[l], (long long)Fp, Fp, D,
-                           a.x1, D, a.x, D, B, a.round_bf16);
+                           a.x1, D, a.x, D, B, pl ? 0 : a.round_bf16, pl ? (const TW*)a.W2p_lo[l] : (const TW*)nullptr);
     }
     if (a.head_W)
         hipLaunchKernelGGL((dec_gemv_kernel<TW>), dim3((a.V1 + DEC_ROWS - 1) / DEC_ROWS), dim3(DEC_T), lds_d, st, a.x, D, a.final_gamma,
                            D, a.eps, (const float*)nullptr, 0, 0, (const int*)nullptr, (const TW*)a.head_W, (long long)D, D, a.V1,
-                           (const float*)nullptr, 0, a.logits, a.ldV, B, a.round_bf16);
+                           (const float*)nullptr, 0, a.logits, a.ldV, B, pl ? 0 : a.round_bf16, pl ? (const TW*)a.head_W_lo : (const TW*)nullptr);
     return omlm_post_launch("omlm_decode_step");
 }
 

@@ -36,7 +36,8 @@ class DecodeArgs(C.Structure):
                 [("bias_table", C.c_void_p), ("bias_ld", C.c_int),
                  ("final_gamma", C.c_void_p), ("head_W", C.c_void_p), ("V1", C.c_int), ("ldV", C.c_int),
                  ("emb_table", C.c_void_p), ("emb_row_offset", C.c_longlong), ("emb_rows", C.c_longlong)] +
-                [(n, C.c_void_p) for n in ("x", "x1", "q", "parts", "u", "logits", "advance_pos", "advance_step", "ln_parts")])
+                [(n, C.c_void_p) for n in ("x", "x1", "q", "parts", "u", "logits", "advance_pos", "advance_step", "ln_parts")] +
+                [("W1p_lo", C.POINTER(C.c_void_p)), ("W2p_lo", C.POINTER(C.c_void_p)), ("head_W_lo", C.c_void_p)])
 
 
 def max_batch(model, precision: str) -> int:
@@ -59,14 +60,15 @@ class CachedDecoder:
     def __init__(self, model, batch: int, max_rows: int, precision: str):
         if batch > max_batch(model, precision):
             raise ValueError(f"cached decode handles up to {max_batch(model, precision)} samples per call here; got {batch}")
-        if precision == "fp16ff":          # the cached decode step is a weight-streaming GEMV chain: it runs the fp16 kernels (hi planes)
-            precision = "fp16"
         self.model, self.B, self.Nmax, self.precision = model, batch, int(max_rows), precision
         tr = model.transformer
         dev = model.start_tokens[0].device
         hip.require_gpu(model.start_tokens[0], "model parameters")
         self.pw = engine.prepared_weights(model, precision)
         self.T = self.pw.T
+        # "fp16ff": the steps read the FF-in / FF-out / head weights as hi + lo planes and keep LayerNorm outputs and h1 un-rounded, like the
+        # three-product forward of the batched path (omlm_decode_args::W1p_lo)
+        self.planes = bool(self.pw.ff3)
         L, D, H = len(tr.layers), tr.dim, tr.heads
         F, Fp = self.pw.layers[0]["F"], self.pw.layers[0]["Fp"]
         self.L, self.D, self.H, self.F, self.Fp = L, D, H, F, Fp
@@ -114,8 +116,13 @@ class CachedDecoder:
         lay = self.pw.layers
         a.Wq, a.Wkv, a.Wo = arr([w["Wq"] for w in lay]), arr([w["Wkv"] for w in lay]), arr([w["Wo"] for w in lay])
         a.W1p, a.W2p = arr([w["W1p"] for w in lay]), arr([w["W2p"] for w in lay])
-        # fp32 views of the (operand-dtype) taps / gamma: same values as the batched path uses
-        a.convw, a.mid_gamma = arr([w["convw"].float() for w in lay]), arr([w["gamma_mid"].float() for w in lay])
+        # fp32 views of the (operand-dtype) taps / gamma: same values as the batched path uses (fp16ff: hi + lo planes)
+        if self.planes:
+            a.convw = arr([w["convw"].float() + w["convw_lo"].float() for w in lay])
+            a.mid_gamma = arr([w["gamma_mid"].float() + w["gamma_mid_lo"].float() for w in lay])
+            a.W1p_lo, a.W2p_lo = arr([w["W1p_lo"] for w in lay]), arr([w["W2p_lo"] for w in lay])
+        else:
+            a.convw, a.mid_gamma = arr([w["convw"].float() for w in lay]), arr([w["gamma_mid"].float() for w in lay])
         a.attn_gamma = arr([attn.norm.gamma for attn, _, _ in tr.layers])
         a.q_scale = arr([attn.q_scale for attn, _, _ in tr.layers])
         a.k_scale = arr([attn.k_scale for attn, _, _ in tr.layers])
@@ -143,7 +150,7 @@ class CachedDecoder:
         assert B == self.B and N <= self.Nmax, (B, N, self.B, self.Nmax)
         lay = engine.get_layout(model, B, lens, ids32.device, True)
         x = engine.embed_forward(model, ids32, lay)
-        y, saved = engine.trunk_forward(tr, self.pw, x, None, B, N, True, False)
+        y, saved = engine.trunk_forward(tr, self.pw, x, None, B, N, True, False, keep_h1_lo_tail=self.planes)
         nseq = len(model.token_sequences)
         logits = engine.heads_forward(model, self.pw, y, lay, [s == nseq - 1 for s in range(nseq)])[-1]
         for l, sv in enumerate(saved["layers"]):
@@ -153,6 +160,8 @@ class CachedDecoder:
             self.hist[l].zero_()
             take = min(2, N)
             self.hist[l][:, 2 - take:].copy_(h1[:, N - take:])
+            if self.planes:                                  # the conv state of "fp16ff" is the un-rounded h1 = hi + lo
+                self.hist[l][:, 2 - take:].add_(sv.h1_lo_tail[:, 2 - take:])
         self.rows = N
         self.pos_dev.fill_(N)
         return logits
@@ -166,6 +175,7 @@ class CachedDecoder:
         a.emb_row_offset = self.codebook * (k % self.Q) if self.Q > 1 else 0
         head = self.pw.heads[-1][(k + 1) % self.Q]
         a.head_W = head.data_ptr()
+        a.head_W_lo = self.pw.heads_lo[-1][(k + 1) % self.Q].data_ptr() if self.planes else None
         ids = new_ids.contiguous()
         assert ids.dtype == torch.int64 and ids.numel() == self.B
         a.emb_table = self.emb.data_ptr()
@@ -221,6 +231,7 @@ class SamplingLoop:
             dec.x.add_(dec.pos_emb.index_select(0, (self.step_dev + self.n0).long()))
         a.emb_table = None
         a.head_W = dec.pw.heads[-1][(k + 1) % dec.Q].data_ptr()
+        a.head_W_lo = dec.pw.heads_lo[-1][(k + 1) % dec.Q].data_ptr() if dec.planes else None
         a.advance_pos, a.advance_step = dec.pos_dev.data_ptr(), self.step_dev.data_ptr()
         call("omlm_decode_step", C.addressof(a), ptr(self.cur), stream_ptr())
 

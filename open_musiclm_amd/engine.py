@@ -445,7 +445,7 @@ def relpos_backward(tr, n: int, saved, dtable: torch.Tensor):
 # ------------------------------------------------------------------------------------------------------
 class LayerSaved:
     __slots__ = ("x", "m1", "r1", "xn", "xc", "q_raw", "kv_raw", "q", "k", "v", "o", "lse", "abias",
-                 "x1", "m2", "r2", "xn2", "h1", "h2", "m3", "r3", "seed", "p", "drop_bits", "gh")
+                 "x1", "m2", "r2", "xn2", "h1", "h2", "m3", "r3", "seed", "p", "drop_bits", "gh", "h1_lo_tail")
 
 
 def dropout_salt(tr, dev) -> torch.Tensor:
@@ -465,8 +465,10 @@ def dropout_salt(tr, dev) -> torch.Tensor:
 
 
 def trunk_forward(tr, pw: PreparedWeights, x: torch.Tensor, keymask: Optional[torch.Tensor], B: int, N: int,
-                  save: bool, training: bool):
-    """x: [B*N, D] fp32 (consumed as the layer-0 residual).  Returns (final LN output in operand dtype, saved)."""
+                  save: bool, training: bool, keep_h1_lo_tail: bool = False):
+    """x: [B*N, D] fp32 (consumed as the layer-0 residual).  Returns (final LN output in operand dtype, saved).
+    keep_h1_lo_tail ("fp16ff" prefill of the cached decoder): the lo plane of the last two h1 rows of every sample survives as sv.h1_lo_tail
+    [B, 2, 2 Fp] fp32 (rows N-2, N-1; zeros where N < 2) -- the causal conv's state is the un-rounded h1."""
     T = pw.T
     dev = x.device
     M, D = x.shape
@@ -551,6 +553,10 @@ def trunk_forward(tr, pw: PreparedWeights, x: torch.Tensor, keymask: Optional[to
             ops.ffmid_fwd_planes(h1, h1_lo, w["convw"], w["convw_lo"], w["gamma_mid"], w["gamma_mid_lo"], h2, h2_lo, m3, r3, N, F, Fp, p, seed,
                                  seed_dev=salt if p > 0 else None, drop_bits=drop_bits, gh=gh)
             ops.gemm_planes16(h2, h2_lo, w["W2p"], w["W2p_lo"], x2, M=M, N=D, K=Fp, Cin=x1)
+            if keep_h1_lo_tail and save:
+                take = min(2, N)
+                sv.h1_lo_tail = torch.zeros(B, 2, 2 * Fp, device=dev)
+                sv.h1_lo_tail[:, 2 - take:].copy_(h1_lo.view(B, N, -1)[:, N - take:])
             del xn2_lo, h1_lo, h2_lo
         else:
             ops.ffmid_fwd(h1, w["convw"], w["gamma_mid"], h2, m3, r3, N, F, Fp, p, seed, seed_dev=salt if p > 0 else None,
