@@ -42,11 +42,18 @@ void        omlm_set_error(const char* msg);
  * Linear layers (transformer.py:48-53) and the autograd backward of each.
  * a_kmajor/b_kmajor: operand stored [K, M] / [K, N] instead of [M, K] / [N, K].
  * a_map / b_map / c_map (optional, int32): physical row of each logical row (k row for k-major operands);
- * c_map < 0 skips the row.  a_rows / b_rows: physical row counts (bounds for out-of-range zero fill). */
+ * c_map < 0 skips the row.  a_rows / b_rows: physical row counts (bounds for out-of-range zero fill).
+ * workspace / workspace_bytes (optional; 16-bit operands): caller-owned scratch for the deterministic split-K of the peeled tail -- the m-tile
+ * rows behind the last full round of 256 x 256 tiles have their K range cut into slices that fill the machine, each slice stores its partial
+ * tile to its own plane of the workspace, a reduction kernel adds the planes in a fixed order with the residual and writes the output type.
+ * omlm_gemm_tail_workspace_bytes(M, N) bounds what an M x N output needs; a smaller buffer or NULL / 0 keeps the one-launch tail.  The library
+ * keeps no pointer: the buffer belongs to the call, one buffer per stream that launches GEMMs concurrently.  $OMLM_GEMM_TAIL_SPLIT=0: off. */
 int omlm_gemm(const void* A, const void* B, void* C, const float* Cin,
               const int* a_map, const int* b_map, const int* c_map, long long a_rows, long long b_rows,
               int M, int N, int K, int lda, int ldb, int ldc, int ldcin,
-              int a_kmajor, int b_kmajor, int in_dtype, int out_dtype, float alpha, void* stream);
+              int a_kmajor, int b_kmajor, int in_dtype, int out_dtype, float alpha,
+              void* workspace, long long workspace_bytes, void* stream);
+long long omlm_gemm_tail_workspace_bytes(int M, int N);
 
 /* LayerNorm (transformer.py:24-31: F.layer_norm, learnable gamma, beta == 0, eps 1e-5).
  * fwd: y = LN(x)*gamma in out_dtype (pitch ldy); xcast (optional) = cast(x) for the K/V projection, which the
@@ -220,7 +227,7 @@ int omlm_cast_pad_group(const omlm_cast_pad_desc* problems, int count, int out_d
 int omlm_gemm_planes(const void* A, long long a_plane_bytes, const void* B, long long b_plane_bytes, void* C, const float* Cin,
                      const int* a_map, const int* b_map, const int* c_map, long long a_rows, long long b_rows,
                      int M, int N, int K, int lda, int ldb, int ldc, int ldcin,
-                     int a_kmajor, int b_kmajor, int out_dtype, float alpha, void* stream);
+                     int a_kmajor, int b_kmajor, int out_dtype, float alpha, void* workspace, long long workspace_bytes, void* stream);
 int omlm_split_planes(const float* x, void* planes, long long n, long long plane_elems, void* stream);
 /* Precision "fp16ff" (round 5): the forward of the two ConvFeedForward linears (transformer.py:144,149 -- 86-88 % of the fp16 logits-error
  * variance, profiles/r05_error_budget.md) on hi/lo planes of the 16-bit operand type `dtype` (1 = bf16, 2 = fp16).  C = A B^T (+ Cin), A [M, K]
@@ -230,13 +237,35 @@ int omlm_split_planes(const float* x, void* planes, long long n, long long plane
  * (the logit heads of the same mode, open_musiclm.py:163-186). */
 int omlm_gemm_planes16(const void* A, const void* A_lo, const void* B, const void* B_lo, void* C, void* C_lo, const float* Cin,
                        const int* a_map, const int* c_map, long long a_rows, long long b_rows, int M, int N, int K,
-                       int lda, int ldb, int ldc, int ldcin, int dtype, void* stream);
-/* Workspace for the deterministic split-K of a GEMM's peeled tail (the m-tile rows behind the last full round of 256 x 256 tiles: their K range is
- * cut into slices that fill the machine, each slice stores its partial tile to its own plane of the workspace, a reduction kernel adds the planes
- * in a fixed order with the residual and writes the output type).  `bytes` of device memory on the current device, kept alive by the caller (64 MiB
- * covers the training step's shapes; a tail that needs more keeps the one-launch form); NULL / 0 switches the form off.  One stream at a time per
- * device may run such GEMMs.  $OMLM_GEMM_TAIL_SPLIT=0: off. */
-int omlm_gemm_set_tail_workspace(void* workspace, long long bytes);
+                       int lda, int ldb, int ldc, int ldcin, int dtype, void* workspace, long long workspace_bytes, void* stream);
+/* Round 6: the same contraction for IEEE-half planes with the two CORRECTION products on fp8 at twice the matrix rate (csrc/gemm_mx.hip):
+ *   C = A_hi B_hi^T (v_mfma_f32_32x32x16_f16)  +  2^(ea + eb - 11) (A_hi8 B_lo8^T + A_lo8 B_hi8^T)  (v_mfma_scale_f32_32x32x64_f8f6f4)
+ * A [M, K] / B [N, K]: the half hi planes (pitch lda / ldb elements).  A8 / B8: the operand's two fp8 (e4m3) planes [hi8 | lo8] at the half plane's
+ * row pitch in BYTES (2 lda / 2 ldb; element k of a row at byte k; bytes [K, ceil128(K)) zero), the lo8 plane a8_stride / b8_stride bytes behind
+ * the hi8 plane, rows padded to a multiple of 256 (both planes readable in full).  a_scale / b_scale: one E8M0 byte per row,
+ * hi8 = fp8(hi 2^-(byte - 127)), lo8 = fp8(lo 2^-(byte - 127 - 11)) (omlm_layernorm_fwd_mx / omlm_ffmid_fwd_mx / omlm_quant_rows_mx write all
+ * of it).  2 x the k-tiles of a plain GEMM instead of omlm_gemm_planes16's 3 x; what the fp8 corrections leave in the logits:
+ * profiles/r06_error_budget_fp8corr.md.  C_lo given: half planes out (no Cin), else fp32 (+ Cin).  workspace as in omlm_gemm
+ * (omlm_gemm_mx16_workspace_bytes(M, N, K)).  K % 64 == 0. */
+int omlm_gemm_mx16(const void* A, const void* A8, long long a8_stride, const unsigned char* a_scale,
+                   const void* B, const void* B8, long long b8_stride, const unsigned char* b_scale,
+                   void* C, void* C_lo, const float* Cin, long long a_rows, long long b_rows,
+                   int M, int N, int K, int lda, int ldb, int ldc, int ldcin,
+                   void* workspace, long long workspace_bytes, void* stream);
+long long omlm_gemm_mx16_workspace_bytes(int M, int N, int K);
+/* Producers of omlm_gemm_mx16's operand form (fp16 only).  Each writes the half hi plane exactly as its plain / planes sibling does, plus the fp8
+ * planes [hi8 | lo8] (row pitch = 2 x the half plane's pitch in elements, in bytes; lo8 plane `*_stride` bytes behind hi8; bytes behind the row's
+ * last element untouched -- zero-fill the buffer once) and one E8M0 scale byte per row, 2^(e) >= 2^-8 x a bound of the row's largest entry:
+ *   omlm_layernorm_fwd_mx : transformer.py:24-31 in front of FF-in; bound = max(xmax - mean, mean - xmin) rstd max|gamma| (no extra pass)
+ *   omlm_ffmid_fwd_mx     : omlm_ffmid_fwd_planes with h2 in this form; bound from the GEGLU output's row max / min the same way
+ *   omlm_quant_rows_mx    : fp32 weights (all problems of a model in one launch); hi = rne_half(w), exact row maximum */
+int omlm_layernorm_fwd_mx(const float* x, const float* gamma, void* y, void* y8, long long y8_stride, unsigned char* scale8,
+                          float* mean, float* rstd, int M, int D, int ldy, float eps, void* stream);
+int omlm_ffmid_fwd_mx(const void* h1, const void* h1_lo, const void* convw, const void* convw_lo, const void* gamma, const void* gamma_lo,
+                      void* h2, void* h2_8, long long h2_8_stride, unsigned char* scale8, float* mean, float* rstd, int M, int nseq, int F, int Fp,
+                      float eps, float p, unsigned long long seed, const unsigned long long* seed_dev, unsigned char* drop_bits, void* gh, void* stream);
+typedef struct omlm_quant_rows_desc { const float* src; unsigned char* dst8; long long lo_stride; unsigned char* scale8; int R, C, ld_src, ld8; } omlm_quant_rows_desc;
+int omlm_quant_rows_mx(const omlm_quant_rows_desc* problems, int count, void* stream);
 /* All weight-gradient contractions of a backward pass in one launch (autograd of nn.Linear, transformer.py:203-212,144,149:
  * dW += dY^T X).  Problem i: C_i [M_i, N_i] fp32 (accumulated, +=; c_map optional: physical row of logical row m, < 0 skips)
  * from 16-bit k-major operands A_i [K_i, M_i] (pitch lda) and B_i [K_i, N_i] (pitch ldb); pitches are multiples of 8 elements.

@@ -318,4 +318,19 @@ __device__ __forceinline__ void store4_from_float(h16_t* p, float a, float b, fl
     *(u32x2*)p = o;
 }
 
+// ---- fp8 (e4m3) planes with one power-of-two scale per row: the operands of omlm_gemm_mx16's correction products (csrc/gemm_mx.hip) --------------
+// four values -> four e4m3 bytes (RNE; |v| <= 448 by construction of the row scale)
+__device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d) {
+    int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+    return (unsigned)r;
+}
+// exponent e of a row whose entries are bounded by `bound`: bound <= 2^(e + 8) (frexp: bound = m 2^ex with m < 1); an all-zero row takes e = -100
+__device__ __forceinline__ int mx_row_exp(float bound) {
+    int ex;
+    (void)frexpf(bound, &ex);
+    ex -= 8;
+    return bound > 0.f && ex > -100 ? (ex > 100 ? 100 : ex) : -100;
+}
+
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }

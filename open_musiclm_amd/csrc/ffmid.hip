@@ -711,6 +711,32 @@ extern "C" int OMLM_API(omlm_ffmid_fwd_planes)(const void* h1, const void* h1_lo
                                     drop_bits, gh, as_stream(stream));
 }
 
+#if OMLM_FP16
+// The plane forward with h2 leaving in omlm_gemm_mx16's operand form (round 6): the half hi plane h2 [M, Fp], fp8 planes [hi8 | lo8] at row pitch
+// 2 Fp bytes (the lo8 plane h2_8_stride bytes behind the hi8 plane) and one E8M0 scale byte per row; everything else as omlm_ffmid_fwd_planes.
+int ffmid2_fwd_mx_launch(const void* h1, const void* h1_lo, const void* convw, const void* convw_lo, const void* gamma, const void* gamma_lo,
+                         void* h2, void* h2_8, long long h2_8_stride, unsigned char* scale8, float* mean, float* rstd, int M, int nseq, int F, int Fp,
+                         float eps, float p, unsigned long long seed, const unsigned long long* seed_dev, unsigned char* drop_bits, void* gh, hipStream_t st);
+}   // namespace OMLM_NS
+extern "C" int omlm_ffmid_fwd_mx(const void* h1, const void* h1_lo, const void* convw, const void* convw_lo, const void* gamma, const void* gamma_lo,
+                                 void* h2, void* h2_8, long long h2_8_stride, unsigned char* scale8, float* mean, float* rstd, int M, int nseq, int F, int Fp,
+                                 float eps, float p, unsigned long long seed, const unsigned long long* seed_dev, unsigned char* drop_bits, void* gh,
+                                 void* stream) {
+    using namespace OMLM_NS;
+    if (M <= 0) return OMLM_OK;
+    OMLM_CHECK_ARG(h1 && h1_lo && convw && convw_lo && gamma && gamma_lo && h2 && h2_8 && scale8 && mean && rstd, "null pointer");
+    OMLM_CHECK_ARG(Fp % 8 == 0 && Fp >= F && ffmid2_supported(Fp), "ffmid_fwd_mx: Fp must be F rounded up to 8 and <= 4096");
+    OMLM_CHECK_ARG(nseq > 0 && M % nseq == 0, "M must be batch * nseq");
+    OMLM_CHECK_ARG(p >= 0.f && p < 1.f && (p == 0.f || drop_bits), "dropout p (keep bits required when p > 0)");
+    OMLM_CHECK_ARG(h2_8_stride >= (long long)M * 2 * Fp && h2_8_stride % 16 == 0, "ffmid_fwd_mx: fp8 plane stride");
+    OMLM_CHECK_ARG((((uintptr_t)h1 | (uintptr_t)h1_lo | (uintptr_t)convw | (uintptr_t)convw_lo | (uintptr_t)gamma | (uintptr_t)gamma_lo |
+                     (uintptr_t)h2 | (uintptr_t)h2_8) % 16) == 0, "ffmid_fwd_mx: 16-byte aligned planes");
+    return ffmid2_fwd_mx_launch(h1, h1_lo, convw, convw_lo, gamma, gamma_lo, h2, h2_8, h2_8_stride, scale8, mean, rstd, M, nseq, F, Fp, eps, p, seed,
+                                seed_dev, drop_bits, gh, as_stream(stream));
+}
+namespace OMLM_NS {
+#endif
+
 // du_tmp: [M, 2*Fp] scratch of the operand dtype; dh1: [M, 2*Fp] output; workspace: omlm_ffmid_bwd_workspace_bytes.
 // dgamma [F], dconv [2F*3] are accumulated into (+=).
 #if !OMLM_FP16

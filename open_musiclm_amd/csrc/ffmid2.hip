@@ -100,7 +100,25 @@ __device__ __forceinline__ void store_planes8(h16_t* hi, h16_t* lo, const v2 (&y
     *(u32x4*)lo = l;
 }
 __device__ __forceinline__ void store_planes8(float*, float*, const v2 (&)[4]) {}          // (fp32 operands have no planes)
-struct FfPlanes { long long h1_lo, convw_lo, gamma_lo; void* h2_lo; };      // element distances hi -> lo of the inputs; lo plane of h2
+struct FfPlanes { long long h1_lo, convw_lo, gamma_lo; void* h2_lo;        // element distances hi -> lo of the inputs; lo plane of h2
+                  unsigned char* h2_8; long long h2_8_stride; unsigned char* scale8; };     // MX instantiations: h2's fp8 planes [hi8 | lo8] (pitch 2 Fp bytes) + row scales instead of h2_lo
+// y as the half hi plane + fp8 planes (omlm_gemm_mx16's operand form): hi8 = e4m3(hi sh), lo8 = e4m3((y - hi) sl)
+__device__ __forceinline__ void store_mx8(h16_t* hi, unsigned char* p8h, unsigned char* p8l, const v2 (&y)[4], float sh, float sl) {
+    u32x4 o;
+    u32x2 h8, l8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = f2_to_bf2(y[i]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const v2 ha = bf2_to_f2(o[2 * i]), hb = bf2_to_f2(o[2 * i + 1]);
+        h8[i] = pack4_fp8(ha[0] * sh, ha[1] * sh, hb[0] * sh, hb[1] * sh);
+        l8[i] = pack4_fp8((y[2 * i][0] - ha[0]) * sl, (y[2 * i][1] - ha[1]) * sl, (y[2 * i + 1][0] - hb[0]) * sl, (y[2 * i + 1][1] - hb[1]) * sl);
+    }
+    *(u32x4*)hi = o;
+    *(u32x2*)p8h = h8;
+    *(u32x2*)p8l = l8;
+}
+__device__ __forceinline__ void store_mx8(float*, unsigned char*, unsigned char*, const v2 (&)[4], float, float) {}
 
 __device__ __forceinline__ void pin_regs(Ch8<h16_t>& a, Ch8<h16_t>& b) { asm volatile("" : "+v"(a.r), "+v"(b.r)); }
 __device__ __forceinline__ void pin_regs(Ch8<float>&, Ch8<float>&) {}
@@ -165,7 +183,10 @@ __device__ __forceinline__ void keep_words(unsigned long long seed, unsigned lon
 // forward.  grid: B * strips workgroups of NT threads (NT = chunks of 8 channels rounded up to waves); strip s of sample b
 // covers rows [s * RB, min(nseq, (s + 1) * RB)).
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T, int NT, bool TRAIN, bool PL = false>
+// MX (with PL): h2 leaves as the half hi plane + fp8 planes + one scale byte per row (csrc/gemm_mx.hip) instead of hi / lo half planes.  The row's
+// scale needs a bound on |y| before the row is written: max(gmax - mean, mean - gmin) rstd max|gamma / keep| from the row's max / min of the GEGLU
+// output, which ride with the LayerNorm sums through the one barrier per batch.
+template <typename T, int NT, bool TRAIN, bool PL = false, bool MX = false>
 __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kernel(const T* __restrict__ h1, const T* __restrict__ convw,
                                                         const T* __restrict__ gamma, T* __restrict__ h2,
                                                         float* __restrict__ mean, float* __restrict__ rstd,
@@ -174,7 +195,8 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
                                                         unsigned char* __restrict__ drop_bits, T* __restrict__ gh_out, const FfPlanes pl) {
     constexpr int NW = NT / 64;
     constexpr int RB_ = (sizeof(T) == 2 && !PL) ? FS_R : (FS_R > 2 ? 2 : FS_R);        // rows per batch: fp32 rows (and hi + lo rows) cost twice the registers
-    __shared__ float st[2][FS_R][NW][2];
+    __shared__ float st[2][FS_R][NW][MX ? 4 : 2];
+    __shared__ float gmx[MX ? NW : 1];
     if (seed_dev) seed += seed_dev[0] * 0x9E3779B97F4A7C15ull;
     const int b = blockIdx.x / strips, s = blockIdx.x - b * strips;
     const int t0 = s * RB, t1 = min(nseq, t0 + RB);
@@ -218,6 +240,17 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
 #pragma unroll
         for (int i = 0; i < 4; ++i) gm[i] = a.get(i) * inv;                  // dropout scale folded into gamma
     }
+    float gmmax = 0.f;                                   // MX: max |gamma / keep| over the row (pad channels carry 0)
+    if constexpr (MX) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gmmax = fmaxf(gmmax, fmaxf(fabsf(gm[i][0]), fabsf(gm[i][1])));
+        gmmax = wave_max(gmmax);                         // (absent lanes of a partial last wave read as 0: harmless for a max of magnitudes)
+        if (lane == 0) gmx[wave] = gmmax;
+        __syncthreads();
+        gmmax = gmx[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) gmmax = fmaxf(gmmax, gmx[w]);
+    }
     // conv window: rows t0 - 1 and t0 - 2 of the same sample (zero before the sample starts, transformer.py:129)
     v2 x1v[4], x1g[4], x2v[4], x2g[4];
     {
@@ -245,13 +278,13 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
     auto batch = [&](auto full_tag, const int tb, const int it) {
         constexpr bool FULL = decltype(full_tag)::value;
         v2 g[RB_][4];
-        float ls[RB_], lq[RB_];
+        float ls[RB_], lq[RB_], lhi[RB_], llo[RB_];
         // sweep 1: conv + GEGLU of the batch, per-thread sums for LayerNorm
 #pragma unroll
         for (int r = 0; r < RB_; ++r) {
-            ls[r] = 0.f; lq[r] = 0.f;
+            ls[r] = 0.f; lq[r] = 0.f; lhi[r] = 0.f; llo[r] = 0.f;
             if (FULL || tb + r < t1) {
-                v2 s2 = splat2(0.f), q2 = splat2(0.f);
+                v2 s2 = splat2(0.f), q2 = splat2(0.f), hi2 = splat2(0.f), lo2 = splat2(0.f);
                 if constexpr (PACKW) {                   // opaque per row: the unpacked taps must not be hoisted back into loop-invariant registers
 #pragma unroll
                     for (int k = 0; k < 3; ++k) pin_regs(tv[k].h, tg[k].h);
@@ -272,9 +305,14 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
                     g[r][i] = gv;
                     s2 += gv;
                     q2 = fma2(gv, gv, q2);
+                    if constexpr (MX) {                  // row max / min of the GEGLU output (0 included: pad channels and absent lanes carry it anyway)
+                        hi2 = mk2(fmaxf(hi2[0], gv[0]), fmaxf(hi2[1], gv[1]));
+                        lo2 = mk2(fminf(lo2[0], gv[0]), fminf(lo2[1], gv[1]));
+                    }
                 }
                 ls[r] = s2[0] + s2[1];
                 lq[r] = q2[0] + q2[1];
+                if constexpr (MX) { lhi[r] = fmaxf(hi2[0], hi2[1]); llo[r] = fminf(lo2[0], lo2[1]); }
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) g[r][i] = splat2(0.f);
@@ -302,26 +340,42 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
             }
 #endif
 #pragma unroll
-        for (int r = 0; r < RB_; ++r) { ls[r] = wave_sum(ls[r]); lq[r] = wave_sum(lq[r]); }
+        for (int r = 0; r < RB_; ++r) {
+            ls[r] = wave_sum(ls[r]); lq[r] = wave_sum(lq[r]);
+            if constexpr (MX) { lhi[r] = wave_max(lhi[r]); llo[r] = -wave_max(-llo[r]); }
+        }
         if (lane == 0) {
 #pragma unroll
-            for (int r = 0; r < RB_; ++r) { st[it & 1][r][wave][0] = ls[r]; st[it & 1][r][wave][1] = lq[r]; }
+            for (int r = 0; r < RB_; ++r) {
+                st[it & 1][r][wave][0] = ls[r]; st[it & 1][r][wave][1] = lq[r];
+                if constexpr (MX) { st[it & 1][r][wave][2] = lhi[r]; st[it & 1][r][wave][3] = llo[r]; }
+            }
         }
         __syncthreads();          // one barrier per batch: the other parity's slots are rewritten only after the next one
         // sweep 2: normalise, gamma, dropout, store
         float mu_r[RB_], rs_r[RB_];
+        int e_r[RB_];
 #pragma unroll
         for (int r = 0; r < RB_; ++r) {
+            e_r[r] = 0;
             if (!FULL && tb + r >= t1) continue;
-            float S = 0.f, Q = 0.f;
+            float S = 0.f, Q = 0.f, HI = 0.f, LO = 0.f;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) { S += st[it & 1][r][w][0]; Q += st[it & 1][r][w][1]; }
+            for (int w = 0; w < NW; ++w) {
+                S += st[it & 1][r][w][0]; Q += st[it & 1][r][w][1];
+                if constexpr (MX) { HI = fmaxf(HI, st[it & 1][r][w][2]); LO = fminf(LO, st[it & 1][r][w][3]); }
+            }
             const float mu = S * invF;
             const float var = fmaxf(Q * invF - mu * mu, 0.f);
             const float rs = rsqrtf(var + eps);
             const size_t row = row0 + tb + r;
+            float sh = 1.f, sl = 1.f;
+            if constexpr (MX) {
+                e_r[r] = mx_row_exp(fmaxf(HI - mu, mu - LO) * rs * gmmax);
+                sh = ldexpf(1.0f, -e_r[r]); sl = ldexpf(1.0f, 11 - e_r[r]);
+            }
             if (FULL) { mu_r[r] = mu; rs_r[r] = rs; }
-            else if (threadIdx.x == 0) { mean[row] = mu; rstd[row] = rs; }
+            else if (threadIdx.x == 0) { mean[row] = mu; rstd[row] = rs; if constexpr (MX) pl.scale8[row] = (unsigned char)(e_r[r] + 127); }
             const v2 nmr = splat2(-mu * rs), rs2 = splat2(rs);
             v2 gh[4], y[4];
 #pragma unroll
@@ -362,7 +416,17 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
             if (!(FS_DIAG & 2) || eps < 0.f) Ch8<T>::store(h2 + row * Fp + col, y);
             if (!(FS_DIAG & 4) || eps < 0.f) { if (TRAIN || gh_out) Ch8<T>::store(gh_out + row * Fp + col, gh); }
 #else
-            if constexpr (PL) store_planes8(h2 + row * Fp + col, (T*)pl.h2_lo + row * Fp + col, y);
+            if constexpr (MX) {
+                store_mx8(h2 + row * Fp + col, pl.h2_8 + row * (2 * (size_t)Fp) + col, pl.h2_8 + pl.h2_8_stride + row * (2 * (size_t)Fp) + col, y, sh, sl);
+                // the row's tail up to a whole 128-byte fp8 k-tile is zero (omlm_gemm_mx16 reads it): written here, the planes need no zero fill
+                if ((int)threadIdx.x < ((((Fp + 127) & ~127) - Fp) >> 3)) {
+                    unsigned char* z8 = pl.h2_8 + row * (2 * (size_t)Fp) + Fp + 8 * threadIdx.x;
+                    u32x2 z; z[0] = 0u; z[1] = 0u;
+                    *(u32x2*)z8 = z;
+                    *(u32x2*)(z8 + pl.h2_8_stride) = z;
+                }
+            }
+            else if constexpr (PL) store_planes8(h2 + row * Fp + col, (T*)pl.h2_lo + row * Fp + col, y);
             else Ch8<T>::store(h2 + row * Fp + col, y);
             if (TRAIN || gh_out) Ch8<T>::store(gh_out + row * Fp + col, gh);
 #endif
@@ -376,6 +440,12 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
             for (int r = 1; r < RB_; ++r) { m = q == r ? mu_r[r] : m; s_ = q == r ? rs_r[r] : s_; }
             mean[row0 + tb + q] = m;
             rstd[row0 + tb + q] = s_;
+            if constexpr (MX) {
+                int e_ = e_r[0];
+#pragma unroll
+                for (int r = 1; r < RB_; ++r) e_ = q == r ? e_r[r] : e_;
+                pl.scale8[row0 + tb + q] = (unsigned char)(e_ + 127);
+            }
         }
     };
     int it = 0, tb = t0;
@@ -627,10 +697,10 @@ static int strip_rows(int nseq, int target) {
 
 bool ffmid2_supported(int Fp) { return Fp % 8 == 0 && Fp / 8 <= 512; }
 
-template <typename T, bool PL = false>
+template <typename T, bool PL = false, bool MX = false>
 static int fwd_launch_t(const void* h1, const void* convw, const void* gamma, void* h2, float* mean, float* rstd, int M, int nseq,
                         int F, int Fp, float eps, float p, unsigned long long seed, const unsigned long long* seed_dev,
-                        unsigned char* drop_bits, void* gh, hipStream_t st, const FfPlanes pl = FfPlanes{0, 0, 0, nullptr}) {
+                        unsigned char* drop_bits, void* gh, hipStream_t st, const FfPlanes pl = FfPlanes{0, 0, 0, nullptr, nullptr, 0, nullptr}) {
     const int B = M / nseq;
     const int RB = strip_rows(nseq, 36);
     const int strips = (nseq + RB - 1) / RB;
@@ -638,9 +708,9 @@ static int fwd_launch_t(const void* h1, const void* convw, const void* gamma, vo
     const int nthr = Fp / 8;                                                   // threads launched: one per chunk
     dim3 grid(B * strips);
     const bool train = p > 0.f && drop_bits != nullptr && gh != nullptr;       // the training call: all three row stores are unconditional
-#define FF2_FWD(NT_) do { if (train) hipLaunchKernelGGL((ffmid2_fwd_kernel<T, NT_, true, PL>), grid, dim3(nthr), 0, st, (const T*)h1, (const T*)convw, \
+#define FF2_FWD(NT_) do { if (train) hipLaunchKernelGGL((ffmid2_fwd_kernel<T, NT_, true, PL, MX>), grid, dim3(nthr), 0, st, (const T*)h1, (const T*)convw, \
         (const T*)gamma, (T*)h2, mean, rstd, nseq, F, Fp, RB, strips, eps, p, seed, seed_dev, drop_bits, (T*)gh, pl); \
-    else hipLaunchKernelGGL((ffmid2_fwd_kernel<T, NT_, false, PL>), grid, dim3(nthr), 0, st, (const T*)h1, (const T*)convw, \
+    else hipLaunchKernelGGL((ffmid2_fwd_kernel<T, NT_, false, PL, MX>), grid, dim3(nthr), 0, st, (const T*)h1, (const T*)convw, \
         (const T*)gamma, (T*)h2, mean, rstd, nseq, F, Fp, RB, strips, eps, p, seed, seed_dev, drop_bits, (T*)gh, pl); } while (0)
     switch (nt) {
         case 64: FF2_FWD(64); break;
@@ -675,8 +745,24 @@ int ffmid2_fwd_planes_launch(const void* h1, const void* h1_lo, const void* conv
     pl.convw_lo = (const h16_t*)convw_lo - (const h16_t*)convw;
     pl.gamma_lo = (const h16_t*)gamma_lo - (const h16_t*)gamma;
     pl.h2_lo = h2_lo;
+    pl.h2_8 = nullptr; pl.h2_8_stride = 0; pl.scale8 = nullptr;
     return fwd_launch_t<h16_t, true>(h1, convw, gamma, h2, mean, rstd, M, nseq, F, Fp, eps, p, seed, seed_dev, drop_bits, gh, st, pl);
 }
+
+#if OMLM_FP16
+// the plane forward with h2 leaving in omlm_gemm_mx16's operand form: half hi plane + fp8 planes [hi8 | lo8] (row pitch 2 Fp bytes) + row scales
+int ffmid2_fwd_mx_launch(const void* h1, const void* h1_lo, const void* convw, const void* convw_lo, const void* gamma, const void* gamma_lo,
+                         void* h2, void* h2_8, long long h2_8_stride, unsigned char* scale8, float* mean, float* rstd, int M, int nseq, int F, int Fp,
+                         float eps, float p, unsigned long long seed, const unsigned long long* seed_dev, unsigned char* drop_bits, void* gh, hipStream_t st) {
+    FfPlanes pl;
+    pl.h1_lo = (const h16_t*)h1_lo - (const h16_t*)h1;
+    pl.convw_lo = (const h16_t*)convw_lo - (const h16_t*)convw;
+    pl.gamma_lo = (const h16_t*)gamma_lo - (const h16_t*)gamma;
+    pl.h2_lo = nullptr;
+    pl.h2_8 = (unsigned char*)h2_8; pl.h2_8_stride = h2_8_stride; pl.scale8 = scale8;
+    return fwd_launch_t<h16_t, true, true>(h1, convw, gamma, h2, mean, rstd, M, nseq, F, Fp, eps, p, seed, seed_dev, drop_bits, gh, st, pl);
+}
+#endif
 
 // bc: [M][2] floats of scratch; part_g: [>= rowsum blocks][Fp]; part_c: [>= NY][2F*3]
 template <typename T>

@@ -127,6 +127,125 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_row1_kernel(const float* __
     }
 }
 
+#if OMLM_FP16
+// ---- LayerNorm forward for omlm_gemm_mx16 (round 6): y as the half hi plane PLUS the two fp8 planes and the row scale ----------------------------
+// The FF-in GEMM of precision "fp16ff" multiplies y_hi on the half matrix cores and corrects with fp8 products (csrc/gemm_mx.hip): per row one
+// power-of-two scale 2^e with |y| <= 2^(e + 8), hi8 = e4m3(y_hi 2^-e), lo8 = e4m3((y - y_hi) 2^-(e - 11)).  The scale must be known before the
+// row is written, so it comes from a BOUND the first reduction round already yields: |y_i| <= max(xmax - mean, mean - xmin) rstd max|gamma|
+// (row max / min ride with the row sum: no extra barrier).  fp8 plane rows have the pitch of the half plane in bytes (2 ldy), the lo8 plane
+// y8_stride bytes behind the hi8 plane; scale8[row] = e + 127 (E8M0).
+// hi plane (half), hi8 / lo8 bytes of four consecutive outputs; sh = 2^-e, sl = 2^-(e - 11)
+__device__ __forceinline__ void store4_mx(h16_t* y, unsigned char* y8h, unsigned char* y8l, float a, float b, float c, float d, float sh, float sl) {
+    u32x2 o;
+    o[0] = pack_h16_rne(a, b);
+    o[1] = pack_h16_rne(c, d);
+    const float ha = h16_lo_to_f(o[0]), hb = h16_hi_to_f(o[0]), hc = h16_lo_to_f(o[1]), hd = h16_hi_to_f(o[1]);
+    *(u32x2*)y = o;
+    *(unsigned*)y8h = pack4_fp8(ha * sh, hb * sh, hc * sh, hd * sh);
+    *(unsigned*)y8l = pack4_fp8((a - ha) * sl, (b - hb) * sl, (c - hc) * sl, (d - hd) * sl);
+}
+
+template <int MAXV>
+__global__ __launch_bounds__(LN_THREADS) void ln_fwd_mx_kernel(const float* __restrict__ x, const float* __restrict__ gamma, h16_t* __restrict__ y,
+                                                               unsigned char* __restrict__ y8, long long y8_stride, unsigned char* __restrict__ scale8,
+                                                               float* __restrict__ mean, float* __restrict__ rstd, int M, int D, int ldy, float eps) {
+    constexpr int NW = LN_THREADS / 64;
+    __shared__ float red[2][4][NW];                     // [parity][sum | max | min | sum of squares][wave]
+    __shared__ float gred[NW];
+    const int nv = D / 4, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 g[MAXV];
+    float gm = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = threadIdx.x + i * LN_THREADS;
+        g[i] = c < nv ? ((const float4*)gamma)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        gm = fmaxf(fmaxf(gm, fmaxf(fabsf(g[i].x), fabsf(g[i].y))), fmaxf(fabsf(g[i].z), fabsf(g[i].w)));
+    }
+    gm = wave_max(gm);
+    if (lane == 0) gred[wave] = gm;
+    __syncthreads();
+    gm = gred[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) gm = fmaxf(gm, gred[w]);
+    int par = 0;
+    for (int row = blockIdx.x; row < M; row += gridDim.x, par ^= 1) {
+        const float4* xr = (const float4*)(x + (size_t)row * D);
+        float4 v[MAXV];
+        float s = 0.f, hi = -3.0e38f, lo = 3.0e38f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = threadIdx.x + i * LN_THREADS;
+            if (c < nv) {
+                v[i] = xr[c];
+                s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+                hi = fmaxf(fmaxf(hi, fmaxf(v[i].x, v[i].y)), fmaxf(v[i].z, v[i].w));
+                lo = fminf(fminf(lo, fminf(v[i].x, v[i].y)), fminf(v[i].z, v[i].w));
+            }
+        }
+        s = wave_sum(s); hi = wave_max(hi); lo = -wave_max(-lo);
+        if (lane == 0) { red[par][0][wave] = s; red[par][1][wave] = hi; red[par][2][wave] = lo; }
+        __syncthreads();
+        float t = 0.f, xmax = -3.0e38f, xmin = 3.0e38f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { t += red[par][0][w]; xmax = fmaxf(xmax, red[par][1][w]); xmin = fminf(xmin, red[par][2][w]); }
+        const float mu = t / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = threadIdx.x + i * LN_THREADS;
+            if (c < nv) {
+                const float a = v[i].x - mu, b = v[i].y - mu, cc = v[i].z - mu, d = v[i].w - mu;
+                q += (a * a + b * b) + (cc * cc + d * d);
+            }
+        }
+        q = wave_sum(q);
+        if (lane == 0) red[par][3][wave] = q;
+        __syncthreads();                                           // parity `par` is rewritten two rows later, two barriers past its last read
+        float u = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) u += red[par][3][w];
+        const float rs = rsqrtf(u / (float)D + eps);
+        const int e = mx_row_exp(fmaxf(xmax - mu, mu - xmin) * rs * gm);
+        const float sh = ldexpf(1.0f, -e), sl = ldexpf(1.0f, 11 - e);
+        if (threadIdx.x == 0) { mean[row] = mu; rstd[row] = rs; scale8[row] = (unsigned char)(e + 127); }
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = threadIdx.x + i * LN_THREADS;
+            if (c < nv) {
+                unsigned char* p8 = y8 + (size_t)row * (2 * (size_t)ldy) + 4 * c;
+                store4_mx(y + (size_t)row * ldy + 4 * c, p8, p8 + y8_stride, (v[i].x - mu) * rs * g[i].x, (v[i].y - mu) * rs * g[i].y,
+                          (v[i].z - mu) * rs * g[i].z, (v[i].w - mu) * rs * g[i].w, sh, sl);
+            }
+        }
+        // the row's tail up to a whole 128-byte fp8 k-tile is zero (omlm_gemm_mx16 reads it): written here, so the planes need no zero fill
+        const int tail4 = (((D + 127) & ~127) - D) >> 2;
+        if ((int)threadIdx.x < tail4) {
+            unsigned char* p8 = y8 + (size_t)row * (2 * (size_t)ldy) + D + 4 * threadIdx.x;
+            *(unsigned*)p8 = 0u;
+            *(unsigned*)(p8 + y8_stride) = 0u;
+        }
+    }
+}
+}   // namespace OMLM_NS
+using namespace OMLM_NS;
+// y: half hi plane [M, ldy]; y8: fp8 planes [hi8 | lo8] at row pitch 2 ldy bytes, the lo8 plane y8_stride bytes behind the hi8 plane; scale8 [M]
+// E8M0 (include/omlm.h).  The hi plane and the statistics are omlm_layernorm_fwd's (bit for bit at D = 1024).
+extern "C" int omlm_layernorm_fwd_mx(const float* x, const float* gamma, void* y, void* y8, long long y8_stride, unsigned char* scale8,
+                                     float* mean, float* rstd, int M, int D, int ldy, float eps, void* stream) {
+    if (M <= 0) return OMLM_OK;
+    OMLM_CHECK_ARG(x && gamma && y && y8 && scale8 && mean && rstd, "null pointer");
+    OMLM_CHECK_ARG(D % 4 == 0 && D <= 4 * LN_THREADS * LN_MAXV, "D must be a multiple of 4 and <= 4096");
+    OMLM_CHECK_ARG(ldy >= D && ldy % 4 == 0 && y8_stride >= (long long)M * 2 * ldy, "ldy / plane stride");
+    dim3 grid(M < 2048 ? M : 2048), block(LN_THREADS);
+    if (D <= 4 * LN_THREADS)
+        hipLaunchKernelGGL((ln_fwd_mx_kernel<1>), grid, block, 0, as_stream(stream), x, gamma, (h16_t*)y, (unsigned char*)y8, y8_stride, scale8, mean, rstd, M, D, ldy, eps);
+    else
+        hipLaunchKernelGGL((ln_fwd_mx_kernel<LN_MAXV>), grid, block, 0, as_stream(stream), x, gamma, (h16_t*)y, (unsigned char*)y8, y8_stride, scale8, mean, rstd, M, D, ldy, eps);
+    return omlm_post_launch("omlm_layernorm_fwd_mx");
+}
+namespace OMLM_NS {
+#endif
+
 // dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma ; dgamma += dy * xhat
 // A thread owns fixed columns, so dgamma is accumulated in registers over the block's rows and
 // flushed with one atomic per column per block.

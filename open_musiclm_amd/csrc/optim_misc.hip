@@ -219,6 +219,65 @@ extern "C" int omlm_cast_pad_group(const omlm_cast_pad_desc* d, int count, int o
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// fp8 planes of fp32 weights for omlm_gemm_mx16 (round 6, csrc/gemm_mx.hip), all problems of a model in ONE launch: with hi = rne_half(w) (the
+// half operand plane the re-pack above writes) and lo = w - hi, row r gets the scale 2^e with max_c |hi| <= 2^(e + 8) and
+//   dst8[r, c] = e4m3(hi 2^-e),  (dst8 + lo_stride)[r, c] = e4m3(lo 2^-(e - 11)),  scale8[r] = e + 127      (row pitch ld8 bytes).
+// Bytes behind column C of a row are left alone (the caller's buffer is zero-filled once: omlm_gemm_mx16 wants zeros up to ceil128(K)).
+struct omlm_quant_rows_desc { const float* src; unsigned char* dst8; long long lo_stride; unsigned char* scale8; int R, C, ld_src, ld8; };     // include/omlm.h
+struct QuantGroupArgs { int n; int start[OMLM_CAST_GROUP_MAX + 1]; omlm_quant_rows_desc d[OMLM_CAST_GROUP_MAX]; };
+__global__ __launch_bounds__(256) void quant_rows_mx_kernel(QuantGroupArgs ga) {
+    __shared__ float red[4];
+    int pi = 0;
+    for (int i = 1; i < ga.n; ++i) if ((int)blockIdx.x >= ga.start[i]) pi = i;           // uniform scalar scan (starts ascend)
+    const omlm_quant_rows_desc q = ga.d[pi];
+    const int blk = blockIdx.x - ga.start[pi], nblk = ga.start[pi + 1] - ga.start[pi];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = blk; r < q.R; r += nblk) {
+        const float* sr = q.src + (size_t)r * q.ld_src;
+        float m = 0.f;
+        for (int c = threadIdx.x; c < q.C; c += 256) m = fmaxf(m, fabsf((float)(f16_t)sr[c]));
+        m = wave_max(m);
+        __syncthreads();                                   // (red is re-used row after row)
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        const int e = mx_row_exp(m);
+        const float sh = ldexpf(1.0f, -e), sl = ldexpf(1.0f, 11 - e);
+        if (threadIdx.x == 0) q.scale8[r] = (unsigned char)(e + 127);
+        unsigned char* d8 = q.dst8 + (size_t)r * q.ld8;
+        for (int c = threadIdx.x * 4; c < q.C; c += 1024) {
+            float w[4], h[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) { w[x] = c + x < q.C ? sr[c + x] : 0.f; h[x] = (float)(f16_t)w[x]; }
+            *(unsigned*)(d8 + c) = pack4_fp8(h[0] * sh, h[1] * sh, h[2] * sh, h[3] * sh);
+            *(unsigned*)(d8 + q.lo_stride + c) = pack4_fp8((w[0] - h[0]) * sl, (w[1] - h[1]) * sl, (w[2] - h[2]) * sl, (w[3] - h[3]) * sl);
+        }
+    }
+}
+extern "C" int omlm_quant_rows_mx(const omlm_quant_rows_desc* d, int count, void* stream) {
+    if (count <= 0) return OMLM_OK;
+    OMLM_CHECK_ARG(d != nullptr, "null descriptor array");
+    for (int base = 0; base < count; base += OMLM_CAST_GROUP_MAX) {
+        const int n = count - base < OMLM_CAST_GROUP_MAX ? count - base : OMLM_CAST_GROUP_MAX;
+        QuantGroupArgs ga;
+        memset(&ga, 0, sizeof(ga));
+        ga.n = n;
+        int start = 0;
+        for (int i = 0; i < n; ++i) {
+            const omlm_quant_rows_desc& q = d[base + i];
+            OMLM_CHECK_ARG(q.src && q.dst8 && q.scale8 && q.R > 0 && q.C > 0 && q.ld_src >= q.C && q.ld8 >= (q.C + 3) / 4 * 4 && q.ld8 % 4 == 0 &&
+                           q.lo_stride % 4 == 0 && ((uintptr_t)q.dst8 % 4) == 0, "quant_rows_mx: bad problem");
+            ga.d[i] = q;
+            ga.start[i] = start;
+            start += q.R < 1024 ? q.R : 1024;
+        }
+        ga.start[n] = start;
+        hipLaunchKernelGGL(quant_rows_mx_kernel, dim3(start), dim3(256), 0, as_stream(stream), ga);
+    }
+    return omlm_post_launch("omlm_quant_rows_mx");
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // dst[r, c] = (T) src[r, c] for c < C ; 0 for C <= c < ldd.   (weight repack / operand casts)
 template <typename T>
 __global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__ src, T* __restrict__ dst, long long R, int C, int lds_, int ldd) {

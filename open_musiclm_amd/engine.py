@@ -70,6 +70,13 @@ _QKNORM_FUSED = os.environ.get("OMLM_QKNORM_FUSED", "1") == "1"
 # determinism; OMLM_RELPOS_FUSED=0: the layer-by-layer path.
 _RELPOS_FUSED = os.environ.get("OMLM_RELPOS_FUSED", "1") == "1"
 _LN_COLSUM_GROUP = os.environ.get("OMLM_LN_COLSUM_GROUP", "1") == "1"    # 0: every LayerNorm backward sums its own d(gamma) partial rows
+
+
+def ff_mx_enabled() -> bool:
+    """precision "fp16ff": FF-in / FF-out as one half product + two fp8 correction products at twice the matrix rate (ops.gemm_mx16, round 6) instead
+    of three half products (ops.gemm_planes16, round 5).  What the fp8 corrections leave in the logits: profiles/r06_error_budget_fp8corr.md.
+    OMLM_FF_MX=0 (read when the weights are prepared): the three-product form."""
+    return os.environ.get("OMLM_FF_MX", "1") == "1"
 _SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 
 
@@ -239,6 +246,8 @@ class PreparedWeights:
         self.precision = precision
         self.T = _PRECISIONS[precision]
         self.ff3 = precision == "fp16ff"          # FF forward on hi/lo planes: lo planes of W1p / W2p / taps / gamma next to the usual images
+        self.mx = self.ff3 and ff_mx_enabled()    # ... with the FF GEMMs' correction products on fp8 planes (W1p8 / W2p8: ops.Fp8Planes)
+        quants = ops.QuantRowsGroup()
         T = self.T
         dev = model.start_tokens[0].device
         D = tr.dim
@@ -285,6 +294,18 @@ class PreparedWeights:
                 packs.add(w1.detach()[F:], W1l[Fp:], F, D, D, D, lo=True)
                 packs.add(w2.detach(), W2l, D, F, F, Fp, lo=True)
                 ent["W1p_lo"], ent["W2p_lo"], ent["convw_lo"], ent["gamma_mid_lo"] = W1l, W2l, convl, gammal
+            if self.mx:
+                mkey = bkey + ("mx",)
+                if not persistent or mkey not in wbuf:
+                    m8 = (ops.Fp8Planes(2 * Fp, D, dev), ops.Fp8Planes(D, Fp, dev))      # zero-filled once: pad rows / row tails stay zero
+                    if persistent:
+                        wbuf[mkey] = m8
+                else:
+                    m8 = wbuf[mkey]
+                quants.add(w1.detach(), m8[0], 0, F, D, D)
+                quants.add(w1.detach()[F:], m8[0], Fp, F, D, D)
+                quants.add(w2.detach(), m8[1], 0, D, F, F)
+                ent["W1p8"], ent["W2p8"] = m8
             if T in _H16 and with_transposes:
                 # k-contiguous W^T copies: every input-gradient GEMM (dX = dY W) then runs in the fast NT form
                 def wt(w, R, C, rows_pad=None, cols_pad=None):
@@ -326,6 +347,7 @@ class PreparedWeights:
                 packs.add(w.detach().reshape(-1, D), lo.view(-1, D), w.numel() // D, D, D, D, lo=True)
                 self.heads_lo.append(lo)
         packs.flush()
+        quants.flush()
         self.heads = []
         self.headsT = []
         for w in model.logit_weights:
@@ -528,7 +550,14 @@ def trunk_forward(tr, pw: PreparedWeights, x: torch.Tensor, keymask: Optional[to
         m2 = torch.empty(M, device=dev); r2 = torch.empty(M, device=dev)
         xn2 = torch.empty(M, D, dtype=T, device=dev)
         h1 = torch.empty(M, 2 * Fp, dtype=T, device=dev)
-        if pw.ff3:
+        if pw.mx:
+            # "fp16ff", round 6: the FF GEMMs as one half product + two fp8 corrections.  The LayerNorm (and, below, the conv-GEGLU-LN kernel)
+            # leaves the hi plane -- what the fp16 backward keeps -- plus fp8 planes and row scales that die with the layer
+            P1 = ops.Fp8Planes(M, D, dev, zero=False)
+            ops.layernorm_fwd_mx(x1, ff.norm_in.gamma.detach(), xn2, P1, m2, r2)
+            h1_lo = torch.empty(M, 2 * Fp, dtype=T, device=dev)
+            ops.gemm_mx16(xn2, P1, w["W1p"], w["W1p8"], h1, h1_lo, M=M, N=2 * Fp, K=D)
+        elif pw.ff3:
             # "fp16ff": LN output, h1 and h2 exist as hi/lo planes during this layer's forward; the lo planes die with the layer (their
             # consumers are the next launches of this stream), the hi planes are what the fp16 backward keeps
             xn2_lo = torch.empty(M, D, dtype=T, device=dev)
@@ -549,15 +578,22 @@ def trunk_forward(tr, pw: PreparedWeights, x: torch.Tensor, keymask: Optional[to
         gh = torch.empty(M, Fp, dtype=T, device=dev) if (save and _FF_SAVE_GH) else None
         x2 = torch.empty(M, D, device=dev)
         if pw.ff3:
-            h2_lo = torch.empty(M, Fp, dtype=T, device=dev)
-            ops.ffmid_fwd_planes(h1, h1_lo, w["convw"], w["convw_lo"], w["gamma_mid"], w["gamma_mid_lo"], h2, h2_lo, m3, r3, N, F, Fp, p, seed,
+            if pw.mx:
+                P2 = ops.Fp8Planes(M, Fp, dev, zero=False)
+                ops.ffmid_fwd_mx(h1, h1_lo, w["convw"], w["convw_lo"], w["gamma_mid"], w["gamma_mid_lo"], h2, P2, m3, r3, N, F, Fp, p, seed,
                                  seed_dev=salt if p > 0 else None, drop_bits=drop_bits, gh=gh)
-            ops.gemm_planes16(h2, h2_lo, w["W2p"], w["W2p_lo"], x2, M=M, N=D, K=Fp, Cin=x1)
+                ops.gemm_mx16(h2, P2, w["W2p"], w["W2p8"], x2, M=M, N=D, K=Fp, Cin=x1)
+            else:
+                h2_lo = torch.empty(M, Fp, dtype=T, device=dev)
+                ops.ffmid_fwd_planes(h1, h1_lo, w["convw"], w["convw_lo"], w["gamma_mid"], w["gamma_mid_lo"], h2, h2_lo, m3, r3, N, F, Fp, p, seed,
+                                     seed_dev=salt if p > 0 else None, drop_bits=drop_bits, gh=gh)
+                ops.gemm_planes16(h2, h2_lo, w["W2p"], w["W2p_lo"], x2, M=M, N=D, K=Fp, Cin=x1)
+                del xn2_lo, h2_lo
             if keep_h1_lo_tail and save:
                 take = min(2, N)
                 sv.h1_lo_tail = torch.zeros(B, 2, 2 * Fp, device=dev)
                 sv.h1_lo_tail[:, 2 - take:].copy_(h1_lo.view(B, N, -1)[:, N - take:])
-            del xn2_lo, h1_lo, h2_lo
+            del h1_lo
         else:
             ops.ffmid_fwd(h1, w["convw"], w["gamma_mid"], h2, m3, r3, N, F, Fp, p, seed, seed_dev=salt if p > 0 else None,
                           drop_bits=drop_bits, gh=gh)

@@ -24,12 +24,17 @@ SIGNATURES = {
     "omlm_version": [],
     "omlm_last_error": [],
     "omlm_set_error": [C.c_char_p],
-    "omlm_gemm": [vp, vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp],
+    "omlm_gemm": [vp, vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, i64, vp],
+    "omlm_gemm_tail_workspace_bytes": [i32, i32],
     "omlm_gemm_wgrad_group": [vp, i32, i32, i32, vp],
-    "omlm_gemm_planes": [vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp],
+    "omlm_gemm_planes": [vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, i64, vp],
     "omlm_split_planes": [vp, vp, i64, i64, vp],
-    "omlm_gemm_set_tail_workspace": [vp, i64],
-    "omlm_gemm_planes16": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "omlm_gemm_planes16": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, vp],
+    "omlm_gemm_mx16": [vp, vp, i64, vp, vp, vp, i64, vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, i32, i32, i32, vp, i64, vp],
+    "omlm_gemm_mx16_workspace_bytes": [i32, i32, i32],
+    "omlm_layernorm_fwd_mx": [vp, vp, vp, vp, i64, vp, vp, vp, i32, i32, i32, f32, vp],
+    "omlm_ffmid_fwd_mx": [vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, i32, i32, i32, i32, f32, f32, u64, vp, vp, vp, vp],
+    "omlm_quant_rows_mx": [vp, i32, vp],
     "omlm_layernorm_fwd_planes": [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp],
     "omlm_ffmid_fwd_planes": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, u64, vp, vp, vp, i32, vp],
     "omlm_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp],
@@ -82,7 +87,7 @@ SIGNATURES = {
     "omlm_sample_topk_gumbel": [vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
     "omlm_probe_tr16": [vp, vp],
 }
-_RESTYPES = {"omlm_last_error": C.c_char_p, "omlm_ffmid_bwd_workspace_bytes": C.c_longlong,
+_RESTYPES = {"omlm_last_error": C.c_char_p, "omlm_gemm_tail_workspace_bytes": C.c_longlong, "omlm_gemm_mx16_workspace_bytes": C.c_longlong, "omlm_ffmid_bwd_workspace_bytes": C.c_longlong,
              "omlm_attn_bias_table_floats": C.c_longlong, "omlm_mqa_attn_bwd_workspace_bytes": C.c_longlong,
              "omlm_layernorm_bwd_workspace_bytes": C.c_longlong, "omlm_set_error": None}
 

@@ -85,23 +85,22 @@ def operand_planes(t: torch.Tensor, rows: int, ld: int):
     return buf, pe * 2
 
 
-_TAIL_WS = {}                  # device index -> workspace of the GEMM tails' deterministic split-K (omlm_gemm_set_tail_workspace)
-_TAIL_WS_CURRENT = [None]
+_TAIL_WS = {}                  # (device index, stream) -> workspace of the GEMM tails' deterministic split-K: a per-call argument of the library
 _TAIL_WS_BYTES = int(os.environ.get("OMLM_GEMM_TAIL_WS_MB", "64")) << 20
 
 
-def _ensure_tail_workspace(device: torch.device):
-    """The library keeps ONE (pointer, device) pair: hand it this device's buffer whenever the device of the launches changes."""
+def tail_workspace(device: torch.device):
+    """(pointer, bytes) of the CURRENT stream's split-K scratch on `device` (include/omlm.h: the buffer belongs to the call, one per stream that
+    launches GEMMs concurrently).  A stream that is capturing gets its own buffer from the graph's pool: it lives as long as the graph that
+    replays its launches."""
+    if _TAIL_WS_BYTES <= 0:
+        return None, 0
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    if _TAIL_WS_CURRENT[0] == idx:
-        return
-    if _TAIL_WS_BYTES > 0:
-        if idx not in _TAIL_WS:
-            if torch.cuda.is_current_stream_capturing():      # never from a graph's private pool: the first eager launch will bring it
-                return
-            _TAIL_WS[idx] = torch.empty(_TAIL_WS_BYTES // 4, device=device)
-        call("omlm_gemm_set_tail_workspace", ptr(_TAIL_WS[idx]), _TAIL_WS_BYTES)
-    _TAIL_WS_CURRENT[0] = idx
+    key = (idx, torch.cuda.current_stream(device).cuda_stream)
+    buf = _TAIL_WS.get(key)
+    if buf is None:
+        buf = _TAIL_WS[key] = torch.empty(_TAIL_WS_BYTES // 4, device=device)
+    return ptr(buf), _TAIL_WS_BYTES
 
 
 def gemm(A: torch.Tensor, B: torch.Tensor, C_: torch.Tensor, *, M: int, N: int, K: int,
@@ -121,19 +120,18 @@ def gemm(A: torch.Tensor, B: torch.Tensor, C_: torch.Tensor, *, M: int, N: int, 
         ldcin = ldcin if ldcin is not None else Cin.shape[-1]
     a_rows = a_rows if a_rows is not None else A.numel() // lda
     b_rows = b_rows if b_rows is not None else B.numel() // ldb
-    if A.dtype in H16:
-        _ensure_tail_workspace(A.device)
+    ws, wsb = tail_workspace(A.device) if (A.dtype in H16 or A.dtype == torch.float32) else (None, 0)
     if (A.dtype == torch.float32 and planes and _X3_PLANES and M * N * K >= _X3_MIN_MACS and not (a_kmajor and a_map is not None)
             and not (b_kmajor and b_map is not None) and (a_kmajor and b_kmajor or K % 8 == 0)):
         pa, sa = operand_planes(A, a_rows, lda)
         pb, sb = operand_planes(B, b_rows, ldb)
         call("omlm_gemm_planes", ptr(pa), sa, ptr(pb), sb, ptr(C_), ptr(Cin), ptr(a_map), ptr(b_map), ptr(c_map),
              a_rows, b_rows, M, N, K, lda, ldb, ldc, ldcin or 0, int(a_kmajor), int(b_kmajor), dcode(C_.dtype), float(alpha),
-             stream_ptr())
+             ws, wsb, stream_ptr())
         return
     call("omlm_gemm", ptr(A), ptr(B), ptr(C_), ptr(Cin), ptr(a_map), ptr(b_map), ptr(c_map),
          a_rows, b_rows, M, N, K, lda, ldb, ldc, ldcin or 0, int(a_kmajor), int(b_kmajor),
-         dcode(A.dtype), dcode(C_.dtype), float(alpha), stream_ptr())
+         dcode(A.dtype), dcode(C_.dtype), float(alpha), ws, wsb, stream_ptr())
 
 
 def gemm_planes16(A, A_lo, B, B_lo, C_, C_lo=None, *, M: int, N: int, K: int, Cin: Optional[torch.Tensor] = None, a_map=None, c_map=None,
@@ -150,10 +148,45 @@ def gemm_planes16(A, A_lo, B, B_lo, C_, C_lo=None, *, M: int, N: int, K: int, Ci
         assert C_.dtype == A.dtype and C_lo.dtype == A.dtype and C_lo.shape == C_.shape and Cin is None
     lda, ldb = A.shape[-1], B.shape[-1]
     ldc = ldc if ldc is not None else C_.shape[-1]
-    _ensure_tail_workspace(A.device)
+    ws, wsb = tail_workspace(A.device)
     call("omlm_gemm_planes16", ptr(A), ptr(A_lo), ptr(B), ptr(B_lo), ptr(C_), ptr(C_lo), ptr(Cin), ptr(a_map), ptr(c_map),
          a_rows if a_rows is not None else A.numel() // lda, b_rows if b_rows is not None else B.numel() // ldb,
-         M, N, K, lda, ldb, ldc, Cin.shape[-1] if Cin is not None else 0, dcode(A.dtype), stream_ptr())
+         M, N, K, lda, ldb, ldc, Cin.shape[-1] if Cin is not None else 0, dcode(A.dtype), ws, wsb, stream_ptr())
+
+
+class Fp8Planes:
+    """The fp8 companions of a half operand [rows, ld] for omlm_gemm_mx16: planes [2, rows padded to 256, 2 ld] bytes (hi8, lo8; element k of a row
+    at byte k, zero up to the next multiple of 128) and one E8M0 scale byte per row.  Written by layernorm_fwd_mx / ffmid_fwd_mx (which also
+    write their rows' zero tails: zero=False is enough for them) / QuantRowsGroup (weights: persistent, zero-filled once)."""
+    __slots__ = ("planes", "scale", "rows", "ld")
+
+    def __init__(self, rows: int, ld: int, device, zero: bool = True):
+        self.rows, self.ld = int(rows), int(ld)
+        rp = (self.rows + 255) // 256 * 256
+        # bytes [K, ceil128(K)) of every real row must be zeros (an fp8 NaN byte there would poison the row's outputs); pad rows and their
+        # scales only ever reach output rows >= M, which no epilogue stores
+        self.planes = (torch.zeros if zero else torch.empty)(2, rp, 2 * self.ld, dtype=torch.uint8, device=device)
+        self.scale = (torch.full((rp,), 127, dtype=torch.uint8, device=device) if zero else torch.empty(rp, dtype=torch.uint8, device=device))
+
+    @property
+    def stride(self) -> int:
+        return self.planes.shape[1] * self.planes.shape[2]
+
+
+def gemm_mx16(A, A8: Fp8Planes, B, B8: Fp8Planes, C_, C_lo=None, *, M: int, N: int, K: int, Cin: Optional[torch.Tensor] = None):
+    """C = A B^T (+ Cin): the half product of the hi planes plus the two correction products on fp8 at twice the matrix rate (omlm_gemm_mx16)."""
+    hip.require_gpu(A, "A")
+    assert A.dtype == torch.float16 and B.dtype == torch.float16
+    lda, ldb = A.shape[-1], B.shape[-1]
+    assert A8.ld == lda and B8.ld == ldb and A8.rows >= M and B8.rows >= N
+    if C_lo is None:
+        assert C_.dtype == torch.float32 and (Cin is None or Cin.dtype == torch.float32)
+    else:
+        assert C_.dtype == A.dtype and C_lo.dtype == A.dtype and C_lo.shape == C_.shape and Cin is None
+    ws, wsb = tail_workspace(A.device)
+    call("omlm_gemm_mx16", ptr(A), ptr(A8.planes), A8.stride, ptr(A8.scale), ptr(B), ptr(B8.planes), B8.stride, ptr(B8.scale),
+         ptr(C_), ptr(C_lo), ptr(Cin), A.numel() // lda, B.numel() // ldb, M, N, K, lda, ldb, C_.shape[-1],
+         Cin.shape[-1] if Cin is not None else 0, ws, wsb, stream_ptr())
 
 
 class _WgradDesc(C.Structure):
@@ -237,6 +270,44 @@ def layernorm_fwd_planes(x, gamma, y, y_lo, mean, rstd, eps=1e-5):
     assert y.dtype in H16 and y_lo.dtype == y.dtype and y_lo.shape == y.shape
     call("omlm_layernorm_fwd_planes", ptr(x), ptr(gamma), ptr(y), ptr(y_lo), ptr(mean), ptr(rstd),
          M, D, y.shape[-1], float(eps), dcode(y.dtype), stream_ptr())
+
+
+def layernorm_fwd_mx(x, gamma, y, P: "Fp8Planes", mean, rstd, eps=1e-5):
+    """layernorm_fwd with y as omlm_gemm_mx16's A operand: the half hi plane y (bit for bit layernorm_fwd's) + its fp8 planes and row scales in P."""
+    M, D = x.shape
+    assert y.dtype == torch.float16 and P.ld == y.shape[-1] and P.rows >= M
+    call("omlm_layernorm_fwd_mx", ptr(x), ptr(gamma), ptr(y), ptr(P.planes), P.stride, ptr(P.scale), ptr(mean), ptr(rstd),
+         M, D, y.shape[-1], float(eps), stream_ptr())
+
+
+class _QuantDesc(C.Structure):
+    """omlm_quant_rows_desc (include/omlm.h)"""
+    _fields_ = [("src", C.c_void_p), ("dst8", C.c_void_p), ("lo_stride", C.c_longlong), ("scale8", C.c_void_p),
+                ("R", C.c_int), ("C", C.c_int), ("ld_src", C.c_int), ("ld8", C.c_int)]
+
+
+class QuantRowsGroup:
+    """Collects the fp8 re-packs of fp32 weights (rows [row0, row0 + R) of an Fp8Planes from src [R, C]) and issues them as one launch."""
+
+    def __init__(self):
+        self.items = []
+
+    def add(self, src, P: "Fp8Planes", row0: int, R: int, C_: int, ld_src: int):
+        hip.require_gpu(src, "src")
+        assert src.dtype == torch.float32 and row0 + R <= P.rows and C_ <= 2 * P.ld
+        self.items.append((src, P, int(row0), int(R), int(C_), int(ld_src)))
+
+    def flush(self):
+        n = len(self.items)
+        if n == 0:
+            return
+        arr = (_QuantDesc * n)()
+        for d, (src, P, row0, R, C_, ld_src) in zip(arr, self.items):
+            pitch = 2 * P.ld
+            d.src, d.dst8, d.lo_stride, d.scale8 = ptr(src), P.planes.data_ptr() + row0 * pitch, P.stride, P.scale.data_ptr() + row0
+            d.R, d.C, d.ld_src, d.ld8 = R, C_, ld_src, pitch
+        call("omlm_quant_rows_mx", C.cast(arr, C.c_void_p), n, stream_ptr())
+        self.items = []
 
 
 _LN_WS = {}
@@ -409,6 +480,18 @@ def ffmid_fwd_planes(h1, h1_lo, convw, convw_lo, gamma, gamma_lo, h2, h2_lo, mea
     assert h1_lo.shape == h1.shape and h2_lo.shape == h2.shape and convw_lo.shape == convw.shape
     call("omlm_ffmid_fwd_planes", ptr(h1), ptr(h1_lo), ptr(convw), ptr(convw_lo), ptr(gamma), ptr(gamma_lo), ptr(h2), ptr(h2_lo), ptr(mean),
          ptr(rstd), h1.shape[0], nseq, F, Fp, float(eps), float(p), int(seed), ptr(seed_dev), ptr(drop_bits), ptr(gh), dcode(h1.dtype),
+         stream_ptr())
+
+
+def ffmid_fwd_mx(h1, h1_lo, convw, convw_lo, gamma, gamma_lo, h2, P: "Fp8Planes", mean, rstd, nseq, F, Fp, p, seed, eps=1e-5, seed_dev=None,
+                 drop_bits=None, gh=None):
+    """ffmid_fwd_planes with h2 leaving as omlm_gemm_mx16's A operand: the half hi plane h2 + its fp8 planes and row scales in P."""
+    assert convw.shape == (3, 2 * Fp) and gamma.numel() == Fp and h1.dtype == torch.float16
+    for t in (h1_lo, convw, convw_lo, gamma, gamma_lo, h2):
+        assert t.dtype == h1.dtype, "every plane travels in the operand dtype of h1"
+    assert h1_lo.shape == h1.shape and convw_lo.shape == convw.shape and P.ld == Fp and P.rows >= h1.shape[0]
+    call("omlm_ffmid_fwd_mx", ptr(h1), ptr(h1_lo), ptr(convw), ptr(convw_lo), ptr(gamma), ptr(gamma_lo), ptr(h2), ptr(P.planes), P.stride,
+         ptr(P.scale), ptr(mean), ptr(rstd), h1.shape[0], nseq, F, Fp, float(eps), float(p), int(seed), ptr(seed_dev), ptr(drop_bits), ptr(gh),
          stream_ptr())
 
 

@@ -1340,6 +1340,64 @@ def test_gemm_planes16_vs_fp64(ops, dev, dtype, M, N, K, planes_out):
         assert e < bar, e
 
 
+def torch_fp8_planes(ops, hi, lo, dev, bound=None):
+    """Reference quantiser of omlm_gemm_mx16's fp8 planes, in torch on the CPU: one power-of-two scale per row (bound / 2^e <= 256), hi8 =
+    e4m3(hi 2^-e), lo8 = e4m3(lo 2^-(e - 11)).  Returns (ops.Fp8Planes on the device, dequantised hi8 [fp64], dequantised lo8 [fp64])."""
+    hi, lo = hi.float().cpu(), lo.float().cpu()
+    R, K = hi.shape
+    b = hi.abs().amax(1) if bound is None else bound.float().cpu()
+    e = torch.ceil(torch.log2(b.clamp(min=2.0 ** -100))) - 8.0
+    q = lambda v, ee: (v * torch.exp2(-ee)[:, None]).clamp(-448, 448).to(torch.float8_e4m3fn)
+    h8, l8 = q(hi, e), q(lo, e - 11.0)
+    P = ops.Fp8Planes(R, K, dev)
+    P.planes[0, :R, :K] = h8.view(torch.uint8).to(dev)
+    P.planes[1, :R, :K] = l8.view(torch.uint8).to(dev)
+    P.scale[:R] = (e + 127).to(torch.uint8).to(dev)
+    return P, h8.double() * torch.exp2(e)[:, None].double(), l8.double() * torch.exp2(e - 11.0)[:, None].double()
+
+
+@pytest.mark.parametrize("M,N,K,planes_out", [(256, 256, 128, False),        # one tile, one half tile pair + 1 + 1 fp8 tiles
+                                              (1100, 1280, 1024, True),      # ragged M, planes out (the FF-in form)
+                                              (2300, 1024, 2752, False),     # FF-out form: K = 43 half tiles (pad tile) + 2 x 22 fp8 tiles (the last one half empty), fp32 + residual
+                                              (333, 5504, 1024, True),       # FF-in width
+                                              (8448, 2048, 1024, True),      # 264 tiles = one machine round + 8: the tail runs as a slice-storing split-K through the workspace
+                                              (8448, 2048, 1024, False)])
+def test_gemm_mx16_vs_fp64(ops, dev, M, N, K, planes_out):
+    """omlm_gemm_mx16: C = A_hi B_hi^T on half MFMAs + the two correction products on fp8 MFMAs with one scale per row.  (1) The kernel's own
+    arithmetic: against the fp64 evaluation of exactly those three products on the values its planes hold -- the bar is fp32 accumulation.
+    (2) What it is for: against the fp64 product of the un-split operands -- the fp8 rounding of the corrections leaves ~2^-15 per term."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A, B = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.05
+    A[::7] *= 30.0                                             # rows of very different size: every row has its own scale
+    B[3::5] *= 0.01
+    Ah, Al = hilo(A.to(dev), torch.float16)
+    Bh, Bl = hilo(B.to(dev), torch.float16)
+    A8, a8h, a8l = torch_fp8_planes(ops, Ah, Al, dev)
+    B8, b8h, b8l = torch_fp8_planes(ops, Bh, Bl, dev)
+    ref_k = (Ah.double().cpu() @ Bh.double().cpu().t() + a8h @ b8l.t() + a8l @ b8h.t()).to(dev)          # what the kernel computes
+    ref = (Ah.double() + Al.double()) @ (Bh.double() + Bl.double()).t()                                  # what it stands for
+    scale = float(ref.abs().max())
+    if planes_out:
+        C, Cl = torch.full((M, N), float("nan"), device=dev, dtype=torch.float16), torch.full((M, N), float("nan"), device=dev, dtype=torch.float16)
+        ops.gemm_mx16(Ah, A8, Bh, B8, C, Cl, M=M, N=N, K=K)
+        got = C.double() + Cl.double()
+        e_k, e = float((got - ref_k).abs().max()) / scale, float((got - ref).abs().max()) / scale
+        # (planes out: the sum is known to the lo plane's own rounding, 2^-22 of the value, and subnormal below 6e-5)
+        assert e_k < 4e-6, e_k
+    else:
+        Cin = torch.randn(M, N, generator=g).to(dev)
+        C = torch.full((M, N), float("nan"), device=dev)
+        ops.gemm_mx16(Ah, A8, Bh, B8, C, M=M, N=N, K=K, Cin=Cin)
+        e_k, e = float((C.double() - Cin.double() - ref_k).abs().max()) / scale, float((C.double() - Cin.double() - ref).abs().max()) / scale
+        assert e_k < 2e-6, e_k
+    # per-row view of the residual error (rows differ by 30x in size): the corrections' fp8 rounding, relative to the row's own largest output
+    C1 = torch.empty(M, N, device=dev)
+    ops.gemm(Ah, Bh, C1, M=M, N=N, K=K)
+    e1 = float((C1.double() - ref).abs().max()) / scale
+    report(f"gemm_mx16[{M},{N},{K},{'planes' if planes_out else 'fp32'}]", vs_own_products=e_k, vs_exact=e, single_half_product=e1)
+    assert e < 6e-5 and e < e1 / 8, (e, e1)
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M,D", [(333, 1024), (6700, 1024), (150, 768)])
 def test_layernorm_fwd_planes(ops, dev, dtype, M, D):
@@ -1409,6 +1467,122 @@ def test_ffmid_fwd_planes_vs_fp64(ops, dev, dtype, F, nseq, Bn, p):
     # erf by A&S 7.1.26 (1.5e-7 abs) bounds the kernel at ~2e-6 of the output range; the single-plane forward sits at its operand rounding
     assert e < (1e-5 if dtype == torch.float16 else 6e-5), e
     assert e_gh < (1e-3 if dtype == torch.float16 else 8e-3) and e < 0.05 * e_single
+
+
+def _fp8_bytes(v, e):
+    """e4m3 bytes of v 2^-e (torch's conversion on the CPU: RNE), e per row"""
+    return (v.float().cpu() * torch.exp2(-e.float().cpu())[:, None]).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+
+
+def _check_mx_planes(P, rows, K, hi, lo_ref, name):
+    """The fp8 planes of an operand against their definition: the scale bounds the row without wasting more than two binades, hi8 is bit for
+    bit e4m3(hi 2^-e), lo8 dequantises to the lo part within e4m3's rounding, the row tails up to a whole 128-byte k-tile are zero."""
+    e = P.scale[:rows].cpu().to(torch.int32) - 127
+    rowmax = hi.float().abs().amax(1).cpu()
+    ok = rowmax > 0
+    assert bool((torch.exp2((e + 8).float())[ok] >= rowmax[ok]).all()), name + ": a row exceeds its scale"
+    assert bool((torch.exp2((e + 8).float())[ok] < 8.0 * rowmax[ok]).all()), name + ": scale wastes three binades"
+    assert torch.equal(P.planes[0, :rows, :K].cpu(), _fp8_bytes(hi, e)), name + ": hi8 bytes"
+    dq_lo = P.planes[1, :rows, :K].cpu().view(torch.float8_e4m3fn).double() * torch.exp2((e - 11).double())[:, None]
+    lo_ref = lo_ref.double().cpu()
+    err = float((dq_lo - lo_ref).abs().max()) / max(float(lo_ref.abs().max()), 1e-30)
+    assert err < 0.07, (name, err)                    # e4m3: half an ulp of a 3-bit mantissa = 2^-4 relative at worst (+ the fp32 noise of lo itself)
+    K128 = (K + 127) // 128 * 128
+    assert K128 <= P.planes.shape[2] and (K128 == K or float(P.planes[:, :rows, K:K128].max()) == 0), name + ": row tails"
+    return err
+
+
+@pytest.mark.parametrize("M,D", [(333, 1024), (6700, 1024), (150, 768), (40, 64)])
+def test_layernorm_fwd_mx(ops, dev, M, D):
+    """omlm_layernorm_fwd_mx: the half hi plane and the statistics are bit for bit omlm_layernorm_fwd's; the fp8 planes and row scales are
+    what omlm_gemm_mx16 defines (written into an UNINITIALISED buffer: the kernel owns the row tails)."""
+    g = torch.Generator().manual_seed(M)
+    x = (torch.randn(M, D, generator=g) * 3 + 1).to(dev)
+    x[5] *= 40.0; x[7] = x[7] * 1e-3 + 2.0                     # rows of very different spread
+    gamma = (1 + 0.1 * torch.randn(D, generator=g)).to(dev)
+    y0 = torch.empty(M, D, device=dev, dtype=torch.float16)
+    m0, r0 = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    ops.layernorm_fwd(x, gamma, y0, None, m0, r0)
+    P = ops.Fp8Planes(M, D, dev, zero=False)
+    P.planes.fill_(0x7f); P.scale.fill_(0xff)                  # fp8 NaN bytes / NaN scales wherever the kernel does not write
+    y = torch.full((M, D), float("nan"), device=dev, dtype=torch.float16)
+    m1, r1 = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    ops.layernorm_fwd_mx(x, gamma, y, P, m1, r1)
+    if D == 1024:             # the product's width: same reduction code as omlm_layernorm_fwd's row kernel -> the same bits
+        assert torch.equal(y, y0) and torch.equal(m0, m1) and torch.equal(r0, r1)
+    else:                     # other widths: the same sums in another instruction selection -- rstd within an ulp, y within a rounding flip
+        assert torch.equal(m0, m1) and float(((r0 - r1) / r0).abs().max()) < 3e-7 and float((y != y0).float().mean()) < 1e-3
+    ref = torch.nn.functional.layer_norm(x.double(), (D,), gamma.double(), None, 1e-5)
+    assert relerr(y, ref) < 6e-4
+    err = _check_mx_planes(P, M, D, y, ref - y.double(), f"layernorm_fwd_mx[{M},{D}]")
+    report(f"layernorm_fwd_mx[{M},{D}]", lo8_rel_err=err)
+
+
+@pytest.mark.parametrize("F,nseq,Bn,p", [(341, 80, 2, 0.0), (2730, 45, 2, 0.1), (1024, 37, 3, 0.1)])
+def test_ffmid_fwd_mx(ops, dev, F, nseq, Bn, p):
+    """omlm_ffmid_fwd_mx against omlm_ffmid_fwd_planes on the same planes: h2's hi plane, the statistics, gh and the keep bits are bit for bit
+    the same; the fp8 planes hold hi / lo as omlm_gemm_mx16 defines them."""
+    M = nseq * Bn
+    Fp = (F + 63) // 64 * 64
+    dtype = torch.float16
+    g = torch.Generator().manual_seed(F + nseq)
+    h1 = torch.zeros(M, 2 * Fp)
+    h1[:, :F] = torch.randn(M, F, generator=g)
+    h1[:, Fp:Fp + F] = torch.randn(M, F, generator=g)
+    h1[3] *= 25.0
+    convw = (torch.randn(2 * F, 3, generator=g) * 0.5).to(dev)
+    gamma = (1 + 0.1 * torch.randn(F, generator=g)).to(dev)
+    h1h, h1l = hilo(h1.to(dev), dtype)
+    taps32, g32 = ops.pack_conv_taps(convw, F, Fp), ops.pad_vector(gamma, Fp)
+    tph, tpl = hilo(taps32, dtype)
+    gph, gpl = hilo(g32, dtype)
+    def run(mx):
+        h2 = torch.full((M, Fp), float("nan"), device=dev, dtype=dtype)
+        gh = torch.full((M, Fp), float("nan"), device=dev, dtype=dtype)
+        m, r = torch.empty(M, device=dev), torch.empty(M, device=dev)
+        bits = torch.zeros(M, Fp // 8, dtype=torch.uint8, device=dev) if p > 0 else None
+        if mx:
+            P = ops.Fp8Planes(M, Fp, dev, zero=False)
+            P.planes.fill_(0x7f); P.scale.fill_(0xff)
+            ops.ffmid_fwd_mx(h1h, h1l, tph, tpl, gph, gpl, h2, P, m, r, nseq, F, Fp, p, 4321, drop_bits=bits, gh=gh)
+            return h2, P, gh, m, r, bits
+        h2l = torch.full((M, Fp), float("nan"), device=dev, dtype=dtype)
+        ops.ffmid_fwd_planes(h1h, h1l, tph, tpl, gph, gpl, h2, h2l, m, r, nseq, F, Fp, p, 4321, drop_bits=bits, gh=gh)
+        return h2, h2l, gh, m, r, bits
+    a, b = run(False), run(True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+    if p > 0:
+        assert torch.equal(a[5], b[5])
+    err = _check_mx_planes(b[1], M, Fp, b[0], a[1], f"ffmid_fwd_mx[{F},{nseq},{p}]")
+    report(f"ffmid_fwd_mx[{F},{nseq},{p}]", lo8_rel_err=err)
+
+
+def test_quant_rows_mx(ops, dev):
+    """omlm_quant_rows_mx (the per-step fp8 re-pack of the FF weights): rows of an fp32 matrix -> hi8 / lo8 / scale at a row offset of the
+    planes, two problems in one launch (the value / gate halves of W1), ragged C."""
+    g = torch.Generator().manual_seed(9)
+    F, Fp, D = 341, 384, 256
+    w1 = (torch.randn(2 * F, D, generator=g) * 0.04).to(dev)
+    w1[11] *= 50.0; w1[12] = 0.0
+    w2 = (torch.randn(D, F, generator=g) * 0.02).to(dev)
+    P1, P2 = ops.Fp8Planes(2 * Fp, D, dev), ops.Fp8Planes(D, Fp, dev)
+    grp = ops.QuantRowsGroup()
+    grp.add(w1, P1, 0, F, D, D)
+    grp.add(w1[F:], P1, Fp, F, D, D)
+    grp.add(w2, P2, 0, D, F, F)
+    grp.flush()
+    for P, rows0, src, K in ((P1, 0, w1[:F], D), (P1, Fp, w1[F:], D), (P2, 0, w2, F)):
+        R = src.shape[0]
+        hi = src.half()
+        lo = src.double() - hi.double()
+        e = P.scale[rows0:rows0 + R].cpu().to(torch.int32) - 127
+        rowmax = hi.float().abs().amax(1).cpu()
+        ok = rowmax > 0
+        assert bool((torch.exp2((e + 8).float())[ok] >= rowmax[ok]).all()) and bool((torch.exp2((e + 8).float())[ok] <= 2.0 * rowmax[ok] * (1 + 1e-6)).all())
+        assert torch.equal(P.planes[0, rows0:rows0 + R, :K].cpu(), _fp8_bytes(hi, e))
+        assert torch.equal(P.planes[1, rows0:rows0 + R, :K].cpu(), _fp8_bytes(lo.float(), e - 11))
+        assert float(P.planes[:, rows0:rows0 + R, K:].max()) == 0
+    assert float(P1.planes[:, F:Fp].max()) == 0 and int(P1.scale[F]) == 127         # pad rows untouched
 
 
 def test_cast_pad_group_lo_planes(ops, dev):

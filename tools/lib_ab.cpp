@@ -27,7 +27,7 @@ typedef long long (*bwsz_t)(int, int, int);
 typedef int (*prep_t)(const float*, float*, int, int, int, const float*, const float*, float, float, void*);
 typedef long long (*tbl_t)(int, int);
 typedef int (*gemm_t)(const void*, const void*, void*, const float*, const int*, const int*, const int*, long long, long long, int, int, int, int, int, int, int,
-                      int, int, int, int, float, void*);
+                      int, int, int, int, float, void*, long long, void*);
 typedef const char* (*err_t)(void);
 struct wgrad_desc { const void* A; const void* B; float* C; const int* c_map; int M, N, K, lda, ldb, ldc; };
 typedef int (*wgrad_t)(const wgrad_desc*, int, int, int, void*);
@@ -41,7 +41,7 @@ typedef long long (*lnws_t)(int);
 typedef int (*lnb_t)(const void*, const float*, const float*, const float*, const float*, const float*, float*, void*, float*, float*, int, int, float, int, int, void*);
 typedef int (*dstep_t)(const omlm_decode_args*, const long long*, void*);
 typedef int (*planes_t)(const void*, long long, const void*, long long, void*, const float*, const int*, const int*, const int*, long long, long long,
-                        int, int, int, int, int, int, int, int, int, int, float, void*);
+                        int, int, int, int, int, int, int, int, int, int, float, void*, long long, void*);
 
 struct Lib {
     std::string path; void* h; fwd_t fwd; bwd_t bwd; bwdw_t bwdw; bwsz_t bwsz; prep_t prep; tbl_t tbl; gemm_t gemm; err_t err; wgrad_t wgrad; planes_t planes; ffwd_t ffwd; fws_t fws; fbwd_t fbwd; lnf_t lnf; lnws_t lnws; lnb_t lnb; dstep_t dstep;
@@ -179,9 +179,9 @@ static void gemm_case(Lib& A, Lib& Bl) {
         Lib& L = *libs[li];
         apply_env(li ? g_env_b : g_env_a);
         uint16_t* Hout = dev_zero<uint16_t>((size_t)M * F2); float* dXo = dev_zero<float>((size_t)M * D); float* dWo = dev_zero<float>((size_t)F2 * D);
-        auto nt = [&] { L.ok(L.gemm(dX_, dW_, Hout, nullptr, nullptr, nullptr, nullptr, M, F2, M, F2, D, D, D, F2, 0, 0, 0, 1, 1, 1.f, nullptr), "gemm NT"); };
-        auto nn = [&] { L.ok(L.gemm(ddH, dW_, dXo, nullptr, nullptr, nullptr, nullptr, M, F2, M, D, F2, F2, D, D, 0, 0, 1, 1, 0, 1.f, nullptr), "gemm NN"); };
-        auto tn = [&] { L.ok(L.gemm(ddH, dX_, dWo, dWo, nullptr, nullptr, nullptr, M, M, F2, D, M, F2, D, D, D, 1, 1, 1, 0, 1.f, nullptr), "gemm TN"); };
+        auto nt = [&] { L.ok(L.gemm(dX_, dW_, Hout, nullptr, nullptr, nullptr, nullptr, M, F2, M, F2, D, D, D, F2, 0, 0, 0, 1, 1, 1.f, nullptr, 0, nullptr), "gemm NT"); };
+        auto nn = [&] { L.ok(L.gemm(ddH, dW_, dXo, nullptr, nullptr, nullptr, nullptr, M, F2, M, D, F2, F2, D, D, 0, 0, 1, 1, 0, 1.f, nullptr, 0, nullptr), "gemm NN"); };
+        auto tn = [&] { L.ok(L.gemm(ddH, dX_, dWo, dWo, nullptr, nullptr, nullptr, M, M, F2, D, M, F2, D, D, D, 1, 1, 1, 0, 1.f, nullptr, 0, nullptr), "gemm TN"); };
         nt(); nn(); tn(); CK(hipDeviceSynchronize());
         r_nt[li] = host(Hout, (size_t)M * F2); r_nn[li] = host(dXo, (size_t)M * D); r_tn[li] = host(dWo, (size_t)F2 * D);
         us[li][0] = time_us(nt, 10); us[li][1] = time_us(nn, 10); us[li][2] = time_us(tn, 10);
@@ -212,7 +212,7 @@ static void gemm_square_case(Lib& A, Lib& Bl) {
             Lib& L = *libs[li];
             apply_env(li ? g_env_b : g_env_a);
             uint16_t* out = dev_zero<uint16_t>((size_t)n * n);
-            auto nt = [&] { L.ok(L.gemm(dX_, dW_, out, nullptr, nullptr, nullptr, nullptr, n, n, n, n, n, n, n, n, 0, 0, 0, 1, 1, 1.f, nullptr), "gemm NT"); };
+            auto nt = [&] { L.ok(L.gemm(dX_, dW_, out, nullptr, nullptr, nullptr, nullptr, n, n, n, n, n, n, n, n, 0, 0, 0, 1, 1, 1.f, nullptr, 0, nullptr), "gemm NT"); };
             nt(); CK(hipDeviceSynchronize());
             const float us = time_us(nt, 20);
             printf("  %c %-40s %8.1f us  %6.0f TFLOP/s\n", li ? 'B' : 'A', L.path.c_str(), us, 2.0 * n * (double)n * n / us / 1e6);
@@ -247,7 +247,7 @@ static void gemm_edge_case(Lib& A, Lib& Bl) {
                 apply_env(li ? g_env_b : g_env_a);
                 const size_t bytes = (size_t)M * ldc * (od ? 2 : 4);
                 unsigned char* dc = dev_zero<unsigned char>(bytes);
-                libs[li]->ok(libs[li]->gemm(da, db, dc, withc ? dcin : nullptr, nullptr, nullptr, nullptr, ar, br, M, N, K, lda, ldb, ldc, ldc, ak, bk, 1, od, 0.5f, nullptr), "gemm edge");
+                libs[li]->ok(libs[li]->gemm(da, db, dc, withc ? dcin : nullptr, nullptr, nullptr, nullptr, ar, br, M, N, K, lda, ldb, ldc, ldc, ak, bk, 1, od, 0.5f, nullptr, 0, nullptr), "gemm edge");
                 CK(hipDeviceSynchronize());
                 out[li] = host(dc, bytes);
                 CK(hipFree(dc));
@@ -271,8 +271,8 @@ static void gemm_edge_case(Lib& A, Lib& Bl) {
             for (int li = 0; li < 2; ++li) {
                 apply_env(li ? g_env_b : g_env_a);
                 float* dc = dev_zero<float>((size_t)crows * ldc);
-                if (mode == 0) libs[li]->ok(libs[li]->gemm(da, db, dc, nullptr, dam, nullptr, dcm, arows, N, M, N, K, lda, ldb, ldc, 0, 0, 0, 1, 0, 1.f, nullptr), "gemm maps");
-                else libs[li]->ok(libs[li]->planes(da, (long long)arows * lda * 2, db, (long long)N * ldb * 2, dc, nullptr, nullptr, nullptr, nullptr, arows, N, M, N, K, lda, ldb, ldc, 0, 0, 0, 0, 1.f, nullptr), "gemm planes");
+                if (mode == 0) libs[li]->ok(libs[li]->gemm(da, db, dc, nullptr, dam, nullptr, dcm, arows, N, M, N, K, lda, ldb, ldc, 0, 0, 0, 1, 0, 1.f, nullptr, 0, nullptr), "gemm maps");
+                else libs[li]->ok(libs[li]->planes(da, (long long)arows * lda * 2, db, (long long)N * ldb * 2, dc, nullptr, nullptr, nullptr, nullptr, arows, N, M, N, K, lda, ldb, ldc, 0, 0, 0, 0, 1.f, nullptr, 0, nullptr), "gemm planes");
                 CK(hipDeviceSynchronize());
                 out[li] = host(dc, (size_t)crows * ldc);
                 CK(hipFree(dc));
@@ -338,10 +338,10 @@ static void gemm5_case(Lib& A, Lib& Bl) {
     Lib* libs[2] = {&A, &Bl};
     uint16_t *o_ffin[2], *o_dh2[2], *o_dxn2[2]; float* o_ffout[2];
     for (int li = 0; li < 2; ++li) { o_ffin[li] = dev_zero<uint16_t>((size_t)M * F2); o_dh2[li] = dev_zero<uint16_t>((size_t)M * Fp); o_dxn2[li] = dev_zero<uint16_t>((size_t)M * D); o_ffout[li] = dev_zero<float>((size_t)M * D); }
-    auto ffin = [&](int li) { libs[li]->ok(libs[li]->gemm(dX, dW1, o_ffin[li], nullptr, nullptr, nullptr, nullptr, M, F2, M, F2, D, D, D, F2, 0, 0, 0, 1, 1, 1.f, nullptr), "ffin"); };
-    auto dh2 = [&](int li) { libs[li]->ok(libs[li]->gemm(dX, dW2, o_dh2[li], nullptr, nullptr, nullptr, nullptr, M, D, M, Fp, D, D, Fp, Fp, 0, 0, 1, 1, 1, 1.f, nullptr), "dh2"); };       // dres [M, D] x W2p [D, Fp] k-major
-    auto dxn2 = [&](int li) { libs[li]->ok(libs[li]->gemm(dH1, dW1, o_dxn2[li], nullptr, nullptr, nullptr, nullptr, M, F2, M, D, F2, F2, D, D, 0, 0, 1, 1, 1, 1.f, nullptr), "dxn2"); };  // dh1 [M, 2Fp] x W1p [2Fp, D] k-major
-    auto ffout = [&](int li) { libs[li]->ok(libs[li]->gemm(dH2, dW2, o_ffout[li], dR, nullptr, nullptr, nullptr, M, D, M, D, Fp, Fp, Fp, D, D, 0, 0, 1, 0, 1.f, nullptr), "ffout"); };
+    auto ffin = [&](int li) { libs[li]->ok(libs[li]->gemm(dX, dW1, o_ffin[li], nullptr, nullptr, nullptr, nullptr, M, F2, M, F2, D, D, D, F2, 0, 0, 0, 1, 1, 1.f, nullptr, 0, nullptr), "ffin"); };
+    auto dh2 = [&](int li) { libs[li]->ok(libs[li]->gemm(dX, dW2, o_dh2[li], nullptr, nullptr, nullptr, nullptr, M, D, M, Fp, D, D, Fp, Fp, 0, 0, 1, 1, 1, 1.f, nullptr, 0, nullptr), "dh2"); };       // dres [M, D] x W2p [D, Fp] k-major
+    auto dxn2 = [&](int li) { libs[li]->ok(libs[li]->gemm(dH1, dW1, o_dxn2[li], nullptr, nullptr, nullptr, nullptr, M, F2, M, D, F2, F2, D, D, 0, 0, 1, 1, 1, 1.f, nullptr, 0, nullptr), "dxn2"); };  // dh1 [M, 2Fp] x W1p [2Fp, D] k-major
+    auto ffout = [&](int li) { libs[li]->ok(libs[li]->gemm(dH2, dW2, o_ffout[li], dR, nullptr, nullptr, nullptr, M, D, M, D, Fp, Fp, Fp, D, D, 0, 0, 1, 0, 1.f, nullptr, 0, nullptr), "ffout"); };
     const char* names[4] = {"ffin_NT 16b", "dh2_NN 16b", "dxn2_NN 16b", "ffout_NT f32+res"};
     const double fl[4] = {2.0 * M * D * (double)F2, 2.0 * M * D * (double)Fp, 2.0 * M * D * (double)F2, 2.0 * M * D * (double)Fp};
     double best[2][4]; for (auto& r : best) for (auto& v : r) v = 1e30;
