@@ -255,10 +255,11 @@ int omlm_gemm_mx16(const void* A, const void* A8, long long a8_stride, const uns
 long long omlm_gemm_mx16_workspace_bytes(int M, int N, int K);
 /* Producers of omlm_gemm_mx16's operand form (fp16 only).  Each writes the half hi plane exactly as its plain / planes sibling does, plus the fp8
  * planes [hi8 | lo8] (row pitch = 2 x the half plane's pitch in elements, in bytes; lo8 plane `*_stride` bytes behind hi8; bytes behind the row's
- * last element untouched -- zero-fill the buffer once) and one E8M0 scale byte per row, 2^(e) >= 2^-8 x a bound of the row's largest entry:
- *   omlm_layernorm_fwd_mx : transformer.py:24-31 in front of FF-in; bound = max(xmax - mean, mean - xmin) rstd max|gamma| (no extra pass)
- *   omlm_ffmid_fwd_mx     : omlm_ffmid_fwd_planes with h2 in this form; bound from the GEGLU output's row max / min the same way
- *   omlm_quant_rows_mx    : fp32 weights (all problems of a model in one launch); hi = rne_half(w), exact row maximum */
+ * last element zero up to the next multiple of 128) and one E8M0 scale byte per row, 2^e >= 2^-8 x a bound of the row's largest entry:
+ *   omlm_layernorm_fwd_mx : transformer.py:24-31 in front of FF-in; bound = sqrt(D) max|gamma| (what a LayerNorm output cannot exceed)
+ *   omlm_ffmid_fwd_mx     : omlm_ffmid_fwd_planes with h2 in this form; bound = sqrt(F) max|gamma / keep| the same way
+ *   omlm_quant_rows_mx    : fp32 weights (all problems of a model in one launch); hi = rne_half(w), exact row maximum; rows' tails untouched
+ *                           (zero-fill the buffer once) */
 int omlm_layernorm_fwd_mx(const float* x, const float* gamma, void* y, void* y8, long long y8_stride, unsigned char* scale8,
                           float* mean, float* rstd, int M, int D, int ldy, float eps, void* stream);
 int omlm_ffmid_fwd_mx(const void* h1, const void* h1_lo, const void* convw, const void* convw_lo, const void* gamma, const void* gamma_lo,

@@ -183,9 +183,10 @@ __device__ __forceinline__ void keep_words(unsigned long long seed, unsigned lon
 // forward.  grid: B * strips workgroups of NT threads (NT = chunks of 8 channels rounded up to waves); strip s of sample b
 // covers rows [s * RB, min(nseq, (s + 1) * RB)).
 // ---------------------------------------------------------------------------------------------------------------------
-// MX (with PL): h2 leaves as the half hi plane + fp8 planes + one scale byte per row (csrc/gemm_mx.hip) instead of hi / lo half planes.  The row's
-// scale needs a bound on |y| before the row is written: max(gmax - mean, mean - gmin) rstd max|gamma / keep| from the row's max / min of the GEGLU
-// output, which ride with the LayerNorm sums through the one barrier per batch.
+// MX (with PL): h2 leaves as the half hi plane + fp8 planes + one scale byte per row (csrc/gemm_mx.hip) instead of hi / lo half planes.  The scale
+// must be known before a row is written; a LayerNorm output is bounded whatever its input: |y_i| <= sqrt(F - 1) max|gamma / keep|.  Every row takes
+// that bound (3-4 binades above a typical row's largest entry, of the 17 e4m3 spans: profiles/r06_error_budget_fp8corr.md, "one scale per tensor")
+// -- no per-element max / min in a kernel that is bound by instruction issue (a data-derived row bound measured +54 us per launch).
 template <typename T, int NT, bool TRAIN, bool PL = false, bool MX = false>
 __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kernel(const T* __restrict__ h1, const T* __restrict__ convw,
                                                         const T* __restrict__ gamma, T* __restrict__ h2,
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
                                                         unsigned char* __restrict__ drop_bits, T* __restrict__ gh_out, const FfPlanes pl) {
     constexpr int NW = NT / 64;
     constexpr int RB_ = (sizeof(T) == 2 && !PL) ? FS_R : (FS_R > 2 ? 2 : FS_R);        // rows per batch: fp32 rows (and hi + lo rows) cost twice the registers
-    __shared__ float st[2][FS_R][NW][MX ? 4 : 2];
+    __shared__ float st[2][FS_R][NW][2];
     __shared__ float gmx[MX ? NW : 1];
     if (seed_dev) seed += seed_dev[0] * 0x9E3779B97F4A7C15ull;
     const int b = blockIdx.x / strips, s = blockIdx.x - b * strips;
@@ -251,6 +252,8 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
 #pragma unroll
         for (int w = 1; w < NW; ++w) gmmax = fmaxf(gmmax, gmx[w]);
     }
+    const int e_mx = MX ? mx_row_exp(sqrtf((float)F) * gmmax) : 0;
+    const float sh_mx = ldexpf(1.0f, -e_mx), sl_mx = ldexpf(1.0f, 11 - e_mx);
     // conv window: rows t0 - 1 and t0 - 2 of the same sample (zero before the sample starts, transformer.py:129)
     v2 x1v[4], x1g[4], x2v[4], x2g[4];
     {
@@ -278,13 +281,13 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
     auto batch = [&](auto full_tag, const int tb, const int it) {
         constexpr bool FULL = decltype(full_tag)::value;
         v2 g[RB_][4];
-        float ls[RB_], lq[RB_], lhi[RB_], llo[RB_];
+        float ls[RB_], lq[RB_];
         // sweep 1: conv + GEGLU of the batch, per-thread sums for LayerNorm
 #pragma unroll
         for (int r = 0; r < RB_; ++r) {
-            ls[r] = 0.f; lq[r] = 0.f; lhi[r] = 0.f; llo[r] = 0.f;
+            ls[r] = 0.f; lq[r] = 0.f;
             if (FULL || tb + r < t1) {
-                v2 s2 = splat2(0.f), q2 = splat2(0.f), hi2 = splat2(0.f), lo2 = splat2(0.f);
+                v2 s2 = splat2(0.f), q2 = splat2(0.f);
                 if constexpr (PACKW) {                   // opaque per row: the unpacked taps must not be hoisted back into loop-invariant registers
 #pragma unroll
                     for (int k = 0; k < 3; ++k) pin_regs(tv[k].h, tg[k].h);
@@ -305,14 +308,9 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
                     g[r][i] = gv;
                     s2 += gv;
                     q2 = fma2(gv, gv, q2);
-                    if constexpr (MX) {                  // row max / min of the GEGLU output (0 included: pad channels and absent lanes carry it anyway)
-                        hi2 = mk2(fmaxf(hi2[0], gv[0]), fmaxf(hi2[1], gv[1]));
-                        lo2 = mk2(fminf(lo2[0], gv[0]), fminf(lo2[1], gv[1]));
-                    }
                 }
                 ls[r] = s2[0] + s2[1];
                 lq[r] = q2[0] + q2[1];
-                if constexpr (MX) { lhi[r] = fmaxf(hi2[0], hi2[1]); llo[r] = fminf(lo2[0], lo2[1]); }
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) g[r][i] = splat2(0.f);
@@ -340,42 +338,27 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
             }
 #endif
 #pragma unroll
-        for (int r = 0; r < RB_; ++r) {
-            ls[r] = wave_sum(ls[r]); lq[r] = wave_sum(lq[r]);
-            if constexpr (MX) { lhi[r] = wave_max(lhi[r]); llo[r] = -wave_max(-llo[r]); }
-        }
+        for (int r = 0; r < RB_; ++r) { ls[r] = wave_sum(ls[r]); lq[r] = wave_sum(lq[r]); }
         if (lane == 0) {
 #pragma unroll
-            for (int r = 0; r < RB_; ++r) {
-                st[it & 1][r][wave][0] = ls[r]; st[it & 1][r][wave][1] = lq[r];
-                if constexpr (MX) { st[it & 1][r][wave][2] = lhi[r]; st[it & 1][r][wave][3] = llo[r]; }
-            }
+            for (int r = 0; r < RB_; ++r) { st[it & 1][r][wave][0] = ls[r]; st[it & 1][r][wave][1] = lq[r]; }
         }
         __syncthreads();          // one barrier per batch: the other parity's slots are rewritten only after the next one
         // sweep 2: normalise, gamma, dropout, store
         float mu_r[RB_], rs_r[RB_];
-        int e_r[RB_];
 #pragma unroll
         for (int r = 0; r < RB_; ++r) {
-            e_r[r] = 0;
             if (!FULL && tb + r >= t1) continue;
-            float S = 0.f, Q = 0.f, HI = 0.f, LO = 0.f;
+            float S = 0.f, Q = 0.f;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                S += st[it & 1][r][w][0]; Q += st[it & 1][r][w][1];
-                if constexpr (MX) { HI = fmaxf(HI, st[it & 1][r][w][2]); LO = fminf(LO, st[it & 1][r][w][3]); }
-            }
+            for (int w = 0; w < NW; ++w) { S += st[it & 1][r][w][0]; Q += st[it & 1][r][w][1]; }
             const float mu = S * invF;
             const float var = fmaxf(Q * invF - mu * mu, 0.f);
             const float rs = rsqrtf(var + eps);
             const size_t row = row0 + tb + r;
-            float sh = 1.f, sl = 1.f;
-            if constexpr (MX) {
-                e_r[r] = mx_row_exp(fmaxf(HI - mu, mu - LO) * rs * gmmax);
-                sh = ldexpf(1.0f, -e_r[r]); sl = ldexpf(1.0f, 11 - e_r[r]);
-            }
+            const float sh = sh_mx, sl = sl_mx;
             if (FULL) { mu_r[r] = mu; rs_r[r] = rs; }
-            else if (threadIdx.x == 0) { mean[row] = mu; rstd[row] = rs; if constexpr (MX) pl.scale8[row] = (unsigned char)(e_r[r] + 127); }
+            else if (threadIdx.x == 0) { mean[row] = mu; rstd[row] = rs; if constexpr (MX) pl.scale8[row] = (unsigned char)(e_mx + 127); }
             const v2 nmr = splat2(-mu * rs), rs2 = splat2(rs);
             v2 gh[4], y[4];
 #pragma unroll
@@ -440,12 +423,7 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
             for (int r = 1; r < RB_; ++r) { m = q == r ? mu_r[r] : m; s_ = q == r ? rs_r[r] : s_; }
             mean[row0 + tb + q] = m;
             rstd[row0 + tb + q] = s_;
-            if constexpr (MX) {
-                int e_ = e_r[0];
-#pragma unroll
-                for (int r = 1; r < RB_; ++r) e_ = q == r ? e_r[r] : e_;
-                pl.scale8[row0 + tb + q] = (unsigned char)(e_ + 127);
-            }
+            if constexpr (MX) pl.scale8[row0 + tb + q] = (unsigned char)(e_mx + 127);
         }
     };
     int it = 0, tb = t0;

@@ -131,9 +131,10 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_row1_kernel(const float* __
 // ---- LayerNorm forward for omlm_gemm_mx16 (round 6): y as the half hi plane PLUS the two fp8 planes and the row scale ----------------------------
 // The FF-in GEMM of precision "fp16ff" multiplies y_hi on the half matrix cores and corrects with fp8 products (csrc/gemm_mx.hip): per row one
 // power-of-two scale 2^e with |y| <= 2^(e + 8), hi8 = e4m3(y_hi 2^-e), lo8 = e4m3((y - y_hi) 2^-(e - 11)).  The scale must be known before the
-// row is written, so it comes from a BOUND the first reduction round already yields: |y_i| <= max(xmax - mean, mean - xmin) rstd max|gamma|
-// (row max / min ride with the row sum: no extra barrier).  fp8 plane rows have the pitch of the half plane in bytes (2 ldy), the lo8 plane
-// y8_stride bytes behind the hi8 plane; scale8[row] = e + 127 (E8M0).
+// row is written: a LayerNorm output is bounded whatever its input, |y_i| <= sqrt(D - 1) max|gamma|, and every row takes that bound (3 binades above
+// a typical row's largest entry, of the 17 e4m3 spans; profiles/r06_error_budget_fp8corr.md "one scale per tensor": the same logits error as
+// data-derived row scales).  fp8 plane rows have the pitch of the half plane in bytes (2 ldy), the lo8 plane y8_stride bytes behind the hi8
+// plane; scale8[row] = e + 127 (E8M0).
 // hi plane (half), hi8 / lo8 bytes of four consecutive outputs; sh = 2^-e, sl = 2^-(e - 11)
 __device__ __forceinline__ void store4_mx(h16_t* y, unsigned char* y8h, unsigned char* y8l, float a, float b, float c, float d, float sh, float sl) {
     u32x2 o;
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_mx_kernel(const float* __re
                                                                unsigned char* __restrict__ y8, long long y8_stride, unsigned char* __restrict__ scale8,
                                                                float* __restrict__ mean, float* __restrict__ rstd, int M, int D, int ldy, float eps) {
     constexpr int NW = LN_THREADS / 64;
-    __shared__ float red[2][4][NW];                     // [parity][sum | max | min | sum of squares][wave]
+    __shared__ float red[2][2][NW];                     // [parity][sum | sum of squares][wave]
     __shared__ float gred[NW];
     const int nv = D / 4, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float4 g[MAXV];
@@ -167,27 +168,24 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_mx_kernel(const float* __re
     gm = gred[0];
 #pragma unroll
     for (int w = 1; w < NW; ++w) gm = fmaxf(gm, gred[w]);
+    const int e = mx_row_exp(sqrtf((float)D) * gm);
+    const float sh = ldexpf(1.0f, -e), sl = ldexpf(1.0f, 11 - e);
     int par = 0;
     for (int row = blockIdx.x; row < M; row += gridDim.x, par ^= 1) {
         const float4* xr = (const float4*)(x + (size_t)row * D);
         float4 v[MAXV];
-        float s = 0.f, hi = -3.0e38f, lo = 3.0e38f;
+        float s = 0.f;
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
             const int c = threadIdx.x + i * LN_THREADS;
-            if (c < nv) {
-                v[i] = xr[c];
-                s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-                hi = fmaxf(fmaxf(hi, fmaxf(v[i].x, v[i].y)), fmaxf(v[i].z, v[i].w));
-                lo = fminf(fminf(lo, fminf(v[i].x, v[i].y)), fminf(v[i].z, v[i].w));
-            }
+            if (c < nv) { v[i] = xr[c]; s += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
         }
-        s = wave_sum(s); hi = wave_max(hi); lo = -wave_max(-lo);
-        if (lane == 0) { red[par][0][wave] = s; red[par][1][wave] = hi; red[par][2][wave] = lo; }
+        s = wave_sum(s);
+        if (lane == 0) red[par][0][wave] = s;
         __syncthreads();
-        float t = 0.f, xmax = -3.0e38f, xmin = 3.0e38f;
+        float t = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) { t += red[par][0][w]; xmax = fmaxf(xmax, red[par][1][w]); xmin = fminf(xmin, red[par][2][w]); }
+        for (int w = 0; w < NW; ++w) t += red[par][0][w];
         const float mu = t / (float)D;
         float q = 0.f;
 #pragma unroll
@@ -199,14 +197,12 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_mx_kernel(const float* __re
             }
         }
         q = wave_sum(q);
-        if (lane == 0) red[par][3][wave] = q;
+        if (lane == 0) red[par][1][wave] = q;
         __syncthreads();                                           // parity `par` is rewritten two rows later, two barriers past its last read
         float u = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) u += red[par][3][w];
+        for (int w = 0; w < NW; ++w) u += red[par][1][w];
         const float rs = rsqrtf(u / (float)D + eps);
-        const int e = mx_row_exp(fmaxf(xmax - mu, mu - xmin) * rs * gm);
-        const float sh = ldexpf(1.0f, -e), sl = ldexpf(1.0f, 11 - e);
         if (threadIdx.x == 0) { mean[row] = mu; rstd[row] = rs; scale8[row] = (unsigned char)(e + 127); }
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {

@@ -290,9 +290,10 @@ class PreparedWeights:
                 else:
                     lo = wbuf[lkey]
                 W1l, W2l, convl, gammal = lo
-                packs.add(w1.detach(), W1l, F, D, D, D, lo=True)
-                packs.add(w1.detach()[F:], W1l[Fp:], F, D, D, D, lo=True)
-                packs.add(w2.detach(), W2l, D, F, F, Fp, lo=True)
+                if not (self.mx and persistent):       # (the training step of the fp8-corrected route never reads them; the cached decoder does)
+                    packs.add(w1.detach(), W1l, F, D, D, D, lo=True)
+                    packs.add(w1.detach()[F:], W1l[Fp:], F, D, D, D, lo=True)
+                    packs.add(w2.detach(), W2l, D, F, F, Fp, lo=True)
                 ent["W1p_lo"], ent["W2p_lo"], ent["convw_lo"], ent["gamma_mid_lo"] = W1l, W2l, convl, gammal
             if self.mx:
                 mkey = bkey + ("mx",)

@@ -1474,19 +1474,21 @@ def _fp8_bytes(v, e):
     return (v.float().cpu() * torch.exp2(-e.float().cpu())[:, None]).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
 
 
-def _check_mx_planes(P, rows, K, hi, lo_ref, name):
-    """The fp8 planes of an operand against their definition: the scale bounds the row without wasting more than two binades, hi8 is bit for
-    bit e4m3(hi 2^-e), lo8 dequantises to the lo part within e4m3's rounding, the row tails up to a whole 128-byte k-tile are zero."""
+def _check_mx_planes(P, rows, K, hi, lo_ref, name, bound):
+    """The fp8 planes of an operand against their definition: the scale is the one the analytic bound sqrt(width) max|gamma| gives (and bounds
+    every row), hi8 is bit for bit e4m3(hi 2^-e), lo8 dequantises to the lo part within e4m3's rounding (relative to the scale's step where the
+    entry is subnormal), the row tails up to a whole 128-byte k-tile are zero."""
     e = P.scale[:rows].cpu().to(torch.int32) - 127
     rowmax = hi.float().abs().amax(1).cpu()
-    ok = rowmax > 0
-    assert bool((torch.exp2((e + 8).float())[ok] >= rowmax[ok]).all()), name + ": a row exceeds its scale"
-    assert bool((torch.exp2((e + 8).float())[ok] < 8.0 * rowmax[ok]).all()), name + ": scale wastes three binades"
+    assert bool((torch.exp2((e + 8).float()) >= rowmax).all()), name + ": a row exceeds its scale"
+    assert bool((e == e[0]).all()) and 2.0 ** (int(e[0]) + 8) >= bound and 2.0 ** (int(e[0]) + 7) < bound * 1.001, (name, int(e[0]), bound)
     assert torch.equal(P.planes[0, :rows, :K].cpu(), _fp8_bytes(hi, e)), name + ": hi8 bytes"
     dq_lo = P.planes[1, :rows, :K].cpu().view(torch.float8_e4m3fn).double() * torch.exp2((e - 11).double())[:, None]
     lo_ref = lo_ref.double().cpu()
+    # e4m3: half an ulp of a 3-bit mantissa = 2^-4 of the entry, or half a subnormal step 2^(e - 11 - 10) below the normal range (+ fp32 noise of lo)
+    tol = lo_ref.abs() * 0.0635 + torch.exp2((e - 21).double())[:, None] + 2e-7 * hi.double().abs().cpu()      # (last term: fp32 evaluation order of y itself)
+    assert bool(((dq_lo - lo_ref).abs() <= tol).all()), name
     err = float((dq_lo - lo_ref).abs().max()) / max(float(lo_ref.abs().max()), 1e-30)
-    assert err < 0.07, (name, err)                    # e4m3: half an ulp of a 3-bit mantissa = 2^-4 relative at worst (+ the fp32 noise of lo itself)
     K128 = (K + 127) // 128 * 128
     assert K128 <= P.planes.shape[2] and (K128 == K or float(P.planes[:, :rows, K:K128].max()) == 0), name + ": row tails"
     return err
@@ -1514,7 +1516,10 @@ def test_layernorm_fwd_mx(ops, dev, M, D):
         assert torch.equal(m0, m1) and float(((r0 - r1) / r0).abs().max()) < 3e-7 and float((y != y0).float().mean()) < 1e-3
     ref = torch.nn.functional.layer_norm(x.double(), (D,), gamma.double(), None, 1e-5)
     assert relerr(y, ref) < 6e-4
-    err = _check_mx_planes(P, M, D, y, ref - y.double(), f"layernorm_fwd_mx[{M},{D}]")
+    # lo = y - hi with y as the KERNEL's fp32 arithmetic has it (its own statistics; on the near-constant row 7, rstd ~ 230, fp32 statistics are
+    # 2e-5 off the fp64 ones -- 100 x a lo value)
+    yk = ((x - m1[:, None]) * r1[:, None] * gamma).double()
+    err = _check_mx_planes(P, M, D, y, yk - y.double(), f"layernorm_fwd_mx[{M},{D}]", math.sqrt(D) * float(gamma.abs().max()))
     report(f"layernorm_fwd_mx[{M},{D}]", lo8_rel_err=err)
 
 
@@ -1553,7 +1558,8 @@ def test_ffmid_fwd_mx(ops, dev, F, nseq, Bn, p):
     assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
     if p > 0:
         assert torch.equal(a[5], b[5])
-    err = _check_mx_planes(b[1], M, Fp, b[0], a[1], f"ffmid_fwd_mx[{F},{nseq},{p}]")
+    # (gamma reaches the kernel as hi + lo half planes with the dropout scale folded in)
+    err = _check_mx_planes(b[1], M, Fp, b[0], a[1], f"ffmid_fwd_mx[{F},{nseq},{p}]", math.sqrt(F) * float((gph.float() + gpl.float()).abs().max()) / (1 - p))
     report(f"ffmid_fwd_mx[{F},{nseq},{p}]", lo8_rel_err=err)
 
 
