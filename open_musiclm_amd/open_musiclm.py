@@ -80,6 +80,15 @@ class TokenConditionedTransformer(nn.Module):
         self.transformer.__dict__["_omlm_owner"] = self
         engine.tag_parameters(self, precision)      # the fused optimizer reads the precision mode off the parameters (16-bit shadow type, loss scale)
 
+    def __setstate__(self, state):
+        """pickle / torch.load(model) / copy.deepcopy (EMA copies) / spawn: the parameter -> model registry of engine.tag_parameters is keyed by
+        object identity, so a reconstructed model registers its own parameters again (the precision tag itself travels in the Parameter's
+        __dict__); without this FusedAdam found 'fp16 parameters without their model' on such a copy."""
+        super().__setstate__(state)
+        self.transformer.__dict__["_omlm_owner"] = self
+        self.__dict__.pop("_omlm_prepared", None)             # operand images of the ORIGINAL's parameters
+        engine.tag_parameters(self, self.precision)
+
     @property
     def device(self):
         return next(self.parameters()).device

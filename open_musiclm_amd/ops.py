@@ -354,7 +354,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dx, dxcast, dgamma, dx_scale=1
     assert dres2 is None or dcode(dres2.dtype) == code, "dres2 must have the cast type"
     if dgamma is not None and defer is not None:
         rows = min(M, 2048)
-        ws = torch.empty(int(hip.lib().omlm_layernorm_bwd_workspace_bytes(D)) // 4, device=x.device)     # private: alive until the group's flush
+        ws = torch.empty(rows * D, device=x.device)     # private, alive until the group's flush: one partial row per workgroup (min(M, 2048) of them)
         call("omlm_layernorm_bwd2", ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dres2), ptr(dx),
              ptr(dxcast), None, ptr(ws), M, D, float(dx_scale), code, dcode(dy.dtype), stream_ptr())
         defer.add(ws, dgamma, rows, D, D)

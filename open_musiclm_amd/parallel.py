@@ -16,6 +16,18 @@ import torch
 import torch.distributed as dist
 
 
+def local_rank_count(world_size: int) -> int:
+    """Ranks per node as the launcher states it (rank-independent by construction: every rank reads the same variables)."""
+    for k in ("LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "SLURM_NTASKS_PER_NODE"):
+        v = os.environ.get(k, "")
+        if v.split("(")[0].isdigit():                # (Slurm writes e.g. "8(x2)")
+            return int(v.split("(")[0])
+    nn = os.environ.get("SLURM_NNODES", os.environ.get("SLURM_JOB_NUM_NODES", ""))
+    if nn.isdigit() and int(nn) > 0:
+        return -(-world_size // int(nn))
+    return world_size
+
+
 class DataParallel:
     def __init__(self, device: Optional[torch.device] = None, backend: Optional[str] = None):
         self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
@@ -32,12 +44,14 @@ class DataParallel:
                 # gloo exchange) shares devices round-robin -- RCCL itself refuses two ranks on one GPU
                 torch.cuda.set_device(self.local_rank % max(torch.cuda.device_count(), 1))
             backend = backend or os.environ.get("OMLM_DP_BACKEND")
-            # ranks share a GPU only on EVIDENCE: the launcher says so (LOCAL_WORLD_SIZE above the visible devices) or this rank's
-            # LOCAL_RANK has no device of its own.  WORLD_SIZE alone proves nothing: a multi-node launch that exports only RANK /
-            # WORLD_SIZE / LOCAL_RANK (srun, mpirun) has WORLD_SIZE = nodes x GPUs and must stay on RCCL.
+            # Do the ranks of this node outnumber its GPUs (a dry run: RCCL refuses two ranks on one device)?  The answer must be the SAME on
+            # every rank -- a per-rank test (LOCAL_RANK >= devices) sent ranks 0-1 to nccl and ranks 2-3 to gloo on a 4-rank / 2-GPU launch
+            # and init_process_group hung -- so it is taken from launch-wide quantities only: the local rank count the launcher
+            # exports (torchrun: LOCAL_WORLD_SIZE; Open MPI: OMPI_COMM_WORLD_LOCAL_SIZE; Slurm: SLURM_NTASKS_PER_NODE, or WORLD_SIZE over
+            # SLURM_NNODES); without any of them WORLD_SIZE itself counts as the local rank count (a multi-node launch that exports none of
+            # these must set LOCAL_WORLD_SIZE or OMLM_DP_BACKEND).
             ndev = torch.cuda.device_count() if use_cuda else 0
-            lws = os.environ.get("LOCAL_WORLD_SIZE")
-            self.shared_gpu = bool(use_cuda and ((lws is not None and int(lws) > ndev) or self.local_rank >= ndev))
+            self.shared_gpu = bool(use_cuda and local_rank_count(self.world_size) > ndev)
             if backend is None:
                 backend = "nccl" if use_cuda else "gloo"
                 if self.shared_gpu:

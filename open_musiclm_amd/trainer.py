@@ -253,6 +253,10 @@ class SingleStageTrainer(nn.Module):
             assert scheduler_path.exists()
             self.scheduler.load_state_dict(torch.load(scheduler_path, map_location=self.device, weights_only=False))
         self._graphed = None        # weights changed under the captured graph: re-capture on the next micro-step
+        # the restored loss-scale block carries the CUMULATIVE skipped-step count, and the restored scheduler was already rewound for those
+        # skips: without this the first train_step after a resume reported them again and rewound the warm-up a second time
+        rep = self.optim.loss_scale_report() if hasattr(self.optim, 'loss_scale_report') else {}
+        self._skipped_seen = rep.get('skipped_steps', 0)
         if self.dp.is_distributed and self.device.type == 'cuda':
             self.optim.sync_replicas(self.dp)
         if steps > 0:

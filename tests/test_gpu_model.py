@@ -779,6 +779,13 @@ def test_fp16_overflow_is_skipped_and_the_loss_scale_backs_off(dev, tmp_path):
     sd = tr.optim.state_dict()
     assert int(float(sd["state"][0]["step"])) == rep["applied_steps"] and sd["omlm_loss_scale"]["scale"] == rep["scale"]
     report("fp16_overflow", **rep, first_loss=losses[0], last_loss=losses[-1])
+    # resume: the restored loss-scale block carries the cumulative skip count; the first step of the resumed trainer must
+    # not report those skips again (it used to rewind the LR warm-up a second time)
+    tr.save(str(tmp_path / "m.pt"), str(tmp_path / "o.pt"))
+    tr.load(str(tmp_path / "m.pt"), str(tmp_path / "o.pt"))
+    assert tr._skipped_seen == rep["skipped_steps"]
+    logs = tr.train_step()
+    assert np.isfinite(logs["loss"]) and logs["skipped_steps"] - rep["skipped_steps"] in (0, 1)          # (a fresh overflow may still be skipped)
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16", "fp16ff"])

@@ -751,15 +751,27 @@ def test_data_parallel_backend_choice_and_shared_gpu_flag(monkeypatch):
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
     dp = parallel.DataParallel(device=torch.device("cuda", 0))
     assert seen["backend"] == "gloo" and seen["device"] == 0 and dp.shared_gpu           # two ranks on one visible GPU: dry run over gloo
-    # a multi-node launch without LOCAL_WORLD_SIZE (srun / mpirun export RANK, WORLD_SIZE, LOCAL_RANK only): 2 nodes x 8 GPUs is NOT a dry run
+    # a multi-node launch without LOCAL_WORLD_SIZE (srun exports RANK, WORLD_SIZE, LOCAL_RANK and its own variables): 2 nodes x 8 GPUs is NOT a dry run
     monkeypatch.delenv("LOCAL_WORLD_SIZE")
+    for k in ("OMPI_COMM_WORLD_LOCAL_SIZE", "SLURM_NTASKS_PER_NODE", "SLURM_NNODES", "SLURM_JOB_NUM_NODES"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("SLURM_NNODES", "2")
     monkeypatch.setenv("WORLD_SIZE", "16"); monkeypatch.setenv("RANK", "11"); monkeypatch.setenv("LOCAL_RANK", "3")
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
     dp = parallel.DataParallel(device=torch.device("cuda", 3))
     assert seen["backend"] == "nccl" and seen["device"] == 3 and not dp.shared_gpu
-    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)                            # ... but a LOCAL_RANK without a device of its own is evidence
-    dp = parallel.DataParallel(device=torch.device("cuda", 1))
-    assert seen["backend"] == "gloo" and dp.shared_gpu
+    monkeypatch.delenv("SLURM_NNODES"); monkeypatch.setenv("OMPI_COMM_WORLD_LOCAL_SIZE", "8")
+    dp = parallel.DataParallel(device=torch.device("cuda", 3))
+    assert seen["backend"] == "nccl" and not dp.shared_gpu
+    # the decision is the same on EVERY rank (a per-rank test split a 4-rank / 2-GPU launch into nccl and gloo ranks)
+    monkeypatch.delenv("OMPI_COMM_WORLD_LOCAL_SIZE"); monkeypatch.setenv("WORLD_SIZE", "4")
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    picked = []
+    for r in range(4):
+        monkeypatch.setenv("RANK", str(r)); monkeypatch.setenv("LOCAL_RANK", str(r))
+        dp = parallel.DataParallel(device=torch.device("cuda", r % 2))
+        picked.append((seen["backend"], dp.shared_gpu))
+    assert picked == [("gloo", True)] * 4
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "2"); monkeypatch.setenv("WORLD_SIZE", "2"); monkeypatch.setenv("RANK", "1"); monkeypatch.setenv("LOCAL_RANK", "1")
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
     monkeypatch.setenv("OMLM_DP_BACKEND", "nccl")
@@ -819,6 +831,14 @@ def test_model_pickles_and_the_parameter_registry_finds_it():
     assert all(engine.model_of(p) is m for p in m.parameters())
     m2 = torch.load(io.BytesIO(buf.getvalue()), weights_only=False)
     assert sorted(m2.state_dict()) == sorted(m.state_dict())
+    # a reconstructed model (torch.load, pickle, copy.deepcopy = EMA copies) registers ITS parameters again -- the fused
+    # optimizer finds the model (and its loss-scale block) through the registry
+    import copy
+    m3 = copy.deepcopy(m)
+    for mm in (m2, m3):
+        assert all(engine.model_of(p) is mm for p in mm.parameters()) and all(p._omlm_precision == "fp16" for p in mm.parameters())
+        assert mm.transformer.__dict__["_omlm_owner"] is mm
+    assert all(engine.model_of(p) is m for p in m.parameters())
 
 
 def test_scheduler_rewind_after_device_skipped_steps():
