@@ -1311,7 +1311,12 @@ static int decode_step2_t(const omlm_decode_args& a, const long long* ids, hipSt
         if (st_x1) { f.stat_in = st_x1; f.nstat_in = npd; f.stat_out = st_u; }
         if (pl) { f.Wlo = a.W1p_lo[l]; f.round_bf16 = 0; }
         if constexpr (sizeof(TW) == 2) {
-            if (pl && B == 1) hipLaunchKernelGGL((dec3_ffin_kernel<TW, 2, true>), dim3((Fp + 7) / 8), dim3(DEC_T), 0, st, f);
+            if (pl && B == 1) {
+                static int cpwl = -1;
+                if (cpwl < 0) { const char* e = getenv("OMLM_DECODE_CPW_PL"); cpwl = e ? atoi(e) : 2; }
+                if (cpwl == 4) hipLaunchKernelGGL((dec3_ffin_kernel<TW, 4, true>), dim3((Fp + 15) / 16), dim3(DEC_T), 0, st, f);
+                else           hipLaunchKernelGGL((dec3_ffin_kernel<TW, 2, true>), dim3((Fp + 7) / 8), dim3(DEC_T), 0, st, f);
+            }
             else if (pl)      dec4_launch<8, DEC2_FFIN, true>(f, (Fp + 7) / 8, st);
         }
         if (pl) {
