@@ -9,14 +9,15 @@ B, N, H = (8, 1817, 16) if large else (int(os.environ.get("B", 32)), 1116, 8)
 M = B * N
 g = torch.Generator().manual_seed(0)
 unit = lambda t: torch.nn.functional.normalize(t, dim=-1)
-q = unit(torch.randn(B, N, H, 64, generator=g)).reshape(M, H * 64).to(dev).bfloat16()
-k = unit(torch.randn(M, 64, generator=g)).to(dev).bfloat16()
-v = torch.randn(M, 64, generator=g).to(dev).bfloat16()
+DT = torch.float16 if os.environ.get("DTYPE", "fp16") == "fp16" else torch.bfloat16
+q = unit(torch.randn(B, N, H, 64, generator=g)).reshape(M, H * 64).to(dev).to(DT)
+k = unit(torch.randn(M, 64, generator=g)).to(dev).to(DT)
+v = torch.randn(M, 64, generator=g).to(dev).to(DT)
 ld = (H + 7) // 8 * 8
 bias = torch.zeros(N, ld); bias[:, :H] = torch.randn(N, H, generator=g) * 0.1; bias = bias.to(dev)
 mask = (torch.rand(B, N, generator=g) > 0.15).to(torch.uint8).to(dev); mask[:, 0] = 1
 out = torch.empty_like(q); lse = torch.empty(B, H, N, device=dev)
-dout = torch.randn(M, H * 64, generator=g).to(dev).bfloat16()
+dout = torch.randn(M, H * 64, generator=g).to(dev).to(DT)
 delta = torch.empty(B, H, N, device=dev)
 dq = torch.empty(M, H * 64, device=dev); dk = torch.empty(M, 64, device=dev); dv = torch.empty(M, 64, device=dev)
 dbias = torch.zeros(N, ld, device=dev)
