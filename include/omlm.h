@@ -111,9 +111,12 @@ int omlm_mqa_attn_fwd(const void* q, const void* k, const void* v, const float* 
 long long omlm_attn_bias_table_floats(int N, int H);
 /* q_scale / k_scale (64 floats each, optional: the learned scales of transformer.py:269-271) or qk_bound > 0 give the bound
  * |q.k| <= max_d |q_scale_d k_scale_d| that lets the bf16 forward exponentiate against a fixed reference point
- * (m_h = scale log2e bound + max bias_h, subtracted from the table) instead of a running maximum; neither: online softmax. */
+ * (m_h = scale log2e bound + max bias_h, subtracted from the table) instead of a running maximum; neither: online softmax.
+ * p_max_log2: 0 for bf16 / fp32 attention operands; 15 for IEEE half operands -- the reference point is lowered by 15 so that the
+ * probability numerators span half's normal range (2^-13 .. 2^15) and the fixed form is selected while scale log2e 2 bound + the
+ * table's range < 28 (wider: the flag in the table stays 0 and the forward runs its online-softmax kernel). */
 int omlm_attn_bias_prepare(const float* bias, float* biasT, int N, int H, int bias_ld, const float* q_scale,
-                           const float* k_scale, float qk_bound, float scale, void* stream);
+                           const float* k_scale, float qk_bound, float scale, int p_max_log2, void* stream);
 /* dbias_ws (optional, omlm_mqa_attn_bwd_workspace_bytes(B, N, H) bytes, contents irrelevant on entry and exit): the dQ kernel leaves
  * each wave's d(bias) bins there with plain stores and a small reduction adds them into dbias; without it every wave adds its bins into
  * dbias with device-scope atomics (measured 290 us per layer slower at B = 8, N = 1817, H = 16). */

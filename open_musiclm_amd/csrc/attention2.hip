@@ -32,6 +32,9 @@ namespace OMLM_NS {
 #ifndef A2_DQ_BATCH
 #define A2_DQ_BATCH 1        /* backward dQ kernel: fragment / bias reads issued in batches (scheduling only, same arithmetic) */
 #endif
+#ifndef A2_SUBFENCE
+#define A2_SUBFENCE 0
+#endif
 #ifndef A2_ABLATE
 #define A2_ABLATE 0          /* profiling builds only: 1 = skip the tile arithmetic, 2 = skip the steady-state DMA, 4 = no exp2; dQ kernel: 8 = no diagonal sums, 16 = no per-block table update, 32 = no global d(bias) flush */
 #endif
@@ -65,33 +68,63 @@ __device__ __forceinline__ h16x8 a2_pack(const f32x16& p, int s) {
 
 // ---- bias table [N, ld] (row = i - j, column = head) -> transposed, padded, pre-multiplied by log2 e: [H8][ldT] ----------
 // One workgroup per head.  With a bound on |q.k| (qk_max, from the learned scales or given) the fixed reference point
-// m_h = c qk_max + max_r table_h[r] is subtracted from every entry (pads included) and written to the row's tail
-// [ldT - 2] = 1.0 (flag), [ldT - 1] = m_h; without one, or if the exponent range could get near fp32's, the flag is 0.
+// m_h = c qk_max + max_r table_h[r] - p_max_log2 is subtracted from every entry (pads included) and written to the row's tail
+// [ldT - 2] = 1.0 (flag), [ldT - 1] = m_h; without a bound, or if the exponent range could leave the operand type's normal range, the
+// flag is 0.  The decision is the SAME for every head (it looks at the widest head's range): the forward picks its kernel by it.
+//   p_max_log2: the largest probability numerator is 2^p_max_log2.  0 for bf16 / fp32 operands (numerators <= 1, fp32's exponent range
+//   below); 15 for IEEE half, whose normal range is 2^-14 .. 2^15.99: numerators in (2^-13, 2^15] while 2 c qk_max + range < 28.
 __global__ void attn2_bias_prep_kernel(const float* __restrict__ bias, float* __restrict__ biasT, int N, int H, int ld, int ldT,
-                                       const float* __restrict__ q_scale, const float* __restrict__ k_scale, float qk_bound, float c) {
-    __shared__ float red[8];
+                                       const float* __restrict__ q_scale, const float* __restrict__ k_scale, float qk_bound, float c,
+                                       int p_max_log2) {
+    __shared__ float red[4][2][8];
+    __shared__ float redq[4];
     const int h = blockIdx.x, t = threadIdx.x;
     float* row = biasT + (size_t)h * ldT;
     const bool has = bias && h < H;
-    float bmax = has ? -3.0e38f : 0.f, bmin = has ? 3.0e38f : 0.f;
-    if (has) for (int r = t; r < N; r += 256) { const float x = bias[(size_t)r * ld + h] * A2_LOG2E; bmax = fmaxf(bmax, x); bmin = fminf(bmin, x); }
+    // every head's extremes (8 heads per pass): the widest range decides for all, this head's maximum sets its reference point
+    float wide = 0.f, own_max = 0.f;
+    if (bias) {
+        for (int hb = 0; hb < H; hb += 8) {
+            float mx[8], mn[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { mx[j] = -3.0e38f; mn[j] = 3.0e38f; }
+            for (int r = t; r < N; r += 256) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float x = hb + j < H ? bias[(size_t)r * ld + hb + j] * A2_LOG2E : 0.f;
+                    mx[j] = fmaxf(mx[j], x); mn[j] = fminf(mn[j], x);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float a = wave_max(mx[j]), b = -wave_max(-mn[j]);
+                if ((t & 63) == 0) { red[t >> 6][0][j] = a; red[t >> 6][1][j] = b; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (hb + j < H) {
+                    const float a = fmaxf(fmaxf(red[0][0][j], red[1][0][j]), fmaxf(red[2][0][j], red[3][0][j]));
+                    const float b = fminf(fminf(red[0][1][j], red[1][1][j]), fminf(red[2][1][j], red[3][1][j]));
+                    wide = fmaxf(wide, a - b);
+                    if (hb + j == h) own_max = a;
+                }
+            }
+        }
+    }
     float qk = qk_bound;
-    if (q_scale && k_scale) { qk = 0.f; if (t < 64) qk = fabsf(q_scale[t] * k_scale[t]); }
-    bmax = wave_max(bmax); bmin = -wave_max(-bmin); qk = wave_max(qk);
-    __syncthreads();
-    if ((t & 63) == 0) { red[t >> 6] = bmax; red[4 + (t >> 6)] = bmin; }
-    __syncthreads();
-    bmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    bmin = fminf(fminf(red[4], red[5]), fminf(red[6], red[7]));
-    if (q_scale && k_scale) qk = __shfl(qk, 0, 64);      // wave 0 holds it; other waves recompute below
-    __syncthreads();
-    if (t == 0) red[0] = qk;
-    __syncthreads();
-    qk = (q_scale && k_scale) ? red[0] : qk_bound;
+    if (q_scale && k_scale) {
+        qk = t < 64 ? fabsf(q_scale[t] * k_scale[t]) : 0.f;
+        qk = wave_max(qk);
+        if ((t & 63) == 0) redq[t >> 6] = qk;
+        __syncthreads();
+        qk = redq[0];
+    }
     const float B = c * qk;
-    // all exponents lie in [-(2 B + bmax - bmin), 0]; keep them well inside the fp32 normal range
-    const bool fixed = qk > 0.f && (2.f * B + (bmax - bmin)) < 80.f;
-    const float m = fixed ? B + bmax : 0.f;
+    // all exponents lie in [p_max_log2 - (2 B + range), p_max_log2]
+    const bool fixed = qk > 0.f && (2.f * B + wide) < (p_max_log2 > 0 ? 13.f + (float)p_max_log2 : 80.f);
+    const float m = fixed ? B + own_max - (float)p_max_log2 : 0.f;
     for (int x = t; x < ldT - 2; x += 256) {
         const int r = x - A2_PAD;
         const float v = (has && r >= 0 && r < N) ? bias[(size_t)r * ld + h] * A2_LOG2E : 0.f;
@@ -141,60 +174,64 @@ struct A2Stager {
     }
 };
 
-template <int QB>
-struct A2Acc {
-    f32x16 acc[QB][2];      // O^T: [query block][d tile]
-    f32x16 accl;            // denominators; row parity (i & 1) == qb holds those of query block qb
-    float m[QB];            // running max (online path only)
+struct A4Acc {
+    f32x16 acc[2][2];       // O^T: [head][d tile]
+    f32x16 accl;            // denominators; row parity (i & 1) == hb holds those of head hb
+    float m[2];             // running max (online form only)
 };
 
-// One 64-key tile against the wave's QB query blocks.
+// One 64-key tile against the wave's two heads x 32 queries.
 //   FIXED: the exponentials are taken against a FIXED reference point instead of a running maximum.  q and k are l2-normalised
 //          vectors times learned scales (transformer.py:269-271), so |q.k| <= max_d |q_scale_d k_scale_d| =: qk_max and every
 //          score is <= m_h = scale log2(e) qk_max + max_rel bias_h.  omlm_attn_bias_prepare subtracts m_h from the table, so the
 //          work per score is ONE fma (score * c + table) and ONE exp2: no row maximum, no cross-lane step, no rescaling of
 //          the accumulators, no dependency between blocks other than the MFMA accumulation itself.  The result is the same
 //          softmax (numerator and denominator share the factor 2^-m_h); it is only selected while 2 c qk_max + the table's
-//          range stays far from the fp32 exponent range (flag in the table's tail), else the online path runs.
-//   FULL:  every block of the tile lies strictly below the diagonal for every query block: straight-line code, no compares.
-template <int QB, bool FIXED, bool FULL>
-__device__ __forceinline__ void a2_tile(A2Acc<QB>& A, const h16x8 (&qf)[QB][4], const char* Ks, const h16_t* livef_tile,
+//          range stays inside the operand type's exponent range (flag in the table's tail), else the online form runs.
+//   FULL:  every block of the tile lies strictly below the diagonal: straight-line code, no compares.
+//   QSEL >= 0: only head QSEL is processed (the online form walks the heads one at a time: fewer live registers).
+//   Addressing: every LDS read of the tile is (one lane-dependent base register) + (compile-time offset) -- the bias window from ONE
+//   base below its lowest entry (the 64 window reads of a tile had an address add each), the live vectors from a per-head base that
+//   points at the sample's liveness array for the lanes whose accumulator rows belong to that head and at a block of zeros for the
+//   others (instead of 32 per-value selects): ~70 of ~260 VALU instructions per tile less in a loop that is VALU-issue bound.
+template <bool FIXED, bool FULL, int QSEL = -1>
+__device__ __forceinline__ void a4_tile(A4Acc& A, const h16x8 (&qf)[2][4], const char* Ks, const h16_t* live0, const h16_t* live1,
                                         float c, int i0, int j0, int wave, int lane) {
     const char* Vs = Ks + 8192;
-    const float* bw = (const float*)(Ks + 16384) + wave * A2_BWIN;
     const int hi = lane >> 5, ql = lane & 31;
-    // both 32-key blocks in one straight line: the scheduler overlaps one block's exponentials with the other's MFMAs
+    // window index of (head hb, query ql, key 32 sub + 4 hi + cr): hb 128 + 64 + ql - 32 sub - 4 hi - cr, cr = crow(r, 0) <= 27
+    // (the base as ONE opaque LDS address: hipcc otherwise folds the stage's 16 KB offset into each read's constant, past the offset field)
+    unsigned bbo = (unsigned)(size_t)LDS_PTR(const float, (const float*)(Ks + 16384) + 2 * wave * A2_BWIN + ql - 4 * hi);
+    asm volatile("" : "+v"(bbo));
+    const __attribute__((address_space(3))) float* bb = (const __attribute__((address_space(3))) float*)(size_t)bbo;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
         const int jb = j0 + 32 * sub;
-        if (!FULL && jb > i0 + 32 * QB - 1) break;              // above the diagonal for every query of the workgroup
+        if (!FULL && jb > i0 + 31) break;                       // above the diagonal for every query of the workgroup
         h16x8 kf[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) kf[s] = a2_frag_rows(Ks, 32 * sub, s, lane);
-        h16x8 pb[QB][2];
-        bool on[QB];
+        h16x8 pb[2][2];
+        const bool diag = !FULL && !(jb + 31 <= i0);
+        const int d0 = (i0 + ql) - (jb + 4 * hi);
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-            on[qb] = FULL || jb <= i0 + 32 * qb + 31;           // wave-uniform
-            if (!on[qb]) continue;
+        for (int hb = 0; hb < 2; ++hb) {
+            if (QSEL >= 0 && hb != QSEL) continue;
             f32x16 st;
 #pragma unroll
             for (int e = 0; e < 16; ++e) st[e] = 0.f;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) st = MFMA16(kf[s], qf[qb][s], st);
-            // window index of (query, key): 64 + 32 qb + ql - 32 sub - 4 hi - cr   (cr = crow(r, 0))
-            const float* bp = bw + (64 + 32 * qb - 32 * sub) + ql - 4 * hi;
-            const bool diag = !FULL && !(jb + 31 <= i0 + 32 * qb);
-            const int d0 = (i0 + 32 * qb + ql) - (jb + 4 * hi);
+            for (int s = 0; s < 4; ++s) st = MFMA16(kf[s], qf[hb][s], st);
+            const __attribute__((address_space(3))) float* bp = bb + (hb * A2_BWIN + 64 - 32 * sub - 27);       // entries [27 - cr]: offsets >= 0
             if (FIXED) {
                 if (!diag) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) st[r] = (A2_ABLATE & 4) ? st[r] * c + bp[-((r & 3) + 8 * (r >> 2))] : __builtin_amdgcn_exp2f(st[r] * c + bp[-((r & 3) + 8 * (r >> 2))]);
+                    for (int r = 0; r < 16; ++r) st[r] = (A2_ABLATE & 4) ? st[r] * c + bp[27 - ((r & 3) + 8 * (r >> 2))] : __builtin_amdgcn_exp2f(st[r] * c + bp[27 - ((r & 3) + 8 * (r >> 2))]);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int cr = (r & 3) + 8 * (r >> 2);
-                        const float e2 = __builtin_amdgcn_exp2f(st[r] * c + bp[-cr]);
+                        const float e2 = __builtin_amdgcn_exp2f(st[r] * c + bp[27 - cr]);
                         st[r] = (d0 - cr >= 0) ? e2 : 0.f;
                     }
                 }
@@ -203,197 +240,257 @@ __device__ __forceinline__ void a2_tile(A2Acc<QB>& A, const h16x8 (&qf)[QB][4], 
                 if (!diag) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        st[r] = st[r] * c + bp[-((r & 3) + 8 * (r >> 2))];
+                        st[r] = st[r] * c + bp[27 - ((r & 3) + 8 * (r >> 2))];
                         mloc = fmaxf(mloc, st[r]);
                     }
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int cr = (r & 3) + 8 * (r >> 2);
-                        const float val = st[r] * c + bp[-cr];
+                        const float val = st[r] * c + bp[27 - cr];
                         st[r] = (d0 - cr >= 0) ? val : A2_NEG;
                         mloc = fmaxf(mloc, st[r]);
                     }
                 }
                 mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-                const float mnew = fmaxf(A.m[qb], mloc);
-                const float alpha = __builtin_amdgcn_exp2f(A.m[qb] - mnew);
-                A.m[qb] = mnew;
+                const float mnew = fmaxf(A.m[hb], mloc);
+                const float alpha = __builtin_amdgcn_exp2f(A.m[hb] - mnew);
+                A.m[hb] = mnew;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) st[r] = __builtin_amdgcn_exp2f(st[r] - mnew);
                 if (!__all(alpha == 1.0f)) {
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) { A.acc[qb][0][e] *= alpha; A.acc[qb][1][e] *= alpha; }
-                    A.accl[qb] *= alpha;                        // rows 0/4 (qb 0) and 1/5 (qb 1) are the ones read
+                    for (int e = 0; e < 16; ++e) { A.acc[hb][0][e] *= alpha; A.acc[hb][1][e] *= alpha; }
+                    A.accl[hb] *= alpha;                        // rows 0/4 (head 0) and 1/5 (head 1) are the ones read
                 }
             }
-            pb[qb][0] = a2_pack(st, 0);
-            pb[qb][1] = a2_pack(st, 1);
+            pb[hb][0] = a2_pack(st, 0);
+            pb[hb][1] = a2_pack(st, 1);
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            // live vector of the 16 keys of this k-step in MFMA k order: keys key0 + 4 hi + {0..3}, key0 + 8 + 4 hi + {0..3};
-            // A rows of parity qb carry it for query block qb, the others 0: ONE denominator accumulator for both blocks
-            const h16_t* lp = livef_tile + 32 * sub + 16 * s + 4 * hi;
-            const u32x2 l0 = *(const u32x2*)lp, l1 = *(const u32x2*)(lp + 8);
             const h16x8 va0 = a2_frag_cols_tr(Vs, 32 * sub, s, 0, lane);
             const h16x8 va1 = a2_frag_cols_tr(Vs, 32 * sub, s, 32, lane);
 #pragma unroll
-            for (int qb = 0; qb < QB; ++qb) {
-                if (!on[qb]) continue;
-                const bool mine = QB == 1 || (ql & 1) == qb;
+            for (int hb = 0; hb < 2; ++hb) {
+                if (QSEL >= 0 && hb != QSEL) continue;
+                // live vector of the 16 keys of this k-step in MFMA k order: keys key0 + 4 hi + {0..3}, key0 + 8 + 4 hi + {0..3}; the
+                // A rows of parity hb carry it for head hb, the others zeros: ONE denominator accumulator for both heads
+                const h16_t* lp = (hb ? live1 : live0) + 32 * sub + 16 * s;
+                const u32x2 l0 = *(const u32x2*)lp, l1 = *(const u32x2*)(lp + 8);
                 u32x4 lv4;
-                lv4[0] = mine ? l0[0] : 0u; lv4[1] = mine ? l0[1] : 0u; lv4[2] = mine ? l1[0] : 0u; lv4[3] = mine ? l1[1] : 0u;
-                A.acc[qb][0] = MFMA16(va0, pb[qb][s], A.acc[qb][0]);
-                A.acc[qb][1] = MFMA16(va1, pb[qb][s], A.acc[qb][1]);
-                A.accl = MFMA16(__builtin_bit_cast(h16x8, lv4), pb[qb][s], A.accl);      // sum over live keys of P
+                lv4[0] = l0[0]; lv4[1] = l0[1]; lv4[2] = l1[0]; lv4[3] = l1[1];
+                A.acc[hb][0] = MFMA16(va0, pb[hb][s], A.acc[hb][0]);
+                A.acc[hb][1] = MFMA16(va1, pb[hb][s], A.acc[hb][1]);
+                A.accl = MFMA16(__builtin_bit_cast(h16x8, lv4), pb[hb][s], A.accl);      // sum over live keys of P
             }
         }
     }
 }
 
-#ifndef A2_OCC
-#define A2_OCC
-#endif
-template <int QB>
-__global__ __launch_bounds__(A2_THREADS) A2_OCC void attn2_fwd_kernel(const h16_t* __restrict__ q, const h16_t* __restrict__ k,
-                                                               const h16_t* __restrict__ v, const float* __restrict__ biasT, int ldT,
-                                                               const unsigned char* __restrict__ keymask, h16_t* __restrict__ out,
-                                                               float* __restrict__ lse, int B, int N, int H, float scale) {
-    constexpr int TQW = 32 * QB;
+// Forward: one workgroup = 4 waves = 8 heads x 32 queries of one sample, each wave TWO heads; two workgroups per CU (63 KB of LDS,
+// <= 256 registers).  Against the 8-wave form it replaces (one head per wave, one workgroup per CU: 122 us -> 95 us per layer at B = 32,
+// N = 1116 with half operands):
+//   * the K fragments and the V (transposed) fragments of a 32-key block are read from LDS once for two heads, and a wave has four
+//     independent (head, key block) chains for the scheduler to interleave exponentials with MFMAs;
+//   * the two waves of a SIMD belong to different workgroups, so they do not meet at the same barrier -- with 8 waves in one workgroup
+//     both waves of a SIMD ran the same phase of the same tile at the same time (both want the VALU, then both want the matrix pipe), and
+//     a workgroup's prologue / epilogue (~3 dependent round trips) had nothing to hide behind.
+#define A4_THREADS 256
+struct A4Stager {
+    unsigned koff[2], voff[2], boff;     // per-lane source byte offsets of the wave's two K units, two V units, one bias unit
+    int vrow[2];
+    // Recomputed from the lane id at every use (a dozen integer ops per tile): kept across the tile loop these seven registers were
+    // spilled (the tile body wants all 256), and hipcc puts s_waitcnt vmcnt(0) behind a scratch reload -- which drains the DMA ring.
+    __device__ __forceinline__ void init(int wave, int lane, int ldT) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int unit = 2 * wave + u;
+            {   // K unit: rows 8 unit + (lane >> 3), slot lane & 7 holds chunk slot ^ ((row >> 1) & 7)
+                const int row = 8 * unit + (lane >> 3), ch = (lane & 7) ^ ((row >> 1) & 7);
+                koff[u] = (unsigned)(row * 128 + ch * 16);
+            }
+            {   // V unit of the blocked image (see A2Stager)
+                const int p = lane >> 3, rq = ((p >> 2) << 1) | ((p >> 1) & 1);
+                vrow[u] = (unit >> 1) * 16 + rq * 4 + ((lane >> 1) & 3);
+                const int col = (unit & 1) * 32 + (p & 1) * 16 + (lane & 1) * 8;
+                voff[u] = (unsigned)(vrow[u] * 128 + col * 2);
+            }
+        }
+        const int hh = 2 * wave + (lane >> 5);                   // bias unit `wave`: heads 2 wave, 2 wave + 1
+        boff = (unsigned)(((size_t)hh * ldT + 4 * (lane & 31)) * 4);
+    }
+};
+
+// FIXED is a template parameter of the KERNEL, and both instances are launched: which softmax form applies is known on the device only
+// (the flag in the table's tail, omlm_attn_bias_prepare), and the instance the flag does not name returns at its first instruction
+// (~3 us per layer).  One kernel holding both forms was tried: at 256 registers it either spilled ~20 loop-invariant registers -- hipcc
+// waits vmcnt(0) behind every scratch reload, which drains the DMA ring -- or, with the online form walking its heads one at a time, kept
+// the fixed form 10 % slower than this split (103 vs 92 us).
+//   FIXED: both heads in one straight line.  Online (more live state: running maxima, rescale factors): the two heads one after the
+//   other (QSEL), re-reading the K / V fragments per head.
+template <bool FIXED>
+__global__ __launch_bounds__(A4_THREADS, 2) void attn4_fwd_kernel(const h16_t* __restrict__ q, const h16_t* __restrict__ k,
+                                                                  const h16_t* __restrict__ v, const float* __restrict__ biasT, int ldT,
+                                                                  const unsigned char* __restrict__ keymask, h16_t* __restrict__ out,
+                                                                  float* __restrict__ lse, int B, int N, int H, float scale) {
+    // the flag of head 0: omlm_attn_bias_prepare decides once for all heads
+    if ((biasT && __builtin_amdgcn_readfirstlane(__float_as_int(biasT[ldT - 2])) != 0) != FIXED) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;                                        // A2_NST stages
-    char* scratch = smem + A2_NST * A2_STAGE;                 // 4 KiB sink for the padding DMA of waves 4-7
-    h16_t* livef = (h16_t*)(scratch + 4096);                // [nkt_all * 64] 1.0 / 0.0 per key of this sample
-
-    const int nqt = (N + TQW - 1) / TQW, ny = (H + 7) / 8;
-    // XCD-aware, sample-major order: the workgroups of one sample (they share its K / V through the XCD's L2) are dealt to
-    // one XCD, heavy (late) query tiles first inside a sample.
-    int lg;
+    h16_t* livef = (h16_t*)(smem + A2_NST * A2_STAGE);      // [nkt_all * 64] 1.0 / 0.0 per key of this sample
+    const int nqt = (N + 31) / 32, ny = (H + 7) / 8;
+    // XCD-aware order: the workgroups of one sample (they share its K / V through the XCD's L2) are dealt to one XCD.  When an XCD's
+    // share is whole samples (B a multiple of 8), its items run heaviest (latest) query tile first ACROSS its samples -- dealt sample by
+    // sample, the last sample's 18-tile items started two thirds into the launch and the SIMDs averaged 1.3 of 2 resident waves.
+    int b, qt, hy;
     {
-        const int total = nqt * ny * B, lin = blockIdx.x;
+        const int per = nqt * ny, total = per * B, lin = blockIdx.x;
         const int qq = total >> 3, rr = total & 7, xcd = lin & 7, idx = lin >> 3;
-        lg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+        const int start = xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq, cnt = qq + (xcd < rr ? 1 : 0);
+        if (start % per == 0 && cnt % per == 0) {
+            const int ns = cnt / per, w = idx % (ns * ny);
+            qt = nqt - 1 - idx / (ns * ny);
+            b = start / per + w / ny;
+            hy = w % ny;
+        } else {                                              // sample-major, heavy tiles first inside a sample
+            const int lg = start + idx;
+            b = lg / per;
+            const int rem = lg - b * per;
+            qt = nqt - 1 - rem / ny;
+            hy = rem % ny;
+        }
     }
-    const int b = lg / (nqt * ny);
-    const int rem = lg - b * (nqt * ny);
-    const int qt = nqt - 1 - rem / ny, hy = rem % ny;
     const int lane = threadIdx.x & 63, hi = lane >> 5, ql = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int h = hy * 8 + wave;
-    const bool active = h < H;
-    const int i0 = qt * TQW;
+    const int h0 = hy * 8 + 2 * wave;                        // heads h0, h0 + 1
+    const int i0 = qt * 32;
     const size_t rowbase = (size_t)b * N;
-    const int nkt = min((i0 + TQW + A2_TKV - 1) / A2_TKV, (N + A2_TKV - 1) / A2_TKV);   // key tiles this query tile needs
+    const int nkt = min((i0 + 32 + A2_TKV - 1) / A2_TKV, (N + A2_TKV - 1) / A2_TKV);   // key tiles this query tile needs
 
-    // ---- prologue: liveness of this sample's keys, as a bf16 1/0 array (denominator operand) and one ballot word per key tile
-    // (V rows of masked keys are DMA'd as zeros).  All byte loads are issued before the first wait: a rolled loop made hipcc
-    // wait for every load separately (one L2 round trip per key tile and workgroup: most of the kernel's time at first).
-    unsigned long long* livebits = (unsigned long long*)(livef + (size_t)((N + 63) / 64) * 64);     // [<= 64 tiles]
+    // ---- prologue: liveness of this sample's keys, as a 1/0 array of the operand type (denominator operand) and one ballot word per key
+    // tile (V rows of masked keys are DMA'd as zeros).  All byte loads are issued before the first wait.
+    unsigned long long* livebits = (unsigned long long*)(livef + (size_t)((N + 63) / 64) * 64);     // [64 tiles]
+    unsigned* zeros = (unsigned*)(livebits + 64);                                                 // 128 B of zeros (see a4_tile)
     {
-        unsigned char mk[8];
+        unsigned char mk[16];
 #pragma unroll
-        for (int it = 0; it < 8; ++it) mk[it] = 1;
+        for (int it = 0; it < 16; ++it) mk[it] = 1;
         if (keymask) {
 #pragma unroll
-            for (int it = 0; it < 8; ++it) mk[it] = keymask[rowbase + min(it * A2_THREADS + (int)threadIdx.x, N - 1)];   // clamped: no branch per load
+            for (int it = 0; it < 16; ++it)
+                if (it * A4_THREADS < nkt * A2_TKV) mk[it] = keymask[rowbase + min(it * A4_THREADS + (int)threadIdx.x, N - 1)];   // uniform condition, clamped index
         }
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int j = it * A2_THREADS + threadIdx.x;
-            if (it * A2_THREADS < nkt * A2_TKV) {               // uniform
+        for (int it = 0; it < 16; ++it) {
+            const int j = it * A4_THREADS + threadIdx.x;
+            if (it * A4_THREADS < nkt * A2_TKV) {               // uniform
                 const bool lv = j < N && mk[it] != 0;
                 const unsigned long long w = __ballot(lv);
                 if (j < nkt * A2_TKV) livef[j] = lv ? (h16_t)1.0f : (h16_t)0.0f;
-                if (lane == 0 && it * 8 + wave < nkt) livebits[it * 8 + wave] = w;
+                if (lane == 0 && it * 4 + wave < nkt) livebits[it * 4 + wave] = w;
             }
         }
+        if (threadIdx.x < 32) zeros[threadIdx.x] = 0u;
     }
     __syncthreads();                                          // livef / livebits visible; no LDS-DMA in flight yet
-    A2Stager stg;
-    stg.init(wave, lane, ldT);
     const a2_rsrc rsK = a2_make_rsrc(k + rowbase * 64, (unsigned)N * 128u);
     const a2_rsrc rsV = a2_make_rsrc(v + rowbase * 64, (unsigned)N * 128u);
     const a2_rsrc rsB = a2_make_rsrc(biasT ? (const void*)(biasT + (size_t)hy * 8 * ldT) : (const void*)k, biasT ? (unsigned)(8 * ldT * 4) : 0u);
-    const unsigned ring_lds = (unsigned)(size_t)LDS_PTR(char, ring), scratch_lds = (unsigned)(size_t)LDS_PTR(char, scratch);
+    const unsigned ring_lds = (unsigned)(size_t)LDS_PTR(char, ring);
 
-    auto issue = [&](int t) {                                  // 3 DMA wave-instructions per wave per tile
+    auto issue = [&](int t, int lane_) {                       // 5 DMA wave-instructions per wave per tile
+        A4Stager stg;
+        stg.init(wave, lane_, ldT);
         const unsigned st = ring_lds + (unsigned)((t % A2_NST) * A2_STAGE);
         const int j0 = t * A2_TKV;
-        const bool vl = (livebits[t] >> stg.vrow) & 1ull;      // one broadcast LDS read per tile
-        a2_dma(rsK, st + wave * 1024, (unsigned)(j0 * 128) + stg.koff);                 // rows >= N: beyond the descriptor -> zeros
-        a2_dma(rsV, st + 8192 + wave * 1024, vl ? (unsigned)(j0 * 128) + stg.voff : OOB_OFF);
-        // bias window of this tile: table index PAD + rel, rel from i0 - j0 - 64
-        const unsigned w0 = (unsigned)((A2_PAD + i0 - j0 - 64) * 4);
-        if (stg.bias_wave) a2_dma(rsB, st + 16384 + (wave & 3) * 1024, w0 + stg.boff);
-        else               a2_dma(rsB, scratch_lds + (wave & 3) * 1024, OOB_OFF);       // keeps every wave at 3 per tile
+        const unsigned long long lb = livebits[t];             // one broadcast LDS read per tile
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            a2_dma(rsK, st + (2 * wave + u) * 1024, (unsigned)(j0 * 128) + stg.koff[u]);           // rows >= N: beyond the descriptor -> zeros
+            a2_dma(rsV, st + 8192 + (2 * wave + u) * 1024, ((lb >> stg.vrow[u]) & 1ull) ? (unsigned)(j0 * 128) + stg.voff[u] : OOB_OFF);
+        }
+        // bias window of this tile: table index PAD + rel, rel from i0 - j0 - 64 (no table: empty descriptor -> zeros)
+        a2_dma(rsB, st + 16384 + wave * 1024, (unsigned)((A2_PAD + i0 - j0 - 64) * 4) + stg.boff);
     };
 
-    issue(0);
-    if (nkt > 1) issue(1);
-    // Q fragments (B operand of S^T = K Q^T): query i0 + 32 qb + ql, dims 16 s + 8 hi .. +7
-    h16x8 qf[QB][4];
+    issue(0, lane);
+    if (nkt > 1) issue(1, lane);
+    // Q fragments (B operand of S^T = K Q^T): query i0 + ql, dims 16 s + 8 hi .. +7, of the wave's two heads
+    h16x8 qf[2][4];
+    const int qi = i0 + ql;
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        const int qi = i0 + 32 * qb + ql;
+    for (int hb = 0; hb < 2; ++hb) {
+        const bool act = h0 + hb < H;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             u32x4 z = {0u, 0u, 0u, 0u};
-            const h16_t* p = q + (rowbase + min(qi, N - 1)) * (size_t)(H * 64) + (size_t)(active ? h : 0) * 64 + 16 * s + 8 * hi;
-            u32x4 val = (active && qi < N) ? *(const u32x4*)p : z;
-            qf[qb][s] = __builtin_bit_cast(h16x8, val);
+            const h16_t* p = q + (rowbase + min(qi, N - 1)) * (size_t)(H * 64) + (size_t)(act ? h0 + hb : 0) * 64 + 16 * s + 8 * hi;
+            u32x4 val = (act && qi < N) ? *(const u32x4*)p : z;
+            qf[hb][s] = __builtin_bit_cast(h16x8, val);
         }
     }
     // Consume the Q loads HERE: hipcc then waits for them before the loop.  Left to their first use inside the loop, its
     // s_waitcnt vmcnt(0) sat in front of the first MFMA of every tile and drained the DMA ring each iteration (seen in the ISA).
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb)
+    for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[qb][s]));
+        for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[hb][s]));
 
-    A2Acc<QB> A;
+    A4Acc A;
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        A.m[qb] = A2_NEG;
+    for (int hb = 0; hb < 2; ++hb) {
+        A.m[hb] = A2_NEG;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { A.acc[qb][0][e] = 0.f; A.acc[qb][1][e] = 0.f; }
+        for (int e = 0; e < 16; ++e) { A.acc[hb][0][e] = 0.f; A.acc[hb][1][e] = 0.f; }
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) A.accl[e] = 0.f;
     const float c = scale * A2_LOG2E;
-    // fixed reference point (see a2_tile): the table prepared for this head carries its flag and value in the row's tail
-    float mfix = 0.f;
-    bool fixed = false;
-    if (biasT && active) {
-        const float* tail = biasT + (size_t)h * ldT + (ldT - 2);
-        fixed = __builtin_amdgcn_readfirstlane(__float_as_int(tail[0])) != 0;
-        mfix = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(tail[1])));
+    float mfix[2] = {0.f, 0.f};                              // fixed reference points of the two heads (table tails)
+    if (FIXED) {
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+            mfix[hb] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(biasT[(size_t)(h0 + hb) * ldT + (ldT - 1)])));
     }
-    asm volatile("" : "+s"(mfix));                            // loaded (and waited for) before the tile loop
+    asm volatile("" : "+s"(mfix[0]), "+s"(mfix[1]));          // loaded (and waited for) before the tile loop
 
     for (int t = 0; t < nkt; ++t) {
-        // own DMA of tile t retired (tile t+1's three may stay in flight), then everybody's; the barrier also says that all
+        // own DMA of tile t retired (tile t+1's five may stay in flight), then everybody's; the barrier also says that all
         // waves are done with tile t-1, whose stage tile t+2 is about to overwrite
-        if (t + 1 < nkt) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        if (t + 1 < nkt) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         else             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (t + 2 < nkt && !(A2_ABLATE & 2)) issue(t + 2);
-        if (!active || (A2_ABLATE & 1)) continue;
+        int lane_ = lane;                                      // opaque per tile: every lane-derived address is rebuilt, none carried (see A4Stager)
+        asm volatile("" : "+v"(lane_));
+        if (t + 2 < nkt && !(A2_ABLATE & 2)) issue(t + 2, lane_);
+        if (A2_ABLATE & 1) continue;
         const char* Ks = ring + (t % A2_NST) * A2_STAGE;
         const int j0 = t * A2_TKV;
-        const bool full = j0 + A2_TKV - 1 <= i0;               // every block of the tile lies below the diagonal of every query block
-        if (fixed) { if (full) a2_tile<QB, true, true>(A, qf, Ks, livef + j0, c, i0, j0, wave, lane);
-                     else      a2_tile<QB, true, false>(A, qf, Ks, livef + j0, c, i0, j0, wave, lane); }
-        else       { if (full) a2_tile<QB, false, true>(A, qf, Ks, livef + j0, c, i0, j0, wave, lane);
-                     else      a2_tile<QB, false, false>(A, qf, Ks, livef + j0, c, i0, j0, wave, lane); }
+        const bool full = j0 + A2_TKV - 1 <= i0;               // every block of the tile lies below the diagonal
+        const h16_t* lv = livef + j0 + 4 * (lane_ >> 5);
+        const h16_t* live0 = (lane_ & 1) == 0 ? lv : (const h16_t*)zeros;
+        const h16_t* live1 = (lane_ & 1) == 1 ? lv : (const h16_t*)zeros;
+        if (FIXED) {
+            if (full) a4_tile<true, true>(A, qf, Ks, live0, live1, c, i0, j0, wave, lane_);
+            else      a4_tile<true, false>(A, qf, Ks, live0, live1, c, i0, j0, wave, lane_);
+        } else if (full) {
+            a4_tile<false, true, 0>(A, qf, Ks, live0, live1, c, i0, j0, wave, lane_);
+            __builtin_amdgcn_sched_barrier(0);
+            a4_tile<false, true, 1>(A, qf, Ks, live0, live1, c, i0, j0, wave, lane_);
+        } else {
+            a4_tile<false, false, 0>(A, qf, Ks, live0, live1, c, i0, j0, wave, lane_);
+            __builtin_amdgcn_sched_barrier(0);
+            a4_tile<false, false, 1>(A, qf, Ks, live0, live1, c, i0, j0, wave, lane_);
+        }
     }
-    if (!active) return;
+    if (qi >= N) return;
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        const int qi = i0 + 32 * qb + ql;
-        if (qi >= N) continue;
-        const float lsum = A.accl[qb];                  // element e = qb: row crow(qb, hi) has parity qb
-        const float mref = fixed ? mfix : A.m[qb];
+    for (int hb = 0; hb < 2; ++hb) {
+        const int h = h0 + hb;
+        if (h >= H) continue;
+        const float lsum = A.accl[hb];                  // element e = hb: row crow(hb, hi) has parity hb
+        const float mref = FIXED ? mfix[hb] : A.m[hb];
         // a query without any live causal key has no defined softmax: emit zeros and an lse that zeroes its backward
         const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
         h16_t* orow = out + (rowbase + qi) * (size_t)(H * 64) + (size_t)h * 64;
@@ -402,8 +499,8 @@ __global__ __launch_bounds__(A2_THREADS) A2_OCC void attn2_fwd_kernel(const h16_
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int d = 32 * dt + 8 * g4 + 4 * hi;
-                store4_from_float(orow + d, A.acc[qb][dt][4 * g4] * inv, A.acc[qb][dt][4 * g4 + 1] * inv,
-                                  A.acc[qb][dt][4 * g4 + 2] * inv, A.acc[qb][dt][4 * g4 + 3] * inv);
+                store4_from_float(orow + d, A.acc[hb][dt][4 * g4] * inv, A.acc[hb][dt][4 * g4 + 1] * inv,
+                                  A.acc[hb][dt][4 * g4 + 2] * inv, A.acc[hb][dt][4 * g4 + 3] * inv);
             }
         if (hi == 0 && lse) lse[((size_t)b * H + h) * N + qi] = lsum > 0.f ? mref + log2f(lsum) : 1.0e30f;   // log2 domain
     }
@@ -694,13 +791,15 @@ extern "C" long long omlm_attn_bias_table_floats(int N, int H) {
 // biasT: omlm_attn_bias_table_floats(N, H) floats.  bias may be null (no rel-pos bias).  q_scale / k_scale (64 floats each, optional):
 // the learned per-dim scales applied after the l2 normalisation -- they give the bound max_d |q_scale_d k_scale_d| on |q.k| that
 // selects the fixed-reference softmax; alternatively qk_bound > 0 states the bound directly (callers with unit q, k: 1.0);
-// neither: online softmax.  scale: the attention scale (8).
+// neither: online softmax.  scale: the attention scale (8).  p_max_log2: 0 for bf16 / fp32 attention operands, 15 for half operands (the
+// fixed reference point is lowered by 15 so that the probability numerators use half's normal range; see attn2_bias_prep_kernel).
 extern "C" int omlm_attn_bias_prepare(const float* bias, float* biasT, int N, int H, int bias_ld, const float* q_scale,
-                                      const float* k_scale, float qk_bound, float scale, void* stream) {
+                                      const float* k_scale, float qk_bound, float scale, int p_max_log2, void* stream) {
     OMLM_CHECK_ARG(biasT && N > 0 && H > 0, "null table / sizes");
+    OMLM_CHECK_ARG(p_max_log2 == 0 || p_max_log2 == 15, "p_max_log2: 0 (bf16 / fp32 operands) or 15 (half operands)");
     const int ldT = (A2_PAD + N + 2 * A2_BWIN + 3) / 4 * 4, H8 = (H + 7) / 8 * 8;
     hipLaunchKernelGGL(attn2_bias_prep_kernel, dim3(H8), dim3(256), 0, as_stream(stream), bias, biasT, N, H, bias_ld, ldT, q_scale, k_scale,
-                       qk_bound, scale * A2_LOG2E);
+                       qk_bound, scale * A2_LOG2E, p_max_log2);
     return omlm_post_launch("omlm_attn_bias_prepare");
 }
 
@@ -747,14 +846,20 @@ extern "C" __attribute__((visibility("hidden"))) int omlm_attn_dbias_reduce_laun
 int attn2_fwd_launch(const void* q, const void* k, const void* v, const float* biasT, const unsigned char* keymask,
                      void* out, float* lse, int B, int N, int H, float scale, hipStream_t st) {
     const int ldT = (A2_PAD + N + 2 * A2_BWIN + 3) / 4 * 4;
-    constexpr int QB = 1;        // query blocks per wave (2 was measured slower and does not fit 256 registers with both key blocks unrolled)
-    const int TQW = 32 * QB, nqt = (N + TQW - 1) / TQW, ny = (H + 7) / 8;
-    const size_t lds = (size_t)A2_NST * A2_STAGE + 4096 + (size_t)((N + 63) / 64 * 64) * 2 + 64 * 8;
-    if (N > 64 * 64) { omlm_set_error("attention: N > 4096 keys per sample is not supported (liveness prologue covers 8 x 512 keys)"); return OMLM_ERR_UNSUPPORTED; }
-    dim3 grid(nqt * ny * B), block(A2_THREADS);
-    static bool a1 = false;
-    if (!a1) { (void)hipFuncSetAttribute((const void*)attn2_fwd_kernel<QB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a1 = true; }
-    hipLaunchKernelGGL(attn2_fwd_kernel<QB>, grid, block, lds, st, (const h16_t*)q, (const h16_t*)k, (const h16_t*)v, biasT, ldT, keymask, (h16_t*)out, lse, B, N, H, scale);
+    if (N > 64 * 64) { omlm_set_error("attention: N > 4096 keys per sample is not supported (liveness prologue covers 4096 keys)"); return OMLM_ERR_UNSUPPORTED; }
+    const int nqt = (N + 31) / 32, ny = (H + 7) / 8;
+    const size_t lds = (size_t)A2_NST * A2_STAGE + (size_t)((N + 63) / 64 * 64) * 2 + 64 * 8 + 128;
+    static bool a4 = false;
+    if (!a4) {
+        (void)hipFuncSetAttribute((const void*)attn4_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)attn4_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        a4 = true;
+    }
+    // both softmax forms: the one the table's flag does not name returns at its first instruction (no table: online only)
+    if (biasT) hipLaunchKernelGGL(attn4_fwd_kernel<true>, dim3(nqt * ny * B), dim3(A4_THREADS), lds, st, (const h16_t*)q, (const h16_t*)k,
+                                  (const h16_t*)v, biasT, ldT, keymask, (h16_t*)out, lse, B, N, H, scale);
+    hipLaunchKernelGGL(attn4_fwd_kernel<false>, dim3(nqt * ny * B), dim3(A4_THREADS), lds, st, (const h16_t*)q, (const h16_t*)k, (const h16_t*)v,
+                       biasT, ldT, keymask, (h16_t*)out, lse, B, N, H, scale);
     return omlm_post_launch("omlm_mqa_attn_fwd");
 }
 

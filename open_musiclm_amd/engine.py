@@ -538,12 +538,10 @@ def trunk_forward(tr, pw: PreparedWeights, x: torch.Tensor, keymask: Optional[to
             torch.cuda.current_stream(dev).wait_stream(side)
             table.record_stream(torch.cuda.current_stream(dev))      # allocated under the side stream, read by the trunk's kernels
             side = None
-        # the layer's bias table in the kernels' layout, with the fixed softmax reference point its scales allow
-        # (fp16: the fixed reference point is an upper bound, so typical probabilities sit around 2^-12 of it -- at the edge of half's
-        # normal range; the online softmax keeps every row's maximum at 1)
-        fixed_ok = T != torch.float16
-        abias = ops.AttnBias(table, N, H, dev, q_scale=attn.q_scale.detach() if fixed_ok else None,
-                             k_scale=attn.k_scale.detach() if fixed_ok else None, scale=ATTN_SCALE)
+        # the layer's bias table in the kernels' layout, with the fixed softmax reference point its scales allow (fp16: 15 octaves below the
+        # bound, so that the probability numerators use half's normal range -- at the bound itself typical ones sat around 2^-12)
+        abias = ops.AttnBias(table, N, H, dev, q_scale=attn.q_scale.detach(), k_scale=attn.k_scale.detach(), scale=ATTN_SCALE,
+                             half=T == torch.float16)
         ops.attn_fwd(q, k, v, abias, keymask, o, lse, B, N, H, ATTN_SCALE)
         x1 = torch.empty(M, D, device=dev)
         ops.gemm(o, w["Wo"], x1, M=M, N=D, K=H * DIM_HEAD, Cin=x)

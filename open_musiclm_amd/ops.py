@@ -398,16 +398,17 @@ class AttnBias:
     column = head) and `tableT`, its transposed / zero-padded / log2(e)-scaled form (omlm_attn_bias_prepare).
 
     q_scale / k_scale (the layer's learned per-dim scales) or qk_bound (an explicit bound on |q . k|, e.g. 1.0 for unit vectors)
-    let the bf16 forward take its exponentials against a fixed reference point instead of a running maximum; without either the
-    online softmax runs."""
+    let the 16-bit forward take its exponentials against a fixed reference point instead of a running maximum; without either the
+    online softmax runs.  half=True (fp16 attention operands): the reference point sits 15 octaves lower, so the probability numerators
+    span half's normal range instead of sitting at its bottom (the kernels fall back to the online softmax if the scales grow too wide)."""
 
     def __init__(self, table: Optional[torch.Tensor], N: int, H: int, device=None, q_scale=None, k_scale=None,
-                 qk_bound: float = 0.0, scale: float = 8.0):
+                 qk_bound: float = 0.0, scale: float = 8.0, half: bool = False):
         self.table, self.N, self.H = table, N, H
         dev = table.device if table is not None else device
         self.tableT = torch.empty(int(hip.lib().omlm_attn_bias_table_floats(N, H)), device=dev)
         call("omlm_attn_bias_prepare", ptr(table), ptr(self.tableT), N, H, table.shape[-1] if table is not None else 0,
-             ptr(q_scale), ptr(k_scale), float(qk_bound), float(scale), stream_ptr())
+             ptr(q_scale), ptr(k_scale), float(qk_bound), float(scale), 15 if half else 0, stream_ptr())
 
     def dbias_workspace(self, B: int, N: int, H: int) -> torch.Tensor:
         """Scratch for the backward's d(bias) partial rows (omlm_mqa_attn_bwd_workspace_bytes): ONE buffer per device, shared by every

@@ -696,6 +696,25 @@ def test_attention_fwd_bwd(ops, dev, dtype, B, N, H):
         report(f"attention_fixed_ref[{B},{N},{H}]", fwd=e_f2, lse_diff=e_lse)
         # lse comes from the MFMA denominator (bf16-rounded P, like the numerator): log2-domain agreement to ~2^-7
         assert e_f2 < tol_f and e_lse < 1e-2, (e_f2, e_lse)
+    if dtype == torch.float16:
+        # half operands: the fixed reference point sits 15 octaves under the bound and is taken while 2 c |q.k| + the table's range < 28 --
+        # not with the +-2 table above (the flag stays 0: online softmax, checked above), so a narrow table here
+        ab0 = ops.AttnBias(bias, N, H, dev, qk_bound=1.0, scale=8.0, half=True)
+        assert float(ab0.tableT.view(-1, ab0.tableT.numel() // ((H + 7) // 8 * 8))[0, -2]) == 0.0
+        out0 = torch.empty_like(out); lse0 = torch.empty_like(lse)
+        ops.attn_fwd(qd, kd, vd, ab0, keymask.to(torch.uint8), out0, lse0, B, N, H, 8.0)
+        assert torch.equal(out0, out) and torch.equal(lse0, lse)                                       # same online kernel, same bits
+        bias_s = bias * 0.05
+        ab = ops.AttnBias(bias_s, N, H, dev, qk_bound=1.0, scale=8.0, half=True)
+        assert float(ab.tableT.view(-1, ab.tableT.numel() // ((H + 7) // 8 * 8))[0, -2]) == 1.0      # the fixed path is taken
+        out2 = torch.empty_like(out); lse2 = torch.empty_like(lse); out3 = torch.empty_like(out); lse3 = torch.empty_like(lse)
+        ops.attn_fwd(qd, kd, vd, ab, keymask.to(torch.uint8), out2, lse2, B, N, H, 8.0)
+        ops.attn_fwd(qd, kd, vd, bias_s, keymask.to(torch.uint8), out3, lse3, B, N, H, 8.0)          # raw table: online softmax
+        ref_s = naive_attention(qd.double().view(B, N, H * 64), kd.double().view(B, N, 64), vd.double().view(B, N, 64), bias_s.double(), keymask, H)
+        e_f2, e_f3 = relerr(out2.view(B, N, -1), ref_s), relerr(out3.view(B, N, -1), ref_s)
+        e_lse = float((lse2 - lse3).abs().max())
+        report(f"attention_fixed_ref_half[{B},{N},{H}]", fwd=e_f2, fwd_online=e_f3, lse_diff=e_lse)
+        assert e_f2 < tol_f and e_f3 < tol_f and e_lse < 2e-3, (e_f2, e_f3, e_lse)
     do = torch.randn(B, N, H * 64, generator=g).to(dev)
     ref.backward(do.double())
     dq = torch.empty(M, H * 64, device=dev)

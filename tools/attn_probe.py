@@ -21,7 +21,7 @@ dout = torch.randn(M, H * 64, generator=g).to(dev).to(DT)
 delta = torch.empty(B, H, N, device=dev)
 dq = torch.empty(M, H * 64, device=dev); dk = torch.empty(M, 64, device=dev); dv = torch.empty(M, 64, device=dev)
 dbias = torch.zeros(N, ld, device=dev)
-ab = ops.AttnBias(bias, N, H, dev, qk_bound=float(os.environ.get('QKB', '1.0')))
+ab = ops.AttnBias(bias, N, H, dev, qk_bound=float(os.environ.get('QKB', '1.0')), half=DT == torch.float16)
 def t(fn, reps=10):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
