@@ -174,6 +174,28 @@ struct A2Stager {
     }
 };
 
+// Work item of workgroup `lin`: (sample b, query tile qt, head group hy).  XCD-aware: the workgroups of one sample (they share its K / V
+// through the XCD's L2) are dealt to one XCD (workgroup lin runs on XCD lin % 8).  When an XCD's share is whole samples (B a multiple of
+// 8), its items run heaviest (latest) query tile first ACROSS its samples -- dealt sample by sample, the last sample's longest items
+// started two thirds into the launch and the SIMDs averaged 1.3 of 2 resident waves (forward 94 -> 86 us per layer at B = 32, N = 1116).
+__device__ __forceinline__ void a2_item_order(int lin, int nqt, int ny, int B, int& b, int& qt, int& hy) {
+    const int per = nqt * ny, total = per * B;
+    const int qq = total >> 3, rr = total & 7, xcd = lin & 7, idx = lin >> 3;
+    const int start = xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq, cnt = qq + (xcd < rr ? 1 : 0);
+    if (start % per == 0 && cnt % per == 0) {
+        const int ns = cnt / per, w = idx % (ns * ny);
+        qt = nqt - 1 - idx / (ns * ny);
+        b = start / per + w / ny;
+        hy = w % ny;
+    } else {                                                  // sample-major, heavy tiles first inside a sample
+        const int lg = start + idx;
+        b = lg / per;
+        const int rem = lg - b * per;
+        qt = nqt - 1 - rem / ny;
+        hy = rem % ny;
+    }
+}
+
 struct A4Acc {
     f32x16 acc[2][2];       // O^T: [head][d tile]
     f32x16 accl;            // denominators; row parity (i & 1) == hb holds those of head hb
@@ -340,27 +362,8 @@ __global__ __launch_bounds__(A4_THREADS, 2) void attn4_fwd_kernel(const h16_t* _
     char* ring = smem;                                        // A2_NST stages
     h16_t* livef = (h16_t*)(smem + A2_NST * A2_STAGE);      // [nkt_all * 64] 1.0 / 0.0 per key of this sample
     const int nqt = (N + 31) / 32, ny = (H + 7) / 8;
-    // XCD-aware order: the workgroups of one sample (they share its K / V through the XCD's L2) are dealt to one XCD.  When an XCD's
-    // share is whole samples (B a multiple of 8), its items run heaviest (latest) query tile first ACROSS its samples -- dealt sample by
-    // sample, the last sample's 18-tile items started two thirds into the launch and the SIMDs averaged 1.3 of 2 resident waves.
     int b, qt, hy;
-    {
-        const int per = nqt * ny, total = per * B, lin = blockIdx.x;
-        const int qq = total >> 3, rr = total & 7, xcd = lin & 7, idx = lin >> 3;
-        const int start = xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq, cnt = qq + (xcd < rr ? 1 : 0);
-        if (start % per == 0 && cnt % per == 0) {
-            const int ns = cnt / per, w = idx % (ns * ny);
-            qt = nqt - 1 - idx / (ns * ny);
-            b = start / per + w / ny;
-            hy = w % ny;
-        } else {                                              // sample-major, heavy tiles first inside a sample
-            const int lg = start + idx;
-            b = lg / per;
-            const int rem = lg - b * per;
-            qt = nqt - 1 - rem / ny;
-            hy = rem % ny;
-        }
-    }
+    a2_item_order(blockIdx.x, nqt, ny, B, b, qt, hy);
     const int lane = threadIdx.x & 63, hi = lane >> 5, ql = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h0 = hy * 8 + 2 * wave;                        // heads h0, h0 + 1
@@ -525,15 +528,8 @@ __global__ __launch_bounds__(A2_THREADS) void attn2_bwd_dq_kernel(const h16_t* _
     float* mb = (float*)(scratch + 4096);                     // [npad] 0 / -1e30 per key of this sample
     float* dbl = mb + npad;                                   // [8 waves][nbp]
     const int nqt = (N + 31) / 32, ny = (H + 7) / 8;
-    int lg;
-    {
-        const int total = nqt * ny * B, lin = blockIdx.x;
-        const int qq = total >> 3, rr = total & 7, xcd = lin & 7, idx = lin >> 3;
-        lg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
-    }
-    const int b = lg / (nqt * ny);
-    const int rem = lg - b * (nqt * ny);
-    const int qt = nqt - 1 - rem / ny, hy = rem % ny;
+    int b, qt, hy;
+    a2_item_order(blockIdx.x, nqt, ny, B, b, qt, hy);
     const int lane = threadIdx.x & 63, hi = lane >> 5, ql = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = hy * 8 + wave;

@@ -91,8 +91,18 @@ void attn3_bwd_dkv_kernel(const h16_t* __restrict__ q, const h16_t* __restrict__
     const int lane = threadIdx.x & 63, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nqt = (N + 31) / 32;
-    const int b = blockIdx.x / wg_per_sample;
-    int rem = blockIdx.x - b * wg_per_sample, r = 0, chunk = 0;
+    // XCD-aware: the workgroups of one sample share its Q / dO tiles through an XCD's L2 (workgroup i runs on XCD i % 8); dealt in launch
+    // order every XCD fetched every sample's Q and dO
+    int lg = blockIdx.x;
+#ifndef A3_NOXCD
+    {
+        const int total = B * wg_per_sample, lin = blockIdx.x;
+        const int qq = total >> 3, rr = total & 7, xcd = lin & 7, idx = lin >> 3;
+        lg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    }
+#endif
+    const int b = lg / wg_per_sample;
+    int rem = lg - b * wg_per_sample, r = 0, chunk = 0;
     for (;; ++r) {                                            // uniform scalar scan: which key range this workgroup belongs to
         const int nch = (nqt - 4 * r + CH - 1) / CH;
         if (rem < nch) { chunk = rem; break; }
