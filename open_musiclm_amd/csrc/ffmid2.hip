@@ -667,6 +667,197 @@ __global__ __launch_bounds__(256) void ffmid2_bwd_kernel(const T* __restrict__ d
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// backward in ONE pass (Fp <= 4 NT channels).  The prepass above exists because LayerNorm^T needs two sums over a WHOLE row before the
+// column-local kernel can touch it -- and it reads dh2, gh and the keep bits (400 MB per coarse-small layer, ~90 us) that the main kernel
+// reads again.  Here a workgroup of NT threads covers ALL channels of its rows (4 per thread), so the row sums cross the waves through
+// LDS: a row's partial sums are taken one row AHEAD of its main pass (its data is in registers by then: rows are requested two ahead),
+// published behind the one barrier of the iteration, and read at the top of the next one -- the reduction's latency sits under the
+// main pass of the previous row.  d(gamma) = sum_rows dropout^T(dh2) gh joins d(conv taps) in registers: one partial row per workgroup
+// of each.  Same element arithmetic and the same summation order inside a row as prepass + main (wave sums, then the waves in order).
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T> struct Bwd3Row { Ch4<T> dy, gh, xv, xg; unsigned bits; float a; };
+// "defined here" for the optimiser: what is derived from the registers after this point is not hoisted above it
+__device__ __forceinline__ void opaque(Ch4<h16_t>& c) { asm volatile("" : "+v"(c.r[0]), "+v"(c.r[1])); }
+__device__ __forceinline__ void opaque(Ch4<float>&) {}
+
+template <typename T, int NT>
+__global__ __launch_bounds__(NT) void ffmid3_bwd_kernel(const T* __restrict__ dh2, const T* __restrict__ h1,
+                                                        const T* __restrict__ convw, const T* __restrict__ gamma,
+                                                        const float* __restrict__ rstd, const T* __restrict__ ghs,
+                                                        const unsigned char* __restrict__ drop_bits, T* __restrict__ dh1,
+                                                        float* __restrict__ part_dconv, float* __restrict__ part_dgamma,
+                                                        int nseq, int F, int Fp, int RB, int strips, int total_strips, float p) {
+    constexpr int NW = NT / 64;
+    __shared__ float red[2][NW][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = threadIdx.x * 4;
+    const bool act = col < Fp;
+    const int colc = act ? col : 0;
+    const int ld = 2 * Fp;
+    const float inv = p > 0.f ? 1.0f / (1.0f - p) : 1.0f, invF = 1.0f / (float)F;
+    const int nib = (threadIdx.x & 1) * 4;
+
+    // taps stay in the operand type (converted where used): as fp32 pairs they were 24 of the 168 registers three waves per SIMD allow
+    Ch4<T> wvr[3], wgr[3];
+    v2 gm[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        wvr[k].zero(); wgr[k].zero();
+        if (act) { wvr[k].load(convw + (size_t)k * ld + colc); wgr[k].load(convw + (size_t)k * ld + Fp + colc); }
+    }
+    {
+        Ch4<T> a;
+        a.load(gamma + colc);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) gm[i] = act ? a.get(i) : splat2(0.f);
+    }
+    v2 dcv[3][2], dcg[3][2], dgam[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        dgam[i] = splat2(0.f);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { dcv[k][i] = splat2(0.f); dcg[k][i] = splat2(0.f); }
+    }
+
+    auto load_row = [&](Bwd3Row<T>& R, size_t row) {
+        R.dy.load(dh2 + row * Fp + colc);
+        R.gh.load(ghs + row * Fp + colc);
+        R.xv.load(h1 + row * ld + colc);
+        R.xg.load(h1 + row * ld + Fp + colc);
+        R.bits = (p > 0.f) ? (unsigned)drop_bits[row * (size_t)(Fp >> 3) + (colc >> 3)] : 0xFFu;
+        R.a = rstd[row];
+    };
+    // dropout^T of the row's dh2 (inactive threads: gamma == 0 keeps them out of every sum)
+    auto dy_kept = [&](const Bwd3Row<T>& R, v2 (&dy)[2]) {
+        const unsigned kb = R.bits >> nib;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            dy[i] = R.dy.get(i) * inv;
+            if (!((kb >> (2 * i)) & 1u)) dy[i][0] = 0.f;
+            if (!((kb >> (2 * i + 1)) & 1u)) dy[i][1] = 0.f;
+        }
+    };
+    // this thread's part of the two LayerNorm^T sums of a row -> the wave's -> LDS slot `buf`
+    auto publish_sums = [&](const Bwd3Row<T>& R, int buf) {
+        v2 dy[2], s1 = splat2(0.f), s2 = splat2(0.f);
+        dy_kept(R, dy);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const v2 gy = dy[i] * gm[i];
+            s1 += gy;
+            s2 = fma2(gy, R.gh.get(i), s2);
+        }
+        const float t1 = wave_sum(s1[0] + s1[1]), t2 = wave_sum(s2[0] + s2[1]);
+        if (lane == 0) { red[buf][wave][0] = t1; red[buf][wave][1] = t2; }
+    };
+
+#pragma unroll 1
+    for (int strip = blockIdx.y; strip < total_strips; strip += gridDim.y) {
+        const int b = strip / strips, s = strip - b * strips;
+        const int t0 = s * RB, t1 = min(nseq, t0 + RB);
+        if (t0 >= t1) continue;                                  // (uniform)
+        const size_t row0 = (size_t)b * nseq;
+        const int tlast = min(t1 + 2, nseq);                     // rows [t0, tlast) are read; du of rows t1, t1 + 1 is recomputed for the conv^T of the strip's last two rows
+        v2 x1v[2], x1g[2], x2v[2], x2g[2], p1v[2], p1g[2], p2v[2], p2g[2];
+        {
+            Ch4<T> a, c, d, e;
+            a.zero(); c.zero(); d.zero(); e.zero();
+            if (t0 >= 1) { a.load(h1 + (row0 + t0 - 1) * ld + colc); c.load(h1 + (row0 + t0 - 1) * ld + Fp + colc); }
+            if (t0 >= 2) { d.load(h1 + (row0 + t0 - 2) * ld + colc); e.load(h1 + (row0 + t0 - 2) * ld + Fp + colc); }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                x1v[i] = a.get(i); x1g[i] = c.get(i); x2v[i] = d.get(i); x2g[i] = e.get(i);
+                p1v[i] = splat2(0.f); p1g[i] = splat2(0.f); p2v[i] = splat2(0.f); p2g[i] = splat2(0.f);
+            }
+        }
+        Bwd3Row<T> cur, nx1, nx2;
+        load_row(cur, row0 + t0);
+        nx1 = cur;
+        if (t0 + 1 < tlast) load_row(nx1, row0 + t0 + 1);
+        __syncthreads();                                         // the previous strip's last reads of `red` are done
+        publish_sums(cur, t0 & 1);
+        __syncthreads();
+        const int tend = t1 + 2;
+#pragma unroll 1
+        for (int t = t0; t < tend; ++t) {
+            nx2 = nx1;
+            if (t + 2 < tlast) load_row(nx2, row0 + t + 2);
+
+            if (t + 1 < tlast) publish_sums(nx1, (t + 1) & 1);   // next row's sums: visible behind this iteration's barrier
+            v2 duv[2], dug[2];
+            if (t < nseq) {
+                float S1 = 0.f, S2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) { S1 += red[t & 1][w][0]; S2 += red[t & 1][w][1]; }
+                const float rs = cur.a * invF;
+                const float bsum = rs * S1, csum = rs * S2;
+                const float own = t < t1 ? 1.f : 0.f;
+                v2 dy[2];
+                dy_kept(cur, dy);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const v2 gh = cur.gh.get(i);
+                    const v2 gy = dy[i] * gm[i];
+                    dgam[i] = fma2(dy[i] * own, gh, dgam[i]);                 // pad columns: gh == 0
+                    v2 dg = fma2(gy, splat2(cur.a), splat2(-bsum));
+                    dg = fma2(gh, splat2(-csum), dg);
+                    const v2 xv = cur.xv.get(i), xg = cur.xg.get(i);
+                    const v2 uv = fma2(wvr[2].get(i), xv, fma2(wvr[1].get(i), x1v[i], wvr[0].get(i) * x2v[i]));
+                    const v2 ug = fma2(wgr[2].get(i), xg, fma2(wgr[1].get(i), x1g[i], wgr[0].get(i) * x2g[i]));
+                    v2 h, ex;
+                    gelu_parts(ug, h, ex);
+                    const v2 gp = fma2(ug * 0.3989422804f, ex, h);          // GELU'(u) = Phi(u) + u phi(u)
+                    const v2 a_ = dg * (ug * h);                             // d(value conv output)
+                    const v2 g_ = (dg * uv) * gp;                            // d(gate conv output)
+                    duv[i] = a_; dug[i] = g_;
+                    const v2 ao = a_ * own, go = g_ * own;                   // d(taps): owned rows only
+                    dcv[0][i] = fma2(ao, x2v[i], dcv[0][i]); dcv[1][i] = fma2(ao, x1v[i], dcv[1][i]); dcv[2][i] = fma2(ao, xv, dcv[2][i]);
+                    dcg[0][i] = fma2(go, x2g[i], dcg[0][i]); dcg[1][i] = fma2(go, x1g[i], dcg[1][i]); dcg[2][i] = fma2(go, xg, dcg[2][i]);
+                    x2v[i] = x1v[i]; x1v[i] = xv; x2g[i] = x1g[i]; x1g[i] = xg;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { duv[i] = splat2(0.f); dug[i] = splat2(0.f); }
+            }
+            // conv^T: dh1[t-2] = w2 du[t-2] + w1 du[t-1] + w0 du[t] is complete now
+            if (t - 2 >= t0 && act) {
+                v2 ov[2], og[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    ov[i] = fma2(wvr[0].get(i), duv[i], p2v[i]);
+                    og[i] = fma2(wgr[0].get(i), dug[i], p2g[i]);
+                }
+                Ch4<T>::store(dh1 + (row0 + t - 2) * ld + col, ov);
+                Ch4<T>::store(dh1 + (row0 + t - 2) * ld + Fp + col, og);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                p2v[i] = fma2(wvr[1].get(i), duv[i], p1v[i]); p1v[i] = wvr[2].get(i) * duv[i];
+                p2g[i] = fma2(wgr[1].get(i), dug[i], p1g[i]); p1g[i] = wgr[2].get(i) * dug[i];
+            }
+            cur = nx1; nx1 = nx2;
+            __syncthreads();
+        }
+    }
+    // partial rows: d(conv taps) in the layout [2F real channels][3] of the reference weight [2F, 1, 3]; d(gamma) [Fp]
+    if (act) {
+        float* pr = part_dconv + (size_t)blockIdx.y * 2 * F * 3;
+        float* pg = part_dgamma + (size_t)blockIdx.y * Fp;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int ch = col + 2 * i + e;
+                pg[ch] = dgam[i][e];
+                if (ch < F) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { pr[(size_t)ch * 3 + k] = dcv[k][i][e]; pr[(size_t)(F + ch) * 3 + k] = dcg[k][i][e]; }
+                }
+            }
+    }
+}
+
 // ---- host side (called by the C-ABI entry points of ffmid.hip) ----------------------------------------------------------
 static int strip_rows(int nseq, int target) {
     const int n = (nseq + target - 1) / target;
@@ -748,6 +939,26 @@ static int bwd_launch_t(const void* dh2, const void* h1, const void* convw, cons
                         void* dh1, float* part_g, int max_g_rows, float* part_c, int max_c_rows, int* g_rows, int* c_rows,
                         int M, int nseq, int F, int Fp, float p, const unsigned char* drop_bits, const void* gh, hipStream_t st) {
     const int B = M / nseq;
+    static int fused = -1;
+    if (fused < 0) { const char* e = getenv("OMLM_FFMID_BWD_FUSED"); fused = (e && e[0] == '0') ? 0 : 1; }
+    if (fused && Fp / 4 <= 768) {
+        // one pass: a workgroup covers all channels of its rows (ffmid3_bwd_kernel); `bc` is not used
+        const int RB = strip_rows(nseq, 35);
+        const int strips = (nseq + RB - 1) / RB;
+        const int total = B * strips;
+        const int per = (total + 255) / 256;                 // strips per workgroup: one workgroup of 8-12 waves per CU
+        int ny = (total + per - 1) / per;
+        if (ny > max_c_rows) ny = max_c_rows;
+        if (ny > max_g_rows) ny = max_g_rows;
+        const int nthr = (Fp / 4 + 63) / 64 * 64;
+#define FF3_BWD(NT_) hipLaunchKernelGGL((ffmid3_bwd_kernel<T, NT_>), dim3(1, ny), dim3(NT_), 0, st, (const T*)dh2, (const T*)h1, (const T*)convw, \
+                       (const T*)gamma, rstd, (const T*)gh, drop_bits, (T*)dh1, part_c, part_g, nseq, F, Fp, RB, strips, total, p)
+        if (nthr <= 128) FF3_BWD(128); else if (nthr <= 256) FF3_BWD(256); else if (nthr <= 512) FF3_BWD(512); else FF3_BWD(768);
+#undef FF3_BWD
+        *g_rows = ny;
+        *c_rows = ny;
+        return omlm_post_launch("omlm_ffmid_bwd (fused strip)");
+    }
     // prepass
     const int rows4 = (M + 3) / 4;
     const int b1 = rows4 < max_g_rows ? rows4 : max_g_rows;
