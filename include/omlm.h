@@ -371,7 +371,13 @@ typedef struct omlm_decode_args {
      * the batched forward's omlm_gemm_planes16 (open_musiclm.py:299-319 evaluated fp32-grade where the error budget puts the error).
      * B >= 2: needs the matrix-core kernels (16-bit weights, D = 1024, ln_parts given, L >= 1), Fp <= 3072. */
     const void* const* W1p_lo; const void* const* W2p_lo; const void* head_W_lo;
+    /* optional scratch of the batched FF-out launch (2 <= B <= 16, matrix-core kernels, ln_parts given): with it a tile of 16 output rows
+     * is cut into four k-slices (256 workgroups instead of 64) that meet through fp32 slabs, added in slice order by the last to arrive.
+     * splitk_ws: OMLM_DECODE_SPLITK_FLOATS(D) floats, contents irrelevant; splitk_cnt: ceil(D / 16) ints, ZERO before the first step
+     * (every step leaves them zero).  One decode stream at a time per scratch pair.  NULL: one workgroup per tile walks the whole row. */
+    float* splitk_ws; int* splitk_cnt;
 } omlm_decode_args;
+#define OMLM_DECODE_SPLITK_FLOATS(D) (4 * (((D) + 15) / 16) * 256)
 #define OMLM_DECODE_LN_PARTS(D, Fp) ((((D) + 15) / 16 > ((Fp) + 7) / 8 ? ((D) + 15) / 16 : ((Fp) + 7) / 8) * 32)
 int omlm_decode_step(const omlm_decode_args* args, const long long* ids, void* stream);
 /* *pos_dev += 1, *step_dev += 1 (either may be null): keeps the row / sampler-step counters on the device so that a

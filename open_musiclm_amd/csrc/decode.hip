@@ -56,6 +56,10 @@ struct omlm_decode_args {
     // precision "fp16ff": lo planes of the FF-in / FF-out / head weights (W = hi + lo, fp32-grade); with them the three launches keep their
     // activation rows and h1 un-rounded, like the three-product forward of the batched path (W1p_lo == NULL: plain 16-bit step)
     const void* const* W1p_lo; const void* const* W2p_lo; const void* head_W_lo;
+    // split-K scratch of the batched FF-out launch (optional; NULL: one workgroup per 16 output rows walks the whole row):
+    // splitk_ws 4 * ceil(D / 16) * 256 floats, contents irrelevant; splitk_cnt ceil(D / 16) ints, ZERO before the first step (every launch
+    // leaves them zero)
+    float* splitk_ws; int* splitk_cnt;
 };
 
 __device__ __forceinline__ float round_if(float v, int on) { return on ? (float)(h16_t)v : v; }
@@ -311,11 +315,15 @@ __global__ __launch_bounds__(DEC_T) void dec_attn_kernel(const float* __restrict
 // loaded it (sum of squares through 4 lane swaps) before it goes to LDS and back to the cache; the probabilities reach the
 // P.V loop through the wave's own LDS row (same-wave LDS ordering, no barrier).
 #define DEC_AT2 512
-__global__ __launch_bounds__(DEC_AT2) void dec_attn2_kernel(const float* __restrict__ q, float* __restrict__ Kc,
+// comb_out / comb_cnt (optional; the batched matrix-core step): the workgroups of a sample count their arrivals in comb_cnt[b] (zero on
+// entry and exit) and the last one combines the sample's partials into comb_out[b, H * 64] -- what dec_attn_combine_kernel did as a
+// launch of its own (5 us of every layer's ~50).  comb_out may be q's buffer: every reader of q[b, :] has arrived by then.
+__global__ __launch_bounds__(DEC_AT2) void dec_attn2_kernel(const float* q, float* __restrict__ Kc,
                                                            const float* __restrict__ Vc, const float* __restrict__ q_scale,
                                                            const float* __restrict__ k_scale, const float* __restrict__ bias, int bias_ld,
-                                                           float* __restrict__ parts, int H, int Nmax, int nsplit,
-                                                           const int* __restrict__ pos_dev, float scale, int round_bf16) {
+                                                           float* parts, int H, int Nmax, int nsplit,
+                                                           const int* __restrict__ pos_dev, float scale, int round_bf16,
+                                                           float* comb_out, int* comb_cnt) {
     extern __shared__ __attribute__((aligned(16))) float dsm[];
     const int pos = *pos_dev;
     const int s = blockIdx.x, b = blockIdx.y;
@@ -383,6 +391,41 @@ __global__ __launch_bounds__(DEC_AT2) void dec_attn2_kernel(const float* __restr
         float acc = 0.f;
         for (int j = 0; j < nk; ++j) acc += sc[wave * 64 + j] * Vs[j * 64 + lane];
         pp[2 + lane] = acc;
+    }
+    if (!comb_cnt) return;
+    // publish the partials, take a ticket (cdna_hip_programming.md: slab stores -> every wave vmcnt(0) -> barrier -> one lane: agent-scope
+    // release, vmcnt(0), relaxed ticket; the last arriver: agent-scope acquire -> barrier -> plain loads)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        sc[0] = __int_as_float(__hip_atomic_fetch_add(comb_cnt + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    __syncthreads();
+    const int ns = pos / DEC_KS + 1;
+    if (__float_as_int(sc[0]) != ns - 1) return;
+    if (threadIdx.x == 0) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); comb_cnt[b] = 0; }
+    __syncthreads();
+    for (int h = wave; h < H; h += 8) {                                   // lane = dim (the arithmetic of dec_attn_combine_kernel)
+        const float* pb = parts + ((size_t)b * nsplit * H + h) * DEC_PART;
+        float m = -3.0e38f, l = 0.f, o = 0.f;
+        for (int s0 = 0; s0 < ns; s0 += 8) {
+            float pm[8], pl[8], po[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float* p = pb + (size_t)min(s0 + j, ns - 1) * H * DEC_PART;
+                pm[j] = p[0]; pl[j] = p[1]; po[j] = p[2 + lane];
+            }
+            float mb = m;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (s0 + j < ns) mb = fmaxf(mb, pm[j]);
+            const float resc = __expf(m - mb);
+            l *= resc; o *= resc; m = mb;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (s0 + j < ns) { const float w = __expf(pm[j] - m); l += w * pl[j]; o += w * po[j]; }
+        }
+        comb_out[((size_t)b * H + h) * 64 + lane] = round_if(o / l, round_bf16);
     }
 }
 
@@ -553,6 +596,9 @@ struct dec2_args {
     // matrix-core kernels: LayerNorm statistics from the producers' per-workgroup partial sums [partial][8 samples][2] instead of a
     // reduction over every sample's row in every workgroup (stat_in, nstat_in partials); this launch's own partials (stat_out)
     const float* stat_in; int nstat_in; float* stat_out;
+    // matrix-core kernels, DEC2_LNGEMV: the k-range of a row cut into nsl slices (grid = tiles * nsl); slabs [tile][slice][16 rows][16 samples]
+    // in sk_ws, one arrival counter per tile in sk_cnt (zero on entry and exit)
+    int nsl; float* sk_ws; int* sk_cnt;
 };
 
 template <typename TW, int NI, int MODE>
@@ -703,6 +749,19 @@ __global__ __launch_bounds__(DEC_T) void dec3_kernel(dec2_args a) {
     static_assert(!PL || MODE == DEC2_LNGEMV, "lo planes: the LayerNorm + row-product launches (FF-out, head); FF-in has dec3_ffin_kernel");
     dec_wreg<TW> wr[NI], wr2[MODE == DEC2_FFIN ? NI : 1], wl[PL ? NI : 1];
     float4 g0[NI], g1[NI], x0[NI], x1[NI];
+    // activation row and gamma FIRST, the weight rows behind them: vector-memory results retire in issue order, so the LayerNorm
+    // statistics (two wave reductions) start when the L2-resident row has landed and run under the weight fetch from HBM
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int c = lane + 64 * i;
+        const bool ok = c < nch;
+        const int cc = ok ? c : 0;
+        x0[i] = *(const float4*)(a.in + cc * 8); x1[i] = *(const float4*)(a.in + cc * 8 + 4);
+        if (a.gamma) { g0[i] = *(const float4*)(a.gamma + cc * 8); g1[i] = *(const float4*)(a.gamma + cc * 8 + 4); }
+        else { g0[i] = make_float4(1.f, 1.f, 1.f, 1.f); g1[i] = g0[i]; }
+        if (!ok) { x0[i] = make_float4(0.f, 0.f, 0.f, 0.f); x1[i] = x0[i]; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int c = lane + 64 * i;
@@ -711,11 +770,9 @@ __global__ __launch_bounds__(DEC_T) void dec3_kernel(dec2_args a) {
         wr[i].load(wrow + cc * 8);
         if (PL) { wl[i].load((const TW*)a.Wlo + (size_t)unit * a.ldw + cc * 8); if (!ok) wl[i].zero(); }
         if (MODE == DEC2_FFIN) wr2[i].load(wrow2 + cc * 8);
-        x0[i] = *(const float4*)(a.in + cc * 8); x1[i] = *(const float4*)(a.in + cc * 8 + 4);
-        if (a.gamma) { g0[i] = *(const float4*)(a.gamma + cc * 8); g1[i] = *(const float4*)(a.gamma + cc * 8 + 4); }
-        else { g0[i] = make_float4(1.f, 1.f, 1.f, 1.f); g1[i] = g0[i]; }
-        if (!ok) { wr[i].zero(); if (MODE == DEC2_FFIN) wr2[i].zero(); x0[i] = make_float4(0.f, 0.f, 0.f, 0.f); x1[i] = x0[i]; }
+        if (!ok) { wr[i].zero(); if (MODE == DEC2_FFIN) wr2[i].zero(); }
     }
+    __builtin_amdgcn_sched_barrier(0);
     // epilogue operands requested now as well (lane 0 consumes them)
     float resv = 0.f, h0v = 0.f, h0g = 0.f, h1v = 0.f, h1g = 0.f, cw[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int pos = 0;
@@ -800,6 +857,14 @@ __global__ __launch_bounds__(DEC_T) void dec3_ffin_kernel(dec2_args a) {
     const int ld = 2 * a.Fp;
     dec_wreg<TW> wv[CPW][NI], wg[CPW][NI], wvl[PL ? CPW : 1][NI], wgl[PL ? CPW : 1][NI];
     float4 g0[NI], g1[NI], x0[NI], x1[NI];
+    // activation row, gamma and the epilogue operands first, the weight rows behind them (see dec3_kernel)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int c = lane + 64 * i;
+        x0[i] = *(const float4*)(a.in + c * 8); x1[i] = *(const float4*)(a.in + c * 8 + 4);
+        g0[i] = *(const float4*)(a.gamma + c * 8); g1[i] = *(const float4*)(a.gamma + c * 8 + 4);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int c = lane + 64 * i;
@@ -813,9 +878,8 @@ __global__ __launch_bounds__(DEC_T) void dec3_ffin_kernel(dec2_args a) {
                 wgl[ch][i].load((const TW*)a.Wlo + (size_t)(a.Fp + cc) * a.ldw + c * 8);
             }
         }
-        x0[i] = *(const float4*)(a.in + c * 8); x1[i] = *(const float4*)(a.in + c * 8 + 4);
-        g0[i] = *(const float4*)(a.gamma + c * 8); g1[i] = *(const float4*)(a.gamma + c * 8 + 4);
     }
+    __builtin_amdgcn_sched_barrier(0);
     // epilogue operands: lane ch finishes channel c0 + ch
     float h0v = 0.f, h0g = 0.f, h1v = 0.f, h1g = 0.f, cw[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int myc = c0 + lane;
@@ -921,7 +985,24 @@ __global__ __launch_bounds__(64) void dec_attn_combine_kernel(const float* __res
 template <int NS, int MODE, bool PL = false>
 __global__ __launch_bounds__(DEC4_T) void dec4_kernel(dec2_args a) {
     extern __shared__ __attribute__((aligned(16))) char dsm4[];
-    const int B = a.B, K = a.K, KP = K + 8;
+    // split-K (DEC2_LNGEMV with a.nsl > 1: the FF-out launch, 16 output rows x Fp per tile): 64 workgroups each walking a 2752-long row at
+    // B = 16 were 21.6 us of the step (14.1 us without the lo planes) -- a quarter of the CUs, every one of them normalising all 16 x 2752
+    // activations in two passes.  Here a tile's row is cut into a.nsl slices (one workgroup each, one pass over 16 samples); the slices
+    // meet through fp32 slabs and the last to arrive adds them in slice order (residual, output and LayerNorm partials as before).
+    int tile = blockIdx.x, slice = 0, k0 = 0, Kown = a.K;
+    if (MODE == DEC2_LNGEMV && a.nsl > 1) {
+        const int ntiles = gridDim.x / a.nsl;
+        if ((ntiles & 7) == 0) {                                // a tile's slices on ONE XCD (workgroup id % 8): the last arriver reads same-XCD slabs
+            const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+            tile = (idx / a.nsl) * 8 + xcd; slice = idx % a.nsl;
+        } else { tile = blockIdx.x / a.nsl; slice = blockIdx.x % a.nsl; }
+        const int steps = a.K >> 5, base = steps / a.nsl, rem = steps % a.nsl;
+        k0 = 32 * (slice * base + min(slice, rem));
+        Kown = 32 * (base + (slice < rem ? 1 : 0));
+    }
+    const int B = a.B, K = Kown, KP = K + 8;
+    const float* a_in = a.in + k0;
+    const float* a_gamma = a.gamma ? a.gamma + k0 : nullptr;
     h16_t* xs = (h16_t*)dsm4;                                   // [B][KP] operand image (PL: [DEC4_IMG][KP] hi, then the lo image)
     h16_t* xs_lo = xs + (size_t)DEC4_IMG(NS) * KP;
     float* red = (float*)(dsm4 + (((size_t)(PL ? 2 * DEC4_IMG(NS) : B) * KP * 2 + 15) & ~(size_t)15));   // [DEC4_NB][4][2]
@@ -933,7 +1014,12 @@ __global__ __launch_bounds__(DEC4_T) void dec4_kernel(dec2_args a) {
     const int r = lane & 15, kq = lane >> 4;
     const int HD = a.H * 64;
     static_assert(MODE != DEC2_OUT, "the matrix-core path takes the combined attention output as a plain input (dec_attn_combine_kernel)");
-    // ---- this lane's weight row and its pieces, requested before anything else ----
+    // ---- this lane's weight row and its pieces ----
+    // WHERE they are requested matters: vector-memory results retire in issue order, so with the weights (64 KB of HBM reads per
+    // workgroup, twice that with lo planes) requested first, the wait for the activation pieces -- L2 hits -- sat behind the whole weight
+    // fetch and the normalisation phase started when the weights had landed (FF-in 14 us with lo planes, 10 us without).  The
+    // LayerNorm-by-partials path and the plain path request them right AFTER their activation loads: those retire first, the weights
+    // stay in flight under the statistics / normalisation / image phase and are waited for at the k-loop.
     int grow;                                                   // global output row of MFMA row r
     const h16_t* wrow;
     bool ln_rows = a.gamma != nullptr;                          // uniform per workgroup
@@ -946,23 +1032,42 @@ __global__ __launch_bounds__(DEC4_T) void dec4_kernel(dec2_args a) {
         ln_rows = blockIdx.x * DEC4_ROWS < HD;                  // HD is a multiple of 16: a workgroup holds q rows or k/v rows, never both
         wrow = grow < HD ? (const h16_t*)a.W + (size_t)grow * a.ldw : (const h16_t*)a.W2 + (size_t)(grow - HD) * a.ldw;
     } else {
-        grow = blockIdx.x * DEC4_ROWS + r;
-        wrow = (const h16_t*)a.W + (size_t)min(grow, a.Nout - 1) * a.ldw;
+        grow = tile * DEC4_ROWS + r;
+        wrow = (const h16_t*)a.W + (size_t)min(grow, a.Nout - 1) * a.ldw + k0;
     }
     const int S = K >> 5;                                       // 32-wide k-steps (K is a multiple of 32)
     u32x4 wr[NS], wl[PL ? NS : 1];
     static_assert(!PL || MODE == DEC2_FFIN || MODE == DEC2_LNGEMV, "lo planes: FF-in, FF-out, head");
+    // what the epilogue reads from memory is requested now (one (sample, row) per thread: B <= 16): the conv history and taps of FF-in,
+    // the residual of the row products -- at the end of the launch they were a dependent round trip in front of the last stores
+    float pre_h[4] = {0.f, 0.f, 0.f, 0.f}, pre_w[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, pre_res = 0.f;
+    if (MODE == DEC2_FFIN) {
+        const int idx = threadIdx.x, b = idx >> 3, col = blockIdx.x * 8 + (idx & 7), ld = 2 * a.Fp;
+        if (idx < B * 8 && col < a.Fp) {
+            const float* h0 = a.hist + (size_t)(b * 2) * ld;
+            pre_h[0] = h0[col]; pre_h[1] = h0[ld + col]; pre_h[2] = h0[a.Fp + col]; pre_h[3] = h0[ld + a.Fp + col];
 #pragma unroll
-    for (int j = 0; j < NS; ++j) {
-        const int s = wave + 4 * j;
-        if (s < S) wr[j] = *(const u32x4*)(wrow + 32 * s + 8 * kq);
-        else { wr[j][0] = 0u; wr[j][1] = 0u; wr[j][2] = 0u; wr[j][3] = 0u; }
-        if constexpr (PL) {
-            const h16_t* wlrow = (const h16_t*)a.Wlo + (wrow - (const h16_t*)a.W);
-            if (s < S) wl[j] = *(const u32x4*)(wlrow + 32 * s + 8 * kq);
-            else { wl[j][0] = 0u; wl[j][1] = 0u; wl[j][2] = 0u; wl[j][3] = 0u; }
+            for (int k = 0; k < 3; ++k) { pre_w[k] = a.convw[(size_t)k * ld + col]; pre_w[3 + k] = a.convw[(size_t)k * ld + a.Fp + col]; }
         }
+    } else if (MODE == DEC2_LNGEMV) {
+        const int idx = threadIdx.x, b = idx / DEC4_ROWS, n = tile * DEC4_ROWS + (idx - b * DEC4_ROWS);
+        if (a.res && idx < B * DEC4_ROWS && n < a.Nout) pre_res = a.res[(size_t)b * a.ldres + n];
     }
+    auto load_weights = [&]() {
+        __builtin_amdgcn_sched_barrier(0);                      // (pinned: behind the activation requests above, ahead of everything below)
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const int s = wave + 4 * j;
+            if (s < S) wr[j] = *(const u32x4*)(wrow + 32 * s + 8 * kq);
+            else { wr[j][0] = 0u; wr[j][1] = 0u; wr[j][2] = 0u; wr[j][3] = 0u; }
+            if constexpr (PL) {
+                const h16_t* wlrow = (const h16_t*)a.Wlo + (wrow - (const h16_t*)a.W);
+                if (s < S) wl[j] = *(const u32x4*)(wlrow + 32 * s + 8 * kq);
+                else { wl[j][0] = 0u; wl[j][1] = 0u; wl[j][2] = 0u; wl[j][3] = 0u; }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
     // the k-loop: one MFMA per 32-wide step (PL: three); samples >= nhave are zero operands
     auto kloop = [&](dec4_acc& acc, const int nhave) {
         const bool have = r < nhave;                            // this lane's B-operand column is a real sample
@@ -1002,7 +1107,7 @@ __global__ __launch_bounds__(DEC4_T) void dec4_kernel(dec2_args a) {
                     const bool in = i < K;
 #pragma unroll
                     for (int b = 0; b < NB2; ++b)
-                        v[ch][b] = (in && h0 + b < B) ? *(const float4*)(a.in + (size_t)(h0 + b) * a.ldin + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        v[ch][b] = (in && h0 + b < B) ? *(const float4*)(a_in + (size_t)(h0 + b) * a.ldin + i) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             };
             auto norm_half = [&](int h0) {
@@ -1036,20 +1141,23 @@ __global__ __launch_bounds__(DEC4_T) void dec4_kernel(dec2_args a) {
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
                 const int i = threadIdx.x * 4 + ch * DEC4_T * 4;
-                gq[ch] = i < K ? *(const float4*)(a.gamma + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+                gq[ch] = i < K ? *(const float4*)(a_gamma + i) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
             load_half(0);
             // all of a thread's partials requested at once (a rolled loop here was one L2 round trip per iteration: 43 of them for the
             // FF-out launch); lane = sample + SB * slice with SB = 8 (B <= 8: 32 slices per workgroup) or 16
-            auto reduce_parts = [&](auto sb_tag) {
+            float2 pv[22];                                          // 352 partials / 16 slices
+            auto load_parts = [&](auto sb_tag) {
                 constexpr int SB = decltype(sb_tag)::value, NSL = 256 / SB, NPI = (352 + NSL - 1) / NSL;
                 const int b = lane & (SB - 1), sl = wave * (64 / SB) + lane / SB;
-                float2 pv[NPI];
 #pragma unroll
                 for (int it = 0; it < NPI; ++it) {
                     const int pi = sl + NSL * it;
                     pv[it] = pi < a.nstat_in ? *(const float2*)(a.stat_in + (pi * DEC4_NB + b) * 2) : make_float2(0.f, 0.f);
                 }
+            };
+            auto reduce_parts = [&](auto sb_tag) {
+                constexpr int SB = decltype(sb_tag)::value, NSL = 256 / SB, NPI = (352 + NSL - 1) / NSL;
                 float ps = 0.f, pq = 0.f;
 #pragma unroll
                 for (int it = 0; it < NPI; ++it) { ps += pv[it].x; pq += pv[it].y; }
@@ -1057,6 +1165,9 @@ __global__ __launch_bounds__(DEC4_T) void dec4_kernel(dec2_args a) {
                 for (int m = SB; m < 64; m <<= 1) { ps += __shfl_xor(ps, m, 64); pq += __shfl_xor(pq, m, 64); }
                 if (lane < SB) { red[(lane * 4 + wave) * 2] = ps; red[(lane * 4 + wave) * 2 + 1] = pq; }
             };
+            if (B <= 8) load_parts(std::integral_constant<int, 8>{});
+            else        load_parts(std::integral_constant<int, 16>{});
+            load_weights();                                         // behind every activation-side request of this launch
             if (B <= 8) reduce_parts(std::integral_constant<int, 8>{});
             else        reduce_parts(std::integral_constant<int, 16>{});
             __syncthreads();
@@ -1084,6 +1195,7 @@ __global__ __launch_bounds__(DEC4_T) void dec4_kernel(dec2_args a) {
                 if (B > NB2) { load_half(NB2); norm_half(NB2); }  // long rows (FF-out) at B > 8: the second eight samples in a second pass
             }
         } else if (ln_rows) {
+            load_weights();
             float s8[NBR], q8[NBR];
 #pragma unroll
             for (int b = 0; b < NBR; ++b) { s8[b] = 0.f; q8[b] = 0.f; }
@@ -1094,7 +1206,7 @@ __global__ __launch_bounds__(DEC4_T) void dec4_kernel(dec2_args a) {
                 if (i >= K) break;
                 float4 v[NBR];
 #pragma unroll
-                for (int b = 0; b < NBR; ++b) v[b] = b < B ? *(const float4*)(a.in + (size_t)b * a.ldin + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int b = 0; b < NBR; ++b) v[b] = b < B ? *(const float4*)(a_in + (size_t)b * a.ldin + i) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int b = 0; b < NBR; ++b) {
                     if (b < B) *(float4*)(xraw + (size_t)b * K + i) = v[b];
@@ -1119,7 +1231,7 @@ __global__ __launch_bounds__(DEC4_T) void dec4_kernel(dec2_args a) {
             }
             __syncthreads();
             for (int i = threadIdx.x * 4; i < K; i += DEC4_T * 4) {
-                const float4 g = *(const float4*)(a.gamma + i);
+                const float4 g = *(const float4*)(a_gamma + i);
 #pragma unroll
                 for (int b = 0; b < NBR; ++b) {
                     if (b < B) {
@@ -1133,11 +1245,13 @@ __global__ __launch_bounds__(DEC4_T) void dec4_kernel(dec2_args a) {
                 }
             }
         } else {
+            bool wreq = false;
             for (int h0 = 0; h0 < B; h0 += NBR)                 // (B > 8: the second eight samples in a second pass)
             for (int i = threadIdx.x * 4; i < K; i += DEC4_T * 4) {
                 float4 v[NBR];
 #pragma unroll
-                for (int b = 0; b < NBR; ++b) v[b] = h0 + b < B ? *(const float4*)(a.in + (size_t)(h0 + b) * a.ldin + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int b = 0; b < NBR; ++b) v[b] = h0 + b < B ? *(const float4*)(a_in + (size_t)(h0 + b) * a.ldin + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!wreq) { load_weights(); wreq = true; }     // behind the first batch of activation requests
 #pragma unroll
                 for (int b = 0; b < NBR; ++b) {
                     if (h0 + b < B) {
@@ -1148,6 +1262,7 @@ __global__ __launch_bounds__(DEC4_T) void dec4_kernel(dec2_args a) {
                     }
                 }
             }
+            if (!wreq) load_weights();                          // (threads without an activation piece: K < 1024)
         }
     }
     if constexpr (!PL) {
@@ -1169,6 +1284,31 @@ __global__ __launch_bounds__(DEC4_T) void dec4_kernel(dec2_args a) {
         const int t = threadIdx.x;                              // (row, sample) = (t >> 4, t & 15)
         vals[t] = part[t] + part[256 + t] + part[512 + t] + part[768 + t];
     }
+    if (MODE == DEC2_LNGEMV && a.nsl > 1) {
+        // publish this slice's tile, take a ticket; the last arriver adds the slabs in slice order.  (cdna_hip_programming.md, split-K
+        // reduction: plain slab stores -> every wave vmcnt(0) -> barrier -> one lane: agent-scope release fence, vmcnt(0), relaxed ticket;
+        // last arriver: agent-scope acquire fence -> barrier -> plain loads.  Placement-independent; the XCD mapping above is speed only.)
+        float* slab = a.sk_ws + ((size_t)tile * a.nsl) * 256;
+        slab[(size_t)slice * 256 + threadIdx.x] = vals[threadIdx.x];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int ticket = __hip_atomic_fetch_add(a.sk_cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            red[0] = __int_as_float(ticket);
+        }
+        __syncthreads();
+        if (__float_as_int(red[0]) != a.nsl - 1) return;
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            a.sk_cnt[tile] = 0;                                 // the next launch finds it zero (stream order)
+        }
+        __syncthreads();
+        float sum = 0.f;
+        for (int sl = 0; sl < a.nsl; ++sl) sum += slab[(size_t)sl * 256 + threadIdx.x];
+        vals[threadIdx.x] = sum;
+    }
     __syncthreads();
     // ---- epilogue ----
     if (MODE == DEC2_FFIN) {
@@ -1180,11 +1320,12 @@ __global__ __launch_bounds__(DEC4_T) void dec4_kernel(dec2_args a) {
             const float hg = round_if(vals[(8 + cc) * 16 + b], a.round_bf16);
             float* h0 = a.hist + (size_t)(b * 2) * ld;          // row p-2
             float* h1 = h0 + ld;                                 // row p-1
-            const float uv = a.convw[col] * h0[col] + a.convw[ld + col] * h1[col] + a.convw[2 * (size_t)ld + col] * hv;
-            const float ug = a.convw[a.Fp + col] * h0[a.Fp + col] + a.convw[ld + a.Fp + col] * h1[a.Fp + col] + a.convw[2 * (size_t)ld + a.Fp + col] * hg;
+            // (pre_h = {h0[col], h1[col], h0[Fp + col], h1[Fp + col]}, pre_w = the six taps: requested at the top; idx == threadIdx.x)
+            const float uv = pre_w[0] * pre_h[0] + pre_w[1] * pre_h[1] + pre_w[2] * hv;
+            const float ug = pre_w[3] * pre_h[2] + pre_w[4] * pre_h[3] + pre_w[5] * hg;
             const float uo = dec_gelu(ug) * uv;
             a.u[(size_t)b * a.Fp + col] = uo;
-            h0[col] = h1[col];       h0[a.Fp + col] = h1[a.Fp + col];
+            h0[col] = pre_h[1];      h0[a.Fp + col] = pre_h[3];
             h1[col] = hv;            h1[a.Fp + col] = hg;
             part[idx] = uo;                                      // `part` is free again (its sums are in `vals`): read back below for the partial sums
         }
@@ -1208,11 +1349,11 @@ __global__ __launch_bounds__(DEC4_T) void dec4_kernel(dec2_args a) {
         }
     } else {
         for (int idx = threadIdx.x; idx < B * DEC4_ROWS; idx += DEC4_T) {
-            const int b = idx / DEC4_ROWS, rr = idx - b * DEC4_ROWS, n = blockIdx.x * DEC4_ROWS + rr;
+            const int b = idx / DEC4_ROWS, rr = idx - b * DEC4_ROWS, n = tile * DEC4_ROWS + rr;
             float v = 0.f;
             if (n < a.Nout) {
                 v = vals[rr * 16 + b];
-                if (a.res) v += a.res[(size_t)b * a.ldres + n];
+                if (a.res) v += MODE == DEC2_LNGEMV ? pre_res : a.res[(size_t)b * a.ldres + n];      // (requested at the top; idx == threadIdx.x)
                 a.out[(size_t)b * a.ldout + n] = v;
             }
             if (a.stat_out) part[idx] = v;                      // (b, row) order; `part` is free again: its sums are in `vals`
@@ -1222,7 +1363,7 @@ __global__ __launch_bounds__(DEC4_T) void dec4_kernel(dec2_args a) {
             if (threadIdx.x < B) {
                 float ps = 0.f, pq = 0.f;
                 for (int rr = 0; rr < DEC4_ROWS; ++rr) { const float t = part[threadIdx.x * DEC4_ROWS + rr]; ps += t; pq += t * t; }
-                a.stat_out[(blockIdx.x * DEC4_NB + threadIdx.x) * 2] = ps; a.stat_out[(blockIdx.x * DEC4_NB + threadIdx.x) * 2 + 1] = pq;
+                a.stat_out[(tile * DEC4_NB + threadIdx.x) * 2] = ps; a.stat_out[(tile * DEC4_NB + threadIdx.x) * 2 + 1] = pq;
             }
         }
         if (MODE == DEC2_LNGEMV && blockIdx.x == 0 && threadIdx.x == 0 && a.adv_pos) {      // see dec3_kernel
@@ -1234,8 +1375,9 @@ __global__ __launch_bounds__(DEC4_T) void dec4_kernel(dec2_args a) {
 
 template <int NS, int MODE, bool PL = false>
 static void dec4_launch(const dec2_args& a, int grid, hipStream_t st) {
-    const size_t lds = (((size_t)(PL ? 2 * DEC4_IMG(NS) : a.B) * (a.K + 8) * 2 + 15) & ~(size_t)15) + (size_t)(DEC4_NB * 8 + DEC4_NB * 2 + 4 * 256 + 256) * sizeof(float) +
-                       ((a.gamma && !a.stat_in) ? (size_t)a.B * a.K * sizeof(float) : 0);      // fp32 staging copy: own-reduction path only (B <= 8)
+    const int kmax = a.nsl > 1 ? 32 * (((a.K >> 5) + a.nsl - 1) / a.nsl) : a.K;       // longest k-range of a workgroup
+    const size_t lds = (((size_t)(PL ? 2 * DEC4_IMG(NS) : a.B) * (kmax + 8) * 2 + 15) & ~(size_t)15) + (size_t)(DEC4_NB * 8 + DEC4_NB * 2 + 4 * 256 + 256) * sizeof(float) +
+                       ((a.gamma && !a.stat_in) ? (size_t)a.B * kmax * sizeof(float) : 0);      // fp32 staging copy: own-reduction path only (B <= 8)
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)dec4_kernel<NS, MODE, PL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     hipLaunchKernelGGL((dec4_kernel<NS, MODE, PL>), dim3(grid), dim3(DEC4_T), lds, st, a);
@@ -1281,6 +1423,10 @@ static int decode_step2_t(const omlm_decode_args& a, const long long* ids, hipSt
     g.B = B; g.round_bf16 = a.round_bf16; g.eps = a.eps; g.H = H; g.nsplit = a.nsplit; g.pos_dev = a.pos_dev; g.Nmax = a.Nmax; g.Fp = Fp;
     // "fp16ff": FF-in / FF-out / head read W = hi + lo and keep their activations and h1 un-rounded (round_bf16 = 0 for those launches)
     const bool pl = a.W1p_lo != nullptr;
+    // FF-out rows cut into four k-slices (see dec4_kernel): the matrix-core kernels with the producers' LayerNorm partials, scratch given
+    static int sk_off = -1;
+    if (sk_off < 0) { const char* e = getenv("OMLM_DECODE_SPLITK"); sk_off = (e && e[0] == '0') ? 1 : 0; }
+    const bool split = !sk_off && mfma && st_x && a.splitk_ws && a.splitk_cnt && (Fp >> 5) >= 8;
     if (pl) {
         OMLM_CHECK_ARG(sizeof(TW) == 2 && a.W2p_lo && (!a.head_W || a.head_W_lo), "lo planes: 16-bit weights, all three families");
         OMLM_CHECK_ARG(B == 1 || (mfma && st_x), "lo planes at B >= 2 run on the matrix-core step kernels (ln_parts given, OMLM_DECODE_MFMA unset)");
@@ -1294,12 +1440,14 @@ static int decode_step2_t(const omlm_decode_args& a, const long long* ids, hipSt
         if (B == 1) dec3_launch<TW, 2, DEC2_QKV>(q, HD + 128, st);
         else if (mfma) dec4_launch<8, DEC2_QKV>(q, (HD + 128) / DEC4_ROWS, st);
         else        dec2_launch<TW, 2, DEC2_QKV>(q, (HD + 128) / DEC2_ROWS, st);
+        const bool comb_in_attn = mfma && a.splitk_cnt != nullptr;                     // the last workgroup of a sample combines its partials
         hipLaunchKernelGGL(dec_attn2_kernel, dim3(a.nsplit, B), dim3(DEC_AT2), lds_at2, st, a.q, a.Kc[l], a.Vc[l], a.q_scale[l], a.k_scale[l],
-                           a.bias_table, a.bias_ld, a.parts, H, a.Nmax, a.nsplit, a.pos_dev, a.scale, a.round_bf16);
+                           a.bias_table, a.bias_ld, a.parts, H, a.Nmax, a.nsplit, a.pos_dev, a.scale, a.round_bf16,
+                           comb_in_attn ? a.q : (float*)nullptr, comb_in_attn ? a.splitk_cnt : (int*)nullptr);
         dec2_args o = g;                                                               // x1 = x + attn Wo^T
         o.K = HD; o.parts = a.parts; o.W = a.Wo[l]; o.ldw = HD; o.Nout = D; o.res = a.x; o.ldres = D; o.out = a.x1; o.ldout = D;
         if (mfma) {                                                                    // combine once, then a plain (no LayerNorm) row product
-            hipLaunchKernelGGL(dec_attn_combine_kernel, dim3(H, B), dim3(64), 0, st, a.parts, a.q, a.nsplit, H, a.pos_dev, a.round_bf16);
+            if (!comb_in_attn) hipLaunchKernelGGL(dec_attn_combine_kernel, dim3(H, B), dim3(64), 0, st, a.parts, a.q, a.nsplit, H, a.pos_dev, a.round_bf16);
             o.in = a.q; o.ldin = HD; o.Kstat = HD; o.gamma = nullptr; o.parts = nullptr;     // a.q is free again: the attention kernel consumed it
             o.stat_out = st_x1;
             dec4_launch<8, DEC2_LNGEMV>(o, (D + DEC4_ROWS - 1) / DEC4_ROWS, st);
@@ -1335,10 +1483,12 @@ static int decode_step2_t(const omlm_decode_args& a, const long long* ids, hipSt
         if (pl) { w.Wlo = a.W2p_lo[l]; w.round_bf16 = 0; }
         if constexpr (sizeof(TW) == 2) {
             if (pl && B == 1) hipLaunchKernelGGL((dec3_kernel<TW, 6, DEC2_LNGEMV, true>), dim3((D + 3) / 4), dim3(DEC_T), 0, st, w);
+            else if (pl && split) { w.nsl = 4; w.sk_ws = a.splitk_ws; w.sk_cnt = a.splitk_cnt; dec4_launch<6, DEC2_LNGEMV, true>(w, 4 * ((D + DEC4_ROWS - 1) / DEC4_ROWS), st); }
             else if (pl)      dec4_launch<24, DEC2_LNGEMV, true>(w, (D + DEC4_ROWS - 1) / DEC4_ROWS, st);
         }
         if (pl) {
         } else if (B == 1 && Fp <= 3072) dec3_launch<TW, 6, DEC2_LNGEMV>(w, D, st);
+        else if (mfma && split) { w.nsl = 4; w.sk_ws = a.splitk_ws; w.sk_cnt = a.splitk_cnt; dec4_launch<6, DEC2_LNGEMV>(w, 4 * ((D + DEC4_ROWS - 1) / DEC4_ROWS), st); }
         else if (mfma) dec4_launch<24, DEC2_LNGEMV>(w, (D + DEC4_ROWS - 1) / DEC4_ROWS, st);
         else if (Fp <= 3072) dec2_launch<TW, 6, DEC2_LNGEMV>(w, (D + DEC2_ROWS - 1) / DEC2_ROWS, st);
         else                 dec2_launch<TW, 8, DEC2_LNGEMV>(w, (D + DEC2_ROWS - 1) / DEC2_ROWS, st);

@@ -37,7 +37,8 @@ class DecodeArgs(C.Structure):
                  ("final_gamma", C.c_void_p), ("head_W", C.c_void_p), ("V1", C.c_int), ("ldV", C.c_int),
                  ("emb_table", C.c_void_p), ("emb_row_offset", C.c_longlong), ("emb_rows", C.c_longlong)] +
                 [(n, C.c_void_p) for n in ("x", "x1", "q", "parts", "u", "logits", "advance_pos", "advance_step", "ln_parts")] +
-                [("W1p_lo", C.POINTER(C.c_void_p)), ("W2p_lo", C.POINTER(C.c_void_p)), ("head_W_lo", C.c_void_p)])
+                [("W1p_lo", C.POINTER(C.c_void_p)), ("W2p_lo", C.POINTER(C.c_void_p)), ("head_W_lo", C.c_void_p)] +
+                [("splitk_ws", C.c_void_p), ("splitk_cnt", C.c_void_p)])
 
 
 def max_batch(model, precision: str) -> int:
@@ -138,6 +139,10 @@ class CachedDecoder:
         # per-workgroup LayerNorm partial sums of the batched step kernels (OMLM_DECODE_LN_PARTS(D, Fp) floats x 3 producers)
         self.ln_parts = torch.zeros(3 * max((a.D + 15) // 16, (a.Fp + 7) // 8) * 32, device=self.x.device)      # [partial][16 samples][2]
         a.ln_parts = self.ln_parts.data_ptr()
+        # split-K scratch of the batched FF-out launch (OMLM_DECODE_SPLITK_FLOATS): slabs + one zeroed arrival counter per 16 output rows
+        self.splitk_ws = torch.empty(4 * ((a.D + 15) // 16) * 256, device=self.x.device)
+        self.splitk_cnt = torch.zeros((a.D + 15) // 16, dtype=torch.int32, device=self.x.device)
+        a.splitk_ws, a.splitk_cnt = self.splitk_ws.data_ptr(), self.splitk_cnt.data_ptr()
         self.args = a
 
     # ---- prompt: the batched forward over all known rows, keeping what the single-row steps need ---------------------
