@@ -93,6 +93,9 @@ class DataParallel:
         bit, so it is off by default)."""
         if not self.is_distributed:
             return flat
+        nb = self.bucket_count(flat)
+        if nb > 1 and os.environ.get("OMLM_DP_GRAD_DTYPE", "fp32") != "bf16":
+            return self.allreduce_buckets_(flat, nb)
         if os.environ.get("OMLM_DP_GRAD_DTYPE", "fp32") == "bf16":
             buf = getattr(self, "_xbuf", None)
             if buf is None or buf.numel() != flat.numel() or buf.device != flat.device:
@@ -102,6 +105,34 @@ class DataParallel:
             flat.copy_(buf)
             return flat
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        return flat
+
+    # ---- gradient buckets --------------------------------------------------------------------------------------------------
+    # The flat buffer as contiguous buckets of $OMLM_DP_BUCKET_MB (default 0 = one collective), each its own asynchronous SUM all-reduce:
+    # element i of the result is the sum over ranks of element i whatever the cut, so the buckets give what the single collective gives
+    # (bit for bit on 2 ranks, where a + b is the only order; on more ranks a ring reduces each chunk in its own rank order, so the
+    # rounding of an element may differ between two cuts -- like between two NCCL versions -- while every rank still receives identical
+    # values).  What the cut buys: a bucket can leave as soon as its gradients are final.  Today that is the end of the backward for
+    # all of them (the weight gradients are ONE grouped launch behind the last layer: csrc/gemm.hip, 3.8 machine rounds instead of 30
+    # split-K GEMMs), so the buckets queue back to back on the communicator's stream and the host call returns when the last is done --
+    # the same wire time as one collective; `bucket_ranges` is what a segmented backward hands over bucket by bucket.
+    def bucket_count(self, flat: torch.Tensor) -> int:
+        mb = float(os.environ.get("OMLM_DP_BUCKET_MB", "0") or 0)
+        if mb <= 0:
+            return 1
+        return max(1, -(-flat.numel() * flat.element_size() // int(mb * (1 << 20))))
+
+    @staticmethod
+    def bucket_ranges(numel: int, nb: int, align: int = 1024):
+        """nb contiguous [start, end) element ranges covering [0, numel), cut at multiples of `align` elements."""
+        per = -(-numel // nb)
+        per = -(-per // align) * align
+        return [(s, min(numel, s + per)) for s in range(0, numel, per)]
+
+    def allreduce_buckets_(self, flat: torch.Tensor, nb: int) -> torch.Tensor:
+        works = [dist.all_reduce(flat[s:e], op=dist.ReduceOp.SUM, async_op=True) for s, e in self.bucket_ranges(flat.numel(), nb)]
+        for w in works:
+            w.wait()            # (nccl: makes the current stream wait for the collective; gloo: blocks the host)
         return flat
 
     def grad_scale(self) -> float:

@@ -53,6 +53,7 @@ def main():
     flat = optim.flat_grad
     assert flat.numel() * 4 > 360e6, flat.numel()
     rep = dict(init_s=round(time.time() - t0, 2), flat_mb=round(flat.numel() * 4 / 1e6, 1), precision=precision, equal=[], ms=[])
+    os.environ["OMLM_DP_BUCKET_MB"] = "64"
     for it in range(3):
         optim.zero_grad()
         loss = fb(**dict(zip(keys, ids)))                       # graph replay: the flat buffer is written by kernels still in flight
@@ -60,7 +61,13 @@ def main():
         before = flat.clone()                                   # same stream, behind the replay
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)             # exactly DataParallel.allreduce_sum_'s call
+        if it == 2:                                             # the bucketed form: six asynchronous 64 MB all-reduces behind the same replay
+            nb = dp.bucket_count(flat)
+            assert nb >= 5, nb
+            rep["buckets"] = nb
+            dp.allreduce_buckets_(flat, nb)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)         # exactly DataParallel.allreduce_sum_'s single-collective call
         e1.record()
         after = flat.clone()
         optim.step(max_grad_norm=0.5, grad_scale=dp.grad_scale())

@@ -268,6 +268,18 @@ dp.allreduce_sum_(h)
 assert float((h - want).abs().max()) <= 2.0 ** -7 * float(want.abs().max()), float((h - want).abs().max())
 both = dp.all_gather_cat(h[None]); assert torch.equal(both[0], both[1])
 os.environ["OMLM_DP_GRAD_DTYPE"] = "fp32"
+# gradient buckets: the flat buffer cut into contiguous asynchronous all-reduces gives the single collective's result bit for bit
+torch.manual_seed(100 + dp.rank)
+big = torch.randn(300_000) * 1e3
+one = big.clone(); dp.allreduce_sum_(one)
+os.environ["OMLM_DP_BUCKET_MB"] = "0.25"              # 1.2 MB of fp32 -> 5 buckets
+assert dp.bucket_count(big) == 5
+rng = dp.bucket_ranges(big.numel(), 5)
+assert rng[0][0] == 0 and rng[-1][1] == big.numel() and all(a[1] == b[0] for a, b in zip(rng, rng[1:])) and all(s %% 1024 == 0 for s, _ in rng)
+cut = big.clone(); dp.allreduce_sum_(cut)
+assert torch.equal(one, cut)
+both = dp.all_gather_cat(cut[None]); assert torch.equal(both[0], both[1])
+os.environ["OMLM_DP_BUCKET_MB"] = "0"
 dp.barrier(); dp.shutdown()
 print('rank', dp.rank, 'ok')
 """
