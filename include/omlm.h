@@ -248,11 +248,13 @@ int omlm_gemm_planes16(const void* A, const void* A_lo, const void* B, const voi
  * the hi8 plane, rows padded to a multiple of 256 (both planes readable in full).  a_scale / b_scale: one E8M0 byte per row,
  * hi8 = fp8(hi 2^-(byte - 127)), lo8 = fp8(lo 2^-(byte - 127 - 11)) (omlm_layernorm_fwd_mx / omlm_ffmid_fwd_mx / omlm_quant_rows_mx write all
  * of it).  2 x the k-tiles of a plain GEMM instead of omlm_gemm_planes16's 3 x; what the fp8 corrections leave in the logits:
- * profiles/r06_error_budget_fp8corr.md.  C_lo given: half planes out (no Cin), else fp32 (+ Cin).  workspace as in omlm_gemm
- * (omlm_gemm_mx16_workspace_bytes(M, N, K)).  K % 64 == 0. */
+ * profiles/r06_error_budget_fp8corr.md.  C_lo given: planes out (no Cin) -- C the half hi plane rne16(v), C_lo the remainder v - C as half
+ * (c_lo_bf8 == 0) or as bf8 (e5m2) BYTES at the same element pitch ldc (c_lo_bf8 != 0: the upper byte of a half, same exponent range, no
+ * scale; C + C_lo ~ v to 2^-14 -- h1 of the ConvFeedForward forward, read back by omlm_ffmid_fwd_mx: half the lo plane's bytes written and
+ * read); else fp32 (+ Cin).  workspace as in omlm_gemm (omlm_gemm_mx16_workspace_bytes(M, N, K)).  K % 64 == 0. */
 int omlm_gemm_mx16(const void* A, const void* A8, long long a8_stride, const unsigned char* a_scale,
                    const void* B, const void* B8, long long b8_stride, const unsigned char* b_scale,
-                   void* C, void* C_lo, const float* Cin, long long a_rows, long long b_rows,
+                   void* C, void* C_lo, int c_lo_bf8, const float* Cin, long long a_rows, long long b_rows,
                    int M, int N, int K, int lda, int ldb, int ldc, int ldcin,
                    void* workspace, long long workspace_bytes, void* stream);
 long long omlm_gemm_mx16_workspace_bytes(int M, int N, int K);
@@ -260,7 +262,8 @@ long long omlm_gemm_mx16_workspace_bytes(int M, int N, int K);
  * planes [hi8 | lo8] (row pitch = 2 x the half plane's pitch in elements, in bytes; lo8 plane `*_stride` bytes behind hi8; bytes behind the row's
  * last element zero up to the next multiple of 128) and one E8M0 scale byte per row, 2^e >= 2^-8 x a bound of the row's largest entry:
  *   omlm_layernorm_fwd_mx : transformer.py:24-31 in front of FF-in; bound = sqrt(D) max|gamma| (what a LayerNorm output cannot exceed)
- *   omlm_ffmid_fwd_mx     : omlm_ffmid_fwd_planes with h2 in this form; bound = sqrt(F) max|gamma / keep| the same way
+ *   omlm_ffmid_fwd_mx     : omlm_ffmid_fwd_planes with h2 in this form; bound = sqrt(F) max|gamma / keep| the same way.  h1_lo: the lo plane
+ *                           of h1 as bf8 BYTES at h1's element pitch (what omlm_gemm_mx16 writes with c_lo_bf8 != 0)
  *   omlm_quant_rows_mx    : fp32 weights (all problems of a model in one launch); hi = rne_half(w), exact row maximum; rows' tails untouched
  *                           (zero-fill the buffer once) */
 int omlm_layernorm_fwd_mx(const float* x, const float* gamma, void* y, void* y8, long long y8_stride, unsigned char* scale8,

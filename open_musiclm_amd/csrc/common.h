@@ -325,6 +325,12 @@ __device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d
     r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
     return (unsigned)r;
 }
+// four values -> four bf8 (e5m2) bytes, RNE: the upper byte of a half, same exponent range -- no scale (the lo plane of h1)
+__device__ __forceinline__ unsigned pack4_bf8(float a, float b, float c, float d) {
+    int r = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false);
+    r = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, r, true);
+    return (unsigned)r;
+}
 // exponent e of a row whose entries are bounded by `bound`: bound <= 2^(e + 8) (frexp: bound = m 2^ex with m < 1); an all-zero row takes e = -100
 __device__ __forceinline__ int mx_row_exp(float bound) {
     int ex;

@@ -512,8 +512,17 @@ __global__ __launch_bounds__(DEC_T) void dec_ffin_kernel(const float* __restrict
 #define DEC2_ROWS 4
 
 template <typename TW> struct dec_wreg;
+#ifndef OMLM_DEC_NT
+#define OMLM_DEC_NT 0          // 1: weight rows of the B = 1 kernels as non-temporal loads (A/B: tools/build_ab.sh nt decode.hip -DOMLM_DEC_NT=1)
+#endif
 template <> struct dec_wreg<h16_t> { u32x4 r;
-    __device__ __forceinline__ void load(const h16_t* p) { r = *(const u32x4*)p; }
+    __device__ __forceinline__ void load(const h16_t* p) {
+#if OMLM_DEC_NT
+        r = __builtin_nontemporal_load((const u32x4*)p);
+#else
+        r = *(const u32x4*)p;
+#endif
+    }
     __device__ __forceinline__ void zero() { r[0] = r[1] = r[2] = r[3] = 0u; }
     __device__ __forceinline__ void unpack(float* w) const {
 #pragma unroll

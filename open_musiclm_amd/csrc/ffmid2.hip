@@ -101,7 +101,31 @@ __device__ __forceinline__ void store_planes8(h16_t* hi, h16_t* lo, const v2 (&y
 }
 __device__ __forceinline__ void store_planes8(float*, float*, const v2 (&)[4]) {}          // (fp32 operands have no planes)
 struct FfPlanes { long long h1_lo, convw_lo, gamma_lo; void* h2_lo;        // element distances hi -> lo of the inputs; lo plane of h2
-                  unsigned char* h2_8; long long h2_8_stride; unsigned char* scale8; };     // MX instantiations: h2's fp8 planes [hi8 | lo8] (pitch 2 Fp bytes) + row scales instead of h2_lo
+                  unsigned char* h2_8; long long h2_8_stride; unsigned char* scale8;        // MX instantiations: h2's fp8 planes [hi8 | lo8] (pitch 2 Fp bytes) + row scales instead of h2_lo
+                  const unsigned char* h1_8; };                                             // MX instantiations: h1's lo plane as bf8 bytes at h1's element pitch (instead of h1_lo)
+// a pair of bf8 (e5m2) bytes of a word -> two floats (the conversion's word select is an immediate)
+__device__ __forceinline__ v2 bf8_pair(u32x2 l, int i) {
+    switch (i) {
+        case 0: return __builtin_amdgcn_cvt_pk_f32_bf8((int)l[0], false);
+        case 1: return __builtin_amdgcn_cvt_pk_f32_bf8((int)l[0], true);
+        case 2: return __builtin_amdgcn_cvt_pk_f32_bf8((int)l[1], false);
+        default: return __builtin_amdgcn_cvt_pk_f32_bf8((int)l[1], true);
+    }
+}
+// 8 channels of h1 at element offset `off`: the operand itself (PL false), hi + half lo planes (PL), hi plane + bf8 lo bytes (MX:
+// omlm_gemm_mx16 leaves h1's lo plane as e5m2 -- 1 byte per element, hi + lo ~ h1 to 2^-14)
+template <typename T, bool PL, bool MX> struct H1Row {
+    Row8<T, PL> r;
+    __device__ __forceinline__ void load(const T* h1, size_t off, const FfPlanes& pl) { r.load(h1 + off, pl.h1_lo); }
+    __device__ __forceinline__ void zero() { r.zero(); }
+    __device__ __forceinline__ v2 get(int i) const { return r.get(i); }
+};
+template <typename T> struct H1Row<T, true, true> {
+    Ch8<T> h; u32x2 l;
+    __device__ __forceinline__ void load(const T* h1, size_t off, const FfPlanes& pl) { h.load(h1 + off); l = *(const u32x2*)(pl.h1_8 + off); }
+    __device__ __forceinline__ void zero() { h.zero(); l[0] = 0u; l[1] = 0u; }
+    __device__ __forceinline__ v2 get(int i) const { return h.get(i) + bf8_pair(l, i); }
+};
 // y as the half hi plane + fp8 planes (omlm_gemm_mx16's operand form): hi8 = e4m3(hi sh), lo8 = e4m3((y - hi) sl)
 __device__ __forceinline__ void store_mx8(h16_t* hi, unsigned char* p8h, unsigned char* p8l, const v2 (&y)[4], float sh, float sl) {
     u32x4 o;
@@ -257,19 +281,19 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
     // conv window: rows t0 - 1 and t0 - 2 of the same sample (zero before the sample starts, transformer.py:129)
     v2 x1v[4], x1g[4], x2v[4], x2g[4];
     {
-        Row8<T, PL> a, c, d, e;
+        H1Row<T, PL, MX> a, c, d, e;
         a.zero(); c.zero(); d.zero(); e.zero();
-        if (t0 >= 1) { a.load(h1 + (row0 + t0 - 1) * ld + col, pl.h1_lo); c.load(h1 + (row0 + t0 - 1) * ld + Fp + col, pl.h1_lo); }
-        if (t0 >= 2) { d.load(h1 + (row0 + t0 - 2) * ld + col, pl.h1_lo); e.load(h1 + (row0 + t0 - 2) * ld + Fp + col, pl.h1_lo); }
+        if (t0 >= 1) { a.load(h1, (row0 + t0 - 1) * ld + col, pl); c.load(h1, (row0 + t0 - 1) * ld + Fp + col, pl); }
+        if (t0 >= 2) { d.load(h1, (row0 + t0 - 2) * ld + col, pl); e.load(h1, (row0 + t0 - 2) * ld + Fp + col, pl); }
 #pragma unroll
         for (int i = 0; i < 4; ++i) { x1v[i] = a.get(i); x1g[i] = c.get(i); x2v[i] = d.get(i); x2g[i] = e.get(i); }
     }
-    Row8<T, PL> rv[RB_], rg[RB_];
+    H1Row<T, PL, MX> rv[RB_], rg[RB_];
 #pragma unroll
     for (int r = 0; r < RB_; ++r)
         if (t0 + r < t1) {
-            rv[r].load(h1 + (row0 + t0 + r) * ld + col, pl.h1_lo);
-            rg[r].load(h1 + (row0 + t0 + r) * ld + Fp + col, pl.h1_lo);
+            rv[r].load(h1, (row0 + t0 + r) * ld + col, pl);
+            rg[r].load(h1, (row0 + t0 + r) * ld + Fp + col, pl);
         }
     const float invF = 1.0f / (float)F;
 
@@ -320,8 +344,8 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
 #if FS_PIN
                 if (FULL) __builtin_amdgcn_sched_barrier(0);     // (hipcc's scheduler otherwise sinks the four requests below the whole sweep)
 #endif
-                rv[r].load(h1 + (row0 + tb + RB_ + r) * ld + col, pl.h1_lo);
-                rg[r].load(h1 + (row0 + tb + RB_ + r) * ld + Fp + col, pl.h1_lo);
+                rv[r].load(h1, (row0 + tb + RB_ + r) * ld + col, pl);
+                rg[r].load(h1, (row0 + tb + RB_ + r) * ld + Fp + col, pl);
 #if FS_PIN
                 if (FULL) __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -333,8 +357,8 @@ __global__ __launch_bounds__(NT, (FS_OCC * NT + 255) / 256) void ffmid2_fwd_kern
 #pragma unroll
         for (int r = 0; r < RB_; ++r)
             if (FULL || tb + RB_ + r < t1) {
-                rv[r].load(h1 + (row0 + tb + RB_ + r) * ld + col, pl.h1_lo);
-                rg[r].load(h1 + (row0 + tb + RB_ + r) * ld + Fp + col, pl.h1_lo);
+                rv[r].load(h1, (row0 + tb + RB_ + r) * ld + col, pl);
+                rg[r].load(h1, (row0 + tb + RB_ + r) * ld + Fp + col, pl);
             }
 #endif
 #pragma unroll
@@ -869,7 +893,7 @@ bool ffmid2_supported(int Fp) { return Fp % 8 == 0 && Fp / 8 <= 512; }
 template <typename T, bool PL = false, bool MX = false>
 static int fwd_launch_t(const void* h1, const void* convw, const void* gamma, void* h2, float* mean, float* rstd, int M, int nseq,
                         int F, int Fp, float eps, float p, unsigned long long seed, const unsigned long long* seed_dev,
-                        unsigned char* drop_bits, void* gh, hipStream_t st, const FfPlanes pl = FfPlanes{0, 0, 0, nullptr, nullptr, 0, nullptr}) {
+                        unsigned char* drop_bits, void* gh, hipStream_t st, const FfPlanes pl = FfPlanes{0, 0, 0, nullptr, nullptr, 0, nullptr, nullptr}) {
     const int B = M / nseq;
     const int RB = strip_rows(nseq, 36);
     const int strips = (nseq + RB - 1) / RB;
@@ -914,17 +938,19 @@ int ffmid2_fwd_planes_launch(const void* h1, const void* h1_lo, const void* conv
     pl.convw_lo = (const h16_t*)convw_lo - (const h16_t*)convw;
     pl.gamma_lo = (const h16_t*)gamma_lo - (const h16_t*)gamma;
     pl.h2_lo = h2_lo;
-    pl.h2_8 = nullptr; pl.h2_8_stride = 0; pl.scale8 = nullptr;
+    pl.h2_8 = nullptr; pl.h2_8_stride = 0; pl.scale8 = nullptr; pl.h1_8 = nullptr;
     return fwd_launch_t<h16_t, true>(h1, convw, gamma, h2, mean, rstd, M, nseq, F, Fp, eps, p, seed, seed_dev, drop_bits, gh, st, pl);
 }
 
 #if OMLM_FP16
-// the plane forward with h2 leaving in omlm_gemm_mx16's operand form: half hi plane + fp8 planes [hi8 | lo8] (row pitch 2 Fp bytes) + row scales
+// the plane forward with h2 leaving in omlm_gemm_mx16's operand form: half hi plane + fp8 planes [hi8 | lo8] (row pitch 2 Fp bytes) + row scales;
+// h1's lo plane arrives as bf8 bytes (h1_lo8, at h1's element pitch: what omlm_gemm_mx16 writes with c_lo_bf8)
 int ffmid2_fwd_mx_launch(const void* h1, const void* h1_lo, const void* convw, const void* convw_lo, const void* gamma, const void* gamma_lo,
                          void* h2, void* h2_8, long long h2_8_stride, unsigned char* scale8, float* mean, float* rstd, int M, int nseq, int F, int Fp,
                          float eps, float p, unsigned long long seed, const unsigned long long* seed_dev, unsigned char* drop_bits, void* gh, hipStream_t st) {
     FfPlanes pl;
-    pl.h1_lo = (const h16_t*)h1_lo - (const h16_t*)h1;
+    pl.h1_lo = 0;
+    pl.h1_8 = (const unsigned char*)h1_lo;
     pl.convw_lo = (const h16_t*)convw_lo - (const h16_t*)convw;
     pl.gamma_lo = (const h16_t*)gamma_lo - (const h16_t*)gamma;
     pl.h2_lo = nullptr;

@@ -634,7 +634,7 @@ __global__ __launch_bounds__(512) void gemm_wgrad_group_kernel(GroupArgs ga) {
     GemmArgs g;
     g.A = q.A; g.B = q.B; g.C = q.C; g.Cin = q.C; g.a_map = nullptr; g.b_map = nullptr; g.c_map = q.c_map;
     g.a_rows = q.K; g.b_rows = q.K; g.M = q.M; g.N = q.N; g.K = q.K; g.lda = q.lda; g.ldb = q.ldb; g.ldc = q.ldc; g.ldcin = q.ldc;
-    g.alpha = 1.f; g.kt_per_split = q.kt_per_split; g.bal_ck = 0; g.bal_chunks = 0; g.debug = 0; g.split3 = 0; g.A_lo = nullptr; g.B_lo = nullptr; g.C_lo = nullptr; g.c_split_stride = 0;
+    g.alpha = 1.f; g.kt_per_split = q.kt_per_split; g.bal_ck = 0; g.bal_chunks = 0; g.debug = 0; g.split3 = 0; g.A_lo = nullptr; g.B_lo = nullptr; g.C_lo = nullptr; g.c_lo8 = 0; g.c_split_stride = 0;
     g.epi_scale = nullptr; g.epi_norm = nullptr; g.epi_groups = 0; g.epi_ldnorm = 0; g.C2 = nullptr; g.c2_col0 = 0; g.ldc2 = 0;
     const int nk = (q.K + BK - 1) / BK;
     if constexpr (T8) {
@@ -884,7 +884,7 @@ static int gemm_impl(const void* A, const void* B, void* C, const float* Cin,
     g.a_rows = a_rows; g.b_rows = b_rows; g.M = M; g.N = N; g.K = K;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldcin = ldcin; g.alpha = alpha;
     { const char* dbg = getenv("OMLM_GEMM_DEBUG"); g.debug = dbg ? atoi(dbg) : 0; }
-    g.split3 = split3; g.A_lo = A_lo; g.B_lo = B_lo; g.C_lo = C_lo; g.c_split_stride = 0;
+    g.split3 = split3; g.A_lo = A_lo; g.B_lo = B_lo; g.C_lo = C_lo; g.c_lo8 = 0; g.c_split_stride = 0;
     g.epi_scale = nullptr; g.epi_norm = nullptr; g.epi_groups = 0; g.epi_ldnorm = 0; g.C2 = nullptr; g.c2_col0 = 0; g.ldc2 = 0;
     hipStream_t st = as_stream(stream);
     // tile shape (bf16 path): 256x256 when both output dims are wide, 256x128 for tall-narrow outputs, else 128x128

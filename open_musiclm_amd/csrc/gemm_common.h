@@ -37,9 +37,12 @@ struct GemmArgs {
     // hi/lo operand planes ("bf16x3" through the tile kernels; round 5: the ConvFeedForward forward of "fp16ff" on IEEE-half planes): A and B
     // point at a 16-bit hi plane, A_lo / B_lo at the matching lo plane (same layout, its own buffer descriptor: the planes may be separate
     // allocations), and the k-loop runs 3 x the k-tiles: (A_hi, B_hi), (A_hi, B_lo), (A_lo, B_hi).  C_lo (TOUT = h16pl_t instantiations):
-    // the result leaves as planes too -- C = rne16(v), C_lo = rne16(v - C) at the same pitch.
+    // the result leaves as planes too -- C = rne16(v), C_lo = rne16(v - C) at the same pitch.  c_lo8: the lo plane as bf8 (e5m2: the upper
+    // byte of a half, same exponent range, no scale) BYTES at the same element pitch -- omlm_gemm_mx16's h1: half the lo plane's bytes on
+    // both sides of it, and v - C keeps 3 significant bits (C + C_lo ~ v to 2^-14 instead of 2^-11 for C alone).
     int split3;
     const void* A_lo; const void* B_lo; void* C_lo;
+    int c_lo8;
     // split-K into SLICES instead of atomics (the peeled tail, gemm_impl): split s stores its fp32 partial tile to C + s * c_split_stride
     // (elements); a reduction kernel adds the slices in a fixed order -- deterministic, and no pre-filled C
     long long c_split_stride;
@@ -526,11 +529,18 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16 (&acc)[M
                     o[2] = pack_h16_rne(v[4 % VEC], v[5 % VEC]); o[3] = pack_h16_rne(v[6 % VEC], v[7 % VEC]);
                     *(u32x4*)(C + prow * g.ldc + col) = o;
                     if constexpr (PLANES) {
-                        u32x4 l;
+                        if (g.c_lo8) {
+                            u32x2 l8;
+                            l8[0] = pack4_bf8(v[0] - h16_lo_to_f(o[0]), v[1] - h16_hi_to_f(o[0]), v[2] - h16_lo_to_f(o[1]), v[3] - h16_hi_to_f(o[1]));
+                            l8[1] = pack4_bf8(v[4 % VEC] - h16_lo_to_f(o[2]), v[5 % VEC] - h16_hi_to_f(o[2]), v[6 % VEC] - h16_lo_to_f(o[3]), v[7 % VEC] - h16_hi_to_f(o[3]));
+                            *(u32x2*)((unsigned char*)g.C_lo + prow * g.ldc + col) = l8;
+                        } else {
+                            u32x4 l;
 #pragma unroll
-                        for (int x = 0; x < 4; ++x)
-                            l[x] = pack_h16_rne(v[(2 * x) % VEC] - h16_lo_to_f(o[x]), v[(2 * x + 1) % VEC] - h16_hi_to_f(o[x]));
-                        *(u32x4*)((h16_t*)g.C_lo + prow * g.ldc + col) = l;
+                            for (int x = 0; x < 4; ++x)
+                                l[x] = pack_h16_rne(v[(2 * x) % VEC] - h16_lo_to_f(o[x]), v[(2 * x + 1) % VEC] - h16_hi_to_f(o[x]));
+                            *(u32x4*)((h16_t*)g.C_lo + prow * g.ldc + col) = l;
+                        }
                     }
                 } else {
                     *(float4*)((float*)g.C + prow * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
@@ -544,7 +554,8 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, f32x16 (&acc)[M
                         store_from_float(C + prow * g.ldc + col + x, o);
                         if constexpr (PLANES) {
                             const h16_t hi = (h16_t)o;
-                            store_from_float((h16_t*)g.C_lo + prow * g.ldc + col + x, o - (float)hi);
+                            if (g.c_lo8) ((unsigned char*)g.C_lo)[prow * g.ldc + col + x] = (unsigned char)(pack4_bf8(o - (float)hi, 0.f, 0.f, 0.f) & 0xFFu);
+                            else store_from_float((h16_t*)g.C_lo + prow * g.ldc + col + x, o - (float)hi);
                         }
                     }
             }
@@ -560,7 +571,7 @@ __device__ __forceinline__ int xcd_logical_id(int lin, int total) {
 }
 
 // Sum of the S fp32 slices a slice-storing split-K left in a workspace (GemmArgs::c_split_stride), in a fixed order, plus the residual.
-// MODE 0: fp32 out; 1: 16-bit out; 2: 16-bit hi/lo planes out.  One thread = 4 consecutive columns of a row.
+// MODE 0: fp32 out; 1: 16-bit out; 2: 16-bit hi/lo planes out; 3: 16-bit hi plane + bf8 lo plane (bytes).  One thread = 4 consecutive columns of a row.
 template <int MODE>
 __global__ __launch_bounds__(256) void gemm_tail_reduce_kernel(const float* __restrict__ ws, int S, long long stride, int M, int N, int ldw,
                                                                void* __restrict__ C, void* __restrict__ C_lo, int ldc,
@@ -585,6 +596,7 @@ __global__ __launch_bounds__(256) void gemm_tail_reduce_kernel(const float* __re
                 const h16_t hi = (h16_t)u;
                 ((h16_t*)C)[(size_t)r * ldc + c + x] = hi;
                 if constexpr (MODE == 2) ((h16_t*)C_lo)[(size_t)r * ldc + c + x] = (h16_t)(u - (float)hi);
+                if constexpr (MODE == 3) ((unsigned char*)C_lo)[(size_t)r * ldc + c + x] = (unsigned char)(pack4_bf8(u - (float)hi, 0.f, 0.f, 0.f) & 0xFFu);
             }
         }
     }

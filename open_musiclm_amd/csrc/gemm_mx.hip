@@ -284,11 +284,12 @@ extern "C" long long omlm_gemm_mx16_workspace_bytes(int M, int N, int K) {
 
 // C = A B^T (+ Cin) for IEEE-half operands given as planes (include/omlm.h).  A8 / B8: the operand's fp8 planes [hi8 | lo8] at the half plane's row
 // pitch, the lo8 plane a8_stride / b8_stride bytes behind the hi8 plane, rows padded to a multiple of 256 (every byte of both planes readable;
-// bytes [K, ceil128(K)) of every row zero).  C_lo != NULL: the result leaves as half hi / lo planes (no Cin); else fp32 (+ Cin).
+// bytes [K, ceil128(K)) of every row zero).  C_lo != NULL: the result leaves as planes (no Cin) -- C the half hi plane, C_lo the lo plane as
+// half (c_lo_bf8 == 0) or as bf8 bytes at the same element pitch (c_lo_bf8 != 0: GemmArgs::c_lo8); else fp32 (+ Cin).
 // workspace: caller-owned, >= omlm_gemm_mx16_workspace_bytes(M, N, K) (or NULL: the tail runs unsplit); one per stream.
 extern "C" int omlm_gemm_mx16(const void* A, const void* A8, long long a8_stride, const unsigned char* a_scale,
                               const void* B, const void* B8, long long b8_stride, const unsigned char* b_scale,
-                              void* C, void* C_lo, const float* Cin, long long a_rows, long long b_rows,
+                              void* C, void* C_lo, int c_lo_bf8, const float* Cin, long long a_rows, long long b_rows,
                               int M, int N, int K, int lda, int ldb, int ldc, int ldcin,
                               void* workspace, long long workspace_bytes, void* stream) {
     if (M <= 0 || N <= 0) return OMLM_OK;
@@ -306,7 +307,8 @@ extern "C" int omlm_gemm_mx16(const void* A, const void* A8, long long a8_stride
     OMLM_CHECK_ARG((workspace == nullptr) == (workspace_bytes == 0) && ((uintptr_t)workspace % 16) == 0, "workspace: 16-byte aligned buffer and its size, or NULL / 0");
     GemmMxArgs g;
     memset(&g, 0, sizeof(g));
-    g.A = A; g.B = B; g.C = C; g.Cin = Cin; g.C_lo = C_lo;
+    g.A = A; g.B = B; g.C = C; g.Cin = Cin; g.C_lo = C_lo; g.c_lo8 = (C_lo && c_lo_bf8) ? 1 : 0;
+    OMLM_CHECK_ARG(!g.c_lo8 || (ldc % 8 == 0 && ((uintptr_t)C_lo % 8) == 0), "bf8 lo plane: 8-byte aligned, pitch a multiple of 8");
     g.a_rows = a_rows; g.b_rows = b_rows; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldcin = ldcin; g.alpha = 1.0f;
     g.A8 = A8; g.B8 = B8; g.a8_stride = (unsigned)a8_stride; g.b8_stride = (unsigned)b8_stride; g.a_scale = a_scale; g.b_scale = b_scale;
     const int nk_all = ((K / BK + 1) & ~1) + 2 * ((K + 127) / 128);
@@ -324,7 +326,7 @@ extern "C" int omlm_gemm_mx16(const void* A, const void* A8, long long a8_stride
     g2.a_scale = a_scale + M1;
     g2.a_rows = a_rows - M1;
     g2.C = (char*)C + (size_t)M1 * ldc * osz;
-    if (C_lo) g2.C_lo = (char*)C_lo + (size_t)M1 * ldc * osz;
+    if (C_lo) g2.C_lo = (char*)C_lo + (size_t)M1 * ldc * (g.c_lo8 ? 1 : osz);
     if (Cin) g2.Cin = Cin + (size_t)M1 * ldcin;
     int rc = run(g1);
     if (rc != OMLM_OK) return rc;
@@ -336,7 +338,8 @@ extern "C" int omlm_gemm_mx16(const void* A, const void* A8, long long a8_stride
     if (rc != OMLM_OK) return rc;
     const long long quads = (long long)Mt * (Nw / 4);
     const int blocks = (int)((quads + 255) / 256 > 4096 ? 4096 : (quads + 255) / 256);
-    if (C_lo) hipLaunchKernelGGL(gemm_tail_reduce_kernel<2>, dim3(blocks), dim3(256), 0, st, (const float*)workspace, S, slice, Mt, N, Nw, g2.C, g2.C_lo, ldc, (const float*)nullptr, 0);
+    if (C_lo && g.c_lo8) hipLaunchKernelGGL(gemm_tail_reduce_kernel<3>, dim3(blocks), dim3(256), 0, st, (const float*)workspace, S, slice, Mt, N, Nw, g2.C, g2.C_lo, ldc, (const float*)nullptr, 0);
+    else if (C_lo) hipLaunchKernelGGL(gemm_tail_reduce_kernel<2>, dim3(blocks), dim3(256), 0, st, (const float*)workspace, S, slice, Mt, N, Nw, g2.C, g2.C_lo, ldc, (const float*)nullptr, 0);
     else      hipLaunchKernelGGL(gemm_tail_reduce_kernel<0>, dim3(blocks), dim3(256), 0, st, (const float*)workspace, S, slice, Mt, N, Nw, g2.C, (void*)nullptr, ldc, g2.Cin, ldcin);
     return omlm_post_launch("omlm_gemm_mx16 (tail reduce)");
 }

@@ -554,7 +554,7 @@ def trunk_forward(tr, pw: PreparedWeights, x: torch.Tensor, keymask: Optional[to
             # leaves the hi plane -- what the fp16 backward keeps -- plus fp8 planes and row scales that die with the layer
             P1 = ops.Fp8Planes(M, D, dev, zero=False)
             ops.layernorm_fwd_mx(x1, ff.norm_in.gamma.detach(), xn2, P1, m2, r2)
-            h1_lo = torch.empty(M, 2 * Fp, dtype=T, device=dev)
+            h1_lo = torch.empty(M, 2 * Fp, dtype=torch.uint8, device=dev)      # the lo plane as bf8 (e5m2) bytes: h1 = hi + lo to 2^-14
             ops.gemm_mx16(xn2, P1, w["W1p"], w["W1p8"], h1, h1_lo, M=M, N=2 * Fp, K=D)
         elif pw.ff3:
             # "fp16ff": LN output, h1 and h2 exist as hi/lo planes during this layer's forward; the lo planes die with the layer (their
@@ -591,7 +591,10 @@ def trunk_forward(tr, pw: PreparedWeights, x: torch.Tensor, keymask: Optional[to
             if keep_h1_lo_tail and save:
                 take = min(2, N)
                 sv.h1_lo_tail = torch.zeros(B, 2, 2 * Fp, device=dev)
-                sv.h1_lo_tail[:, 2 - take:].copy_(h1_lo.view(B, N, -1)[:, N - take:])
+                tail = h1_lo.view(B, N, -1)[:, N - take:]
+                if tail.dtype == torch.uint8:                              # bf8 bytes are the upper bytes of halves
+                    tail = (tail.contiguous().to(torch.int16) << 8).view(torch.float16)
+                sv.h1_lo_tail[:, 2 - take:].copy_(tail)
             del h1_lo
         else:
             ops.ffmid_fwd(h1, w["convw"], w["gamma_mid"], h2, m3, r3, N, F, Fp, p, seed, seed_dev=salt if p > 0 else None,

@@ -30,7 +30,7 @@ SIGNATURES = {
     "omlm_gemm_planes": [vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, i64, vp],
     "omlm_split_planes": [vp, vp, i64, i64, vp],
     "omlm_gemm_planes16": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, vp],
-    "omlm_gemm_mx16": [vp, vp, i64, vp, vp, vp, i64, vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, i32, i32, i32, vp, i64, vp],
+    "omlm_gemm_mx16": [vp, vp, i64, vp, vp, vp, i64, vp, vp, vp, i32, vp, i64, i64, i32, i32, i32, i32, i32, i32, i32, vp, i64, vp],
     "omlm_gemm_mx16_workspace_bytes": [i32, i32, i32],
     "omlm_layernorm_fwd_mx": [vp, vp, vp, vp, i64, vp, vp, vp, i32, i32, i32, f32, vp],
     "omlm_ffmid_fwd_mx": [vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, i32, i32, i32, i32, f32, f32, u64, vp, vp, vp, vp],

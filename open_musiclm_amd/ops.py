@@ -174,7 +174,8 @@ class Fp8Planes:
 
 
 def gemm_mx16(A, A8: Fp8Planes, B, B8: Fp8Planes, C_, C_lo=None, *, M: int, N: int, K: int, Cin: Optional[torch.Tensor] = None):
-    """C = A B^T (+ Cin): the half product of the hi planes plus the two correction products on fp8 at twice the matrix rate (omlm_gemm_mx16)."""
+    """C = A B^T (+ Cin): the half product of the hi planes plus the two correction products on fp8 at twice the matrix rate (omlm_gemm_mx16).
+    C_lo: plane output -- a half tensor, or a uint8 tensor of C's shape for the lo plane as bf8 (e5m2) bytes."""
     hip.require_gpu(A, "A")
     assert A.dtype == torch.float16 and B.dtype == torch.float16
     lda, ldb = A.shape[-1], B.shape[-1]
@@ -182,10 +183,10 @@ def gemm_mx16(A, A8: Fp8Planes, B, B8: Fp8Planes, C_, C_lo=None, *, M: int, N: i
     if C_lo is None:
         assert C_.dtype == torch.float32 and (Cin is None or Cin.dtype == torch.float32)
     else:
-        assert C_.dtype == A.dtype and C_lo.dtype == A.dtype and C_lo.shape == C_.shape and Cin is None
+        assert C_.dtype == A.dtype and C_lo.dtype in (A.dtype, torch.uint8) and C_lo.shape == C_.shape and Cin is None
     ws, wsb = tail_workspace(A.device)
     call("omlm_gemm_mx16", ptr(A), ptr(A8.planes), A8.stride, ptr(A8.scale), ptr(B), ptr(B8.planes), B8.stride, ptr(B8.scale),
-         ptr(C_), ptr(C_lo), ptr(Cin), A.numel() // lda, B.numel() // ldb, M, N, K, lda, ldb, C_.shape[-1],
+         ptr(C_), ptr(C_lo), int(C_lo is not None and C_lo.dtype == torch.uint8), ptr(Cin), A.numel() // lda, B.numel() // ldb, M, N, K, lda, ldb, C_.shape[-1],
          Cin.shape[-1] if Cin is not None else 0, ws, wsb, stream_ptr())
 
 
@@ -486,9 +487,10 @@ def ffmid_fwd_planes(h1, h1_lo, convw, convw_lo, gamma, gamma_lo, h2, h2_lo, mea
 
 def ffmid_fwd_mx(h1, h1_lo, convw, convw_lo, gamma, gamma_lo, h2, P: "Fp8Planes", mean, rstd, nseq, F, Fp, p, seed, eps=1e-5, seed_dev=None,
                  drop_bits=None, gh=None):
-    """ffmid_fwd_planes with h2 leaving as omlm_gemm_mx16's A operand: the half hi plane h2 + its fp8 planes and row scales in P."""
-    assert convw.shape == (3, 2 * Fp) and gamma.numel() == Fp and h1.dtype == torch.float16
-    for t in (h1_lo, convw, convw_lo, gamma, gamma_lo, h2):
+    """ffmid_fwd_planes with h2 leaving as omlm_gemm_mx16's A operand: the half hi plane h2 + its fp8 planes and row scales in P.
+    h1_lo: the lo plane of h1 as bf8 bytes (uint8, h1's shape: gemm_mx16's plane output)."""
+    assert convw.shape == (3, 2 * Fp) and gamma.numel() == Fp and h1.dtype == torch.float16 and h1_lo.dtype == torch.uint8
+    for t in (convw, convw_lo, gamma, gamma_lo, h2):
         assert t.dtype == h1.dtype, "every plane travels in the operand dtype of h1"
     assert h1_lo.shape == h1.shape and convw_lo.shape == convw.shape and P.ld == Fp and P.rows >= h1.shape[0]
     call("omlm_ffmid_fwd_mx", ptr(h1), ptr(h1_lo), ptr(convw), ptr(convw_lo), ptr(gamma), ptr(gamma_lo), ptr(h2), ptr(P.planes), P.stride,

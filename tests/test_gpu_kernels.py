@@ -1403,6 +1403,17 @@ def test_gemm_mx16_vs_fp64(ops, dev, M, N, K, planes_out):
         e_k, e = float((got - ref_k).abs().max()) / scale, float((got - ref).abs().max()) / scale
         # (planes out: the sum is known to the lo plane's own rounding, 2^-22 of the value, and subnormal below 6e-5)
         assert e_k < 4e-6, e_k
+        # the lo plane as bf8 (e5m2) bytes: same hi plane bit for bit; the bytes are the upper bytes of halves, within e5m2's rounding
+        # (3 significant bits) of the half lo plane, so hi + lo8 knows the value to 2^-11 2^-3
+        C8, Cl8 = torch.full((M, N), float("nan"), device=dev, dtype=torch.float16), torch.full((M, N), 0x7f, device=dev, dtype=torch.uint8)
+        ops.gemm_mx16(Ah, A8, Bh, B8, C8, Cl8, M=M, N=N, K=K)
+        assert torch.equal(C8, C)
+        lo8 = (Cl8.to(torch.int16) << 8).view(torch.float16).double()
+        d8 = (lo8 - Cl.double()).abs()
+        assert bool((d8 <= 0.126 * Cl.double().abs() + 2.0 ** -17).all()), float((d8 / (Cl.double().abs() + 1e-30)).max())
+        e8 = float((C8.double() + lo8 - ref_k).abs().max()) / scale
+        report(f"gemm_mx16_bf8_lo[{M},{N},{K}]", vs_own_products=e8)
+        assert e8 < 2.0 ** -13, e8
     else:
         Cin = torch.randn(M, N, generator=g).to(dev)
         C = torch.full((M, N), float("nan"), device=dev)
@@ -1557,6 +1568,9 @@ def test_ffmid_fwd_mx(ops, dev, F, nseq, Bn, p):
     convw = (torch.randn(2 * F, 3, generator=g) * 0.5).to(dev)
     gamma = (1 + 0.1 * torch.randn(F, generator=g)).to(dev)
     h1h, h1l = hilo(h1.to(dev), dtype)
+    # the MX form reads h1's lo plane as bf8 (e5m2) bytes -- the upper bytes of halves: the planes run gets the same values as a half plane
+    h1l8 = ((h1l.view(torch.int16).to(torch.int32) + 0x80) >> 8).clamp(-128, 127).to(torch.int8).view(torch.uint8)      # (round half up on the magnitude bits: any e5m2 values do)
+    h1l = (h1l8.to(torch.int16) << 8).view(torch.float16)
     taps32, g32 = ops.pack_conv_taps(convw, F, Fp), ops.pad_vector(gamma, Fp)
     tph, tpl = hilo(taps32, dtype)
     gph, gpl = hilo(g32, dtype)
@@ -1568,7 +1582,7 @@ def test_ffmid_fwd_mx(ops, dev, F, nseq, Bn, p):
         if mx:
             P = ops.Fp8Planes(M, Fp, dev, zero=False)
             P.planes.fill_(0x7f); P.scale.fill_(0xff)
-            ops.ffmid_fwd_mx(h1h, h1l, tph, tpl, gph, gpl, h2, P, m, r, nseq, F, Fp, p, 4321, drop_bits=bits, gh=gh)
+            ops.ffmid_fwd_mx(h1h, h1l8, tph, tpl, gph, gpl, h2, P, m, r, nseq, F, Fp, p, 4321, drop_bits=bits, gh=gh)
             return h2, P, gh, m, r, bits
         h2l = torch.full((M, Fp), float("nan"), device=dev, dtype=dtype)
         ops.ffmid_fwd_planes(h1h, h1l, tph, tpl, gph, gpl, h2, h2l, m, r, nseq, F, Fp, p, 4321, drop_bits=bits, gh=gh)

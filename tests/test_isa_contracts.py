@@ -128,4 +128,7 @@ def test_plane_route_ring_kernel_fits_and_keeps_its_dma_offsets_scalar(tmp_path)
         assert any("v_readfirstlane_b32" in l for l in body)
         assert sum(1 for l in body if "v_mfma_f32_32x32x16_f16" in l) == sum(1 for l in single if "v_mfma_f32_32x32x16_f16" in l)   # same loop body, 3 x the trips
     st = lambda body: sum(1 for l in body if "global_store_dwordx4" in l)
-    assert st(planes) == 2 * st(single), (st(planes), st(single))
+    # (round 6: the lo plane may also leave as bf8 bytes -- GemmArgs::c_lo8 --, a second epilogue arm whose hi-plane stores hipcc may or may
+    # not share with the half arm: at least the half arm's 2 x, at most both arms' hi stores on top, and 8-byte stores for the bf8 plane)
+    assert 2 * st(single) <= st(planes) <= 3 * st(single), (st(planes), st(single))
+    assert any("global_store_dwordx2" in l for l in planes)
