@@ -158,6 +158,14 @@ class TrainLeg:
             ops_p16(A, A_lo, B, B_lo, C_, C_lo, M=M, N=N, K=K, **kw)
             e1.record()
             rec.append((e0, e1, 2.0 * M * N * K, (M, N, K, str(A.dtype)[6:] + " hi/lo planes", (str(C_.dtype)[6:] + " planes") if C_lo is not None else str(C_.dtype)[6:], 0, 0), 3))
+        ops_mx = ops.gemm_mx16
+
+        def timed_mx(A, A8, B, B8, C_, C_lo=None, *, M, N, K, **kw):           # fp16ff: one half product + two fp8 correction products at twice the rate
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ops_mx(A, A8, B, B8, C_, C_lo, M=M, N=N, K=K, **kw)
+            e1.record()
+            rec.append((e0, e1, 2.0 * M * N * K, (M, N, K, str(A.dtype)[6:] + " + fp8 planes (mx16)", (str(C_.dtype)[6:] + " planes") if C_lo is not None else str(C_.dtype)[6:], 0, 0), 2))
         ops_qkn = ops.gemm_qknorm
 
         def timed_qkn(A, B, C_, scale, norm_out, groups, *, M, N, K, **kw):      # q / k projections with the l2-norm epilogue: GEMM launches too
@@ -180,6 +188,7 @@ class TrainLeg:
             rec.append((e0, e1, fl, ('wgrad_group', len(wg.items), splits)))
         E.ops.gemm = timed_gemm
         E.ops.gemm_planes16 = timed_p16
+        E.ops.gemm_mx16 = timed_mx
         E.ops.gemm_qknorm = timed_qkn
         ops.WgradGroup.flush = timed_flush
         try:
@@ -189,12 +198,13 @@ class TrainLeg:
         finally:
             E.ops.gemm = ops_gemm
             E.ops.gemm_planes16 = ops_p16
+            E.ops.gemm_mx16 = ops_mx
             E.ops.gemm_qknorm = ops_qkn
             ops.WgradGroup.flush = group_flush
         tot_ms = sum(r[0].elapsed_time(r[1]) for r in rec)
         tot_fl = sum(r[2] for r in rec)
         mult = 3 if self.precision == "bf16x3" else 1
-        issued_fl = sum(r[2] * (r[4] if len(r) > 4 else mult) for r in rec)      # products the matrix cores are issued (hi/lo plane launches: 3 per algorithmic one)
+        issued_fl = sum(r[2] * (r[4] if len(r) > 4 else mult) for r in rec)      # products the matrix cores are issued, in half-rate equivalents (hi/lo half planes: 3 per algorithmic one; mx16: 1 half + 2 fp8 at twice the rate = 2)
         big = [(r[0].elapsed_time(r[1]), r[2]) for r in rec if r[2] > 1e11]
         if os.environ.get("OMLM_BENCH_GEMM_TABLE"):        # per-shape table of the same launches (tools: profiles/*_gemm_calls.md)
             agg = {}
@@ -215,8 +225,9 @@ class TrainLeg:
                 "large_gemm_achieved": round(sum(f for _, f in big) / (sum(t for t, _ in big) * 1e-3) / 1e12, 2) if big else None,
                 "single_product_achieved": (round(sum(r[2] for r in rec if len(r) <= 4) / (sum(r[0].elapsed_time(r[1]) for r in rec if len(r) <= 4) * 1e-3) / 1e12, 2)
                                             if any(len(r) > 4 for r in rec) else None),
-                "note": ("achieved / frac count ALGORITHMIC flops (2 M N K per linear); the hi/lo-plane launches of fp16ff (FF-in, FF-out, heads forward) issue three "
-                         "products each: mfma_issue_frac counts those; single_product_achieved = every other GEMM launch of the step")
+                "note": ("achieved / frac count ALGORITHMIC flops (2 M N K per linear); the FF-in / FF-out forward launches of fp16ff issue one half product + two fp8 "
+                         "correction products at twice the matrix rate (omlm_gemm_mx16: 2 half-rate equivalents), the head launches three half products "
+                         "(omlm_gemm_planes16): mfma_issue_frac counts those; single_product_achieved = every other GEMM launch of the step")
                         if any(len(r) > 4 for r in rec) else "achieved / frac count algorithmic flops (2 M N K per linear)"}
 
     def free(self):

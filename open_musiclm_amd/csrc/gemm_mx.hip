@@ -46,9 +46,11 @@ __device__ __forceinline__ h16x8 half8(i32x8 v) {
     return __builtin_bit_cast(h16x8, h);
 }
 
-template <typename TOUT, bool SLICE>
+// FUSE: one launch carries the full-round tiles (output type TOUT) AND the k-slices of the peeled tail (fp32 slices into the workspace): `tail`
+// (uniform per workgroup) selects the epilogue; the k-loop is the same code for both.
+template <typename TOUT, bool SLICE, bool FUSE = false>
 __device__ __forceinline__ void gemm_mx_body(const GemmMxArgs& g, const int m0, const int n0, const int kt0, const int kt1, const bool split,
-                                             const int ksplit, char* smem) {
+                                             const int ksplit, char* smem, const bool tail = false) {
     constexpr int A_BYTES = 256 * BK * 2, STAGE = 2 * A_BYTES;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -200,6 +202,17 @@ __device__ __forceinline__ void gemm_mx_body(const GemmMxArgs& g, const int m0, 
 #undef T8_SYNC_OUT
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           // the dead requests of the last phases (zeros into LDS) are drained
     __syncthreads();
+    if constexpr (FUSE) {
+        if (tail) {
+#pragma unroll
+            for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb)
+                    tile_epilogue<2, 1, 32, float, 0, true, true>(g, reinterpret_cast<f32x16 (&)[2][1]>(acc[ha][hb]), smem, m0, n0, ha * 128 + wr * 64,
+                                                                  hb * 128 + wc * 32, wave, lane, 0, true, nullptr, ksplit);
+            return;
+        }
+    }
 #pragma unroll
     for (int ha = 0; ha < 2; ++ha)
 #pragma unroll
@@ -239,6 +252,46 @@ static int launch_mx(const GemmMxArgs& g, int splits, hipStream_t st) {
     hipLaunchKernelGGL(k, dim3(tiles, splits), dim3(512), LDS, st, g);
     return omlm_post_launch("omlm_gemm_mx16");
 }
+
+// The full-round tiles of `g` and the S k-slices of the peeled tail `t` (its C = the workspace, c_split_stride = one slice) in ONE grid: workgroups
+// [0, main_tiles) are g's tiles in its XCD-aware order, the rest t's (tile, slice) pairs -- dispatched last, they fill the CUs the last round
+// of g leaves idle instead of running as a launch of their own on a third of the machine (round 6: 41 us per FF GEMM).
+struct GemmMxPair { GemmMxArgs g, t; int main_tiles, tail_tiles; };
+template <typename TOUT>
+__global__ __launch_bounds__(512) void gemm_mx_fused_kernel(GemmMxPair pr) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const bool tail = (int)blockIdx.x >= pr.main_tiles;                      // (uniform)
+    const GemmMxArgs& g = tail ? pr.t : pr.g;
+    const int nwg = tail ? pr.tail_tiles : pr.main_tiles;
+    const int lin = tail ? (int)blockIdx.x - pr.main_tiles : (int)blockIdx.x;
+    const int total = tail ? (int)gridDim.x - pr.main_tiles : pr.main_tiles;
+    const int lg = xcd_logical_id(lin, total);
+    const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + 255) / 256;
+    const int ksplit = lg / nwg, bid = lg - ksplit * nwg;
+    const int nk_all = ((g.K / BK + 1) & ~1) + 2 * ((g.K + 127) / 128);
+    const int kt0 = ksplit * g.kt_per_split, kt1 = min(nk_all, kt0 + g.kt_per_split);
+    constexpr int GROUP = OMLM_SUPER_ROWS / 256;
+    const int gsz = GROUP * tiles_n;
+    const int grp = bid / gsz, first_m = grp * GROUP;
+    const int rows_in = min(GROUP, tiles_m - first_m);
+    const int tm = first_m + (bid - grp * gsz) % rows_in, tn = (bid - grp * gsz) / rows_in;
+    if (kt0 >= kt1) return;
+    gemm_mx_body<TOUT, false, true>(g, tm * 256, tn * 256, kt0, kt1, tail, ksplit, smem, tail);
+}
+template <typename TOUT>
+static int launch_mx_fused(const GemmMxArgs& g, const GemmMxArgs& t, int S, hipStream_t st) {
+    constexpr size_t LDS = 2 * (size_t)(256 + 256) * BK * 2;
+    GemmMxPair pr;
+    pr.g = g; pr.t = t;
+    pr.main_tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
+    pr.tail_tiles = ((t.M + 255) / 256) * ((t.N + 255) / 256);
+    auto k = gemm_mx_fused_kernel<TOUT>;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); attr = true; }
+    hipLaunchKernelGGL(k, dim3(pr.main_tiles + pr.tail_tiles * S), dim3(512), LDS, st, pr);
+    return omlm_post_launch("omlm_gemm_mx16 (full rounds + tail slices)");
+}
+static bool mx_fuse_tail() { const char* e = getenv("OMLM_MX_FUSE_TAIL"); return !(e && e[0] == '0'); }      // (read per call: the kernel test toggles it)
 
 static int mx_ncu() {
     static int ncu = 0;
@@ -328,14 +381,24 @@ extern "C" int omlm_gemm_mx16(const void* A, const void* A8, long long a8_stride
     g2.C = (char*)C + (size_t)M1 * ldc * osz;
     if (C_lo) g2.C_lo = (char*)C_lo + (size_t)M1 * ldc * (g.c_lo8 ? 1 : osz);
     if (Cin) g2.Cin = Cin + (size_t)M1 * ldcin;
-    int rc = run(g1);
-    if (rc != OMLM_OK) return rc;
     const int Mt = g2.M, Nw = (N + 3) / 4 * 4;
     const long long slice = (long long)Mt * Nw;
     GemmMxArgs gw = g2;
     gw.C = workspace; gw.C_lo = nullptr; gw.Cin = nullptr; gw.ldc = Nw; gw.ldcin = 0; gw.c_split_stride = slice; gw.kt_per_split = ktps;
-    rc = launch_mx<float, true>(gw, S, st);
-    if (rc != OMLM_OK) return rc;
+    int rc;
+    // one grid where the last round of the full tiles leaves CUs idle (FF-in at B = 32: 3058 tiles = 11.95 rounds; the tail's 88 slices start on the
+    // 14 idle CUs and finish ~20 us behind the round instead of 41 us as their own launch: 804 -> 781 us).  A main part of WHOLE rounds (FF-out:
+    // 512 tiles) gains nothing from it (381 -> 392 us measured): two launches.  OMLM_MX_FUSE_TAIL=0: always two launches.
+    const int main_tiles = (int)(M1 / 256) * ((N + 255) / 256);
+    if (mx_fuse_tail() && main_tiles % mx_ncu() != 0) {
+        rc = C_lo ? launch_mx_fused<h16pl_t>(g1, gw, S, st) : launch_mx_fused<float>(g1, gw, S, st);
+        if (rc != OMLM_OK) return rc;
+    } else {
+        rc = run(g1);
+        if (rc != OMLM_OK) return rc;
+        rc = launch_mx<float, true>(gw, S, st);
+        if (rc != OMLM_OK) return rc;
+    }
     const long long quads = (long long)Mt * (Nw / 4);
     const int blocks = (int)((quads + 255) / 256 > 4096 ? 4096 : (quads + 255) / 256);
     if (C_lo && g.c_lo8) hipLaunchKernelGGL(gemm_tail_reduce_kernel<3>, dim3(blocks), dim3(256), 0, st, (const float*)workspace, S, slice, Mt, N, Nw, g2.C, g2.C_lo, ldc, (const float*)nullptr, 0);

@@ -1380,7 +1380,9 @@ def torch_fp8_planes(ops, hi, lo, dev, bound=None):
                                               (2300, 1024, 2752, False),     # FF-out form: K = 43 half tiles (pad tile) + 2 x 22 fp8 tiles (the last one half empty), fp32 + residual
                                               (333, 5504, 1024, True),       # FF-in width
                                               (8448, 2048, 1024, True),      # 264 tiles = one machine round + 8: the tail runs as a slice-storing split-K through the workspace
-                                              (8448, 2048, 1024, False)])
+                                              (8448, 2048, 1024, False),
+                                              (3200, 5504, 1024, True),      # 286 tiles: 242 full-round tiles (not a whole round) + 44 tail tiles x 4 slices in ONE grid (gemm_mx_fused_kernel)
+                                              (3200, 5504, 1024, False)])
 def test_gemm_mx16_vs_fp64(ops, dev, M, N, K, planes_out):
     """omlm_gemm_mx16: C = A_hi B_hi^T on half MFMAs + the two correction products on fp8 MFMAs with one scale per row.  (1) The kernel's own
     arithmetic: against the fp64 evaluation of exactly those three products on the values its planes hold -- the bar is fp32 accumulation.
@@ -1420,6 +1422,24 @@ def test_gemm_mx16_vs_fp64(ops, dev, M, N, K, planes_out):
         ops.gemm_mx16(Ah, A8, Bh, B8, C, M=M, N=N, K=K, Cin=Cin)
         e_k, e = float((C.double() - Cin.double() - ref_k).abs().max()) / scale, float((C.double() - Cin.double() - ref).abs().max()) / scale
         assert e_k < 2e-6, e_k
+    # the tail's k-slices ride in the full-round launch (gemm_mx_fused_kernel); OMLM_MX_FUSE_TAIL=0 runs them as a launch of their own:
+    # same tiles, same k order, same slice sum -- bit for bit
+    old = os.environ.get("OMLM_MX_FUSE_TAIL")
+    try:
+        os.environ["OMLM_MX_FUSE_TAIL"] = "0"
+        if planes_out:
+            C2, Cl2 = torch.full_like(C, float("nan")), torch.full_like(Cl, float("nan"))
+            ops.gemm_mx16(Ah, A8, Bh, B8, C2, Cl2, M=M, N=N, K=K)
+            assert torch.equal(C2, C) and torch.equal(Cl2, Cl)
+        else:
+            C2 = torch.full_like(C, float("nan"))
+            ops.gemm_mx16(Ah, A8, Bh, B8, C2, M=M, N=N, K=K, Cin=Cin)
+            assert torch.equal(C2, C)
+    finally:
+        if old is None:
+            os.environ.pop("OMLM_MX_FUSE_TAIL", None)
+        else:
+            os.environ["OMLM_MX_FUSE_TAIL"] = old
     # per-row view of the residual error (rows differ by 30x in size): the corrections' fp8 rounding, relative to the row's own largest output
     C1 = torch.empty(M, N, device=dev)
     ops.gemm(Ah, Bh, C1, M=M, N=N, K=K)
