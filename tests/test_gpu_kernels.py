@@ -1739,3 +1739,51 @@ def test_gemm_peeled_tail_as_deterministic_split_k(ops, dev, case, monkeypatch):
     assert head and e_two <= 1.5 * e_one + 1e-7, (e_one, e_two)
     assert differ < (0.02 if out16 else 0.6)       # fp32 outputs: the last bit moves with the summation order; 16-bit: only across rounding boundaries
     assert differ > 0 or M * N == 0               # (the split form did run: some bit of some tail element differs)
+
+
+def test_tail_split_gemms_on_two_streams_keep_their_own_scratch(ops, dev):
+    """VERDICT round 5, item 6: the split-K scratch of a peeled tail is an ARGUMENT of the call (include/omlm.h: workspace / workspace_bytes;
+    ops.tail_workspace keeps one buffer per stream), not process-global state.  Two streams run tail-split GEMMs at the same time -- a
+    single-product fp16 launch (d(xn2)'s form) on one, the MX launch (FF-in's form, tail slices inside the full-round grid) on the other,
+    different operands every burst -- and every result must equal, bit for bit, what the same launch returns on an idle GPU."""
+    g = torch.Generator().manual_seed(23)
+    M1, N1, K1 = 17920, 1024, 5504
+    A1 = torch.randn(M1, K1, generator=g).to(dev).half()
+    B1 = (torch.randn(K1, N1, generator=g) * 0.05).to(dev).half()
+    M2, N2, K2 = 3200, 5504, 1024
+    A2, B2 = torch.randn(M2, K2, generator=g).to(dev), (torch.randn(N2, K2, generator=g) * 0.05).to(dev)
+    A2h, A2l = hilo(A2, torch.float16)
+    B2h, B2l = hilo(B2, torch.float16)
+    A28, _, _ = torch_fp8_planes(ops, A2h, A2l, dev)
+    B28, _, _ = torch_fp8_planes(ops, B2h, B2l, dev)
+
+    def run1(out):
+        ops.gemm(A1, B1, out, M=M1, N=N1, K=K1, b_kmajor=True)
+
+    def run2(out, lo):
+        ops.gemm_mx16(A2h, A28, B2h, B28, out, lo, M=M2, N=N2, K=K2)
+    ref1 = torch.empty(M1, N1, device=dev, dtype=torch.float16)
+    ref2, ref2l = torch.empty(M2, N2, device=dev, dtype=torch.float16), torch.empty(M2, N2, device=dev, dtype=torch.float16)
+    run1(ref1); run2(ref2, ref2l)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs1 = [torch.empty_like(ref1) for _ in range(6)]
+    outs2 = [(torch.empty_like(ref2), torch.empty_like(ref2l)) for _ in range(6)]
+    bad = 0
+    for rep in range(8):
+        for o in outs1:
+            o.fill_(float("nan"))
+        for o, l in outs2:
+            o.fill_(float("nan")); l.fill_(float("nan"))
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s1):
+            for o in outs1:
+                run1(o)
+        with torch.cuda.stream(s2):
+            for o, l in outs2:
+                run2(o, l)
+        torch.cuda.synchronize()
+        bad += sum(int(not torch.equal(o, ref1)) for o in outs1)
+        bad += sum(int(not (torch.equal(o, ref2) and torch.equal(l, ref2l))) for o, l in outs2)
+    report("gemm_tail_two_streams", bad_launches=bad, launches=8 * 12)
+    assert bad == 0, bad
