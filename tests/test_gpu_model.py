@@ -1426,7 +1426,7 @@ def test_benchmarked_batch_forward_vs_oracle(dev, precision):
     assert e_loss < tol["loss"]
 
 
-@pytest.mark.parametrize("precision", ["fp16ff"])            # the headline mode (its backward is fp16's, reading the hi planes of the forward)
+@pytest.mark.parametrize("precision", ["fp16ff", "bf16"])    # the headline mode (its backward is fp16's, reading the hi planes of the forward) and the dtype BASELINE config 2 names
 def test_full_size_gradients_of_every_parameter_vs_oracle(dev, precision):
     """Every parameter tensor of the full-size coarse-small model (the B = 2 test checks 15 of them): B = 1,
     N = 1116, forgetful mask injected, all 82 non-zero gradients against the oracle's autograd.  Bars: TOL's per-tensor bar; the rel-pos MLP's
@@ -1472,4 +1472,5 @@ def test_full_size_gradients_of_every_parameter_vs_oracle(dev, precision):
     assert len(errs) + len(zero) == len(pnames) and len(errs) >= 80          # coarse-small: 84 tensors, 2 of them zero-weight heads
     # bar: ~2-3 x the worst values measured at B = 1 in fp16ff (rel-pos MLP weights 4.8e-3 / 4.6e-3, profiles/r05g_model_report.json; in plain fp16 the
     # head logit_weights.2 led with 1.48e-2 -- its forward now runs on planes)
-    assert worst[0][1] < 1.5e-2 and worst[1][1] < TOL[precision]["grad"], worst
+    # bf16 (8 significand bits instead of 11: 8 x the 16-bit bars; the 15-tensor check at B = 2 measured <= 7.2e-2 per tensor)
+    assert worst[0][1] < (1.5e-2 if precision == "fp16ff" else 1.5e-1) and worst[1][1] < TOL[precision]["grad"], worst
