@@ -240,10 +240,10 @@ class TrainLeg:
 
 def gemm_source_sha16():
     """Identity of the GEMM kernels a committed traffic measurement belongs to: the first 16 hex digits of sha256 over csrc/gemm.hip +
-    csrc/common.h (tools/pmc_gemm_traffic.sh records it; roofline.traffic is only attached while it matches the tree)."""
+    common.h + gemm_common.h + gemm_mx.hip (tools/pmc_gemm_traffic.sh records it; roofline.traffic is only attached while it matches the tree)."""
     import hashlib
     m = hashlib.sha256()
-    for f in ("gemm.hip", "common.h"):
+    for f in ("gemm.hip", "common.h", "gemm_common.h", "gemm_mx.hip"):
         with open(os.path.join(ROOT, "open_musiclm_amd", "csrc", f), "rb") as fh:
             m.update(fh.read())
     return m.hexdigest()[:16]

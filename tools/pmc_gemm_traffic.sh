@@ -36,7 +36,7 @@ for (k, grid), d in sorted(agg.items(), key=lambda kv: -sum(kv[1].get("dur_FETCH
 out = {"unit": "bytes per optimizer step, all GEMM launches", "fetch_bytes": round(tot_f / steps), "write_bytes": round(tot_w / steps),
        "steps_in_trace": steps, "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (KB); FETCH x2 (gfx950 counts 128-B requests at 64 B), WRITE as reported",
        "command": "tools/pmc_gemm_traffic.sh", "precision": __import__("os").environ.get("OMLM_BENCH_PRECISION", "fp16ff"),
-       "gemm_source_sha16": __import__("hashlib").sha256(open("open_musiclm_amd/csrc/gemm.hip", "rb").read() + open("open_musiclm_amd/csrc/common.h", "rb").read()).hexdigest()[:16]}
+       "gemm_source_sha16": __import__("hashlib").sha256(b"".join(open("open_musiclm_amd/csrc/" + f, "rb").read() for f in ("gemm.hip", "common.h", "gemm_common.h", "gemm_mx.hip"))).hexdigest()[:16]}
 open("gpurun_out/gemm_traffic.json", "w").write(json.dumps(out))
 open("gpurun_out/gemm_traffic.md", "w").write("# HBM-side traffic of the GEMM launches of a training step\n\n" + "\n".join(lines) + f"\n\nper step: fetch {tot_f / steps / 1e9:.2f} GB (x2-corrected), write {tot_w / steps / 1e9:.2f} GB over {steps:.0f} traced steps\n")
 print("\n".join(lines)); print(json.dumps(out))
