@@ -8,7 +8,7 @@ from open_musiclm_amd import open_musiclm as M, decode
 
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-model = M.create_coarse_transformer(dim=1024, depth=6, heads=8, num_coarse_quantizers=3, precision="bf16").to(dev)
+model = M.create_coarse_transformer(dim=1024, depth=6, heads=8, num_coarse_quantizers=3, precision=os.environ.get("PREC", "fp16ff")).to(dev)
 stage = M.CoarseStage(coarse_transformer=model).eval()
 g = torch.Generator().manual_seed(99)
 B = int(os.environ.get("B", 1))
