@@ -78,13 +78,34 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
     const bool skip = gnorm_sq && !(gnorm_sq[0] < 3.0e38f);
     const float gs = gscale * clip;
     const float step = lr / bc1;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        if (skip) { if (zero_grad) g[i] = 0.f; continue; }
-        float pi = p[i], gi = g[i] * gs;
+    // one element: the update of AdamW / Adam exactly as written above (the vector path below runs the same expression per lane element)
+    auto upd = [&](float& pi, float gi, float& mi, float& vi) {
+        gi *= gs;
         if (decoupled) pi *= (1.0f - lr * wd); else gi += wd * pi;
-        const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
-        const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+        mi = beta1 * mi + (1.0f - beta1) * gi;
+        vi = beta2 * vi + (1.0f - beta2) * gi * gi;
         pi -= step * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    };
+    // 16-byte pieces (round 6: dword loads / stores moved 34 B per parameter at 4.9 TB/s; four parameters per lane per trip), scalar tail
+    const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0) && (!p16 || ((uintptr_t)p16 & 7) == 0);
+    const long long n4 = vec ? n >> 2 : 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        if (skip) { if (zero_grad) ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+        float4 p4 = ((const float4*)p)[i], m4 = ((const float4*)m)[i], v4 = ((const float4*)v)[i];
+        const float4 g4 = ((const float4*)g)[i];
+        upd(p4.x, g4.x, m4.x, v4.x); upd(p4.y, g4.y, m4.y, v4.y); upd(p4.z, g4.z, m4.z, v4.z); upd(p4.w, g4.w, m4.w, v4.w);
+        ((float4*)p)[i] = p4; ((float4*)m)[i] = m4; ((float4*)v)[i] = v4;
+        if (p16) {
+            union { T16 h[4]; uint2 u; } pk;
+            pk.h[0] = (T16)p4.x; pk.h[1] = (T16)p4.y; pk.h[2] = (T16)p4.z; pk.h[3] = (T16)p4.w;
+            *(uint2*)(p16 + 4 * i) = pk.u;
+        }
+        if (zero_grad) ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (long long i = 4 * n4 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        if (skip) { if (zero_grad) g[i] = 0.f; continue; }
+        float pi = p[i], mi = m[i], vi = v[i];
+        upd(pi, g[i], mi, vi);
         p[i] = pi; m[i] = mi; v[i] = vi;
         if (p16) p16[i] = (T16)pi;
         if (zero_grad) g[i] = 0.f;
@@ -99,7 +120,7 @@ extern "C" int omlm_adamw_clip_step(float* p, float* g, float* m, float* v, void
     OMLM_CHECK_ARG(p && g && m && v && step >= 1, "adamw arguments");
     OMLM_CHECK_ARG(!p16 || p16_dtype == OMLM_DT_BF16 || p16_dtype == OMLM_DT_F16, "p16_dtype: 1 = bf16, 2 = fp16");
     const float bc1 = (float)(1.0 - pow((double)beta1, (double)step)), bc2 = (float)sqrt(1.0 - pow((double)beta2, (double)step));
-    long long blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
+    long long blocks = (n / 4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
     if (p16 && p16_dtype == OMLM_DT_F16)
         hipLaunchKernelGGL(adamw_kernel<f16_t>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), p, g, m, v, (f16_t*)p16, n,
                            lr, beta1, beta2, eps, wd, bc1, bc2, gscale, gnorm_sq, max_norm, decoupled, zero_grad, ls_state);
