@@ -218,7 +218,15 @@ class TrainLeg:
                 for key, (n, ms, fl) in rows:
                     fh.write(f"| {key} | {n / 2:g} | {ms / n * 1e3:.1f} | {fl / (ms * 1e-3) / 1e12:.0f} | {ms / 2:.3f} |\n")
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
-        return {"bound": "mfma", "kernel": "gemm kernels (all layouts, every GEMM launch of a train step)",
+        # the launch family that takes the most time of a step (fp16ff: FF-in forward on omlm_gemm_mx16), per launch
+        fam = {}
+        for r in rec:
+            t = fam.setdefault(r[3], [0, 0.0, 0.0, r[4] if len(r) > 4 else mult]); t[0] += 1; t[1] += r[0].elapsed_time(r[1]); t[2] += r[2]
+        dk, (dn, dms, dfl, dmult) = max(fam.items(), key=lambda kv: kv[1][1])
+        dominant = {"launch": str(dk), "launches_per_step": dn / 2, "us_per_launch": round(dms / dn * 1e3, 1), "flops_per_launch": dfl / dn,
+                    "achieved": round(dfl / (dms * 1e-3) / 1e12, 1), "unit": "TFLOP/s", "frac": round(dfl / (dms * 1e-3) / 1e12 / PEAK_TFLOPS, 4),
+                    "issue_frac": round(dmult * dfl / (dms * 1e-3) / 1e12 / PEAK_TFLOPS, 4), "ms_per_step": round(dms / 2, 3)}
+        return {"bound": "mfma", "kernel": "gemm kernels (all layouts, every GEMM launch of a train step)", "dominant_launch": dominant,
                 "achieved": round(ach, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS, 4),
                 "traffic": traffic, "launches": len(rec) // 2, "gemm_ms_per_step": round(tot_ms / 2, 3),
                 "mfma_issue_frac": round(issued_fl / (tot_ms * 1e-3) / 1e12 / PEAK_TFLOPS, 4),
