@@ -700,6 +700,9 @@ __global__ __launch_bounds__(256) void ffmid2_bwd_kernel(const T* __restrict__ d
 // main pass of the previous row.  d(gamma) = sum_rows dropout^T(dh2) gh joins d(conv taps) in registers: one partial row per workgroup
 // of each.  Same element arithmetic and the same summation order inside a row as prepass + main (wave sums, then the waves in order).
 // ---------------------------------------------------------------------------------------------------------------------
+#ifndef FF3_DPP
+#define FF3_DPP 1
+#endif
 template <typename T> struct Bwd3Row { Ch4<T> dy, gh, xv, xg; unsigned bits; float a; };
 // "defined here" for the optimiser: what is derived from the registers after this point is not hoisted above it
 __device__ __forceinline__ void opaque(Ch4<h16_t>& c) { asm volatile("" : "+v"(c.r[0]), "+v"(c.r[1])); }
@@ -713,7 +716,7 @@ __global__ __launch_bounds__(NT) void ffmid3_bwd_kernel(const T* __restrict__ dh
                                                         float* __restrict__ part_dconv, float* __restrict__ part_dgamma,
                                                         int nseq, int F, int Fp, int RB, int strips, int total_strips, float p) {
     constexpr int NW = NT / 64;
-    __shared__ float red[2][NW][2];
+    __shared__ __attribute__((aligned(16))) float red[2][NW][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = threadIdx.x * 4;
     const bool act = col < Fp;
@@ -772,7 +775,13 @@ __global__ __launch_bounds__(NT) void ffmid3_bwd_kernel(const T* __restrict__ dh
             s1 += gy;
             s2 = fma2(gy, R.gh.get(i), s2);
         }
+#if FF3_DPP
+        // (every lane of the NT-thread workgroup exists -- inactive channels carry zeros --, so the VALU form is safe here: four DPP adds + four
+        // readlanes per sum instead of six dependent LDS-crossbar round trips on the row's critical path)
+        const float t1 = wave_sum_dpp(s1[0] + s1[1]), t2 = wave_sum_dpp(s2[0] + s2[1]);
+#else
         const float t1 = wave_sum(s1[0] + s1[1]), t2 = wave_sum(s2[0] + s2[1]);
+#endif
         if (lane == 0) { red[buf][wave][0] = t1; red[buf][wave][1] = t2; }
     };
 
@@ -803,6 +812,8 @@ __global__ __launch_bounds__(NT) void ffmid3_bwd_kernel(const T* __restrict__ dh
         publish_sums(cur, t0 & 1);
         __syncthreads();
         const int tend = t1 + 2;
+        // (measured and dropped, round 6: the loop unrolled by three with rotating register roles instead of `cur = nx1; nx1 = nx2` -- 20 fewer
+        // moves per row, 162 registers, no spills, and 375 us against 324: hipcc's schedule of the tripled body loses more than the moves cost)
 #pragma unroll 1
         for (int t = t0; t < tend; ++t) {
             nx2 = nx1;
@@ -811,9 +822,10 @@ __global__ __launch_bounds__(NT) void ffmid3_bwd_kernel(const T* __restrict__ dh
             if (t + 1 < tlast) publish_sums(nx1, (t + 1) & 1);   // next row's sums: visible behind this iteration's barrier
             v2 duv[2], dug[2];
             if (t < nseq) {
-                float S1 = 0.f, S2 = 0.f;
+                v2 S12 = splat2(0.f);                                    // (S1, S2) as a register pair: one packed add per wave's partials, same order
 #pragma unroll
-                for (int w = 0; w < NW; ++w) { S1 += red[t & 1][w][0]; S2 += red[t & 1][w][1]; }
+                for (int w = 0; w < NW; ++w) S12 += *(const v2*)&red[t & 1][w][0];
+                const float S1 = S12[0], S2 = S12[1];
                 const float rs = cur.a * invF;
                 const float bsum = rs * S1, csum = rs * S2;
                 const float own = t < t1 ? 1.f : 0.f;
