@@ -657,19 +657,31 @@ __global__ __launch_bounds__(256) void relpos_mlp_bwd_params_kernel(relpos_mlp_p
         // workgroups).  Rows staged 16 at a time: thread (h = t >> 4, 4 columns).
         const int k0 = b * 64, h = t >> 4, kx = t & 15;
         float acc[4] = {0.f, 0.f, 0.f, 0.f}, bacc = 0.f;
-        for (int r0 = 0; r0 < a.n; r0 += 16) {
-            {
-                const int rr = t >> 4, hh = t & 15, row = r0 + rr;            // 16 rows x 16 (padded) heads
-                sd[rr * SP + hh] = (row < a.n && hh < a.H) ? a.dtable[(size_t)row * a.ldb + hh] : 0.f;
-            }
+        // rows staged 64 at a time, the next trip requested under this one's arithmetic (round 6: 16 rows per trip were 70 trips of two barriers
+        // + one exposed L2 round trip each -- this branch, 8 workgroups, was the launch's long pole).  Same row order per element: same bits.
+        float dq[4], zq[16];
+        auto request3 = [&](int r0) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int idx = t + 256 * i, rr = idx >> 6, cc = idx & 63, row = r0 + rr;
-                sz[rr * SP + cc] = row < a.n ? a.z2[(size_t)row * Hd + k0 + cc] : 0.f;
+                const int idx = t + 256 * i, rr = idx >> 4, hh = idx & 15, row = r0 + rr;      // 64 rows x 16 (padded) heads
+                dq[i] = (row < a.n && hh < a.H) ? a.dtable[(size_t)row * a.ldb + hh] : 0.f;
             }
-            __syncthreads();
 #pragma unroll
-            for (int rr = 0; rr < 16; ++rr) {
+            for (int i = 0; i < 16; ++i) {
+                const int idx = t + 256 * i, rr = idx >> 6, cc = idx & 63, row = r0 + rr;
+                zq[i] = row < a.n ? a.z2[(size_t)row * Hd + k0 + cc] : 0.f;
+            }
+        };
+        request3(0);
+        for (int r0 = 0; r0 < a.n; r0 += RC) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const int idx = t + 256 * i; sd[(idx >> 4) * SP + (idx & 15)] = dq[i]; }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { const int idx = t + 256 * i; sz[(idx >> 6) * SP + (idx & 63)] = zq[i]; }
+            __syncthreads();
+            if (r0 + RC < a.n) request3(r0 + RC);
+#pragma unroll 16
+            for (int rr = 0; rr < RC; ++rr) {
                 const float dv = sd[rr * SP + h];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[j] = fmaf(dv, sz[rr * SP + kx + 16 * j], acc[j]);
