@@ -206,6 +206,30 @@ __global__ __launch_bounds__(256) void cast_pad_group_kernel(CastGroupArgs ga) {
             const int r = (int)(e / q.C), c = (int)(e - (long long)r * q.C);
             store_from_float(dst + (size_t)c * q.ld_dst + r, val(q.src[(size_t)r * q.ld_src + c]));
         }
+    } else if (sizeof(T) == 2 && (q.ld_dst & 7) == 0 && (q.ld_src & 3) == 0 && (((uintptr_t)q.src | (uintptr_t)q.dst) & 15) == 0) {
+        // 16-bit outputs in 16-byte pieces: eight elements per thread per trip (round 6: the element-wise form below moved the ~400 MB of a
+        // coarse-small re-pack at 2.7 TB/s)
+        // the block's rows blk, blk + nblk, ... flattened with their 8-element pieces: every thread has a piece on every trip (a 1024-wide row alone
+        // is half a block)
+        const int P = q.ld_dst >> 3, nrows = (q.R - blk + nblk - 1) / nblk;
+        for (int idx = threadIdx.x; idx < nrows * P; idx += 256) {
+            const int ri = idx / P, c = (idx - ri * P) * 8, r = blk + ri * nblk;
+            const float* sr = q.src + (size_t)r * q.ld_src;
+            {
+                float v[8];
+                if (c + 8 <= q.C) {
+                    const float4 a = *(const float4*)(sr + c), b = *(const float4*)(sr + c + 4);
+                    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = c + e < q.C ? sr[c + e] : 0.f;
+                }
+                union { T h[8]; uint4 u; } pk;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pk.h[e] = (T)(c + e < q.C ? val(v[e]) : 0.f);
+                *(uint4*)(dst + (size_t)r * q.ld_dst + c) = pk.u;
+            }
+        }
     } else {
         for (int r = blk; r < q.R; r += nblk)
             for (int c = threadIdx.x; c < q.ld_dst; c += 256)
@@ -256,6 +280,17 @@ __global__ __launch_bounds__(256) void quant_rows_mx_kernel(QuantGroupArgs ga) {
     for (int r = blk; r < q.R; r += nblk) {
         const float* sr = q.src + (size_t)r * q.ld_src;
         float m = 0.f;
+        const bool vec4 = ((q.ld_src & 3) == 0) && (((uintptr_t)q.src & 15) == 0);
+        if (vec4) {                                        // 16-byte loads (round 6; the element-wise passes ran at a third of the HBM rate)
+            for (int c = threadIdx.x * 4; c < q.C; c += 1024) {
+                if (c + 4 <= q.C) {
+                    const float4 a = *(const float4*)(sr + c);
+                    m = fmaxf(fmaxf(m, fabsf((float)(f16_t)a.x)), fmaxf(fabsf((float)(f16_t)a.y), fmaxf(fabsf((float)(f16_t)a.z), fabsf((float)(f16_t)a.w))));
+                } else {
+                    for (int x = 0; c + x < q.C; ++x) m = fmaxf(m, fabsf((float)(f16_t)sr[c + x]));
+                }
+            }
+        } else
         for (int c = threadIdx.x; c < q.C; c += 256) m = fmaxf(m, fabsf((float)(f16_t)sr[c]));
         m = wave_max(m);
         __syncthreads();                                   // (red is re-used row after row)
@@ -268,8 +303,13 @@ __global__ __launch_bounds__(256) void quant_rows_mx_kernel(QuantGroupArgs ga) {
         unsigned char* d8 = q.dst8 + (size_t)r * q.ld8;
         for (int c = threadIdx.x * 4; c < q.C; c += 1024) {
             float w[4], h[4];
+            if (vec4 && c + 4 <= q.C) { const float4 a = *(const float4*)(sr + c); w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; }
+            else {
 #pragma unroll
-            for (int x = 0; x < 4; ++x) { w[x] = c + x < q.C ? sr[c + x] : 0.f; h[x] = (float)(f16_t)w[x]; }
+                for (int x = 0; x < 4; ++x) w[x] = c + x < q.C ? sr[c + x] : 0.f;
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x) h[x] = (float)(f16_t)w[x];
             *(unsigned*)(d8 + c) = pack4_fp8(h[0] * sh, h[1] * sh, h[2] * sh, h[3] * sh);
             *(unsigned*)(d8 + q.lo_stride + c) = pack4_fp8((w[0] - h[0]) * sl, (w[1] - h[1]) * sl, (w[2] - h[2]) * sl, (w[3] - h[3]) * sl);
         }
