@@ -117,6 +117,12 @@ long long omlm_attn_bias_table_floats(int N, int H);
  * table's range < 28 (wider: the flag in the table stays 0 and the forward runs its online-softmax kernel). */
 int omlm_attn_bias_prepare(const float* bias, float* biasT, int N, int H, int bias_ld, const float* q_scale,
                            const float* k_scale, float qk_bound, float scale, int p_max_log2, void* stream);
+/* The tables of `layers` attention layers over ONE rel-pos table in ONE launch (transformer.py:402-405 computes the bias once per forward and
+ * hands it to every layer; here each layer's copy carries that layer's reference point): biasT[l] from q_scale[l] / k_scale[l].
+ * biasT / q_scale / k_scale: HOST arrays (length `layers`) of DEVICE pointers; q_scale and k_scale both given or both NULL (then qk_bound). */
+int omlm_attn_bias_prepare_group(const float* bias, float* const* biasT, int layers, int N, int H, int bias_ld,
+                                 const float* const* q_scale, const float* const* k_scale, float qk_bound, float scale,
+                                 int p_max_log2, void* stream);
 /* dbias_ws (optional, omlm_mqa_attn_bwd_workspace_bytes(B, N, H) bytes, contents irrelevant on entry and exit): the dQ kernel leaves
  * each wave's d(bias) bins there with plain stores and a small reduction adds them into dbias; without it every wave adds its bins into
  * dbias with device-scope atomics (measured 290 us per layer slower at B = 8, N = 1817, H = 16). */

@@ -73,12 +73,18 @@ __device__ __forceinline__ h16x8 a2_pack(const f32x16& p, int s) {
 // flag is 0.  The decision is the SAME for every head (it looks at the widest head's range): the forward picks its kernel by it.
 //   p_max_log2: the largest probability numerator is 2^p_max_log2.  0 for bf16 / fp32 operands (numerators <= 1, fp32's exponent range
 //   below); 15 for IEEE half, whose normal range is 2^-14 .. 2^15.99: numerators in (2^-13, 2^15] while 2 c qk_max + range < 28.
-__global__ void attn2_bias_prep_kernel(const float* __restrict__ bias, float* __restrict__ biasT, int N, int H, int ld, int ldT,
-                                       const float* __restrict__ q_scale, const float* __restrict__ k_scale, float qk_bound, float c,
-                                       int p_max_log2) {
+// (round 6) grid.y = layers: every layer's table in ONE launch -- the tables of a forward differ only through their layer's learned scales, and
+// six launches of 8 workgroups were 6 x 14 us of latency per step (omlm_attn_bias_prepare_group; the single-layer entry passes one layer).
+#define A2_PREP_MAX 32
+struct A2PrepGroup { float* out[A2_PREP_MAX]; const float* qs[A2_PREP_MAX]; const float* ks[A2_PREP_MAX]; };
+__global__ void attn2_bias_prep_kernel(const float* __restrict__ bias, A2PrepGroup grp, int N, int H, int ld, int ldT,
+                                       float qk_bound, float c, int p_max_log2) {
     __shared__ float red[4][2][8];
     __shared__ float redq[4];
     const int h = blockIdx.x, t = threadIdx.x;
+    float* biasT = grp.out[blockIdx.y];
+    const float* q_scale = grp.qs[blockIdx.y];
+    const float* k_scale = grp.ks[blockIdx.y];
     float* row = biasT + (size_t)h * ldT;
     const bool has = bias && h < H;
     // every head's extremes (8 heads per pass): the widest range decides for all, this head's maximum sets its reference point
@@ -794,9 +800,38 @@ extern "C" int omlm_attn_bias_prepare(const float* bias, float* biasT, int N, in
     OMLM_CHECK_ARG(biasT && N > 0 && H > 0, "null table / sizes");
     OMLM_CHECK_ARG(p_max_log2 == 0 || p_max_log2 == 15, "p_max_log2: 0 (bf16 / fp32 operands) or 15 (half operands)");
     const int ldT = (A2_PAD + N + 2 * A2_BWIN + 3) / 4 * 4, H8 = (H + 7) / 8 * 8;
-    hipLaunchKernelGGL(attn2_bias_prep_kernel, dim3(H8), dim3(256), 0, as_stream(stream), bias, biasT, N, H, bias_ld, ldT, q_scale, k_scale,
+    A2PrepGroup grp;
+    memset(&grp, 0, sizeof(grp));
+    grp.out[0] = biasT; grp.qs[0] = q_scale; grp.ks[0] = k_scale;
+    hipLaunchKernelGGL(attn2_bias_prep_kernel, dim3(H8, 1), dim3(256), 0, as_stream(stream), bias, grp, N, H, bias_ld, ldT,
                        qk_bound, scale * A2_LOG2E, p_max_log2);
     return omlm_post_launch("omlm_attn_bias_prepare");
+}
+// The tables of `layers` attention layers over ONE rel-pos table in one launch: biasT[l] (omlm_attn_bias_table_floats(N, H) floats each) from
+// the layer's learned scales q_scale[l] / k_scale[l] (64 floats each; all given, or all NULL with qk_bound as in omlm_attn_bias_prepare).
+// biasT / q_scale / k_scale: HOST arrays of device pointers.
+extern "C" int omlm_attn_bias_prepare_group(const float* bias, float* const* biasT, int layers, int N, int H, int bias_ld,
+                                            const float* const* q_scale, const float* const* k_scale, float qk_bound, float scale,
+                                            int p_max_log2, void* stream) {
+    if (layers <= 0) return OMLM_OK;
+    OMLM_CHECK_ARG(biasT && N > 0 && H > 0, "null table / sizes");
+    OMLM_CHECK_ARG(p_max_log2 == 0 || p_max_log2 == 15, "p_max_log2: 0 (bf16 / fp32 operands) or 15 (half operands)");
+    OMLM_CHECK_ARG((q_scale == nullptr) == (k_scale == nullptr), "q_scale and k_scale: both or neither");
+    const int ldT = (A2_PAD + N + 2 * A2_BWIN + 3) / 4 * 4, H8 = (H + 7) / 8 * 8;
+    for (int base = 0; base < layers; base += A2_PREP_MAX) {
+        const int n = layers - base < A2_PREP_MAX ? layers - base : A2_PREP_MAX;
+        A2PrepGroup grp;
+        memset(&grp, 0, sizeof(grp));
+        for (int l = 0; l < n; ++l) {
+            OMLM_CHECK_ARG(biasT[base + l], "null table");
+            grp.out[l] = biasT[base + l];
+            grp.qs[l] = q_scale ? q_scale[base + l] : nullptr;
+            grp.ks[l] = k_scale ? k_scale[base + l] : nullptr;
+        }
+        hipLaunchKernelGGL(attn2_bias_prep_kernel, dim3(H8, n), dim3(256), 0, as_stream(stream), bias, grp, N, H, bias_ld, ldT,
+                           qk_bound, scale * A2_LOG2E, p_max_log2);
+    }
+    return omlm_post_launch("omlm_attn_bias_prepare_group");
 }
 
 // d(bias) partial rows -> the [N, bias_ld] table.  The dQ kernels leave one fp32 row of nqt*32 bins per (sample, head, query tile) in

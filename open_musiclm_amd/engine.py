@@ -506,6 +506,7 @@ def trunk_forward(tr, pw: PreparedWeights, x: torch.Tensor, keymask: Optional[to
     else:
         table, rp_saved = relpos_forward(tr, N, save)
     saved_layers: List[LayerSaved] = []
+    abiases = None
     salt, seeds = (None, None)
     if training and any(float(ff.dropout_p) > 0 for _, _, ff in tr.layers):
         salt, seeds = dropout_salt(tr, dev)
@@ -540,8 +541,12 @@ def trunk_forward(tr, pw: PreparedWeights, x: torch.Tensor, keymask: Optional[to
             side = None
         # the layer's bias table in the kernels' layout, with the fixed softmax reference point its scales allow (fp16: 15 octaves below the
         # bound, so that the probability numerators use half's normal range -- at the bound itself typical ones sat around 2^-12)
-        abias = ops.AttnBias(table, N, H, dev, q_scale=attn.q_scale.detach(), k_scale=attn.k_scale.detach(), scale=ATTN_SCALE,
-                             half=T == torch.float16)
+        # (round 6: the tables of all layers leave in ONE launch in front of the first attention kernel -- they differ only through the layers'
+        # learned scales, and a launch per layer was six 14-us latency chains per step)
+        if abiases is None:
+            abiases = ops.AttnBias.group(table, N, H, dev, [a_.q_scale.detach() for a_, _, _ in tr.layers],
+                                         [a_.k_scale.detach() for a_, _, _ in tr.layers], scale=ATTN_SCALE, half=T == torch.float16)
+        abias = abiases[li]
         ops.attn_fwd(q, k, v, abias, keymask, o, lse, B, N, H, ATTN_SCALE)
         x1 = torch.empty(M, D, device=dev)
         ops.gemm(o, w["Wo"], x1, M=M, N=D, K=H * DIM_HEAD, Cin=x)

@@ -47,6 +47,7 @@ SIGNATURES = {
     "omlm_qk_norm_bwd2": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "omlm_attn_bias_table_floats": [i32, i32],
     "omlm_attn_bias_prepare": [vp, vp, i32, i32, i32, vp, vp, f32, f32, i32, vp],
+    "omlm_attn_bias_prepare_group": [vp, vp, i32, i32, i32, i32, vp, vp, f32, f32, i32, vp],
     "omlm_mqa_attn_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, vp],
     "omlm_mqa_attn_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, vp],
     "omlm_mqa_attn_bwd_workspace_bytes": [i32, i32, i32],

@@ -404,12 +404,32 @@ class AttnBias:
     span half's normal range instead of sitting at its bottom (the kernels fall back to the online softmax if the scales grow too wide)."""
 
     def __init__(self, table: Optional[torch.Tensor], N: int, H: int, device=None, q_scale=None, k_scale=None,
-                 qk_bound: float = 0.0, scale: float = 8.0, half: bool = False):
+                 qk_bound: float = 0.0, scale: float = 8.0, half: bool = False, _tableT: Optional[torch.Tensor] = None):
         self.table, self.N, self.H = table, N, H
         dev = table.device if table is not None else device
+        if _tableT is not None:                         # (AttnBias.group: the table was written by the grouped launch)
+            self.tableT = _tableT
+            return
         self.tableT = torch.empty(int(hip.lib().omlm_attn_bias_table_floats(N, H)), device=dev)
         call("omlm_attn_bias_prepare", ptr(table), ptr(self.tableT), N, H, table.shape[-1] if table is not None else 0,
              ptr(q_scale), ptr(k_scale), float(qk_bound), float(scale), 15 if half else 0, stream_ptr())
+
+    @staticmethod
+    def group(table: Optional[torch.Tensor], N: int, H: int, device, q_scales, k_scales, scale: float = 8.0, half: bool = False):
+        """One AttnBias per layer (q_scales[l], k_scales[l]) over the same rel-pos table, written by ONE launch
+        (omlm_attn_bias_prepare_group) instead of one small launch per layer."""
+        L = len(q_scales)
+        dev = table.device if table is not None else device
+        nfl = int(hip.lib().omlm_attn_bias_table_floats(N, H))
+        buf = torch.empty(L, nfl, device=dev)
+        outs = (C.c_void_p * L)(*[buf[l].data_ptr() for l in range(L)])
+        qs = (C.c_void_p * L)(*[t.data_ptr() for t in q_scales])
+        ks = (C.c_void_p * L)(*[t.data_ptr() for t in k_scales])
+        for t in list(q_scales) + list(k_scales):
+            hip.require_gpu(t, "scale")
+        call("omlm_attn_bias_prepare_group", ptr(table), C.cast(outs, C.c_void_p), L, N, H, table.shape[-1] if table is not None else 0,
+             C.cast(qs, C.c_void_p), C.cast(ks, C.c_void_p), 0.0, float(scale), 15 if half else 0, stream_ptr())
+        return [AttnBias(table, N, H, dev, _tableT=buf[l]) for l in range(L)]
 
     def dbias_workspace(self, B: int, N: int, H: int) -> torch.Tensor:
         """Scratch for the backward's d(bias) partial rows (omlm_mqa_attn_bwd_workspace_bytes): ONE buffer per device, shared by every

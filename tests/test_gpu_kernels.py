@@ -1787,3 +1787,25 @@ def test_tail_split_gemms_on_two_streams_keep_their_own_scratch(ops, dev):
         bad += sum(int(not (torch.equal(o, ref2) and torch.equal(l, ref2l))) for o, l in outs2)
     report("gemm_tail_two_streams", bad_launches=bad, launches=8 * 12)
     assert bad == 0, bad
+
+
+@pytest.mark.parametrize("half", [False, True])
+def test_attn_bias_prepare_group_equals_per_layer_launches(ops, dev, half):
+    """omlm_attn_bias_prepare_group (round 6): the tables of all layers of a forward in one launch -- every layer's table must equal, bit for bit,
+    what omlm_attn_bias_prepare writes for that layer's scales (incl. a layer whose scales are too wide for the fixed reference point)."""
+    g = torch.Generator().manual_seed(5)
+    N, H, L = 333, 8, 5
+    table = torch.zeros(N, 8)
+    table[:, :H] = torch.randn(N, H, generator=g) * 0.7
+    table = table.to(dev)
+    qs = [(0.6 + 0.05 * torch.randn(64, generator=g)).to(dev) for _ in range(L)]      # (|q.k| <= ~0.5: inside half's exponent budget as well)
+    ks = [(0.6 + 0.05 * torch.randn(64, generator=g)).to(dev) for _ in range(L)]
+    qs[3] = qs[3] * 40.0                                       # beyond the exponent budget: flag 0, online softmax for this layer only
+    grp = ops.AttnBias.group(table, N, H, dev, qs, ks, scale=8.0, half=half)
+    flags = []
+    for l in range(L):
+        one = ops.AttnBias(table, N, H, dev, q_scale=qs[l], k_scale=ks[l], scale=8.0, half=half)
+        assert torch.equal(one.tableT, grp[l].tableT), l
+        ldT = one.tableT.numel() // 8
+        flags.append(float(one.tableT.view(8, ldT)[0, ldT - 2]))
+    assert flags[3] == 0.0 and flags[0] == 1.0, flags
