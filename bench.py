@@ -96,18 +96,32 @@ class TrainLeg:
         self.fb = GraphedForwardBackward(lambda **kw: self.stage(**kw, return_loss=True, return_logits=False)[0], loss_scale=1.0 / accum,
                                          enabled=use_graph)
         self.optim.zero_grad()                                 # adopt the flat parameter / gradient buffers before capture
+        # gradient accumulation (--accum > 1): the rel-pos MLP once per optimizer step, like SingleStageTrainer (engine.RelposStepCache)
+        self.rc = None
+        trunk = getattr(self.model, "transformer", None)
+        if (accum > 1 and os.environ.get("OMLM_RELPOS_CACHE", "1") != "0" and trunk is not None
+                and getattr(trunk, "rel_pos_bias", None) is not None and getattr(trunk, "relative_position_bias_type", "") != "t5"):
+            from open_musiclm_amd import engine
+            self.rc = engine.relpos_step_cache(trunk)
+            self.rc.enabled = True
 
         def discard():
             self.optim.mark_grads_dirty()
             self.optim.zero_grad()
+            if self.rc is not None:
+                self.rc.reset_accum()
         self.fb.prepare(dict(zip(self.keys, self.batches[0])), after_warmup=discard)
 
     def step(self, k, eager=False, exchange=True):
         self.optim.zero_grad()
+        if self.rc is not None:
+            self.rc.refresh()
         for a in range(self.accum):
             kw = dict(zip(self.keys, self.batches[(k * self.accum + a) % len(self.batches)]))
             loss = self.fb._eager(kw) if eager else self.fb(**kw)
             self.optim.mark_grads_dirty()
+        if self.rc is not None:
+            self.rc.flush()
         if exchange:
             self.dp.allreduce_sum_(self.optim.flat_grad)
         self.optim.step(max_grad_norm=0.5, grad_scale=self.dp.grad_scale())

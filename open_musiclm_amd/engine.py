@@ -380,6 +380,60 @@ def prepared_weights(model, precision: str) -> PreparedWeights:
 # ------------------------------------------------------------------------------------------------------
 # relative position bias  ->  table [N, ldb] (row = i - j >= 0, column = head)
 # ------------------------------------------------------------------------------------------------------
+class RelposStepCache:
+    """The rel-pos MLP once per OPTIMIZER step instead of once per micro-batch (round 6).  The reference recomputes
+    the bias in every forward (transformer.py:402-405), but between two optimizer steps its weights do not change: the table of micro-batch
+    2 .. k is the table of micro-batch 1, and the MLP's backward is linear in d(table), so the k micro-batches may add their d(table) into
+    ONE buffer and the MLP runs backward once, on the sum.  Opt-in (SingleStageTrainer enables it when grad_accum_every > 1): the owner
+    calls refresh() before the micro-batches of a step and flush() after the last one, before the gradient exchange.  The first training
+    forward computes the table in line and is adopted (it fixes N); from then on the captured micro-step contains neither the MLP's forward
+    nor its backward -- it reads `table` and accumulates into `dtable`, two persistent buffers.  Gradients equal the per-micro-batch form up
+    to the order of fp32 additions."""
+
+    def __init__(self, tr):
+        self.tr, self.enabled, self.valid = tr, False, False
+        self.n, self.table, self.dtable, self.saved = None, None, None, None
+
+    def __getstate__(self):                          # (a pickled / deep-copied model starts without the buffers)
+        return dict(tr=self.tr, enabled=False, valid=False, n=None, table=None, dtable=None, saved=None)
+
+    def usable(self, n: int) -> bool:
+        return self.enabled and self.valid and self.n == n
+
+    def adopt(self, n: int, table: torch.Tensor, saved):
+        self.n, self.table, self.saved = n, table, saved
+        self.dtable = torch.zeros_like(table)
+        self.valid = True
+
+    def reset_accum(self):
+        if self.dtable is not None:
+            self.dtable.zero_()
+
+    def refresh(self):
+        """Start of an optimizer step: the table of the CURRENT weights into the persistent buffer, d(table) cleared."""
+        if not self.enabled or self.n is None:
+            return
+        table, saved = relpos_forward(self.tr, self.n, True)
+        self.table.copy_(table)
+        self.saved = saved
+        self.dtable.zero_()
+        self.valid = True
+
+    def flush(self):
+        """After the last micro-batch: the MLP's backward on the accumulated d(table); the cache is stale from here on (the optimizer moves
+        the weights), so forwards in between -- validation -- compute the table in line."""
+        if self.enabled and self.valid and self.n is not None:
+            relpos_backward(self.tr, self.n, self.saved, self.dtable)
+        self.valid = False
+
+
+def relpos_step_cache(tr) -> "RelposStepCache":
+    c = tr.__dict__.get("_omlm_relpos_cache")
+    if c is None:
+        c = tr.__dict__["_omlm_relpos_cache"] = RelposStepCache(tr)
+    return c
+
+
 def relpos_forward(tr, n: int, save: bool):
     rp = tr.rel_pos_bias
     if rp is None:
@@ -504,7 +558,17 @@ def trunk_forward(tr, pw: PreparedWeights, x: torch.Tensor, keymask: Optional[to
         with torch.cuda.stream(side):
             table, rp_saved = relpos_forward(tr, N, save)       # joined in front of the first attention kernel
     else:
-        table, rp_saved = relpos_forward(tr, N, save)
+        rc = tr.__dict__.get("_omlm_relpos_cache")
+        if rc is not None and save and training and rc.usable(N):
+            table, rp_saved = rc.table, ("cached", rc)            # (RelposStepCache: computed once for this optimizer step)
+        else:
+            table, rp_saved = relpos_forward(tr, N, save)
+            # the FIRST training forward is adopted, once: a captured micro-step holds the addresses of the cache's buffers, so they are
+            # never replaced (a stale cache -- validation between two optimizer steps -- computes in line and leaves the cache alone)
+            if (rc is not None and rc.enabled and rc.n is None and save and training and rp_saved is not None and rp_saved[0] != "t5"
+                    and not torch.cuda.is_current_stream_capturing()):
+                rc.adopt(N, table, rp_saved)
+                rp_saved = ("cached", rc)
     saved_layers: List[LayerSaved] = []
     abiases = None
     salt, seeds = (None, None)
@@ -636,7 +700,8 @@ def trunk_backward(tr, pw: PreparedWeights, saved, dy: torch.Tensor, B: int, N: 
     M, D = dy.shape
     H = tr.heads
     table, keymask = saved["table"], saved["keymask"]
-    dtable = torch.zeros_like(table) if table is not None else None
+    rp_cached = saved["rp"] is not None and saved["rp"][0] == "cached"
+    dtable = (saved["rp"][1].dtable if rp_cached else torch.zeros_like(table)) if table is not None else None
     nl = len(saved["layers"])
     rp_async = (_RELPOS_ASYNC and nl > 0 and dtable is not None and saved["rp"] is not None and saved["rp"][0] == "mlp")
     rp_side = None
@@ -750,7 +815,7 @@ def trunk_backward(tr, pw: PreparedWeights, saved, dy: torch.Tensor, B: int, N: 
         wg.flush()
     if rp_side is not None:
         torch.cuda.current_stream(dev).wait_stream(rp_side)
-    elif dtable is not None and saved["rp"] is not None:
+    elif dtable is not None and saved["rp"] is not None and not rp_cached:      # (cached: RelposStepCache.flush runs it once per optimizer step)
         relpos_backward(tr, N, saved["rp"], dtable)
     return dres
 

@@ -303,6 +303,9 @@ class SingleStageTrainer(nn.Module):
                 def discard():                          # warm-up steps really ran: throw their gradients away
                     self.optim.mark_grads_dirty()
                     self.optim.zero_grad()
+                    rc = self._relpos_cache()
+                    if rc is not None:
+                        rc.reset_accum()
                 self._graphed.prepare(data_kwargs, after_warmup=discard)
                 if self._graphed.capture_error:
                     self.print(f'HIP graph capture unavailable ({self._graphed.capture_error}); launching eagerly')
@@ -313,6 +316,19 @@ class SingleStageTrainer(nn.Module):
         (loss / self.grad_accum_every).backward()
         self.optim.mark_grads_dirty()
         return loss.detach()
+
+    def _relpos_cache(self):
+        """engine.RelposStepCache of the transformer's trunk when gradient accumulation makes it pay (grad_accum_every > 1, learned MLP bias,
+        HIP path); OMLM_RELPOS_CACHE=0 keeps the per-micro-batch form."""
+        if self.grad_accum_every <= 1 or self.device.type != 'cuda' or os.environ.get("OMLM_RELPOS_CACHE", "1") == "0":
+            return None
+        tr = getattr(self.transformer, "transformer", None)
+        if tr is None or getattr(tr, "rel_pos_bias", None) is None or getattr(tr, "relative_position_bias_type", "") == "t5":
+            return None
+        from . import engine
+        rc = engine.relpos_step_cache(tr)
+        rc.enabled = True
+        return rc
 
     def optimizer_step(self):
         """ONE gradient exchange + fused clip/Adam(W)/zero_grad + scheduler tick.  Precision "fp16": a step whose gradients overflowed is
@@ -340,8 +356,13 @@ class SingleStageTrainer(nn.Module):
         self.train_wrapper.train()
         self.optim.zero_grad()
         loss_acc = torch.zeros((), device=self.device)
+        rc = self._relpos_cache()
+        if rc is not None:
+            rc.refresh()                                # the rel-pos table of this step's weights, once for all its micro-batches
         for _ in range(self.grad_accum_every):
             loss_acc += self.micro_step(self._next_batch(self.dl_iter))
+        if rc is not None:
+            rc.flush()                                  # the MLP's backward on the micro-batches' summed d(table), before the exchange
         self.optimizer_step()
         logs = {'loss': float(loss_acc.item()) / self.grad_accum_every}       # single host sync per optimizer step
         if self.device.type == 'cuda':

@@ -1474,3 +1474,43 @@ def test_full_size_gradients_of_every_parameter_vs_oracle(dev, precision):
     # head logit_weights.2 led with 1.48e-2 -- its forward now runs on planes)
     # bf16 (8 significand bits instead of 11: 8 x the 16-bit bars; the 15-tensor check at B = 2 measured <= 7.2e-2 per tensor)
     assert worst[0][1] < (1.5e-2 if precision == "fp16ff" else 1.5e-1) and worst[1][1] < TOL[precision]["grad"], worst
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_relpos_once_per_optimizer_step_equals_once_per_micro_batch(dev, tmp_path, monkeypatch, use_graph):
+    """engine.RelposStepCache (round 6): with gradient accumulation the trainer evaluates the rel-pos MLP once per
+    optimizer step (table before the micro-batches, backward once on their summed d(table)) instead of once per micro-batch.  Same
+    weights, same batches: every parameter after four optimizer steps of three micro-batches must agree with the per-micro-batch form
+    (OMLM_RELPOS_CACHE=0) up to the order of fp32 additions, and the captured micro-step must not contain the MLP any more."""
+    from open_musiclm_amd import engine
+    from open_musiclm_amd import open_musiclm as M
+    from open_musiclm_amd.data import SyntheticTokenDataset
+    from open_musiclm_amd.trainer import SingleStageTrainer
+
+    def run(cache: str):
+        monkeypatch.setenv("OMLM_RELPOS_CACHE", cache)
+        torch.manual_seed(0)
+        model = M.create_coarse_transformer(dim=128, depth=2, heads=2, num_coarse_quantizers=3, ff_dropout=0.0, precision="bf16x3").to(dev)
+        ds = SyntheticTokenDataset("coarse", length=12, coarse_window_seconds=1, semantic_window_seconds=2)
+        tr = SingleStageTrainer(model, "coarse", num_train_steps=10, batch_size=2, dataset=ds, lr=1e-3, lr_warmup=0,
+                                grad_accum_every=3, wd=0.01, max_grad_norm=0.5, valid_frac=0.0, save_results_every=1000,
+                                save_model_every=1000, results_folder=str(tmp_path / f"res{cache}{int(use_graph)}"), save_predicted_tokens=False,
+                                save_reconstructed_wave=False, use_hip_graph=use_graph)
+        calls = {"n": 0}
+        orig = engine.relpos_backward
+
+        def counted(*a, **k):
+            calls["n"] += 1
+            return orig(*a, **k)
+        monkeypatch.setattr(engine, "relpos_backward", counted)
+        losses = [tr.train_step()["loss"] for _ in range(4)]
+        monkeypatch.setattr(engine, "relpos_backward", orig)
+        return {k: v.detach().clone() for k, v in model.state_dict().items()}, losses, calls["n"]
+    p0, l0, n0 = run("0")
+    p1, l1, n1 = run("1")
+    worst = max(float((p1[k].double() - p0[k].double()).abs().max() / (p0[k].double().abs().max() + 1e-12)) for k in p0)
+    report(f"relpos_step_cache[graph={use_graph}]", worst_param_rel=worst, backward_calls=(n0, n1), losses=(l0[-1], l1[-1]))
+    # (parameters: the bias of the MLP's last layer moves every head's scores by a constant -- a direction the softmax does not see, whose
+    # gradient is rounding noise on both sides and which Adam turns into +- lr steps; everything else agrees to ~1e-3 after four steps)
+    assert worst < 5e-2 and all(abs(a - b) < 1e-5 * abs(a) for a, b in zip(l0, l1)), (worst, l0, l1)
+    assert n1 == 4, n1                                   # one MLP backward per optimizer step (Python-side count: eager calls only)
