@@ -88,7 +88,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
     };
     // 16-byte pieces (round 6: dword loads / stores moved 34 B per parameter at 4.9 TB/s; four parameters per lane per trip), scalar tail
     const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0) && (!p16 || ((uintptr_t)p16 & 7) == 0);
+#ifdef OMLM_ADAMW_SCALAR
+    const long long n4 = 0;                                // (A/B build: the element-wise form)
+#else
     const long long n4 = vec ? n >> 2 : 0;
+#endif
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         if (skip) { if (zero_grad) ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
         float4 p4 = ((const float4*)p)[i], m4 = ((const float4*)m)[i], v4 = ((const float4*)v)[i];
