@@ -218,6 +218,41 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
     }
 }
 
+// 16-bit outputs, one WAVE per row (round 6): a lane owns 8 consecutive columns per trip (two 16-byte loads, one 16-byte store) instead of one
+// column per thread per trip with 2-byte stores (50 us for 125 MB in + 60 MB out at coarse-small)
+template <typename T>
+__global__ __launch_bounds__(256) void ce_bwd_wave_kernel(const float* __restrict__ logits, const int* __restrict__ labels,
+                                                          const float* __restrict__ row_lse, const float* __restrict__ gscale,
+                                                          float coef, T* __restrict__ dlogits, int R, int V, int ld, int ldd) {
+    const float g = coef * (gscale ? gscale[0] : 1.0f);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int row = blockIdx.x * 4 + wave; row < R; row += gridDim.x * 4) {
+        const float* lr = logits + (size_t)row * ld;
+        T* dr = dlogits + (size_t)row * ldd;
+        const int lb = labels[row];
+        const float lse = row_lse[row];
+        const bool live = lb >= 0 && lb < V;
+        for (int c = lane * 8; c < ldd; c += 512) {
+            float x[8];
+            if (c + 8 <= V) {
+                const float4 a = *(const float4*)(lr + c), b = *(const float4*)(lr + c + 4);
+                x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = c + e < V ? lr[c + e] : 0.f;
+            }
+            union { T h[8]; uint4 u; } pk;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = 0.f;
+                if (c + e < V && live) v = g * (__expf(x[e] - lse) - (c + e == lb ? 1.0f : 0.0f));
+                pk.h[e] = (T)v;
+            }
+            *(uint4*)(dr + c) = pk.u;
+        }
+    }
+}
+
 extern "C" int omlm_cross_entropy_fwd(const float* logits, const int* labels, float* row_lse, float* nll_sum,
                                       int R, int V, int ld, int* err_flag, void* stream) {
     if (R <= 0) return OMLM_OK;
@@ -236,6 +271,17 @@ extern "C" int omlm_cross_entropy_bwd(const float* logits, const int* labels, co
     OMLM_CHECK_ARG(logits && labels && row_lse && dlogits && ld >= V && ldd >= V, "cross entropy arguments");
     dim3 grid(R < 8192 ? R : 8192), block(256);
     OMLM_CHECK_ARG(out_dtype >= 0 && out_dtype <= 2, "out_dtype: 0 = fp32, 1 = bf16, 2 = fp16");
+    // 16-bit outputs with 16-byte friendly pitches: the wave-per-row kernel
+    const bool wave_ok = out_dtype != 0 && (ldd & 7) == 0 && (ld & 3) == 0 && (((uintptr_t)logits | (uintptr_t)dlogits) & 15) == 0;
+    if (wave_ok) {
+        const int blocks = (R + 3) / 4;
+        dim3 wgrid(blocks < 8192 ? blocks : 8192);
+        if (out_dtype == OMLM_DT_F16)
+            hipLaunchKernelGGL(ce_bwd_wave_kernel<f16_t>, wgrid, block, 0, as_stream(stream), logits, labels, row_lse, gscale, coef, (f16_t*)dlogits, R, V, ld, ldd);
+        else
+            hipLaunchKernelGGL(ce_bwd_wave_kernel<h16_t>, wgrid, block, 0, as_stream(stream), logits, labels, row_lse, gscale, coef, (h16_t*)dlogits, R, V, ld, ldd);
+        return omlm_post_launch("omlm_cross_entropy_bwd");
+    }
     if (out_dtype == 0)
         hipLaunchKernelGGL(ce_bwd_kernel<float>, grid, block, 0, as_stream(stream), logits, labels, row_lse, gscale, coef, (float*)dlogits, R, V, ld, ldd);
     else if (out_dtype == OMLM_DT_F16)
